@@ -1,0 +1,501 @@
+"""
+oracle/annchor_oracle.py -- CPU (NumPy) restatement of the ANNchor `fit()` hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under annchor_amd/ may import this module; only
+tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg use it, as the
+checker and the timed CPU baseline -- never as the thing shipped or measured as
+the product.
+
+Every function cites the reference lines (relative to /root/reference/) it
+restates.  The reference is pure Python/NumPy + numba; its own functions are
+deterministic except where NumPy's *unstable* selection routines decide between
+tied keys (np.argsort default kind, np.argpartition, numba quicksort).  The
+restatement fixes ONE tie rule everywhere ("ties resolve to the smaller index /
+earlier position") -- the same rule the HIP kernels implement -- so that
+oracle == GPU is a bit-exact comparison, while oracle-vs-reference is compared
+exactly on every tie-free quantity and set-wise (cut-off value + membership
+above/below it) on the tie-affected selections.  See tests/test_oracle_golden.py.
+
+Pinning status:
+  * reference's own functions: pinned by golden vectors captured from the imported
+    reference (tests/golden/make_golden.py, run in the build container where
+    /root/reference exists) and by the reference tests' known answers;
+  * RNG stream of the sampler: the reference seeds numba's in-njit RNG
+    (utils.py:572), which cannot be run here; this restatement (and the golden
+    capture) use NumPy's legacy global RNG with the same seed arithmetic --
+    "parity unpinned" for the exact sample set of a real numba run;
+  * OLS coefficients: sklearn LinearRegression (regressors.py:33,68) -- pinned by
+    captured coefficients only.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg
+
+FEATURE_NAMES = ["lower bound", "upper bound", "double anchor distance", "is anchor"]
+
+
+# --------------------------------------------------------------------------- a0
+def budget(nx, n_anchors, n_samples, p_work, n_neighbors, loc_min=None):
+    """Constructor arithmetic, annchor.py:117-148,167-168."""
+    N = (nx * (nx - 1)) // 2
+    na = int(sum(nx - j for j in range(1, n_anchors + 1)))
+    if p_work > 1:
+        p_work = 1.0
+    min_p_work = (2 * (na + n_samples) + 1) / N
+    min_p_work = 1 if min_p_work > 1 else min_p_work
+    if p_work < min_p_work:
+        p_work = min_p_work
+    lm = 10 * n_neighbors if loc_min is None else loc_min
+    lm = int(np.clip(lm, 0, nx - 1))
+    return dict(N=N, na=na, p_work=p_work, loc_min=lm)
+
+
+# --------------------------------------------------------------------------- a6
+def maxmin_anchors(one_to_all, nx, n_anchors, seed):
+    """MaxMinAnchorPicker.get_anchors, pickers.py:18-52.
+
+    one_to_all(ix) -> float64[nx] with out[j] = f(X[ix], X[j]).
+    Note the reference quirk kept here: after the first round the running min
+    excludes anchor 0's row (`np_min(D[1:], 0)`, pickers.py:47-50).
+    np.argmax returns the first maximal index (defined tie rule).
+    """
+    np.random.seed(seed)
+    D = np.zeros((n_anchors, nx)) + np.inf
+    A = np.zeros(n_anchors, dtype=np.int64)
+    ix = np.random.randint(nx)
+    for i in range(n_anchors):
+        A[i] = ix
+        D[i] = one_to_all(ix)
+        if i == 0:
+            ix = int(np.argmax(D[:1].min(axis=0)))
+        else:
+            ix = int(np.argmax(D[1 : i + 1].min(axis=0)))
+    return A, np.ascontiguousarray(D.T)
+
+
+def maxmin_first_index(nx, seed):
+    """The only RNG draw of the picker (pickers.py:21,30)."""
+    np.random.seed(seed)
+    return int(np.random.randint(nx))
+
+
+# --------------------------------------------------------------------------- a7
+def nearest_anchor_sets(D, locality):
+    """sid = argsort(D, axis=1)[:, :locality], annchor.py:235 (stable tie rule)."""
+    return np.argsort(D, axis=1, kind="stable")[:, :locality]
+
+
+def locality_pairs(D, locality, loc_thresh, loc_min):
+    """get_locality / get_check / adjust_check / get_IJs_from_check,
+    annchor.py:208-256, utils.py:437-540.
+
+    Returns sid, IJs (int64 [n,2], i<j, sorted by (i,j)), I_ptr (int64 [nx+1]),
+    I_idx (int64 [2n]) with I_idx[I_ptr[i]:I_ptr[i+1]] = positions in IJs that
+    contain i, ordered by the other endpoint ascending (the reference's order
+    inside a group comes from an unstable argsort, utils.py:512, i.e. is
+    arbitrary; every consumer is order-free up to ties).
+
+    Deviation (documented): the reference's trailing-boundary arithmetic
+    (utils.py:518,521) truncates I[.] for the last groups when the final i-group
+    has more than one pair; the restatement keeps the full groups.
+    """
+    nx, na = D.shape
+    sid = nearest_anchor_sets(D, locality)
+    Am = np.zeros((nx, na), dtype=np.int32)
+    np.put_along_axis(Am, sid, 1, axis=1)
+    C = Am @ Am.T  # C[i,j] = |sid[i] & sid[j]|  == sum(A[sid[i], :], axis=0)[j]
+    _loc_min = min(loc_min, nx - 1)
+    # (loc_min+1)-th largest count in each row (utils.py:472-473)
+    kth = -np.partition(-C, _loc_min, axis=1)[:, _loc_min]
+    thr = np.minimum(loc_thresh, kth)  # utils.py:475-480
+    keep = (C >= thr[:, None]) | (C >= thr[None, :])  # adjust_check symmetrisation
+    iu = np.triu(keep, k=1)
+    I0, J0 = np.nonzero(iu)  # row-major => sorted by (i, j)
+    IJs = np.stack([I0, J0], axis=1).astype(np.int64)
+    I_ptr, I_idx = build_I(IJs, nx)
+    return sid, IJs, I_ptr, I_idx
+
+
+def build_I(IJs, nx):
+    n = IJs.shape[0]
+    pos = np.arange(n, dtype=np.int64)
+    owner = np.concatenate([IJs[:, 1], IJs[:, 0]])
+    other = np.concatenate([IJs[:, 0], IJs[:, 1]])
+    p2 = np.concatenate([pos, pos])
+    order = np.lexsort((other, owner))
+    I_idx = p2[order]
+    counts = np.bincount(owner, minlength=nx)
+    I_ptr = np.zeros(nx + 1, dtype=np.int64)
+    np.cumsum(counts, out=I_ptr[1:])
+    return I_ptr, I_idx
+
+
+def check_locality_size(I_ptr, n_neighbors):
+    """utils.py:592-597 / annchor.py:252-256."""
+    return bool(np.any(np.diff(I_ptr) < n_neighbors))
+
+
+# ------------------------------------------------------------------- a8, a9, a10
+def bounds(IJs, D):
+    """get_bounds_njit_ijs, utils.py:274-301."""
+    Di, Dj = D[IJs[:, 0]], D[IJs[:, 1]]
+    return np.abs(Di - Dj).max(axis=1), (Di + Dj).min(axis=1)
+
+
+def dad(IJs, D):
+    """get_dad_ijs, utils.py:355-380 (argmin = first minimal index)."""
+    cA = np.argmin(D, axis=1)
+    i, j = IJs[:, 0], IJs[:, 1]
+    return (D[i, cA[j]] + D[j, cA[i]]) / 2
+
+
+def features(IJs, D, A, I_ptr, I_idx):
+    """get_features_IJ, annchor.py:258-303."""
+    lb, ub = bounds(IJs, D)
+    dd = dad(IJs, D)
+    anchors = np.zeros(IJs.shape[0])
+    for a in np.asarray(A, dtype=np.int64):
+        anchors[I_idx[I_ptr[a] : I_ptr[a + 1]]] = 1
+    feats = np.vstack([lb, ub, dd, anchors]).T
+    return feats, feats[:, 3] < 1
+
+
+# -------------------------------------------------------------------------- a11
+def stratified_partition(sample_feature, n_samples, n_partitions=7):
+    """SimpleStratifiedSampler.get_partition, samplers.py:119-140."""
+    n = sample_feature.shape[0]
+    iq1, iq3 = int(n / 100), int(99 * n / 100)
+    if iq1 * n_partitions < n_samples:
+        iq1, iq3 = int(n / 10), int(9 * n / 10)
+    if iq1 * n_partitions < n_samples:
+        n_samples = iq1 * n_partitions
+    q1 = np.partition(sample_feature, iq1)[iq1]
+    q3 = np.partition(sample_feature, iq3)[iq3]
+    b = np.linspace(q1, q3, n_partitions - 1)
+    return np.hstack([-np.inf, b, np.inf]), n_samples
+
+
+class NothingToSample(Exception):
+    pass
+
+
+def stratified_sample(feats, ncm, n_samples, seed, loop_num, n_partitions=7):
+    """Sampler.sample + sample_partition + loop_partitions,
+    samplers.py:44-110, utils.py:543-578 (NumPy legacy RNG stands in for numba's)."""
+    if not ncm.any():
+        raise NothingToSample()
+    sf = feats[ncm][:, 2]
+    indices = np.arange(ncm.shape[0])[ncm]
+    bins, n_samples = stratified_partition(sf, n_samples, n_partitions)
+    if n_samples == 0:
+        raise NothingToSample()
+    bin_size, remainder = n_samples // n_partitions, n_samples % n_partitions
+    np.random.seed(seed + loop_num)
+    out = []
+    for b in range(n_partitions):
+        mask = (sf >= bins[b]) & (sf < bins[b + 1])
+        ixmask = indices[mask]
+        want = bin_size + (b < remainder)
+        if ixmask.shape[0] < want:
+            got = ixmask
+        else:
+            got = np.random.choice(ixmask, size=want, replace=False)
+        if len(got) < 2:
+            raise Exception("Some sampler bins contain too few samples")
+        out.append(got)
+    ixs = np.hstack(out)
+    return ixs, ixs.shape[0], bins
+
+
+# -------------------------------------------------------------------------- a12
+def ols(X, y):
+    """sklearn LinearRegression(fit_intercept=True).fit: centre, lstsq (gelsd)."""
+    xm, ym = X.mean(axis=0), y.mean()
+    Xc, yc = X - xm, y - ym
+    cond = max(Xc.shape) * np.finfo(Xc.dtype).eps
+    coef = scipy.linalg.lstsq(Xc, yc, cond=cond)[0]
+    return coef, ym - xm @ coef
+
+
+def regression_fit(sample_feats, sample_y, bins):
+    """SimpleStratifiedLinearRegression.fit, regressors.py:39-69 (bin edges
+    `lo < F <= hi`)."""
+    F = sample_feats[:, 2]
+    nb = bins.shape[0] - 1
+    W = np.zeros((nb, 3))
+    c = np.zeros(nb)
+    for b in range(nb):
+        m = (F > bins[b]) & (F <= bins[b + 1])
+        W[b], c[b] = ols(sample_feats[m][:, :3], sample_y[m])
+    return W, c
+
+
+def regression_bin(F, bins):
+    """Index b with bins[b] < F <= bins[b+1] (regressors.py:84-87,97-101)."""
+    return np.clip(np.searchsorted(bins, F, side="left") - 1, 0, bins.shape[0] - 2)
+
+
+def regression_predict(feats, bins, W, c):
+    """SimpleStratifiedLinearRegression.predict, regressors.py:71-103.
+    Arithmetic order fixed as ((w0*lb + w1*ub) + w2*dad) + c, no FMA."""
+    b = regression_bin(feats[:, 2], bins)
+    w = W[b]
+    return ((w[:, 0] * feats[:, 0] + w[:, 1] * feats[:, 1]) + w[:, 2] * feats[:, 2]) + c[b]
+
+
+def merge_prediction(RA, pred, feats, ncm, sample_ixs, sample_y):
+    """annchor.py:359-380: clip to [lb, ub]; first call initialises RefineApprox,
+    later calls overwrite only not-computed entries; samples get exact values."""
+    pred = np.minimum(np.maximum(pred, feats[:, 0]), feats[:, 1])
+    if RA is None:
+        RA = pred.copy()
+    else:
+        RA[ncm] = pred[ncm]
+    RA[sample_ixs] = sample_y
+    return RA
+
+
+# -------------------------------------------------------------------------- a13
+def error_fit(sample_feats, sample_err, bins):
+    """SimpleStratifiedErrorRegression.fit, error_predictors.py:26-54
+    (closed on both sides)."""
+    sf = sample_feats[:, 2]
+    errs = []
+    for b in range(bins.shape[0] - 1):
+        m = (sf >= bins[b]) & (sf <= bins[b + 1])
+        errs.append(np.sort(sample_err[m]))
+    return errs
+
+
+def error_labels(F, bins):
+    """SimpleStratifiedErrorRegression.predict, error_predictors.py:56-67: later
+    bins overwrite earlier ones at shared edges => largest b with lo_b <= F."""
+    return np.clip(np.searchsorted(bins, F, side="right") - 1, 0, bins.shape[0] - 2)
+
+
+# -------------------------------------------------------------------------- a14
+def row_kth(RA, I_ptr, I_idx, k):
+    """thresh[i] = np.partition(RA[I[i]], k)[k], annchor.py:399-404."""
+    nx = I_ptr.shape[0] - 1
+    out = np.empty(nx)
+    for i in range(nx):
+        v = RA[I_idx[I_ptr[i] : I_ptr[i + 1]]]
+        out[i] = np.partition(v, k)[k]
+    return out
+
+
+def guarantee_nmin(RA, ncm, I_ptr, I_idx, nmin):
+    """guarantee_nmin + argpartition, utils.py:600-621 (sequential in i, in place)."""
+    nx = I_ptr.shape[0] - 1
+    for i in range(nx):
+        Ii = I_idx[I_ptr[i] : I_ptr[i + 1]]
+        mask = ncm[Ii]
+        n_todo = nmin - int(np.sum(~mask))
+        if n_todo > 0:
+            a = RA[Ii][mask]
+            dxs = np.partition(a, n_todo)[n_todo]
+            RA[Ii[mask][a < dxs]] = -1
+    return RA
+
+
+def ecdf_prob(p, labels, errs):
+    """get_probs, utils.py:581-589: searchsorted(side='left') / len."""
+    prob = np.empty(p.shape)
+    for b, e in enumerate(errs):
+        m = labels == b
+        prob[m] = np.searchsorted(e, p[m])
+        prob[m] /= len(e)
+    return prob
+
+
+def n_refine_budget(p_work, N, na, n_samples, w):
+    """annchor.py:438-442."""
+    n = int((p_work * N - na - n_samples) * w) + 1
+    return 0 if n < 0 else n
+
+
+def select_candidates(prob, n_refine, lookahead):
+    """annchor.py:444-457 with the tie rule (prob desc, position asc).
+    Returns (candidates, next) as indices into the compacted not-computed
+    array, each sorted ascending."""
+    n = prob.shape[0]
+    if n_refine >= n:
+        return np.arange(n), np.arange(n)
+    order = np.argsort(-prob, kind="stable")
+    big = order if n_refine * lookahead >= n else order[: n_refine * lookahead]
+    return np.sort(big[:n_refine]), np.sort(big[n_refine:])
+
+
+def refine_probabilities(RA, ncm, IJs, thresh, labels_all, errs):
+    """p and prob of annchor.py:416-436 on the compacted not-computed array."""
+    p0 = (thresh[IJs[:, 0]] - RA)[ncm]
+    p1 = (thresh[IJs[:, 1]] - RA)[ncm]
+    p = np.maximum(p0, p1)
+    return ecdf_prob(p, labels_all[ncm], errs)
+
+
+# -------------------------------------------------------------------------- a15
+def update_bounds(IJs, RA, ncm, I_ptr, I_idx, nextback, lb, ub):
+    """update_anchor_points + update_bounds/get_bounds_alt, annchor.py:475-512,
+    utils.py:304-352, without the wall-clock cut-off (all chunks processed)."""
+    nx = I_ptr.shape[0] - 1
+    dis, ds = [], []
+    for y in range(nx):
+        Iy = I_idx[I_ptr[y] : I_ptr[y + 1]]
+        m = Iy[~ncm[Iy]]
+        pr = IJs[m]
+        other = np.where(pr[:, 0] == y, pr[:, 1], pr[:, 0])
+        o = np.argsort(other, kind="stable")
+        dis.append(other[o])
+        ds.append(RA[m][o])
+    lb, ub = lb.copy(), ub.copy()
+    for t in nextback:
+        i, j = IJs[t]
+        _, ia, ja = np.intersect1d(dis[i], dis[j], assume_unique=True, return_indices=True)
+        if ia.size:
+            a = ds[i][ia] + ds[j][ja]
+            b = np.abs(ds[i][ia] - ds[j][ja])
+            ub[t] = min(ub[t], a.min())
+            lb[t] = max(lb[t], b.max())
+    return lb, ub
+
+
+# -------------------------------------------------------------------------- a16
+def get_nn(RA, ncm, IJs, I_ptr, I_idx, nn):
+    """get_nn + get_ann, utils.py:383-429, annchor.py:514-530.  Tie rule: equal
+    distances come out in I[i] order (= other endpoint ascending)."""
+    nx = I_ptr.shape[0] - 1
+    ngi = np.zeros((nx, nn - 1), dtype=np.int64)
+    ngd = np.zeros((nx, nn - 1))
+    for i in range(nx):
+        Ii = I_idx[I_ptr[i] : I_ptr[i + 1]]
+        d = RA[Ii].copy()
+        mx = d.max()
+        d[ncm[Ii]] += mx
+        t = np.partition(d, nn - 1)[nn - 1]
+        m = d <= t
+        iy = Ii[m][np.argsort(d[m], kind="stable")][: nn - 1]
+        ngd[i] = RA[iy]
+        f = IJs[iy]
+        ngi[i] = np.where(f[:, 0] == i, f[:, 1], f[:, 0])
+    return (
+        np.hstack([np.arange(nx)[:, None], ngi]),
+        np.hstack([np.zeros((nx, 1)), ngd]),
+    )
+
+
+# -------------------------------------------------------------------------- a17
+def compare_neighbor_graphs(nng_1, nng_2, n_neighbors):
+    """annchor.py:1026-1066."""
+    from collections import Counter
+
+    err = 0
+    for ix in range(nng_1[0].shape[0]):
+        a = Counter(np.round(nng_1[1][ix][:n_neighbors], 3).astype(np.float32))
+        b = Counter(np.round(nng_2[1][ix][:n_neighbors], 3).astype(np.float32))
+        err += len(a - b)
+    return err
+
+
+def brute_force(metric_pairs, nx):
+    """BruteForce.fit, annchor.py:1004-1023 (stable sort)."""
+    iu = np.triu_indices(nx, k=1)
+    IJ = np.stack(iu, axis=1).astype(np.int64)
+    d = metric_pairs(IJ)
+    D = np.zeros((nx, nx))
+    D[iu] = d
+    D = D + D.T
+    idx = np.argsort(D, axis=1, kind="stable")
+    return idx, np.take_along_axis(D, idx, axis=1), D
+
+
+# ----------------------------------------------------------------------- driver
+class OracleAnnchor:
+    """Annchor.fit(), annchor.py:532-623, on top of the stage functions above.
+
+    metric_pairs(IJ int64[n,2]) -> float64[n] is the a2 boundary
+    (utils.py:110-177).  Default plugins only (MaxMin picker, stratified
+    sampler / linear regression / error regression)."""
+
+    def __init__(self, nx, metric_pairs, n_anchors=20, n_neighbors=15, n_samples=5000,
+                 p_work=0.1, random_seed=42, locality=5, loc_thresh=1, loc_min=None,
+                 niters=2, lookahead=5, anchors=None, trace=None):
+        self.nx, self.metric_pairs = nx, metric_pairs
+        b = budget(nx, n_anchors, n_samples, p_work, n_neighbors, loc_min)
+        self.N, self.na, self.p_work, self.loc_min = b["N"], b["na"], b["p_work"], b["loc_min"]
+        self.n_anchors, self.n_neighbors, self.n_samples = n_anchors, n_neighbors, n_samples
+        self.random_seed, self.locality, self.loc_thresh = random_seed, locality, loc_thresh
+        self.niters, self.lookahead = niters, lookahead
+        self.evals = 0
+        self.anchors = anchors
+        self.trace = trace  # optional dict collecting per-stage snapshots
+
+    def _snap(self, key, **kw):
+        if self.trace is not None:
+            self.trace[key] = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+
+    def one_to_all(self, ix):
+        IJ = np.stack([np.full(self.nx, ix, dtype=np.int64), np.arange(self.nx, dtype=np.int64)], axis=1)
+        return self.metric_pairs(IJ)
+
+    def fit(self):
+        nx, k = self.nx, self.n_neighbors
+        if self.anchors is None:
+            self.A, self.D = maxmin_anchors(self.one_to_all, nx, self.n_anchors, self.random_seed)
+        else:  # SelectedAnchorPicker, pickers.py:86-106
+            self.A = np.asarray(self.anchors, dtype=np.int64)
+            self.D = np.stack([self.one_to_all(int(a)) for a in self.A], axis=1)
+        self.evals += self.n_anchors * nx
+        self.sid, self.IJs, self.I_ptr, self.I_idx = locality_pairs(
+            self.D, self.locality, self.loc_thresh, self.loc_min)
+        if check_locality_size(self.I_ptr, k):
+            raise Exception("Error: Not enough candidates in pool for all indices.\n"
+                            "Try again with higher locality.")
+        self.features, self.ncm = features(self.IJs, self.D, self.A, self.I_ptr, self.I_idx)
+        self._snap("features", features=self.features, ncm=self.ncm)
+        self.RA = None
+        for it in range(self.niters):
+            try:
+                self.sample_ixs, self.n_samples, self.bins = stratified_sample(
+                    self.features, self.ncm, self.n_samples, self.random_seed, it)
+            except NothingToSample:
+                if it == 0:
+                    raise ValueError("Sampler raised NothingToSample on first iteration.")
+                break
+            sf = self.features[self.sample_ixs]
+            self.sample_y = self.metric_pairs(self.IJs[self.sample_ixs])
+            self.ncm[self.sample_ixs] = False
+            self.evals += self.sample_y.shape[0]
+            self.W, self.c = regression_fit(sf, self.sample_y, self.bins)
+            pred = regression_predict(self.features, self.bins, self.W, self.c)
+            sample_predict = pred[self.sample_ixs]
+            self.RA = merge_prediction(self.RA, pred, self.features, self.ncm,
+                                       self.sample_ixs, self.sample_y)
+            self.errs = error_fit(sf, self.sample_y - sample_predict, self.bins)
+            self.labels = error_labels(self.features[:, 2], self.bins)
+            self._snap("regress%d" % it, sample_ixs=self.sample_ixs, bins=self.bins, W=self.W,
+                       c=self.c, RA=self.RA, labels=self.labels, sample_y=self.sample_y)
+            # select_refine_candidate_pairs
+            self.thresh = row_kth(self.RA, self.I_ptr, self.I_idx, k)
+            if it == 0:
+                self.RA = guarantee_nmin(self.RA, self.ncm, self.I_ptr, self.I_idx, 3 * k // 2)
+            prob = refine_probabilities(self.RA, self.ncm, self.IJs, self.thresh,
+                                        self.labels, self.errs)
+            n_refine = n_refine_budget(self.p_work, self.N, self.na, self.n_samples, 1 / self.niters)
+            cand, nxt = select_candidates(prob, n_refine, self.lookahead)
+            unc = np.arange(self.ncm.shape[0])[self.ncm]
+            self.nextback, mapback = unc[nxt], unc[cand]
+            self._snap("select%d" % it, thresh=self.thresh, RA=self.RA, prob=prob,
+                       mapback=mapback, nextback=self.nextback, n_refine=n_refine)
+            exact = self.metric_pairs(self.IJs[mapback])
+            self.evals += exact.shape[0]
+            self.RA[mapback] = exact
+            self.ncm[mapback] = False
+            if it < self.niters - 1:
+                lb, ub = update_bounds(self.IJs, self.RA, self.ncm, self.I_ptr, self.I_idx,
+                                       self.nextback, self.features[:, 0], self.features[:, 1])
+                self.features[:, 0], self.features[:, 1] = lb, ub
+                self._snap("update%d" % it, lb=lb, ub=ub)
+        self.neighbor_graph = get_nn(self.RA, self.ncm, self.IJs, self.I_ptr, self.I_idx, k)
+        return self

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""
+tests/golden/make_golden.py -- generates the golden vectors under tests/golden/.
+
+Runs ONLY in the build container, where the read-only reference lives at
+/root/reference.  It imports the reference's own Python package and drives its
+own `Annchor` stage methods in the order `Annchor.fit()` does
+(annchor/annchor.py:532-623), snapshotting the object's state between stages.
+Nothing from the reference is copied: the outputs are data (inputs + expected
+outputs).
+
+The reference needs three third-party modules that are not installed here
+(numba, Levenshtein, pynndescent).  tests/golden/_refshim/ provides:
+  * `numba`: decorators become identity wrappers -- the reference's own NumPy
+    code then runs unchanged as plain Python (no arithmetic replaced);
+  * `Levenshtein.distance`, `pynndescent.distances.kantorovich`: delegate to the
+    oracle's C restatements, which are pinned independently (reference test
+    known-answers; the reference's stored exact-EMD graph).
+So: vectors for the reference's OWN functions (a0, a6-a17) are genuine reference
+outputs; metric values inside them come from the oracle's metric restatements.
+
+Usage:  python tests/golden/make_golden.py [small|blobs|strings_full|digits_full|all]
+"""
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [os.path.join(HERE, "_refshim"), "/root/reference", ROOT]
+
+import numpy as np  # noqa: E402
+
+import annchor as ref  # noqa: E402  (the reference)
+from annchor.samplers import NothingToSample  # noqa: E402
+from oracle import metrics as om  # noqa: E402
+
+
+def I_to_csr(I, nx):
+    ptr = np.zeros(nx + 1, dtype=np.int64)
+    for i in range(nx):
+        ptr[i + 1] = ptr[i] + len(I[i])
+    idx = np.concatenate([np.asarray(I[i], dtype=np.int64) for i in range(nx)])
+    return ptr, idx
+
+
+def staged_fit(ann, snaps):
+    """Annchor.fit() body (annchor.py:545-623) with snapshots between stages."""
+    ann.get_anchors()
+    snaps["A"], snaps["D"] = np.asarray(ann.A, dtype=np.int64), np.ascontiguousarray(ann.D)
+    ann.get_locality()
+    snaps["sid"], snaps["IJs"] = ann.sid.copy(), ann.IJs.copy()
+    snaps["I_ptr"], snaps["I_idx"] = I_to_csr(ann.I, ann.nx)
+    ann.get_features()
+    snaps["features0"], snaps["ncm0"] = ann.features.copy(), ann.not_computed_mask.copy()
+    niters = ann.niters
+    for it in range(niters):
+        p = "it%d_" % it
+        try:
+            ann.get_sample()
+        except NothingToSample:
+            break
+        snaps[p + "sample_ixs"], snaps[p + "bins"] = ann.sample_ixs.copy(), ann.sample_bins.copy()
+        snaps[p + "sample_y"] = ann.sample_y.copy()
+        snaps[p + "ncm_after_sample"] = ann.not_computed_mask.copy()
+        ann.fit_predict_regression()
+        snaps[p + "coef"] = np.array([lr.coef_ for lr in ann.regression.LRs])
+        snaps[p + "intercept"] = np.array([lr.intercept_ for lr in ann.regression.LRs])
+        snaps[p + "sample_predict"] = ann.sample_predict.copy()
+        snaps[p + "RA_after_regression"] = ann.RefineApprox.copy()
+        ann.fit_predict_errors()
+        for b, e in ann.error_predictor.errs.items():
+            snaps[p + "errs%d" % b] = e.copy()
+        snaps[p + "labels"] = ann.errors.astype(np.int8)
+        ncm_before = ann.not_computed_mask.copy()
+        ann.select_refine_candidate_pairs(w=1 / niters, it=it)
+        snaps[p + "thresh"] = ann.thresh.copy()
+        unc = np.arange(ncm_before.shape[0])[ncm_before]
+        snaps[p + "mapback"] = np.sort(unc[ann.candidates])
+        snaps[p + "nextback"] = np.sort(ann.nextback)
+        snaps[p + "RA_after_refine"] = ann.RefineApprox.copy()
+        snaps[p + "ncm_after_refine"] = ann.not_computed_mask.copy()
+        if it < niters - 1:
+            ann.update_anchor_points(timeout=1e9)
+            snaps[p + "lbub_after_update"] = ann.features[:, :2].copy()
+    ann.get_ann()
+    snaps["ng_idx"], snaps["ng_dist"] = ann.neighbor_graph[0].copy(), ann.neighbor_graph[1].copy()
+    snaps["evals"] = np.int64(ann.evals)
+    snaps["n_samples_final"] = np.int64(ann.n_samples)
+    snaps["p_work"] = np.float64(ann.p_work)
+    snaps["na_budget"] = np.int64(ann.na)
+    return snaps
+
+
+def save(name, snaps):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **snaps)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def strings_evaluator(P):
+    return lambda f, X, IJ: P.pairs(np.asarray(IJ, dtype=np.int64))
+
+
+def gen_small():
+    X, _ = om.load_strings()
+    # (a) strings, dense locality, integer metric, 2 iterations
+    Xs = X[::5]  # 320 strings covering all 8 clusters (a prefix gives empty sampler bins)
+    n = len(Xs)
+    P = om.PackedStrings(Xs)
+    cfg = dict(n_anchors=8, n_neighbors=10, n_samples=700, p_work=0.3, random_seed=42, niters=2)
+    ann = ref.Annchor(np.array(Xs), "levenshtein", get_exact_ijs=strings_evaluator(P), **cfg)
+    snaps = staged_fit(ann, {"cfg_" + k: np.float64(v) for k, v in cfg.items()})
+    snaps["n"] = np.int64(n)
+    save("strings_small", snaps)
+
+    # (b) Euclidean float64, clustered => sparse locality, loc_min widening, 3 iterations
+    rng = np.random.default_rng(7)
+    cent = rng.uniform(-10, 10, (12, 3))
+    Xe = (cent[rng.integers(0, 12, 260)] + rng.standard_normal((260, 3))).astype(np.float64)
+    cfg = dict(n_anchors=12, n_neighbors=8, n_samples=400, p_work=0.25, random_seed=3, niters=3,
+               locality=3)
+    ev = lambda f, X, IJ: om.euclidean_pairs(X, np.asarray(IJ, dtype=np.int64))  # noqa: E731
+    ann = ref.Annchor(Xe, "euclidean", get_exact_ijs=ev, **cfg)
+    snaps = staged_fit(ann, {"cfg_" + k: np.float64(v) for k, v in cfg.items()})
+    snaps["X"] = Xe
+    save("euclid_small", snaps)
+
+
+def gen_blobs():
+    """reference tests/test_examples.py:88-230: pinned anchor vector and error counts."""
+    from sklearn.datasets import make_blobs
+
+    X, _, centers = make_blobs(centers=10, n_samples=1000, random_state=42, return_centers=True)
+    ev = lambda f, X, IJ: om.euclidean_pairs(X, np.asarray(IJ, dtype=np.int64))  # noqa: E731
+    bf = ref.BruteForce(X, "euclidean", get_exact_ijs=ev)
+    bf.fit()
+    ann = ref.Annchor(X, "euclidean", n_anchors=10, p_work=0.05, get_exact_ijs=ev)
+    ann.fit()
+    err = ref.compare_neighbor_graphs(bf.neighbor_graph, ann.neighbor_graph, 15)
+    pinned = np.array([102, 674, 347, 586, 214, 963, 365, 348, 430, 429])
+    assert np.array_equal(ann.A, pinned), ann.A
+    print("blobs: A matches pinned vector, errors =", err)
+    save("blobs", dict(X=X, centers=centers, A=np.asarray(ann.A, dtype=np.int64), D=np.ascontiguousarray(ann.D),
+                       errors=np.int64(err), evals=np.int64(ann.evals),
+                       bf_dist=bf.neighbor_graph[1][:, :16].copy(),
+                       ng_dist=ann.neighbor_graph[1].copy()))
+
+
+def gen_strings_full():
+    X, _ = om.load_strings()
+    P = om.PackedStrings(X)
+    t = time.time()
+    dense = P.all_pairs()
+    print("brute force %.1fs" % (time.time() - t))
+    idx = np.argsort(dense, axis=1, kind="stable")[:, :100]
+    truth_d = np.take_along_axis(dense, idx, axis=1)
+    out = dict(truth_idx=idx.astype(np.int16), truth_dist=truth_d.astype(np.int16))
+    assert dense[10, 165] == 299  # reference tests/test_datasets.py:234-235
+    for tag, cfg in {
+        "c1": dict(n_anchors=15, n_neighbors=25, p_work=0.12, random_seed=42),          # BASELINE cfg 1/2
+        "readme": dict(n_anchors=20, n_neighbors=25, p_work=0.12, random_seed=42),      # README.md:102
+        "test": dict(n_anchors=23, n_neighbors=15, p_work=0.12, random_seed=42, niters=4,
+                     n_samples=5000),                                                   # tests/test_annchor.py:83-96
+    }.items():
+        t = time.time()
+        ann = ref.Annchor(np.array(X), "levenshtein", get_exact_ijs=strings_evaluator(P), **cfg)
+        ann.fit()
+        k = cfg["n_neighbors"]
+        err = ref.compare_neighbor_graphs((idx, truth_d), ann.neighbor_graph, k)
+        print(tag, "evals", ann.evals, "pairs", ann.IJs.shape[0], "errors", err, "%.0fs" % (time.time() - t))
+        out[tag + "_A"] = np.asarray(ann.A, dtype=np.int64)
+        out[tag + "_D"] = ann.D.astype(np.int16)
+        out[tag + "_evals"] = np.int64(ann.evals)
+        out[tag + "_npairs"] = np.int64(ann.IJs.shape[0])
+        out[tag + "_errors"] = np.int64(err)
+        out[tag + "_ng_dist"] = ann.neighbor_graph[1].astype(np.int16)
+    save("strings_full", out)
+
+
+def gen_digits_full():
+    d = om.load_digits()
+    H = om.Histograms(d["X"], d["cost_matrix"])
+    ev = lambda f, X, IJ: H.pairs(np.asarray(IJ, dtype=np.int64))  # noqa: E731
+    out = {}
+    for tag, cfg in {
+        "c4": dict(n_anchors=20, n_neighbors=25, n_samples=5000, p_work=0.16, random_seed=42),
+        "test": dict(n_anchors=25, n_neighbors=25, n_samples=5000, p_work=0.16, random_seed=42),
+    }.items():
+        t = time.time()
+        ann = ref.Annchor(d["X"], "wasserstein", func_kwargs={"cost_matrix": d["cost_matrix"]},
+                          get_exact_ijs=ev, **cfg)
+        ann.fit()
+        err = ref.compare_neighbor_graphs(d["neighbor_graph"], ann.neighbor_graph, 25)
+        print(tag, "evals", ann.evals, "pairs", ann.IJs.shape[0], "errors", err, "%.0fs" % (time.time() - t))
+        out[tag + "_A"] = np.asarray(ann.A, dtype=np.int64)
+        out[tag + "_D"] = np.ascontiguousarray(ann.D)
+        out[tag + "_evals"] = np.int64(ann.evals)
+        out[tag + "_npairs"] = np.int64(ann.IJs.shape[0])
+        out[tag + "_errors"] = np.int64(err)
+        out[tag + "_ng_dist"] = ann.neighbor_graph[1].copy()
+    save("digits_full", out)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("small", "all"):
+        gen_small()
+    if what in ("blobs", "all"):
+        gen_blobs()
+    if what in ("strings_full", "all"):
+        gen_strings_full()
+    if what in ("digits_full", "all"):
+        gen_digits_full()

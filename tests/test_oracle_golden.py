@@ -1,0 +1,190 @@
+"""
+Pins the CPU oracle (oracle/annchor_oracle.py) against golden vectors captured from
+the imported reference (tests/golden/make_golden.py).  Each stage function is fed
+the REFERENCE's inputs to that stage and must reproduce the reference's outputs:
+bit-exactly where the reference is deterministic, and set-wise (cut value +
+membership) where NumPy's unstable selection decides between tied keys.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import annchor_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def csr_sets(ptr, idx):
+    return [np.sort(idx[ptr[i]:ptr[i + 1]]) for i in range(len(ptr) - 1)]
+
+
+@pytest.fixture(scope="module", params=["strings_small", "euclid_small"])
+def G(request):
+    return load(request.param)
+
+
+def cfg(G, k, default=None):
+    key = "cfg_" + k
+    return (type(default)(G[key]) if default is not None else int(G[key])) if key in G.files else default
+
+
+def test_budget(G):
+    nx = G["D"].shape[0]
+    b = O.budget(nx, cfg(G, "n_anchors"), cfg(G, "n_samples"), float(G["cfg_p_work"]), cfg(G, "n_neighbors"))
+    assert b["na"] == int(G["na_budget"])
+    assert b["p_work"] == float(G["p_work"])
+
+
+def test_maxmin_picker_from_D(G):
+    """Re-derive A from the golden D columns (picker arithmetic only)."""
+    A, D = G["A"], G["D"]
+    nx, na = D.shape
+    col = {int(a): D[:, r] for r, a in enumerate(A)}
+    A2, D2 = O.maxmin_anchors(lambda ix: col[ix], nx, na, cfg(G, "random_seed"))
+    assert np.array_equal(A2, A)
+    assert np.array_equal(D2, D)
+
+
+def test_locality_pairs(G):
+    D = G["D"]
+    nx = D.shape[0]
+    k = cfg(G, "n_neighbors")
+    b = O.budget(nx, cfg(G, "n_anchors"), cfg(G, "n_samples"), float(G["cfg_p_work"]), k)
+    loc = cfg(G, "locality", 5)
+    sid, IJs, I_ptr, I_idx = O.locality_pairs(D, loc, 1, b["loc_min"])
+    # nearest-anchor SETS agree unless D has a tie exactly at the cut
+    Ds = np.sort(D, axis=1)
+    tie_at_cut = Ds[:, loc - 1] == Ds[:, loc]
+    same = np.array([set(a) == set(b_) for a, b_ in zip(sid, G["sid"])])
+    assert np.all(same | tie_at_cut)
+    if not tie_at_cut.any():
+        assert np.array_equal(IJs, G["IJs"])
+        ref_sets = csr_sets(G["I_ptr"], G["I_idx"])
+        got_sets = csr_sets(I_ptr, I_idx)
+        assert all(np.array_equal(a, b_) for a, b_ in zip(ref_sets, got_sets))
+
+
+def test_features(G):
+    I_ptr, I_idx = O.build_I(G["IJs"], G["D"].shape[0])
+    feats, ncm = O.features(G["IJs"], G["D"], G["A"], I_ptr, I_idx)
+    assert np.array_equal(feats, G["features0"])  # bit-exact
+    assert np.array_equal(ncm, G["ncm0"])
+
+
+def _iters(G):
+    return [it for it in range(8) if "it%d_bins" % it in G.files]
+
+
+def _state_before(G, it):
+    """(features, ncm, RA) as the reference had them entering iteration `it`."""
+    feats = G["features0"].copy()
+    if it == 0:
+        return feats, G["ncm0"].copy(), None
+    feats[:, :2] = G["it%d_lbub_after_update" % (it - 1)]
+    return feats, G["it%d_ncm_after_refine" % (it - 1)].copy(), G["it%d_RA_after_refine" % (it - 1)].copy()
+
+
+def test_sampler(G):
+    for it in _iters(G):
+        feats, ncm, _ = _state_before(G, it)
+        ns = cfg(G, "n_samples") if it == 0 else len(G["it%d_sample_ixs" % (it - 1)])
+        ixs, n, bins = O.stratified_sample(feats, ncm, ns, cfg(G, "random_seed"), it)
+        assert np.array_equal(bins, G["it%d_bins" % it])
+        assert np.array_equal(ixs, G["it%d_sample_ixs" % it])
+
+
+def test_regression_and_errors(G):
+    for it in _iters(G):
+        p = "it%d_" % it
+        feats, ncm, RA = _state_before(G, it)
+        sx, sy, bins = G[p + "sample_ixs"], G[p + "sample_y"], G[p + "bins"]
+        ncm[sx] = False
+        assert np.array_equal(ncm, G[p + "ncm_after_sample"])
+        W, c = O.regression_fit(feats[sx], sy, bins)
+        np.testing.assert_allclose(W, G[p + "coef"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(c, G[p + "intercept"], rtol=1e-9, atol=1e-9)
+        # predict with the reference's coefficients: isolates the predict arithmetic
+        pred = O.regression_predict(feats, bins, G[p + "coef"], G[p + "intercept"])
+        np.testing.assert_allclose(pred[sx], G[p + "sample_predict"], rtol=1e-13, atol=1e-11)
+        RA2 = O.merge_prediction(RA, pred, feats, ncm, sx, sy)
+        np.testing.assert_allclose(RA2, G[p + "RA_after_regression"], rtol=1e-13, atol=1e-11)
+        errs = O.error_fit(feats[sx], sy - G[p + "sample_predict"], bins)
+        for b, e in enumerate(errs):
+            assert np.array_equal(e, G[p + "errs%d" % b])
+        assert np.array_equal(O.error_labels(feats[:, 2], bins), G[p + "labels"])
+
+
+def test_select_refine(G):
+    nx = G["D"].shape[0]
+    k = cfg(G, "n_neighbors")
+    I_ptr, I_idx = G["I_ptr"], G["I_idx"]
+    niters = cfg(G, "niters", 2)
+    b = O.budget(nx, cfg(G, "n_anchors"), cfg(G, "n_samples"), float(G["cfg_p_work"]), k)
+    for it in _iters(G):
+        p = "it%d_" % it
+        RA = G[p + "RA_after_regression"].copy()
+        ncm = G[p + "ncm_after_sample"].copy()
+        thresh = O.row_kth(RA, I_ptr, I_idx, k)
+        assert np.array_equal(thresh, G[p + "thresh"])
+        if it == 0:
+            RA = O.guarantee_nmin(RA, ncm, I_ptr, I_idx, 3 * k // 2)
+        errs = [G[p + "errs%d" % b_] for b_ in range(len(G[p + "bins"]) - 1)]
+        prob = O.refine_probabilities(RA, ncm, G["IJs"], thresh, G[p + "labels"].astype(np.int64), errs)
+        n_samples = len(G[p + "sample_ixs"])
+        n_refine = O.n_refine_budget(b["p_work"], b["N"], b["na"], n_samples, 1 / niters)
+        cand, nxt = O.select_candidates(prob, n_refine, 5)
+        unc = np.arange(ncm.shape[0])[ncm]
+        ref_c, ref_n = G[p + "mapback"], G[p + "nextback"]
+        assert len(cand) == len(ref_c) and len(nxt) == len(ref_n)
+        # set-wise parity under ties: identical cut values; strictly-above members identical
+        pos = np.full(ncm.shape[0], -1)
+        pos[unc] = np.arange(len(unc))
+        for mine, theirs in ((unc[cand], ref_c), (np.concatenate([unc[cand], unc[nxt]]),
+                                                  np.concatenate([ref_c, ref_n]))):
+            pm, pt = prob[pos[mine]], prob[pos[theirs]]
+            assert pm.min() == pt.min()
+            cut = pm.min()
+            assert set(mine[pm > cut]) == set(theirs[pt > cut])
+            assert np.all(prob[np.setdiff1d(pos[unc], pos[theirs])] <= cut)
+
+
+def test_update_bounds(G):
+    for it in _iters(G):
+        p = "it%d_" % it
+        if p + "lbub_after_update" not in G.files:
+            continue
+        feats, _, _ = _state_before(G, it)
+        lb, ub = O.update_bounds(G["IJs"], G[p + "RA_after_refine"], G[p + "ncm_after_refine"],
+                                 G["I_ptr"], G["I_idx"], G[p + "nextback"], feats[:, 0], feats[:, 1])
+        assert np.array_equal(np.stack([lb, ub], 1), G[p + "lbub_after_update"])
+
+
+def test_get_nn(G):
+    last = _iters(G)[-1]
+    RA, ncm = G["it%d_RA_after_refine" % last], G["it%d_ncm_after_refine" % last]
+    k = cfg(G, "n_neighbors")
+    ngi, ngd = O.get_nn(RA, ncm, G["IJs"], G["I_ptr"], G["I_idx"], k)
+    assert np.array_equal(ngd, G["ng_dist"])  # distances are tie-independent
+    # indices agree wherever the row has no tie at or inside the k-th distance
+    for i in range(ngd.shape[0]):
+        if len(np.unique(ngd[i])) == ngd.shape[1]:
+            assert np.array_equal(ngi[i], G["ng_idx"][i])
+
+
+def test_compare_neighbor_graphs():
+    """reference tests/test_annchor.py:15-32 restated on the digits golden graph."""
+    from oracle import metrics as om
+
+    ng = om.load_digits()["neighbor_graph"]
+    assert O.compare_neighbor_graphs(ng, ng, 30) == 0
+    rs = np.random.RandomState(42)
+    ixs, ds = ng[0].copy(), ng[1].copy()
+    for i in range(ds.shape[0]):
+        ds[i, rs.randint(20, 100)] += rs.random_sample() + 0.01
+    assert O.compare_neighbor_graphs(ng, (ixs, ds), 100) == ds.shape[0]
+    assert O.compare_neighbor_graphs(ng, (ixs, ds), 20) == 0
