@@ -1,0 +1,329 @@
+"""
+ctypes binding of libannchor_hip.so (include/annchor_hip.h).
+
+The product path is the HIP library; there is no CPU implementation behind this
+module.  Importing works without a GPU (so that the host logic can be tested), but
+creating an `Engine` fails loudly when the library or a device is missing.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libannchor_hip.so")
+
+# field ids (include/annchor_hip.h)
+F_D, F_A, F_SID, F_IJS, F_I_PTR, F_I_IDX, F_FEATURES, F_NCM, F_RA, F_LABELS, F_THRESH, F_PROB, F_CAND, F_NEXT, F_DAD = range(1, 16)
+_FIELD_DTYPE = {
+    F_D: np.float64, F_A: np.int64, F_SID: np.uint64, F_IJS: np.int64, F_I_PTR: np.int64, F_I_IDX: np.int64,
+    F_FEATURES: np.float64, F_NCM: np.uint8, F_RA: np.float64, F_LABELS: np.int64, F_THRESH: np.float64,
+    F_PROB: np.float64, F_CAND: np.int64, F_NEXT: np.int64, F_DAD: np.float64,
+}
+
+METRIC_LEVENSHTEIN, METRIC_EUCLIDEAN_F32, METRIC_EUCLIDEAN_F64, METRIC_WASSERSTEIN = 1, 2, 3, 4
+
+# every entry point declared in include/annchor_hip.h: name -> (restype, argtypes)
+_vp, _i32, _i64, _dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+_SIGNATURES = {
+    "annchor_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    "annchor_destroy": (None, [_vp]),
+    "annchor_last_error": (ctypes.c_char_p, [_vp]),
+    "annchor_create_error": (ctypes.c_char_p, []),
+    "annchor_device_name": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
+    "annchor_synchronize": (ctypes.c_int, [_vp]),
+    "annchor_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    "annchor_set_strings": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32]),
+    "annchor_set_points_f32": (ctypes.c_int, [_vp, _vp, _i64, _i32]),
+    "annchor_set_points_f64": (ctypes.c_int, [_vp, _vp, _i64, _i32]),
+    "annchor_set_histograms": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "annchor_set_opaque": (ctypes.c_int, [_vp, _i64]),
+    "annchor_metric_pairs": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
+    "annchor_brute_force": (ctypes.c_int, [_vp, _i32, _vp, _vp]),
+    "annchor_pick_anchors_maxmin": (ctypes.c_int, [_vp, _i32, _i64]),
+    "annchor_pick_anchors_selected": (ctypes.c_int, [_vp, _vp, _i32]),
+    "annchor_set_anchor_distances": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i32]),
+    "annchor_build_locality": (ctypes.c_int, [_vp, _i32, _i32, _i32, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "annchor_compute_features": (ctypes.c_int, [_vp]),
+    "annchor_count_uncomputed": (ctypes.c_int, [_vp, ctypes.POINTER(_i64)]),
+    "annchor_kth_uncomputed_dad": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
+    "annchor_bin_counts": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
+    "annchor_select_by_rank": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _vp]),
+    "annchor_gather_features": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
+    "annchor_evaluate_samples": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
+    "annchor_set_samples": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
+    "annchor_predict_merge": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "annchor_merge_host_prediction": (ctypes.c_int, [_vp, _vp, _i32, _i32]),
+    "annchor_set_labels": (ctypes.c_int, [_vp, _vp]),
+    "annchor_select_candidates": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i64, _i32,
+                                                 ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "annchor_refine_candidates": (ctypes.c_int, [_vp]),
+    "annchor_set_refined": (ctypes.c_int, [_vp, _vp, _i64]),
+    "annchor_update_bounds": (ctypes.c_int, [_vp]),
+    "annchor_neighbor_graph": (ctypes.c_int, [_vp, _i32, _vp, _vp]),
+    "annchor_field_size": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_i64)]),
+    "annchor_download": (ctypes.c_int, [_vp, _i32, _vp, _i64]),
+    "annchor_upload": (ctypes.c_int, [_vp, _i32, _vp, _i64]),
+    "annchor_prof_enable": (ctypes.c_int, [_vp, _i32]),
+    "annchor_prof_reset": (ctypes.c_int, [_vp]),
+    "annchor_prof_get": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load_library():
+    """Load libannchor_hip.so and bind every declared entry point (no GPU needed)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                "libannchor_hip.so is not built (%s).  Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `python annchor_amd/build.py`; there is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Engine:
+    """One device context (one GPU).  All pipeline state lives in HBM inside it."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = _vp()
+        rc = self.lib.annchor_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise NativeError("annchor_create(device=%d) failed (%d): %s -- the HIP path is the only path; "
+                              "no CPU fallback exists." % (device, rc, self.lib.annchor_create_error().decode()))
+        self.h = h
+        self.device = device
+        self.nx = 0
+        self.metric = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.annchor_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NativeError("libannchor_hip error %d: %s" % (rc, self.lib.annchor_last_error(self.h).decode()))
+
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        self._chk(self.lib.annchor_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def synchronize(self):
+        self._chk(self.lib.annchor_synchronize(self.h))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float()
+        self._chk(self.lib.annchor_last_kernel_ms(self.h, ctypes.byref(ms)))
+        return ms.value
+
+    # ------------------------------------------------------------ data set
+    def set_strings(self, codes, offs, lens, alphabet):
+        codes, offs, lens = _c(codes, np.uint8), _c(offs, np.int64), _c(lens, np.int32)
+        self._chk(self.lib.annchor_set_strings(self.h, _ptr(codes), _ptr(offs), _ptr(lens), len(lens), int(alphabet)))
+        self.nx, self.metric = len(lens), METRIC_LEVENSHTEIN
+
+    def set_points(self, X):
+        X = np.asarray(X)
+        if X.dtype == np.float32:
+            X = _c(X, np.float32)
+            self._chk(self.lib.annchor_set_points_f32(self.h, _ptr(X), X.shape[0], X.shape[1]))
+            self.metric = METRIC_EUCLIDEAN_F32
+        else:
+            X = _c(X, np.float64)
+            self._chk(self.lib.annchor_set_points_f64(self.h, _ptr(X), X.shape[0], X.shape[1]))
+            self.metric = METRIC_EUCLIDEAN_F64
+        self.nx = X.shape[0]
+
+    def set_histograms(self, X, cost):
+        X, cost = _c(X, np.float64), _c(cost, np.float64)
+        assert cost.shape == (X.shape[1], X.shape[1]), "cost_matrix must be [nbins, nbins]"
+        self._chk(self.lib.annchor_set_histograms(self.h, _ptr(X), X.shape[0], X.shape[1], _ptr(cost)))
+        self.nx, self.metric = X.shape[0], METRIC_WASSERSTEIN
+
+    def set_opaque(self, nx):
+        self._chk(self.lib.annchor_set_opaque(self.h, int(nx)))
+        self.nx, self.metric = int(nx), 0
+
+    # ----------------------------------------------------------- metric (a2)
+    def metric_pairs(self, IJ):
+        IJ = _c(IJ, np.int64).reshape(-1, 2)
+        out = np.zeros(IJ.shape[0], dtype=np.float64)
+        self._chk(self.lib.annchor_metric_pairs(self.h, _ptr(IJ), IJ.shape[0], _ptr(out)))
+        return out
+
+    def brute_force(self, k):
+        idx = np.zeros((self.nx, k), dtype=np.int64)
+        dist = np.zeros((self.nx, k), dtype=np.float64)
+        self._chk(self.lib.annchor_brute_force(self.h, int(k), _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    # -------------------------------------------------------------- anchors
+    def pick_anchors_maxmin(self, na, first):
+        self._chk(self.lib.annchor_pick_anchors_maxmin(self.h, int(na), int(first)))
+
+    def pick_anchors_selected(self, A):
+        A = _c(A, np.int64)
+        self._chk(self.lib.annchor_pick_anchors_selected(self.h, _ptr(A), len(A)))
+
+    def set_anchor_distances(self, D, A):
+        D = _c(D, np.float64)
+        A = _c(A, np.int64).reshape(-1)
+        self._chk(self.lib.annchor_set_anchor_distances(self.h, _ptr(D), D.shape[1], _ptr(A) if len(A) else None, len(A)))
+
+    # ------------------------------------------------------------- pipeline
+    def build_locality(self, locality, loc_thresh, loc_min):
+        n, m = _i64(), _i64()
+        self._chk(self.lib.annchor_build_locality(self.h, int(locality), int(loc_thresh), int(loc_min),
+                                                  ctypes.byref(n), ctypes.byref(m)))
+        return n.value, m.value
+
+    def compute_features(self):
+        self._chk(self.lib.annchor_compute_features(self.h))
+
+    def count_uncomputed(self):
+        n = _i64()
+        self._chk(self.lib.annchor_count_uncomputed(self.h, ctypes.byref(n)))
+        return n.value
+
+    def kth_uncomputed_dad(self, ks):
+        ks = _c(ks, np.int64)
+        out = np.zeros(len(ks), dtype=np.float64)
+        self._chk(self.lib.annchor_kth_uncomputed_dad(self.h, _ptr(ks), len(ks), _ptr(out)))
+        return out
+
+    def bin_counts(self, bins):
+        bins = _c(bins, np.float64)
+        out = np.zeros(len(bins) - 1, dtype=np.int64)
+        self._chk(self.lib.annchor_bin_counts(self.h, _ptr(bins), len(bins) - 1, _ptr(out)))
+        return out
+
+    def select_by_rank(self, bins, bin_of, ranks):
+        bins, bin_of, ranks = _c(bins, np.float64), _c(bin_of, np.int32), _c(ranks, np.int64)
+        out = np.zeros(len(ranks), dtype=np.int64)
+        self._chk(self.lib.annchor_select_by_rank(self.h, _ptr(bins), len(bins) - 1, _ptr(bin_of), _ptr(ranks),
+                                                  len(ranks), _ptr(out)))
+        return out
+
+    def gather_features(self, pos):
+        pos = _c(pos, np.int64)
+        out = np.zeros((len(pos), 4), dtype=np.float64)
+        self._chk(self.lib.annchor_gather_features(self.h, _ptr(pos), len(pos), _ptr(out)))
+        return out
+
+    def evaluate_samples(self, pos):
+        pos = _c(pos, np.int64)
+        out = np.zeros(len(pos), dtype=np.float64)
+        self._chk(self.lib.annchor_evaluate_samples(self.h, _ptr(pos), len(pos), _ptr(out)))
+        return out
+
+    def set_samples(self, pos, y):
+        pos, y = _c(pos, np.int64), _c(y, np.float64)
+        self._chk(self.lib.annchor_set_samples(self.h, _ptr(pos), len(pos), _ptr(y)))
+
+    def predict_merge(self, bins, W, c, first, is_metric, n_samples):
+        bins, W, c = _c(bins, np.float64), _c(W, np.float64), _c(c, np.float64)
+        sp = np.zeros(n_samples, dtype=np.float64)
+        self._chk(self.lib.annchor_predict_merge(self.h, _ptr(bins), len(bins) - 1, _ptr(W), _ptr(c), int(first),
+                                                 int(is_metric), _ptr(sp)))
+        return sp
+
+    def merge_host_prediction(self, pred, first, is_metric):
+        pred = _c(pred, np.float64)
+        self._chk(self.lib.annchor_merge_host_prediction(self.h, _ptr(pred), int(first), int(is_metric)))
+
+    def set_labels(self, labels):
+        labels = _c(labels, np.int64)
+        self._chk(self.lib.annchor_set_labels(self.h, _ptr(labels)))
+
+    def select_candidates(self, n_neighbors, nmin, errs_list, n_refine, lookahead):
+        ptr = np.zeros(len(errs_list) + 1, dtype=np.int64)
+        np.cumsum([len(e) for e in errs_list], out=ptr[1:])
+        errs = _c(np.concatenate(errs_list) if len(errs_list) else np.zeros(0), np.float64)
+        nc, nn = _i64(), _i64()
+        self._chk(self.lib.annchor_select_candidates(self.h, int(n_neighbors), int(nmin), _ptr(errs), _ptr(ptr),
+                                                     len(errs_list), int(n_refine), int(lookahead),
+                                                     ctypes.byref(nc), ctypes.byref(nn)))
+        return nc.value, nn.value
+
+    def refine_candidates(self):
+        self._chk(self.lib.annchor_refine_candidates(self.h))
+
+    def set_refined(self, exact):
+        exact = _c(exact, np.float64)
+        self._chk(self.lib.annchor_set_refined(self.h, _ptr(exact), len(exact)))
+
+    def update_bounds(self):
+        self._chk(self.lib.annchor_update_bounds(self.h))
+
+    def neighbor_graph(self, k):
+        idx = np.zeros((self.nx, k), dtype=np.int64)
+        dist = np.zeros((self.nx, k), dtype=np.float64)
+        self._chk(self.lib.annchor_neighbor_graph(self.h, int(k), _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    # ---------------------------------------------------------- state access
+    def field_size(self, field):
+        n = _i64()
+        self._chk(self.lib.annchor_field_size(self.h, int(field), ctypes.byref(n)))
+        return n.value
+
+    def download(self, field):
+        n = self.field_size(field)
+        out = np.zeros(n, dtype=_FIELD_DTYPE[field])
+        if n:
+            self._chk(self.lib.annchor_download(self.h, int(field), _ptr(out), n))
+        return out
+
+    def upload(self, field, arr):
+        arr = _c(arr, _FIELD_DTYPE[field]).reshape(-1)
+        self._chk(self.lib.annchor_upload(self.h, int(field), _ptr(arr), arr.size))
+
+    # ------------------------------------------------------------ profiling
+    def prof_enable(self, on=True):
+        self._chk(self.lib.annchor_prof_enable(self.h, int(bool(on))))
+
+    def prof_reset(self):
+        self._chk(self.lib.annchor_prof_reset(self.h))
+
+    def prof_get(self):
+        cap = 64
+        names = (ctypes.c_char_p * cap)()
+        ms = np.zeros(cap, dtype=np.float64)
+        launches = np.zeros(cap, dtype=np.int64)
+        alg = np.zeros(cap, dtype=np.float64)
+        n = self.lib.annchor_prof_get(self.h, cap, names, _ptr(ms), _ptr(launches), _ptr(alg))
+        if n < 0:
+            self._chk(n)
+        return {names[i].decode(): dict(ms=float(ms[i]), launches=int(launches[i]), alg_bytes=float(alg[i]))
+                for i in range(n)}

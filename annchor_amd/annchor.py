@@ -1,0 +1,383 @@
+"""
+annchor_amd.annchor -- host orchestration of the ANNchor k-NN graph build on MI355X.
+
+Mirrors the reference's user API (annchor/annchor.py): `Annchor(X, func, ...)`,
+`.fit()`, `.neighbor_graph`, the per-stage methods `fit()` calls, `BruteForce`, and
+`compare_neighbor_graphs`; same constructor arguments, same budget arithmetic, same
+plugin protocols (AnchorPicker / Sampler / Regression / ErrorPredictor /
+get_exact_ijs).  What differs is where the work happens: every stage is a call into
+libannchor_hip.so (include/annchor_hip.h) operating on state that stays in HBM.
+NumPy views of that state (`D`, `IJs`, `I`, `features`, `RefineApprox`, ...) are
+materialised only when a user plugin or a test asks for them.
+
+There is no CPU implementation of the pipeline in this package: without the HIP
+library and a GPU, constructing an `Annchor` raises.
+"""
+import time
+from collections import Counter
+
+import numpy as np
+
+from . import _native
+from .distances import DeviceMetric
+from .error_predictors import SimpleStratifiedErrorRegression
+from .pickers import MaxMinAnchorPicker
+from .regressors import SimpleStratifiedLinearRegression
+from .samplers import NothingToSample, SimpleStratifiedSampler
+from .utils import get_exact_ijs_, get_function_from_input, test_parallelisation
+
+FEATURE_NAMES = ["lower bound", "upper bound", "double anchor distance", "is anchor"]
+
+
+class _IndexCSR:
+    """Read-only stand-in for the reference's typed dict `I` (utils.py:533-540):
+    I[i] -> int64 array of positions in IJs that contain i."""
+
+    def __init__(self, ptr, idx):
+        self.ptr, self.idx = ptr, idx
+
+    def __getitem__(self, i):
+        return self.idx[self.ptr[i]:self.ptr[i + 1]]
+
+    def __len__(self):
+        return len(self.ptr) - 1
+
+    def keys(self):
+        return range(len(self))
+
+
+class Annchor:
+    """Quickly computes the approximate k-NN graph for slow metrics (annchor.py:21-115).
+
+    Parameters are those of the reference, plus `device` (GPU ordinal, default 0).
+    """
+
+    def __init__(self, X, func, func_kwargs=None, n_anchors=20, n_neighbors=15, n_samples=5000, p_work=0.1,
+                 anchor_picker=None, sampler=None, regression=None, error_predictor=None, random_seed=42,
+                 locality=5, loc_thresh=1, loc_min=None, verbose=False, is_metric=True, get_exact_ijs=None,
+                 backend="loky", niters=2, lookahead=5, device=0):
+        self.X = X
+        self.nx = len(X)
+        self.N = (self.nx * (self.nx - 1)) // 2
+        self.f = get_function_from_input(func, func_kwargs)
+        self.evals = 0
+        self.n_anchors = n_anchors
+        self.na = int(np.sum([self.nx - j for j in range(1, self.n_anchors + 1)]))
+        self.n_neighbors = n_neighbors
+        self.p_work = p_work
+        self.n_samples = n_samples
+
+        # budget arithmetic, annchor.py:132-148
+        if self.p_work > 1:
+            print("Warning: p_work should not exceed 1.  Setting it to 1.")
+            self.p_work = 1.0
+        min_p_work = (2 * (self.na + self.n_samples) + 1) / self.N
+        min_p_work = 1 if min_p_work > 1 else min_p_work
+        if self.p_work < min_p_work:
+            print("Warning: Too many anchors/samples for specified p_work.")
+            print("Increasing p_work to %5.3f." % min_p_work)
+            self.p_work = min_p_work
+        if self.p_work > 0.75:
+            print("Warning: High Value of p_work.")
+            print("Think about decreasing n_anchors or n_samples," + " or using BruteForce.")
+
+        self.anchor_picker = MaxMinAnchorPicker() if anchor_picker is None else anchor_picker
+        self.sampler = SimpleStratifiedSampler() if sampler is None else sampler
+        self.regression = SimpleStratifiedLinearRegression() if regression is None else regression
+        self.error_predictor = SimpleStratifiedErrorRegression() if error_predictor is None else error_predictor
+
+        self.random_seed = random_seed
+        self.verbose = verbose
+        self.locality = locality
+        self.loc_thresh = loc_thresh
+        self.loc_min = 10 * self.n_neighbors if loc_min is None else loc_min
+        self.loc_min = np.clip(self.loc_min, 0, self.nx - 1)
+        self.is_metric = is_metric
+        self.niters = niters
+        self.lookahead = lookahead
+        self.feature_names = list(FEATURE_NAMES)
+        assert backend in ["loky", "multiprocessing"]
+        self.backend = backend
+
+        # ---- the engine: fails loudly when the HIP library or a GPU is missing
+        self._engine = _native.Engine(device)
+        self._device_metric = isinstance(self.f, DeviceMetric) and get_exact_ijs is None
+        if self._device_metric:
+            self.f.bind(self._engine, X)
+            self.get_exact_ijs = self._device_get_exact_ijs
+        else:
+            self._engine.set_opaque(self.nx)
+            if get_exact_ijs is None:
+                self.get_exact_ijs = get_exact_ijs_(self.f, verbose=self.verbose, backend=backend)
+            else:
+                self.get_exact_ijs = get_exact_ijs
+        test_parallelisation(self.get_exact_ijs, self.f, self.X, self.nx, backend, s=20)
+        self.get_exact_query_ijs = None
+        self._anchors_on_device = False
+        self._cache = {}
+        self._first_merge = True
+        self.timings = {}
+
+    # ------------------------------------------------------------ metric boundary
+    def _device_get_exact_ijs(self, f, X, IJ):
+        """get_exact(f, X, IJ) (utils.py:110-177) against the uploaded data set."""
+        return self._engine.metric_pairs(np.asarray(IJ, dtype=np.int64))
+
+    # ------------------------------------------------------------- lazy NumPy views
+    def _view(self, key, loader):
+        if key not in self._cache:
+            self._cache[key] = loader()
+        return self._cache[key]
+
+    def _invalidate(self, *keys):
+        for k in keys:
+            self._cache.pop(k, None)
+
+    @property
+    def D(self):
+        return self._view("D", lambda: self._engine.download(_native.F_D).reshape(self.nx, self.n_anchors))
+
+    @property
+    def A(self):
+        return self._view("A", lambda: self._engine.download(_native.F_A))
+
+    @property
+    def IJs(self):
+        return self._view("IJs", lambda: self._engine.download(_native.F_IJS).reshape(-1, 2))
+
+    @property
+    def I(self):
+        return self._view("I", lambda: _IndexCSR(self._engine.download(_native.F_I_PTR),
+                                                 self._engine.download(_native.F_I_IDX)))
+
+    @property
+    def sid(self):
+        def load():
+            m = self._engine.download(_native.F_SID)
+            return np.array([[a for a in range(self.n_anchors) if (int(w) >> a) & 1] for w in m])
+        return self._view("sid", load)
+
+    @property
+    def features(self):
+        return self._view("features", lambda: self._engine.download(_native.F_FEATURES).reshape(-1, 4))
+
+    @property
+    def not_computed_mask(self):
+        return self._view("ncm", lambda: self._engine.download(_native.F_NCM).astype(bool))
+
+    @property
+    def RefineApprox(self):
+        return self._view("RA", lambda: self._engine.download(_native.F_RA))
+
+    @property
+    def errors(self):
+        return self._view("labels", lambda: self._engine.download(_native.F_LABELS))
+
+    @property
+    def thresh(self):
+        return self._view("thresh", lambda: self._engine.download(_native.F_THRESH))
+
+    # --------------------------------------------------------------------- stages
+    def get_anchors(self):
+        """annchor.py:191-206."""
+        self._anchors_on_device = False
+        A, D, evals = self.anchor_picker.get_anchors(self)
+        if not self._anchors_on_device:
+            D = np.ascontiguousarray(D, dtype=np.float64)
+            self._engine.set_anchor_distances(D, np.asarray(A, dtype=np.int64))
+        self._invalidate("D", "A")
+        self.evals += evals
+
+    def get_locality(self):
+        """annchor.py:208-256."""
+        n, min_len = self._engine.build_locality(self.locality, self.loc_thresh, int(self.loc_min))
+        self.n_pairs = n
+        self._invalidate("IJs", "I", "sid", "features", "ncm", "RA", "labels", "thresh")
+        if min_len < self.n_neighbors:
+            raise Exception("Error: Not enough candidates in pool for all indices.\n"
+                            + "Try again with higher locality.")
+
+    def get_features(self):
+        """annchor.py:258-311."""
+        self._engine.compute_features()
+        self._first_merge = True
+        self._invalidate("features", "ncm", "RA", "labels", "thresh")
+
+    def get_sample(self):
+        """annchor.py:313-343."""
+        eng = self._engine
+        if type(self.sampler) is SimpleStratifiedSampler:
+            self.sample_ixs, self.n_samples, self.sample_bins = self.sampler.sample_device(
+                eng, self.n_samples, self.random_seed)
+        else:
+            self.sample_ixs, self.n_samples, self.sample_bins = self.sampler.sample(
+                self.features, self.feature_names, self.n_samples, self.not_computed_mask, self.random_seed)
+        self.sample_ixs = np.asarray(self.sample_ixs, dtype=np.int64)
+        self.sample_features = eng.gather_features(self.sample_ixs)
+        if self._device_metric:
+            self.sample_y = eng.evaluate_samples(self.sample_ixs)
+        else:
+            self.sample_ijs = self.IJs[self.sample_ixs]
+            self.sample_y = np.asarray(self.get_exact_ijs(self.f, self.X, self.sample_ijs), dtype=np.float64)
+            eng.set_samples(self.sample_ixs, self.sample_y)
+        self._invalidate("ncm")
+        self.evals += self.sample_y.shape[0]
+
+    def fit_predict_regression(self):
+        """annchor.py:345-380."""
+        self.regression.fit(self.sample_features, self.feature_names, self.sample_y, sample_bins=self.sample_bins)
+        model = self.regression.coefficients() if type(self.regression) is SimpleStratifiedLinearRegression else None
+        self._fused_labels = False
+        if model is not None:
+            bins, W, c = model
+            self.sample_predict = self._engine.predict_merge(bins, W, c, self._first_merge, self.is_metric,
+                                                             len(self.sample_ixs))
+            # the fused kernel labels pairs with the same bin edges; valid for the
+            # built-in error predictor when it is handed these edges (it is, below)
+            self._fused_labels = (type(self.error_predictor) is SimpleStratifiedErrorRegression
+                                  and self.error_predictor.partition_feature_name == "double anchor distance"
+                                  and np.array_equal(bins, self.sample_bins))
+        else:
+            pred = np.asarray(self.regression.predict(self.features, self.feature_names), dtype=np.float64)
+            self.sample_predict = pred[self.sample_ixs]
+            self._engine.merge_host_prediction(pred, self._first_merge, self.is_metric)
+        self._first_merge = False
+        self._invalidate("RA", "labels")
+
+    def fit_predict_errors(self):
+        """annchor.py:382-393."""
+        self.error_predictor.fit(self.sample_features, self.feature_names, self.sample_y - self.sample_predict,
+                                 sample_bins=self.sample_bins)
+        if not self._fused_labels:
+            labels = self.error_predictor.predict(self.features, self.feature_names)
+            self._engine.set_labels(labels)
+        self._invalidate("labels")
+
+    def select_refine_candidate_pairs(self, w=0.5, it=0):
+        """annchor.py:395-473."""
+        nn = self.n_neighbors
+        labels = list(self.error_predictor.labels)
+        errs = [np.asarray(self.error_predictor.errs[lab], dtype=np.float64) for lab in labels]
+        assert labels == list(range(len(labels))), "error labels must be 0..L-1"
+        n_refine = int((self.p_work * self.N - self.na - self.n_samples) * w) + 1  # annchor.py:440
+        n_refine = 0 if n_refine < 0 else n_refine
+        nmin = 3 * nn // 2 if it == 0 else 0
+        ncand, nnext = self._engine.select_candidates(nn, nmin, errs, n_refine, self.lookahead)
+        self.n_refine = n_refine
+        self._invalidate("RA", "thresh", "cand", "next")
+        if self._device_metric:
+            self._engine.refine_candidates()
+        elif ncand:
+            mapback = self._engine.download(_native.F_CAND)
+            exact = np.asarray(self.get_exact_ijs(self.f, self.X, self.IJs[mapback]), dtype=np.float64)
+            self._engine.set_refined(exact)
+        self.evals += ncand
+        self._invalidate("RA", "ncm")
+
+    @property
+    def nextback(self):
+        return self._view("next", lambda: self._engine.download(_native.F_NEXT))
+
+    @property
+    def mapback(self):
+        return self._view("cand", lambda: self._engine.download(_native.F_CAND))
+
+    def update_anchor_points(self, timeout=None, chunk_size=None):
+        """annchor.py:475-512 (no wall-clock cut: all lookahead pairs are processed)."""
+        self._engine.update_bounds()
+        self._invalidate("features")
+
+    def get_ann(self):
+        """annchor.py:514-530."""
+        self.neighbor_graph = self._engine.neighbor_graph(self.n_neighbors)
+
+    def fit(self):
+        """Computes the approximate nearest-neighbour graph (annchor.py:532-623)."""
+        origin = time.perf_counter()
+        t = self.timings = {}
+
+        def stage(name, fn, *a, **k):
+            s = time.perf_counter()
+            fn(*a, **k)
+            t[name] = t.get(name, 0.0) + time.perf_counter() - s
+            if self.verbose:
+                print("%40s: %6.3f | %6.3f" % (name, time.perf_counter() - s, time.perf_counter() - origin))
+
+        stage("get_anchors", self.get_anchors)
+        stage("get_locality", self.get_locality)
+        stage("get_features", self.get_features)
+        niters = self.niters
+        for it in range(niters):
+            try:
+                stage("get_sample", self.get_sample)
+            except NothingToSample as err:
+                if it == 0:
+                    raise ValueError("Sampler raised NothingToSample on first iteration.") from err
+                print("Warning: main loop terminated early with nothing " + "left to sample.")
+                break
+            stage("fit_predict_regression", self.fit_predict_regression)
+            stage("fit_predict_errors", self.fit_predict_errors)
+            stage("select_refine_candidate_pairs", self.select_refine_candidate_pairs, w=1 / niters, it=it)
+            if it < niters - 1:
+                stage("update_anchor_points", self.update_anchor_points)
+        stage("get_ann", self.get_ann)
+        t["total"] = time.perf_counter() - origin
+        return self
+
+    def to_sparse_matrix(self):
+        """annchor.py:625-641: DOK sparse distance matrix of the k-NN graph."""
+        from scipy.sparse import dok_matrix
+
+        D = dok_matrix((self.nx, self.nx), dtype=np.float64)
+        eps = np.nextafter(0, 1, dtype=np.float64)
+        for i, (js, ds) in enumerate(zip(*self.neighbor_graph)):
+            for j, d in zip(js, ds):
+                D[i, j] = D[j, i] = d + eps
+        return D
+
+
+class BruteForce:
+    """All-pairs k-NN graph (annchor.py:943-1023)."""
+
+    def __init__(self, X, func, func_kwargs=None, verbose=False, get_exact_ijs=None, backend="loky", device=0):
+        self.X = X
+        self.nx = len(X)
+        self.f = get_function_from_input(func, func_kwargs)
+        self.verbose = verbose
+        assert backend in ["loky", "multiprocessing"]
+        self._device_metric = isinstance(self.f, DeviceMetric) and get_exact_ijs is None
+        if self._device_metric:
+            self._engine = _native.Engine(device)
+            self.f.bind(self._engine, X)
+            self.get_exact_ijs = lambda f, X, IJ: self._engine.metric_pairs(np.asarray(IJ, dtype=np.int64))
+        elif get_exact_ijs is None:
+            self.get_exact_ijs = get_exact_ijs_(self.f, verbose=self.verbose, backend=backend)
+        else:
+            self.get_exact_ijs = get_exact_ijs
+        test_parallelisation(self.get_exact_ijs, self.f, self.X, self.nx, backend, s=20)
+
+    def fit(self):
+        if self._device_metric:
+            self.neighbor_graph = self._engine.brute_force(self.nx)
+            return self
+        iu = np.triu_indices(self.nx, k=1)
+        IJs = np.stack(iu, axis=1)
+        dists = self.get_exact_ijs(self.f, self.X, IJs)
+        self.D = np.zeros(shape=(self.nx, self.nx))
+        self.D[iu] = dists
+        self.D = self.D + self.D.T
+        order = np.argsort(self.D, axis=1, kind="stable")
+        self.neighbor_graph = (order, np.take_along_axis(self.D, order, axis=1))
+        return self
+
+
+def compare_neighbor_graphs(nng_1, nng_2, n_neighbors):
+    """Number of incorrect NN pairs of nng_2 w.r.t. nng_1, counting equal distances
+    as interchangeable (annchor.py:1026-1066)."""
+    nx = nng_1[0].shape[0]
+    h = []
+    for ix in range(nx):
+        a = Counter(np.round(nng_1[1][ix][:n_neighbors], 3).astype(np.float32))
+        b = Counter(np.round(nng_2[1][ix][:n_neighbors], 3).astype(np.float32))
+        h.append(len(a - b))
+    return int(np.sum(h))

@@ -1,0 +1,170 @@
+// common.h -- shared declarations for libannchor_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/annchor_hip.h"
+
+#define ANN_WAVE 64
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct ProfEntry {
+    const char *name;
+    double ms = 0;
+    int64_t launches = 0;
+    double alg_bytes = 0;
+};
+
+struct PendingEvent {
+    int entry;
+    hipEvent_t a, b;
+};
+
+struct annchor_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipDeviceProp_t prop;
+
+    // ---- data set
+    int metric = ANNCHOR_METRIC_NONE;
+    int64_t nx = 0;
+    DevBuf sym, soff, slen;  // strings: symbols (uint8, 16B-aligned starts), int32 offsets, int32 lens
+    int alphabet = 0, maxlen = 0;
+    DevBuf pts;              // points (f32 or f64) row-major [nx, dim]
+    int dim = 0;
+    DevBuf hist, cost, supp; // histograms f64 [nx, nbins], cost [nbins, nbins], support sizes int32 [nx]
+    int nbins = 0, max_support = 0;
+
+    // ---- anchors
+    int na = 0, nA = 0;
+    DevBuf Dt;          // double [na][nx]   (anchor-major: lane-coalesced over points)
+    DevBuf A;           // int32 [na]
+    DevBuf anchorRank;  // int32 [nx]  rank of the LAST occurrence in A, -1 if not an anchor
+    DevBuf runmin, redval, redidx;
+
+    // ---- locality
+    DevBuf sid, cA, thr;          // uint64 [nx], int32 [nx], int32 [nx]
+    DevBuf Kbits, Kpref;          // uint64 [nx][kw], uint32 [nx][kw]
+    DevBuf deg, low, rowstart;    // int32 [nx], int32 [nx], int64 [nx+1]
+    DevBuf Iptr, Iidx;            // int64 [nx+1], int32 [2n]
+    int64_t n = 0;                // number of candidate pairs
+    DevBuf ij;                    // int2 [n]
+
+    // ---- per-pair state
+    DevBuf lb, ub, dad, RA, prob;  // double [n]
+    DevBuf anc, ncm, label;        // uint8 [n]
+    bool have_features = false, have_RA = false;
+
+    // ---- samples
+    DevBuf spos, sy;  // int32 [m], double [m]
+    int64_t nsamp = 0;
+
+    // ---- selection
+    DevBuf thresh;               // double [nx]
+    DevBuf cand, next;           // int32 lists
+    int64_t ncand = 0, nnext = 0;
+    DevBuf gl_val, gl_pos, gl_cnt, gl_ncomp, marked, markcount;  // guarantee_nmin scratch
+    DevBuf sel_hist, sel_state, blk_cnt, blk_off;                // radix select / compaction scratch
+    DevBuf errs, errptr;
+    DevBuf cptr, cidx, cval;     // computed-neighbour CSR for update_bounds
+    DevBuf tmp0, tmp1, tmp2, tmp3;
+    DevBuf scan_tmp;
+
+    // ---- staging
+    DevBuf stage_in, stage_out;
+
+    // ---- profiling
+    bool prof_on = false;
+    std::vector<ProfEntry> prof;
+    std::vector<PendingEvent> pending;
+    hipEvent_t call_a = nullptr, call_b = nullptr;
+    bool call_timed = false;
+};
+
+const char *ann_set_err(annchor_ctx *c, const char *fmt, ...);
+
+#define ANN_CHECK_HIP(c, expr)                                                                  \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            ann_set_err((c), "%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,                 \
+                        hipGetErrorString(_e));                                                 \
+            return ANNCHOR_EHIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+#define ANN_TRY(expr)                \
+    do {                             \
+        int _r = (expr);             \
+        if (_r != ANNCHOR_OK) return _r; \
+    } while (0)
+
+#define ANN_REQUIRE(c, cond, code, ...)    \
+    do {                                   \
+        if (!(cond)) {                     \
+            ann_set_err((c), __VA_ARGS__); \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+int ann_reserve(annchor_ctx *c, DevBuf &b, size_t bytes);
+int ann_h2d(annchor_ctx *c, void *dst, const void *src, size_t bytes);
+int ann_d2h(annchor_ctx *c, void *dst, const void *src, size_t bytes);
+
+// profiling scopes: one entry per kernel family
+int ann_prof_entry(annchor_ctx *c, const char *name);
+struct ProfScope {
+    annchor_ctx *c;
+    int entry = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(annchor_ctx *ctx, const char *name, double alg_bytes = 0);
+    ~ProfScope();
+};
+
+static inline int ann_blocks(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
+
+// ---- device helpers ------------------------------------------------------
+// order-preserving map double -> uint64 (ascending)
+__device__ __forceinline__ uint64_t ann_key_asc(double v)
+{
+    uint64_t u = (uint64_t)__double_as_longlong(v);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ann_key_asc_inv(uint64_t k)
+{
+    uint64_t u = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+// ---- internal cross-file entry points -------------------------------------
+// metric on a device pair list: out[t] (and optionally RA[pos[t]] = d, ncm[pos[t]] = 0)
+struct PairSource {
+    const int2 *ij = nullptr;     // explicit pairs (when idx == nullptr: pair t = ij[t])
+    const int32_t *idx = nullptr; // optional positions into ij: pair t = ij[idx[t]]
+    const int32_t *anchor = nullptr; // one-to-all: pair t = (*anchor, t)
+    int64_t n = 0;
+};
+int ann_metric_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
+int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
+int ann_euclid_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
+int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
+
+// generic device primitives (scan.hip)
+int ann_exclusive_scan_i32_to_i64(annchor_ctx *c, const int32_t *in, int64_t *out, int64_t n);  // out has n+1
+// k-th smallest (0-based) of double keys where flag != 0 (flag may be null = all)
+int ann_kth_smallest(annchor_ctx *c, const double *vals, const uint8_t *flag, int64_t n, const int64_t *ks,
+                     int nk, double *h_out);
+
+int ann_set_anchor_flags(annchor_ctx *c, const int64_t *hA, int nA);

@@ -1,0 +1,352 @@
+// ctx.hip -- context lifecycle, memory, data-set upload, state access, profiling.
+#include <cstdarg>
+
+#include "common.h"
+
+static std::string g_create_err;
+
+const char *ann_set_err(annchor_ctx *c, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return c ? c->err.c_str() : g_create_err.c_str();
+}
+
+int ann_reserve(annchor_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return ANNCHOR_OK;
+    if (b.p) ANN_CHECK_HIP(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = (bytes + 255) & ~(size_t)255;
+    ANN_CHECK_HIP(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return ANNCHOR_OK;
+}
+
+int ann_h2d(annchor_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return ANNCHOR_OK;
+    ANN_CHECK_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));  // pageable host memory: do not retain the pointer
+    return ANNCHOR_OK;
+}
+
+int ann_d2h(annchor_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return ANNCHOR_OK;
+    ANN_CHECK_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    return ANNCHOR_OK;
+}
+
+// ------------------------------------------------------------------ profiling
+int ann_prof_entry(annchor_ctx *c, const char *name)
+{
+    for (size_t i = 0; i < c->prof.size(); ++i)
+        if (c->prof[i].name == name || strcmp(c->prof[i].name, name) == 0) return (int)i;
+    ProfEntry e;
+    e.name = name;
+    c->prof.push_back(e);
+    return (int)c->prof.size() - 1;
+}
+
+static void prof_drain(annchor_ctx *c)
+{
+    for (auto &p : c->pending) {
+        float ms = 0;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess)
+            c->prof[p.entry].ms += ms;
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    c->pending.clear();
+}
+
+ProfScope::ProfScope(annchor_ctx *ctx, const char *name, double alg_bytes) : c(ctx)
+{
+    if (!c->prof_on) return;
+    entry = ann_prof_entry(c, name);
+    c->prof[entry].launches += 1;
+    c->prof[entry].alg_bytes += alg_bytes;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { entry = -1; return; }
+    (void)hipEventRecord(a, c->stream);
+}
+
+ProfScope::~ProfScope()
+{
+    if (entry < 0) return;
+    (void)hipEventRecord(b, c->stream);
+    c->pending.push_back({entry, a, b});
+    if (c->pending.size() > 4096) prof_drain(c);
+}
+
+extern "C" int annchor_prof_enable(annchor_ctx *c, int32_t on)
+{
+    if (!c) return ANNCHOR_EINVAL;
+    c->prof_on = on != 0;
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_prof_reset(annchor_ctx *c)
+{
+    if (!c) return ANNCHOR_EINVAL;
+    prof_drain(c);
+    for (auto &e : c->prof) { e.ms = 0; e.launches = 0; e.alg_bytes = 0; }
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_prof_get(annchor_ctx *c, int32_t max_entries, const char **names, double *ms,
+                                int64_t *launches, double *alg_bytes)
+{
+    if (!c) return ANNCHOR_EINVAL;
+    (void)hipStreamSynchronize(c->stream);
+    prof_drain(c);
+    int n = 0;
+    for (auto &e : c->prof) {
+        if (n >= max_entries) break;
+        names[n] = e.name;
+        ms[n] = e.ms;
+        launches[n] = e.launches;
+        alg_bytes[n] = e.alg_bytes;
+        ++n;
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------ lifecycle
+extern "C" int annchor_create(int device, annchor_ctx **out)
+{
+    if (!out) return ANNCHOR_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        ann_set_err(nullptr, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return ANNCHOR_ENODEV;
+    }
+    if (device < 0 || device >= count) {
+        ann_set_err(nullptr, "device %d out of range (have %d)", device, count);
+        return ANNCHOR_EINVAL;
+    }
+    annchor_ctx *c = new annchor_ctx();
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&c->prop, device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        ann_set_err(nullptr, "device init failed: %s", hipGetErrorString(e));
+        delete c;
+        return ANNCHOR_EHIP;
+    }
+    (void)hipEventCreate(&c->call_a);
+    (void)hipEventCreate(&c->call_b);
+    *out = c;
+    return ANNCHOR_OK;
+}
+
+extern "C" void annchor_destroy(annchor_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    prof_drain(c);
+    DevBuf *bufs[] = {&c->sym, &c->soff, &c->slen, &c->pts, &c->hist, &c->cost, &c->supp, &c->Dt, &c->A,
+                      &c->anchorRank, &c->runmin, &c->redval, &c->redidx, &c->sid, &c->cA, &c->thr, &c->Kbits,
+                      &c->Kpref, &c->deg, &c->low, &c->rowstart, &c->Iptr, &c->Iidx, &c->ij, &c->lb, &c->ub,
+                      &c->dad, &c->RA, &c->prob, &c->anc, &c->ncm, &c->label, &c->spos, &c->sy, &c->thresh,
+                      &c->cand, &c->next, &c->gl_val, &c->gl_pos, &c->gl_cnt, &c->gl_ncomp, &c->marked,
+                      &c->markcount, &c->sel_hist, &c->sel_state, &c->blk_cnt, &c->blk_off, &c->errs, &c->errptr,
+                      &c->cptr, &c->cidx, &c->cval, &c->tmp0, &c->tmp1, &c->tmp2, &c->tmp3, &c->scan_tmp,
+                      &c->stage_in, &c->stage_out};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (c->call_a) (void)hipEventDestroy(c->call_a);
+    if (c->call_b) (void)hipEventDestroy(c->call_b);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char *annchor_last_error(annchor_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+extern "C" const char *annchor_create_error(void) { return g_create_err.c_str(); }
+
+extern "C" int annchor_device_name(annchor_ctx *c, char *buf, int buflen)
+{
+    if (!c || !buf || buflen <= 0) return ANNCHOR_EINVAL;
+    snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", c->prop.name, c->prop.gcnArchName, c->prop.multiProcessorCount);
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_synchronize(annchor_ctx *c)
+{
+    if (!c) return ANNCHOR_EINVAL;
+    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_last_kernel_ms(annchor_ctx *c, float *ms)
+{
+    if (!c || !ms) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->call_timed, ANNCHOR_EINVAL, "no timed call yet");
+    ANN_CHECK_HIP(c, hipEventSynchronize(c->call_b));
+    ANN_CHECK_HIP(c, hipEventElapsedTime(ms, c->call_a, c->call_b));
+    return ANNCHOR_OK;
+}
+
+// ------------------------------------------------------------------- data set
+static void reset_pipeline(annchor_ctx *c)
+{
+    c->na = c->nA = 0;
+    c->n = 0;
+    c->have_features = c->have_RA = false;
+    c->nsamp = c->ncand = c->nnext = 0;
+}
+
+extern "C" int annchor_set_opaque(annchor_ctx *c, int64_t nx)
+{
+    if (!c) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, nx > 1 && nx < (1ll << 31), ANNCHOR_ELIMIT, "nx=%lld out of range", (long long)nx);
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    c->metric = ANNCHOR_METRIC_NONE;
+    c->nx = nx;
+    reset_pipeline(c);
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_set_strings(annchor_ctx *c, const uint8_t *symbols, const int64_t *offs,
+                                   const int32_t *lens, int64_t nx, int32_t alphabet)
+{
+    if (!c || !symbols || !offs || !lens) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, nx > 1 && nx < (1ll << 31), ANNCHOR_ELIMIT, "nx=%lld out of range", (long long)nx);
+    ANN_REQUIRE(c, alphabet >= 1 && alphabet <= 256, ANNCHOR_ELIMIT, "alphabet=%d not in 1..256", alphabet);
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    // repack with 16-byte aligned starts so that lanes can use wide loads
+    std::vector<int32_t> o((size_t)nx);
+    size_t total = 0;
+    int maxlen = 0;
+    for (int64_t s = 0; s < nx; ++s) {
+        ANN_REQUIRE(c, lens[s] >= 0, ANNCHOR_EINVAL, "negative length at %lld", (long long)s);
+        o[(size_t)s] = (int32_t)total;
+        total += ((size_t)lens[s] + 15) & ~(size_t)15;
+        if (lens[s] > maxlen) maxlen = lens[s];
+        ANN_REQUIRE(c, total < (1ull << 31), ANNCHOR_ELIMIT, "string pool exceeds 2 GiB");
+    }
+    ANN_REQUIRE(c, maxlen <= 32 * 64 * 8, ANNCHOR_ELIMIT, "string length %d exceeds the supported 16384", maxlen);
+    std::vector<uint8_t> pool(total + 16, 0);
+    for (int64_t s = 0; s < nx; ++s) {
+        for (int32_t k = 0; k < lens[s]; ++k)
+            ANN_REQUIRE(c, symbols[offs[s] + k] < alphabet, ANNCHOR_EINVAL, "symbol code out of range in string %lld",
+                        (long long)s);
+        memcpy(pool.data() + o[(size_t)s], symbols + offs[s], (size_t)lens[s]);
+    }
+    ANN_TRY(ann_reserve(c, c->sym, pool.size()));
+    ANN_TRY(ann_reserve(c, c->soff, sizeof(int32_t) * (size_t)nx));
+    ANN_TRY(ann_reserve(c, c->slen, sizeof(int32_t) * (size_t)nx));
+    ANN_TRY(ann_h2d(c, c->sym.p, pool.data(), pool.size()));
+    ANN_TRY(ann_h2d(c, c->soff.p, o.data(), sizeof(int32_t) * (size_t)nx));
+    ANN_TRY(ann_h2d(c, c->slen.p, lens, sizeof(int32_t) * (size_t)nx));
+    c->metric = ANNCHOR_METRIC_LEVENSHTEIN;
+    c->nx = nx;
+    c->alphabet = alphabet;
+    c->maxlen = maxlen;
+    reset_pipeline(c);
+    return ANNCHOR_OK;
+}
+
+static int set_points(annchor_ctx *c, const void *X, int64_t nx, int32_t dim, size_t esz, int metric)
+{
+    if (!c || !X) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, nx > 1 && nx < (1ll << 31), ANNCHOR_ELIMIT, "nx=%lld out of range", (long long)nx);
+    ANN_REQUIRE(c, dim >= 1 && dim <= 65536, ANNCHOR_ELIMIT, "dim=%d out of range", dim);
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    size_t bytes = esz * (size_t)nx * (size_t)dim;
+    ANN_TRY(ann_reserve(c, c->pts, bytes));
+    ANN_TRY(ann_h2d(c, c->pts.p, X, bytes));
+    c->metric = metric;
+    c->nx = nx;
+    c->dim = dim;
+    reset_pipeline(c);
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_set_points_f32(annchor_ctx *c, const float *X, int64_t nx, int32_t dim)
+{
+    return set_points(c, X, nx, dim, sizeof(float), ANNCHOR_METRIC_EUCLIDEAN_F32);
+}
+
+extern "C" int annchor_set_points_f64(annchor_ctx *c, const double *X, int64_t nx, int32_t dim)
+{
+    return set_points(c, X, nx, dim, sizeof(double), ANNCHOR_METRIC_EUCLIDEAN_F64);
+}
+
+extern "C" int annchor_set_histograms(annchor_ctx *c, const double *hist, int64_t nx, int32_t nbins,
+                                      const double *cost)
+{
+    if (!c || !hist || !cost) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, nx > 1 && nx < (1ll << 31), ANNCHOR_ELIMIT, "nx=%lld out of range", (long long)nx);
+    ANN_REQUIRE(c, nbins >= 1 && nbins <= 64, ANNCHOR_ELIMIT, "nbins=%d: this build supports 1..64 bins", nbins);
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    int maxs = 0;
+    for (int64_t s = 0; s < nx; ++s) {
+        int k = 0;
+        for (int b = 0; b < nbins; ++b) k += hist[s * nbins + b] != 0;
+        ANN_REQUIRE(c, k > 0, ANNCHOR_EINVAL, "histogram %lld is empty", (long long)s);
+        if (k > maxs) maxs = k;
+    }
+    ANN_TRY(ann_reserve(c, c->hist, sizeof(double) * (size_t)nx * nbins));
+    ANN_TRY(ann_reserve(c, c->cost, sizeof(double) * (size_t)nbins * nbins));
+    ANN_TRY(ann_h2d(c, c->hist.p, hist, sizeof(double) * (size_t)nx * nbins));
+    ANN_TRY(ann_h2d(c, c->cost.p, cost, sizeof(double) * (size_t)nbins * nbins));
+    c->metric = ANNCHOR_METRIC_WASSERSTEIN;
+    c->nx = nx;
+    c->nbins = nbins;
+    c->max_support = maxs;
+    reset_pipeline(c);
+    return ANNCHOR_OK;
+}
+
+// ----------------------------------------------------------- metric boundary
+int ann_metric_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm)
+{
+    switch (c->metric) {
+    case ANNCHOR_METRIC_LEVENSHTEIN: return ann_lev_launch(c, src, d_out, d_RA, d_ncm);
+    case ANNCHOR_METRIC_EUCLIDEAN_F32:
+    case ANNCHOR_METRIC_EUCLIDEAN_F64: return ann_euclid_launch(c, src, d_out, d_RA, d_ncm);
+    case ANNCHOR_METRIC_WASSERSTEIN: return ann_emd_launch(c, src, d_out, d_RA, d_ncm);
+    default: ann_set_err(c, "no device metric bound to this context"); return ANNCHOR_EINVAL;
+    }
+}
+
+__global__ void k_ij64_to_int2(const int64_t *__restrict__ ij, int2 *__restrict__ out, int64_t n)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = make_int2((int)ij[2 * t], (int)ij[2 * t + 1]);
+}
+
+extern "C" int annchor_metric_pairs(annchor_ctx *c, const int64_t *ij, int64_t n, double *out)
+{
+    if (!c || (n > 0 && (!ij || !out))) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->metric != ANNCHOR_METRIC_NONE, ANNCHOR_EINVAL, "no device metric bound to this context");
+    ANN_REQUIRE(c, n >= 0 && n < (1ll << 31), ANNCHOR_ELIMIT, "n=%lld out of range", (long long)n);
+    if (n == 0) return ANNCHOR_OK;
+    for (int64_t t = 0; t < 2 * n; ++t)
+        ANN_REQUIRE(c, ij[t] >= 0 && ij[t] < c->nx, ANNCHOR_EINVAL, "pair index %lld out of range", (long long)ij[t]);
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(ann_reserve(c, c->stage_in, sizeof(int64_t) * 2 * (size_t)n));
+    ANN_TRY(ann_reserve(c, c->tmp0, sizeof(int2) * (size_t)n));
+    ANN_TRY(ann_reserve(c, c->stage_out, sizeof(double) * (size_t)n));
+    ANN_TRY(ann_h2d(c, c->stage_in.p, ij, sizeof(int64_t) * 2 * (size_t)n));
+    k_ij64_to_int2<<<ann_blocks(n, 256), 256, 0, c->stream>>>(c->stage_in.as<int64_t>(), c->tmp0.as<int2>(), n);
+    PairSource src;
+    src.ij = c->tmp0.as<int2>();
+    src.n = n;
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    ANN_TRY(ann_metric_launch(c, src, c->stage_out.as<double>(), nullptr, nullptr));
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+    c->call_timed = true;
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ann_d2h(c, out, c->stage_out.p, sizeof(double) * (size_t)n);
+}

@@ -1,0 +1,532 @@
+// features.hip -- per-pair features, sampler support, regression predict / clip / merge.
+//
+// Replaces get_bounds_njit_ijs, get_dad_ijs (reference annchor/utils.py:274-301,
+// 355-380), Annchor.get_features_IJ (annchor/annchor.py:258-303), the device side
+// of Sampler.sample (annchor/samplers.py:44-140, annchor/utils.py:543-578),
+// SimpleStratifiedLinearRegression.predict + clip + RefineApprox merge
+// (annchor/regressors.py:71-103, annchor/annchor.py:356-380) and
+// SimpleStratifiedErrorRegression.predict (annchor/error_predictors.py:56-67).
+//
+// Layout: structure-of-arrays float64 lb[], ub[], dad[], RA[] + uint8 masks, all
+// indexed by pair position; pairs are sorted by (i, j) so consecutive lanes share i
+// (scalar broadcast of D[.][i]) and read D[.][j] from consecutive addresses of the
+// anchor-major Dt.  All arithmetic is float64 and uses only |a-b|, a+b, min, max,
+// /2 -- results are bit-identical to the reference's NumPy arithmetic.  The
+// regression predict is evaluated as ((w0*lb + w1*ub) + w2*dad) + c with
+// contraction disabled so that host and device agree bit for bit.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+__global__ __launch_bounds__(256) void k_features(const int2 *__restrict__ ij, int64_t n, const double *__restrict__ Dt,
+                                                 int64_t nx, int na, const int32_t *__restrict__ cA,
+                                                 const int32_t *__restrict__ anchorRank, double *__restrict__ lb,
+                                                 double *__restrict__ ub, double *__restrict__ dad,
+                                                 uint8_t *__restrict__ anc, uint8_t *__restrict__ ncm)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int2 q = ij[p];
+    const int i = q.x, j = q.y;
+    double l = 0.0, u = INFINITY;
+    for (int a = 0; a < na; ++a) {
+        const double di = Dt[(size_t)a * nx + i], dj = Dt[(size_t)a * nx + j];
+        l = fmax(l, fabs(di - dj));
+        u = fmin(u, di + dj);
+    }
+    lb[p] = l;
+    ub[p] = u;
+    dad[p] = (Dt[(size_t)cA[j] * nx + i] + Dt[(size_t)cA[i] * nx + j]) / 2;
+    const uint8_t isa = (anchorRank[i] >= 0) | (anchorRank[j] >= 0);
+    anc[p] = isa;
+    ncm[p] = !isa;
+}
+
+extern "C" int annchor_compute_features(annchor_ctx *c)
+{
+    if (!c) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->n > 0, ANNCHOR_EINVAL, "locality not built");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->n;
+    ANN_TRY(ann_reserve(c, c->lb, 8 * n));
+    ANN_TRY(ann_reserve(c, c->ub, 8 * n));
+    ANN_TRY(ann_reserve(c, c->dad, 8 * n));
+    ANN_TRY(ann_reserve(c, c->RA, 8 * n));
+    ANN_TRY(ann_reserve(c, c->prob, 8 * n));
+    ANN_TRY(ann_reserve(c, c->anc, n));
+    ANN_TRY(ann_reserve(c, c->ncm, n));
+    ANN_TRY(ann_reserve(c, c->label, n));
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    {
+        // algorithmic bytes per pair: 8 (ij) + 3*8 (lb, ub, dad) + 2 (masks)
+        ProfScope ps(c, "bounds_dad_features", (double)n * 34.0);
+        k_features<<<ann_blocks(c->n, 256), 256, 0, c->stream>>>(c->ij.as<int2>(), c->n, c->Dt.as<double>(), c->nx, c->na,
+                                                                c->cA.as<int32_t>(), c->anchorRank.as<int32_t>(),
+                                                                c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>(),
+                                                                c->anc.as<uint8_t>(), c->ncm.as<uint8_t>());
+    }
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+    c->call_timed = true;
+    ANN_CHECK_HIP(c, hipGetLastError());
+    c->have_features = true;
+    c->have_RA = false;
+    c->nsamp = 0;
+    return ANNCHOR_OK;
+}
+
+// ------------------------------------------------------------ sampler support
+__global__ __launch_bounds__(256) void k_count_flags(const uint8_t *__restrict__ f, int64_t n, unsigned long long *out)
+{
+    unsigned long long s = 0;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) s += f[t] != 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+extern "C" int annchor_count_uncomputed(annchor_ctx *c, int64_t *n_unc)
+{
+    if (!c || !n_unc) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(ann_reserve(c, c->tmp2, 64));
+    ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp2.p, 0, 8, c->stream));
+    int blocks = min(ann_blocks(c->n, 256 * 16), c->prop.multiProcessorCount * 4);
+    k_count_flags<<<blocks, 256, 0, c->stream>>>(c->ncm.as<uint8_t>(), c->n, c->tmp2.as<unsigned long long>());
+    unsigned long long v = 0;
+    ANN_TRY(ann_d2h(c, &v, c->tmp2.p, 8));
+    *n_unc = (int64_t)v;
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_kth_uncomputed_dad(annchor_ctx *c, const int64_t *ks, int32_t nk, double *out)
+{
+    if (!c || !ks || !out) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    return ann_kth_smallest(c, c->dad.as<double>(), c->ncm.as<uint8_t>(), c->n, ks, nk, out);
+}
+
+#define MAXBINS 64
+struct BinEdges {
+    double e[MAXBINS + 1];
+    int nb;
+};
+
+// sampler bin: lo <= x < hi   (utils.py:547-549); -1 if none
+__device__ __forceinline__ int sampler_bin(const BinEdges &b, double x)
+{
+    for (int k = 0; k < b.nb; ++k)
+        if (x >= b.e[k] && x < b.e[k + 1]) return k;
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void k_bin_counts(const double *__restrict__ dad, const uint8_t *__restrict__ ncm,
+                                                   int64_t n, BinEdges be, unsigned long long *__restrict__ counts)
+{
+    __shared__ unsigned int lc[MAXBINS];
+    for (int t = threadIdx.x; t < MAXBINS; t += blockDim.x) lc[t] = 0;
+    __syncthreads();
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        if (!ncm[t]) continue;
+        int b = sampler_bin(be, dad[t]);
+        if (b >= 0) atomicAdd(&lc[b], 1u);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < be.nb; t += blockDim.x)
+        if (lc[t]) atomicAdd(&counts[t], (unsigned long long)lc[t]);
+}
+
+static int load_bins(annchor_ctx *c, const double *bins, int32_t nbins, BinEdges &be)
+{
+    ANN_REQUIRE(c, nbins >= 1 && nbins <= MAXBINS, ANNCHOR_ELIMIT, "1..%d partitions supported", MAXBINS);
+    be.nb = nbins;
+    for (int k = 0; k <= nbins; ++k) be.e[k] = bins[k];
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_bin_counts(annchor_ctx *c, const double *bins, int32_t nbins, int64_t *counts)
+{
+    if (!c || !bins || !counts) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    BinEdges be;
+    ANN_TRY(load_bins(c, bins, nbins, be));
+    ANN_TRY(ann_reserve(c, c->tmp2, 8 * MAXBINS));
+    ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp2.p, 0, 8 * MAXBINS, c->stream));
+    int blocks = min(ann_blocks(c->n, 256 * 8), c->prop.multiProcessorCount * 4);
+    {
+        ProfScope ps(c, "sampler_bin_counts", (double)c->n * 9.0);
+        k_bin_counts<<<blocks, 256, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), c->n, be,
+                                                   c->tmp2.as<unsigned long long>());
+    }
+    return ann_d2h(c, counts, c->tmp2.p, 8 * (size_t)nbins);
+}
+
+// ---- rank-in-bin selection: a blocked scan of per-bin membership counts
+#define RB_THREADS 256
+#define RB_ITEMS 8
+#define RB_TILE (RB_THREADS * RB_ITEMS)
+
+__global__ __launch_bounds__(RB_THREADS) void k_rb_count(const double *__restrict__ dad, const uint8_t *__restrict__ ncm,
+                                                        int64_t n, BinEdges be, uint32_t *__restrict__ blkcnt)
+{
+    __shared__ unsigned int lc[MAXBINS];
+    for (int t = threadIdx.x; t < MAXBINS; t += blockDim.x) lc[t] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * RB_TILE;
+    for (int k = 0; k < RB_ITEMS; ++k) {
+        int64_t t = base + (int64_t)k * RB_THREADS + threadIdx.x;
+        if (t < n && ncm[t]) {
+            int b = sampler_bin(be, dad[t]);
+            if (b >= 0) atomicAdd(&lc[b], 1u);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < be.nb; t += blockDim.x) blkcnt[(size_t)blockIdx.x * be.nb + t] = lc[t];
+}
+
+__global__ void k_rb_scan(uint32_t *__restrict__ blkcnt, int nblocks, int nb)
+{
+    // thread b scans bin b over the blocks (nblocks is a few hundred)
+    int b = threadIdx.x;
+    if (b >= nb) return;
+    uint32_t run = 0;
+    for (int k = 0; k < nblocks; ++k) {
+        uint32_t v = blkcnt[(size_t)k * nb + b];
+        blkcnt[(size_t)k * nb + b] = run;
+        run += v;
+    }
+}
+
+// slotmap[binbase[b] + rank] = request slot or -1.  One wave per tile keeps the
+// in-tile order (position order) with ballots; tiles are RB_TILE long.
+__global__ __launch_bounds__(64) void k_rb_emit(const double *__restrict__ dad, const uint8_t *__restrict__ ncm, int64_t n,
+                                               BinEdges be, const uint32_t *__restrict__ blkoff,
+                                               const int64_t *__restrict__ binbase, const int32_t *__restrict__ slotmap,
+                                               int64_t *__restrict__ positions)
+{
+    const int lane = threadIdx.x;
+    // lane k carries the running count of bin k (nb <= 64)
+    uint32_t myrun = lane < be.nb ? blkoff[(size_t)blockIdx.x * be.nb + lane] : 0u;
+    int64_t base = (int64_t)blockIdx.x * RB_TILE;
+    for (int64_t t0 = base; t0 < base + RB_TILE && t0 < n; t0 += 64) {
+        int64_t t = t0 + lane;
+        int b = -1;
+        if (t < n && ncm[t]) b = sampler_bin(be, dad[t]);
+        for (int k = 0; k < be.nb; ++k) {
+            unsigned long long m = __ballot(b == k);
+            if (!m) continue;
+            const uint32_t rk = __shfl(myrun, k);
+            if (b == k) {
+                uint32_t r = rk + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                int32_t slot = slotmap[binbase[k] + r];
+                if (slot >= 0) positions[slot] = t;
+            }
+            if (lane == k) myrun += (uint32_t)__popcll(m);
+        }
+    }
+}
+
+__global__ void k_scatter_slots(const int32_t *__restrict__ bin_of, const int64_t *__restrict__ ranks, int64_t nreq,
+                                const int64_t *__restrict__ binbase, int32_t *__restrict__ slotmap)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nreq) slotmap[binbase[bin_of[t]] + ranks[t]] = (int32_t)t;
+}
+
+extern "C" int annchor_select_by_rank(annchor_ctx *c, const double *bins, int32_t nbins, const int32_t *bin_of,
+                                      const int64_t *ranks, int64_t nreq, int64_t *positions)
+{
+    if (!c || !bins || (nreq > 0 && (!bin_of || !ranks || !positions))) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    if (nreq == 0) return ANNCHOR_OK;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    BinEdges be;
+    ANN_TRY(load_bins(c, bins, nbins, be));
+    const int64_t n = c->n;
+    const int nblocks = ann_blocks(n, RB_TILE);
+    // per-bin totals (host needs them to lay out the slot map)
+    std::vector<int64_t> counts((size_t)nbins), base((size_t)nbins + 1, 0);
+    ANN_TRY(annchor_bin_counts(c, bins, nbins, counts.data()));
+    for (int b = 0; b < nbins; ++b) base[(size_t)b + 1] = base[(size_t)b] + counts[(size_t)b];
+    for (int64_t t = 0; t < nreq; ++t) {
+        ANN_REQUIRE(c, bin_of[t] >= 0 && bin_of[t] < nbins, ANNCHOR_EINVAL, "bin index out of range");
+        ANN_REQUIRE(c, ranks[t] >= 0 && ranks[t] < counts[(size_t)bin_of[t]], ANNCHOR_EINVAL, "rank %lld outside bin %d (size %lld)",
+                    (long long)ranks[t], bin_of[t], (long long)counts[(size_t)bin_of[t]]);
+    }
+    const int64_t total = base[(size_t)nbins];
+    ANN_TRY(ann_reserve(c, c->blk_cnt, sizeof(uint32_t) * (size_t)nblocks * nbins));
+    ANN_TRY(ann_reserve(c, c->tmp0, sizeof(int32_t) * (size_t)(total + 1)));  // slotmap
+    ANN_TRY(ann_reserve(c, c->tmp1, sizeof(int64_t) * (size_t)(nbins + 1)));  // binbase
+    ANN_TRY(ann_reserve(c, c->stage_in, (sizeof(int32_t) + sizeof(int64_t)) * (size_t)nreq + 64));
+    ANN_TRY(ann_reserve(c, c->stage_out, sizeof(int64_t) * (size_t)nreq));
+    int64_t *d_ranks = c->stage_in.as<int64_t>();
+    int32_t *d_binof = reinterpret_cast<int32_t *>(d_ranks + nreq);
+    ANN_TRY(ann_h2d(c, d_ranks, ranks, sizeof(int64_t) * (size_t)nreq));
+    ANN_TRY(ann_h2d(c, d_binof, bin_of, sizeof(int32_t) * (size_t)nreq));
+    ANN_TRY(ann_h2d(c, c->tmp1.p, base.data(), sizeof(int64_t) * (size_t)(nbins + 1)));
+    ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp0.p, 0xff, sizeof(int32_t) * (size_t)(total + 1), c->stream));
+    ANN_CHECK_HIP(c, hipMemsetAsync(c->stage_out.p, 0xff, sizeof(int64_t) * (size_t)nreq, c->stream));
+    {
+        ProfScope ps(c, "sampler_select_by_rank", (double)n * 18.0);
+        k_scatter_slots<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(d_binof, d_ranks, nreq, c->tmp1.as<int64_t>(),
+                                                                     c->tmp0.as<int32_t>());
+        k_rb_count<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be,
+                                                         c->blk_cnt.as<uint32_t>());
+        k_rb_scan<<<1, MAXBINS, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nblocks, nbins);
+        k_rb_emit<<<nblocks, 64, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be, c->blk_cnt.as<uint32_t>(),
+                                                c->tmp1.as<int64_t>(), c->tmp0.as<int32_t>(), c->stage_out.as<int64_t>());
+    }
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ann_d2h(c, positions, c->stage_out.p, sizeof(int64_t) * (size_t)nreq);
+}
+
+// ------------------------------------------------------------ sample plumbing
+__global__ void k_gather_features(const int32_t *__restrict__ pos, int64_t m, const double *__restrict__ lb,
+                                  const double *__restrict__ ub, const double *__restrict__ dad,
+                                  const uint8_t *__restrict__ anc, double *__restrict__ out)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    int32_t p = pos[t];
+    out[4 * t + 0] = lb[p];
+    out[4 * t + 1] = ub[p];
+    out[4 * t + 2] = dad[p];
+    out[4 * t + 3] = (double)anc[p];
+}
+
+static int upload_positions(annchor_ctx *c, const int64_t *pos, int64_t m, DevBuf &dst)
+{
+    std::vector<int32_t> p32((size_t)m);
+    for (int64_t t = 0; t < m; ++t) {
+        ANN_REQUIRE(c, pos[t] >= 0 && pos[t] < c->n, ANNCHOR_EINVAL, "pair position %lld out of range", (long long)pos[t]);
+        p32[(size_t)t] = (int32_t)pos[t];
+    }
+    ANN_TRY(ann_reserve(c, dst, sizeof(int32_t) * (size_t)m));
+    return ann_h2d(c, dst.p, p32.data(), sizeof(int32_t) * (size_t)m);
+}
+
+extern "C" int annchor_gather_features(annchor_ctx *c, const int64_t *pos, int64_t m, double *feats)
+{
+    if (!c || (m > 0 && (!pos || !feats))) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    if (m == 0) return ANNCHOR_OK;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(upload_positions(c, pos, m, c->tmp3));
+    ANN_TRY(ann_reserve(c, c->stage_out, sizeof(double) * 4 * (size_t)m));
+    k_gather_features<<<ann_blocks(m, 256), 256, 0, c->stream>>>(c->tmp3.as<int32_t>(), m, c->lb.as<double>(),
+                                                                c->ub.as<double>(), c->dad.as<double>(),
+                                                                c->anc.as<uint8_t>(), c->stage_out.as<double>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ann_d2h(c, feats, c->stage_out.p, sizeof(double) * 4 * (size_t)m);
+}
+
+__global__ void k_clear_flags(const int32_t *__restrict__ pos, int64_t m, uint8_t *__restrict__ ncm)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m) ncm[pos[t]] = 0;
+}
+
+extern "C" int annchor_evaluate_samples(annchor_ctx *c, const int64_t *pos, int64_t m, double *sample_y)
+{
+    if (!c || (m > 0 && (!pos || !sample_y))) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_REQUIRE(c, c->metric != ANNCHOR_METRIC_NONE, ANNCHOR_EINVAL, "no device metric bound to this context");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(upload_positions(c, pos, m, c->spos));
+    ANN_TRY(ann_reserve(c, c->sy, sizeof(double) * (size_t)m));
+    c->nsamp = m;
+    if (m == 0) return ANNCHOR_OK;
+    PairSource src;
+    src.ij = c->ij.as<int2>();
+    src.idx = c->spos.as<int32_t>();
+    src.n = m;
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    ANN_TRY(ann_metric_launch(c, src, c->sy.as<double>(), nullptr, nullptr));
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+    c->call_timed = true;
+    k_clear_flags<<<ann_blocks(m, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), m, c->ncm.as<uint8_t>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ann_d2h(c, sample_y, c->sy.p, sizeof(double) * (size_t)m);
+}
+
+extern "C" int annchor_set_samples(annchor_ctx *c, const int64_t *pos, int64_t m, const double *sample_y)
+{
+    if (!c || (m > 0 && (!pos || !sample_y))) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(upload_positions(c, pos, m, c->spos));
+    ANN_TRY(ann_reserve(c, c->sy, sizeof(double) * (size_t)m));
+    ANN_TRY(ann_h2d(c, c->sy.p, sample_y, sizeof(double) * (size_t)m));
+    c->nsamp = m;
+    if (m > 0) k_clear_flags<<<ann_blocks(m, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), m, c->ncm.as<uint8_t>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
+// ------------------------------------------------- predict / clip / label / merge
+struct RegModel {
+    double e[MAXBINS + 1];
+    double w[MAXBINS][3];
+    double c[MAXBINS];
+    int nb;
+};
+
+__device__ __forceinline__ double reg_predict(const RegModel &m, double l, double u, double d)
+{
+    // regression bin: lo < F <= hi (regressors.py:84-87); pairs outside every bin keep 0
+    int b = -1;
+    for (int k = 0; k < m.nb; ++k)
+        if (d > m.e[k] && d <= m.e[k + 1]) b = k;
+    if (b < 0) return 0.0;
+    return ((m.w[b][0] * l + m.w[b][1] * u) + m.w[b][2] * d) + m.c[b];
+}
+
+__device__ __forceinline__ int err_label(const RegModel &m, double d)
+{
+    // error bins: lo <= F <= hi, later bins overwrite (error_predictors.py:61-66)
+    int b = -1;
+    for (int k = 0; k < m.nb; ++k)
+        if (d >= m.e[k] && d <= m.e[k + 1]) b = k;
+    return b;
+}
+
+__global__ __launch_bounds__(256) void k_predict_merge(int64_t n, RegModel m, int first, int is_metric,
+                                                      const int2 *__restrict__ ij, const double *__restrict__ Dt,
+                                                      int64_t nx, const int32_t *__restrict__ anchorRank,
+                                                      const double *__restrict__ lb, const double *__restrict__ ub,
+                                                      const double *__restrict__ dad, const uint8_t *__restrict__ anc,
+                                                      const uint8_t *__restrict__ ncm, double *__restrict__ RA,
+                                                      uint8_t *__restrict__ label)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const double l = lb[p], u = ub[p], d = dad[p];
+    double pr = reg_predict(m, l, u, d);
+    pr = fmin(fmax(pr, l), u);  // np.clip(pred, lb, ub)
+    if (!is_metric && anc[p]) {
+        // annchor.py:368-372: anchor pairs take their exact value from D; a later
+        // anchor in A overrides an earlier one
+        const int2 q = ij[p];
+        const int ri = anchorRank[q.x], rj = anchorRank[q.y];
+        pr = (ri > rj) ? Dt[(size_t)ri * nx + q.y] : Dt[(size_t)rj * nx + q.x];
+    }
+    if (first || ncm[p]) RA[p] = pr;
+    const int lbl = err_label(m, d);
+    label[p] = (uint8_t)(lbl < 0 ? 255 : lbl);
+}
+
+__global__ void k_sample_predict_scatter(const int32_t *__restrict__ pos, const double *__restrict__ sy, int64_t ms,
+                                         RegModel m, const double *__restrict__ lb, const double *__restrict__ ub,
+                                         const double *__restrict__ dad, double *__restrict__ RA,
+                                         double *__restrict__ spred)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ms) return;
+    const int32_t p = pos[t];
+    spred[t] = reg_predict(m, lb[p], ub[p], dad[p]);  // unclipped (annchor.py:357)
+    RA[p] = sy[t];                                    // annchor.py:380
+}
+
+extern "C" int annchor_predict_merge(annchor_ctx *c, const double *bins, int32_t nb, const double *W, const double *cc,
+                                     int32_t first_iteration, int32_t is_metric, double *sample_predict)
+{
+    if (!c || !bins || !W || !cc) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_REQUIRE(c, nb >= 1 && nb <= MAXBINS, ANNCHOR_ELIMIT, "1..%d partitions supported", MAXBINS);
+    ANN_REQUIRE(c, first_iteration || c->have_RA, ANNCHOR_EINVAL, "RefineApprox not initialised");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    RegModel m;
+    m.nb = nb;
+    for (int k = 0; k <= nb; ++k) m.e[k] = bins[k];
+    for (int k = 0; k < nb; ++k) {
+        m.w[k][0] = W[3 * k]; m.w[k][1] = W[3 * k + 1]; m.w[k][2] = W[3 * k + 2];
+        m.c[k] = cc[k];
+    }
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    {
+        // algorithmic bytes per pair: 3*8 read (lb, ub, dad) + 1 (mask) + 8 (RA) + 1 (label)
+        ProfScope ps(c, "predict_clip_label_merge", (double)c->n * 34.0);
+        k_predict_merge<<<ann_blocks(c->n, 256), 256, 0, c->stream>>>(
+            c->n, m, first_iteration, is_metric, c->ij.as<int2>(), c->Dt.as<double>(), c->nx, c->anchorRank.as<int32_t>(),
+            c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>(), c->anc.as<uint8_t>(), c->ncm.as<uint8_t>(),
+            c->RA.as<double>(), c->label.as<uint8_t>());
+    }
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+    c->call_timed = true;
+    c->have_RA = true;
+    if (c->nsamp > 0) {
+        ANN_TRY(ann_reserve(c, c->stage_out, sizeof(double) * (size_t)c->nsamp));
+        k_sample_predict_scatter<<<ann_blocks(c->nsamp, 256), 256, 0, c->stream>>>(
+            c->spos.as<int32_t>(), c->sy.as<double>(), c->nsamp, m, c->lb.as<double>(), c->ub.as<double>(),
+            c->dad.as<double>(), c->RA.as<double>(), c->stage_out.as<double>());
+        ANN_CHECK_HIP(c, hipGetLastError());
+        if (sample_predict) ANN_TRY(ann_d2h(c, sample_predict, c->stage_out.p, sizeof(double) * (size_t)c->nsamp));
+    }
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
+__global__ __launch_bounds__(256) void k_merge_host_pred(int64_t n, const double *__restrict__ pred, int first,
+                                                        int is_metric, const int2 *__restrict__ ij,
+                                                        const double *__restrict__ Dt, int64_t nx,
+                                                        const int32_t *__restrict__ anchorRank,
+                                                        const double *__restrict__ lb, const double *__restrict__ ub,
+                                                        const uint8_t *__restrict__ anc, const uint8_t *__restrict__ ncm,
+                                                        double *__restrict__ RA)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    double pr = fmin(fmax(pred[p], lb[p]), ub[p]);
+    if (!is_metric && anc[p]) {
+        const int2 q = ij[p];
+        const int ri = anchorRank[q.x], rj = anchorRank[q.y];
+        pr = (ri > rj) ? Dt[(size_t)ri * nx + q.y] : Dt[(size_t)rj * nx + q.x];
+    }
+    if (first || ncm[p]) RA[p] = pr;
+}
+
+__global__ void k_scatter_f64(const int32_t *__restrict__ pos, const double *__restrict__ v, int64_t m, double *__restrict__ dst)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m) dst[pos[t]] = v[t];
+}
+
+extern "C" int annchor_merge_host_prediction(annchor_ctx *c, const double *pred, int32_t first_iteration, int32_t is_metric)
+{
+    if (!c || !pred) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_REQUIRE(c, first_iteration || c->have_RA, ANNCHOR_EINVAL, "RefineApprox not initialised");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(ann_reserve(c, c->stage_in, sizeof(double) * (size_t)c->n));
+    ANN_TRY(ann_h2d(c, c->stage_in.p, pred, sizeof(double) * (size_t)c->n));
+    k_merge_host_pred<<<ann_blocks(c->n, 256), 256, 0, c->stream>>>(
+        c->n, c->stage_in.as<double>(), first_iteration, is_metric, c->ij.as<int2>(), c->Dt.as<double>(), c->nx,
+        c->anchorRank.as<int32_t>(), c->lb.as<double>(), c->ub.as<double>(), c->anc.as<uint8_t>(), c->ncm.as<uint8_t>(),
+        c->RA.as<double>());
+    if (c->nsamp > 0)
+        k_scatter_f64<<<ann_blocks(c->nsamp, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), c->sy.as<double>(), c->nsamp,
+                                                                       c->RA.as<double>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    c->have_RA = true;
+    return ANNCHOR_OK;
+}
+
+__global__ void k_labels_from_i64(const int64_t *__restrict__ in, int64_t n, uint8_t *__restrict__ out)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = (in[t] >= 0 && in[t] < 255) ? (uint8_t)in[t] : (uint8_t)255;
+}
+
+extern "C" int annchor_set_labels(annchor_ctx *c, const int64_t *labels)
+{
+    if (!c || !labels) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(ann_reserve(c, c->stage_in, sizeof(int64_t) * (size_t)c->n));
+    ANN_TRY(ann_h2d(c, c->stage_in.p, labels, sizeof(int64_t) * (size_t)c->n));
+    k_labels_from_i64<<<ann_blocks(c->n, 256), 256, 0, c->stream>>>(c->stage_in.as<int64_t>(), c->n, c->label.as<uint8_t>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}

@@ -1,0 +1,243 @@
+// locality.hip -- candidate-pair generation (permutation / shared-nearest-anchor prefilter).
+//
+// Replaces Annchor.get_locality (reference annchor/annchor.py:208-256) with
+// get_check / adjust_check / create_IJs / get_IJs_from_check
+// (annchor/utils.py:437-540) and check_locality_size (utils.py:592-597).
+//
+// The reference materialises a dense one-hot matrix and Python dicts; here
+//   * sid[i]   = the `locality` nearest anchors of point i as a 64-bit mask
+//                (ties resolve to the smaller anchor index),
+//   * c_ij     = popcount(sid[i] & sid[j])            (= sum(A[sid[i], :])[j]),
+//   * thr_i    = min(loc_thresh, (loc_min+1)-th largest c_i.)   (utils.py:472-480),
+//   * keep_ij  = c_ij >= min(thr_i, thr_j)            (adjust_check symmetrisation),
+// and keep is stored as a symmetric bitmap with per-word prefix counts, from which
+// the sorted pair list IJs and the CSR index I are written without atomics:
+// rank queries are O(1) popcounts.  I[i] lists pair positions by ascending other
+// endpoint (the reference's order inside a group is arbitrary -- unstable argsort).
+#include "common.h"
+
+__global__ void k_sid(const double *__restrict__ Dt, int64_t nx, int na, int locality, uint64_t *__restrict__ sid,
+                      int32_t *__restrict__ cA)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nx) return;
+    uint64_t mask = 0;
+    int first = 0;
+    for (int r = 0; r < locality; ++r) {
+        double best = INFINITY;
+        int ba = -1;
+        for (int a = 0; a < na; ++a) {
+            if ((mask >> a) & 1ull) continue;
+            double v = Dt[(size_t)a * nx + i];
+            if (ba < 0 || v < best) { best = v; ba = a; }  // strict <: smaller index wins ties
+        }
+        if (ba < 0) break;
+        if (r == 0) first = ba;
+        mask |= 1ull << ba;
+    }
+    sid[i] = mask;
+    cA[i] = first;  // np.argmin(D[i]) -- first minimal index (utils.py:375)
+}
+
+#define LOC_THREADS 256
+// one block per row: histogram of c_ij over all j, then the (loc_min+1)-th largest
+__global__ __launch_bounds__(LOC_THREADS) void k_loc_thresh(const uint64_t *__restrict__ sid, int64_t nx, int loc_thresh,
+                                                           int loc_min, int32_t *__restrict__ thr)
+{
+    __shared__ uint32_t hist[65];
+    for (int t = threadIdx.x; t < 65; t += blockDim.x) hist[t] = 0;
+    __syncthreads();
+    const int64_t i = blockIdx.x;
+    const uint64_t mi = sid[i];
+    for (int64_t j = threadIdx.x; j < nx; j += blockDim.x) atomicAdd(&hist[__popcll(mi & sid[j])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t lm = loc_min < nx - 1 ? loc_min : nx - 1;
+        int64_t cum = 0;
+        int v = 64;
+        for (; v >= 0; --v) {
+            cum += hist[v];
+            if (cum >= lm + 1) break;
+        }
+        if (v < 0) v = 0;
+        thr[i] = v < loc_thresh ? v : loc_thresh;
+    }
+}
+
+// thread per (row, 64-column word): keep bits
+__global__ void k_keep_bits(const uint64_t *__restrict__ sid, const int32_t *__restrict__ thr, int64_t nx, int kw,
+                            uint64_t *__restrict__ K)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nx * kw) return;
+    int64_t i = t / kw;
+    int w = (int)(t - i * kw);
+    const uint64_t mi = sid[i];
+    const int ti = thr[i];
+    uint64_t bits = 0;
+    int64_t j0 = (int64_t)w * 64;
+    for (int b = 0; b < 64; ++b) {
+        int64_t j = j0 + b;
+        if (j >= nx) break;
+        if (j == i) continue;
+        int cc = __popcll(mi & sid[j]);
+        int tj = thr[j];
+        if (cc >= (ti < tj ? ti : tj)) bits |= 1ull << b;
+    }
+    K[t] = bits;
+}
+
+// one block per row: exclusive prefix of popcounts over the row's words
+__global__ __launch_bounds__(LOC_THREADS) void k_row_prefix(const uint64_t *__restrict__ K, int64_t nx, int kw,
+                                                           uint32_t *__restrict__ pref, int32_t *__restrict__ deg,
+                                                           int32_t *__restrict__ low, int32_t *__restrict__ up)
+{
+    __shared__ uint32_t wsum[LOC_THREADS / 64];
+    __shared__ uint32_t carry_s;
+    const int64_t i = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < kw; base += LOC_THREADS) {
+        int w = base + threadIdx.x;
+        uint32_t v = w < kw ? (uint32_t)__popcll(K[i * kw + w]) : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t b = carry_s;
+        for (int ww = 0; ww < wave; ++ww) b += wsum[ww];
+        if (w < kw) pref[i * kw + w] = b + inc - v;
+        __syncthreads();
+        if (threadIdx.x == LOC_THREADS - 1) carry_s = b + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        uint32_t d = carry_s;
+        int wi = (int)(i >> 6);
+        uint32_t l = pref[i * kw + wi] + (uint32_t)__popcll(K[i * kw + wi] & ((1ull << (i & 63)) - 1ull));
+        deg[i] = (int32_t)d;
+        low[i] = (int32_t)l;
+        up[i] = (int32_t)(d - l);
+    }
+}
+
+__device__ __forceinline__ uint32_t keep_rank(const uint64_t *K, const uint32_t *pref, int kw, int64_t row, int64_t col)
+{
+    int w = (int)(col >> 6);
+    return pref[row * kw + w] + (uint32_t)__popcll(K[row * kw + w] & ((1ull << (col & 63)) - 1ull));
+}
+
+// thread per (row, word): emit pairs and the CSR index
+__global__ void k_emit_pairs(const uint64_t *__restrict__ K, const uint32_t *__restrict__ pref, int64_t nx, int kw,
+                             const int32_t *__restrict__ low, const int64_t *__restrict__ rowstart,
+                             const int64_t *__restrict__ Iptr, int2 *__restrict__ ij, int32_t *__restrict__ Iidx)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nx * kw) return;
+    int64_t i = t / kw;
+    int w = (int)(t - i * kw);
+    uint64_t bits = K[t];
+    uint32_t r = pref[t];
+    const int64_t ip = Iptr[i], rs = rowstart[i];
+    const int32_t li = low[i];
+    while (bits) {
+        int b = __ffsll((unsigned long long)bits) - 1;
+        bits &= bits - 1;
+        int64_t j = (int64_t)w * 64 + b;
+        int64_t pos;
+        if (j > i) {
+            pos = rs + ((int64_t)r - li);
+            ij[pos] = make_int2((int)i, (int)j);
+        } else {
+            pos = rowstart[j] + ((int64_t)keep_rank(K, pref, kw, j, i) - low[j]);
+        }
+        Iidx[ip + r] = (int32_t)pos;
+        ++r;
+    }
+}
+
+__global__ void k_min_i32(const int32_t *__restrict__ v, int64_t n, int32_t *__restrict__ out)
+{
+    // single block
+    int m = 0x7fffffff;
+    for (int64_t t = threadIdx.x; t < n; t += blockDim.x) m = min(m, v[t]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off));
+    __shared__ int s[16];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = min(m, s[w]);
+        *out = m;
+    }
+}
+
+extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t loc_thresh, int32_t loc_min,
+                                      int64_t *n_pairs, int64_t *min_row_len)
+{
+    if (!c || !n_pairs || !min_row_len) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->na > 0, ANNCHOR_EINVAL, "anchors not set");
+    ANN_REQUIRE(c, locality >= 1, ANNCHOR_EINVAL, "locality must be >= 1");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    const int64_t nx = c->nx;
+    const int kw = (int)((nx + 63) / 64);
+    ANN_REQUIRE(c, (double)nx * kw * 12.0 < 64e9, ANNCHOR_ELIMIT,
+                "nx=%lld is too large for the pair-list form (use the streamed form)", (long long)nx);
+    if (locality > c->na) locality = c->na;
+    ANN_TRY(ann_reserve(c, c->sid, sizeof(uint64_t) * (size_t)nx));
+    ANN_TRY(ann_reserve(c, c->cA, sizeof(int32_t) * (size_t)nx));
+    ANN_TRY(ann_reserve(c, c->thr, sizeof(int32_t) * (size_t)nx));
+    ANN_TRY(ann_reserve(c, c->Kbits, sizeof(uint64_t) * (size_t)nx * kw));
+    ANN_TRY(ann_reserve(c, c->Kpref, sizeof(uint32_t) * (size_t)nx * kw));
+    ANN_TRY(ann_reserve(c, c->deg, sizeof(int32_t) * (size_t)nx));
+    ANN_TRY(ann_reserve(c, c->low, sizeof(int32_t) * (size_t)nx));
+    ANN_TRY(ann_reserve(c, c->tmp1, sizeof(int32_t) * (size_t)nx));  // up[]
+    ANN_TRY(ann_reserve(c, c->rowstart, sizeof(int64_t) * (size_t)(nx + 1)));
+    ANN_TRY(ann_reserve(c, c->Iptr, sizeof(int64_t) * (size_t)(nx + 1)));
+    ANN_TRY(ann_reserve(c, c->tmp2, sizeof(int32_t) * 4));
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    {
+        ProfScope ps(c, "locality_sid", (double)nx * (c->na * 8.0 + 12));
+        k_sid<<<ann_blocks(nx, 256), 256, 0, c->stream>>>(c->Dt.as<double>(), nx, c->na, locality, c->sid.as<uint64_t>(),
+                                                         c->cA.as<int32_t>());
+    }
+    {
+        ProfScope ps(c, "locality_keep_bitmap", (double)nx * kw * 12.0);
+        k_loc_thresh<<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx, loc_thresh, loc_min,
+                                                            c->thr.as<int32_t>());
+        k_keep_bits<<<ann_blocks(nx * kw, 256), 256, 0, c->stream>>>(c->sid.as<uint64_t>(), c->thr.as<int32_t>(), nx, kw,
+                                                                    c->Kbits.as<uint64_t>());
+        k_row_prefix<<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->Kbits.as<uint64_t>(), nx, kw, c->Kpref.as<uint32_t>(),
+                                                            c->deg.as<int32_t>(), c->low.as<int32_t>(),
+                                                            c->tmp1.as<int32_t>());
+        k_min_i32<<<1, 1024, 0, c->stream>>>(c->deg.as<int32_t>(), nx, c->tmp2.as<int32_t>());
+    }
+    ANN_TRY(ann_exclusive_scan_i32_to_i64(c, c->tmp1.as<int32_t>(), c->rowstart.as<int64_t>(), nx));
+    ANN_TRY(ann_exclusive_scan_i32_to_i64(c, c->deg.as<int32_t>(), c->Iptr.as<int64_t>(), nx));
+    int64_t n = 0;
+    int32_t mn = 0;
+    ANN_TRY(ann_d2h(c, &n, c->rowstart.as<int64_t>() + nx, sizeof n));
+    ANN_TRY(ann_d2h(c, &mn, c->tmp2.p, sizeof mn));
+    ANN_REQUIRE(c, n < (1ll << 30), ANNCHOR_ELIMIT, "%lld candidate pairs exceed the pair-list limit", (long long)n);
+    ANN_TRY(ann_reserve(c, c->ij, sizeof(int2) * (size_t)n));
+    ANN_TRY(ann_reserve(c, c->Iidx, sizeof(int32_t) * 2 * (size_t)n));
+    {
+        ProfScope ps(c, "locality_emit_pairs", (double)n * 16 + (double)nx * kw * 12.0);
+        k_emit_pairs<<<ann_blocks(nx * kw, 256), 256, 0, c->stream>>>(
+            c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), nx, kw, c->low.as<int32_t>(), c->rowstart.as<int64_t>(),
+            c->Iptr.as<int64_t>(), c->ij.as<int2>(), c->Iidx.as<int32_t>());
+    }
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+    c->call_timed = true;
+    ANN_CHECK_HIP(c, hipGetLastError());
+    c->n = n;
+    c->have_features = c->have_RA = false;
+    *n_pairs = n;
+    *min_row_len = mn;
+    return ANNCHOR_OK;
+}

@@ -1,0 +1,73 @@
+// rowsel.h -- block-level selection helpers shared by select.hip and refine.hip.
+// One 256-thread block owns one row of the CSR index I; the row's float64 keys are
+// mapped to order-preserving uint64 and the k-th smallest is found by an MSB-first
+// 8-bit radix descent on an LDS histogram (exact, tie-safe, no sort).
+#pragma once
+#include "common.h"
+
+#define ROW_THREADS 256
+#define ROW_LDS_KEYS 6144  // rows up to this many entries keep their keys in LDS (48 KiB)
+
+struct RowSelShared {
+    uint32_t hist[256];
+    uint32_t wsum[ROW_THREADS / 64];
+    uint64_t prefix;
+    uint32_t k;
+    uint32_t digit;
+};
+
+// Exclusive prefix (in thread order) of `v` over the block; *total = block sum.
+__device__ __forceinline__ uint32_t row_block_scan(uint32_t v, uint32_t *wsum, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < ROW_THREADS / 64; ++w) {
+        if (w < wave) base += wsum[w];
+        tot += wsum[w];
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+// k-th smallest (0-based) key of the row.  KeyFn(s) returns the uint64 key of row
+// slot s (s in [0, len)).  All threads return the same key.  k is clamped to len-1.
+template <typename KeyFn> __device__ uint64_t row_kth_key(RowSelShared &sh, int len, uint32_t k, KeyFn key)
+{
+    if (k >= (uint32_t)len) k = (uint32_t)len - 1;
+    if (threadIdx.x == 0) { sh.prefix = 0; sh.k = k; }
+    __syncthreads();
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        const uint64_t himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+        sh.hist[threadIdx.x] = 0;  // ROW_THREADS == 256
+        __syncthreads();
+        const uint64_t pre = sh.prefix;
+        for (int s = threadIdx.x; s < len; s += ROW_THREADS) {
+            const uint64_t kk = key(s);
+            if ((kk & himask) == pre) atomicAdd(&sh.hist[(uint32_t)(kk >> shift) & 0xffu], 1u);
+        }
+        __syncthreads();
+        const uint32_t h = sh.hist[threadIdx.x];
+        uint32_t tot;
+        const uint32_t ex = row_block_scan(h, sh.wsum, &tot);
+        const uint32_t kk = sh.k;
+        __syncthreads();
+        if (h != 0 && kk >= ex && kk < ex + h) {
+            sh.digit = threadIdx.x;
+            sh.k = kk - ex;
+            sh.prefix = pre | ((uint64_t)threadIdx.x << shift);
+        }
+        __syncthreads();
+    }
+    return sh.prefix;
+}

@@ -1,0 +1,514 @@
+// select.hip -- candidate selection for refinement.
+//
+// Replaces Annchor.select_refine_candidate_pairs (reference annchor/annchor.py:395-473)
+// with guarantee_nmin / argpartition (annchor/utils.py:600-621) and get_probs
+// (annchor/utils.py:581-589):
+//   thresh[i]  = value at sorted position n_neighbors of RefineApprox[I[i]]
+//   guarantee_nmin (first iteration): rows with too few computed pairs force their
+//                best not-computed pairs to RefineApprox = -1
+//   p          = max(thresh[i], thresh[j]) - RefineApprox      on not-computed pairs
+//   prob       = searchsorted(errs[label], p, 'left') / len(errs[label])
+//   candidates = top n_refine by prob, next = the following n_refine*(lookahead-1)
+// Tie rule (the reference's np.argpartition is arbitrary inside tie groups):
+// (prob descending, pair position ascending).
+//
+// guarantee_nmin is sequential over rows in the reference (row i sees the -1 marks
+// left by rows < i).  Here the expensive part -- each row's nmin+1 smallest
+// not-computed entries -- is computed for all rows in parallel; the sequential
+// sweep that remains touches nmin+1 entries per row and runs in a single wavefront.
+#include "common.h"
+#include "rowsel.h"
+
+// ------------------------------------------------------------------- thresholds
+__global__ __launch_bounds__(ROW_THREADS) void k_row_thresh(const int64_t *__restrict__ Iptr, const int32_t *__restrict__ Iidx,
+                                                           const double *__restrict__ RA, uint32_t k,
+                                                           double *__restrict__ thresh)
+{
+    __shared__ RowSelShared sh;
+    __shared__ uint64_t keys[ROW_LDS_KEYS];
+    const int64_t i = blockIdx.x;
+    const int64_t b = Iptr[i];
+    const int len = (int)(Iptr[i + 1] - b);
+    if (len <= 0) { if (threadIdx.x == 0) thresh[i] = INFINITY; return; }
+    uint64_t res;
+    if (len <= ROW_LDS_KEYS) {
+        for (int s = threadIdx.x; s < len; s += ROW_THREADS) keys[s] = ann_key_asc(RA[Iidx[b + s]]);
+        __syncthreads();
+        res = row_kth_key(sh, len, k, [&](int s) { return keys[s]; });
+    } else {
+        res = row_kth_key(sh, len, k, [&](int s) { return ann_key_asc(RA[Iidx[b + s]]); });
+    }
+    if (threadIdx.x == 0) thresh[i] = ann_key_asc_inv(res);
+}
+
+// -------------------------------------------------------------- guarantee_nmin
+// per row: number of computed entries and the L smallest not-computed entries
+// sorted by (value, slot)
+__global__ __launch_bounds__(ROW_THREADS) void k_gn_lists(const int64_t *__restrict__ Iptr, const int32_t *__restrict__ Iidx,
+                                                         const double *__restrict__ RA, const uint8_t *__restrict__ ncm,
+                                                         int L, double *__restrict__ gl_val, int32_t *__restrict__ gl_pos,
+                                                         int32_t *__restrict__ gl_cnt, int32_t *__restrict__ gl_ncomp)
+{
+    __shared__ RowSelShared sh;
+    __shared__ uint64_t keys[ROW_LDS_KEYS];
+    __shared__ uint32_t cnt_lt, n_unc_s;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    uint64_t *lkey = reinterpret_cast<uint64_t *>(dyn);       // [L]
+    int32_t *lslot = reinterpret_cast<int32_t *>(lkey + L);   // [L]
+    const int64_t i = blockIdx.x;
+    const int64_t b = Iptr[i];
+    const int len = (int)(Iptr[i + 1] - b);
+    const bool in_lds = len <= ROW_LDS_KEYS;
+    const uint64_t KINF = ~0ull;  // computed entries sort last
+    auto key_of = [&](int s) -> uint64_t {
+        const int32_t p = Iidx[b + s];
+        return ncm[p] ? ann_key_asc(RA[p]) : KINF;
+    };
+    if (threadIdx.x == 0) { cnt_lt = 0; n_unc_s = 0; }
+    __syncthreads();
+    uint32_t my_unc = 0;
+    for (int s = threadIdx.x; s < len; s += ROW_THREADS) {
+        const uint64_t kk = key_of(s);
+        if (in_lds) keys[s] = kk;
+        my_unc += kk != KINF;
+    }
+    if (my_unc) atomicAdd(&n_unc_s, my_unc);
+    __syncthreads();
+    const int n_unc = (int)n_unc_s;
+    const int want = min(L, n_unc);
+    if (threadIdx.x == 0) { gl_cnt[i] = want; gl_ncomp[i] = len - n_unc; }
+    if (want == 0) return;
+    auto kf = [&](int s) -> uint64_t { return in_lds ? keys[s] : key_of(s); };
+    const uint64_t t = row_kth_key(sh, len, (uint32_t)(want - 1), kf);
+    // strictly smaller entries (at most want-1 of them), any order
+    for (int s = threadIdx.x; s < len; s += ROW_THREADS) {
+        const uint64_t kk = kf(s);
+        if (kk < t) {
+            const uint32_t o = atomicAdd(&cnt_lt, 1u);
+            lkey[o] = kk; lslot[o] = s;
+        }
+    }
+    __syncthreads();
+    const uint32_t nlt = cnt_lt;
+    // entries equal to t, in slot order, until the list is full
+    uint32_t run = nlt;
+    for (int base = 0; base < len && run < (uint32_t)want; base += ROW_THREADS) {
+        const int s = base + threadIdx.x;
+        const uint32_t f = (s < len && kf(s) == t) ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t ex = row_block_scan(f, sh.wsum, &tot);
+        if (f && run + ex < (uint32_t)want) { lkey[run + ex] = t; lslot[run + ex] = s; }
+        run += tot;
+        __syncthreads();
+    }
+    __syncthreads();
+    // rank sort by (key, slot)
+    for (int e = threadIdx.x; e < want; e += ROW_THREADS) {
+        const uint64_t ke = lkey[e];
+        const int32_t se = lslot[e];
+        int r = 0;
+        for (int o = 0; o < want; ++o) r += (lkey[o] < ke) || (lkey[o] == ke && lslot[o] < se);
+        gl_val[i * L + r] = ann_key_asc_inv(ke);
+        gl_pos[i * L + r] = Iidx[b + se];
+    }
+}
+
+__device__ __forceinline__ uint8_t ld_u8_agent(const uint8_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t ld_i32_agent(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// single wavefront, sequential over rows (utils.py:611-619)
+__global__ __launch_bounds__(64) void k_gn_sequential(int64_t nx, int nmin, int L, const double *__restrict__ gl_val,
+                                                     const int32_t *__restrict__ gl_pos, const int32_t *__restrict__ gl_cnt,
+                                                     const int32_t *__restrict__ gl_ncomp, const int2 *__restrict__ ij,
+                                                     double *__restrict__ RA, uint8_t *__restrict__ marked,
+                                                     int32_t *__restrict__ markcount, int32_t *__restrict__ err)
+{
+    const int lane = threadIdx.x;
+    for (int64_t i = 0; i < nx; ++i) {
+        const int ntodo = nmin - gl_ncomp[i];
+        if (ntodo <= 0) continue;
+        const int cnt = gl_cnt[i];
+        // the reference's np.partition(a, n_todo) needs n_todo < len(a)
+        if (cnt <= ntodo && cnt < L) { if (lane == 0) *err = 1; continue; }
+        const int need = ntodo + 1 - ld_i32_agent(&markcount[i]);
+        if (need <= 0) continue;
+        // value of the need-th smallest not-yet-marked entry
+        double t = 0;
+        bool found = false;
+        int cum = 0;
+        for (int base = 0; base < cnt && !found; base += 64) {
+            const int e = base + lane;
+            const bool valid = e < cnt;
+            const double v = valid ? gl_val[i * L + e] : 0.0;
+            const int32_t p = valid ? gl_pos[i * L + e] : 0;
+            const bool um = valid && !ld_u8_agent(&marked[p]);
+            const unsigned long long m = __ballot(um);
+            const int cmask = __popcll(m);
+            if (cum + cmask >= need) {
+                const int want = need - cum - 1;  // 0-based rank inside this chunk
+                const int myrank = __popcll(m & ((1ull << lane) - 1ull));
+                const unsigned long long hit = __ballot(um && myrank == want);
+                const int src = __ffsll((unsigned long long)hit) - 1;
+                t = __shfl(v, src);
+                found = true;
+            }
+            cum += cmask;
+        }
+        if (!found) { if (lane == 0) *err = 2; continue; }
+        for (int base = 0; base < cnt; base += 64) {
+            const int e = base + lane;
+            if (e < cnt) {
+                const double v = gl_val[i * L + e];
+                const int32_t p = gl_pos[i * L + e];
+                if (v < t && !ld_u8_agent(&marked[p])) {
+                    RA[p] = -1.0;
+                    __hip_atomic_store(&marked[p], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int2 q = ij[p];
+                    const int other = q.x == (int)i ? q.y : q.x;
+                    atomicAdd(&markcount[other], 1);
+                }
+            }
+        }
+        // the marks of this row must be visible (in L2) before the next row reads them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+// -------------------------------------------------------------------- ECDF prob
+__global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict__ ij, const double *__restrict__ thresh,
+                                             const double *__restrict__ RA, const uint8_t *__restrict__ ncm,
+                                             const uint8_t *__restrict__ label, const double *__restrict__ errs,
+                                             const int64_t *__restrict__ errptr, int nlabels, int errs_in_lds,
+                                             double *__restrict__ prob)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    double *le = reinterpret_cast<double *>(dyn);
+    __shared__ int64_t lptr[257];
+    for (int t = threadIdx.x; t <= nlabels; t += blockDim.x) lptr[t] = errptr[t];
+    __syncthreads();
+    if (errs_in_lds) {
+        const int64_t tot = lptr[nlabels];
+        for (int64_t t = threadIdx.x; t < tot; t += blockDim.x) le[t] = errs[t];
+        __syncthreads();
+    }
+    const double *E = errs_in_lds ? le : errs;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        double pr = -1.0;
+        if (ncm[p]) {
+            const int2 q = ij[p];
+            const double pv = fmax(thresh[q.x], thresh[q.y]) - RA[p];
+            const int lb = label[p];
+            if (lb < nlabels) {
+                const int64_t b = lptr[lb], e = lptr[lb + 1];
+                // searchsorted(side='left'): number of entries < pv
+                int64_t lo = b, hi = e;
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (E[mid] < pv) lo = mid + 1; else hi = mid;
+                }
+                pr = (double)(lo - b) / (double)(e - b);
+            } else {
+                pr = 0.0;
+            }
+        }
+        prob[p] = pr;
+    }
+}
+
+// ----------------------------------------------------- top-K split + compaction
+#define CP_THREADS 256
+#define CP_ITEMS 8
+#define CP_TILE (CP_THREADS * CP_ITEMS)
+
+struct CutState {
+    double t1, t5;          // cut values (prob of the K1-th / K5-th largest)
+    int64_t K1, K5;         // requested counts
+    int64_t e1, e5;         // how many entries equal to the cut are taken
+    int64_t ncand, nnext;
+    int all1, all5;         // take every not-computed pair
+};
+
+__global__ __launch_bounds__(CP_THREADS) void k_cut_count(const double *__restrict__ prob, int64_t n,
+                                                         const CutState *__restrict__ cs, uint32_t *__restrict__ blk)
+{
+    __shared__ uint32_t acc[4];
+    if (threadIdx.x < 4) acc[threadIdx.x] = 0;
+    __syncthreads();
+    const double t1 = cs->t1, t5 = cs->t5;
+    uint32_t g1 = 0, q1 = 0, g5 = 0, q5 = 0;
+    const int64_t base = (int64_t)blockIdx.x * CP_TILE;
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        const int64_t p = base + (int64_t)k * CP_THREADS + threadIdx.x;
+        if (p < n) {
+            const double v = prob[p];
+            if (v >= 0.0) { g1 += v > t1; q1 += v == t1; g5 += v > t5; q5 += v == t5; }
+        }
+    }
+    atomicAdd(&acc[0], g1); atomicAdd(&acc[1], q1); atomicAdd(&acc[2], g5); atomicAdd(&acc[3], q5);
+    __syncthreads();
+    if (threadIdx.x < 4) blk[(size_t)blockIdx.x * 4 + threadIdx.x] = acc[threadIdx.x];
+}
+
+// single block: totals, then per-tile offsets {eq1 prefix, eq5 prefix, cand offset, next offset}
+__global__ __launch_bounds__(CP_THREADS) void k_cut_scan(uint32_t *__restrict__ blk, int nb, CutState *__restrict__ cs,
+                                                        int64_t *__restrict__ off)
+{
+    __shared__ int64_t wsum[CP_THREADS / 64];
+    __shared__ int64_t tot_s[2];
+    auto block_scan = [&](int64_t v, int64_t *total) -> int64_t {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        int64_t inc = v;
+        for (int o = 1; o < 64; o <<= 1) { int64_t x = __shfl_up(inc, o); if (lane >= o) inc += x; }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int64_t base = 0, tot = 0;
+        for (int w = 0; w < CP_THREADS / 64; ++w) { if (w < wave) base += wsum[w]; tot += wsum[w]; }
+        *total = tot;
+        return base + inc - v;
+    };
+    // totals of gt1 / gt5
+    int64_t g1 = 0, g5 = 0;
+    for (int t = threadIdx.x; t < nb; t += CP_THREADS) { g1 += blk[(size_t)t * 4]; g5 += blk[(size_t)t * 4 + 2]; }
+    int64_t T1, T5;
+    block_scan(g1, &T1);
+    block_scan(g5, &T5);
+    const int64_t e1 = cs->all1 ? (1ll << 62) : cs->K1 - T1;
+    const int64_t e5 = cs->all5 ? (1ll << 62) : cs->K5 - T5;
+    int64_t c_eq1 = 0, c_eq5 = 0, c_cand = 0, c_next = 0;
+    for (int base = 0; base < nb; base += CP_THREADS) {
+        const int t = base + threadIdx.x;
+        const int64_t gt1 = t < nb ? blk[(size_t)t * 4] : 0, eq1 = t < nb ? blk[(size_t)t * 4 + 1] : 0;
+        const int64_t gt5 = t < nb ? blk[(size_t)t * 4 + 2] : 0, eq5 = t < nb ? blk[(size_t)t * 4 + 3] : 0;
+        int64_t tot;
+        const int64_t p1 = c_eq1 + block_scan(eq1, &tot); c_eq1 += tot;
+        const int64_t p5 = c_eq5 + block_scan(eq5, &tot); c_eq5 += tot;
+        const int64_t take1 = min(eq1, max((int64_t)0, e1 - p1));
+        const int64_t take5 = min(eq5, max((int64_t)0, e5 - p5));
+        const int64_t ncand = gt1 + take1;
+        const int64_t nbig = gt5 + take5;
+        // when everything is taken for both lists, `next` is the full list again (annchor.py:444-446)
+        const int64_t nnext = (cs->all1 && cs->all5) ? nbig : nbig - ncand;
+        const int64_t oc = c_cand + block_scan(ncand, &tot); c_cand += tot;
+        const int64_t on = c_next + block_scan(nnext, &tot); c_next += tot;
+        if (t < nb) { off[(size_t)t * 4] = p1; off[(size_t)t * 4 + 1] = p5; off[(size_t)t * 4 + 2] = oc; off[(size_t)t * 4 + 3] = on; }
+    }
+    if (threadIdx.x == 0) { cs->e1 = e1; cs->e5 = e5; cs->ncand = c_cand; cs->nnext = c_next; }
+    (void)tot_s;
+}
+
+__global__ __launch_bounds__(CP_THREADS) void k_cut_emit(const double *__restrict__ prob, int64_t n,
+                                                        const CutState *__restrict__ cs, const int64_t *__restrict__ off,
+                                                        int32_t *__restrict__ cand, int32_t *__restrict__ next)
+{
+    __shared__ uint32_t wsum[CP_THREADS / 64];
+    const double t1 = cs->t1, t5 = cs->t5;
+    const int64_t e1 = cs->e1, e5 = cs->e5;
+    const bool both_all = cs->all1 && cs->all5;
+    const int64_t base = (int64_t)blockIdx.x * CP_TILE + (int64_t)threadIdx.x * CP_ITEMS;  // thread-contiguous: keeps position order
+    double v[CP_ITEMS];
+    uint32_t q1 = 0, q5 = 0;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        v[k] = (base + k < n) ? prob[base + k] : -1.0;
+        if (v[k] >= 0.0) { q1 += v[k] == t1; q5 += v[k] == t5; }
+    }
+    auto scan2 = [&](uint32_t a, uint32_t b, uint32_t *ea, uint32_t *eb) {
+        // packs two counters (each < 2^16 per block) into one 32-bit scan
+        uint32_t tot;
+        const uint32_t packed = row_block_scan((a << 16) | b, wsum, &tot);
+        __syncthreads();
+        *ea = packed >> 16;
+        *eb = packed & 0xffffu;
+    };
+    uint32_t x1, x5;
+    scan2(q1, q5, &x1, &x5);
+    int64_t r1 = off[(size_t)blockIdx.x * 4] + x1, r5 = off[(size_t)blockIdx.x * 4 + 1] + x5;
+    uint8_t fc[CP_ITEMS], fn[CP_ITEMS];
+    uint32_t nc = 0, nn = 0;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        bool c1 = false, c5 = false;
+        if (v[k] >= 0.0) {
+            c1 = v[k] > t1 || (v[k] == t1 && r1 < e1);
+            c5 = v[k] > t5 || (v[k] == t5 && r5 < e5);
+            r1 += v[k] == t1;
+            r5 += v[k] == t5;
+        }
+        fc[k] = c1;
+        fn[k] = both_all ? c5 : (c5 && !c1);
+        nc += fc[k];
+        nn += fn[k];
+    }
+    uint32_t oc, on;
+    scan2(nc, nn, &oc, &on);
+    int64_t wc = off[(size_t)blockIdx.x * 4 + 2] + oc, wn = off[(size_t)blockIdx.x * 4 + 3] + on;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        if (fc[k]) cand[wc++] = (int32_t)(base + k);
+        if (fn[k]) next[wn++] = (int32_t)(base + k);
+    }
+}
+
+extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, int32_t nmin, const double *errs,
+                                         const int64_t *err_ptr, int32_t nlabels, int64_t n_refine, int32_t lookahead,
+                                         int64_t *n_cand, int64_t *n_next)
+{
+    if (!c || !errs || !err_ptr || !n_cand || !n_next) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_RA, ANNCHOR_EINVAL, "RefineApprox not initialised");
+    ANN_REQUIRE(c, nlabels >= 1 && nlabels <= 255, ANNCHOR_ELIMIT, "1..255 error labels supported");
+    ANN_REQUIRE(c, n_neighbors >= 1 && lookahead >= 1 && n_refine >= 0, ANNCHOR_EINVAL, "bad selection parameters");
+    for (int b = 0; b < nlabels; ++b)
+        ANN_REQUIRE(c, err_ptr[b + 1] > err_ptr[b], ANNCHOR_ESTATE, "error bin %d has no samples", b);
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    const int64_t n = c->n, nx = c->nx;
+    ANN_TRY(ann_reserve(c, c->thresh, sizeof(double) * (size_t)nx));
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    {
+        // algorithmic bytes: every pair value is read from both of its rows: 2n * (8 + 4)
+        ProfScope ps(c, "row_kth_threshold", (double)n * 24.0);
+        k_row_thresh<<<(int)nx, ROW_THREADS, 0, c->stream>>>(c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(), c->RA.as<double>(),
+                                                            (uint32_t)n_neighbors, c->thresh.as<double>());
+    }
+    if (nmin > 0) {
+        const int L = nmin + 1;
+        ANN_REQUIRE(c, L <= 1024, ANNCHOR_ELIMIT, "nmin=%d too large", nmin);
+        ANN_TRY(ann_reserve(c, c->gl_val, sizeof(double) * (size_t)nx * L));
+        ANN_TRY(ann_reserve(c, c->gl_pos, sizeof(int32_t) * (size_t)nx * L));
+        ANN_TRY(ann_reserve(c, c->gl_cnt, sizeof(int32_t) * (size_t)nx));
+        ANN_TRY(ann_reserve(c, c->gl_ncomp, sizeof(int32_t) * (size_t)nx));
+        ANN_TRY(ann_reserve(c, c->marked, (size_t)n));
+        ANN_TRY(ann_reserve(c, c->markcount, sizeof(int32_t) * (size_t)nx));
+        ANN_TRY(ann_reserve(c, c->tmp2, 64));
+        ANN_CHECK_HIP(c, hipMemsetAsync(c->marked.p, 0, (size_t)n, c->stream));
+        ANN_CHECK_HIP(c, hipMemsetAsync(c->markcount.p, 0, sizeof(int32_t) * (size_t)nx, c->stream));
+        ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp2.p, 0, 4, c->stream));
+        {
+            ProfScope ps(c, "guarantee_nmin_lists", (double)n * 26.0);
+            k_gn_lists<<<(int)nx, ROW_THREADS, (size_t)L * 12, c->stream>>>(
+                c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(), c->RA.as<double>(), c->ncm.as<uint8_t>(), L,
+                c->gl_val.as<double>(), c->gl_pos.as<int32_t>(), c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>());
+        }
+        {
+            ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 13.0);
+            k_gn_sequential<<<1, 64, 0, c->stream>>>(nx, nmin, L, c->gl_val.as<double>(), c->gl_pos.as<int32_t>(),
+                                                    c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(), c->ij.as<int2>(),
+                                                    c->RA.as<double>(), c->marked.as<uint8_t>(), c->markcount.as<int32_t>(),
+                                                    c->tmp2.as<int32_t>());
+        }
+    }
+    // ---- probabilities
+    const int64_t nerr = err_ptr[nlabels];
+    ANN_TRY(ann_reserve(c, c->errs, sizeof(double) * (size_t)nerr));
+    ANN_TRY(ann_reserve(c, c->errptr, sizeof(int64_t) * (size_t)(nlabels + 1)));
+    ANN_TRY(ann_h2d(c, c->errs.p, errs, sizeof(double) * (size_t)nerr));
+    ANN_TRY(ann_h2d(c, c->errptr.p, err_ptr, sizeof(int64_t) * (size_t)(nlabels + 1)));
+    {
+        const int in_lds = nerr * 8 <= 60 * 1024;
+        const size_t dyn = in_lds ? (size_t)nerr * 8 : 0;
+        int blocks = min(ann_blocks(n, 256 * 4), c->prop.multiProcessorCount * 8);
+        // algorithmic bytes per pair: 8 (ij) + 8 (RA) + 2 (mask, label) + 8 (prob)
+        ProfScope ps(c, "ecdf_probability", (double)n * 26.0);
+        k_prob<<<blocks, 256, dyn, c->stream>>>(n, c->ij.as<int2>(), c->thresh.as<double>(), c->RA.as<double>(),
+                                               c->ncm.as<uint8_t>(), c->label.as<uint8_t>(), c->errs.as<double>(),
+                                               c->errptr.as<int64_t>(), nlabels, in_lds, c->prob.as<double>());
+    }
+    ANN_CHECK_HIP(c, hipGetLastError());
+    if (nmin > 0) {
+        int32_t e = 0;
+        ANN_TRY(ann_d2h(c, &e, c->tmp2.p, 4));
+        ANN_REQUIRE(c, e == 0, ANNCHOR_ESTATE, "guarantee_nmin: a row has fewer not-computed candidates than it must refine");
+    }
+    // ---- cut values
+    int64_t n_unc = 0;
+    ANN_TRY(annchor_count_uncomputed(c, &n_unc));
+    CutState cs;
+    memset(&cs, 0, sizeof cs);
+    cs.K1 = n_refine;
+    cs.K5 = n_refine * (int64_t)lookahead;
+    cs.all1 = n_refine >= n_unc;
+    cs.all5 = cs.all1 || cs.K5 >= n_unc;
+    cs.t1 = cs.t5 = INFINITY;
+    if (n_refine > 0 && !(cs.all1 && cs.all5)) {
+        int64_t ks[2];
+        int nk = 0;
+        if (!cs.all1) ks[nk++] = n_unc - cs.K1;
+        if (!cs.all5) ks[nk++] = n_unc - cs.K5;
+        double tv[2];
+        // flag = ncm: prob >= 0 exactly on not-computed pairs
+        ANN_TRY(ann_kth_smallest(c, c->prob.as<double>(), c->ncm.as<uint8_t>(), n, ks, nk, tv));
+        nk = 0;
+        if (!cs.all1) cs.t1 = tv[nk++];
+        if (!cs.all5) cs.t5 = tv[nk++];
+    }
+    if (cs.all1) cs.t1 = -1.0;
+    if (cs.all5) cs.t5 = -1.0;
+    if (n_refine == 0) { cs.all1 = cs.all5 = 0; cs.t1 = cs.t5 = INFINITY; cs.K1 = cs.K5 = 0; }
+    const int nb = ann_blocks(n, CP_TILE);
+    ANN_TRY(ann_reserve(c, c->sel_state, sizeof(CutState) + 256));
+    ANN_TRY(ann_reserve(c, c->blk_cnt, sizeof(uint32_t) * 4 * (size_t)nb));
+    ANN_TRY(ann_reserve(c, c->blk_off, sizeof(int64_t) * 4 * (size_t)nb));
+    const int64_t maxc = cs.all1 ? n_unc : cs.K1, maxn = cs.all5 ? n_unc : cs.K5;
+    ANN_TRY(ann_reserve(c, c->cand, sizeof(int32_t) * (size_t)(maxc + 1)));
+    ANN_TRY(ann_reserve(c, c->next, sizeof(int32_t) * (size_t)(maxn + 1)));
+    ANN_TRY(ann_h2d(c, c->sel_state.p, &cs, sizeof cs));
+    {
+        ProfScope ps(c, "topk_split_compact", (double)n * 16.0 + (double)(maxc + maxn) * 4.0);
+        k_cut_count<<<nb, CP_THREADS, 0, c->stream>>>(c->prob.as<double>(), n, c->sel_state.as<CutState>(), c->blk_cnt.as<uint32_t>());
+        k_cut_scan<<<1, CP_THREADS, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nb, c->sel_state.as<CutState>(), c->blk_off.as<int64_t>());
+        k_cut_emit<<<nb, CP_THREADS, 0, c->stream>>>(c->prob.as<double>(), n, c->sel_state.as<CutState>(), c->blk_off.as<int64_t>(),
+                                                    c->cand.as<int32_t>(), c->next.as<int32_t>());
+    }
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+    c->call_timed = true;
+    ANN_CHECK_HIP(c, hipGetLastError());
+    ANN_TRY(ann_d2h(c, &cs, c->sel_state.p, sizeof cs));
+    c->ncand = cs.ncand;
+    c->nnext = cs.nnext;
+    *n_cand = cs.ncand;
+    *n_next = cs.nnext;
+    return ANNCHOR_OK;
+}
+
+// ------------------------------------------------------------------- refinement
+extern "C" int annchor_refine_candidates(annchor_ctx *c)
+{
+    if (!c) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_RA, ANNCHOR_EINVAL, "RefineApprox not initialised");
+    ANN_REQUIRE(c, c->metric != ANNCHOR_METRIC_NONE, ANNCHOR_EINVAL, "no device metric bound to this context");
+    if (c->ncand == 0) return ANNCHOR_OK;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    PairSource src;
+    src.ij = c->ij.as<int2>();
+    src.idx = c->cand.as<int32_t>();
+    src.n = c->ncand;
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    ANN_TRY(ann_metric_launch(c, src, nullptr, c->RA.as<double>(), c->ncm.as<uint8_t>()));
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+    c->call_timed = true;
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
+__global__ void k_write_refined(const int32_t *__restrict__ pos, const double *__restrict__ v, int64_t m,
+                                double *__restrict__ RA, uint8_t *__restrict__ ncm)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m) { RA[pos[t]] = v[t]; ncm[pos[t]] = 0; }
+}
+
+extern "C" int annchor_set_refined(annchor_ctx *c, const double *exact, int64_t n_cand)
+{
+    if (!c || (n_cand > 0 && !exact)) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_RA, ANNCHOR_EINVAL, "RefineApprox not initialised");
+    ANN_REQUIRE(c, n_cand == c->ncand, ANNCHOR_EINVAL, "expected %lld refined values, got %lld", (long long)c->ncand,
+                (long long)n_cand);
+    if (n_cand == 0) return ANNCHOR_OK;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(ann_reserve(c, c->stage_in, sizeof(double) * (size_t)n_cand));
+    ANN_TRY(ann_h2d(c, c->stage_in.p, exact, sizeof(double) * (size_t)n_cand));
+    k_write_refined<<<ann_blocks(n_cand, 256), 256, 0, c->stream>>>(c->cand.as<int32_t>(), c->stage_in.as<double>(), n_cand,
+                                                                   c->RA.as<double>(), c->ncm.as<uint8_t>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}

@@ -1,0 +1,73 @@
+"""
+Regressors (reference annchor/regressors.py:18-103).  Protocol, unchanged:
+    regression.fit(sample_features, feature_names, sample_y, sample_bins=None)
+    regression.predict(features, feature_names) -> float64[n]
+
+`SimpleStratifiedLinearRegression` fits 7 tiny OLS models on the host (7 x ~700 x 3)
+and exposes them as `coefficients()`; inside `Annchor` its predict over all pairs is
+the fused HIP kernel (predict + clip + merge + label).  `predict()` on a NumPy array
+is kept for plugin compatibility and evaluates the same expression, in the same
+floating-point order, with NumPy.
+"""
+import numpy as np
+import scipy.linalg
+
+
+def _ols(X, y):
+    # sklearn LinearRegression(fit_intercept=True): centre, lstsq (gelsd), intercept
+    xm, ym = X.mean(axis=0), y.mean()
+    Xc, yc = X - xm, y - ym
+    cond = max(Xc.shape) * np.finfo(np.float64).eps
+    coef = scipy.linalg.lstsq(Xc, yc, cond=cond)[0]
+    return coef, ym - xm @ coef
+
+
+class SimpleStratifiedLinearRegression:
+    def __init__(self, reg_feature_names=["lower bound", "upper bound", "double anchor distance"],
+                 partition_feature_name="double anchor distance", n_partitions=7):
+        self.n_partitions = n_partitions
+        self.partition_feature_name = partition_feature_name
+        self.reg_feature_names = reg_feature_names
+        self.coef_ = None
+        self.intercept_ = None
+
+    def _columns(self, feature_names):
+        return (feature_names.index(self.partition_feature_name),
+                [i for i, name in enumerate(feature_names) if name in self.reg_feature_names])
+
+    def fit(self, sample_features, feature_names, sample_y, sample_bins=None):
+        i_part, i_features = self._columns(feature_names)
+        F = sample_features[:, i_part]
+        if sample_bins is None:
+            n = F.shape[0]
+            iq1, iq3 = int(n / 100), int(99 * n / 100)
+            q1, q3 = np.partition(F, iq1)[iq1], np.partition(F, iq3)[iq3]
+            self.sample_bins = np.hstack([-np.inf, np.linspace(q1, q3, self.n_partitions - 1), np.inf])
+        else:
+            self.n_partitions = sample_bins.shape[0] - 1
+            self.sample_bins = sample_bins
+        self.coef_ = np.zeros((self.n_partitions, len(i_features)))
+        self.intercept_ = np.zeros(self.n_partitions)
+        for nbin in range(self.n_partitions):
+            mask = (F > self.sample_bins[nbin]) * (F <= self.sample_bins[nbin + 1])
+            self.coef_[nbin], self.intercept_[nbin] = _ols(sample_features[mask][:, i_features], sample_y[mask])
+
+    def coefficients(self):
+        """(bins [nb+1], W [nb,3], c [nb]) for the fused device predict; None if the
+        feature selection is not the default (lb, ub, dad)."""
+        if list(self.reg_feature_names) != ["lower bound", "upper bound", "double anchor distance"] or \
+                self.partition_feature_name != "double anchor distance":
+            return None
+        return self.sample_bins, self.coef_, self.intercept_
+
+    def predict(self, features, feature_names):
+        i_part, i_features = self._columns(feature_names)
+        X, F = features[:, i_features], features[:, i_part]
+        y = np.zeros(X.shape[0])
+        for nbin in range(self.n_partitions):
+            mask = (F > self.sample_bins[nbin]) * (F <= self.sample_bins[nbin + 1])
+            acc = np.zeros(int(mask.sum()))
+            for k in range(X.shape[1]):
+                acc = acc + self.coef_[nbin, k] * X[mask, k]
+            y[mask] = acc + self.intercept_[nbin]
+        return y

@@ -1,0 +1,156 @@
+"""
+Samplers (reference annchor/samplers.py:18-175).  Protocol, unchanged:
+    sampler.sample(features[n,4], feature_names, n_samples, not_computed_mask, random_seed)
+        -> (sample_ixs, n_samples, sample_bins);  raises NothingToSample
+
+`SimpleStratifiedSampler` additionally implements `sample_device(ann, ...)`: the same
+draw, bit for bit (same order statistics, same bins, same NumPy legacy RNG stream --
+`np.random.seed(seed + loop_num)` then one `np.random.choice(..., replace=False)` per
+bin), but with the O(n) work -- quantiles of the feature over not-computed pairs,
+bin populations, rank -> pair position -- done by device kernels on the resident
+state instead of on a materialised features array.
+"""
+from abc import ABC, abstractmethod
+
+import numpy as np
+
+
+class NothingToSample(Exception):
+    pass
+
+
+class SamplingError(Exception):
+    def __init__(self, message):
+        super().__init__(message)
+
+
+class Sampler(ABC):
+    """Base class (samplers.py:22-110): descendants implement get_partition and may
+    override sample_partition."""
+
+    def __init__(self, partition_feature_name, n_partitions):
+        self.partition_feature_name = partition_feature_name
+        self.n_partitions = n_partitions
+        self.loop_num = 0
+
+    @abstractmethod
+    def get_partition(self, sample_feature, new_samples):
+        pass
+
+    def sample_partition(self, indices, n_samples, sample_feature, sample_bins, random_seed):
+        bin_size = n_samples // self.n_partitions
+        remainder = n_samples % self.n_partitions
+        # utils.py:560-578 (the reference seeds numba's RNG inside njit; without numba
+        # the NumPy legacy stream is the reproducible equivalent)
+        np.random.seed(random_seed + self.loop_num)
+        samples = []
+        for nbin in range(self.n_partitions):
+            mask = (sample_feature >= sample_bins[nbin]) * (sample_feature < sample_bins[nbin + 1])
+            ixmask = indices[mask]
+            want = bin_size + (nbin < remainder)
+            if ixmask.shape[0] < want:
+                samples.append(ixmask)
+            else:
+                samples.append(np.random.choice(ixmask, size=want, replace=False))
+        self.loop_num += 1
+        for s in samples:
+            if len(s) < 2:
+                raise Exception("Some sampler bins contain too few samples")
+        return np.hstack(samples)
+
+    def sample(self, features, feature_names, n_samples, not_computed_mask, random_seed):
+        if not not_computed_mask.any():
+            raise NothingToSample()
+        i_feature = feature_names.index(self.partition_feature_name)
+        sample_feature = features[not_computed_mask][:, i_feature]
+        indices = np.arange(not_computed_mask.shape[0])[not_computed_mask]
+        sample_bins, new_n_samples = self.get_partition(sample_feature, n_samples)
+        if new_n_samples != n_samples:
+            print("Warning: n_samples has changed from %d to %d." % (n_samples, new_n_samples))
+        n_samples = new_n_samples
+        if n_samples == 0:
+            raise NothingToSample()
+        sample_ixs = self.sample_partition(indices, n_samples, sample_feature, sample_bins, random_seed)
+        if n_samples != sample_ixs.shape[0]:
+            print("Warning: Some bins contained fewer samples than requested")
+        return sample_ixs, sample_ixs.shape[0], sample_bins
+
+
+class SimpleStratifiedSampler(Sampler):
+    """samplers.py:113-140: 1 % / 99 % (fallback 10 % / 90 %) order statistics of the
+    feature, 6 linspace edges + +-inf => 7 bins."""
+
+    def __init__(self, partition_feature_name="double anchor distance", n_partitions=7):
+        super().__init__(partition_feature_name, n_partitions)
+
+    @staticmethod
+    def _quantile_ranks(n, n_samples, n_partitions):
+        iq1, iq3 = int(n / 100), int(99 * n / 100)
+        if (iq1 * n_partitions) < n_samples:
+            iq1, iq3 = int(n / 10), int(9 * n / 10)
+        if (iq1 * n_partitions) < n_samples:
+            n_samples = iq1 * n_partitions
+            print("Warning: n_samples too large for data set size.\n" + "Reducing n_samples to %d." % n_samples)
+        return iq1, iq3, n_samples
+
+    def get_partition(self, sample_feature, n_samples):
+        iq1, iq3, n_samples = self._quantile_ranks(sample_feature.shape[0], n_samples, self.n_partitions)
+        q1 = np.partition(sample_feature, iq1)[iq1]
+        q3 = np.partition(sample_feature, iq3)[iq3]
+        sample_bins = np.linspace(q1, q3, self.n_partitions - 1)
+        return np.hstack([-np.inf, sample_bins, np.inf]), n_samples
+
+    def sample_device(self, engine, n_samples, random_seed):
+        """Same result as sample(), computed against the device-resident state."""
+        if self.partition_feature_name != "double anchor distance":
+            raise NotImplementedError
+        n_unc = engine.count_uncomputed()
+        if n_unc == 0:
+            raise NothingToSample()
+        iq1, iq3, new_n = self._quantile_ranks(n_unc, n_samples, self.n_partitions)
+        if new_n != n_samples:
+            print("Warning: n_samples has changed from %d to %d." % (n_samples, new_n))
+        n_samples = new_n
+        q1, q3 = engine.kth_uncomputed_dad([iq1, iq3])
+        sample_bins = np.hstack([-np.inf, np.linspace(q1, q3, self.n_partitions - 1), np.inf])
+        if n_samples == 0:
+            raise NothingToSample()
+        counts = engine.bin_counts(sample_bins)
+        bin_size, remainder = n_samples // self.n_partitions, n_samples % self.n_partitions
+        np.random.seed(random_seed + self.loop_num)
+        bin_of, ranks = [], []
+        for nbin in range(self.n_partitions):
+            want = bin_size + (nbin < remainder)
+            c = int(counts[nbin])
+            if c < want:
+                r = np.arange(c, dtype=np.int64)
+            else:
+                # np.random.choice(ixmask, size=want, replace=False) == ixmask[permutation(c)[:want]]
+                r = np.random.permutation(c)[:want].astype(np.int64)
+            if len(r) < 2:
+                self.loop_num += 1
+                raise Exception("Some sampler bins contain too few samples")
+            bin_of.append(np.full(len(r), nbin, dtype=np.int32))
+            ranks.append(r)
+        self.loop_num += 1
+        bin_of, ranks = np.concatenate(bin_of), np.concatenate(ranks)
+        sample_ixs = engine.select_by_rank(sample_bins, bin_of, ranks)
+        if n_samples != sample_ixs.shape[0]:
+            print("Warning: Some bins contained fewer samples than requested")
+        return sample_ixs, sample_ixs.shape[0], sample_bins
+
+
+class ClusterSampler(Sampler):
+    """samplers.py:143-170 (host only: k-means on the feature)."""
+
+    def __init__(self, partition_feature_name="double anchor distance", n_partitions=5):
+        super().__init__(partition_feature_name, n_partitions)
+
+    def get_partition(self, sample_feature, n_samples):
+        from sklearn.cluster import KMeans
+
+        labels = KMeans(n_clusters=self.n_partitions).fit_predict(sample_feature.reshape(-1, 1))
+        partitions = np.array([[np.min(sample_feature[labels == i]), np.max(sample_feature[labels == i])]
+                               for i in range(self.n_partitions)])
+        partitions = np.sort(partitions.flatten())
+        return np.hstack([-np.inf, partitions[1:-1:2], np.inf]), n_samples

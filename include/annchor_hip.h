@@ -1,0 +1,194 @@
+/*
+ * annchor_hip.h -- C-ABI of libannchor_hip.so, the MI355X (gfx950) implementation of
+ * the ANNchor `Annchor.fit()` -> `neighbor_graph` hot path.
+ *
+ * The reference (gchq/annchor) is pure Python + numba and has no FFI of its own; the
+ * entry points below are exactly what a binding of its hot-path functions would
+ * call.  Each one cites the reference function it replaces (paths relative to the
+ * reference repository root).  INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative ANNCHOR_E* code;
+ *     annchor_last_error(ctx) gives a message for the last failure on that ctx;
+ *   - all pointer arguments are HOST pointers owned by the caller; the library
+ *     copies in/out and keeps no host pointer after returning;
+ *   - all pipeline state lives in HBM inside the opaque context between calls;
+ *   - one in-flight call per context (no internal locking); contexts are independent;
+ *   - "pair position" = row index into the candidate pair list IJs built by
+ *     annchor_build_locality (sorted by (i, j), i < j).
+ */
+#ifndef ANNCHOR_HIP_H
+#define ANNCHOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct annchor_ctx annchor_ctx;
+
+enum {
+    ANNCHOR_OK = 0,
+    ANNCHOR_EINVAL = -1,   /* bad argument / call out of order            */
+    ANNCHOR_EHIP = -2,     /* HIP runtime error (message has the details) */
+    ANNCHOR_ENODEV = -3,   /* no usable GPU                               */
+    ANNCHOR_ELIMIT = -4,   /* size outside what this build supports       */
+    ANNCHOR_ESTATE = -5    /* algorithmic failure the reference raises on */
+};
+
+enum { ANNCHOR_METRIC_NONE = 0, ANNCHOR_METRIC_LEVENSHTEIN = 1, ANNCHOR_METRIC_EUCLIDEAN_F32 = 2,
+       ANNCHOR_METRIC_EUCLIDEAN_F64 = 3, ANNCHOR_METRIC_WASSERSTEIN = 4 };
+
+/* fields for annchor_download / annchor_upload */
+enum {
+    ANNCHOR_F_D = 1,        /* float64 [nx, na]  anchor distances (row-major as the reference's D) */
+    ANNCHOR_F_A = 2,        /* int64   [nA]      anchor indices                                    */
+    ANNCHOR_F_SID = 3,      /* uint64  [nx]      nearest-anchor bitmask (bit a = anchor a in sid)   */
+    ANNCHOR_F_IJS = 4,      /* int64   [n, 2]    candidate pairs                                   */
+    ANNCHOR_F_I_PTR = 5,    /* int64   [nx+1]    CSR offsets of I                                  */
+    ANNCHOR_F_I_IDX = 6,    /* int64   [2n]      CSR pair positions of I                           */
+    ANNCHOR_F_FEATURES = 7, /* float64 [n, 4]    lb, ub, dad, is_anchor                            */
+    ANNCHOR_F_NCM = 8,      /* uint8   [n]       not_computed_mask                                 */
+    ANNCHOR_F_RA = 9,       /* float64 [n]       RefineApprox                                      */
+    ANNCHOR_F_LABELS = 10,  /* int64   [n]       error-bin label per pair                          */
+    ANNCHOR_F_THRESH = 11,  /* float64 [nx]      per-row threshold                                 */
+    ANNCHOR_F_PROB = 12,    /* float64 [n]       ECDF probability (-1 on computed pairs)           */
+    ANNCHOR_F_CAND = 13,    /* int64   [ncand]   pair positions selected for refinement (ascending) */
+    ANNCHOR_F_NEXT = 14,    /* int64   [nnext]   lookahead pair positions (ascending)              */
+    ANNCHOR_F_DAD = 15      /* float64 [n]       double anchor distance only                       */
+};
+
+/* ---------------------------------------------------------------- lifecycle */
+int annchor_create(int device, annchor_ctx **out);
+void annchor_destroy(annchor_ctx *ctx);
+const char *annchor_last_error(annchor_ctx *ctx);
+/* Non-ctx error text for failures of annchor_create itself. */
+const char *annchor_create_error(void);
+int annchor_device_name(annchor_ctx *ctx, char *buf, int buflen);
+int annchor_synchronize(annchor_ctx *ctx);
+/* Device-side elapsed time (ms) of the work enqueued by the most recent call,
+ * measured with HIP events on the context's stream. */
+int annchor_last_kernel_ms(annchor_ctx *ctx, float *ms);
+
+/* ------------------------------------------------------------------ data set
+ * Replaces the `X` operand of get_exact(f, X, IJ) (annchor/utils.py:110-177).
+ * Strings: symbols[offs[s] .. offs[s]+lens[s]) are dense symbol codes
+ * 0..alphabet-1 (the host maps characters to codes). */
+int annchor_set_strings(annchor_ctx *ctx, const uint8_t *symbols, const int64_t *offs,
+                        const int32_t *lens, int64_t nx, int32_t alphabet);
+int annchor_set_points_f32(annchor_ctx *ctx, const float *X, int64_t nx, int32_t dim);
+int annchor_set_points_f64(annchor_ctx *ctx, const double *X, int64_t nx, int32_t dim);
+/* Wasserstein: hist float64 [nx, nbins], cost float64 [nbins, nbins]
+ * (annchor/utils.py:75-86, func_kwargs['cost_matrix']). */
+int annchor_set_histograms(annchor_ctx *ctx, const double *hist, int64_t nx, int32_t nbins,
+                           const double *cost);
+/* Data set without a device metric (user metric evaluated on the host). */
+int annchor_set_opaque(annchor_ctx *ctx, int64_t nx);
+
+/* --------------------------------------------------------- metric boundary a2
+ * get_exact(f, X, IJ): out[t] = f(X[IJ[t,0]], X[IJ[t,1]]) as float64
+ * (annchor/utils.py:110-177).  ij: int64 [n, 2]; may contain i == j and repeats. */
+int annchor_metric_pairs(annchor_ctx *ctx, const int64_t *ij, int64_t n, double *out);
+/* BruteForce.fit (annchor/annchor.py:1004-1023): all-pairs metric + per-row stable
+ * sort; writes the first k columns of (argsort(D), sort(D)). */
+int annchor_brute_force(annchor_ctx *ctx, int32_t k, int64_t *ng_idx, double *ng_dist);
+
+/* ------------------------------------------------------------------ anchors a6
+ * MaxMinAnchorPicker.get_anchors (annchor/pickers.py:18-52).  `first` is the
+ * host-drawn np.random.randint(nx).  Fills A and D inside the context. */
+int annchor_pick_anchors_maxmin(annchor_ctx *ctx, int32_t n_anchors, int64_t first);
+/* SelectedAnchorPicker / RandomAnchorPicker (pickers.py:86-128): given indices. */
+int annchor_pick_anchors_selected(annchor_ctx *ctx, const int64_t *A, int32_t n_anchors);
+/* Any other picker (ExternalAnchorPicker, user classes): the host hands over
+ * (A, D, evals) as AnchorPicker.get_anchors returns them.  D float64 [nx, na]. */
+int annchor_set_anchor_distances(annchor_ctx *ctx, const double *D, int32_t n_anchors,
+                                 const int64_t *A, int32_t nA);
+
+/* ----------------------------------------------------------------- locality a7
+ * Annchor.get_locality + get_check/adjust_check/get_IJs_from_check
+ * (annchor/annchor.py:208-256, annchor/utils.py:437-540).  Returns the number of
+ * candidate pairs and the smallest |I[i]| (annchor.py:252-256 raises when it is
+ * below n_neighbors -- the host does that). */
+int annchor_build_locality(annchor_ctx *ctx, int32_t locality, int32_t loc_thresh, int32_t loc_min,
+                           int64_t *n_pairs, int64_t *min_row_len);
+
+/* ------------------------------------------------------------- features a8-a10
+ * get_bounds_njit_ijs, get_dad_ijs, get_features_IJ (utils.py:274-301,355-380;
+ * annchor.py:258-303): lb, ub, dad, is_anchor, not_computed_mask for every pair. */
+int annchor_compute_features(annchor_ctx *ctx);
+
+/* ------------------------------------------------------------------ sample a11
+ * Helpers for Sampler.sample (annchor/samplers.py:75-140) on the device-resident
+ * state.  kth_uncomputed_dad: np.partition(dad[ncm], k)[k] for each requested k. */
+int annchor_count_uncomputed(annchor_ctx *ctx, int64_t *n_unc);
+int annchor_kth_uncomputed_dad(annchor_ctx *ctx, const int64_t *ks, int32_t nk, double *out);
+/* counts[b] = #{uncomputed pairs with bins[b] <= dad < bins[b+1]} (utils.py:547-549). */
+int annchor_bin_counts(annchor_ctx *ctx, const double *bins, int32_t nbins, int64_t *counts);
+/* For each request t: the pair position of the ranks[t]-th (0-based, position
+ * order) uncomputed pair inside bin bin_of[t]. */
+int annchor_select_by_rank(annchor_ctx *ctx, const double *bins, int32_t nbins, const int32_t *bin_of,
+                           const int64_t *ranks, int64_t nreq, int64_t *positions);
+/* Gather features [m, 4] at the given pair positions (self.features[sample_ixs]). */
+int annchor_gather_features(annchor_ctx *ctx, const int64_t *pos, int64_t m, double *feats);
+/* get_sample (annchor.py:336-343): evaluate the metric on the sample pairs, clear
+ * their not_computed_mask bit, remember (positions, y) for the merge. */
+int annchor_evaluate_samples(annchor_ctx *ctx, const int64_t *pos, int64_t m, double *sample_y);
+/* Same, when the metric was evaluated by the host. */
+int annchor_set_samples(annchor_ctx *ctx, const int64_t *pos, int64_t m, const double *sample_y);
+
+/* ----------------------------------------------------- regression/errors a12-13
+ * SimpleStratifiedLinearRegression.predict + clip + RefineApprox merge
+ * (regressors.py:71-103, annchor.py:356-380) and
+ * SimpleStratifiedErrorRegression.predict (error_predictors.py:56-67), fused.
+ * bins float64 [nb+1], W float64 [nb,3], c float64 [nb].  sample_predict receives
+ * the UNCLIPPED prediction at the current sample positions (annchor.py:357). */
+int annchor_predict_merge(annchor_ctx *ctx, const double *bins, int32_t nb, const double *W,
+                          const double *c, int32_t first_iteration, int32_t is_metric,
+                          double *sample_predict);
+/* Custom Regression / ErrorPredictor plugins: host-computed arrays are merged. */
+int annchor_merge_host_prediction(annchor_ctx *ctx, const double *pred, int32_t first_iteration,
+                                  int32_t is_metric);
+int annchor_set_labels(annchor_ctx *ctx, const int64_t *labels);
+
+/* --------------------------------------------------------------- selection a14
+ * select_refine_candidate_pairs (annchor.py:395-473) up to, not including, the
+ * metric call: thresh, guarantee_nmin (when nmin > 0), p, ECDF prob (errs:
+ * concatenated sorted residuals, err_ptr int64 [nlabels+1]), top-n_refine and
+ * lookahead selection with the tie rule (prob desc, pair position asc). */
+int annchor_select_candidates(annchor_ctx *ctx, int32_t n_neighbors, int32_t nmin, const double *errs,
+                              const int64_t *err_ptr, int32_t nlabels, int64_t n_refine,
+                              int32_t lookahead, int64_t *n_cand, int64_t *n_next);
+/* Evaluate the metric on the selected candidates and write back
+ * (annchor.py:467-473). */
+int annchor_refine_candidates(annchor_ctx *ctx);
+/* Same, host-evaluated metric: exact float64 [n_cand] in ANNCHOR_F_CAND order. */
+int annchor_set_refined(annchor_ctx *ctx, const double *exact, int64_t n_cand);
+
+/* ----------------------------------------------------------- bound update a15
+ * update_anchor_points + update_bounds/get_bounds_alt (annchor.py:475-512,
+ * utils.py:304-352) over the lookahead pairs, all chunks (no wall-clock cut). */
+int annchor_update_bounds(annchor_ctx *ctx);
+
+/* ------------------------------------------------------------------ graph a16
+ * get_ann + get_nn (annchor.py:514-530, utils.py:383-429).  ng_idx int64 [nx, k],
+ * ng_dist float64 [nx, k], column 0 = self. */
+int annchor_neighbor_graph(annchor_ctx *ctx, int32_t n_neighbors, int64_t *ng_idx, double *ng_dist);
+
+/* -------------------------------------------------------------- state access */
+int annchor_field_size(annchor_ctx *ctx, int32_t field, int64_t *n_elems);
+int annchor_download(annchor_ctx *ctx, int32_t field, void *dst, int64_t n_elems);
+int annchor_upload(annchor_ctx *ctx, int32_t field, const void *src, int64_t n_elems);
+
+/* ------------------------------------------------------------------ profiling
+ * Per-kernel-family accumulated device time since the last reset (HIP events on
+ * the stream): names[i] is a static string; returns the number of entries. */
+int annchor_prof_enable(annchor_ctx *ctx, int32_t on);
+int annchor_prof_reset(annchor_ctx *ctx);
+int annchor_prof_get(annchor_ctx *ctx, int32_t max_entries, const char **names, double *ms,
+                     int64_t *launches, double *alg_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANNCHOR_HIP_H */
