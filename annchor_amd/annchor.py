@@ -29,6 +29,28 @@ from .utils import get_exact_ijs_, get_function_from_input, test_parallelisation
 FEATURE_NAMES = ["lower bound", "upper bound", "double anchor distance", "is anchor"]
 
 
+def budget(nx, n_anchors, n_neighbors, n_samples, p_work, loc_min=None, quiet=True):
+    """Constructor arithmetic of the reference (annchor.py:117-148,167-168)."""
+    N = (nx * (nx - 1)) // 2
+    na = int(np.sum([nx - j for j in range(1, n_anchors + 1)]))
+    say = (lambda *a: None) if quiet else print
+    if p_work > 1:
+        say("Warning: p_work should not exceed 1.  Setting it to 1.")
+        p_work = 1.0
+    min_p_work = (2 * (na + n_samples) + 1) / N
+    min_p_work = 1 if min_p_work > 1 else min_p_work
+    if p_work < min_p_work:
+        say("Warning: Too many anchors/samples for specified p_work.")
+        say("Increasing p_work to %5.3f." % min_p_work)
+        p_work = min_p_work
+    if p_work > 0.75:
+        say("Warning: High Value of p_work.")
+        say("Think about decreasing n_anchors or n_samples," + " or using BruteForce.")
+    lm = 10 * n_neighbors if loc_min is None else loc_min
+    lm = np.clip(lm, 0, nx - 1)
+    return dict(N=N, na=na, p_work=p_work, loc_min=lm)
+
+
 class _IndexCSR:
     """Read-only stand-in for the reference's typed dict `I` (utils.py:533-540):
     I[i] -> int64 array of positions in IJs that contain i."""
@@ -58,28 +80,13 @@ class Annchor:
                  backend="loky", niters=2, lookahead=5, device=0):
         self.X = X
         self.nx = len(X)
-        self.N = (self.nx * (self.nx - 1)) // 2
         self.f = get_function_from_input(func, func_kwargs)
         self.evals = 0
         self.n_anchors = n_anchors
-        self.na = int(np.sum([self.nx - j for j in range(1, self.n_anchors + 1)]))
         self.n_neighbors = n_neighbors
-        self.p_work = p_work
         self.n_samples = n_samples
-
-        # budget arithmetic, annchor.py:132-148
-        if self.p_work > 1:
-            print("Warning: p_work should not exceed 1.  Setting it to 1.")
-            self.p_work = 1.0
-        min_p_work = (2 * (self.na + self.n_samples) + 1) / self.N
-        min_p_work = 1 if min_p_work > 1 else min_p_work
-        if self.p_work < min_p_work:
-            print("Warning: Too many anchors/samples for specified p_work.")
-            print("Increasing p_work to %5.3f." % min_p_work)
-            self.p_work = min_p_work
-        if self.p_work > 0.75:
-            print("Warning: High Value of p_work.")
-            print("Think about decreasing n_anchors or n_samples," + " or using BruteForce.")
+        b = budget(self.nx, n_anchors, n_neighbors, n_samples, p_work, loc_min, quiet=False)
+        self.N, self.na, self.p_work = b["N"], b["na"], b["p_work"]
 
         self.anchor_picker = MaxMinAnchorPicker() if anchor_picker is None else anchor_picker
         self.sampler = SimpleStratifiedSampler() if sampler is None else sampler
@@ -90,8 +97,7 @@ class Annchor:
         self.verbose = verbose
         self.locality = locality
         self.loc_thresh = loc_thresh
-        self.loc_min = 10 * self.n_neighbors if loc_min is None else loc_min
-        self.loc_min = np.clip(self.loc_min, 0, self.nx - 1)
+        self.loc_min = b["loc_min"]
         self.is_metric = is_metric
         self.niters = niters
         self.lookahead = lookahead

@@ -1,0 +1,132 @@
+"""CPU tests of the host layer: constructor arithmetic, metric resolution, samplers /
+regressors / error predictors (NumPy protocol forms) against the oracle and the golden
+vectors, and the RNG identity the device sampler relies on."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import annchor_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+NAMES = ["lower bound", "upper bound", "double anchor distance", "is anchor"]
+
+
+def test_budget_matches_reference_arithmetic():
+    """reference annchor/tests/test_annchor.py:148-160 (test_bad_pwork)."""
+    from annchor_amd.annchor import budget
+
+    b = budget(1600, 20, 15, 5000, 1.1)
+    assert b["p_work"] == 1.0
+    b = budget(1600, 20, 15, 5000, 0.0)
+    assert b["p_work"] == (2 * (b["na"] + 5000) + 1) / b["N"]
+    assert b["N"] == 1600 * 1599 // 2 and b["na"] == sum(1600 - j for j in range(1, 21))
+    for nx, na, k, ns, pw in [(1600, 15, 25, 5000, 0.12), (300, 8, 10, 700, 0.3), (50, 30, 40, 100, 0.5)]:
+        o = O.budget(nx, na, ns, pw, k)
+        h = budget(nx, na, k, ns, pw)
+        assert (h["N"], h["na"], h["p_work"], h["loc_min"]) == (o["N"], o["na"], o["p_work"], o["loc_min"])
+
+
+def test_metric_resolution():
+    """reference annchor/utils.py:62-107."""
+    from annchor_amd import distances
+    from annchor_amd.utils import get_function_from_input
+
+    assert get_function_from_input("levenshtein", None) is distances.levenshtein
+    assert get_function_from_input("euclidean", None) is distances.euclidean
+    w = get_function_from_input("wasserstein", {"cost_matrix": np.eye(4)})
+    assert isinstance(w, distances.Wasserstein) and w.cost_matrix.shape == (4, 4)
+    with pytest.raises(AssertionError):
+        get_function_from_input("wasserstein", {})
+    with pytest.raises(AssertionError):
+        get_function_from_input("manhattan", None)
+    f = get_function_from_input(lambda x, y, p=1: abs(x - y) ** p, {"p": 2})
+    assert f(1, 4) == 9
+    g = lambda x, y: 7  # noqa: E731
+    assert get_function_from_input(g, None) is g
+
+
+def test_host_evaluator_serial_and_parallel():
+    from annchor_amd.utils import get_exact_ijs_
+
+    X = np.arange(10.0)
+    IJ = np.array([[0, 3], [2, 2], [9, 1]])
+    f = lambda a, b: abs(a - b)  # noqa: E731
+    assert np.array_equal(get_exact_ijs_(f, parallel=False)(f, X, IJ), [3, 0, 8])
+    assert np.array_equal(get_exact_ijs_(f)(f, X, IJ), [3, 0, 8])
+
+
+def test_string_encoding_roundtrip():
+    from annchor_amd.distances import encode_strings
+
+    codes, offs, lens, A = encode_strings(["abc", "", "cab", "zz"])
+    assert A == 4 and list(lens) == [3, 0, 3, 2] and list(offs) == [0, 3, 3, 6]
+    assert list(codes) == [0, 1, 2, 2, 0, 1, 3, 3]
+    with pytest.raises(ValueError):
+        encode_strings(["".join(chr(300 + k) for k in range(300))])
+
+
+def test_legacy_choice_is_permutation_prefix():
+    """The device sampler draws `permutation(c)[:want]`; NumPy's legacy
+    `choice(a, size, replace=False)` is exactly `a[permutation(len(a))[:size]]`."""
+    a = np.arange(1000) * 3 + 1
+    for seed in (0, 42, 43):
+        np.random.seed(seed)
+        x1 = np.random.choice(a, size=37, replace=False)
+        x2 = np.random.choice(a[:500], size=11, replace=False)
+        np.random.seed(seed)
+        y1 = a[np.random.permutation(1000)[:37]]
+        y2 = a[:500][np.random.permutation(500)[:11]]
+        assert np.array_equal(x1, y1) and np.array_equal(x2, y2)
+
+
+@pytest.mark.parametrize("name", ["strings_small", "euclid_small"])
+def test_numpy_protocol_plugins_match_golden(name):
+    """The NumPy forms of the built-in plugins (what a user's code sees) reproduce the
+    reference's captured stage outputs."""
+    from annchor_amd.error_predictors import SimpleStratifiedErrorRegression
+    from annchor_amd.regressors import SimpleStratifiedLinearRegression
+    from annchor_amd.samplers import SimpleStratifiedSampler
+
+    G = np.load(os.path.join(GOLD, name + ".npz"))
+    feats, ncm = G["features0"], G["ncm0"]
+    s = SimpleStratifiedSampler()
+    ixs, n, bins = s.sample(feats, NAMES, int(G["cfg_n_samples"]), ncm, int(G["cfg_random_seed"]))
+    assert np.array_equal(ixs, G["it0_sample_ixs"]) and np.array_equal(bins, G["it0_bins"])
+    r = SimpleStratifiedLinearRegression()
+    r.fit(feats[ixs], NAMES, G["it0_sample_y"], sample_bins=bins)
+    np.testing.assert_allclose(r.coef_, G["it0_coef"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(r.intercept_, G["it0_intercept"], rtol=1e-9, atol=1e-9)
+    pred = r.predict(feats, NAMES)
+    np.testing.assert_allclose(pred[ixs], G["it0_sample_predict"], rtol=1e-9, atol=1e-9)
+    e = SimpleStratifiedErrorRegression()
+    e.fit(feats[ixs], NAMES, G["it0_sample_y"] - G["it0_sample_predict"], sample_bins=bins)
+    for b in range(7):
+        assert np.array_equal(e.errs[b], G["it0_errs%d" % b])
+    assert np.array_equal(e.predict(feats, NAMES), G["it0_labels"])
+
+
+def test_compare_neighbor_graphs_counts_injected_errors():
+    """reference annchor/tests/test_annchor.py:15-32."""
+    from annchor_amd import compare_neighbor_graphs
+    from annchor_amd.datasets import load_digits
+
+    ng = load_digits()["neighbor_graph"]
+    assert compare_neighbor_graphs(ng, ng, 30) == 0
+    rs = np.random.RandomState(42)
+    ixs, ds = ng[0].copy(), ng[1].copy()
+    for i in range(ds.shape[0]):
+        ds[i, rs.randint(20, 100)] += rs.random_sample() + 0.01
+    assert compare_neighbor_graphs(ng, (ixs, ds), 100) == ds.shape[0]
+    assert compare_neighbor_graphs(ng, (ixs, ds), 20) == 0
+
+
+def test_datasets_known_values():
+    """reference annchor/tests/test_datasets.py:17-108,205-235."""
+    from annchor_amd.datasets import load_digits, load_strings
+
+    d = load_digits()
+    assert d["X"].shape == (1797, 64) and d["y"].shape == (1797,) and d["neighbor_graph"].shape == (2, 1797, 100)
+    assert d["y"][10] == 0 and int(d["neighbor_graph"][0][10, 15]) == 676
+    s = load_strings()
+    assert s["X"].shape == (1600,) and s["y"].shape == (1600,) and len(s["X"][10]) == 501
