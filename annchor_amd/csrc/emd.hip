@@ -1,8 +1,246 @@
-// emd.hip -- placeholder until the exact-OT kernel lands (next commit).
+// emd.hip -- exact optimal transport (Wasserstein / Kantorovich) between histograms.
+//
+// Replaces, for f = wasserstein (reference annchor/utils.py:75-86 ->
+// pynndescent.distances.kantorovich(x, y, cost=M): restrict x, y to their supports,
+// normalise each to unit mass, return the optimum of the transportation LP), the
+// evaluator get_exact(f, X, IJ) of annchor/utils.py:110-177.
+//
+// Sinkhorn is NOT used for the returned value: SURVEY.md section 7 (hard part 2)
+// measured entropic OT 30-100x outside the tolerance that parity needs (and inexact
+// anchor distances void the triangle bounds).  The kernel is an exact primal-dual
+// solver shaped for a wavefront:
+//   * one wavefront per pair; lane j owns sink j (its demand, potential v_j, tentative
+//     distance, predecessor) and lane i owns source i (supply, u_i);
+//   * Dijkstra on reduced costs over the dense bipartite graph: "pop the nearest
+//     unscanned sink" is a DPP min-reduction, "relax a source row" is one LDS row read
+//     of the cost matrix executed by all lanes;
+//   * the flow matrix F (n x m float64, <= 33 KB) lives in LDS, one slab per wave; the
+//     ground-cost matrix (<= 32 KB) is staged in LDS once per workgroup;
+//   * control flow is wave-uniform (scalar branches); no atomics, no global scratch.
+// Latency/branch bound by nature: reported as pairs/s and
+// microseconds per pair, not as an HBM or MFMA fraction.
 #include "common.h"
 
-int ann_emd_launch(annchor_ctx *c, const PairSource &, double *, double *, uint8_t *)
+#define EMD_MAXB 64
+
+struct EmdArgs {
+    const double *hist;
+    const double *cost;
+    int nb;
+    int S;          // padded row stride of the flow slab (odd)
+    int waves;      // waves per block
+    const int2 *ij;
+    const int32_t *idx;
+    const int32_t *anchor;
+    int64_t n;
+    double *out;
+    double *RA;
+    uint8_t *ncm;
+    int32_t *fail;  // set if the iteration guard trips
+};
+
+// ---- wave-level min over lanes (double), result broadcast; DPP, no LDS traffic
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_f64(double v, double identity)
 {
-    ann_set_err(c, "wasserstein kernel not built into this library yet");
-    return ANNCHOR_EINVAL;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int ilo = __double2loint(identity), ihi = __double2hiint(identity);
+    lo = __builtin_amdgcn_update_dpp(ilo, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(ihi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+    const double inf = INFINITY;
+    v = fmin(v, dpp_f64<0xb1, 0xf>(v, inf));   // quad_perm [1,0,3,2]
+    v = fmin(v, dpp_f64<0x4e, 0xf>(v, inf));   // quad_perm [2,3,0,1]
+    v = fmin(v, dpp_f64<0x141, 0xf>(v, inf));  // row_half_mirror
+    v = fmin(v, dpp_f64<0x140, 0xf>(v, inf));  // row_mirror
+    v = fmin(v, dpp_f64<0x142, 0xa>(v, inf));  // row_bcast:15 -> rows 1,3
+    v = fmin(v, dpp_f64<0x143, 0xc>(v, inf));  // row_bcast:31 -> rows 2,3
+    // lane 63 now holds the minimum of all 64 lanes
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(512) void k_emd(EmdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nb = a.nb, S = a.S;
+    double *costL = reinterpret_cast<double *>(smem);                       // [nb][nb]
+    double *F = costL + nb * nb + (size_t)wave * (EMD_MAXB * S + 2 * EMD_MAXB);  // [<=64][S] flow slab
+    int *rowsL = reinterpret_cast<int *>(F + EMD_MAXB * S);                 // [64] support of x
+    int *colsL = rowsL + EMD_MAXB;                                          // [64] support of y
+    for (int t = threadIdx.x; t < nb * nb; t += blockDim.x) costL[t] = a.cost[t];
+    __syncthreads();
+
+    const int64_t wave_global = (int64_t)blockIdx.x * a.waves + wave;
+    const int64_t wave_stride = (int64_t)gridDim.x * a.waves;
+    for (int64_t t = wave_global; t < a.n; t += wave_stride) {
+        int pi, pj;
+        int64_t opos = t;
+        if (a.anchor) { pi = *a.anchor; pj = (int)t; }
+        else {
+            int64_t q = a.idx ? a.idx[t] : t;
+            int2 p = a.ij[q];
+            pi = p.x; pj = p.y;
+            if (a.idx) opos = q;
+        }
+        pi = __builtin_amdgcn_readfirstlane(pi);
+        pj = __builtin_amdgcn_readfirstlane(pj);
+        const double *hx = a.hist + (size_t)pi * nb, *hy = a.hist + (size_t)pj * nb;
+        // masses and their sums in index order (same order as the oracle: exact parity
+        // of the normalisation for non-integer inputs)
+        const double xk = lane < nb ? hx[lane] : 0.0, yk = lane < nb ? hy[lane] : 0.0;
+        double sa = 0, sb = 0;
+        for (int k = 0; k < nb; ++k) { sa += readlane_f64(xk, k); sb += readlane_f64(yk, k); }
+        const unsigned long long mx = __ballot(xk != 0.0), my = __ballot(yk != 0.0);
+        const int n = __popcll(mx), m = __popcll(my);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (xk != 0.0) rowsL[__popcll(mx & below)] = lane;
+        if (yk != 0.0) colsL[__popcll(my & below)] = lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int myrow = lane < n ? rowsL[lane] : 0;   // source `lane` is histogram bin myrow
+        const int mycol = lane < m ? colsL[lane] : 0;   // sink `lane` is histogram bin mycol
+        double a_rem = lane < n ? hx[myrow] / sa : 0.0;  // supply of source `lane`
+        double b_rem = lane < m ? hy[mycol] / sb : 0.0;  // demand of sink `lane`
+        double u = 0.0;                                  // potential of source `lane`
+        // v_j = min_i C[i][j]
+        double v = INFINITY;
+        for (int i = 0; i < n; ++i) {
+            const int r = __builtin_amdgcn_readlane(myrow, i);
+            if (lane < m) v = fmin(v, costL[r * nb + mycol]);
+        }
+        // zero the flow slab
+        for (int i = 0; i < n; ++i)
+            if (lane < m) F[i * S + lane] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+
+        int guard = 64 * (n + m) + 1024;
+        bool failed = false, dust = false;
+        for (int s = 0; s < n && !dust && !failed; ++s) {
+            const int rs = __builtin_amdgcn_readlane(myrow, s);
+            for (;;) {
+                const double as = readlane_f64(a_rem, s);
+                if (!(as > 0.0)) break;
+                if (--guard < 0) { failed = true; break; }
+                // ---- Dijkstra from source s on reduced costs
+                const double us = readlane_f64(u, s);
+                double dist = lane < m ? costL[rs * nb + mycol] - us - v : INFINITY;
+                int pred = s;
+                unsigned long long sinkdone = 0, srcdone = 1ull << s;
+                double srcdist = 0.0;   // valid on lanes whose srcdone bit is set
+                int srcfrom = -1;
+                int jend = -1;
+                double mu = 0.0;
+                for (;;) {
+                    const bool open = lane < m && !((sinkdone >> lane) & 1ull);
+                    const double best = wave_min_f64(open ? dist : INFINITY);
+                    const unsigned long long hit = __ballot(open && dist == best);
+                    if (!hit) break;                       // every sink scanned: only rounding dust left
+                    const int js = __ffsll((unsigned long long)hit) - 1;  // first index on ties
+                    sinkdone |= 1ull << js;
+                    mu = best;
+                    if (readlane_f64(b_rem, js) > 0.0) { jend = js; break; }
+                    // sources with flow into js that are not scanned yet
+                    const double fcol = lane < n ? F[lane * S + js] : 0.0;
+                    unsigned long long todo = __ballot(lane < n && fcol > 0.0 && !((srcdone >> lane) & 1ull));
+                    while (todo) {
+                        const int i = __ffsll((unsigned long long)todo) - 1;
+                        todo &= todo - 1;
+                        srcdone |= 1ull << i;
+                        if (lane == i) { srcdist = mu; srcfrom = js; }
+                        const int ri = __builtin_amdgcn_readlane(myrow, i);
+                        const double ui = readlane_f64(u, i);
+                        if (lane < m && !((sinkdone >> lane) & 1ull)) {
+                            const double nd = mu + (costL[ri * nb + mycol] - ui - v);
+                            if (nd < dist) { dist = nd; pred = i; }
+                        }
+                    }
+                }
+                if (jend < 0) { dust = true; break; }
+                // ---- potentials
+                if ((srcdone >> lane) & 1ull) u += mu - srcdist;
+                if ((sinkdone >> lane) & 1ull) v -= mu - dist;
+                // ---- bottleneck along the path, then augment
+                double delta = fmin(as, readlane_f64(b_rem, jend));
+                for (int j = jend;;) {
+                    const int i = __builtin_amdgcn_readlane(pred, j);
+                    if (i == s) break;
+                    const int jj = __builtin_amdgcn_readlane(srcfrom, i);
+                    delta = fmin(delta, F[i * S + jj]);   // uniform address: LDS broadcast
+                    j = jj;
+                }
+                for (int j = jend;;) {
+                    const int i = __builtin_amdgcn_readlane(pred, j);
+                    if (lane == 0) F[i * S + j] += delta;
+                    if (i == s) break;
+                    const int jj = __builtin_amdgcn_readlane(srcfrom, i);
+                    if (lane == 0) F[i * S + jj] -= delta;
+                    j = jj;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (lane == s) a_rem -= delta;
+                if (lane == jend) b_rem -= delta;
+            }
+        }
+        // ---- objective
+        double tot = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const int r = __builtin_amdgcn_readlane(myrow, i);
+            if (lane < m) tot += F[i * S + lane] * costL[r * nb + mycol];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        if (failed) { tot = NAN; if (lane == 0) *a.fail = 1; }
+        if (lane == 0) {
+            if (a.out) a.out[t] = tot;
+            if (a.RA) { a.RA[opos] = tot; a.ncm[opos] = 0; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm)
+{
+    if (src.n == 0) return ANNCHOR_OK;
+    EmdArgs a;
+    a.hist = c->hist.as<double>();
+    a.cost = c->cost.as<double>();
+    a.nb = c->nbins;
+    int S = c->max_support | 1;  // odd stride: conflict-free column reads
+    a.S = S;
+    a.ij = src.ij; a.idx = src.idx; a.anchor = src.anchor; a.n = src.n;
+    a.out = d_out; a.RA = d_RA; a.ncm = d_ncm;
+    ANN_TRY(ann_reserve(c, c->supp, 64));
+    a.fail = c->supp.as<int32_t>();
+    ANN_CHECK_HIP(c, hipMemsetAsync(a.fail, 0, 4, c->stream));
+    const size_t cost_bytes = sizeof(double) * (size_t)a.nb * a.nb;
+    const size_t slab = sizeof(double) * ((size_t)EMD_MAXB * S + 2 * EMD_MAXB);
+    int waves = (int)((160 * 1024 - cost_bytes) / slab);
+    if (waves > 8) waves = 8;
+    ANN_REQUIRE(c, waves >= 1, ANNCHOR_ELIMIT, "histogram support %d needs more LDS than a CU has", c->max_support);
+    a.waves = waves;
+    const size_t lds = cost_bytes + slab * waves;
+    ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_emd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t blocks = (src.n + waves - 1) / waves;
+    if (blocks > c->prop.multiProcessorCount) blocks = c->prop.multiProcessorCount;  // one resident block per CU (LDS bound)
+    ProfScope ps(c, "wasserstein_pairs", (double)src.n * (2.0 * a.nb * 8 + 8));
+    k_emd<<<(int)blocks, waves * 64, lds, c->stream>>>(a);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
 }

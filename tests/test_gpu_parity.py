@@ -260,3 +260,79 @@ def test_host_metric_path(strings):
     assert np.array_equal(ann.neighbor_graph[1], ora.neighbor_graph[1])
     assert np.array_equal(ann.neighbor_graph[0], ora.neighbor_graph[0])
     assert sum(calls) >= ora.evals
+
+
+# ------------------------------------------------------------------ metric: a4
+def test_wasserstein_known_answer_and_stored_graph():
+    """reference tests/test_datasets.py:107-108 and the reference's stored exact-EMD graph."""
+    from annchor_amd import _native
+    from annchor_amd.distances import Wasserstein
+
+    d = om.load_digits()
+    X, M, (ngi, ngd) = d["X"], d["cost_matrix"], d["neighbor_graph"]
+    eng = _native.Engine(0)
+    Wasserstein(M).bind(eng, X)
+    assert abs(eng.metric_pairs(np.array([[10, 676]]))[0] - 0.305587260000565) < 1e-12
+    rng = np.random.default_rng(0)
+    rows = rng.integers(0, 1797, 30000)
+    cols = rng.integers(0, 100, 30000)
+    IJ = np.stack([rows, ngi[rows, cols]], axis=1)
+    got = eng.metric_pairs(IJ)
+    # float tolerance: 1e-12 absolute against the reference's stored float64 distances
+    np.testing.assert_allclose(got, ngd[rows, cols], rtol=0, atol=1e-12)
+
+
+def test_wasserstein_pairs_vs_oracle_far_pairs():
+    from annchor_amd import _native
+    from annchor_amd.distances import Wasserstein
+
+    d = om.load_digits()
+    X, M = d["X"], d["cost_matrix"]
+    eng = _native.Engine(0)
+    Wasserstein(M).bind(eng, X)
+    rng = np.random.default_rng(1)
+    IJ = rng.integers(0, 1797, (20000, 2))
+    IJ[:10, 1] = IJ[:10, 0]
+    got = eng.metric_pairs(IJ)
+    want = om.Histograms(X, M).pairs(IJ)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    assert np.all(got[:10] == 0)
+
+
+def test_wasserstein_non_integer_histograms():
+    """General float histograms with sparse and full supports, non-grid cost."""
+    from annchor_amd import _native
+    from annchor_amd.distances import Wasserstein
+
+    rng = np.random.default_rng(2)
+    nb = 24
+    pts = rng.random((nb, 3))
+    M = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+    X = rng.random((200, nb)) * (rng.random((200, nb)) < 0.6)
+    X[:, 0] += 0.1  # no empty histogram
+    X[5] = 1.0      # full support
+    eng = _native.Engine(0)
+    Wasserstein(M).bind(eng, X)
+    IJ = rng.integers(0, 200, (3000, 2))
+    got = eng.metric_pairs(IJ)
+    want = om.Histograms(X, M).pairs(IJ)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+
+
+def test_fit_digits_c4():
+    """BASELINE config 4: digits Wasserstein, N=1797, n_anchors=20, k=25, p_work=0.16."""
+    from annchor_amd import Annchor, compare_neighbor_graphs
+
+    d = om.load_digits()
+    G = np.load(os.path.join(GOLD, "digits_full.npz"))
+    ann = Annchor(d["X"], "wasserstein", func_kwargs={"cost_matrix": d["cost_matrix"]}, n_anchors=20,
+                  n_neighbors=25, n_samples=5000, p_work=0.16, random_seed=42).fit()
+    assert np.array_equal(ann.A, G["c4_A"])
+    np.testing.assert_allclose(ann.D, G["c4_D"], rtol=0, atol=1e-12)
+    assert ann.evals == int(G["c4_evals"])
+    err = compare_neighbor_graphs(d["neighbor_graph"], ann.neighbor_graph, 25)
+    assert err <= 10, err  # reference run: 7 of 44 925; reference test bar: < 10
+    # every reported distance within 1e-9 of the exact EMD of the reported neighbour
+    idx, dist = ann.neighbor_graph
+    IJ = np.stack([np.repeat(np.arange(1797), 24), idx[:, 1:].ravel()], axis=1)
+    np.testing.assert_allclose(om.Histograms(d["X"], d["cost_matrix"]).pairs(IJ), dist[:, 1:].ravel(), rtol=0, atol=1e-9)
