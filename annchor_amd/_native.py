@@ -49,6 +49,7 @@ _SIGNATURES = {
     "annchor_kth_uncomputed_dad": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
     "annchor_bin_counts": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
     "annchor_select_by_rank": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _vp]),
+    "annchor_legacy_choice_ranks": (ctypes.c_int, [ctypes.c_uint32, _vp, _vp, _i32, _vp, _vp]),
     "annchor_gather_features": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "annchor_evaluate_samples": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "annchor_set_samples": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
@@ -102,6 +103,19 @@ def _ptr(a):
 
 def _c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
+
+
+def legacy_choice_ranks(seed, counts, want):
+    """np.random.seed(seed); per bin np.random.permutation(counts[b])[:want[b]] (or the whole
+    bin when it is smaller) -- NumPy's legacy stream, generated by the library's host code."""
+    lib = load_library()
+    counts, want = _c(counts, np.int64), _c(want, np.int64)
+    out = np.zeros(int(np.minimum(counts, want).sum()), dtype=np.int64)
+    n_out = np.zeros(len(counts), dtype=np.int64)
+    rc = lib.annchor_legacy_choice_ranks(int(seed) & 0xFFFFFFFF, _ptr(counts), _ptr(want), len(counts), _ptr(out), _ptr(n_out))
+    if rc != 0:
+        raise NativeError("annchor_legacy_choice_ranks failed (%d)" % rc)
+    return np.split(out, np.cumsum(n_out)[:-1])
 
 
 class Engine:

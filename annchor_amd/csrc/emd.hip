@@ -99,7 +99,7 @@ __global__ __launch_bounds__(512) void k_emd(EmdArgs a)
         pi = __builtin_amdgcn_readfirstlane(pi);
         pj = __builtin_amdgcn_readfirstlane(pj);
         const double *hx = a.hist + (size_t)pi * nb, *hy = a.hist + (size_t)pj * nb;
-        // masses and their sums in index order (same order as the oracle: exact parity
+        // masses and their sums in index order (sequential index order: exact parity
         // of the normalisation for non-integer inputs)
         const double xk = lane < nb ? hx[lane] : 0.0, yk = lane < nb ? hy[lane] : 0.0;
         double sa = 0, sb = 0;

@@ -9,9 +9,11 @@
 //   * The shorter string of a pair is the bit-vector "pattern", cut into 32-bit
 //     words; word w of pair slot g lives in lane g*G + w (G = words of the longest
 //     string in the data set).  P = 64/G pairs share one wavefront.
-//   * The longer string is the "text".  At step t lane w processes text column
-//     t - w: the column's symbol and the two horizontal carry bits travel down the
-//     lanes through one `wave_shr:1` DPP move per step (no LDS, no shuffle unit).
+//   * The longer string is the "text".  At iteration k lane w processes text columns
+//     2(k-w) and 2(k-w)+1: their four horizontal carry bits travel down the lanes through
+//     one `wave_shr:1` DPP move per iteration (no LDS, no shuffle unit); the loop body is
+//     branch-free and its LDS reads (text pair, two match masks) are software-pipelined
+//     two iterations deep, so only the DPP carry chain is loop-carried.
 //   * Per-pattern match masks PM[symbol][word] sit in LDS (alphabet * G * 4 B per
 //     pair slot, e.g. 2 KB for a-z and 600-char strings); every lane fetches one
 //     dword per step, bank-conflict free within a symbol.
@@ -122,39 +124,66 @@ __global__ __launch_bounds__(LEV_THREADS) void k_lev(LevArgs a)
         }
         wave_lds_fence();
 
-        // ---- systolic sweep
+        // ---- systolic sweep, two text columns per iteration.  At iteration k lane w handles
+        // columns 2(k-w) and 2(k-w)+1; the two symbols and the four carry bits of the lane
+        // above arrive in one register through one DPP move.  Validity is a function of
+        // (k - w, n) alone, so no flag travels with the data and the loop body is branch-free.
         uint32_t vp = 0xffffffffu, vn = 0u;
         int score = m;
         const uint32_t last = (active && w == Wp - 1) ? (1u << ((m - 1) & 31)) : 0u;
-        int steps = (active && m > 0) ? n + Wp - 1 : 0;
-        // wave-uniform trip count
+        const uint32_t un = (active && m > 0) ? (uint32_t)n : 0u;
+        int steps = (active && m > 0) ? ((n + 1) >> 1) + Wp - 1 : 0;
         int max_steps = steps;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) max_steps = max(max_steps, __shfl_xor(max_steps, off));
         max_steps = __builtin_amdgcn_readfirstlane(max_steps);
-        uint32_t packed = 0;  // [7:0] symbol, [8] hp carry, [9] hn carry, [10] valid
-        for (int t = 0; t < max_steps; ++t) {
-            uint32_t in = dpp_wave_shr1(packed);
-            if (w == 0) {
-                uint32_t c = (t < n) ? (uint32_t)txt_g[t] : 0u;
-                in = (t < n && active) ? (c | 0x100u | 0x400u) : 0u;  // top row: +1 horizontal delta
-            }
-            const uint32_t c = in & 0xffu;
-            const uint32_t hpc = (in >> 8) & 1u, hnc = (in >> 9) & 1u;
-            const bool valid = (in & 0x400u) != 0;
-            const uint32_t eq = pm_g[c * G + w];
-            const uint32_t x = eq | hnc;
-            const uint32_t d0 = (((x & vp) + vp) ^ vp) | x | vn;
+        const uint32_t *pm_w = pm_g + w;
+        const uint16_t *txt2 = reinterpret_cast<const uint16_t *>(txt_g);
+        const int tmax = (a.text_stride >> 1) - 1;
+        // Two-deep software pipeline over LDS: the text pair of iteration k+2 and the match
+        // masks of iteration k+1 are requested while iteration k computes, so neither LDS
+        // latency sits on the loop-carried dependency (which is the DPP carry chain only).
+        auto text_at = [&](int kk) -> uint32_t { return txt2[min(max(kk, 0), tmax)]; };
+        uint32_t c0 = text_at(0 - w), c1 = text_at(1 - w);
+        uint32_t eqA = pm_w[(c0 & 0xffu) * G], eqB = pm_w[(c0 >> 8) * G];
+        uint32_t carry = 0;  // [0] hpA, [1] hnA, [2] hpB, [3] hnB of this lane's last iteration
+        for (int k = 0; k < max_steps; ++k) {
+            const uint32_t c2 = text_at(k + 2 - w);
+            const uint32_t eqA_n = pm_w[(c1 & 0xffu) * G], eqB_n = pm_w[(c1 >> 8) * G];
+            uint32_t in = dpp_wave_shr1(carry);
+            // keep the three LDS requests above the arithmetic (hipcc otherwise rotates the loop
+            // and waits for each request right where it was issued)
+            __builtin_amdgcn_sched_barrier(0);
+            in = (w == 0) ? 0x5u : in;  // top row of the DP: +1 horizontal delta, never -1
+            const uint32_t col = (uint32_t)(k - w) * 2u;  // huge when k < w
+            const bool vA = col < un, vB = (col + 1u) < un;
+            // ---- column A
+            uint32_t hpc = in & 1u, hnc = (in >> 1) & 1u;
+            uint32_t x = eqA | hnc;
+            uint32_t d0 = (((x & vp) + vp) ^ vp) | x | vn;
             uint32_t hp = vn | ~(d0 | vp);
             uint32_t hn = d0 & vp;
-            const uint32_t hpo = hp >> 31, hno = hn >> 31;
-            const int ds = ((hp & last) != 0) - ((hn & last) != 0);
+            const uint32_t hpoA = hp >> 31, hnoA = hn >> 31;
+            int ds = ((hp & last) != 0) - ((hn & last) != 0);
             hp = (hp << 1) | hpc;
             hn = (hn << 1) | hnc;
-            const uint32_t nvp = hn | ~(d0 | hp);
-            const uint32_t nvn = hp & d0;
-            if (valid) { vp = nvp; vn = nvn; score += ds; }
-            packed = valid ? (c | (hpo << 8) | (hno << 9) | 0x400u) : 0u;
+            uint32_t nvp = hn | ~(d0 | hp), nvn = hp & d0;
+            vp = vA ? nvp : vp; vn = vA ? nvn : vn; score += vA ? ds : 0;
+            // ---- column B
+            hpc = (in >> 2) & 1u; hnc = (in >> 3) & 1u;
+            x = eqB | hnc;
+            d0 = (((x & vp) + vp) ^ vp) | x | vn;
+            hp = vn | ~(d0 | vp);
+            hn = d0 & vp;
+            const uint32_t hpoB = hp >> 31, hnoB = hn >> 31;
+            ds = ((hp & last) != 0) - ((hn & last) != 0);
+            hp = (hp << 1) | hpc;
+            hn = (hn << 1) | hnc;
+            nvp = hn | ~(d0 | hp); nvn = hp & d0;
+            vp = vB ? nvp : vp; vn = vB ? nvn : vn; score += vB ? ds : 0;
+            carry = hpoA | (hnoA << 1) | (hpoB << 2) | (hnoB << 3);
+            __builtin_amdgcn_sched_barrier(0);  // consume the prefetched values only down here
+            eqA = eqA_n; eqB = eqB_n; c1 = c2;
         }
         if (active) {
             const bool writer = (m == 0) ? (w == 0) : (w == Wp - 1);

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row_thresh(const int64_t *__res
 // sorted by (value, slot)
 __global__ __launch_bounds__(ROW_THREADS) void k_gn_lists(const int64_t *__restrict__ Iptr, const int32_t *__restrict__ Iidx,
                                                          const double *__restrict__ RA, const uint8_t *__restrict__ ncm,
-                                                         int L, double *__restrict__ gl_val, int32_t *__restrict__ gl_pos,
+                                                         const int2 *__restrict__ ij, int L, double *__restrict__ gl_val,
+                                                         int32_t *__restrict__ gl_pos, int32_t *__restrict__ gl_oth,
                                                          int32_t *__restrict__ gl_cnt, int32_t *__restrict__ gl_ncomp)
 {
     __shared__ RowSelShared sh;
@@ -108,8 +109,102 @@ __global__ __launch_bounds__(ROW_THREADS) void k_gn_lists(const int64_t *__restr
         const int32_t se = lslot[e];
         int r = 0;
         for (int o = 0; o < want; ++o) r += (lkey[o] < ke) || (lkey[o] == ke && lslot[o] < se);
+        const int32_t p = Iidx[b + se];
+        const int2 q = ij[p];
         gl_val[i * L + r] = ann_key_asc_inv(ke);
-        gl_pos[i * L + r] = Iidx[b + se];
+        gl_pos[i * L + r] = p;
+        gl_oth[i * L + r] = q.x == (int)i ? q.y : q.x;
+    }
+}
+
+// twin[i][e] = slot of the same pair in the other endpoint's list, or -1
+__global__ void k_gn_twin(int64_t nx, int L, const int32_t *__restrict__ gl_pos, const int32_t *__restrict__ gl_oth,
+                          const int32_t *__restrict__ gl_cnt, int32_t *__restrict__ gl_twin)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nx * L) return;
+    const int64_t i = t / L;
+    const int e = (int)(t - i * L);
+    int tw = -1;
+    if (e < gl_cnt[i]) {
+        const int32_t p = gl_pos[t], j = gl_oth[t];
+        const int cj = gl_cnt[j];
+        for (int o = 0; o < cj; ++o)
+            if (gl_pos[(int64_t)j * L + o] == p) { tw = o; break; }
+    }
+    gl_twin[t] = tw;
+}
+
+// LDS form of the sequential sweep (utils.py:611-619): all state that one row hands to
+// the next -- "this entry of your list is already -1" flags and the per-row count of -1
+// entries -- lives in LDS; the per-row lists are read-only and prefetched one row ahead.
+__global__ __launch_bounds__(64) void k_gn_sweep_lds(int64_t nx, int nmin, int L, const double *__restrict__ gl_val,
+                                                    const int32_t *__restrict__ gl_pos, const int32_t *__restrict__ gl_oth,
+                                                    const int32_t *__restrict__ gl_twin, const int32_t *__restrict__ gl_cnt,
+                                                    const int32_t *__restrict__ gl_ncomp, double *__restrict__ RA,
+                                                    int32_t *__restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    const int lane = threadIdx.x;
+    const int Lw = (L + 31) / 32;
+    uint32_t *mflag = reinterpret_cast<uint32_t *>(dyn);   // [nx][Lw] bit e: entry e of the row is marked
+    int32_t *mcount = reinterpret_cast<int32_t *>(mflag + (size_t)nx * Lw);  // [nx]
+    for (int64_t t = lane; t < nx * Lw; t += 64) mflag[t] = 0;
+    for (int64_t t = lane; t < nx; t += 64) mcount[t] = 0;
+    __syncthreads();
+    const int chunks = (L + 63) / 64;
+    // prefetch registers for chunk 0 of the next row
+    double nv = 0; int32_t np_ = 0, no = 0, nt = -1; int ncnt = 0, nncomp = 0;
+    auto fetch = [&](int64_t r) {
+        if (r < nx) {
+            ncnt = gl_cnt[r]; nncomp = gl_ncomp[r];
+            if (lane < L) { nv = gl_val[r * L + lane]; np_ = gl_pos[r * L + lane]; no = gl_oth[r * L + lane]; nt = gl_twin[r * L + lane]; }
+        }
+    };
+    fetch(0);
+    for (int64_t i = 0; i < nx; ++i) {
+        const double v0 = nv; const int32_t p0 = np_, o0 = no, t0 = nt; const int cnt = ncnt, ncomp = nncomp;
+        fetch(i + 1);
+        const int ntodo = nmin - ncomp;
+        if (ntodo <= 0) continue;
+        if (cnt <= ntodo && cnt < L) { if (lane == 0) *err = 1; continue; }
+        const int need = ntodo + 1 - mcount[i];
+        if (need <= 0) continue;
+        double t = 0;
+        bool found = false;
+        int cum = 0;
+        for (int ch = 0; ch < chunks && !found; ++ch) {
+            const int e = ch * 64 + lane;
+            const bool valid = e < cnt;
+            const double v = ch == 0 ? v0 : (valid ? gl_val[i * L + e] : 0.0);
+            const bool um = valid && !((mflag[i * Lw + (e >> 5)] >> (e & 31)) & 1u);
+            const unsigned long long m = __ballot(um);
+            const int cm = __popcll(m);
+            if (cum + cm >= need) {
+                const int want = need - cum - 1;
+                const int myrank = __popcll(m & ((1ull << lane) - 1ull));
+                const unsigned long long hit = __ballot(um && myrank == want);
+                t = __shfl(v, __ffsll((unsigned long long)hit) - 1);
+                found = true;
+            }
+            cum += cm;
+        }
+        if (!found) { if (lane == 0) *err = 2; continue; }
+        for (int ch = 0; ch < chunks; ++ch) {
+            const int e = ch * 64 + lane;
+            if (e < cnt) {
+                const double v = ch == 0 ? v0 : gl_val[i * L + e];
+                const int32_t p = ch == 0 ? p0 : gl_pos[i * L + e];
+                const int32_t o = ch == 0 ? o0 : gl_oth[i * L + e];
+                const int32_t tw = ch == 0 ? t0 : gl_twin[i * L + e];
+                if (v < t && !((mflag[i * Lw + (e >> 5)] >> (e & 31)) & 1u)) {
+                    RA[p] = -1.0;
+                    if (tw >= 0) atomicOr(&mflag[(int64_t)o * Lw + (tw >> 5)], 1u << (tw & 31));
+                    atomicAdd(&mcount[o], 1);
+                }
+            }
+        }
+        __syncthreads();  // single wave: orders this row's LDS updates before the next row's reads
     }
 }
 
@@ -374,7 +469,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         const int L = nmin + 1;
         ANN_REQUIRE(c, L <= 1024, ANNCHOR_ELIMIT, "nmin=%d too large", nmin);
         ANN_TRY(ann_reserve(c, c->gl_val, sizeof(double) * (size_t)nx * L));
-        ANN_TRY(ann_reserve(c, c->gl_pos, sizeof(int32_t) * (size_t)nx * L));
+        ANN_TRY(ann_reserve(c, c->gl_pos, sizeof(int32_t) * (size_t)nx * L * 3));  // pos | other endpoint | twin
         ANN_TRY(ann_reserve(c, c->gl_cnt, sizeof(int32_t) * (size_t)nx));
         ANN_TRY(ann_reserve(c, c->gl_ncomp, sizeof(int32_t) * (size_t)nx));
         ANN_TRY(ann_reserve(c, c->marked, (size_t)n));
@@ -386,10 +481,23 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         {
             ProfScope ps(c, "guarantee_nmin_lists", (double)n * 26.0);
             k_gn_lists<<<(int)nx, ROW_THREADS, (size_t)L * 12, c->stream>>>(
-                c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(), c->RA.as<double>(), c->ncm.as<uint8_t>(), L,
-                c->gl_val.as<double>(), c->gl_pos.as<int32_t>(), c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>());
+                c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(), c->RA.as<double>(), c->ncm.as<uint8_t>(), c->ij.as<int2>(), L,
+                c->gl_val.as<double>(), c->gl_pos.as<int32_t>(), c->gl_pos.as<int32_t>() + (size_t)nx * L,
+                c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>());
         }
-        {
+        const size_t sweep_lds = (size_t)nx * (((size_t)L + 31) / 32 * 4 + 4);
+        if (sweep_lds <= 150 * 1024) {
+            ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 21.0);
+            int32_t *oth = c->gl_pos.as<int32_t>() + (size_t)nx * L, *twin = oth + (size_t)nx * L;
+            k_gn_twin<<<ann_blocks(nx * L, 256), 256, 0, c->stream>>>(nx, L, c->gl_pos.as<int32_t>(), oth,
+                                                                     c->gl_cnt.as<int32_t>(), twin);
+            if (sweep_lds > 64 * 1024)
+                ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_gn_sweep_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)sweep_lds));
+            k_gn_sweep_lds<<<1, 64, sweep_lds, c->stream>>>(nx, nmin, L, c->gl_val.as<double>(), c->gl_pos.as<int32_t>(), oth,
+                                                           twin, c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
+                                                           c->RA.as<double>(), c->tmp2.as<int32_t>());
+        } else {
             ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 13.0);
             k_gn_sequential<<<1, 64, 0, c->stream>>>(nx, nmin, L, c->gl_val.as<double>(), c->gl_pos.as<int32_t>(),
                                                     c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(), c->ij.as<int2>(),

@@ -117,21 +117,22 @@ class SimpleStratifiedSampler(Sampler):
             raise NothingToSample()
         counts = engine.bin_counts(sample_bins)
         bin_size, remainder = n_samples // self.n_partitions, n_samples % self.n_partitions
-        np.random.seed(random_seed + self.loop_num)
+        from . import _native
+
+        want = np.array([bin_size + (nbin < remainder) for nbin in range(self.n_partitions)], dtype=np.int64)
+        seed = random_seed + self.loop_num
+        if 0 <= seed < 2 ** 32:
+            per_bin = _native.legacy_choice_ranks(seed, counts, want)
+        else:  # outside the legacy int-seed range NumPy raises; keep its behaviour
+            np.random.seed(seed)
+            per_bin = [np.arange(c) if c < w else np.random.permutation(int(c))[:w] for c, w in zip(counts, want)]
         bin_of, ranks = [], []
-        for nbin in range(self.n_partitions):
-            want = bin_size + (nbin < remainder)
-            c = int(counts[nbin])
-            if c < want:
-                r = np.arange(c, dtype=np.int64)
-            else:
-                # np.random.choice(ixmask, size=want, replace=False) == ixmask[permutation(c)[:want]]
-                r = np.random.permutation(c)[:want].astype(np.int64)
+        for nbin, r in enumerate(per_bin):
             if len(r) < 2:
                 self.loop_num += 1
                 raise Exception("Some sampler bins contain too few samples")
             bin_of.append(np.full(len(r), nbin, dtype=np.int32))
-            ranks.append(r)
+            ranks.append(np.asarray(r, dtype=np.int64))
         self.loop_num += 1
         bin_of, ranks = np.concatenate(bin_of), np.concatenate(ranks)
         sample_ixs = engine.select_by_rank(sample_bins, bin_of, ranks)

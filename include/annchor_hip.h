@@ -129,6 +129,14 @@ int annchor_bin_counts(annchor_ctx *ctx, const double *bins, int32_t nbins, int6
  * order) uncomputed pair inside bin bin_of[t]. */
 int annchor_select_by_rank(annchor_ctx *ctx, const double *bins, int32_t nbins, const int32_t *bin_of,
                            const int64_t *ranks, int64_t nreq, int64_t *positions);
+/* Host-only helper (no device work, no context): the draws of
+ * `np.random.seed(seed)` followed, per bin, by
+ * `np.random.choice(ixmask, want[b], replace=False)` (annchor/utils.py:543-578),
+ * returned as ranks into the bin (= positions of the legacy permutation prefix);
+ * a bin with counts[b] < want[b] yields 0..counts[b]-1 without consuming the stream.
+ * ranks_out must hold sum(min(counts, want)); n_out[b] = entries written for bin b. */
+int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins,
+                                int64_t *ranks_out, int64_t *n_out);
 /* Gather features [m, 4] at the given pair positions (self.features[sample_ixs]). */
 int annchor_gather_features(annchor_ctx *ctx, const int64_t *pos, int64_t m, double *feats);
 /* get_sample (annchor.py:336-343): evaluate the metric on the sample pairs, clear

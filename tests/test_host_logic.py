@@ -130,3 +130,21 @@ def test_datasets_known_values():
     assert d["y"][10] == 0 and int(d["neighbor_graph"][0][10, 15]) == 676
     s = load_strings()
     assert s["X"].shape == (1600,) and s["y"].shape == (1600,) and len(s["X"][10]) == 501
+
+
+def test_library_rng_matches_numpy_legacy_stream():
+    """annchor_legacy_choice_ranks (host code of the library) == NumPy's legacy stream."""
+    import __graft_entry__ as g
+
+    g.build()
+    from annchor_amd import _native
+
+    cases = [([667, 37493, 60, 5, 4, 18000, 873, 1, 0, 715, 2, 3], [715, 715, 714, 714, 714, 714, 714, 0, 0, 715, 2, 2]),
+             ([1700, 18800, 17100, 17600, 18300, 33000, 18500], [715, 715, 714, 714, 714, 714, 714]),
+             ([1, 2, 3], [1, 1, 3])]
+    for seed in (0, 42, 43, 2 ** 32 - 1):
+        for counts, want in cases:
+            got = _native.legacy_choice_ranks(seed, counts, want)
+            np.random.seed(seed)
+            ref = [np.arange(c) if c < w else np.random.permutation(int(c))[:w] for c, w in zip(counts, want)]
+            assert all(np.array_equal(a, b) for a, b in zip(got, ref))
