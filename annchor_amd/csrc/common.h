@@ -16,6 +16,7 @@
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool in_arena = false;  // carved from the context arena (not individually freed)
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -36,6 +37,11 @@ struct annchor_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     hipDeviceProp_t prop;
+
+    // ---- one slab per context, sized from nx when the data set is bound, from which the
+    // pipeline buffers are carved: fit() then runs without hipMalloc/hipFree calls
+    char *arena = nullptr;
+    size_t arena_size = 0, arena_off = 0;
 
     // ---- data set
     int metric = ANNCHOR_METRIC_NONE;
@@ -120,6 +126,7 @@ const char *ann_set_err(annchor_ctx *c, const char *fmt, ...);
     } while (0)
 
 int ann_reserve(annchor_ctx *c, DevBuf &b, size_t bytes);
+int ann_arena_init(annchor_ctx *c, int64_t nx);
 int ann_h2d(annchor_ctx *c, void *dst, const void *src, size_t bytes);
 int ann_d2h(annchor_ctx *c, void *dst, const void *src, size_t bytes);
 

@@ -20,12 +20,36 @@ int ann_reserve(annchor_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return ANNCHOR_OK;
-    if (b.p) ANN_CHECK_HIP(c, hipFree(b.p));
+    size_t want = (bytes + 255) & ~(size_t)255;
+    if (c->arena && c->arena_off + want <= c->arena_size) {
+        if (b.p && !b.in_arena) ANN_CHECK_HIP(c, hipFree(b.p));
+        b.p = c->arena + c->arena_off;  // a previous (smaller) arena slice is simply abandoned
+        c->arena_off += want;
+        b.cap = want;
+        b.in_arena = true;
+        return ANNCHOR_OK;
+    }
+    if (b.p && !b.in_arena) ANN_CHECK_HIP(c, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
-    size_t want = (bytes + 255) & ~(size_t)255;
+    b.in_arena = false;
     ANN_CHECK_HIP(c, hipMalloc(&b.p, want));
     b.cap = want;
+    return ANNCHOR_OK;
+}
+
+int ann_arena_init(annchor_ctx *c, int64_t nx)
+{
+    if (c->arena) return ANNCHOR_OK;  // one slab per context
+    // pair-list state is ~100 B per candidate pair (worst case: all pairs) + O(nx) rows
+    double pairs = 0.5 * (double)nx * (double)(nx - 1);
+    if (pairs > 32e6) pairs = 32e6;  // larger problems fall back to per-buffer allocations beyond the slab
+    size_t bytes = (size_t)(pairs * 112.0) + (size_t)nx * 4096 + ((size_t)64 << 20);
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return ANNCHOR_OK; }  // optional
+    c->arena = (char *)p;
+    c->arena_size = bytes;
+    c->arena_off = 0;
     return ANNCHOR_OK;
 }
 
@@ -163,7 +187,8 @@ extern "C" void annchor_destroy(annchor_ctx *c)
                       &c->cptr, &c->cidx, &c->cval, &c->tmp0, &c->tmp1, &c->tmp2, &c->tmp3, &c->scan_tmp,
                       &c->stage_in, &c->stage_out};
     for (DevBuf *b : bufs)
-        if (b->p) (void)hipFree(b->p);
+        if (b->p && !b->in_arena) (void)hipFree(b->p);
+    if (c->arena) (void)hipFree(c->arena);
     if (c->call_a) (void)hipEventDestroy(c->call_a);
     if (c->call_b) (void)hipEventDestroy(c->call_b);
     (void)hipStreamDestroy(c->stream);
@@ -210,6 +235,7 @@ extern "C" int annchor_set_opaque(annchor_ctx *c, int64_t nx)
     if (!c) return ANNCHOR_EINVAL;
     ANN_REQUIRE(c, nx > 1 && nx < (1ll << 31), ANNCHOR_ELIMIT, "nx=%lld out of range", (long long)nx);
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(ann_arena_init(c, nx));
     c->metric = ANNCHOR_METRIC_NONE;
     c->nx = nx;
     reset_pipeline(c);
@@ -242,6 +268,7 @@ extern "C" int annchor_set_strings(annchor_ctx *c, const uint8_t *symbols, const
                         (long long)s);
         memcpy(pool.data() + o[(size_t)s], symbols + offs[s], (size_t)lens[s]);
     }
+    ANN_TRY(ann_arena_init(c, nx));
     ANN_TRY(ann_reserve(c, c->sym, pool.size()));
     ANN_TRY(ann_reserve(c, c->soff, sizeof(int32_t) * (size_t)nx));
     ANN_TRY(ann_reserve(c, c->slen, sizeof(int32_t) * (size_t)nx));
@@ -263,6 +290,7 @@ static int set_points(annchor_ctx *c, const void *X, int64_t nx, int32_t dim, si
     ANN_REQUIRE(c, dim >= 1 && dim <= 65536, ANNCHOR_ELIMIT, "dim=%d out of range", dim);
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     size_t bytes = esz * (size_t)nx * (size_t)dim;
+    ANN_TRY(ann_arena_init(c, nx));
     ANN_TRY(ann_reserve(c, c->pts, bytes));
     ANN_TRY(ann_h2d(c, c->pts.p, X, bytes));
     c->metric = metric;
@@ -296,6 +324,7 @@ extern "C" int annchor_set_histograms(annchor_ctx *c, const double *hist, int64_
         ANN_REQUIRE(c, k > 0, ANNCHOR_EINVAL, "histogram %lld is empty", (long long)s);
         if (k > maxs) maxs = k;
     }
+    ANN_TRY(ann_arena_init(c, nx));
     ANN_TRY(ann_reserve(c, c->hist, sizeof(double) * (size_t)nx * nbins));
     ANN_TRY(ann_reserve(c, c->cost, sizeof(double) * (size_t)nbins * nbins));
     ANN_TRY(ann_h2d(c, c->hist.p, hist, sizeof(double) * (size_t)nx * nbins));

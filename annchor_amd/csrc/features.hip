@@ -186,16 +186,28 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_count(const double *__restric
     for (int t = threadIdx.x; t < be.nb; t += blockDim.x) blkcnt[(size_t)blockIdx.x * be.nb + t] = lc[t];
 }
 
-__global__ void k_rb_scan(uint32_t *__restrict__ blkcnt, int nblocks, int nb)
+__global__ __launch_bounds__(256) void k_rb_scan(uint32_t *__restrict__ blkcnt, int nblocks, int nb)
 {
-    // thread b scans bin b over the blocks (nblocks is a few hundred)
-    int b = threadIdx.x;
-    if (b >= nb) return;
-    uint32_t run = 0;
-    for (int k = 0; k < nblocks; ++k) {
-        uint32_t v = blkcnt[(size_t)k * nb + b];
-        blkcnt[(size_t)k * nb + b] = run;
-        run += v;
+    // block b scans bin b over the tiles (exclusive, in tile order)
+    __shared__ uint32_t wsum[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += 256) {
+        const int k = base + threadIdx.x;
+        const uint32_t v = k < nblocks ? blkcnt[(size_t)k * nb + b] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wave) pre += wsum[w]; tot += wsum[w]; }
+        if (k < nblocks) blkcnt[(size_t)k * nb + b] = carry + pre + inc - v;
+        carry += tot;
     }
 }
 
@@ -274,7 +286,7 @@ extern "C" int annchor_select_by_rank(annchor_ctx *c, const double *bins, int32_
                                                                      c->tmp0.as<int32_t>());
         k_rb_count<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be,
                                                          c->blk_cnt.as<uint32_t>());
-        k_rb_scan<<<1, MAXBINS, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nblocks, nbins);
+        k_rb_scan<<<nbins, 256, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nblocks, nbins);
         k_rb_emit<<<nblocks, 64, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be, c->blk_cnt.as<uint32_t>(),
                                                 c->tmp1.as<int64_t>(), c->tmp0.as<int32_t>(), c->stage_out.as<int64_t>());
     }

@@ -47,7 +47,7 @@ struct LevArgs {
     int alphabet;
     int text_stride;  // bytes of LDS text per slot (multiple of 16)
     int pm_bytes;     // bytes of PM per wave (multiple of 16)
-    int wave_bytes;   // pm_bytes + P * text_stride
+    int wave_bytes;   // pm_bytes + P * text_stride + 256
 };
 
 // LDS traffic of one wave is ordered by the hardware; this only stops the compiler
@@ -68,6 +68,7 @@ __global__ __launch_bounds__(LEV_THREADS) void k_lev(LevArgs a)
     const int G = a.G, P = a.P, A = a.alphabet;
     uint32_t *pm = reinterpret_cast<uint32_t *>(smem + (size_t)wave * a.wave_bytes);
     unsigned char *txt = smem + (size_t)wave * a.wave_bytes + a.pm_bytes;
+    int *ssum = reinterpret_cast<int *>(txt + (size_t)a.P * a.text_stride);  // [P] per-slot popcount sums
 
     const int g = lane / G;          // pair slot of this lane
     const int w = lane - g * G;      // word index inside the slot
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(LEV_THREADS) void k_lev(LevArgs a)
         const uint8_t *tex = a.sym + (active ? a.soff[ts] : 0);
         const int Wp = (m + 31) >> 5;
 
+        if (slot_ok && w == 0) ssum[g] = 0;
         // ---- build PM column of this lane: zero, then OR in the 32 pattern symbols
         if (slot_ok)
             for (int c = 0; c < A; ++c) pm_g[c * G + w] = 0u;
@@ -129,8 +131,6 @@ __global__ __launch_bounds__(LEV_THREADS) void k_lev(LevArgs a)
         // above arrive in one register through one DPP move.  Validity is a function of
         // (k - w, n) alone, so no flag travels with the data and the loop body is branch-free.
         uint32_t vp = 0xffffffffu, vn = 0u;
-        int score = m;
-        const uint32_t last = (active && w == Wp - 1) ? (1u << ((m - 1) & 31)) : 0u;
         const uint32_t un = (active && m > 0) ? (uint32_t)n : 0u;
         int steps = (active && m > 0) ? ((n + 1) >> 1) + Wp - 1 : 0;
         int max_steps = steps;
@@ -164,11 +164,10 @@ __global__ __launch_bounds__(LEV_THREADS) void k_lev(LevArgs a)
             uint32_t hp = vn | ~(d0 | vp);
             uint32_t hn = d0 & vp;
             const uint32_t hpoA = hp >> 31, hnoA = hn >> 31;
-            int ds = ((hp & last) != 0) - ((hn & last) != 0);
             hp = (hp << 1) | hpc;
             hn = (hn << 1) | hnc;
             uint32_t nvp = hn | ~(d0 | hp), nvn = hp & d0;
-            vp = vA ? nvp : vp; vn = vA ? nvn : vn; score += vA ? ds : 0;
+            vp = vA ? nvp : vp; vn = vA ? nvn : vn;
             // ---- column B
             hpc = (in >> 2) & 1u; hnc = (in >> 3) & 1u;
             x = eqB | hnc;
@@ -176,22 +175,26 @@ __global__ __launch_bounds__(LEV_THREADS) void k_lev(LevArgs a)
             hp = vn | ~(d0 | vp);
             hn = d0 & vp;
             const uint32_t hpoB = hp >> 31, hnoB = hn >> 31;
-            ds = ((hp & last) != 0) - ((hn & last) != 0);
             hp = (hp << 1) | hpc;
             hn = (hn << 1) | hnc;
             nvp = hn | ~(d0 | hp); nvn = hp & d0;
-            vp = vB ? nvp : vp; vn = vB ? nvn : vn; score += vB ? ds : 0;
+            vp = vB ? nvp : vp; vn = vB ? nvn : vn;
             carry = hpoA | (hnoA << 1) | (hpoB << 2) | (hnoB << 3);
             __builtin_amdgcn_sched_barrier(0);  // consume the prefetched values only down here
             eqA = eqA_n; eqB = eqB_n; c1 = c2;
         }
-        if (active) {
-            const bool writer = (m == 0) ? (w == 0) : (w == Wp - 1);
-            if (writer) {
-                const double d = (m == 0) ? (double)n : (double)score;
-                if (a.out) a.out[t_pair] = d;
-                if (a.RA) { a.RA[opos] = d; a.ncm[opos] = 0; }
-            }
+        // D[m][n] = D[0][n] + sum of the vertical deltas of the last column
+        //         = n + popcount(VP & rows) - popcount(VN & rows), summed over the slot's words
+        if (active && w < Wp) {
+            const uint32_t rows = (w == Wp - 1) ? (0xffffffffu >> (31 - ((m - 1) & 31))) : 0xffffffffu;
+            const int part = __popc(vp & rows) - __popc(vn & rows);
+            if (part) atomicAdd(&ssum[g], part);
+        }
+        wave_lds_fence();
+        if (active && w == 0) {
+            const double d = (double)(n + ssum[g]);  // m == 0: no word contributes, d = n
+            if (a.out) a.out[t_pair] = d;
+            if (a.RA) { a.RA[opos] = d; a.ncm[opos] = 0; }
         }
         wave_lds_fence();
     }
@@ -220,7 +223,7 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
     a.alphabet = c->alphabet;
     a.text_stride = ((c->maxlen + 15) & ~15) + 16;
     a.pm_bytes = (int)((((size_t)a.P * a.alphabet * G * 4) + 15) & ~(size_t)15);
-    a.wave_bytes = a.pm_bytes + a.P * a.text_stride;
+    a.wave_bytes = a.pm_bytes + a.P * a.text_stride + 256;  // + per-slot sums (<= 64 ints)
     size_t lds = (size_t)a.wave_bytes * LEV_WAVES;
     ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "alphabet %d x length %d needs %zu B of LDS (> 160 KiB)", c->alphabet,
                 c->maxlen, lds);

@@ -129,26 +129,39 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double *__restrict__ val
         if (lh[t]) atomicAdd(&hist[t], lh[t]);
 }
 
-__global__ void k_sel_step(SelState *st, uint32_t *hist)
+__global__ __launch_bounds__(256) void k_sel_step(SelState *st, uint32_t *hist)
 {
-    // one wave; thread q resolves query q
-    int q = threadIdx.x;
+    // thread d owns digit d; one block-wide scan per query finds the bucket holding rank k
+    __shared__ uint32_t wsum[4];
+    __shared__ int64_t newk[SEL_MAXQ];
+    __shared__ int newd[SEL_MAXQ];
+    const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
     const int shift = 56 - 8 * st->pass;
-    if (q < st->nq) {
-        int64_t k = st->k[q];
-        int d = 0;
-        for (; d < 256; ++d) {
-            uint32_t h = hist[q * 256 + d];
-            if (k < (int64_t)h) break;
-            k -= h;
+    const int nq = st->nq;
+    for (int q = 0; q < nq; ++q) {
+        const uint32_t h = hist[q * 256 + d];
+        uint32_t inc = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
         }
-        if (d > 255) d = 255;  // k out of range: clamps to the maximum
-        st->prefix[q] |= (uint64_t)d << shift;
-        st->k[q] = k;
+        __syncthreads();
+        if (lane == 63) wsum[wave] = inc;
+        if (d == 0) { newd[q] = 255; newk[q] = 0; }  // rank beyond the population clamps to the maximum
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        const int64_t ex = (int64_t)base + inc - h, k = st->k[q];
+        if (h != 0 && k >= ex && k < ex + h) { newd[q] = d; newk[q] = k - ex; }
+        hist[q * 256 + d] = 0;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < SEL_MAXQ * 256; t += blockDim.x) hist[t] = 0;
-    if (threadIdx.x == 0) st->pass += 1;
+    if (d < nq) {
+        st->prefix[d] |= (uint64_t)newd[d] << shift;
+        st->k[d] = newk[d];
+    }
+    if (d == 0) st->pass += 1;
 }
 
 int ann_kth_smallest(annchor_ctx *c, const double *vals, const uint8_t *flag, int64_t n, const int64_t *ks, int nk,
