@@ -62,6 +62,16 @@ _SIGNATURES = {
     "annchor_set_refined": (ctypes.c_int, [_vp, _vp, _i64]),
     "annchor_update_bounds": (ctypes.c_int, [_vp]),
     "annchor_neighbor_graph": (ctypes.c_int, [_vp, _i32, _vp, _vp]),
+    "annchor_stream_bind": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i64, _i32]),
+    "annchor_stream_anchor_round": (ctypes.c_int, [_vp, _vp, _i32, _i32, ctypes.POINTER(_dbl), ctypes.POINTER(_i64)]),
+    "annchor_stream_get_row": (ctypes.c_int, [_vp, _i64, _vp]),
+    "annchor_stream_order": (ctypes.c_int, [_vp, _i32] + [ctypes.POINTER(_vp)] * 6 + [ctypes.POINTER(_i64), ctypes.POINTER(_i32),
+                                                                                   ctypes.POINTER(_i32)]),
+    "annchor_stream_knn": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _vp, _vp, _vp,
+                                          ctypes.POINTER(_i64)]),
+    "annchor_device_alloc": (ctypes.c_int, [_vp, _i64, ctypes.POINTER(_vp)]),
+    "annchor_device_free": (ctypes.c_int, [_vp, _vp]),
+    "annchor_device_copy": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32]),
     "annchor_field_size": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_i64)]),
     "annchor_download": (ctypes.c_int, [_vp, _i32, _vp, _i64]),
     "annchor_upload": (ctypes.c_int, [_vp, _i32, _vp, _i64]),
@@ -305,6 +315,60 @@ class Engine:
         dist = np.zeros((self.nx, k), dtype=np.float64)
         self._chk(self.lib.annchor_neighbor_graph(self.h, int(k), _ptr(idx), _ptr(dist)))
         return idx, dist
+
+    # ------------------------------------------------------- streamed form
+    def stream_bind(self, X, global_base=0, device_ptr=None, shape=None):
+        """Bind this rank's rows: a float32 NumPy array, or a raw device pointer + shape."""
+        if device_ptr is not None:
+            n, d = shape
+            self._chk(self.lib.annchor_stream_bind(self.h, device_ptr, int(n), int(d), int(global_base), 1))
+        else:
+            X = _c(X, np.float32)
+            n, d = X.shape
+            self._chk(self.lib.annchor_stream_bind(self.h, _ptr(X), n, d, int(global_base), 0))
+        self.nx, self.metric = int(n), METRIC_EUCLIDEAN_F32
+        self._stream_dim = int(d)
+
+    def stream_anchor_round(self, anchor_vec, rnd, n_anchors):
+        v = _c(anchor_vec, np.float32)
+        mx, arg = _dbl(), _i64()
+        self._chk(self.lib.annchor_stream_anchor_round(self.h, _ptr(v), int(rnd), int(n_anchors), ctypes.byref(mx), ctypes.byref(arg)))
+        return mx.value, arg.value
+
+    def stream_get_row(self, local_idx):
+        out = np.zeros(self._stream_dim, dtype=np.float32)
+        self._chk(self.lib.annchor_stream_get_row(self.h, int(local_idx), _ptr(out)))
+        return out
+
+    def stream_order(self, min_tiles=0):
+        ptrs = [_vp() for _ in range(6)]
+        n_pad, nt, dimp = _i64(), _i32(), _i32()
+        self._chk(self.lib.annchor_stream_order(self.h, int(min_tiles), *[ctypes.byref(p) for p in ptrs], ctypes.byref(n_pad),
+                                                ctypes.byref(nt), ctypes.byref(dimp)))
+        names = ("Xs", "rs", "perm", "lo", "hi", "mid")
+        return {k: p.value for k, p in zip(names, ptrs)}, n_pad.value, nt.value, dimp.value
+
+    def stream_knn(self, ptrs, n_all, nt_all, n_anchors, dim_padded, tile_begin, tile_count, k, p_work):
+        rows = tile_count * 128
+        row_ids = np.zeros(rows, dtype=np.int64)
+        idx = np.zeros((rows, k), dtype=np.int64)
+        dist = np.zeros((rows, k), dtype=np.float64)
+        ev = _i64()
+        self._chk(self.lib.annchor_stream_knn(self.h, ptrs["Xs"], ptrs["rs"], ptrs["perm"], ptrs["lo"], ptrs["hi"], ptrs["mid"], int(n_all),
+                                              int(nt_all), int(n_anchors), int(dim_padded), int(tile_begin), int(tile_count),
+                                              int(k), float(p_work), _ptr(row_ids), _ptr(idx), _ptr(dist), ctypes.byref(ev)))
+        return row_ids, idx, dist, ev.value
+
+    def device_alloc(self, nbytes):
+        p = _vp()
+        self._chk(self.lib.annchor_device_alloc(self.h, int(nbytes), ctypes.byref(p)))
+        return p.value
+
+    def device_free(self, dptr):
+        self._chk(self.lib.annchor_device_free(self.h, dptr))
+
+    def device_copy(self, dst, src, nbytes, kind):
+        self._chk(self.lib.annchor_device_copy(self.h, dst, src, int(nbytes), {"h2d": 1, "d2h": 2, "d2d": 3}[kind]))
 
     # ---------------------------------------------------------- state access
     def field_size(self, field):

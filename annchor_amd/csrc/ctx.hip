@@ -4,6 +4,7 @@
 #include "common.h"
 
 static std::string g_create_err;
+void ann_stream_release(annchor_ctx *c);
 
 const char *ann_set_err(annchor_ctx *c, const char *fmt, ...)
 {
@@ -178,6 +179,7 @@ extern "C" void annchor_destroy(annchor_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_drain(c);
+    ann_stream_release(c);
     DevBuf *bufs[] = {&c->sym, &c->soff, &c->slen, &c->pts, &c->hist, &c->cost, &c->supp, &c->Dt, &c->A,
                       &c->anchorRank, &c->runmin, &c->redval, &c->redidx, &c->sid, &c->cA, &c->thr, &c->Kbits,
                       &c->Kpref, &c->deg, &c->low, &c->rowstart, &c->Iptr, &c->Iidx, &c->ij, &c->lb, &c->ub,

@@ -1,0 +1,814 @@
+// streamed.hip -- the streamed (tile-granular) form of the path for Euclidean data at
+// N >> 10^4, where the pair-list form of the reference cannot exist (its candidate list
+// alone would be ~10^11 pairs, SURVEY.md section 7 hard part 3).
+//
+// Same stages as Annchor.fit() (reference annchor/annchor.py:532-623), lifted from pairs
+// to 128-point tiles:
+//   anchors   max-min picking, D = distances to the anchors        (pickers.py:18-52)
+//   locality  points are ordered by (nearest anchor, distance to it); consecutive 128
+//             points form a tile with per-anchor distance intervals [lo, hi]
+//   bounds    the triangle inequality of utils.py:274-301 on intervals:
+//             lb(I, J) = max_a max(lo_I[a] - hi_J[a], lo_J[a] - hi_I[a], 0)
+//   refine    for each row tile the column tiles are visited in ascending lb; the exact
+//             metric is evaluated for a whole tile pair as a float32 MFMA GEMM
+//             (|x|^2 + |y|^2 - 2 x.y); a tile is skipped as soon as lb^2 >= the worst
+//             current k-th squared distance of the row tile; at most p_work * (#tiles)
+//             column tiles are evaluated per row tile (the work budget of annchor.py:438-442)
+//   top-k     per-row k smallest, kept in LDS while streaming          (utils.py:383-429)
+// For float32 inputs evaluating a pair exactly costs 2*d flops on the matrix cores while a
+// per-pair triangle bound costs ~5*n_anchors VALU ops at the same peak rate -- so the
+// regression / ECDF ranking of single pairs (annchor.py:345-473) has no place here: whole
+// tiles are ranked by their bound instead.  With the budget not binding the result is the
+// exact k-NN graph.
+//
+// MFMA mapping (v_mfma_f32_32x32x2_f32, exact f32): a 256-thread workgroup owns a row tile;
+// each of its 4 waves keeps its 32 rows x d operand in registers for the whole kernel
+// (d/2 VGPRs), column tiles are streamed through LDS in 32-column slabs (row stride d+1
+// floats: bank-conflict-free operand reads), accumulators are compared against per-row
+// thresholds in LDS and only the survivors are inserted into the per-row lists.
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+#define ST_T 128
+#define ST_SLAB 32
+#define ST_THREADS 256
+#define ST_KMAX 32
+#define ST_SURV 1024
+#define ST_KEEP 512
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct StreamState {
+    // local shard (this context's rows), all device memory owned by the context
+    DevBuf X;        // float [n_local][dim]      (copy of the caller's rows)
+    DevBuf keys, keys2, vals, vals2, cubtmp;
+    DevBuf Xs;       // float [n_pad][dimp]       rows in tile order, zero padded
+    DevBuf rs;       // float [n_pad]             squared norms (+inf on padding rows)
+    DevBuf perm;     // int64 [n_pad]             global id of each ordered row (-1 padding)
+    DevBuf lo, hi, mid;  // float [na][nt]        per-tile anchor-distance intervals and means
+    DevBuf avec;     // float [dimp]              current anchor vector
+    DevBuf runmin, red_val, red_idx;
+    DevBuf D;        // float [na][n_local]       distances to anchors (f32)
+    DevBuf out_d2, out_col;
+    DevBuf evals;
+    int64_t n_local = 0, n_pad = 0, base = 0;
+    int dim = 0, dimp = 0, na = 0, nt = 0;
+};
+
+static std::vector<std::pair<annchor_ctx *, StreamState *>> g_states;
+
+static StreamState *state_of(annchor_ctx *c, bool create)
+{
+    for (auto &p : g_states)
+        if (p.first == c) return p.second;
+    if (!create) return nullptr;
+    StreamState *s = new StreamState();
+    g_states.push_back({c, s});
+    return s;
+}
+
+void ann_stream_release(annchor_ctx *c)
+{
+    for (size_t i = 0; i < g_states.size(); ++i)
+        if (g_states[i].first == c) {
+            StreamState *s = g_states[i].second;
+            DevBuf *bufs[] = {&s->X, &s->keys, &s->keys2, &s->vals, &s->vals2, &s->cubtmp, &s->Xs, &s->rs, &s->perm, &s->lo,
+                              &s->hi, &s->mid, &s->avec, &s->runmin, &s->red_val, &s->red_idx, &s->D, &s->out_d2, &s->out_col, &s->evals};
+            for (DevBuf *b : bufs)
+                if (b->p && !b->in_arena) (void)hipFree(b->p);
+            delete s;
+            g_states.erase(g_states.begin() + (long)i);
+            return;
+        }
+}
+
+static int sreserve(annchor_ctx *c, DevBuf &b, size_t bytes)
+{
+    // streamed buffers are large: always individual allocations
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return ANNCHOR_OK;
+    if (b.p && !b.in_arena) ANN_CHECK_HIP(c, hipFree(b.p));
+    b.p = nullptr; b.cap = 0; b.in_arena = false;
+    size_t want = (bytes + 255) & ~(size_t)255;
+    ANN_CHECK_HIP(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return ANNCHOR_OK;
+}
+
+static int padded_dim(int dim) { return dim <= 32 ? 32 : dim <= 64 ? 64 : dim <= 128 ? 128 : dim <= 256 ? 256 : -1; }
+
+// ------------------------------------------------------------------ bind
+extern "C" int annchor_stream_bind(annchor_ctx *c, const float *X, int64_t n_local, int32_t dim, int64_t global_base,
+                                   int32_t x_on_device)
+{
+    if (!c || !X) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, n_local >= 1 && n_local < (1ll << 31), ANNCHOR_ELIMIT, "n_local=%lld out of range", (long long)n_local);
+    ANN_REQUIRE(c, padded_dim(dim) > 0, ANNCHOR_ELIMIT, "streamed form supports dim <= 256 (got %d)", dim);
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    StreamState *s = state_of(c, true);
+    s->n_local = n_local; s->dim = dim; s->dimp = padded_dim(dim); s->base = global_base; s->na = 0;
+    const size_t bytes = sizeof(float) * (size_t)n_local * dim;
+    ANN_TRY(sreserve(c, s->X, bytes));
+    ANN_CHECK_HIP(c, hipMemcpyAsync(s->X.p, X, bytes, x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    ANN_TRY(sreserve(c, s->avec, sizeof(float) * 256));
+    ANN_TRY(sreserve(c, s->runmin, sizeof(float) * (size_t)n_local));
+    c->metric = ANNCHOR_METRIC_EUCLIDEAN_F32;
+    c->nx = n_local;
+    return ANNCHOR_OK;
+}
+
+// ------------------------------------------------------------ anchor rounds
+// one-to-all distances from a vector: 16 lanes per row, 16-byte loads; HBM bound
+// (n_local * dim * 4 bytes per round)
+__global__ __launch_bounds__(256) void k_st_one_to_all(const float *__restrict__ X, int64_t n, int dim,
+                                                      const float *__restrict__ av, float *__restrict__ out)
+{
+    const int sub = threadIdx.x & 15;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    float acc = 0.f;
+    if (i < n) {
+        const float *x = X + (size_t)i * dim;
+        if ((dim & 3) == 0) {
+            for (int k = sub * 4; k < dim; k += 64) {
+                const float4 u = *reinterpret_cast<const float4 *>(x + k), w = *reinterpret_cast<const float4 *>(av + k);
+                float d0 = u.x - w.x, d1 = u.y - w.y, d2 = u.z - w.z, d3 = u.w - w.w;
+                acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
+        } else {
+            for (int k = sub; k < dim; k += 16) { float d = x[k] - av[k]; acc += d * d; }
+        }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+    if (i < n && sub == 0) out[i] = sqrtf(acc);
+}
+
+__global__ __launch_bounds__(256) void k_st_runmin_argmax(const float *__restrict__ row, float *__restrict__ runmin, int64_t n,
+                                                         int reset, float *__restrict__ redval, int64_t *__restrict__ redidx)
+{
+    float bv = -INFINITY;
+    int64_t bi = 0x7fffffffffffffffll;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        float v = row[j];
+        if (!reset) v = fminf(runmin[j], v);
+        runmin[j] = v;
+        if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float ov = __shfl_xor(bv, off);
+        int64_t oi = __shfl_xor(bi, off);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    __shared__ float sv[4];
+    __shared__ int64_t si[4];
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        redval[blockIdx.x] = bv;
+        redidx[blockIdx.x] = bi;
+    }
+}
+
+// One max-min round on the local shard (pickers.py:44-50): distances of all local rows to
+// `anchor_vec`, running-min update (reset for rounds 0 and 1, as the reference's D[1:]
+// quirk demands) and the local arg-max (value, local index; first index on ties).
+extern "C" int annchor_stream_anchor_round(annchor_ctx *c, const float *anchor_vec, int32_t round, int32_t n_anchors,
+                                           double *local_max, int64_t *local_arg)
+{
+    if (!c || !anchor_vec || !local_max || !local_arg) return ANNCHOR_EINVAL;
+    StreamState *s = state_of(c, false);
+    ANN_REQUIRE(c, s && s->n_local > 0, ANNCHOR_EINVAL, "annchor_stream_bind first");
+    ANN_REQUIRE(c, n_anchors >= 1 && n_anchors <= 64 && round >= 0 && round < n_anchors, ANNCHOR_ELIMIT, "bad anchor round");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    if (round == 0) {
+        s->na = n_anchors;
+        ANN_TRY(sreserve(c, s->D, sizeof(float) * (size_t)n_anchors * (size_t)s->n_local));
+    }
+    const int64_t n = s->n_local;
+    int rblocks = (int)std::min<int64_t>(1024, (n + 1023) / 1024);
+    ANN_TRY(sreserve(c, s->red_val, sizeof(float) * 1024));
+    ANN_TRY(sreserve(c, s->red_idx, sizeof(int64_t) * 1024));
+    ANN_CHECK_HIP(c, hipMemcpyAsync(s->avec.p, anchor_vec, sizeof(float) * (size_t)s->dim, hipMemcpyHostToDevice, c->stream));
+    float *row = s->D.as<float>() + (size_t)round * n;
+    {
+        ProfScope ps(c, "stream_anchor_one_to_all", (double)n * (s->dim * 4.0 + 4.0));
+        k_st_one_to_all<<<ann_blocks(n * 16, 256), 256, 0, c->stream>>>(s->X.as<float>(), n, s->dim, s->avec.as<float>(), row);
+    }
+    k_st_runmin_argmax<<<rblocks, 256, 0, c->stream>>>(row, s->runmin.as<float>(), n, round <= 1 ? 1 : 0, s->red_val.as<float>(),
+                                                      s->red_idx.as<int64_t>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    std::vector<float> hv((size_t)rblocks);
+    std::vector<int64_t> hi((size_t)rblocks);
+    ANN_TRY(ann_d2h(c, hv.data(), s->red_val.p, sizeof(float) * (size_t)rblocks));
+    ANN_TRY(ann_d2h(c, hi.data(), s->red_idx.p, sizeof(int64_t) * (size_t)rblocks));
+    float bv = -INFINITY;
+    int64_t bi = 0;
+    for (int b = 0; b < rblocks; ++b)
+        if (hv[(size_t)b] > bv || (hv[(size_t)b] == bv && hi[(size_t)b] < bi)) { bv = hv[(size_t)b]; bi = hi[(size_t)b]; }
+    *local_max = (double)bv;
+    *local_arg = bi;
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_stream_get_row(annchor_ctx *c, int64_t local_idx, float *out)
+{
+    if (!c || !out) return ANNCHOR_EINVAL;
+    StreamState *s = state_of(c, false);
+    ANN_REQUIRE(c, s && local_idx >= 0 && local_idx < s->n_local, ANNCHOR_EINVAL, "row out of range");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    return ann_d2h(c, out, s->X.as<float>() + (size_t)local_idx * s->dim, sizeof(float) * (size_t)s->dim);
+}
+
+// ---------------------------------------------------------------- ordering
+// ---- locality ordering: balanced k-d splits in anchor-distance space.
+// Level l cuts the current order into 2^l equal position ranges ("segments"); every segment
+// is sorted along the anchor coordinate on which its points spread most, so that after
+// ceil(log2(#tiles)) levels each 128-row tile is a small box in several anchor coordinates:
+// tight [lo, hi] intervals, hence strong triangle bounds between tiles.
+__device__ __forceinline__ int st_seg_of(int64_t p, int64_t n, int level) { return (int)((p << level) / n); }
+
+__global__ __launch_bounds__(256) void k_st_spread(const float *__restrict__ D, const uint32_t *__restrict__ order, int64_t n,
+                                                  int na, int level, double *__restrict__ ssum, double *__restrict__ ssq)
+{
+    // per (segment, anchor): sum and sum of squares of the anchor distances
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = p < n;
+    const int seg = ok ? st_seg_of(p, n, level) : -1;
+    const int seg0 = __shfl(seg, 0), seg63 = __shfl(ok ? seg : seg0, 63);
+    const uint32_t src = ok ? order[p] : 0;
+    for (int a = 0; a < na; ++a) {
+        const double v = ok ? (double)D[(size_t)a * n + src] : 0.0;
+        if (seg0 == seg63 && seg0 >= 0) {  // whole wave inside one segment: reduce first
+            double s1 = v, s2 = v * v;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&ssum[(size_t)seg0 * na + a], s1);
+                atomicAdd(&ssq[(size_t)seg0 * na + a], s2);
+            }
+        } else if (ok) {
+            atomicAdd(&ssum[(size_t)seg * na + a], v);
+            atomicAdd(&ssq[(size_t)seg * na + a], v * v);
+        }
+    }
+}
+
+__global__ void k_st_pick_coord(const double *__restrict__ ssum, const double *__restrict__ ssq, int64_t n, int level, int nseg,
+                                int na, int32_t *__restrict__ coord)
+{
+    // split every segment along the anchor coordinate of largest variance
+    const int sgm = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sgm >= nseg) return;
+    const int64_t b = ((int64_t)sgm * n + (1ll << level) - 1) >> level, e = ((int64_t)(sgm + 1) * n + (1ll << level) - 1) >> level;
+    const double cnt = (double)(e - b > 0 ? e - b : 1);
+    double best = -1.0;
+    int ba = 0;
+    for (int a = 0; a < na; ++a) {
+        const double m = ssum[(size_t)sgm * na + a] / cnt;
+        const double var = ssq[(size_t)sgm * na + a] / cnt - m * m;
+        if (var > best) { best = var; ba = a; }
+    }
+    coord[sgm] = ba;
+}
+
+__global__ void k_st_level_keys(const float *__restrict__ D, const uint32_t *__restrict__ order, int64_t n, int level,
+                                const int32_t *__restrict__ coord, unsigned long long *__restrict__ keys)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int sgm = st_seg_of(p, n, level);
+    const float v = D[(size_t)coord[sgm] * n + order[p]];
+    keys[p] = ((unsigned long long)sgm << 32) | (unsigned long long)__float_as_uint(v);
+}
+
+__global__ void k_st_iota(uint32_t *v, int64_t n)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) v[p] = (uint32_t)p;
+}
+
+__global__ void k_st_gather(const float *__restrict__ X, const uint32_t *__restrict__ order, int64_t n, int64_t n_pad, int dim,
+                            int dimp, int64_t base, float *__restrict__ Xs, float *__restrict__ rs, int64_t *__restrict__ perm)
+{
+    // 16 lanes per row
+    const int sub = threadIdx.x & 15;
+    const int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (s >= n_pad) return;
+    float acc = 0.f;
+    if (s < n) {
+        const uint32_t src = order[s];
+        for (int k = sub; k < dimp; k += 16) {
+            float v = k < dim ? X[(size_t)src * dim + k] : 0.f;
+            Xs[(size_t)s * dimp + k] = v;
+            acc += v * v;
+        }
+    } else {
+        for (int k = sub; k < dimp; k += 16) Xs[(size_t)s * dimp + k] = 0.f;
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+    if (sub == 0) {
+        rs[s] = s < n ? acc : INFINITY;
+        perm[s] = s < n ? base + (int64_t)order[s] : -1;
+    }
+}
+
+__global__ __launch_bounds__(ST_T) void k_st_intervals(const float *__restrict__ D, const uint32_t *__restrict__ order, int64_t n,
+                                                      int na, int nt, float *__restrict__ lo, float *__restrict__ hi,
+                                                      float *__restrict__ mid)
+{
+    // block = tile, thread = row of the tile
+    const int t = blockIdx.x;
+    const int64_t s = (int64_t)t * ST_T + threadIdx.x;
+    __shared__ float smin[ST_T / 64], smax[ST_T / 64], ssm[ST_T / 64];
+    __shared__ int scnt[ST_T / 64];
+    const bool ok = s < n;
+    const uint32_t src = ok ? order[s] : 0;
+    for (int a = 0; a < na; ++a) {
+        float v = ok ? D[(size_t)a * n + src] : 0.f;
+        float mn = ok ? v : INFINITY, mx = ok ? v : -INFINITY, sm = ok ? v : 0.f;
+        int cn = ok ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off));
+            sm += __shfl_xor(sm, off); cn += __shfl_xor(cn, off);
+        }
+        if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; ssm[threadIdx.x >> 6] = sm; scnt[threadIdx.x >> 6] = cn; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            lo[(size_t)a * nt + t] = fminf(smin[0], smin[1]);
+            hi[(size_t)a * nt + t] = fmaxf(smax[0], smax[1]);
+            const int cc = scnt[0] + scnt[1];
+            mid[(size_t)a * nt + t] = cc ? (ssm[0] + ssm[1]) / (float)cc : INFINITY;   // mean anchor distance of the tile
+        }
+        __syncthreads();
+    }
+}
+
+// Order the local rows by (nearest anchor, distance to it), build the tile-ordered copies
+// and the per-tile anchor-distance intervals.  Returns device pointers so that a
+// multi-GPU host can all-gather them (single GPU: hand them straight back to
+// annchor_stream_knn).
+extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs, void **rs, void **perm, void **lo, void **hi,
+                                    void **mid, int64_t *n_pad, int32_t *n_tiles, int32_t *dim_padded)
+{
+    if (!c || !Xs || !rs || !perm || !lo || !hi || !mid || !n_pad || !n_tiles || !dim_padded) return ANNCHOR_EINVAL;
+    StreamState *s = state_of(c, false);
+    ANN_REQUIRE(c, s && s->na > 0, ANNCHOR_EINVAL, "anchor rounds not run");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    const int64_t n = s->n_local;
+    s->nt = (int)((n + ST_T - 1) / ST_T);
+    if (s->nt < min_tiles) s->nt = min_tiles;  // common tile count across ranks; extra tiles are pure padding
+    s->n_pad = (int64_t)s->nt * ST_T;
+    ANN_TRY(sreserve(c, s->keys, 8 * (size_t)n));
+    ANN_TRY(sreserve(c, s->keys2, 8 * (size_t)n));
+    ANN_TRY(sreserve(c, s->vals, 4 * (size_t)n));
+    ANN_TRY(sreserve(c, s->vals2, 4 * (size_t)n));
+    ANN_TRY(sreserve(c, s->Xs, sizeof(float) * (size_t)s->n_pad * s->dimp));
+    ANN_TRY(sreserve(c, s->rs, sizeof(float) * (size_t)s->n_pad));
+    ANN_TRY(sreserve(c, s->perm, sizeof(int64_t) * (size_t)s->n_pad));
+    ANN_TRY(sreserve(c, s->lo, sizeof(float) * (size_t)s->na * s->nt));
+    ANN_TRY(sreserve(c, s->hi, sizeof(float) * (size_t)s->na * s->nt));
+    ANN_TRY(sreserve(c, s->mid, sizeof(float) * (size_t)s->na * s->nt));
+    ProfScope ps(c, "stream_order_tiles", (double)n * (s->dim * 8.0 + s->na * 8.0 + 40.0));
+    int levels = 0;
+    while (((int64_t)ST_T << levels) < n) ++levels;   // segments end up <= one tile long
+    const int max_seg = 1 << levels;
+    ANN_TRY(sreserve(c, s->red_val, sizeof(double) * 2 * (size_t)max_seg * s->na));
+    ANN_TRY(sreserve(c, s->red_idx, sizeof(int32_t) * (size_t)max_seg));
+    double *ssum = s->red_val.as<double>(), *ssq = ssum + (size_t)max_seg * s->na;
+    uint32_t *cur = s->vals.as<uint32_t>(), *nxt = s->vals2.as<uint32_t>();
+    k_st_iota<<<ann_blocks(n, 256), 256, 0, c->stream>>>(cur, n);
+    size_t tmp_bytes = 0;
+    ANN_CHECK_HIP(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, s->keys.as<unsigned long long>(),
+                                                        s->keys2.as<unsigned long long>(), cur, nxt, (int)n, 0, 64, c->stream));
+    ANN_TRY(sreserve(c, s->cubtmp, tmp_bytes));
+    for (int level = 0; level < levels; ++level) {
+        const int nseg = 1 << level;
+        ANN_CHECK_HIP(c, hipMemsetAsync(ssum, 0, sizeof(double) * (size_t)nseg * s->na, c->stream));
+        ANN_CHECK_HIP(c, hipMemsetAsync(ssq, 0, sizeof(double) * (size_t)nseg * s->na, c->stream));
+        k_st_spread<<<ann_blocks(n, 256), 256, 0, c->stream>>>(s->D.as<float>(), cur, n, s->na, level, ssum, ssq);
+        k_st_pick_coord<<<ann_blocks(nseg, 256), 256, 0, c->stream>>>(ssum, ssq, n, level, nseg, s->na, s->red_idx.as<int32_t>());
+        k_st_level_keys<<<ann_blocks(n, 256), 256, 0, c->stream>>>(s->D.as<float>(), cur, n, level, s->red_idx.as<int32_t>(),
+                                                                  s->keys.as<unsigned long long>());
+        ANN_CHECK_HIP(c, hipcub::DeviceRadixSort::SortPairs(s->cubtmp.p, tmp_bytes, s->keys.as<unsigned long long>(),
+                                                            s->keys2.as<unsigned long long>(), cur, nxt, (int)n, 0, 32 + level,
+                                                            c->stream));
+        uint32_t *t = cur; cur = nxt; nxt = t;
+    }
+    if (cur != s->vals2.as<uint32_t>())
+        ANN_CHECK_HIP(c, hipMemcpyAsync(s->vals2.p, cur, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+    k_st_gather<<<ann_blocks(s->n_pad * 16, 256), 256, 0, c->stream>>>(s->X.as<float>(), s->vals2.as<uint32_t>(), n, s->n_pad,
+                                                                      s->dim, s->dimp, s->base, s->Xs.as<float>(),
+                                                                      s->rs.as<float>(), s->perm.as<int64_t>());
+    k_st_intervals<<<s->nt, ST_T, 0, c->stream>>>(s->D.as<float>(), s->vals2.as<uint32_t>(), n, s->na, s->nt, s->lo.as<float>(),
+                                                 s->hi.as<float>(), s->mid.as<float>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    *Xs = s->Xs.p; *rs = s->rs.p; *perm = s->perm.p; *lo = s->lo.p; *hi = s->hi.p; *mid = s->mid.p;
+    *n_pad = s->n_pad; *n_tiles = s->nt; *dim_padded = s->dimp;
+    return ANNCHOR_OK;
+}
+
+// ------------------------------------------------------------------ k-NN
+struct KnnArgs {
+    const float *Xs;      // [n_all][DIM]   all column tiles (every rank's ordered shard, concatenated)
+    const float *rs;      // [n_all]
+    const float *lo, *hi, *mid; // [na][nt_all]
+    int nt_all, na;
+    int tile_begin;       // first row tile of this launch inside the global tile numbering
+    int tile_count;
+    int K;                // neighbours kept per row, self excluded
+    int max_tiles;        // column-tile budget per row tile
+    float *out_d2;        // [tile_count*128][K]
+    int32_t *out_col;     // [tile_count*128][K]   global ordered column index
+    unsigned long long *evals;
+};
+
+template <int DIM, int KMAX> struct KnnShared {
+    float Bs[ST_SLAB][DIM + 1];
+    float rsJ[ST_SLAB];
+    float cand_d[ST_T][ST_SLAB];
+    int32_t cand_c[ST_T][ST_SLAB];
+    float list_d[ST_T][KMAX];
+    int32_t list_c[ST_T][KMAX];
+    float thr[ST_T];
+    int cnt[ST_T];
+    float loI[64], hiI[64], midI[64];
+    float surv_lb[ST_SURV];   // rank key (mid-point bound)
+    float surv_vb[ST_SURV];   // valid interval lower bound
+    int32_t surv_j[ST_SURV];
+    unsigned int thrmax_bits;
+    int nsurv;
+    int processed;
+};
+
+template <int DIM, int KMAX>
+__device__ __forceinline__ void knn_process_tile(KnnShared<DIM, KMAX> &sh, const KnnArgs &a, int J, const float (&areg)[DIM / 2],
+                                                 const float (&ri)[16], int rowbase_wave, int64_t grow0, int K)
+{
+    const int lane = threadIdx.x & 63;
+    for (int slab = 0; slab < ST_T / ST_SLAB; ++slab) {
+        const int64_t col0 = (int64_t)J * ST_T + slab * ST_SLAB;
+        __syncthreads();  // previous slab fully consumed (operands, candidates merged)
+        // ---- stage the slab: 32 columns x DIM floats, coalesced 16-byte reads
+        for (int q = threadIdx.x; q < ST_SLAB * DIM / 4; q += ST_THREADS) {
+            const int colr = q / (DIM / 4), k4 = (q % (DIM / 4)) * 4;
+            const float4 v = *reinterpret_cast<const float4 *>(a.Xs + (size_t)(col0 + colr) * DIM + k4);
+            sh.Bs[colr][k4] = v.x; sh.Bs[colr][k4 + 1] = v.y; sh.Bs[colr][k4 + 2] = v.z; sh.Bs[colr][k4 + 3] = v.w;
+        }
+        if (threadIdx.x < ST_SLAB) sh.rsJ[threadIdx.x] = a.rs[col0 + threadIdx.x];
+        __syncthreads();
+        // ---- 32x32 block of dot products per wave: DIM/2 MFMAs of K = 2
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float *bp = &sh.Bs[lane & 31][lane >> 5];
+#pragma unroll
+        for (int s = 0; s < DIM / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s], bp[2 * s], acc, 0, 0, 0);
+        // ---- thresholds: C layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        const int col = lane & 31;
+        const float rj = sh.rsJ[col];
+        const int64_t jglob = col0 + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rowl = rowbase_wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float d2 = fmaxf(ri[r] + rj - 2.f * acc[r], 0.f);
+            if (d2 < sh.thr[rowl] && jglob != grow0 + rowl) {
+                const int slot = atomicAdd(&sh.cnt[rowl], 1);
+                sh.cand_d[rowl][slot] = d2;
+                sh.cand_c[rowl][slot] = (int32_t)jglob;
+            }
+        }
+        __syncthreads();
+        // ---- merge survivors into the sorted per-row lists (one thread per row)
+        if (threadIdx.x < ST_T) {
+            const int row = threadIdx.x;
+            const int nc = sh.cnt[row];
+            if (nc) {
+                for (int q = 0; q < nc; ++q) {
+                    const float d = sh.cand_d[row][q];
+                    const int32_t cc = sh.cand_c[row][q];
+                    // insertion by (d, col); list is padded with +inf
+                    if (d < sh.list_d[row][K - 1] || (d == sh.list_d[row][K - 1] && cc < sh.list_c[row][K - 1])) {
+                        int p = K - 1;
+                        while (p > 0 && (d < sh.list_d[row][p - 1] || (d == sh.list_d[row][p - 1] && cc < sh.list_c[row][p - 1]))) {
+                            sh.list_d[row][p] = sh.list_d[row][p - 1];
+                            sh.list_c[row][p] = sh.list_c[row][p - 1];
+                            --p;
+                        }
+                        sh.list_d[row][p] = d;
+                        sh.list_c[row][p] = cc;
+                    }
+                }
+                sh.cnt[row] = 0;
+                sh.thr[row] = sh.list_d[row][K - 1];
+            }
+        }
+    }
+    __syncthreads();
+    // worst k-th squared distance of the row tile (padding rows have thr = -1)
+    if (threadIdx.x == 0) sh.thrmax_bits = 0;
+    __syncthreads();
+    if (threadIdx.x < ST_T && sh.thr[threadIdx.x] >= 0.f) atomicMax(&sh.thrmax_bits, __float_as_uint(sh.thr[threadIdx.x]));
+    if (threadIdx.x == 0) sh.processed += 1;
+    __syncthreads();
+}
+
+template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS) void k_st_knn(KnnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    KnnShared<DIM, KMAX> &sh = *reinterpret_cast<KnnShared<DIM, KMAX> *>(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int I = a.tile_begin + blockIdx.x;
+    const int64_t grow0 = (int64_t)I * ST_T;
+    const int K = a.K;
+    // ---- per-wave row operand in registers: lane holds row (lane & 31), dims of parity (lane >> 5)
+    float areg[DIM / 2];
+    {
+        const float *xr = a.Xs + (size_t)(grow0 + wave * 32 + (lane & 31)) * DIM + (lane >> 5);
+#pragma unroll
+        for (int s = 0; s < DIM / 2; ++s) areg[s] = xr[2 * s];
+    }
+    float ri[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ri[r] = a.rs[grow0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+    if (threadIdx.x < ST_T) {
+        const int row = threadIdx.x;
+        const bool real = a.rs[grow0 + row] < INFINITY;
+        sh.thr[row] = real ? INFINITY : -1.f;  // padding rows never accept candidates
+        sh.cnt[row] = 0;
+        for (int q = 0; q < KMAX; ++q) { sh.list_d[row][q] = INFINITY; sh.list_c[row][q] = 0x7fffffff; }
+    }
+    if (threadIdx.x < a.na) {
+        sh.loI[threadIdx.x] = a.lo[(size_t)threadIdx.x * a.nt_all + I];
+        sh.hiI[threadIdx.x] = a.hi[(size_t)threadIdx.x * a.nt_all + I];
+        sh.midI[threadIdx.x] = a.mid[(size_t)threadIdx.x * a.nt_all + I];
+    }
+    if (threadIdx.x == 0) { sh.nsurv = 0; sh.processed = 0; sh.thrmax_bits = 0x7f800000u; }
+    __syncthreads();
+
+    // ---- phase A: the row tile against itself (gives every row k finite candidates)
+    knn_process_tile<DIM, KMAX>(sh, a, I, areg, ri, wave * 32, grow0, K);
+
+    // ---- phase B: all other column tiles.  A tile is ELIGIBLE while its interval bound lb
+    // (a valid lower bound of every pair distance) is below the worst k-th distance of the
+    // row tile; eligible tiles are RANKED by the distance between the tiles' mean
+    // anchor-distance vectors (the anchors embed the data; this is the tile analogue of
+    // ranking pairs by a distance predicted from anchor features, annchor.py:345-380).  Rounds: scan all tiles keeping the ST_KEEP best-ranked not yet considered,
+    // evaluate them in rank order, repeat until nothing is eligible or the budget is spent.
+    float done_key = -1.f;   // (done_key, done_j): rank key of the last tile already considered
+    int done_j = -1;
+    for (;;) {
+        float cut_key = INFINITY;  // keys at or beyond (cut_key, cut_j) are dropped in this round
+        int cut_j = 0x7fffffff;
+        bool truncated = false;
+        for (int base = 0; base < a.nt_all; base += ST_THREADS) {
+            const int J = base + threadIdx.x;
+            if (J < a.nt_all && J != I) {
+                float lb = 0.f, lbc = 0.f;
+                for (int an = 0; an < a.na; ++an) {
+                    const float lj = a.lo[(size_t)an * a.nt_all + J], hj = a.hi[(size_t)an * a.nt_all + J];
+                    const float gap = fmaxf(sh.loI[an] - hj, lj - sh.hiI[an]);
+                    // slack for the float32 rounding of D (bounds must stay valid lower bounds)
+                    lb = fmaxf(lb, gap - 4e-6f * (fabsf(hj) + fabsf(sh.hiI[an])));
+                    const float dm = a.mid[(size_t)an * a.nt_all + J] - sh.midI[an];
+                    lbc += dm * dm;   // rank key: squared L2 distance between the tiles' mean anchor vectors
+                }
+                const bool after_done = lbc > done_key || (lbc == done_key && J > done_j);
+                const bool before_cut = lbc < cut_key || (lbc == cut_key && J < cut_j);
+                if (lb * lb < __uint_as_float(sh.thrmax_bits) && after_done && before_cut && lbc < INFINITY) {
+                    const int slot = atomicAdd(&sh.nsurv, 1);
+                    sh.surv_lb[slot] = lbc;   // cannot overflow: compacted below before 256 more can arrive
+                    sh.surv_vb[slot] = lb;
+                    sh.surv_j[slot] = J;
+                }
+            }
+            __syncthreads();
+            const bool last = base + ST_THREADS >= a.nt_all;
+            const int ns = sh.nsurv;
+            if (ns > 0 && (last || ns > ST_SURV - ST_THREADS)) {
+                // sort by (rank key, J): bitonic over ST_SURV slots
+                for (int q = threadIdx.x; q < ST_SURV; q += ST_THREADS)
+                    if (q >= ns) { sh.surv_lb[q] = INFINITY; sh.surv_j[q] = 0x7fffffff; }
+                __syncthreads();
+                for (int k2 = 2; k2 <= ST_SURV; k2 <<= 1)
+                    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                        for (int q = threadIdx.x; q < ST_SURV; q += ST_THREADS) {
+                            const int p = q ^ j2;
+                            if (p > q) {
+                                const bool up = (q & k2) == 0;
+                                const float lq = sh.surv_lb[q], lp = sh.surv_lb[p];
+                                const int jq = sh.surv_j[q], jp = sh.surv_j[p];
+                                const bool gt = lq > lp || (lq == lp && jq > jp);
+                                if (gt == up) {
+                                    sh.surv_lb[q] = lp; sh.surv_lb[p] = lq; sh.surv_j[q] = jp; sh.surv_j[p] = jq;
+                                    const float t = sh.surv_vb[q]; sh.surv_vb[q] = sh.surv_vb[p]; sh.surv_vb[p] = t;
+                                }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                if (!last && ns > ST_KEEP) {
+                    cut_key = sh.surv_lb[ST_KEEP - 1];
+                    cut_j = sh.surv_j[ST_KEEP - 1] + 1;   // keep entries up to and including slot ST_KEEP-1
+                    truncated = true;
+                    __syncthreads();
+                    if (threadIdx.x == 0) sh.nsurv = ST_KEEP;
+                    __syncthreads();
+                }
+            }
+        }
+        int ns = sh.nsurv;
+        if (ns > ST_KEEP && truncated) ns = ST_KEEP;
+        if (ns == 0) break;
+        for (int q = 0; q < ns; ++q) {
+            if (sh.processed >= a.max_tiles) break;
+            const int J = sh.surv_j[q];
+            const float lb = sh.surv_vb[q];  // re-check against the current, tighter threshold
+            if (lb * lb < __uint_as_float(sh.thrmax_bits)) knn_process_tile<DIM, KMAX>(sh, a, J, areg, ri, wave * 32, grow0, K);
+        }
+        done_key = sh.surv_lb[ns - 1];
+        done_j = sh.surv_j[ns - 1];
+        __syncthreads();
+        if (threadIdx.x == 0) sh.nsurv = 0;
+        __syncthreads();
+        if (sh.processed >= a.max_tiles) break;
+        if (ns < ST_KEEP && !truncated) break;   // the scan saw every eligible tile
+    }
+    __syncthreads();
+    // ---- write the lists
+    for (int q = threadIdx.x; q < ST_T * K; q += ST_THREADS) {
+        const int row = q / K, e = q - row * K;
+        a.out_d2[((size_t)blockIdx.x * ST_T + row) * K + e] = sh.list_d[row][e];
+        a.out_col[((size_t)blockIdx.x * ST_T + row) * K + e] = sh.list_c[row][e];
+    }
+    if (threadIdx.x == 0) atomicAdd(a.evals, (unsigned long long)sh.processed);
+}
+
+// exact float32 distances of the selected neighbours + final per-row ordering
+__global__ __launch_bounds__(256) void k_st_finalize(const float *__restrict__ Xs, const int64_t *__restrict__ perm_all, int dimp,
+                                                    int64_t row_begin, int64_t rows, int K, const int32_t *__restrict__ col,
+                                                    int64_t *__restrict__ oidx, float *__restrict__ odist)
+{
+    // 16 lanes per (row, entry)
+    const int sub = threadIdx.x & 15;
+    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (t >= rows * K) return;
+    const int64_t r = t / K;
+    const int e = (int)(t - r * K);
+    const int32_t cc = col[t];
+    double acc = 0;
+    const bool ok = cc != 0x7fffffff;
+    if (ok) {
+        const float *x = Xs + (size_t)(row_begin + r) * dimp, *y = Xs + (size_t)cc * dimp;
+        for (int k = sub; k < dimp; k += 16) { double d = (double)x[k] - (double)y[k]; acc += d * d; }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+    if (sub == 0) {
+        odist[r * K + e] = ok ? (float)sqrt(acc) : INFINITY;
+        oidx[r * K + e] = ok ? perm_all[cc] : -1;
+    }
+}
+
+__global__ void k_st_rowsort(int64_t rows, int K, int64_t *__restrict__ oidx, float *__restrict__ odist)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    int64_t *ii = oidx + r * K;
+    float *dd = odist + r * K;
+    for (int a = 1; a < K; ++a) {  // insertion sort by (distance, id): K <= 32
+        const float d = dd[a];
+        const int64_t id = ii[a];
+        int p = a;
+        while (p > 0 && (dd[p - 1] > d || (dd[p - 1] == d && ii[p - 1] > id))) { dd[p] = dd[p - 1]; ii[p] = ii[p - 1]; --p; }
+        dd[p] = d; ii[p] = id;
+    }
+}
+
+template <int DIM, int KMAX> static int launch_knn2(annchor_ctx *c, const KnnArgs &a)
+{
+    const size_t lds = sizeof(KnnShared<DIM, KMAX>);
+    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "streamed k-NN needs %zu B of LDS", lds);
+    ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knn<DIM, KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_st_knn<DIM, KMAX><<<a.tile_count, ST_THREADS, lds, c->stream>>>(a);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
+template <int DIM> static int launch_knn(annchor_ctx *c, const KnnArgs &a)
+{
+    return a.K <= 16 ? launch_knn2<DIM, 16>(c, a) : launch_knn2<DIM, ST_KMAX>(c, a);
+}
+
+// k nearest neighbours (self included as column 0, like get_ann of annchor.py:514-530) of
+// the row tiles [tile_begin, tile_begin + tile_count) against ALL column tiles.  The five
+// array arguments are DEVICE pointers laid out as annchor_stream_order produces them
+// (concatenated over ranks for multi-GPU runs).  Outputs are HOST arrays:
+// ng_idx int64 [rows, k] (global ids), ng_dist float64 [rows, k], in tile order;
+// row_ids int64 [rows] gives the global id of each output row (-1 = padding row).
+extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void *rs_all, const void *perm_all,
+                                  const void *lo_all, const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors,
+                                  int32_t dim_padded, int32_t tile_begin, int32_t tile_count, int32_t k, double p_work,
+                                  int64_t *row_ids, int64_t *ng_idx, double *ng_dist, int64_t *tile_evals)
+{
+    if (!c || !Xs_all || !rs_all || !perm_all || !lo_all || !hi_all || !mid_all || !row_ids || !ng_idx || !ng_dist) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, k >= 2 && k - 1 <= ST_KMAX, ANNCHOR_ELIMIT, "streamed form supports 2 <= n_neighbors <= %d", ST_KMAX + 1);
+    ANN_REQUIRE(c, n_all == (int64_t)nt_all * ST_T && tile_begin >= 0 && tile_begin + tile_count <= nt_all, ANNCHOR_EINVAL,
+                "tile range out of bounds");
+    ANN_REQUIRE(c, n_all < (1ll << 31), ANNCHOR_ELIMIT, "n_all exceeds 2^31");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    StreamState *s = state_of(c, true);
+    const int K = k - 1;
+    const int64_t rows = (int64_t)tile_count * ST_T;
+    ANN_TRY(sreserve(c, s->out_d2, sizeof(float) * (size_t)rows * K));
+    ANN_TRY(sreserve(c, s->out_col, sizeof(int32_t) * (size_t)rows * K));
+    ANN_TRY(sreserve(c, s->evals, 64));
+    ANN_CHECK_HIP(c, hipMemsetAsync(s->evals.p, 0, 8, c->stream));
+    KnnArgs a;
+    a.Xs = (const float *)Xs_all; a.rs = (const float *)rs_all; a.lo = (const float *)lo_all; a.hi = (const float *)hi_all; a.mid = (const float *)mid_all;
+    a.nt_all = nt_all; a.na = n_anchors; a.tile_begin = tile_begin; a.tile_count = tile_count; a.K = K;
+    double mt = p_work >= 1.0 ? (double)nt_all : std::ceil(p_work * (double)nt_all);
+    a.max_tiles = (int)std::max(1.0, std::min(mt, (double)nt_all));
+    a.out_d2 = s->out_d2.as<float>(); a.out_col = s->out_col.as<int32_t>();
+    a.evals = s->evals.as<unsigned long long>();
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    {
+        // algorithmic flops are data dependent (tiles that survive the bound): reported by the caller from tile_evals
+        ProfScope ps(c, "stream_tile_gemm_topk", 0.0);
+        switch (dim_padded) {
+        case 32: ANN_TRY(launch_knn<32>(c, a)); break;
+        case 64: ANN_TRY(launch_knn<64>(c, a)); break;
+        case 128: ANN_TRY(launch_knn<128>(c, a)); break;
+        case 256: ANN_TRY(launch_knn<256>(c, a)); break;
+        default: ann_set_err(c, "unsupported padded dim %d", dim_padded); return ANNCHOR_ELIMIT;
+        }
+    }
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+    c->call_timed = true;
+    // exact distances of the selected neighbours, final order, ids
+    ANN_TRY(sreserve(c, s->keys, sizeof(int64_t) * (size_t)rows * K));   // reuse: ids
+    ANN_TRY(sreserve(c, s->keys2, sizeof(float) * (size_t)rows * K));    // reuse: distances
+    int64_t *d_idx = s->keys.as<int64_t>();
+    float *d_dist = s->keys2.as<float>();
+    {
+        ProfScope ps(c, "stream_finalize", (double)rows * K * (2.0 * dim_padded * 4 + 16));
+        k_st_finalize<<<ann_blocks(rows * K * 16, 256), 256, 0, c->stream>>>(a.Xs, (const int64_t *)perm_all, dim_padded,
+                                                                             (int64_t)tile_begin * ST_T, rows, K, a.out_col, d_idx,
+                                                                             d_dist);
+        k_st_rowsort<<<ann_blocks(rows, 256), 256, 0, c->stream>>>(rows, K, d_idx, d_dist);
+    }
+    ANN_CHECK_HIP(c, hipGetLastError());
+    std::vector<int64_t> hidx((size_t)rows * K);
+    std::vector<float> hd((size_t)rows * K);
+    ANN_TRY(ann_d2h(c, hidx.data(), d_idx, sizeof(int64_t) * hidx.size()));
+    ANN_TRY(ann_d2h(c, hd.data(), d_dist, sizeof(float) * hd.size()));
+    ANN_TRY(ann_d2h(c, row_ids, (const int64_t *)perm_all + (size_t)tile_begin * ST_T, sizeof(int64_t) * (size_t)rows));
+    for (int64_t r = 0; r < rows; ++r) {
+        ng_idx[r * k] = row_ids[r];
+        ng_dist[r * k] = 0.0;
+        for (int e = 0; e < K; ++e) {
+            ng_idx[r * k + 1 + e] = hidx[(size_t)r * K + e];
+            ng_dist[r * k + 1 + e] = (double)hd[(size_t)r * K + e];
+        }
+    }
+    if (tile_evals) {
+        unsigned long long ev = 0;
+        ANN_TRY(ann_d2h(c, &ev, s->evals.p, 8));
+        *tile_evals = (int64_t)ev;
+    }
+    return ANNCHOR_OK;
+}
+
+// ------------------------------------------------ raw device memory for host-staged gathers
+extern "C" int annchor_device_alloc(annchor_ctx *c, int64_t bytes, void **dptr)
+{
+    if (!c || !dptr || bytes <= 0) return ANNCHOR_EINVAL;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_CHECK_HIP(c, hipMalloc(dptr, (size_t)bytes));
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_device_free(annchor_ctx *c, void *dptr)
+{
+    if (!c) return ANNCHOR_EINVAL;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    if (dptr) ANN_CHECK_HIP(c, hipFree(dptr));
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_device_copy(annchor_ctx *c, void *dst, const void *src, int64_t bytes, int32_t kind)
+{
+    if (!c || !dst || !src || bytes < 0) return ANNCHOR_EINVAL;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    hipMemcpyKind kk = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    ANN_CHECK_HIP(c, hipMemcpyAsync(dst, src, (size_t)bytes, kk, c->stream));
+    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    return ANNCHOR_OK;
+}

@@ -1,0 +1,230 @@
+"""
+annchor_amd.streamed -- host orchestration of the streamed (tile-granular) form of the
+k-NN graph build for float32 Euclidean data at N >> 10^4, on one or several GPUs.
+
+One process per GPU, rows sharded contiguously: rank r owns rows
+[base_r, base_r + n_r).  Per stage (reference annchor/annchor.py:532-623 -> here):
+
+  get_anchors   max-min rounds (pickers.py:18-52).  Every round: the owner of the current
+                anchor broadcasts its coordinates (dim * 4 bytes), every rank sweeps its
+                rows on the GPU (one-to-all distances, running min, local arg-max), the
+                ranks all-gather (value, index) -- 16 bytes each -- and take the arg-max
+                with the first-index tie rule.
+  locality      each rank orders its rows by (nearest anchor, distance to it) into 128-row
+                tiles with per-anchor distance intervals.
+  exchange      all-gather of the ordered shards (rows, norms, ids) and of the interval
+                tables: the one real data exchange of the path (RCCL over xGMI when the
+                process group is `nccl`; staged through host memory otherwise).
+  refine+top-k  each rank evaluates its own row tiles against every column tile that its
+                triangle bound cannot exclude (MFMA tile GEMM + in-LDS top-k), within the
+                p_work tile budget.
+  result        each rank holds the graph rows of its shard; `gather_graph()` assembles
+                the full graph on every rank.
+
+With one rank the collectives are no-ops and no torch import happens.
+"""
+import numpy as np
+
+TILE = 128
+
+
+# ----------------------------------------------------------------------- comms
+class SingleComm:
+    rank, world = 0, 1
+
+    def allgather_obj(self, x):
+        return [x]
+
+    def bcast_array(self, arr, src, n, dtype):
+        return arr
+
+    def allgather_device(self, engine, dptr, nbytes):
+        return dptr, None
+
+
+class TorchComm:
+    """torch.distributed adapter.  `nccl` groups move device buffers directly (RCCL);
+    any other backend stages through host memory."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self._keep = []
+
+    def allgather_obj(self, x):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, x, group=self.group)
+        return out
+
+    def bcast_array(self, arr, src, n, dtype):
+        import torch
+
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.empty(n, dtype=getattr(torch, np.dtype(dtype).name), device=dev)
+        if self.rank == src:
+            t.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)))
+        self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, src) if self.group is not None else src,
+                            group=self.group)
+        return t.cpu().numpy()
+
+    def allgather_device(self, engine, dptr, nbytes):
+        """All-gather `nbytes` bytes at device pointer `dptr` from every rank; returns the
+        device pointer of the rank-ordered concatenation (+ an owner object to keep alive)."""
+        import torch
+
+        if self.backend == "nccl":
+            inp = device_tensor_u8(dptr, nbytes, engine.device)
+            out = torch.empty(self.world * nbytes, dtype=torch.uint8, device=inp.device)
+            torch.cuda.synchronize(inp.device)
+            self.dist.all_gather_into_tensor(out, inp, group=self.group)
+            torch.cuda.synchronize(inp.device)
+            return out.data_ptr(), out
+        host = np.empty(nbytes, dtype=np.uint8)
+        engine.device_copy(host.ctypes.data, dptr, nbytes, "d2h")
+        parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+        self.dist.all_gather(parts, torch.from_numpy(host), group=self.group)
+        allh = torch.cat(parts).numpy()
+        out = engine.device_alloc(allh.nbytes)
+        engine.device_copy(out, allh.ctypes.data, allh.nbytes, "h2d")
+        return out, _DeviceOwner(engine, out)
+
+
+class _DeviceOwner:
+    def __init__(self, engine, ptr):
+        self.engine, self.ptr = engine, ptr
+
+    def __del__(self):
+        try:
+            self.engine.device_free(self.ptr)
+        except Exception:
+            pass
+
+
+class _CAI:
+    """Minimal __cuda_array_interface__ carrier for a raw device pointer."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor_u8(ptr, nbytes, device=0):
+    """View `nbytes` bytes of device memory at `ptr` as a torch uint8 tensor (no copy)."""
+    import torch
+
+    return torch.as_tensor(_CAI(ptr, nbytes), device=torch.device("cuda", device))
+
+
+# ------------------------------------------------------------------ helpers
+def owner_of(ix, shards):
+    """Rank whose shard [base, base+n) contains global row ix."""
+    for r, (base, n) in enumerate(shards):
+        if base <= ix < base + n:
+            return r
+    raise ValueError("row %d is in no shard" % ix)
+
+
+def combine_argmax(cands):
+    """Global arg-max of per-rank (value, global index): largest value, then smallest index
+    (np.argmax's first-index rule, pickers.py:47-50)."""
+    best_v, best_i = -np.inf, None
+    for v, i in cands:
+        if best_i is None or v > best_v or (v == best_v and i < best_i):
+            best_v, best_i = v, i
+    return int(best_i)
+
+
+class StreamedAnnchor:
+    """k-NN graph of float32 points under the Euclidean metric, streamed form.
+
+    X is THIS rank's shard (float32 [n_local, dim]); `base` its first global row id.
+    `engine` is an `annchor_amd._native.Engine` (or any object with the same stream_*
+    methods -- the CPU tests use a NumPy stand-in to exercise the multi-rank protocol)."""
+
+    def __init__(self, X, n_anchors=32, n_neighbors=15, p_work=0.1, random_seed=42, base=0, comm=None, engine=None,
+                 device=0):
+        self.X = np.ascontiguousarray(X, dtype=np.float32)
+        self.n_local, self.dim = self.X.shape
+        self.n_anchors, self.n_neighbors, self.p_work = n_anchors, n_neighbors, p_work
+        self.random_seed, self.base = random_seed, int(base)
+        self.comm = comm if comm is not None else SingleComm()
+        if engine is None:
+            from . import _native
+
+            engine = _native.Engine(device)
+        self._engine = engine
+        self._engine.stream_bind(self.X, self.base)
+        self.shards = self.comm.allgather_obj((self.base, self.n_local))
+        self.n_total = int(sum(n for _, n in self.shards))
+        self.evals = 0
+        self.timings = {}
+
+    def get_anchors(self):
+        eng, comm, na = self._engine, self.comm, self.n_anchors
+        np.random.seed(self.random_seed)
+        ix = int(np.random.randint(self.n_total))  # identical on every rank
+        A = np.zeros(na, dtype=np.int64)
+        for r in range(na):
+            A[r] = ix
+            src = owner_of(ix, self.shards)
+            vec = eng.stream_get_row(ix - self.base) if comm.rank == src else None
+            vec = comm.bcast_array(vec, src, self.dim, np.float32)
+            lmax, larg = eng.stream_anchor_round(vec, r, na)
+            ix = combine_argmax(comm.allgather_obj((float(lmax), int(self.base + larg))))
+        self.A = A
+        self.evals += na * self.n_total
+
+    def fit(self):
+        import time
+
+        t0 = time.perf_counter()
+        eng, comm = self._engine, self.comm
+        self.get_anchors()
+        t1 = time.perf_counter()
+        min_tiles = max((n + TILE - 1) // TILE for _, n in self.shards)
+        ptrs, n_pad, nt, dimp = eng.stream_order(min_tiles)
+        t2 = time.perf_counter()
+        keep = []
+        if comm.world > 1:
+            sizes = {"Xs": n_pad * dimp * 4, "rs": n_pad * 4, "perm": n_pad * 8}
+            allp = {}
+            for name, nbytes in sizes.items():
+                allp[name], owner = comm.allgather_device(eng, ptrs[name], nbytes)
+                keep.append(owner)
+            # interval tables [n_anchors, nt] are small: gather on the host, join along the tile axis
+            for name in ("lo", "hi", "mid"):
+                host = np.empty((self.n_anchors, nt), dtype=np.float32)
+                eng.device_copy(host.ctypes.data, ptrs[name], host.nbytes, "d2h")
+                joined = np.ascontiguousarray(np.concatenate(comm.allgather_obj(host), axis=1))
+                d = eng.device_alloc(joined.nbytes)
+                eng.device_copy(d, joined.ctypes.data, joined.nbytes, "h2d")
+                allp[name] = d
+                keep.append(_DeviceOwner(eng, d))
+            ptrs = allp
+        t3 = time.perf_counter()
+        n_all, nt_all = n_pad * comm.world, nt * comm.world
+        row_ids, idx, dist, tile_evals = eng.stream_knn(ptrs, n_all, nt_all, self.n_anchors, dimp, comm.rank * nt, nt,
+                                                        self.n_neighbors, self.p_work)
+        t4 = time.perf_counter()
+        del keep
+        real = row_ids >= 0
+        loc = row_ids[real] - self.base
+        k = self.n_neighbors
+        ng_idx = np.zeros((self.n_local, k), dtype=np.int64)
+        ng_dist = np.zeros((self.n_local, k), dtype=np.float64)
+        ng_idx[loc], ng_dist[loc] = idx[real], dist[real]
+        self.neighbor_graph = (ng_idx, ng_dist)
+        self.tile_evals = int(tile_evals)
+        self.evals += self.tile_evals * TILE * TILE
+        self.n_tiles_total = nt_all
+        self.timings = dict(get_anchors=t1 - t0, order=t2 - t1, exchange=t3 - t2, knn=t4 - t3, total=time.perf_counter() - t0)
+        return self
+
+    def gather_graph(self):
+        """Full graph (all shards, global row order) on every rank: the final
+        neighbour-graph gather."""
+        parts = self.comm.allgather_obj((self.base, self.neighbor_graph[0], self.neighbor_graph[1]))
+        parts.sort(key=lambda p: p[0])
+        return np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])

@@ -183,6 +183,43 @@ int annchor_update_bounds(annchor_ctx *ctx);
  * ng_dist float64 [nx, k], column 0 = self. */
 int annchor_neighbor_graph(annchor_ctx *ctx, int32_t n_neighbors, int64_t *ng_idx, double *ng_dist);
 
+/* ------------------------------------------------ streamed form (large-N Euclidean)
+ * Tile-granular form of the same path for float32 points when the pair list cannot
+ * exist (N >> 10^4).  One context = one GPU = one
+ * contiguous shard of rows [global_base, global_base + n_local).  See
+ * annchor_amd/csrc/streamed.hip for how each stage of Annchor.fit()
+ * (annchor/annchor.py:532-623) maps onto tiles.
+ *
+ * annchor_stream_bind: copy the shard (host or device pointer) into the context.
+ * annchor_stream_anchor_round: one max-min round (annchor/pickers.py:44-50) on the shard:
+ *   distances of every local row to `anchor_vec` (host float32 [dim]), running-min update,
+ *   local arg-max (local index, first index on ties).  The host combines ranks.
+ * annchor_stream_get_row: fetch one local row (the next anchor's coordinates).
+ * annchor_stream_order: order rows by (nearest anchor, distance), build 128-row tiles and
+ *   their anchor-distance intervals; returns DEVICE pointers (owned by the context) for a
+ *   multi-GPU host to all-gather: Xs float32 [n_pad, dim_padded], rs float32 [n_pad],
+ *   perm int64 [n_pad] (global ids, -1 on padding), lo/hi/mid float32 [n_anchors, n_tiles]
+ *   (per-tile min / max / mean distance to each anchor).
+ *   min_tiles pads the shard to a common tile count across ranks.
+ * annchor_stream_knn: k-NN rows of tiles [tile_begin, tile_begin+tile_count) against all
+ *   column tiles (DEVICE pointers, concatenated over ranks); get_ann-shaped HOST outputs
+ *   (annchor/annchor.py:514-530): column 0 = self. */
+int annchor_stream_bind(annchor_ctx *ctx, const float *X, int64_t n_local, int32_t dim, int64_t global_base,
+                        int32_t x_on_device);
+int annchor_stream_anchor_round(annchor_ctx *ctx, const float *anchor_vec, int32_t round, int32_t n_anchors,
+                                double *local_max, int64_t *local_arg);
+int annchor_stream_get_row(annchor_ctx *ctx, int64_t local_idx, float *out);
+int annchor_stream_order(annchor_ctx *ctx, int32_t min_tiles, void **Xs, void **rs, void **perm, void **lo, void **hi,
+                         void **mid, int64_t *n_pad, int32_t *n_tiles, int32_t *dim_padded);
+int annchor_stream_knn(annchor_ctx *ctx, const void *Xs_all, const void *rs_all, const void *perm_all, const void *lo_all,
+                       const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors, int32_t dim_padded,
+                       int32_t tile_begin, int32_t tile_count, int32_t k, double p_work, int64_t *row_ids,
+                       int64_t *ng_idx, double *ng_dist, int64_t *tile_evals);
+/* Raw device copies for hosts that stage the all-gather through host memory. */
+int annchor_device_alloc(annchor_ctx *ctx, int64_t bytes, void **dptr);
+int annchor_device_free(annchor_ctx *ctx, void *dptr);
+int annchor_device_copy(annchor_ctx *ctx, void *dst, const void *src, int64_t bytes, int32_t kind /*1 H2D, 2 D2H, 3 D2D*/);
+
 /* -------------------------------------------------------------- state access */
 int annchor_field_size(annchor_ctx *ctx, int32_t field, int64_t *n_elems);
 int annchor_download(annchor_ctx *ctx, int32_t field, void *dst, int64_t n_elems);

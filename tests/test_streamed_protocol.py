@@ -1,0 +1,85 @@
+"""CPU tests of the multi-rank (row-sharded) orchestration: two gloo ranks with a NumPy
+engine must pick the same anchors and produce the same graph as one rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+
+
+def _data(n=700, d=12, seed=5):
+    rng = np.random.default_rng(seed)
+    Z = rng.standard_normal((n, 4))
+    W = rng.standard_normal((4, d))
+    return (Z @ W + 0.05 * rng.standard_normal((n, d))).astype(np.float32)
+
+
+def test_helpers():
+    from annchor_amd.streamed import combine_argmax, owner_of
+
+    shards = [(0, 300), (300, 280), (580, 120)]
+    assert owner_of(0, shards) == 0 and owner_of(299, shards) == 0 and owner_of(300, shards) == 1 and owner_of(699, shards) == 2
+    with pytest.raises(ValueError):
+        owner_of(700, shards)
+    assert combine_argmax([(1.0, 5), (3.0, 9), (3.0, 7), (2.0, 1)]) == 7   # first index on ties
+    assert combine_argmax([(-np.inf, 3)]) == 3
+
+
+def test_single_rank_matches_bruteforce_and_oracle_anchors():
+    from fake_stream_engine import FakeStreamEngine
+    from annchor_amd.streamed import StreamedAnnchor
+    from oracle import annchor_oracle as O
+
+    X = _data()
+    sa = StreamedAnnchor(X, n_anchors=6, n_neighbors=5, p_work=1.0, random_seed=42, engine=FakeStreamEngine()).fit()
+
+    def one_to_all(ix):
+        return np.sqrt(((X - X[ix][None, :]) ** 2).sum(axis=1, dtype=np.float32)).astype(np.float32)
+
+    A, _ = O.maxmin_anchors(one_to_all, len(X), 6, 42)   # the reference picker semantics (pickers.py:18-52)
+    assert np.array_equal(sa.A, A)
+    idx, dist = sa.neighbor_graph
+    assert np.array_equal(idx[:, 0], np.arange(len(X))) and np.all(dist[:, 0] == 0)
+    D = np.sqrt(((X[:, None, :].astype(np.float64) - X[None, :, :]) ** 2).sum(-1))
+    np.testing.assert_allclose(dist, np.sort(D, axis=1)[:, :5], rtol=1e-5, atol=1e-6)
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fake_stream_engine import FakeStreamEngine
+    from annchor_amd.streamed import StreamedAnnchor, TorchComm
+
+    X = _data()
+    cuts = [0, 410, 700]   # ragged shards: 410 and 290 rows (different tile counts -> padding path)
+    Xl = X[cuts[rank]:cuts[rank + 1]]
+    sa = StreamedAnnchor(Xl, n_anchors=6, n_neighbors=5, p_work=1.0, random_seed=42, base=cuts[rank], comm=TorchComm(),
+                         engine=FakeStreamEngine()).fit()
+    gi, gd = sa.gather_graph()
+    if rank == 0:
+        np.savez(out, A=sa.A, idx=gi, dist=gd, evals=sa.evals)
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_equal_one_rank(tmp_path):
+    import torch.multiprocessing as mp
+
+    from fake_stream_engine import FakeStreamEngine
+    from annchor_amd.streamed import StreamedAnnchor
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "w2.npz")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    R = np.load(out)
+    one = StreamedAnnchor(_data(), n_anchors=6, n_neighbors=5, p_work=1.0, random_seed=42, engine=FakeStreamEngine()).fit()
+    assert np.array_equal(R["A"], one.A)
+    assert np.array_equal(R["idx"], one.neighbor_graph[0])
+    np.testing.assert_allclose(R["dist"], one.neighbor_graph[1], rtol=0, atol=0)
