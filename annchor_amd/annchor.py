@@ -26,6 +26,10 @@ from .regressors import SimpleStratifiedLinearRegression
 from .samplers import NothingToSample, SimpleStratifiedSampler
 from .utils import get_exact_ijs_, get_function_from_input, test_parallelisation
 
+from .distances import euclidean as distances_euclidean  # noqa: E402
+
+PAIRLIST_MAX_POINTS = 20000  # above this the candidate pair list (~nx^2/2 x ~100 B) is not materialised
+
 FEATURE_NAMES = ["lower bound", "upper bound", "double anchor distance", "is anchor"]
 
 
@@ -104,6 +108,23 @@ class Annchor:
         self.feature_names = list(FEATURE_NAMES)
         assert backend in ["loky", "multiprocessing"]
         self.backend = backend
+
+        # ---- large float Euclidean data: the streamed (tile-granular) form.  The pair list of
+        # the reference would hold ~nx^2/2 entries (hard part 3).
+        self._streamed = None
+        defaults = anchor_picker is None and sampler is None and regression is None and error_predictor is None
+        if (self.f is distances_euclidean and get_exact_ijs is None and defaults and self.nx > PAIRLIST_MAX_POINTS
+                and getattr(np.asarray(X), "ndim", 0) == 2 and np.asarray(X).shape[1] <= 256):
+            from .streamed import StreamedAnnchor
+
+            self._streamed = StreamedAnnchor(np.asarray(X, dtype=np.float32), n_anchors=n_anchors, n_neighbors=n_neighbors,
+                                             p_work=self.p_work, random_seed=random_seed, device=device)
+            self._engine = self._streamed._engine
+            self._device_metric = True
+            self.get_exact_ijs = self._device_get_exact_ijs
+            self.get_exact_query_ijs = None
+            self._cache, self.timings = {}, {}
+            return
 
         # ---- the engine: fails loudly when the HIP library or a GPU is missing
         self._engine = _native.Engine(device)
@@ -299,6 +320,12 @@ class Annchor:
 
     def fit(self):
         """Computes the approximate nearest-neighbour graph (annchor.py:532-623)."""
+        if self._streamed is not None:
+            st = self._streamed.fit()
+            self.neighbor_graph = st.neighbor_graph
+            self._cache["A"] = st.A
+            self.evals, self.timings = st.evals, st.timings
+            return self
         origin = time.perf_counter()
         t = self.timings = {}
 

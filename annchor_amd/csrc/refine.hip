@@ -21,7 +21,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_comp_count(const int64_t *__res
     __shared__ uint32_t acc;
     if (threadIdx.x == 0) acc = 0;
     __syncthreads();
-    const int64_t i = blockIdx.x, b = Iptr[i];
+    const int64_t i = row_of_block(gridDim.x), b = Iptr[i];
     const int len = (int)(Iptr[i + 1] - b);
     uint32_t s = 0;
     for (int k = threadIdx.x; k < len; k += ROW_THREADS) s += !ncm[Iidx[b + k]];
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_comp_fill(const int64_t *__rest
                                                           int32_t *__restrict__ cidx, double *__restrict__ cval)
 {
     __shared__ uint32_t wsum[ROW_THREADS / 64];
-    const int64_t i = blockIdx.x, b = Iptr[i];
+    const int64_t i = row_of_block(gridDim.x), b = Iptr[i];
     const int len = (int)(Iptr[i + 1] - b);
     int64_t w = cptr[i];
     for (int base = 0; base < len; base += ROW_THREADS) {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_get_nn(const int64_t *__restric
     const int L = nn - 1;
     uint64_t *lkey = reinterpret_cast<uint64_t *>(dyn);      // [L]
     int32_t *lslot = reinterpret_cast<int32_t *>(lkey + L);  // [L]
-    const int64_t i = blockIdx.x, b = Iptr[i];
+    const int64_t i = row_of_block(gridDim.x), b = Iptr[i];
     const int len = (int)(Iptr[i + 1] - b);
     if (threadIdx.x == 0) { ngi[i * nn] = i; ngd[i * nn] = 0.0; cnt_lt = 0; }
     // row maximum of RA (utils.py:418)

@@ -6,6 +6,17 @@
 #include "common.h"
 
 #define ROW_THREADS 256
+
+// Row owned by this workgroup.  Workgroups are dispatched round-robin over the 8 XCDs
+// (block b -> XCD b % 8, a speed heuristic only): give each XCD a contiguous band of rows
+// so that the column-like half of a row's gather (pairs (j, i), j < i, one 8-byte value per
+// 64-byte line) is shared through that XCD's own L2 by the neighbouring rows.
+__device__ __forceinline__ int64_t row_of_block(int64_t nrows)
+{
+    const int64_t b = blockIdx.x, q = nrows >> 3, r = nrows & 7, x = b & 7, y = b >> 3;
+    // bijective for any nrows: XCD x owns q (+1 if x < r) rows
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+}
 #define ROW_LDS_KEYS 6144  // rows up to this many entries keep their keys in LDS (48 KiB)
 
 struct RowSelShared {

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row_thresh(const int64_t *__res
 {
     __shared__ RowSelShared sh;
     __shared__ uint64_t keys[ROW_LDS_KEYS];
-    const int64_t i = blockIdx.x;
+    const int64_t i = row_of_block(gridDim.x);
     const int64_t b = Iptr[i];
     const int len = (int)(Iptr[i + 1] - b);
     if (len <= 0) { if (threadIdx.x == 0) thresh[i] = INFINITY; return; }
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_gn_lists(const int64_t *__restr
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     uint64_t *lkey = reinterpret_cast<uint64_t *>(dyn);       // [L]
     int32_t *lslot = reinterpret_cast<int32_t *>(lkey + L);   // [L]
-    const int64_t i = blockIdx.x;
+    const int64_t i = row_of_block(gridDim.x);
     const int64_t b = Iptr[i];
     const int len = (int)(Iptr[i + 1] - b);
     const bool in_lds = len <= ROW_LDS_KEYS;

@@ -54,6 +54,94 @@ def lev_work(ann, X):
     return len(li), word_steps, cells
 
 
+def euclid_shard(rank, n_per_rank, d=128):
+    """SURVEY.md section 8d recipe (8-d latent manifold in 128-d), sharded by rows: shard r is
+    generated from its own stream so that no rank ever holds the whole set."""
+    W = np.random.default_rng(1234).standard_normal((8, d))
+    rng = np.random.default_rng(10_000 + rank)
+    Z = rng.standard_normal((n_per_rank, 8))
+    return (Z @ W + 0.05 * rng.standard_normal((n_per_rank, d))).astype(np.float32)
+
+
+def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch):
+    """BASELINE configs[2]/[4]: synthetic Euclidean float32, 1M rows per GPU, d=128,
+    n_anchors=32, k=15, p_work=0.1, rows sharded across ranks (streamed form)."""
+    from annchor_amd.streamed import SingleComm, StreamedAnnchor, TorchComm
+
+    X = euclid_shard(rank, n_per_rank)
+    comm = TorchComm() if world > 1 else SingleComm()
+    k, pw, na = 15, 0.1, 32
+    times, last = [], None
+    for it in range(warmup + steps):
+        sa = StreamedAnnchor(X, n_anchors=na, n_neighbors=k, p_work=pw, base=rank * n_per_rank, comm=comm, device=local)
+        sa._engine.prof_enable(True)
+        torch.cuda.synchronize()
+        if dist_mod is not None:
+            dist_mod.barrier()
+        t0 = time.perf_counter()
+        sa.fit()
+        torch.cuda.synchronize()
+        if dist_mod is not None:
+            dist_mod.barrier()
+        dt = time.perf_counter() - t0
+        if dist_mod is not None:
+            tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist_mod.all_reduce(tt, op=dist_mod.ReduceOp.MAX)
+            dt = float(tt.item())
+        if it >= warmup:
+            times.append(dt)
+        last = sa
+    out = None
+    if rank == 0:
+        prof = last._engine.prof_get()
+        gemm = prof.get("stream_tile_gemm_topk", dict(ms=0.0, launches=1))
+        flops = last.tile_evals * 128.0 * 128.0 * 2.0 * 128.0
+        gemm_s = gemm["ms"] / max(1, gemm["launches"]) * 1e-3
+        # recall on a 200-row sample of rank 0's shard against ALL shards (regenerated one at a time)
+        rows = np.random.default_rng(1).choice(n_per_rank, 200, replace=False)
+        q = X[rows].astype(np.float64)
+        best_d = np.full((200, k), np.inf)
+        for r in range(world):
+            Y = (X if r == 0 else euclid_shard(r, n_per_rank)).astype(np.float64)
+            d2 = (q ** 2).sum(1)[:, None] + (Y ** 2).sum(1)[None, :] - 2.0 * q @ Y.T
+            if r == 0:
+                d2[np.arange(200), rows] = -1.0
+            part = np.sort(np.sqrt(np.maximum(np.partition(d2, k, axis=1)[:, :k], 0)), axis=1)
+            best_d = np.sort(np.concatenate([best_d, part], axis=1), axis=1)[:, :k]
+        from annchor_amd import compare_neighbor_graphs
+
+        err = compare_neighbor_graphs((np.zeros((200, k), dtype=np.int64), best_d),
+                                      (last.neighbor_graph[0][rows], last.neighbor_graph[1][rows]), k)
+        fit_s = float(np.mean(times))
+        out = {
+            "workload": "synthetic Euclidean f32 (8-d latent in 128-d), %d rows/GPU x %d GPU(s), n_anchors=32 k=15 p_work=0.1, "
+                        "row-sharded streamed form" % (n_per_rank, world),
+            "fit_time_s": fit_s, "graphs_per_s": 1.0 / fit_s, "rows_per_s": world * n_per_rank / fit_s,
+            "recall_at_k_200row_sample": 1.0 - err / (200.0 * k), "tile_evals_rank0": int(last.tile_evals),
+            "tile_fraction": last.tile_evals / float((last.n_tiles_total // world) * last.n_tiles_total),
+            "stage_s_rank0": {a: round(b, 4) for a, b in last.timings.items()},
+            "roofline": {"kernel": "stream_tile_gemm_topk (k_st_knn, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                         "achieved": flops / gemm_s / 1e12 if gemm_s > 0 else 0.0, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": (flops / gemm_s / 1e12 / 157.3) if gemm_s > 0 else 0.0, "traffic": pmc_traffic("k_st_knn"),
+                         "note": "algorithmic flops = evaluated tile pairs x 128 x 128 x 2 x d; peak = dense f32 MFMA"},
+            "kernels_ms_rank0": {kk: round(v["ms"], 3) for kk, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+        }
+    return out
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units, FETCH doubled as the gfx950 guide prescribes)."""
+    try:
+        T = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        for name, v in T.items():
+            if name.replace("void ", "").startswith(kernel_prefix):
+                return v["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(X, cfg):
     """The oracle (CPU restatement) timed on this box: one full fit() of the same
     workload (~10 s): C Levenshtein (Myers, OpenMP over all cores) + NumPy pipeline."""
@@ -77,6 +165,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--no-euclid", action="store_true", help="skip the secondary row-sharded Euclidean workload")
+    ap.add_argument("--euclid-rows", type=int, default=1_000_000, help="rows per GPU of the Euclidean workload")
     args = ap.parse_args()
 
     import torch
@@ -122,6 +212,14 @@ def main():
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    euclid = None
+    if not args.no_euclid:
+        del anns[:args.warmup]
+        try:
+            euclid = euclid_run(world, rank, local, dist, args.euclid_rows, 2, 1, torch)
+        except Exception as e:  # the secondary workload must never cost the primary line
+            euclid = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         ann = timed[-1]
@@ -175,7 +273,7 @@ def main():
                 ach = word_steps * LEV_OPS_PER_WORD_STEP / lev_s / 1e12
                 out["roofline"] = {
                     "kernel": dom, "bound": "valu_int32", "achieved": ach, "peak": INT32_VALU_PEAK_TOPS,
-                    "unit": "Tops/s", "frac": ach / INT32_VALU_PEAK_TOPS, "traffic": None,
+                    "unit": "Tops/s", "frac": ach / INT32_VALU_PEAK_TOPS, "traffic": pmc_traffic("k_lev"),
                     "gcups": cells / lev_s / 1e9, "pairs_per_fit": npairs, "word_steps_per_fit": word_steps,
                     "note": "integer-ALU bound (string pool is 1 MB, cache resident): HBM fraction is not meaningful "
                             "for this kernel; the HBM-bound pair-list kernels are listed under `kernels`",
@@ -184,6 +282,8 @@ def main():
                 g = kernels[dom]
                 out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": g["alg_GBps"], "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": g["hbm_frac"], "traffic": None}
+        if euclid is not None:
+            out["euclid_row_sharded"] = euclid
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(X, cfg)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -135,3 +135,15 @@ def test_two_ranks_row_sharded_equal_one_rank(tmp_path):
     np.testing.assert_allclose(R["dist"], one.neighbor_graph[1], rtol=1e-6, atol=1e-6)
     same = (R["idx"] == one.neighbor_graph[0]).mean()
     assert same > 0.999   # identical up to exact-tie order between differently tiled runs
+
+
+def test_annchor_api_dispatches_large_euclidean_to_streamed_form():
+    from annchor_amd import Annchor
+
+    X = latent(21000, 32)
+    ann = Annchor(X, "euclidean", n_anchors=8, n_neighbors=6, p_work=1.0).fit()
+    assert ann._streamed is not None and ann.neighbor_graph[0].shape == (21000, 6)
+    rows = np.arange(0, 21000, 701)
+    bi, bd = brute(X, rows, 6)
+    np.testing.assert_allclose(ann.neighbor_graph[1][rows], bd, rtol=1e-5, atol=1e-6)
+    assert len(ann.A) == 8 and ann.evals > 0
