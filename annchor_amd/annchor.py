@@ -389,9 +389,11 @@ class BruteForce:
             self.get_exact_ijs = get_exact_ijs
         test_parallelisation(self.get_exact_ijs, self.f, self.X, self.nx, backend, s=20)
 
-    def fit(self):
+    def fit(self, n_neighbors=None):
+        """Full rows like the reference (annchor.py:1020-1023) by default; `n_neighbors` keeps
+        only the first columns (needed above ~8000 points)."""
         if self._device_metric:
-            self.neighbor_graph = self._engine.brute_force(self.nx)
+            self.neighbor_graph = self._engine.brute_force(self.nx if n_neighbors is None else min(n_neighbors, self.nx))
             return self
         iu = np.triu_indices(self.nx, k=1)
         IJs = np.stack(iu, axis=1)

@@ -336,3 +336,30 @@ def test_fit_digits_c4():
     idx, dist = ann.neighbor_graph
     IJ = np.stack([np.repeat(np.arange(1797), 24), idx[:, 1:].ravel()], axis=1)
     np.testing.assert_allclose(om.Histograms(d["X"], d["cost_matrix"]).pairs(IJ), dist[:, 1:].ravel(), rtol=0, atol=1e-9)
+
+
+# ------------------------------------------------------------------ BruteForce (f1)
+def test_brute_force_digits_matches_stored_graph():
+    """reference tests/test_annchor.py:216-248: BruteForce on X[:500] == stored graph restricted
+    to the first 500 points -> 0 errors."""
+    from annchor_amd import BruteForce, compare_neighbor_graphs
+
+    d = om.load_digits()
+    ngi, ngd = d["neighbor_graph"]
+    small = (np.array([ngi[i][ngi[i] < 500][:10] for i in range(500)]), np.array([ngd[i][ngi[i] < 500][:10] for i in range(500)]))
+    bf = BruteForce(d["X"][:500], "wasserstein", func_kwargs={"cost_matrix": d["cost_matrix"]}).fit()
+    assert bf.neighbor_graph[0].shape == (500, 500)
+    assert compare_neighbor_graphs(small, bf.neighbor_graph, 10) == 0
+    assert np.array_equal(bf.neighbor_graph[0][:, 0], np.arange(500))
+
+
+def test_brute_force_strings_equals_oracle(strings):
+    from annchor_amd import BruteForce
+
+    Xs = strings[::4]
+    bf = BruteForce(np.array(Xs), "levenshtein").fit()
+    oi, od, _ = O.brute_force(om.PackedStrings(Xs).pairs, len(Xs))
+    assert np.array_equal(bf.neighbor_graph[1], od)
+    assert np.array_equal(bf.neighbor_graph[0], oi)   # stable (distance, index) order
+    part = BruteForce(np.array(Xs), "levenshtein").fit(n_neighbors=7)
+    assert np.array_equal(part.neighbor_graph[0], oi[:, :7])
