@@ -49,6 +49,7 @@ _SIGNATURES = {
     "annchor_kth_uncomputed_dad": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
     "annchor_bin_counts": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
     "annchor_select_by_rank": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _vp]),
+    "annchor_legacy_prefetch": (ctypes.c_int, [ctypes.c_uint32, _i64]),
     "annchor_legacy_choice_ranks": (ctypes.c_int, [ctypes.c_uint32, _vp, _vp, _i32, _vp, _vp]),
     "annchor_gather_features": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "annchor_evaluate_samples": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
@@ -113,6 +114,12 @@ def _ptr(a):
 
 def _c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
+
+
+def legacy_prefetch(seed, ndraws):
+    """Begin producing the legacy MT19937 stream of `seed` on a background thread."""
+    if 0 <= seed < 2 ** 32 and ndraws > 0:
+        load_library().annchor_legacy_prefetch(int(seed), int(ndraws))
 
 
 def legacy_choice_ranks(seed, counts, want):

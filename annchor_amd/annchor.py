@@ -328,6 +328,11 @@ class Annchor:
             return self
         origin = time.perf_counter()
         t = self.timings = {}
+        if type(self.sampler) is SimpleStratifiedSampler:
+            # the sampler's MT19937 streams depend on the seeds only: produce them on host
+            # threads while the GPU runs the stages before each sampling step
+            for it in range(self.niters):
+                _native.legacy_prefetch(self.random_seed + self.sampler.loop_num + it, self.N + self.N // 2 + 4096)
 
         def stage(name, fn, *a, **k):
             s = time.perf_counter()

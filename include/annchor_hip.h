@@ -135,6 +135,10 @@ int annchor_select_by_rank(annchor_ctx *ctx, const double *bins, int32_t nbins, 
  * returned as ranks into the bin (= positions of the legacy permutation prefix);
  * a bin with counts[b] < want[b] yields 0..counts[b]-1 without consuming the stream.
  * ranks_out must hold sum(min(counts, want)); n_out[b] = entries written for bin b. */
+/* Start generating the raw MT19937 stream of `seed` on a background host thread (it
+ * depends on the seed only); a later annchor_legacy_choice_ranks(seed, ...) consumes it.
+ * Purely an overlap device: results are identical with or without it. */
+int annchor_legacy_prefetch(uint32_t seed, int64_t ndraws);
 int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins,
                                 int64_t *ranks_out, int64_t *n_out);
 /* Gather features [m, 4] at the given pair positions (self.features[sample_ixs]). */

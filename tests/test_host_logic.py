@@ -144,6 +144,8 @@ def test_library_rng_matches_numpy_legacy_stream():
              ([1, 2, 3], [1, 1, 3])]
     for seed in (0, 42, 43, 2 ** 32 - 1):
         for counts, want in cases:
+            if seed in (42, 43):   # with and without a background-prefetched stream (short one: forces inline extension)
+                _native.legacy_prefetch(seed, 5000 if seed == 42 else 200000)
             got = _native.legacy_choice_ranks(seed, counts, want)
             np.random.seed(seed)
             ref = [np.arange(c) if c < w else np.random.permutation(int(c))[:w] for c, w in zip(counts, want)]
