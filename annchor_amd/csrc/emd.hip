@@ -117,16 +117,36 @@ __global__ __launch_bounds__(512) void k_emd(EmdArgs a)
         double a_rem = lane < n ? hx[myrow] / sa : 0.0;  // supply of source `lane`
         double b_rem = lane < m ? hy[mycol] / sb : 0.0;  // demand of sink `lane`
         double u = 0.0;                                  // potential of source `lane`
-        // v_j = min_i C[i][j]
+        // v_j = min_i C[i][j] (first minimal source on ties): dual feasible with u = 0, and
+        // arc (amin_j, j) is tight for every sink
         double v = INFINITY;
+        int amin = 0;
         for (int i = 0; i < n; ++i) {
             const int r = __builtin_amdgcn_readlane(myrow, i);
-            if (lane < m) v = fmin(v, costL[r * nb + mycol]);
+            if (lane < m) {
+                const double cc = costL[r * nb + mycol];
+                if (cc < v) { v = cc; amin = i; }
+            }
         }
         // zero the flow slab
         for (int i = 0; i < n; ++i)
             if (lane < m) F[i * S + lane] = 0.0;
         __builtin_amdgcn_wave_barrier();
+        // greedy start on the tight arcs (complementary slackness holds: flow only where the
+        // reduced cost is zero).  For near-by histograms most mass sits on identical bins
+        // (cost 0) and is routed here, before any shortest-path search.
+        for (int j = 0; j < m; ++j) {
+            const int i = __builtin_amdgcn_readlane(amin, j);
+            const double f = fmin(readlane_f64(a_rem, i), readlane_f64(b_rem, j));
+            if (f > 0.0) {
+                if (lane == 0) F[i * S + j] = f;
+                if (lane == i) a_rem -= f;
+                if (lane == j) b_rem -= f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
         int guard = 64 * (n + m) + 1024;
         bool failed = false, dust = false;
