@@ -44,6 +44,7 @@ _SIGNATURES = {
     "annchor_pick_anchors_selected": (ctypes.c_int, [_vp, _vp, _i32]),
     "annchor_set_anchor_distances": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i32]),
     "annchor_build_locality": (ctypes.c_int, [_vp, _i32, _i32, _i32, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "annchor_build_query_locality": (ctypes.c_int, [_vp, _i64, _i32, _i32, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "annchor_compute_features": (ctypes.c_int, [_vp]),
     "annchor_count_uncomputed": (ctypes.c_int, [_vp, ctypes.POINTER(_i64)]),
     "annchor_kth_uncomputed_dad": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
@@ -237,6 +238,12 @@ class Engine:
         n, m = _i64(), _i64()
         self._chk(self.lib.annchor_build_locality(self.h, int(locality), int(loc_thresh), int(loc_min),
                                                   ctypes.byref(n), ctypes.byref(m)))
+        return n.value, m.value
+
+    def build_query_locality(self, nx_base, locality, loc_thresh):
+        n, m = _i64(), _i64()
+        self._chk(self.lib.annchor_build_query_locality(self.h, int(nx_base), int(locality), int(loc_thresh),
+                                                        ctypes.byref(n), ctypes.byref(m)))
         return n.value, m.value
 
     def compute_features(self):

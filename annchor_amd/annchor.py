@@ -362,6 +362,81 @@ class Annchor:
         t["total"] = time.perf_counter() - origin
         return self
 
+    def query(self, Q, nn=15, p_work=0.3, get_exact_query_ijs=None):
+        """Query new data against the fitted index (annchor.py:643-683 ->
+        query_functions.py:183-212): anchor distances of the queries, shared-nearest-anchor
+        candidates, bounds / dad features, the FITTED regression + error model, one
+        select-and-refine pass with the work budget p_work * len(Q) * nx, then the nn nearest
+        per query.  Returns (indices [nq, nn], distances [nq, nn]) into X.
+
+        Runs on a second engine holding X followed by Q; the fitted state is untouched.
+        `get_exact_query_ijs(f, X, Z, IJ)` (pairs index (X[i], Z[j])) replaces the metric
+        evaluator as in the reference."""
+        if self._streamed is not None:
+            raise NotImplementedError("query() is not available for the streamed form")
+        if self.p_work > 1:
+            print("Warning: p_work should not exceed 1.  Setting it to 1.")
+            self.p_work = 1.0
+        nq, nx = len(Q), self.nx
+        na = self.n_anchors * nq
+        nbf = nq * nx
+        limit = ((nq * nn * 3) // 2 - 1 + na) / nbf   # annchor.py:668-675
+        if p_work < limit:
+            print("Warning: p_work too low")
+            print("Increasing p_work to %5.3f" % limit)
+            p_work = limit
+        if get_exact_query_ijs is not None:
+            self.get_exact_query_ijs = get_exact_query_ijs
+        device_q = isinstance(self.f, DeviceMetric) and self._device_metric and self.get_exact_query_ijs is None
+        eng = _native.Engine(self._engine.device)
+        A = np.asarray(self.A, dtype=np.int64)
+        assert len(A) == self.n_anchors, "query() needs anchors that are data-set members (annchor.py uses X[A])"
+        if device_q:
+            both = list(self.X) + list(Q) if not isinstance(self.X, np.ndarray) else np.concatenate([self.X, np.asarray(Q)])
+            self.f.bind(eng, both)
+            IJa = np.stack([np.repeat(A, nq), np.tile(nx + np.arange(nq), len(A))], axis=1)
+            QD = eng.metric_pairs(IJa).reshape(len(A), nq).T            # get_query_anchor_dists (:10-15)
+        else:
+            eng.set_opaque(nx + nq)
+            if self.get_exact_query_ijs is None:
+                def default_q(f, X, Z, IJ):
+                    from joblib import Parallel, delayed
+                    from .utils import CPU_COUNT
+                    return np.array(Parallel(n_jobs=CPU_COUNT, backend=self.backend, timeout=30)(
+                        delayed(f)(X[i], Z[j]) for i, j in IJ), dtype=np.float64)
+                self.get_exact_query_ijs = default_q
+            XA = [self.X[a] for a in A]
+            IJa = np.array([[i, j] for j in range(nq) for i in range(len(A))])
+            QD = np.asarray(self.get_exact_query_ijs(self.f, XA, Q, IJa), dtype=np.float64).reshape(nq, len(A))
+        eng.set_anchor_distances(np.vstack([self.D, QD]), A)
+        n_pairs, min_len = eng.build_query_locality(nx, self.locality, self.loc_thresh)   # get_query_locality (:18-37)
+        if min_len <= nn:
+            raise Exception("Error: Not enough candidates in pool for all queries.\nTry again with higher locality.")
+        eng.compute_features()                                                            # get_query_features (:40-67)
+        model = self.regression.coefficients() if type(self.regression) is SimpleStratifiedLinearRegression else None
+        fused = (model is not None and type(self.error_predictor) is SimpleStratifiedErrorRegression
+                 and np.array_equal(model[0], self.error_predictor.partition_bins))
+        if fused:
+            eng.predict_merge(model[0], model[1], model[2], True, True, 0)                # predict + clip (:199-202)
+        else:
+            feats = eng.download(_native.F_FEATURES).reshape(-1, 4)
+            eng.merge_host_prediction(np.asarray(self.regression.predict(feats, self.feature_names), dtype=np.float64), True, True)
+            eng.set_labels(self.error_predictor.predict(feats, self.feature_names[:-1]))
+        labels = list(self.error_predictor.labels)
+        errs = [np.asarray(self.error_predictor.errs[lab], dtype=np.float64) for lab in labels]
+        n_refine = int((p_work * nbf - na)) + 1                                           # query_functions.py:163-168
+        ncand, _ = eng.select_candidates(nn, 3 * nn // 2, errs, max(n_refine, 0), 1)
+        if device_q:
+            eng.refine_candidates()
+        elif ncand:
+            IJc = eng.download(_native.F_IJS).reshape(-1, 2)[eng.download(_native.F_CAND)]
+            IJc[:, 1] -= nx
+            eng.set_refined(np.asarray(self.get_exact_query_ijs(self.f, self.X, Q, IJc), dtype=np.float64))
+        self.query_evals = na + ncand
+        idx, dist = eng.neighbor_graph(nn + 1)                                            # get_nn(nq, nn + 1, ...) (:210)
+        eng.close()
+        return idx[nx:, 1:], dist[nx:, 1:]
+
     def to_sparse_matrix(self):
         """annchor.py:625-641: DOK sparse distance matrix of the k-NN graph."""
         from scipy.sparse import dok_matrix

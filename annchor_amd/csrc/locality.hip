@@ -241,3 +241,104 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
     *min_row_len = mn;
     return ANNCHOR_OK;
 }
+
+// ------------------------------------------------------------------ query locality
+// get_query_locality + the pair list of get_query_features (reference
+// annchor/query_functions.py:18-62): the data set bound to the context is X (rows
+// [0, nx_base)) followed by the query set Q (rows [nx_base, nx)); candidates of query j are
+// the points i < nx_base sharing >= loc_thresh of their `locality` nearest anchors with it
+// (no loc_min widening on the query side).  Pairs are (i, nx_base + j), sorted by (j, i): the
+// entries of a query row are contiguous, so I is the identity over each row's range and
+// rows of X are empty.
+__global__ __launch_bounds__(LOC_THREADS) void k_qloc_count(const uint64_t *__restrict__ sid, int64_t nxb, int loc_thresh,
+                                                           int32_t *__restrict__ cnt)
+{
+    __shared__ uint32_t acc;
+    if (threadIdx.x == 0) acc = 0;
+    __syncthreads();
+    const int64_t q = nxb + blockIdx.x;
+    const uint64_t mq = sid[q];
+    uint32_t s = 0;
+    for (int64_t i = threadIdx.x; i < nxb; i += blockDim.x) s += __popcll(mq & sid[i]) >= loc_thresh;
+    if (s) atomicAdd(&acc, s);
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[q] = (int32_t)acc;
+}
+
+__global__ __launch_bounds__(LOC_THREADS) void k_qloc_emit(const uint64_t *__restrict__ sid, int64_t nxb, int loc_thresh,
+                                                          const int64_t *__restrict__ Iptr, int2 *__restrict__ ij,
+                                                          int32_t *__restrict__ Iidx)
+{
+    __shared__ uint32_t wsum[LOC_THREADS / 64];
+    __shared__ uint32_t run_s;
+    const int64_t q = nxb + blockIdx.x;
+    const uint64_t mq = sid[q];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) run_s = 0;
+    __syncthreads();
+    const int64_t base = Iptr[q];
+    for (int64_t b0 = 0; b0 < nxb; b0 += LOC_THREADS) {
+        const int64_t i = b0 + threadIdx.x;
+        const uint32_t f = (i < nxb && __popcll(mq & sid[i]) >= loc_thresh) ? 1u : 0u;
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t pre = run_s;
+        for (int w = 0; w < wave; ++w) pre += wsum[w];
+        if (f) {
+            const int64_t pos = base + pre + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            ij[pos] = make_int2((int)i, (int)q);
+            Iidx[pos] = (int32_t)pos;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) run_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+}
+
+__global__ void k_zero_i32(int32_t *p, int64_t n)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) p[t] = 0;
+}
+
+extern "C" int annchor_build_query_locality(annchor_ctx *c, int64_t nx_base, int32_t locality, int32_t loc_thresh,
+                                            int64_t *n_pairs, int64_t *min_row_len)
+{
+    if (!c || !n_pairs || !min_row_len) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->na > 0, ANNCHOR_EINVAL, "anchors not set");
+    ANN_REQUIRE(c, nx_base >= 1 && nx_base < c->nx, ANNCHOR_EINVAL, "nx_base=%lld outside (0, nx)", (long long)nx_base);
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    const int64_t nx = c->nx, nq = nx - nx_base;
+    if (locality > c->na) locality = c->na;
+    ANN_TRY(ann_reserve(c, c->sid, sizeof(uint64_t) * (size_t)nx));
+    ANN_TRY(ann_reserve(c, c->cA, sizeof(int32_t) * (size_t)nx));
+    ANN_TRY(ann_reserve(c, c->deg, sizeof(int32_t) * (size_t)nx));
+    ANN_TRY(ann_reserve(c, c->Iptr, sizeof(int64_t) * (size_t)(nx + 1)));
+    ANN_TRY(ann_reserve(c, c->tmp2, sizeof(int32_t) * 4));
+    k_sid<<<ann_blocks(nx, 256), 256, 0, c->stream>>>(c->Dt.as<double>(), nx, c->na, locality, c->sid.as<uint64_t>(),
+                                                     c->cA.as<int32_t>());
+    k_zero_i32<<<ann_blocks(nx, 256), 256, 0, c->stream>>>(c->deg.as<int32_t>(), nx);
+    {
+        ProfScope ps(c, "query_locality", (double)nq * nx_base * 8.0);
+        k_qloc_count<<<(int)nq, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx_base, loc_thresh, c->deg.as<int32_t>());
+    }
+    k_min_i32<<<1, 1024, 0, c->stream>>>(c->deg.as<int32_t>() + nx_base, nq, c->tmp2.as<int32_t>());
+    ANN_TRY(ann_exclusive_scan_i32_to_i64(c, c->deg.as<int32_t>(), c->Iptr.as<int64_t>(), nx));
+    int64_t n = 0;
+    int32_t mn = 0;
+    ANN_TRY(ann_d2h(c, &n, c->Iptr.as<int64_t>() + nx, sizeof n));
+    ANN_TRY(ann_d2h(c, &mn, c->tmp2.p, sizeof mn));
+    ANN_REQUIRE(c, n < (1ll << 30), ANNCHOR_ELIMIT, "%lld query pairs exceed the pair-list limit", (long long)n);
+    ANN_TRY(ann_reserve(c, c->ij, sizeof(int2) * (size_t)(n + 1)));
+    ANN_TRY(ann_reserve(c, c->Iidx, sizeof(int32_t) * (size_t)(n + 1)));
+    if (n > 0)
+        k_qloc_emit<<<(int)nq, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx_base, loc_thresh, c->Iptr.as<int64_t>(),
+                                                           c->ij.as<int2>(), c->Iidx.as<int32_t>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    c->n = n;
+    c->have_features = c->have_RA = false;
+    *n_pairs = n;
+    *min_row_len = mn;
+    return ANNCHOR_OK;
+}

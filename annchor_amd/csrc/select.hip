@@ -29,7 +29,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row_thresh(const int64_t *__res
     const int64_t i = row_of_block(gridDim.x);
     const int64_t b = Iptr[i];
     const int len = (int)(Iptr[i + 1] - b);
-    if (len <= 0) { if (threadIdx.x == 0) thresh[i] = INFINITY; return; }
+    if (len <= 0) { if (threadIdx.x == 0) thresh[i] = -INFINITY; return; }  // empty row (query form): never the max
     uint64_t res;
     if (len <= ROW_LDS_KEYS) {
         for (int s = threadIdx.x; s < len; s += ROW_THREADS) keys[s] = ann_key_asc(RA[Iidx[b + s]]);
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void k_gn_sweep_lds(int64_t nx, int nmin, int L
         const double v0 = nv; const int32_t p0 = np_, o0 = no, t0 = nt; const int cnt = ncnt, ncomp = nncomp;
         fetch(i + 1);
         const int ntodo = nmin - ncomp;
-        if (ntodo <= 0) continue;
+        if (ntodo <= 0 || (cnt == 0 && ncomp == 0)) continue;   // enough computed, or an empty row
         if (cnt <= ntodo && cnt < L) { if (lane == 0) *err = 1; continue; }
         const int need = ntodo + 1 - mcount[i];
         if (need <= 0) continue;
@@ -223,6 +223,7 @@ __global__ __launch_bounds__(64) void k_gn_sequential(int64_t nx, int nmin, int 
         const int ntodo = nmin - gl_ncomp[i];
         if (ntodo <= 0) continue;
         const int cnt = gl_cnt[i];
+        if (cnt == 0 && gl_ncomp[i] == 0) continue;   // empty row
         // the reference's np.partition(a, n_todo) needs n_todo < len(a)
         if (cnt <= ntodo && cnt < L) { if (lane == 0) *err = 1; continue; }
         const int need = ntodo + 1 - ld_i32_agent(&markcount[i]);

@@ -525,7 +525,15 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS) void k_st_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KnnShared<DIM, KMAX> &sh = *reinterpret_cast<KnnShared<DIM, KMAX> *>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int I = a.tile_begin + blockIdx.x;
+    // XCD-banded row-tile assignment (block b runs on XCD b % 8): the workgroups resident on
+    // one XCD own consecutive row tiles of the k-d order, whose column-tile lists overlap, so
+    // the streamed column tiles are shared through that XCD's L2
+    int bt;
+    {
+        const int nb_ = gridDim.x, q = nb_ >> 3, r = nb_ & 7, x = blockIdx.x & 7, y = blockIdx.x >> 3;
+        bt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int I = a.tile_begin + bt;
     const int64_t grow0 = (int64_t)I * ST_T;
     const int K = a.K;
     // ---- per-wave row operand in registers: lane holds row (lane & 31), dims of parity (lane >> 5)
@@ -645,8 +653,8 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS) void k_st_
     // ---- write the lists
     for (int q = threadIdx.x; q < ST_T * K; q += ST_THREADS) {
         const int row = q / K, e = q - row * K;
-        a.out_d2[((size_t)blockIdx.x * ST_T + row) * K + e] = sh.list_d[row][e];
-        a.out_col[((size_t)blockIdx.x * ST_T + row) * K + e] = sh.list_c[row][e];
+        a.out_d2[((size_t)bt * ST_T + row) * K + e] = sh.list_d[row][e];
+        a.out_col[((size_t)bt * ST_T + row) * K + e] = sh.list_c[row][e];
     }
     if (threadIdx.x == 0) atomicAdd(a.evals, (unsigned long long)sh.processed);
 }

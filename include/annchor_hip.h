@@ -113,6 +113,12 @@ int annchor_set_anchor_distances(annchor_ctx *ctx, const double *D, int32_t n_an
 int annchor_build_locality(annchor_ctx *ctx, int32_t locality, int32_t loc_thresh, int32_t loc_min,
                            int64_t *n_pairs, int64_t *min_row_len);
 
+/* Query form (Annchor.query, annchor/query_functions.py:18-62): the bound data set is X
+ * (rows [0, nx_base)) followed by the queries; candidate pairs are (i, nx_base + j) with
+ * |sid[i] & sid[nx_base + j]| >= loc_thresh, sorted by (j, i); rows of X are empty. */
+int annchor_build_query_locality(annchor_ctx *ctx, int64_t nx_base, int32_t locality, int32_t loc_thresh,
+                                 int64_t *n_pairs, int64_t *min_row_len);
+
 /* ------------------------------------------------------------- features a8-a10
  * get_bounds_njit_ijs, get_dad_ijs, get_features_IJ (utils.py:274-301,355-380;
  * annchor.py:258-303): lb, ub, dad, is_anchor, not_computed_mask for every pair. */

@@ -499,3 +499,55 @@ class OracleAnnchor:
                 self._snap("update%d" % it, lb=lb, ub=ub)
         self.neighbor_graph = get_nn(self.RA, self.ncm, self.IJs, self.I_ptr, self.I_idx, k)
         return self
+
+
+# ------------------------------------------------------------------- query (f2)
+def query(fitted, query_pairs, nq, nn=15, p_work=0.3):
+    """query_ + helpers, annchor/query_functions.py:10-212, on a fitted OracleAnnchor.
+
+    query_pairs(IJ int64 [n,2]) -> float64[n] with IJ[:,0] indexing X and IJ[:,1] indexing Q
+    (get_exact_query_ijs, utils.py:180-245).  Tie rules as everywhere in this module."""
+    o = fitted
+    nx, na = o.nx, o.n_anchors
+    A = np.asarray(o.A, dtype=np.int64)
+    # get_query_anchor_dists (:10-15)
+    IJa = np.stack([np.repeat(A, nq), np.tile(np.arange(nq), na)], axis=1)
+    QD = query_pairs(IJa).reshape(na, nq).T
+    # get_query_locality (:18-37): shared nearest anchors, no loc_min widening
+    sid_x = nearest_anchor_sets(o.D, o.locality)
+    sid_q = nearest_anchor_sets(QD, o.locality)
+    Ax = np.zeros((nx, na), dtype=np.int32)
+    np.put_along_axis(Ax, sid_x, 1, axis=1)
+    Aq = np.zeros((nq, na), dtype=np.int32)
+    np.put_along_axis(Aq, sid_q, 1, axis=1)
+    C = Aq @ Ax.T                                  # [nq, nx]
+    J, I = np.nonzero(C >= o.loc_thresh)           # row-major: sorted by (j, i)
+    IJs = np.stack([I, J], axis=1).astype(np.int64)
+    counts = np.bincount(J, minlength=nq)
+    QI_ptr = np.concatenate([[0], np.cumsum(counts)])
+    QI_idx = np.arange(len(IJs), dtype=np.int64)
+    # get_query_features (:40-129)
+    Di, Qj = o.D[IJs[:, 0]], QD[IJs[:, 1]]
+    lb, ub = np.abs(Di - Qj).max(axis=1), (Di + Qj).min(axis=1)
+    cA, cQA = np.argmin(o.D, axis=1), np.argmin(QD, axis=1)
+    dd = (o.D[IJs[:, 0], cQA[IJs[:, 1]]] + QD[IJs[:, 1], cA[IJs[:, 0]]]) / 2
+    anchors = np.isin(IJs[:, 0], A).astype(np.float64)
+    feats = np.vstack([lb, ub, dd, anchors]).T
+    ncm = feats[:, 3] < 1
+    # predict + clip (:198-203)
+    pred = regression_predict(feats, o.bins, o.W, o.c)
+    QRA = np.minimum(np.maximum(pred, feats[:, 0]), feats[:, 1])
+    labels = error_labels(feats[:, 2], o.bins)
+    # select_refine_candidate_query_pairs (:132-180)
+    thresh = row_kth(QRA, QI_ptr, QI_idx, nn)
+    QRA = guarantee_nmin(QRA, ncm, QI_ptr, QI_idx, 3 * nn // 2)
+    p = (thresh[IJs[:, 1]] - QRA)[ncm]
+    prob = ecdf_prob(p, labels[ncm], o.errs)
+    n_refine = int((p_work * nq * nx - na * nq)) + 1
+    cand, _ = select_candidates(prob, max(n_refine, 0), 1)
+    mapback = np.arange(ncm.shape[0])[ncm][cand]
+    QRA[mapback] = query_pairs(IJs[mapback])
+    ncm[mapback] = False
+    # get_nn(nq, nn + 1, ...) (:210): raw output, no self column
+    idx, dist = get_nn(QRA, ncm, np.stack([IJs[:, 0], IJs[:, 0]], axis=1), QI_ptr, QI_idx, nn + 1)   # neighbour = the X endpoint
+    return idx[:, 1:], dist[:, 1:], dict(QD=QD, IJs=IJs, n_refine=n_refine, evals=na * nq + len(mapback))

@@ -363,3 +363,43 @@ def test_brute_force_strings_equals_oracle(strings):
     assert np.array_equal(bf.neighbor_graph[0], oi)   # stable (distance, index) order
     part = BruteForce(np.array(Xs), "levenshtein").fit(n_neighbors=7)
     assert np.array_equal(part.neighbor_graph[0], oi[:, :7])
+
+
+# ------------------------------------------------------------------ query (f2)
+def test_query_matches_oracle_strings(strings):
+    """Annchor.query (annchor.py:643-683, query_functions.py:183-212) against the oracle."""
+    from annchor_amd import Annchor
+
+    Xs, Q = list(strings[::5]), list(strings[2::40])
+    cfg = dict(n_anchors=8, n_neighbors=10, n_samples=700, p_work=0.3, random_seed=42, niters=2)
+    ann = Annchor(np.array(Xs), "levenshtein", **cfg).fit()
+    gi, gd = ann.query(np.array(Q), nn=5, p_work=0.3)
+    P = om.PackedStrings(Xs)
+    PQ = om.PackedStrings(Xs + Q)
+    ora = O.OracleAnnchor(len(Xs), P.pairs, **cfg).fit()
+    oi, od, info = O.query(ora, lambda IJ: PQ.pairs(np.stack([IJ[:, 0], IJ[:, 1] + len(Xs)], 1)), len(Q), nn=5, p_work=0.3)
+    assert ann.query_evals == info["evals"]
+    assert np.array_equal(gd, od)
+    assert np.array_equal(gi, oi)
+
+
+def test_query_digits_recall():
+    """reference tests/test_examples.py:12-58 pattern: fit on a train split, query the rest;
+    recall >= 0.99 against brute force at p_work = 0.2."""
+    from annchor_amd import Annchor, compare_neighbor_graphs
+
+    d = om.load_digits()
+    X, M = d["X"], d["cost_matrix"]
+    rs = np.random.RandomState(0)
+    perm = rs.permutation(len(X))
+    tr, te = perm[:1347], perm[1347:]
+    ann = Annchor(X[tr], "wasserstein", func_kwargs={"cost_matrix": M}, n_anchors=25, n_neighbors=25, p_work=0.16).fit()
+    gi, gd = ann.query(X[te], nn=15, p_work=0.2)
+    H = om.Histograms(X, M)
+    IJ = np.stack([np.repeat(te, len(tr)), np.tile(tr, len(te))], axis=1)
+    full = H.pairs(IJ).reshape(len(te), len(tr))
+    bd = np.sort(full, axis=1)[:, :15]
+    err = compare_neighbor_graphs((np.zeros_like(bd, dtype=np.int64), bd), (gi, gd), 15)
+    assert 1 - err / bd.size >= 0.99, err
+    # reported neighbours are train-set members at their exact distances
+    np.testing.assert_allclose(full[np.arange(len(te))[:, None], gi], gd, rtol=0, atol=1e-9)
