@@ -72,6 +72,7 @@ struct annchor_ctx {
     DevBuf lb, ub, dad, RA, prob;  // double [n]
     DevBuf anc, ncm, label;        // uint8 [n]
     bool have_features = false, have_RA = false;
+    int64_t n_unc = -1;            // cached count of not-computed pairs (-1 = unknown: recount)
 
     // ---- samples
     DevBuf spos, sy;  // int32 [m], double [m]

@@ -71,14 +71,24 @@ extern "C" int annchor_compute_features(annchor_ctx *c)
     c->have_features = true;
     c->have_RA = false;
     c->nsamp = 0;
+    c->n_unc = -1;
     return ANNCHOR_OK;
 }
 
 // ------------------------------------------------------------ sampler support
 __global__ __launch_bounds__(256) void k_count_flags(const uint8_t *__restrict__ f, int64_t n, unsigned long long *out)
 {
+    // 16 flags per load (the arrays are 256-byte aligned)
     unsigned long long s = 0;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) s += f[t] != 0;
+    const int64_t n16 = n >> 4;
+    const uint4 *f16 = reinterpret_cast<const uint4 *>(f);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n16; t += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 v = f16[t];
+        // flags are 0/1 bytes: the byte sum of a word is its popcount
+        s += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t t = (n16 << 4) + threadIdx.x; t < n; t += blockDim.x) s += f[t] != 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
@@ -88,6 +98,7 @@ extern "C" int annchor_count_uncomputed(annchor_ctx *c, int64_t *n_unc)
 {
     if (!c || !n_unc) return ANNCHOR_EINVAL;
     ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    if (c->n_unc >= 0) { *n_unc = c->n_unc; return ANNCHOR_OK; }  // maintained incrementally by the stages below
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     ANN_TRY(ann_reserve(c, c->tmp2, 64));
     ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp2.p, 0, 8, c->stream));
@@ -96,6 +107,7 @@ extern "C" int annchor_count_uncomputed(annchor_ctx *c, int64_t *n_unc)
     unsigned long long v = 0;
     ANN_TRY(ann_d2h(c, &v, c->tmp2.p, 8));
     *n_unc = (int64_t)v;
+    c->n_unc = (int64_t)v;
     return ANNCHOR_OK;
 }
 
@@ -349,6 +361,7 @@ extern "C" int annchor_evaluate_samples(annchor_ctx *c, const int64_t *pos, int6
     ANN_TRY(upload_positions(c, pos, m, c->spos));
     ANN_TRY(ann_reserve(c, c->sy, sizeof(double) * (size_t)m));
     c->nsamp = m;
+    c->n_unc = -1;   // recount lazily: a custom sampler may hand back already-computed or repeated pairs
     if (m == 0) return ANNCHOR_OK;
     PairSource src;
     src.ij = c->ij.as<int2>();
@@ -372,6 +385,7 @@ extern "C" int annchor_set_samples(annchor_ctx *c, const int64_t *pos, int64_t m
     ANN_TRY(ann_reserve(c, c->sy, sizeof(double) * (size_t)m));
     ANN_TRY(ann_h2d(c, c->sy.p, sample_y, sizeof(double) * (size_t)m));
     c->nsamp = m;
+    c->n_unc = -1;
     if (m > 0) k_clear_flags<<<ann_blocks(m, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), m, c->ncm.as<uint8_t>());
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;

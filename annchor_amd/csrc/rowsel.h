@@ -25,6 +25,7 @@ struct RowSelShared {
     uint64_t prefix;
     uint32_t k;
     uint32_t digit;
+    unsigned long long diff;  // OR over the row of (key ^ key[0]): bytes that are zero here are shared by all keys
 };
 
 // Exclusive prefix (in thread order) of `v` over the block; *total = block sum.
@@ -55,10 +56,27 @@ __device__ __forceinline__ uint32_t row_block_scan(uint32_t v, uint32_t *wsum, u
 template <typename KeyFn> __device__ uint64_t row_kth_key(RowSelShared &sh, int len, uint32_t k, KeyFn key)
 {
     if (k >= (uint32_t)len) k = (uint32_t)len - 1;
-    if (threadIdx.x == 0) { sh.prefix = 0; sh.k = k; }
+    const uint64_t key0 = key(0);
+    if (threadIdx.x == 0) { sh.prefix = 0; sh.k = k; sh.diff = 0; }
     __syncthreads();
+    {
+        // which key bytes vary at all inside this row?  (integer-valued or narrowly ranged
+        // distances share most of their 8 bytes: those radix passes are skipped)
+        uint64_t d = 0;
+        for (int s = threadIdx.x; s < len; s += ROW_THREADS) d |= key(s) ^ key0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) d |= __shfl_xor(d, off);
+        if ((threadIdx.x & 63) == 0 && d) atomicOr(&sh.diff, (unsigned long long)d);
+        __syncthreads();
+    }
+    const uint64_t diff = sh.diff;
     for (int pass = 0; pass < 8; ++pass) {
         const int shift = 56 - 8 * pass;
+        if (((diff >> shift) & 0xffull) == 0) {   // uniform byte: nothing to select on
+            if (threadIdx.x == 0) sh.prefix |= key0 & (0xffull << shift);
+            __syncthreads();
+            continue;
+        }
         const uint64_t himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
         sh.hist[threadIdx.x] = 0;  // ROW_THREADS == 256
         __syncthreads();

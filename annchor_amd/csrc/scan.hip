@@ -104,7 +104,28 @@ struct SelState {
     int64_t k[SEL_MAXQ];        // remaining rank inside the current bucket
     int nq;
     int pass;
+    unsigned long long vor, vand;  // OR / AND of all (flagged) keys: equal bytes are uniform and skipped
 };
+
+__global__ __launch_bounds__(256) void k_sel_orand(const double *__restrict__ vals, const uint8_t *__restrict__ flag, int64_t n,
+                                                  SelState *__restrict__ st)
+{
+    unsigned long long o = 0, a = ~0ull;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        if (flag && !flag[t]) continue;
+        const unsigned long long key = ann_key_asc(vals[t]);
+        o |= key; a &= key;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { o |= __shfl_xor(o, off); a &= __shfl_xor(a, off); }
+    __shared__ unsigned long long so[4], sa[4];
+    if ((threadIdx.x & 63) == 0) { so[threadIdx.x >> 6] = o; sa[threadIdx.x >> 6] = a; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicOr(&st->vor, so[0] | so[1] | so[2] | so[3]);
+        atomicAnd(&st->vand, sa[0] & sa[1] & sa[2] & sa[3]);
+    }
+}
 
 __global__ __launch_bounds__(256) void k_sel_hist(const double *__restrict__ vals, const uint8_t *__restrict__ flag,
                                                  int64_t n, const SelState *__restrict__ st, uint32_t *__restrict__ hist)
@@ -114,6 +135,7 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double *__restrict__ val
     __syncthreads();
     const int nq = st->nq, pass = st->pass;
     const int shift = 56 - 8 * pass;
+    if ((((st->vor ^ st->vand) >> shift) & 0xffull) == 0) return;  // uniform byte: k_sel_step fills it in
     uint64_t pre[SEL_MAXQ];
     for (int q = 0; q < SEL_MAXQ; ++q) pre[q] = st->prefix[q];
     const uint64_t himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
@@ -138,6 +160,12 @@ __global__ __launch_bounds__(256) void k_sel_step(SelState *st, uint32_t *hist)
     const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
     const int shift = 56 - 8 * st->pass;
     const int nq = st->nq;
+    if ((((st->vor ^ st->vand) >> shift) & 0xffull) == 0) {
+        __syncthreads();
+        if (d < nq) st->prefix[d] |= st->vor & (0xffull << shift);
+        if (d == 0) st->pass += 1;
+        return;
+    }
     for (int q = 0; q < nq; ++q) {
         const uint32_t h = hist[q * 256 + d];
         uint32_t inc = h;
@@ -174,6 +202,7 @@ int ann_kth_smallest(annchor_ctx *c, const double *vals, const uint8_t *flag, in
     memset(&h, 0, sizeof h);
     h.nq = nk;
     for (int q = 0; q < nk; ++q) h.k[q] = ks[q];
+    h.vor = 0; h.vand = ~0ull;
     ANN_TRY(ann_h2d(c, c->sel_state.p, &h, sizeof h));
     ANN_CHECK_HIP(c, hipMemsetAsync(c->sel_hist.p, 0, sizeof(uint32_t) * SEL_MAXQ * 256, c->stream));
     int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
@@ -181,6 +210,7 @@ int ann_kth_smallest(annchor_ctx *c, const double *vals, const uint8_t *flag, in
     if (blocks < 1) blocks = 1;
     {
         ProfScope ps(c, "radix_select_f64", (double)n * 9 * 8);
+        k_sel_orand<<<blocks, 256, 0, c->stream>>>(vals, flag, n, c->sel_state.as<SelState>());
         for (int pass = 0; pass < 8; ++pass) {
             k_sel_hist<<<blocks, 256, 0, c->stream>>>(vals, flag, n, c->sel_state.as<SelState>(), c->sel_hist.as<uint32_t>());
             k_sel_step<<<1, 256, 0, c->stream>>>(c->sel_state.as<SelState>(), c->sel_hist.as<uint32_t>());

@@ -208,6 +208,105 @@ __global__ __launch_bounds__(64) void k_gn_sweep_lds(int64_t nx, int nmin, int L
     }
 }
 
+
+// Same sweep, with the read-only per-row lists streamed through a double-buffered LDS ring
+// by all four waves of the workgroup while wave 0 alone performs the (sequential) sweep:
+// the global-memory latency of the lists no longer sits between consecutive rows.
+#define GN_B 32          // rows per batch
+#define GN_LMAX 64       // list length handled by this form
+__global__ __launch_bounds__(256) void k_gn_sweep_ring(int64_t nx, int nmin, int L, const double *__restrict__ gl_val,
+                                                      const int32_t *__restrict__ gl_pos, const int32_t *__restrict__ gl_oth,
+                                                      const int32_t *__restrict__ gl_twin, const int32_t *__restrict__ gl_cnt,
+                                                      const int32_t *__restrict__ gl_ncomp, double *__restrict__ RA,
+                                                      int32_t *__restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Lw = (L + 31) / 32;
+    const int BL = GN_B * L;                                   // entries per batch
+    double *rval = reinterpret_cast<double *>(dyn);            // [2][BL]
+    int32_t *rpos = reinterpret_cast<int32_t *>(rval + 2 * BL);  // [2][BL]
+    int32_t *roth = rpos + 2 * BL, *rtwin = roth + 2 * BL;     // [2][BL] each
+    int32_t *rcnt = rtwin + 2 * BL, *rncomp = rcnt + 2 * GN_B; // [2][GN_B] each
+    uint32_t *mflag = reinterpret_cast<uint32_t *>(rncomp + 2 * GN_B);  // [nx][Lw]
+    int32_t *mcount = reinterpret_cast<int32_t *>(mflag + (size_t)nx * Lw);  // [nx]
+    for (int64_t t = threadIdx.x; t < nx * Lw; t += 256) mflag[t] = 0;
+    for (int64_t t = threadIdx.x; t < nx; t += 256) mcount[t] = 0;
+    constexpr int PER = (GN_B * GN_LMAX + 255) / 256;          // 8 entries per thread at most
+    double tv[PER]; int32_t tp[PER], to[PER], tt[PER];
+    int32_t tc = 0, tn = 0;
+    const int nbatch = (int)((nx + GN_B - 1) / GN_B);
+    auto load = [&](int b) {
+        const int64_t base = (int64_t)b * BL, lim = nx * L;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = q * 256 + threadIdx.x;
+            const bool ok = e < BL && base + e < lim;
+            tv[q] = ok ? gl_val[base + e] : 0.0;
+            tp[q] = ok ? gl_pos[base + e] : 0;
+            to[q] = ok ? gl_oth[base + e] : 0;
+            tt[q] = ok ? gl_twin[base + e] : -1;
+        }
+        if (threadIdx.x < GN_B) {
+            const int64_t r = (int64_t)b * GN_B + threadIdx.x;
+            tc = r < nx ? gl_cnt[r] : 0;
+            tn = r < nx ? gl_ncomp[r] : nmin;
+        }
+    };
+    auto stash = [&](int slot) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = q * 256 + threadIdx.x;
+            if (e < BL) { rval[slot * BL + e] = tv[q]; rpos[slot * BL + e] = tp[q]; roth[slot * BL + e] = to[q]; rtwin[slot * BL + e] = tt[q]; }
+        }
+        if (threadIdx.x < GN_B) { rcnt[slot * GN_B + threadIdx.x] = tc; rncomp[slot * GN_B + threadIdx.x] = tn; }
+    };
+    load(0);
+    stash(0);
+    __syncthreads();
+    for (int b = 0; b < nbatch; ++b) {
+        const int slot = b & 1;
+        if (b + 1 < nbatch) load(b + 1);
+        if (wave == 0) {
+            for (int rr = 0; rr < GN_B; ++rr) {
+                const int64_t i = (int64_t)b * GN_B + rr;
+                if (i >= nx) break;
+                // every LDS operand of the row is requested up front (one round trip), the
+                // decisions are then pure register work; LDS is in-order per wave, so these
+                // reads observe the marks the previous row just issued
+                const int e = lane;   // L <= 64: one entry per lane
+                const int cnt = rcnt[slot * GN_B + rr], ncomp = rncomp[slot * GN_B + rr];
+                const int mc = mcount[i];
+                const uint32_t fl = e < L ? mflag[i * Lw + (e >> 5)] : 0u;
+                const double v = e < L ? rval[slot * BL + rr * L + e] : 0.0;
+                const int32_t p = e < L ? rpos[slot * BL + rr * L + e] : 0;
+                const int32_t o = e < L ? roth[slot * BL + rr * L + e] : 0;
+                const int32_t tw = e < L ? rtwin[slot * BL + rr * L + e] : -1;
+                const int ntodo = nmin - ncomp;
+                const int need = ntodo + 1 - mc;
+                const bool empty = cnt == 0 && ncomp == 0;
+                const bool um = e < cnt && !((fl >> (e & 31)) & 1u);
+                const unsigned long long m = __ballot(um);
+                if (ntodo <= 0 || empty || need <= 0) continue;
+                if ((cnt <= ntodo && cnt < L) || __popcll(m) < need) { if (lane == 0) *err = 1; continue; }
+                const int myrank = __popcll(m & ((1ull << lane) - 1ull));
+                const unsigned long long hit = __ballot(um && myrank == need - 1);
+                const int src = __ffsll((unsigned long long)hit) - 1;
+                const double t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                                                  __builtin_amdgcn_readlane(__double2loint(v), src));
+                if (um && v < t) {
+                    RA[p] = -1.0;
+                    if (tw >= 0) atomicOr(&mflag[(int64_t)o * Lw + (tw >> 5)], 1u << (tw & 31));
+                    atomicAdd(&mcount[o], 1);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (b + 1 < nbatch) stash(slot ^ 1);
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ uint8_t ld_u8_agent(const uint8_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int32_t ld_i32_agent(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -487,7 +586,18 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
                 c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>());
         }
         const size_t sweep_lds = (size_t)nx * (((size_t)L + 31) / 32 * 4 + 4);
-        if (sweep_lds <= 150 * 1024) {
+        const size_t ring_lds = sweep_lds + 2 * (size_t)GN_B * L * 20 + 4 * GN_B * 4 + 64;
+        if (L <= GN_LMAX && ring_lds <= 156 * 1024) {
+            ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 21.0);
+            int32_t *oth = c->gl_pos.as<int32_t>() + (size_t)nx * L, *twin = oth + (size_t)nx * L;
+            k_gn_twin<<<ann_blocks(nx * L, 256), 256, 0, c->stream>>>(nx, L, c->gl_pos.as<int32_t>(), oth,
+                                                                     c->gl_cnt.as<int32_t>(), twin);
+            ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_gn_sweep_ring, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)ring_lds));
+            k_gn_sweep_ring<<<1, 256, ring_lds, c->stream>>>(nx, nmin, L, c->gl_val.as<double>(), c->gl_pos.as<int32_t>(), oth, twin,
+                                                            c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
+                                                            c->RA.as<double>(), c->tmp2.as<int32_t>());
+        } else if (sweep_lds <= 150 * 1024) {
             ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 21.0);
             int32_t *oth = c->gl_pos.as<int32_t>() + (size_t)nx * L, *twin = oth + (size_t)nx * L;
             k_gn_twin<<<ann_blocks(nx * L, 256), 256, 0, c->stream>>>(nx, L, c->gl_pos.as<int32_t>(), oth,
@@ -573,6 +683,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     ANN_CHECK_HIP(c, hipGetLastError());
     ANN_TRY(ann_d2h(c, &cs, c->sel_state.p, sizeof cs));
     c->ncand = cs.ncand;
+    c->n_unc = n_unc;  // candidates are distinct not-computed pairs: refinement lowers the count by ncand
     c->nnext = cs.nnext;
     *n_cand = cs.ncand;
     *n_next = cs.nnext;
@@ -596,6 +707,7 @@ extern "C" int annchor_refine_candidates(annchor_ctx *c)
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;
     ANN_CHECK_HIP(c, hipGetLastError());
+    if (c->n_unc >= 0) c->n_unc -= c->ncand;
     return ANNCHOR_OK;
 }
 
@@ -619,5 +731,6 @@ extern "C" int annchor_set_refined(annchor_ctx *c, const double *exact, int64_t 
     k_write_refined<<<ann_blocks(n_cand, 256), 256, 0, c->stream>>>(c->cand.as<int32_t>(), c->stage_in.as<double>(), n_cand,
                                                                    c->RA.as<double>(), c->ncm.as<uint8_t>());
     ANN_CHECK_HIP(c, hipGetLastError());
+    if (c->n_unc >= 0) c->n_unc -= n_cand;
     return ANNCHOR_OK;
 }

@@ -130,6 +130,7 @@ extern "C" int annchor_upload(annchor_ctx *c, int32_t field, const void *src, in
         return ANNCHOR_OK;
     case ANNCHOR_F_NCM:
         ANN_REQUIRE(c, n_elems == n, ANNCHOR_EINVAL, "ncm: expected %lld elements", (long long)n);
+        c->n_unc = -1;
         return ann_h2d(c, c->ncm.p, src, (size_t)n);
     case ANNCHOR_F_RA:
         ANN_REQUIRE(c, n_elems == n, ANNCHOR_EINVAL, "RA: expected %lld elements", (long long)n);
