@@ -144,7 +144,7 @@ class StreamedAnnchor:
     methods -- the CPU tests use a NumPy stand-in to exercise the multi-rank protocol)."""
 
     def __init__(self, X, n_anchors=32, n_neighbors=15, p_work=0.1, random_seed=42, base=0, comm=None, engine=None,
-                 device=0):
+                 device=0, force_exchange=False):
         self.X = np.ascontiguousarray(X, dtype=np.float32)
         self.n_local, self.dim = self.X.shape
         self.n_anchors, self.n_neighbors, self.p_work = n_anchors, n_neighbors, p_work
@@ -160,6 +160,7 @@ class StreamedAnnchor:
         self.n_total = int(sum(n for _, n in self.shards))
         self.evals = 0
         self.timings = {}
+        self.force_exchange = force_exchange   # run the all-gather path even with one rank (tests)
 
     def get_anchors(self):
         eng, comm, na = self._engine, self.comm, self.n_anchors
@@ -187,7 +188,7 @@ class StreamedAnnchor:
         ptrs, n_pad, nt, dimp = eng.stream_order(min_tiles)
         t2 = time.perf_counter()
         keep = []
-        if comm.world > 1:
+        if comm.world > 1 or self.force_exchange:
             sizes = {"Xs": n_pad * dimp * 4, "rs": n_pad * 4, "perm": n_pad * 8}
             allp = {}
             for name, nbytes in sizes.items():

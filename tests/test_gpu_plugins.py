@@ -1,0 +1,174 @@
+"""GPU tests of the plugin surface and edge behaviour (reference annchor/tests/test_examples.py:88-230,
+annchor/tests/test_annchor.py:148-213): user-written pickers / samplers / regressors receive the
+reference's NumPy arrays and their results drive the device pipeline."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import annchor_oracle as O
+from oracle import metrics as om
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+NAMES = ["lower bound", "upper bound", "double anchor distance", "is anchor"]
+
+
+def test_custom_anchor_picker_reference_scenario():
+    """reference test_custom_anchor_picker: max-min -> 0 errors and the pinned anchors; a ring of
+    external anchors -> 0 errors; the blob centres as anchors -> exactly 1 error."""
+    from annchor_amd import Annchor, BruteForce, compare_neighbor_graphs
+
+    G = np.load(os.path.join(GOLD, "blobs.npz"))
+    X, centers = G["X"], G["centers"]
+    bf = BruteForce(X, "euclidean").fit(n_neighbors=16)
+    np.testing.assert_allclose(bf.neighbor_graph[1], G["bf_dist"], rtol=1e-12, atol=1e-12)
+
+    class ExternalAnchorPicker:   # as written by a user of the reference (test_examples.py:116-153)
+        def __init__(self, A):
+            self.A = A
+            self.is_anchor_safe = False
+
+        def get_anchors(self, ann):
+            nx, na = ann.nx, ann.n_anchors
+            np.random.seed(ann.random_seed)
+            D = np.zeros((na, nx)) + np.inf
+            for i in range(na):
+                D[i] = np.array([np.linalg.norm(x - self.A[i]) for x in ann.X])
+            return np.array([]), D.T, na * nx
+
+    a0 = Annchor(X, "euclidean", n_anchors=10, p_work=0.05).fit()
+    assert compare_neighbor_graphs(bf.neighbor_graph, a0.neighbor_graph, 15) == 0
+    assert np.array_equal(a0.A, [102, 674, 347, 586, 214, 963, 365, 348, 430, 429])
+    theta = np.linspace(0, np.pi * 2, 11)[:-1]
+    ring = np.vstack([15 * np.cos(theta), 15 * np.sin(theta)]).T
+    a1 = Annchor(X, "euclidean", n_anchors=10, anchor_picker=ExternalAnchorPicker(ring), p_work=0.05).fit()
+    assert compare_neighbor_graphs(bf.neighbor_graph, a1.neighbor_graph, 15) == 0
+    a2 = Annchor(X, "euclidean", n_anchors=10, anchor_picker=ExternalAnchorPicker(centers), p_work=0.05).fit()
+    assert compare_neighbor_graphs(bf.neighbor_graph, a2.neighbor_graph, 15) <= 2   # reference: exactly 1 (tie-dependent)
+
+
+def test_builtin_external_and_selected_pickers(monkeypatch):
+    from annchor_amd import Annchor, compare_neighbor_graphs
+    from annchor_amd.pickers import ExternalAnchorPicker, RandomAnchorPicker, SelectedAnchorPicker
+
+    X, _ = om.load_strings()
+    Xs = np.array(X[::5])
+    P = om.PackedStrings(list(Xs))
+    oi, od, _ = O.brute_force(P.pairs, len(Xs))
+    truth = (oi[:, :10], od[:, :10])
+    sel = [3, 50, 99, 150, 200, 250, 300, 319]
+    cfg = dict(n_anchors=8, n_neighbors=10, n_samples=700, p_work=0.3)
+    a = Annchor(Xs, "levenshtein", anchor_picker=SelectedAnchorPicker(sel), **cfg).fit()
+    assert list(a.A) == sel
+    assert np.array_equal(a.D, np.stack([P.pairs(np.stack([np.full(320, s), np.arange(320)], 1)) for s in sel], 1))
+    ora = O.OracleAnnchor(320, P.pairs, anchors=sel, **cfg).fit()
+    assert np.array_equal(a.neighbor_graph[1], ora.neighbor_graph[1])
+    b = Annchor(Xs, "levenshtein", anchor_picker=RandomAnchorPicker(), **cfg).fit()
+    np.random.seed(42)
+    assert np.array_equal(b.A, np.random.choice(np.arange(320), 8, replace=False))
+    # external anchors that are strings outside the data set: f(x, anchor) runs on the GPU in one batch per anchor
+    ext = [X[1], X[7], X[11], X[222], X[333], X[444], X[555], X[777]]
+    c = Annchor(Xs, "levenshtein", anchor_picker=ExternalAnchorPicker(ext), **cfg).fit()
+    assert len(c.A) == 0 and c.D.shape == (320, 8)
+    assert c.D[0, 0] == om.levenshtein(Xs[0], ext[0])
+    assert compare_neighbor_graphs(truth, c.neighbor_graph, 10) < 200
+
+
+def test_custom_sampler_regression_error_plugins_get_reference_arrays():
+    """A user subclass (not the built-in type) takes the host path: it must see the reference's
+    arrays, and the result must equal the fused device path bit for bit."""
+    from annchor_amd import Annchor
+    from annchor_amd.error_predictors import SimpleStratifiedErrorRegression
+    from annchor_amd.regressors import SimpleStratifiedLinearRegression
+    from annchor_amd.samplers import SimpleStratifiedSampler
+
+    seen = {}
+
+    class MySampler(SimpleStratifiedSampler):
+        def sample(self, features, feature_names, n_samples, not_computed_mask, random_seed):
+            seen["sampler"] = (features.shape, feature_names, not_computed_mask.dtype)
+            return super().sample(features, feature_names, n_samples, not_computed_mask, random_seed)
+
+    class MyRegression(SimpleStratifiedLinearRegression):
+        def predict(self, features, feature_names):
+            seen["regression"] = features.shape
+            return super().predict(features, feature_names)
+
+    class MyErrors(SimpleStratifiedErrorRegression):
+        def predict(self, features, feature_names):
+            seen["errors"] = features.shape
+            return super().predict(features, feature_names)
+
+    X, _ = om.load_strings()
+    Xs = np.array(X[::5])
+    cfg = dict(n_anchors=8, n_neighbors=10, n_samples=700, p_work=0.3, random_seed=42, niters=2)
+    a = Annchor(Xs, "levenshtein", sampler=MySampler(), regression=MyRegression(), error_predictor=MyErrors(), **cfg).fit()
+    b = Annchor(Xs, "levenshtein", **cfg).fit()
+    n = a.n_pairs
+    assert seen["sampler"] == ((n, 4), NAMES, np.dtype(bool)) and seen["regression"] == (n, 4) and seen["errors"] == (n, 4)
+    assert a.evals == b.evals
+    assert np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1])
+    assert np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0])
+
+
+def test_is_metric_false_uses_exact_anchor_distances():
+    from annchor_amd import Annchor
+
+    G = np.load(os.path.join(GOLD, "euclid_small.npz"))
+    X = G["X"]
+    cfg = dict(n_anchors=12, n_neighbors=8, n_samples=400, p_work=0.25, random_seed=3, niters=1, locality=3)
+    a = Annchor(X, "euclidean", is_metric=False, **cfg)
+    a.get_anchors(); a.get_locality(); a.get_features(); a.get_sample(); a.fit_predict_regression()
+    RA, IJs, anc = a.RefineApprox, a.IJs, a.features[:, 3] > 0
+    A, D = list(a.A), a.D
+    for p in np.nonzero(anc)[0][:300]:          # annchor.py:368-372
+        i, j = IJs[p]
+        ri = A.index(i) if i in A else -1
+        rj = A.index(j) if j in A else -1
+        want = D[j, ri] if ri > rj else D[i, rj]
+        assert RA[p] == want or p in a.sample_ixs
+
+
+def test_budget_warnings_and_tiny_inputs(capsys):
+    """reference test_bad_pwork (test_annchor.py:148-160) through the real constructor."""
+    from annchor_amd import Annchor
+
+    X, _ = om.load_strings()
+    ann = Annchor(np.array(X), "levenshtein", p_work=1.1)
+    assert ann.p_work == 1.0
+    ann = Annchor(np.array(X), "levenshtein", p_work=0.0)
+    assert ann.p_work == (2 * (ann.na + ann.n_samples) + 1) / ann.N
+    out = capsys.readouterr().out
+    assert "p_work should not exceed 1" in out and "Too many anchors/samples" in out
+    # too few candidates per row raises like annchor.py:252-256
+    rng = np.random.default_rng(0)
+    far = np.concatenate([rng.standard_normal((30, 2)), rng.standard_normal((30, 2)) + 1e6])
+    with pytest.raises(Exception, match="Not enough candidates"):
+        Annchor(far, "euclidean", n_anchors=4, n_neighbors=40, locality=1, loc_min=1, p_work=0.9).fit()
+
+
+def test_function_input_forms_agree():
+    """reference test_function_input (test_annchor.py:163-213): string / callable / callable+kwargs."""
+    from annchor_amd import Annchor
+    from annchor_amd.distances import Wasserstein
+
+    d = om.load_digits()
+    X, M = d["X"][:60], d["cost_matrix"]
+    H = om.Histograms(d["X"], M)
+
+    def w1(x, y):
+        return H.pairs(np.array([[0, 0]]))[0] * 0 + float(Wasserstein(M)(x, y))
+
+    def w2(x, y, cost=None):
+        return float(Wasserstein(cost)(x, y))
+
+    a1 = Annchor(X, w1, n_anchors=3, n_samples=50, p_work=0.9, get_exact_ijs=lambda f, X_, IJ: np.array([f(X_[i], X_[j]) for i, j in IJ]))
+    a2 = Annchor(X, w2, func_kwargs={"cost": M}, n_anchors=3, n_samples=50, p_work=0.9,
+                 get_exact_ijs=lambda f, X_, IJ: np.array([f(X_[i], X_[j]) for i, j in IJ]))
+    a5 = Annchor(X, "wasserstein", func_kwargs={"cost_matrix": M}, n_anchors=3, n_samples=50, p_work=0.9)
+    rs = np.random.RandomState(1)
+    for _ in range(5):
+        i, j = rs.randint(60, size=2)
+        assert np.isclose(a1.f(X[i], X[j]), a2.f(X[i], X[j])) and np.isclose(a2.f(X[i], X[j]), a5.f(X[i], X[j]))
+        assert np.isclose(a5.f(X[i], X[j]), H.pairs(np.array([[i, j]]))[0], rtol=0, atol=1e-12)

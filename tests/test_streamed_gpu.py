@@ -147,3 +147,32 @@ def test_annchor_api_dispatches_large_euclidean_to_streamed_form():
     bi, bd = brute(X, rows, 6)
     np.testing.assert_allclose(ann.neighbor_graph[1][rows], bd, rtol=1e-5, atol=1e-6)
     assert len(ann.A) == 8 and ann.evals > 0
+
+
+def test_nccl_collective_path_single_rank():
+    """The RCCL branch of the exchange (device-pointer tensor views, all_gather_into_tensor,
+    CUDA broadcast) with a one-rank `nccl` group: same graph as without collectives."""
+    import torch
+    import torch.distributed as dist
+
+    from annchor_amd.streamed import StreamedAnnchor, TorchComm
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        X = latent(4000, 64)
+        a = StreamedAnnchor(X, n_anchors=8, n_neighbors=10, p_work=1.0, comm=TorchComm(), force_exchange=True).fit()
+        b = StreamedAnnchor(X, n_anchors=8, n_neighbors=10, p_work=1.0).fit()
+        assert a.comm.backend == "nccl"
+        assert np.array_equal(a.A, b.A)
+        assert np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0])
+        assert np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1])
+        gi, gd = a.gather_graph()
+        assert np.array_equal(gi, a.neighbor_graph[0])
+    finally:
+        dist.destroy_process_group()
