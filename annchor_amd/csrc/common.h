@@ -52,6 +52,7 @@ struct annchor_ctx {
     int dim = 0;
     DevBuf hist, cost, supp; // histograms f64 [nx, nbins], cost [nbins, nbins], support sizes int32 [nx]
     int nbins = 0, max_support = 0;
+    bool hist_integral = false;  // all masses integer valued and (row sum)^2 < 2^31: exact int32 flows
 
     // ---- anchors
     int na = 0, nA = 0;

@@ -320,9 +320,18 @@ extern "C" int annchor_set_histograms(annchor_ctx *c, const double *hist, int64_
     ANN_REQUIRE(c, nbins >= 1 && nbins <= 64, ANNCHOR_ELIMIT, "nbins=%d: this build supports 1..64 bins", nbins);
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     int maxs = 0;
+    bool integral = true;
+    double maxsum = 0;
     for (int64_t s = 0; s < nx; ++s) {
         int k = 0;
-        for (int b = 0; b < nbins; ++b) k += hist[s * nbins + b] != 0;
+        double sum = 0;
+        for (int b = 0; b < nbins; ++b) {
+            const double v = hist[s * nbins + b];
+            k += v != 0;
+            sum += v;
+            if (v < 0 || v != (double)(int64_t)v) integral = false;
+        }
+        if (sum > maxsum) maxsum = sum;
         ANN_REQUIRE(c, k > 0, ANNCHOR_EINVAL, "histogram %lld is empty", (long long)s);
         if (k > maxs) maxs = k;
     }
@@ -335,6 +344,7 @@ extern "C" int annchor_set_histograms(annchor_ctx *c, const double *hist, int64_
     c->nx = nx;
     c->nbins = nbins;
     c->max_support = maxs;
+    c->hist_integral = integral && maxsum * maxsum < 2147483647.0;
     reset_pipeline(c);
     return ANNCHOR_OK;
 }

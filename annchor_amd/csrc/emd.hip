@@ -29,6 +29,7 @@ struct EmdArgs {
     int nb;
     int S;          // padded row stride of the flow slab (odd)
     int waves;      // waves per block
+    int slab_bytes; // LDS bytes per wave (flow slab + support index lists)
     const int2 *ij;
     const int32_t *idx;
     const int32_t *anchor;
@@ -71,15 +72,25 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(512) void k_emd(EmdArgs a)
+// Flow / mass type: double in general; int32 when both histograms are integer valued (then
+// supplies x_i * sum(y) and demands y_j * sum(x) are exact integers and the flow slab is half
+// the size, which doubles the waves a CU can hold).
+__device__ __forceinline__ double rl(double v, int lane) { return readlane_f64(v, lane); }
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ double tmin(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ int tmin(int a, int b) { return a < b ? a : b; }
+
+template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
 {
+    constexpr bool INTEGRAL = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nb = a.nb, S = a.S;
     double *costL = reinterpret_cast<double *>(smem);                       // [nb][nb]
-    double *F = costL + nb * nb + (size_t)wave * (EMD_MAXB * S + 2 * EMD_MAXB);  // [<=64][S] flow slab
-    int *rowsL = reinterpret_cast<int *>(F + EMD_MAXB * S);                 // [64] support of x
+    unsigned char *slab = reinterpret_cast<unsigned char *>(costL + nb * nb) + (size_t)wave * a.slab_bytes;
+    T *F = reinterpret_cast<T *>(slab);                                     // [<=64][S] flow slab
+    int *rowsL = reinterpret_cast<int *>(slab + a.slab_bytes - 2 * EMD_MAXB * sizeof(int));  // [64] support of x
     int *colsL = rowsL + EMD_MAXB;                                          // [64] support of y
     for (int t = threadIdx.x; t < nb * nb; t += blockDim.x) costL[t] = a.cost[t];
     __syncthreads();
@@ -114,8 +125,14 @@ __global__ __launch_bounds__(512) void k_emd(EmdArgs a)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int myrow = lane < n ? rowsL[lane] : 0;   // source `lane` is histogram bin myrow
         const int mycol = lane < m ? colsL[lane] : 0;   // sink `lane` is histogram bin mycol
-        double a_rem = lane < n ? hx[myrow] / sa : 0.0;  // supply of source `lane`
-        double b_rem = lane < m ? hy[mycol] / sb : 0.0;  // demand of sink `lane`
+        T a_rem, b_rem;   // supply of source `lane`, demand of sink `lane`
+        if (INTEGRAL) {   // units of 1 / (sa * sb): exact integers
+            a_rem = lane < n ? (T)(hx[myrow] * sb) : (T)0;
+            b_rem = lane < m ? (T)(hy[mycol] * sa) : (T)0;
+        } else {
+            a_rem = lane < n ? (T)(hx[myrow] / sa) : (T)0;
+            b_rem = lane < m ? (T)(hy[mycol] / sb) : (T)0;
+        }
         double u = 0.0;                                  // potential of source `lane`
         // v_j = min_i C[i][j] (first minimal source on ties): dual feasible with u = 0, and
         // arc (amin_j, j) is tight for every sink
@@ -130,15 +147,15 @@ __global__ __launch_bounds__(512) void k_emd(EmdArgs a)
         }
         // zero the flow slab
         for (int i = 0; i < n; ++i)
-            if (lane < m) F[i * S + lane] = 0.0;
+            if (lane < m) F[i * S + lane] = (T)0;
         __builtin_amdgcn_wave_barrier();
         // greedy start on the tight arcs (complementary slackness holds: flow only where the
         // reduced cost is zero).  For near-by histograms most mass sits on identical bins
         // (cost 0) and is routed here, before any shortest-path search.
         for (int j = 0; j < m; ++j) {
             const int i = __builtin_amdgcn_readlane(amin, j);
-            const double f = fmin(readlane_f64(a_rem, i), readlane_f64(b_rem, j));
-            if (f > 0.0) {
+            const T f = tmin(rl(a_rem, i), rl(b_rem, j));
+            if (f > (T)0) {
                 if (lane == 0) F[i * S + j] = f;
                 if (lane == i) a_rem -= f;
                 if (lane == j) b_rem -= f;
@@ -153,8 +170,8 @@ __global__ __launch_bounds__(512) void k_emd(EmdArgs a)
         for (int s = 0; s < n && !dust && !failed; ++s) {
             const int rs = __builtin_amdgcn_readlane(myrow, s);
             for (;;) {
-                const double as = readlane_f64(a_rem, s);
-                if (!(as > 0.0)) break;
+                const T as = rl(a_rem, s);
+                if (!(as > (T)0)) break;
                 if (--guard < 0) { failed = true; break; }
                 // ---- Dijkstra from source s on reduced costs
                 const double us = readlane_f64(u, s);
@@ -173,10 +190,10 @@ __global__ __launch_bounds__(512) void k_emd(EmdArgs a)
                     const int js = __ffsll((unsigned long long)hit) - 1;  // first index on ties
                     sinkdone |= 1ull << js;
                     mu = best;
-                    if (readlane_f64(b_rem, js) > 0.0) { jend = js; break; }
+                    if (rl(b_rem, js) > (T)0) { jend = js; break; }
                     // sources with flow into js that are not scanned yet
-                    const double fcol = lane < n ? F[lane * S + js] : 0.0;
-                    unsigned long long todo = __ballot(lane < n && fcol > 0.0 && !((srcdone >> lane) & 1ull));
+                    const T fcol = lane < n ? F[lane * S + js] : (T)0;
+                    unsigned long long todo = __ballot(lane < n && fcol > (T)0 && !((srcdone >> lane) & 1ull));
                     while (todo) {
                         const int i = __ffsll((unsigned long long)todo) - 1;
                         todo &= todo - 1;
@@ -195,12 +212,12 @@ __global__ __launch_bounds__(512) void k_emd(EmdArgs a)
                 if ((srcdone >> lane) & 1ull) u += mu - srcdist;
                 if ((sinkdone >> lane) & 1ull) v -= mu - dist;
                 // ---- bottleneck along the path, then augment
-                double delta = fmin(as, readlane_f64(b_rem, jend));
+                T delta = tmin(as, rl(b_rem, jend));
                 for (int j = jend;;) {
                     const int i = __builtin_amdgcn_readlane(pred, j);
                     if (i == s) break;
                     const int jj = __builtin_amdgcn_readlane(srcfrom, i);
-                    delta = fmin(delta, F[i * S + jj]);   // uniform address: LDS broadcast
+                    delta = tmin(delta, F[i * S + jj]);   // uniform address: LDS broadcast
                     j = jj;
                 }
                 for (int j = jend;;) {
@@ -222,10 +239,11 @@ __global__ __launch_bounds__(512) void k_emd(EmdArgs a)
         double tot = 0.0;
         for (int i = 0; i < n; ++i) {
             const int r = __builtin_amdgcn_readlane(myrow, i);
-            if (lane < m) tot += F[i * S + lane] * costL[r * nb + mycol];
+            if (lane < m) tot += (double)F[i * S + lane] * costL[r * nb + mycol];
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        if (INTEGRAL) tot /= sa * sb;
         if (failed) { tot = NAN; if (lane == 0) *a.fail = 1; }
         if (lane == 0) {
             if (a.out) a.out[t] = tot;
@@ -250,17 +268,21 @@ int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
     a.fail = c->supp.as<int32_t>();
     ANN_CHECK_HIP(c, hipMemsetAsync(a.fail, 0, 4, c->stream));
     const size_t cost_bytes = sizeof(double) * (size_t)a.nb * a.nb;
-    const size_t slab = sizeof(double) * ((size_t)EMD_MAXB * S + 2 * EMD_MAXB);
+    const bool integral = c->hist_integral;
+    const size_t slab = (((integral ? 4 : 8) * (size_t)c->max_support * S + 2 * EMD_MAXB * sizeof(int)) + 15) & ~(size_t)15;
+    a.slab_bytes = (int)slab;
     int waves = (int)((160 * 1024 - cost_bytes) / slab);
-    if (waves > 8) waves = 8;
+    if (waves > 16) waves = 16;
     ANN_REQUIRE(c, waves >= 1, ANNCHOR_ELIMIT, "histogram support %d needs more LDS than a CU has", c->max_support);
     a.waves = waves;
     const size_t lds = cost_bytes + slab * waves;
-    ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_emd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const void *fn = integral ? (const void *)k_emd<int> : (const void *)k_emd<double>;
+    ANN_CHECK_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t blocks = (src.n + waves - 1) / waves;
     if (blocks > c->prop.multiProcessorCount) blocks = c->prop.multiProcessorCount;  // one resident block per CU (LDS bound)
     ProfScope ps(c, "wasserstein_pairs", (double)src.n * (2.0 * a.nb * 8 + 8));
-    k_emd<<<(int)blocks, waves * 64, lds, c->stream>>>(a);
+    if (integral) k_emd<int><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
+    else k_emd<double><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
 }

@@ -453,17 +453,35 @@ __device__ __forceinline__ void knn_process_tile(KnnShared<DIM, KMAX> &sh, const
                                                  const float (&ri)[16], int rowbase_wave, int64_t grow0, int K)
 {
     const int lane = threadIdx.x & 63;
+    // register staging of the next 32-column slab: the global loads are issued before the
+    // MFMA block of the current slab and land in LDS after it, so only the first slab of a
+    // tile exposes memory latency
+    constexpr int NLD = ST_SLAB * DIM / 4 / ST_THREADS;   // float4 loads per thread per slab
+    float4 stage[NLD];
+    float stage_r = 0.f;
+    auto slab_load = [&](int slab) {
+        const int64_t c0 = (int64_t)J * ST_T + slab * ST_SLAB;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int q = u * ST_THREADS + threadIdx.x;
+            const int colr = q / (DIM / 4), k4 = (q % (DIM / 4)) * 4;
+            stage[u] = *reinterpret_cast<const float4 *>(a.Xs + (size_t)(c0 + colr) * DIM + k4);
+        }
+        if (threadIdx.x < ST_SLAB) stage_r = a.rs[c0 + threadIdx.x];
+    };
+    slab_load(0);
     for (int slab = 0; slab < ST_T / ST_SLAB; ++slab) {
         const int64_t col0 = (int64_t)J * ST_T + slab * ST_SLAB;
         __syncthreads();  // previous slab fully consumed (operands, candidates merged)
-        // ---- stage the slab: 32 columns x DIM floats, coalesced 16-byte reads
-        for (int q = threadIdx.x; q < ST_SLAB * DIM / 4; q += ST_THREADS) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int q = u * ST_THREADS + threadIdx.x;
             const int colr = q / (DIM / 4), k4 = (q % (DIM / 4)) * 4;
-            const float4 v = *reinterpret_cast<const float4 *>(a.Xs + (size_t)(col0 + colr) * DIM + k4);
-            sh.Bs[colr][k4] = v.x; sh.Bs[colr][k4 + 1] = v.y; sh.Bs[colr][k4 + 2] = v.z; sh.Bs[colr][k4 + 3] = v.w;
+            sh.Bs[colr][k4] = stage[u].x; sh.Bs[colr][k4 + 1] = stage[u].y; sh.Bs[colr][k4 + 2] = stage[u].z; sh.Bs[colr][k4 + 3] = stage[u].w;
         }
-        if (threadIdx.x < ST_SLAB) sh.rsJ[threadIdx.x] = a.rs[col0 + threadIdx.x];
+        if (threadIdx.x < ST_SLAB) sh.rsJ[threadIdx.x] = stage_r;
         __syncthreads();
+        if (slab + 1 < ST_T / ST_SLAB) slab_load(slab + 1);
         // ---- 32x32 block of dot products per wave: DIM/2 MFMAs of K = 2
         f32x16 acc;
 #pragma unroll
