@@ -20,6 +20,8 @@
 //   * The text itself is staged once into LDS with 16-byte coalesced reads.
 // Work per pair = words(pattern) * len(text) word-steps of ~25 integer VALU ops:
 // the kernel is integer-ALU bound (the data set is L2 resident), not HBM bound.
+#include <cstdlib>
+
 #include "common.h"
 
 #define LEV_THREADS 256
@@ -59,28 +61,223 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// LDS layout per wave: [P][alphabet][G] uint32 PM, then [P][text_stride] bytes text.
-__global__ __launch_bounds__(LEV_THREADS) void k_lev(LevArgs a)
+// LDS layout per wave and slot set: [P][alphabet][G] uint32 PM, [P][text_stride] bytes text,
+// [P] int sums.  ILP independent slot sets share one instruction stream (each lane serves
+// word w of slot g in every set): the dependent VALU chain of one set fills the issue bubbles
+// of the other, which is what the latency-bound one-to-all rounds (few waves per SIMD) need.
+template <int ILP> __global__ __launch_bounds__(LEV_THREADS) void k_lev(LevArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int G = a.G, P = a.P, A = a.alphabet;
-    uint32_t *pm = reinterpret_cast<uint32_t *>(smem + (size_t)wave * a.wave_bytes);
-    unsigned char *txt = smem + (size_t)wave * a.wave_bytes + a.pm_bytes;
-    int *ssum = reinterpret_cast<int *>(txt + (size_t)a.P * a.text_stride);  // [P] per-slot popcount sums
-
     const int g = lane / G;          // pair slot of this lane
     const int w = lane - g * G;      // word index inside the slot
     const bool slot_ok = g < P;
-    uint32_t *pm_g = pm + (size_t)(slot_ok ? g : 0) * A * G;
-    unsigned char *txt_g = txt + (size_t)(slot_ok ? g : 0) * a.text_stride;
-
-    const int64_t n_tasks = (a.n + P - 1) / P;
+    uint32_t *pm_g[ILP];
+    unsigned char *txt_g[ILP];
+    int *ssum[ILP];
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) {
+        unsigned char *base = smem + ((size_t)wave * ILP + u) * a.wave_bytes;
+        pm_g[u] = reinterpret_cast<uint32_t *>(base) + (size_t)(slot_ok ? g : 0) * A * G;
+        txt_g[u] = base + a.pm_bytes + (size_t)(slot_ok ? g : 0) * a.text_stride;
+        ssum[u] = reinterpret_cast<int *>(base + a.pm_bytes + (size_t)P * a.text_stride);
+    }
+    const int PP = P * ILP;  // pairs per wave task
+    const int64_t n_tasks = (a.n + PP - 1) / PP;
     const int64_t wave_global = (int64_t)blockIdx.x * LEV_WAVES + wave;
     const int64_t wave_stride = (int64_t)gridDim.x * LEV_WAVES;
+    const int tmax = (a.text_stride >> 1) - 1;
 
     for (int64_t task = wave_global; task < n_tasks; task += wave_stride) {
+        int64_t t_pair[ILP], opos[ILP];
+        bool active[ILP];
+        int m[ILP], n[ILP], Wp[ILP];
+#pragma unroll
+        for (int u = 0; u < ILP; ++u) {
+            t_pair[u] = task * PP + u * P + g;
+            active[u] = slot_ok && t_pair[u] < a.n;
+            int si = 0, sj = 0;
+            opos[u] = t_pair[u];
+            if (active[u]) {
+                if (a.anchor) { si = *a.anchor; sj = (int)t_pair[u]; }
+                else {
+                    int64_t q = a.idx ? a.idx[t_pair[u]] : t_pair[u];
+                    int2 p = a.ij[q];
+                    si = p.x; sj = p.y;
+                    if (a.idx) opos[u] = q;
+                }
+            }
+            const int li = active[u] ? a.slen[si] : 0, lj = active[u] ? a.slen[sj] : 0;
+            // pattern = shorter string, text = longer
+            const bool swap = li > lj;
+            const int ps = swap ? sj : si, ts = swap ? si : sj;
+            m[u] = swap ? lj : li; n[u] = swap ? li : lj;
+            const uint8_t *pat = a.sym + (active[u] ? a.soff[ps] : 0);
+            const uint8_t *tex = a.sym + (active[u] ? a.soff[ts] : 0);
+            Wp[u] = (m[u] + 31) >> 5;
+            if (slot_ok && w == 0) ssum[u][g] = 0;
+            // ---- build PM column of this lane: zero, then OR in the 32 pattern symbols
+            if (slot_ok)
+                for (int c = 0; c < A; ++c) pm_g[u][c * G + w] = 0u;
+            if (active[u] && w < Wp[u]) {
+                const uint4 *p16 = reinterpret_cast<const uint4 *>(pat + w * 32);
+                uint4 q0 = p16[0], q1 = p16[1];  // starts are 16B aligned and padded
+                uint32_t wd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                const int valid = min(32, m[u] - w * 32);
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    uint32_t c = (wd[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+                    if (k < valid) atomicOr(&pm_g[u][c * G + w], 1u << k);
+                }
+            }
+            // ---- stage the text: lanes of the slot copy 16B chunks
+            if (active[u]) {
+                const int chunks = (n[u] + 15) >> 4;
+                for (int ch = w; ch < chunks; ch += G)
+                    reinterpret_cast<uint4 *>(txt_g[u])[ch] = reinterpret_cast<const uint4 *>(tex)[ch];
+            }
+        }
+        wave_lds_fence();
+
+        // ---- systolic sweep, two text columns per iteration.  At iteration k lane w handles
+        // columns 2(k-w) and 2(k-w)+1; the four carry bits of the lane above arrive in one
+        // register through one DPP move.  Validity is a function of (k - w, n) alone, so no
+        // flag travels with the data and the loop body is branch-free.
+        uint32_t vp[ILP], vn[ILP], un[ILP], carry[ILP], c1[ILP], eqA[ILP], eqB[ILP];
+        const uint32_t *pm_w[ILP];
+        const uint16_t *txt2[ILP];
+        int max_steps = 0;
+#pragma unroll
+        for (int u = 0; u < ILP; ++u) {
+            vp[u] = 0xffffffffu; vn[u] = 0u; carry[u] = 0u;
+            const bool run = active[u] && m[u] > 0;
+            un[u] = run ? (uint32_t)n[u] : 0u;
+            max_steps = max(max_steps, run ? ((n[u] + 1) >> 1) + Wp[u] - 1 : 0);
+            pm_w[u] = pm_g[u] + w;
+            txt2[u] = reinterpret_cast<const uint16_t *>(txt_g[u]);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) max_steps = max(max_steps, __shfl_xor(max_steps, off));
+        max_steps = __builtin_amdgcn_readfirstlane(max_steps);
+        // Two-deep software pipeline over LDS: the text pair of iteration k+2 and the match
+        // masks of iteration k+1 are requested while iteration k computes, so neither LDS
+        // latency sits on the loop-carried dependency (which is the DPP carry chain only).
+#pragma unroll
+        for (int u = 0; u < ILP; ++u) {
+            const uint32_t c0 = txt2[u][min(max(0 - w, 0), tmax)];
+            c1[u] = txt2[u][min(max(1 - w, 0), tmax)];
+            eqA[u] = pm_w[u][(c0 & 0xffu) * G];
+            eqB[u] = pm_w[u][(c0 >> 8) * G];
+        }
+        for (int k = 0; k < max_steps; ++k) {
+            uint32_t c2[ILP], eqA_n[ILP], eqB_n[ILP], in[ILP];
+#pragma unroll
+            for (int u = 0; u < ILP; ++u) {
+                c2[u] = txt2[u][min(max(k + 2 - w, 0), tmax)];
+                eqA_n[u] = pm_w[u][(c1[u] & 0xffu) * G];
+                eqB_n[u] = pm_w[u][(c1[u] >> 8) * G];
+                in[u] = dpp_wave_shr1(carry[u]);
+            }
+            // keep the LDS requests above the arithmetic (hipcc otherwise rotates the loop and
+            // waits for each request right where it was issued)
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t col = (uint32_t)(k - w) * 2u;  // huge when k < w
+#pragma unroll
+            for (int u = 0; u < ILP; ++u) {
+                const uint32_t cin = (w == 0) ? 0x5u : in[u];  // top row of the DP: +1 horizontal delta, never -1
+                const bool vA = col < un[u], vB = (col + 1u) < un[u];
+                // ---- column A
+                uint32_t hpc = cin & 1u, hnc = (cin >> 1) & 1u;
+                uint32_t x = eqA[u] | hnc;
+                uint32_t d0 = (((x & vp[u]) + vp[u]) ^ vp[u]) | x | vn[u];
+                uint32_t hp = vn[u] | ~(d0 | vp[u]);
+                uint32_t hn = d0 & vp[u];
+                const uint32_t hpoA = hp >> 31, hnoA = hn >> 31;
+                hp = (hp << 1) | hpc;
+                hn = (hn << 1) | hnc;
+                uint32_t nvp = hn | ~(d0 | hp), nvn = hp & d0;
+                vp[u] = vA ? nvp : vp[u]; vn[u] = vA ? nvn : vn[u];
+                // ---- column B
+                hpc = (cin >> 2) & 1u; hnc = (cin >> 3) & 1u;
+                x = eqB[u] | hnc;
+                d0 = (((x & vp[u]) + vp[u]) ^ vp[u]) | x | vn[u];
+                hp = vn[u] | ~(d0 | vp[u]);
+                hn = d0 & vp[u];
+                const uint32_t hpoB = hp >> 31, hnoB = hn >> 31;
+                hp = (hp << 1) | hpc;
+                hn = (hn << 1) | hnc;
+                nvp = hn | ~(d0 | hp); nvn = hp & d0;
+                vp[u] = vB ? nvp : vp[u]; vn[u] = vB ? nvn : vn[u];
+                carry[u] = hpoA | (hnoA << 1) | (hpoB << 2) | (hnoB << 3);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // consume the prefetched values only down here
+#pragma unroll
+            for (int u = 0; u < ILP; ++u) { eqA[u] = eqA_n[u]; eqB[u] = eqB_n[u]; c1[u] = c2[u]; }
+        }
+        // D[m][n] = D[0][n] + sum of the vertical deltas of the last column
+        //         = n + popcount(VP & rows) - popcount(VN & rows), summed over the slot's words
+#pragma unroll
+        for (int u = 0; u < ILP; ++u)
+            if (active[u] && w < Wp[u]) {
+                const uint32_t rows = (w == Wp[u] - 1) ? (0xffffffffu >> (31 - ((m[u] - 1) & 31))) : 0xffffffffu;
+                const int part = __popc(vp[u] & rows) - __popc(vn[u] & rows);
+                if (part) atomicAdd(&ssum[u][g], part);
+            }
+        wave_lds_fence();
+#pragma unroll
+        for (int u = 0; u < ILP; ++u)
+            if (active[u] && w == 0) {
+                const double d = (double)(n[u] + ssum[u][g]);  // m == 0: no word contributes, d = n
+                if (a.out) a.out[t_pair[u]] = d;
+                if (a.RA) { a.RA[opos[u]] = d; a.ncm[opos[u]] = 0; }
+            }
+        wave_lds_fence();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// R words per lane.  The kernels above spend ~35 instructions per (word, column) step, most
+// of it moving carries between lanes (extract, pack, DPP, unpack) and re-testing validity per
+// word.  Here a lane owns R consecutive pattern words and walks them in registers: the
+// horizontal carries between its own words never leave the VGPRs (one v_alignbit_b32 shifts a
+// word and pulls in the top bit of the word below), only the last word's hp/hn cross to the
+// next lane (two DPP moves per column), the match masks of the R words come from one vector
+// LDS read, and validity is tested once per column.  ~14 instructions per step.
+struct LevArgsR {
+    LevArgs b;
+    int GL;        // lanes per slot = ceil(words / R)
+    int pm_stride; // words per symbol row of a slot's PM table (GL * R)
+};
+
+#define LEVR_PAD 64   // text entries of padding either side of a slot's text (>= lanes per slot)
+
+template <int R> __global__ __launch_bounds__(ANN_WAVE) void k_lev_r(LevArgsR ar)
+{
+    // one wave per workgroup: waves never synchronise with each other, and small workgroups
+    // let the LDS allocator pack as many waves per CU as the tables allow
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LevArgs &a = ar.b;
+    const int lane = threadIdx.x;
+    const int GL = ar.GL, P = a.P, A = a.alphabet, PS = ar.pm_stride;
+    const int g = lane / GL;         // pair slot of this lane
+    const int w = lane - g * GL;     // lane index inside the slot: owns words w*R .. w*R+R-1
+    const bool slot_ok = g < P;
+    uint32_t *pm_g = reinterpret_cast<uint32_t *>(smem) + (size_t)(slot_ok ? g : 0) * A * PS;
+    // text of a slot: uint16 entries = byte offset of the symbol's PM row, LEVR_PAD entries of
+    // padding either side so that the pipelined reads of lanes outside their column range
+    // stay inside the slot (their values are never used)
+    uint16_t *txt_g = reinterpret_cast<uint16_t *>(smem + a.pm_bytes + (size_t)(slot_ok ? g : 0) * a.text_stride);
+    int *ssum = reinterpret_cast<int *>(smem + a.pm_bytes + (size_t)P * a.text_stride);
+    const int64_t n_tasks = (a.n + P - 1) / P;
+    const uint32_t row_bytes = (uint32_t)PS * 4u;
+    typedef uint32_t vecR __attribute__((ext_vector_type(R)));
+
+    if (slot_ok)
+        for (int e = w * 8; e < a.text_stride / 2; e += GL * 8) *reinterpret_cast<uint4 *>(txt_g + e) = make_uint4(0, 0, 0, 0);
+
+    for (int64_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
         const int64_t t_pair = task * P + g;
         const bool active = slot_ok && t_pair < a.n;
         int si = 0, sj = 0;
@@ -94,110 +291,142 @@ __global__ __launch_bounds__(LEV_THREADS) void k_lev(LevArgs a)
                 if (a.idx) opos = q;
             }
         }
-        int li = active ? a.slen[si] : 0, lj = active ? a.slen[sj] : 0;
-        // pattern = shorter string, text = longer
-        const bool swap = li > lj;
+        const int li = active ? a.slen[si] : 0, lj = active ? a.slen[sj] : 0;
+        // pattern = LONGER string (its words spread over the slot's lanes, which are reserved
+        // anyway), text = shorter one: the column loop runs min(li, lj) + lanes steps
+        const bool swap = li < lj;
         const int ps = swap ? sj : si, ts = swap ? si : sj;
         const int m = swap ? lj : li, n = swap ? li : lj;
         const uint8_t *pat = a.sym + (active ? a.soff[ps] : 0);
         const uint8_t *tex = a.sym + (active ? a.soff[ts] : 0);
-        const int Wp = (m + 31) >> 5;
-
+        const int Wp = (m + 31) >> 5;          // pattern words
+        const int Gp = (Wp + R - 1) / R;       // lanes that hold pattern words
         if (slot_ok && w == 0) ssum[g] = 0;
-        // ---- build PM column of this lane: zero, then OR in the 32 pattern symbols
         if (slot_ok)
-            for (int c = 0; c < A; ++c) pm_g[c * G + w] = 0u;
-        if (active && w < Wp) {
-            const uint4 *p16 = reinterpret_cast<const uint4 *>(pat + w * 32);
-            uint4 q0 = p16[0], q1 = p16[1];  // starts are 16B aligned and padded
-            uint32_t wd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-            const int valid = min(32, m - w * 32);
+            for (int c = 0; c < A; ++c) {
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                uint32_t c = (wd[k >> 2] >> ((k & 3) * 8)) & 0xffu;
-                if (k < valid) atomicOr(&pm_g[c * G + w], 1u << k);
+                for (int r = 0; r < R; ++r) pm_g[c * PS + w * R + r] = 0u;
+            }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int wi = w * R + r;
+            if (active && wi < Wp) {
+                const uint4 *p16 = reinterpret_cast<const uint4 *>(pat + wi * 32);
+                const uint4 q0 = p16[0], q1 = p16[1];
+                const uint32_t wd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                const int valid = min(32, m - wi * 32);
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    const uint32_t c = (wd[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+                    if (k < valid) atomicOr(&pm_g[c * PS + wi], 1u << k);
+                }
             }
         }
-        // ---- stage the text: lanes of the slot copy 16B chunks
         if (active) {
             const int chunks = (n + 15) >> 4;
-            for (int ch = w; ch < chunks; ch += G)
-                reinterpret_cast<uint4 *>(txt_g)[ch] = reinterpret_cast<const uint4 *>(tex)[ch];
+            for (int ch = w; ch < chunks; ch += GL) {
+                const uint4 q = reinterpret_cast<const uint4 *>(tex)[ch];
+                const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+                uint32_t o[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t c0 = (wd[k >> 1] >> ((k & 1) * 16)) & 0xffu, c1 = (wd[k >> 1] >> ((k & 1) * 16 + 8)) & 0xffu;
+                    o[k] = (c0 * row_bytes) | ((c1 * row_bytes) << 16);
+                }
+                uint4 *dst = reinterpret_cast<uint4 *>(txt_g + LEVR_PAD + ch * 16);
+                dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+            }
         }
         wave_lds_fence();
 
-        // ---- systolic sweep, two text columns per iteration.  At iteration k lane w handles
-        // columns 2(k-w) and 2(k-w)+1; the two symbols and the four carry bits of the lane
-        // above arrive in one register through one DPP move.  Validity is a function of
-        // (k - w, n) alone, so no flag travels with the data and the loop body is branch-free.
-        uint32_t vp = 0xffffffffu, vn = 0u;
+        uint32_t vp[R], vn[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { vp[r] = 0xffffffffu; vn[r] = 0u; }
         const uint32_t un = (active && m > 0) ? (uint32_t)n : 0u;
-        int steps = (active && m > 0) ? ((n + 1) >> 1) + Wp - 1 : 0;
-        int max_steps = steps;
+        int max_steps = (active && m > 0) ? n + Gp - 1 : 0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) max_steps = max(max_steps, __shfl_xor(max_steps, off));
         max_steps = __builtin_amdgcn_readfirstlane(max_steps);
-        const uint32_t *pm_w = pm_g + w;
-        const uint16_t *txt2 = reinterpret_cast<const uint16_t *>(txt_g);
-        const int tmax = (a.text_stride >> 1) - 1;
-        // Two-deep software pipeline over LDS: the text pair of iteration k+2 and the match
-        // masks of iteration k+1 are requested while iteration k computes, so neither LDS
-        // latency sits on the loop-carried dependency (which is the DPP carry chain only).
-        auto text_at = [&](int kk) -> uint32_t { return txt2[min(max(kk, 0), tmax)]; };
-        uint32_t c0 = text_at(0 - w), c1 = text_at(1 - w);
-        uint32_t eqA = pm_w[(c0 & 0xffu) * G], eqB = pm_w[(c0 >> 8) * G];
-        uint32_t carry = 0;  // [0] hpA, [1] hnA, [2] hpB, [3] hnB of this lane's last iteration
+        const unsigned char *pm_w = reinterpret_cast<const unsigned char *>(pm_g + w * R);
+        const uint16_t *tp = txt_g + LEVR_PAD - w;   // tp[k] = row offset of this lane's symbol at iteration k
+        // 2-deep LDS pipeline: symbol of iteration k+2 and match masks of iteration k+1 are in
+        // flight while iteration k computes
+        uint32_t c1 = tp[1];
+        vecR eq = *reinterpret_cast<const vecR *>(pm_w + tp[0]);
+        uint32_t out_hp = 0, out_hn = 0;   // hp / hn of this lane's last word in the previous iteration
         for (int k = 0; k < max_steps; ++k) {
-            const uint32_t c2 = text_at(k + 2 - w);
-            const uint32_t eqA_n = pm_w[(c1 & 0xffu) * G], eqB_n = pm_w[(c1 >> 8) * G];
-            uint32_t in = dpp_wave_shr1(carry);
-            // keep the three LDS requests above the arithmetic (hipcc otherwise rotates the loop
-            // and waits for each request right where it was issued)
+            const uint32_t c2 = tp[k + 2];
+            const vecR eq_n = *reinterpret_cast<const vecR *>(pm_w + c1);
+            uint32_t hp_up = dpp_wave_shr1(out_hp), hn_up = dpp_wave_shr1(out_hn);
             __builtin_amdgcn_sched_barrier(0);
-            in = (w == 0) ? 0x5u : in;  // top row of the DP: +1 horizontal delta, never -1
-            const uint32_t col = (uint32_t)(k - w) * 2u;  // huge when k < w
-            const bool vA = col < un, vB = (col + 1u) < un;
-            // ---- column A
-            uint32_t hpc = in & 1u, hnc = (in >> 1) & 1u;
-            uint32_t x = eqA | hnc;
-            uint32_t d0 = (((x & vp) + vp) ^ vp) | x | vn;
-            uint32_t hp = vn | ~(d0 | vp);
-            uint32_t hn = d0 & vp;
-            const uint32_t hpoA = hp >> 31, hnoA = hn >> 31;
-            hp = (hp << 1) | hpc;
-            hn = (hn << 1) | hnc;
-            uint32_t nvp = hn | ~(d0 | hp), nvn = hp & d0;
-            vp = vA ? nvp : vp; vn = vA ? nvn : vn;
-            // ---- column B
-            hpc = (in >> 2) & 1u; hnc = (in >> 3) & 1u;
-            x = eqB | hnc;
-            d0 = (((x & vp) + vp) ^ vp) | x | vn;
-            hp = vn | ~(d0 | vp);
-            hn = d0 & vp;
-            const uint32_t hpoB = hp >> 31, hnoB = hn >> 31;
-            hp = (hp << 1) | hpc;
-            hn = (hn << 1) | hnc;
-            nvp = hn | ~(d0 | hp); nvn = hp & d0;
-            vp = vB ? nvp : vp; vn = vB ? nvn : vn;
-            carry = hpoA | (hnoA << 1) | (hpoB << 2) | (hnoB << 3);
-            __builtin_amdgcn_sched_barrier(0);  // consume the prefetched values only down here
-            eqA = eqA_n; eqB = eqB_n; c1 = c2;
+            // the row above the first pattern row: D[0][j] - D[0][j-1] = +1
+            hp_up = (w == 0) ? 0x80000000u : hp_up;
+            hn_up = (w == 0) ? 0u : hn_up;
+            const bool valid = (uint32_t)(k - w) < un;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t x = eq[r] | (hn_up >> 31);
+                const uint32_t d0 = (((x & vp[r]) + vp[r]) ^ vp[r]) | x | vn[r];
+                const uint32_t hp = vn[r] | ~(d0 | vp[r]);
+                const uint32_t hn = d0 & vp[r];
+                const uint32_t hps = __builtin_amdgcn_alignbit(hp, hp_up, 31);   // (hp << 1) | carry from the word below
+                const uint32_t hns = __builtin_amdgcn_alignbit(hn, hn_up, 31);
+                const uint32_t nvp = hns | ~(d0 | hps), nvn = hps & d0;
+                vp[r] = valid ? nvp : vp[r];
+                vn[r] = valid ? nvn : vn[r];
+                hp_up = hp;
+                hn_up = hn;
+            }
+            out_hp = hp_up;
+            out_hn = hn_up;
+            __builtin_amdgcn_sched_barrier(0);
+            eq = eq_n;
+            c1 = c2;
         }
-        // D[m][n] = D[0][n] + sum of the vertical deltas of the last column
-        //         = n + popcount(VP & rows) - popcount(VN & rows), summed over the slot's words
-        if (active && w < Wp) {
-            const uint32_t rows = (w == Wp - 1) ? (0xffffffffu >> (31 - ((m - 1) & 31))) : 0xffffffffu;
-            const int part = __popc(vp & rows) - __popc(vn & rows);
+        if (active) {
+            int part = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int wi = w * R + r;
+                const uint32_t rows = wi < Wp - 1 ? 0xffffffffu : (wi == Wp - 1 ? (0xffffffffu >> (31 - ((m - 1) & 31))) : 0u);
+                part += __popc(vp[r] & rows) - __popc(vn[r] & rows);
+            }
             if (part) atomicAdd(&ssum[g], part);
         }
         wave_lds_fence();
         if (active && w == 0) {
-            const double d = (double)(n + ssum[g]);  // m == 0: no word contributes, d = n
+            const double d = (double)(n + ssum[g]);
             if (a.out) a.out[t_pair] = d;
             if (a.RA) { a.RA[opos] = d; a.ncm[opos] = 0; }
         }
         wave_lds_fence();
     }
+}
+
+template <int R> static int launch_r(annchor_ctx *c, LevArgs a, int64_t npairs)
+{
+    const int W = (c->maxlen + 31) / 32 > 0 ? (c->maxlen + 31) / 32 : 1;
+    LevArgsR ar;
+    ar.GL = (W + R - 1) / R;
+    ar.pm_stride = ar.GL * R;
+    a.G = ar.GL;
+    a.P = 64 / ar.GL;
+    a.pm_bytes = (int)((((size_t)a.P * a.alphabet * ar.pm_stride * 4) + 15) & ~(size_t)15);
+    a.text_stride = 2 * (2 * LEVR_PAD + ((c->maxlen + 15) & ~15) + 16);
+    a.wave_bytes = a.pm_bytes + a.P * a.text_stride + 256;
+    ar.b = a;
+    const size_t lds = (size_t)a.wave_bytes;
+    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "alphabet %d x length %d needs %zu B of LDS (> 160 KiB)", c->alphabet,
+                c->maxlen, lds);
+    if (lds > 64 * 1024)
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev_r<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t blocks = (npairs + a.P - 1) / a.P;
+    const int64_t max_blocks = (int64_t)c->prop.multiProcessorCount * 32;
+    if (blocks > max_blocks) blocks = max_blocks;
+    k_lev_r<R><<<(int)blocks, ANN_WAVE, lds, c->stream>>>(ar);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
 }
 
 int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm)
@@ -224,18 +453,40 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
     a.text_stride = ((c->maxlen + 15) & ~15) + 16;
     a.pm_bytes = (int)((((size_t)a.P * a.alphabet * G * 4) + 15) & ~(size_t)15);
     a.wave_bytes = a.pm_bytes + a.P * a.text_stride + 256;  // + per-slot sums (<= 64 ints)
-    size_t lds = (size_t)a.wave_bytes * LEV_WAVES;
+    // kernel choice: R words per lane (default), R by launch size: few pairs -> more lanes per
+    // pair (shorter critical path), many pairs -> more words per lane (fewer instructions)
+    static const int force_r = getenv("ANNCHOR_LEV_R") ? atoi(getenv("ANNCHOR_LEV_R")) : -1;
+    {
+        const int W = (c->maxlen + 31) / 32;
+        // measured on MI355X (tools/lev_ab.py, strings of ~500 symbols): launches of a few
+        // thousand pairs (the anchor rounds: latency of one wave's column loop) are fastest with
+        // the two-columns-per-iteration kernel below, large launches (refine: throughput) with
+        // one word per lane and the lean per-column bookkeeping of k_lev_r; R = 2 / 4 cut
+        // instructions further but their tables leave < 2 waves per SIMD
+        (void)W;
+        int R = force_r >= 0 ? force_r : (src.n >= 8192 ? 1 : 0);
+        if (R == 1 || R == 2 || R == 4) {
+            ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
+            return R == 1 ? launch_r<1>(c, a, src.n) : R == 2 ? launch_r<2>(c, a, src.n) : launch_r<4>(c, a, src.n);
+        }
+    }
+    // ANNCHOR_LEV_R=0: the two-columns-per-iteration kernel, one word per lane
+    static const int force_ilp = getenv("ANNCHOR_LEV_ILP") ? atoi(getenv("ANNCHOR_LEV_ILP")) : 0;
+    int ilp = force_ilp ? force_ilp : 1;
+    if ((size_t)a.wave_bytes * LEV_WAVES * ilp > 160 * 1024) ilp = 1;
+    size_t lds = (size_t)a.wave_bytes * LEV_WAVES * ilp;
     ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "alphabet %d x length %d needs %zu B of LDS (> 160 KiB)", c->alphabet,
                 c->maxlen, lds);
-    if (lds > 64 * 1024)
-        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int64_t tasks = (src.n + a.P - 1) / a.P;
+    const void *fn = ilp == 2 ? (const void *)k_lev<2> : (const void *)k_lev<1>;
+    if (lds > 64 * 1024) ANN_CHECK_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t tasks = (src.n + (int64_t)a.P * ilp - 1) / ((int64_t)a.P * ilp);
     int64_t blocks = (tasks + LEV_WAVES - 1) / LEV_WAVES;
     int max_blocks = c->prop.multiProcessorCount * 8;
     if (blocks > max_blocks) blocks = max_blocks;
     // algorithmic work: one byte per symbol of both strings is all that must be read
     ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
-    k_lev<<<(int)blocks, LEV_THREADS, lds, c->stream>>>(a);
+    if (ilp == 2) k_lev<2><<<(int)blocks, LEV_THREADS, lds, c->stream>>>(a);
+    else k_lev<1><<<(int)blocks, LEV_THREADS, lds, c->stream>>>(a);
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
 }
