@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include <type_traits>
 
 #define LEV_THREADS 256
 #define LEV_WAVES (LEV_THREADS / ANN_WAVE)
@@ -110,8 +111,8 @@ template <int ILP> __global__ __launch_bounds__(LEV_THREADS) void k_lev(LevArgs 
                 }
             }
             const int li = active[u] ? a.slen[si] : 0, lj = active[u] ? a.slen[sj] : 0;
-            // pattern = shorter string, text = longer
-            const bool swap = li > lj;
+            // pattern = longer string (the slot reserves lanes for it anyway), text = shorter
+            const bool swap = li < lj;
             const int ps = swap ? sj : si, ts = swap ? si : sj;
             m[u] = swap ? lj : li; n[u] = swap ? li : lj;
             const uint8_t *pat = a.sym + (active[u] ? a.soff[ps] : 0);
@@ -355,7 +356,7 @@ template <int R> __global__ __launch_bounds__(ANN_WAVE) void k_lev_r(LevArgsR ar
         uint32_t c1 = tp[1];
         vecR eq = *reinterpret_cast<const vecR *>(pm_w + tp[0]);
         uint32_t out_hp = 0, out_hn = 0;   // hp / hn of this lane's last word in the previous iteration
-        for (int k = 0; k < max_steps; ++k) {
+        auto column = [&](int k, auto checked) {
             const uint32_t c2 = tp[k + 2];
             const vecR eq_n = *reinterpret_cast<const vecR *>(pm_w + c1);
             uint32_t hp_up = dpp_wave_shr1(out_hp), hn_up = dpp_wave_shr1(out_hn);
@@ -363,7 +364,7 @@ template <int R> __global__ __launch_bounds__(ANN_WAVE) void k_lev_r(LevArgsR ar
             // the row above the first pattern row: D[0][j] - D[0][j-1] = +1
             hp_up = (w == 0) ? 0x80000000u : hp_up;
             hn_up = (w == 0) ? 0u : hn_up;
-            const bool valid = (uint32_t)(k - w) < un;
+            const bool valid = !decltype(checked)::value || (uint32_t)(k - w) < un;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t x = eq[r] | (hn_up >> 31);
@@ -383,7 +384,18 @@ template <int R> __global__ __launch_bounds__(ANN_WAVE) void k_lev_r(LevArgsR ar
             __builtin_amdgcn_sched_barrier(0);
             eq = eq_n;
             c1 = c2;
-        }
+        };
+        // Lane w works on column k - w.  Between k = GL - 1 (every lane has started) and the
+        // shortest text of the wave's pairs (no lane has finished) every column is a real one:
+        // that stretch runs without the per-column validity test.
+        int k_lo = min(GL - 1, max_steps), k_hi = (active && m > 0) ? n : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) k_hi = min(k_hi, __shfl_xor(k_hi, off));
+        k_hi = max(k_lo, min(__builtin_amdgcn_readfirstlane(k_hi), max_steps));
+        int k = 0;
+        for (; k < k_lo; ++k) column(k, std::true_type());
+        for (; k < k_hi; ++k) column(k, std::false_type());
+        for (; k < max_steps; ++k) column(k, std::true_type());
         if (active) {
             int part = 0;
 #pragma unroll
