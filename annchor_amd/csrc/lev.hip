@@ -467,7 +467,8 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
     a.wave_bytes = a.pm_bytes + a.P * a.text_stride + 256;  // + per-slot sums (<= 64 ints)
     // kernel choice: R words per lane (default), R by launch size: few pairs -> more lanes per
     // pair (shorter critical path), many pairs -> more words per lane (fewer instructions)
-    static const int force_r = getenv("ANNCHOR_LEV_R") ? atoi(getenv("ANNCHOR_LEV_R")) : -1;
+    const char *env_r = getenv("ANNCHOR_LEV_R");   // test / tuning override, read per launch
+    const int force_r = env_r ? atoi(env_r) : -1;
     {
         const int W = (c->maxlen + 31) / 32;
         // measured on MI355X (tools/lev_ab.py, strings of ~500 symbols): launches of a few

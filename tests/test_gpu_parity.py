@@ -81,6 +81,32 @@ def test_levenshtein_random_ragged():
     assert list(got) == want
 
 
+@pytest.mark.parametrize("variant", ["0", "1", "2", "4"])
+def test_levenshtein_kernel_variants_ragged(variant, monkeypatch):
+    """Every Levenshtein kernel variant (two-column systolic kernel = 0, R words per lane = 1/2/4;
+    normally chosen by launch size) against the oracle on ragged input: empty strings, lengths
+    around the 32-symbol word boundaries, one very long string (sets the slot width), equal
+    strings, a 60-symbol alphabet."""
+    from annchor_amd import _native
+    from annchor_amd.distances import levenshtein
+
+    monkeypatch.setenv("ANNCHOR_LEV_R", variant)
+    rng = np.random.default_rng(7)
+    alphabet = [chr(c) for c in range(60, 120)]
+    lens = list(range(0, 70)) + [95, 96, 97, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 640, 1000]
+    X = ["".join(rng.choice(alphabet[: rng.integers(2, 60)], n)) for n in lens for _ in range(3)]
+    X += [X[5], X[100], "", ""]
+    eng = _native.Engine(0)
+    levenshtein.bind(eng, X)
+    IJ = rng.integers(0, len(X), (12000, 2))
+    IJ[:200, 1] = IJ[:200, 0]
+    got = eng.metric_pairs(IJ)
+    want = om.PackedStrings(X).pairs(IJ)
+    assert np.array_equal(got, want)
+    few = IJ[:7]  # a launch smaller than one wave's slots
+    assert np.array_equal(eng.metric_pairs(few), want[:7])
+
+
 @pytest.mark.parametrize("dtype,dim", [(np.float32, 128), (np.float64, 3), (np.float32, 7), (np.float64, 64)])
 def test_euclidean_pairs_vs_oracle(dtype, dim):
     from annchor_amd import _native
