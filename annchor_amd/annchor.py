@@ -437,6 +437,33 @@ class Annchor:
         eng.close()
         return idx[nx:, 1:], dist[nx:, 1:]
 
+    # ---------------------------------------------- nearest enemies / selective subset
+    def _require_pair_list(self, what):
+        if self._streamed is not None:
+            raise NotImplementedError(what + " needs the pair-list form (nx <= %d)" % PAIRLIST_MAX_POINTS)
+
+    def get_nearest_enemies(self, y, nn=3, loc_min=100):
+        """annchor.py:685-782: the nn nearest points of a different label for every point;
+        result in self.nearest_enemy_graph = (indices [nx, nn], distances [nx, nn])."""
+        from . import enemies
+
+        self._require_pair_list("get_nearest_enemies")
+        enemies.nearest_enemies(self, y, nn=nn, loc_min=loc_min)
+
+    def annchor_selective_subset(self, y, dne=None, alpha=0):
+        """annchor.py:784-901: indices of a selective subset of X for labels y."""
+        from . import enemies
+
+        self._require_pair_list("annchor_selective_subset")
+        return enemies.selective_subset(self, y, dne=dne, alpha=alpha)
+
+    def alpha_rss(self, y, dne=None, alpha=0):
+        """annchor.py:903-927."""
+        from . import enemies
+
+        self._require_pair_list("alpha_rss")
+        return enemies.alpha_rss(self, y, dne=dne, alpha=alpha)
+
     def to_sparse_matrix(self):
         """annchor.py:625-641: DOK sparse distance matrix of the k-NN graph."""
         from scipy.sparse import dok_matrix

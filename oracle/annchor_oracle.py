@@ -117,7 +117,15 @@ def locality_pairs(D, locality, loc_thresh, loc_min):
     return sid, IJs, I_ptr, I_idx
 
 
-def build_I(IJs, nx):
+def build_I(IJs, nx, reference_truncation=False):
+    """CSR of pair positions per point (get_IJs_from_check, utils.py:502-540).
+    reference_truncation=True reproduces the reference's trailing-boundary arithmetic
+    (utils.py:518,521: both group-boundary arrays are closed with `start of the last i-group
+    + 1` resp. `+ 2`), which drops entries of the last i-group and of the last j-group; it is
+    used only to show that the remaining differences from the reference's nearest-enemy
+    outputs are that latent bug and nothing else."""
+    if reference_truncation:
+        return _build_I_truncated(IJs, nx)
     n = IJs.shape[0]
     pos = np.arange(n, dtype=np.int64)
     owner = np.concatenate([IJs[:, 1], IJs[:, 0]])
@@ -129,6 +137,25 @@ def build_I(IJs, nx):
     I_ptr = np.zeros(nx + 1, dtype=np.int64)
     np.cumsum(counts, out=I_ptr[1:])
     return I_ptr, I_idx
+
+
+def _build_I_truncated(IJs, nx):
+    n = IJs.shape[0]
+    fi = IJs[:, 0]
+    jsort = np.argsort(IJs[:, 1])  # NumPy default kind, as the reference calls it
+    fj = IJs[jsort, 1]
+    i_start = np.concatenate([[0], np.nonzero(np.diff(fi))[0] + 1])
+    j_start = np.concatenate([[0], np.nonzero(np.diff(fj))[0] + 1])
+    i_end = np.concatenate([i_start[1:], [i_start[-1] + 1]])   # last i-group: one entry
+    j_end = np.concatenate([j_start[1:], [i_start[-1] + 2]])   # last j-group: closed with the i bound
+    rows = [[np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)] for _ in range(nx)]
+    for s0, e0 in zip(j_start, j_end):
+        rows[fj[s0]][0] = jsort[s0:max(e0, s0)]
+    for s0, e0 in zip(i_start, i_end):
+        rows[fi[s0]][1] = np.arange(s0, e0, dtype=np.int64)
+    rows = [np.concatenate(r) for r in rows]
+    I_ptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    return I_ptr, (np.concatenate(rows).astype(np.int64) if n else np.zeros(0, dtype=np.int64))
 
 
 def check_locality_size(I_ptr, n_neighbors):
@@ -551,3 +578,180 @@ def query(fitted, query_pairs, nq, nn=15, p_work=0.3):
     # get_nn(nq, nn + 1, ...) (:210): raw output, no self column
     idx, dist = get_nn(QRA, ncm, np.stack([IJs[:, 0], IJs[:, 0]], axis=1), QI_ptr, QI_idx, nn + 1)   # neighbour = the X endpoint
     return idx[:, 1:], dist[:, 1:], dict(QD=QD, IJs=IJs, n_refine=n_refine, evals=na * nq + len(mapback))
+
+
+# ------------------------------------------------ nearest enemies / selective subset (f4)
+def nearest_enemies(fitted, y, nn=3, loc_min=100, first=50, reference_truncation=False):
+    """Annchor.get_nearest_enemies, annchor.py:685-782, on a fitted OracleAnnchor.
+
+    Extends the fitted pair list by enemy pairs (different labels) chosen by shared nearest
+    anchors among enemies only (get_check with the label filter, utils.py:454-491, minus the
+    pairs fit() already holds), predicts them with the fitted regression, evaluates exactly
+    each row's uncomputed entries among its `first` closest-looking enemies, and reads the nn
+    nearest enemies per row.  The fitted object's pair-list state is extended in place, as in
+    the reference.  Returns (idx int64 [nx, nn], dist float64 [nx, nn]).
+    Tie rule as everywhere in this restatement: stable sorts (the reference's are unstable)."""
+    o = fitted
+    nx = o.nx
+    y = np.asarray(y)
+    assert y.shape[0] == nx, "Label dimension mismatch: len(y)=%d, len(X)=%d" % (y.shape[0], nx)
+    labels, counts = np.unique(y, return_counts=True)
+    assert labels.shape[0] > 1, "Data must have more than one label"
+    assert np.all(counts >= nn), "At least one label occurs fewer times than specified nn=%d" % nn
+
+    na = o.D.shape[1]
+    Am = np.zeros((nx, na), dtype=np.int32)
+    np.put_along_axis(Am, o.sid, 1, axis=1)
+    C = Am @ Am.T
+    # candidates fit() already holds (symmetric): keep_fit[i, j]
+    keep_fit = np.zeros((nx, nx), dtype=bool)
+    keep_fit[o.IJs[:, 0], o.IJs[:, 1]] = True
+    keep_fit |= keep_fit.T
+    np.fill_diagonal(keep_fit, True)
+    new = np.zeros((nx, nx), dtype=bool)
+    lowered = False
+    for i in range(nx):
+        enemy = y != y[i]
+        c = C[i][enemy]
+        lm = min(loc_min, c.shape[0] - 1)
+        kth = -np.partition(-c, lm)[lm]
+        thr = o.loc_thresh
+        if kth < o.loc_thresh:
+            thr, lowered = kth, True
+        new[i] = enemy & (C[i] >= thr)
+    if lowered:  # adjust_check: the smaller index of a pair learns about it from the larger
+        new |= np.tril(new, -1).T
+    new &= ~keep_fit
+    I0, J0 = np.nonzero(np.triu(new, 1))
+    IJn = np.stack([I0, J0], axis=1).astype(np.int64)
+    n0 = o.IJs.shape[0]
+    ptr_n, idx_n = build_I(IJn, nx, reference_truncation)
+    fn, ncm_n = features(IJn, o.D, o.A, ptr_n, idx_n)
+    pred = np.clip(regression_predict(fn, o.bins, o.W, o.c), fn[:, 0], fn[:, 1])
+    # append (annchor.py:729-740)
+    o.IJs = np.vstack([o.IJs, IJn])
+    o.ncm = np.concatenate([o.ncm, ncm_n])
+    o.RA = np.concatenate([o.RA, pred])
+    o.features = np.vstack([o.features, fn])
+    rows = [np.concatenate([o.I_idx[o.I_ptr[i]:o.I_ptr[i + 1]], idx_n[ptr_n[i]:ptr_n[i + 1]] + n0]) for i in range(nx)]
+    o.I_ptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    o.I_idx = np.concatenate(rows).astype(np.int64)
+
+    def other(i, Ii):
+        f = o.IJs[Ii]
+        return np.where(f[:, 0] == i, f[:, 1], f[:, 0])
+
+    todo = []
+    for i in range(nx):
+        Ii = rows[i]
+        fi = other(i, Ii)
+        lm = y[fi] != y[i]
+        order = np.argsort(o.RA[Ii][lm], kind="stable")[:first]
+        sel = Ii[lm][order]
+        todo.append(sel[o.ncm[sel]])
+    todo = np.concatenate(todo)
+    if todo.shape[0] > 0:
+        o.RA[todo] = o.metric_pairs(o.IJs[todo])
+        o.ncm[todo] = False
+    ngi = np.zeros((nx, nn), dtype=np.int64)
+    ngd = np.zeros((nx, nn))
+    for i in range(nx):
+        Ii = rows[i]
+        fi = other(i, Ii)
+        d = o.RA[Ii].copy()
+        mx = d.max()
+        d[o.ncm[Ii]] += mx
+        d[y[fi] == y[i]] += mx
+        pick = np.argsort(d, kind="stable")[:nn]
+        ngd[i] = o.RA[Ii[pick]]
+        ngi[i] = fi[pick]
+    o.nearest_enemy_graph = (ngi, ngd)
+    return ngi, ngd
+
+
+def _cover_count(ngd_rows, alpha_dne):
+    """ebuffer: how many leading entries of each sorted row lie closer than the (scaled)
+    nearest-enemy distance, annchor.py:826-831."""
+    return np.array([np.searchsorted(r, t - 1e-6) for r, t in zip(ngd_rows, alpha_dne)], dtype=np.int64)
+
+
+def selective_subset(fitted, y, dne=None, alpha=0):
+    """Annchor.annchor_selective_subset, annchor.py:784-901: greedy cover on the k-NN graph
+    (a point is covered when a subset member is among its neighbours closer than its nearest
+    enemy), then pruning against the full candidate rows (uncomputed pairs at their upper
+    bound)."""
+    o = fitted
+    nx = o.nx
+    if dne is None:
+        if not hasattr(o, "nearest_enemy_graph"):
+            nearest_enemies(o, y)
+        dne = o.nearest_enemy_graph[1][:, 0]
+    dne = np.asarray(dne, dtype=np.float64)
+    if np.any(dne == 0):
+        raise Exception("Error: The following indices are distance zero from a point  with a different label:\n"
+                        + "".join("\t %d\n" % i for i in np.nonzero(dne == 0)[0]))
+    adne = dne / (1 + alpha)
+    ngi, ngd = o.neighbor_graph
+    eb = _cover_count(ngd, adne)
+    rss = [int(i) for i in np.nonzero(eb == 1)[0]]
+    in_rss = np.zeros(nx, dtype=bool)
+    in_rss[rss] = True
+
+    def covered(i):  # first subset member in row i's neighbour list sits inside its buffer
+        hit = np.nonzero(in_rss[ngi[i]])[0]
+        return hit.shape[0] > 0 and hit[0] < eb[i]
+
+    done = np.array([covered(i) for i in range(nx)])
+    while not done.all():
+        votes = np.zeros(nx, dtype=np.int64)
+        for i in np.nonzero(~done)[0]:
+            np.add.at(votes, ngi[i][:eb[i]], 1)
+        nxt = int(np.argmax(votes))  # most frequent, smallest index on ties (np.unique order)
+        rss.append(nxt)
+        for i in np.nonzero(~done)[0]:
+            hit = np.nonzero(ngi[i] == nxt)[0]
+            if hit.shape[0] > 0 and hit[0] < eb[i]:
+                done[i] = True
+    rss = np.array(rss, dtype=np.int64)
+    # pruning phase (annchor.py:869-901)
+    dists = o.RA.copy()
+    dists[o.ncm] = o.features[o.ncm, 1]
+    member = np.zeros((nx, rss.shape[0]), dtype=bool)
+    pos_in_rss = -np.ones(nx, dtype=np.int64)
+    pos_in_rss[rss] = np.arange(rss.shape[0])
+    for i in range(nx):
+        Ii = o.I_idx[o.I_ptr[i]:o.I_ptr[i + 1]]
+        order = np.argsort(dists[Ii], kind="stable")
+        f = o.IJs[Ii[order]]
+        nbr = np.concatenate([[i], f.sum(axis=1) - i])
+        nd = np.concatenate([[0.0], dists[Ii][order]])
+        buf = nbr[: np.searchsorted(nd, adne[i] - 1e-6)]
+        p = pos_in_rss[buf]
+        member[i, p[p >= 0]] = True
+    cover = member.sum(axis=1)
+    keep = np.ones(rss.shape[0], dtype=bool)
+    for r in range(rss.shape[0]):
+        if np.min(cover - member[:, r]) != 0:
+            cover = cover - member[:, r]
+            keep[r] = False
+    return rss[keep]
+
+
+def alpha_rss(fitted, y, dne=None, alpha=0):
+    """Annchor.alpha_rss, annchor.py:903-927: scan points by increasing nearest-enemy
+    distance; a point joins when no member is closer than its (scaled) nearest enemy."""
+    o = fitted
+    if dne is None:
+        if not hasattr(o, "nearest_enemy_graph"):
+            nearest_enemies(o, y)
+        dne = o.nearest_enemy_graph[1][:, 0]
+    dne = np.asarray(dne, dtype=np.float64)
+    order = np.argsort(dne, kind="stable")
+    rss = [int(order[0])]
+    adne = dne / (1 + alpha)
+    for i in order:
+        ds = o.metric_pairs(np.array([[i, r] for r in rss], dtype=np.int64))
+        m = ds.min()
+        if m > adne[i] or np.isclose(m, adne[i]):
+            rss.append(int(i))
+    return np.array(rss, dtype=np.int64)

@@ -19,7 +19,7 @@ The reference needs three third-party modules that are not installed here
 So: vectors for the reference's OWN functions (a0, a6-a17) are genuine reference
 outputs; metric values inside them come from the oracle's metric restatements.
 
-Usage:  python tests/golden/make_golden.py [small|blobs|strings_full|digits_full|all]
+Usage:  python tests/golden/make_golden.py [small|blobs|strings_full|digits_full|enemies|all]
 """
 import os
 import sys
@@ -202,6 +202,80 @@ def gen_digits_full():
     save("digits_full", out)
 
 
+def gen_enemies():
+    """reference tests/test_examples.py:61-85 (annchor_selective_subset on blobs / moons; the
+    pinned sizes there, 90 / 16, belong to numba's RNG stream -- under the pass-through numba
+    stand-in the reference draws its samples from NumPy's legacy stream, so the sizes recorded
+    here are the reference's own results for THAT stream) plus get_nearest_enemies and
+    alpha_rss.  State is snapshotted after fit() so that the restatement can be checked from
+    the same starting point."""
+    from sklearn.datasets import make_blobs, make_moons
+
+    np.random.seed(1)
+    X, y = make_blobs(n_samples=1000, centers=5)
+    U, v = make_moons(n_samples=1000, noise=0.1)
+    U = np.fliplr(U)
+    ev = lambda f, X, IJ: om.euclidean_pairs(X, np.asarray(IJ, dtype=np.int64))  # noqa: E731
+    out = {}
+    for tag, (Z, lab) in (("blobs", (X, y)), ("moons", (np.ascontiguousarray(U), v))):
+        ann = ref.Annchor(Z, "euclidean", n_neighbors=15, p_work=0.2, get_exact_ijs=ev)
+        ann.fit()
+        out[tag + "_X"], out[tag + "_y"] = Z, np.asarray(lab, dtype=np.int64)
+        out[tag + "_ng_idx"], out[tag + "_ng_dist"] = ann.neighbor_graph[0].copy(), ann.neighbor_graph[1].copy()
+        out[tag + "_n_pairs_fit"] = np.int64(len(ann.IJs))
+        ann.get_nearest_enemies(lab)
+        out[tag + "_ne_idx"], out[tag + "_ne_dist"] = (ann.nearest_enemy_graph[0].copy(),
+                                                       ann.nearest_enemy_graph[1].copy())
+        out[tag + "_n_pairs_ne"] = np.int64(len(ann.IJs))
+        out[tag + "_n_computed_ne"] = np.int64((~ann.not_computed_mask).sum())
+        for alpha in (0, 0.1):
+            ss = ann.annchor_selective_subset(y=lab, alpha=alpha)
+            out[tag + "_ss_a%g" % alpha] = np.asarray(ss, dtype=np.int64)
+            print(tag, "alpha", alpha, "selective subset size", len(ss))
+        rss = ann.alpha_rss(lab, alpha=0)
+        out[tag + "_alpha_rss"] = np.asarray(rss, dtype=np.int64)
+        print(tag, "alpha_rss size", len(rss))
+    save("enemies", out)
+
+
+def gen_enemies_state():
+    """State-pinned vectors for get_nearest_enemies / annchor_selective_subset / alpha_rss:
+    the reference's complete post-fit state on a 400-point set (so a restatement can start
+    from exactly the same state; under the slow numba stand-in the reference's
+    update_anchor_points stops at its 10 s cutoff, so end-to-end states are not comparable)
+    and the reference's outputs from there."""
+    from sklearn.datasets import make_moons
+
+    np.random.seed(3)
+    U, v = make_moons(n_samples=400, noise=0.15)
+    U = np.ascontiguousarray(np.fliplr(U))
+    ev = lambda f, X, IJ: om.euclidean_pairs(X, np.asarray(IJ, dtype=np.int64))  # noqa: E731
+    ann = ref.Annchor(U, "euclidean", n_anchors=20, n_neighbors=6, n_samples=1000, p_work=0.2, locality=3,
+                      get_exact_ijs=ev)
+    ann.fit()
+    nx = ann.nx
+    ptr, idx = I_to_csr(ann.I, nx)
+    out = dict(X=U, y=np.asarray(v, dtype=np.int64), D=np.ascontiguousarray(ann.D), A=np.asarray(ann.A, dtype=np.int64),
+               sid=np.asarray(ann.sid, dtype=np.int64), IJs=ann.IJs.copy(), I_ptr=ptr, I_idx=idx,
+               features=ann.features.copy(), ncm=ann.not_computed_mask.copy(), RA=ann.RefineApprox.copy(),
+               bins=ann.regression.sample_bins.copy(),
+               W=np.array([lr.coef_ for lr in ann.regression.LRs]), c=np.array([lr.intercept_ for lr in ann.regression.LRs]),
+               ng_idx=ann.neighbor_graph[0].copy(), ng_dist=ann.neighbor_graph[1].copy(),
+               loc_thresh=np.int64(ann.loc_thresh))
+    ann.get_nearest_enemies(v, nn=3, loc_min=80)
+    ptr2, idx2 = I_to_csr(ann.I, nx)
+    out.update(ne_idx=ann.nearest_enemy_graph[0].copy(), ne_dist=ann.nearest_enemy_graph[1].copy(),
+               ne_IJs_new=ann.IJs[len(out["IJs"]):].copy(), ne_ncm=ann.not_computed_mask.copy(),
+               ne_RA=ann.RefineApprox.copy(), ne_I_ptr=ptr2, ne_I_idx=idx2)
+    for alpha in (0, 0.2):
+        out["ss_a%g" % alpha] = np.asarray(ann.annchor_selective_subset(y=v, alpha=alpha), dtype=np.int64)
+        print("alpha", alpha, "selective subset size", len(out["ss_a%g" % alpha]))
+    out["alpha_rss"] = np.asarray(ann.alpha_rss(v, alpha=0), dtype=np.int64)
+    out["alpha_rss_a0.2"] = np.asarray(ann.alpha_rss(v, alpha=0.2), dtype=np.int64)
+    print("alpha_rss", len(out["alpha_rss"]), len(out["alpha_rss_a0.2"]), "new pairs", len(out["ne_IJs_new"]))
+    save("enemies_state", out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("small", "all"):
@@ -212,3 +286,6 @@ if __name__ == "__main__":
         gen_strings_full()
     if what in ("digits_full", "all"):
         gen_digits_full()
+    if what in ("enemies", "all"):
+        gen_enemies()
+        gen_enemies_state()
