@@ -150,3 +150,26 @@ def test_library_rng_matches_numpy_legacy_stream():
             np.random.seed(seed)
             ref = [np.arange(c) if c < w else np.random.permutation(int(c))[:w] for c, w in zip(counts, want)]
             assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+
+
+def test_library_rng_portable_path_matches_numpy():
+    """The same check with the AVX-512 scan disabled (ANNCHOR_RNG_SCALAR=1 is read once per
+    process, hence the subprocess)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, __graft_entry__ as g\n"
+        "g.build()\n"
+        "from annchor_amd import _native\n"
+        "counts, want = [1700, 18800, 17100, 17600, 18300, 33000, 18500, 3, 0], [715, 715, 714, 714, 714, 714, 714, 5, 0]\n"
+        "for seed in (0, 42):\n"
+        "    got = _native.legacy_choice_ranks(seed, counts, want)\n"
+        "    np.random.seed(seed)\n"
+        "    ref = [np.arange(c) if c < w else np.random.permutation(int(c))[:w] for c, w in zip(counts, want)]\n"
+        "    assert all(np.array_equal(a, b) for a, b in zip(got, ref))\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ANNCHOR_RNG_SCALAR="1", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
