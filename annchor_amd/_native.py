@@ -60,6 +60,7 @@ _SIGNATURES = {
     "annchor_set_labels": (ctypes.c_int, [_vp, _vp]),
     "annchor_select_candidates": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i64, _i32,
                                                  ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "annchor_mark_candidates": (ctypes.c_int, [_vp]),
     "annchor_refine_candidates": (ctypes.c_int, [_vp]),
     "annchor_set_refined": (ctypes.c_int, [_vp, _vp, _i64]),
     "annchor_update_bounds": (ctypes.c_int, [_vp]),
@@ -313,6 +314,9 @@ class Engine:
                                                      len(errs_list), int(n_refine), int(lookahead),
                                                      ctypes.byref(nc), ctypes.byref(nn)))
         return nc.value, nn.value
+
+    def mark_candidates(self):
+        self._chk(self.lib.annchor_mark_candidates(self.h))
 
     def refine_candidates(self):
         self._chk(self.lib.annchor_refine_candidates(self.h))

@@ -143,6 +143,7 @@ class Annchor:
         self._anchors_on_device = False
         self._cache = {}
         self._first_merge = True
+        self._sample_ticket, self._pipelined = None, False
         self.timings = {}
 
     # ------------------------------------------------------------ metric boundary
@@ -234,8 +235,10 @@ class Annchor:
         """annchor.py:313-343."""
         eng = self._engine
         if type(self.sampler) is SimpleStratifiedSampler:
-            self.sample_ixs, self.n_samples, self.sample_bins = self.sampler.sample_device(
-                eng, self.n_samples, self.random_seed)
+            ticket, self._sample_ticket = self._sample_ticket, None
+            if ticket is None:
+                ticket = self.sampler.begin_device(eng, self.n_samples, self.random_seed)
+            self.sample_ixs, self.n_samples, self.sample_bins = self.sampler.finish_device(ticket)
         else:
             self.sample_ixs, self.n_samples, self.sample_bins = self.sampler.sample(
                 self.features, self.feature_names, self.n_samples, self.not_computed_mask, self.random_seed)
@@ -292,6 +295,12 @@ class Annchor:
         ncand, nnext = self._engine.select_candidates(nn, nmin, errs, n_refine, self.lookahead)
         self.n_refine = n_refine
         self._invalidate("RA", "thresh", "cand", "next")
+        if (self._pipelined and self._device_metric and ncand and it < self.niters - 1
+                and type(self.sampler) is SimpleStratifiedSampler):
+            # inside fit(): the next sampling step's statistics depend on the mask and dad only,
+            # so take them now and let the host draw overlap the refinement kernel
+            self._engine.mark_candidates()
+            self._sample_ticket = self.sampler.begin_device(self._engine, self.n_samples, self.random_seed)
         if self._device_metric:
             self._engine.refine_candidates()
         elif ncand:
@@ -341,6 +350,7 @@ class Annchor:
             if self.verbose:
                 print("%40s: %6.3f | %6.3f" % (name, time.perf_counter() - s, time.perf_counter() - origin))
 
+        self._pipelined = True
         stage("get_anchors", self.get_anchors)
         stage("get_locality", self.get_locality)
         stage("get_features", self.get_features)
@@ -359,6 +369,7 @@ class Annchor:
             if it < niters - 1:
                 stage("update_anchor_points", self.update_anchor_points)
         stage("get_ann", self.get_ann)
+        self._pipelined = False
         t["total"] = time.perf_counter() - origin
         return self
 

@@ -83,6 +83,7 @@ struct annchor_ctx {
     DevBuf thresh;               // double [nx]
     DevBuf cand, next;           // int32 lists
     int64_t ncand = 0, nnext = 0;
+    bool cand_marked = false;      // not_computed_mask already cleared for the current candidates
     DevBuf gl_val, gl_pos, gl_cnt, gl_ncomp, marked, markcount;  // guarantee_nmin scratch
     DevBuf sel_hist, sel_state, blk_cnt, blk_off;                // radix select / compaction scratch
     DevBuf errs, errptr;

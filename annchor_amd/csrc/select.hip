@@ -684,6 +684,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     ANN_TRY(ann_d2h(c, &cs, c->sel_state.p, sizeof cs));
     c->ncand = cs.ncand;
     c->n_unc = n_unc;  // candidates are distinct not-computed pairs: refinement lowers the count by ncand
+    c->cand_marked = false;
     c->nnext = cs.nnext;
     *n_cand = cs.ncand;
     *n_next = cs.nnext;
@@ -691,6 +692,25 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
 }
 
 // ------------------------------------------------------------------- refinement
+__global__ void k_mark_candidates(const int32_t *__restrict__ pos, int64_t m, uint8_t *__restrict__ ncm)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m) ncm[pos[t]] = 0;
+}
+
+extern "C" int annchor_mark_candidates(annchor_ctx *c)
+{
+    if (!c) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_RA, ANNCHOR_EINVAL, "RefineApprox not initialised");
+    if (c->ncand == 0 || c->cand_marked) return ANNCHOR_OK;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    k_mark_candidates<<<ann_blocks(c->ncand, 256), 256, 0, c->stream>>>(c->cand.as<int32_t>(), c->ncand, c->ncm.as<uint8_t>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    if (c->n_unc >= 0) c->n_unc -= c->ncand;
+    c->cand_marked = true;
+    return ANNCHOR_OK;
+}
+
 extern "C" int annchor_refine_candidates(annchor_ctx *c)
 {
     if (!c) return ANNCHOR_EINVAL;
@@ -707,7 +727,8 @@ extern "C" int annchor_refine_candidates(annchor_ctx *c)
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;
     ANN_CHECK_HIP(c, hipGetLastError());
-    if (c->n_unc >= 0) c->n_unc -= c->ncand;
+    if (c->n_unc >= 0 && !c->cand_marked) c->n_unc -= c->ncand;
+    c->cand_marked = true;
     return ANNCHOR_OK;
 }
 
@@ -731,6 +752,7 @@ extern "C" int annchor_set_refined(annchor_ctx *c, const double *exact, int64_t 
     k_write_refined<<<ann_blocks(n_cand, 256), 256, 0, c->stream>>>(c->cand.as<int32_t>(), c->stage_in.as<double>(), n_cand,
                                                                    c->RA.as<double>(), c->ncm.as<uint8_t>());
     ANN_CHECK_HIP(c, hipGetLastError());
-    if (c->n_unc >= 0) c->n_unc -= n_cand;
+    if (c->n_unc >= 0 && !c->cand_marked) c->n_unc -= n_cand;
+    c->cand_marked = true;
     return ANNCHOR_OK;
 }

@@ -13,12 +13,31 @@ import numpy as np
 import scipy.linalg
 
 
+try:  # the LAPACK driver scipy.linalg.lstsq dispatches to, minus ~20 us of argument checking per call
+    from scipy.linalg.lapack import dgelsd as _gelsd, dgelsd_lwork as _gelsd_lwork
+except ImportError:  # pragma: no cover
+    _gelsd = None
+
+
+def _lstsq(A, b, cond):
+    if _gelsd is None:
+        return scipy.linalg.lstsq(A, b, cond=cond)[0]
+    m, n = A.shape
+    work, iwork, info = _gelsd_lwork(m, n, 1, cond)
+    if info != 0:
+        return scipy.linalg.lstsq(A, b, cond=cond)[0]
+    x, _, _, info = _gelsd(A, b.reshape(-1, 1), int(work.real), int(iwork), cond, False, False)
+    if info != 0:
+        return scipy.linalg.lstsq(A, b, cond=cond)[0]
+    return x[:n, 0]
+
+
 def _ols(X, y):
     # sklearn LinearRegression(fit_intercept=True): centre, lstsq (gelsd), intercept
     xm, ym = X.mean(axis=0), y.mean()
     Xc, yc = X - xm, y - ym
     cond = max(Xc.shape) * np.finfo(np.float64).eps
-    coef = scipy.linalg.lstsq(Xc, yc, cond=cond)[0]
+    coef = _lstsq(Xc, yc, cond) if Xc.shape[0] >= Xc.shape[1] else scipy.linalg.lstsq(Xc, yc, cond=cond)[0]
     return coef, ym - xm @ coef
 
 

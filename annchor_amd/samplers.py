@@ -102,32 +102,64 @@ class SimpleStratifiedSampler(Sampler):
 
     def sample_device(self, engine, n_samples, random_seed):
         """Same result as sample(), computed against the device-resident state."""
-        if self.partition_feature_name != "double anchor distance":
-            raise NotImplementedError
-        n_unc = engine.count_uncomputed()
-        if n_unc == 0:
-            raise NothingToSample()
-        iq1, iq3, new_n = self._quantile_ranks(n_unc, n_samples, self.n_partitions)
-        if new_n != n_samples:
-            print("Warning: n_samples has changed from %d to %d." % (n_samples, new_n))
-        n_samples = new_n
-        q1, q3 = engine.kth_uncomputed_dad([iq1, iq3])
-        sample_bins = np.hstack([-np.inf, np.linspace(q1, q3, self.n_partitions - 1), np.inf])
-        if n_samples == 0:
-            raise NothingToSample()
-        counts = engine.bin_counts(sample_bins)
-        bin_size, remainder = n_samples // self.n_partitions, n_samples % self.n_partitions
+        return self.finish_device(self.begin_device(engine, n_samples, random_seed))
+
+    def begin_device(self, engine, n_samples, random_seed):
+        """First half of sample_device: the statistics the draw depends on (number of
+        not-computed pairs, dad quantiles, bin counts -- functions of not_computed_mask and dad
+        only), then the draw itself on a host thread.  Annchor.fit() calls this as soon as the
+        refinement candidates are known, so that the draw overlaps the refinement kernel.
+        Errors are kept in the ticket and raised by finish_device, where sample() would raise."""
+        import threading
+
         from . import _native
 
-        want = np.array([bin_size + (nbin < remainder) for nbin in range(self.n_partitions)], dtype=np.int64)
-        seed = random_seed + self.loop_num
-        if 0 <= seed < 2 ** 32:
-            per_bin = _native.legacy_choice_ranks(seed, counts, want)
-        else:  # outside the legacy int-seed range NumPy raises; keep its behaviour
-            np.random.seed(seed)
-            per_bin = [np.arange(c) if c < w else np.random.permutation(int(c))[:w] for c, w in zip(counts, want)]
+        ticket = {"engine": engine, "error": None, "thread": None, "per_bin": None}
+        try:
+            if self.partition_feature_name != "double anchor distance":
+                raise NotImplementedError
+            n_unc = engine.count_uncomputed()
+            if n_unc == 0:
+                raise NothingToSample()
+            iq1, iq3, new_n = self._quantile_ranks(n_unc, n_samples, self.n_partitions)
+            if new_n != n_samples:
+                print("Warning: n_samples has changed from %d to %d." % (n_samples, new_n))
+            n_samples = new_n
+            q1, q3 = engine.kth_uncomputed_dad([iq1, iq3])
+            sample_bins = np.hstack([-np.inf, np.linspace(q1, q3, self.n_partitions - 1), np.inf])
+            if n_samples == 0:
+                raise NothingToSample()
+            counts = engine.bin_counts(sample_bins)
+            bin_size, remainder = n_samples // self.n_partitions, n_samples % self.n_partitions
+            want = np.array([bin_size + (nbin < remainder) for nbin in range(self.n_partitions)], dtype=np.int64)
+            seed = random_seed + self.loop_num
+            ticket.update(n_samples=n_samples, sample_bins=sample_bins)
+
+            def draw():
+                try:
+                    if 0 <= seed < 2 ** 32:
+                        ticket["per_bin"] = _native.legacy_choice_ranks(seed, counts, want)
+                    else:  # outside the legacy int-seed range NumPy raises; keep its behaviour
+                        np.random.seed(seed)
+                        ticket["per_bin"] = [np.arange(c) if c < w else np.random.permutation(int(c))[:w]
+                                             for c, w in zip(counts, want)]
+                except BaseException as err:  # noqa: BLE001 -- re-raised in finish_device
+                    ticket["error"] = err
+
+            ticket["thread"] = threading.Thread(target=draw)
+            ticket["thread"].start()
+        except BaseException as err:  # noqa: BLE001
+            ticket["error"] = err
+        return ticket
+
+    def finish_device(self, ticket):
+        if ticket["thread"] is not None:
+            ticket["thread"].join()
+        if ticket["error"] is not None:
+            raise ticket["error"]
+        engine, n_samples, sample_bins = ticket["engine"], ticket["n_samples"], ticket["sample_bins"]
         bin_of, ranks = [], []
-        for nbin, r in enumerate(per_bin):
+        for nbin, r in enumerate(ticket["per_bin"]):
             if len(r) < 2:
                 self.loop_num += 1
                 raise Exception("Some sampler bins contain too few samples")

@@ -177,6 +177,12 @@ int annchor_set_labels(annchor_ctx *ctx, const int64_t *labels);
 int annchor_select_candidates(annchor_ctx *ctx, int32_t n_neighbors, int32_t nmin, const double *errs,
                               const int64_t *err_ptr, int32_t nlabels, int64_t n_refine,
                               int32_t lookahead, int64_t *n_cand, int64_t *n_next);
+/* Clear not_computed_mask for the selected candidates ahead of their refinement
+ * (annchor.py:473 does it after the metric calls).  Lets the next iteration's sampling
+ * statistics (which depend on the mask and dad only, samplers.py:119-140) be taken, and the
+ * host-side draw be made, while the refinement kernel runs.  Idempotent with
+ * annchor_refine_candidates / annchor_set_refined. */
+int annchor_mark_candidates(annchor_ctx *ctx);
 /* Evaluate the metric on the selected candidates and write back
  * (annchor.py:467-473). */
 int annchor_refine_candidates(annchor_ctx *ctx);
