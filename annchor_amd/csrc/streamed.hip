@@ -39,6 +39,14 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// LDS hand-over between lanes of ONE wavefront (a wave's LDS instructions execute in order)
+__device__ __forceinline__ void wave_fence_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 struct StreamState {
     // local shard (this context's rows), all device memory owned by the context
     DevBuf X;        // float [n_local][dim]      (copy of the caller's rows)
@@ -434,7 +442,7 @@ template <int DIM, int KMAX> struct KnnShared {
     float Bs[ST_SLAB][DIM + 1];
     float rsJ[ST_SLAB];
     float cand_d[ST_T][ST_SLAB];
-    int32_t cand_c[ST_T][ST_SLAB];
+    uint8_t cand_c[ST_T][ST_SLAB];   // column inside the slab
     float list_d[ST_T][KMAX];
     int32_t list_c[ST_T][KMAX];
     float thr[ST_T];
@@ -448,15 +456,22 @@ template <int DIM, int KMAX> struct KnnShared {
     int processed;
 };
 
+// One column tile against the workgroup's row tile.  Rows [32 w, 32 w + 32) belong to wave w
+// for the whole kernel -- operand registers, thresholds, candidate slots and result lists --
+// so everything after the dot products is wave-private and needs no workgroup barrier:
+//   slab s:  [barrier] stage registers -> LDS  [barrier]  global loads of slab s+1 in flight
+//            MFMA block of slab s, with the threshold test of slab s-1's accumulators issued
+//            between the MFMAs (VALU work in the shadow of the matrix pipe)
+//            merge of slab s-1's survivors into the wave's row lists
+// The two barriers only hand the single LDS operand buffer from its readers to its writers.
 template <int DIM, int KMAX>
 __device__ __forceinline__ void knn_process_tile(KnnShared<DIM, KMAX> &sh, const KnnArgs &a, int J, const float (&areg)[DIM / 2],
                                                  const float (&ri)[16], int rowbase_wave, int64_t grow0, int K)
 {
     const int lane = threadIdx.x & 63;
-    // register staging of the next 32-column slab: the global loads are issued before the
-    // MFMA block of the current slab and land in LDS after it, so only the first slab of a
-    // tile exposes memory latency
     constexpr int NLD = ST_SLAB * DIM / 4 / ST_THREADS;   // float4 loads per thread per slab
+    constexpr int NSLAB = ST_T / ST_SLAB;
+    constexpr int MF = DIM / 32;                           // MFMAs per accumulator row group (16 groups)
     float4 stage[NLD];
     float stage_r = 0.f;
     auto slab_load = [&](int slab) {
@@ -469,49 +484,19 @@ __device__ __forceinline__ void knn_process_tile(KnnShared<DIM, KMAX> &sh, const
         }
         if (threadIdx.x < ST_SLAB) stage_r = a.rs[c0 + threadIdx.x];
     };
-    slab_load(0);
-    for (int slab = 0; slab < ST_T / ST_SLAB; ++slab) {
-        const int64_t col0 = (int64_t)J * ST_T + slab * ST_SLAB;
-        __syncthreads();  // previous slab fully consumed (operands, candidates merged)
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int q = u * ST_THREADS + threadIdx.x;
-            const int colr = q / (DIM / 4), k4 = (q % (DIM / 4)) * 4;
-            sh.Bs[colr][k4] = stage[u].x; sh.Bs[colr][k4 + 1] = stage[u].y; sh.Bs[colr][k4 + 2] = stage[u].z; sh.Bs[colr][k4 + 3] = stage[u].w;
-        }
-        if (threadIdx.x < ST_SLAB) sh.rsJ[threadIdx.x] = stage_r;
-        __syncthreads();
-        if (slab + 1 < ST_T / ST_SLAB) slab_load(slab + 1);
-        // ---- 32x32 block of dot products per wave: DIM/2 MFMAs of K = 2
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float *bp = &sh.Bs[lane & 31][lane >> 5];
-#pragma unroll
-        for (int s = 0; s < DIM / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s], bp[2 * s], acc, 0, 0, 0);
-        // ---- thresholds: C layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-        const int col = lane & 31;
-        const float rj = sh.rsJ[col];
-        const int64_t jglob = col0 + col;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rowl = rowbase_wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const float d2 = fmaxf(ri[r] + rj - 2.f * acc[r], 0.f);
-            if (d2 < sh.thr[rowl] && jglob != grow0 + rowl) {
-                const int slot = atomicAdd(&sh.cnt[rowl], 1);
-                sh.cand_d[rowl][slot] = d2;
-                sh.cand_c[rowl][slot] = (int32_t)jglob;
-            }
-        }
-        __syncthreads();
-        // ---- merge survivors into the sorted per-row lists (one thread per row)
-        if (threadIdx.x < ST_T) {
-            const int row = threadIdx.x;
+    const int col = lane & 31;
+    const int rowq = rowbase_wave + 4 * (lane >> 5);   // C layout: row = rowq + (r & 3) + 8 (r >> 2), col = lane & 31
+    const bool self_tile = (int64_t)J * ST_T == grow0;
+    // merge of a slab's survivors into the sorted per-row lists: lane l < 32 owns row 32 w + l
+    auto merge = [&](int64_t col0) {
+        wave_fence_lds();
+        if (lane < 32) {
+            const int row = rowbase_wave + lane;
             const int nc = sh.cnt[row];
             if (nc) {
                 for (int q = 0; q < nc; ++q) {
                     const float d = sh.cand_d[row][q];
-                    const int32_t cc = sh.cand_c[row][q];
+                    const int32_t cc = (int32_t)(col0 + sh.cand_c[row][q]);
                     // insertion by (d, col); list is padded with +inf
                     if (d < sh.list_d[row][K - 1] || (d == sh.list_d[row][K - 1] && cc < sh.list_c[row][K - 1])) {
                         int p = K - 1;
@@ -528,7 +513,117 @@ __device__ __forceinline__ void knn_process_tile(KnnShared<DIM, KMAX> &sh, const
                 sh.thr[row] = sh.list_d[row][K - 1];
             }
         }
+        wave_fence_lds();
+    };
+    f32x16 acc_prev;
+    float rj_prev = 0.f;
+    slab_load(0);
+    for (int slab = 0; slab < NSLAB; ++slab) {
+        __syncthreads();  // every wave is done reading the previous slab's operands
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int q = u * ST_THREADS + threadIdx.x;
+            const int colr = q / (DIM / 4), k4 = (q % (DIM / 4)) * 4;
+            sh.Bs[colr][k4] = stage[u].x; sh.Bs[colr][k4 + 1] = stage[u].y; sh.Bs[colr][k4 + 2] = stage[u].z; sh.Bs[colr][k4 + 3] = stage[u].w;
+        }
+        if (threadIdx.x < ST_SLAB) sh.rsJ[threadIdx.x] = stage_r;
+        __syncthreads();
+        if (slab + 1 < NSLAB) slab_load(slab + 1);
+        const float rj = sh.rsJ[col];
+        // ---- 32x32 block of dot products per wave: DIM/2 MFMAs of K = 2, the previous slab's
+        // threshold tests issued in their shadow (row group g after the g-th bundle of MFMAs)
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float *bp = &sh.Bs[col][lane >> 5];
+        // operands of bundle g+1 and the thresholds of the lane's 16 rows are requested ahead of
+        // use: nothing in the MFMA stream waits for an LDS round trip
+        float thr_r[16];
+        if (slab > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(&sh.thr[rowq + 8 * q]);
+                thr_r[4 * q] = t4.x; thr_r[4 * q + 1] = t4.y; thr_r[4 * q + 2] = t4.z; thr_r[4 * q + 3] = t4.w;
+            }
+        }
+        float breg[2][MF];
+#pragma unroll
+        for (int u = 0; u < MF; ++u) breg[0][u] = bp[2 * u];
+        // Straight-line MFMA stream; in the shadow of bundle g the previous slab's accumulator
+        // row g is turned into a distance and compared with its row threshold.  Only the
+        // outcome bit is kept: survivors are rare once the lists have warmed up, and they are
+        // inserted after the stream (one branch per slab instead of one per row).
+        uint32_t pass = 0;
+        float d2r[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            if (g + 1 < 16) {
+#pragma unroll
+                for (int u = 0; u < MF; ++u) breg[(g + 1) & 1][u] = bp[2 * ((g + 1) * MF + u)];
+            }
+#pragma unroll
+            for (int u = 0; u < MF; ++u)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[g * MF + u], breg[g & 1][u], acc, 0, 0, 0);
+            if (slab > 0) {
+                d2r[g] = fmaxf(ri[g] + rj_prev - 2.f * acc_prev[g], 0.f);
+                pass |= (d2r[g] < thr_r[g] ? 1u : 0u) << g;
+            }
+        }
+        if (slab > 0 && pass) {
+            if (self_tile) {   // a point is not its own neighbour
+                const int dcol = (slab - 1) * ST_SLAB + col - rowq;   // row offset inside the lane's row set that equals its column
+                if (dcol >= 0 && dcol < 32 && (dcol & 4) == 0) pass &= ~(1u << ((dcol & 3) + 4 * (dcol >> 3)));
+            }
+            while (pass) {
+                const int g = __builtin_ctz(pass);
+                pass &= pass - 1;
+                const int rowl = rowq + (g & 3) + 8 * (g >> 2);
+                float d2 = d2r[0];
+#pragma unroll
+                for (int t = 1; t < 16; ++t) d2 = g == t ? d2r[t] : d2;
+                const int slot = atomicAdd(&sh.cnt[rowl], 1);
+                sh.cand_d[rowl][slot] = d2;
+                sh.cand_c[rowl][slot] = (uint8_t)col;
+            }
+        }
+        if (slab > 0) merge((int64_t)J * ST_T + (slab - 1) * ST_SLAB);
+        acc_prev = acc;
+        rj_prev = rj;
     }
+    // last slab: nothing left to hide it behind
+    {
+        uint32_t pass = 0;
+        float d2r[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(&sh.thr[rowq + 8 * q]);
+            const float tq[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int g = 4 * q + e;
+                d2r[g] = fmaxf(ri[g] + rj_prev - 2.f * acc_prev[g], 0.f);
+                pass |= (d2r[g] < tq[e] ? 1u : 0u) << g;
+            }
+        }
+        if (pass) {
+            if (self_tile) {
+                const int dcol = (NSLAB - 1) * ST_SLAB + col - rowq;
+                if (dcol >= 0 && dcol < 32 && (dcol & 4) == 0) pass &= ~(1u << ((dcol & 3) + 4 * (dcol >> 3)));
+            }
+            while (pass) {
+                const int g = __builtin_ctz(pass);
+                pass &= pass - 1;
+                const int rowl = rowq + (g & 3) + 8 * (g >> 2);
+                float d2 = d2r[0];
+#pragma unroll
+                for (int t = 1; t < 16; ++t) d2 = g == t ? d2r[t] : d2;
+                const int slot = atomicAdd(&sh.cnt[rowl], 1);
+                sh.cand_d[rowl][slot] = d2;
+                sh.cand_c[rowl][slot] = (uint8_t)col;
+            }
+        }
+    }
+    merge((int64_t)J * ST_T + (NSLAB - 1) * ST_SLAB);
     __syncthreads();
     // worst k-th squared distance of the row tile (padding rows have thr = -1)
     if (threadIdx.x == 0) sh.thrmax_bits = 0;
@@ -538,7 +633,7 @@ __device__ __forceinline__ void knn_process_tile(KnnShared<DIM, KMAX> &sh, const
     __syncthreads();
 }
 
-template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS) void k_st_knn(KnnArgs a)
+template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 128 ? 2 : 1)) void k_st_knn(KnnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KnnShared<DIM, KMAX> &sh = *reinterpret_cast<KnnShared<DIM, KMAX> *>(smem);
