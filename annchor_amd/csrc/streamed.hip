@@ -451,9 +451,8 @@ template <int DIM, int KMAX> struct KnnShared {
     float surv_lb[ST_SURV];   // rank key (mid-point bound)
     float surv_vb[ST_SURV];   // valid interval lower bound
     int32_t surv_j[ST_SURV];
-    unsigned int thrmax_bits;
+    float wave_thr[ST_THREADS / 64];
     int nsurv;
-    int processed;
 };
 
 // One column tile against the workgroup's row tile.  Rows [32 w, 32 w + 32) belong to wave w
@@ -464,18 +463,28 @@ template <int DIM, int KMAX> struct KnnShared {
 //            between the MFMAs (VALU work in the shadow of the matrix pipe)
 //            merge of slab s-1's survivors into the wave's row lists
 // The two barriers only hand the single LDS operand buffer from its readers to its writers.
+// Register staging of one 32-column slab; survives from one tile to the next so that the
+// first slab of the next tile is already in flight while the current tile finishes.
+template <int DIM> struct SlabStage {
+    float4 v[ST_SLAB * DIM / 4 / ST_THREADS];
+    float r;
+    int J;   // tile whose slab 0 is held (-1: none)
+};
+
+// Returns the worst k-th squared distance over the row tile after this column tile.
 template <int DIM, int KMAX>
-__device__ __forceinline__ void knn_process_tile(KnnShared<DIM, KMAX> &sh, const KnnArgs &a, int J, const float (&areg)[DIM / 2],
-                                                 const float (&ri)[16], int rowbase_wave, int64_t grow0, int K)
+__device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, const KnnArgs &a, int J, int Jnext, SlabStage<DIM> &st,
+                                                  const float (&areg)[DIM / 2], const float (&ri)[16], int rowbase_wave,
+                                                  int64_t grow0, int K)
 {
     const int lane = threadIdx.x & 63;
     constexpr int NLD = ST_SLAB * DIM / 4 / ST_THREADS;   // float4 loads per thread per slab
     constexpr int NSLAB = ST_T / ST_SLAB;
     constexpr int MF = DIM / 32;                           // MFMAs per accumulator row group (16 groups)
-    float4 stage[NLD];
-    float stage_r = 0.f;
-    auto slab_load = [&](int slab) {
-        const int64_t c0 = (int64_t)J * ST_T + slab * ST_SLAB;
+    float4 (&stage)[NLD] = st.v;
+    float &stage_r = st.r;
+    auto slab_load = [&](int Jl, int slab) {
+        const int64_t c0 = (int64_t)Jl * ST_T + slab * ST_SLAB;
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int q = u * ST_THREADS + threadIdx.x;
@@ -517,9 +526,11 @@ __device__ __forceinline__ void knn_process_tile(KnnShared<DIM, KMAX> &sh, const
     };
     f32x16 acc_prev;
     float rj_prev = 0.f;
-    slab_load(0);
+    if (st.J != J) slab_load(J, 0);   // not prefetched by the previous tile
     for (int slab = 0; slab < NSLAB; ++slab) {
-        __syncthreads();  // every wave is done reading the previous slab's operands
+        // every wave is done reading the previous slab's operands (slab 0: the caller's last
+        // barrier -- tile end or candidate scan -- already guarantees it)
+        if (slab > 0) __syncthreads();
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int q = u * ST_THREADS + threadIdx.x;
@@ -528,7 +539,8 @@ __device__ __forceinline__ void knn_process_tile(KnnShared<DIM, KMAX> &sh, const
         }
         if (threadIdx.x < ST_SLAB) sh.rsJ[threadIdx.x] = stage_r;
         __syncthreads();
-        if (slab + 1 < NSLAB) slab_load(slab + 1);
+        if (slab + 1 < NSLAB) slab_load(J, slab + 1);
+        else if (Jnext >= 0) slab_load(Jnext, 0);   // speculative: the next ranked tile is almost never pruned
         const float rj = sh.rsJ[col];
         // ---- 32x32 block of dot products per wave: DIM/2 MFMAs of K = 2, the previous slab's
         // threshold tests issued in their shadow (row group g after the g-th bundle of MFMAs)
@@ -624,13 +636,15 @@ __device__ __forceinline__ void knn_process_tile(KnnShared<DIM, KMAX> &sh, const
         }
     }
     merge((int64_t)J * ST_T + (NSLAB - 1) * ST_SLAB);
+    st.J = Jnext;
+    // worst k-th squared distance of the row tile (padding rows have thr = -1): wave maxima,
+    // one barrier (which is also the operand-buffer hand-over for the next tile)
+    float t = lane < 32 ? sh.thr[rowbase_wave + lane] : -1.f;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) t = fmaxf(t, __shfl_xor(t, off));
+    if (lane == 0) sh.wave_thr[threadIdx.x >> 6] = t;
     __syncthreads();
-    // worst k-th squared distance of the row tile (padding rows have thr = -1)
-    if (threadIdx.x == 0) sh.thrmax_bits = 0;
-    __syncthreads();
-    if (threadIdx.x < ST_T && sh.thr[threadIdx.x] >= 0.f) atomicMax(&sh.thrmax_bits, __float_as_uint(sh.thr[threadIdx.x]));
-    if (threadIdx.x == 0) sh.processed += 1;
-    __syncthreads();
+    return fmaxf(fmaxf(sh.wave_thr[0], sh.wave_thr[1]), fmaxf(sh.wave_thr[2], sh.wave_thr[3]));
 }
 
 template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 128 ? 2 : 1)) void k_st_knn(KnnArgs a)
@@ -671,11 +685,16 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
         sh.hiI[threadIdx.x] = a.hi[(size_t)threadIdx.x * a.nt_all + I];
         sh.midI[threadIdx.x] = a.mid[(size_t)threadIdx.x * a.nt_all + I];
     }
-    if (threadIdx.x == 0) { sh.nsurv = 0; sh.processed = 0; sh.thrmax_bits = 0x7f800000u; }
+    if (threadIdx.x == 0) sh.nsurv = 0;
+    float thrmax = INFINITY;   // worst k-th squared distance of the row tile (uniform)
+    int processed = 0;         // column tiles evaluated so far (uniform)
+    SlabStage<DIM> st;
+    st.J = -1;
     __syncthreads();
 
     // ---- phase A: the row tile against itself (gives every row k finite candidates)
-    knn_process_tile<DIM, KMAX>(sh, a, I, areg, ri, wave * 32, grow0, K);
+    thrmax = knn_process_tile<DIM, KMAX>(sh, a, I, -1, st, areg, ri, wave * 32, grow0, K);
+    ++processed;
 
     // ---- phase B: all other column tiles.  A tile is ELIGIBLE while its interval bound lb
     // (a valid lower bound of every pair distance) is below the worst k-th distance of the
@@ -703,7 +722,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
                 }
                 const bool after_done = lbc > done_key || (lbc == done_key && J > done_j);
                 const bool before_cut = lbc < cut_key || (lbc == cut_key && J < cut_j);
-                if (lb * lb < __uint_as_float(sh.thrmax_bits) && after_done && before_cut && lbc < INFINITY) {
+                if (lb * lb < thrmax && after_done && before_cut && lbc < INFINITY) {
                     const int slot = atomicAdd(&sh.nsurv, 1);
                     sh.surv_lb[slot] = lbc;   // cannot overflow: compacted below before 256 more can arrive
                     sh.surv_vb[slot] = lb;
@@ -749,17 +768,21 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
         if (ns > ST_KEEP && truncated) ns = ST_KEEP;
         if (ns == 0) break;
         for (int q = 0; q < ns; ++q) {
-            if (sh.processed >= a.max_tiles) break;
+            if (processed >= a.max_tiles) break;
             const int J = sh.surv_j[q];
             const float lb = sh.surv_vb[q];  // re-check against the current, tighter threshold
-            if (lb * lb < __uint_as_float(sh.thrmax_bits)) knn_process_tile<DIM, KMAX>(sh, a, J, areg, ri, wave * 32, grow0, K);
+            if (lb * lb < thrmax) {
+                const int Jn = (q + 1 < ns && processed + 1 < a.max_tiles) ? sh.surv_j[q + 1] : -1;
+                thrmax = knn_process_tile<DIM, KMAX>(sh, a, J, Jn, st, areg, ri, wave * 32, grow0, K);
+                ++processed;
+            }
         }
         done_key = sh.surv_lb[ns - 1];
         done_j = sh.surv_j[ns - 1];
         __syncthreads();
         if (threadIdx.x == 0) sh.nsurv = 0;
         __syncthreads();
-        if (sh.processed >= a.max_tiles) break;
+        if (processed >= a.max_tiles) break;
         if (ns < ST_KEEP && !truncated) break;   // the scan saw every eligible tile
     }
     __syncthreads();
@@ -769,7 +792,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
         a.out_d2[((size_t)bt * ST_T + row) * K + e] = sh.list_d[row][e];
         a.out_col[((size_t)bt * ST_T + row) * K + e] = sh.list_c[row][e];
     }
-    if (threadIdx.x == 0) atomicAdd(a.evals, (unsigned long long)sh.processed);
+    if (threadIdx.x == 0) atomicAdd(a.evals, (unsigned long long)processed);
 }
 
 // exact float32 distances of the selected neighbours + final per-row ordering
