@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libannchor_hip.so")
+LIB_PATH = os.environ.get("ANNCHOR_HIP_LIB", os.path.join(_HERE, "libannchor_hip.so"))   # override: profiling builds
 
 # field ids (include/annchor_hip.h)
 F_D, F_A, F_SID, F_IJS, F_I_PTR, F_I_IDX, F_FEATURES, F_NCM, F_RA, F_LABELS, F_THRESH, F_PROB, F_CAND, F_NEXT, F_DAD = range(1, 16)

@@ -39,6 +39,14 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef ST_PROFILE
+#define ST_PROF_DECL long long pf_t = clock64(); long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define ST_PROF(i) { const long long pf_n = clock64(); pf[i] += pf_n - pf_t; pf_t = pf_n; }
+#else
+#define ST_PROF_DECL
+#define ST_PROF(i)
+#endif
+
 // LDS hand-over between lanes of ONE wavefront (a wave's LDS instructions execute in order)
 __device__ __forceinline__ void wave_fence_lds()
 {
@@ -59,6 +67,7 @@ struct StreamState {
     DevBuf runmin, red_val, red_idx;
     DevBuf D;        // float [na][n_local]       distances to anchors (f32)
     DevBuf out_d2, out_col;
+    DevBuf scr_key, scr_lb;   // float [tile_count][nt_all]: per-row-tile rank keys / bounds of all column tiles
     DevBuf evals;
     int64_t n_local = 0, n_pad = 0, base = 0;
     int dim = 0, dimp = 0, na = 0, nt = 0;
@@ -435,7 +444,9 @@ struct KnnArgs {
     int max_tiles;        // column-tile budget per row tile
     float *out_d2;        // [tile_count*128][K]
     int32_t *out_col;     // [tile_count*128][K]   global ordered column index
+    float *scr_key, *scr_lb;   // [tile_count][nt_all] per-row-tile rank keys / valid bounds of every column tile
     unsigned long long *evals;
+    unsigned long long *prof;   // ST_PROFILE builds only: per-phase cycle sums (8 counters)
 };
 
 template <int DIM, int KMAX> struct KnnShared {
@@ -453,6 +464,8 @@ template <int DIM, int KMAX> struct KnnShared {
     int32_t surv_j[ST_SURV];
     float wave_thr[ST_THREADS / 64];
     int nsurv;
+    int sel_bin;
+    uint32_t sel_before;
 };
 
 // One column tile against the workgroup's row tile.  Rows [32 w, 32 w + 32) belong to wave w
@@ -475,8 +488,12 @@ template <int DIM> struct SlabStage {
 template <int DIM, int KMAX>
 __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, const KnnArgs &a, int J, int Jnext, SlabStage<DIM> &st,
                                                   const float (&areg)[DIM / 2], const float (&ri)[16], int rowbase_wave,
-                                                  int64_t grow0, int K)
+                                                  int64_t grow0, int K, long long *pf_ext)
 {
+#ifdef ST_PROFILE
+    long long pf_t = clock64();
+    long long *pf = pf_ext;
+#endif
     const int lane = threadIdx.x & 63;
     constexpr int NLD = ST_SLAB * DIM / 4 / ST_THREADS;   // float4 loads per thread per slab
     constexpr int NSLAB = ST_T / ST_SLAB;
@@ -531,6 +548,7 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
         // every wave is done reading the previous slab's operands (slab 0: the caller's last
         // barrier -- tile end or candidate scan -- already guarantees it)
         if (slab > 0) __syncthreads();
+        ST_PROF(0)
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int q = u * ST_THREADS + threadIdx.x;
@@ -538,7 +556,9 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
             sh.Bs[colr][k4] = stage[u].x; sh.Bs[colr][k4 + 1] = stage[u].y; sh.Bs[colr][k4 + 2] = stage[u].z; sh.Bs[colr][k4 + 3] = stage[u].w;
         }
         if (threadIdx.x < ST_SLAB) sh.rsJ[threadIdx.x] = stage_r;
+        ST_PROF(1)
         __syncthreads();
+        ST_PROF(2)
         if (slab + 1 < NSLAB) slab_load(J, slab + 1);
         else if (Jnext >= 0) slab_load(Jnext, 0);   // speculative: the next ranked tile is almost never pruned
         const float rj = sh.rsJ[col];
@@ -581,6 +601,7 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
                 pass |= (d2r[g] < thr_r[g] ? 1u : 0u) << g;
             }
         }
+        ST_PROF(3)
         if (slab > 0 && pass) {
             if (self_tile) {   // a point is not its own neighbour
                 const int dcol = (slab - 1) * ST_SLAB + col - rowq;   // row offset inside the lane's row set that equals its column
@@ -598,7 +619,9 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
                 sh.cand_c[rowl][slot] = (uint8_t)col;
             }
         }
+        ST_PROF(4)
         if (slab > 0) merge((int64_t)J * ST_T + (slab - 1) * ST_SLAB);
+        ST_PROF(5)
         acc_prev = acc;
         rj_prev = rj;
     }
@@ -644,6 +667,7 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
     for (int off = 16; off > 0; off >>= 1) t = fmaxf(t, __shfl_xor(t, off));
     if (lane == 0) sh.wave_thr[threadIdx.x >> 6] = t;
     __syncthreads();
+    ST_PROF(6)
     return fmaxf(fmaxf(sh.wave_thr[0], sh.wave_thr[1]), fmaxf(sh.wave_thr[2], sh.wave_thr[3]));
 }
 
@@ -690,10 +714,15 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
     int processed = 0;         // column tiles evaluated so far (uniform)
     SlabStage<DIM> st;
     st.J = -1;
+    long long *pf_ptr = nullptr;
+    ST_PROF_DECL
+#ifdef ST_PROFILE
+    pf_ptr = pf;
+#endif
     __syncthreads();
 
     // ---- phase A: the row tile against itself (gives every row k finite candidates)
-    thrmax = knn_process_tile<DIM, KMAX>(sh, a, I, -1, st, areg, ri, wave * 32, grow0, K);
+    thrmax = knn_process_tile<DIM, KMAX>(sh, a, I, -1, st, areg, ri, wave * 32, grow0, K, pf_ptr);
     ++processed;
 
     // ---- phase B: all other column tiles.  A tile is ELIGIBLE while its interval bound lb
@@ -702,88 +731,146 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
     // anchor-distance vectors (the anchors embed the data; this is the tile analogue of
     // ranking pairs by a distance predicted from anchor features, annchor.py:345-380).  Rounds: scan all tiles keeping the ST_KEEP best-ranked not yet considered,
     // evaluate them in rank order, repeat until nothing is eligible or the budget is spent.
-    float done_key = -1.f;   // (done_key, done_j): rank key of the last tile already considered
-    int done_j = -1;
+    // Implementation: (1) once per row tile, the rank key and the valid bound of every column
+    // tile go to a scratch row in global memory (two floats per tile; at N = 8M that is 62 500
+    // tiles, far more than LDS holds); (2) each round selects the next ST_KEEP tiles in
+    // (key, J) order among the still eligible ones with a 3-level radix selection on the key
+    // bits (12 + 12 + 8; non-negative floats order like their bit patterns), collects them and
+    // sorts them once.  A round costs four sweeps over the scratch row and one 1024-entry
+    // bitonic sort, independent of how the keys are distributed.
+    float *skey = a.scr_key + (size_t)bt * a.nt_all;
+    float *slb = a.scr_lb + (size_t)bt * a.nt_all;
+    for (int J = threadIdx.x; J < a.nt_all; J += ST_THREADS) {
+        float lb = 0.f, lbc = 0.f;
+        for (int an = 0; an < a.na; ++an) {
+            const float lj = a.lo[(size_t)an * a.nt_all + J], hj = a.hi[(size_t)an * a.nt_all + J];
+            const float gap = fmaxf(sh.loI[an] - hj, lj - sh.hiI[an]);
+            // slack for the float32 rounding of D (bounds must stay valid lower bounds)
+            lb = fmaxf(lb, gap - 4e-6f * (fabsf(hj) + fabsf(sh.hiI[an])));
+            const float dm = a.mid[(size_t)an * a.nt_all + J] - sh.midI[an];
+            lbc += dm * dm;   // rank key: squared L2 distance between the tiles' mean anchor vectors
+        }
+        skey[J] = (J == I || !(lbc < INFINITY)) ? INFINITY : lbc;   // +inf: never a candidate
+        slb[J] = lb;
+    }
+    __syncthreads();   // block-scope visibility of the scratch row (same CU)
+    uint32_t *hist = reinterpret_cast<uint32_t *>(&sh.cand_d[0][0]);   // 4096 bins; cand_d is idle between tiles
+    static_assert(sizeof(sh.cand_d) >= 4096 * sizeof(uint32_t), "histogram does not fit");
+    uint32_t done_bits = 0;   // (done_bits, done_j): key bits / index of the last tile already considered
+    int done_j = -1;          // (nothing considered yet: every key is > (0, -1))
     for (;;) {
-        float cut_key = INFINITY;  // keys at or beyond (cut_key, cut_j) are dropped in this round
-        int cut_j = 0x7fffffff;
-        bool truncated = false;
-        for (int base = 0; base < a.nt_all; base += ST_THREADS) {
-            const int J = base + threadIdx.x;
-            if (J < a.nt_all && J != I) {
-                float lb = 0.f, lbc = 0.f;
-                for (int an = 0; an < a.na; ++an) {
-                    const float lj = a.lo[(size_t)an * a.nt_all + J], hj = a.hi[(size_t)an * a.nt_all + J];
-                    const float gap = fmaxf(sh.loI[an] - hj, lj - sh.hiI[an]);
-                    // slack for the float32 rounding of D (bounds must stay valid lower bounds)
-                    lb = fmaxf(lb, gap - 4e-6f * (fabsf(hj) + fabsf(sh.hiI[an])));
-                    const float dm = a.mid[(size_t)an * a.nt_all + J] - sh.midI[an];
-                    lbc += dm * dm;   // rank key: squared L2 distance between the tiles' mean anchor vectors
-                }
-                const bool after_done = lbc > done_key || (lbc == done_key && J > done_j);
-                const bool before_cut = lbc < cut_key || (lbc == cut_key && J < cut_j);
-                if (lb * lb < thrmax && after_done && before_cut && lbc < INFINITY) {
-                    const int slot = atomicAdd(&sh.nsurv, 1);
-                    sh.surv_lb[slot] = lbc;   // cannot overflow: compacted below before 256 more can arrive
-                    sh.surv_vb[slot] = lb;
-                    sh.surv_j[slot] = J;
-                }
+        // ---- selection: bits of the ST_KEEP-th smallest remaining key
+        uint32_t prefix = 0;       // key bits fixed so far (high part)
+        uint32_t want = ST_KEEP;   // rank still to be located inside the current prefix class
+        bool all = false;          // fewer than ST_KEEP candidates remain: take them all
+        for (int level = 0; level < 3 && !all; ++level) {
+            const int shift = level == 0 ? 20 : level == 1 ? 8 : 0;
+            const int nbins = level == 2 ? 256 : 4096;
+            const uint32_t pmask = level == 0 ? 0u : level == 1 ? 0xfff00000u : 0xffffff00u;
+            for (int q = threadIdx.x; q < nbins; q += ST_THREADS) hist[q] = 0;
+            __syncthreads();
+            for (int J = threadIdx.x; J < a.nt_all; J += ST_THREADS) {
+                const uint32_t kb = __float_as_uint(skey[J]);
+                const float lb = slb[J];
+                const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
+                if (kb < 0x7f800000u && after_done && lb * lb < thrmax && (kb & pmask) == prefix)
+                    atomicAdd(&hist[(kb >> shift) & (nbins - 1)], 1u);
             }
             __syncthreads();
-            const bool last = base + ST_THREADS >= a.nt_all;
-            const int ns = sh.nsurv;
-            if (ns > 0 && (last || ns > ST_SURV - ST_THREADS)) {
-                // sort by (rank key, J): bitonic over ST_SURV slots
-                for (int q = threadIdx.x; q < ST_SURV; q += ST_THREADS)
-                    if (q >= ns) { sh.surv_lb[q] = INFINITY; sh.surv_j[q] = 0x7fffffff; }
-                __syncthreads();
-                for (int k2 = 2; k2 <= ST_SURV; k2 <<= 1)
-                    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-                        for (int q = threadIdx.x; q < ST_SURV; q += ST_THREADS) {
-                            const int p = q ^ j2;
-                            if (p > q) {
-                                const bool up = (q & k2) == 0;
-                                const float lq = sh.surv_lb[q], lp = sh.surv_lb[p];
-                                const int jq = sh.surv_j[q], jp = sh.surv_j[p];
-                                const bool gt = lq > lp || (lq == lp && jq > jp);
-                                if (gt == up) {
-                                    sh.surv_lb[q] = lp; sh.surv_lb[p] = lq; sh.surv_j[q] = jp; sh.surv_j[p] = jq;
-                                    const float t = sh.surv_vb[q]; sh.surv_vb[q] = sh.surv_vb[p]; sh.surv_vb[p] = t;
-                                }
-                            }
-                        }
-                        __syncthreads();
-                    }
-                if (!last && ns > ST_KEEP) {
-                    cut_key = sh.surv_lb[ST_KEEP - 1];
-                    cut_j = sh.surv_j[ST_KEEP - 1] + 1;   // keep entries up to and including slot ST_KEEP-1
-                    truncated = true;
-                    __syncthreads();
-                    if (threadIdx.x == 0) sh.nsurv = ST_KEEP;
-                    __syncthreads();
-                }
+            // first bin whose cumulative count reaches `want`: thread t owns bins [per t, per (t+1));
+            // exclusive scan of the per-thread sums (wave shuffles + 4 wave totals), then the
+            // one thread whose range holds the crossing walks its own bins
+            const int per = nbins / ST_THREADS;
+            uint32_t mine = 0;
+            for (int q = 0; q < per; ++q) mine += hist[threadIdx.x * per + q];
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off);
+                if (lane >= off) incl += up;
+            }
+            uint32_t *wtot = reinterpret_cast<uint32_t *>(&sh.surv_lb[0]);   // 4 wave totals (surv_lb is idle here)
+            if (threadIdx.x == 0) sh.sel_bin = -1;
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            uint32_t before = incl - mine;
+            for (int w2 = 0; w2 < wave; ++w2) before += wtot[w2];
+            if (before < want && before + mine >= want) {
+                uint32_t acc = before;
+                int q = threadIdx.x * per;
+                for (;; ++q) { if (acc + hist[q] >= want) break; acc += hist[q]; }
+                sh.sel_bin = q;
+                sh.sel_before = acc;
+            }
+            __syncthreads();
+            if (sh.sel_bin < 0) all = true;
+            else { prefix |= (uint32_t)sh.sel_bin << shift; want -= sh.sel_before; }
+            __syncthreads();
+        }
+        const uint32_t cut_bits = all ? 0x7f7fffffu : prefix;   // take keys <= cut (ties resolved by the sort below)
+        // ---- collect (at most ST_SURV; more than ST_SURV - ST_KEEP ties on one key value would be dropped)
+        if (threadIdx.x == 0) sh.nsurv = 0;
+        __syncthreads();
+        for (int J = threadIdx.x; J < a.nt_all; J += ST_THREADS) {
+            const uint32_t kb = __float_as_uint(skey[J]);
+            const float lb = slb[J];
+            const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
+            if (kb < 0x7f800000u && after_done && lb * lb < thrmax && kb <= cut_bits) {
+                const int slot = atomicAdd(&sh.nsurv, 1);
+                if (slot < ST_SURV) { sh.surv_lb[slot] = __uint_as_float(kb); sh.surv_vb[slot] = lb; sh.surv_j[slot] = J; }
             }
         }
-        int ns = sh.nsurv;
-        if (ns > ST_KEEP && truncated) ns = ST_KEEP;
+        __syncthreads();
+        int ns = min(sh.nsurv, ST_SURV);
         if (ns == 0) break;
+        {   // sort by (rank key, J): bitonic over ST_SURV slots
+            for (int q = threadIdx.x; q < ST_SURV; q += ST_THREADS)
+                if (q >= ns) { sh.surv_lb[q] = INFINITY; sh.surv_j[q] = 0x7fffffff; }
+            __syncthreads();
+            for (int k2 = 2; k2 <= ST_SURV; k2 <<= 1)
+                for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                    for (int q = threadIdx.x; q < ST_SURV; q += ST_THREADS) {
+                        const int p2 = q ^ j2;
+                        if (p2 > q) {
+                            const bool up = (q & k2) == 0;
+                            const float lq = sh.surv_lb[q], lp = sh.surv_lb[p2];
+                            const int jq = sh.surv_j[q], jp = sh.surv_j[p2];
+                            const bool gt = lq > lp || (lq == lp && jq > jp);
+                            if (gt == up) {
+                                sh.surv_lb[q] = lp; sh.surv_lb[p2] = lq; sh.surv_j[q] = jp; sh.surv_j[p2] = jq;
+                                const float t = sh.surv_vb[q]; sh.surv_vb[q] = sh.surv_vb[p2]; sh.surv_vb[p2] = t;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+        }
+        const bool more = !all;          // the selection was cut at ST_KEEP: later tiles remain
+        if (ns > ST_KEEP && more) ns = ST_KEEP;
+        const uint32_t round_last_bits = __float_as_uint(sh.surv_lb[ns - 1]);
+        const int round_last_j = sh.surv_j[ns - 1];
+        __syncthreads();   // hist (cand_d) and the partial sums (surv_lb) are idle again: tiles may run
         for (int q = 0; q < ns; ++q) {
             if (processed >= a.max_tiles) break;
             const int J = sh.surv_j[q];
             const float lb = sh.surv_vb[q];  // re-check against the current, tighter threshold
             if (lb * lb < thrmax) {
                 const int Jn = (q + 1 < ns && processed + 1 < a.max_tiles) ? sh.surv_j[q + 1] : -1;
-                thrmax = knn_process_tile<DIM, KMAX>(sh, a, J, Jn, st, areg, ri, wave * 32, grow0, K);
+#ifdef ST_PROFILE
+                pf[7] += clock64() - pf_t;
+#endif
+                thrmax = knn_process_tile<DIM, KMAX>(sh, a, J, Jn, st, areg, ri, wave * 32, grow0, K, pf_ptr);
                 ++processed;
+#ifdef ST_PROFILE
+                pf_t = clock64();
+#endif
             }
         }
-        done_key = sh.surv_lb[ns - 1];
-        done_j = sh.surv_j[ns - 1];
-        __syncthreads();
-        if (threadIdx.x == 0) sh.nsurv = 0;
+        done_bits = round_last_bits;
+        done_j = round_last_j;
         __syncthreads();
         if (processed >= a.max_tiles) break;
-        if (ns < ST_KEEP && !truncated) break;   // the scan saw every eligible tile
+        if (!more) break;   // the selection saw every eligible tile
     }
     __syncthreads();
     // ---- write the lists
@@ -793,6 +880,11 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
         a.out_col[((size_t)bt * ST_T + row) * K + e] = sh.list_c[row][e];
     }
     if (threadIdx.x == 0) atomicAdd(a.evals, (unsigned long long)processed);
+#ifdef ST_PROFILE
+    pf[7] += clock64() - pf_t;
+    if (lane == 0 && a.prof)
+        for (int i = 0; i < 8; ++i) atomicAdd(a.prof + i, (unsigned long long)pf[i]);
+#endif
 }
 
 // exact float32 distances of the selected neighbours + final per-row ordering
@@ -881,7 +973,17 @@ extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void
     double mt = p_work >= 1.0 ? (double)nt_all : std::ceil(p_work * (double)nt_all);
     a.max_tiles = (int)std::max(1.0, std::min(mt, (double)nt_all));
     a.out_d2 = s->out_d2.as<float>(); a.out_col = s->out_col.as<int32_t>();
+    ANN_TRY(sreserve(c, s->scr_key, sizeof(float) * (size_t)tile_count * (size_t)nt_all));
+    ANN_TRY(sreserve(c, s->scr_lb, sizeof(float) * (size_t)tile_count * (size_t)nt_all));
+    a.scr_key = s->scr_key.as<float>(); a.scr_lb = s->scr_lb.as<float>();
     a.evals = s->evals.as<unsigned long long>();
+    a.prof = nullptr;
+#ifdef ST_PROFILE
+    static unsigned long long *d_prof = nullptr;
+    if (!d_prof) (void)hipMalloc(&d_prof, 64);
+    (void)hipMemsetAsync(d_prof, 0, 64, c->stream);
+    a.prof = d_prof;
+#endif
     ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
     {
         // algorithmic flops are data dependent (tiles that survive the bound): reported by the caller from tile_evals
@@ -922,6 +1024,17 @@ extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void
             ng_dist[r * k + 1 + e] = (double)hd[(size_t)r * K + e];
         }
     }
+#ifdef ST_PROFILE
+    {
+        unsigned long long hp[8];
+        ANN_TRY(ann_d2h(c, hp, a.prof, 64));
+        static const char *names[8] = {"barrier before stash", "stash (incl. global-load wait)", "barrier after stash",
+                                       "MFMA stream + thresholds", "survivor inserts", "merge", "tile end", "candidate scan + rest"};
+        double tot = 0;
+        for (int i = 0; i < 8; ++i) tot += (double)hp[i];
+        for (int i = 0; i < 8; ++i) fprintf(stderr, "[st-prof] %-32s %6.2f %%\n", names[i], 100.0 * (double)hp[i] / tot);
+    }
+#endif
     if (tile_evals) {
         unsigned long long ev = 0;
         ANN_TRY(ann_d2h(c, &ev, s->evals.p, 8));
