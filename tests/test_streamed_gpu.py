@@ -69,6 +69,21 @@ def test_anchors_follow_the_reference_picker():
     assert np.array_equal(sa.A, A)
 
 
+def test_exact_with_several_selection_rounds():
+    """More column tiles (547) than one candidate-selection round takes (512): the radix selection's
+    cut, the (key, tile) continuation across rounds and the second round's tiles are all needed for
+    the exact result."""
+    from annchor_amd.streamed import StreamedAnnchor
+
+    n, k = 70000, 10
+    X = latent(n, 32)
+    sa = StreamedAnnchor(X, n_anchors=8, n_neighbors=k, p_work=1.0).fit()
+    rows = np.random.default_rng(3).choice(n, 400, replace=False)
+    bi, bd = brute(X, rows, k)
+    np.testing.assert_allclose(sa.neighbor_graph[1][rows], bd, rtol=1e-5, atol=1e-6)
+    assert sa.tile_evals <= 547 * 547
+
+
 def test_budgeted_recall():
     from annchor_amd import compare_neighbor_graphs
     from annchor_amd.streamed import StreamedAnnchor
