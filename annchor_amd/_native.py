@@ -366,15 +366,18 @@ class Engine:
         names = ("Xs", "rs", "perm", "lo", "hi", "mid")
         return {k: p.value for k, p in zip(names, ptrs)}, n_pad.value, nt.value, dimp.value
 
-    def stream_knn(self, ptrs, n_all, nt_all, n_anchors, dim_padded, tile_begin, tile_count, k, p_work):
-        rows = tile_count * 128
-        row_ids = np.zeros(rows, dtype=np.int64)
-        idx = np.zeros((rows, k), dtype=np.int64)
-        dist = np.zeros((rows, k), dtype=np.float64)
+    def stream_knn(self, ptrs, n_all, nt_all, n_anchors, dim_padded, tile_begin, tile_count, k, p_work, n_local=None):
+        """n_local given: graph rows come back in the bound shard's own row order ([n_local, k],
+        row_ids is None); otherwise in tile order with row_ids (global id per row, -1 = padding)."""
+        rows = tile_count * 128 if n_local is None else int(n_local)
+        row_ids = np.zeros(rows, dtype=np.int64) if n_local is None else None
+        idx = np.empty((rows, k), dtype=np.int64)
+        dist = np.empty((rows, k), dtype=np.float64)
         ev = _i64()
         self._chk(self.lib.annchor_stream_knn(self.h, ptrs["Xs"], ptrs["rs"], ptrs["perm"], ptrs["lo"], ptrs["hi"], ptrs["mid"], int(n_all),
                                               int(nt_all), int(n_anchors), int(dim_padded), int(tile_begin), int(tile_count),
-                                              int(k), float(p_work), _ptr(row_ids), _ptr(idx), _ptr(dist), ctypes.byref(ev)))
+                                              int(k), float(p_work), _ptr(row_ids) if row_ids is not None else None, _ptr(idx),
+                                              _ptr(dist), ctypes.byref(ev)))
         return row_ids, idx, dist, ev.value
 
     def device_alloc(self, nbytes):

@@ -67,6 +67,7 @@ struct StreamState {
     DevBuf runmin, red_val, red_idx;
     DevBuf D;        // float [na][n_local]       distances to anchors (f32)
     DevBuf out_d2, out_col;
+    DevBuf emit_idx, emit_dist;   // int64 / double [n_local][k]: graph rows in shard order
     DevBuf scr_key, scr_lb;   // float [tile_count][nt_all]: per-row-tile rank keys / bounds of all column tiles
     DevBuf evals;
     int64_t n_local = 0, n_pad = 0, base = 0;
@@ -91,7 +92,8 @@ void ann_stream_release(annchor_ctx *c)
         if (g_states[i].first == c) {
             StreamState *s = g_states[i].second;
             DevBuf *bufs[] = {&s->X, &s->keys, &s->keys2, &s->vals, &s->vals2, &s->cubtmp, &s->Xs, &s->rs, &s->perm, &s->lo,
-                              &s->hi, &s->mid, &s->avec, &s->runmin, &s->red_val, &s->red_idx, &s->D, &s->out_d2, &s->out_col, &s->evals};
+                              &s->hi, &s->mid, &s->avec, &s->runmin, &s->red_val, &s->red_idx, &s->D, &s->out_d2, &s->out_col, &s->evals,
+                              &s->scr_key, &s->scr_lb, &s->emit_idx, &s->emit_dist};
             for (DevBuf *b : bufs)
                 if (b->p && !b->in_arena) (void)hipFree(b->p);
             delete s;
@@ -928,6 +930,25 @@ __global__ void k_st_rowsort(int64_t rows, int K, int64_t *__restrict__ oidx, fl
     }
 }
 
+// final graph rows in the shard's own row order: row perm[r] - base gets (self, 0.0) followed by
+// the K ordered neighbours, as int64 / float64 (the reference's neighbor_graph dtypes)
+__global__ void k_st_emit(const int64_t *__restrict__ perm, int64_t row_begin, int64_t rows, int K, int64_t base, int64_t n_local,
+                          const int64_t *__restrict__ idx, const float *__restrict__ dist, int64_t *__restrict__ oidx,
+                          double *__restrict__ odist)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = K + 1;
+    if (t >= rows * k) return;
+    const int64_t r = t / k;
+    const int e = (int)(t - r * k);
+    const int64_t g = perm[row_begin + r];
+    if (g < 0) return;   // padding row
+    const int64_t loc = g - base;
+    if (loc < 0 || loc >= n_local) return;
+    oidx[loc * k + e] = e == 0 ? g : idx[r * K + e - 1];
+    odist[loc * k + e] = e == 0 ? 0.0 : (double)dist[r * K + e - 1];
+}
+
 template <int DIM, int KMAX> static int launch_knn2(annchor_ctx *c, const KnnArgs &a)
 {
     const size_t lds = sizeof(KnnShared<DIM, KMAX>);
@@ -949,12 +970,15 @@ template <int DIM> static int launch_knn(annchor_ctx *c, const KnnArgs &a)
 // (concatenated over ranks for multi-GPU runs).  Outputs are HOST arrays:
 // ng_idx int64 [rows, k] (global ids), ng_dist float64 [rows, k], in tile order;
 // row_ids int64 [rows] gives the global id of each output row (-1 = padding row).
+// With row_ids == NULL the outputs are instead [n_local, k] arrays in the bound shard's own row
+// order (row = global id - global_base of annchor_stream_bind), written by a device kernel and
+// copied out in one piece -- no host-side reordering.
 extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void *rs_all, const void *perm_all,
                                   const void *lo_all, const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors,
                                   int32_t dim_padded, int32_t tile_begin, int32_t tile_count, int32_t k, double p_work,
                                   int64_t *row_ids, int64_t *ng_idx, double *ng_dist, int64_t *tile_evals)
 {
-    if (!c || !Xs_all || !rs_all || !perm_all || !lo_all || !hi_all || !mid_all || !row_ids || !ng_idx || !ng_dist) return ANNCHOR_EINVAL;
+    if (!c || !Xs_all || !rs_all || !perm_all || !lo_all || !hi_all || !mid_all || !ng_idx || !ng_dist) return ANNCHOR_EINVAL;
     ANN_REQUIRE(c, k >= 2 && k - 1 <= ST_KMAX, ANNCHOR_ELIMIT, "streamed form supports 2 <= n_neighbors <= %d", ST_KMAX + 1);
     ANN_REQUIRE(c, n_all == (int64_t)nt_all * ST_T && tile_begin >= 0 && tile_begin + tile_count <= nt_all, ANNCHOR_EINVAL,
                 "tile range out of bounds");
@@ -1011,17 +1035,29 @@ extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void
         k_st_rowsort<<<ann_blocks(rows, 256), 256, 0, c->stream>>>(rows, K, d_idx, d_dist);
     }
     ANN_CHECK_HIP(c, hipGetLastError());
-    std::vector<int64_t> hidx((size_t)rows * K);
-    std::vector<float> hd((size_t)rows * K);
-    ANN_TRY(ann_d2h(c, hidx.data(), d_idx, sizeof(int64_t) * hidx.size()));
-    ANN_TRY(ann_d2h(c, hd.data(), d_dist, sizeof(float) * hd.size()));
-    ANN_TRY(ann_d2h(c, row_ids, (const int64_t *)perm_all + (size_t)tile_begin * ST_T, sizeof(int64_t) * (size_t)rows));
-    for (int64_t r = 0; r < rows; ++r) {
-        ng_idx[r * k] = row_ids[r];
-        ng_dist[r * k] = 0.0;
-        for (int e = 0; e < K; ++e) {
-            ng_idx[r * k + 1 + e] = hidx[(size_t)r * K + e];
-            ng_dist[r * k + 1 + e] = (double)hd[(size_t)r * K + e];
+    if (!row_ids) {
+        const int64_t n_local = s->n_local;
+        ANN_TRY(sreserve(c, s->emit_idx, sizeof(int64_t) * (size_t)n_local * k));
+        ANN_TRY(sreserve(c, s->emit_dist, sizeof(double) * (size_t)n_local * k));
+        k_st_emit<<<ann_blocks(rows * k, 256), 256, 0, c->stream>>>((const int64_t *)perm_all, (int64_t)tile_begin * ST_T, rows, K, s->base,
+                                                                   n_local, d_idx, d_dist, s->emit_idx.as<int64_t>(),
+                                                                   s->emit_dist.as<double>());
+        ANN_CHECK_HIP(c, hipGetLastError());
+        ANN_TRY(ann_d2h(c, ng_idx, s->emit_idx.p, sizeof(int64_t) * (size_t)n_local * k));
+        ANN_TRY(ann_d2h(c, ng_dist, s->emit_dist.p, sizeof(double) * (size_t)n_local * k));
+    } else {
+        std::vector<int64_t> hidx((size_t)rows * K);
+        std::vector<float> hd((size_t)rows * K);
+        ANN_TRY(ann_d2h(c, hidx.data(), d_idx, sizeof(int64_t) * hidx.size()));
+        ANN_TRY(ann_d2h(c, hd.data(), d_dist, sizeof(float) * hd.size()));
+        ANN_TRY(ann_d2h(c, row_ids, (const int64_t *)perm_all + (size_t)tile_begin * ST_T, sizeof(int64_t) * (size_t)rows));
+        for (int64_t r = 0; r < rows; ++r) {
+            ng_idx[r * k] = row_ids[r];
+            ng_dist[r * k] = 0.0;
+            for (int e = 0; e < K; ++e) {
+                ng_idx[r * k + 1 + e] = hidx[(size_t)r * K + e];
+                ng_dist[r * k + 1 + e] = (double)hd[(size_t)r * K + e];
+            }
         }
     }
 #ifdef ST_PROFILE

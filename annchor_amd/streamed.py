@@ -207,15 +207,18 @@ class StreamedAnnchor:
         t3 = time.perf_counter()
         n_all, nt_all = n_pad * comm.world, nt * comm.world
         row_ids, idx, dist, tile_evals = eng.stream_knn(ptrs, n_all, nt_all, self.n_anchors, dimp, comm.rank * nt, nt,
-                                                        self.n_neighbors, self.p_work)
+                                                        self.n_neighbors, self.p_work, n_local=self.n_local)
         t4 = time.perf_counter()
         del keep
-        real = row_ids >= 0
-        loc = row_ids[real] - self.base
-        k = self.n_neighbors
-        ng_idx = np.zeros((self.n_local, k), dtype=np.int64)
-        ng_dist = np.zeros((self.n_local, k), dtype=np.float64)
-        ng_idx[loc], ng_dist[loc] = idx[real], dist[real]
+        if row_ids is None:   # rows already in this shard's order (emitted on the device)
+            ng_idx, ng_dist = idx, dist
+        else:                 # tile order + global row ids: reorder on the host
+            real = row_ids >= 0
+            loc = row_ids[real] - self.base
+            k = self.n_neighbors
+            ng_idx = np.zeros((self.n_local, k), dtype=np.int64)
+            ng_dist = np.zeros((self.n_local, k), dtype=np.float64)
+            ng_idx[loc], ng_dist[loc] = idx[real], dist[real]
         self.neighbor_graph = (ng_idx, ng_dist)
         self.tile_evals = int(tile_evals)
         self.evals += self.tile_evals * TILE * TILE

@@ -67,7 +67,7 @@ class FakeStreamEngine:
         ptrs = {k: self._alloc(v) for k, v in dict(Xs=Xs, rs=rs, perm=perm, lo=lo, hi=hi, mid=mid).items()}
         return ptrs, n_pad, nt, self.dim
 
-    def stream_knn(self, ptrs, n_all, nt_all, na, dimp, tile_begin, tile_count, k, p_work):
+    def stream_knn(self, ptrs, n_all, nt_all, na, dimp, tile_begin, tile_count, k, p_work, n_local=None):
         Xs = _view(ptrs["Xs"], (n_all, dimp), np.float32)
         perm = _view(ptrs["perm"], (n_all,), np.int64)
         rows = np.arange(tile_begin * TILE, (tile_begin + tile_count) * TILE)
