@@ -22,6 +22,7 @@ _FIELD_DTYPE = {
 }
 
 METRIC_LEVENSHTEIN, METRIC_EUCLIDEAN_F32, METRIC_EUCLIDEAN_F64, METRIC_WASSERSTEIN = 1, 2, 3, 4
+METRIC_COSINE_F32, METRIC_COSINE_F64 = 5, 6
 
 # every entry point declared in include/annchor_hip.h: name -> (restype, argtypes)
 _vp, _i32, _i64, _dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
@@ -36,6 +37,8 @@ _SIGNATURES = {
     "annchor_set_strings": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32]),
     "annchor_set_points_f32": (ctypes.c_int, [_vp, _vp, _i64, _i32]),
     "annchor_set_points_f64": (ctypes.c_int, [_vp, _vp, _i64, _i32]),
+    "annchor_set_points_cosine_f32": (ctypes.c_int, [_vp, _vp, _i64, _i32]),
+    "annchor_set_points_cosine_f64": (ctypes.c_int, [_vp, _vp, _i64, _i32]),
     "annchor_set_histograms": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "annchor_set_opaque": (ctypes.c_int, [_vp, _i64]),
     "annchor_metric_pairs": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
@@ -186,16 +189,18 @@ class Engine:
         self._chk(self.lib.annchor_set_strings(self.h, _ptr(codes), _ptr(offs), _ptr(lens), len(lens), int(alphabet)))
         self.nx, self.metric = len(lens), METRIC_LEVENSHTEIN
 
-    def set_points(self, X):
+    def set_points(self, X, cosine=False):
         X = np.asarray(X)
         if X.dtype == np.float32:
             X = _c(X, np.float32)
-            self._chk(self.lib.annchor_set_points_f32(self.h, _ptr(X), X.shape[0], X.shape[1]))
-            self.metric = METRIC_EUCLIDEAN_F32
+            fn = self.lib.annchor_set_points_cosine_f32 if cosine else self.lib.annchor_set_points_f32
+            self._chk(fn(self.h, _ptr(X), X.shape[0], X.shape[1]))
+            self.metric = METRIC_COSINE_F32 if cosine else METRIC_EUCLIDEAN_F32
         else:
             X = _c(X, np.float64)
-            self._chk(self.lib.annchor_set_points_f64(self.h, _ptr(X), X.shape[0], X.shape[1]))
-            self.metric = METRIC_EUCLIDEAN_F64
+            fn = self.lib.annchor_set_points_cosine_f64 if cosine else self.lib.annchor_set_points_f64
+            self._chk(fn(self.h, _ptr(X), X.shape[0], X.shape[1]))
+            self.metric = METRIC_COSINE_F64 if cosine else METRIC_EUCLIDEAN_F64
         self.nx = X.shape[0]
 
     def set_histograms(self, X, cost):

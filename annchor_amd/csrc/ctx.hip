@@ -312,6 +312,16 @@ extern "C" int annchor_set_points_f64(annchor_ctx *c, const double *X, int64_t n
     return set_points(c, X, nx, dim, sizeof(double), ANNCHOR_METRIC_EUCLIDEAN_F64);
 }
 
+extern "C" int annchor_set_points_cosine_f32(annchor_ctx *c, const float *X, int64_t nx, int32_t dim)
+{
+    return set_points(c, X, nx, dim, sizeof(float), ANNCHOR_METRIC_COSINE_F32);
+}
+
+extern "C" int annchor_set_points_cosine_f64(annchor_ctx *c, const double *X, int64_t nx, int32_t dim)
+{
+    return set_points(c, X, nx, dim, sizeof(double), ANNCHOR_METRIC_COSINE_F64);
+}
+
 extern "C" int annchor_set_histograms(annchor_ctx *c, const double *hist, int64_t nx, int32_t nbins,
                                       const double *cost)
 {
@@ -355,7 +365,9 @@ int ann_metric_launch(annchor_ctx *c, const PairSource &src, double *d_out, doub
     switch (c->metric) {
     case ANNCHOR_METRIC_LEVENSHTEIN: return ann_lev_launch(c, src, d_out, d_RA, d_ncm);
     case ANNCHOR_METRIC_EUCLIDEAN_F32:
-    case ANNCHOR_METRIC_EUCLIDEAN_F64: return ann_euclid_launch(c, src, d_out, d_RA, d_ncm);
+    case ANNCHOR_METRIC_EUCLIDEAN_F64:
+    case ANNCHOR_METRIC_COSINE_F32:
+    case ANNCHOR_METRIC_COSINE_F64: return ann_euclid_launch(c, src, d_out, d_RA, d_ncm);
     case ANNCHOR_METRIC_WASSERSTEIN: return ann_emd_launch(c, src, d_out, d_RA, d_ncm);
     default: ann_set_err(c, "no device metric bound to this context"); return ANNCHOR_EINVAL;
     }

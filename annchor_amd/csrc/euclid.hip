@@ -1,8 +1,9 @@
 // euclid.hip -- Euclidean distance over a pair list (the pair-list form of the path).
 //
 // Replaces, for f = euclidean (reference annchor/distances.py:8-13,
-// `np.linalg.norm(x - y)` in the dtype of X, stored into a float64 array), the
-// evaluator get_exact(f, X, IJ) of annchor/utils.py:110-177.
+// `np.linalg.norm(x - y)` in the dtype of X, stored into a float64 array) and f = cosine
+// (annchor/utils.py:14,67: scipy.spatial.distance.cosine), the evaluator
+// get_exact(f, X, IJ) of annchor/utils.py:110-177.
 //
 // A pair is a gather of two rows, so the kernel is gather/HBM bound: 16 lanes
 // cooperate on one pair with 16-byte loads when the row stride allows it, the
@@ -25,7 +26,7 @@ template <typename T> struct EuArgs {
     uint8_t *ncm;
 };
 
-template <typename T, int VEC> __global__ __launch_bounds__(256) void k_euclid(EuArgs<T> a)
+template <typename T, int VEC, bool COS> __global__ __launch_bounds__(256) void k_euclid(EuArgs<T> a)
 {
     const int sub = threadIdx.x & (EU_LPP - 1);
     const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / EU_LPP;
@@ -42,7 +43,11 @@ template <typename T, int VEC> __global__ __launch_bounds__(256) void k_euclid(E
         }
     }
     const T *xi = a.X + (size_t)i * a.dim, *xj = a.X + (size_t)j * a.dim;
-    double acc = 0;
+    double acc = 0, uu = 0, vv = 0;   // Euclidean: sum of squared differences; cosine: u.v, u.u, v.v
+    auto term = [&](double x, double y) {
+        if (COS) { acc += x * y; uu += x * x; vv += y * y; }
+        else { const double d = x - y; acc += d * d; }
+    };
     if (active) {
         if (VEC > 1) {
             struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
@@ -50,23 +55,35 @@ template <typename T, int VEC> __global__ __launch_bounds__(256) void k_euclid(E
             for (int k = sub; k < nv; k += EU_LPP) {
                 V u = reinterpret_cast<const V *>(xi)[k], w = reinterpret_cast<const V *>(xj)[k];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) { double d = (double)u.v[e] - (double)w.v[e]; acc += d * d; }
+                for (int e = 0; e < VEC; ++e) term((double)u.v[e], (double)w.v[e]);
             }
         } else {
-            for (int k = sub; k < a.dim; k += EU_LPP) { double d = (double)xi[k] - (double)xj[k]; acc += d * d; }
+            for (int k = sub; k < a.dim; k += EU_LPP) term((double)xi[k], (double)xj[k]);
         }
     }
 #pragma unroll
-    for (int off = EU_LPP / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, EU_LPP);
+    for (int off = EU_LPP / 2; off > 0; off >>= 1) {
+        acc += __shfl_xor(acc, off, EU_LPP);
+        if (COS) { uu += __shfl_xor(uu, off, EU_LPP); vv += __shfl_xor(vv, off, EU_LPP); }
+    }
     if (active && sub == 0) {
-        double d = sqrt(acc);
-        if (sizeof(T) == 4) d = (double)(float)d;
+        double d;
+        if (COS) {
+            // scipy.spatial.distance.cosine: the three dot products in the dtype of X, then
+            // 1 - uv / sqrt(uu * vv) in float64, clipped to [0, 2]
+            if (sizeof(T) == 4) { acc = (double)(float)acc; uu = (double)(float)uu; vv = (double)(float)vv; }
+            d = 1.0 - acc / sqrt(uu * vv);
+            d = fmin(fmax(d, 0.0), 2.0);
+        } else {
+            d = sqrt(acc);
+            if (sizeof(T) == 4) d = (double)(float)d;
+        }
         if (a.out) a.out[t] = d;
         if (a.RA) { a.RA[opos] = d; a.ncm[opos] = 0; }
     }
 }
 
-template <typename T> static int launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm)
+template <typename T, bool COS> static int launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm)
 {
     EuArgs<T> a;
     a.X = c->pts.as<T>();
@@ -75,9 +92,9 @@ template <typename T> static int launch(annchor_ctx *c, const PairSource &src, d
     a.out = d_out; a.RA = d_RA; a.ncm = d_ncm;
     const int vec = 16 / (int)sizeof(T);
     int blocks = ann_blocks(src.n * EU_LPP, 256);
-    ProfScope ps(c, "euclidean_pairs", (double)src.n * (2.0 * c->dim * sizeof(T) + 16));
-    if (c->dim % vec == 0) k_euclid<T, 16 / sizeof(T)><<<blocks, 256, 0, c->stream>>>(a);
-    else k_euclid<T, 1><<<blocks, 256, 0, c->stream>>>(a);
+    ProfScope ps(c, COS ? "cosine_pairs" : "euclidean_pairs", (double)src.n * (2.0 * c->dim * sizeof(T) + 16));
+    if (c->dim % vec == 0) k_euclid<T, 16 / sizeof(T), COS><<<blocks, 256, 0, c->stream>>>(a);
+    else k_euclid<T, 1, COS><<<blocks, 256, 0, c->stream>>>(a);
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
 }
@@ -85,6 +102,10 @@ template <typename T> static int launch(annchor_ctx *c, const PairSource &src, d
 int ann_euclid_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm)
 {
     if (src.n == 0) return ANNCHOR_OK;
-    if (c->metric == ANNCHOR_METRIC_EUCLIDEAN_F32) return launch<float>(c, src, d_out, d_RA, d_ncm);
-    return launch<double>(c, src, d_out, d_RA, d_ncm);
+    switch (c->metric) {
+    case ANNCHOR_METRIC_EUCLIDEAN_F32: return launch<float, false>(c, src, d_out, d_RA, d_ncm);
+    case ANNCHOR_METRIC_COSINE_F32: return launch<float, true>(c, src, d_out, d_RA, d_ncm);
+    case ANNCHOR_METRIC_COSINE_F64: return launch<double, true>(c, src, d_out, d_RA, d_ncm);
+    default: return launch<double, false>(c, src, d_out, d_RA, d_ncm);
+    }
 }

@@ -92,6 +92,21 @@ class _Euclidean(DeviceMetric):
         engine.set_points(X)
 
 
+class _Cosine(DeviceMetric):
+    """scipy.spatial.distance.cosine(x, y) = 1 - x.y / (|x| |y|), the dot products in the dtype of
+    X, clipped to [0, 2] (utils.py:14,67)."""
+
+    name = "cosine"
+
+    def bind(self, engine, X):
+        X = np.asarray(X)
+        if X.ndim == 1:
+            X = X[:, None]
+        if X.dtype != np.float32:
+            X = X.astype(np.float64)
+        engine.set_points(X, cosine=True)
+
+
 class Wasserstein(DeviceMetric):
     """kantorovich(x, y, cost=M): exact optimal transport between the normalised
     histograms restricted to their supports (utils.py:75-86)."""
@@ -107,3 +122,4 @@ class Wasserstein(DeviceMetric):
 
 levenshtein = _Levenshtein()
 euclidean = _Euclidean()
+cosine = _Cosine()

@@ -32,9 +32,7 @@ def get_function_from_input(func, func_kwargs):
             return distances.euclidean
         if func == "levenshtein":
             return distances.levenshtein
-        # 'cosine' (scipy.spatial.distance.cosine, utils.py:14,67) has no kernel yet: host metric
-        from scipy.spatial.distance import cosine
-        return cosine
+        return distances.cosine   # scipy.spatial.distance.cosine, utils.py:14,67
     if func_kwargs is None:
         return func
 

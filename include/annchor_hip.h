@@ -38,7 +38,8 @@ enum {
 };
 
 enum { ANNCHOR_METRIC_NONE = 0, ANNCHOR_METRIC_LEVENSHTEIN = 1, ANNCHOR_METRIC_EUCLIDEAN_F32 = 2,
-       ANNCHOR_METRIC_EUCLIDEAN_F64 = 3, ANNCHOR_METRIC_WASSERSTEIN = 4 };
+       ANNCHOR_METRIC_EUCLIDEAN_F64 = 3, ANNCHOR_METRIC_WASSERSTEIN = 4, ANNCHOR_METRIC_COSINE_F32 = 5,
+       ANNCHOR_METRIC_COSINE_F64 = 6 };
 
 /* fields for annchor_download / annchor_upload */
 enum {
@@ -79,6 +80,10 @@ int annchor_set_strings(annchor_ctx *ctx, const uint8_t *symbols, const int64_t 
                         const int32_t *lens, int64_t nx, int32_t alphabet);
 int annchor_set_points_f32(annchor_ctx *ctx, const float *X, int64_t nx, int32_t dim);
 int annchor_set_points_f64(annchor_ctx *ctx, const double *X, int64_t nx, int32_t dim);
+/* Same data, metric = cosine distance 1 - u.v / (|u| |v|), clipped to [0, 2]
+ * (annchor/utils.py:14,67 -> scipy.spatial.distance.cosine). */
+int annchor_set_points_cosine_f32(annchor_ctx *ctx, const float *X, int64_t nx, int32_t dim);
+int annchor_set_points_cosine_f64(annchor_ctx *ctx, const double *X, int64_t nx, int32_t dim);
 /* Wasserstein: hist float64 [nx, nbins], cost float64 [nbins, nbins]
  * (annchor/utils.py:75-86, func_kwargs['cost_matrix']). */
 int annchor_set_histograms(annchor_ctx *ctx, const double *hist, int64_t nx, int32_t nbins,

@@ -107,6 +107,37 @@ def test_levenshtein_kernel_variants_ragged(variant, monkeypatch):
     assert np.array_equal(eng.metric_pairs(few), want[:7])
 
 
+@pytest.mark.parametrize("dtype,dim", [(np.float32, 128), (np.float64, 64), (np.float64, 5)])
+def test_cosine_pairs_vs_scipy(dtype, dim):
+    """'cosine' (reference utils.py:14,67 -> scipy.spatial.distance.cosine).  No reference test pins
+    it: pinned here against scipy itself.  Tolerance: the three dot products are summed
+    in a different order than BLAS does -- 1e-12 absolute for float64 data, 2e-6 for float32 data
+    (dot products rounded to float32 as scipy's are)."""
+    from scipy.spatial.distance import cosine as sp_cosine
+
+    from annchor_amd import Annchor, BruteForce, _native
+    from annchor_amd.distances import cosine
+
+    rng = np.random.default_rng(11)
+    X = (rng.standard_normal((400, dim)) + 0.5).astype(dtype)
+    eng = _native.Engine(0)
+    cosine.bind(eng, X)
+    IJ = rng.integers(0, 400, (3000, 2))
+    IJ[:20, 1] = IJ[:20, 0]
+    got = eng.metric_pairs(IJ)
+    want = np.array([sp_cosine(X[i], X[j]) for i, j in IJ])
+    tol = 2e-6 if dtype == np.float32 else 1e-12
+    np.testing.assert_allclose(got, want, rtol=0, atol=tol)
+    assert np.all(got >= 0) and np.all(got <= 2)
+    # the whole pipeline runs on the device metric: exact graph by brute force, Annchor reports true distances
+    bf = BruteForce(X, "cosine").fit(n_neighbors=6)
+    ann = Annchor(X, "cosine", n_anchors=10, n_neighbors=6, n_samples=600, p_work=0.5).fit()
+    idx, dist = ann.neighbor_graph
+    for r in range(0, 400, 37):
+        np.testing.assert_allclose(dist[r, 1:], [sp_cosine(X[r], X[j]) for j in idx[r, 1:]], rtol=0, atol=tol)
+    assert np.all(bf.neighbor_graph[1][:, 0] <= tol)
+
+
 @pytest.mark.parametrize("dtype,dim", [(np.float32, 128), (np.float64, 3), (np.float32, 7), (np.float64, 64)])
 def test_euclidean_pairs_vs_oracle(dtype, dim):
     from annchor_amd import _native
