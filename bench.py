@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-euclid", action="store_true", help="skip the secondary row-sharded Euclidean workload")
     ap.add_argument("--euclid-rows", type=int, default=1_000_000, help="rows per GPU of the Euclidean workload")
+    ap.add_argument("--euclid-timeout", type=int, default=600, help="seconds before the secondary workload is abandoned")
     args = ap.parse_args()
 
     import torch
@@ -217,14 +218,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    euclid = None
-    if not args.no_euclid:
-        del anns[:args.warmup]
-        try:
-            euclid = euclid_run(world, rank, local, dist, args.euclid_rows, 2, 1, torch)
-        except Exception as e:  # the secondary workload must never cost the primary line
-            euclid = {"error": "%s: %s" % (type(e).__name__, e)}
-
+    out = None
     if rank == 0:
         ann = timed[-1]
         ms_per_step = elapsed / args.steps * 1e3
@@ -290,12 +284,42 @@ def main():
                 g = kernels[dom]
                 out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": g["alg_GBps"], "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": g["hbm_frac"], "traffic": None}
-        if euclid is not None:
-            out["euclid_row_sharded"] = euclid
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(X, cfg)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+
+    # ---- secondary workload (row-sharded Euclidean, collectives across ranks).  It must never cost
+    # the primary line: the line is complete at this point, and a watchdog thread emits it and ends
+    # the process if the secondary workload blocks (a failed rank would leave the others inside a
+    # collective forever).
+    if not args.no_euclid:
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["euclid_row_sharded"] = {"error": "timed out after %d s" % args.euclid_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.euclid_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        del anns[:args.warmup]
+        try:
+            euclid = euclid_run(world, rank, local, dist, args.euclid_rows, 2, 1, torch)
+        except Exception as e:
+            euclid = {"error": "%s: %s" % (type(e).__name__, e)}
+            if world > 1:   # the other ranks may be inside a collective: do not wait for them
+                dog.cancel()
+                if rank == 0:
+                    out["euclid_row_sharded"] = euclid
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+        dog.cancel()
+        if rank == 0:
+            out["euclid_row_sharded"] = euclid
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
