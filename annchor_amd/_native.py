@@ -415,7 +415,8 @@ class Engine:
 
     # ------------------------------------------------------------ profiling
     def prof_enable(self, on=True):
-        self._chk(self.lib.annchor_prof_enable(self.h, int(bool(on))))
+        """on: False/0 off, True/1 every kernel family, 2 the metric kernels only."""
+        self._chk(self.lib.annchor_prof_enable(self.h, int(on)))
 
     def prof_reset(self):
         self._chk(self.lib.annchor_prof_reset(self.h))

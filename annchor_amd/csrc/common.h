@@ -96,10 +96,20 @@ struct annchor_ctx {
 
     // ---- profiling
     bool prof_on = false;
+    int prof_mode = 0;             // 1: every kernel family, 2: metric kernels only (names ending in "_pairs")
+    std::vector<hipEvent_t> ev_pool;   // recycled profiling events
     std::vector<ProfEntry> prof;
     std::vector<PendingEvent> pending;
     hipEvent_t call_a = nullptr, call_b = nullptr;
     bool call_timed = false;
+    // pinned staging for small host transfers (a pageable hipMemcpy of a few bytes costs ~25 us on
+    // this stack, the pinned path ~13 us; small uploads need no synchronisation at all)
+    static constexpr int PIN_SLOTS = 8;
+    static constexpr size_t PIN_SLOT_BYTES = 64 * 1024;
+    unsigned char *pin = nullptr;            // PIN_SLOTS + 1 slots: ring for uploads, last one for downloads
+    hipEvent_t pin_ev[PIN_SLOTS] = {};
+    bool pin_busy[PIN_SLOTS] = {};
+    int pin_next = 0;
 };
 
 const char *ann_set_err(annchor_ctx *c, const char *fmt, ...);

@@ -1,5 +1,6 @@
 // ctx.hip -- context lifecycle, memory, data-set upload, state access, profiling.
 #include <cstdarg>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -57,6 +58,19 @@ int ann_arena_init(annchor_ctx *c, int64_t nx)
 int ann_h2d(annchor_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (bytes == 0) return ANNCHOR_OK;
+    if (c->pin && bytes <= annchor_ctx::PIN_SLOT_BYTES) {
+        // small upload: copy into a pinned ring slot, enqueue, return -- the caller's buffer is
+        // free again at once and the stream orders the copy before the kernels that follow
+        const int sl = c->pin_next;
+        c->pin_next = (sl + 1) % annchor_ctx::PIN_SLOTS;
+        if (c->pin_busy[sl]) ANN_CHECK_HIP(c, hipEventSynchronize(c->pin_ev[sl]));
+        unsigned char *slot = c->pin + (size_t)sl * annchor_ctx::PIN_SLOT_BYTES;
+        memcpy(slot, src, bytes);
+        ANN_CHECK_HIP(c, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
+        ANN_CHECK_HIP(c, hipEventRecord(c->pin_ev[sl], c->stream));
+        c->pin_busy[sl] = true;
+        return ANNCHOR_OK;
+    }
     ANN_CHECK_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));  // pageable host memory: do not retain the pointer
     return ANNCHOR_OK;
@@ -65,6 +79,13 @@ int ann_h2d(annchor_ctx *c, void *dst, const void *src, size_t bytes)
 int ann_d2h(annchor_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (bytes == 0) return ANNCHOR_OK;
+    if (c->pin && bytes <= annchor_ctx::PIN_SLOT_BYTES) {
+        unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
+        ANN_CHECK_HIP(c, hipMemcpyAsync(slot, src, bytes, hipMemcpyDeviceToHost, c->stream));
+        ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        memcpy(dst, slot, bytes);
+        return ANNCHOR_OK;
+    }
     ANN_CHECK_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     return ANNCHOR_OK;
@@ -87,8 +108,8 @@ static void prof_drain(annchor_ctx *c)
         float ms = 0;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess)
             c->prof[p.entry].ms += ms;
-        (void)hipEventDestroy(p.a);
-        (void)hipEventDestroy(p.b);
+        c->ev_pool.push_back(p.a);
+        c->ev_pool.push_back(p.b);
     }
     c->pending.clear();
 }
@@ -96,10 +117,18 @@ static void prof_drain(annchor_ctx *c)
 ProfScope::ProfScope(annchor_ctx *ctx, const char *name, double alg_bytes) : c(ctx)
 {
     if (!c->prof_on) return;
+    if (c->prof_mode == 2) {   // metric kernels only
+        const size_t n = strlen(name);
+        if (n < 6 || strcmp(name + n - 6, "_pairs") != 0) return;
+    }
     entry = ann_prof_entry(c, name);
     c->prof[entry].launches += 1;
     c->prof[entry].alg_bytes += alg_bytes;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { entry = -1; return; }
+    auto get = [&](hipEvent_t *e) {
+        if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); return true; }
+        return hipEventCreate(e) == hipSuccess;
+    };
+    if (!get(&a) || !get(&b)) { entry = -1; return; }
     (void)hipEventRecord(a, c->stream);
 }
 
@@ -115,6 +144,7 @@ extern "C" int annchor_prof_enable(annchor_ctx *c, int32_t on)
 {
     if (!c) return ANNCHOR_EINVAL;
     c->prof_on = on != 0;
+    c->prof_mode = on;
     return ANNCHOR_OK;
 }
 
@@ -169,6 +199,10 @@ extern "C" int annchor_create(int device, annchor_ctx **out)
     }
     (void)hipEventCreate(&c->call_a);
     (void)hipEventCreate(&c->call_b);
+    if (getenv("ANNCHOR_NO_PIN") ||
+        hipHostMalloc((void **)&c->pin, (annchor_ctx::PIN_SLOTS + 1) * annchor_ctx::PIN_SLOT_BYTES, hipHostMallocDefault) != hipSuccess)
+        c->pin = nullptr;   // fall back to pageable transfers
+    for (int i = 0; i < annchor_ctx::PIN_SLOTS; ++i) (void)hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming);
     *out = c;
     return ANNCHOR_OK;
 }
@@ -191,6 +225,10 @@ extern "C" void annchor_destroy(annchor_ctx *c)
     for (DevBuf *b : bufs)
         if (b->p && !b->in_arena) (void)hipFree(b->p);
     if (c->arena) (void)hipFree(c->arena);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < annchor_ctx::PIN_SLOTS; ++i)
+        if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
+    if (c->pin) (void)hipHostFree(c->pin);
     if (c->call_a) (void)hipEventDestroy(c->call_a);
     if (c->call_b) (void)hipEventDestroy(c->call_b);
     (void)hipStreamDestroy(c->stream);

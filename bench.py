@@ -196,8 +196,10 @@ def main():
         a.fit()
     timed = anns[args.warmup:]
     if not args.no_kernel_events:
+        # inside the timed region only the metric kernels (the roofline kernel) carry HIP events
+        # (38 events per fit); the table of all kernel families comes from untimed fits below
         for a in timed:
-            a._engine.prof_enable(True)
+            a._engine.prof_enable(2)
 
     def sync():
         torch.cuda.synchronize()
@@ -246,20 +248,32 @@ def main():
         out["recall_at_k"] = 1.0 - err / (k * len(X))
         out["evals"] = int(ann.evals)
         out["host_stage_ms"] = {s: round(v * 1e3, 3) for s, v in ann.timings.items()}
-        # ---- per-kernel device time (HIP events on the engine stream, timed region only)
+        # ---- per-kernel device time: the roofline kernel from the timed region (HIP events on the
+        # engine stream), every other kernel family from untimed fits of the same workload
         if not args.no_kernel_events:
             agg = {}
             for a in timed:
                 for name, e in a._engine.prof_get().items():
-                    g = agg.setdefault(name, dict(ms=0.0, launches=0, alg_bytes=0.0))
+                    g = agg.setdefault(name, dict(ms=0.0, launches=0, alg_bytes=0.0, fits=args.steps, timed=True))
+                    g["ms"] += e["ms"]; g["launches"] += e["launches"]; g["alg_bytes"] += e["alg_bytes"]
+            n_extra = 3
+            for _ in range(n_extra):
+                extra = Annchor(X, metric, func_kwargs=kwargs, device=local, **cfg)
+                extra._engine.prof_enable(1)
+                extra.fit()
+                for name, e in extra._engine.prof_get().items():
+                    if name in agg and agg[name]["timed"]:
+                        continue   # measured in the timed region
+                    g = agg.setdefault(name, dict(ms=0.0, launches=0, alg_bytes=0.0, fits=n_extra, timed=False))
                     g["ms"] += e["ms"]; g["launches"] += e["launches"]; g["alg_bytes"] += e["alg_bytes"]
             kernels = {}
-            for name, g in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            for name, g in sorted(agg.items(), key=lambda kv: -kv[1]["ms"] / max(1, kv[1]["fits"])):
                 if g["launches"] == 0:
                     continue
                 avg_ms = g["ms"] / g["launches"]
                 gbs = g["alg_bytes"] / g["launches"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-                kernels[name] = dict(ms_per_fit=round(g["ms"] / args.steps, 4), launches_per_fit=g["launches"] / args.steps,
+                kernels[name] = dict(ms_per_fit=round(g["ms"] / g["fits"], 4), launches_per_fit=g["launches"] / g["fits"],
+                                     timed_region=g["timed"],
                                      avg_launch_us=round(avg_ms * 1e3, 2), alg_GBps=round(gbs, 1),
                                      hbm_frac=round(gbs / HBM_PEAK_GBS, 4))
             out["kernels"] = kernels

@@ -248,7 +248,9 @@ int annchor_upload(annchor_ctx *ctx, int32_t field, const void *src, int64_t n_e
 
 /* ------------------------------------------------------------------ profiling
  * Per-kernel-family accumulated device time since the last reset (HIP events on
- * the stream): names[i] is a static string; returns the number of entries. */
+ * the stream): names[i] is a static string; returns the number of entries.
+ * on: 0 = off, 1 = every kernel family, 2 = the metric kernels only ("*_pairs"; cheap enough
+ * to leave on inside a timed region). */
 int annchor_prof_enable(annchor_ctx *ctx, int32_t on);
 int annchor_prof_reset(annchor_ctx *ctx);
 int annchor_prof_get(annchor_ctx *ctx, int32_t max_entries, const char **names, double *ms,
