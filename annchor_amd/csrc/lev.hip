@@ -483,23 +483,21 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
             return R == 1 ? launch_r<1>(c, a, src.n) : R == 2 ? launch_r<2>(c, a, src.n) : launch_r<4>(c, a, src.n);
         }
     }
-    // ANNCHOR_LEV_R=0: the two-columns-per-iteration kernel, one word per lane
-    static const int force_ilp = getenv("ANNCHOR_LEV_ILP") ? atoi(getenv("ANNCHOR_LEV_ILP")) : 0;
-    int ilp = force_ilp ? force_ilp : 1;
-    if ((size_t)a.wave_bytes * LEV_WAVES * ilp > 160 * 1024) ilp = 1;
-    size_t lds = (size_t)a.wave_bytes * LEV_WAVES * ilp;
+    // the two-columns-per-iteration kernel, one word per lane, one slot set per lane.  (The
+    // template's second slot set per lane -- two independent dependency chains -- measured
+    // slower: a wave already issues at the VALU's rate, tools/microbench/valu_peak.hip.)
+    const size_t lds = (size_t)a.wave_bytes * LEV_WAVES;
     ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "alphabet %d x length %d needs %zu B of LDS (> 160 KiB)", c->alphabet,
                 c->maxlen, lds);
-    const void *fn = ilp == 2 ? (const void *)k_lev<2> : (const void *)k_lev<1>;
-    if (lds > 64 * 1024) ANN_CHECK_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int64_t tasks = (src.n + (int64_t)a.P * ilp - 1) / ((int64_t)a.P * ilp);
+    if (lds > 64 * 1024)
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t tasks = (src.n + a.P - 1) / a.P;
     int64_t blocks = (tasks + LEV_WAVES - 1) / LEV_WAVES;
-    int max_blocks = c->prop.multiProcessorCount * 8;
+    const int max_blocks = c->prop.multiProcessorCount * 8;
     if (blocks > max_blocks) blocks = max_blocks;
     // algorithmic work: one byte per symbol of both strings is all that must be read
     ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
-    if (ilp == 2) k_lev<2><<<(int)blocks, LEV_THREADS, lds, c->stream>>>(a);
-    else k_lev<1><<<(int)blocks, LEV_THREADS, lds, c->stream>>>(a);
+    k_lev<1><<<(int)blocks, LEV_THREADS, lds, c->stream>>>(a);
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
 }
