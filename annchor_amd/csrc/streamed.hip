@@ -66,6 +66,7 @@ struct StreamState {
     DevBuf avec;     // float [dimp]              current anchor vector
     DevBuf runmin, red_val, red_idx;
     DevBuf D;        // float [na][n_local]       distances to anchors (f32)
+    DevBuf Dt;       // float [n_local][na padded to 4]  the same, point-major (ordering gathers)
     DevBuf out_d2, out_col;
     DevBuf emit_idx, emit_dist;   // int64 / double [n_local][k]: graph rows in shard order
     DevBuf scr_key, scr_lb;   // float [tile_count][nt_all]: per-row-tile rank keys / bounds of all column tiles
@@ -93,7 +94,7 @@ void ann_stream_release(annchor_ctx *c)
             StreamState *s = g_states[i].second;
             DevBuf *bufs[] = {&s->X, &s->keys, &s->keys2, &s->vals, &s->vals2, &s->cubtmp, &s->Xs, &s->rs, &s->perm, &s->lo,
                               &s->hi, &s->mid, &s->avec, &s->runmin, &s->red_val, &s->red_idx, &s->D, &s->out_d2, &s->out_col, &s->evals,
-                              &s->scr_key, &s->scr_lb, &s->emit_idx, &s->emit_dist};
+                              &s->scr_key, &s->scr_lb, &s->emit_idx, &s->emit_dist, &s->Dt};
             for (DevBuf *b : bufs)
                 if (b->p && !b->in_arena) (void)hipFree(b->p);
             delete s;
@@ -251,7 +252,19 @@ extern "C" int annchor_stream_get_row(annchor_ctx *c, int64_t local_idx, float *
 // tight [lo, hi] intervals, hence strong triangle bounds between tiles.
 __device__ __forceinline__ int st_seg_of(int64_t p, int64_t n, int level) { return (int)((p << level) / n); }
 
-__global__ __launch_bounds__(256) void k_st_spread(const float *__restrict__ D, const uint32_t *__restrict__ order, int64_t n,
+// point-major copy of the anchor distances: a point's whole anchor vector is one contiguous
+// (16-byte aligned) run, so the per-level gathers through `order` touch one or two cache lines
+// per point instead of one line per (point, anchor)
+__global__ void k_st_transpose_D(const float *__restrict__ D, int64_t n, int na, int nap, float *__restrict__ Dt)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * nap) return;
+    const int64_t p = t / nap;
+    const int a = (int)(t - p * nap);
+    Dt[t] = a < na ? D[(size_t)a * n + p] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_st_spread(const float *__restrict__ Dt, int nap, const uint32_t *__restrict__ order, int64_t n,
                                                   int na, int level, double *__restrict__ ssum, double *__restrict__ ssq)
 {
     // per (segment, anchor): sum and sum of squares of the anchor distances
@@ -260,8 +273,12 @@ __global__ __launch_bounds__(256) void k_st_spread(const float *__restrict__ D, 
     const int seg = ok ? st_seg_of(p, n, level) : -1;
     const int seg0 = __shfl(seg, 0), seg63 = __shfl(ok ? seg : seg0, 63);
     const uint32_t src = ok ? order[p] : 0;
+    const float4 *row = reinterpret_cast<const float4 *>(Dt + (size_t)src * nap);
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int a = 0; a < na; ++a) {
-        const double v = ok ? (double)D[(size_t)a * n + src] : 0.0;
+        if ((a & 3) == 0 && ok) q4 = row[a >> 2];
+        const float qv = (a & 3) == 0 ? q4.x : (a & 3) == 1 ? q4.y : (a & 3) == 2 ? q4.z : q4.w;
+        const double v = ok ? (double)qv : 0.0;
         if (seg0 == seg63 && seg0 >= 0) {  // whole wave inside one segment: reduce first
             double s1 = v, s2 = v * v;
 #pragma unroll
@@ -403,6 +420,9 @@ extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs
     double *ssum = s->red_val.as<double>(), *ssq = ssum + (size_t)max_seg * s->na;
     uint32_t *cur = s->vals.as<uint32_t>(), *nxt = s->vals2.as<uint32_t>();
     k_st_iota<<<ann_blocks(n, 256), 256, 0, c->stream>>>(cur, n);
+    const int nap = (s->na + 3) & ~3;
+    ANN_TRY(sreserve(c, s->Dt, sizeof(float) * (size_t)n * nap));
+    k_st_transpose_D<<<ann_blocks(n * nap, 256), 256, 0, c->stream>>>(s->D.as<float>(), n, s->na, nap, s->Dt.as<float>());
     size_t tmp_bytes = 0;
     ANN_CHECK_HIP(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, s->keys.as<unsigned long long>(),
                                                         s->keys2.as<unsigned long long>(), cur, nxt, (int)n, 0, 64, c->stream));
@@ -411,7 +431,7 @@ extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs
         const int nseg = 1 << level;
         ANN_CHECK_HIP(c, hipMemsetAsync(ssum, 0, sizeof(double) * (size_t)nseg * s->na, c->stream));
         ANN_CHECK_HIP(c, hipMemsetAsync(ssq, 0, sizeof(double) * (size_t)nseg * s->na, c->stream));
-        k_st_spread<<<ann_blocks(n, 256), 256, 0, c->stream>>>(s->D.as<float>(), cur, n, s->na, level, ssum, ssq);
+        k_st_spread<<<ann_blocks(n, 256), 256, 0, c->stream>>>(s->Dt.as<float>(), nap, cur, n, s->na, level, ssum, ssq);
         k_st_pick_coord<<<ann_blocks(nseg, 256), 256, 0, c->stream>>>(ssum, ssq, n, level, nseg, s->na, s->red_idx.as<int32_t>());
         k_st_level_keys<<<ann_blocks(n, 256), 256, 0, c->stream>>>(s->D.as<float>(), cur, n, level, s->red_idx.as<int32_t>(),
                                                                   s->keys.as<unsigned long long>());
