@@ -146,6 +146,17 @@ def pmc_traffic(kernel_prefix):
     return None
 
 
+def pmc_valu_busy():
+    """VALU-busy share of the Levenshtein kernels from the committed PMC pass (profiles/r01_pmc_lev.json,
+    tools/pmc_lev.sh): SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (kernel cycles x 1024 SIMDs)."""
+    try:
+        T = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_lev.json")))
+        return {k: round(v["SQ_ACTIVE_INST_VALU"] * 4 / (v["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
+                for k, v in T.items() if k.startswith("k_lev")}
+    except Exception:
+        return None
+
+
 def cpu_baseline(X, cfg):
     """The oracle (CPU restatement) timed on this box: one full fit() of the same
     workload (~10 s): C Levenshtein (Myers, OpenMP over all cores) + NumPy pipeline."""
@@ -291,8 +302,11 @@ def main():
                     # (both strings of every pair, once) / kernel time -- tiny by construction, see `note`
                     "hbm_view": {"bound": "hbm", "achieved": kernels[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": kernels[dom]["hbm_frac"]},
+                    "valu_busy_pmc": pmc_valu_busy(),
                     "note": "integer-ALU bound (string pool is 1 MB, cache resident): HBM fraction is not meaningful "
-                            "for this kernel; the HBM-bound pair-list kernels are listed under `kernels`",
+                            "for this kernel; the HBM-bound pair-list kernels are listed under `kernels`.  `peak` is the "
+                            "nominal 2-cycle SIMD-32 rate; these integer ops issue at ~4 cycles per wave instruction "
+                            "(tools/microbench/valu_peak.hip), and the PMC pass shows the refine kernel's VALU 96 % busy",
                 }
             else:
                 g = kernels[dom]
