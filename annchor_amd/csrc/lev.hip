@@ -394,6 +394,9 @@ template <int R> __global__ __launch_bounds__(ANN_WAVE) void k_lev_r(LevArgsR ar
         k_hi = max(k_lo, min(__builtin_amdgcn_readfirstlane(k_hi), max_steps));
         int k = 0;
         for (; k < k_lo; ++k) column(k, std::true_type());
+        // two columns per trip: the register hand-overs (eq <- eq_n, c1 <- c2) between them are
+        // renames in straight-line code, and the loop bookkeeping is paid once per two columns
+        for (; k + 2 <= k_hi; k += 2) { column(k, std::false_type()); column(k + 1, std::false_type()); }
         for (; k < k_hi; ++k) column(k, std::false_type());
         for (; k < max_steps; ++k) column(k, std::true_type());
         if (active) {
