@@ -474,13 +474,13 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
     const int force_r = env_r ? atoi(env_r) : -1;
     {
         const int W = (c->maxlen + 31) / 32;
-        // measured on MI355X (tools/lev_ab.py, strings of ~500 symbols): launches of a few
-        // thousand pairs (the anchor rounds: latency of one wave's column loop) are fastest with
-        // the two-columns-per-iteration kernel below, large launches (refine: throughput) with
-        // one word per lane and the lean per-column bookkeeping of k_lev_r; R = 2 / 4 cut
-        // instructions further but their tables leave < 2 waves per SIMD
+        // measured on MI355X (tools/lev_ab.py, strings of ~500 symbols): one word per lane with
+        // the lean per-column bookkeeping of k_lev_r wins for the small anchor-round launches
+        // (38 us vs 44 us for the two-columns-per-iteration kernel below) and for the large
+        // refine launches (420 us vs 600 us); R = 2 / 4 cut instructions further but their
+        // tables leave < 2 waves per SIMD.  ANNCHOR_LEV_R = 0 / 2 / 4 select the other variants.
         (void)W;
-        int R = force_r >= 0 ? force_r : (src.n >= 8192 ? 1 : 0);
+        int R = force_r >= 0 ? force_r : 1;
         if (R == 1 || R == 2 || R == 4) {
             ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
             return R == 1 ? launch_r<1>(c, a, src.n) : R == 2 ? launch_r<2>(c, a, src.n) : launch_r<4>(c, a, src.n);
