@@ -85,7 +85,7 @@ def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch):
             dist_mod.barrier()
         dt = time.perf_counter() - t0
         if dist_mod is not None:
-            tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            tt = torch.tensor([dt], device="cuda" if dist_mod.get_backend() == "nccl" else "cpu", dtype=torch.float64)
             dist_mod.all_reduce(tt, op=dist_mod.ReduceOp.MAX)
             dt = float(tt.item())
         if it >= warmup:
@@ -183,6 +183,9 @@ def main():
     ap.add_argument("--no-euclid", action="store_true", help="skip the secondary row-sharded Euclidean workload")
     ap.add_argument("--euclid-rows", type=int, default=1_000_000, help="rows per GPU of the Euclidean workload")
     ap.add_argument("--euclid-timeout", type=int, default=600, help="seconds before the secondary workload is abandoned")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank flow)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0 (implies --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -194,8 +197,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        if args.share_gpu:
+            args.backend, local = "gloo", 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
     from annchor_amd import Annchor, compare_neighbor_graphs
@@ -226,8 +234,9 @@ def main():
         a._engine.synchronize()
     sync()
     elapsed = time.perf_counter() - t0
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
     if dist is not None:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
