@@ -1,0 +1,32 @@
+"""bench.py prints ONE JSON line with the fields the driver and the judge read."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_line_has_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-euclid"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    b = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in b, key
+    assert b["n_gpus"] == 1 and b["steps"] == 2 and b["warmup"] == 1 and b["higher_is_better"] is True
+    assert b["value"] > 0 and abs(b["value"] - 1e3 / b["ms_per_step"]) / b["value"] < 1e-6
+    assert "workload" in b["config"] and "model" not in b["config"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in b["roofline"], key
+    assert abs(b["roofline"]["frac"] - b["roofline"]["achieved"] / b["roofline"]["peak"]) < 1e-9
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in b["cpu_baseline"], key
+    assert b["cpu_baseline"]["kind"] in ("port", "reference")
+    assert b["errors_vs_bruteforce"] <= 504   # no worse than the reference's own run
