@@ -1,0 +1,90 @@
+"""Property-based parity of the three metric kernels against the oracle's C restatements
+(hypothesis draws the shapes; every example is one batched launch through the C-ABI)."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from oracle import metrics as om
+
+pytestmark = pytest.mark.gpu
+SETTINGS = dict(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+
+
+@settings(**SETTINGS)
+@given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(2, 60), max_len=st.integers(0, 300), alpha=st.integers(1, 40),
+       variant=st.sampled_from(["0", "1", "2", "4"]))
+def test_levenshtein_kernel_equals_dp(seed, n, max_len, alpha, variant):
+    import os
+
+    from annchor_amd import _native
+    from annchor_amd.distances import levenshtein
+
+    rng = np.random.default_rng(seed)
+    letters = [chr(48 + a) for a in range(alpha)]
+    X = ["".join(rng.choice(letters, rng.integers(0, max_len + 1))) for _ in range(n)]
+    # related strings as well as unrelated ones
+    for t in range(0, n - 1, 3):
+        s = list(X[t])
+        for _ in range(rng.integers(0, 6)):
+            if s and rng.random() < 0.5:
+                s.pop(rng.integers(0, len(s)))
+            else:
+                s.insert(rng.integers(0, len(s) + 1), rng.choice(letters))
+        X[t + 1] = "".join(s)
+    os.environ["ANNCHOR_LEV_R"] = variant
+    try:
+        eng = _native.Engine(0)
+        levenshtein.bind(eng, X)
+        IJ = rng.integers(0, n, (200, 2))
+        got = eng.metric_pairs(IJ)
+    finally:
+        del os.environ["ANNCHOR_LEV_R"]
+    want = np.array([om.levenshtein(X[i], X[j], "dp") for i, j in IJ], dtype=np.float64)
+    assert np.array_equal(got, want)
+    # metric properties: identity, symmetry
+    sym = eng.metric_pairs(IJ[:, ::-1].copy())
+    assert np.array_equal(sym, got)
+    assert np.all(got[IJ[:, 0] == IJ[:, 1]] == 0)
+
+
+@settings(**SETTINGS)
+@given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(2, 80), dim=st.integers(1, 300), f32=st.booleans(), cos=st.booleans())
+def test_point_metrics(seed, n, dim, f32, cos):
+    from scipy.spatial.distance import cosine as sp_cosine
+
+    from annchor_amd import _native
+
+    rng = np.random.default_rng(seed)
+    X = (rng.standard_normal((n, dim)) * rng.uniform(0.1, 10) + rng.uniform(-1, 1)).astype(np.float32 if f32 else np.float64)
+    eng = _native.Engine(0)
+    eng.set_points(X, cosine=cos)
+    IJ = rng.integers(0, n, (300, 2))
+    got = eng.metric_pairs(IJ)
+    if cos:
+        want = np.array([sp_cosine(X[i], X[j]) if i != j or True else 0.0 for i, j in IJ])
+        np.testing.assert_allclose(got, want, rtol=0, atol=4e-6 if f32 else 1e-12)
+    else:
+        want = om.euclidean_pairs(X, IJ)
+        # one rounding of the input precision (reference: np.linalg.norm in X's dtype)
+        np.testing.assert_allclose(got, want, rtol=2e-6 if f32 else 1e-14, atol=0)
+        assert np.all(got[IJ[:, 0] == IJ[:, 1]] == 0)
+
+
+@settings(**dict(SETTINGS, max_examples=15))
+@given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(2, 40), bins=st.integers(2, 64), integral=st.booleans())
+def test_wasserstein_kernel_equals_exact_ot(seed, n, bins, integral):
+    from annchor_amd import _native
+
+    rng = np.random.default_rng(seed)
+    H = rng.integers(0, 17, (n, bins)).astype(np.float64) if integral else rng.random((n, bins)) * (rng.random((n, bins)) < 0.6)
+    H[H.sum(axis=1) == 0, 0] = 1.0
+    side = int(np.ceil(np.sqrt(bins)))
+    P = np.array([(i // side, i % side) for i in range(bins)], dtype=np.float64)
+    M = np.sqrt(((P[:, None, :] - P[None, :, :]) ** 2).sum(-1))
+    eng = _native.Engine(0)
+    eng.set_histograms(H, M)
+    IJ = rng.integers(0, n, (120, 2))
+    got = eng.metric_pairs(IJ)
+    want = om.Histograms(H, M).pairs(IJ)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
