@@ -12,3 +12,5 @@ t=time.perf_counter(); _native.legacy_prefetch(99, 1900000); r=_native.legacy_ch
 np.random.seed(42); ref=[np.random.permutation(c)[:w] for c,w in zip(counts,want)]
 _native.legacy_prefetch(42, 1900000); r=_native.legacy_choice_ranks(42, counts, want)
 print(all(np.array_equal(a,b) for a,b in zip(r,ref)))
+for rep in range(4):
+    t=time.perf_counter(); r=_native.legacy_choice_ranks(1000+rep, counts, want); print("no prefetch (inline generation) %.3f ms"%((time.perf_counter()-t)*1e3))
