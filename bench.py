@@ -226,6 +226,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    import gc
+
+    gc.collect()
+    gc.disable()   # no cyclic-GC pause inside the timed region (the fits create no reference cycles to speak of)
     sync()
     t0 = time.perf_counter()
     for a in timed:
@@ -234,6 +238,7 @@ def main():
         a._engine.synchronize()
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
     if dist is not None:
         tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
