@@ -19,17 +19,17 @@ __global__ void k_bf_pairs(int64_t nx, int2 *__restrict__ ij)
 }
 
 __global__ __launch_bounds__(ROW_THREADS) void k_bf_rows(const double *__restrict__ vals, int64_t nx, int k,
-                                                        int64_t *__restrict__ oidx, double *__restrict__ odist)
+                                                        int64_t *__restrict__ oidx, double *__restrict__ odist, int cap)
 {
     __shared__ RowSelShared sh;
-    __shared__ uint64_t keys[ROW_LDS_KEYS];
     __shared__ uint32_t cnt_lt;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    uint64_t *lkey = reinterpret_cast<uint64_t *>(dyn);      // [k]
+    uint64_t *keys = reinterpret_cast<uint64_t *>(dyn);      // [cap]
+    uint64_t *lkey = keys + cap;                             // [k]
     int32_t *lslot = reinterpret_cast<int32_t *>(lkey + k);  // [k]
     const int64_t i = row_of_block(gridDim.x);
     const int len = (int)nx;
-    const bool in_lds = len <= ROW_LDS_KEYS;
+    const bool in_lds = len <= cap;
     auto key_of = [&](int s) -> uint64_t {
         if (s == i) return ann_key_asc(0.0);  // the diagonal of D
         const int64_t a = s < i ? s : i, b = s < i ? i : s;
@@ -93,12 +93,14 @@ extern "C" int annchor_brute_force(annchor_ctx *c, int32_t k, int64_t *ng_idx, d
     ANN_TRY(ann_metric_launch(c, src, c->RA.as<double>(), nullptr, nullptr));
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;
-    const size_t dyn = (size_t)k * 12;
-    if (dyn + 52 * 1024 > 64 * 1024)
-        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_bf_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    const size_t tail = (((size_t)k * 12) + 15) & ~(size_t)15;
+    ANN_REQUIRE(c, tail < ROW_LDS_LIMIT / 2, ANNCHOR_ELIMIT, "n_neighbors %d too large for the row kernel", k);
+    const int cap = row_lds_cap(nx, tail);
+    const size_t dyn = (size_t)cap * 8 + tail;
+    ANN_TRY(row_lds_prepare(c, k_bf_rows, dyn));
     {
         ProfScope ps(c, "brute_force_row_sort", (double)n * 2 * 8.0 + (double)cells * 16.0);
-        k_bf_rows<<<(int)nx, ROW_THREADS, dyn, c->stream>>>(c->RA.as<double>(), nx, k, d_i, d_d);
+        k_bf_rows<<<(int)nx, ROW_THREADS, dyn, c->stream>>>(c->RA.as<double>(), nx, k, d_i, d_d, cap);
     }
     ANN_CHECK_HIP(c, hipGetLastError());
     ANN_TRY(ann_d2h(c, ng_idx, d_i, cells * 8));

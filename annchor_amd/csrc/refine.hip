@@ -137,15 +137,15 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
 __global__ __launch_bounds__(ROW_THREADS) void k_get_nn(const int64_t *__restrict__ Iptr, const int32_t *__restrict__ Iidx,
                                                        const double *__restrict__ RA, const uint8_t *__restrict__ ncm,
                                                        const int2 *__restrict__ ij, int nn, int64_t *__restrict__ ngi,
-                                                       double *__restrict__ ngd)
+                                                       double *__restrict__ ngd, int cap)
 {
     __shared__ RowSelShared sh;
-    __shared__ uint64_t keys[ROW_LDS_KEYS];
     __shared__ double wmax[ROW_THREADS / 64];
     __shared__ uint32_t cnt_lt;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     const int L = nn - 1;
-    uint64_t *lkey = reinterpret_cast<uint64_t *>(dyn);      // [L]
+    uint64_t *keys = reinterpret_cast<uint64_t *>(dyn);      // [cap]
+    uint64_t *lkey = keys + cap;                             // [L]
     int32_t *lslot = reinterpret_cast<int32_t *>(lkey + L);  // [L]
     const int64_t i = row_of_block(gridDim.x), b = Iptr[i];
     const int len = (int)(Iptr[i + 1] - b);
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_get_nn(const int64_t *__restric
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
     __syncthreads();
     mx = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
-    const bool in_lds = len <= ROW_LDS_KEYS;
+    const bool in_lds = len <= cap;
     auto key_of = [&](int s) -> uint64_t {
         const int32_t p = Iidx[b + s];
         double d = RA[p];
@@ -218,9 +218,12 @@ extern "C" int annchor_neighbor_graph(annchor_ctx *c, int32_t nn, int64_t *ng_id
     ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
     {
         ProfScope ps(c, "row_topk_graph", (double)c->n * 2 * 13.0 + (double)cells * 16.0);
-        k_get_nn<<<(int)c->nx, ROW_THREADS, (size_t)(nn - 1) * 12, c->stream>>>(
+        const size_t tail = (((size_t)(nn - 1) * 12) + 15) & ~(size_t)15;
+        const int cap = row_lds_cap(c->nx, tail);
+        ANN_TRY(row_lds_prepare(c, k_get_nn, (size_t)cap * 8 + tail));
+        k_get_nn<<<(int)c->nx, ROW_THREADS, (size_t)cap * 8 + tail, c->stream>>>(
             c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(), c->RA.as<double>(), c->ncm.as<uint8_t>(), c->ij.as<int2>(), nn, d_i,
-            d_d);
+            d_d, cap);
     }
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;

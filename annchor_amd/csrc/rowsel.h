@@ -17,7 +17,23 @@ __device__ __forceinline__ int64_t row_of_block(int64_t nrows)
     // bijective for any nrows: XCD x owns q (+1 if x < r) rows
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
 }
-#define ROW_LDS_KEYS 6144  // rows up to this many entries keep their keys in LDS (48 KiB)
+// Row keys live in DYNAMIC shared memory sized per launch: rows up to `cap` entries are gathered
+// once and every later pass (byte census, radix passes, collection) reads LDS; longer rows fall
+// back to re-gathering.  cap = longest possible row, bounded by what one workgroup may hold.
+#define ROW_LDS_LIMIT (156 * 1024)   // dynamic LDS a row kernel may ask for (static shared stays < 4 KiB)
+static inline int row_lds_cap(int64_t max_row_len, size_t other_dyn_bytes)
+{
+    int64_t cap = (int64_t)((ROW_LDS_LIMIT - other_dyn_bytes) / 8);
+    if (cap > max_row_len) cap = max_row_len;
+    if (cap < 1) cap = 1;
+    return (int)((cap + 1) & ~1ll);   // keep what follows 16-byte aligned
+}
+template <typename K> static inline int row_lds_prepare(annchor_ctx *c, K kernel, size_t dyn_bytes)
+{
+    if (dyn_bytes > 64 * 1024)
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes));
+    return ANNCHOR_OK;
+}
 
 struct RowSelShared {
     uint32_t hist[256];

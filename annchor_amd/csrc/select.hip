@@ -22,16 +22,17 @@
 // ------------------------------------------------------------------- thresholds
 __global__ __launch_bounds__(ROW_THREADS) void k_row_thresh(const int64_t *__restrict__ Iptr, const int32_t *__restrict__ Iidx,
                                                            const double *__restrict__ RA, uint32_t k,
-                                                           double *__restrict__ thresh)
+                                                           double *__restrict__ thresh, int cap)
 {
     __shared__ RowSelShared sh;
-    __shared__ uint64_t keys[ROW_LDS_KEYS];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_rt[];
+    uint64_t *keys = reinterpret_cast<uint64_t *>(dyn_rt);   // [cap]
     const int64_t i = row_of_block(gridDim.x);
     const int64_t b = Iptr[i];
     const int len = (int)(Iptr[i + 1] - b);
     if (len <= 0) { if (threadIdx.x == 0) thresh[i] = -INFINITY; return; }  // empty row (query form): never the max
     uint64_t res;
-    if (len <= ROW_LDS_KEYS) {
+    if (len <= cap) {
         for (int s = threadIdx.x; s < len; s += ROW_THREADS) keys[s] = ann_key_asc(RA[Iidx[b + s]]);
         __syncthreads();
         res = row_kth_key(sh, len, k, [&](int s) { return keys[s]; });
@@ -48,18 +49,18 @@ __global__ __launch_bounds__(ROW_THREADS) void k_gn_lists(const int64_t *__restr
                                                          const double *__restrict__ RA, const uint8_t *__restrict__ ncm,
                                                          const int2 *__restrict__ ij, int L, double *__restrict__ gl_val,
                                                          int32_t *__restrict__ gl_pos, int32_t *__restrict__ gl_oth,
-                                                         int32_t *__restrict__ gl_cnt, int32_t *__restrict__ gl_ncomp)
+                                                         int32_t *__restrict__ gl_cnt, int32_t *__restrict__ gl_ncomp, int cap)
 {
     __shared__ RowSelShared sh;
-    __shared__ uint64_t keys[ROW_LDS_KEYS];
     __shared__ uint32_t cnt_lt, n_unc_s;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    uint64_t *lkey = reinterpret_cast<uint64_t *>(dyn);       // [L]
+    uint64_t *keys = reinterpret_cast<uint64_t *>(dyn);       // [cap]
+    uint64_t *lkey = keys + cap;                              // [L]
     int32_t *lslot = reinterpret_cast<int32_t *>(lkey + L);   // [L]
     const int64_t i = row_of_block(gridDim.x);
     const int64_t b = Iptr[i];
     const int len = (int)(Iptr[i + 1] - b);
-    const bool in_lds = len <= ROW_LDS_KEYS;
+    const bool in_lds = len <= cap;
     const uint64_t KINF = ~0ull;  // computed entries sort last
     auto key_of = [&](int s) -> uint64_t {
         const int32_t p = Iidx[b + s];
@@ -562,8 +563,11 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     {
         // algorithmic bytes: every pair value is read from both of its rows: 2n * (8 + 4)
         ProfScope ps(c, "row_kth_threshold", (double)n * 24.0);
-        k_row_thresh<<<(int)nx, ROW_THREADS, 0, c->stream>>>(c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(), c->RA.as<double>(),
-                                                            (uint32_t)n_neighbors, c->thresh.as<double>());
+        const int cap = row_lds_cap(nx, 0);
+        ANN_TRY(row_lds_prepare(c, k_row_thresh, (size_t)cap * 8));
+        k_row_thresh<<<(int)nx, ROW_THREADS, (size_t)cap * 8, c->stream>>>(c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(),
+                                                                         c->RA.as<double>(), (uint32_t)n_neighbors,
+                                                                         c->thresh.as<double>(), cap);
     }
     if (nmin > 0) {
         const int L = nmin + 1;
@@ -580,10 +584,13 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp2.p, 0, 4, c->stream));
         {
             ProfScope ps(c, "guarantee_nmin_lists", (double)n * 26.0);
-            k_gn_lists<<<(int)nx, ROW_THREADS, (size_t)L * 12, c->stream>>>(
+            const size_t tail = (((size_t)L * 12) + 15) & ~(size_t)15;
+            const int cap = row_lds_cap(nx, tail);
+            ANN_TRY(row_lds_prepare(c, k_gn_lists, (size_t)cap * 8 + tail));
+            k_gn_lists<<<(int)nx, ROW_THREADS, (size_t)cap * 8 + tail, c->stream>>>(
                 c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(), c->RA.as<double>(), c->ncm.as<uint8_t>(), c->ij.as<int2>(), L,
                 c->gl_val.as<double>(), c->gl_pos.as<int32_t>(), c->gl_pos.as<int32_t>() + (size_t)nx * L,
-                c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>());
+                c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(), cap);
         }
         const size_t sweep_lds = (size_t)nx * (((size_t)L + 31) / 32 * 4 + 4);
         const size_t ring_lds = sweep_lds + 2 * (size_t)GN_B * L * 20 + 4 * GN_B * 4 + 64;
