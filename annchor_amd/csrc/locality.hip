@@ -259,7 +259,7 @@ __global__ __launch_bounds__(LOC_THREADS) void k_qloc_count(const uint64_t *__re
     const int64_t q = nxb + blockIdx.x;
     const uint64_t mq = sid[q];
     uint32_t s = 0;
-    for (int64_t i = threadIdx.x; i < nxb; i += blockDim.x) s += __popcll(mq & sid[i]) >= loc_thresh;
+    for (int64_t i = threadIdx.x; i < nxb; i += blockDim.x) s += (int)__popcll(mq & sid[i]) >= loc_thresh;
     if (s) atomicAdd(&acc, s);
     __syncthreads();
     if (threadIdx.x == 0) cnt[q] = (int32_t)acc;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(LOC_THREADS) void k_qloc_emit(const uint64_t *__res
     const int64_t base = Iptr[q];
     for (int64_t b0 = 0; b0 < nxb; b0 += LOC_THREADS) {
         const int64_t i = b0 + threadIdx.x;
-        const uint32_t f = (i < nxb && __popcll(mq & sid[i]) >= loc_thresh) ? 1u : 0u;
+        const uint32_t f = (i < nxb && (int)__popcll(mq & sid[i]) >= loc_thresh) ? 1u : 0u;
         const unsigned long long m = __ballot(f);
         if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
         __syncthreads();

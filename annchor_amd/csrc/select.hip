@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void k_gn_sweep_ring(int64_t nx, int nmin, int
                 const bool um = e < cnt && !((fl >> (e & 31)) & 1u);
                 const unsigned long long m = __ballot(um);
                 if (ntodo <= 0 || empty || need <= 0) continue;
-                if ((cnt <= ntodo && cnt < L) || __popcll(m) < need) { if (lane == 0) *err = 1; continue; }
+                if ((cnt <= ntodo && cnt < L) || (int)__popcll(m) < need) { if (lane == 0) *err = 1; continue; }
                 const int myrank = __popcll(m & ((1ull << lane) - 1ull));
                 const unsigned long long hit = __ballot(um && myrank == need - 1);
                 const int src = __ffsll((unsigned long long)hit) - 1;

@@ -726,7 +726,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
         sh.cnt[row] = 0;
         for (int q = 0; q < KMAX; ++q) { sh.list_d[row][q] = INFINITY; sh.list_c[row][q] = 0x7fffffff; }
     }
-    if (threadIdx.x < a.na) {
+    if ((int)threadIdx.x < a.na) {
         sh.loI[threadIdx.x] = a.lo[(size_t)threadIdx.x * a.nt_all + I];
         sh.hiI[threadIdx.x] = a.hi[(size_t)threadIdx.x * a.nt_all + I];
         sh.midI[threadIdx.x] = a.mid[(size_t)threadIdx.x * a.nt_all + I];
