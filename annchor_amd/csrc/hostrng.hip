@@ -276,7 +276,9 @@ struct Scan {
     }
 };
 
-void scan_bin_scalar(Scan &S, int64_t c, uint32_t *Jc)
+// STORE = false: only advance through the bin's draws (pass 1 of the parallel scheme: where
+// does the next bin start in the stream?)
+template <bool STORE> void scan_bin_scalar(Scan &S, int64_t c, uint32_t *Jc)
 {
     size_t t = 0;
     for (uint32_t i = c >= 2 ? (uint32_t)(c - 1) : 0u; i >= 1;) {
@@ -296,7 +298,7 @@ void scan_bin_scalar(Scan &S, int64_t c, uint32_t *Jc)
                 }
                 if (unsure) break;
                 for (int u = 0; u < 8; ++u) {
-                    Jc[t] = v[u];
+                    if (STORE) Jc[t] = v[u];
                     const uint32_t acc = (v[u] <= lo_t);
                     t += acc;
                     i -= acc;
@@ -305,7 +307,7 @@ void scan_bin_scalar(Scan &S, int64_t c, uint32_t *Jc)
             }
             for (int u = 0; u < 8 && p < avail && i >= lo; ++u) {  // exact steps (window with an unsure draw / band edge)
                 const uint32_t v = buf[p++] & mask;
-                Jc[t] = v;
+                if (STORE) Jc[t] = v;
                 const uint32_t acc = (v <= i);
                 t += acc;
                 i -= acc;
@@ -315,7 +317,7 @@ void scan_bin_scalar(Scan &S, int64_t c, uint32_t *Jc)
     }
 }
 
-__attribute__((target("avx512f,avx512bw,popcnt"))) void scan_bin_avx512(Scan &S, int64_t c, uint32_t *Jc)
+template <bool STORE> __attribute__((target("avx512f,avx512bw,popcnt"))) void scan_bin_avx512(Scan &S, int64_t c, uint32_t *Jc)
 {
     size_t t = 0;
     for (uint32_t i = c >= 2 ? (uint32_t)(c - 1) : 0u; i >= 1;) {
@@ -331,7 +333,7 @@ __attribute__((target("avx512f,avx512bw,popcnt"))) void scan_bin_avx512(Scan &S,
                 const __mmask16 acc = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32((int)(i - 16)));
                 const __mmask16 rej = _mm512_cmpgt_epu32_mask(v, _mm512_set1_epi32((int)i));
                 if ((__mmask16)(acc | rej) != 0xffff) break;
-                _mm512_storeu_si512(Jc + t, _mm512_maskz_compress_epi32(acc, v));   // Jc has 32 words of slack
+                if (STORE) _mm512_storeu_si512(Jc + t, _mm512_maskz_compress_epi32(acc, v));   // Jc has 32 words of slack
                 const uint32_t n = (uint32_t)__builtin_popcount(acc);
                 t += n;
                 i -= n;
@@ -339,7 +341,7 @@ __attribute__((target("avx512f,avx512bw,popcnt"))) void scan_bin_avx512(Scan &S,
             }
             for (int u = 0; u < 16 && p < avail && i >= lo; ++u) {
                 const uint32_t v = buf[p++] & mask;
-                Jc[t] = v;
+                if (STORE) Jc[t] = v;
                 const uint32_t a = (v <= i);
                 t += a;
                 i -= a;
@@ -390,6 +392,56 @@ extern "C" int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts,
         n_out[b] = counts[b] < want[b] ? counts[b] : want[b];
         offs[(size_t)b + 1] = offs[(size_t)b] + n_out[b];
     }
+    // Large draws (pair lists of 10^7..10^8 candidates: the shuffles cover every not-computed
+    // pair): two passes.  Pass 1 runs through the stream counting only -- which word does each
+    // bin start at? -- then the bins, now independent, are scanned (with stores) and traced
+    // by one thread each.  The sequential part drops to the count-only scan.
+    {
+        static const int64_t par_threshold = getenv("ANNCHOR_RNG_PAR_MIN") ? atoll(getenv("ANNCHOR_RNG_PAR_MIN")) : (4ll << 20);
+        int64_t total = 0;
+        int nlive = 0;
+        for (int b = 0; b < nbins; ++b)
+            if (counts[b] >= want[b]) { total += counts[b]; ++nlive; }
+        if (total >= par_threshold && nlive > 1) {
+            std::vector<size_t> start((size_t)nbins, 0);
+            for (int b = 0; b < nbins; ++b) {
+                const int64_t c = counts[b], k = want[b];
+                if (c < k) {
+                    int64_t *out = ranks_out + offs[(size_t)b];
+                    for (int64_t t = 0; t < c; ++t) out[t] = t;
+                    continue;
+                }
+                start[(size_t)b] = S.cur;
+                if (use_avx512()) scan_bin_avx512<false>(S, c, nullptr);
+                else scan_bin_scalar<false>(S, c, nullptr);
+            }
+            const double t_count = ms_since(t_entry);
+            for (int b = 0; b < nbins; ++b) {   // grow the scratch before the threads start
+                BinScratch *sc = g_scratch[(size_t)b].get();
+                if (counts[b] >= want[b] && sc->J.size() < (size_t)counts[b] + 32) sc->J.resize((size_t)counts[b] + 32);
+            }
+            std::atomic<int> next{0};
+            auto work = [&] {
+                for (;;) {
+                    const int b = next.fetch_add(1);
+                    if (b >= nbins) return;
+                    if (counts[b] < want[b]) continue;
+                    Scan S2{st.get(), start[(size_t)b]};   // every word of the bin is already generated
+                    BinScratch *sc = g_scratch[(size_t)b].get();
+                    if (use_avx512()) scan_bin_avx512<true>(S2, counts[b], sc->J.data());
+                    else scan_bin_scalar<true>(S2, counts[b], sc->J.data());
+                    trace_prefix(sc, counts[b], want[b], ranks_out + offs[(size_t)b]);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nlive; ++t) pool.emplace_back(work);
+            work();
+            for (auto &th : pool) th.join();
+            if (timing)
+                fprintf(stderr, "[rng] parallel: count pass %.3f ms, all bins done %.3f ms, words %zu\n", t_count, ms_since(t_entry), S.cur);
+            return ANNCHOR_OK;
+        }
+    }
     // Backward traces: one helper thread takes scanned bins from the front while this thread
     // is still scanning; when the scan is done this thread takes bins from the back.  (A
     // thread per bin measured slower: each lands on a sleeping core.)
@@ -421,8 +473,8 @@ extern "C" int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts,
         // starts where the previous one stopped)
         BinScratch *sc = g_scratch[(size_t)b].get();
         if (sc->J.size() < (size_t)c + 32) sc->J.resize((size_t)c + 32);
-        if (use_avx512()) scan_bin_avx512(S, c, sc->J.data());
-        else scan_bin_scalar(S, c, sc->J.data());
+        if (use_avx512()) scan_bin_avx512<true>(S, c, sc->J.data());
+        else scan_bin_scalar<true>(S, c, sc->J.data());
         state[(size_t)b].store(READY, std::memory_order_release);
     }
     const double t_scan = ms_since(t_entry);

@@ -173,3 +173,20 @@ def test_library_rng_portable_path_matches_numpy():
     env = dict(os.environ, ANNCHOR_RNG_SCALAR="1", PYTHONPATH=root)
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_library_rng_parallel_path_matches_numpy():
+    """Draws above 4 M elements take the two-pass route (count-only pass for the bins' stream
+    offsets, then one thread per bin): same stream, same result."""
+    import __graft_entry__ as g
+
+    g.build()
+    from annchor_amd import _native
+
+    counts = [300000, 1500000, 900000, 40, 1200000, 3, 700000]
+    want = [715, 715, 714, 714, 714, 5, 714]
+    for seed in (7, 42):
+        got = _native.legacy_choice_ranks(seed, counts, want)
+        np.random.seed(seed)
+        ref = [np.arange(c) if c < w else np.random.permutation(int(c))[:w] for c, w in zip(counts, want)]
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref))

@@ -17,3 +17,4 @@ for name, e in sorted(ann._engine.prof_get().items(), key=lambda kv: -kv[1]["ms"
         us = e["ms"] / e["launches"] * 1e3
         print("  %-28s %8.1f us/launch x %3d   %7.1f GB/s algorithmic (%.1f %% of 8 TB/s)" % (
             name, us, e["launches"], e["alg_bytes"] / e["launches"] / us / 1e3, e["alg_bytes"] / e["launches"] / us / 1e3 / 80))
+print("host stage ms:", {k: round(v * 1e3, 1) for k, v in ann.timings.items()})
