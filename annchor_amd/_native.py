@@ -75,6 +75,8 @@ _SIGNATURES = {
                                                                                    ctypes.POINTER(_i32)]),
     "annchor_stream_knn": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _vp, _vp, _vp,
                                           ctypes.POINTER(_i64)]),
+    "annchor_stream_query": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _dbl, _vp, _vp,
+                                            ctypes.POINTER(_i64)]),
     "annchor_device_alloc": (ctypes.c_int, [_vp, _i64, ctypes.POINTER(_vp)]),
     "annchor_device_free": (ctypes.c_int, [_vp, _vp]),
     "annchor_device_copy": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32]),
@@ -384,6 +386,16 @@ class Engine:
                                               int(k), float(p_work), _ptr(row_ids) if row_ids is not None else None, _ptr(idx),
                                               _ptr(dist), ctypes.byref(ev)))
         return row_ids, idx, dist, ev.value
+
+    def stream_query(self, cols, n_all, nt_all, n_anchors, dim_padded, nn, p_work):
+        """nn nearest data rows of every (bound + ordered) query row; cols = the data set's column arrays."""
+        idx = np.empty((self.nx, nn), dtype=np.int64)
+        dist = np.empty((self.nx, nn), dtype=np.float64)
+        ev = _i64()
+        self._chk(self.lib.annchor_stream_query(self.h, cols["Xs"], cols["rs"], cols["perm"], cols["lo"], cols["hi"], cols["mid"],
+                                                int(n_all), int(nt_all), int(n_anchors), int(dim_padded), int(nn), float(p_work),
+                                                _ptr(idx), _ptr(dist), ctypes.byref(ev)))
+        return idx, dist, ev.value
 
     def device_alloc(self, nbytes):
         p = _vp()

@@ -383,8 +383,8 @@ class Annchor:
         Runs on a second engine holding X followed by Q; the fitted state is untouched.
         `get_exact_query_ijs(f, X, Z, IJ)` (pairs index (X[i], Z[j])) replaces the metric
         evaluator as in the reference."""
-        if self._streamed is not None:
-            raise NotImplementedError("query() is not available for the streamed form")
+        if self._streamed is not None:   # large float32 Euclidean data: tile-granular query, same kernel as fit()
+            return self._streamed.query(np.asarray(Q, dtype=np.float32), nn=nn, p_work=p_work)
         if self.p_work > 1:
             print("Warning: p_work should not exceed 1.  Setting it to 1.")
             self.p_work = 1.0

@@ -460,7 +460,11 @@ struct KnnArgs {
     const float *rs;      // [n_all]
     const float *lo, *hi, *mid; // [na][nt_all]
     int nt_all, na;
-    int tile_begin;       // first row tile of this launch inside the global tile numbering
+    // row tiles: the same arrays for the k-NN graph; a separate (query) set for annchor_stream_query
+    const float *Rs, *rr, *rlo, *rhi, *rmid;
+    int nt_r;             // tile count of the row tables (stride of rlo / rhi / rmid)
+    int query;            // 1: rows are queries -- no self tile, no self exclusion
+    int tile_begin;       // first row tile of this launch inside the row tile numbering
     int tile_count;
     int K;                // neighbours kept per row, self excluded
     int max_tiles;        // column-tile budget per row tile
@@ -534,7 +538,7 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
     };
     const int col = lane & 31;
     const int rowq = rowbase_wave + 4 * (lane >> 5);   // C layout: row = rowq + (r & 3) + 8 (r >> 2), col = lane & 31
-    const bool self_tile = (int64_t)J * ST_T == grow0;
+    const bool self_tile = !a.query && (int64_t)J * ST_T == grow0;
     // merge of a slab's survivors into the sorted per-row lists: lane l < 32 owns row 32 w + l
     auto merge = [&](int64_t col0) {
         wave_fence_lds();
@@ -712,24 +716,24 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
     // ---- per-wave row operand in registers: lane holds row (lane & 31), dims of parity (lane >> 5)
     float areg[DIM / 2];
     {
-        const float *xr = a.Xs + (size_t)(grow0 + wave * 32 + (lane & 31)) * DIM + (lane >> 5);
+        const float *xr = a.Rs + (size_t)(grow0 + wave * 32 + (lane & 31)) * DIM + (lane >> 5);
 #pragma unroll
         for (int s = 0; s < DIM / 2; ++s) areg[s] = xr[2 * s];
     }
     float ri[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ri[r] = a.rs[grow0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+    for (int r = 0; r < 16; ++r) ri[r] = a.rr[grow0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
     if (threadIdx.x < ST_T) {
         const int row = threadIdx.x;
-        const bool real = a.rs[grow0 + row] < INFINITY;
+        const bool real = a.rr[grow0 + row] < INFINITY;
         sh.thr[row] = real ? INFINITY : -1.f;  // padding rows never accept candidates
         sh.cnt[row] = 0;
         for (int q = 0; q < KMAX; ++q) { sh.list_d[row][q] = INFINITY; sh.list_c[row][q] = 0x7fffffff; }
     }
     if ((int)threadIdx.x < a.na) {
-        sh.loI[threadIdx.x] = a.lo[(size_t)threadIdx.x * a.nt_all + I];
-        sh.hiI[threadIdx.x] = a.hi[(size_t)threadIdx.x * a.nt_all + I];
-        sh.midI[threadIdx.x] = a.mid[(size_t)threadIdx.x * a.nt_all + I];
+        sh.loI[threadIdx.x] = a.rlo[(size_t)threadIdx.x * a.nt_r + I];
+        sh.hiI[threadIdx.x] = a.rhi[(size_t)threadIdx.x * a.nt_r + I];
+        sh.midI[threadIdx.x] = a.rmid[(size_t)threadIdx.x * a.nt_r + I];
     }
     if (threadIdx.x == 0) sh.nsurv = 0;
     float thrmax = INFINITY;   // worst k-th squared distance of the row tile (uniform)
@@ -743,9 +747,12 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
 #endif
     __syncthreads();
 
-    // ---- phase A: the row tile against itself (gives every row k finite candidates)
-    thrmax = knn_process_tile<DIM, KMAX>(sh, a, I, -1, st, areg, ri, wave * 32, grow0, K, pf_ptr);
-    ++processed;
+    // ---- phase A: the row tile against itself (gives every row k finite candidates); query
+    // rows are not part of the data set and start from the ranked tiles directly
+    if (!a.query) {
+        thrmax = knn_process_tile<DIM, KMAX>(sh, a, I, -1, st, areg, ri, wave * 32, grow0, K, pf_ptr);
+        ++processed;
+    }
 
     // ---- phase B: all other column tiles.  A tile is ELIGIBLE while its interval bound lb
     // (a valid lower bound of every pair distance) is below the worst k-th distance of the
@@ -772,7 +779,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
             const float dm = a.mid[(size_t)an * a.nt_all + J] - sh.midI[an];
             lbc += dm * dm;   // rank key: squared L2 distance between the tiles' mean anchor vectors
         }
-        skey[J] = (J == I || !(lbc < INFINITY)) ? INFINITY : lbc;   // +inf: never a candidate
+        skey[J] = ((J == I && !a.query) || !(lbc < INFINITY)) ? INFINITY : lbc;   // +inf: never a candidate
         slb[J] = lb;
     }
     __syncthreads();   // block-scope visibility of the scratch row (same CU)
@@ -910,7 +917,8 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
 }
 
 // exact float32 distances of the selected neighbours + final per-row ordering
-__global__ __launch_bounds__(256) void k_st_finalize(const float *__restrict__ Xs, const int64_t *__restrict__ perm_all, int dimp,
+__global__ __launch_bounds__(256) void k_st_finalize(const float *__restrict__ Xs, const float *__restrict__ Rs,
+                                                    const int64_t *__restrict__ perm_all, int dimp,
                                                     int64_t row_begin, int64_t rows, int K, const int32_t *__restrict__ col,
                                                     int64_t *__restrict__ oidx, float *__restrict__ odist)
 {
@@ -924,7 +932,7 @@ __global__ __launch_bounds__(256) void k_st_finalize(const float *__restrict__ X
     double acc = 0;
     const bool ok = cc != 0x7fffffff;
     if (ok) {
-        const float *x = Xs + (size_t)(row_begin + r) * dimp, *y = Xs + (size_t)cc * dimp;
+        const float *x = Rs + (size_t)(row_begin + r) * dimp, *y = Xs + (size_t)cc * dimp;
         for (int k = sub; k < dimp; k += 16) { double d = (double)x[k] - (double)y[k]; acc += d * d; }
     }
 #pragma unroll
@@ -969,6 +977,20 @@ __global__ void k_st_emit(const int64_t *__restrict__ perm, int64_t row_begin, i
     odist[loc * k + e] = e == 0 ? 0.0 : (double)dist[r * K + e - 1];
 }
 
+// query results in the queries' own order: row perm_q[r] gets its K ordered neighbours (no self column)
+__global__ void k_st_emit_query(const int64_t *__restrict__ perm_q, int64_t rows, int K, int64_t nq, const int64_t *__restrict__ idx,
+                                const float *__restrict__ dist, int64_t *__restrict__ oidx, double *__restrict__ odist)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * K) return;
+    const int64_t r = t / K;
+    const int e = (int)(t - r * K);
+    const int64_t g = perm_q[r];
+    if (g < 0 || g >= nq) return;   // padding row
+    oidx[g * K + e] = idx[t];
+    odist[g * K + e] = (double)dist[t];
+}
+
 template <int DIM, int KMAX> static int launch_knn2(annchor_ctx *c, const KnnArgs &a)
 {
     const size_t lds = sizeof(KnnShared<DIM, KMAX>);
@@ -993,32 +1015,22 @@ template <int DIM> static int launch_knn(annchor_ctx *c, const KnnArgs &a)
 // With row_ids == NULL the outputs are instead [n_local, k] arrays in the bound shard's own row
 // order (row = global id - global_base of annchor_stream_bind), written by a device kernel and
 // copied out in one piece -- no host-side reordering.
-extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void *rs_all, const void *perm_all,
-                                  const void *lo_all, const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors,
-                                  int32_t dim_padded, int32_t tile_begin, int32_t tile_count, int32_t k, double p_work,
-                                  int64_t *row_ids, int64_t *ng_idx, double *ng_dist, int64_t *tile_evals)
+// shared by the graph build (rows = a range of the column tiles) and by queries (rows = the
+// context's own ordered query tiles): launch, exact distances of the kept neighbours, row order
+static int knn_run(annchor_ctx *c, StreamState *s, KnnArgs &a, const void *perm_all, int dim_padded, double p_work,
+                   int64_t **d_idx_out, float **d_dist_out, int64_t *tile_evals)
 {
-    if (!c || !Xs_all || !rs_all || !perm_all || !lo_all || !hi_all || !mid_all || !ng_idx || !ng_dist) return ANNCHOR_EINVAL;
-    ANN_REQUIRE(c, k >= 2 && k - 1 <= ST_KMAX, ANNCHOR_ELIMIT, "streamed form supports 2 <= n_neighbors <= %d", ST_KMAX + 1);
-    ANN_REQUIRE(c, n_all == (int64_t)nt_all * ST_T && tile_begin >= 0 && tile_begin + tile_count <= nt_all, ANNCHOR_EINVAL,
-                "tile range out of bounds");
-    ANN_REQUIRE(c, n_all < (1ll << 31), ANNCHOR_ELIMIT, "n_all exceeds 2^31");
-    ANN_CHECK_HIP(c, hipSetDevice(c->device));
-    StreamState *s = state_of(c, true);
-    const int K = k - 1;
-    const int64_t rows = (int64_t)tile_count * ST_T;
+    const int K = a.K;
+    const int64_t rows = (int64_t)a.tile_count * ST_T;
     ANN_TRY(sreserve(c, s->out_d2, sizeof(float) * (size_t)rows * K));
     ANN_TRY(sreserve(c, s->out_col, sizeof(int32_t) * (size_t)rows * K));
     ANN_TRY(sreserve(c, s->evals, 64));
     ANN_CHECK_HIP(c, hipMemsetAsync(s->evals.p, 0, 8, c->stream));
-    KnnArgs a;
-    a.Xs = (const float *)Xs_all; a.rs = (const float *)rs_all; a.lo = (const float *)lo_all; a.hi = (const float *)hi_all; a.mid = (const float *)mid_all;
-    a.nt_all = nt_all; a.na = n_anchors; a.tile_begin = tile_begin; a.tile_count = tile_count; a.K = K;
-    double mt = p_work >= 1.0 ? (double)nt_all : std::ceil(p_work * (double)nt_all);
-    a.max_tiles = (int)std::max(1.0, std::min(mt, (double)nt_all));
+    double mt = p_work >= 1.0 ? (double)a.nt_all : std::ceil(p_work * (double)a.nt_all);
+    a.max_tiles = (int)std::max(1.0, std::min(mt, (double)a.nt_all));
     a.out_d2 = s->out_d2.as<float>(); a.out_col = s->out_col.as<int32_t>();
-    ANN_TRY(sreserve(c, s->scr_key, sizeof(float) * (size_t)tile_count * (size_t)nt_all));
-    ANN_TRY(sreserve(c, s->scr_lb, sizeof(float) * (size_t)tile_count * (size_t)nt_all));
+    ANN_TRY(sreserve(c, s->scr_key, sizeof(float) * (size_t)a.tile_count * (size_t)a.nt_all));
+    ANN_TRY(sreserve(c, s->scr_lb, sizeof(float) * (size_t)a.tile_count * (size_t)a.nt_all));
     a.scr_key = s->scr_key.as<float>(); a.scr_lb = s->scr_lb.as<float>();
     a.evals = s->evals.as<unsigned long long>();
     a.prof = nullptr;
@@ -1049,12 +1061,54 @@ extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void
     float *d_dist = s->keys2.as<float>();
     {
         ProfScope ps(c, "stream_finalize", (double)rows * K * (2.0 * dim_padded * 4 + 16));
-        k_st_finalize<<<ann_blocks(rows * K * 16, 256), 256, 0, c->stream>>>(a.Xs, (const int64_t *)perm_all, dim_padded,
-                                                                             (int64_t)tile_begin * ST_T, rows, K, a.out_col, d_idx,
+        k_st_finalize<<<ann_blocks(rows * K * 16, 256), 256, 0, c->stream>>>(a.Xs, a.Rs, (const int64_t *)perm_all, dim_padded,
+                                                                             (int64_t)a.tile_begin * ST_T, rows, K, a.out_col, d_idx,
                                                                              d_dist);
         k_st_rowsort<<<ann_blocks(rows, 256), 256, 0, c->stream>>>(rows, K, d_idx, d_dist);
     }
     ANN_CHECK_HIP(c, hipGetLastError());
+    *d_idx_out = d_idx;
+    *d_dist_out = d_dist;
+    if (tile_evals) {
+        unsigned long long ev = 0;
+        ANN_TRY(ann_d2h(c, &ev, s->evals.p, 8));
+        *tile_evals = (int64_t)ev;
+    }
+#ifdef ST_PROFILE
+    {
+        unsigned long long hp[8];
+        ANN_TRY(ann_d2h(c, hp, a.prof, 64));
+        static const char *names[8] = {"barrier before stash", "stash (incl. global-load wait)", "barrier after stash",
+                                       "MFMA stream + thresholds", "survivor inserts", "merge", "tile end", "candidate scan + rest"};
+        double tot = 0;
+        for (int i = 0; i < 8; ++i) tot += (double)hp[i];
+        for (int i = 0; i < 8; ++i) fprintf(stderr, "[st-prof] %-32s %6.2f %%\n", names[i], 100.0 * (double)hp[i] / tot);
+    }
+#endif
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void *rs_all, const void *perm_all,
+                                  const void *lo_all, const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors,
+                                  int32_t dim_padded, int32_t tile_begin, int32_t tile_count, int32_t k, double p_work,
+                                  int64_t *row_ids, int64_t *ng_idx, double *ng_dist, int64_t *tile_evals)
+{
+    if (!c || !Xs_all || !rs_all || !perm_all || !lo_all || !hi_all || !mid_all || !ng_idx || !ng_dist) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, k >= 2 && k - 1 <= ST_KMAX, ANNCHOR_ELIMIT, "streamed form supports 2 <= n_neighbors <= %d", ST_KMAX + 1);
+    ANN_REQUIRE(c, n_all == (int64_t)nt_all * ST_T && tile_begin >= 0 && tile_begin + tile_count <= nt_all, ANNCHOR_EINVAL,
+                "tile range out of bounds");
+    ANN_REQUIRE(c, n_all < (1ll << 31), ANNCHOR_ELIMIT, "n_all exceeds 2^31");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    StreamState *s = state_of(c, true);
+    const int K = k - 1;
+    const int64_t rows = (int64_t)tile_count * ST_T;
+    KnnArgs a;
+    a.Xs = (const float *)Xs_all; a.rs = (const float *)rs_all; a.lo = (const float *)lo_all; a.hi = (const float *)hi_all; a.mid = (const float *)mid_all;
+    a.Rs = a.Xs; a.rr = a.rs; a.rlo = a.lo; a.rhi = a.hi; a.rmid = a.mid; a.nt_r = nt_all; a.query = 0;
+    a.nt_all = nt_all; a.na = n_anchors; a.tile_begin = tile_begin; a.tile_count = tile_count; a.K = K;
+    int64_t *d_idx = nullptr;
+    float *d_dist = nullptr;
+    ANN_TRY(knn_run(c, s, a, perm_all, dim_padded, p_work, &d_idx, &d_dist, tile_evals));
     if (!row_ids) {
         const int64_t n_local = s->n_local;
         ANN_TRY(sreserve(c, s->emit_idx, sizeof(int64_t) * (size_t)n_local * k));
@@ -1080,23 +1134,44 @@ extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void
             }
         }
     }
-#ifdef ST_PROFILE
-    {
-        unsigned long long hp[8];
-        ANN_TRY(ann_d2h(c, hp, a.prof, 64));
-        static const char *names[8] = {"barrier before stash", "stash (incl. global-load wait)", "barrier after stash",
-                                       "MFMA stream + thresholds", "survivor inserts", "merge", "tile end", "candidate scan + rest"};
-        double tot = 0;
-        for (int i = 0; i < 8; ++i) tot += (double)hp[i];
-        for (int i = 0; i < 8; ++i) fprintf(stderr, "[st-prof] %-32s %6.2f %%\n", names[i], 100.0 * (double)hp[i] / tot);
-    }
-#endif
-    if (tile_evals) {
-        unsigned long long ev = 0;
-        ANN_TRY(ann_d2h(c, &ev, s->evals.p, 8));
-        *tile_evals = (int64_t)ev;
-    }
     return ANNCHOR_OK;
+}
+
+// Queries against a fitted (ordered) data set: the context holds the QUERY rows -- bound with
+// annchor_stream_bind (global_base 0), given the data set's anchor vectors through
+// annchor_stream_anchor_round, ordered with annchor_stream_order -- and the six column arrays
+// are the data set's (device pointers from ITS annchor_stream_order / all-gather).  For every
+// query the nn nearest data rows: out_idx int64 [nq, nn] (global ids), out_dist float64 [nq, nn],
+// in the queries' own order.  Replaces Annchor.query (annchor.py:643-683 ->
+// query_functions.py:183-212) for data sets too large for the pair-list form.
+extern "C" int annchor_stream_query(annchor_ctx *c, const void *Xs_all, const void *rs_all, const void *perm_all, const void *lo_all,
+                                    const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors,
+                                    int32_t dim_padded, int32_t nn, double p_work, int64_t *out_idx, double *out_dist,
+                                    int64_t *tile_evals)
+{
+    if (!c || !Xs_all || !rs_all || !perm_all || !lo_all || !hi_all || !mid_all || !out_idx || !out_dist) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, nn >= 1 && nn <= ST_KMAX, ANNCHOR_ELIMIT, "streamed query supports 1 <= nn <= %d", ST_KMAX);
+    ANN_REQUIRE(c, n_all == (int64_t)nt_all * ST_T && n_all < (1ll << 31), ANNCHOR_EINVAL, "column arrays out of range");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    StreamState *s = state_of(c, false);
+    ANN_REQUIRE(c, s && s->nt > 0 && s->Xs.p && s->na == n_anchors && s->dimp == dim_padded, ANNCHOR_ESTATE,
+                "queries are not ordered (bind, anchor rounds with the data set's anchors, order) or do not match the data set");
+    KnnArgs a;
+    a.Xs = (const float *)Xs_all; a.rs = (const float *)rs_all; a.lo = (const float *)lo_all; a.hi = (const float *)hi_all; a.mid = (const float *)mid_all;
+    a.Rs = s->Xs.as<float>(); a.rr = s->rs.as<float>(); a.rlo = s->lo.as<float>(); a.rhi = s->hi.as<float>(); a.rmid = s->mid.as<float>();
+    a.nt_r = s->nt; a.query = 1;
+    a.nt_all = nt_all; a.na = n_anchors; a.tile_begin = 0; a.tile_count = s->nt; a.K = nn;
+    int64_t *d_idx = nullptr;
+    float *d_dist = nullptr;
+    ANN_TRY(knn_run(c, s, a, perm_all, dim_padded, p_work, &d_idx, &d_dist, tile_evals));
+    const int64_t rows = (int64_t)s->nt * ST_T, nq = s->n_local;
+    ANN_TRY(sreserve(c, s->emit_idx, sizeof(int64_t) * (size_t)nq * nn));
+    ANN_TRY(sreserve(c, s->emit_dist, sizeof(double) * (size_t)nq * nn));
+    k_st_emit_query<<<ann_blocks(rows * nn, 256), 256, 0, c->stream>>>(s->perm.as<int64_t>(), rows, nn, nq, d_idx, d_dist,
+                                                                      s->emit_idx.as<int64_t>(), s->emit_dist.as<double>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    ANN_TRY(ann_d2h(c, out_idx, s->emit_idx.p, sizeof(int64_t) * (size_t)nq * nn));
+    return ann_d2h(c, out_dist, s->emit_dist.p, sizeof(double) * (size_t)nq * nn);
 }
 
 // ------------------------------------------------ raw device memory for host-staged gathers

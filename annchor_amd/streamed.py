@@ -167,11 +167,13 @@ class StreamedAnnchor:
         np.random.seed(self.random_seed)
         ix = int(np.random.randint(self.n_total))  # identical on every rank
         A = np.zeros(na, dtype=np.int64)
+        self.anchor_vectors = np.zeros((na, self.dim), dtype=np.float32)   # kept for query()
         for r in range(na):
             A[r] = ix
             src = owner_of(ix, self.shards)
             vec = eng.stream_get_row(ix - self.base) if comm.rank == src else None
             vec = comm.bcast_array(vec, src, self.dim, np.float32)
+            self.anchor_vectors[r] = vec
             lmax, larg = eng.stream_anchor_round(vec, r, na)
             ix = combine_argmax(comm.allgather_obj((float(lmax), int(self.base + larg))))
         self.A = A
@@ -209,7 +211,8 @@ class StreamedAnnchor:
         row_ids, idx, dist, tile_evals = eng.stream_knn(ptrs, n_all, nt_all, self.n_anchors, dimp, comm.rank * nt, nt,
                                                         self.n_neighbors, self.p_work, n_local=self.n_local)
         t4 = time.perf_counter()
-        del keep
+        # the ordered column arrays (all ranks' shards) stay alive: query() runs against them
+        self._columns = dict(ptrs=ptrs, n_all=n_all, nt_all=nt_all, dimp=dimp, keep=keep)
         if row_ids is None:   # rows already in this shard's order (emitted on the device)
             ng_idx, ng_dist = idx, dist
         else:                 # tile order + global row ids: reorder on the host
@@ -225,6 +228,32 @@ class StreamedAnnchor:
         self.n_tiles_total = nt_all
         self.timings = dict(get_anchors=t1 - t0, order=t2 - t1, exchange=t3 - t2, knn=t4 - t3, total=time.perf_counter() - t0)
         return self
+
+    def query(self, Q, nn=15, p_work=0.1, device=None):
+        """The nn nearest data rows of every row of Q (indices [nq, nn] into the global row
+        numbering, distances [nq, nn]) -- Annchor.query (annchor.py:643-683) for the streamed
+        form: the queries get the fitted anchors' distances, are ordered into tiles like the data,
+        and every query tile evaluates its best-ranked ceil(p_work * #tiles) data tiles with the
+        same kernel.  Any rank can answer: after fit() each holds all ordered shards."""
+        from . import _native
+
+        if not hasattr(self, "_columns"):
+            raise RuntimeError("fit() first")
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        if Q.ndim != 2 or Q.shape[1] != self.dim:
+            raise ValueError("queries must be float32 [nq, %d]" % self.dim)
+        qe = _native.Engine(self._engine.device if device is None else device)
+        try:
+            qe.stream_bind(Q, 0)
+            for r in range(self.n_anchors):
+                qe.stream_anchor_round(self.anchor_vectors[r], r, self.n_anchors)
+            _, _, _, dimp = qe.stream_order(0)
+            c = self._columns
+            idx, dist, tile_evals = qe.stream_query(c["ptrs"], c["n_all"], c["nt_all"], self.n_anchors, dimp, nn, p_work)
+        finally:
+            qe.close()
+        self.evals += int(tile_evals) * TILE * TILE
+        return idx, dist
 
     def gather_graph(self):
         """Full graph (all shards, global row order) on every rank: the final

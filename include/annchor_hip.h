@@ -236,6 +236,15 @@ int annchor_stream_knn(annchor_ctx *ctx, const void *Xs_all, const void *rs_all,
                        const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors, int32_t dim_padded,
                        int32_t tile_begin, int32_t tile_count, int32_t k, double p_work, int64_t *row_ids,
                        int64_t *ng_idx, double *ng_dist, int64_t *tile_evals);
+/* Queries against a fitted data set in the streamed form (Annchor.query, annchor.py:643-683 ->
+ * query_functions.py:183-212, for data sets beyond the pair-list form).  The context holds
+ * the QUERY rows: bound with annchor_stream_bind (global_base 0), given the data set's anchor
+ * vectors through annchor_stream_anchor_round, ordered with annchor_stream_order.  The six
+ * column arrays are the data set's.  out_idx int64 [nq, nn] (global ids), out_dist float64
+ * [nq, nn], in the queries' own order. */
+int annchor_stream_query(annchor_ctx *ctx, const void *Xs_all, const void *rs_all, const void *perm_all, const void *lo_all,
+                         const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors, int32_t dim_padded,
+                         int32_t nn, double p_work, int64_t *out_idx, double *out_dist, int64_t *tile_evals);
 /* Raw device copies for hosts that stage the all-gather through host memory. */
 int annchor_device_alloc(annchor_ctx *ctx, int64_t bytes, void **dptr);
 int annchor_device_free(annchor_ctx *ctx, void *dptr);
