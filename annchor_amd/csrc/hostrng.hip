@@ -176,6 +176,29 @@ struct Stream {
 
 std::mutex g_mu;
 std::map<uint32_t, std::shared_ptr<Stream>> g_streams;
+// Finished streams are kept (the stream is a pure function of the seed, and the default seed is
+// the same for every Annchor): a later fit with the same seed finds its words already there.
+// At most RNG_CACHE_ENTRIES streams of at most RNG_CACHE_MAX_WORDS words, least recently used out.
+constexpr size_t RNG_CACHE_ENTRIES = 4, RNG_CACHE_MAX_WORDS = 16u << 20;   // 64 MB each
+std::vector<std::pair<uint32_t, std::shared_ptr<Stream>>> g_cache;   // most recent last
+
+std::shared_ptr<Stream> cache_take(uint32_t seed)   // g_mu held
+{
+    for (size_t i = 0; i < g_cache.size(); ++i)
+        if (g_cache[i].first == seed) {
+            auto st = g_cache[i].second;
+            g_cache.erase(g_cache.begin() + (long)i);
+            return st;
+        }
+    return nullptr;
+}
+void cache_put(uint32_t seed, const std::shared_ptr<Stream> &st)   // g_mu held
+{
+    if (st->producing.load() || st->ready.load() > RNG_CACHE_MAX_WORDS) return;
+    if (st->producer.joinable()) st->producer.join();
+    g_cache.push_back({seed, st});
+    if (g_cache.size() > RNG_CACHE_ENTRIES) g_cache.erase(g_cache.begin());
+}
 
 // Per-bin scratch kept across calls (grow-only; `bits` all zero and `slot_of` all -1
 // between uses) so that a call neither allocates nor first-touches megabytes.
@@ -355,6 +378,11 @@ template <bool STORE> __attribute__((target("avx512f,avx512bw,popcnt"))) void sc
 extern "C" int annchor_legacy_prefetch(uint32_t seed, int64_t ndraws)
 {
     if (ndraws <= 0 || ndraws > (1ll << 33)) return ANNCHOR_EINVAL;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto &e : g_cache)
+            if (e.first == seed && e.second->ready.load() >= (size_t)ndraws) return ANNCHOR_OK;   // already generated
+    }
     auto s = std::make_shared<Stream>();
     s->start(seed, (size_t)ndraws, true);
     std::lock_guard<std::mutex> lk(g_mu);
@@ -375,7 +403,8 @@ extern "C" int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts,
     {
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g_streams.find(seed);
-        if (it != g_streams.end()) { st = it->second; g_streams.erase(it); }  // a stream is consumed once
+        if (it != g_streams.end()) { st = it->second; g_streams.erase(it); }   // prefetched for this call
+        else st = cache_take(seed);                                           // generated by an earlier call
     }
     if (!st) {
         st = std::make_shared<Stream>();
@@ -384,6 +413,15 @@ extern "C" int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts,
         st->start(seed, (size_t)(tot + tot / 2 + 1024), false);
     }
     std::lock_guard<std::mutex> call_lk(g_call_mu);
+    struct Keep {   // on every way out: the (finished) stream goes to the per-seed cache
+        uint32_t seed;
+        std::shared_ptr<Stream> &st;
+        ~Keep()
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            cache_put(seed, st);
+        }
+    } keep{seed, st};
     while (g_scratch.size() < (size_t)nbins) g_scratch.emplace_back(new BinScratch());
     Scan S{st.get(), 0};  // next unread word of the stream
     std::vector<int64_t> offs((size_t)nbins + 1, 0);
