@@ -53,6 +53,7 @@ _SIGNATURES = {
     "annchor_kth_uncomputed_dad": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
     "annchor_bin_counts": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
     "annchor_select_by_rank": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _vp]),
+    "annchor_sample_pairs": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "annchor_legacy_prefetch": (ctypes.c_int, [ctypes.c_uint32, _i64]),
     "annchor_legacy_choice_ranks": (ctypes.c_int, [ctypes.c_uint32, _vp, _vp, _i32, _vp, _vp]),
     "annchor_gather_features": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
@@ -280,6 +281,16 @@ class Engine:
         self._chk(self.lib.annchor_select_by_rank(self.h, _ptr(bins), len(bins) - 1, _ptr(bin_of), _ptr(ranks),
                                                   len(ranks), _ptr(out)))
         return out
+
+    def sample_pairs(self, bins, counts, bin_of, ranks):
+        """select_by_rank + gather_features + evaluate_samples in one call (device metric only)."""
+        bins, counts = _c(bins, np.float64), _c(counts, np.int64)
+        bin_of, ranks = _c(bin_of, np.int32), _c(ranks, np.int64)
+        m = len(ranks)
+        pos, feats, y = np.empty(m, dtype=np.int64), np.empty((m, 4), dtype=np.float64), np.empty(m, dtype=np.float64)
+        self._chk(self.lib.annchor_sample_pairs(self.h, _ptr(bins), len(bins) - 1, _ptr(counts), _ptr(bin_of), _ptr(ranks), m,
+                                                _ptr(pos), _ptr(feats), _ptr(y)))
+        return pos, feats, y
 
     def gather_features(self, pos):
         pos = _c(pos, np.int64)

@@ -238,6 +238,12 @@ class Annchor:
             ticket, self._sample_ticket = self._sample_ticket, None
             if ticket is None:
                 ticket = self.sampler.begin_device(eng, self.n_samples, self.random_seed)
+            if self._device_metric:   # positions, feature rows and distances in one device pass
+                (self.sample_ixs, self.n_samples, self.sample_bins, self.sample_features,
+                 self.sample_y) = self.sampler.finish_device(ticket, evaluate=True)
+                self._invalidate("ncm")
+                self.evals += self.sample_y.shape[0]
+                return
             self.sample_ixs, self.n_samples, self.sample_bins = self.sampler.finish_device(ticket)
         else:
             self.sample_ixs, self.n_samples, self.sample_bins = self.sampler.sample(

@@ -259,20 +259,19 @@ __global__ void k_scatter_slots(const int32_t *__restrict__ bin_of, const int64_
     if (t < nreq) slotmap[binbase[bin_of[t]] + ranks[t]] = (int32_t)t;
 }
 
-extern "C" int annchor_select_by_rank(annchor_ctx *c, const double *bins, int32_t nbins, const int32_t *bin_of,
-                                      const int64_t *ranks, int64_t nreq, int64_t *positions)
+// positions (int64, device: c->stage_out) of the requested (bin, rank) entries; counts_opt = the
+// per-bin totals if the caller already holds them (annchor_bin_counts), else they are recounted
+static int select_by_rank_device(annchor_ctx *c, const double *bins, int32_t nbins, const int64_t *counts_opt,
+                                 const int32_t *bin_of, const int64_t *ranks, int64_t nreq)
 {
-    if (!c || !bins || (nreq > 0 && (!bin_of || !ranks || !positions))) return ANNCHOR_EINVAL;
-    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
-    if (nreq == 0) return ANNCHOR_OK;
-    ANN_CHECK_HIP(c, hipSetDevice(c->device));
     BinEdges be;
     ANN_TRY(load_bins(c, bins, nbins, be));
     const int64_t n = c->n;
     const int nblocks = ann_blocks(n, RB_TILE);
     // per-bin totals (host needs them to lay out the slot map)
     std::vector<int64_t> counts((size_t)nbins), base((size_t)nbins + 1, 0);
-    ANN_TRY(annchor_bin_counts(c, bins, nbins, counts.data()));
+    if (counts_opt) for (int b = 0; b < nbins; ++b) counts[(size_t)b] = counts_opt[b];
+    else ANN_TRY(annchor_bin_counts(c, bins, nbins, counts.data()));
     for (int b = 0; b < nbins; ++b) base[(size_t)b + 1] = base[(size_t)b] + counts[(size_t)b];
     for (int64_t t = 0; t < nreq; ++t) {
         ANN_REQUIRE(c, bin_of[t] >= 0 && bin_of[t] < nbins, ANNCHOR_EINVAL, "bin index out of range");
@@ -303,6 +302,17 @@ extern "C" int annchor_select_by_rank(annchor_ctx *c, const double *bins, int32_
                                                 c->tmp1.as<int64_t>(), c->tmp0.as<int32_t>(), c->stage_out.as<int64_t>());
     }
     ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_select_by_rank(annchor_ctx *c, const double *bins, int32_t nbins, const int32_t *bin_of,
+                                      const int64_t *ranks, int64_t nreq, int64_t *positions)
+{
+    if (!c || !bins || (nreq > 0 && (!bin_of || !ranks || !positions))) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    if (nreq == 0) return ANNCHOR_OK;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(select_by_rank_device(c, bins, nbins, nullptr, bin_of, ranks, nreq));
     return ann_d2h(c, positions, c->stage_out.p, sizeof(int64_t) * (size_t)nreq);
 }
 
@@ -374,6 +384,59 @@ extern "C" int annchor_evaluate_samples(annchor_ctx *c, const int64_t *pos, int6
     k_clear_flags<<<ann_blocks(m, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), m, c->ncm.as<uint8_t>());
     ANN_CHECK_HIP(c, hipGetLastError());
     return ann_d2h(c, sample_y, c->sy.p, sizeof(double) * (size_t)m);
+}
+
+__global__ void k_pos_to_i32(const int64_t *__restrict__ pos, int64_t m, int32_t *__restrict__ out, int32_t *__restrict__ bad)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    if (pos[t] < 0) *bad = 1;   // a requested (bin, rank) entry was not found
+    out[t] = (int32_t)(pos[t] < 0 ? 0 : pos[t]);
+}
+
+// The built-in sampling step in one call (get_sample, annchor.py:313-343): (bin, rank) -> pair
+// positions, their feature rows, their exact distances, not_computed_mask cleared -- the
+// positions never leave the device between the steps and the host waits once.  `counts` are
+// the per-bin totals of annchor_bin_counts for the same edges.  The drawn pairs are distinct
+// not-computed pairs by construction, so the cached count drops by exactly nreq.
+extern "C" int annchor_sample_pairs(annchor_ctx *c, const double *bins, int32_t nbins, const int64_t *counts,
+                                    const int32_t *bin_of, const int64_t *ranks, int64_t nreq, int64_t *positions,
+                                    double *feats, double *sample_y)
+{
+    if (!c || !bins || !counts || (nreq > 0 && (!bin_of || !ranks || !positions || !feats || !sample_y))) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_REQUIRE(c, c->metric != ANNCHOR_METRIC_NONE, ANNCHOR_EINVAL, "no device metric bound to this context");
+    c->nsamp = nreq;
+    if (nreq == 0) return ANNCHOR_OK;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(select_by_rank_device(c, bins, nbins, counts, bin_of, ranks, nreq));
+    ANN_TRY(ann_reserve(c, c->spos, sizeof(int32_t) * (size_t)nreq + 16));
+    ANN_TRY(ann_reserve(c, c->sy, sizeof(double) * (size_t)nreq));
+    ANN_TRY(ann_reserve(c, c->tmp3, sizeof(double) * 4 * (size_t)nreq));
+    int32_t *bad = c->spos.as<int32_t>() + nreq;
+    ANN_CHECK_HIP(c, hipMemsetAsync(bad, 0, sizeof(int32_t), c->stream));
+    k_pos_to_i32<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->stage_out.as<int64_t>(), nreq, c->spos.as<int32_t>(), bad);
+    k_gather_features<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), nreq, c->lb.as<double>(),
+                                                                   c->ub.as<double>(), c->dad.as<double>(), c->anc.as<uint8_t>(),
+                                                                   c->tmp3.as<double>());
+    PairSource src;
+    src.ij = c->ij.as<int2>();
+    src.idx = c->spos.as<int32_t>();
+    src.n = nreq;
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    ANN_TRY(ann_metric_launch(c, src, c->sy.as<double>(), nullptr, nullptr));
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+    c->call_timed = true;
+    k_clear_flags<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), nreq, c->ncm.as<uint8_t>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    int32_t h_bad = 0;
+    ANN_TRY(ann_d2h(c, positions, c->stage_out.p, sizeof(int64_t) * (size_t)nreq));
+    ANN_TRY(ann_d2h(c, feats, c->tmp3.p, sizeof(double) * 4 * (size_t)nreq));
+    ANN_TRY(ann_d2h(c, sample_y, c->sy.p, sizeof(double) * (size_t)nreq));
+    ANN_TRY(ann_d2h(c, &h_bad, bad, sizeof(int32_t)));
+    ANN_REQUIRE(c, !h_bad, ANNCHOR_ESTATE, "sample_pairs: a (bin, rank) entry does not exist (stale counts?)");
+    if (c->n_unc >= 0) c->n_unc -= nreq;
+    return ANNCHOR_OK;
 }
 
 extern "C" int annchor_set_samples(annchor_ctx *c, const int64_t *pos, int64_t m, const double *sample_y)

@@ -67,9 +67,16 @@ class SimpleStratifiedLinearRegression:
             self.sample_bins = sample_bins
         self.coef_ = np.zeros((self.n_partitions, len(i_features)))
         self.intercept_ = np.zeros(self.n_partitions)
+        # bin of a sample: bins[b] < F <= bins[b + 1]  ==  number of interior edges below F.  One
+        # stable sort groups the samples (original order kept inside a bin, so every sum runs
+        # over the same numbers in the same order as with a boolean mask per bin)
+        b = np.searchsorted(self.sample_bins[1:-1], F, side="left")
+        order = np.argsort(b, kind="stable")
+        Xs, ys = sample_features[order][:, i_features], sample_y[order]
+        cuts = np.searchsorted(b[order], np.arange(self.n_partitions + 1), side="left")
         for nbin in range(self.n_partitions):
-            mask = (F > self.sample_bins[nbin]) * (F <= self.sample_bins[nbin + 1])
-            self.coef_[nbin], self.intercept_[nbin] = _ols(sample_features[mask][:, i_features], sample_y[mask])
+            lo, hi = cuts[nbin], cuts[nbin + 1]
+            self.coef_[nbin], self.intercept_[nbin] = _ols(Xs[lo:hi], ys[lo:hi])
 
     def coefficients(self):
         """(bins [nb+1], W [nb,3], c [nb]) for the fused device predict; None if the

@@ -133,7 +133,7 @@ class SimpleStratifiedSampler(Sampler):
             bin_size, remainder = n_samples // self.n_partitions, n_samples % self.n_partitions
             want = np.array([bin_size + (nbin < remainder) for nbin in range(self.n_partitions)], dtype=np.int64)
             seed = random_seed + self.loop_num
-            ticket.update(n_samples=n_samples, sample_bins=sample_bins)
+            ticket.update(n_samples=n_samples, sample_bins=sample_bins, counts=counts)
 
             def draw():
                 try:
@@ -152,7 +152,9 @@ class SimpleStratifiedSampler(Sampler):
             ticket["error"] = err
         return ticket
 
-    def finish_device(self, ticket):
+    def finish_device(self, ticket, evaluate=False):
+        """evaluate=True (device metric): also returns the samples' feature rows and exact
+        distances, from the fused annchor_sample_pairs call."""
         if ticket["thread"] is not None:
             ticket["thread"].join()
         if ticket["error"] is not None:
@@ -167,10 +169,15 @@ class SimpleStratifiedSampler(Sampler):
             ranks.append(np.asarray(r, dtype=np.int64))
         self.loop_num += 1
         bin_of, ranks = np.concatenate(bin_of), np.concatenate(ranks)
-        sample_ixs = engine.select_by_rank(sample_bins, bin_of, ranks)
+        extra = ()
+        if evaluate:
+            sample_ixs, feats, y = engine.sample_pairs(sample_bins, ticket["counts"], bin_of, ranks)
+            extra = (feats, y)
+        else:
+            sample_ixs = engine.select_by_rank(sample_bins, bin_of, ranks)
         if n_samples != sample_ixs.shape[0]:
             print("Warning: Some bins contained fewer samples than requested")
-        return sample_ixs, sample_ixs.shape[0], sample_bins
+        return (sample_ixs, sample_ixs.shape[0], sample_bins) + extra
 
 
 class ClusterSampler(Sampler):

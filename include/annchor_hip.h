@@ -157,6 +157,13 @@ int annchor_gather_features(annchor_ctx *ctx, const int64_t *pos, int64_t m, dou
 /* get_sample (annchor.py:336-343): evaluate the metric on the sample pairs, clear
  * their not_computed_mask bit, remember (positions, y) for the merge. */
 int annchor_evaluate_samples(annchor_ctx *ctx, const int64_t *pos, int64_t m, double *sample_y);
+/* The built-in sampling step in one call (get_sample, annchor.py:313-343): (bin, rank) -> pair
+ * positions [nreq], their feature rows [nreq, 4], their exact distances [nreq]; clears
+ * not_computed_mask for them.  counts = annchor_bin_counts for the same edges.  Equivalent to
+ * annchor_select_by_rank + annchor_gather_features + annchor_evaluate_samples with one host
+ * wait and no host round trip of the positions. */
+int annchor_sample_pairs(annchor_ctx *ctx, const double *bins, int32_t nbins, const int64_t *counts, const int32_t *bin_of,
+                         const int64_t *ranks, int64_t nreq, int64_t *positions, double *feats, double *sample_y);
 /* Same, when the metric was evaluated by the host. */
 int annchor_set_samples(annchor_ctx *ctx, const int64_t *pos, int64_t m, const double *sample_y);
 
