@@ -127,45 +127,25 @@ __global__ __launch_bounds__(256) void k_sel_orand(const double *__restrict__ va
     }
 }
 
-__global__ __launch_bounds__(256) void k_sel_hist(const double *__restrict__ vals, const uint8_t *__restrict__ flag,
-                                                 int64_t n, const SelState *__restrict__ st, uint32_t *__restrict__ hist)
+// One radix step for every query from the histogram of byte `pass` (thread d owns digit d):
+// st_in -> (prefix, k) after the step, returned in registers to all threads through `sh`.
+struct SelStepShared {
+    uint32_t wsum[4];
+    uint64_t prefix[SEL_MAXQ];
+    int64_t k[SEL_MAXQ];
+};
+__device__ __forceinline__ void sel_step(const SelState *st_in, const uint32_t *hist, int pass, SelStepShared &sh)
 {
-    __shared__ uint32_t lh[SEL_MAXQ * 256];
-    for (int t = threadIdx.x; t < SEL_MAXQ * 256; t += blockDim.x) lh[t] = 0;
-    __syncthreads();
-    const int nq = st->nq, pass = st->pass;
-    const int shift = 56 - 8 * pass;
-    if ((((st->vor ^ st->vand) >> shift) & 0xffull) == 0) return;  // uniform byte: k_sel_step fills it in
-    uint64_t pre[SEL_MAXQ];
-    for (int q = 0; q < SEL_MAXQ; ++q) pre[q] = st->prefix[q];
-    const uint64_t himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        if (flag && !flag[t]) continue;
-        uint64_t key = ann_key_asc(vals[t]);
-        uint32_t d = (uint32_t)(key >> shift) & 0xffu;
-        for (int q = 0; q < nq; ++q)
-            if ((key & himask) == pre[q]) atomicAdd(&lh[q * 256 + d], 1u);
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < nq * 256; t += blockDim.x)
-        if (lh[t]) atomicAdd(&hist[t], lh[t]);
-}
-
-__global__ __launch_bounds__(256) void k_sel_step(SelState *st, uint32_t *hist)
-{
-    // thread d owns digit d; one block-wide scan per query finds the bucket holding rank k
-    __shared__ uint32_t wsum[4];
-    __shared__ int64_t newk[SEL_MAXQ];
-    __shared__ int newd[SEL_MAXQ];
     const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
-    const int shift = 56 - 8 * st->pass;
-    const int nq = st->nq;
-    if ((((st->vor ^ st->vand) >> shift) & 0xffull) == 0) {
-        __syncthreads();
-        if (d < nq) st->prefix[d] |= st->vor & (0xffull << shift);
-        if (d == 0) st->pass += 1;
-        return;
+    const int shift = 56 - 8 * pass;
+    const int nq = st_in->nq;
+    const bool uniform = (((st_in->vor ^ st_in->vand) >> shift) & 0xffull) == 0;
+    if (d < nq) {
+        sh.prefix[d] = st_in->prefix[d] | (uniform ? (st_in->vor & (0xffull << shift)) : ((uint64_t)255 << shift));
+        sh.k[d] = uniform ? st_in->k[d] : 0;   // non-uniform default: rank beyond the population clamps to the maximum
     }
+    __syncthreads();
+    if (uniform) return;
     for (int q = 0; q < nq; ++q) {
         const uint32_t h = hist[q * 256 + d];
         uint32_t inc = h;
@@ -175,49 +155,88 @@ __global__ __launch_bounds__(256) void k_sel_step(SelState *st, uint32_t *hist)
             if (lane >= off) inc += o;
         }
         __syncthreads();
-        if (lane == 63) wsum[wave] = inc;
-        if (d == 0) { newd[q] = 255; newk[q] = 0; }  // rank beyond the population clamps to the maximum
+        if (lane == 63) sh.wsum[wave] = inc;
         __syncthreads();
         uint32_t base = 0;
-        for (int w = 0; w < wave; ++w) base += wsum[w];
-        const int64_t ex = (int64_t)base + inc - h, k = st->k[q];
-        if (h != 0 && k >= ex && k < ex + h) { newd[q] = d; newk[q] = k - ex; }
-        hist[q * 256 + d] = 0;
+        for (int w = 0; w < wave; ++w) base += sh.wsum[w];
+        const int64_t ex = (int64_t)base + inc - h, k = st_in->k[q];
+        if (h != 0 && k >= ex && k < ex + h) {
+            sh.prefix[q] = st_in->prefix[q] | ((uint64_t)d << shift);
+            sh.k[q] = k - ex;
+        }
     }
     __syncthreads();
-    if (d < nq) {
-        st->prefix[d] |= (uint64_t)newd[d] << shift;
-        st->k[d] = newk[d];
+}
+
+// Pass `pass` of the selection in ONE launch: every block first replays the previous pass's
+// step from that pass's (now complete) histogram -- 256 bins, a microsecond -- then histograms
+// byte `pass` of the keys under the resulting prefixes.  Block 0 also publishes the state for
+// the next launch.  (A separate one-block step kernel per pass doubled the launch count of a
+// selection that is launch bound: 17 launches of ~7 us.)  hist holds one table per pass.
+__global__ __launch_bounds__(256) void k_sel_pass(const double *__restrict__ vals, const uint8_t *__restrict__ flag, int64_t n,
+                                                 SelState *st, uint32_t *hist_all, int pass)
+{
+    __shared__ uint32_t lh[SEL_MAXQ * 256];
+    __shared__ SelStepShared sh;
+    // st[pass] = state before this pass's step is known; st[pass] is written by block 0 of this launch
+    const SelState *st_prev = st + (pass > 0 ? pass - 1 : 0);
+    const int nq = st_prev->nq;
+    if (pass > 0) sel_step(st_prev, hist_all + (size_t)(pass - 1) * SEL_MAXQ * 256, pass - 1, sh);
+    else {
+        if ((int)threadIdx.x < nq) { sh.prefix[threadIdx.x] = st_prev->prefix[threadIdx.x]; sh.k[threadIdx.x] = st_prev->k[threadIdx.x]; }
+        __syncthreads();
     }
-    if (d == 0) st->pass += 1;
+    if (blockIdx.x == 0 && pass > 0) {   // publish (prefix, k) after step pass-1 for the next launch
+        SelState *o = st + pass;
+        if ((int)threadIdx.x < nq) { o->prefix[threadIdx.x] = sh.prefix[threadIdx.x]; o->k[threadIdx.x] = sh.k[threadIdx.x]; }
+        if (threadIdx.x == 0) { o->nq = nq; o->vor = st_prev->vor; o->vand = st_prev->vand; }
+    }
+    if (pass == 8) return;   // final launch: only the last step
+    const int shift = 56 - 8 * pass;
+    if ((((st_prev->vor ^ st_prev->vand) >> shift) & 0xffull) == 0) return;  // uniform byte: the next step fills it in
+    uint32_t *hist = hist_all + (size_t)pass * SEL_MAXQ * 256;
+    for (int t = threadIdx.x; t < SEL_MAXQ * 256; t += blockDim.x) lh[t] = 0;
+    uint64_t pre[SEL_MAXQ];
+    for (int q = 0; q < SEL_MAXQ; ++q) pre[q] = q < nq ? sh.prefix[q] : 0;
+    __syncthreads();
+    const uint64_t himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        if (flag && !flag[t]) continue;
+        uint64_t key = ann_key_asc(vals[t]);
+        uint32_t d = (uint32_t)(key >> shift) & 0xffu;
+        for (int q = 0; q < nq; ++q)
+            if ((key & himask) == (pre[q] & himask)) atomicAdd(&lh[q * 256 + d], 1u);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nq * 256; t += blockDim.x)
+        if (lh[t]) atomicAdd(&hist[t], lh[t]);
 }
 
 int ann_kth_smallest(annchor_ctx *c, const double *vals, const uint8_t *flag, int64_t n, const int64_t *ks, int nk,
                      double *h_out)
 {
     ANN_REQUIRE(c, nk >= 1 && nk <= SEL_MAXQ, ANNCHOR_EINVAL, "kth_smallest: 1..%d ranks per call", SEL_MAXQ);
-    ANN_TRY(ann_reserve(c, c->sel_state, sizeof(SelState)));
-    ANN_TRY(ann_reserve(c, c->sel_hist, sizeof(uint32_t) * SEL_MAXQ * 256));
+    ANN_TRY(ann_reserve(c, c->sel_state, sizeof(SelState) * 9));   // state before pass 0 .. after pass 7
+    ANN_TRY(ann_reserve(c, c->sel_hist, sizeof(uint32_t) * 8 * SEL_MAXQ * 256));
     SelState h;
     memset(&h, 0, sizeof h);
     h.nq = nk;
     for (int q = 0; q < nk; ++q) h.k[q] = ks[q];
     h.vor = 0; h.vand = ~0ull;
     ANN_TRY(ann_h2d(c, c->sel_state.p, &h, sizeof h));
-    ANN_CHECK_HIP(c, hipMemsetAsync(c->sel_hist.p, 0, sizeof(uint32_t) * SEL_MAXQ * 256, c->stream));
+    ANN_CHECK_HIP(c, hipMemsetAsync(c->sel_hist.p, 0, sizeof(uint32_t) * 8 * SEL_MAXQ * 256, c->stream));
     int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
     if (blocks > c->prop.multiProcessorCount * 4) blocks = c->prop.multiProcessorCount * 4;
     if (blocks < 1) blocks = 1;
     {
         ProfScope ps(c, "radix_select_f64", (double)n * 9 * 8);
         k_sel_orand<<<blocks, 256, 0, c->stream>>>(vals, flag, n, c->sel_state.as<SelState>());
-        for (int pass = 0; pass < 8; ++pass) {
-            k_sel_hist<<<blocks, 256, 0, c->stream>>>(vals, flag, n, c->sel_state.as<SelState>(), c->sel_hist.as<uint32_t>());
-            k_sel_step<<<1, 256, 0, c->stream>>>(c->sel_state.as<SelState>(), c->sel_hist.as<uint32_t>());
-        }
+        for (int pass = 0; pass < 8; ++pass)
+            k_sel_pass<<<blocks, 256, 0, c->stream>>>(vals, flag, n, c->sel_state.as<SelState>(), c->sel_hist.as<uint32_t>(), pass);
+        k_sel_pass<<<1, 256, 0, c->stream>>>(vals, flag, n, c->sel_state.as<SelState>(), c->sel_hist.as<uint32_t>(), 8);
     }
     ANN_CHECK_HIP(c, hipGetLastError());
-    ANN_TRY(ann_d2h(c, &h, c->sel_state.p, sizeof h));
+    ANN_TRY(ann_d2h(c, &h, c->sel_state.as<SelState>() + 8, sizeof h));
     for (int q = 0; q < nk; ++q) {
         uint64_t key = h.prefix[q];
         uint64_t u = (key & 0x8000000000000000ull) ? (key & 0x7fffffffffffffffull) : ~key;
