@@ -225,12 +225,12 @@ __global__ __launch_bounds__(256) void k_gn_sweep_ring(int64_t nx, int nmin, int
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Lw = (L + 31) / 32;
     const int BL = GN_B * L;                                   // entries per batch
-    double *rval = reinterpret_cast<double *>(dyn);            // [2][BL]
-    int32_t *rpos = reinterpret_cast<int32_t *>(rval + 2 * BL);  // [2][BL]
-    int32_t *roth = rpos + 2 * BL, *rtwin = roth + 2 * BL;     // [2][BL] each
-    int32_t *rcnt = rtwin + 2 * BL, *rncomp = rcnt + 2 * GN_B; // [2][GN_B] each
-    uint32_t *mflag = reinterpret_cast<uint32_t *>(rncomp + 2 * GN_B);  // [nx][Lw]
-    int32_t *mcount = reinterpret_cast<int32_t *>(mflag + (size_t)nx * Lw);  // [nx]
+    double *rval = reinterpret_cast<double *>(dyn);                      // [2][BL] + 64 slack
+    int32_t *rpos = reinterpret_cast<int32_t *>(rval + 2 * BL + 64);     // [2][BL] + 64 slack
+    int32_t *roth = rpos + 2 * BL + 64, *rtwin = roth + 2 * BL + 64;     // [2][BL] + 64 slack each
+    int32_t *rcnt = rtwin + 2 * BL + 64, *rncomp = rcnt + 2 * GN_B;      // [2][GN_B] each
+    uint32_t *mflag = reinterpret_cast<uint32_t *>(rncomp + 2 * GN_B);   // [nx][Lw] + 2 slack
+    int32_t *mcount = reinterpret_cast<int32_t *>(mflag + (size_t)nx * Lw + 2);  // [nx]
     for (int64_t t = threadIdx.x; t < nx * Lw; t += 256) mflag[t] = 0;
     for (int64_t t = threadIdx.x; t < nx; t += 256) mcount[t] = 0;
     constexpr int PER = (GN_B * GN_LMAX + 255) / 256;          // 8 entries per thread at most
@@ -278,11 +278,16 @@ __global__ __launch_bounds__(256) void k_gn_sweep_ring(int64_t nx, int nmin, int
                 const int e = lane;   // L <= 64: one entry per lane
                 const int cnt = rcnt[slot * GN_B + rr], ncomp = rncomp[slot * GN_B + rr];
                 const int mc = mcount[i];
-                const uint32_t fl = e < L ? mflag[i * Lw + (e >> 5)] : 0u;
-                const double v = e < L ? rval[slot * BL + rr * L + e] : 0.0;
-                const int32_t p = e < L ? rpos[slot * BL + rr * L + e] : 0;
-                const int32_t o = e < L ? roth[slot * BL + rr * L + e] : 0;
-                const int32_t tw = e < L ? rtwin[slot * BL + rr * L + e] : -1;
+                // UNCONDITIONAL loads (lanes >= L read the next row's entries / the slack behind
+                // the ring: never used, `um` masks them with e < cnt <= L): a predicated load
+                // becomes an exec-mask branch per operand, which split this block into several
+                // LDS round trips
+                uint32_t fl = mflag[i * Lw + (e >> 5)];
+                asm volatile("" : "+v"(fl));   // keep this load with the others (hipcc sinks it under `e < cnt`: a second round trip)
+                const double v = rval[slot * BL + rr * L + e];
+                const int32_t p = rpos[slot * BL + rr * L + e];
+                const int32_t o = roth[slot * BL + rr * L + e];
+                const int32_t tw = rtwin[slot * BL + rr * L + e];
                 const int ntodo = nmin - ncomp;
                 const int need = ntodo + 1 - mc;
                 const bool empty = cnt == 0 && ncomp == 0;
@@ -593,7 +598,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
                 c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(), cap);
         }
         const size_t sweep_lds = (size_t)nx * (((size_t)L + 31) / 32 * 4 + 4);
-        const size_t ring_lds = sweep_lds + 2 * (size_t)GN_B * L * 20 + 4 * GN_B * 4 + 64;
+        const size_t ring_lds = sweep_lds + 2 * (size_t)GN_B * L * 20 + 64 * 20 + 4 * GN_B * 4 + 64 + 16;
         if (L <= GN_LMAX && ring_lds <= 156 * 1024) {
             ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 21.0);
             int32_t *oth = c->gl_pos.as<int32_t>() + (size_t)nx * L, *twin = oth + (size_t)nx * L;
