@@ -27,6 +27,7 @@ from .samplers import NothingToSample, SimpleStratifiedSampler
 from .utils import get_exact_ijs_, get_function_from_input, test_parallelisation
 
 from .distances import euclidean as distances_euclidean  # noqa: E402
+from .distances import cosine as distances_cosine  # noqa: E402
 
 PAIRLIST_MAX_POINTS = 20000  # above this the candidate pair list (~nx^2/2 x ~100 B) is not materialised
 
@@ -113,11 +114,21 @@ class Annchor:
         # the reference would hold ~nx^2/2 entries (hard part 3).
         self._streamed = None
         defaults = anchor_picker is None and sampler is None and regression is None and error_predictor is None
-        if (self.f is distances_euclidean and get_exact_ijs is None and defaults and self.nx > PAIRLIST_MAX_POINTS
-                and getattr(np.asarray(X), "ndim", 0) == 2 and np.asarray(X).shape[1] <= 256):
+        self._cosine_streamed = False
+        if ((self.f is distances_euclidean or self.f is distances_cosine) and get_exact_ijs is None and defaults
+                and self.nx > PAIRLIST_MAX_POINTS and getattr(np.asarray(X), "ndim", 0) == 2 and np.asarray(X).shape[1] <= 256):
             from .streamed import StreamedAnnchor
 
-            self._streamed = StreamedAnnchor(np.asarray(X, dtype=np.float32), n_anchors=n_anchors, n_neighbors=n_neighbors,
+            Xs = np.asarray(X, dtype=np.float32)
+            if self.f is distances_cosine:
+                # on the unit sphere |u - v|^2 = 2 - 2 cos(u, v): cosine distance = (Euclidean distance)^2 / 2
+                # of the normalised rows, the same neighbours in the same order
+                norms = np.linalg.norm(Xs.astype(np.float64), axis=1)
+                if not np.all(norms > 0):
+                    raise ValueError("cosine distance is undefined for zero rows")
+                Xs = (Xs / norms[:, None]).astype(np.float32)
+                self._cosine_streamed = True
+            self._streamed = StreamedAnnchor(Xs, n_anchors=n_anchors, n_neighbors=n_neighbors,
                                              p_work=self.p_work, random_seed=random_seed, device=device)
             self._engine = self._streamed._engine
             self._device_metric = True
@@ -338,6 +349,8 @@ class Annchor:
         if self._streamed is not None:
             st = self._streamed.fit()
             self.neighbor_graph = st.neighbor_graph
+            if self._cosine_streamed:
+                self.neighbor_graph = (st.neighbor_graph[0], st.neighbor_graph[1] ** 2 / 2.0)
             self._cache["A"] = st.A
             self.evals, self.timings = st.evals, st.timings
             return self
@@ -390,7 +403,11 @@ class Annchor:
         `get_exact_query_ijs(f, X, Z, IJ)` (pairs index (X[i], Z[j])) replaces the metric
         evaluator as in the reference."""
         if self._streamed is not None:   # large float32 Euclidean data: tile-granular query, same kernel as fit()
-            return self._streamed.query(np.asarray(Q, dtype=np.float32), nn=nn, p_work=p_work)
+            Qs = np.asarray(Q, dtype=np.float32)
+            if self._cosine_streamed:
+                Qs = (Qs / np.linalg.norm(Qs.astype(np.float64), axis=1)[:, None]).astype(np.float32)
+            idx, dist = self._streamed.query(Qs, nn=nn, p_work=p_work)
+            return (idx, dist ** 2 / 2.0) if self._cosine_streamed else (idx, dist)
         if self.p_work > 1:
             print("Warning: p_work should not exceed 1.  Setting it to 1.")
             self.p_work = 1.0

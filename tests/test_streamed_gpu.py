@@ -223,3 +223,24 @@ def test_streamed_query_matches_brute_force():
     ann = Annchor(X, "euclidean", n_anchors=16, n_neighbors=8, p_work=1.0).fit()
     i3, d3 = ann.query(Q[:100], nn=k, p_work=1.0)
     np.testing.assert_allclose(d3, bd[:100], rtol=1e-5, atol=1e-6)
+
+
+def test_annchor_cosine_large_n_uses_streamed_form():
+    """'cosine' above the pair-list size: rows normalised, streamed Euclidean form, distances
+    mapped back with d_cos = d_euclid^2 / 2 (exact on the unit sphere).  Tolerance 2e-6 absolute
+    (float32 rows; scipy's cosine on float32 data is no tighter)."""
+    from annchor_amd import Annchor
+
+    n, k = 21000, 8
+    X = latent(n, 48) + 0.3
+    ann = Annchor(X, "cosine", n_anchors=12, n_neighbors=k, p_work=1.0).fit()
+    idx, dist = ann.neighbor_graph
+    Xn = X.astype(np.float64) / np.linalg.norm(X.astype(np.float64), axis=1)[:, None]
+    rows = np.random.default_rng(4).choice(n, 300, replace=False)
+    C = 1.0 - Xn[rows] @ Xn.T
+    C[np.arange(300), rows] = -1.0
+    want = np.sort(C, axis=1)[:, :k]
+    want[:, 0] = 0.0
+    np.testing.assert_allclose(dist[rows], want, rtol=0, atol=2e-6)
+    qi, qd = ann.query(X[:50] * 3.0, nn=4, p_work=1.0)   # scaling a query does not change its cosine distances
+    assert np.array_equal(qi[:, 0], np.arange(50)) and np.all(qd[:, 0] < 2e-6)
