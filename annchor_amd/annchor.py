@@ -499,15 +499,30 @@ class Annchor:
         return enemies.alpha_rss(self, y, dne=dne, alpha=alpha)
 
     def to_sparse_matrix(self):
-        """annchor.py:625-641: DOK sparse distance matrix of the k-NN graph."""
-        from scipy.sparse import dok_matrix
+        """annchor.py:625-641: DOK sparse distance matrix of the k-NN graph (symmetric; every
+        stored entry carries eps = nextafter(0, 1) so that explicit zeros survive).  Built from
+        flat arrays (the reference fills the DOK cell by cell); where a pair is listed from both
+        sides the later row's value wins, as in the reference's loop order."""
+        from scipy.sparse import coo_matrix
 
-        D = dok_matrix((self.nx, self.nx), dtype=np.float64)
+        idx, dist = self.neighbor_graph
+        nx, k = idx.shape
         eps = np.nextafter(0, 1, dtype=np.float64)
-        for i, (js, ds) in enumerate(zip(*self.neighbor_graph)):
-            for j, d in zip(js, ds):
-                D[i, j] = D[j, i] = d + eps
-        return D
+        i = np.repeat(np.arange(nx, dtype=np.int64), k)
+        j = idx.ravel().astype(np.int64)
+        v = dist.ravel() + eps
+        # reference order of assignments: for i, for j in row i: D[i, j] = D[j, i] = v
+        rows = np.stack([i, j], axis=1).ravel()
+        cols = np.stack([j, i], axis=1).ravel()
+        vals = np.repeat(v, 2)
+        key = rows * nx + cols
+        # keep the LAST assignment of every cell
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        last = np.ones(ks.shape[0], dtype=bool)
+        last[:-1] = ks[1:] != ks[:-1]
+        sel = order[last]
+        return coo_matrix((vals[sel], (rows[sel], cols[sel])), shape=(nx, nx), dtype=np.float64).todok()
 
 
 class BruteForce:

@@ -190,3 +190,31 @@ def test_library_rng_parallel_path_matches_numpy():
         np.random.seed(seed)
         ref = [np.arange(c) if c < w else np.random.permutation(int(c))[:w] for c, w in zip(counts, want)]
         assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+
+
+def test_to_sparse_matrix_equals_reference_loop():
+    """annchor.py:625-641: vectorised construction == the reference's cell-by-cell DOK fill
+    (symmetric, eps on every stored entry, later assignment wins)."""
+    from scipy.sparse import dok_matrix
+
+    from annchor_amd.annchor import Annchor
+
+    rng = np.random.default_rng(0)
+    nx, k = 200, 6
+    idx = np.stack([np.r_[i, rng.choice(np.delete(np.arange(nx), i), k - 1, replace=False)] for i in range(nx)])
+    dist = np.sort(rng.random((nx, k)), axis=1)
+    dist[:, 0] = 0
+
+    class Holder:
+        pass
+
+    a = Holder()
+    a.neighbor_graph, a.nx = (idx, dist), nx
+    got = Annchor.to_sparse_matrix(a)
+    want = dok_matrix((nx, nx), dtype=np.float64)
+    eps = np.nextafter(0, 1)
+    for i, (js, ds) in enumerate(zip(idx, dist)):
+        for j, d in zip(js, ds):
+            want[i, j] = want[j, i] = d + eps
+    assert isinstance(got, dok_matrix) and (got != want).nnz == 0 and got.nnz == want.nnz
+    assert got[5, 5] == eps   # explicit zero survives
