@@ -269,42 +269,74 @@ __global__ __launch_bounds__(256) void k_gn_sweep_ring(int64_t nx, int nmin, int
         const int slot = b & 1;
         if (b + 1 < nbatch) load(b + 1);
         if (wave == 0) {
-            for (int rr = 0; rr < GN_B; ++rr) {
-                const int64_t i = (int64_t)b * GN_B + rr;
-                if (i >= nx) break;
-                // every LDS operand of the row is requested up front (one round trip), the
-                // decisions are then pure register work; LDS is in-order per wave, so these
-                // reads observe the marks the previous row just issued
-                const int e = lane;   // L <= 64: one entry per lane
-                const int cnt = rcnt[slot * GN_B + rr], ncomp = rncomp[slot * GN_B + rr];
-                const int mc = mcount[i];
+            // Software pipeline over the rows of the batch: the nine LDS operands of row rr+1
+            // are requested before row rr is decided, so their latency hides behind row rr's
+            // register work.  They cannot contain row rr's own marks; at most one of those can
+            // concern row rr+1 (the pair (i, i+1) is unique) and it is applied to the prefetched
+            // registers directly.  Marks of earlier rows are in LDS already (a wave's LDS
+            // operations execute in order).
+            const int e = lane;   // L <= 64: one entry per lane
+            struct RowOps { int cnt, ncomp, mc; uint32_t fl; double v; int32_t p, o, tw; };
+            auto fetch = [&](int rr, int64_t i) {
+                RowOps r;
+                r.cnt = rcnt[slot * GN_B + rr]; r.ncomp = rncomp[slot * GN_B + rr];
+                r.mc = mcount[i];
                 // UNCONDITIONAL loads (lanes >= L read the next row's entries / the slack behind
                 // the ring: never used, `um` masks them with e < cnt <= L): a predicated load
-                // becomes an exec-mask branch per operand, which split this block into several
+                // becomes an exec-mask branch per operand and splits the block into several
                 // LDS round trips
-                uint32_t fl = mflag[i * Lw + (e >> 5)];
-                asm volatile("" : "+v"(fl));   // keep this load with the others (hipcc sinks it under `e < cnt`: a second round trip)
-                const double v = rval[slot * BL + rr * L + e];
-                const int32_t p = rpos[slot * BL + rr * L + e];
-                const int32_t o = roth[slot * BL + rr * L + e];
-                const int32_t tw = rtwin[slot * BL + rr * L + e];
+                r.fl = mflag[i * Lw + (e >> 5)];
+                r.v = rval[slot * BL + rr * L + e];
+                r.p = rpos[slot * BL + rr * L + e];
+                r.o = roth[slot * BL + rr * L + e];
+                r.tw = rtwin[slot * BL + rr * L + e];
+                return r;
+            };
+            const int64_t i0 = (int64_t)b * GN_B;
+            const int nrows = (int)min((int64_t)GN_B, nx - i0);
+            RowOps cur = fetch(0, i0);
+            for (int rr = 0; rr < nrows; ++rr) {
+                const int64_t i = i0 + rr;
+                const bool more = rr + 1 < nrows;
+                RowOps nxt = cur;
+                if (more) nxt = fetch(rr + 1, i + 1);
+                asm volatile("" : "+v"(nxt.fl), "+v"(nxt.p), "+v"(nxt.o), "+v"(nxt.tw));   // keep the prefetch here
+                const int cnt = cur.cnt, ncomp = cur.ncomp, mc = cur.mc;
+                const uint32_t fl = cur.fl;
+                const double v = cur.v;
+                const int32_t p = cur.p, o = cur.o, tw = cur.tw;
                 const int ntodo = nmin - ncomp;
                 const int need = ntodo + 1 - mc;
                 const bool empty = cnt == 0 && ncomp == 0;
                 const bool um = e < cnt && !((fl >> (e & 31)) & 1u);
                 const unsigned long long m = __ballot(um);
-                if (ntodo <= 0 || empty || need <= 0) continue;
-                if ((cnt <= ntodo && cnt < L) || (int)__popcll(m) < need) { if (lane == 0) *err = 1; continue; }
-                const int myrank = __popcll(m & ((1ull << lane) - 1ull));
-                const unsigned long long hit = __ballot(um && myrank == need - 1);
-                const int src = __ffsll((unsigned long long)hit) - 1;
-                const double t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
-                                                  __builtin_amdgcn_readlane(__double2loint(v), src));
-                if (um && v < t) {
-                    RA[p] = -1.0;
-                    if (tw >= 0) atomicOr(&mflag[(int64_t)o * Lw + (tw >> 5)], 1u << (tw & 31));
-                    atomicAdd(&mcount[o], 1);
+                bool mark = false;
+                if (!(ntodo <= 0 || empty || need <= 0)) {
+                    if ((cnt <= ntodo && cnt < L) || (int)__popcll(m) < need) { if (lane == 0) *err = 1; }
+                    else {
+                        const int myrank = __popcll(m & ((1ull << lane) - 1ull));
+                        const unsigned long long hit = __ballot(um && myrank == need - 1);
+                        const int src = __ffsll((unsigned long long)hit) - 1;
+                        const double t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                                                          __builtin_amdgcn_readlane(__double2loint(v), src));
+                        mark = um && v < t;
+                        if (mark) {
+                            RA[p] = -1.0;
+                            if (tw >= 0) atomicOr(&mflag[(int64_t)o * Lw + (tw >> 5)], 1u << (tw & 31));
+                            atomicAdd(&mcount[o], 1);
+                        }
+                    }
                 }
+                if (more) {   // this row's mark on the pair (i, i+1), if any, reaches the prefetched registers
+                    const unsigned long long hn = __ballot(mark && o == (int32_t)(i + 1));
+                    if (hn) {
+                        const int srcn = __ffsll((unsigned long long)hn) - 1;
+                        const int twn = __builtin_amdgcn_readlane(tw, srcn);
+                        nxt.mc += 1;
+                        if (twn >= 0 && (e >> 5) == (twn >> 5)) nxt.fl |= 1u << (twn & 31);
+                    }
+                }
+                cur = nxt;
                 __builtin_amdgcn_wave_barrier();
             }
         }
