@@ -47,6 +47,35 @@ __global__ __launch_bounds__(RED_THREADS) void k_runmin_argmax(const double *__r
     }
 }
 
+// small data sets (one workgroup covers them): running minimum + arg-max + next anchor in ONE
+// launch -- the rounds are a chain of dependent launches, each one costs a dispatch gap
+__global__ __launch_bounds__(1024) void k_runmin_argmax_one(const double *__restrict__ row, double *__restrict__ runmin, int64_t nx,
+                                                           int reset, int32_t *__restrict__ next_anchor)
+{
+    double bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int64_t j = threadIdx.x; j < nx; j += blockDim.x) {
+        double v = row[j];
+        if (!reset) v = fmin(runmin[j], v);
+        runmin[j] = v;
+        argmax_combine(bv, bi, v, (int)j);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double ov = __shfl_xor(bv, off);
+        int oi = __shfl_xor(bi, off);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    __shared__ double sv[16];
+    __shared__ int si[16];
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) argmax_combine(bv, bi, sv[w], si[w]);
+        *next_anchor = bi;
+    }
+}
+
 __global__ void k_argmax_final(const double *__restrict__ redval, const int *__restrict__ redidx, int nblocks,
                                int32_t *__restrict__ next_anchor)
 {
@@ -124,10 +153,15 @@ extern "C" int annchor_pick_anchors_maxmin(annchor_ctx *c, int32_t na, int64_t f
         if (r + 1 < na) {
             ProfScope ps(c, "maxmin_argmax", (double)nx * 24);
             // pickers.py:47-50: min over all rows for r == 0, over rows 1..r afterwards
-            k_runmin_argmax<<<rblocks, RED_THREADS, 0, c->stream>>>(row, c->runmin.as<double>(), nx, r <= 1 ? 1 : 0,
-                                                                   c->redval.as<double>(), c->redidx.as<int>());
-            k_argmax_final<<<1, 64, 0, c->stream>>>(c->redval.as<double>(), c->redidx.as<int>(), rblocks,
-                                                   c->A.as<int32_t>() + r + 1);
+            if (nx <= 16384)
+                k_runmin_argmax_one<<<1, 1024, 0, c->stream>>>(row, c->runmin.as<double>(), nx, r <= 1 ? 1 : 0,
+                                                              c->A.as<int32_t>() + r + 1);
+            else {
+                k_runmin_argmax<<<rblocks, RED_THREADS, 0, c->stream>>>(row, c->runmin.as<double>(), nx, r <= 1 ? 1 : 0,
+                                                                       c->redval.as<double>(), c->redidx.as<int>());
+                k_argmax_final<<<1, 64, 0, c->stream>>>(c->redval.as<double>(), c->redidx.as<int>(), rblocks,
+                                                       c->A.as<int32_t>() + r + 1);
+            }
         }
     }
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
