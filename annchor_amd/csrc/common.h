@@ -86,6 +86,8 @@ struct annchor_ctx {
     bool cand_marked = false;      // not_computed_mask already cleared for the current candidates
     DevBuf gl_val, gl_pos, gl_cnt, gl_ncomp, marked, markcount;  // guarantee_nmin scratch
     DevBuf sel_hist, sel_state, blk_cnt, blk_off;                // radix select / compaction scratch
+    DevBuf sel2, sel_bufA, sel_bufB, sel_seg;                             // filter-then-finish selection: tables, candidates
+    const void *sel2_clean = nullptr;                            // sel2 tables known to be zero at this address
     DevBuf errs, errptr;
     DevBuf cptr, cidx, cval;     // computed-neighbour CSR for update_bounds
     DevBuf tmp0, tmp1, tmp2, tmp3;
@@ -166,6 +168,14 @@ __device__ __forceinline__ double ann_key_asc_inv(uint64_t k)
 {
     uint64_t u = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)u);
+}
+
+// Load at a clamped index (n > 0).  `t < n ? p[t] : x` compiles to a branch around every load
+// with an s_waitcnt vmcnt(0) after each, i.e. one memory round trip per element; clamping keeps
+// a batch of loads in flight and the caller masks the value.
+template <typename T> __device__ __forceinline__ T ann_ldc(const T *__restrict__ p, int64_t t, int64_t n)
+{
+    return p[t < n ? t : n - 1];
 }
 
 // ---- internal cross-file entry points -------------------------------------

@@ -219,7 +219,7 @@ extern "C" void annchor_destroy(annchor_ctx *c)
                       &c->Kpref, &c->deg, &c->low, &c->rowstart, &c->Iptr, &c->Iidx, &c->ij, &c->lb, &c->ub,
                       &c->dad, &c->RA, &c->prob, &c->anc, &c->ncm, &c->label, &c->spos, &c->sy, &c->thresh,
                       &c->cand, &c->next, &c->gl_val, &c->gl_pos, &c->gl_cnt, &c->gl_ncomp, &c->marked,
-                      &c->markcount, &c->sel_hist, &c->sel_state, &c->blk_cnt, &c->blk_off, &c->errs, &c->errptr,
+                      &c->markcount, &c->sel_hist, &c->sel_state, &c->sel2, &c->sel_bufA, &c->sel_bufB, &c->sel_seg, &c->blk_cnt, &c->blk_off, &c->errs, &c->errptr,
                       &c->cptr, &c->cidx, &c->cval, &c->tmp0, &c->tmp1, &c->tmp2, &c->tmp3, &c->scan_tmp,
                       &c->stage_in, &c->stage_out};
     for (DevBuf *b : bufs)

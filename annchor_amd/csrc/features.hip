@@ -29,10 +29,21 @@ __global__ __launch_bounds__(256) void k_features(const int2 *__restrict__ ij, i
     const int2 q = ij[p];
     const int i = q.x, j = q.y;
     double l = 0.0, u = INFINITY;
-    for (int a = 0; a < na; ++a) {
-        const double di = Dt[(size_t)a * nx + i], dj = Dt[(size_t)a * nx + j];
-        l = fmax(l, fabs(di - dj));
-        u = fmin(u, di + dj);
+    // eight anchors' loads in flight per step (the plain loop waited out one L2 round trip per
+    // anchor: 3.5 ms for 127 M pairs); the tail repeats the last anchor, which max / min ignore
+    for (int a0 = 0; a0 < na; a0 += 8) {
+        double di[8], dj[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const size_t row = (size_t)min(a0 + e, na - 1) * nx;
+            di[e] = Dt[row + i];
+            dj[e] = Dt[row + j];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            l = fmax(l, fabs(di[e] - dj[e]));
+            u = fmin(u, di[e] + dj[e]);
+        }
     }
     lb[p] = l;
     ub[p] = u;
@@ -82,16 +93,25 @@ __global__ __launch_bounds__(256) void k_count_flags(const uint8_t *__restrict__
     unsigned long long s = 0;
     const int64_t n16 = n >> 4;
     const uint4 *f16 = reinterpret_cast<const uint4 *>(f);
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n16; t += (int64_t)gridDim.x * blockDim.x) {
-        const uint4 v = f16[t];
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n16; t += 4 * step) {
+        uint4 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ann_ldc(f16, t + e * step, n16);
         // flags are 0/1 bytes: the byte sum of a word is its popcount
-        s += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (t + e * step < n16) s += __popc(v[e].x) + __popc(v[e].y) + __popc(v[e].z) + __popc(v[e].w);
     }
     if (blockIdx.x == 0)
         for (int64_t t = (n16 << 4) + threadIdx.x; t < n; t += blockDim.x) s += f[t] != 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+    // one atomic per workgroup: same-address atomics serialise at ~12.5 ns each (tools/microbench/atomics.hip)
+    __shared__ unsigned long long ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && (ws[0] | ws[1] | ws[2] | ws[3])) atomicAdd(out, ws[0] + ws[1] + ws[2] + ws[3]);
 }
 
 extern "C" int annchor_count_uncomputed(annchor_ctx *c, int64_t *n_unc)
@@ -102,7 +122,7 @@ extern "C" int annchor_count_uncomputed(annchor_ctx *c, int64_t *n_unc)
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     ANN_TRY(ann_reserve(c, c->tmp2, 64));
     ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp2.p, 0, 8, c->stream));
-    int blocks = min(ann_blocks(c->n, 256 * 16), c->prop.multiProcessorCount * 4);
+    int blocks = min(ann_blocks(c->n, 256 * 16 * 4), c->prop.multiProcessorCount);
     k_count_flags<<<blocks, 256, 0, c->stream>>>(c->ncm.as<uint8_t>(), c->n, c->tmp2.as<unsigned long long>());
     unsigned long long v = 0;
     ANN_TRY(ann_d2h(c, &v, c->tmp2.p, 8));
@@ -133,20 +153,41 @@ __device__ __forceinline__ int sampler_bin(const BinEdges &b, double x)
     return -1;
 }
 
-__global__ __launch_bounds__(256) void k_bin_counts(const double *__restrict__ dad, const uint8_t *__restrict__ ncm,
-                                                   int64_t n, BinEdges be, unsigned long long *__restrict__ counts)
+#define BC_THREADS 1024
+#define BC_ITEMS 8
+#define BC_TILE (BC_THREADS * BC_ITEMS)
+// Few fat workgroups (their closing atomics on the shared bin counters serialise), eight
+// unconditional loads per thread in flight, per-wave LDS counters.
+__global__ __launch_bounds__(BC_THREADS) void k_bin_counts(const double *__restrict__ dad, const uint8_t *__restrict__ ncm,
+                                                          int64_t n, BinEdges be, unsigned long long *__restrict__ counts)
 {
-    __shared__ unsigned int lc[MAXBINS];
-    for (int t = threadIdx.x; t < MAXBINS; t += blockDim.x) lc[t] = 0;
+    __shared__ unsigned int lc[BC_THREADS / 64][MAXBINS];
+    const int wave = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < (BC_THREADS / 64) * MAXBINS; t += BC_THREADS) (&lc[0][0])[t] = 0;
     __syncthreads();
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        if (!ncm[t]) continue;
-        int b = sampler_bin(be, dad[t]);
-        if (b >= 0) atomicAdd(&lc[b], 1u);
+    const int64_t ntiles = (n + BC_TILE - 1) / BC_TILE;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        double v[BC_ITEMS];
+        uint8_t f[BC_ITEMS];
+#pragma unroll
+        for (int k = 0; k < BC_ITEMS; ++k) {
+            const int64_t t = tile * BC_TILE + k * BC_THREADS + threadIdx.x;
+            v[k] = ann_ldc(dad, t, n);
+            f[k] = ann_ldc(ncm, t, n);
+            if (t >= n) f[k] = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < BC_ITEMS; ++k) {
+            const int b = f[k] ? sampler_bin(be, v[k]) : -1;
+            if (b >= 0) atomicAdd(&lc[wave][b], 1u);
+        }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < be.nb; t += blockDim.x)
-        if (lc[t]) atomicAdd(&counts[t], (unsigned long long)lc[t]);
+    if ((int)threadIdx.x < be.nb) {
+        unsigned long long s = 0;
+        for (int w = 0; w < BC_THREADS / 64; ++w) s += lc[w][threadIdx.x];
+        if (s) atomicAdd(&counts[threadIdx.x], s);
+    }
 }
 
 static int load_bins(annchor_ctx *c, const double *bins, int32_t nbins, BinEdges &be)
@@ -166,10 +207,11 @@ extern "C" int annchor_bin_counts(annchor_ctx *c, const double *bins, int32_t nb
     ANN_TRY(load_bins(c, bins, nbins, be));
     ANN_TRY(ann_reserve(c, c->tmp2, 8 * MAXBINS));
     ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp2.p, 0, 8 * MAXBINS, c->stream));
-    int blocks = min(ann_blocks(c->n, 256 * 8), c->prop.multiProcessorCount * 4);
+    const int64_t ntiles = (c->n + BC_TILE - 1) / BC_TILE;
+    const int blocks = (int)(ntiles <= 256 ? ntiles : std::min<int64_t>(1024, std::max<int64_t>(256, ntiles / 4)));
     {
         ProfScope ps(c, "sampler_bin_counts", (double)c->n * 9.0);
-        k_bin_counts<<<blocks, 256, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), c->n, be,
+        k_bin_counts<<<blocks, BC_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), c->n, be,
                                                    c->tmp2.as<unsigned long long>());
     }
     return ann_d2h(c, counts, c->tmp2.p, 8 * (size_t)nbins);
@@ -187,12 +229,19 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_count(const double *__restric
     for (int t = threadIdx.x; t < MAXBINS; t += blockDim.x) lc[t] = 0;
     __syncthreads();
     int64_t base = (int64_t)blockIdx.x * RB_TILE;
+    double v[RB_ITEMS];
+    uint8_t f[RB_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RB_ITEMS; ++k) {   // all loads in flight, masked afterwards
+        const int64_t t = base + (int64_t)k * RB_THREADS + threadIdx.x;
+        v[k] = ann_ldc(dad, t, n);
+        f[k] = ann_ldc(ncm, t, n);
+        if (t >= n) f[k] = 0;
+    }
+#pragma unroll
     for (int k = 0; k < RB_ITEMS; ++k) {
-        int64_t t = base + (int64_t)k * RB_THREADS + threadIdx.x;
-        if (t < n && ncm[t]) {
-            int b = sampler_bin(be, dad[t]);
-            if (b >= 0) atomicAdd(&lc[b], 1u);
-        }
+        const int b = f[k] ? sampler_bin(be, v[k]) : -1;
+        if (b >= 0) atomicAdd(&lc[b], 1u);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < be.nb; t += blockDim.x) blkcnt[(size_t)blockIdx.x * be.nb + t] = lc[t];
@@ -223,33 +272,57 @@ __global__ __launch_bounds__(256) void k_rb_scan(uint32_t *__restrict__ blkcnt, 
     }
 }
 
-// slotmap[binbase[b] + rank] = request slot or -1.  One wave per tile keeps the
-// in-tile order (position order) with ballots; tiles are RB_TILE long.
-__global__ __launch_bounds__(64) void k_rb_emit(const double *__restrict__ dad, const uint8_t *__restrict__ ncm, int64_t n,
-                                               BinEdges be, const uint32_t *__restrict__ blkoff,
-                                               const int64_t *__restrict__ binbase, const int32_t *__restrict__ slotmap,
-                                               int64_t *__restrict__ positions)
+// slotmap[binbase[b] + rank] = request slot or -1.  A tile is RB_TILE positions; each of the
+// four waves owns 512 consecutive ones (eight coalesced 64-wide chunks, all loaded up front),
+// counts its bins into LDS so that every wave knows where its ranks start, then ranks its own
+// elements with ballots (position order inside a chunk = lane order).
+__global__ __launch_bounds__(RB_THREADS) void k_rb_emit(const double *__restrict__ dad, const uint8_t *__restrict__ ncm, int64_t n,
+                                                       BinEdges be, const uint32_t *__restrict__ blkoff,
+                                                       const int64_t *__restrict__ binbase, const int32_t *__restrict__ slotmap,
+                                                       int64_t *__restrict__ positions)
 {
-    const int lane = threadIdx.x;
+    constexpr int CH = RB_TILE / RB_THREADS;   // chunks of 64 per wave
+    __shared__ uint32_t wcnt[RB_THREADS / 64][MAXBINS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < (RB_THREADS / 64) * MAXBINS; t += RB_THREADS) (&wcnt[0][0])[t] = 0;
+    __syncthreads();
+    const int64_t wbase = (int64_t)blockIdx.x * RB_TILE + (int64_t)wave * (CH * 64);
+    int b[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        const int64_t t = wbase + ch * 64 + lane;
+        const double v = ann_ldc(dad, t, n);
+        const uint8_t f = ann_ldc(ncm, t, n);
+        b[ch] = (t < n && f) ? sampler_bin(be, v) : -1;
+    }
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+        if (b[ch] >= 0) atomicAdd(&wcnt[wave][b[ch]], 1u);
+    __syncthreads();
     // lane k carries the running count of bin k (nb <= 64)
-    uint32_t myrun = lane < be.nb ? blkoff[(size_t)blockIdx.x * be.nb + lane] : 0u;
-    int64_t base = (int64_t)blockIdx.x * RB_TILE;
-    for (int64_t t0 = base; t0 < base + RB_TILE && t0 < n; t0 += 64) {
-        int64_t t = t0 + lane;
-        int b = -1;
-        if (t < n && ncm[t]) b = sampler_bin(be, dad[t]);
+    uint32_t myrun = 0;
+    if (lane < be.nb) {
+        myrun = blkoff[(size_t)blockIdx.x * be.nb + lane];
+        for (int w = 0; w < wave; ++w) myrun += wcnt[w][lane];
+    }
+    uint32_t rank[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        rank[ch] = 0;
         for (int k = 0; k < be.nb; ++k) {
-            unsigned long long m = __ballot(b == k);
+            const unsigned long long m = __ballot(b[ch] == k);
             if (!m) continue;
             const uint32_t rk = __shfl(myrun, k);
-            if (b == k) {
-                uint32_t r = rk + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                int32_t slot = slotmap[binbase[k] + r];
-                if (slot >= 0) positions[slot] = t;
-            }
+            if (b[ch] == k) rank[ch] = rk + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (lane == k) myrun += (uint32_t)__popcll(m);
         }
     }
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+        if (b[ch] >= 0) {
+            const int32_t slot = slotmap[binbase[b[ch]] + rank[ch]];
+            if (slot >= 0) positions[slot] = wbase + ch * 64 + lane;
+        }
 }
 
 __global__ void k_scatter_slots(const int32_t *__restrict__ bin_of, const int64_t *__restrict__ ranks, int64_t nreq,
@@ -298,7 +371,7 @@ static int select_by_rank_device(annchor_ctx *c, const double *bins, int32_t nbi
         k_rb_count<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be,
                                                          c->blk_cnt.as<uint32_t>());
         k_rb_scan<<<nbins, 256, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nblocks, nbins);
-        k_rb_emit<<<nblocks, 64, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be, c->blk_cnt.as<uint32_t>(),
+        k_rb_emit<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be, c->blk_cnt.as<uint32_t>(),
                                                 c->tmp1.as<int64_t>(), c->tmp0.as<int32_t>(), c->stage_out.as<int64_t>());
     }
     ANN_CHECK_HIP(c, hipGetLastError());

@@ -57,12 +57,14 @@ __global__ __launch_bounds__(ROW_THREADS) void k_comp_fill(const int64_t *__rest
 }
 
 // one wavefront per lookahead pair
+#define UB_STAGE 1024   // keys of the searched list a wave keeps in LDS
 __global__ __launch_bounds__(256) void k_update_bounds(const int32_t *__restrict__ next, int64_t nnext,
                                                       const int2 *__restrict__ ij, const int64_t *__restrict__ cptr,
                                                       const int32_t *__restrict__ cidx, const double *__restrict__ cval,
                                                       double *__restrict__ lb, double *__restrict__ ub)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ int32_t stage[4][UB_STAGE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (t >= nnext) return;
     const int32_t p = next[t];
@@ -70,17 +72,43 @@ __global__ __launch_bounds__(256) void k_update_bounds(const int32_t *__restrict
     int64_t a0 = cptr[q.x], a1 = cptr[q.x + 1], b0 = cptr[q.y], b1 = cptr[q.y + 1];
     if (a1 - a0 > b1 - b0) { int64_t x = a0; a0 = b0; b0 = x; x = a1; a1 = b1; b1 = x; }  // walk the shorter list
     double nl = 0.0, nu = INFINITY;
-    for (int64_t e = a0 + lane; e < a1; e += 64) {
-        const int32_t key = cidx[e];
-        int64_t lo = b0, hi = b1;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (cidx[mid] < key) lo = mid + 1; else hi = mid;
+    const int nbk = (int)(b1 - b0);
+    if (nbk <= UB_STAGE) {
+        // the searched list's keys go to LDS (one coalesced pass): ~10 dependent probes per element
+        // at LDS latency instead of L2 latency
+        int32_t *sk = stage[wave];
+        for (int e = lane; e < nbk; e += 64) sk[e] = cidx[b0 + e];
+        // (a wave's LDS writes are visible to its own later reads -- in-order LDS queue -- the
+        // fence only keeps the compiler from moving the reads above the writes)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int64_t e = a0 + lane; e < a1; e += 64) {
+            const int32_t key = cidx[e];
+            int lo = 0, hi = nbk;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (sk[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            if (lo < nbk && sk[lo] == key) {
+                const double x = cval[e], y = cval[b0 + lo];
+                nu = fmin(nu, x + y);
+                nl = fmax(nl, fabs(x - y));
+            }
         }
-        if (lo < b1 && cidx[lo] == key) {
-            const double x = cval[e], y = cval[lo];
-            nu = fmin(nu, x + y);
-            nl = fmax(nl, fabs(x - y));
+    } else {
+        for (int64_t e = a0 + lane; e < a1; e += 64) {
+            const int32_t key = cidx[e];
+            int64_t lo = b0, hi = b1;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (cidx[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            if (lo < b1 && cidx[lo] == key) {
+                const double x = cval[e], y = cval[lo];
+                nu = fmin(nu, x + y);
+                nl = fmax(nl, fabs(x - y));
+            }
         }
     }
 #pragma unroll

@@ -39,10 +39,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const int32_t 
 {
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
     int64_t s = 0;
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        int64_t t = base + (int64_t)k * SCAN_THREADS + threadIdx.x;
-        if (t < n) s += in[t];
-    }
+    int32_t v[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = ann_ldc(in, base + (int64_t)k * SCAN_THREADS + threadIdx.x, n);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + (int64_t)k * SCAN_THREADS + threadIdx.x < n) s += v[k];
     int64_t tot;
     block_exclusive_scan_i64(s, &tot);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
@@ -70,8 +72,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const int32_t *__re
     int32_t v[SCAN_ITEMS];
     int64_t s = 0;
 #pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = ann_ldc(in, base + k, n);
+#pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        v[k] = (base + k < n) ? in[base + k] : 0;
+        if (base + k >= n) v[k] = 0;
         s += v[k];
     }
     int64_t tot;
@@ -106,26 +110,6 @@ struct SelState {
     int pass;
     unsigned long long vor, vand;  // OR / AND of all (flagged) keys: equal bytes are uniform and skipped
 };
-
-__global__ __launch_bounds__(256) void k_sel_orand(const double *__restrict__ vals, const uint8_t *__restrict__ flag, int64_t n,
-                                                  SelState *__restrict__ st)
-{
-    unsigned long long o = 0, a = ~0ull;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        if (flag && !flag[t]) continue;
-        const unsigned long long key = ann_key_asc(vals[t]);
-        o |= key; a &= key;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { o |= __shfl_xor(o, off); a &= __shfl_xor(a, off); }
-    __shared__ unsigned long long so[4], sa[4];
-    if ((threadIdx.x & 63) == 0) { so[threadIdx.x >> 6] = o; sa[threadIdx.x >> 6] = a; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicOr(&st->vor, so[0] | so[1] | so[2] | so[3]);
-        atomicAnd(&st->vand, sa[0] & sa[1] & sa[2] & sa[3]);
-    }
-}
 
 // One radix step for every query from the histogram of byte `pass` (thread d owns digit d):
 // st_in -> (prefix, k) after the step, returned in registers to all threads through `sh`.
@@ -174,19 +158,20 @@ __device__ __forceinline__ void sel_step(const SelState *st_in, const uint32_t *
 // the next launch.  (A separate one-block step kernel per pass doubled the launch count of a
 // selection that is launch bound: 17 launches of ~7 us.)  hist holds one table per pass.
 __global__ __launch_bounds__(256) void k_sel_pass(const double *__restrict__ vals, const uint8_t *__restrict__ flag, int64_t n,
-                                                 SelState *st, uint32_t *hist_all, int pass)
+                                                 SelState *st, uint32_t *hist_all, int pass, int first)
 {
     __shared__ uint32_t lh[SEL_MAXQ * 256];
     __shared__ SelStepShared sh;
     // st[pass] = state before this pass's step is known; st[pass] is written by block 0 of this launch
-    const SelState *st_prev = st + (pass > 0 ? pass - 1 : 0);
+    // (first = the pass the selection starts at: its input state is st[first])
+    const SelState *st_prev = st + (pass > first ? pass - 1 : first);
     const int nq = st_prev->nq;
-    if (pass > 0) sel_step(st_prev, hist_all + (size_t)(pass - 1) * SEL_MAXQ * 256, pass - 1, sh);
+    if (pass > first) sel_step(st_prev, hist_all + (size_t)(pass - 1) * SEL_MAXQ * 256, pass - 1, sh);
     else {
         if ((int)threadIdx.x < nq) { sh.prefix[threadIdx.x] = st_prev->prefix[threadIdx.x]; sh.k[threadIdx.x] = st_prev->k[threadIdx.x]; }
         __syncthreads();
     }
-    if (blockIdx.x == 0 && pass > 0) {   // publish (prefix, k) after step pass-1 for the next launch
+    if (blockIdx.x == 0 && pass > first) {   // publish (prefix, k) after step pass-1 for the next launch
         SelState *o = st + pass;
         if ((int)threadIdx.x < nq) { o->prefix[threadIdx.x] = sh.prefix[threadIdx.x]; o->k[threadIdx.x] = sh.k[threadIdx.x]; }
         if (threadIdx.x == 0) { o->nq = nq; o->vor = st_prev->vor; o->vand = st_prev->vand; }
@@ -199,7 +184,7 @@ __global__ __launch_bounds__(256) void k_sel_pass(const double *__restrict__ val
     uint64_t pre[SEL_MAXQ];
     for (int q = 0; q < SEL_MAXQ; ++q) pre[q] = q < nq ? sh.prefix[q] : 0;
     __syncthreads();
-    const uint64_t himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+    const uint64_t himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         if (flag && !flag[t]) continue;
         uint64_t key = ann_key_asc(vals[t]);
@@ -212,33 +197,428 @@ __global__ __launch_bounds__(256) void k_sel_pass(const double *__restrict__ val
         if (lh[t]) atomicAdd(&hist[t], lh[t]);
 }
 
+// ------------------------------------------------- filter-then-finish selection
+// The byte-at-a-time selection above reads all n keys nine times in ten launches.  This one
+// reads them twice: a histogram of the top 11 key bits, then one pass that keeps only the keys
+// in the bucket(s) holding the wanted ranks while it histograms their next 11 bits.  A third
+// launch narrows the candidates by 10 more bits, and a single workgroup finishes the last 32
+// bits from LDS.  A bucket that is one repeated value (tied distances / probabilities) is
+// recognised from the OR and AND of its keys; a mixed bucket too long for LDS falls back to
+// the byte passes above.
+//
+// Atomics on ONE global address cost ~12.5 ns each on this part, serialised, returning or not
+// (tools/microbench/atomics.hip: 625 workgroups -> 8.8 us, 4096 -> 50 us), so the layout avoids
+// them: few fat workgroups (1024 threads, <= S2_MAXWG of them) flush their LDS histograms once,
+// and the candidate lists are segmented -- tile i's survivors go to slots [i*S2_TILE, ...) with
+// their count in segcnt[i] -- instead of being appended through a shared counter.
+#define S2_T 1024
+#define S2_ITEMS 8
+#define S2_TILE (S2_T * S2_ITEMS)
+#define S2_MAXWG 1024
+#define S2_NB0 2048   // bits 63..53
+#define S2_NB1 2048   // bits 52..42
+#define S2_NB2 1024   // bits 41..32
+#define S2_NB3 2048   // bits 31..21 (long lists only)
+#define S2_CAP 4096   // candidates the finishing workgroup holds in LDS
+#define S2_LEVEL3_MIN (1ll << 22)   // lists this long filter a third time (smooth keys leave ~n / 2^11 candidates per level)
+struct Sel2State {
+    uint64_t prefix[SEL_MAXQ];
+    int64_t k[SEL_MAXQ];
+    int nq, unfinished;
+    unsigned long long cnt;
+};
+struct Sel2Tables {
+    uint32_t hist0[S2_NB0];
+    uint32_t hist1[SEL_MAXQ * S2_NB1];
+    uint32_t hist2[SEL_MAXQ * S2_NB2];
+    uint32_t hist3[SEL_MAXQ * S2_NB3];
+    unsigned long long vor[SEL_MAXQ], vnand[SEL_MAXQ];   // OR of key / OR of ~key over each query's last-level candidates
+    // ---- not part of the zeroed region
+    Sel2State st1, st2, st3, out;
+};
+#define S2_ZERO_BYTES offsetof(Sel2Tables, st1)
+struct Sel2Sh {
+    uint32_t wsum[S2_T / 64];
+    int digit;
+    int64_t krem;
+};
+
+// rank k_in among NB bins (thread t owns bins t*PER..): the bin holding it and the rank inside
+// that bin.  A rank beyond the population clamps to the largest key.
+template <int NB> __device__ __forceinline__ void sel2_step(const uint32_t *hist, int64_t k_in, Sel2Sh &sh, int &digit, int64_t &krem)
+{
+    constexpr int PER = NB >= S2_T ? NB / S2_T : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t cb[PER], s = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { cb[j] = tid * PER + j < NB ? hist[tid * PER + j] : 0u; s += cb[j]; }
+    uint32_t inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) sh.wsum[wave] = inc;
+    if (tid == 0) { sh.digit = NB - 1; sh.krem = 0; }
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < S2_T / 64; ++w) { const uint32_t x = sh.wsum[w]; if (w < wave) base += x; total += x; }
+    int64_t k = k_in;
+    if (k >= (int64_t)total) k = (int64_t)total - 1;
+    int64_t ex = (int64_t)base + inc - s;
+    if (s != 0 && k >= ex && k < ex + s) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (k >= ex && k < ex + cb[j]) { sh.digit = tid * PER + j; sh.krem = k - ex; }
+            ex += cb[j];
+        }
+    }
+    __syncthreads();
+    digit = sh.digit;
+    krem = sh.krem;
+}
+
+__global__ __launch_bounds__(S2_T) void k_sel2_hist0(const double *__restrict__ vals, const uint8_t *__restrict__ flag, int64_t n,
+                                                    Sel2Tables *__restrict__ tb)
+{
+    __shared__ uint32_t lh[S2_NB0];
+    for (int t = threadIdx.x; t < S2_NB0; t += S2_T) lh[t] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t ntiles = (n + S2_TILE - 1) / S2_TILE;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        double v[S2_ITEMS];
+        uint8_t f[S2_ITEMS];
+#pragma unroll
+        for (int j = 0; j < S2_ITEMS; ++j) {   // keys and flags in flight together
+            const int64_t t = tile * S2_TILE + j * S2_T + threadIdx.x;
+            v[j] = ann_ldc(vals, t, n);
+            f[j] = flag ? ann_ldc(flag, t, n) : (uint8_t)1;
+            if (t >= n) f[j] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < S2_ITEMS; ++j) {
+            // sign + exponent: a handful of distinct digits per wave, so the first lane's digit is
+            // counted once for everyone who shares it
+            const bool act = f[j] != 0;
+            const uint32_t d = (uint32_t)(ann_key_asc(v[j]) >> 53);
+            const unsigned long long am = __ballot(act);
+            if (!am) continue;
+            const int lead = __ffsll((long long)am) - 1;
+            const uint32_t d0 = __shfl(d, lead);
+            const unsigned long long m = __ballot(act && d == d0);
+            if (lane == lead) atomicAdd(&lh[d0], (uint32_t)__popcll(m));
+            if (act && d != d0) atomicAdd(&lh[d], 1u);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < S2_NB0; t += S2_T)
+        if (lh[t]) atomicAdd(&tb->hist0[t], lh[t]);
+}
+
+struct Sel2Init { int nq; int64_t k[SEL_MAXQ]; };
+
+// LEVEL 1: all keys -> candidates A (top 11 bits match a wanted bucket), histogram of bits 52..42.
+// LEVEL 2: candidates A -> candidates B (top 22 bits match), histogram of bits 41..32.
+// LEVEL 3: candidates B -> candidates C (top 32 bits match), histogram of bits 31..21.
+// The candidate lists are segmented by tile (see above); segcnt_in is the view of the input list.
+// LAST: this level's candidates are the ones the finishing workgroup sees (tie statistics).
+template <int LEVEL, bool LAST> __global__ __launch_bounds__(S2_T) void k_sel2_filter(const double *__restrict__ vals,
+                                                                          const uint8_t *__restrict__ flag, int64_t n,
+                                                                          const uint32_t *__restrict__ segcnt_in, Sel2Init init,
+                                                                          Sel2Tables *__restrict__ tb, double *__restrict__ dst,
+                                                                          uint32_t *__restrict__ segcnt_out)
+{
+    constexpr int NBP = LEVEL == 1 ? S2_NB0 : LEVEL == 2 ? S2_NB1 : S2_NB2;
+    constexpr int NBN = LEVEL == 1 ? S2_NB1 : LEVEL == 2 ? S2_NB2 : S2_NB3;
+    constexpr int SHP = LEVEL == 1 ? 53 : LEVEL == 2 ? 42 : 32, SHN = LEVEL == 1 ? 42 : LEVEL == 2 ? 32 : 21;
+    __shared__ uint32_t lh[SEL_MAXQ * NBN];
+    __shared__ unsigned long long lor[SEL_MAXQ], lnand[SEL_MAXQ];
+    __shared__ Sel2Sh sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Sel2State *si = LEVEL == 2 ? &tb->st1 : &tb->st2;   // (LEVEL 1 starts from `init`)
+    const int nq = LEVEL == 1 ? init.nq : si->nq;
+    uint64_t pre[SEL_MAXQ];
+    int64_t kk[SEL_MAXQ];
+#pragma unroll
+    for (int q = 0; q < SEL_MAXQ; ++q) {
+        pre[q] = 0; kk[q] = 0;
+        if (q < nq) {
+            int digit; int64_t krem;
+            const uint32_t *hp = LEVEL == 1 ? tb->hist0 : LEVEL == 2 ? tb->hist1 + q * S2_NB1 : tb->hist2 + q * S2_NB2;
+            sel2_step<NBP>(hp, LEVEL == 1 ? init.k[q] : si->k[q], sh, digit, krem);
+            pre[q] = (LEVEL == 1 ? 0ull : si->prefix[q]) | ((uint64_t)digit << SHP);
+            kk[q] = krem;
+        }
+    }
+    Sel2State *so = LEVEL == 1 ? &tb->st1 : LEVEL == 2 ? &tb->st2 : &tb->st3;
+    if (blockIdx.x == 0 && tid == 0) {
+        for (int q = 0; q < SEL_MAXQ; ++q) { so->prefix[q] = pre[q]; so->k[q] = kk[q]; }
+        so->nq = nq; so->unfinished = 0; so->cnt = 0;
+    }
+    for (int t = tid; t < nq * NBN; t += S2_T) lh[t] = 0;
+    if (tid < SEL_MAXQ) { lor[tid] = 0; lnand[tid] = 0; }
+    __syncthreads();
+    uint32_t *hnext = LEVEL == 1 ? tb->hist1 : LEVEL == 2 ? tb->hist2 : tb->hist3;
+    unsigned long long vo[SEL_MAXQ] = {0, 0, 0, 0}, vn[SEL_MAXQ] = {0, 0, 0, 0};
+    const int64_t ntiles = (n + S2_TILE - 1) / S2_TILE;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t lim = LEVEL == 1 ? min((int64_t)S2_TILE, n - tile * S2_TILE) : (int64_t)segcnt_in[tile];
+        if (lim == 0) {   // an empty segment stays empty
+            if (tid == 0) segcnt_out[tile] = 0;
+            continue;
+        }
+        double v[S2_ITEMS];
+        uint8_t f[S2_ITEMS];
+#pragma unroll
+        for (int j = 0; j < S2_ITEMS; ++j) {
+            const int o = j * S2_T + tid;
+            const int64_t t = tile * S2_TILE + o;
+            // (clamped, unconditional: the whole batch stays in flight; a tile always has lim >= 1 or is skipped)
+            const int64_t tc = o < lim ? t : tile * S2_TILE;
+            v[j] = vals[tc];
+            f[j] = (LEVEL == 1 && flag) ? flag[tc] : (uint8_t)1;
+            if (o >= lim) f[j] = 0;
+        }
+        uint32_t keep = 0;
+#pragma unroll
+        for (int j = 0; j < S2_ITEMS; ++j) {
+            const uint64_t key = ann_key_asc(v[j]);
+#pragma unroll
+            for (int q = 0; q < SEL_MAXQ; ++q) {
+                if (q >= nq) continue;
+                const bool hit = f[j] && (key >> SHP) == (pre[q] >> SHP);
+                // ties put whole waves on one bin: the first hit's digit is counted once for all who share it
+                const unsigned long long hm = __ballot(hit);
+                if (!hm) continue;
+                const uint32_t d = (uint32_t)((key >> SHN) & (NBN - 1));
+                const int lead = __ffsll((long long)hm) - 1;
+                const uint32_t d0 = __shfl(d, lead);
+                const unsigned long long m = __ballot(hit && d == d0);
+                if (lane == lead) atomicAdd(&lh[q * NBN + d0], (uint32_t)__popcll(m));
+                if (hit && d != d0) atomicAdd(&lh[q * NBN + d], 1u);
+                if (hit) {
+                    keep |= 1u << j;
+                    if (LAST) { vo[q] |= key; vn[q] |= ~key; }
+                }
+            }
+        }
+        // workgroup-wide exclusive scan of the keep counts -> this tile's own segment
+        const uint32_t mine = (uint32_t)__popc(keep);
+        uint32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        __syncthreads();
+        if (lane == 63) sh.wsum[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
+        for (int w = 0; w < S2_T / 64; ++w) { const uint32_t x = sh.wsum[w]; if (w < wave) wbase += x; total += x; }
+        if (tid == 0) segcnt_out[tile] = total;
+        int64_t o = tile * S2_TILE + wbase + inc - mine;
+#pragma unroll
+        for (int j = 0; j < S2_ITEMS; ++j)
+            if (keep & (1u << j)) dst[o++] = v[j];
+    }
+    if (LAST) {
+        // which low bits all of a query's candidates share: a bucket that is one value repeated
+        // (tied distances, tied probabilities) is then resolved without another pass
+#pragma unroll
+        for (int q = 0; q < SEL_MAXQ; ++q) {
+            if (q >= nq) continue;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { vo[q] |= __shfl_xor(vo[q], off); vn[q] |= __shfl_xor(vn[q], off); }
+            if (lane == 0 && (vo[q] | vn[q])) { atomicOr(&lor[q], vo[q]); atomicOr(&lnand[q], vn[q]); }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < nq * NBN; t += S2_T)
+        if (lh[t]) atomicAdd(&hnext[t], lh[t]);
+    if (LAST && tid < nq && (lor[tid] | lnand[tid])) { atomicOr(&tb->vor[tid], lor[tid]); atomicOr(&tb->vnand[tid], lnand[tid]); }
+}
+
+// levels = filter levels run (2: hist2 splits bits 41..32, 32 bits left; 3: hist3 splits bits 31..21, 21 left)
+__global__ __launch_bounds__(S2_T) void k_sel2_finish(Sel2Tables *__restrict__ tb, const double *__restrict__ cand,
+                                                     const uint32_t *__restrict__ segcnt, int64_t nseg, int levels)
+{
+    __shared__ uint64_t keys[S2_CAP];
+    __shared__ uint32_t lh[SEL_MAXQ * 256];
+    __shared__ uint32_t sbase[S2_T], scnt[S2_T];
+    __shared__ Sel2Sh sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Sel2State *si = levels == 2 ? &tb->st2 : &tb->st3;
+    const int nq = si->nq;
+    const int rem0 = levels == 2 ? 32 : 21;          // key bits still open after this step
+    const int shp = levels == 2 ? 42 : 32;           // the candidates agree with their query on bits >= shp
+    uint64_t pre[SEL_MAXQ];
+    int64_t kk[SEL_MAXQ];
+#pragma unroll
+    for (int q = 0; q < SEL_MAXQ; ++q) {
+        pre[q] = 0; kk[q] = 0;
+        if (q < nq) {
+            int digit; int64_t krem;
+            if (levels == 2) sel2_step<S2_NB2>(tb->hist2 + q * S2_NB2, si->k[q], sh, digit, krem);
+            else sel2_step<S2_NB3>(tb->hist3 + q * S2_NB3, si->k[q], sh, digit, krem);
+            pre[q] = si->prefix[q] | ((uint64_t)digit << rem0);
+            kk[q] = krem;
+        }
+    }
+    // how many candidates in all
+    unsigned long long cnt = 0;
+    {
+        uint32_t s = 0;
+        for (int64_t g = tid; g < nseg; g += S2_T) s += segcnt[g];
+        unsigned long long x = s;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        __syncthreads();
+        if (lane == 0) { sh.wsum[wave] = (uint32_t)x; }   // < 2^32 candidates (pair positions are int32)
+        __syncthreads();
+        for (int w = 0; w < S2_T / 64; ++w) cnt += sh.wsum[w];
+    }
+    // resolved at once if each query's bucket is one repeated value (tied distances / probabilities)
+    const uint64_t low = (1ull << shp) - 1;
+    bool tied = cnt > 0;
+#pragma unroll
+    for (int q = 0; q < SEL_MAXQ; ++q)
+        if (q < nq && ((tb->vor[q] ^ ~tb->vnand[q]) & low)) tied = false;
+    if (tied) {
+#pragma unroll
+        for (int q = 0; q < SEL_MAXQ; ++q)
+            if (q < nq) { pre[q] = si->prefix[q] | (tb->vor[q] & low); kk[q] = 0; }
+    }
+    const bool fits = !tied && cnt <= S2_CAP;   // else: the last 32 bits from LDS, or (mixed bucket too long) unfinished
+    if (fits) {
+        // gather the segments into LDS: 1024 segments at a time, a wave per segment
+        uint32_t filled = 0;
+        for (int64_t g0 = 0; g0 < nseg; g0 += S2_T) {
+            const uint32_t c = g0 + tid < nseg ? segcnt[g0 + tid] : 0u;
+            uint32_t inc = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t o = __shfl_up(inc, off);
+                if (lane >= off) inc += o;
+            }
+            __syncthreads();
+            if (lane == 63) sh.wsum[wave] = inc;
+            __syncthreads();
+            uint32_t wbase = 0, total = 0;
+            for (int w = 0; w < S2_T / 64; ++w) { const uint32_t x = sh.wsum[w]; if (w < wave) wbase += x; total += x; }
+            sbase[tid] = filled + wbase + inc - c;
+            scnt[tid] = c;
+            __syncthreads();
+            for (int sidx = wave; sidx < S2_T; sidx += S2_T / 64) {
+                const uint32_t cs = scnt[sidx];
+                for (uint32_t e = lane; e < cs; e += 64)
+                    keys[sbase[sidx] + e] = ann_key_asc(cand[(g0 + sidx) * S2_TILE + e]);
+            }
+            filled += total;
+        }
+        for (int rem = rem0; rem > 0;) {
+            const int w = rem < 8 ? rem : 8, shift = rem - w;
+            for (int t = tid; t < nq * 256; t += S2_T) lh[t] = 0;
+            __syncthreads();
+            for (int t = tid; t < (int)cnt; t += S2_T) {
+                const uint64_t key = keys[t];
+#pragma unroll
+                for (int q = 0; q < SEL_MAXQ; ++q)
+                    if (q < nq && (key >> rem) == (pre[q] >> rem))
+                        atomicAdd(&lh[q * 256 + (int)((key >> shift) & ((1u << w) - 1))], 1u);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < SEL_MAXQ; ++q)
+                if (q < nq) {
+                    int digit; int64_t krem;
+                    sel2_step<256>(lh + q * 256, kk[q], sh, digit, krem);
+                    pre[q] |= (uint64_t)digit << shift;
+                    kk[q] = krem;
+                }
+            rem = shift;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int q = 0; q < SEL_MAXQ; ++q) { tb->out.prefix[q] = pre[q]; tb->out.k[q] = kk[q]; }
+        tb->out.nq = nq; tb->out.unfinished = (fits || tied) ? 0 : 1; tb->out.cnt = cnt;
+    }
+    // leave the tables zeroed for the next selection (saves a memset launch per call)
+    uint4 *z = reinterpret_cast<uint4 *>(tb);
+    for (int t = tid; t < (int)(S2_ZERO_BYTES / 16); t += S2_T) z[t] = make_uint4(0, 0, 0, 0);
+}
+
 int ann_kth_smallest(annchor_ctx *c, const double *vals, const uint8_t *flag, int64_t n, const int64_t *ks, int nk,
                      double *h_out)
 {
     ANN_REQUIRE(c, nk >= 1 && nk <= SEL_MAXQ, ANNCHOR_EINVAL, "kth_smallest: 1..%d ranks per call", SEL_MAXQ);
-    ANN_TRY(ann_reserve(c, c->sel_state, sizeof(SelState) * 9));   // state before pass 0 .. after pass 7
-    ANN_TRY(ann_reserve(c, c->sel_hist, sizeof(uint32_t) * 8 * SEL_MAXQ * 256));
-    SelState h;
-    memset(&h, 0, sizeof h);
-    h.nq = nk;
-    for (int q = 0; q < nk; ++q) h.k[q] = ks[q];
-    h.vor = 0; h.vand = ~0ull;
-    ANN_TRY(ann_h2d(c, c->sel_state.p, &h, sizeof h));
-    ANN_CHECK_HIP(c, hipMemsetAsync(c->sel_hist.p, 0, sizeof(uint32_t) * 8 * SEL_MAXQ * 256, c->stream));
-    int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
-    if (blocks > c->prop.multiProcessorCount * 4) blocks = c->prop.multiProcessorCount * 4;
-    if (blocks < 1) blocks = 1;
+    ANN_REQUIRE(c, n > 0, ANNCHOR_EINVAL, "kth_smallest: empty list");
+    static_assert(S2_ZERO_BYTES % 16 == 0, "zeroed region is cleared with 16-byte stores");
+    const int64_t ntiles = std::max<int64_t>((n + S2_TILE - 1) / S2_TILE, 1);
+    ANN_TRY(ann_reserve(c, c->sel2, sizeof(Sel2Tables)));
+    ANN_TRY(ann_reserve(c, c->sel_bufA, sizeof(double) * (size_t)ntiles * S2_TILE));
+    ANN_TRY(ann_reserve(c, c->sel_bufB, sizeof(double) * (size_t)ntiles * S2_TILE));
+    ANN_TRY(ann_reserve(c, c->sel_seg, sizeof(uint32_t) * 2 * (size_t)ntiles));
+    Sel2Tables *tb = c->sel2.as<Sel2Tables>();
+    uint32_t *segA = c->sel_seg.as<uint32_t>(), *segB = segA + ntiles;
+    if (c->sel2_clean != (const void *)tb) {
+        ANN_CHECK_HIP(c, hipMemsetAsync(tb, 0, sizeof(Sel2Tables), c->stream));
+        c->sel2_clean = nullptr;
+    }
+    Sel2Init init;
+    memset(&init, 0, sizeof init);
+    init.nq = nk;
+    for (int q = 0; q < nk; ++q) init.k[q] = ks[q];
+    // few fat workgroups: every one ends with atomics on shared histogram bins (~12.5 ns each, serialised)
+    const int grid = (int)(ntiles <= 256 ? ntiles : std::min<int64_t>(S2_MAXWG, std::max<int64_t>(256, ntiles / 4)));
+    Sel2State out;
     {
-        ProfScope ps(c, "radix_select_f64", (double)n * 9 * 8);
-        k_sel_orand<<<blocks, 256, 0, c->stream>>>(vals, flag, n, c->sel_state.as<SelState>());
-        for (int pass = 0; pass < 8; ++pass)
-            k_sel_pass<<<blocks, 256, 0, c->stream>>>(vals, flag, n, c->sel_state.as<SelState>(), c->sel_hist.as<uint32_t>(), pass);
-        k_sel_pass<<<1, 256, 0, c->stream>>>(vals, flag, n, c->sel_state.as<SelState>(), c->sel_hist.as<uint32_t>(), 8);
+        // algorithmic bytes: one read of the keys and their flags
+        ProfScope ps(c, "radix_select_f64", (double)n * 9.0);
+        k_sel2_hist0<<<grid, S2_T, 0, c->stream>>>(vals, flag, n, tb);
+        double *A = c->sel_bufA.as<double>(), *B = c->sel_bufB.as<double>();
+        k_sel2_filter<1, false><<<grid, S2_T, 0, c->stream>>>(vals, flag, n, nullptr, init, tb, A, segA);
+        const char *l3 = getenv("ANNCHOR_SEL_LEVEL3_MIN");   // tests reach the three-level route on short lists
+        if (n < (l3 ? atoll(l3) : S2_LEVEL3_MIN)) {
+            k_sel2_filter<2, true><<<grid, S2_T, 0, c->stream>>>(A, nullptr, n, segA, init, tb, B, segB);
+            k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, B, segB, ntiles, 2);
+        } else {   // (C reuses A's slots: A is dead once B exists)
+            k_sel2_filter<2, false><<<grid, S2_T, 0, c->stream>>>(A, nullptr, n, segA, init, tb, B, segB);
+            k_sel2_filter<3, true><<<grid, S2_T, 0, c->stream>>>(B, nullptr, n, segB, init, tb, A, segA);
+            k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, A, segA, ntiles, 3);
+        }
     }
     ANN_CHECK_HIP(c, hipGetLastError());
-    ANN_TRY(ann_d2h(c, &h, c->sel_state.as<SelState>() + 8, sizeof h));
+    c->sel2_clean = nullptr;
+    ANN_TRY(ann_d2h(c, &out, &tb->out, sizeof out));
+    c->sel2_clean = (const void *)tb;
+    if (out.unfinished) {
+        // a mixed bucket longer than the finishing workgroup's LDS: the byte passes over all keys
+        ANN_TRY(ann_reserve(c, c->sel_state, sizeof(SelState) * 9));
+        ANN_TRY(ann_reserve(c, c->sel_hist, sizeof(uint32_t) * 8 * SEL_MAXQ * 256));
+        SelState h;
+        memset(&h, 0, sizeof h);
+        h.nq = nk;
+        for (int q = 0; q < nk; ++q) h.k[q] = ks[q];
+        h.vor = ~0ull; h.vand = 0ull;   // no byte is known to be uniform
+        ANN_TRY(ann_h2d(c, c->sel_state.p, &h, sizeof h));
+        ANN_CHECK_HIP(c, hipMemsetAsync(c->sel_hist.p, 0, sizeof(uint32_t) * 8 * SEL_MAXQ * 256, c->stream));
+        int blocks = (int)std::min<int64_t>((n + 256 * 8 - 1) / (256 * 8), c->prop.multiProcessorCount * 4);
+        if (blocks < 1) blocks = 1;
+        {
+            ProfScope ps(c, "radix_select_f64_bytewise", (double)n * 9.0);
+            for (int pass = 0; pass < 8; ++pass)
+                k_sel_pass<<<blocks, 256, 0, c->stream>>>(vals, flag, n, c->sel_state.as<SelState>(), c->sel_hist.as<uint32_t>(), pass, 0);
+            k_sel_pass<<<1, 256, 0, c->stream>>>(vals, flag, n, c->sel_state.as<SelState>(), c->sel_hist.as<uint32_t>(), 8, 0);
+        }
+        ANN_CHECK_HIP(c, hipGetLastError());
+        ANN_TRY(ann_d2h(c, &h, c->sel_state.as<SelState>() + 8, sizeof h));
+        for (int q = 0; q < nk; ++q) out.prefix[q] = h.prefix[q];
+    }
     for (int q = 0; q < nk; ++q) {
-        uint64_t key = h.prefix[q];
+        uint64_t key = out.prefix[q];
         uint64_t u = (key & 0x8000000000000000ull) ? (key & 0x7fffffffffffffffull) : ~key;
         memcpy(&h_out[q], &u, sizeof(double));
     }

@@ -425,26 +425,64 @@ __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict_
         __syncthreads();
     }
     const double *E = errs_in_lds ? le : errs;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        double pr = -1.0;
-        if (ncm[p]) {
-            const int2 q = ij[p];
-            const double pv = fmax(thresh[q.x], thresh[q.y]) - RA[p];
-            const int lb = label[p];
-            if (lb < nlabels) {
-                const int64_t b = lptr[lb], e = lptr[lb + 1];
-                // searchsorted(side='left'): number of entries < pv
-                int64_t lo = b, hi = e;
-                while (lo < hi) {
-                    const int64_t mid = (lo + hi) >> 1;
-                    if (E[mid] < pv) lo = mid + 1; else hi = mid;
-                }
-                pr = (double)(lo - b) / (double)(e - b);
-            } else {
-                pr = 0.0;
-            }
+    // Four pairs per thread per step: their streams (mask, pair, RA, label) are loaded together,
+    // then the two threshold gathers, then the four binary searches advance in lock step -- one
+    // pair at a time the chain mask -> pair -> thresholds -> ~13 dependent LDS probes ran at
+    // memory latency (2.0 ms for 127 M pairs, 20 % of the HBM rate).
+    constexpr int PI = 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * PI;
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x * PI + threadIdx.x; p0 < n; p0 += stride) {
+        uint8_t m[PI], lbv[PI];
+        int2 q[PI];
+        double ra[PI];
+#pragma unroll
+        for (int e = 0; e < PI; ++e) {
+            const int64_t p = p0 + (int64_t)e * blockDim.x;
+            const bool in = p < n;
+            m[e] = in ? ncm[p] : (uint8_t)0;
+            q[e] = in ? ij[p] : make_int2(0, 0);
+            ra[e] = in ? RA[p] : 0.0;
+            lbv[e] = in ? label[p] : (uint8_t)0;
         }
-        prob[p] = pr;
+        double pv[PI];
+#pragma unroll
+        for (int e = 0; e < PI; ++e) pv[e] = fmax(thresh[q[e].x], thresh[q[e].y]) - ra[e];
+        int64_t b[PI], lo[PI], hi[PI];
+        bool busy = false;
+#pragma unroll
+        for (int e = 0; e < PI; ++e) {
+            const bool search = m[e] && (int)lbv[e] < nlabels;
+            b[e] = search ? lptr[lbv[e]] : 0;
+            lo[e] = b[e];
+            hi[e] = search ? lptr[lbv[e] + 1] : 0;
+            busy |= lo[e] < hi[e];
+        }
+        // searchsorted(side='left'): number of entries < pv
+        while (busy) {
+            busy = false;
+#pragma unroll
+            for (int e = 0; e < PI; ++e)
+                if (lo[e] < hi[e]) {
+                    const int64_t mid = (lo[e] + hi[e]) >> 1;
+                    if (E[mid] < pv[e]) lo[e] = mid + 1; else hi[e] = mid;
+                    busy |= lo[e] < hi[e];
+                }
+        }
+#pragma unroll
+        for (int e = 0; e < PI; ++e) {
+            const int64_t p = p0 + (int64_t)e * blockDim.x;
+            if (p >= n) continue;
+            double pr = -1.0;
+            if (m[e]) {
+                if ((int)lbv[e] < nlabels) {
+                    const int64_t len = lptr[lbv[e] + 1] - b[e];
+                    pr = (double)(lo[e] - b[e]) / (double)len;
+                } else {
+                    pr = 0.0;
+                }
+            }
+            prob[p] = pr;
+        }
     }
 }
 
@@ -470,64 +508,111 @@ __global__ __launch_bounds__(CP_THREADS) void k_cut_count(const double *__restri
     const double t1 = cs->t1, t5 = cs->t5;
     uint32_t g1 = 0, q1 = 0, g5 = 0, q5 = 0;
     const int64_t base = (int64_t)blockIdx.x * CP_TILE;
-    for (int k = 0; k < CP_ITEMS; ++k) {
-        const int64_t p = base + (int64_t)k * CP_THREADS + threadIdx.x;
-        if (p < n) {
-            const double v = prob[p];
-            if (v >= 0.0) { g1 += v > t1; q1 += v == t1; g5 += v > t5; q5 += v == t5; }
+    double v[CP_ITEMS];
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) v[k] = ann_ldc(prob, base + (int64_t)k * CP_THREADS + threadIdx.x, n);   // one batch in flight
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k)
+        if (base + (int64_t)k * CP_THREADS + threadIdx.x < n && v[k] >= 0.0) {
+            g1 += v[k] > t1; q1 += v[k] == t1; g5 += v[k] > t5; q5 += v[k] == t5;
         }
+    // four 8-bit-per-item counters packed into one wave reduction (each <= 64 * CP_ITEMS = 512 < 2^16)
+    unsigned long long pk = (unsigned long long)g1 | ((unsigned long long)q1 << 16) | ((unsigned long long)g5 << 32) |
+                            ((unsigned long long)q5 << 48);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pk += __shfl_xor(pk, off);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&acc[0], (uint32_t)(pk & 0xffff)); atomicAdd(&acc[1], (uint32_t)((pk >> 16) & 0xffff));
+        atomicAdd(&acc[2], (uint32_t)((pk >> 32) & 0xffff)); atomicAdd(&acc[3], (uint32_t)(pk >> 48));
     }
-    atomicAdd(&acc[0], g1); atomicAdd(&acc[1], q1); atomicAdd(&acc[2], g5); atomicAdd(&acc[3], q5);
     __syncthreads();
     if (threadIdx.x < 4) blk[(size_t)blockIdx.x * 4 + threadIdx.x] = acc[threadIdx.x];
 }
 
-// single block: totals, then per-tile offsets {eq1 prefix, eq5 prefix, cand offset, next offset}
-__global__ __launch_bounds__(CP_THREADS) void k_cut_scan(uint32_t *__restrict__ blk, int nb, CutState *__restrict__ cs,
+// single block: totals, then per-tile offsets {eq1 prefix, eq5 prefix, cand offset, next offset}.
+// 1024 threads own four consecutive tiles each per step and scan two 32-bit counters packed in
+// one 64-bit word (every total is < 2^31: pair positions are int32), so 62 K tiles (127 M pairs)
+// take 16 steps of two workgroup scans instead of 243 steps of four.
+#define CS_THREADS 1024
+#define CS_ITEMS 4
+__global__ __launch_bounds__(CS_THREADS) void k_cut_scan(const uint32_t *__restrict__ blk, int nb, CutState *__restrict__ cs,
                                                         int64_t *__restrict__ off)
 {
-    __shared__ int64_t wsum[CP_THREADS / 64];
-    __shared__ int64_t tot_s[2];
-    auto block_scan = [&](int64_t v, int64_t *total) -> int64_t {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        int64_t inc = v;
-        for (int o = 1; o < 64; o <<= 1) { int64_t x = __shfl_up(inc, o); if (lane >= o) inc += x; }
+    __shared__ unsigned long long wsum[CS_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto block_scan = [&](unsigned long long v, unsigned long long *total) -> unsigned long long {
+        unsigned long long inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { unsigned long long x = __shfl_up(inc, o); if (lane >= o) inc += x; }
         __syncthreads();
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
-        int64_t base = 0, tot = 0;
-        for (int w = 0; w < CP_THREADS / 64; ++w) { if (w < wave) base += wsum[w]; tot += wsum[w]; }
+        unsigned long long base = 0, tot = 0;
+        for (int w = 0; w < CS_THREADS / 64; ++w) { const unsigned long long x = wsum[w]; if (w < wave) base += x; tot += x; }
         *total = tot;
         return base + inc - v;
     };
+    const uint4 *blk4 = reinterpret_cast<const uint4 *>(blk);   // {gt1, eq1, gt5, eq5} per tile
     // totals of gt1 / gt5
-    int64_t g1 = 0, g5 = 0;
-    for (int t = threadIdx.x; t < nb; t += CP_THREADS) { g1 += blk[(size_t)t * 4]; g5 += blk[(size_t)t * 4 + 2]; }
-    int64_t T1, T5;
-    block_scan(g1, &T1);
-    block_scan(g5, &T5);
+    unsigned long long g = 0;
+    for (int t0 = threadIdx.x; t0 < nb; t0 += CS_THREADS * CS_ITEMS) {
+        uint4 b[CS_ITEMS];
+#pragma unroll
+        for (int e = 0; e < CS_ITEMS; ++e) b[e] = ann_ldc(blk4, t0 + e * CS_THREADS, nb);
+#pragma unroll
+        for (int e = 0; e < CS_ITEMS; ++e)
+            if (t0 + e * CS_THREADS < nb) g += (unsigned long long)b[e].x | ((unsigned long long)b[e].z << 32);
+    }
+    unsigned long long T;
+    block_scan(g, &T);
+    const int64_t T1 = (int64_t)(T & 0xffffffffull), T5 = (int64_t)(T >> 32);
     const int64_t e1 = cs->all1 ? (1ll << 62) : cs->K1 - T1;
     const int64_t e5 = cs->all5 ? (1ll << 62) : cs->K5 - T5;
-    int64_t c_eq1 = 0, c_eq5 = 0, c_cand = 0, c_next = 0;
-    for (int base = 0; base < nb; base += CP_THREADS) {
-        const int t = base + threadIdx.x;
-        const int64_t gt1 = t < nb ? blk[(size_t)t * 4] : 0, eq1 = t < nb ? blk[(size_t)t * 4 + 1] : 0;
-        const int64_t gt5 = t < nb ? blk[(size_t)t * 4 + 2] : 0, eq5 = t < nb ? blk[(size_t)t * 4 + 3] : 0;
-        int64_t tot;
-        const int64_t p1 = c_eq1 + block_scan(eq1, &tot); c_eq1 += tot;
-        const int64_t p5 = c_eq5 + block_scan(eq5, &tot); c_eq5 += tot;
-        const int64_t take1 = min(eq1, max((int64_t)0, e1 - p1));
-        const int64_t take5 = min(eq5, max((int64_t)0, e5 - p5));
-        const int64_t ncand = gt1 + take1;
-        const int64_t nbig = gt5 + take5;
-        // when everything is taken for both lists, `next` is the full list again (annchor.py:444-446)
-        const int64_t nnext = (cs->all1 && cs->all5) ? nbig : nbig - ncand;
-        const int64_t oc = c_cand + block_scan(ncand, &tot); c_cand += tot;
-        const int64_t on = c_next + block_scan(nnext, &tot); c_next += tot;
-        if (t < nb) { off[(size_t)t * 4] = p1; off[(size_t)t * 4 + 1] = p5; off[(size_t)t * 4 + 2] = oc; off[(size_t)t * 4 + 3] = on; }
+    const bool both_all = cs->all1 && cs->all5;
+    unsigned long long c_eq = 0, c_out = 0;   // running {eq1 | eq5 << 32}, {cand | next << 32}
+    for (int base = 0; base < nb; base += CS_THREADS * CS_ITEMS) {
+        const int t0 = base + threadIdx.x * CS_ITEMS;   // thread-contiguous tiles: scan order = tile order
+        uint4 b[CS_ITEMS];
+#pragma unroll
+        for (int e = 0; e < CS_ITEMS; ++e) {
+            b[e] = ann_ldc(blk4, t0 + e, nb);
+            if (t0 + e >= nb) b[e] = make_uint4(0, 0, 0, 0);
+        }
+        unsigned long long eqs = 0;
+#pragma unroll
+        for (int e = 0; e < CS_ITEMS; ++e) eqs += (unsigned long long)b[e].y | ((unsigned long long)b[e].w << 32);
+        unsigned long long tot;
+        unsigned long long ex = c_eq + block_scan(eqs, &tot);
+        c_eq += tot;
+        int64_t p1[CS_ITEMS], p5[CS_ITEMS];
+        unsigned long long outv[CS_ITEMS], outs = 0;
+#pragma unroll
+        for (int e = 0; e < CS_ITEMS; ++e) {
+            p1[e] = (int64_t)(ex & 0xffffffffull);
+            p5[e] = (int64_t)(ex >> 32);
+            const int64_t eq1 = b[e].y, eq5 = b[e].w;
+            const int64_t take1 = min(eq1, max((int64_t)0, e1 - p1[e]));
+            const int64_t take5 = min(eq5, max((int64_t)0, e5 - p5[e]));
+            const int64_t ncand = (int64_t)b[e].x + take1;
+            const int64_t nbig = (int64_t)b[e].z + take5;
+            // when everything is taken for both lists, `next` is the full list again (annchor.py:444-446)
+            const int64_t nnext = both_all ? nbig : nbig - ncand;
+            outv[e] = (unsigned long long)ncand | ((unsigned long long)nnext << 32);
+            outs += outv[e];
+            ex += (unsigned long long)eq1 | ((unsigned long long)eq5 << 32);
+        }
+        unsigned long long exo = c_out + block_scan(outs, &tot);
+        c_out += tot;
+#pragma unroll
+        for (int e = 0; e < CS_ITEMS; ++e) {
+            if (t0 + e < nb) {
+                int64_t *o = off + (size_t)(t0 + e) * 4;
+                o[0] = p1[e]; o[1] = p5[e]; o[2] = (int64_t)(exo & 0xffffffffull); o[3] = (int64_t)(exo >> 32);
+            }
+            exo += outv[e];
+        }
     }
-    if (threadIdx.x == 0) { cs->e1 = e1; cs->e5 = e5; cs->ncand = c_cand; cs->nnext = c_next; }
-    (void)tot_s;
+    if (threadIdx.x == 0) { cs->e1 = e1; cs->e5 = e5; cs->ncand = (int64_t)(c_out & 0xffffffffull); cs->nnext = (int64_t)(c_out >> 32); }
 }
 
 __global__ __launch_bounds__(CP_THREADS) void k_cut_emit(const double *__restrict__ prob, int64_t n,
@@ -718,7 +803,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     {
         ProfScope ps(c, "topk_split_compact", (double)n * 16.0 + (double)(maxc + maxn) * 4.0);
         k_cut_count<<<nb, CP_THREADS, 0, c->stream>>>(c->prob.as<double>(), n, c->sel_state.as<CutState>(), c->blk_cnt.as<uint32_t>());
-        k_cut_scan<<<1, CP_THREADS, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nb, c->sel_state.as<CutState>(), c->blk_off.as<int64_t>());
+        k_cut_scan<<<1, CS_THREADS, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nb, c->sel_state.as<CutState>(), c->blk_off.as<int64_t>());
         k_cut_emit<<<nb, CP_THREADS, 0, c->stream>>>(c->prob.as<double>(), n, c->sel_state.as<CutState>(), c->blk_off.as<int64_t>(),
                                                     c->cand.as<int32_t>(), c->next.as<int32_t>());
     }
