@@ -29,20 +29,41 @@ __global__ __launch_bounds__(256) void k_features(const int2 *__restrict__ ij, i
     const int2 q = ij[p];
     const int i = q.x, j = q.y;
     double l = 0.0, u = INFINITY;
-    // eight anchors' loads in flight per step (the plain loop waited out one L2 round trip per
-    // anchor: 3.5 ms for 127 M pairs); the tail repeats the last anchor, which max / min ignore
-    for (int a0 = 0; a0 < na; a0 += 8) {
-        double di[8], dj[8];
+    // Eight anchors' loads in flight per step (the plain loop waited out one L2 round trip per
+    // anchor); the tail repeats the last anchor, which max / min ignore.  The vector memory
+    // pipeline is this kernel's limit at scale (48 loads per pair: tools/microbench/
+    // features_probe.hip), and pairs are sorted by i, so a wave that sits inside one row -- all
+    // but one wave per row -- reads its D[.][i] through the scalar cache instead.
+    const int i0 = __builtin_amdgcn_readfirstlane(i);
+    if (__all(i == i0)) {
+        for (int a0 = 0; a0 < na; a0 += 8) {
+            double di[8], dj[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const size_t row = (size_t)min(a0 + e, na - 1) * nx;
-            di[e] = Dt[row + i];
-            dj[e] = Dt[row + j];
+            for (int e = 0; e < 8; ++e) {
+                const size_t row = (size_t)min(a0 + e, na - 1) * nx;
+                di[e] = Dt[row + i0];
+                dj[e] = Dt[row + j];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                l = fmax(l, fabs(di[e] - dj[e]));
+                u = fmin(u, di[e] + dj[e]);
+            }
         }
+    } else {
+        for (int a0 = 0; a0 < na; a0 += 8) {
+            double di[8], dj[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            l = fmax(l, fabs(di[e] - dj[e]));
-            u = fmin(u, di[e] + dj[e]);
+            for (int e = 0; e < 8; ++e) {
+                const size_t row = (size_t)min(a0 + e, na - 1) * nx;
+                di[e] = Dt[row + i];
+                dj[e] = Dt[row + j];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                l = fmax(l, fabs(di[e] - dj[e]));
+                u = fmin(u, di[e] + dj[e]);
+            }
         }
     }
     lb[p] = l;

@@ -232,7 +232,9 @@ struct Sel2Tables {
     uint32_t hist1[SEL_MAXQ * S2_NB1];
     uint32_t hist2[SEL_MAXQ * S2_NB2];
     uint32_t hist3[SEL_MAXQ * S2_NB3];
-    unsigned long long vor[SEL_MAXQ], vnand[SEL_MAXQ];   // OR of key / OR of ~key over each query's last-level candidates
+    // OR of key / OR of ~key over each query's candidates after level 2 ([0]) and level 3 ([1]): a bucket whose
+    // keys are one repeated value shows vor == ~vnand on the open bits
+    unsigned long long vor[2][SEL_MAXQ], vnand[2][SEL_MAXQ];
     // ---- not part of the zeroed region
     Sel2State st1, st2, st3, out;
 };
@@ -319,12 +321,24 @@ __global__ __launch_bounds__(S2_T) void k_sel2_hist0(const double *__restrict__ 
 
 struct Sel2Init { int nq; int64_t k[SEL_MAXQ]; };
 
+// every query's bucket is non-empty and one repeated value on the bits below `open`
+__device__ __forceinline__ bool sel2_tied(const unsigned long long *vor, const unsigned long long *vnand, int nq, int open)
+{
+    const uint64_t low = (1ull << open) - 1;
+    bool tied = true;
+#pragma unroll
+    for (int q = 0; q < SEL_MAXQ; ++q)
+        if (q < nq && ((vor[q] ^ ~vnand[q]) & low)) tied = false;
+    return tied;
+}
+
 // LEVEL 1: all keys -> candidates A (top 11 bits match a wanted bucket), histogram of bits 52..42.
 // LEVEL 2: candidates A -> candidates B (top 22 bits match), histogram of bits 41..32.
 // LEVEL 3: candidates B -> candidates C (top 32 bits match), histogram of bits 31..21.
 // The candidate lists are segmented by tile (see above); segcnt_in is the view of the input list.
-// LAST: this level's candidates are the ones the finishing workgroup sees (tie statistics).
-template <int LEVEL, bool LAST> __global__ __launch_bounds__(S2_T) void k_sel2_filter(const double *__restrict__ vals,
+// Levels 2 and 3 also gather the tie statistics of their survivors; level 3 does nothing when
+// level 2 already found every bucket to be one repeated value.
+template <int LEVEL> __global__ __launch_bounds__(S2_T, LEVEL == 1 ? 8 : 4) void k_sel2_filter(const double *__restrict__ vals,
                                                                           const uint8_t *__restrict__ flag, int64_t n,
                                                                           const uint32_t *__restrict__ segcnt_in, Sel2Init init,
                                                                           Sel2Tables *__restrict__ tb, double *__restrict__ dst,
@@ -333,12 +347,15 @@ template <int LEVEL, bool LAST> __global__ __launch_bounds__(S2_T) void k_sel2_f
     constexpr int NBP = LEVEL == 1 ? S2_NB0 : LEVEL == 2 ? S2_NB1 : S2_NB2;
     constexpr int NBN = LEVEL == 1 ? S2_NB1 : LEVEL == 2 ? S2_NB2 : S2_NB3;
     constexpr int SHP = LEVEL == 1 ? 53 : LEVEL == 2 ? 42 : 32, SHN = LEVEL == 1 ? 42 : LEVEL == 2 ? 32 : 21;
+    constexpr bool LAST = LEVEL >= 2;   // gathers tie statistics
+    constexpr int SLOT = LEVEL == 3 ? 1 : 0;
     __shared__ uint32_t lh[SEL_MAXQ * NBN];
     __shared__ unsigned long long lor[SEL_MAXQ], lnand[SEL_MAXQ];
     __shared__ Sel2Sh sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Sel2State *si = LEVEL == 2 ? &tb->st1 : &tb->st2;   // (LEVEL 1 starts from `init`)
     const int nq = LEVEL == 1 ? init.nq : si->nq;
+    if (LEVEL == 3 && sel2_tied(tb->vor[0], tb->vnand[0], nq, 42)) return;   // level 2 resolved everything
     uint64_t pre[SEL_MAXQ];
     int64_t kk[SEL_MAXQ];
 #pragma unroll
@@ -349,6 +366,9 @@ template <int LEVEL, bool LAST> __global__ __launch_bounds__(S2_T) void k_sel2_f
             const uint32_t *hp = LEVEL == 1 ? tb->hist0 : LEVEL == 2 ? tb->hist1 + q * S2_NB1 : tb->hist2 + q * S2_NB2;
             sel2_step<NBP>(hp, LEVEL == 1 ? init.k[q] : si->k[q], sh, digit, krem);
             pre[q] = (LEVEL == 1 ? 0ull : si->prefix[q]) | ((uint64_t)digit << SHP);
+            // (workgroup-uniform: keep it in scalar registers)
+            pre[q] = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pre[q] >> 32)) << 32) |
+                     (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)pre[q]);
             kk[q] = krem;
         }
     }
@@ -377,13 +397,17 @@ template <int LEVEL, bool LAST> __global__ __launch_bounds__(S2_T) void k_sel2_f
             const int64_t t = tile * S2_TILE + o;
             // (clamped, unconditional: the whole batch stays in flight; a tile always has lim >= 1 or is skipped)
             const int64_t tc = o < lim ? t : tile * S2_TILE;
-            v[j] = vals[tc];
-            f[j] = (LEVEL == 1 && flag) ? flag[tc] : (uint8_t)1;
-            if (o >= lim) f[j] = 0;
+            v[j] = 0.0; f[j] = 0;
+            if (LEVEL == 1 || j * S2_T < lim) {   // (uniform) a short segment fills only its first slices
+                v[j] = vals[tc];
+                f[j] = (LEVEL == 1 && flag) ? flag[tc] : (uint8_t)1;
+                if (o >= lim) f[j] = 0;
+            }
         }
         uint32_t keep = 0;
 #pragma unroll
         for (int j = 0; j < S2_ITEMS; ++j) {
+            if (LEVEL != 1 && j * S2_T >= lim) break;
             const uint64_t key = ann_key_asc(v[j]);
 #pragma unroll
             for (int q = 0; q < SEL_MAXQ; ++q) {
@@ -404,24 +428,26 @@ template <int LEVEL, bool LAST> __global__ __launch_bounds__(S2_T) void k_sel2_f
                 }
             }
         }
-        // workgroup-wide exclusive scan of the keep counts -> this tile's own segment
-        const uint32_t mine = (uint32_t)__popc(keep);
-        uint32_t inc = mine;
+        // this tile's own segment, wave by wave, item by item: the survivors of one 64-wide load
+        // go to consecutive slots (coalesced stores); the order inside a segment is irrelevant
+        uint32_t wtot = 0;
+        uint32_t slot[S2_ITEMS];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t o = __shfl_up(inc, off);
-            if (lane >= off) inc += o;
+        for (int j = 0; j < S2_ITEMS; ++j) {
+            const unsigned long long km = __ballot((keep >> j) & 1u);
+            slot[j] = wtot + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+            wtot += (uint32_t)__popcll(km);
         }
         __syncthreads();
-        if (lane == 63) sh.wsum[wave] = inc;
+        if (lane == 0) sh.wsum[wave] = wtot;
         __syncthreads();
         uint32_t wbase = 0, total = 0;
         for (int w = 0; w < S2_T / 64; ++w) { const uint32_t x = sh.wsum[w]; if (w < wave) wbase += x; total += x; }
         if (tid == 0) segcnt_out[tile] = total;
-        int64_t o = tile * S2_TILE + wbase + inc - mine;
+        double *seg = dst + tile * S2_TILE + wbase;
 #pragma unroll
         for (int j = 0; j < S2_ITEMS; ++j)
-            if (keep & (1u << j)) dst[o++] = v[j];
+            if (keep & (1u << j)) seg[slot[j]] = v[j];
     }
     if (LAST) {
         // which low bits all of a query's candidates share: a bucket that is one value repeated
@@ -437,7 +463,7 @@ template <int LEVEL, bool LAST> __global__ __launch_bounds__(S2_T) void k_sel2_f
     __syncthreads();
     for (int t = tid; t < nq * NBN; t += S2_T)
         if (lh[t]) atomicAdd(&hnext[t], lh[t]);
-    if (LAST && tid < nq && (lor[tid] | lnand[tid])) { atomicOr(&tb->vor[tid], lor[tid]); atomicOr(&tb->vnand[tid], lnand[tid]); }
+    if (LAST && tid < nq && (lor[tid] | lnand[tid])) { atomicOr(&tb->vor[SLOT][tid], lor[tid]); atomicOr(&tb->vnand[SLOT][tid], lnand[tid]); }
 }
 
 // levels = filter levels run (2: hist2 splits bits 41..32, 32 bits left; 3: hist3 splits bits 31..21, 21 left)
@@ -450,7 +476,7 @@ __global__ __launch_bounds__(S2_T) void k_sel2_finish(Sel2Tables *__restrict__ t
     __shared__ Sel2Sh sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Sel2State *si = levels == 2 ? &tb->st2 : &tb->st3;
-    const int nq = si->nq;
+    const int nq = tb->st2.nq;   // (st3 is stale when level 3 had nothing to do)
     const int rem0 = levels == 2 ? 32 : 21;          // key bits still open after this step
     const int shp = levels == 2 ? 42 : 32;           // the candidates agree with their query on bits >= shp
     uint64_t pre[SEL_MAXQ];
@@ -479,16 +505,19 @@ __global__ __launch_bounds__(S2_T) void k_sel2_finish(Sel2Tables *__restrict__ t
         __syncthreads();
         for (int w = 0; w < S2_T / 64; ++w) cnt += sh.wsum[w];
     }
-    // resolved at once if each query's bucket is one repeated value (tied distances / probabilities)
-    const uint64_t low = (1ull << shp) - 1;
-    bool tied = cnt > 0;
-#pragma unroll
-    for (int q = 0; q < SEL_MAXQ; ++q)
-        if (q < nq && ((tb->vor[q] ^ ~tb->vnand[q]) & low)) tied = false;
-    if (tied) {
+    // resolved at once if each query's bucket is one repeated value (tied distances / probabilities);
+    // with three levels the second one may already have seen that (the third then did nothing)
+    bool tied = false;
+    if (levels == 3 && sel2_tied(tb->vor[0], tb->vnand[0], nq, 42)) {
+        tied = true;
 #pragma unroll
         for (int q = 0; q < SEL_MAXQ; ++q)
-            if (q < nq) { pre[q] = si->prefix[q] | (tb->vor[q] & low); kk[q] = 0; }
+            if (q < nq) { pre[q] = tb->st2.prefix[q] | (tb->vor[0][q] & ((1ull << 42) - 1)); kk[q] = 0; }
+    } else if (sel2_tied(tb->vor[levels - 2], tb->vnand[levels - 2], nq, shp)) {
+        tied = true;
+#pragma unroll
+        for (int q = 0; q < SEL_MAXQ; ++q)
+            if (q < nq) { pre[q] = si->prefix[q] | (tb->vor[levels - 2][q] & ((1ull << shp) - 1)); kk[q] = 0; }
     }
     const bool fits = !tied && cnt <= S2_CAP;   // else: the last 32 bits from LDS, or (mixed bucket too long) unfinished
     if (fits) {
@@ -579,14 +608,14 @@ int ann_kth_smallest(annchor_ctx *c, const double *vals, const uint8_t *flag, in
         ProfScope ps(c, "radix_select_f64", (double)n * 9.0);
         k_sel2_hist0<<<grid, S2_T, 0, c->stream>>>(vals, flag, n, tb);
         double *A = c->sel_bufA.as<double>(), *B = c->sel_bufB.as<double>();
-        k_sel2_filter<1, false><<<grid, S2_T, 0, c->stream>>>(vals, flag, n, nullptr, init, tb, A, segA);
+        k_sel2_filter<1><<<grid, S2_T, 0, c->stream>>>(vals, flag, n, nullptr, init, tb, A, segA);
         const char *l3 = getenv("ANNCHOR_SEL_LEVEL3_MIN");   // tests reach the three-level route on short lists
         if (n < (l3 ? atoll(l3) : S2_LEVEL3_MIN)) {
-            k_sel2_filter<2, true><<<grid, S2_T, 0, c->stream>>>(A, nullptr, n, segA, init, tb, B, segB);
+            k_sel2_filter<2><<<grid, S2_T, 0, c->stream>>>(A, nullptr, n, segA, init, tb, B, segB);
             k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, B, segB, ntiles, 2);
         } else {   // (C reuses A's slots: A is dead once B exists)
-            k_sel2_filter<2, false><<<grid, S2_T, 0, c->stream>>>(A, nullptr, n, segA, init, tb, B, segB);
-            k_sel2_filter<3, true><<<grid, S2_T, 0, c->stream>>>(B, nullptr, n, segB, init, tb, A, segA);
+            k_sel2_filter<2><<<grid, S2_T, 0, c->stream>>>(A, nullptr, n, segA, init, tb, B, segB);
+            k_sel2_filter<3><<<grid, S2_T, 0, c->stream>>>(B, nullptr, n, segB, init, tb, A, segA);
             k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, A, segA, ntiles, 3);
         }
     }

@@ -63,6 +63,37 @@ def euclid_shard(rank, n_per_rank, d=128):
     return (Z @ W + 0.05 * rng.standard_normal((n_per_rank, d))).astype(np.float32)
 
 
+def pairlist_at_scale(local, n=16000):
+    """The pair-list kernels at a size where HBM traffic, not launch latency, decides: N = 16000
+    Euclidean float64 points whose locality keeps every pair (127 M candidate pairs, ~1 GB per
+    per-pair column).  Two fits, the second one profiled with HIP events per kernel family.
+    Reported per family: average launch time, algorithmic GB/s (DESIGN.md's per-pair bytes) and
+    the fraction of the 8 TB/s HBM peak."""
+    from annchor_amd import Annchor
+    rng = np.random.default_rng(5)
+    Z = rng.standard_normal((n, 6))
+    X = (Z @ rng.standard_normal((6, 48)) + 0.05 * rng.standard_normal((n, 48))).astype(np.float64)
+    cfg = dict(n_anchors=24, n_neighbors=15, p_work=0.05, n_samples=5000)
+    Annchor(X, "euclidean", device=local, **cfg).fit()
+    ann = Annchor(X, "euclidean", device=local, **cfg)
+    ann._engine.prof_enable(1)
+    t = time.perf_counter()
+    ann.fit()
+    dt = time.perf_counter() - t
+    fams = {}
+    for name, e in sorted(ann._engine.prof_get().items(), key=lambda kv: -kv[1]["ms"]):
+        if not e["launches"]:
+            continue
+        us = e["ms"] / e["launches"] * 1e3
+        gbs = e["alg_bytes"] / e["launches"] / us / 1e3
+        fams[name] = {"avg_launch_us": round(us, 1), "launches": int(e["launches"]), "alg_GBps": round(gbs, 1),
+                      "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+    return {"workload": "synthetic Euclidean f64 N=%d d=48 n_anchors=24 k=15 p_work=0.05 (pair-list form)" % n,
+            "pairs": int(ann.n_pairs), "evals": int(ann.evals), "fit_time_s_profiled": dt,
+            "host_stage_ms": {k: round(v * 1e3, 1) for k, v in ann.timings.items()}, "kernels": fams,
+            "note": "fit time at this size is the host-side legacy-RNG sampling (get_sample); the table is the device kernels"}
+
+
 def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch):
     """BASELINE configs[2]/[4]: synthetic Euclidean float32, 1M rows per GPU, d=128,
     n_anchors=32, k=15, p_work=0.1, rows sharded across ranks (streamed form)."""
@@ -181,6 +212,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-euclid", action="store_true", help="skip the secondary row-sharded Euclidean workload")
+    ap.add_argument("--no-scale", action="store_true", help="skip the pair-list kernel table at N=16000 (127 M pairs)")
     ap.add_argument("--euclid-rows", type=int, default=1_000_000, help="rows per GPU of the Euclidean workload")
     ap.add_argument("--euclid-timeout", type=int, default=600, help="seconds before the secondary workload is abandoned")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -329,6 +361,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(X, cfg)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+
+    # ---- the pair-list kernels where HBM decides (single-GPU runs only; the line is complete by now)
+    if not args.no_scale and world == 1:
+        try:
+            out["pairlist_kernels_at_scale"] = pairlist_at_scale(local)
+        except Exception as e:
+            out["pairlist_kernels_at_scale"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- secondary workload (row-sharded Euclidean, collectives across ranks).  It must never cost
     # the primary line: the line is complete at this point, and a watchdog thread emits it and ends
