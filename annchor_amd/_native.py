@@ -56,6 +56,8 @@ _SIGNATURES = {
     "annchor_sample_pairs": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "annchor_legacy_prefetch": (ctypes.c_int, [ctypes.c_uint32, _i64]),
     "annchor_legacy_choice_ranks": (ctypes.c_int, [ctypes.c_uint32, _vp, _vp, _i32, _vp, _vp]),
+    "annchor_legacy_choice_begin": (ctypes.c_int, [ctypes.c_uint32, _vp, _vp, _i32, ctypes.POINTER(_vp)]),
+    "annchor_legacy_choice_end": (ctypes.c_int, [_vp, _vp, _vp]),
     "annchor_gather_features": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "annchor_evaluate_samples": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "annchor_set_samples": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
@@ -138,6 +140,28 @@ def legacy_choice_ranks(seed, counts, want):
     out = np.zeros(int(np.minimum(counts, want).sum()), dtype=np.int64)
     n_out = np.zeros(len(counts), dtype=np.int64)
     rc = lib.annchor_legacy_choice_ranks(int(seed) & 0xFFFFFFFF, _ptr(counts), _ptr(want), len(counts), _ptr(out), _ptr(n_out))
+    if rc != 0:
+        raise NativeError("annchor_legacy_choice_ranks failed (%d)" % rc)
+    return np.split(out, np.cumsum(n_out)[:-1])
+
+
+def legacy_choice_begin(seed, counts, want):
+    """legacy_choice_ranks on the library's persistent worker thread: returns a ticket at once."""
+    lib = load_library()
+    counts, want = _c(counts, np.int64), _c(want, np.int64)
+    t = _vp()
+    rc = lib.annchor_legacy_choice_begin(int(seed) & 0xFFFFFFFF, _ptr(counts), _ptr(want), len(counts), ctypes.byref(t))
+    if rc != 0:
+        raise NativeError("annchor_legacy_choice_begin failed (%d)" % rc)
+    return (t, int(np.minimum(counts, want).sum()), len(counts))
+
+
+def legacy_choice_end(ticket):
+    """Wait for legacy_choice_begin's draw; same return value as legacy_choice_ranks."""
+    t, total, nbins = ticket
+    out = np.zeros(total, dtype=np.int64)
+    n_out = np.zeros(nbins, dtype=np.int64)
+    rc = load_library().annchor_legacy_choice_end(t, _ptr(out), _ptr(n_out))
     if rc != 0:
         raise NativeError("annchor_legacy_choice_ranks failed (%d)" % rc)
     return np.split(out, np.cumsum(n_out)[:-1])

@@ -248,7 +248,7 @@ class Annchor:
         if type(self.sampler) is SimpleStratifiedSampler:
             ticket, self._sample_ticket = self._sample_ticket, None
             if ticket is None:
-                ticket = self.sampler.begin_device(eng, self.n_samples, self.random_seed)
+                ticket = self.sampler.begin_device(eng, self.n_samples, self.random_seed, overlap=False)
             if self._device_metric:   # positions, feature rows and distances in one device pass
                 (self.sample_ixs, self.n_samples, self.sample_bins, self.sample_features,
                  self.sample_y) = self.sampler.finish_device(ticket, evaluate=True)

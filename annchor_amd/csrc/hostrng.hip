@@ -27,6 +27,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
@@ -351,14 +353,24 @@ template <bool STORE> __attribute__((target("avx512f,avx512bw,popcnt"))) void sc
             size_t avail;
             const uint32_t *buf = S.fill(&avail);
             size_t p = S.cur;
-            while (p + 16 <= avail && i >= lo + 16) {
+            // The thresholds of a 16-draw block come from the running index TWO blocks back (i2):
+            // the index now is in [i2 - 32, i2] and stays within 16 of that inside the block, so a
+            // draw <= i2 - 48 is accepted and one > i2 rejected whatever happened in between.  The
+            // compare therefore does not wait for the previous block's popcount (GPR -> vector
+            // broadcast, compare, mask -> GPR, popcount: ~30 cycles of latency per block when
+            // chained; the chain now spans two blocks and overlaps).  A draw in (i2 - 48, i2]
+            // sends the block to the exact loop below.
+            uint32_t i1 = i, i2 = i;
+            while (p + 16 <= avail && i >= lo + 16 && i >= 64) {
                 const __m512i v = _mm512_and_si512(_mm512_loadu_si512(buf + p), vmask);
-                const __mmask16 acc = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32((int)(i - 16)));
-                const __mmask16 rej = _mm512_cmpgt_epu32_mask(v, _mm512_set1_epi32((int)i));
+                const __mmask16 acc = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32((int)(i2 - 48)));
+                const __mmask16 rej = _mm512_cmpgt_epu32_mask(v, _mm512_set1_epi32((int)i2));
                 if ((__mmask16)(acc | rej) != 0xffff) break;
                 if (STORE) _mm512_storeu_si512(Jc + t, _mm512_maskz_compress_epi32(acc, v));   // Jc has 32 words of slack
                 const uint32_t n = (uint32_t)__builtin_popcount(acc);
                 t += n;
+                i2 = i1;
+                i1 = i;
                 i -= n;
                 p += 16;
             }
@@ -373,6 +385,77 @@ template <bool STORE> __attribute__((target("avx512f,avx512bw,popcnt"))) void sc
         }
     }
 }
+
+// Persistent helpers for the backward traces.  A thread created per call lands on a sleeping
+// core with cold caches (measured on the box: the same draw takes 1.1-1.3 ms on a fresh thread,
+// 0.75-0.8 ms on a warm one); these block on a condition variable between calls, are woken when
+// a draw starts and spin on the bin states while the scan runs.
+struct HelperPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<uint64_t> gen{0};
+    const std::function<void()> *job = nullptr;
+    std::atomic<int> inside{0};
+    int nthreads = 0;
+    // After a job a helper keeps polling for the next one for a while before it blocks: the two
+    // draws of a fit are ~3 ms apart and consecutive fits follow at once, and a helper that went
+    // to sleep comes back on a cold, down-clocked core (its share then finishes 0.3 ms after the
+    // calling thread's).  ANNCHOR_RNG_SPIN_US = 0 turns the polling off.
+    static int64_t spin_ns()
+    {
+        static const int64_t v = 1000 * (getenv("ANNCHOR_RNG_SPIN_US") ? atoll(getenv("ANNCHOR_RNG_SPIN_US")) : 5000);
+        return v;
+    }
+    void start(int n)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (; nthreads < n; ++nthreads)
+            std::thread([this] {
+                uint64_t seen = 0;
+                for (;;) {
+                    // poll, then block
+                    const auto t0 = std::chrono::steady_clock::now();
+                    while (gen.load(std::memory_order_acquire) == seen) {
+                        _mm_pause();
+                        if (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() >= spin_ns()) {
+                            std::unique_lock<std::mutex> lk(mu);
+                            cv.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen; });
+                            break;
+                        }
+                    }
+                    const std::function<void()> *j;
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        seen = gen.load(std::memory_order_acquire);
+                        j = job;
+                        if (!j) continue;          // the job is already over: nothing to join
+                        inside.fetch_add(1, std::memory_order_acq_rel);
+                    }
+                    (*j)();
+                    inside.fetch_sub(1, std::memory_order_acq_rel);
+                }
+            }).detach();
+    }
+    void post(const std::function<void()> *j)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = j;
+            gen.fetch_add(1, std::memory_order_acq_rel);
+        }
+        cv.notify_all();
+    }
+    // no helper may enter the job any more; wait for those inside to leave it
+    void finish()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = nullptr;
+        }
+        while (inside.load(std::memory_order_acquire) != 0) _mm_pause();
+    }
+};
+HelperPool *g_helpers = new HelperPool();   // leaked on purpose: its threads outlive static destruction
 }  // namespace
 
 extern "C" int annchor_legacy_prefetch(uint32_t seed, int64_t ndraws)
@@ -487,18 +570,24 @@ extern "C" int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts,
     std::unique_ptr<std::atomic<int>[]> state(new std::atomic<int>[(size_t)nbins + 1]);
     for (int b = 0; b < nbins; ++b) state[(size_t)b].store(PENDING, std::memory_order_relaxed);
     auto trace_bin = [&](int b) {
+        const double t0 = timing ? ms_since(t_entry) : 0.0;
         trace_prefix(g_scratch[(size_t)b].get(), counts[b], want[b], ranks_out + offs[(size_t)b]);
+        if (timing) fprintf(stderr, "[rng]   bin %d (%lld): trace %.3f -> %.3f ms\n", b, (long long)counts[b], t0, ms_since(t_entry));
     };
-    std::thread helper;
-    if (nbins > 1)
-        helper = std::thread([&] {
-            for (int b = 0; b < nbins; ++b) {
-                int s;
-                while ((s = state[(size_t)b].load(std::memory_order_acquire)) == PENDING) _mm_pause();
-                int want_s = READY;
-                if (s == READY && state[(size_t)b].compare_exchange_strong(want_s, TAKEN, std::memory_order_acq_rel)) trace_bin(b);
-            }
-        });
+    const std::function<void()> claim_front = [&] {
+        for (int b = 0; b < nbins; ++b) {
+            int s;
+            while ((s = state[(size_t)b].load(std::memory_order_acquire)) == PENDING) _mm_pause();
+            int want_s = READY;
+            if (s == READY && state[(size_t)b].compare_exchange_strong(want_s, TAKEN, std::memory_order_acq_rel)) trace_bin(b);
+        }
+    };
+    static const int n_helpers = getenv("ANNCHOR_RNG_HELPERS") ? atoi(getenv("ANNCHOR_RNG_HELPERS")) : 3;
+    const bool pooled = nbins > 1 && n_helpers > 0;
+    if (pooled) {
+        g_helpers->start(n_helpers);
+        g_helpers->post(&claim_front);
+    }
     for (int b = 0; b < nbins; ++b) {
         const int64_t c = counts[b], k = want[b];
         int64_t *out = ranks_out + offs[(size_t)b];
@@ -521,9 +610,92 @@ extern "C" int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts,
         if (state[(size_t)b].compare_exchange_strong(want_s, TAKEN, std::memory_order_acq_rel)) trace_bin(b);
     }
     const double t_own = ms_since(t_entry);
-    if (helper.joinable()) helper.join();
+    if (pooled) g_helpers->finish();
     if (timing)
         fprintf(stderr, "[rng] scan done %.3f ms, own traces done %.3f ms, helper joined %.3f ms, words %zu, producer %s\n", t_scan,
                 t_own, ms_since(t_entry), S.cur, st->producing.load() ? "still running" : "finished");
     return ANNCHOR_OK;
+}
+
+// ---- the draw on a persistent worker thread (see include/annchor_hip.h)
+namespace {
+struct DrawJob {
+    uint32_t seed;
+    std::vector<int64_t> counts, want, ranks, n_out;
+    int rc = 0;
+    bool done = false;
+};
+struct DrawWorker {
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    std::vector<DrawJob *> queue;
+    bool started = false;
+    void submit(DrawJob *j)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!started) {
+                started = true;
+                std::thread([this] {
+                    for (;;) {
+                        DrawJob *job;
+                        {
+                            std::unique_lock<std::mutex> lk(mu);
+                            cv.wait(lk, [&] { return !queue.empty(); });
+                            job = queue.front();
+                            queue.erase(queue.begin());
+                        }
+                        job->rc = annchor_legacy_choice_ranks(job->seed, job->counts.data(), job->want.data(), (int32_t)job->counts.size(),
+                                                              job->ranks.data(), job->n_out.data());
+                        {
+                            std::lock_guard<std::mutex> lk(mu);
+                            job->done = true;
+                        }
+                        done_cv.notify_all();
+                    }
+                }).detach();
+            }
+            queue.push_back(j);
+        }
+        cv.notify_one();
+    }
+    void wait(DrawJob *j)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [&] { return j->done; });
+    }
+};
+DrawWorker *g_draw = new DrawWorker();   // leaked on purpose, like the helper pool
+}  // namespace
+
+extern "C" int annchor_legacy_choice_begin(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins, void **ticket)
+{
+    if (!counts || !want || !ticket || nbins < 0) return ANNCHOR_EINVAL;
+    DrawJob *j = new DrawJob();
+    j->seed = seed;
+    j->counts.assign(counts, counts + nbins);
+    j->want.assign(want, want + nbins);
+    int64_t tot = 0;
+    for (int b = 0; b < nbins; ++b) tot += counts[b] < want[b] ? (counts[b] > 0 ? counts[b] : 0) : (want[b] > 0 ? want[b] : 0);
+    j->ranks.resize((size_t)tot + 1);
+    j->n_out.resize((size_t)nbins + 1);
+    g_draw->submit(j);
+    *ticket = j;
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_legacy_choice_end(void *ticket, int64_t *ranks_out, int64_t *n_out)
+{
+    if (!ticket) return ANNCHOR_EINVAL;
+    DrawJob *j = static_cast<DrawJob *>(ticket);
+    g_draw->wait(j);
+    const int rc = j->rc;
+    if (rc == ANNCHOR_OK && ranks_out && n_out) {
+        const size_t nb = j->counts.size();
+        int64_t tot = 0;
+        for (size_t b = 0; b < nb; ++b) { n_out[b] = j->n_out[b]; tot += j->n_out[b]; }
+        memcpy(ranks_out, j->ranks.data(), sizeof(int64_t) * (size_t)tot);
+    }
+    delete j;
+    return rc == ANNCHOR_OK && !(ranks_out && n_out) ? ANNCHOR_EINVAL : rc;
 }

@@ -102,19 +102,19 @@ class SimpleStratifiedSampler(Sampler):
 
     def sample_device(self, engine, n_samples, random_seed):
         """Same result as sample(), computed against the device-resident state."""
-        return self.finish_device(self.begin_device(engine, n_samples, random_seed))
+        return self.finish_device(self.begin_device(engine, n_samples, random_seed, overlap=False))
 
-    def begin_device(self, engine, n_samples, random_seed):
+    def begin_device(self, engine, n_samples, random_seed, overlap=True):
         """First half of sample_device: the statistics the draw depends on (number of
         not-computed pairs, dad quantiles, bin counts -- functions of not_computed_mask and dad
-        only), then the draw itself on a host thread.  Annchor.fit() calls this as soon as the
-        refinement candidates are known, so that the draw overlaps the refinement kernel.
+        only), then the draw itself.  Annchor.fit() calls this as soon as the refinement candidates
+        are known, so that the draw overlaps the refinement kernel (overlap=True: the draw runs on
+        the library's persistent worker thread; overlap=False: nothing is enqueued in between, so
+        it runs here, on the calling thread's warm core).
         Errors are kept in the ticket and raised by finish_device, where sample() would raise."""
-        import threading
-
         from . import _native
 
-        ticket = {"engine": engine, "error": None, "thread": None, "per_bin": None}
+        ticket = {"engine": engine, "error": None, "draw": None, "per_bin": None}
         try:
             if self.partition_feature_name != "double anchor distance":
                 raise NotImplementedError
@@ -135,19 +135,14 @@ class SimpleStratifiedSampler(Sampler):
             seed = random_seed + self.loop_num
             ticket.update(n_samples=n_samples, sample_bins=sample_bins, counts=counts)
 
-            def draw():
-                try:
-                    if 0 <= seed < 2 ** 32:
-                        ticket["per_bin"] = _native.legacy_choice_ranks(seed, counts, want)
-                    else:  # outside the legacy int-seed range NumPy raises; keep its behaviour
-                        np.random.seed(seed)
-                        ticket["per_bin"] = [np.arange(c) if c < w else np.random.permutation(int(c))[:w]
-                                             for c, w in zip(counts, want)]
-                except BaseException as err:  # noqa: BLE001 -- re-raised in finish_device
-                    ticket["error"] = err
-
-            ticket["thread"] = threading.Thread(target=draw)
-            ticket["thread"].start()
+            if not 0 <= seed < 2 ** 32:  # outside the legacy int-seed range NumPy raises; keep its behaviour
+                np.random.seed(seed)
+                ticket["per_bin"] = [np.arange(c) if c < w else np.random.permutation(int(c))[:w]
+                                     for c, w in zip(counts, want)]
+            elif overlap:
+                ticket["draw"] = _native.legacy_choice_begin(seed, counts, want)
+            else:
+                ticket["per_bin"] = _native.legacy_choice_ranks(seed, counts, want)
         except BaseException as err:  # noqa: BLE001
             ticket["error"] = err
         return ticket
@@ -155,8 +150,15 @@ class SimpleStratifiedSampler(Sampler):
     def finish_device(self, ticket, evaluate=False):
         """evaluate=True (device metric): also returns the samples' feature rows and exact
         distances, from the fused annchor_sample_pairs call."""
-        if ticket["thread"] is not None:
-            ticket["thread"].join()
+        if ticket["draw"] is not None:
+            from . import _native
+
+            draw, ticket["draw"] = ticket["draw"], None
+            try:
+                ticket["per_bin"] = _native.legacy_choice_end(draw)
+            except BaseException as err:  # noqa: BLE001
+                if ticket["error"] is None:
+                    ticket["error"] = err
         if ticket["error"] is not None:
             raise ticket["error"]
         engine, n_samples, sample_bins = ticket["engine"], ticket["n_samples"], ticket["sample_bins"]

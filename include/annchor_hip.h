@@ -152,6 +152,12 @@ int annchor_select_by_rank(annchor_ctx *ctx, const double *bins, int32_t nbins, 
 int annchor_legacy_prefetch(uint32_t seed, int64_t ndraws);
 int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins,
                                 int64_t *ranks_out, int64_t *n_out);
+/* The same draw on the library's persistent worker thread (warm core, warm caches), so that it
+ * overlaps device work the caller enqueues meanwhile: begin() copies the inputs and returns at
+ * once; end() waits, writes ranks_out / n_out as annchor_legacy_choice_ranks would, returns its
+ * status and releases the ticket. */
+int annchor_legacy_choice_begin(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins, void **ticket);
+int annchor_legacy_choice_end(void *ticket, int64_t *ranks_out, int64_t *n_out);
 /* Gather features [m, 4] at the given pair positions (self.features[sample_ixs]). */
 int annchor_gather_features(annchor_ctx *ctx, const int64_t *pos, int64_t m, double *feats);
 /* get_sample (annchor.py:336-343): evaluate the metric on the sample pairs, clear

@@ -152,6 +152,32 @@ def test_library_rng_matches_numpy_legacy_stream():
             assert all(np.array_equal(a, b) for a, b in zip(got, ref))
 
 
+def test_library_rng_async_worker_matches_numpy():
+    """annchor_legacy_choice_begin / _end (the draw on the library's persistent worker thread, several
+    tickets outstanding, interleaved with synchronous calls) == NumPy's legacy stream; large bins so
+    that the lagged-threshold AVX-512 scan and the pooled backward traces are the code that runs."""
+    import __graft_entry__ as g
+
+    g.build()
+    from annchor_amd import _native
+
+    rng = np.random.RandomState(7)
+    jobs = []
+    for seed in (5, 6, 7, 8):
+        counts = rng.randint(50, 400000, 7)
+        want = np.array([715, 715, 714, 714, 714, 714, 714])
+        jobs.append((seed, counts, want, _native.legacy_choice_begin(seed, counts, want)))
+    sync = _native.legacy_choice_ranks(9, [300000, 2000, 70], [500, 500, 100])
+    np.random.seed(9)
+    ref = [np.arange(c) if c < w else np.random.permutation(int(c))[:w] for c, w in zip([300000, 2000, 70], [500, 500, 100])]
+    assert all(np.array_equal(a, b) for a, b in zip(sync, ref))
+    for seed, counts, want, ticket in jobs:
+        got = _native.legacy_choice_end(ticket)
+        np.random.seed(seed)
+        ref = [np.arange(c) if c < w else np.random.permutation(int(c))[:w] for c, w in zip(counts, want)]
+        assert len(got) == len(ref) and all(np.array_equal(a, b) for a, b in zip(got, ref))
+
+
 def test_library_rng_portable_path_matches_numpy():
     """The same check with the AVX-512 scan disabled (ANNCHOR_RNG_SCALAR=1 is read once per
     process, hence the subprocess)."""
