@@ -108,7 +108,8 @@ struct annchor_ctx {
     // this stack, the pinned path ~13 us; small uploads need no synchronisation at all)
     static constexpr int PIN_SLOTS = 8;
     static constexpr size_t PIN_SLOT_BYTES = 64 * 1024;
-    unsigned char *pin = nullptr;            // PIN_SLOTS + 1 slots: ring for uploads, last one for downloads
+    static constexpr size_t PIN_DL_BYTES = 1024 * 1024;   // downloads up to this size go through pinned memory
+    unsigned char *pin = nullptr;            // PIN_SLOTS slots: ring for uploads; then PIN_DL_BYTES for downloads
     hipEvent_t pin_ev[PIN_SLOTS] = {};
     bool pin_busy[PIN_SLOTS] = {};
     int pin_next = 0;

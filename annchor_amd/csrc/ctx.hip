@@ -79,7 +79,9 @@ int ann_h2d(annchor_ctx *c, void *dst, const void *src, size_t bytes)
 int ann_d2h(annchor_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (bytes == 0) return ANNCHOR_OK;
-    if (c->pin && bytes <= annchor_ctx::PIN_SLOT_BYTES) {
+    if (c->pin && bytes <= annchor_ctx::PIN_DL_BYTES) {
+        // (a pageable destination costs the runtime ~100 us of staging for a few hundred KB: the graph,
+        // the sample's feature rows)
         unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
         ANN_CHECK_HIP(c, hipMemcpyAsync(slot, src, bytes, hipMemcpyDeviceToHost, c->stream));
         ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
@@ -200,7 +202,7 @@ extern "C" int annchor_create(int device, annchor_ctx **out)
     (void)hipEventCreate(&c->call_a);
     (void)hipEventCreate(&c->call_b);
     if (getenv("ANNCHOR_NO_PIN") ||
-        hipHostMalloc((void **)&c->pin, (annchor_ctx::PIN_SLOTS + 1) * annchor_ctx::PIN_SLOT_BYTES, hipHostMallocDefault) != hipSuccess)
+        hipHostMalloc((void **)&c->pin, annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES + annchor_ctx::PIN_DL_BYTES, hipHostMallocDefault) != hipSuccess)
         c->pin = nullptr;   // fall back to pageable transfers
     for (int i = 0; i < annchor_ctx::PIN_SLOTS; ++i) (void)hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming);
     *out = c;

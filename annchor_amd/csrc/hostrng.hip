@@ -21,8 +21,8 @@
 //      backwards for those entries alone (bitmap-filtered), on a helper thread while the
 //      scan of the later bins proceeds, and on the calling thread once the scan is done.
 // Measured on the MI355X box's host (EPYC 9575F), C2 bin sizes (1.25 M draws, 1.8 M stream
-// words): scan 0.49 ms (AVX-512: 16 draws per compare + register compress; 1.5 ms portable),
-// trace tail 0.18 ms.
+// words): scan 0.43 ms (AVX-512: 16 draws per compare, thresholds lagged two blocks, register
+// compress; 1.5 ms portable), trace of the last big bin 0.25-0.35 ms on a pooled helper thread.
 #include <immintrin.h>
 
 #include <atomic>
@@ -397,13 +397,13 @@ struct HelperPool {
     const std::function<void()> *job = nullptr;
     std::atomic<int> inside{0};
     int nthreads = 0;
-    // After a job a helper keeps polling for the next one for a while before it blocks: the two
-    // draws of a fit are ~3 ms apart and consecutive fits follow at once, and a helper that went
-    // to sleep comes back on a cold, down-clocked core (its share then finishes 0.3 ms after the
-    // calling thread's).  ANNCHOR_RNG_SPIN_US = 0 turns the polling off.
+    // Optionally (ANNCHOR_RNG_SPIN_US > 0) a helper keeps polling for the next job for that long
+    // before it blocks.  Off by default: on the box's host (EPYC 9575F) 150-fit medians were 5.95 ms
+    // without polling and 6.15 ms with 5 ms of it -- the polling cores cost the calling thread more
+    // boost clock than their warm caches give back.
     static int64_t spin_ns()
     {
-        static const int64_t v = 1000 * (getenv("ANNCHOR_RNG_SPIN_US") ? atoll(getenv("ANNCHOR_RNG_SPIN_US")) : 5000);
+        static const int64_t v = 1000 * (getenv("ANNCHOR_RNG_SPIN_US") ? atoll(getenv("ANNCHOR_RNG_SPIN_US")) : 0);
         return v;
     }
     void start(int n)
@@ -629,6 +629,7 @@ struct DrawWorker {
     std::mutex mu;
     std::condition_variable cv, done_cv;
     std::vector<DrawJob *> queue;
+    std::atomic<int> pending{0};
     bool started = false;
     void submit(DrawJob *j)
     {
@@ -640,10 +641,18 @@ struct DrawWorker {
                     for (;;) {
                         DrawJob *job;
                         {
+                            // poll before blocking, like the trace helpers: the next draw of a running
+                            // series of fits is a few milliseconds away
+                            const auto t0 = std::chrono::steady_clock::now();
+                            while (pending.load(std::memory_order_acquire) == 0 &&
+                                   std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() <
+                                       HelperPool::spin_ns())
+                                _mm_pause();
                             std::unique_lock<std::mutex> lk(mu);
                             cv.wait(lk, [&] { return !queue.empty(); });
                             job = queue.front();
                             queue.erase(queue.begin());
+                            pending.fetch_sub(1, std::memory_order_acq_rel);
                         }
                         job->rc = annchor_legacy_choice_ranks(job->seed, job->counts.data(), job->want.data(), (int32_t)job->counts.size(),
                                                               job->ranks.data(), job->n_out.data());
@@ -656,6 +665,7 @@ struct DrawWorker {
                 }).detach();
             }
             queue.push_back(j);
+            pending.fetch_add(1, std::memory_order_acq_rel);
         }
         cv.notify_one();
     }

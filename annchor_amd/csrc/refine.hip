@@ -256,6 +256,15 @@ extern "C" int annchor_neighbor_graph(annchor_ctx *c, int32_t nn, int64_t *ng_id
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;
     ANN_CHECK_HIP(c, hipGetLastError());
+    if (c->pin && cells * 16 <= annchor_ctx::PIN_DL_BYTES) {
+        // indices and distances sit back to back: one transfer into the pinned download region
+        unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
+        ANN_CHECK_HIP(c, hipMemcpyAsync(slot, d_i, cells * 16, hipMemcpyDeviceToHost, c->stream));
+        ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        memcpy(ng_idx, slot, cells * 8);
+        memcpy(ng_dist, slot + cells * 8, cells * 8);
+        return ANNCHOR_OK;
+    }
     ANN_TRY(ann_d2h(c, ng_idx, d_i, cells * 8));
     return ann_d2h(c, ng_dist, d_d, cells * 8);
 }
