@@ -186,7 +186,23 @@ struct PairSource {
     const int32_t *idx = nullptr; // optional positions into ij: pair t = ij[idx[t]]
     const int32_t *anchor = nullptr; // one-to-all: pair t = (*anchor, t)
     int64_t n = 0;
+    // Max-min picking fused into a one-to-all launch (optional).  The launch first derives its own
+    // anchor from the previous round's distances: runmin = reset ? row : min(runmin, row), anchor =
+    // first arg-max of runmin (pickers.py:47-50), stored to *pick_out (== anchor) -- every workgroup
+    // computes it for itself, so the separate arg-max launch and its dispatch gap disappear.  A
+    // metric launch that did this sets *pick_fused; otherwise the caller picks as before.
+    const double *pick_row = nullptr;
+    double *pick_runmin = nullptr;
+    int32_t *pick_out = nullptr;
+    int pick_reset = 0;
+    bool *pick_fused = nullptr;
 };
+
+// np.argmax: first maximal index
+__device__ __forceinline__ void argmax_combine(double &v, int &i, double ov, int oi)
+{
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
 int ann_metric_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
 int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
 int ann_euclid_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);

@@ -250,6 +250,12 @@ struct LevArgsR {
     LevArgs b;
     int GL;        // lanes per slot = ceil(words / R)
     int pm_stride; // words per symbol row of a slot's PM table (GL * R)
+    // fused max-min pick (see PairSource): the anchor of this one-to-all launch is the first
+    // arg-max of the running minimum, derived by every wave for itself
+    const double *pick_row;
+    double *pick_runmin;
+    int32_t *pick_out;
+    int pick_reset, pick_nx;
 };
 
 #define LEVR_PAD 64   // text entries of padding either side of a slot's text (>= lanes per slot)
@@ -278,13 +284,49 @@ template <int R> __global__ __launch_bounds__(ANN_WAVE) void k_lev_r(LevArgsR ar
     if (slot_ok)
         for (int e = w * 8; e < a.text_stride / 2; e += GL * 8) *reinterpret_cast<uint4 *>(txt_g + e) = make_uint4(0, 0, 0, 0);
 
+    int picked = -1;
+    if (ar.pick_row) {
+        // every wave: runmin and its first arg-max over the (small) data set, loads batched;
+        // workgroup 0 also stores the running minimum and the anchor.  Other workgroups may read
+        // runmin[j] before or after that store: min(min(r, d), d) == min(r, d).
+        double bv = -INFINITY;
+        int bi = 0x7fffffff;
+        const int nx = ar.pick_nx;
+        for (int j0 = 0; j0 < nx; j0 += 64 * 8) {
+            double d[8], rm[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = min(j0 + e * 64 + lane, nx - 1);
+                d[e] = ar.pick_row[j];
+                rm[e] = ar.pick_reset ? 0.0 : ar.pick_runmin[j];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = j0 + e * 64 + lane;
+                if (j < nx) {
+                    const double v = ar.pick_reset ? d[e] : fmin(rm[e], d[e]);
+                    if (blockIdx.x == 0) ar.pick_runmin[j] = v;
+                    argmax_combine(bv, bi, v, j);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            argmax_combine(bv, bi, ov, oi);
+        }
+        picked = bi;
+        if (blockIdx.x == 0 && lane == 0) *ar.pick_out = bi;
+    }
+
     for (int64_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
         const int64_t t_pair = task * P + g;
         const bool active = slot_ok && t_pair < a.n;
         int si = 0, sj = 0;
         int64_t opos = t_pair;
         if (active) {
-            if (a.anchor) { si = *a.anchor; sj = (int)t_pair; }
+            if (a.anchor) { si = picked >= 0 ? picked : *a.anchor; sj = (int)t_pair; }
             else {
                 int64_t q = a.idx ? a.idx[t_pair] : t_pair;
                 int2 p = a.ij[q];
@@ -419,7 +461,7 @@ template <int R> __global__ __launch_bounds__(ANN_WAVE) void k_lev_r(LevArgsR ar
     }
 }
 
-template <int R> static int launch_r(annchor_ctx *c, LevArgs a, int64_t npairs)
+template <int R> static int launch_r(annchor_ctx *c, LevArgs a, int64_t npairs, const PairSource &src)
 {
     const int W = (c->maxlen + 31) / 32 > 0 ? (c->maxlen + 31) / 32 : 1;
     LevArgsR ar;
@@ -431,6 +473,16 @@ template <int R> static int launch_r(annchor_ctx *c, LevArgs a, int64_t npairs)
     a.text_stride = 2 * (2 * LEVR_PAD + ((c->maxlen + 15) & ~15) + 16);
     a.wave_bytes = a.pm_bytes + a.P * a.text_stride + 256;
     ar.b = a;
+    ar.pick_row = nullptr; ar.pick_runmin = nullptr; ar.pick_out = nullptr; ar.pick_reset = 0; ar.pick_nx = 0;
+    // fused anchor pick: each of the launch's waves scans all nx distances once, worth it while
+    // that is small against the launch's own work (and the separate arg-max launch it replaces)
+    if (src.anchor && src.pick_fused && c->nx <= 8192) {
+        *src.pick_fused = true;
+        if (src.pick_row) {
+            ar.pick_row = src.pick_row; ar.pick_runmin = src.pick_runmin; ar.pick_out = src.pick_out;
+            ar.pick_reset = src.pick_reset; ar.pick_nx = (int)c->nx;
+        }
+    }
     const size_t lds = (size_t)a.wave_bytes;
     ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "alphabet %d x length %d needs %zu B of LDS (> 160 KiB)", c->alphabet,
                 c->maxlen, lds);
@@ -483,7 +535,7 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
         int R = force_r >= 0 ? force_r : 1;
         if (R == 1 || R == 2 || R == 4) {
             ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
-            return R == 1 ? launch_r<1>(c, a, src.n) : R == 2 ? launch_r<2>(c, a, src.n) : launch_r<4>(c, a, src.n);
+            return R == 1 ? launch_r<1>(c, a, src.n, src) : R == 2 ? launch_r<2>(c, a, src.n, src) : launch_r<4>(c, a, src.n, src);
         }
     }
     // the two-columns-per-iteration kernel, one word per lane, one slot set per lane.  (The

@@ -12,12 +12,6 @@
 
 #define RED_THREADS 256
 
-__device__ __forceinline__ void argmax_combine(double &v, int &i, double ov, int oi)
-{
-    // np.argmax: first maximal index
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-}
-
 __global__ __launch_bounds__(RED_THREADS) void k_runmin_argmax(const double *__restrict__ row, double *__restrict__ runmin,
                                                               int64_t nx, int reset, double *__restrict__ redval,
                                                               int *__restrict__ redidx)
@@ -144,13 +138,24 @@ extern "C" int annchor_pick_anchors_maxmin(annchor_ctx *c, int32_t na, int64_t f
     int32_t f = (int32_t)first;
     ANN_TRY(ann_h2d(c, c->A.p, &f, sizeof f));
     ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    bool fused_prev = false;   // the launch of round r picked its own anchor from row r - 1
     for (int r = 0; r < na; ++r) {
         PairSource src;
         src.anchor = c->A.as<int32_t>() + r;
         src.n = nx;
         double *row = c->Dt.as<double>() + (size_t)r * nx;
+        bool fused = false;
+        if (r >= 1 && fused_prev) {   // (round 0 decides whether this metric fuses at all)
+            src.pick_row = row - nx;
+            src.pick_runmin = c->runmin.as<double>();
+            src.pick_out = c->A.as<int32_t>() + r;
+            src.pick_reset = r - 1 <= 1 ? 1 : 0;   // pickers.py:47-50: min over all rows for r == 0, over rows 1..r afterwards
+        }
+        src.pick_fused = &fused;
         ANN_TRY(ann_metric_launch(c, src, row, nullptr, nullptr));
-        if (r + 1 < na) {
+        if (r == 0) fused_prev = fused;             // a capable launch reports it even without a pick request
+        else if (fused_prev) ANN_REQUIRE(c, fused, ANNCHOR_ESTATE, "metric launch stopped fusing the anchor pick");
+        if (r + 1 < na && !fused_prev) {
             ProfScope ps(c, "maxmin_argmax", (double)nx * 24);
             // pickers.py:47-50: min over all rows for r == 0, over rows 1..r afterwards
             if (nx <= 16384)

@@ -12,7 +12,12 @@ state instead of on a materialised features array.
 """
 from abc import ABC, abstractmethod
 
+import os
+
 import numpy as np
+
+
+_WORKER_ALWAYS = os.environ.get("ANNCHOR_DRAW_WORKER_ALWAYS", "0") == "1"
 
 
 class NothingToSample(Exception):
@@ -139,7 +144,7 @@ class SimpleStratifiedSampler(Sampler):
                 np.random.seed(seed)
                 ticket["per_bin"] = [np.arange(c) if c < w else np.random.permutation(int(c))[:w]
                                      for c, w in zip(counts, want)]
-            elif overlap:
+            elif overlap or _WORKER_ALWAYS:
                 ticket["draw"] = _native.legacy_choice_begin(seed, counts, want)
             else:
                 ticket["per_bin"] = _native.legacy_choice_ranks(seed, counts, want)
