@@ -145,6 +145,7 @@ int ann_reserve(annchor_ctx *c, DevBuf &b, size_t bytes);
 int ann_arena_init(annchor_ctx *c, int64_t nx);
 int ann_h2d(annchor_ctx *c, void *dst, const void *src, size_t bytes);
 int ann_d2h(annchor_ctx *c, void *dst, const void *src, size_t bytes);
+int ann_d2h2(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, void *dst2, const void *src2, size_t bytes2);
 
 // profiling scopes: one entry per kernel family
 int ann_prof_entry(annchor_ctx *c, const char *name);

@@ -93,6 +93,23 @@ int ann_d2h(annchor_ctx *c, void *dst, const void *src, size_t bytes)
     return ANNCHOR_OK;
 }
 
+// two small downloads, one wait
+int ann_d2h2(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, void *dst2, const void *src2, size_t bytes2)
+{
+    const size_t off2 = (bytes1 + 63) & ~(size_t)63;
+    if (c->pin && off2 + bytes2 <= annchor_ctx::PIN_DL_BYTES) {
+        unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
+        ANN_CHECK_HIP(c, hipMemcpyAsync(slot, src1, bytes1, hipMemcpyDeviceToHost, c->stream));
+        ANN_CHECK_HIP(c, hipMemcpyAsync(slot + off2, src2, bytes2, hipMemcpyDeviceToHost, c->stream));
+        ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        memcpy(dst1, slot, bytes1);
+        memcpy(dst2, slot + off2, bytes2);
+        return ANNCHOR_OK;
+    }
+    ANN_TRY(ann_d2h(c, dst1, src1, bytes1));
+    return ann_d2h(c, dst2, src2, bytes2);
+}
+
 // ------------------------------------------------------------------ profiling
 int ann_prof_entry(annchor_ctx *c, const char *name)
 {

@@ -456,6 +456,17 @@ __global__ void k_clear_flags(const int32_t *__restrict__ pos, int64_t m, uint8_
     if (t < m) ncm[pos[t]] = 0;
 }
 
+// the same, plus the sample's distances and the error flag copied next to the staged positions /
+// feature rows (annchor_sample_pairs hands everything back in one transfer)
+__global__ void k_clear_flags_stage(const int32_t *__restrict__ pos, int64_t m, uint8_t *__restrict__ ncm,
+                                    const double *__restrict__ sy, const int32_t *__restrict__ bad, double *__restrict__ st_y,
+                                    int64_t *__restrict__ st_bad)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m) { ncm[pos[t]] = 0; st_y[t] = sy[t]; }
+    if (t == 0) *st_bad = *bad;
+}
+
 extern "C" int annchor_evaluate_samples(annchor_ctx *c, const int64_t *pos, int64_t m, double *sample_y)
 {
     if (!c || (m > 0 && (!pos || !sample_y))) return ANNCHOR_EINVAL;
@@ -503,16 +514,20 @@ extern "C" int annchor_sample_pairs(annchor_ctx *c, const double *bins, int32_t 
     c->nsamp = nreq;
     if (nreq == 0) return ANNCHOR_OK;
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
-    ANN_TRY(select_by_rank_device(c, bins, nbins, counts, bin_of, ranks, nreq));
+    // one staging block for everything the host gets back: positions | feature rows | distances | flag
+    const size_t stage_bytes = sizeof(double) * (6 * (size_t)nreq + 1);
+    ANN_TRY(ann_reserve(c, c->stage_out, stage_bytes));
+    ANN_TRY(select_by_rank_device(c, bins, nbins, counts, bin_of, ranks, nreq));   // positions -> stage_out[0 .. nreq)
     ANN_TRY(ann_reserve(c, c->spos, sizeof(int32_t) * (size_t)nreq + 16));
     ANN_TRY(ann_reserve(c, c->sy, sizeof(double) * (size_t)nreq));
-    ANN_TRY(ann_reserve(c, c->tmp3, sizeof(double) * 4 * (size_t)nreq));
+    double *st_feats = c->stage_out.as<double>() + nreq, *st_y = st_feats + 4 * (size_t)nreq;
+    int64_t *st_bad = reinterpret_cast<int64_t *>(st_y + nreq);
     int32_t *bad = c->spos.as<int32_t>() + nreq;
     ANN_CHECK_HIP(c, hipMemsetAsync(bad, 0, sizeof(int32_t), c->stream));
     k_pos_to_i32<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->stage_out.as<int64_t>(), nreq, c->spos.as<int32_t>(), bad);
     k_gather_features<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), nreq, c->lb.as<double>(),
                                                                    c->ub.as<double>(), c->dad.as<double>(), c->anc.as<uint8_t>(),
-                                                                   c->tmp3.as<double>());
+                                                                   st_feats);
     PairSource src;
     src.ij = c->ij.as<int2>();
     src.idx = c->spos.as<int32_t>();
@@ -521,13 +536,24 @@ extern "C" int annchor_sample_pairs(annchor_ctx *c, const double *bins, int32_t 
     ANN_TRY(ann_metric_launch(c, src, c->sy.as<double>(), nullptr, nullptr));
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;
-    k_clear_flags<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), nreq, c->ncm.as<uint8_t>());
+    k_clear_flags_stage<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), nreq, c->ncm.as<uint8_t>(),
+                                                                     c->sy.as<double>(), bad, st_y, st_bad);
     ANN_CHECK_HIP(c, hipGetLastError());
-    int32_t h_bad = 0;
-    ANN_TRY(ann_d2h(c, positions, c->stage_out.p, sizeof(int64_t) * (size_t)nreq));
-    ANN_TRY(ann_d2h(c, feats, c->tmp3.p, sizeof(double) * 4 * (size_t)nreq));
-    ANN_TRY(ann_d2h(c, sample_y, c->sy.p, sizeof(double) * (size_t)nreq));
-    ANN_TRY(ann_d2h(c, &h_bad, bad, sizeof(int32_t)));
+    int64_t h_bad = 0;
+    if (c->pin && stage_bytes <= annchor_ctx::PIN_DL_BYTES) {   // one transfer, one wait
+        unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
+        ANN_CHECK_HIP(c, hipMemcpyAsync(slot, c->stage_out.p, stage_bytes, hipMemcpyDeviceToHost, c->stream));
+        ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        memcpy(positions, slot, sizeof(int64_t) * (size_t)nreq);
+        memcpy(feats, slot + sizeof(double) * (size_t)nreq, sizeof(double) * 4 * (size_t)nreq);
+        memcpy(sample_y, slot + sizeof(double) * 5 * (size_t)nreq, sizeof(double) * (size_t)nreq);
+        memcpy(&h_bad, slot + sizeof(double) * 6 * (size_t)nreq, sizeof h_bad);
+    } else {
+        ANN_TRY(ann_d2h(c, positions, c->stage_out.p, sizeof(int64_t) * (size_t)nreq));
+        ANN_TRY(ann_d2h(c, feats, st_feats, sizeof(double) * 4 * (size_t)nreq));
+        ANN_TRY(ann_d2h(c, sample_y, st_y, sizeof(double) * (size_t)nreq));
+        ANN_TRY(ann_d2h(c, &h_bad, st_bad, sizeof h_bad));
+    }
     ANN_REQUIRE(c, !h_bad, ANNCHOR_ESTATE, "sample_pairs: a (bin, rank) entry does not exist (stale counts?)");
     if (c->n_unc >= 0) c->n_unc -= nreq;
     return ANNCHOR_OK;

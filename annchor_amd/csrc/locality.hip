@@ -221,8 +221,7 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
     ANN_TRY(ann_exclusive_scan_i32_to_i64(c, c->deg.as<int32_t>(), c->Iptr.as<int64_t>(), nx));
     int64_t n = 0;
     int32_t mn = 0;
-    ANN_TRY(ann_d2h(c, &n, c->rowstart.as<int64_t>() + nx, sizeof n));
-    ANN_TRY(ann_d2h(c, &mn, c->tmp2.p, sizeof mn));
+    ANN_TRY(ann_d2h2(c, &n, c->rowstart.as<int64_t>() + nx, sizeof n, &mn, c->tmp2.p, sizeof mn));
     ANN_REQUIRE(c, n < (1ll << 30), ANNCHOR_ELIMIT, "%lld candidate pairs exceed the pair-list limit", (long long)n);
     ANN_TRY(ann_reserve(c, c->ij, sizeof(int2) * (size_t)n));
     ANN_TRY(ann_reserve(c, c->Iidx, sizeof(int32_t) * 2 * (size_t)n));

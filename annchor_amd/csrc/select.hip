@@ -703,7 +703,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         ANN_TRY(ann_reserve(c, c->tmp2, 64));
         ANN_CHECK_HIP(c, hipMemsetAsync(c->marked.p, 0, (size_t)n, c->stream));
         ANN_CHECK_HIP(c, hipMemsetAsync(c->markcount.p, 0, sizeof(int32_t) * (size_t)nx, c->stream));
-        ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp2.p, 0, 4, c->stream));
+        ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp2.as<int32_t>() + 8, 0, 4, c->stream));   // sweep error flag (words 0..1: uncomputed count)
         {
             ProfScope ps(c, "guarantee_nmin_lists", (double)n * 26.0);
             const size_t tail = (((size_t)L * 12) + 15) & ~(size_t)15;
@@ -725,7 +725,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
                                                  (int)ring_lds));
             k_gn_sweep_ring<<<1, 256, ring_lds, c->stream>>>(nx, nmin, L, c->gl_val.as<double>(), c->gl_pos.as<int32_t>(), oth, twin,
                                                             c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
-                                                            c->RA.as<double>(), c->tmp2.as<int32_t>());
+                                                            c->RA.as<double>(), c->tmp2.as<int32_t>() + 8);
         } else if (sweep_lds <= 150 * 1024) {
             ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 21.0);
             int32_t *oth = c->gl_pos.as<int32_t>() + (size_t)nx * L, *twin = oth + (size_t)nx * L;
@@ -736,13 +736,13 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
                                                      (int)sweep_lds));
             k_gn_sweep_lds<<<1, 64, sweep_lds, c->stream>>>(nx, nmin, L, c->gl_val.as<double>(), c->gl_pos.as<int32_t>(), oth,
                                                            twin, c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
-                                                           c->RA.as<double>(), c->tmp2.as<int32_t>());
+                                                           c->RA.as<double>(), c->tmp2.as<int32_t>() + 8);
         } else {
             ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 13.0);
             k_gn_sequential<<<1, 64, 0, c->stream>>>(nx, nmin, L, c->gl_val.as<double>(), c->gl_pos.as<int32_t>(),
                                                     c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(), c->ij.as<int2>(),
                                                     c->RA.as<double>(), c->marked.as<uint8_t>(), c->markcount.as<int32_t>(),
-                                                    c->tmp2.as<int32_t>());
+                                                    c->tmp2.as<int32_t>() + 8);
         }
     }
     // ---- probabilities
@@ -762,11 +762,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
                                                c->errptr.as<int64_t>(), nlabels, in_lds, c->prob.as<double>());
     }
     ANN_CHECK_HIP(c, hipGetLastError());
-    if (nmin > 0) {
-        int32_t e = 0;
-        ANN_TRY(ann_d2h(c, &e, c->tmp2.p, 4));
-        ANN_REQUIRE(c, e == 0, ANNCHOR_ESTATE, "guarantee_nmin: a row has fewer not-computed candidates than it must refine");
-    }
+    // (the sweep's error flag is read with the final state below: one host wait less)
     // ---- cut values
     int64_t n_unc = 0;
     ANN_TRY(annchor_count_uncomputed(c, &n_unc));
@@ -810,7 +806,13 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;
     ANN_CHECK_HIP(c, hipGetLastError());
-    ANN_TRY(ann_d2h(c, &cs, c->sel_state.p, sizeof cs));
+    if (nmin > 0) {
+        int32_t e = 0;
+        ANN_TRY(ann_d2h2(c, &cs, c->sel_state.p, sizeof cs, &e, c->tmp2.as<int32_t>() + 8, 4));
+        ANN_REQUIRE(c, e == 0, ANNCHOR_ESTATE, "guarantee_nmin: a row has fewer not-computed candidates than it must refine");
+    } else {
+        ANN_TRY(ann_d2h(c, &cs, c->sel_state.p, sizeof cs));
+    }
     c->ncand = cs.ncand;
     c->n_unc = n_unc;  // candidates are distinct not-computed pairs: refinement lowers the count by ncand
     c->cand_marked = false;
