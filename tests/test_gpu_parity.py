@@ -107,6 +107,26 @@ def test_levenshtein_kernel_variants_ragged(variant, monkeypatch):
     assert np.array_equal(eng.metric_pairs(few), want[:7])
 
 
+@pytest.mark.parametrize("variant", ["0", "2"])
+def test_anchor_pick_fused_vs_separate(variant, strings, monkeypatch):
+    """The max-min anchor pick (pickers.py:47-50) fused into the next round's Levenshtein launch
+    (k_lev_r, default) against the separate arg-max launch (ANNCHOR_LEV_R=0: the kernel that does
+    not fuse) and against the two-words-per-lane variant of the fusing kernel: same anchors, same
+    anchor distances, same graph."""
+    from annchor_amd import Annchor
+    X = np.array(strings[::4])
+    cfg = dict(n_anchors=12, n_neighbors=10, n_samples=700, p_work=0.3, random_seed=42)
+    ref = Annchor(X, "levenshtein", **cfg)
+    ref.fit()
+    monkeypatch.setenv("ANNCHOR_LEV_R", variant)
+    alt = Annchor(X, "levenshtein", **cfg)
+    alt.fit()
+    assert np.array_equal(ref.A, alt.A)
+    assert np.array_equal(ref.D, alt.D)
+    assert np.array_equal(ref.neighbor_graph[0], alt.neighbor_graph[0])
+    assert np.array_equal(ref.neighbor_graph[1], alt.neighbor_graph[1])
+
+
 @pytest.mark.parametrize("dtype,dim", [(np.float32, 128), (np.float64, 64), (np.float64, 5)])
 def test_cosine_pairs_vs_scipy(dtype, dim):
     """'cosine' (reference utils.py:14,67 -> scipy.spatial.distance.cosine).  No reference test pins
