@@ -58,6 +58,7 @@ _SIGNATURES = {
     "annchor_legacy_choice_ranks": (ctypes.c_int, [ctypes.c_uint32, _vp, _vp, _i32, _vp, _vp]),
     "annchor_legacy_choice_begin": (ctypes.c_int, [ctypes.c_uint32, _vp, _vp, _i32, ctypes.POINTER(_vp)]),
     "annchor_legacy_choice_end": (ctypes.c_int, [_vp, _vp, _vp]),
+    "annchor_ols_bins": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "annchor_gather_features": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "annchor_evaluate_samples": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "annchor_set_samples": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
@@ -143,6 +144,45 @@ def legacy_choice_ranks(seed, counts, want):
     if rc != 0:
         raise NativeError("annchor_legacy_choice_ranks failed (%d)" % rc)
     return np.split(out, np.cumsum(n_out)[:-1])
+
+
+_DGELSD = None
+
+
+def _dgelsd_pointer():
+    """Address of scipy's Fortran dgelsd (the routine scipy.linalg.lapack.dgelsd wraps), or 0."""
+    global _DGELSD
+    if _DGELSD is None:
+        try:
+            from scipy.linalg import cython_lapack
+            cap = cython_lapack.__pyx_capi__["dgelsd"]
+            api = ctypes.pythonapi
+            api.PyCapsule_GetName.restype, api.PyCapsule_GetName.argtypes = ctypes.c_char_p, [ctypes.py_object]
+            api.PyCapsule_GetPointer.restype, api.PyCapsule_GetPointer.argtypes = ctypes.c_void_p, [ctypes.py_object, ctypes.c_char_p]
+            _DGELSD = api.PyCapsule_GetPointer(cap, api.PyCapsule_GetName(cap)) or 0
+        except Exception:  # noqa: BLE001 -- no scipy.linalg.cython_lapack: the Python path does the work
+            _DGELSD = 0
+    return _DGELSD
+
+
+def ols_bins(Xs, ys, cuts):
+    """Per-partition OLS pieces (coef, xmean, ymean, status) for samples grouped by partition; Xs is
+    the (n, nf) design matrix in column-major order, ys the targets, cuts the partition boundaries.
+    None when scipy's LAPACK pointer is not available."""
+    ptr = _dgelsd_pointer()
+    if not ptr:
+        return None
+    n, nf = Xs.shape
+    Xf = np.asfortranarray(Xs, dtype=np.float64)
+    ys = _c(ys, np.float64)
+    cuts = _c(cuts, np.int64)
+    nb = len(cuts) - 1
+    coef, xm = np.zeros((nb, nf)), np.zeros((nb, nf))
+    ym, status = np.zeros(nb), np.zeros(nb, dtype=np.int32)
+    rc = load_library().annchor_ols_bins(ptr, _ptr(Xf), _ptr(ys), n, nf, _ptr(cuts), nb, _ptr(coef), _ptr(xm), _ptr(ym), _ptr(status))
+    if rc != 0:
+        raise NativeError("annchor_ols_bins failed (%d)" % rc)
+    return coef, xm, ym, status
 
 
 def legacy_choice_begin(seed, counts, want):

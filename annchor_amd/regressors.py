@@ -9,6 +9,8 @@ the fused HIP kernel (predict + clip + merge + label).  `predict()` on a NumPy a
 is kept for plugin compatibility and evaluates the same expression, in the same
 floating-point order, with NumPy.
 """
+import os
+
 import numpy as np
 import scipy.linalg
 
@@ -71,12 +73,36 @@ class SimpleStratifiedLinearRegression:
         # stable sort groups the samples (original order kept inside a bin, so every sum runs
         # over the same numbers in the same order as with a boolean mask per bin)
         b = np.searchsorted(self.sample_bins[1:-1], F, side="left")
-        order = np.argsort(b, kind="stable")
-        Xs, ys = sample_features[order][:, i_features], sample_y[order]
-        cuts = np.searchsorted(b[order], np.arange(self.n_partitions + 1), side="left")
+        if b.size < 2 or bool(np.all(b[1:] >= b[:-1])):
+            # the stratified sampler hands its samples over bin by bin: already grouped (a stable
+            # sort of a sorted key is the identity), unless a value sits exactly on an edge
+            Xs, ys, bs = sample_features[:, i_features], sample_y, b
+        else:
+            order = np.argsort(b, kind="stable")
+            Xs, ys, bs = sample_features[order][:, i_features], sample_y[order], b[order]
+        cuts = np.searchsorted(bs, np.arange(self.n_partitions + 1), side="left")
+        batch = self._batched(Xs, ys, cuts)
         for nbin in range(self.n_partitions):
             lo, hi = cuts[nbin], cuts[nbin + 1]
-            self.coef_[nbin], self.intercept_[nbin] = _ols(Xs[lo:hi], ys[lo:hi])
+            if batch is not None and batch[3][nbin] == 0:
+                coef, xm, ym = batch[0][nbin], batch[1][nbin], batch[2][nbin]
+                self.coef_[nbin], self.intercept_[nbin] = coef, ym - xm @ coef
+            else:
+                self.coef_[nbin], self.intercept_[nbin] = _ols(Xs[lo:hi], ys[lo:hi])
+
+    @staticmethod
+    def _batched(Xs, ys, cuts):
+        """All partitions' centring + dgelsd in one native call (annchor_ols_bins: the same LAPACK
+        routine and the same summation orders as _ols, bit for bit -- tests/test_host_logic.py);
+        None when the library or scipy's LAPACK pointer is not there (the loop above then runs
+        _ols per partition)."""
+        if _gelsd is None or os.environ.get("ANNCHOR_OLS_PYTHON"):
+            return None
+        try:
+            from . import _native
+            return _native.ols_bins(Xs, ys, cuts)
+        except Exception:  # noqa: BLE001 -- e.g. the shared library has not been built
+            return None
 
     def coefficients(self):
         """(bins [nb+1], W [nb,3], c [nb]) for the fused device predict; None if the

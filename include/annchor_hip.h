@@ -158,6 +158,17 @@ int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts, const int6
  * status and releases the ticket. */
 int annchor_legacy_choice_begin(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins, void **ticket);
 int annchor_legacy_choice_end(void *ticket, int64_t *ranks_out, int64_t *n_out);
+
+/* Host-only helper (no device work, no context): the per-partition ordinary least squares of
+ * SimpleStratifiedLinearRegression.fit (annchor/regressors.py:60-84; sklearn LinearRegression =
+ * centre, LAPACK dgelsd, intercept) for all partitions in one call.  dgelsd_ptr: the Fortran
+ * dgelsd of the caller's LAPACK (Python: scipy.linalg.cython_lapack.__pyx_capi__["dgelsd"]).
+ * X: nf columns of ld doubles (column k at X + k * ld), y: ld doubles, samples grouped by
+ * partition: partition b = rows cuts[b] .. cuts[b+1].  Out: coef [nbins, nf], xmean [nbins, nf],
+ * ymean [nbins] (the intercept is ymean - xmean . coef), status [nbins] (0 = solved, 1 = fewer
+ * rows than features, > 1 = LAPACK failure: solve that partition on the caller's general path). */
+int annchor_ols_bins(void *dgelsd_ptr, const double *X, const double *y, int64_t ld, int32_t nf, const int64_t *cuts,
+                     int32_t nbins, double *coef, double *xmean, double *ymean, int32_t *status);
 /* Gather features [m, 4] at the given pair positions (self.features[sample_ixs]). */
 int annchor_gather_features(annchor_ctx *ctx, const int64_t *pos, int64_t m, double *feats);
 /* get_sample (annchor.py:336-343): evaluate the metric on the sample pairs, clear

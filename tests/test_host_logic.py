@@ -178,6 +178,57 @@ def test_library_rng_async_worker_matches_numpy():
         assert len(got) == len(ref) and all(np.array_equal(a, b) for a, b in zip(got, ref))
 
 
+def test_native_batched_ols_matches_python_path_bit_for_bit():
+    """annchor_ols_bins (centring with NumPy's pairwise sums + scipy's own dgelsd through its C
+    pointer) against regressors._ols, the Python restatement of the reference's per-partition
+    sklearn LinearRegression (annchor/regressors.py:60-84): identical coefficients and intercepts,
+    including rank-deficient partitions; partitions with fewer rows than features are left to the
+    Python path (status 1)."""
+    import __graft_entry__ as g
+
+    g.build()
+    from annchor_amd import _native
+    from annchor_amd.regressors import SimpleStratifiedLinearRegression, _ols
+
+    rng = np.random.RandomState(3)
+    compared = 0
+    for trial in range(60):
+        n = rng.randint(30, 4000)
+        F = rng.randn(n, 4) * rng.choice([1, 50, 1e-2])
+        yv = F[:, 0] * 0.3 + F[:, 1] * 0.5 + rng.randn(n) * 0.1
+        if trial % 7 == 0:
+            F[:, 1] = F[:, 0]   # rank deficient
+        order = np.argsort(rng.randint(0, 7, n), kind="stable")
+        Xs, ys = F[order][:, [0, 1, 2]], yv[order]
+        cuts = np.sort(np.r_[0, rng.randint(0, n + 1, 6), n])
+        out = _native.ols_bins(Xs, ys, cuts)
+        if out is None:
+            pytest.skip("scipy.linalg.cython_lapack does not expose dgelsd here")
+        coef, xm, ym, st = out
+        for b in range(7):
+            lo, hi = cuts[b], cuts[b + 1]
+            if hi - lo < 3:
+                assert st[b] == 1
+                continue
+            c, i = _ols(Xs[lo:hi], ys[lo:hi])
+            assert st[b] == 0 and np.array_equal(c, coef[b]) and i == ym[b] - xm[b] @ coef[b]
+            compared += 1
+    assert compared > 300
+    # and through the regressor: batched and per-partition fits agree exactly
+    names = ["lower bound", "upper bound", "double anchor distance", "is anchor"]
+    F = rng.rand(5000, 4) * 300
+    y = F[:, 2] * 0.8 + rng.randn(5000)
+    bins = np.hstack([-np.inf, np.linspace(30, 270, 6), np.inf])
+    a, b = SimpleStratifiedLinearRegression(), SimpleStratifiedLinearRegression()
+    a.fit(F, names, y, bins)
+    os.environ["ANNCHOR_OLS_PYTHON"] = "1"
+    try:
+        b.fit(F, names, y, bins)
+    finally:
+        del os.environ["ANNCHOR_OLS_PYTHON"]
+    assert np.array_equal(a.coef_, b.coef_) and np.array_equal(a.intercept_, b.intercept_)
+
+
 def test_library_rng_portable_path_matches_numpy():
     """The same check with the AVX-512 scan disabled (ANNCHOR_RNG_SCALAR=1 is read once per
     process, hence the subprocess)."""
