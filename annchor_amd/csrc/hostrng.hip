@@ -24,6 +24,7 @@
 // words): scan 0.43 ms (AVX-512: 16 draws per compare, thresholds lagged two blocks, register
 // compress; 1.5 ms portable), trace of the last big bin 0.25-0.35 ms on a pooled helper thread.
 #include <immintrin.h>
+#include <pthread.h>
 
 #include <atomic>
 #include <chrono>
@@ -676,6 +677,18 @@ struct DrawWorker {
     }
 };
 DrawWorker *g_draw = new DrawWorker();   // leaked on purpose, like the helper pool
+
+// fork(): the child has none of the parent's threads.  Give it fresh (thread-less) pools so that its
+// first draw starts its own instead of waiting for workers that do not exist.
+struct ForkGuard {
+    ForkGuard()
+    {
+        pthread_atfork(nullptr, nullptr, [] {
+            g_helpers = new HelperPool();
+            g_draw = new DrawWorker();
+        });
+    }
+} g_fork_guard;
 }  // namespace
 
 extern "C" int annchor_legacy_choice_begin(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins, void **ticket)

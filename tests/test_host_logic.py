@@ -229,6 +229,36 @@ def test_native_batched_ols_matches_python_path_bit_for_bit():
     assert np.array_equal(a.coef_, b.coef_) and np.array_equal(a.intercept_, b.intercept_)
 
 
+def test_library_rng_workers_survive_fork():
+    """The draw worker and the trace helpers are persistent threads; a forked child has none of them
+    and must start its own (pthread_atfork handler) instead of waiting for the parent's."""
+    import __graft_entry__ as g
+
+    g.build()
+    from annchor_amd import _native
+
+    counts, want = np.array([12000, 150000, 250000]), np.array([700, 700, 700])
+    a = _native.legacy_choice_end(_native.legacy_choice_begin(5, counts, want))
+    pid = os.fork()
+    if pid == 0:
+        try:
+            b = _native.legacy_choice_end(_native.legacy_choice_begin(5, counts, want))
+            ok = all(np.array_equal(x, y) for x, y in zip(a, b))
+        except BaseException:  # noqa: BLE001
+            ok = False
+        os._exit(0 if ok else 3)
+    import time
+    deadline = time.time() + 60
+    while time.time() < deadline:
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            assert os.WEXITSTATUS(status) == 0
+            return
+        time.sleep(0.05)
+    os.kill(pid, 9)
+    raise AssertionError("forked child hung in the draw")
+
+
 def test_library_rng_portable_path_matches_numpy():
     """The same check with the AVX-512 scan disabled (ANNCHOR_RNG_SCALAR=1 is read once per
     process, hence the subprocess)."""
