@@ -73,6 +73,16 @@ class _IndexCSR:
         return range(len(self))
 
 
+class _DeviceExact:
+    """get_exact(f, X, IJ) (utils.py:110-177) against the data set uploaded to `engine`."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def __call__(self, f, X, IJ):
+        return self.engine.metric_pairs(np.asarray(IJ, dtype=np.int64))
+
+
 class Annchor:
     """Quickly computes the approximate k-NN graph for slow metrics (annchor.py:21-115).
 
@@ -132,7 +142,7 @@ class Annchor:
                                              p_work=self.p_work, random_seed=random_seed, device=device)
             self._engine = self._streamed._engine
             self._device_metric = True
-            self.get_exact_ijs = self._device_get_exact_ijs
+            self.get_exact_ijs = _DeviceExact(self._engine)
             self.get_exact_query_ijs = None
             self._cache, self.timings = {}, {}
             return
@@ -142,7 +152,7 @@ class Annchor:
         self._device_metric = isinstance(self.f, DeviceMetric) and get_exact_ijs is None
         if self._device_metric:
             self.f.bind(self._engine, X)
-            self.get_exact_ijs = self._device_get_exact_ijs
+            self.get_exact_ijs = _DeviceExact(self._engine)
         else:
             self._engine.set_opaque(self.nx)
             if get_exact_ijs is None:
@@ -161,6 +171,9 @@ class Annchor:
     def _device_get_exact_ijs(self, f, X, IJ):
         """get_exact(f, X, IJ) (utils.py:110-177) against the uploaded data set."""
         return self._engine.metric_pairs(np.asarray(IJ, dtype=np.int64))
+    # (the `get_exact_ijs` attribute is a _DeviceExact holding the engine only: a bound method of
+    # self stored on self would be a reference cycle, and the engine -- a stream, pinned memory and
+    # the device arena -- would then live until the cyclic collector happens to run)
 
     # ------------------------------------------------------------- lazy NumPy views
     def _view(self, key, loader):

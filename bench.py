@@ -88,6 +88,12 @@ def pairlist_at_scale(local, n=16000):
         gbs = e["alg_bytes"] / e["launches"] / us / 1e3
         fams[name] = {"avg_launch_us": round(us, 1), "launches": int(e["launches"]), "alg_GBps": round(gbs, 1),
                       "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+    res = _scale_result(ann, n, dt, fams)
+    ann._engine.close()   # ~10 GB of device arena: release it now, not whenever the collector runs
+    return res
+
+
+def _scale_result(ann, n, dt, fams):
     return {"workload": "synthetic Euclidean f64 N=%d d=48 n_anchors=24 k=15 p_work=0.05 (pair-list form)" % n,
             "pairs": int(ann.n_pairs), "evals": int(ann.evals), "fit_time_s_profiled": dt,
             "host_stage_ms": {k: round(v * 1e3, 1) for k, v in ann.timings.items()}, "kernels": fams,

@@ -172,3 +172,26 @@ def test_function_input_forms_agree():
         i, j = rs.randint(60, size=2)
         assert np.isclose(a1.f(X[i], X[j]), a2.f(X[i], X[j])) and np.isclose(a2.f(X[i], X[j]), a5.f(X[i], X[j]))
         assert np.isclose(a5.f(X[i], X[j]), H.pairs(np.array([[i, j]]))[0], rtol=0, atol=1e-12)
+
+
+def test_engine_released_with_the_annchor_object():
+    """An Annchor holds no reference cycle through its engine: dropping the last reference destroys
+    the device context at once (stream, pinned memory, device arena), not whenever the cyclic
+    collector runs."""
+    import gc
+    import weakref
+
+    from annchor_amd import Annchor
+    from annchor_amd.datasets import load_strings
+
+    X = load_strings()["X"][::4]
+    gc.collect()
+    gc.disable()
+    try:
+        ann = Annchor(X, "levenshtein", n_anchors=12, n_neighbors=10, n_samples=700, p_work=0.3)
+        ann.fit()
+        eng = weakref.ref(ann._engine)
+        del ann
+        assert eng() is None
+    finally:
+        gc.enable()
