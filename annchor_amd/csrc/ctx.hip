@@ -3,6 +3,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include <mutex>
 
 static std::string g_create_err;
 void ann_stream_release(annchor_ctx *c);
@@ -42,11 +43,18 @@ int ann_reserve(annchor_ctx *c, DevBuf &b, size_t bytes)
 
 int ann_arena_init(annchor_ctx *c, int64_t nx)
 {
-    if (c->arena) return ANNCHOR_OK;  // one slab per context
     // pair-list state is ~100 B per candidate pair (worst case: all pairs) + O(nx) rows
     double pairs = 0.5 * (double)nx * (double)(nx - 1);
     if (pairs > 32e6) pairs = 32e6;  // larger problems fall back to per-buffer allocations beyond the slab
     size_t bytes = (size_t)(pairs * 112.0) + (size_t)nx * 4096 + ((size_t)64 << 20);
+    if (c->arena) {
+        // one slab per context; a slab inherited from a parked context (see annchor_destroy) is kept
+        // when it is large enough and nothing has been carved from it yet
+        if (c->arena_size >= bytes || c->arena_off != 0) return ANNCHOR_OK;
+        (void)hipFree(c->arena);
+        c->arena = nullptr;
+        c->arena_size = 0;
+    }
     void *p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return ANNCHOR_OK; }  // optional
     c->arena = (char *)p;
@@ -194,6 +202,26 @@ extern "C" int annchor_prof_get(annchor_ctx *c, int32_t max_entries, const char 
 }
 
 // ------------------------------------------------------------------ lifecycle
+// What a context needs from the runtime besides its buffers.  A destroyed context parks these for
+// the next one on the same device: hipStreamCreate / hipStreamDestroy / hipHostMalloc / hipHostFree
+// and the slab's hipMalloc / hipFree add up to ~4 ms per context on this stack
+// (tools/lifecycle_time.py), against a 5.5 ms fit.  Parked shells are never freed (process exit).
+struct CtxShell {
+    int device = 0;
+    hipDeviceProp_t prop;
+    hipStream_t stream = nullptr;
+    unsigned char *pin = nullptr;
+    hipEvent_t pin_ev[annchor_ctx::PIN_SLOTS] = {};
+    hipEvent_t call_a = nullptr, call_b = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    char *arena = nullptr;
+    size_t arena_size = 0;
+};
+static std::mutex g_shell_mu;
+static std::vector<CtxShell> g_shells;
+static constexpr size_t SHELL_MAX = 4;
+static constexpr size_t SHELL_ARENA_MAX = (size_t)2 << 30;
+
 extern "C" int annchor_create(int device, annchor_ctx **out)
 {
     if (!out) return ANNCHOR_EINVAL;
@@ -210,7 +238,29 @@ extern "C" int annchor_create(int device, annchor_ctx **out)
     }
     annchor_ctx *c = new annchor_ctx();
     c->device = device;
-    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&c->prop, device)) != hipSuccess ||
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        ann_set_err(nullptr, "device init failed: %s", hipGetErrorString(e));
+        delete c;
+        return ANNCHOR_EHIP;
+    }
+    {
+        // a parked shell of this device (stream, pinned staging, events, device slab): creating and
+        // destroying those costs ~4 ms per context, more than half a C2 fit
+        std::lock_guard<std::mutex> lk(g_shell_mu);
+        for (size_t i = 0; i < g_shells.size(); ++i)
+            if (g_shells[i].device == device) {
+                CtxShell &sh = g_shells[i];
+                c->prop = sh.prop; c->stream = sh.stream; c->pin = sh.pin;
+                for (int k = 0; k < annchor_ctx::PIN_SLOTS; ++k) c->pin_ev[k] = sh.pin_ev[k];
+                c->call_a = sh.call_a; c->call_b = sh.call_b;
+                c->ev_pool.swap(sh.ev_pool);
+                c->arena = sh.arena; c->arena_size = sh.arena_size; c->arena_off = 0;
+                g_shells.erase(g_shells.begin() + (long)i);
+                *out = c;
+                return ANNCHOR_OK;
+            }
+    }
+    if ((e = hipGetDeviceProperties(&c->prop, device)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         ann_set_err(nullptr, "device init failed: %s", hipGetErrorString(e));
         delete c;
@@ -243,6 +293,24 @@ extern "C" void annchor_destroy(annchor_ctx *c)
                       &c->stage_in, &c->stage_out};
     for (DevBuf *b : bufs)
         if (b->p && !b->in_arena) (void)hipFree(b->p);
+    {
+        // park the shell for the next context of this device (at most SHELL_MAX of them, slabs up to
+        // SHELL_ARENA_MAX; ANNCHOR_NO_CTX_POOL=1 turns the parking off)
+        static const bool no_pool = getenv("ANNCHOR_NO_CTX_POOL") != nullptr;
+        std::lock_guard<std::mutex> lk(g_shell_mu);
+        if (!no_pool && g_shells.size() < SHELL_MAX && c->stream && c->pin) {
+            CtxShell sh;
+            sh.device = c->device; sh.prop = c->prop; sh.stream = c->stream; sh.pin = c->pin;
+            for (int k = 0; k < annchor_ctx::PIN_SLOTS; ++k) sh.pin_ev[k] = c->pin_ev[k];
+            sh.call_a = c->call_a; sh.call_b = c->call_b;
+            sh.ev_pool.swap(c->ev_pool);
+            sh.arena = c->arena; sh.arena_size = c->arena_size;
+            if (sh.arena && sh.arena_size > SHELL_ARENA_MAX) { (void)hipFree(sh.arena); sh.arena = nullptr; sh.arena_size = 0; }
+            g_shells.push_back(std::move(sh));
+            delete c;
+            return;
+        }
+    }
     if (c->arena) (void)hipFree(c->arena);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < annchor_ctx::PIN_SLOTS; ++i)

@@ -18,11 +18,21 @@ def encode_strings(strings):
     Symbols are mapped to dense codes 0..A-1 (A <= 256)."""
     strings = list(strings)
     lens = np.fromiter((len(s) for s in strings), dtype=np.int32, count=len(strings))
-    raw = np.frombuffer("".join(strings).encode("utf-32-le"), dtype=np.uint32)
-    symbols = np.unique(raw)
-    if symbols.size > 256:
-        raise ValueError("levenshtein on the GPU supports at most 256 distinct symbols, got %d" % symbols.size)
-    codes = np.searchsorted(symbols, raw).astype(np.uint8)
+    joined = "".join(strings)
+    try:
+        # every code point below 256 (the usual case): one byte per symbol, dense codes through a
+        # 256-entry table -- the general path below sorts the whole text to find its alphabet
+        # (10 ms for the 0.8 M symbols of the C2 data set, against a 5.5 ms fit)
+        raw = np.frombuffer(joined.encode("latin-1"), dtype=np.uint8)
+        present = np.bincount(raw, minlength=256) > 0
+        symbols = np.flatnonzero(present)
+        codes = (np.cumsum(present) - 1).astype(np.uint8)[raw]
+    except UnicodeEncodeError:
+        raw = np.frombuffer(joined.encode("utf-32-le"), dtype=np.uint32)
+        symbols = np.unique(raw)
+        if symbols.size > 256:
+            raise ValueError("levenshtein on the GPU supports at most 256 distinct symbols, got %d" % symbols.size)
+        codes = np.searchsorted(symbols, raw).astype(np.uint8)
     offs = np.zeros(len(strings), dtype=np.int64)
     if len(strings) > 1:
         np.cumsum(lens[:-1], out=offs[1:])
