@@ -240,8 +240,14 @@ extern "C" int annchor_neighbor_graph(annchor_ctx *c, int32_t nn, int64_t *ng_id
     ANN_REQUIRE(c, nn >= 2 && nn <= 1024, ANNCHOR_ELIMIT, "n_neighbors=%d: 2..1024 supported", nn);
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     const size_t cells = (size_t)c->nx * nn;
+    // Small graphs are written by the kernel straight into the pinned download region (hipHostMalloc
+    // memory is device addressable): the device-to-host copy and its dispatch (~100 us after the
+    // kernel on this stack) disappear, only the wait remains.  ANNCHOR_NO_ZEROCOPY=1: staged copy.
+    static const bool no_zc = getenv("ANNCHOR_NO_ZEROCOPY") != nullptr;
+    const bool direct = c->pin && !no_zc && cells * 16 <= annchor_ctx::PIN_DL_BYTES;
+    unsigned char *slot = c->pin ? c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES : nullptr;
     ANN_TRY(ann_reserve(c, c->stage_out, cells * 16));
-    int64_t *d_i = c->stage_out.as<int64_t>();
+    int64_t *d_i = direct ? reinterpret_cast<int64_t *>(slot) : c->stage_out.as<int64_t>();
     double *d_d = reinterpret_cast<double *>(d_i + cells);
     ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
     {
@@ -256,9 +262,14 @@ extern "C" int annchor_neighbor_graph(annchor_ctx *c, int32_t nn, int64_t *ng_id
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;
     ANN_CHECK_HIP(c, hipGetLastError());
+    if (direct) {
+        ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        memcpy(ng_idx, slot, cells * 8);
+        memcpy(ng_dist, slot + cells * 8, cells * 8);
+        return ANNCHOR_OK;
+    }
     if (c->pin && cells * 16 <= annchor_ctx::PIN_DL_BYTES) {
         // indices and distances sit back to back: one transfer into the pinned download region
-        unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
         ANN_CHECK_HIP(c, hipMemcpyAsync(slot, d_i, cells * 16, hipMemcpyDeviceToHost, c->stream));
         ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
         memcpy(ng_idx, slot, cells * 8);
