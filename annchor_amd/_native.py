@@ -32,6 +32,7 @@ _SIGNATURES = {
     "annchor_last_error": (ctypes.c_char_p, [_vp]),
     "annchor_create_error": (ctypes.c_char_p, []),
     "annchor_device_name": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
+    "annchor_device_pci_bus_id": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
     "annchor_synchronize": (ctypes.c_int, [_vp]),
     "annchor_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "annchor_set_strings": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32]),
@@ -125,6 +126,36 @@ def _ptr(a):
 
 def _c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
+
+
+def bind_to_device_numa(device=0):
+    """Restrict this process (and the threads it starts from now on) to the CPUs of the NUMA node
+    the GPU hangs off -- what `numactl --cpunodebind` does for a launcher.  Call it before the first
+    Annchor / Engine is created.  On the MI355X box the C2 fit takes 5.25 ms from the GPU's node and
+    5.57 ms from the other one.  Returns a description, or None when the topology cannot be read."""
+    import os
+
+    buf = ctypes.create_string_buffer(64)
+    try:
+        if load_library().annchor_device_pci_bus_id(int(device), buf, 64) != 0:
+            return None
+        bus = buf.value.decode().lower()
+        with open("/sys/bus/pci/devices/%s/numa_node" % bus) as fh:
+            node = int(fh.read())
+        if node < 0:
+            return None
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as fh:
+            cpus = set()
+            for part in fh.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return "NUMA node %d of GPU %s (%d CPUs)" % (node, bus, len(cpus))
+    except (OSError, ValueError, AttributeError):
+        return None
 
 
 def legacy_prefetch(seed, ndraws):

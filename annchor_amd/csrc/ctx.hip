@@ -322,6 +322,14 @@ extern "C" void annchor_destroy(annchor_ctx *c)
     delete c;
 }
 
+// PCI bus id of a device ("0000:c1:00.0"): lets a launcher bind its process to the CPUs of the
+// GPU's NUMA node (/sys/bus/pci/devices/<id>/numa_node) before it creates contexts
+extern "C" int annchor_device_pci_bus_id(int device, char *buf, int buflen)
+{
+    if (!buf || buflen < 16) return ANNCHOR_EINVAL;
+    return hipDeviceGetPCIBusId(buf, buflen, device) == hipSuccess ? ANNCHOR_OK : ANNCHOR_EHIP;
+}
+
 extern "C" const char *annchor_last_error(annchor_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 extern "C" const char *annchor_create_error(void) { return g_create_err.c_str(); }
 

@@ -223,6 +223,7 @@ def main():
     ap.add_argument("--euclid-timeout", type=int, default=600, help="seconds before the secondary workload is abandoned")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank flow)")
+    ap.add_argument("--no-numa-bind", action="store_true", help="do not bind the process to the CPUs of the GPU's NUMA node")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0 (implies --backend gloo)")
     args = ap.parse_args()
 
@@ -245,6 +246,12 @@ def main():
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
     from annchor_amd import Annchor, compare_neighbor_graphs
+    from annchor_amd import _native as _nat
+
+    # one process per GPU, bound to the CPUs next to it (the launcher's numactl, done here so that
+    # the driver's plain `python bench.py` / torch.distributed.run command lines get it too)
+    all_cpus = os.sched_getaffinity(0)
+    affinity = None if args.no_numa_bind else _nat.bind_to_device_numa(local)
 
     X, metric, kwargs, cfg, workload = strings_workload()
     # constructors (engine creation, upload, plumbing smoke test) are outside the timed region
@@ -301,6 +308,7 @@ def main():
             "data": "reference fixture (annchor/data/edit_data.npz: 1600 synthetic strings, length 378-594)",
             "config": {"workload": workload, "graphs_per_step_per_gpu": 1, "parallelism": "independent graph build per GPU"},
             "device": ann._engine.device_name(),
+            "cpu_affinity": affinity or "unbound",
         }
         # ---- recall vs brute force (golden truth regenerated with the oracle metric)
         G = np.load(os.path.join(ROOT, "tests", "golden", "strings_full.npz"))
@@ -365,8 +373,11 @@ def main():
                 out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": g["alg_GBps"], "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": g["hbm_frac"], "traffic": None}
         if not args.no_cpu_baseline and world == 1:
+            os.sched_setaffinity(0, all_cpus)   # the CPU baseline gets every core of the host, not one NUMA node
             out["cpu_baseline"] = cpu_baseline(X, cfg)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            if affinity:
+                _nat.bind_to_device_numa(local)
 
     # ---- the pair-list kernels where HBM decides (single-GPU runs only; the line is complete by now)
     if not args.no_scale and world == 1:
