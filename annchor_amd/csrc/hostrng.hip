@@ -187,6 +187,7 @@ std::vector<std::pair<uint32_t, std::shared_ptr<Stream>>> g_cache;   // most rec
 
 std::shared_ptr<Stream> cache_take(uint32_t seed)   // g_mu held
 {
+    if (getenv("ANNCHOR_RNG_NO_CACHE")) { g_cache.clear(); return nullptr; }
     for (size_t i = 0; i < g_cache.size(); ++i)
         if (g_cache[i].first == seed) {
             auto st = g_cache[i].second;
@@ -197,6 +198,7 @@ std::shared_ptr<Stream> cache_take(uint32_t seed)   // g_mu held
 }
 void cache_put(uint32_t seed, const std::shared_ptr<Stream> &st)   // g_mu held
 {
+    if (getenv("ANNCHOR_RNG_NO_CACHE")) return;   // (read per call: bench.py reports the fit time without the cache too)
     if (st->producing.load() || st->ready.load() > RNG_CACHE_MAX_WORDS) return;
     if (st->producer.joinable()) st->producer.join();
     g_cache.push_back({seed, st});
@@ -464,6 +466,7 @@ extern "C" int annchor_legacy_prefetch(uint32_t seed, int64_t ndraws)
     if (ndraws <= 0 || ndraws > (1ll << 33)) return ANNCHOR_EINVAL;
     {
         std::lock_guard<std::mutex> lk(g_mu);
+        if (getenv("ANNCHOR_RNG_NO_CACHE")) g_cache.clear();
         for (auto &e : g_cache)
             if (e.first == seed && e.second->ready.load() >= (size_t)ndraws) return ANNCHOR_OK;   // already generated
     }
