@@ -87,8 +87,50 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const int32_t *__re
     }
 }
 
+// short inputs (the per-row arrays of a small data set): the whole scan in one workgroup, one launch
+#define SCAN1_THREADS 1024
+#define SCAN1_ITEMS 8
+__global__ __launch_bounds__(SCAN1_THREADS) void k_scan_one(const int32_t *__restrict__ in, int64_t n, int64_t *__restrict__ out)
+{
+    __shared__ int64_t wsum[SCAN1_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)threadIdx.x * SCAN1_ITEMS;   // thread-contiguous: scan order = index order
+    int32_t v[SCAN1_ITEMS];
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN1_ITEMS; ++k) v[k] = ann_ldc(in, base + k, n);
+#pragma unroll
+    for (int k = 0; k < SCAN1_ITEMS; ++k) {
+        if (base + k >= n) v[k] = 0;
+        s += v[k];
+    }
+    int64_t inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int64_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int64_t pre = 0, tot = 0;
+    for (int w = 0; w < SCAN1_THREADS / 64; ++w) { const int64_t x = wsum[w]; if (w < wave) pre += x; tot += x; }
+    int64_t ex = pre + inc - s;
+#pragma unroll
+    for (int k = 0; k < SCAN1_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = ex;
+        ex += v[k];
+    }
+    if (threadIdx.x == 0) out[n] = tot;
+}
+
 int ann_exclusive_scan_i32_to_i64(annchor_ctx *c, const int32_t *in, int64_t *out, int64_t n)
 {
+    if (n >= 1 && n <= SCAN1_THREADS * SCAN1_ITEMS) {
+        ProfScope ps(c, "exclusive_scan", (double)n * 12);
+        k_scan_one<<<1, SCAN1_THREADS, 0, c->stream>>>(in, n, out);
+        ANN_CHECK_HIP(c, hipGetLastError());
+        return ANNCHOR_OK;
+    }
     int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
     if (nb < 1) nb = 1;
     ANN_TRY(ann_reserve(c, c->scan_tmp, sizeof(int64_t) * (size_t)(nb + 1)));
