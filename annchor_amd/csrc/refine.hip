@@ -138,7 +138,14 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
         k_comp_count<<<(int)nx, ROW_THREADS, 0, c->stream>>>(c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(), c->ncm.as<uint8_t>(),
                                                             c->tmp1.as<int32_t>());
         ANN_TRY(ann_exclusive_scan_i32_to_i64(c, c->tmp1.as<int32_t>(), c->cptr.as<int64_t>(), nx));
-        ANN_TRY(ann_d2h(c, &total, c->cptr.as<int64_t>() + nx, sizeof total));
+        // how many computed entries (both directions)?  Small lists: room for the worst case (every pair
+        // computed) instead of a host wait for the exact number; the profile's byte count then uses the
+        // host's running count of computed pairs
+        if ((size_t)c->n * 2 * 12 <= ((size_t)256 << 20)) {
+            total = 2 * c->n;
+        } else {
+            ANN_TRY(ann_d2h(c, &total, c->cptr.as<int64_t>() + nx, sizeof total));
+        }
         ANN_TRY(ann_reserve(c, c->cidx, sizeof(int32_t) * (size_t)(total + 1)));
         ANN_TRY(ann_reserve(c, c->cval, sizeof(double) * (size_t)(total + 1)));
         k_comp_fill<<<(int)nx, ROW_THREADS, 0, c->stream>>>(c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(), c->ncm.as<uint8_t>(),
@@ -147,7 +154,8 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
     }
     {
         // algorithmic bytes per lookahead pair: both computed lists once, 12 B per entry
-        const double avg = nx > 0 ? (double)total / (double)nx : 0.0;
+        const int64_t counted = c->n_unc >= 0 ? 2 * (c->n - c->n_unc) : total;   // computed entries, both directions
+        const double avg = nx > 0 ? (double)counted / (double)nx : 0.0;
         ProfScope ps(c, "update_bounds_intersect", (double)c->nnext * (2.0 * avg * 12.0 + 36.0));
         k_update_bounds<<<ann_blocks(c->nnext * 64, 256), 256, 0, c->stream>>>(
             c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(),
