@@ -29,6 +29,7 @@ _vp, _i32, _i64, _dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.
 _SIGNATURES = {
     "annchor_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "annchor_destroy": (None, [_vp]),
+    "annchor_release_parked": (ctypes.c_int, []),
     "annchor_last_error": (ctypes.c_char_p, [_vp]),
     "annchor_create_error": (ctypes.c_char_p, []),
     "annchor_device_name": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
@@ -126,6 +127,12 @@ def _ptr(a):
 
 def _c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
+
+
+def release_parked_contexts():
+    """Free the runtime shells (stream, pinned staging, device slab) that destroyed engines left
+    parked for the next one; returns how many there were."""
+    return int(load_library().annchor_release_parked())
 
 
 def bind_to_device_numa(device=0):

@@ -322,6 +322,28 @@ extern "C" void annchor_destroy(annchor_ctx *c)
     delete c;
 }
 
+// free the parked context shells (device slabs, pinned staging, streams); contexts in use are untouched
+extern "C" int annchor_release_parked(void)
+{
+    std::vector<CtxShell> shells;
+    {
+        std::lock_guard<std::mutex> lk(g_shell_mu);
+        shells.swap(g_shells);
+    }
+    for (CtxShell &sh : shells) {
+        (void)hipSetDevice(sh.device);
+        if (sh.arena) (void)hipFree(sh.arena);
+        for (hipEvent_t e : sh.ev_pool) (void)hipEventDestroy(e);
+        for (int i = 0; i < annchor_ctx::PIN_SLOTS; ++i)
+            if (sh.pin_ev[i]) (void)hipEventDestroy(sh.pin_ev[i]);
+        if (sh.pin) (void)hipHostFree(sh.pin);
+        if (sh.call_a) (void)hipEventDestroy(sh.call_a);
+        if (sh.call_b) (void)hipEventDestroy(sh.call_b);
+        if (sh.stream) (void)hipStreamDestroy(sh.stream);
+    }
+    return (int)shells.size();
+}
+
 // PCI bus id of a device ("0000:c1:00.0"): lets a launcher bind its process to the CPUs of the
 // GPU's NUMA node (/sys/bus/pci/devices/<id>/numa_node) before it creates contexts
 extern "C" int annchor_device_pci_bus_id(int device, char *buf, int buflen)

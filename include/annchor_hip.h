@@ -63,6 +63,10 @@ enum {
 /* ---------------------------------------------------------------- lifecycle */
 int annchor_create(int device, annchor_ctx **out);
 void annchor_destroy(annchor_ctx *ctx);
+/* A destroyed context parks its stream, pinned staging, events and device slab (up to 2 GB) for the
+ * next context on the same device (at most four such shells per process).  This frees them; returns
+ * how many there were. */
+int annchor_release_parked(void);
 const char *annchor_last_error(annchor_ctx *ctx);
 /* Non-ctx error text for failures of annchor_create itself. */
 const char *annchor_create_error(void);

@@ -195,3 +195,24 @@ def test_engine_released_with_the_annchor_object():
         assert eng() is None
     finally:
         gc.enable()
+
+
+def test_parked_context_shells_are_reused_and_releasable():
+    """A destroyed engine parks its stream / pinned staging / device slab; the next engine on the
+    device takes them over (results unchanged); release_parked_contexts() frees what is parked."""
+    from annchor_amd import Annchor, _native
+    from annchor_amd.datasets import load_strings
+
+    X = load_strings()["X"][::4]
+    cfg = dict(n_anchors=12, n_neighbors=10, n_samples=700, p_work=0.3)
+    _native.release_parked_contexts()
+    a = Annchor(X, "levenshtein", **cfg).fit()
+    ga = [np.array(g) for g in a.neighbor_graph]
+    del a                                   # parks one shell
+    b = Annchor(X, "levenshtein", **cfg).fit()   # reuses it (stale slab contents must not matter)
+    assert np.array_equal(ga[0], b.neighbor_graph[0]) and np.array_equal(ga[1], b.neighbor_graph[1])
+    del b
+    assert _native.release_parked_contexts() == 1
+    assert _native.release_parked_contexts() == 0
+    c = Annchor(X, "levenshtein", **cfg).fit()   # a fresh shell again
+    assert np.array_equal(ga[0], c.neighbor_graph[0])
