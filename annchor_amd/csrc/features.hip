@@ -187,6 +187,7 @@ __global__ __launch_bounds__(BC_THREADS) void k_bin_counts(const double *__restr
     for (int t = threadIdx.x; t < (BC_THREADS / 64) * MAXBINS; t += BC_THREADS) (&lc[0][0])[t] = 0;
     __syncthreads();
     const int64_t ntiles = (n + BC_TILE - 1) / BC_TILE;
+    uint32_t rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         double v[BC_ITEMS];
         uint8_t f[BC_ITEMS];
@@ -197,10 +198,31 @@ __global__ __launch_bounds__(BC_THREADS) void k_bin_counts(const double *__restr
             f[k] = ann_ldc(ncm, t, n);
             if (t >= n) f[k] = 0;
         }
+        if (be.nb <= 8) {
+            // few partitions (the default sampler has 7): membership counted in registers with
+            // compare-adds, no LDS atomics in the streaming loop
 #pragma unroll
-        for (int k = 0; k < BC_ITEMS; ++k) {
-            const int b = f[k] ? sampler_bin(be, v[k]) : -1;
-            if (b >= 0) atomicAdd(&lc[wave][b], 1u);
+            for (int k = 0; k < BC_ITEMS; ++k) {
+                if (!f[k]) continue;
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    rc[b] += (b < be.nb && v[k] >= be.e[b] && v[k] < be.e[b + 1]) ? 1u : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < BC_ITEMS; ++k) {
+                const int b = f[k] ? sampler_bin(be, v[k]) : -1;
+                if (b >= 0) atomicAdd(&lc[wave][b], 1u);
+            }
+        }
+    }
+    if (be.nb <= 8) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            uint32_t x = rc[b];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if ((threadIdx.x & 63) == 0 && x) lc[wave][b] = x;
         }
     }
     __syncthreads();
@@ -259,10 +281,28 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_count(const double *__restric
         f[k] = ann_ldc(ncm, t, n);
         if (t >= n) f[k] = 0;
     }
+    if (be.nb <= 8) {   // few partitions: register compare-adds, one LDS add per wave and partition
+        uint32_t rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < RB_ITEMS; ++k) {
-        const int b = f[k] ? sampler_bin(be, v[k]) : -1;
-        if (b >= 0) atomicAdd(&lc[b], 1u);
+        for (int k = 0; k < RB_ITEMS; ++k) {
+            if (!f[k]) continue;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                rc[b] += (b < be.nb && v[k] >= be.e[b] && v[k] < be.e[b + 1]) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            uint32_t x = rc[b];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if ((threadIdx.x & 63) == 0 && x) atomicAdd(&lc[b], x);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RB_ITEMS; ++k) {
+            const int b = f[k] ? sampler_bin(be, v[k]) : -1;
+            if (b >= 0) atomicAdd(&lc[b], 1u);
+        }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < be.nb; t += blockDim.x) blkcnt[(size_t)blockIdx.x * be.nb + t] = lc[t];

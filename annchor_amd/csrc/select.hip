@@ -425,11 +425,11 @@ __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict_
         __syncthreads();
     }
     const double *E = errs_in_lds ? le : errs;
-    // Four pairs per thread per step: their streams (mask, pair, RA, label) are loaded together,
-    // then the two threshold gathers, then the four binary searches advance in lock step -- one
+    // Eight pairs per thread per step: their streams (mask, pair, RA, label) are loaded together,
+    // then the two threshold gathers, then the eight binary searches advance in lock step -- one
     // pair at a time the chain mask -> pair -> thresholds -> ~13 dependent LDS probes ran at
     // memory latency (2.0 ms for 127 M pairs, 20 % of the HBM rate).
-    constexpr int PI = 4;
+    constexpr int PI = 8;   // (int32 search indices: the error lists hold at most the sample count)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * PI;
     for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x * PI + threadIdx.x; p0 < n; p0 += stride) {
         uint8_t m[PI], lbv[PI];
@@ -447,14 +447,14 @@ __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict_
         double pv[PI];
 #pragma unroll
         for (int e = 0; e < PI; ++e) pv[e] = fmax(thresh[q[e].x], thresh[q[e].y]) - ra[e];
-        int64_t b[PI], lo[PI], hi[PI];
+        int32_t b[PI], lo[PI], hi[PI];
         bool busy = false;
 #pragma unroll
         for (int e = 0; e < PI; ++e) {
             const bool search = m[e] && (int)lbv[e] < nlabels;
-            b[e] = search ? lptr[lbv[e]] : 0;
+            b[e] = search ? (int32_t)lptr[lbv[e]] : 0;
             lo[e] = b[e];
-            hi[e] = search ? lptr[lbv[e] + 1] : 0;
+            hi[e] = search ? (int32_t)lptr[lbv[e] + 1] : 0;
             busy |= lo[e] < hi[e];
         }
         // searchsorted(side='left'): number of entries < pv
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict_
 #pragma unroll
             for (int e = 0; e < PI; ++e)
                 if (lo[e] < hi[e]) {
-                    const int64_t mid = (lo[e] + hi[e]) >> 1;
+                    const int32_t mid = (lo[e] + hi[e]) >> 1;
                     if (E[mid] < pv[e]) lo[e] = mid + 1; else hi[e] = mid;
                     busy |= lo[e] < hi[e];
                 }
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict_
             double pr = -1.0;
             if (m[e]) {
                 if ((int)lbv[e] < nlabels) {
-                    const int64_t len = lptr[lbv[e] + 1] - b[e];
+                    const int32_t len = (int32_t)lptr[lbv[e] + 1] - b[e];
                     pr = (double)(lo[e] - b[e]) / (double)len;
                 } else {
                     pr = 0.0;
@@ -754,7 +754,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     {
         const int in_lds = nerr * 8 <= 60 * 1024;
         const size_t dyn = in_lds ? (size_t)nerr * 8 : 0;
-        int blocks = min(ann_blocks(n, 256 * 4), c->prop.multiProcessorCount * 8);
+        int blocks = min(ann_blocks(n, 256 * 8), c->prop.multiProcessorCount * 8);
         // algorithmic bytes per pair: 8 (ij) + 8 (RA) + 2 (mask, label) + 8 (prob)
         ProfScope ps(c, "ecdf_probability", (double)n * 26.0);
         k_prob<<<blocks, 256, dyn, c->stream>>>(n, c->ij.as<int2>(), c->thresh.as<double>(), c->RA.as<double>(),
