@@ -18,7 +18,7 @@
 //      sequential across bins (a bin starts where the previous one stopped) but is a
 //      branch-free compare/advance loop;
 //   3. only the first `want` entries of each shuffled bin are needed: the swaps are undone
-//      backwards for those entries alone (bitmap-filtered), on a helper thread while the
+//      backwards for those entries alone (bitmap-filtered), on pooled helper threads while the
 //      scan of the later bins proceeds, and on the calling thread once the scan is done.
 // Measured on the MI355X box's host (EPYC 9575F), C2 bin sizes (1.25 M draws, 1.8 M stream
 // words): scan 0.43 ms (AVX-512: 16 draws per compare, thresholds lagged two blocks, register
@@ -567,9 +567,9 @@ extern "C" int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts,
             return ANNCHOR_OK;
         }
     }
-    // Backward traces: one helper thread takes scanned bins from the front while this thread
-    // is still scanning; when the scan is done this thread takes bins from the back.  (A
-    // thread per bin measured slower: each lands on a sleeping core.)
+    // Backward traces: the pooled helper threads take scanned bins from the front while this
+    // thread is still scanning; when the scan is done this thread takes bins from the back.  (A
+    // thread created per call, let alone per bin, lands on a sleeping core: see HelperPool.)
     enum { PENDING = 0, READY = 1, TAKEN = 2, SKIP = 3 };
     std::unique_ptr<std::atomic<int>[]> state(new std::atomic<int>[(size_t)nbins + 1]);
     for (int b = 0; b < nbins; ++b) state[(size_t)b].store(PENDING, std::memory_order_relaxed);

@@ -1,7 +1,7 @@
 // scan.hip -- small device primitives shared by the pipeline stages:
 //   * exclusive prefix sum int32 -> int64,
-//   * exact k-th order statistic of float64 keys under a byte mask (MSB-first
-//     8-bit radix select; up to 4 ranks resolved in the same passes).
+//   * exact k-th order statistic of float64 keys under a byte mask (filter-then-finish radix
+//     selection, up to 4 ranks per call; the MSB-first 8-bit radix select is its fallback).
 // The second one implements np.partition(x[mask], k)[k] as used by
 // SimpleStratifiedSampler.get_partition (reference annchor/samplers.py:119-140).
 #include "common.h"
