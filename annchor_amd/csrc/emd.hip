@@ -273,6 +273,7 @@ int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
     a.slab_bytes = (int)slab;
     int waves = (int)((160 * 1024 - cost_bytes) / slab);
     if (waves > 16) waves = 16;
+    if (const char *w = getenv("ANNCHOR_EMD_WAVES")) { const int ww = atoi(w); if (ww >= 1 && ww < waves) waves = ww; }   // tuning / occupancy experiments
     ANN_REQUIRE(c, waves >= 1, ANNCHOR_ELIMIT, "histogram support %d needs more LDS than a CU has", c->max_support);
     a.waves = waves;
     const size_t lds = cost_bytes + slab * waves;
