@@ -386,17 +386,24 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_emit(const double *__restrict
         }
 }
 
+// also initialises the request's output position to -1 ("not found") and, when given, the caller's
+// error flag to 0: two memset launches less per sampling step
 __global__ void k_scatter_slots(const int32_t *__restrict__ bin_of, const int64_t *__restrict__ ranks, int64_t nreq,
-                                const int64_t *__restrict__ binbase, int32_t *__restrict__ slotmap)
+                                const int64_t *__restrict__ binbase, int32_t *__restrict__ slotmap,
+                                int64_t *__restrict__ positions, int32_t *__restrict__ flag)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < nreq) slotmap[binbase[bin_of[t]] + ranks[t]] = (int32_t)t;
+    if (t < nreq) {
+        slotmap[binbase[bin_of[t]] + ranks[t]] = (int32_t)t;
+        positions[t] = -1;
+    }
+    if (t == 0 && flag) *flag = 0;
 }
 
 // positions (int64, device: c->stage_out) of the requested (bin, rank) entries; counts_opt = the
 // per-bin totals if the caller already holds them (annchor_bin_counts), else they are recounted
 static int select_by_rank_device(annchor_ctx *c, const double *bins, int32_t nbins, const int64_t *counts_opt,
-                                 const int32_t *bin_of, const int64_t *ranks, int64_t nreq)
+                                 const int32_t *bin_of, const int64_t *ranks, int64_t nreq, int32_t *zero_flag = nullptr)
 {
     BinEdges be;
     ANN_TRY(load_bins(c, bins, nbins, be));
@@ -424,11 +431,10 @@ static int select_by_rank_device(annchor_ctx *c, const double *bins, int32_t nbi
     ANN_TRY(ann_h2d(c, d_binof, bin_of, sizeof(int32_t) * (size_t)nreq));
     ANN_TRY(ann_h2d(c, c->tmp1.p, base.data(), sizeof(int64_t) * (size_t)(nbins + 1)));
     ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp0.p, 0xff, sizeof(int32_t) * (size_t)(total + 1), c->stream));
-    ANN_CHECK_HIP(c, hipMemsetAsync(c->stage_out.p, 0xff, sizeof(int64_t) * (size_t)nreq, c->stream));
     {
         ProfScope ps(c, "sampler_select_by_rank", (double)n * 18.0);
         k_scatter_slots<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(d_binof, d_ranks, nreq, c->tmp1.as<int64_t>(),
-                                                                     c->tmp0.as<int32_t>());
+                                                                     c->tmp0.as<int32_t>(), c->stage_out.as<int64_t>(), zero_flag);
         k_rb_count<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be,
                                                          c->blk_cnt.as<uint32_t>());
         k_rb_scan<<<nbins, 256, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nblocks, nbins);
@@ -557,13 +563,12 @@ extern "C" int annchor_sample_pairs(annchor_ctx *c, const double *bins, int32_t 
     // one staging block for everything the host gets back: positions | feature rows | distances | flag
     const size_t stage_bytes = sizeof(double) * (6 * (size_t)nreq + 1);
     ANN_TRY(ann_reserve(c, c->stage_out, stage_bytes));
-    ANN_TRY(select_by_rank_device(c, bins, nbins, counts, bin_of, ranks, nreq));   // positions -> stage_out[0 .. nreq)
     ANN_TRY(ann_reserve(c, c->spos, sizeof(int32_t) * (size_t)nreq + 16));
     ANN_TRY(ann_reserve(c, c->sy, sizeof(double) * (size_t)nreq));
+    int32_t *bad = c->spos.as<int32_t>() + nreq;
+    ANN_TRY(select_by_rank_device(c, bins, nbins, counts, bin_of, ranks, nreq, bad));   // positions -> stage_out[0 .. nreq); *bad = 0
     double *st_feats = c->stage_out.as<double>() + nreq, *st_y = st_feats + 4 * (size_t)nreq;
     int64_t *st_bad = reinterpret_cast<int64_t *>(st_y + nreq);
-    int32_t *bad = c->spos.as<int32_t>() + nreq;
-    ANN_CHECK_HIP(c, hipMemsetAsync(bad, 0, sizeof(int32_t), c->stream));
     k_pos_to_i32<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->stage_out.as<int64_t>(), nreq, c->spos.as<int32_t>(), bad);
     k_gather_features<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), nreq, c->lb.as<double>(),
                                                                    c->ub.as<double>(), c->dad.as<double>(), c->anc.as<uint8_t>(),
