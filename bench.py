@@ -374,7 +374,7 @@ def main():
                     "note": "integer-ALU bound (string pool is 1 MB, cache resident): HBM fraction is not meaningful "
                             "for this kernel; the HBM-bound pair-list kernels are listed under `kernels`.  `peak` is the "
                             "nominal 2-cycle SIMD-32 rate; these integer ops issue at ~4 cycles per wave instruction "
-                            "(tools/microbench/valu_peak.hip), and the PMC pass shows the refine kernel's VALU 96 % busy",
+                            "(tools/microbench/valu_peak.hip), and the PMC pass shows the pair-list launches 96-99 % VALU busy, the one-wave-deep anchor rounds ~25 %",
                 }
             else:
                 g = kernels[dom]
