@@ -529,54 +529,97 @@ class OracleAnnchor:
 
 
 # ------------------------------------------------------------------- query (f2)
-def query(fitted, query_pairs, nq, nn=15, p_work=0.3):
-    """query_ + helpers, annchor/query_functions.py:10-212, on a fitted OracleAnnchor.
+def query_anchor_dists(query_pairs, A, nq):
+    """get_query_anchor_dists, query_functions.py:10-15: QD[j, a] = f(X[A[a]], Q[j])."""
+    A = np.asarray(A, dtype=np.int64)
+    IJa = np.stack([np.repeat(A, nq), np.tile(np.arange(nq), len(A))], axis=1)
+    return query_pairs(IJa).reshape(len(A), nq).T
+
+
+def query_locality(sid_x, QD, locality, loc_thresh, na):
+    """get_query_locality, query_functions.py:18-37, + the pair list of get_query_features (:42-47):
+    data points sharing >= loc_thresh of the `locality` nearest anchors with the query, NO loc_min
+    widening; pairs (i in X, j in Q) sorted by (j, i).  sid_x = the fitted nearest-anchor sets
+    (ann.Amatrix is their one-hot form, annchor.py:237-241)."""
+    nx, nq = len(sid_x), len(QD)
+    sid_q = nearest_anchor_sets(QD, locality)
+    Ax = np.zeros((nx, na), dtype=np.int32)
+    np.put_along_axis(Ax, np.asarray(sid_x, dtype=np.int64), 1, axis=1)
+    Aq = np.zeros((nq, na), dtype=np.int32)
+    np.put_along_axis(Aq, sid_q, 1, axis=1)
+    C = Aq @ Ax.T                                  # [nq, nx]
+    J, I = np.nonzero(C >= loc_thresh)             # row-major: sorted by (j, i)
+    IJs = np.stack([I, J], axis=1).astype(np.int64)
+    QI_ptr = np.concatenate([[0], np.cumsum(np.bincount(J, minlength=nq))]).astype(np.int64)
+    return sid_q, IJs, QI_ptr
+
+
+def query_features(IJs, D, QD, A):
+    """get_query_features / get_query_dad_ijs / get_query_bounds_njit_ijs, query_functions.py:40-129."""
+    Di, Qj = D[IJs[:, 0]], QD[IJs[:, 1]]
+    lb, ub = np.abs(Di - Qj).max(axis=1), (Di + Qj).min(axis=1)
+    cA, cQA = np.argmin(D, axis=1), np.argmin(QD, axis=1)
+    dd = (D[IJs[:, 0], cQA[IJs[:, 1]]] + QD[IJs[:, 1], cA[IJs[:, 0]]]) / 2
+    anchors = np.isin(IJs[:, 0], np.asarray(A)).astype(np.float64)
+    feats = np.vstack([lb, ub, dd, anchors]).T
+    return feats, feats[:, 3] < 1
+
+
+def query_n_refine(p_work, nq, nx, n_anchors):
+    """query_functions.py:163-168."""
+    return int((p_work * nq * nx - n_anchors * nq)) + 1
+
+
+def query_select(QRA, ncm, IJs, QI_ptr, labels, errs, nn, n_refine):
+    """select_refine_candidate_query_pairs up to the metric call, query_functions.py:132-176:
+    thresholds on the query side only, guarantee_nmin with 3nn//2, one global top-n_refine."""
+    QI_idx = np.arange(len(IJs), dtype=np.int64)
+    thresh = row_kth(QRA, QI_ptr, QI_idx, nn)
+    QRA = guarantee_nmin(QRA, ncm, QI_ptr, QI_idx, 3 * nn // 2)
+    p = (thresh[IJs[:, 1]] - QRA)[ncm]
+    prob = ecdf_prob(p, labels[ncm], errs)
+    cand, _ = select_candidates(prob, max(n_refine, 0), 1)
+    mapback = np.arange(ncm.shape[0])[ncm][cand]
+    return thresh, QRA, prob, mapback
+
+
+def query_get_nn(QRA, ncm, IJs, QI_ptr, nn):
+    """get_nn(nq, nn + 1, ...) of query_ (query_functions.py:210): raw output, the neighbour is
+    the X endpoint; no self column."""
+    QI_idx = np.arange(len(IJs), dtype=np.int64)
+    return get_nn(QRA, ncm, np.stack([IJs[:, 0], IJs[:, 0]], axis=1), QI_ptr, QI_idx, nn + 1)
+
+
+def query_p_work(p_work, nq, nx, n_anchors, nn):
+    """The floor Annchor.query applies first (annchor.py:664-675)."""
+    limit = ((nq * nn * 3) // 2 - 1 + n_anchors * nq) / (nq * nx)
+    return max(p_work, limit)
+
+
+def query(fitted, query_pairs, nq, nn=15, p_work=0.3, sid_x=None, apply_floor=False):
+    """query_ + helpers, annchor/query_functions.py:10-212, on a fitted OracleAnnchor (or any object
+    with nx, n_anchors, A, D, locality, loc_thresh, bins, W, c, errs).
 
     query_pairs(IJ int64 [n,2]) -> float64[n] with IJ[:,0] indexing X and IJ[:,1] indexing Q
     (get_exact_query_ijs, utils.py:180-245).  Tie rules as everywhere in this module."""
     o = fitted
     nx, na = o.nx, o.n_anchors
-    A = np.asarray(o.A, dtype=np.int64)
-    # get_query_anchor_dists (:10-15)
-    IJa = np.stack([np.repeat(A, nq), np.tile(np.arange(nq), na)], axis=1)
-    QD = query_pairs(IJa).reshape(na, nq).T
-    # get_query_locality (:18-37): shared nearest anchors, no loc_min widening
-    sid_x = nearest_anchor_sets(o.D, o.locality)
-    sid_q = nearest_anchor_sets(QD, o.locality)
-    Ax = np.zeros((nx, na), dtype=np.int32)
-    np.put_along_axis(Ax, sid_x, 1, axis=1)
-    Aq = np.zeros((nq, na), dtype=np.int32)
-    np.put_along_axis(Aq, sid_q, 1, axis=1)
-    C = Aq @ Ax.T                                  # [nq, nx]
-    J, I = np.nonzero(C >= o.loc_thresh)           # row-major: sorted by (j, i)
-    IJs = np.stack([I, J], axis=1).astype(np.int64)
-    counts = np.bincount(J, minlength=nq)
-    QI_ptr = np.concatenate([[0], np.cumsum(counts)])
-    QI_idx = np.arange(len(IJs), dtype=np.int64)
-    # get_query_features (:40-129)
-    Di, Qj = o.D[IJs[:, 0]], QD[IJs[:, 1]]
-    lb, ub = np.abs(Di - Qj).max(axis=1), (Di + Qj).min(axis=1)
-    cA, cQA = np.argmin(o.D, axis=1), np.argmin(QD, axis=1)
-    dd = (o.D[IJs[:, 0], cQA[IJs[:, 1]]] + QD[IJs[:, 1], cA[IJs[:, 0]]]) / 2
-    anchors = np.isin(IJs[:, 0], A).astype(np.float64)
-    feats = np.vstack([lb, ub, dd, anchors]).T
-    ncm = feats[:, 3] < 1
+    if apply_floor:
+        p_work = query_p_work(p_work, nq, nx, na, nn)
+    QD = query_anchor_dists(query_pairs, o.A, nq)
+    if sid_x is None:
+        sid_x = nearest_anchor_sets(o.D, o.locality)
+    _, IJs, QI_ptr = query_locality(sid_x, QD, o.locality, o.loc_thresh, na)
+    feats, ncm = query_features(IJs, o.D, QD, o.A)
     # predict + clip (:198-203)
     pred = regression_predict(feats, o.bins, o.W, o.c)
     QRA = np.minimum(np.maximum(pred, feats[:, 0]), feats[:, 1])
     labels = error_labels(feats[:, 2], o.bins)
-    # select_refine_candidate_query_pairs (:132-180)
-    thresh = row_kth(QRA, QI_ptr, QI_idx, nn)
-    QRA = guarantee_nmin(QRA, ncm, QI_ptr, QI_idx, 3 * nn // 2)
-    p = (thresh[IJs[:, 1]] - QRA)[ncm]
-    prob = ecdf_prob(p, labels[ncm], o.errs)
-    n_refine = int((p_work * nq * nx - na * nq)) + 1
-    cand, _ = select_candidates(prob, max(n_refine, 0), 1)
-    mapback = np.arange(ncm.shape[0])[ncm][cand]
+    n_refine = query_n_refine(p_work, nq, nx, na)
+    _, QRA, _, mapback = query_select(QRA, ncm, IJs, QI_ptr, labels, o.errs, nn, n_refine)
     QRA[mapback] = query_pairs(IJs[mapback])
     ncm[mapback] = False
-    # get_nn(nq, nn + 1, ...) (:210): raw output, no self column
-    idx, dist = get_nn(QRA, ncm, np.stack([IJs[:, 0], IJs[:, 0]], axis=1), QI_ptr, QI_idx, nn + 1)   # neighbour = the X endpoint
+    idx, dist = query_get_nn(QRA, ncm, IJs, QI_ptr, nn)
     return idx[:, 1:], dist[:, 1:], dict(QD=QD, IJs=IJs, n_refine=n_refine, evals=na * nq + len(mapback))
 
 

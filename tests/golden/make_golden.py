@@ -19,7 +19,7 @@ The reference needs three third-party modules that are not installed here
 So: vectors for the reference's OWN functions (a0, a6-a17) are genuine reference
 outputs; metric values inside them come from the oracle's metric restatements.
 
-Usage:  python tests/golden/make_golden.py [small|blobs|strings_full|digits_full|enemies|all]
+Usage:  python tests/golden/make_golden.py [small|blobs|strings_full|digits_full|enemies|query|all]
 """
 import os
 import sys
@@ -276,6 +276,131 @@ def gen_enemies_state():
     save("enemies_state", out)
 
 
+def staged_query(ann, Q, nn, p_work, ev_q, snaps, tag, slim=False):
+    """query_ body (query_functions.py:183-212) stage by stage with the reference's own helpers,
+    snapshotting between stages; `Annchor.query` itself (annchor.py:643-683) is then run end to
+    end on the same inputs and must give the same result (both outputs are stored)."""
+    import annchor.query_functions as qf
+    from annchor.utils import get_nn
+
+    nq = len(Q)
+    # the p_work floor of Annchor.query (annchor.py:668-675)
+    na_q, nbf = ann.n_anchors * nq, nq * ann.nx
+    limit = ((nq * nn * 3) // 2 - 1 + na_q) / nbf
+    p_eff = max(p_work, limit)
+    ann.get_exact_query_ijs = ev_q
+    QD = qf.get_query_anchor_dists(ann, Q)
+    check = qf.get_query_locality(ann, QD)
+    IJs, QI, Qf, Qncm = qf.get_query_features(ann, QD, check)
+    Qpred = ann.regression.predict(Qf, ann.feature_names)
+    Qclip = np.clip(Qpred, Qf[:, 0], Qf[:, 1])
+    Qerr = ann.error_predictor.predict(Qf, ann.feature_names[:-1])
+    ncm0 = Qncm.copy()
+    thresh = np.array([np.partition(Qclip[QI[i]], nn)[nn] for i in range(nq)])
+    QRA, Qncm2 = qf.select_refine_candidate_query_pairs(ann, IJs, Q, QI, Qclip.copy(), Qncm.copy(), Qerr, p_eff, nn)
+    ngi, ngd = get_nn(nq, nn + 1, QRA, IJs, QI, Qncm2)
+    P = tag + "_"
+    snaps.update({
+        P + "QD": QD, P + "IJs": IJs.astype(np.int64), P + "features": Qf, P + "ncm0": ncm0,
+        P + "pred": Qpred, P + "labels": np.asarray(Qerr).astype(np.int8), P + "thresh": thresh,
+        P + "mapback": np.sort(np.arange(len(ncm0))[ncm0 & ~Qncm2]), P + "RA_after": QRA, P + "ncm_after": Qncm2,
+        P + "ngi_raw": ngi, P + "ngd_raw": ngd, P + "nn": np.int64(nn), P + "p_work": np.float64(p_work),
+        P + "p_work_effective": np.float64(p_eff),
+    })
+    if slim:   # large case: per-pair arrays kept for a fixed random sample of pairs only
+        rows = np.sort(np.random.default_rng(0).choice(len(ncm0), 20000, replace=False))
+        snaps[P + "rows"] = rows
+        for key in ("features", "pred", "labels"):
+            snaps[P + key] = snaps[P + key][rows]
+        snaps[P + "RA_after_at_mapback"] = QRA[snaps[P + "mapback"]]
+        snaps[P + "IJs"] = snaps[P + "IJs"].astype(np.int16)
+        snaps[P + "mapback"] = snaps[P + "mapback"].astype(np.int32)
+        for key in ("ncm0", "RA_after", "ncm_after"):
+            del snaps[P + key]
+    e2e = ann.query(Q, nn=nn, p_work=p_work, get_exact_query_ijs=ev_q)
+    snaps[P + "e2e_idx"], snaps[P + "e2e_dist"] = e2e[0].copy(), e2e[1].copy()
+    return snaps
+
+
+def fitted_state(ann, snaps):
+    """What query() reads from a fitted Annchor (annchor.py:643-683, query_functions.py)."""
+    snaps.update(A=np.asarray(ann.A, dtype=np.int64), D=np.ascontiguousarray(ann.D), sid=np.asarray(ann.sid, dtype=np.int64),
+                 bins=ann.regression.sample_bins.copy(),
+                 W=np.array([lr.coef_ for lr in ann.regression.LRs]), c=np.array([lr.intercept_ for lr in ann.regression.LRs]),
+                 err_bins=np.asarray(ann.error_predictor.partition_bins, dtype=np.float64),
+                 locality=np.int64(ann.locality), loc_thresh=np.int64(ann.loc_thresh), nx=np.int64(ann.nx))
+    for b, e in ann.error_predictor.errs.items():
+        snaps["errs%d" % b] = e.copy()
+    return snaps
+
+
+def gen_query():
+    """Annchor.query (annchor.py:643-683 -> query_functions.py:10-212; reference test
+    tests/test_examples.py:12-58) driven on (a) a strings split and (b) the digits split of the
+    reference's own test (train_test_split(random_state=0), n_anchors=25, k=25, n_samples=5000,
+    p_work=0.16; query p_work=0.2)."""
+    # (a) strings: 400 strings, every 5th held out as a query
+    X, _ = om.load_strings()
+    sub = X[::4]
+    tr = [s for t, s in enumerate(sub) if t % 5]
+    qs = [s for t, s in enumerate(sub) if t % 5 == 0]
+    P = om.PackedStrings(tr + qs)
+    ntr = len(tr)
+    cfg = dict(n_anchors=8, n_neighbors=10, n_samples=700, p_work=0.3, random_seed=42, niters=2)
+    ann = ref.Annchor(np.array(tr), "levenshtein", get_exact_ijs=strings_evaluator(P), **cfg)
+    ann.fit()
+    A = np.asarray(ann.A, dtype=np.int64)
+
+    def ev_q(f, Xa, Z, IJ):   # pairs index (Xa[i], Z[j]); Xa is X[A] for the anchor call, X otherwise
+        IJ = np.asarray(IJ, dtype=np.int64)
+        i = A[IJ[:, 0]] if len(Xa) == len(A) else IJ[:, 0]
+        return P.pairs(np.stack([i, ntr + IJ[:, 1]], axis=1))
+
+    snaps = fitted_state(ann, {"cfg_" + k: np.float64(v) for k, v in cfg.items()})
+    snaps["n_train"], snaps["n_query"] = np.int64(ntr), np.int64(len(qs))
+    staged_query(ann, np.array(qs), 10, 0.3, ev_q, snaps, "q")
+    staged_query(ann, np.array(qs[:7]), 5, 0.01, ev_q, snaps, "qlow")   # p_work below the floor: raised (annchor.py:668-675)
+    save("query_strings", snaps)
+
+    # (b) digits, the reference test's own split
+    from sklearn.model_selection import train_test_split
+
+    d = om.load_digits()
+    Xd, yd, M = d["X"], d["y"], d["cost_matrix"]
+    idx_tr, idx_te = train_test_split(np.arange(len(Xd)), random_state=0)
+    X_train, X_test = train_test_split(Xd, random_state=0)
+    assert np.array_equal(X_train, Xd[idx_tr]) and np.array_equal(X_test, Xd[idx_te])
+    H = om.Histograms(np.concatenate([X_train, X_test]), M)
+    ntr = len(X_train)
+    ev = lambda f, X, IJ: H.pairs(np.asarray(IJ, dtype=np.int64))  # noqa: E731
+    t = time.time()
+    ann = ref.Annchor(X_train, "wasserstein", func_kwargs={"cost_matrix": M}, n_anchors=25, n_neighbors=25,
+                      n_samples=5000, p_work=0.16, get_exact_ijs=ev)
+    ann.fit()
+    A = np.asarray(ann.A, dtype=np.int64)
+    print("digits train fit %.0fs" % (time.time() - t))
+    snaps = fitted_state(ann, dict(idx_train=idx_tr.astype(np.int64), idx_test=idx_te.astype(np.int64)))
+    staged_query(ann, X_test, 15, 0.2, ev_q_factory(H, A, ntr), snaps, "q", slim=True)
+    # truth for the reference test's own recall criterion (exact 15-NN of every query)
+    IJall = np.stack([np.repeat(np.arange(ntr), len(X_test)), ntr + np.tile(np.arange(len(X_test)), ntr)], axis=1)
+    dd = H.pairs(IJall).reshape(ntr, len(X_test)).T
+    order = np.argsort(dd, axis=1, kind="stable")[:, :15]
+    snaps["truth_idx"], snaps["truth_dist"] = order.astype(np.int64), np.take_along_axis(dd, order, axis=1)
+    got = snaps["q_e2e_idx"]
+    errs = sum(len(np.setdiff1d(order[i], got[i])) for i in range(len(X_test)))
+    snaps["ref_recall"] = np.float64(1 - errs / (15.0 * len(X_test)))
+    print("digits query: reference recall@15 = %.5f  (%.0fs)" % (snaps["ref_recall"], time.time() - t))
+    save("query_digits", snaps)
+
+
+def ev_q_factory(H, A, ntr):
+    def ev_q(f, Xa, Z, IJ):
+        IJ = np.asarray(IJ, dtype=np.int64)
+        i = A[IJ[:, 0]] if len(Xa) == len(A) else IJ[:, 0]
+        return H.pairs(np.stack([i, ntr + IJ[:, 1]], axis=1))
+    return ev_q
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("small", "all"):
@@ -289,3 +414,5 @@ if __name__ == "__main__":
     if what in ("enemies", "all"):
         gen_enemies()
         gen_enemies_state()
+    if what in ("query", "all"):
+        gen_query()

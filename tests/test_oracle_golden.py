@@ -188,3 +188,151 @@ def test_compare_neighbor_graphs():
         ds[i, rs.randint(20, 100)] += rs.random_sample() + 0.01
     assert O.compare_neighbor_graphs(ng, (ixs, ds), 100) == ds.shape[0]
     assert O.compare_neighbor_graphs(ng, (ixs, ds), 20) == 0
+
+
+# ----------------------------------------------------------------- query (f2)
+# Fixtures: tests/golden/make_golden.py::gen_query drives the imported reference's own
+# query_functions helpers stage by stage AND Annchor.query end to end (annchor.py:643-683,
+# query_functions.py:10-212) on a strings split and on the digits split of the reference's
+# tests/test_examples.py:12-58.
+class _Fitted:
+    def __init__(self, G):
+        self.nx, self.A, self.D = int(G["nx"]), G["A"], G["D"]
+        self.n_anchors = self.D.shape[1]
+        self.locality, self.loc_thresh = int(G["locality"]), int(G["loc_thresh"])
+        self.bins, self.W, self.c = G["bins"], G["W"], G["c"]
+        self.errs = [G["errs%d" % b] for b in range(len(self.bins) - 1)]
+
+
+def _strings_query_metric():
+    from oracle import metrics as om
+
+    X, _ = om.load_strings()
+    sub = X[::4]
+    tr = [s for t, s in enumerate(sub) if t % 5]
+    qs = [s for t, s in enumerate(sub) if t % 5 == 0]
+    P = om.PackedStrings(tr + qs)
+    return tr, qs, (lambda IJ: P.pairs(np.stack([IJ[:, 0], IJ[:, 1] + len(tr)], axis=1)))
+
+
+@pytest.mark.parametrize("tag", ["q", "qlow"])
+def test_query_stages_strings(tag):
+    """Every stage of O.query fed the REFERENCE's inputs to that stage (strings split)."""
+    G = load("query_strings")
+    o = _Fitted(G)
+    tr, qs, qp = _strings_query_metric()
+    P = tag + "_"
+    nn, nq = int(G[P + "nn"]), G[P + "QD"].shape[0]
+    assert O.query_p_work(float(G[P + "p_work"]), nq, o.nx, o.n_anchors, nn) == float(G[P + "p_work_effective"])
+    QD = O.query_anchor_dists(qp, o.A, nq)
+    assert np.array_equal(QD, G[P + "QD"])
+    # locality: identical pair list unless a query has a tie exactly at the nearest-anchor cut
+    sid_q, IJs, QI_ptr = O.query_locality(G["sid"], QD, o.locality, o.loc_thresh, o.n_anchors)
+    Qs = np.sort(QD, axis=1)
+    tie = Qs[:, o.locality - 1] == Qs[:, o.locality]
+    ref_IJs = G[P + "IJs"]
+    for j in np.nonzero(~tie)[0]:
+        assert np.array_equal(IJs[IJs[:, 1] == j, 0], ref_IJs[ref_IJs[:, 1] == j, 0])
+    assert (~tie).sum() >= nq // 2
+    # from here on: the reference's own pair list
+    IJs = ref_IJs
+    QI_ptr = np.concatenate([[0], np.cumsum(np.bincount(IJs[:, 1], minlength=nq))])
+    feats, ncm = O.query_features(IJs, o.D, QD, o.A)
+    assert np.array_equal(feats, G[P + "features"])   # bit-exact
+    assert np.array_equal(ncm, G[P + "ncm0"])
+    pred = O.regression_predict(feats, o.bins, o.W, o.c)
+    np.testing.assert_allclose(pred, G[P + "pred"], rtol=1e-13, atol=1e-11)
+    assert np.array_equal(O.error_labels(feats[:, 2], G["err_bins"]), G[P + "labels"])
+    QRA = np.clip(G[P + "pred"], feats[:, 0], feats[:, 1])
+    n_refine = O.query_n_refine(float(G[P + "p_work_effective"]), nq, o.nx, o.n_anchors)
+    thresh, QRA2, prob, mapback = O.query_select(QRA.copy(), ncm.copy(), IJs, QI_ptr, G[P + "labels"].astype(np.int64),
+                                                 o.errs, nn, n_refine)
+    assert np.array_equal(thresh, G[P + "thresh"])
+    ref_m = G[P + "mapback"]
+    assert len(mapback) == len(ref_m) == min(n_refine, int(ncm.sum()))
+    pos = np.full(len(ncm), -1)
+    pos[np.nonzero(ncm)[0]] = np.arange(int(ncm.sum()))
+    pm, pt = prob[pos[mapback]], prob[pos[ref_m]]
+    assert pm.min() == pt.min()       # same cut value; strictly-above members identical
+    assert set(mapback[pm > pm.min()]) == set(ref_m[pt > pt.min()])
+    # refined values and the final rows from the reference's post-refine state
+    assert np.array_equal(qp(IJs[ref_m]), G[P + "RA_after"][ref_m])
+    idx, dist = O.query_get_nn(G[P + "RA_after"], G[P + "ncm_after"], IJs, QI_ptr, nn)
+    idx, dist = idx[:, 1:], dist[:, 1:]          # the oracle's get_nn prepends the self column (annchor.py:519-525)
+    assert np.array_equal(dist, G[P + "ngd_raw"])
+    assert np.array_equal(dist, G[P + "e2e_dist"])
+    for i in range(nq):
+        if len(np.unique(dist[i])) == dist.shape[1]:
+            assert np.array_equal(idx[i], G[P + "ngi_raw"][i])
+
+
+def test_query_end_to_end_strings():
+    """O.query end to end vs the reference's Annchor.query.  Integer distances tie everywhere (the
+    nearest-anchor cut of 4 queries, the global top-n_refine cut), so the two candidate sets differ
+    by tie members: every reported distance must be exact, and the error count against brute force
+    must match the reference run's to within those tie swaps."""
+    G = load("query_strings")
+    o = _Fitted(G)
+    tr, qs, qp = _strings_query_metric()
+    nx = len(tr)
+    IJ = np.stack([np.repeat(np.arange(nx), len(qs)), np.tile(np.arange(len(qs)), nx)], 1)
+    dense = qp(IJ).reshape(nx, len(qs)).T
+    for tag in ("q", "qlow"):
+        P = tag + "_"
+        nn, nq = int(G[P + "nn"]), G[P + "QD"].shape[0]
+        idx, dist, info = O.query(o, qp, nq, nn=nn, p_work=float(G[P + "p_work"]), sid_x=G["sid"], apply_floor=True)
+        assert dist.shape == G[P + "e2e_dist"].shape
+        assert np.array_equal(dist, dense[np.repeat(np.arange(nq), nn), idx.ravel()].reshape(nq, nn))
+        assert info["evals"] == o.n_anchors * nq + len(G[P + "mapback"])
+        order = np.argsort(dense[:nq], axis=1, kind="stable")[:, :nn]
+        truth = (order, np.take_along_axis(dense[:nq], order, axis=1))
+        e_ora = O.compare_neighbor_graphs(truth, (idx, dist), nn)
+        e_ref = O.compare_neighbor_graphs(truth, (G[P + "e2e_idx"], G[P + "e2e_dist"]), nn)
+        assert abs(e_ora - e_ref) <= 0.02 * nq * nn + 2, (e_ora, e_ref)
+        assert O.compare_neighbor_graphs((G[P + "e2e_idx"], G[P + "e2e_dist"]), (idx, dist), nn) <= 0.04 * nq * nn + 2
+
+
+def test_query_digits_reference_split():
+    """The reference test's own configuration (tests/test_examples.py:12-58): digits,
+    train_test_split(random_state=0), n_anchors=25, k=25, p_work=0.16; query nn=15, p_work=0.2."""
+    from oracle import metrics as om
+
+    G = load("query_digits")
+    o = _Fitted(G)
+    d = om.load_digits()
+    tr, te = G["idx_train"], G["idx_test"]
+    H = om.Histograms(np.concatenate([d["X"][tr], d["X"][te]]), d["cost_matrix"])
+    qp = lambda IJ: H.pairs(np.stack([IJ[:, 0], IJ[:, 1] + len(tr)], axis=1))  # noqa: E731
+    nq, nn = len(te), int(G["q_nn"])
+    QD = O.query_anchor_dists(qp, o.A, nq)
+    np.testing.assert_allclose(QD, G["q_QD"], rtol=0, atol=1e-12)
+    sid_q, IJs, QI_ptr = O.query_locality(G["sid"], G["q_QD"], o.locality, o.loc_thresh, o.n_anchors)
+    assert np.array_equal(IJs, G["q_IJs"].astype(np.int64))
+    feats, ncm = O.query_features(IJs, o.D, G["q_QD"], o.A)
+    rows = G["q_rows"]
+    assert np.array_equal(feats[rows], G["q_features"])
+    pred = O.regression_predict(feats, o.bins, o.W, o.c)
+    np.testing.assert_allclose(pred[rows], G["q_pred"], rtol=1e-13, atol=1e-12)
+    labels = O.error_labels(feats[:, 2], G["err_bins"])
+    assert np.array_equal(labels[rows], G["q_labels"])
+    QRA = np.minimum(np.maximum(pred, feats[:, 0]), feats[:, 1])
+    n_refine = O.query_n_refine(float(G["q_p_work_effective"]), nq, o.nx, o.n_anchors)
+    thresh, _, prob, mapback = O.query_select(QRA.copy(), ncm.copy(), IJs, QI_ptr, labels, o.errs, nn, n_refine)
+    np.testing.assert_allclose(thresh, G["q_thresh"], rtol=1e-13, atol=1e-12)
+    ref_m = G["q_mapback"].astype(np.int64)
+    assert len(mapback) == len(ref_m)
+    # set-wise parity: same cut value (probability 0.0 here -- a third of the pool is tied at the
+    # cut), members strictly above it identical
+    pos = np.full(len(ncm), -1)
+    pos[np.nonzero(ncm)[0]] = np.arange(int(ncm.sum()))
+    pm, pt = prob[pos[mapback]], prob[pos[ref_m]]
+    assert pm.min() == pt.min()
+    assert set(mapback[pm > pm.min()]) == set(ref_m[pt > pt.min()])
+    np.testing.assert_allclose(qp(IJs[ref_m]), G["q_RA_after_at_mapback"], rtol=0, atol=1e-12)
+    # end to end
+    idx, dist, info = O.query(o, qp, nq, nn=nn, p_work=float(G["q_p_work"]), sid_x=G["sid"], apply_floor=True)
+    diff = O.compare_neighbor_graphs((G["q_e2e_idx"], G["q_e2e_dist"]), (idx, dist), nn)
+    assert diff <= 3, diff
+    errs = sum(len(np.setdiff1d(G["truth_idx"][i], idx[i])) for i in range(nq))
+    assert 1 - errs / (15.0 * nq) >= 0.99          # the reference test's own criterion
+    assert float(G["ref_recall"]) >= 0.99
