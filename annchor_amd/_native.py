@@ -342,6 +342,8 @@ class Engine:
     def set_anchor_distances(self, D, A):
         D = _c(D, np.float64)
         A = _c(A, np.int64).reshape(-1)
+        if D.ndim != 2 or D.shape[0] != self.nx:
+            raise ValueError("anchor distances must be [nx=%d, n_anchors], got %r" % (self.nx, D.shape))
         self._chk(self.lib.annchor_set_anchor_distances(self.h, _ptr(D), D.shape[1], _ptr(A) if len(A) else None, len(A)))
 
     # ------------------------------------------------------------- pipeline
@@ -417,12 +419,21 @@ class Engine:
                                                  int(is_metric), _ptr(sp)))
         return sp
 
+    def n_pairs(self):
+        return self.field_size(F_NCM)
+
     def merge_host_prediction(self, pred, first, is_metric):
-        pred = _c(pred, np.float64)
+        pred = _c(pred, np.float64).reshape(-1)
+        if pred.shape[0] != self.n_pairs():
+            raise ValueError("regression.predict returned %d values for %d candidate pairs" % (pred.shape[0], self.n_pairs()))
         self._chk(self.lib.annchor_merge_host_prediction(self.h, _ptr(pred), int(first), int(is_metric)))
 
     def set_labels(self, labels):
-        labels = _c(labels, np.int64)
+        labels = _c(labels, np.int64).reshape(-1)
+        if labels.shape[0] != self.n_pairs():
+            raise ValueError("error_predictor.predict returned %d labels for %d candidate pairs" % (labels.shape[0], self.n_pairs()))
+        if labels.size and (labels.min() < 0 or labels.max() >= 255):
+            raise ValueError("error labels must lie in 0..254 (got %d..%d)" % (labels.min(), labels.max()))
         self._chk(self.lib.annchor_set_labels(self.h, _ptr(labels)))
 
     def select_candidates(self, n_neighbors, nmin, errs_list, n_refine, lookahead):

@@ -74,13 +74,22 @@ class _IndexCSR:
 
 
 class _DeviceExact:
-    """get_exact(f, X, IJ) (utils.py:110-177) against the data set uploaded to `engine`."""
+    """get_exact(f, X, IJ) (utils.py:110-177).  The data set bound at construction is resident
+    on the device: pairs of THAT data set under THAT metric are one kernel call.  The protocol
+    lets a plugin pass any f and any X, though -- those are honoured: another data set under a
+    bundled metric is evaluated on the device through a scratch context, any other callable on
+    the host."""
 
-    def __init__(self, engine):
-        self.engine = engine
+    def __init__(self, engine, f, X):
+        self.engine, self._f, self._X = engine, f, X
 
     def __call__(self, f, X, IJ):
-        return self.engine.metric_pairs(np.asarray(IJ, dtype=np.int64))
+        IJ = np.asarray(IJ, dtype=np.int64).reshape(-1, 2)
+        if f is self._f and X is self._X:
+            return self.engine.metric_pairs(IJ)
+        if isinstance(f, DeviceMetric):
+            return np.asarray(f.many([X[i] for i in IJ[:, 0]], [X[j] for j in IJ[:, 1]]), dtype=np.float64)
+        return np.array([f(X[i], X[j]) for i, j in IJ], dtype=np.float64)
 
 
 class Annchor:
@@ -142,7 +151,7 @@ class Annchor:
                                              p_work=self.p_work, random_seed=random_seed, device=device)
             self._engine = self._streamed._engine
             self._device_metric = True
-            self.get_exact_ijs = _DeviceExact(self._engine)
+            self.get_exact_ijs = _DeviceExact(self._engine, self.f, self.X)
             self.get_exact_query_ijs = None
             self._cache, self.timings = {}, {}
             return
@@ -152,7 +161,7 @@ class Annchor:
         self._device_metric = isinstance(self.f, DeviceMetric) and get_exact_ijs is None
         if self._device_metric:
             self.f.bind(self._engine, X)
-            self.get_exact_ijs = _DeviceExact(self._engine)
+            self.get_exact_ijs = _DeviceExact(self._engine, self.f, self.X)
         else:
             self._engine.set_opaque(self.nx)
             if get_exact_ijs is None:
@@ -255,10 +264,17 @@ class Annchor:
         self._first_merge = True
         self._invalidate("features", "ncm", "RA", "labels", "thresh")
 
+    def _sampler_on_device(self):
+        """The built-in stratified sampler partitioning on the double anchor distance runs against
+        the resident state; any other sampler (or partition feature) gets the NumPy arrays of the
+        protocol."""
+        return (type(self.sampler) is SimpleStratifiedSampler
+                and self.sampler.partition_feature_name == "double anchor distance")
+
     def get_sample(self):
         """annchor.py:313-343."""
         eng = self._engine
-        if type(self.sampler) is SimpleStratifiedSampler:
+        if self._sampler_on_device():
             ticket, self._sample_ticket = self._sample_ticket, None
             if ticket is None:
                 ticket = self.sampler.begin_device(eng, self.n_samples, self.random_seed, overlap=False)
@@ -318,15 +334,16 @@ class Annchor:
         nn = self.n_neighbors
         labels = list(self.error_predictor.labels)
         errs = [np.asarray(self.error_predictor.errs[lab], dtype=np.float64) for lab in labels]
-        assert labels == list(range(len(labels))), "error labels must be 0..L-1"
+        if labels != list(range(len(labels))):
+            raise NotImplementedError("error_predictor.labels must be 0..L-1 (got %r): the device label array "
+                                      "indexes the residual lists by position" % (labels[:8],))
         n_refine = int((self.p_work * self.N - self.na - self.n_samples) * w) + 1  # annchor.py:440
         n_refine = 0 if n_refine < 0 else n_refine
         nmin = 3 * nn // 2 if it == 0 else 0
         ncand, nnext = self._engine.select_candidates(nn, nmin, errs, n_refine, self.lookahead)
         self.n_refine = n_refine
         self._invalidate("RA", "thresh", "cand", "next")
-        if (self._pipelined and self._device_metric and ncand and it < self.niters - 1
-                and type(self.sampler) is SimpleStratifiedSampler):
+        if self._pipelined and self._device_metric and ncand and it < self.niters - 1 and self._sampler_on_device():
             # inside fit(): the next sampling step's statistics depend on the mask and dad only,
             # so take them now and let the host draw overlap the refinement kernel
             self._engine.mark_candidates()
@@ -369,7 +386,7 @@ class Annchor:
             return self
         origin = time.perf_counter()
         t = self.timings = {}
-        if type(self.sampler) is SimpleStratifiedSampler:
+        if self._sampler_on_device():
             # the sampler's MT19937 streams depend on the seeds only: produce them on host
             # threads while the GPU runs the stages before each sampling step
             for it in range(self.niters):
@@ -551,7 +568,7 @@ class BruteForce:
         if self._device_metric:
             self._engine = _native.Engine(device)
             self.f.bind(self._engine, X)
-            self.get_exact_ijs = lambda f, X, IJ: self._engine.metric_pairs(np.asarray(IJ, dtype=np.int64))
+            self.get_exact_ijs = _DeviceExact(self._engine, self.f, self.X)
         elif get_exact_ijs is None:
             self.get_exact_ijs = get_exact_ijs_(self.f, verbose=self.verbose, backend=backend)
         else:

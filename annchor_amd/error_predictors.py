@@ -3,36 +3,52 @@ Error predictors (reference annchor/error_predictors.py:18-67).  Protocol, uncha
     fit(sample_features, feature_names, sample_error, sample_bins=None)
     predict(features, feature_names) -> int labels[n]
     .errs: dict[label -> sorted float64[]],  .labels: iterable
+
+Written around one sort and binary searches instead of a mask per partition; the
+behaviour at shared partition edges is the reference's: a sample ON an edge counts for
+both neighbouring partitions when the residual lists are fitted (closed intervals on both
+sides), and a pair on an edge is labelled with the later partition.
 """
 import numpy as np
 
 
 class SimpleStratifiedErrorRegression:
     def __init__(self, partition_feature_name="double anchor distance", n_partitions=7):
-        self.n_partitions = n_partitions
         self.partition_feature_name = partition_feature_name
+        self.n_partitions = n_partitions
         self.labels = range(n_partitions)
+        self.partition_bins = None
+        self.errs = {}
+
+    def _column(self, features, feature_names):
+        return np.asarray(features)[:, feature_names.index(self.partition_feature_name)]
+
+    def _own_edges(self, values):
+        """Edges when the caller hands none over: 1 % / 99 % order statistics, evenly spaced between."""
+        ordered = np.sort(values)
+        n = ordered.shape[0]
+        inner = np.linspace(ordered[n // 100], ordered[(99 * n) // 100], self.n_partitions - 1)
+        return np.concatenate(([-np.inf], inner, [np.inf]))
 
     def fit(self, sample_features, feature_names, sample_error, sample_bins=None):
-        sample_feature = sample_features[:, feature_names.index(self.partition_feature_name)]
+        values = self._column(sample_features, feature_names)
         if sample_bins is None:
-            n = sample_feature.shape[0]
-            iq1, iq3 = int(n / 100), int(99 * n / 100)
-            q1, q3 = np.partition(sample_feature, iq1)[iq1], np.partition(sample_feature, iq3)[iq3]
-            self.partition_bins = np.hstack([-np.inf, np.linspace(q1, q3, self.n_partitions - 1), np.inf])
+            self.partition_bins = self._own_edges(values)
         else:
-            self.n_partitions = sample_bins.shape[0] - 1
             self.partition_bins = sample_bins
+            self.n_partitions = len(sample_bins) - 1
         self.labels = range(self.n_partitions)
-        self.errs = {}
-        for nbin in range(self.n_partitions):
-            mask = (sample_feature >= self.partition_bins[nbin]) * (sample_feature <= self.partition_bins[nbin + 1])
-            self.errs[nbin] = np.sort(sample_error[mask])
+        edges = np.asarray(self.partition_bins, dtype=np.float64)
+        order = np.argsort(values, kind="stable")
+        by_value = values[order]
+        residual = np.asarray(sample_error)[order]
+        first = np.searchsorted(by_value, edges[:-1], side="left")    # first sample >= lower edge
+        last = np.searchsorted(by_value, edges[1:], side="right")     # one past the last sample <= upper edge
+        self.errs = {b: np.sort(residual[first[b]:max(last[b], first[b])]) for b in range(self.n_partitions)}
 
     def predict(self, features, feature_names):
-        labels = np.empty(shape=features.shape[0]).astype(int)
-        feature = features[:, feature_names.index(self.partition_feature_name)]
-        for nbin in range(self.n_partitions):
-            mask = (feature >= self.partition_bins[nbin]) * (feature <= self.partition_bins[nbin + 1])
-            labels[mask] = nbin
-        return labels
+        values = self._column(features, feature_names)
+        edges = np.asarray(self.partition_bins, dtype=np.float64)
+        # the last partition whose lower edge is <= value (shared edges go to the later partition)
+        lab = np.searchsorted(edges, values, side="right") - 1
+        return np.clip(lab, 0, self.n_partitions - 1).astype(int)

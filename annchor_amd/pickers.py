@@ -25,14 +25,22 @@ class MaxMinAnchorPicker:
             ann._engine.pick_anchors_maxmin(na, ix)
             ann._anchors_on_device = True
             return None, None, na * nx
-        D = np.zeros((na, nx)) + np.inf
-        A = np.zeros(na).astype(int)
-        for i in range(na):
-            A[i] = ix
-            IJs = np.array([[ix, j] for j in range(nx)])
-            D[i] = ann.get_exact_ijs(ann.f, ann.X, IJs)
-            ix = np.argmax(np.min(D[:1], axis=0)) if i == 0 else np.argmax(np.min(D[1:i + 1], axis=0))
-        return A, D.T, na * nx
+        # host metric: one one-to-all sweep per round through the caller's evaluator.  `spread` is
+        # the running minimum the next anchor maximises; from round 1 on it restarts WITHOUT
+        # anchor 0's row (the reference quirk described above)
+        everyone = np.arange(nx, dtype=np.int64)
+        rows, chosen, spread = [], [], None
+        for rnd in range(na):
+            chosen.append(int(ix))
+            row = np.asarray(ann.get_exact_ijs(ann.f, ann.X, np.column_stack((np.full(nx, ix, dtype=np.int64), everyone))),
+                             dtype=np.float64)
+            rows.append(row)
+            if rnd == 0:
+                ix = int(np.argmax(row))
+            else:
+                spread = row.copy() if spread is None else np.minimum(spread, row)
+                ix = int(np.argmax(spread))
+        return np.array(chosen, dtype=int), np.stack(rows, axis=1), na * nx
 
 
 class ExternalAnchorPicker:
@@ -45,14 +53,10 @@ class ExternalAnchorPicker:
     def get_anchors(self, ann):
         nx, na = ann.nx, ann.n_anchors
         np.random.seed(ann.random_seed)
-        D = np.zeros((na, nx)) + np.inf
-        batched = getattr(ann.f, "one_to_many", None)
-        for i in range(na):
-            if batched is not None:
-                D[i] = batched(self.A[i], ann.X)
-            else:
-                D[i] = np.array([ann.f(x, self.A[i]) for x in ann.X])
-        return np.array([]), D.T, na * nx
+        sweep = getattr(ann.f, "one_to_many", None)
+        cols = [np.asarray(sweep(a, ann.X) if sweep is not None else [ann.f(x, a) for x in ann.X], dtype=np.float64)
+                for a in (self.A[i] for i in range(na))]
+        return np.array([]), np.stack(cols, axis=1), na * nx
 
 
 class SelectedAnchorPicker:
@@ -82,6 +86,7 @@ def _selected(ann, A, nx, na):
         ann._engine.pick_anchors_selected(A)
         ann._anchors_on_device = True
         return None, None, na * nx
-    IJ = np.array([[i, j] for i in A for j in range(nx)])
-    D = ann.get_exact_ijs(ann.f, ann.X, IJ).reshape(na, nx)
+    A = np.asarray(A)
+    IJ = np.column_stack((np.repeat(A.astype(np.int64), nx), np.tile(np.arange(nx, dtype=np.int64), len(A))))
+    D = np.asarray(ann.get_exact_ijs(ann.f, ann.X, IJ), dtype=np.float64).reshape(len(A), nx)
     return A, D.T, na * nx

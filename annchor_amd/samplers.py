@@ -43,42 +43,47 @@ class Sampler(ABC):
         pass
 
     def sample_partition(self, indices, n_samples, sample_feature, sample_bins, random_seed):
-        bin_size = n_samples // self.n_partitions
-        remainder = n_samples % self.n_partitions
-        # utils.py:560-578 (the reference seeds numba's RNG inside njit; without numba
-        # the NumPy legacy stream is the reproducible equivalent)
+        """Draw without replacement from every partition (utils.py:543-578): partition b is
+        lo_b <= x < hi_b and gets n_samples // P (+1 for the first n_samples % P partitions), or all
+        of its members when it has fewer.  The reference seeds numba's RNG inside njit; without
+        numba the NumPy legacy stream is the reproducible equivalent: one
+        `permutation(len(members))[:want]` per partition, in partition order, after
+        `seed(random_seed + loop_num)` -- the draws `np.random.choice(members, want, replace=False)`
+        makes."""
+        P = self.n_partitions
+        edges = np.asarray(sample_bins, dtype=np.float64)
+        part = np.searchsorted(edges, sample_feature, side="right") - 1      # last edge <= x
+        grouped = np.argsort(part, kind="stable")                            # members of a partition keep their order
+        start = np.searchsorted(part[grouped], np.arange(P + 1), side="left")
+        quota = n_samples // P + (np.arange(P) < n_samples % P)
         np.random.seed(random_seed + self.loop_num)
-        samples = []
-        for nbin in range(self.n_partitions):
-            mask = (sample_feature >= sample_bins[nbin]) * (sample_feature < sample_bins[nbin + 1])
-            ixmask = indices[mask]
-            want = bin_size + (nbin < remainder)
-            if ixmask.shape[0] < want:
-                samples.append(ixmask)
-            else:
-                samples.append(np.random.choice(ixmask, size=want, replace=False))
+        picked = []
+        for b in range(P):
+            members = indices[grouped[start[b]:start[b + 1]]]
+            if len(members) >= quota[b]:
+                members = members[np.random.permutation(len(members))[:quota[b]]]
+            picked.append(members)
         self.loop_num += 1
-        for s in samples:
-            if len(s) < 2:
-                raise Exception("Some sampler bins contain too few samples")
-        return np.hstack(samples)
+        if min(len(m) for m in picked) < 2:
+            raise Exception("Some sampler bins contain too few samples")
+        return np.concatenate(picked)
 
     def sample(self, features, feature_names, n_samples, not_computed_mask, random_seed):
-        if not not_computed_mask.any():
+        """samplers.py:75-110: partition the not-computed pairs on one feature and draw from each
+        partition; returns (positions in the pair list, how many, partition edges)."""
+        open_pairs = np.flatnonzero(not_computed_mask)
+        if open_pairs.size == 0:
             raise NothingToSample()
-        i_feature = feature_names.index(self.partition_feature_name)
-        sample_feature = features[not_computed_mask][:, i_feature]
-        indices = np.arange(not_computed_mask.shape[0])[not_computed_mask]
-        sample_bins, new_n_samples = self.get_partition(sample_feature, n_samples)
-        if new_n_samples != n_samples:
-            print("Warning: n_samples has changed from %d to %d." % (n_samples, new_n_samples))
-        n_samples = new_n_samples
-        if n_samples == 0:
+        values = np.asarray(features)[open_pairs, feature_names.index(self.partition_feature_name)]
+        edges, granted = self.get_partition(values, n_samples)
+        if granted != n_samples:
+            print("Warning: n_samples has changed from %d to %d." % (n_samples, granted))
+        if granted == 0:
             raise NothingToSample()
-        sample_ixs = self.sample_partition(indices, n_samples, sample_feature, sample_bins, random_seed)
-        if n_samples != sample_ixs.shape[0]:
+        drawn = self.sample_partition(open_pairs, granted, values, edges, random_seed)
+        if len(drawn) != granted:
             print("Warning: Some bins contained fewer samples than requested")
-        return sample_ixs, sample_ixs.shape[0], sample_bins
+        return drawn, len(drawn), edges
 
 
 class SimpleStratifiedSampler(Sampler):

@@ -305,6 +305,43 @@ def test_fit_strings_readme_config_zero_errors(strings):
     assert compare_neighbor_graphs(truth, ann.neighbor_graph, 25) == int(Go["readme_errors"]) <= 2
 
 
+def test_fit_strings_reference_test_config(strings):
+    """The reference's own test_strings configuration (tests/test_annchor.py:83-102): n_anchors=23,
+    n_neighbors=15, n_samples=5000, p_work=0.12, niters=4 -- three update_bounds passes on the
+    device.  Anchors / anchor distances / evaluation count equal the reference run's; the graph is
+    bit-identical to the oracle's (tests/golden/make_oracle_fixtures.py); the reference test's bar
+    is < 15 errors (its own run here: 4)."""
+    from annchor_amd import Annchor, compare_neighbor_graphs
+
+    G = np.load(os.path.join(GOLD, "strings_full.npz"))
+    Go = np.load(os.path.join(GOLD, "strings_full_oracle.npz"))
+    cfg = dict(n_anchors=23, n_neighbors=15, n_samples=5000, p_work=0.12, niters=4, random_seed=42)
+    ann = Annchor(np.array(strings), "levenshtein", **cfg).fit()
+    assert np.array_equal(ann.A, G["test_A"])
+    assert np.array_equal(ann.D, G["test_D"].astype(np.float64))
+    assert ann.evals == int(G["test_evals"]) == int(Go["test_evals"])
+    assert ann.n_pairs == int(G["test_npairs"]) == int(Go["test_npairs"])
+    assert np.array_equal(ann.neighbor_graph[1], Go["test_ng_dist"].astype(np.float64))
+    assert np.array_equal(ann.neighbor_graph[0], Go["test_ng_idx"].astype(np.int64))
+    truth = (G["truth_idx"].astype(np.int64), G["truth_dist"].astype(np.float64))
+    err = compare_neighbor_graphs(truth, ann.neighbor_graph, 15)
+    assert err == int(Go["test_errors"]) and err < 15
+    idx, dist = ann.neighbor_graph
+    IJ = np.stack([np.repeat(np.arange(1600), 14), idx[:, 1:].ravel()], axis=1)
+    assert np.array_equal(om.PackedStrings(strings).pairs(IJ), dist[:, 1:].ravel())
+
+
+def test_fit_strings_four_iterations_stagewise(strings):
+    """niters=4 stage by stage against the oracle (every update_bounds pass, every selection)."""
+    from annchor_amd import Annchor
+
+    Xs = strings[::4]
+    cfg = dict(n_anchors=10, n_neighbors=8, n_samples=600, p_work=0.3, random_seed=7, niters=4)
+    ann = Annchor(np.array(Xs), "levenshtein", **cfg)
+    P = om.PackedStrings(Xs)
+    _staged_compare(ann, lambda tr: O.OracleAnnchor(len(Xs), P.pairs, trace=tr, **cfg))
+
+
 def test_blobs_pinned_anchors_and_errors():
     """reference tests/test_examples.py:88-230: pinned A, 0 errors with max-min anchors."""
     from annchor_amd import Annchor, compare_neighbor_graphs
@@ -480,3 +517,60 @@ def test_query_digits_recall():
     assert 1 - err / bd.size >= 0.99, err
     # reported neighbours are train-set members at their exact distances
     np.testing.assert_allclose(full[np.arange(len(te))[:, None], gi], gd, rtol=0, atol=1e-9)
+
+
+def test_query_reference_digits_split():
+    """The reference test's own query configuration (tests/test_examples.py:12-58) against the
+    reference's own run of it (tests/golden/query_digits.npz, make_golden.py::gen_query): digits
+    train_test_split(random_state=0), n_anchors=25, k=25, n_samples=5000, p_work=0.16; query
+    nn=15, p_work=0.2.  Float tolerance: EMD values 1e-9 absolute."""
+    from annchor_amd import Annchor, compare_neighbor_graphs
+
+    G = np.load(os.path.join(GOLD, "query_digits.npz"))
+    d = om.load_digits()
+    X, M = d["X"], d["cost_matrix"]
+    tr, te = G["idx_train"], G["idx_test"]
+    ann = Annchor(X[tr], "wasserstein", func_kwargs={"cost_matrix": M}, n_anchors=25, n_neighbors=25, n_samples=5000,
+                  p_work=0.16).fit()
+    assert np.array_equal(ann.A, G["A"])
+    np.testing.assert_allclose(ann.D, G["D"], rtol=0, atol=1e-12)
+    gi, gd = ann.query(X[te], nn=15, p_work=0.2)
+    assert gi.shape == G["q_e2e_idx"].shape
+    # the reference's own answer: at most a handful of rows differ (float ties at the selection cut)
+    assert compare_neighbor_graphs((G["q_e2e_idx"], G["q_e2e_dist"]), (gi, gd), 15) <= 5
+    errs = sum(len(np.setdiff1d(G["truth_idx"][i], gi[i])) for i in range(len(te)))
+    assert 1 - errs / (15.0 * len(te)) >= 0.99          # the reference test's criterion
+    H = om.Histograms(np.concatenate([X[tr], X[te]]), M)
+    IJ = np.stack([gi.ravel(), len(tr) + np.repeat(np.arange(len(te)), 15)], axis=1)
+    np.testing.assert_allclose(H.pairs(IJ), gd.ravel(), rtol=0, atol=1e-9)
+
+
+def test_query_reference_strings_split(strings):
+    """Annchor.query against the reference's run on the strings split of gen_query (integer
+    metric: every reported distance exact; error count vs brute force within the tie swaps of
+    the reference's own arbitrary argpartition order), and bit-exact against the oracle."""
+    from annchor_amd import Annchor, compare_neighbor_graphs
+
+    G = np.load(os.path.join(GOLD, "query_strings.npz"))
+    sub = strings[::4]
+    trn = [s for t, s in enumerate(sub) if t % 5]
+    qs = [s for t, s in enumerate(sub) if t % 5 == 0]
+    cfg = dict(n_anchors=8, n_neighbors=10, n_samples=700, p_work=0.3, random_seed=42, niters=2)
+    ann = Annchor(np.array(trn), "levenshtein", **cfg).fit()
+    assert np.array_equal(ann.A, G["A"]) and np.array_equal(ann.D, G["D"])
+    PQ = om.PackedStrings(trn + qs)
+    qp = lambda IJ: PQ.pairs(np.stack([IJ[:, 0], IJ[:, 1] + len(trn)], 1))  # noqa: E731
+    ora = O.OracleAnnchor(len(trn), om.PackedStrings(trn).pairs, **cfg).fit()
+    nx = len(trn)
+    dense = qp(np.stack([np.repeat(np.arange(nx), len(qs)), np.tile(np.arange(len(qs)), nx)], 1)).reshape(nx, len(qs)).T
+    for tag, Q in (("q", qs), ("qlow", qs[:7])):
+        nn, pw = int(G[tag + "_nn"]), float(G[tag + "_p_work"])
+        gi, gd = ann.query(np.array(Q), nn=nn, p_work=pw)
+        oi, od, info = O.query(ora, qp, len(Q), nn=nn, p_work=pw, apply_floor=True)
+        assert np.array_equal(gd, od) and np.array_equal(gi, oi)
+        assert ann.query_evals == info["evals"] == ora.n_anchors * len(Q) + len(G[tag + "_mapback"])
+        order = np.argsort(dense[:len(Q)], axis=1, kind="stable")[:, :nn]
+        truth = (order, np.take_along_axis(dense[:len(Q)], order, axis=1))
+        e_gpu = compare_neighbor_graphs(truth, (gi, gd), nn)
+        e_ref = compare_neighbor_graphs(truth, (G[tag + "_e2e_idx"], G[tag + "_e2e_dist"]), nn)
+        assert abs(e_gpu - e_ref) <= 0.02 * len(Q) * nn + 2, (e_gpu, e_ref)
