@@ -79,10 +79,16 @@ _SIGNATURES = {
     "annchor_stream_get_row": (ctypes.c_int, [_vp, _i64, _vp]),
     "annchor_stream_order": (ctypes.c_int, [_vp, _i32] + [ctypes.POINTER(_vp)] * 6 + [ctypes.POINTER(_i64), ctypes.POINTER(_i32),
                                                                                    ctypes.POINTER(_i32)]),
-    "annchor_stream_knn": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _vp, _vp, _vp,
-                                          ctypes.POINTER(_i64)]),
+    "annchor_stream_knn": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _i32, _i32, _vp,
+                                          _vp, _vp, ctypes.POINTER(_i64)]),
+    "annchor_stream_knn_begin": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                                ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
+    "annchor_stream_knn_join": (ctypes.c_int, [_vp, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
+    "annchor_stream_budget": (ctypes.c_int, [_i32, _dbl, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
+    "annchor_stream_knn_end": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "annchor_stream_query": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _dbl, _vp, _vp,
                                             ctypes.POINTER(_i64)]),
+    "annchor_stream_join_tables": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "annchor_device_alloc": (ctypes.c_int, [_vp, _i64, ctypes.POINTER(_vp)]),
     "annchor_device_free": (ctypes.c_int, [_vp, _vp]),
     "annchor_device_copy": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32]),
@@ -163,6 +169,17 @@ def bind_to_device_numa(device=0):
         return "NUMA node %d of GPU %s (%d CPUs)" % (node, bus, len(cpus))
     except (OSError, ValueError, AttributeError):
         return None
+
+
+def stream_budget(n_tiles, p_work, join_passes):
+    """(total, tile_phase, per_pass): the streamed form's per-row-tile work budget and its split
+    between the tile phase and the join passes (include/annchor_hip.h: annchor_stream_budget)."""
+    T, tp, pp = _i32(), _i32(), _i32()
+    rc = load_library().annchor_stream_budget(int(n_tiles), float(p_work), int(join_passes), ctypes.byref(T), ctypes.byref(tp),
+                                              ctypes.byref(pp))
+    if rc != 0:
+        raise NativeError("annchor_stream_budget failed (%d)" % rc)
+    return T.value, tp.value, pp.value
 
 
 def legacy_prefetch(seed, ndraws):
@@ -497,7 +514,7 @@ class Engine:
         names = ("Xs", "rs", "perm", "lo", "hi", "mid")
         return {k: p.value for k, p in zip(names, ptrs)}, n_pad.value, nt.value, dimp.value
 
-    def stream_knn(self, ptrs, n_all, nt_all, n_anchors, dim_padded, tile_begin, tile_count, k, p_work, n_local=None):
+    def stream_knn(self, ptrs, n_all, nt_all, n_anchors, dim_padded, tile_begin, tile_count, k, p_work, n_local=None, join_passes=0, join_extra=0):
         """n_local given: graph rows come back in the bound shard's own row order ([n_local, k],
         row_ids is None); otherwise in tile order with row_ids (global id per row, -1 = padding)."""
         rows = tile_count * 128 if n_local is None else int(n_local)
@@ -507,8 +524,37 @@ class Engine:
         ev = _i64()
         self._chk(self.lib.annchor_stream_knn(self.h, ptrs["Xs"], ptrs["rs"], ptrs["perm"], ptrs["lo"], ptrs["hi"], ptrs["mid"], int(n_all),
                                               int(nt_all), int(n_anchors), int(dim_padded), int(tile_begin), int(tile_count),
-                                              int(k), float(p_work), _ptr(row_ids) if row_ids is not None else None, _ptr(idx),
-                                              _ptr(dist), ctypes.byref(ev)))
+                                              int(k), float(p_work), int(join_passes), int(join_extra),
+                                              _ptr(row_ids) if row_ids is not None else None,
+                                              _ptr(idx), _ptr(dist), ctypes.byref(ev)))
+        return row_ids, idx, dist, ev.value
+
+    def stream_knn_begin(self, ptrs, n_all, nt_all, n_anchors, dim_padded, tile_begin, tile_count, k, tile_budget):
+        """Tile phase of a row-sharded build (tile_budget column tiles per row tile: stream_budget);
+        returns (device pointer, bytes) of this rank's lists."""
+        lp, nb = _vp(), _i64()
+        self._chk(self.lib.annchor_stream_knn_begin(self.h, ptrs["Xs"], ptrs["rs"], ptrs["perm"], ptrs["lo"], ptrs["hi"], ptrs["mid"],
+                                                    int(n_all), int(nt_all), int(n_anchors), int(dim_padded), int(tile_begin),
+                                                    int(tile_count), int(k), int(tile_budget), ctypes.byref(lp), ctypes.byref(nb)))
+        self._knn_shape = (int(tile_count), int(k))
+        return lp.value, nb.value
+
+    def stream_knn_join(self, lists_all, per_pass):
+        """One join pass against the all-gathered lists; returns (device pointer of the new local lists,
+        list entries the pass replaced)."""
+        lp, upd = _vp(), _i64()
+        self._chk(self.lib.annchor_stream_knn_join(self.h, lists_all, int(per_pass), ctypes.byref(lp), ctypes.byref(upd)))
+        return lp.value, upd.value
+
+    def stream_knn_end(self, n_local=None):
+        tile_count, k = self._knn_shape
+        rows = tile_count * 128 if n_local is None else int(n_local)
+        row_ids = np.zeros(rows, dtype=np.int64) if n_local is None else None
+        idx = np.empty((rows, k), dtype=np.int64)
+        dist = np.empty((rows, k), dtype=np.float64)
+        ev = _i64()
+        self._chk(self.lib.annchor_stream_knn_end(self.h, _ptr(row_ids) if row_ids is not None else None, _ptr(idx), _ptr(dist),
+                                                  ctypes.byref(ev)))
         return row_ids, idx, dist, ev.value
 
     def stream_query(self, cols, n_all, nt_all, n_anchors, dim_padded, nn, p_work):
@@ -520,6 +566,9 @@ class Engine:
                                                 int(n_all), int(nt_all), int(n_anchors), int(dim_padded), int(nn), float(p_work),
                                                 _ptr(idx), _ptr(dist), ctypes.byref(ev)))
         return idx, dist, ev.value
+
+    def stream_join_tables(self, gathered, world, n_anchors, n_tiles, joined):
+        self._chk(self.lib.annchor_stream_join_tables(self.h, gathered, int(world), int(n_anchors), int(n_tiles), joined))
 
     def device_alloc(self, nbytes):
         p = _vp()

@@ -29,7 +29,8 @@ from .utils import get_exact_ijs_, get_function_from_input, test_parallelisation
 from .distances import euclidean as distances_euclidean  # noqa: E402
 from .distances import cosine as distances_cosine  # noqa: E402
 
-PAIRLIST_MAX_POINTS = 20000  # above this the candidate pair list (~nx^2/2 x ~100 B) is not materialised
+PAIRLIST_MAX_POINTS = 30000   # float32 Euclidean / cosine data above this size takes the streamed (tile-granular) form
+PAIRLIST_HARD_MAX = 30000     # the candidate pair list (~nx^2 / 2 entries x ~100 B) is not materialised above this size
 
 FEATURE_NAMES = ["lower bound", "upper bound", "double anchor distance", "is anchor"]
 
@@ -95,13 +96,15 @@ class _DeviceExact:
 class Annchor:
     """Quickly computes the approximate k-NN graph for slow metrics (annchor.py:21-115).
 
-    Parameters are those of the reference, plus `device` (GPU ordinal, default 0).
+    Parameters are those of the reference, plus `device` (GPU ordinal, default 0) and `streamed`
+    (None: float32 Euclidean / cosine data above PAIRLIST_MAX_POINTS points takes the streamed
+    tile-granular form, announced on stdout; True / False force either form).
     """
 
     def __init__(self, X, func, func_kwargs=None, n_anchors=20, n_neighbors=15, n_samples=5000, p_work=0.1,
                  anchor_picker=None, sampler=None, regression=None, error_predictor=None, random_seed=42,
                  locality=5, loc_thresh=1, loc_min=None, verbose=False, is_metric=True, get_exact_ijs=None,
-                 backend="loky", niters=2, lookahead=5, device=0):
+                 backend="loky", niters=2, lookahead=5, device=0, streamed=None):
         self.X = X
         self.nx = len(X)
         self.f = get_function_from_input(func, func_kwargs)
@@ -129,16 +132,39 @@ class Annchor:
         assert backend in ["loky", "multiprocessing"]
         self.backend = backend
 
-        # ---- large float Euclidean data: the streamed (tile-granular) form.  The pair list of
-        # the reference would hold ~nx^2/2 entries (hard part 3).
+        # ---- large float32 Euclidean / cosine data: the streamed (tile-granular) form.  The pair list
+        # of the reference would hold ~nx^2/2 entries (hard part 3).  `streamed`:
+        # None = by size, True / False = forced.  The streamed form computes in float32 and has no
+        # sampler / regression / error model, so it is only taken for float32 input with the
+        # default plugins -- never by narrowing float64 data behind the caller's back.
         self._streamed = None
-        defaults = anchor_picker is None and sampler is None and regression is None and error_predictor is None
         self._cosine_streamed = False
-        if ((self.f is distances_euclidean or self.f is distances_cosine) and get_exact_ijs is None and defaults
-                and self.nx > PAIRLIST_MAX_POINTS and getattr(np.asarray(X), "ndim", 0) == 2 and np.asarray(X).shape[1] <= 256):
+        self._anchors_on_device = False
+        self._first_merge = True
+        self._sample_ticket, self._pipelined = None, False
+        Xa = X if isinstance(X, np.ndarray) else None
+        bundled = self.f is distances_euclidean or self.f is distances_cosine
+        defaults = (anchor_picker is None and sampler is None and regression is None and error_predictor is None
+                    and get_exact_ijs is None)
+        can_stream = (bundled and defaults and Xa is not None and Xa.ndim == 2 and Xa.dtype == np.float32 and Xa.shape[1] <= 256)
+        if streamed is True and not can_stream:
+            raise ValueError("streamed=True needs a float32 [n, dim <= 256] array, the 'euclidean' or 'cosine' metric and the "
+                             "default plugins (float64 data is not narrowed: convert it yourself if float32 distances are acceptable)")
+        want_stream = can_stream and (streamed is True or (streamed is None and self.nx > PAIRLIST_MAX_POINTS))
+        if not want_stream and self.nx > PAIRLIST_HARD_MAX:
+            raise ValueError("%d points: the candidate pair list of the reference form (~nx^2/2 entries) is only materialised up to "
+                             "%d points.  Larger sets need the streamed form: float32 [n, dim <= 256] data, 'euclidean' or "
+                             "'cosine', default plugins%s." % (self.nx, PAIRLIST_HARD_MAX,
+                                                             "" if streamed is not False else " (and streamed != False)"))
+        if want_stream:
             from .streamed import StreamedAnnchor
 
-            Xs = np.asarray(X, dtype=np.float32)
+            if streamed is None:
+                print("Note: %d float32 points under '%s': using the streamed (tile-granular) form -- anchors, a p_work tile budget "
+                      "and %d neighbour-join passes (niters); n_samples, locality, loc_thresh, loc_min, lookahead and is_metric "
+                      "do not apply to it (streamed=False forces the pair-list form up to %d points)."
+                      % (self.nx, self.f.name, niters, PAIRLIST_HARD_MAX))
+            Xs = np.ascontiguousarray(Xa)
             if self.f is distances_cosine:
                 # on the unit sphere |u - v|^2 = 2 - 2 cos(u, v): cosine distance = (Euclidean distance)^2 / 2
                 # of the normalised rows, the same neighbours in the same order
@@ -147,8 +173,8 @@ class Annchor:
                     raise ValueError("cosine distance is undefined for zero rows")
                 Xs = (Xs / norms[:, None]).astype(np.float32)
                 self._cosine_streamed = True
-            self._streamed = StreamedAnnchor(Xs, n_anchors=n_anchors, n_neighbors=n_neighbors,
-                                             p_work=self.p_work, random_seed=random_seed, device=device)
+            self._streamed = StreamedAnnchor(Xs, n_anchors=n_anchors, n_neighbors=n_neighbors, p_work=self.p_work,
+                                             random_seed=random_seed, device=device, join_passes=max(int(niters), 0))
             self._engine = self._streamed._engine
             self._device_metric = True
             self.get_exact_ijs = _DeviceExact(self._engine, self.f, self.X)
@@ -239,8 +265,14 @@ class Annchor:
         return self._view("thresh", lambda: self._engine.download(_native.F_THRESH))
 
     # --------------------------------------------------------------------- stages
+    def _pair_list_stage(self, what):
+        if self._streamed is not None:
+            raise NotImplementedError("%s is a stage of the pair-list form; this object runs the streamed form "
+                                      "(fit() does everything; pass streamed=False for the staged pipeline)" % what)
+
     def get_anchors(self):
         """annchor.py:191-206."""
+        self._pair_list_stage("get_anchors")
         self._anchors_on_device = False
         A, D, evals = self.anchor_picker.get_anchors(self)
         if not self._anchors_on_device:
@@ -251,6 +283,7 @@ class Annchor:
 
     def get_locality(self):
         """annchor.py:208-256."""
+        self._pair_list_stage("get_locality")
         n, min_len = self._engine.build_locality(self.locality, self.loc_thresh, int(self.loc_min))
         self.n_pairs = n
         self._invalidate("IJs", "I", "sid", "features", "ncm", "RA", "labels", "thresh")
@@ -260,6 +293,7 @@ class Annchor:
 
     def get_features(self):
         """annchor.py:258-311."""
+        self._pair_list_stage("get_features")
         self._engine.compute_features()
         self._first_merge = True
         self._invalidate("features", "ncm", "RA", "labels", "thresh")
@@ -273,6 +307,7 @@ class Annchor:
 
     def get_sample(self):
         """annchor.py:313-343."""
+        self._pair_list_stage("get_sample")
         eng = self._engine
         if self._sampler_on_device():
             ticket, self._sample_ticket = self._sample_ticket, None
@@ -301,6 +336,7 @@ class Annchor:
 
     def fit_predict_regression(self):
         """annchor.py:345-380."""
+        self._pair_list_stage("fit_predict_regression")
         self.regression.fit(self.sample_features, self.feature_names, self.sample_y, sample_bins=self.sample_bins)
         model = self.regression.coefficients() if type(self.regression) is SimpleStratifiedLinearRegression else None
         self._fused_labels = False
@@ -322,6 +358,7 @@ class Annchor:
 
     def fit_predict_errors(self):
         """annchor.py:382-393."""
+        self._pair_list_stage("fit_predict_errors")
         self.error_predictor.fit(self.sample_features, self.feature_names, self.sample_y - self.sample_predict,
                                  sample_bins=self.sample_bins)
         if not self._fused_labels:
@@ -331,6 +368,7 @@ class Annchor:
 
     def select_refine_candidate_pairs(self, w=0.5, it=0):
         """annchor.py:395-473."""
+        self._pair_list_stage("select_refine_candidate_pairs")
         nn = self.n_neighbors
         labels = list(self.error_predictor.labels)
         errs = [np.asarray(self.error_predictor.errs[lab], dtype=np.float64) for lab in labels]
@@ -367,11 +405,13 @@ class Annchor:
 
     def update_anchor_points(self, timeout=None, chunk_size=None):
         """annchor.py:475-512 (no wall-clock cut: all lookahead pairs are processed)."""
+        self._pair_list_stage("update_anchor_points")
         self._engine.update_bounds()
         self._invalidate("features")
 
     def get_ann(self):
         """annchor.py:514-530."""
+        self._pair_list_stage("get_ann")
         self.neighbor_graph = self._engine.neighbor_graph(self.n_neighbors)
 
     def fit(self):
@@ -504,7 +544,7 @@ class Annchor:
     # ---------------------------------------------- nearest enemies / selective subset
     def _require_pair_list(self, what):
         if self._streamed is not None:
-            raise NotImplementedError(what + " needs the pair-list form (nx <= %d)" % PAIRLIST_MAX_POINTS)
+            raise NotImplementedError(what + " needs the pair-list form (streamed=False, nx <= %d)" % PAIRLIST_HARD_MAX)
 
     def get_nearest_enemies(self, y, nn=3, loc_min=100):
         """annchor.py:685-782: the nn nearest points of a different label for every point;

@@ -71,11 +71,19 @@ struct StreamState {
     DevBuf emit_idx, emit_dist;   // int64 / double [n_local][k]: graph rows in shard order
     DevBuf scr_key, scr_lb;   // float [tile_count][nt_all]: per-row-tile rank keys / bounds of all column tiles
     DevBuf evals;
+    DevBuf eval_bits;         // uint32 [tile_count][ceil(nt_all / 32)]: column tiles the tile phase evaluated, per row tile
+    DevBuf out_d2b, out_colb; // second list buffers: a join pass reads the old lists of ALL rows and writes new ones
+    DevBuf ucand, ucount;     // uint32 [tile_count][JN_CAP] / int32 [tile_count]: join candidates per row tile
+    DevBuf rev_cnt, rev_ptr, rev_edges, rev;   // reverse neighbour lists of every ordered row (join passes)
     int64_t n_local = 0, n_pad = 0, base = 0;
     int dim = 0, dimp = 0, na = 0, nt = 0;
+    struct KnnArgs *run = nullptr;   // arguments of the graph build in progress (begin / join / end)
+    const void *run_perm = nullptr;
+    int run_dimp = 0;
 };
 
 static std::vector<std::pair<annchor_ctx *, StreamState *>> g_states;
+static void ann_stream_free_run(StreamState *s);
 
 static StreamState *state_of(annchor_ctx *c, bool create)
 {
@@ -94,9 +102,11 @@ void ann_stream_release(annchor_ctx *c)
             StreamState *s = g_states[i].second;
             DevBuf *bufs[] = {&s->X, &s->keys, &s->keys2, &s->vals, &s->vals2, &s->cubtmp, &s->Xs, &s->rs, &s->perm, &s->lo,
                               &s->hi, &s->mid, &s->avec, &s->runmin, &s->red_val, &s->red_idx, &s->D, &s->out_d2, &s->out_col, &s->evals,
-                              &s->scr_key, &s->scr_lb, &s->emit_idx, &s->emit_dist, &s->Dt};
+                              &s->scr_key, &s->scr_lb, &s->emit_idx, &s->emit_dist, &s->Dt, &s->eval_bits, &s->out_d2b, &s->out_colb,
+                              &s->ucand, &s->ucount, &s->rev_cnt, &s->rev_ptr, &s->rev_edges, &s->rev};
             for (DevBuf *b : bufs)
                 if (b->p && !b->in_arena) (void)hipFree(b->p);
+            ann_stream_free_run(s);
             delete s;
             g_states.erase(g_states.begin() + (long)i);
             return;
@@ -473,6 +483,16 @@ struct KnnArgs {
     float *scr_key, *scr_lb;   // [tile_count][nt_all] per-row-tile rank keys / valid bounds of every column tile
     unsigned long long *evals;
     unsigned long long *prof;   // ST_PROFILE builds only: per-phase cycle sums (8 counters)
+    uint32_t *eval_bits;  // [tile_count][eval_words] evaluated column tiles per row tile (NULL: not recorded)
+    int eval_words;
+    // join passes (k_st_join_cands / k_st_join)
+    const int32_t *lists_all;   // [n_all][K] current neighbour lists of EVERY ordered row (all ranks)
+    const uint32_t *ucand;      // [tile_count][ucap] sorted candidate columns per row tile, 0xffffffff padded to 128
+    const int32_t *ucount;      // [tile_count]
+    int ucap;
+    float *out_d2_new;          // [tile_count*128][K] lists after the pass
+    int32_t *out_col_new;
+    unsigned long long *updates; // list insertions of the pass (its yield: the host stops when it dries up)
 };
 
 template <int DIM, int KMAX> struct KnnShared {
@@ -489,6 +509,7 @@ template <int DIM, int KMAX> struct KnnShared {
     float surv_vb[ST_SURV];   // valid interval lower bound
     int32_t surv_j[ST_SURV];
     float wave_thr[ST_THREADS / 64];
+    uint32_t slab_id[2][ST_SLAB];   // join passes: ordered column index of each staged column (slab parity)
     int nsurv;
     int sel_bin;
     uint32_t sel_before;
@@ -507,18 +528,23 @@ template <int DIM, int KMAX> struct KnnShared {
 template <int DIM> struct SlabStage {
     float4 v[ST_SLAB * DIM / 4 / ST_THREADS];
     float r;
+    uint32_t id; // join passes: ordered column index of the staged column (threads < ST_SLAB)
+    int ins;     // join passes: list insertions made by this thread's rows
     int J;   // tile whose slab 0 is held (-1: none)
 };
 
 // Returns the worst k-th squared distance over the row tile after this column tile.
-template <int DIM, int KMAX>
+// GATHER (join passes): "tile" J is the J-th run of 128 entries of the row tile's candidate list
+// a.ucand (ordered column indices, 0xffffffff = padding) instead of 128 consecutive columns.
+template <int DIM, int KMAX, bool GATHER = false>
 __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, const KnnArgs &a, int J, int Jnext, SlabStage<DIM> &st,
                                                   const float (&areg)[DIM / 2], const float (&ri)[16], int rowbase_wave,
-                                                  int64_t grow0, int K, long long *pf_ext)
+                                                  int64_t grow0, int K, long long *pf_ext, const uint32_t *ulist = nullptr)
 {
 #ifdef ST_PROFILE
     long long pf_t = clock64();
-    long long *pf = pf_ext;
+    long long pf_none[8];
+    long long *pf = pf_ext ? pf_ext : pf_none;
 #endif
     const int lane = threadIdx.x & 63;
     constexpr int NLD = ST_SLAB * DIM / 4 / ST_THREADS;   // float4 loads per thread per slab
@@ -528,19 +554,37 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
     float &stage_r = st.r;
     auto slab_load = [&](int Jl, int slab) {
         const int64_t c0 = (int64_t)Jl * ST_T + slab * ST_SLAB;
+        if constexpr (GATHER) {
+            uint32_t ids[NLD];
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int q = u * ST_THREADS + threadIdx.x;
-            const int colr = q / (DIM / 4), k4 = (q % (DIM / 4)) * 4;
-            stage[u] = *reinterpret_cast<const float4 *>(a.Xs + (size_t)(c0 + colr) * DIM + k4);
+            for (int u = 0; u < NLD; ++u) ids[u] = ulist[c0 + (u * ST_THREADS + threadIdx.x) / (DIM / 4)];
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int q = u * ST_THREADS + threadIdx.x;
+                const int k4 = (q % (DIM / 4)) * 4;
+                const uint32_t src = ids[u] == 0xffffffffu ? 0u : ids[u];
+                stage[u] = *reinterpret_cast<const float4 *>(a.Xs + (size_t)src * DIM + k4);
+            }
+            if (threadIdx.x < ST_SLAB) {
+                const uint32_t id = ulist[c0 + threadIdx.x];
+                st.id = id;
+                stage_r = id == 0xffffffffu ? INFINITY : a.rs[id];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int q = u * ST_THREADS + threadIdx.x;
+                const int colr = q / (DIM / 4), k4 = (q % (DIM / 4)) * 4;
+                stage[u] = *reinterpret_cast<const float4 *>(a.Xs + (size_t)(c0 + colr) * DIM + k4);
+            }
+            if (threadIdx.x < ST_SLAB) stage_r = a.rs[c0 + threadIdx.x];
         }
-        if (threadIdx.x < ST_SLAB) stage_r = a.rs[c0 + threadIdx.x];
     };
     const int col = lane & 31;
     const int rowq = rowbase_wave + 4 * (lane >> 5);   // C layout: row = rowq + (r & 3) + 8 (r >> 2), col = lane & 31
-    const bool self_tile = !a.query && (int64_t)J * ST_T == grow0;
+    const bool self_tile = !GATHER && !a.query && (int64_t)J * ST_T == grow0;
     // merge of a slab's survivors into the sorted per-row lists: lane l < 32 owns row 32 w + l
-    auto merge = [&](int64_t col0) {
+    auto merge = [&](int64_t col0, int par) {
         wave_fence_lds();
         if (lane < 32) {
             const int row = rowbase_wave + lane;
@@ -548,7 +592,17 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
             if (nc) {
                 for (int q = 0; q < nc; ++q) {
                     const float d = sh.cand_d[row][q];
-                    const int32_t cc = (int32_t)(col0 + sh.cand_c[row][q]);
+                    int32_t cc;
+                    if constexpr (GATHER) {
+                        // gathered columns: the point itself and columns the row already lists may come by
+                        cc = (int32_t)sh.slab_id[par][sh.cand_c[row][q]];
+                        bool skip = (int64_t)cc == grow0 + row;
+                        for (int e = 0; e < K && !skip; ++e) skip = sh.list_c[row][e] == cc;
+                        if (skip) continue;
+                        if (d < sh.list_d[row][K - 1] || (d == sh.list_d[row][K - 1] && cc < sh.list_c[row][K - 1])) ++st.ins;
+                    } else {
+                        cc = (int32_t)(col0 + sh.cand_c[row][q]);
+                    }
                     // insertion by (d, col); list is padded with +inf
                     if (d < sh.list_d[row][K - 1] || (d == sh.list_d[row][K - 1] && cc < sh.list_c[row][K - 1])) {
                         int p = K - 1;
@@ -581,7 +635,10 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
             const int colr = q / (DIM / 4), k4 = (q % (DIM / 4)) * 4;
             sh.Bs[colr][k4] = stage[u].x; sh.Bs[colr][k4 + 1] = stage[u].y; sh.Bs[colr][k4 + 2] = stage[u].z; sh.Bs[colr][k4 + 3] = stage[u].w;
         }
-        if (threadIdx.x < ST_SLAB) sh.rsJ[threadIdx.x] = stage_r;
+        if (threadIdx.x < ST_SLAB) {
+            sh.rsJ[threadIdx.x] = stage_r;
+            if constexpr (GATHER) sh.slab_id[slab & 1][threadIdx.x] = st.id;
+        }
         ST_PROF(1)
         __syncthreads();
         ST_PROF(2)
@@ -646,7 +703,7 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
             }
         }
         ST_PROF(4)
-        if (slab > 0) merge((int64_t)J * ST_T + (slab - 1) * ST_SLAB);
+        if (slab > 0) merge((int64_t)J * ST_T + (slab - 1) * ST_SLAB, (slab - 1) & 1);
         ST_PROF(5)
         acc_prev = acc;
         rj_prev = rj;
@@ -684,7 +741,7 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
             }
         }
     }
-    merge((int64_t)J * ST_T + (NSLAB - 1) * ST_SLAB);
+    merge((int64_t)J * ST_T + (NSLAB - 1) * ST_SLAB, (NSLAB - 1) & 1);
     st.J = Jnext;
     // worst k-th squared distance of the row tile (padding rows have thr = -1): wave maxima,
     // one barrier (which is also the operand-buffer hand-over for the next tile)
@@ -753,6 +810,10 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
         thrmax = knn_process_tile<DIM, KMAX>(sh, a, I, -1, st, areg, ri, wave * 32, grow0, K, pf_ptr);
         ++processed;
     }
+    // column tiles this row tile has evaluated (a join pass skips candidates inside them): this
+    // workgroup is the only writer of its bitmap row
+    uint32_t *ebits = a.eval_bits ? a.eval_bits + (size_t)bt * a.eval_words : nullptr;
+    if (ebits && !a.query && threadIdx.x == 0) ebits[I >> 5] |= 1u << (I & 31);
 
     // ---- phase B: all other column tiles.  A tile is ELIGIBLE while its interval bound lb
     // (a valid lower bound of every pair distance) is below the worst k-th distance of the
@@ -890,6 +951,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
 #endif
                 thrmax = knn_process_tile<DIM, KMAX>(sh, a, J, Jn, st, areg, ri, wave * 32, grow0, K, pf_ptr);
                 ++processed;
+                if (ebits && threadIdx.x == 0) ebits[J >> 5] |= 1u << (J & 31);
 #ifdef ST_PROFILE
                 pf_t = clock64();
 #endif
@@ -914,6 +976,308 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
     if (lane == 0 && a.prof)
         for (int i = 0; i < 8; ++i) atomicAdd(a.prof + i, (unsigned long long)pf[i]);
 #endif
+}
+
+
+// ------------------------------------------------------------------ join passes
+// The streamed analogue of update_anchor_points (reference annchor/annchor.py:475-512,
+// utils.py:304-352): there, pairs (i, j) that share an already-computed neighbour c get the bounds
+// |d_ic - d_jc| <= d_ij <= d_ic + d_jc and the next iteration refines the promising ones.  Here the
+// computed neighbours of a row are its current k-NN list, so the pairs with a common computed
+// neighbour are (i, j) with j in list(c), c in list(i): every row TILE collects that set for its
+// 128 rows (minus the columns inside column tiles it has already evaluated), sorts / deduplicates
+// it (k_st_join_cands) and evaluates all 128 x |U| pairs exactly as gathered tile GEMMs
+// (k_st_join) -- the whole candidate set of a tile costs a few dozen tile evaluations.
+#define JN_CAP 8192      // candidate columns per row tile (LDS sort buffer)
+#define JN_B1 8192       // first-hop ids per row tile (128 rows x (K + JN_RK) <= 6144)
+#define JN_RK 15         // reverse neighbours kept per point (the closest by list position)
+#define ANNCHOR_JOIN_YIELD 0.01   // extra join passes run while a pass still replaces more than this share of the list entries
+
+// ascending bitonic sort of P (a power of two) uint32 keys in LDS by one 256-thread workgroup
+__device__ __forceinline__ void jn_sort(uint32_t *v, int P)
+{
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += ST_THREADS) {
+                const int q = ((t & ~(j2 - 1)) << 1) | (t & (j2 - 1));   // element with bit j2 clear
+                const int p2 = q | j2;
+                const uint32_t x = v[q], y = v[p2];
+                const bool up = (q & k2) == 0;
+                if ((x > y) == up) { v[q] = y; v[p2] = x; }
+            }
+            __syncthreads();
+        }
+}
+
+// in-place compaction of the distinct keys != 0xffffffff of a sorted array; returns their number
+// (uniform).  Every thread owns a contiguous run, reads it to registers, then writes behind a
+// workgroup scan of the run counts.
+// cnt_out != NULL: also the multiplicity of every distinct key (run length in the sorted input), same order
+template <int PER> __device__ __forceinline__ int jn_unique(uint32_t *v, int P, uint32_t *wsum /*[5]*/, uint32_t *cnt_out = nullptr)
+{
+    const int per = P / ST_THREADS;   // <= PER
+    const int b = threadIdx.x * per;
+    uint32_t r[PER];
+    uint16_t rc[PER];
+    uint32_t prev = b > 0 ? v[b - 1] : 0xffffffffu;
+    int mine = 0;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        uint32_t x = 0xffffffffu;
+        if (e < per) x = v[b + e];
+        const bool keep = e < per && x != 0xffffffffu && (x != prev || (b + e) == 0);
+        r[e] = keep ? x : 0xffffffffu;
+        rc[e] = 0;
+        if (keep && cnt_out) {   // end of the run: first position > b + e whose key differs (binary search, input still intact)
+            int lo = b + e + 1, hi = P;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (v[mid] == x) lo = mid + 1; else hi = mid; }
+            rc[e] = (uint16_t)min(lo - (b + e), 65535);
+        }
+        mine += keep;
+        if (e < per) prev = x;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int up = __shfl_up(inc, off); if (lane >= off) inc += up; }
+    __syncthreads();   // every run is in registers
+    if (lane == 63) wsum[wave] = (uint32_t)inc;
+    __syncthreads();
+    int base = inc - mine, tot = 0;
+    for (int w2 = 0; w2 < ST_THREADS / 64; ++w2) { if (w2 < wave) base += (int)wsum[w2]; tot += (int)wsum[w2]; }
+#pragma unroll
+    for (int e = 0; e < PER; ++e)
+        if (r[e] != 0xffffffffu) {
+            if (cnt_out) cnt_out[base] = rc[e];
+            v[base++] = r[e];
+        }
+    __syncthreads();
+    return tot;
+}
+
+// ascending bitonic sort of P (a power of two) 64-bit keys in LDS
+__device__ __forceinline__ void jn_sort64(unsigned long long *v, int P)
+{
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += ST_THREADS) {
+                const int q = ((t & ~(j2 - 1)) << 1) | (t & (j2 - 1));
+                const int p2 = q | j2;
+                const unsigned long long x = v[q], y = v[p2];
+                const bool up = (q & k2) == 0;
+                if ((x > y) == up) { v[q] = y; v[p2] = x; }
+            }
+            __syncthreads();
+        }
+}
+
+// ---- reverse neighbour lists: rev[c] = the (at most JN_RK) rows that list c, those that rank it
+// highest first (key = position in the lister's list, then the lister's index: deterministic)
+__global__ void k_st_rev_count(const int32_t *__restrict__ lists_all, int64_t n_edges, int32_t *__restrict__ cnt)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_edges) return;
+    const int32_t dst = lists_all[t];
+    if (dst != 0x7fffffff) atomicAdd(&cnt[dst], 1);
+}
+
+__global__ void k_st_rev_fill(const int32_t *__restrict__ lists_all, int64_t n_edges, int K, const int64_t *__restrict__ ptr,
+                              int32_t *__restrict__ cursor, unsigned long long *__restrict__ edges)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_edges) return;
+    const int32_t dst = lists_all[t];
+    if (dst == 0x7fffffff) return;
+    const int64_t src = t / K;
+    const int e = (int)(t - src * K);
+    const int pos = atomicAdd(&cursor[dst], 1);
+    edges[ptr[dst] + pos] = ((unsigned long long)e << 32) | (unsigned long long)src;
+}
+
+__global__ void k_st_rev_select(const int64_t *__restrict__ ptr, const unsigned long long *__restrict__ edges, int64_t n_all,
+                                int32_t *__restrict__ rev)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_all) return;
+    const int64_t b = ptr[c], e = ptr[c + 1];
+    unsigned long long last = 0;
+    bool first = true;
+    for (int r = 0; r < JN_RK; ++r) {
+        unsigned long long best = ~0ull;
+        for (int64_t q = b; q < e; ++q) {
+            const unsigned long long kq = edges[q];
+            if ((first || kq > last) && kq < best) best = kq;
+        }
+        rev[c * JN_RK + r] = best == ~0ull ? 0x7fffffff : (int32_t)(best & 0xffffffffull);
+        if (best == ~0ull) { for (int r2 = r + 1; r2 < JN_RK; ++r2) rev[c * JN_RK + r2] = 0x7fffffff; break; }
+        last = best;
+        first = false;
+    }
+}
+
+// Candidate columns of one row tile: first hop = the current neighbours and reverse neighbours of
+// its 128 rows; second hop = their neighbours and reverse neighbours (and the first hop itself),
+// minus everything inside column tiles this row tile has already evaluated; sorted, distinct.
+__global__ __launch_bounds__(ST_THREADS) void k_st_join_cands(const int32_t *__restrict__ lists_all, const int32_t *__restrict__ rev,
+                                                             int K, int tile_begin, const uint32_t *__restrict__ eval_bits,
+                                                             int eval_words, int max_cols, uint32_t *__restrict__ ucand,
+                                                             int32_t *__restrict__ ucount)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char jsm[];
+    uint32_t *buf = reinterpret_cast<uint32_t *>(jsm);   // [JN_CAP]
+    uint32_t *b1 = buf + JN_CAP;                         // [JN_B1]
+    uint32_t *wsum = b1 + JN_B1;                         // [8]
+    __shared__ int nsurv_s;
+    const int bt = blockIdx.x, I = tile_begin + bt;
+    const int64_t grow0 = (int64_t)I * ST_T;
+    const int KK = K + (rev ? JN_RK : 0);
+    auto base_of = [&](uint32_t c, int e) -> int32_t {
+        return e < K ? lists_all[(size_t)c * K + e] : rev[(size_t)c * JN_RK + (e - K)];
+    };
+    // ---- first hop
+    const int n0 = ST_T * KK;
+    int P0 = 256;
+    while (P0 < n0) P0 <<= 1;
+    for (int t = threadIdx.x; t < P0; t += ST_THREADS) {
+        int32_t id = 0x7fffffff;
+        if (t < n0) id = base_of((uint32_t)(grow0 + t / KK), t % KK);
+        b1[t] = id == 0x7fffffff ? 0xffffffffu : (uint32_t)id;
+    }
+    __syncthreads();
+    jn_sort(b1, P0);
+    int n1 = jn_unique<JN_B1 / ST_THREADS>(b1, P0, wsum);
+    // ---- second hop, filtered, appended in any order (sorted below)
+    const uint32_t *eb = eval_bits + (size_t)bt * eval_words;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (threadIdx.x == 0) nsurv_s = 0;
+        __syncthreads();
+        const int n2 = n1 * (KK + 1);
+        for (int t = threadIdx.x; t < n2; t += ST_THREADS) {
+            const uint32_t c = b1[t / (KK + 1)];
+            const int e = t % (KK + 1);
+            const int32_t id = e == KK ? (int32_t)c : base_of(c, e);
+            if (id != 0x7fffffff) {
+                const int J = id >> 7;   // ST_T = 128
+                if (!((eb[J >> 5] >> (J & 31)) & 1u)) {
+                    const int pos = atomicAdd(&nsurv_s, 1);
+                    if (pos < JN_CAP) buf[pos] = (uint32_t)id;
+                }
+            }
+        }
+        __syncthreads();
+        if (nsurv_s <= JN_CAP) break;
+        n1 = JN_CAP / (KK + 1);   // overflow (which entries an atomic append drops is arbitrary): keep a prefix that always fits
+        __syncthreads();
+    }
+    const int ns = min(nsurv_s, JN_CAP);
+    int P = 256;
+    while (P < ns) P <<= 1;
+    for (int t = ns + threadIdx.x; t < P; t += ST_THREADS) buf[t] = 0xffffffffu;
+    __syncthreads();
+    jn_sort(buf, P);
+    int nu = jn_unique<JN_CAP / ST_THREADS>(buf, P, wsum, b1);   // b1 (free by now) receives the multiplicities
+    if (nu > max_cols) {
+        // More candidates than this pass may evaluate: keep the max_cols reached over the most
+        // two-hop paths from the tile's rows (the tile analogue of ranking pairs by their
+        // probability and refining the top of the list, annchor.py:444-457), ties to the smaller index.
+        constexpr int PER64 = JN_CAP / ST_THREADS;
+        uint32_t ids[PER64], cn[PER64];
+#pragma unroll
+        for (int e = 0; e < PER64; ++e) {
+            const int t = e * ST_THREADS + threadIdx.x;
+            ids[e] = t < nu ? buf[t] : 0xffffffffu;
+            cn[e] = t < nu ? b1[t] : 0u;
+        }
+        __syncthreads();
+        unsigned long long *k64 = reinterpret_cast<unsigned long long *>(jsm);   // [JN_CAP] over buf + b1
+        int P64 = 256;
+        while (P64 < nu) P64 <<= 1;
+#pragma unroll
+        for (int e = 0; e < PER64; ++e) {
+            const int t = e * ST_THREADS + threadIdx.x;
+            if (t < P64) k64[t] = t < nu ? ((unsigned long long)(0xffffffffu - cn[e]) << 32) | ids[e] : ~0ull;
+        }
+        __syncthreads();
+        jn_sort64(k64, P64);
+        uint32_t keep[PER64];
+#pragma unroll
+        for (int e = 0; e < PER64; ++e) {
+            const int t = e * ST_THREADS + threadIdx.x;
+            keep[e] = t < max_cols ? (uint32_t)(k64[t] & 0xffffffffull) : 0xffffffffu;
+        }
+        __syncthreads();
+        int P2 = 256;
+        while (P2 < max_cols) P2 <<= 1;
+#pragma unroll
+        for (int e = 0; e < PER64; ++e) {
+            const int t = e * ST_THREADS + threadIdx.x;
+            if (t < P2) buf[t] = keep[e];
+        }
+        __syncthreads();
+        jn_sort(buf, P2);   // back to index order (row gathers of neighbouring indices share pages)
+        nu = max_cols;
+    }
+    const int padded = (nu + ST_T - 1) / ST_T * ST_T;
+    uint32_t *dst = ucand + (size_t)bt * JN_CAP;
+    for (int t = threadIdx.x; t < padded; t += ST_THREADS) dst[t] = t < nu ? buf[t] : 0xffffffffu;
+    if (threadIdx.x == 0) ucount[bt] = nu;
+}
+
+template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 128 ? 2 : 1)) void k_st_join(KnnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    KnnShared<DIM, KMAX> &sh = *reinterpret_cast<KnnShared<DIM, KMAX> *>(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int bt;
+    {
+        const int nb_ = gridDim.x, q = nb_ >> 3, r = nb_ & 7, x = blockIdx.x & 7, y = blockIdx.x >> 3;
+        bt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int I = a.tile_begin + bt;
+    const int64_t grow0 = (int64_t)I * ST_T;
+    const int K = a.K;
+    float areg[DIM / 2];
+    {
+        const float *xr = a.Rs + (size_t)(grow0 + wave * 32 + (lane & 31)) * DIM + (lane >> 5);
+#pragma unroll
+        for (int s = 0; s < DIM / 2; ++s) areg[s] = xr[2 * s];
+    }
+    float ri[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ri[r] = a.rr[grow0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+    // the lists as the previous phase left them
+    for (int q = threadIdx.x; q < ST_T * KMAX; q += ST_THREADS) {
+        const int row = q / KMAX, e = q - row * KMAX;
+        sh.list_d[row][e] = e < K ? a.out_d2[((size_t)bt * ST_T + row) * K + e] : INFINITY;
+        sh.list_c[row][e] = e < K ? a.lists_all[((size_t)grow0 + row) * K + e] : 0x7fffffff;
+    }
+    __syncthreads();
+    if (threadIdx.x < ST_T) {
+        const int row = threadIdx.x;
+        const bool real = a.rr[grow0 + row] < INFINITY;
+        sh.thr[row] = real ? sh.list_d[row][K - 1] : -1.f;
+        sh.cnt[row] = 0;
+    }
+    const int nu = a.ucount[bt];
+    const int nchunks = (nu + ST_T - 1) / ST_T;
+    const uint32_t *ulist = a.ucand + (size_t)bt * a.ucap;
+    SlabStage<DIM> st;
+    st.J = -1;
+    st.ins = 0;
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch)
+        knn_process_tile<DIM, KMAX, true>(sh, a, ch, ch + 1 < nchunks ? ch + 1 : -1, st, areg, ri, wave * 32, grow0, K, nullptr, ulist);
+    __syncthreads();
+    for (int q = threadIdx.x; q < ST_T * K; q += ST_THREADS) {
+        const int row = q / K, e = q - row * K;
+        a.out_d2_new[((size_t)bt * ST_T + row) * K + e] = sh.list_d[row][e];
+        a.out_col_new[((size_t)bt * ST_T + row) * K + e] = sh.list_c[row][e];
+    }
+    if (threadIdx.x == 0) atomicAdd(a.evals, (unsigned long long)nchunks);
+    int ins = st.ins;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ins += __shfl_xor(ins, off);
+    if (lane == 0 && ins) atomicAdd(a.updates, (unsigned long long)ins);
 }
 
 // exact float32 distances of the selected neighbours + final per-row ordering
@@ -991,34 +1355,71 @@ __global__ void k_st_emit_query(const int64_t *__restrict__ perm_q, int64_t rows
     odist[g * K + e] = (double)dist[t];
 }
 
-template <int DIM, int KMAX> static int launch_knn2(annchor_ctx *c, const KnnArgs &a)
+template <int DIM, int KMAX> static int launch_knn2(annchor_ctx *c, const KnnArgs &a, bool join)
 {
     const size_t lds = sizeof(KnnShared<DIM, KMAX>);
     ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "streamed k-NN needs %zu B of LDS", lds);
-    ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knn<DIM, KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_st_knn<DIM, KMAX><<<a.tile_count, ST_THREADS, lds, c->stream>>>(a);
+    if (join) {
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_join<DIM, KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_st_join<DIM, KMAX><<<a.tile_count, ST_THREADS, lds, c->stream>>>(a);
+    } else {
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knn<DIM, KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_st_knn<DIM, KMAX><<<a.tile_count, ST_THREADS, lds, c->stream>>>(a);
+    }
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
 }
 
-template <int DIM> static int launch_knn(annchor_ctx *c, const KnnArgs &a)
+template <int DIM> static int launch_knn(annchor_ctx *c, const KnnArgs &a, bool join)
 {
-    return a.K <= 16 ? launch_knn2<DIM, 16>(c, a) : launch_knn2<DIM, ST_KMAX>(c, a);
+    return a.K <= 16 ? launch_knn2<DIM, 16>(c, a, join) : launch_knn2<DIM, ST_KMAX>(c, a, join);
 }
 
-// k nearest neighbours (self included as column 0, like get_ann of annchor.py:514-530) of
-// the row tiles [tile_begin, tile_begin + tile_count) against ALL column tiles.  The five
-// array arguments are DEVICE pointers laid out as annchor_stream_order produces them
-// (concatenated over ranks for multi-GPU runs).  Outputs are HOST arrays:
-// ng_idx int64 [rows, k] (global ids), ng_dist float64 [rows, k], in tile order;
-// row_ids int64 [rows] gives the global id of each output row (-1 = padding row).
-// With row_ids == NULL the outputs are instead [n_local, k] arrays in the bound shard's own row
-// order (row = global id - global_base of annchor_stream_bind), written by a device kernel and
-// copied out in one piece -- no host-side reordering.
-// shared by the graph build (rows = a range of the column tiles) and by queries (rows = the
-// context's own ordered query tiles): launch, exact distances of the kept neighbours, row order
-static int knn_run(annchor_ctx *c, StreamState *s, KnnArgs &a, const void *perm_all, int dim_padded, double p_work,
-                   int64_t **d_idx_out, float **d_dist_out, int64_t *tile_evals)
+static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool join)
+{
+    switch (dim_padded) {
+    case 32: return launch_knn<32>(c, a, join);
+    case 64: return launch_knn<64>(c, a, join);
+    case 128: return launch_knn<128>(c, a, join);
+    case 256: return launch_knn<256>(c, a, join);
+    default: ann_set_err(c, "unsupported padded dim %d", dim_padded); return ANNCHOR_ELIMIT;
+    }
+}
+
+// The p_work budget of one row tile -- ceil(p_work * n_tiles) tile evaluations, the streamed
+// form's share of ITS brute force (n_tiles per row tile) -- split between the tile phase and the
+// join passes: every pass may evaluate up to per_pass runs of 128 gathered columns (an eighth of
+// the budget, at most 24), the tile phase gets the rest.
+extern "C" int annchor_stream_budget(int32_t n_tiles, double p_work, int32_t join_passes, int32_t *total, int32_t *tile_phase,
+                                     int32_t *per_pass)
+{
+    if (n_tiles < 1 || join_passes < 0 || !total || !tile_phase || !per_pass) return ANNCHOR_EINVAL;
+    const double mt = p_work >= 1.0 ? (double)n_tiles : std::ceil(p_work * (double)n_tiles);
+    const int T = (int)std::max(1.0, std::min(mt, (double)n_tiles));
+    static const int div_ = getenv("ANNCHOR_JOIN_DIV") ? atoi(getenv("ANNCHOR_JOIN_DIV")) : 8;
+    int pp = std::min(24, std::max(1, T / div_));
+    if (join_passes == 0) pp = 0;
+    int tp = T - pp * join_passes;
+    if (tp < 1) tp = 1;
+    if (T >= n_tiles) tp = n_tiles;   // the full budget evaluates every tile: nothing is left to join
+    *total = T; *tile_phase = tp; *per_pass = pp;
+    return ANNCHOR_OK;
+}
+
+static void ann_stream_free_run(StreamState *s)
+{
+    delete s->run;
+    s->run = nullptr;
+}
+
+// The graph build of row tiles [tile_begin, tile_begin + tile_count) against ALL column tiles runs
+// in three steps shared by the one-call form (annchor_stream_knn), the multi-rank form
+// (annchor_stream_knn_begin / _join / _end: the ranks all-gather their lists between the steps)
+// and queries:
+//   knn_tile_phase  budgeted tile evaluation (k_st_knn); the lists stay on the device
+//   knn_join_pass   one pass over the neighbours' neighbours (k_st_join_cands + k_st_join)
+//   knn_finish      exact float32 distances of the kept neighbours, final order, ids
+static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_padded, int tile_budget, bool record_tiles)
 {
     const int K = a.K;
     const int64_t rows = (int64_t)a.tile_count * ST_T;
@@ -1026,13 +1427,22 @@ static int knn_run(annchor_ctx *c, StreamState *s, KnnArgs &a, const void *perm_
     ANN_TRY(sreserve(c, s->out_col, sizeof(int32_t) * (size_t)rows * K));
     ANN_TRY(sreserve(c, s->evals, 64));
     ANN_CHECK_HIP(c, hipMemsetAsync(s->evals.p, 0, 8, c->stream));
-    double mt = p_work >= 1.0 ? (double)a.nt_all : std::ceil(p_work * (double)a.nt_all);
-    a.max_tiles = (int)std::max(1.0, std::min(mt, (double)a.nt_all));
+    a.max_tiles = std::max(1, std::min(tile_budget, a.nt_all));
     a.out_d2 = s->out_d2.as<float>(); a.out_col = s->out_col.as<int32_t>();
     ANN_TRY(sreserve(c, s->scr_key, sizeof(float) * (size_t)a.tile_count * (size_t)a.nt_all));
     ANN_TRY(sreserve(c, s->scr_lb, sizeof(float) * (size_t)a.tile_count * (size_t)a.nt_all));
     a.scr_key = s->scr_key.as<float>(); a.scr_lb = s->scr_lb.as<float>();
     a.evals = s->evals.as<unsigned long long>();
+    a.eval_bits = nullptr;
+    a.eval_words = (a.nt_all + 31) / 32;
+    if (record_tiles) {
+        const size_t nb = sizeof(uint32_t) * (size_t)a.tile_count * a.eval_words;
+        ANN_TRY(sreserve(c, s->eval_bits, nb));
+        ANN_CHECK_HIP(c, hipMemsetAsync(s->eval_bits.p, 0, nb, c->stream));
+        a.eval_bits = s->eval_bits.as<uint32_t>();
+    }
+    a.lists_all = nullptr; a.ucand = nullptr; a.ucount = nullptr; a.ucap = JN_CAP; a.out_d2_new = nullptr; a.out_col_new = nullptr;
+    a.updates = nullptr;
     a.prof = nullptr;
 #ifdef ST_PROFILE
     static unsigned long long *d_prof = nullptr;
@@ -1044,16 +1454,89 @@ static int knn_run(annchor_ctx *c, StreamState *s, KnnArgs &a, const void *perm_
     {
         // algorithmic flops are data dependent (tiles that survive the bound): reported by the caller from tile_evals
         ProfScope ps(c, "stream_tile_gemm_topk", 0.0);
-        switch (dim_padded) {
-        case 32: ANN_TRY(launch_knn<32>(c, a)); break;
-        case 64: ANN_TRY(launch_knn<64>(c, a)); break;
-        case 128: ANN_TRY(launch_knn<128>(c, a)); break;
-        case 256: ANN_TRY(launch_knn<256>(c, a)); break;
-        default: ann_set_err(c, "unsupported padded dim %d", dim_padded); return ANNCHOR_ELIMIT;
-        }
+        ANN_TRY(launch_by_dim(c, a, dim_padded, false));
     }
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;
+#ifdef ST_PROFILE
+    {
+        unsigned long long hp[8];
+        ANN_TRY(ann_d2h(c, hp, a.prof, 64));
+        static const char *names[8] = {"barrier before stash", "stash (incl. global-load wait)", "barrier after stash",
+                                       "MFMA stream + thresholds", "survivor inserts", "merge", "tile end", "candidate scan + rest"};
+        double tot = 0;
+        for (int i = 0; i < 8; ++i) tot += (double)hp[i];
+        for (int i = 0; i < 8; ++i) fprintf(stderr, "[st-prof] %-32s %6.2f %%\n", names[i], 100.0 * (double)hp[i] / tot);
+    }
+#endif
+    return ANNCHOR_OK;
+}
+
+// lists_all: current lists of every ordered row of every rank, int32 [n_all][K] (single rank: the
+// context's own list buffer).  The new lists replace the context's own (a.out_col / a.out_d2).
+static int knn_join_pass(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_padded, const int32_t *lists_all, int per_pass,
+                         int64_t *updates)
+{
+    const int K = a.K;
+    const int64_t rows = (int64_t)a.tile_count * ST_T;
+    const int64_t n_all = (int64_t)a.nt_all * ST_T;
+    ANN_REQUIRE(c, a.eval_bits != nullptr, ANNCHOR_ESTATE, "join pass without a recorded tile phase");
+    ANN_TRY(sreserve(c, s->ucand, sizeof(uint32_t) * (size_t)a.tile_count * JN_CAP));
+    ANN_TRY(sreserve(c, s->ucount, sizeof(int32_t) * (size_t)a.tile_count));
+    const bool to_b = a.out_col == s->out_col.as<int32_t>();
+    DevBuf &nd = to_b ? s->out_d2b : s->out_d2, &nc = to_b ? s->out_colb : s->out_col;
+    ANN_TRY(sreserve(c, nd, sizeof(float) * (size_t)rows * K));
+    ANN_TRY(sreserve(c, nc, sizeof(int32_t) * (size_t)rows * K));
+    a.lists_all = lists_all;
+    a.ucand = s->ucand.as<uint32_t>(); a.ucount = s->ucount.as<int32_t>(); a.ucap = JN_CAP;
+    a.out_d2_new = nd.as<float>(); a.out_col_new = nc.as<int32_t>();
+    {
+        // reverse lists of every ordered row: count, scan, fill, select (the lists are short: K on average)
+        ProfScope ps(c, "stream_join_reverse_lists", (double)n_all * K * 24.0);
+        const int64_t n_edges = n_all * K;
+        ANN_TRY(sreserve(c, s->rev_cnt, sizeof(int32_t) * (size_t)(n_all + 1)));
+        ANN_TRY(sreserve(c, s->rev_ptr, sizeof(int64_t) * (size_t)(n_all + 1)));
+        ANN_TRY(sreserve(c, s->rev_edges, sizeof(unsigned long long) * (size_t)n_edges));
+        ANN_TRY(sreserve(c, s->rev, sizeof(int32_t) * (size_t)n_all * JN_RK));
+        ANN_CHECK_HIP(c, hipMemsetAsync(s->rev_cnt.p, 0, sizeof(int32_t) * (size_t)(n_all + 1), c->stream));
+        k_st_rev_count<<<ann_blocks(n_edges, 256), 256, 0, c->stream>>>(lists_all, n_edges, s->rev_cnt.as<int32_t>());
+        ANN_TRY(ann_exclusive_scan_i32_to_i64(c, s->rev_cnt.as<int32_t>(), s->rev_ptr.as<int64_t>(), n_all));   // ptr has n_all + 1 entries
+        ANN_CHECK_HIP(c, hipMemsetAsync(s->rev_cnt.p, 0, sizeof(int32_t) * (size_t)(n_all + 1), c->stream));
+        k_st_rev_fill<<<ann_blocks(n_edges, 256), 256, 0, c->stream>>>(lists_all, n_edges, K, s->rev_ptr.as<int64_t>(),
+                                                                      s->rev_cnt.as<int32_t>(), s->rev_edges.as<unsigned long long>());
+        k_st_rev_select<<<ann_blocks(n_all, 256), 256, 0, c->stream>>>(s->rev_ptr.as<int64_t>(), s->rev_edges.as<unsigned long long>(),
+                                                                      n_all, s->rev.as<int32_t>());
+    }
+    {
+        ProfScope ps(c, "stream_join_candidates", (double)rows * (K + JN_RK) * 4.0 * (K + JN_RK + 1));
+        const size_t lds = sizeof(uint32_t) * (JN_CAP + JN_B1 + 8);
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_join_cands, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int max_cols = std::max(1, std::min(per_pass * ST_T, JN_CAP));
+        k_st_join_cands<<<a.tile_count, ST_THREADS, lds, c->stream>>>(lists_all, s->rev.as<int32_t>(), K, a.tile_begin, a.eval_bits,
+                                                                      a.eval_words, max_cols, s->ucand.as<uint32_t>(),
+                                                                      s->ucount.as<int32_t>());
+    }
+    a.updates = s->evals.as<unsigned long long>() + 1;
+    ANN_CHECK_HIP(c, hipMemsetAsync(a.updates, 0, 8, c->stream));
+    {
+        ProfScope ps(c, "stream_join_gemm_topk", 0.0);
+        ANN_TRY(launch_by_dim(c, a, dim_padded, true));
+    }
+    ANN_CHECK_HIP(c, hipGetLastError());
+    a.out_d2 = a.out_d2_new; a.out_col = a.out_col_new;
+    if (updates) {
+        unsigned long long u = 0;
+        ANN_TRY(ann_d2h(c, &u, a.updates, 8));
+        *updates = (int64_t)u;
+    }
+    return ANNCHOR_OK;
+}
+
+static int knn_finish(annchor_ctx *c, StreamState *s, KnnArgs &a, const void *perm_all, int dim_padded, int64_t **d_idx_out,
+                      float **d_dist_out, int64_t *tile_evals)
+{
+    const int K = a.K;
+    const int64_t rows = (int64_t)a.tile_count * ST_T;
     // exact distances of the selected neighbours, final order, ids
     ANN_TRY(sreserve(c, s->keys, sizeof(int64_t) * (size_t)rows * K));   // reuse: ids
     ANN_TRY(sreserve(c, s->keys2, sizeof(float) * (size_t)rows * K));    // reuse: distances
@@ -1074,46 +1557,19 @@ static int knn_run(annchor_ctx *c, StreamState *s, KnnArgs &a, const void *perm_
         ANN_TRY(ann_d2h(c, &ev, s->evals.p, 8));
         *tile_evals = (int64_t)ev;
     }
-#ifdef ST_PROFILE
-    {
-        unsigned long long hp[8];
-        ANN_TRY(ann_d2h(c, hp, a.prof, 64));
-        static const char *names[8] = {"barrier before stash", "stash (incl. global-load wait)", "barrier after stash",
-                                       "MFMA stream + thresholds", "survivor inserts", "merge", "tile end", "candidate scan + rest"};
-        double tot = 0;
-        for (int i = 0; i < 8; ++i) tot += (double)hp[i];
-        for (int i = 0; i < 8; ++i) fprintf(stderr, "[st-prof] %-32s %6.2f %%\n", names[i], 100.0 * (double)hp[i] / tot);
-    }
-#endif
     return ANNCHOR_OK;
 }
 
-extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void *rs_all, const void *perm_all,
-                                  const void *lo_all, const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors,
-                                  int32_t dim_padded, int32_t tile_begin, int32_t tile_count, int32_t k, double p_work,
-                                  int64_t *row_ids, int64_t *ng_idx, double *ng_dist, int64_t *tile_evals)
+static int knn_download_graph(annchor_ctx *c, StreamState *s, const KnnArgs &a, const void *perm_all, int64_t *d_idx, float *d_dist,
+                              int64_t *row_ids, int64_t *ng_idx, double *ng_dist)
 {
-    if (!c || !Xs_all || !rs_all || !perm_all || !lo_all || !hi_all || !mid_all || !ng_idx || !ng_dist) return ANNCHOR_EINVAL;
-    ANN_REQUIRE(c, k >= 2 && k - 1 <= ST_KMAX, ANNCHOR_ELIMIT, "streamed form supports 2 <= n_neighbors <= %d", ST_KMAX + 1);
-    ANN_REQUIRE(c, n_all == (int64_t)nt_all * ST_T && tile_begin >= 0 && tile_begin + tile_count <= nt_all, ANNCHOR_EINVAL,
-                "tile range out of bounds");
-    ANN_REQUIRE(c, n_all < (1ll << 31), ANNCHOR_ELIMIT, "n_all exceeds 2^31");
-    ANN_CHECK_HIP(c, hipSetDevice(c->device));
-    StreamState *s = state_of(c, true);
-    const int K = k - 1;
-    const int64_t rows = (int64_t)tile_count * ST_T;
-    KnnArgs a;
-    a.Xs = (const float *)Xs_all; a.rs = (const float *)rs_all; a.lo = (const float *)lo_all; a.hi = (const float *)hi_all; a.mid = (const float *)mid_all;
-    a.Rs = a.Xs; a.rr = a.rs; a.rlo = a.lo; a.rhi = a.hi; a.rmid = a.mid; a.nt_r = nt_all; a.query = 0;
-    a.nt_all = nt_all; a.na = n_anchors; a.tile_begin = tile_begin; a.tile_count = tile_count; a.K = K;
-    int64_t *d_idx = nullptr;
-    float *d_dist = nullptr;
-    ANN_TRY(knn_run(c, s, a, perm_all, dim_padded, p_work, &d_idx, &d_dist, tile_evals));
+    const int K = a.K, k = K + 1;
+    const int64_t rows = (int64_t)a.tile_count * ST_T;
     if (!row_ids) {
         const int64_t n_local = s->n_local;
         ANN_TRY(sreserve(c, s->emit_idx, sizeof(int64_t) * (size_t)n_local * k));
         ANN_TRY(sreserve(c, s->emit_dist, sizeof(double) * (size_t)n_local * k));
-        k_st_emit<<<ann_blocks(rows * k, 256), 256, 0, c->stream>>>((const int64_t *)perm_all, (int64_t)tile_begin * ST_T, rows, K, s->base,
+        k_st_emit<<<ann_blocks(rows * k, 256), 256, 0, c->stream>>>((const int64_t *)perm_all, (int64_t)a.tile_begin * ST_T, rows, K, s->base,
                                                                    n_local, d_idx, d_dist, s->emit_idx.as<int64_t>(),
                                                                    s->emit_dist.as<double>());
         ANN_CHECK_HIP(c, hipGetLastError());
@@ -1124,7 +1580,7 @@ extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void
         std::vector<float> hd((size_t)rows * K);
         ANN_TRY(ann_d2h(c, hidx.data(), d_idx, sizeof(int64_t) * hidx.size()));
         ANN_TRY(ann_d2h(c, hd.data(), d_dist, sizeof(float) * hd.size()));
-        ANN_TRY(ann_d2h(c, row_ids, (const int64_t *)perm_all + (size_t)tile_begin * ST_T, sizeof(int64_t) * (size_t)rows));
+        ANN_TRY(ann_d2h(c, row_ids, (const int64_t *)perm_all + (size_t)a.tile_begin * ST_T, sizeof(int64_t) * (size_t)rows));
         for (int64_t r = 0; r < rows; ++r) {
             ng_idx[r * k] = row_ids[r];
             ng_dist[r * k] = 0.0;
@@ -1135,6 +1591,115 @@ extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void
         }
     }
     return ANNCHOR_OK;
+}
+
+static int knn_args_graph(annchor_ctx *c, KnnArgs &a, const void *Xs_all, const void *rs_all, const void *lo_all, const void *hi_all,
+                          const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors, int32_t tile_begin,
+                          int32_t tile_count, int32_t k)
+{
+    ANN_REQUIRE(c, k >= 2 && k - 1 <= ST_KMAX, ANNCHOR_ELIMIT, "streamed form supports 2 <= n_neighbors <= %d", ST_KMAX + 1);
+    ANN_REQUIRE(c, n_all == (int64_t)nt_all * ST_T && tile_begin >= 0 && tile_begin + tile_count <= nt_all, ANNCHOR_EINVAL,
+                "tile range out of bounds");
+    ANN_REQUIRE(c, n_all < (1ll << 31), ANNCHOR_ELIMIT, "n_all exceeds 2^31");
+    a.Xs = (const float *)Xs_all; a.rs = (const float *)rs_all; a.lo = (const float *)lo_all; a.hi = (const float *)hi_all; a.mid = (const float *)mid_all;
+    a.Rs = a.Xs; a.rr = a.rs; a.rlo = a.lo; a.rhi = a.hi; a.rmid = a.mid; a.nt_r = nt_all; a.query = 0;
+    a.nt_all = nt_all; a.na = n_anchors; a.tile_begin = tile_begin; a.tile_count = tile_count; a.K = k - 1;
+    return ANNCHOR_OK;
+}
+
+// k nearest neighbours (self included as column 0, like get_ann of annchor.py:514-530) of
+// the row tiles [tile_begin, tile_begin + tile_count) against ALL column tiles.  The array
+// arguments are DEVICE pointers laid out as annchor_stream_order produces them.  join_passes > 0
+// (only when the launch covers every row tile, i.e. one rank: the passes read every row's list)
+// runs that many neighbour-of-neighbour passes after the tile phase.  Outputs are HOST arrays:
+// ng_idx int64 [rows, k] (global ids), ng_dist float64 [rows, k], in tile order;
+// row_ids int64 [rows] gives the global id of each output row (-1 = padding row).
+// With row_ids == NULL the outputs are instead [n_local, k] arrays in the bound shard's own row
+// order (row = global id - global_base of annchor_stream_bind), written by a device kernel and
+// copied out in one piece -- no host-side reordering.  tile_evals counts 128 x 128 pair blocks
+// (tile phase + join passes).
+extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void *rs_all, const void *perm_all,
+                                  const void *lo_all, const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors,
+                                  int32_t dim_padded, int32_t tile_begin, int32_t tile_count, int32_t k, double p_work,
+                                  int32_t join_passes, int32_t join_extra, int64_t *row_ids, int64_t *ng_idx, double *ng_dist,
+                                  int64_t *tile_evals)
+{
+    if (!c || !Xs_all || !rs_all || !perm_all || !lo_all || !hi_all || !mid_all || !ng_idx || !ng_dist) return ANNCHOR_EINVAL;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    StreamState *s = state_of(c, true);
+    KnnArgs a;
+    ANN_TRY(knn_args_graph(c, a, Xs_all, rs_all, lo_all, hi_all, mid_all, n_all, nt_all, n_anchors, tile_begin, tile_count, k));
+    ANN_REQUIRE(c, join_passes >= 0 && join_extra >= 0 && (join_passes + join_extra == 0 || tile_count == nt_all), ANNCHOR_EINVAL,
+                "join passes need every row's list: use annchor_stream_knn_begin / _join / _end across ranks");
+    int T = 0, tp = 0, pp = 0;
+    ANN_TRY(annchor_stream_budget(nt_all, p_work, join_passes, &T, &tp, &pp));
+    ANN_TRY(knn_tile_phase(c, s, a, dim_padded, tp, join_passes + join_extra > 0 && tp < nt_all));
+    // join_passes passes always; up to join_extra more while a pass still replaces more than
+    // ANNCHOR_JOIN_YIELD (1 %) of all list entries and the budget has room for another pass
+    const double floor_updates = ANNCHOR_JOIN_YIELD * (double)tile_count * ST_T * (k - 1);
+    for (int p = 0; tp < nt_all && p < join_passes + join_extra; ++p) {
+        if (p >= join_passes && tp + (p + 1) * std::max(pp, 1) > T) break;
+        int64_t upd = 0;
+        ANN_TRY(knn_join_pass(c, s, a, dim_padded, a.out_col, std::max(pp, 1), &upd));
+        if (p + 1 >= join_passes && (double)upd <= floor_updates) break;
+    }
+    int64_t *d_idx = nullptr;
+    float *d_dist = nullptr;
+    ANN_TRY(knn_finish(c, s, a, perm_all, dim_padded, &d_idx, &d_dist, tile_evals));
+    return knn_download_graph(c, s, a, perm_all, d_idx, d_dist, row_ids, ng_idx, ng_dist);
+}
+
+// The same build in steps, for row-sharded runs: after _begin (tile phase) and after every _join
+// the caller all-gathers the ranks' list buffers (*lists_local: int32 [tile_count * 128][k - 1],
+// device memory, ordered column indices; every rank has the same tile_count) into
+// lists_all [n_all][k - 1] and hands that to the next _join; _end finishes and downloads.
+extern "C" int annchor_stream_knn_begin(annchor_ctx *c, const void *Xs_all, const void *rs_all, const void *perm_all,
+                                        const void *lo_all, const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all,
+                                        int32_t n_anchors, int32_t dim_padded, int32_t tile_begin, int32_t tile_count, int32_t k,
+                                        int32_t tile_budget, void **lists_local, int64_t *lists_bytes)
+{
+    if (!c || !Xs_all || !rs_all || !perm_all || !lo_all || !hi_all || !mid_all || !lists_local || !lists_bytes) return ANNCHOR_EINVAL;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    StreamState *s = state_of(c, true);
+    ann_stream_free_run(s);
+    KnnArgs *a = new KnnArgs();
+    s->run = a;
+    int rc = knn_args_graph(c, *a, Xs_all, rs_all, lo_all, hi_all, mid_all, n_all, nt_all, n_anchors, tile_begin, tile_count, k);
+    if (rc == ANNCHOR_OK) rc = knn_tile_phase(c, s, *a, dim_padded, tile_budget, true);
+    if (rc != ANNCHOR_OK) { ann_stream_free_run(s); return rc; }
+    s->run_perm = perm_all;
+    s->run_dimp = dim_padded;
+    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    *lists_local = a->out_col;
+    *lists_bytes = (int64_t)sizeof(int32_t) * tile_count * ST_T * (k - 1);
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_stream_knn_join(annchor_ctx *c, const void *lists_all, int32_t per_pass, void **lists_local, int64_t *updates)
+{
+    if (!c || !lists_all || !lists_local || !updates) return ANNCHOR_EINVAL;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    StreamState *s = state_of(c, false);
+    ANN_REQUIRE(c, s && s->run, ANNCHOR_ESTATE, "annchor_stream_knn_begin not called");
+    ANN_REQUIRE(c, per_pass >= 1, ANNCHOR_EINVAL, "per_pass must be >= 1");
+    ANN_TRY(knn_join_pass(c, s, *s->run, s->run_dimp, (const int32_t *)lists_all, per_pass, updates));
+    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    *lists_local = s->run->out_col;
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_stream_knn_end(annchor_ctx *c, int64_t *row_ids, int64_t *ng_idx, double *ng_dist, int64_t *tile_evals)
+{
+    if (!c || !ng_idx || !ng_dist) return ANNCHOR_EINVAL;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    StreamState *s = state_of(c, false);
+    ANN_REQUIRE(c, s && s->run, ANNCHOR_ESTATE, "annchor_stream_knn_begin not called");
+    int64_t *d_idx = nullptr;
+    float *d_dist = nullptr;
+    int rc = knn_finish(c, s, *s->run, s->run_perm, s->run_dimp, &d_idx, &d_dist, tile_evals);
+    if (rc == ANNCHOR_OK) rc = knn_download_graph(c, s, *s->run, s->run_perm, d_idx, d_dist, row_ids, ng_idx, ng_dist);
+    ann_stream_free_run(s);
+    return rc;
 }
 
 // Queries against a fitted (ordered) data set: the context holds the QUERY rows -- bound with
@@ -1163,7 +1728,10 @@ extern "C" int annchor_stream_query(annchor_ctx *c, const void *Xs_all, const vo
     a.nt_all = nt_all; a.na = n_anchors; a.tile_begin = 0; a.tile_count = s->nt; a.K = nn;
     int64_t *d_idx = nullptr;
     float *d_dist = nullptr;
-    ANN_TRY(knn_run(c, s, a, perm_all, dim_padded, p_work, &d_idx, &d_dist, tile_evals));
+    int T = 0, tp = 0, pp = 0;
+    ANN_TRY(annchor_stream_budget(nt_all, p_work, 0, &T, &tp, &pp));
+    ANN_TRY(knn_tile_phase(c, s, a, dim_padded, tp, false));
+    ANN_TRY(knn_finish(c, s, a, perm_all, dim_padded, &d_idx, &d_dist, tile_evals));
     const int64_t rows = (int64_t)s->nt * ST_T, nq = s->n_local;
     ANN_TRY(sreserve(c, s->emit_idx, sizeof(int64_t) * (size_t)nq * nn));
     ANN_TRY(sreserve(c, s->emit_dist, sizeof(double) * (size_t)nq * nn));
@@ -1172,6 +1740,31 @@ extern "C" int annchor_stream_query(annchor_ctx *c, const void *Xs_all, const vo
     ANN_CHECK_HIP(c, hipGetLastError());
     ANN_TRY(ann_d2h(c, out_idx, s->emit_idx.p, sizeof(int64_t) * (size_t)nq * nn));
     return ann_d2h(c, out_dist, s->emit_dist.p, sizeof(double) * (size_t)nq * nn);
+}
+
+// interval tables after an all-gather: [world][na][nt] (rank-major, as the collective delivers
+// them) -> [na][world * nt] (the tile axis joined across ranks, as the kernels index them)
+__global__ void k_st_join_tables(const float *__restrict__ src, int world, int na, int nt, float *__restrict__ dst)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)na * nt;
+    if (t >= per * world) return;
+    const int r = (int)(t / per);
+    const int64_t rem = t - (int64_t)r * per;
+    const int a = (int)(rem / nt), j = (int)(rem - (int64_t)a * nt);
+    dst[(size_t)a * world * nt + (size_t)r * nt + j] = src[t];
+}
+
+extern "C" int annchor_stream_join_tables(annchor_ctx *c, const void *gathered, int32_t world, int32_t n_anchors, int32_t n_tiles,
+                                          void *joined)
+{
+    if (!c || !gathered || !joined || world < 1 || n_anchors < 1 || n_tiles < 1) return ANNCHOR_EINVAL;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    const int64_t tot = (int64_t)world * n_anchors * n_tiles;
+    k_st_join_tables<<<ann_blocks(tot, 256), 256, 0, c->stream>>>((const float *)gathered, world, n_anchors, n_tiles, (float *)joined);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    return ANNCHOR_OK;
 }
 
 // ------------------------------------------------ raw device memory for host-staged gathers

@@ -26,14 +26,19 @@ With one rank the collectives are no-ops and no torch import happens.
 import numpy as np
 
 TILE = 128
+MIN_TILE_BUDGET = 64   # tile evaluations per row tile below which p_work is raised (see StreamedAnnchor.__init__)
+JOIN_YIELD = 0.01   # extra join passes run while a pass still replaces more than this share of all list entries
 
 
 # ----------------------------------------------------------------------- comms
+# Everything that crosses ranks on the fit path is a fixed-size numeric buffer: 16 bytes per rank and
+# anchor round (value, index), the anchor's coordinates, the ordered shards / interval tables /
+# neighbour lists (device buffers), the graph shards.  No pickled objects.
 class SingleComm:
     rank, world = 0, 1
 
-    def allgather_obj(self, x):
-        return [x]
+    def allgather_f64(self, values):
+        return np.asarray(values, dtype=np.float64)[None, :]
 
     def bcast_array(self, arr, src, n, dtype):
         return arr
@@ -41,9 +46,12 @@ class SingleComm:
     def allgather_device(self, engine, dptr, nbytes):
         return dptr, None
 
+    def allgather_host(self, arr):
+        return [arr]
+
 
 class TorchComm:
-    """torch.distributed adapter.  `nccl` groups move device buffers directly (RCCL);
+    """torch.distributed adapter.  `nccl` groups (RCCL over xGMI) move device buffers directly;
     any other backend stages through host memory."""
 
     def __init__(self, group=None):
@@ -52,18 +60,23 @@ class TorchComm:
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.backend = dist.get_backend(group)
-        self._keep = []
 
-    def allgather_obj(self, x):
-        out = [None] * self.world
-        self.dist.all_gather_object(out, x, group=self.group)
-        return out
+    def _dev(self):
+        return "cuda" if self.backend == "nccl" else "cpu"
+
+    def allgather_f64(self, values):
+        """[world, len(values)] float64: every rank's small vector (arg-max candidates, shard extents)."""
+        import torch
+
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self._dev())
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t, group=self.group)
+        return torch.stack(parts).cpu().numpy()
 
     def bcast_array(self, arr, src, n, dtype):
         import torch
 
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.empty(n, dtype=getattr(torch, np.dtype(dtype).name), device=dev)
+        t = torch.empty(n, dtype=getattr(torch, np.dtype(dtype).name), device=self._dev())
         if self.rank == src:
             t.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)))
         self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, src) if self.group is not None else src,
@@ -78,7 +91,7 @@ class TorchComm:
         if self.backend == "nccl":
             inp = device_tensor_u8(dptr, nbytes, engine.device)
             out = torch.empty(self.world * nbytes, dtype=torch.uint8, device=inp.device)
-            torch.cuda.synchronize(inp.device)
+            engine.synchronize()                       # the engine's stream produced the buffer
             self.dist.all_gather_into_tensor(out, inp, group=self.group)
             torch.cuda.synchronize(inp.device)
             return out.data_ptr(), out
@@ -90,6 +103,16 @@ class TorchComm:
         out = engine.device_alloc(allh.nbytes)
         engine.device_copy(out, allh.ctypes.data, allh.nbytes, "h2d")
         return out, _DeviceOwner(engine, out)
+
+    def allgather_host(self, arr):
+        """Every rank's equally shaped NumPy array, as a list in rank order (tensor all-gather; the
+        arrays ride through device memory when the group is `nccl`)."""
+        import torch
+
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(self._dev())
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t, group=self.group)
+        return [p.cpu().numpy() for p in parts]
 
 
 class _DeviceOwner:
@@ -144,7 +167,7 @@ class StreamedAnnchor:
     methods -- the CPU tests use a NumPy stand-in to exercise the multi-rank protocol)."""
 
     def __init__(self, X, n_anchors=32, n_neighbors=15, p_work=0.1, random_seed=42, base=0, comm=None, engine=None,
-                 device=0, force_exchange=False):
+                 device=0, force_exchange=False, join_passes=2, join_extra=4):
         self.X = np.ascontiguousarray(X, dtype=np.float32)
         self.n_local, self.dim = self.X.shape
         self.n_anchors, self.n_neighbors, self.p_work = n_anchors, n_neighbors, p_work
@@ -156,11 +179,30 @@ class StreamedAnnchor:
             engine = _native.Engine(device)
         self._engine = engine
         self._engine.stream_bind(self.X, self.base)
-        self.shards = self.comm.allgather_obj((self.base, self.n_local))
+        self.join_passes, self.join_extra = int(join_passes), int(join_extra)
+        ext = self.comm.allgather_f64((self.base, self.n_local))
+        self.shards = [(int(b), int(n)) for b, n in ext]
         self.n_total = int(sum(n for _, n in self.shards))
+        # The budget is spent in whole 128 x 128 tile evaluations: below MIN_TILE_BUDGET of them per row
+        # tile it is too coarse to mean anything, so p_work has a floor -- the same treatment the
+        # reference gives a p_work too small for its anchors and samples (annchor.py:136-142)
+        nt_total = sum((n + TILE - 1) // TILE for _, n in self.shards)
+        floor = min(1.0, MIN_TILE_BUDGET / float(max(nt_total, 1)))
+        if self.p_work < floor:
+            if self.comm.rank == 0:
+                print("Warning: p_work too low for %d tiles of 128 points.\nIncreasing p_work to %5.3f." % (nt_total, floor))
+            self.p_work = floor
         self.evals = 0
         self.timings = {}
         self.force_exchange = force_exchange   # run the all-gather path even with one rank (tests)
+
+    def _budget(self, nt_all):
+        """(total, tile phase, per join pass) tile evaluations per row tile: annchor_stream_budget."""
+        if hasattr(self._engine, "stream_budget"):
+            return self._engine.stream_budget(nt_all, self.p_work, self.join_passes)
+        from . import _native
+
+        return _native.stream_budget(nt_all, self.p_work, self.join_passes)
 
     def get_anchors(self):
         eng, comm, na = self._engine, self.comm, self.n_anchors
@@ -175,7 +217,7 @@ class StreamedAnnchor:
             vec = comm.bcast_array(vec, src, self.dim, np.float32)
             self.anchor_vectors[r] = vec
             lmax, larg = eng.stream_anchor_round(vec, r, na)
-            ix = combine_argmax(comm.allgather_obj((float(lmax), int(self.base + larg))))
+            ix = combine_argmax([(v, int(i)) for v, i in comm.allgather_f64((lmax, self.base + larg))])
         self.A = A
         self.evals += na * self.n_total
 
@@ -196,20 +238,39 @@ class StreamedAnnchor:
             for name, nbytes in sizes.items():
                 allp[name], owner = comm.allgather_device(eng, ptrs[name], nbytes)
                 keep.append(owner)
-            # interval tables [n_anchors, nt] are small: gather on the host, join along the tile axis
+            # interval tables [n_anchors, nt]: gathered rank-major, then joined along the tile axis
+            # ([world][na][nt] -> [na][world * nt]) by a device kernel
+            tab_bytes = self.n_anchors * nt * 4
             for name in ("lo", "hi", "mid"):
-                host = np.empty((self.n_anchors, nt), dtype=np.float32)
-                eng.device_copy(host.ctypes.data, ptrs[name], host.nbytes, "d2h")
-                joined = np.ascontiguousarray(np.concatenate(comm.allgather_obj(host), axis=1))
-                d = eng.device_alloc(joined.nbytes)
-                eng.device_copy(d, joined.ctypes.data, joined.nbytes, "h2d")
+                gathered, owner = comm.allgather_device(eng, ptrs[name], tab_bytes)
+                d = eng.device_alloc(tab_bytes * max(comm.world, 1))
+                eng.stream_join_tables(gathered, max(comm.world, 1), self.n_anchors, nt, d)
                 allp[name] = d
                 keep.append(_DeviceOwner(eng, d))
+                del owner
             ptrs = allp
         t3 = time.perf_counter()
         n_all, nt_all = n_pad * comm.world, nt * comm.world
-        row_ids, idx, dist, tile_evals = eng.stream_knn(ptrs, n_all, nt_all, self.n_anchors, dimp, comm.rank * nt, nt,
-                                                        self.n_neighbors, self.p_work, n_local=self.n_local)
+        if comm.world == 1 and not self.force_exchange:
+            row_ids, idx, dist, tile_evals = eng.stream_knn(ptrs, n_all, nt_all, self.n_anchors, dimp, 0, nt, self.n_neighbors,
+                                                            self.p_work, n_local=self.n_local, join_passes=self.join_passes,
+                                                            join_extra=self.join_extra)
+        else:
+            # row-sharded: tile phase, then join passes against the all-gathered neighbour lists
+            total, tile_budget, per_pass = self._budget(nt_all)
+            lists, nbytes = eng.stream_knn_begin(ptrs, n_all, nt_all, self.n_anchors, dimp, comm.rank * nt, nt, self.n_neighbors,
+                                                 tile_budget)
+            floor_updates = JOIN_YIELD * n_all * (self.n_neighbors - 1)
+            for p in range(self.join_passes + self.join_extra if tile_budget < nt_all else 0):
+                if p >= self.join_passes and tile_budget + (p + 1) * max(per_pass, 1) > total:
+                    break      # the budget has no room for another pass
+                lists_all, owner = comm.allgather_device(eng, lists, nbytes)
+                lists, upd = eng.stream_knn_join(lists_all, max(per_pass, 1))
+                del owner
+                # every rank takes the same decision: the yield of the pass summed over ranks
+                if p + 1 >= self.join_passes and comm.allgather_f64((upd,)).sum() <= floor_updates:
+                    break
+            row_ids, idx, dist, tile_evals = eng.stream_knn_end(n_local=self.n_local)
         t4 = time.perf_counter()
         # the ordered column arrays (all ranks' shards) stay alive: query() runs against them
         self._columns = dict(ptrs=ptrs, n_all=n_all, nt_all=nt_all, dimp=dimp, keep=keep)
@@ -256,8 +317,14 @@ class StreamedAnnchor:
         return idx, dist
 
     def gather_graph(self):
-        """Full graph (all shards, global row order) on every rank: the final
-        neighbour-graph gather."""
-        parts = self.comm.allgather_obj((self.base, self.neighbor_graph[0], self.neighbor_graph[1]))
-        parts.sort(key=lambda p: p[0])
-        return np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])
+        """Full graph (all shards, global row order) on every rank: the final neighbour-graph
+        gather -- two tensor all-gathers (indices, distances) of shards padded to the largest."""
+        k = self.n_neighbors
+        most = max(n for _, n in self.shards)
+        idx = np.full((most, k), -1, dtype=np.int64)
+        dist = np.full((most, k), np.inf, dtype=np.float64)
+        idx[:self.n_local], dist[:self.n_local] = self.neighbor_graph
+        all_idx, all_dist = self.comm.allgather_host(idx), self.comm.allgather_host(dist)
+        order = sorted(range(len(self.shards)), key=lambda r: self.shards[r][0])
+        return (np.concatenate([all_idx[r][:self.shards[r][1]] for r in order]),
+                np.concatenate([all_dist[r][:self.shards[r][1]] for r in order]))

@@ -254,7 +254,18 @@ int annchor_neighbor_graph(annchor_ctx *ctx, int32_t n_neighbors, int64_t *ng_id
  *   min_tiles pads the shard to a common tile count across ranks.
  * annchor_stream_knn: k-NN rows of tiles [tile_begin, tile_begin+tile_count) against all
  *   column tiles (DEVICE pointers, concatenated over ranks); get_ann-shaped HOST outputs
- *   (annchor/annchor.py:514-530): column 0 = self. */
+ *   (annchor/annchor.py:514-530): column 0 = self.  Two phases: the budgeted tile phase
+ *   (ceil(p_work * n_tiles) column tiles per row tile, the work budget of annchor.py:438-442),
+ *   then `join_passes` passes of the streamed update_anchor_points (annchor.py:475-512,
+ *   utils.py:304-352): pairs that share a computed neighbour -- j in list(c), c in list(i) --
+ *   are evaluated exactly, per row tile, as gathered tile GEMMs; up to `join_extra` further
+ *   passes run while a pass still replaces more than 1 % of the list entries (small data sets,
+ *   whose tile budget is coarse).  Join passes need the launch to cover every row tile (one rank).
+ * annchor_stream_knn_begin / _join / _end: the same build in steps for row-sharded runs: the
+ *   ranks all-gather their list buffers (*lists_local: int32 [tile_count*128][k-1] ordered column
+ *   indices, device memory; lists_bytes its size) after _begin and after every _join into
+ *   lists_all [n_all][k-1], the input of the next _join (*updates: list entries the pass replaced
+ *   on this rank); _end = annchor_stream_knn's outputs. */
 int annchor_stream_bind(annchor_ctx *ctx, const float *X, int64_t n_local, int32_t dim, int64_t global_base,
                         int32_t x_on_device);
 int annchor_stream_anchor_round(annchor_ctx *ctx, const float *anchor_vec, int32_t round, int32_t n_anchors,
@@ -264,8 +275,21 @@ int annchor_stream_order(annchor_ctx *ctx, int32_t min_tiles, void **Xs, void **
                          void **mid, int64_t *n_pad, int32_t *n_tiles, int32_t *dim_padded);
 int annchor_stream_knn(annchor_ctx *ctx, const void *Xs_all, const void *rs_all, const void *perm_all, const void *lo_all,
                        const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors, int32_t dim_padded,
-                       int32_t tile_begin, int32_t tile_count, int32_t k, double p_work, int64_t *row_ids,
-                       int64_t *ng_idx, double *ng_dist, int64_t *tile_evals);
+                       int32_t tile_begin, int32_t tile_count, int32_t k, double p_work, int32_t join_passes, int32_t join_extra,
+                       int64_t *row_ids, int64_t *ng_idx, double *ng_dist, int64_t *tile_evals);
+int annchor_stream_knn_begin(annchor_ctx *ctx, const void *Xs_all, const void *rs_all, const void *perm_all, const void *lo_all,
+                             const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors,
+                             int32_t dim_padded, int32_t tile_begin, int32_t tile_count, int32_t k, int32_t tile_budget,
+                             void **lists_local, int64_t *lists_bytes);
+int annchor_stream_knn_join(annchor_ctx *ctx, const void *lists_all, int32_t per_pass, void **lists_local, int64_t *updates);
+/* The work budget of the streamed form.  p_work is the share of THIS form's brute force -- n_tiles
+ * tile evaluations per row tile -- that one row tile may spend, all phases included:
+ * total = ceil(p_work * n_tiles) = tile_phase + join_passes * per_pass (per_pass = runs of 128
+ * gathered columns one join pass may evaluate; when a tile has more candidates, the ones reached
+ * over the most two-hop paths are kept). */
+int annchor_stream_budget(int32_t n_tiles, double p_work, int32_t join_passes, int32_t *total, int32_t *tile_phase,
+                          int32_t *per_pass);
+int annchor_stream_knn_end(annchor_ctx *ctx, int64_t *row_ids, int64_t *ng_idx, double *ng_dist, int64_t *tile_evals);
 /* Queries against a fitted data set in the streamed form (Annchor.query, annchor.py:643-683 ->
  * query_functions.py:183-212, for data sets beyond the pair-list form).  The context holds
  * the QUERY rows: bound with annchor_stream_bind (global_base 0), given the data set's anchor
@@ -275,6 +299,10 @@ int annchor_stream_knn(annchor_ctx *ctx, const void *Xs_all, const void *rs_all,
 int annchor_stream_query(annchor_ctx *ctx, const void *Xs_all, const void *rs_all, const void *perm_all, const void *lo_all,
                          const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors, int32_t dim_padded,
                          int32_t nn, double p_work, int64_t *out_idx, double *out_dist, int64_t *tile_evals);
+/* Interval tables after a rank-major all-gather ([world][n_anchors][n_tiles], device) joined along
+ * the tile axis ([n_anchors][world * n_tiles], device): the layout the column arguments above use. */
+int annchor_stream_join_tables(annchor_ctx *ctx, const void *gathered, int32_t world, int32_t n_anchors, int32_t n_tiles,
+                               void *joined);
 /* Raw device copies for hosts that stage the all-gather through host memory. */
 int annchor_device_alloc(annchor_ctx *ctx, int64_t bytes, void **dptr);
 int annchor_device_free(annchor_ctx *ctx, void *dptr);

@@ -67,7 +67,43 @@ class FakeStreamEngine:
         ptrs = {k: self._alloc(v) for k, v in dict(Xs=Xs, rs=rs, perm=perm, lo=lo, hi=hi, mid=mid).items()}
         return ptrs, n_pad, nt, self.dim
 
-    def stream_knn(self, ptrs, n_all, nt_all, na, dimp, tile_begin, tile_count, k, p_work, n_local=None):
+    def synchronize(self):
+        pass
+
+    def stream_join_tables(self, gathered, world, na, nt, joined):
+        src = _view(gathered, (world, na, nt), np.float32)
+        _view(joined, (na, world * nt), np.float32)[:] = np.concatenate(list(src), axis=1)
+
+    # row-sharded build in steps: the stand-in is exact in its "tile phase", so the join passes only
+    # have to move plausible buffers through the collectives
+    def stream_budget(self, nt_all, p_work, join_passes):
+        total = max(1, min(nt_all, int(np.ceil(p_work * nt_all))))
+        return total, max(1, total - join_passes), 1   # (the stand-in's "tile phase" is exact whatever it is given)
+
+    def stream_knn_begin(self, ptrs, n_all, nt_all, na, dimp, tile_begin, tile_count, k, tile_budget):
+        self._run = (ptrs, n_all, nt_all, na, dimp, tile_begin, tile_count, k, 1.0)
+        nbytes = tile_count * TILE * (k - 1) * 4
+        self._lists = self._alloc(np.full(nbytes // 4, tile_begin, dtype=np.int32))
+        return self._lists, nbytes
+
+    def stream_knn_join(self, lists_all, per_pass):
+        ptrs, n_all, nt_all, na, dimp, tile_begin, tile_count, k, p_work = self._run
+        every = _view(lists_all, (n_all, k - 1), np.int32)
+        mine = every[tile_begin * TILE:(tile_begin + tile_count) * TILE]
+        assert np.all(mine == tile_begin), "all-gathered lists are not in rank order"
+        self.joins = getattr(self, "joins", 0) + 1
+        return self._lists, 0
+
+    def stream_knn_end(self, n_local=None):
+        return self.stream_knn(*self._run, n_local=n_local)
+
+    def stream_knn(self, ptrs, n_all, nt_all, na, dimp, tile_begin, tile_count, k, p_work, n_local=None, join_passes=0, join_extra=0):
+        if n_local is not None:   # shard-order output: rows = the bound shard's own rows
+            rid, idx, dist, ev = self.stream_knn(ptrs, n_all, nt_all, na, dimp, tile_begin, tile_count, k, p_work)
+            oi, od = np.zeros((n_local, k), dtype=np.int64), np.zeros((n_local, k))
+            real = rid >= 0
+            oi[rid[real] - self.base], od[rid[real] - self.base] = idx[real], dist[real]
+            return None, oi, od, ev
         Xs = _view(ptrs["Xs"], (n_all, dimp), np.float32)
         perm = _view(ptrs["perm"], (n_all,), np.int64)
         rows = np.arange(tile_begin * TILE, (tile_begin + tile_count) * TILE)

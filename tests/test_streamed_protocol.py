@@ -62,7 +62,7 @@ def _worker(rank, world, port, out):
                          engine=FakeStreamEngine()).fit()
     gi, gd = sa.gather_graph()
     if rank == 0:
-        np.savez(out, A=sa.A, idx=gi, dist=gd, evals=sa.evals)
+        np.savez(out, A=sa.A, idx=gi, dist=gd, evals=sa.evals, joins=getattr(sa._engine, "joins", 0))
     dist.destroy_process_group()
 
 
@@ -81,5 +81,6 @@ def test_two_gloo_ranks_equal_one_rank(tmp_path):
     R = np.load(out)
     one = StreamedAnnchor(_data(), n_anchors=6, n_neighbors=5, p_work=1.0, random_seed=42, engine=FakeStreamEngine()).fit()
     assert np.array_equal(R["A"], one.A)
+    assert int(R["joins"]) == 2   # both join passes ran against the all-gathered neighbour lists
     assert np.array_equal(R["idx"], one.neighbor_graph[0])
     np.testing.assert_allclose(R["dist"], one.neighbor_graph[1], rtol=0, atol=0)
