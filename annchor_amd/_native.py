@@ -84,6 +84,7 @@ _SIGNATURES = {
     "annchor_stream_knn_begin": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                                 ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
     "annchor_stream_knn_join": (ctypes.c_int, [_vp, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
+    "annchor_stream_last_counts": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "annchor_stream_budget": (ctypes.c_int, [_i32, _dbl, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "annchor_stream_knn_end": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "annchor_stream_query": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _dbl, _vp, _vp,
@@ -566,6 +567,12 @@ class Engine:
                                                 int(n_all), int(nt_all), int(n_anchors), int(dim_padded), int(nn), float(p_work),
                                                 _ptr(idx), _ptr(dist), ctypes.byref(ev)))
         return idx, dist, ev.value
+
+    def stream_last_counts(self):
+        """(tile evaluations of the tile phase, 128-column runs of the join passes) of the last build."""
+        a, b = _i64(), _i64()
+        self._chk(self.lib.annchor_stream_last_counts(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def stream_join_tables(self, gathered, world, n_anchors, n_tiles, joined):
         self._chk(self.lib.annchor_stream_join_tables(self.h, gathered, int(world), int(n_anchors), int(n_tiles), joined))

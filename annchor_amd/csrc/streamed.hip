@@ -76,6 +76,7 @@ struct StreamState {
     DevBuf ucand, ucount;     // uint32 [tile_count][JN_CAP] / int32 [tile_count]: join candidates per row tile
     DevBuf rev_cnt, rev_ptr, rev_edges, rev;   // reverse neighbour lists of every ordered row (join passes)
     int64_t n_local = 0, n_pad = 0, base = 0;
+    int64_t last_tile_evals = 0, last_join_chunks = 0;
     int dim = 0, dimp = 0, na = 0, nt = 0;
     struct KnnArgs *run = nullptr;   // arguments of the graph build in progress (begin / join / end)
     const void *run_perm = nullptr;
@@ -1273,7 +1274,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
         a.out_d2_new[((size_t)bt * ST_T + row) * K + e] = sh.list_d[row][e];
         a.out_col_new[((size_t)bt * ST_T + row) * K + e] = sh.list_c[row][e];
     }
-    if (threadIdx.x == 0) atomicAdd(a.evals, (unsigned long long)nchunks);
+    if (threadIdx.x == 0) atomicAdd(a.evals + 2, (unsigned long long)nchunks);   // slot 2: join chunks (0: tile phase, 1: pass yield)
     int ins = st.ins;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ins += __shfl_xor(ins, off);
@@ -1426,7 +1427,7 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
     ANN_TRY(sreserve(c, s->out_d2, sizeof(float) * (size_t)rows * K));
     ANN_TRY(sreserve(c, s->out_col, sizeof(int32_t) * (size_t)rows * K));
     ANN_TRY(sreserve(c, s->evals, 64));
-    ANN_CHECK_HIP(c, hipMemsetAsync(s->evals.p, 0, 8, c->stream));
+    ANN_CHECK_HIP(c, hipMemsetAsync(s->evals.p, 0, 32, c->stream));
     a.max_tiles = std::max(1, std::min(tile_budget, a.nt_all));
     a.out_d2 = s->out_d2.as<float>(); a.out_col = s->out_col.as<int32_t>();
     ANN_TRY(sreserve(c, s->scr_key, sizeof(float) * (size_t)a.tile_count * (size_t)a.nt_all));
@@ -1553,10 +1554,23 @@ static int knn_finish(annchor_ctx *c, StreamState *s, KnnArgs &a, const void *pe
     *d_idx_out = d_idx;
     *d_dist_out = d_dist;
     if (tile_evals) {
-        unsigned long long ev = 0;
-        ANN_TRY(ann_d2h(c, &ev, s->evals.p, 8));
-        *tile_evals = (int64_t)ev;
+        unsigned long long ev[3] = {0, 0, 0};
+        ANN_TRY(ann_d2h(c, ev, s->evals.p, 24));
+        *tile_evals = (int64_t)(ev[0] + ev[2]);
+        s->last_tile_evals = (int64_t)ev[0];
+        s->last_join_chunks = (int64_t)ev[2];
     }
+    return ANNCHOR_OK;
+}
+
+// tile evaluations of the last build's tile phase and 128-column runs of its join passes
+extern "C" int annchor_stream_last_counts(annchor_ctx *c, int64_t *tile_phase_evals, int64_t *join_chunks)
+{
+    if (!c || !tile_phase_evals || !join_chunks) return ANNCHOR_EINVAL;
+    StreamState *s = state_of(c, false);
+    ANN_REQUIRE(c, s != nullptr, ANNCHOR_ESTATE, "no streamed build on this context");
+    *tile_phase_evals = s->last_tile_evals;
+    *join_chunks = s->last_join_chunks;
     return ANNCHOR_OK;
 }
 

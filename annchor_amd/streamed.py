@@ -5,11 +5,11 @@ k-NN graph build for float32 Euclidean data at N >> 10^4, on one or several GPUs
 One process per GPU, rows sharded contiguously: rank r owns rows
 [base_r, base_r + n_r).  Per stage (reference annchor/annchor.py:532-623 -> here):
 
-  get_anchors   max-min rounds (pickers.py:18-52).  Every round: the owner of the current
-                anchor broadcasts its coordinates (dim * 4 bytes), every rank sweeps its
-                rows on the GPU (one-to-all distances, running min, local arg-max), the
-                ranks all-gather (value, index) -- 16 bytes each -- and take the arg-max
-                with the first-index tie rule.
+  get_anchors   max-min rounds (pickers.py:18-52).  Every round: every rank sweeps its rows on
+                the GPU (one-to-all distances, running min, local arg-max), then ONE all-gather
+                of (value, index, that row's coordinates) -- (2 + dim) doubles per rank: the
+                arg-max with the first-index tie rule is taken locally and the next anchor's
+                vector is already there (no broadcast from its owner).
   locality      each rank orders its rows by (nearest anchor, distance to it) into 128-row
                 tiles with per-anchor distance intervals.
   exchange      all-gather of the ordered shards (rows, norms, ids) and of the interval
@@ -40,9 +40,6 @@ class SingleComm:
     def allgather_f64(self, values):
         return np.asarray(values, dtype=np.float64)[None, :]
 
-    def bcast_array(self, arr, src, n, dtype):
-        return arr
-
     def allgather_device(self, engine, dptr, nbytes):
         return dptr, None
 
@@ -72,16 +69,6 @@ class TorchComm:
         parts = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(parts, t, group=self.group)
         return torch.stack(parts).cpu().numpy()
-
-    def bcast_array(self, arr, src, n, dtype):
-        import torch
-
-        t = torch.empty(n, dtype=getattr(torch, np.dtype(dtype).name), device=self._dev())
-        if self.rank == src:
-            t.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)))
-        self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, src) if self.group is not None else src,
-                            group=self.group)
-        return t.cpu().numpy()
 
     def allgather_device(self, engine, dptr, nbytes):
         """All-gather `nbytes` bytes at device pointer `dptr` from every rank; returns the
@@ -205,19 +192,34 @@ class StreamedAnnchor:
         return _native.stream_budget(nt_all, self.p_work, self.join_passes)
 
     def get_anchors(self):
+        """Max-min rounds (pickers.py:18-52) over the sharded rows.  One collective per round: every
+        rank contributes its local arg-max (value, global index) TOGETHER with that row's coordinates
+        -- (2 + dim) doubles -- so that after the all-gather every rank knows the winner and already
+        holds the next anchor's vector (no separate broadcast from the owner)."""
         eng, comm, na = self._engine, self.comm, self.n_anchors
         np.random.seed(self.random_seed)
         ix = int(np.random.randint(self.n_total))  # identical on every rank
         A = np.zeros(na, dtype=np.int64)
         self.anchor_vectors = np.zeros((na, self.dim), dtype=np.float32)   # kept for query()
+
+        def exchange(value, index, local_row):
+            mine = np.empty(2 + self.dim, dtype=np.float64)
+            mine[0], mine[1] = value, index
+            mine[2:] = eng.stream_get_row(local_row) if local_row >= 0 else 0.0
+            G = comm.allgather_f64(mine)
+            win = combine_argmax([(G[r, 0], int(G[r, 1])) for r in range(G.shape[0]) if G[r, 1] >= 0])
+            r = [int(G[q, 1]) for q in range(G.shape[0])].index(win)
+            return win, G[r, 2:].astype(np.float32)
+
+        # the first anchor: only its owner has a candidate
+        mine = self.base <= ix < self.base + self.n_local
+        ix, vec = exchange(0.0, ix if mine else -1, ix - self.base if mine else -1)
         for r in range(na):
             A[r] = ix
-            src = owner_of(ix, self.shards)
-            vec = eng.stream_get_row(ix - self.base) if comm.rank == src else None
-            vec = comm.bcast_array(vec, src, self.dim, np.float32)
             self.anchor_vectors[r] = vec
             lmax, larg = eng.stream_anchor_round(vec, r, na)
-            ix = combine_argmax([(v, int(i)) for v, i in comm.allgather_f64((lmax, self.base + larg))])
+            if r + 1 < na:
+                ix, vec = exchange(float(lmax), int(self.base + larg), int(larg))
         self.A = A
         self.evals += na * self.n_total
 

@@ -3,12 +3,18 @@
 bench.py -- k-NN graph build benchmark (BASELINE.json metric: k-NN graph build time +
 recall@k vs brute force).
 
-A "step" is one `Annchor(...).fit()` over the workload's data set, inputs already
-resident in HBM (the constructor uploads; only fit() is timed).  Default workload =
-BASELINE configs[1]: load_strings Levenshtein, N=1600, n_anchors=15, k=25,
-p_work=0.12 on one MI355X.  With --gpus N (launched by torch.distributed.run, one
-rank per GPU) every rank builds graphs independently (this workload is 1600 points:
-see DESIGN.md "multi-GPU") and the line reports whole-job graphs/s.
+A "step" is one `fit()` over the workload's data set, inputs already resident in HBM (the
+constructor uploads; only fit() is timed).
+  --gpus 1 : BASELINE configs[1]: load_strings Levenshtein, N=1600, n_anchors=15, k=25,
+             p_work=0.12 on one MI355X (the metric's quoted configuration).  The line also
+             carries C4 (digits Wasserstein), C3 (Euclidean N=10^6) and the pair-list kernels
+             at N=16000 as extra blocks.
+  --gpus N : (torch.distributed.run, one rank per GPU, RCCL) the row-sharded Euclidean build:
+             BASELINE configs[2] -- N=10^6 float32 x 128, n_anchors=32, k=15, p_work=0.1 --
+             with the rows sharded N/G per GPU: STRONG scaling (total work fixed), value =
+             graphs/s = 1 / fit time.  The strings workload is 1600 points in a chain of
+             dependent launches and does not shard; per-rank replicas of it are reported as an
+             extra block.  With 8 ranks BASELINE configs[4] (N=8*10^6) is added as a block.
 
 Prints ONE JSON line on rank 0.
 """
@@ -100,15 +106,17 @@ def _scale_result(ann, n, dt, fams):
             "note": "fit time at this size is the host-side legacy-RNG sampling (get_sample); the table is the device kernels"}
 
 
-def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch):
-    """BASELINE configs[2]/[4]: synthetic Euclidean float32, 1M rows per GPU, d=128,
-    n_anchors=32, k=15, p_work=0.1, rows sharded across ranks (streamed form)."""
+def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, recall_rows=10000):
+    """BASELINE configs[2] / [4]: synthetic Euclidean float32 (SURVEY.md 8d recipe), d=128, n_anchors=32,
+    k=15, p_work=0.1, rows sharded contiguously across the ranks (streamed form).  Timed like the
+    headline: barrier + synchronize on both sides of every fit, maximum over ranks."""
     from annchor_amd.streamed import SingleComm, StreamedAnnchor, TorchComm
 
     X = euclid_shard(rank, n_per_rank)
     comm = TorchComm() if world > 1 else SingleComm()
     k, pw, na = 15, 0.1, 32
     times, last = [], None
+    red_dev = "cuda" if (dist_mod is not None and dist_mod.get_backend() == "nccl") else "cpu"
     for it in range(warmup + steps):
         sa = StreamedAnnchor(X, n_anchors=na, n_neighbors=k, p_work=pw, base=rank * n_per_rank, comm=comm, device=local)
         sa._engine.prof_enable(True)
@@ -122,47 +130,63 @@ def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch):
             dist_mod.barrier()
         dt = time.perf_counter() - t0
         if dist_mod is not None:
-            tt = torch.tensor([dt], device="cuda" if dist_mod.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+            tt = torch.tensor([dt], device=red_dev, dtype=torch.float64)
             dist_mod.all_reduce(tt, op=dist_mod.ReduceOp.MAX)
             dt = float(tt.item())
         if it >= warmup:
             times.append(dt)
+        if last is not None:
+            last._engine.close()
         last = sa
+    tiles_all = last.tile_evals
+    if dist_mod is not None:
+        tt = torch.tensor([float(last.tile_evals)], device=red_dev, dtype=torch.float64)
+        dist_mod.all_reduce(tt, op=dist_mod.ReduceOp.SUM)
+        tiles_all = int(tt.item())
     out = None
     if rank == 0:
-        prof = last._engine.prof_get()
-        gemm = prof.get("stream_tile_gemm_topk", dict(ms=0.0, launches=1))
-        flops = last.tile_evals * 128.0 * 128.0 * 2.0 * 128.0
-        gemm_s = gemm["ms"] / max(1, gemm["launches"]) * 1e-3
-        # recall on a 200-row sample of rank 0's shard against ALL shards (regenerated one at a time)
-        rows = np.random.default_rng(1).choice(n_per_rank, 200, replace=False)
-        q = X[rows].astype(np.float64)
-        best_d = np.full((200, k), np.inf)
-        for r in range(world):
-            Y = (X if r == 0 else euclid_shard(r, n_per_rank)).astype(np.float64)
-            d2 = (q ** 2).sum(1)[:, None] + (Y ** 2).sum(1)[None, :] - 2.0 * q @ Y.T
-            if r == 0:
-                d2[np.arange(200), rows] = -1.0
-            part = np.sort(np.sqrt(np.maximum(np.partition(d2, k, axis=1)[:, :k], 0)), axis=1)
-            best_d = np.sort(np.concatenate([best_d, part], axis=1), axis=1)[:, :k]
         from annchor_amd import compare_neighbor_graphs
 
-        err = compare_neighbor_graphs((np.zeros((200, k), dtype=np.int64), best_d),
-                                      (last.neighbor_graph[0][rows], last.neighbor_graph[1][rows]), k)
+        prof = last._engine.prof_get()
+        gemm = prof.get("stream_tile_gemm_topk", dict(ms=0.0, launches=1))
+        gemm_s = gemm["ms"] / max(1, gemm["launches"]) * 1e-3
+        # tile evaluations of the tile phase on this rank = all of this rank's minus its join chunks (the
+        # join kernel is timed separately); its flops = evaluations x 128 x 128 x 2 x d
+        nt_all = last.n_tiles_total
+        total, tile_budget, per_pass = last._budget(nt_all)
+        # recall on recall_rows rows of rank 0's shard: exact k-NN over ALL shards from the tile kernel with
+        # the full budget (streamed query), i.e. GPU brute force of that subset
+        m = min(recall_rows, n_per_rank)
+        rows = np.sort(np.random.default_rng(99).choice(n_per_rank, m, replace=False))
+        t_q = time.perf_counter()
+        ti, td = last.query(X[rows], nn=k, p_work=1.0)
+        truth_s = time.perf_counter() - t_q
+        err = compare_neighbor_graphs((ti, td), (last.neighbor_graph[0][rows], last.neighbor_graph[1][rows]), k)
         fit_s = float(np.mean(times))
+        n_total = world * n_per_rank
         out = {
-            "workload": "synthetic Euclidean f32 (8-d latent in 128-d), %d rows/GPU x %d GPU(s), n_anchors=32 k=15 p_work=0.1, "
-                        "row-sharded streamed form" % (n_per_rank, world),
-            "fit_time_s": fit_s, "graphs_per_s": 1.0 / fit_s, "rows_per_s": world * n_per_rank / fit_s,
-            "recall_at_k_200row_sample": 1.0 - err / (200.0 * k), "tile_evals_rank0": int(last.tile_evals),
-            "tile_fraction": last.tile_evals / float((last.n_tiles_total // world) * last.n_tiles_total),
+            "workload": "synthetic Euclidean f32 (8-d latent in 128-d, SURVEY 8d recipe) N=%d d=128 n_anchors=32 k=15 p_work=0.1, "
+                        "streamed form, rows sharded %d per GPU over %d GPU(s)" % (n_total, n_per_rank, world),
+            "fit_time_s": fit_s, "graphs_per_s": 1.0 / fit_s, "rows_per_s": n_total / fit_s,
+            "recall_at_k": 1.0 - err / (float(m) * k), "recall_rows": int(m),
+            "recall_truth": "exact k-NN of %d fixed rows of rank 0's shard over all shards (tile kernel, full budget, %.2f s)" % (m, truth_s),
+            "budget_tiles_per_row_tile": {"total": total, "tile_phase": tile_budget, "per_join_pass": per_pass},
+            "tile_evals_all_ranks": int(tiles_all),
+            "tile_fraction_of_brute_force": tiles_all / float(nt_all) / float(nt_all),
             "stage_s_rank0": {a: round(b, 4) for a, b in last.timings.items()},
-            "roofline": {"kernel": "stream_tile_gemm_topk (k_st_knn, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
-                         "achieved": flops / gemm_s / 1e12 if gemm_s > 0 else 0.0, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": (flops / gemm_s / 1e12 / 157.3) if gemm_s > 0 else 0.0, "traffic": pmc_traffic("k_st_knn"),
-                         "note": "algorithmic flops = evaluated tile pairs x 128 x 128 x 2 x d; peak = dense f32 MFMA"},
             "kernels_ms_rank0": {kk: round(v["ms"], 3) for kk, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
         }
+        if gemm_s > 0:
+            tile_phase_evals, join_chunks = last._engine.stream_last_counts()
+            out["join_chunks_rank0"] = int(join_chunks)
+            flops = tile_phase_evals * 128.0 * 128.0 * 2.0 * 128.0
+            out["roofline"] = {"kernel": "stream_tile_gemm_topk (k_st_knn, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                               "achieved": flops / gemm_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                               "frac": flops / gemm_s / 1e12 / 157.3, "traffic": pmc_traffic("k_st_knn"),
+                               "tile_pairs": int(tile_phase_evals),
+                               "note": "algorithmic flops = tile pairs of the tile phase (<= its budget x row tiles of rank 0) "
+                                       "x 128 x 128 x 2 x d; peak = dense f32 MFMA"}
+    last._engine.close()
     return out
 
 
@@ -210,49 +234,17 @@ def cpu_baseline(X, cfg):
                 evals=int(ora.evals))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
-    ap.add_argument("--no-euclid", action="store_true", help="skip the secondary row-sharded Euclidean workload")
-    ap.add_argument("--no-scale", action="store_true", help="skip the pair-list kernel table at N=16000 (127 M pairs)")
-    ap.add_argument("--euclid-rows", type=int, default=1_000_000, help="rows per GPU of the Euclidean workload")
-    ap.add_argument("--euclid-timeout", type=int, default=600, help="seconds before the secondary workload is abandoned")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank flow)")
-    ap.add_argument("--no-numa-bind", action="store_true", help="do not bind the process to the CPUs of the GPU's NUMA node")
-    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0 (implies --backend gloo)")
-    args = ap.parse_args()
-
-    import torch
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        if args.share_gpu:
-            args.backend, local = "gloo", 0
-        torch.cuda.set_device(local)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group("gloo")
-    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
-
+def strings_run(args, steps, warmup, world, rank, local, dist, torch, all_cpus, affinity):
+    """BASELINE configs[1] (the metric's quoted configuration) on every rank; rank 0 returns the line."""
     from annchor_amd import Annchor, compare_neighbor_graphs
     from annchor_amd import _native as _nat
 
-    # one process per GPU, bound to the CPUs next to it (the launcher's numactl, done here so that
-    # the driver's plain `python bench.py` / torch.distributed.run command lines get it too)
-    all_cpus = os.sched_getaffinity(0)
-    affinity = None if args.no_numa_bind else _nat.bind_to_device_numa(local)
-
+    class _A:   # the old body reads args.steps / args.warmup
+        pass
+    a_ = _A()
+    a_.__dict__.update(vars(args))
+    a_.steps, a_.warmup = steps, warmup
+    args = a_
     X, metric, kwargs, cfg, workload = strings_workload()
     # constructors (engine creation, upload, plumbing smoke test) are outside the timed region
     anns, ctor_s = [], []
@@ -310,7 +302,9 @@ def main():
             "vs_baseline": None,
             "dtype": "int32 bit-vectors (Levenshtein) + f64 (bounds/regression/selection)",
             "data": "reference fixture (annchor/data/edit_data.npz: 1600 synthetic strings, length 378-594)",
-            "config": {"workload": workload, "graphs_per_step_per_gpu": 1, "parallelism": "independent graph build per GPU"},
+            "config": {"workload": workload, "graphs_per_step_per_gpu": 1,
+                       "parallelism": "one GPU" if world == 1 else "independent graph build per GPU (replicas)"},
+            "rng_stream_cache": "off (ANNCHOR_RNG_NO_CACHE=1: every fit regenerates its MT19937 streams)",
             "device": ann._engine.device_name(),
             "cpu_affinity": affinity or "unbound",
             # outside the timed region (the contract times fit() with the inputs resident): string encoding,
@@ -380,69 +374,234 @@ def main():
                 g = kernels[dom]
                 out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": g["alg_GBps"], "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": g["hbm_frac"], "traffic": None}
-        # transparency: every timed fit above uses seed 42, whose raw MT19937 stream (a pure function of
-        # the seed) the library keeps after the first fit of the process; the same fit with that cache
-        # off regenerates it on the producer thread each time
-        if world == 1:
-            os.environ["ANNCHOR_RNG_NO_CACHE"] = "1"
-            try:
-                unc = []
-                for _ in range(6):
-                    u = Annchor(X, metric, func_kwargs=kwargs, device=local, **cfg)
-                    t_u = time.perf_counter()
-                    u.fit()
-                    unc.append(time.perf_counter() - t_u)
-                out["fit_time_s_rng_stream_cache_off"] = float(np.median(unc[1:]))
-            finally:
-                del os.environ["ANNCHOR_RNG_NO_CACHE"]
         if not args.no_cpu_baseline and world == 1:
-            os.sched_setaffinity(0, all_cpus)   # the CPU baseline gets every core of the host, not one NUMA node
+            os.sched_setaffinity(0, all_cpus)   # the CPU baselines get every core of the host, not one NUMA node
             out["cpu_baseline"] = cpu_baseline(X, cfg)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            try:
+                out["cpu_baseline_python_metric"] = cpu_baseline_python_metric(X, local)
+            except Exception as e:   # never at the cost of the line
+                out["cpu_baseline_python_metric"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if affinity:
                 _nat.bind_to_device_numa(local)
 
-    # ---- the pair-list kernels where HBM decides (single-GPU runs only; the line is complete by now)
-    if not args.no_scale and world == 1:
+    return out
+
+
+def c4_block(local):
+    """BASELINE configs[3]: load_digits Wasserstein (exact EMD), N=1797, n_anchors=20, k=25, p_work=0.16."""
+    from annchor_amd import Annchor, compare_neighbor_graphs
+    from annchor_amd.datasets import load_digits
+
+    d = load_digits()
+    cfg = dict(n_anchors=20, n_neighbors=25, n_samples=5000, p_work=0.16, random_seed=42)
+    mk = lambda: Annchor(d["X"], "wasserstein", func_kwargs={"cost_matrix": d["cost_matrix"]}, device=local, **cfg)  # noqa: E731
+    mk().fit()
+    ts = []
+    for _ in range(3):
+        ann = mk()
+        ann._engine.prof_enable(1)
+        t = time.perf_counter()
+        ann.fit()
+        ts.append(time.perf_counter() - t)
+    prof = ann._engine.prof_get()
+    emd = prof.get("wasserstein_pairs", prof.get("emd_pairs", None))
+    err = compare_neighbor_graphs(d["neighbor_graph"], ann.neighbor_graph, 25)
+    res = {"workload": "load_digits Wasserstein (exact EMD, 8x8 images) N=1797 n_anchors=20 k=25 n_samples=5000 p_work=0.16 niters=2",
+           "fit_time_s": float(np.median(ts)), "evals": int(ann.evals),
+           "errors_vs_stored_exact_graph": int(err), "recall_at_k": 1.0 - err / (25.0 * 1797),
+           "reference_published": {"fit_time_s": 21.3, "errors": 8, "us_per_metric_call": 203,
+                                   "source": "doc/user_guide.rst:104,189-209 (other hardware)"},
+           "kernels_ms": {kk: round(v["ms"], 3) for kk, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:6]}}
+    if emd and emd["ms"] > 0:
+        res["metric_kernel_us_per_pair"] = emd["ms"] * 1e3 / max(1, ann.evals)
+    else:
+        top = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        res["metric_kernel_us_per_pair"] = top[1]["ms"] * 1e3 / max(1, ann.evals)
+        res["metric_kernel"] = top[0]
+    ann._engine.close()
+    return res
+
+
+def cpu_baseline_python_metric(X, local, n=160):
+    """CPU baseline #2 (BASELINE.md section 3 / configs[0] "plumbing"): Annchor(X, python_callable) -- the
+    metric is an arbitrary Python function evaluated on the HOST through the joblib get_exact_ijs
+    (reference utils.py:152-175), everything downstream of it on the GPU.  Bounded sample: the first
+    n strings (a pure-Python Levenshtein costs ~25 ms per pair of 500-symbol strings), all cores."""
+    from annchor_amd import Annchor
+
+    def py_lev(a, b):   # textbook two-row DP
+        prev = list(range(len(b) + 1))
+        for i, ca in enumerate(a, 1):
+            cur = [i]
+            for j, cb in enumerate(b, 1):
+                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+            prev = cur
+        return float(prev[-1])
+
+    Xs = np.array(list(X[:: max(1, len(X) // n)][:n]))
+    cfg = dict(n_anchors=6, n_neighbors=8, n_samples=300, p_work=0.3, random_seed=42)
+    t = time.perf_counter()
+    ann = Annchor(Xs, py_lev, device=local, **cfg)
+    ann.fit()
+    dt = time.perf_counter() - t
+    dev = Annchor(Xs, "levenshtein", device=local, **cfg).fit()
+    same = bool(np.array_equal(ann.neighbor_graph[1], dev.neighbor_graph[1]))
+    return {"value": ann.evals / dt, "unit": "metric evaluations/s", "fit_time_s": dt, "evals": int(ann.evals), "cores": int(os.cpu_count()),
+            "kind": "port", "sample": "Annchor(X[:%d strings], python Levenshtein callable) incl. constructor: host metric via joblib "
+                                      "(loky, all cores), pipeline on the GPU" % len(Xs),
+            "graph_equals_device_metric_run": same}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--no-euclid", action="store_true", help="skip the secondary row-sharded Euclidean workload")
+    ap.add_argument("--no-scale", action="store_true", help="skip the pair-list kernel table at N=16000 (127 M pairs)")
+    ap.add_argument("--euclid-rows", type=int, default=1_000_000, help="TOTAL rows of the Euclidean workload (sharded over the GPUs)")
+    ap.add_argument("--no-c5", action="store_true", help="8 ranks: skip the BASELINE configs[4] block (N = 8 000 000)")
+    ap.add_argument("--euclid-timeout", type=int, default=600, help="seconds before the secondary workload is abandoned")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank flow)")
+    ap.add_argument("--no-numa-bind", action="store_true", help="do not bind the process to the CPUs of the GPU's NUMA node")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0 (implies --backend gloo)")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        if args.share_gpu:
+            args.backend, local = "gloo", 0
+        torch.cuda.set_device(local)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+
+    from annchor_amd import _native as _nat
+
+    os.environ["ANNCHOR_RNG_NO_CACHE"] = "1"   # no per-seed MT19937 stream cache: every fit pays for its own streams
+
+    # one process per GPU, bound to the CPUs next to it (the launcher's numactl, done here so that
+    # the driver's plain `python bench.py` / torch.distributed.run command lines get it too)
+    all_cpus = os.sched_getaffinity(0)
+    affinity = None if args.no_numa_bind else _nat.bind_to_device_numa(local)
+
+
+    if world == 1:
+        out = strings_run(args, args.steps, args.warmup, world, rank, local, dist, torch, all_cpus, affinity)
         try:
-            out["pairlist_kernels_at_scale"] = pairlist_at_scale(local)
+            out["c4_digits_wasserstein"] = c4_block(local)
         except Exception as e:
-            out["pairlist_kernels_at_scale"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["c4_digits_wasserstein"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # ---- the pair-list kernels where HBM decides (the line is complete by now)
+        if not args.no_scale:
+            try:
+                out["pairlist_kernels_at_scale"] = pairlist_at_scale(local)
+                ks = out["pairlist_kernels_at_scale"]["kernels"]
+                pick = [n for n in ("row_kth_threshold", "row_topk_graph", "guarantee_nmin_lists", "bounds_dad_features",
+                                    "predict_clip_label_merge", "topk_split_compact", "ecdf_probability") if n in ks]
+                out["roofline_pairlist_kernels_at_scale"] = {
+                    "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "workload": out["pairlist_kernels_at_scale"]["workload"],
+                    "kernels": {n: {"achieved": ks[n]["alg_GBps"], "frac": ks[n]["hbm_frac"]} for n in pick}}
+            except Exception as e:
+                out["pairlist_kernels_at_scale"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if not args.no_euclid:
+            try:
+                out["c3_euclid_streamed"] = euclid_run(1, 0, local, None, args.euclid_rows, 2, 1, torch)
+            except Exception as e:
+                out["c3_euclid_streamed"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        print(json.dumps(out), flush=True)
+        return
 
-    # ---- secondary workload (row-sharded Euclidean, collectives across ranks).  It must never cost
-    # the primary line: the line is complete at this point, and a watchdog thread emits it and ends
-    # the process if the secondary workload blocks (a failed rank would leave the others inside a
-    # collective forever).
-    if not args.no_euclid:
-        import threading
+    # ---------------------------------------------------------------- N > 1: the row-sharded build
+    import threading
 
-        def bail():
-            if rank == 0:
-                out["euclid_row_sharded"] = {"error": "timed out after %d s" % args.euclid_timeout}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-
-        dog = threading.Timer(args.euclid_timeout, bail)
-        dog.daemon = True
-        dog.start()
-        del anns[:args.warmup]
-        try:
-            euclid = euclid_run(world, rank, local, dist, args.euclid_rows, 2, 1, torch)
-        except Exception as e:
-            euclid = {"error": "%s: %s" % (type(e).__name__, e)}
-            if world > 1:   # the other ranks may be inside a collective: do not wait for them
-                dog.cancel()
-                if rank == 0:
-                    out["euclid_row_sharded"] = euclid
-                    print(json.dumps(out), flush=True)
-                os._exit(0)
-        dog.cancel()
+    def bail():
         if rank == 0:
-            out["euclid_row_sharded"] = euclid
+            print(json.dumps({"metric": "knn_graph_builds_per_s", "value": 0.0, "unit": "graphs/s", "n_gpus": world,
+                              "error": "timed out after %d s" % args.euclid_timeout}), flush=True)
+        os._exit(1)
+
+    dog = threading.Timer(args.euclid_timeout, bail)   # a failed rank would leave the others inside a collective forever
+    dog.daemon = True
+    dog.start()
+    n_per_rank = args.euclid_rows // world
+    res = euclid_run(world, rank, local, dist, n_per_rank, args.steps, args.warmup, torch)
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "knn_graph_builds_per_s (1 / fit() wall-clock; BASELINE: k-NN graph build time + recall@k)",
+            "value": res["graphs_per_s"], "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["fit_time_s"] * 1e3, "fit_time_s": res["fit_time_s"], "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (MFMA tile GEMM v_mfma_f32_32x32x2_f32; reported distances recomputed in f64 from the f32 rows)",
+            "data": "synthetic (SURVEY.md 8d recipe: 8-d latent manifold in 128-d, float32), generated per shard",
+            "config": {"workload": res["workload"], "total_rows": n_per_rank * world,
+                       "parallelism": "rows sharded N/G per GPU; per anchor round one all-gather of (value, index, row); all-gather of "
+                                      "the ordered shards and of the neighbour lists before each join pass (RCCL); final graph gather "
+                                      "not timed (each rank keeps its rows)"},
+            "recall_at_k": res["recall_at_k"], "rows_per_s": res["rows_per_s"],
+            "roofline": res.get("roofline"), "detail": res,
+            "cpu_affinity": affinity or "unbound",
+        }
+    # the same workload on ONE GPU, measured in this run by rank 0 while the others wait (strong-scaling reference)
+    try:
+        if rank == 0:
+            Xall = np.concatenate([euclid_shard(r, n_per_rank) for r in range(world)])
+            from annchor_amd.streamed import StreamedAnnchor
+
+            ts = []
+            for it in range(3):
+                sa = StreamedAnnchor(Xall, n_anchors=32, n_neighbors=15, p_work=0.1, device=local)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                sa.fit()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+                sa._engine.close()
+            one = float(np.mean(ts[1:]))
+            out["single_gpu_same_workload"] = {"fit_time_s": one, "value": 1.0 / one}
+            out["speedup_vs_single_gpu"] = one / res["fit_time_s"]
+            out["scaling_efficiency_vs_single_gpu"] = one / res["fit_time_s"] / world
+            del Xall
+        dist.barrier()
+    except Exception as e:
+        if rank == 0:
+            out["single_gpu_same_workload"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # BASELINE configs[4]: N = 8 000 000 over 8 GPUs
+    if world == 8 and not args.no_c5:
+        try:
+            c5 = euclid_run(world, rank, local, dist, 1_000_000, 1, 1, torch)
+            if rank == 0:
+                out["c5_euclid_8M_rows"] = c5
+        except Exception as e:
+            if rank == 0:
+                out["c5_euclid_8M_rows"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # per-rank replicas of the strings workload (BASELINE configs[1]); it does not shard (DESIGN.md)
+    try:
+        st = strings_run(args, 10, 2, world, rank, local, dist, torch, all_cpus, affinity)
+        if rank == 0:
+            out["strings_replicas"] = {kk: st[kk] for kk in ("value", "unit", "ms_per_step", "errors_vs_bruteforce", "evals", "config")
+                                       if kk in st}
+    except Exception as e:
+        if rank == 0:
+            out["strings_replicas"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    dog.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

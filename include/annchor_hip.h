@@ -290,6 +290,8 @@ int annchor_stream_knn_join(annchor_ctx *ctx, const void *lists_all, int32_t per
 int annchor_stream_budget(int32_t n_tiles, double p_work, int32_t join_passes, int32_t *total, int32_t *tile_phase,
                           int32_t *per_pass);
 int annchor_stream_knn_end(annchor_ctx *ctx, int64_t *row_ids, int64_t *ng_idx, double *ng_dist, int64_t *tile_evals);
+/* Split of the last build's tile_evals: tile evaluations of the tile phase, 128-column runs of the join passes. */
+int annchor_stream_last_counts(annchor_ctx *ctx, int64_t *tile_phase_evals, int64_t *join_chunks);
 /* Queries against a fitted data set in the streamed form (Annchor.query, annchor.py:643-683 ->
  * query_functions.py:183-212, for data sets beyond the pair-list form).  The context holds
  * the QUERY rows: bound with annchor_stream_bind (global_base 0), given the data set's anchor

@@ -30,3 +30,28 @@ def test_bench_line_has_the_contract_fields():
         assert key in b["cpu_baseline"], key
     assert b["cpu_baseline"]["kind"] in ("port", "reference")
     assert b["errors_vs_bruteforce"] <= 504   # no worse than the reference's own run
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharing_the_gpu_headlines_the_row_sharded_build():
+    """--gpus 2 rehearsal on the one GPU of the test box (gloo, both ranks on GPU 0): the headline is the
+    row-sharded Euclidean build (strong scaling), with recall and the single-GPU time of the same workload."""
+    import socket
+
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--share-gpu", "--euclid-rows", "200000"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["config"]["total_rows"] == 200000
+    assert "rows sharded" in b["config"]["parallelism"]
+    assert b["value"] > 0 and abs(b["value"] - 1e3 / b["ms_per_step"]) / b["value"] < 1e-6
+    assert b["recall_at_k"] >= 0.9
+    assert b["single_gpu_same_workload"]["fit_time_s"] > 0
+    assert b["strings_replicas"]["errors_vs_bruteforce"] <= 504

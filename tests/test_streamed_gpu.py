@@ -230,6 +230,56 @@ def test_two_ranks_row_sharded_equal_one_rank(tmp_path):
     assert same > 0.999   # identical up to exact-tie order between differently tiled runs
 
 
+def _worker_budgeted(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from annchor_amd.streamed import StreamedAnnchor, TorchComm
+
+    X = latent(40000, 64)
+    cuts = [0, 21000, 40000]
+    sa = StreamedAnnchor(X[cuts[rank]:cuts[rank + 1]], n_anchors=16, n_neighbors=10, p_work=0.25, base=cuts[rank],
+                         comm=TorchComm(), device=0).fit()
+    gi, gd = sa.gather_graph()
+    ev = sa.comm.allgather_f64((sa.tile_evals,)).sum()
+    if rank == 0:
+        np.savez(out, idx=gi, dist=gd, tile_evals=ev, nt=sa.n_tiles_total)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_budgeted_with_join_passes(tmp_path):
+    """Row-sharded build with a binding budget: tile phase per rank, neighbour lists all-gathered
+    before each join pass (annchor_stream_knn_begin / _join / _end), graph gathered at the end.
+    The two-rank graph is not bit-equal to the one-rank graph (each rank tiles its own shard) but
+    must reach the same quality inside the same budget."""
+    import torch.multiprocessing as mp
+
+    from annchor_amd import compare_neighbor_graphs
+    from annchor_amd.streamed import StreamedAnnchor
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "w2b.npz")
+    mp.spawn(_worker_budgeted, args=(2, port, out), nprocs=2, join=True)
+    R = np.load(out)
+    X = latent(40000, 64)
+    k = 10
+    one = StreamedAnnchor(X, n_anchors=16, n_neighbors=k, p_work=0.25).fit()
+    nojoin = StreamedAnnchor(X, n_anchors=16, n_neighbors=k, p_work=0.25, join_passes=0, join_extra=0).fit()
+    rows = np.random.default_rng(2).choice(40000, 1500, replace=False)
+    ti, td = one.query(X[rows], nn=k, p_work=1.0)
+    e_two = compare_neighbor_graphs((ti, td), (R["idx"][rows], R["dist"][rows]), k)
+    e_one = compare_neighbor_graphs((ti, td), (one.neighbor_graph[0][rows], one.neighbor_graph[1][rows]), k)
+    e_nojoin = compare_neighbor_graphs((ti, td), (nojoin.neighbor_graph[0][rows], nojoin.neighbor_graph[1][rows]), k)
+    nt = int(R["nt"])
+    assert int(R["tile_evals"]) <= int(np.ceil(0.25 * nt)) * nt
+    assert np.array_equal(R["idx"][:, 0], np.arange(40000))
+    assert e_two < e_nojoin and e_two <= 2.0 * e_one + 0.01 * len(rows) * k, (e_two, e_one, e_nojoin)
+
+
 def test_annchor_api_dispatches_large_euclidean_to_streamed_form():
     from annchor_amd import Annchor
 
