@@ -496,6 +496,224 @@ template <int R> static int launch_r(annchor_ctx *c, LevArgs a, int64_t npairs, 
     return ANNCHOR_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// k_lev_f: one word per lane like k_lev_r<1>, with the per-column instruction count cut from 19
+// to 15 VALU and a bank-conflict-free match-mask table:
+//   * the carry-in fix of a slot's first lane (top DP row: hp = 1, hn = 0) rides on the DPP move
+//     itself -- `v_or_b32_dpp` / `v_and_b32_dpp` with a per-lane constant second operand -- instead
+//     of two v_cndmask after two v_mov_dpp;
+//   * the recurrence is written in v_bitop3_b32 terms (gfx950: any 3-input boolean function):
+//     12 ALU ops per column instead of the 14 the compiler derives from the textbook form;
+//   * PM[half][symbol][lane % 32]: a lane's match-mask words sit in bank lane % 32 for every
+//     symbol, so the 32 lanes an LDS cycle serves never collide whatever symbols they look up
+//     (the slot-major table had 63 % of its LDS-busy cycles in bank conflicts, profiles/r01_pmc_lev.json).
+__device__ __forceinline__ uint32_t dpp_shr1_or(uint32_t v, uint32_t m)
+{
+    // lane l: v[l-1] | m[l]; lane 0 (no source lane, bound_ctrl): 0 | m[0]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true) | m;
+}
+__device__ __forceinline__ uint32_t dpp_shr1_and(uint32_t v, uint32_t m)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true) & m;
+}
+
+#define LEVF_ROW 128   // bytes per symbol row of one half-wave's PM table (32 lanes x 4 B)
+
+__global__ __launch_bounds__(ANN_WAVE) void k_lev_f(LevArgsR ar)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LevArgs &a = ar.b;
+    const int lane = threadIdx.x;
+    const int GL = ar.GL, P = a.P, A = a.alphabet;
+    const int g = lane / GL;         // pair slot of this lane
+    const int w = lane - g * GL;     // word of the slot's pattern this lane owns
+    const bool slot_ok = g < P;
+    // PM: [2 halves][A symbols][32 lanes] uint32; this lane's column
+    unsigned char *pm_col = smem + (size_t)(lane >> 5) * A * LEVF_ROW + (size_t)(lane & 31) * 4;
+    // text of a slot: one byte per symbol (its dense code), LEVR_PAD bytes of padding either side so that
+    // the pipelined reads of lanes outside their column range stay inside the slot (values never used)
+    uint8_t *txt_g = smem + a.pm_bytes + (size_t)(slot_ok ? g : 0) * a.text_stride;
+    int *ssum = reinterpret_cast<int *>(smem + a.pm_bytes + (size_t)P * a.text_stride);
+    const int64_t n_tasks = (a.n + P - 1) / P;
+
+    if (slot_ok)
+        for (int e = w * 16; e < a.text_stride; e += GL * 16) *reinterpret_cast<uint4 *>(txt_g + e) = make_uint4(0, 0, 0, 0);
+
+    int picked = -1;
+    if (ar.pick_row) {   // fused max-min pick, as in k_lev_r
+        double bv = -INFINITY;
+        int bi = 0x7fffffff;
+        const int nx = ar.pick_nx;
+        for (int j0 = 0; j0 < nx; j0 += 64 * 8) {
+            double d[8], rm[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = min(j0 + e * 64 + lane, nx - 1);
+                d[e] = ar.pick_row[j];
+                rm[e] = ar.pick_reset ? 0.0 : ar.pick_runmin[j];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = j0 + e * 64 + lane;
+                if (j < nx) {
+                    const double v = ar.pick_reset ? d[e] : fmin(rm[e], d[e]);
+                    if (blockIdx.x == 0) ar.pick_runmin[j] = v;
+                    argmax_combine(bv, bi, v, j);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            argmax_combine(bv, bi, ov, oi);
+        }
+        picked = bi;
+        if (blockIdx.x == 0 && lane == 0) *ar.pick_out = bi;
+    }
+    // carry-in constants of this lane: the first lane of a slot sees the row above the pattern
+    // (horizontal delta +1: hp carry 1, hn carry 0) instead of the previous slot's last word
+    uint32_t hp_or = w == 0 ? 0x80000000u : 0u;
+    uint32_t hn_and = w == 0 ? 0u : 0xffffffffu;
+    asm volatile("" : "+v"(hp_or), "+v"(hn_and));   // opaque: keeps them operands of v_or_b32_dpp / v_and_b32_dpp (not a select)
+
+    for (int64_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        const int64_t t_pair = task * P + g;
+        const bool active = slot_ok && t_pair < a.n;
+        int si = 0, sj = 0;
+        int64_t opos = t_pair;
+        if (active) {
+            if (a.anchor) { si = picked >= 0 ? picked : *a.anchor; sj = (int)t_pair; }
+            else {
+                int64_t q = a.idx ? a.idx[t_pair] : t_pair;
+                int2 p = a.ij[q];
+                si = p.x; sj = p.y;
+                if (a.idx) opos = q;
+            }
+        }
+        const int li = active ? a.slen[si] : 0, lj = active ? a.slen[sj] : 0;
+        const bool swap = li < lj;
+        const int ps = swap ? sj : si, ts = swap ? si : sj;
+        const int m = swap ? lj : li, n = swap ? li : lj;
+        const uint8_t *pat = a.sym + (active ? a.soff[ps] : 0);
+        const uint8_t *tex = a.sym + (active ? a.soff[ts] : 0);
+        const int Wp = (m + 31) >> 5;          // pattern words = lanes that hold pattern words
+        if (slot_ok && w == 0) ssum[g] = 0;
+        // every lane clears its own column (lanes outside the slots too: their reads must stay defined)
+        for (int c = 0; c < A; ++c) *reinterpret_cast<uint32_t *>(pm_col + (size_t)c * LEVF_ROW) = 0u;
+        if (active && w < Wp) {
+            const uint4 *p16 = reinterpret_cast<const uint4 *>(pat + w * 32);
+            const uint4 q0 = p16[0], q1 = p16[1];
+            const uint32_t wd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            const int valid = min(32, m - w * 32);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const uint32_t c = (wd[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+                // the column is private to this lane: plain read-modify-write
+                if (k < valid) *reinterpret_cast<uint32_t *>(pm_col + (size_t)c * LEVF_ROW) |= 1u << k;
+            }
+        }
+        if (active) {
+            const int chunks = (n + 15) >> 4;
+            for (int ch = w; ch < chunks; ch += GL)
+                reinterpret_cast<uint4 *>(txt_g + LEVR_PAD)[ch] = reinterpret_cast<const uint4 *>(tex)[ch];
+        }
+        wave_lds_fence();
+
+        uint32_t vp = 0xffffffffu, vn = 0u;
+        const uint32_t un = (active && m > 0) ? (uint32_t)n : 0u;
+        int max_steps = (active && m > 0) ? n + Wp - 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) max_steps = max(max_steps, __shfl_xor(max_steps, off));
+        max_steps = __builtin_amdgcn_readfirstlane(max_steps);
+        const uint8_t *tp = txt_g + LEVR_PAD - w;   // tp[k] = this lane's symbol at iteration k (row = symbol * LEVF_ROW: one v_lshl_add)
+        uint32_t c1 = tp[1];
+        uint32_t eq = *reinterpret_cast<const uint32_t *>(pm_col + (uint32_t)tp[0] * LEVF_ROW);
+        uint32_t out_hp = 0, out_hn = 0;   // hp / hn of this lane's word in the previous iteration
+        auto column = [&](int k, auto checked) {
+            const uint32_t c2 = tp[k + 2];
+            const uint32_t eq_n = *reinterpret_cast<const uint32_t *>(pm_col + c1 * LEVF_ROW);
+            const uint32_t hp_up = dpp_shr1_or(out_hp, hp_or), hn_up = dpp_shr1_and(out_hn, hn_and);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool valid = !decltype(checked)::value || (uint32_t)(k - w) < un;
+            const uint32_t c = hn_up >> 31;
+            const uint32_t x = eq | c;
+            const uint32_t t = __builtin_amdgcn_bitop3_b32(c, eq, vp, 0xa8);       // (c | eq) & vp
+            const uint32_t sm = t + vp;
+            const uint32_t d0p = __builtin_amdgcn_bitop3_b32(sm, vp, x, 0xbe);   // (sm ^ vp) | x
+            const uint32_t hp = __builtin_amdgcn_bitop3_b32(vn, d0p, vp, 0xf1);    // vn | ~(d0p | vp)
+            const uint32_t d0 = d0p | vn;
+            const uint32_t hn = d0 & vp;
+            const uint32_t hps = __builtin_amdgcn_alignbit(hp, hp_up, 31);          // (hp << 1) | carry from the word above
+            const uint32_t hns = __builtin_amdgcn_alignbit(hn, hn_up, 31);
+            const uint32_t nvp = __builtin_amdgcn_bitop3_b32(hns, d0, hps, 0xf1);  // hns | ~(d0 | hps)
+            const uint32_t nvn = hps & d0;
+            vp = valid ? nvp : vp;
+            vn = valid ? nvn : vn;
+            out_hp = hp;
+            out_hn = hn;
+            __builtin_amdgcn_sched_barrier(0);
+            eq = eq_n;
+            c1 = c2;
+        };
+        int k_lo = min(GL - 1, max_steps), k_hi = (active && m > 0) ? n : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) k_hi = min(k_hi, __shfl_xor(k_hi, off));
+        k_hi = max(k_lo, min(__builtin_amdgcn_readfirstlane(k_hi), max_steps));
+        int k = 0;
+        for (; k < k_lo; ++k) column(k, std::true_type());
+        for (; k + 2 <= k_hi; k += 2) { column(k, std::false_type()); column(k + 1, std::false_type()); }
+        for (; k < k_hi; ++k) column(k, std::false_type());
+        for (; k < max_steps; ++k) column(k, std::true_type());
+        if (active) {
+            const uint32_t rows = w < Wp - 1 ? 0xffffffffu : (w == Wp - 1 ? (0xffffffffu >> (31 - ((m - 1) & 31))) : 0u);
+            const int part = __popc(vp & rows) - __popc(vn & rows);
+            if (part) atomicAdd(&ssum[g], part);
+        }
+        wave_lds_fence();
+        if (active && w == 0) {
+            const double d = (double)(n + ssum[g]);
+            if (a.out) a.out[t_pair] = d;
+            if (a.RA) { a.RA[opos] = d; a.ncm[opos] = 0; }
+        }
+        wave_lds_fence();
+    }
+}
+
+static int launch_f(annchor_ctx *c, LevArgs a, int64_t npairs, const PairSource &src)
+{
+    const int W = (c->maxlen + 31) / 32 > 0 ? (c->maxlen + 31) / 32 : 1;
+    LevArgsR ar;
+    ar.GL = W;
+    ar.pm_stride = 32;
+    a.G = ar.GL;
+    a.P = 64 / ar.GL;
+    a.pm_bytes = 2 * a.alphabet * LEVF_ROW;
+    a.text_stride = 2 * LEVR_PAD + ((c->maxlen + 15) & ~15) + 16;
+    a.wave_bytes = a.pm_bytes + a.P * a.text_stride + 256;
+    ar.b = a;
+    ar.pick_row = nullptr; ar.pick_runmin = nullptr; ar.pick_out = nullptr; ar.pick_reset = 0; ar.pick_nx = 0;
+    if (src.anchor && src.pick_fused && c->nx <= 8192) {
+        *src.pick_fused = true;
+        if (src.pick_row) {
+            ar.pick_row = src.pick_row; ar.pick_runmin = src.pick_runmin; ar.pick_out = src.pick_out;
+            ar.pick_reset = src.pick_reset; ar.pick_nx = (int)c->nx;
+        }
+    }
+    const size_t lds = (size_t)a.wave_bytes;
+    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "alphabet %d x length %d needs %zu B of LDS (> 160 KiB)", c->alphabet,
+                c->maxlen, lds);
+    if (lds > 64 * 1024)
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev_f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t blocks = (npairs + a.P - 1) / a.P;
+    const int64_t max_blocks = (int64_t)c->prop.multiProcessorCount * 32;
+    if (blocks > max_blocks) blocks = max_blocks;
+    k_lev_f<<<(int)blocks, ANN_WAVE, lds, c->stream>>>(ar);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
 int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm)
 {
     if (src.n == 0) return ANNCHOR_OK;
@@ -532,7 +750,12 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
         // refine launches (420 us vs 600 us); R = 2 / 4 cut instructions further but their
         // tables leave < 2 waves per SIMD.  ANNCHOR_LEV_R = 0 / 2 / 4 select the other variants.
         (void)W;
-        int R = force_r >= 0 ? force_r : 1;
+        int R = force_r >= 0 ? force_r : 9;   // default: k_lev_f (394 vs 415 us per 65 536 pairs, 34 vs 37.5 us per anchor round)
+        if (R == 9 && W <= 32) {   // k_lev_f (strings up to 1024 symbols: a slot's lanes must map to distinct banks)
+            ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
+            return launch_f(c, a, src.n, src);
+        }
+        if (R == 9) R = 1;
         if (R == 1 || R == 2 || R == 4) {
             ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
             return R == 1 ? launch_r<1>(c, a, src.n, src) : R == 2 ? launch_r<2>(c, a, src.n, src) : launch_r<4>(c, a, src.n, src);

@@ -81,7 +81,7 @@ def test_levenshtein_random_ragged():
     assert list(got) == want
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "4"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "4", "9"])
 def test_levenshtein_kernel_variants_ragged(variant, monkeypatch):
     """Every Levenshtein kernel variant (two-column systolic kernel = 0, R words per lane = 1/2/4;
     normally chosen by launch size) against the oracle on ragged input: empty strings, lengths
