@@ -68,6 +68,11 @@ struct annchor_ctx {
     DevBuf Iptr, Iidx;            // int64 [nx+1], int32 [2n]
     int64_t n = 0;                // number of candidate pairs
     DevBuf ij;                    // int2 [n]
+    bool have_bitmap = false;     // Kbits / Kpref / low / rowstart describe the current pair list
+    // column-ordered copy of the "column-like" half of the rows: T[colbase(i) + s] = RA[pair (j_s, i)],
+    // j_s < i ascending, colbase(i) = Iptr[i] - rowstart[i]; rebuilt by ann_transpose_columns before a
+    // row kernel runs over a large pair list (rowsel.h)
+    DevBuf colT, colM;            // double [n], uint8 [n]
 
     // ---- per-pair state
     DevBuf lb, ub, dad, RA, prob;  // double [n]

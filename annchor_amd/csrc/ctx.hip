@@ -382,7 +382,7 @@ extern "C" int annchor_last_kernel_ms(annchor_ctx *c, float *ms)
 static void reset_pipeline(annchor_ctx *c)
 {
     c->na = c->nA = 0;
-    c->n = 0;
+    c->n = 0; c->have_bitmap = false;
     c->have_features = c->have_RA = false;
     c->nsamp = c->ncand = c->nnext = 0;
 }

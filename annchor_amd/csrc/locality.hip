@@ -132,32 +132,34 @@ __device__ __forceinline__ uint32_t keep_rank(const uint64_t *K, const uint32_t 
     return pref[row * kw + w] + (uint32_t)__popcll(K[row * kw + w] & ((1ull << (col & 63)) - 1ull));
 }
 
-// thread per (row, word): emit pairs and the CSR index
-__global__ void k_emit_pairs(const uint64_t *__restrict__ K, const uint32_t *__restrict__ pref, int64_t nx, int kw,
-                             const int32_t *__restrict__ low, const int64_t *__restrict__ rowstart,
-                             const int64_t *__restrict__ Iptr, int2 *__restrict__ ij, int32_t *__restrict__ Iidx)
+// wave per (row, 64-column word), lane = column bit: consecutive kept columns are consecutive
+// positions of the pair list and of the CSR index, so both are written in whole lines (one thread per
+// word walking its bits wrote 64 scattered 8-byte pieces per store instruction)
+__global__ __launch_bounds__(256) void k_emit_pairs(const uint64_t *__restrict__ K, const uint32_t *__restrict__ pref, int64_t nx, int kw,
+                                                   const int32_t *__restrict__ low, const int64_t *__restrict__ rowstart,
+                                                   const int64_t *__restrict__ Iptr, int2 *__restrict__ ij, int32_t *__restrict__ Iidx)
 {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nx * kw) return;
-    int64_t i = t / kw;
-    int w = (int)(t - i * kw);
-    uint64_t bits = K[t];
-    uint32_t r = pref[t];
-    const int64_t ip = Iptr[i], rs = rowstart[i];
-    const int32_t li = low[i];
-    while (bits) {
-        int b = __ffsll((unsigned long long)bits) - 1;
-        bits &= bits - 1;
-        int64_t j = (int64_t)w * 64 + b;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t wave_count = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t items = nx * kw;
+    for (int64_t t = wave_global; t < items; t += wave_count) {
+        const int64_t i = t / kw;
+        const int w = (int)(t - i * kw);
+        const uint64_t bits = K[t];          // wave-uniform
+        if (bits == 0) continue;
+        const bool mine = (bits >> lane) & 1ull;
+        if (!mine) continue;
+        const uint32_t r = pref[t] + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));   // rank of this column among row i's partners
+        const int64_t j = (int64_t)w * 64 + lane;
         int64_t pos;
         if (j > i) {
-            pos = rs + ((int64_t)r - li);
+            pos = rowstart[i] + ((int64_t)r - low[i]);
             ij[pos] = make_int2((int)i, (int)j);
         } else {
             pos = rowstart[j] + ((int64_t)keep_rank(K, pref, kw, j, i) - low[j]);
         }
-        Iidx[ip + r] = (int32_t)pos;
-        ++r;
+        Iidx[Iptr[i] + r] = (int32_t)pos;
     }
 }
 
@@ -227,7 +229,7 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
     ANN_TRY(ann_reserve(c, c->Iidx, sizeof(int32_t) * 2 * (size_t)n));
     {
         ProfScope ps(c, "locality_emit_pairs", (double)n * 16 + (double)nx * kw * 12.0);
-        k_emit_pairs<<<ann_blocks(nx * kw, 256), 256, 0, c->stream>>>(
+        k_emit_pairs<<<(int)std::min<int64_t>(ann_blocks(nx * kw * 64, 256), (int64_t)c->prop.multiProcessorCount * 64), 256, 0, c->stream>>>(
             c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), nx, kw, c->low.as<int32_t>(), c->rowstart.as<int64_t>(),
             c->Iptr.as<int64_t>(), c->ij.as<int2>(), c->Iidx.as<int32_t>());
     }
@@ -235,6 +237,7 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
     c->call_timed = true;
     ANN_CHECK_HIP(c, hipGetLastError());
     c->n = n;
+    c->have_bitmap = true;
     c->have_features = c->have_RA = false;
     *n_pairs = n;
     *min_row_len = mn;
@@ -336,6 +339,7 @@ extern "C" int annchor_build_query_locality(annchor_ctx *c, int64_t nx_base, int
                                                            c->ij.as<int2>(), c->Iidx.as<int32_t>());
     ANN_CHECK_HIP(c, hipGetLastError());
     c->n = n;
+    c->have_bitmap = false;   // query form: rows are contiguous already, no bitmap
     c->have_features = c->have_RA = false;
     *n_pairs = n;
     *min_row_len = mn;

@@ -15,38 +15,46 @@
 #include "rowsel.h"
 
 // ---- computed-neighbour CSR
-__global__ __launch_bounds__(ROW_THREADS) void k_comp_count(const int64_t *__restrict__ Iptr, const int32_t *__restrict__ Iidx,
-                                                           const uint8_t *__restrict__ ncm, int32_t *__restrict__ cnt)
+__global__ __launch_bounds__(ROW_THREADS) void k_comp_count(const int64_t *__restrict__ Iptr, RowSrc src, int32_t *__restrict__ cnt)
 {
     __shared__ uint32_t acc;
     if (threadIdx.x == 0) acc = 0;
     __syncthreads();
     const int64_t i = row_of_block(gridDim.x), b = Iptr[i];
     const int len = (int)(Iptr[i + 1] - b);
+    const RowView rv = row_view(src, i, b);
     uint32_t s = 0;
-    for (int k = threadIdx.x; k < len; k += ROW_THREADS) s += !ncm[Iidx[b + k]];
+    for (int k0 = threadIdx.x; k0 < len; k0 += 4 * ROW_THREADS) {
+        bool u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = rv.unc(min(k0 + e * ROW_THREADS, len - 1));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += (k0 + e * ROW_THREADS < len) && !u[e];
+    }
     if (s) atomicAdd(&acc, s);
     __syncthreads();
     if (threadIdx.x == 0) cnt[i] = (int32_t)acc;
 }
 
-__global__ __launch_bounds__(ROW_THREADS) void k_comp_fill(const int64_t *__restrict__ Iptr, const int32_t *__restrict__ Iidx,
-                                                          const uint8_t *__restrict__ ncm, const int2 *__restrict__ ij,
-                                                          const double *__restrict__ RA, const int64_t *__restrict__ cptr,
+__global__ __launch_bounds__(ROW_THREADS) void k_comp_fill(const int64_t *__restrict__ Iptr, RowSrc src, const int2 *__restrict__ ij,
+                                                          const int64_t *__restrict__ cptr,
                                                           int32_t *__restrict__ cidx, double *__restrict__ cval)
 {
     __shared__ uint32_t wsum[ROW_THREADS / 64];
     const int64_t i = row_of_block(gridDim.x), b = Iptr[i];
     const int len = (int)(Iptr[i + 1] - b);
+    const RowView rv = row_view(src, i, b);
+    const int32_t *Iidx = src.Iidx;
+    const double *RA = src.RA;
     int64_t w = cptr[i];
     for (int base = 0; base < len; base += ROW_THREADS) {
         const int k = base + threadIdx.x;
-        int32_t p = 0;
         uint32_t f = 0;
-        if (k < len) { p = Iidx[b + k]; f = !ncm[p]; }
+        if (k < len) f = !rv.unc(k);
         uint32_t tot;
         const uint32_t ex = row_block_scan(f, wsum, &tot);
         if (f) {
+            const int32_t p = Iidx[b + k];   // only the computed entries (a few per cent) look their pair up
             const int2 q = ij[p];
             cidx[w + ex] = q.x == (int)i ? q.y : q.x;
             cval[w + ex] = RA[p];
@@ -133,10 +141,11 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
     ANN_TRY(ann_reserve(c, c->cptr, sizeof(int64_t) * (size_t)(nx + 1)));
     ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
     int64_t total = 0;
+    RowSrc rsrc;
+    ANN_TRY(ann_transpose_columns(c, &rsrc, false));   // the mask alone (one byte per pair)
     {
         ProfScope ps(c, "computed_neighbour_csr", (double)c->n * 2 * 5.0);
-        k_comp_count<<<(int)nx, ROW_THREADS, 0, c->stream>>>(c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(), c->ncm.as<uint8_t>(),
-                                                            c->tmp1.as<int32_t>());
+        k_comp_count<<<(int)nx, ROW_THREADS, 0, c->stream>>>(c->Iptr.as<int64_t>(), rsrc, c->tmp1.as<int32_t>());
         ANN_TRY(ann_exclusive_scan_i32_to_i64(c, c->tmp1.as<int32_t>(), c->cptr.as<int64_t>(), nx));
         // how many computed entries (both directions)?  Small lists: room for the worst case (every pair
         // computed) instead of a host wait for the exact number; the profile's byte count then uses the
@@ -148,8 +157,7 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
         }
         ANN_TRY(ann_reserve(c, c->cidx, sizeof(int32_t) * (size_t)(total + 1)));
         ANN_TRY(ann_reserve(c, c->cval, sizeof(double) * (size_t)(total + 1)));
-        k_comp_fill<<<(int)nx, ROW_THREADS, 0, c->stream>>>(c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(), c->ncm.as<uint8_t>(),
-                                                           c->ij.as<int2>(), c->RA.as<double>(), c->cptr.as<int64_t>(),
+        k_comp_fill<<<(int)nx, ROW_THREADS, 0, c->stream>>>(c->Iptr.as<int64_t>(), rsrc, c->ij.as<int2>(), c->cptr.as<int64_t>(),
                                                            c->cidx.as<int32_t>(), c->cval.as<double>());
     }
     {
@@ -167,46 +175,193 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
     return ANNCHOR_OK;
 }
 
+
+// ------------------------------------------------------- column-half transpose (rowsel.h: RowSrc)
+// 64 x 64 tiles of the (j, i), j < i, triangle through LDS: the read side walks row j of the pair
+// list (consecutive kept columns = consecutive positions), the write side walks column i of the copy
+// (consecutive kept rows = consecutive positions of T): both sides in whole cache lines, where a
+// row kernel gathering its column-like half directly touches one line per 8-byte value.
+#define TR_T 64
+template <bool VALUES> __global__ __launch_bounds__(256) void k_transpose_cols(const uint64_t *__restrict__ K, const uint32_t *__restrict__ pref, int kw,
+                                                       const int32_t *__restrict__ low, const int64_t *__restrict__ rowstart,
+                                                       const int64_t *__restrict__ Iptr, const double *__restrict__ RA,
+                                                       const uint8_t *__restrict__ ncm, int64_t nx, double *__restrict__ T,
+                                                       uint8_t *__restrict__ Tm)
+{
+    __shared__ double tv[TR_T][TR_T + 1];
+    __shared__ uint8_t tm[TR_T][TR_T + 4];
+    // tile (jb, ib), jb <= ib, from the linear block index (row-major over the upper triangle of tiles)
+    const int nb = kw;   // 64-wide blocks per side == bitmap words per row
+    int64_t t = blockIdx.x;
+    int jb = (int)((2.0 * nb + 1.0 - sqrt((2.0 * nb + 1.0) * (2.0 * nb + 1.0) - 8.0 * (double)t)) * 0.5);
+    while ((int64_t)jb * nb - (int64_t)jb * (jb - 1) / 2 > t) --jb;
+    while ((int64_t)(jb + 1) * nb - (int64_t)(jb + 1) * jb / 2 <= t) ++jb;
+    const int ib = jb + (int)(t - ((int64_t)jb * nb - (int64_t)jb * (jb - 1) / 2));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- read: wave handles 16 rows j, lane = column i
+    const int64_t i_r = (int64_t)ib * 64 + lane;
+    {
+        // positions of the wave's 16 rows first (wave-uniform table reads), then all value loads together
+        int64_t pos[16];
+        bool ok[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int64_t j = min((int64_t)jb * 64 + wave * 16 + q, nx - 1);
+            const uint64_t bits = K[j * kw + ib];
+            ok[q] = (int64_t)jb * 64 + wave * 16 + q < nx && i_r > j && ((bits >> lane) & 1ull);
+            const int64_t p = rowstart[j] + ((int64_t)pref[j * kw + ib] + __popcll(bits & ((1ull << lane) - 1ull)) - low[j]);
+            pos[q] = ok[q] ? p : 0;
+        }
+        double v[16];
+        uint8_t m[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { v[q] = VALUES ? RA[pos[q]] : 0.0; m[q] = ncm[pos[q]]; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (VALUES) tv[wave * 16 + q][lane] = ok[q] ? v[q] : 0.0;
+            tm[wave * 16 + q][lane] = ok[q] ? m[q] : (uint8_t)0;
+        }
+    }
+    __syncthreads();
+    // ---- write: wave handles 16 columns i, lane = row j
+    const int64_t j_w = (int64_t)jb * 64 + lane;
+    for (int q = 0; q < 16; ++q) {
+        const int il = wave * 16 + q;
+        const int64_t i = (int64_t)ib * 64 + il;
+        if (i >= nx) continue;
+        const uint64_t bits = K[i * kw + jb];   // symmetric bitmap: bit j of row i <=> pair (j, i) kept
+        if (j_w < i && ((bits >> lane) & 1ull)) {
+            const int64_t dst = (Iptr[i] - rowstart[i]) + ((int64_t)pref[i * kw + jb] + __popcll(bits & ((1ull << lane) - 1ull)));
+            if (VALUES) T[dst] = tv[lane][il];
+            Tm[dst] = tm[lane][il];
+        }
+    }
+}
+
+// Row kernels over a large pair list take the column-like halves from a column-ordered copy.
+#define ANN_TRANSPOSE_MIN_PAIRS (8ll << 20)   // below this the per-pair arrays are L2 / MALL resident: gather directly
+int ann_transpose_columns(annchor_ctx *c, RowSrc *src, bool with_values)
+{
+    src->RA = c->RA.as<double>(); src->ncm = c->ncm.as<uint8_t>(); src->Iidx = c->Iidx.as<int32_t>();
+    src->T = nullptr; src->Tm = nullptr; src->rowstart = c->rowstart.as<int64_t>(); src->low = c->low.as<int32_t>();
+    static const long long min_pairs = getenv("ANNCHOR_TRANSPOSE_MIN") ? atoll(getenv("ANNCHOR_TRANSPOSE_MIN")) : ANN_TRANSPOSE_MIN_PAIRS;
+    if (!c->have_bitmap || c->n < min_pairs) return ANNCHOR_OK;
+    ANN_TRY(ann_reserve(c, c->colT, sizeof(double) * (size_t)c->n));
+    ANN_TRY(ann_reserve(c, c->colM, (size_t)c->n));
+    const int kw = (int)((c->nx + 63) / 64);
+    const int64_t tiles = (int64_t)kw * (kw + 1) / 2;
+    if (!with_values) {
+        ProfScope ps(c, "transpose_column_half_mask", (double)c->n * 2.0);
+        k_transpose_cols<false><<<(unsigned)tiles, 256, 0, c->stream>>>(c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), kw, c->low.as<int32_t>(),
+                                                                       c->rowstart.as<int64_t>(), c->Iptr.as<int64_t>(), c->RA.as<double>(),
+                                                                       c->ncm.as<uint8_t>(), c->nx, c->colT.as<double>(), c->colM.as<uint8_t>());
+    } else {
+        // algorithmic bytes: every pair's value and mask read once, written once
+        ProfScope ps(c, "transpose_column_half", (double)c->n * 18.0);
+        k_transpose_cols<true><<<(unsigned)tiles, 256, 0, c->stream>>>(c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), kw, c->low.as<int32_t>(),
+                                                                c->rowstart.as<int64_t>(), c->Iptr.as<int64_t>(), c->RA.as<double>(),
+                                                                c->ncm.as<uint8_t>(), c->nx, c->colT.as<double>(), c->colM.as<uint8_t>());
+    }
+    ANN_CHECK_HIP(c, hipGetLastError());
+    src->T = c->colT.as<double>();
+    src->Tm = c->colM.as<uint8_t>();
+    return ANNCHOR_OK;
+}
+
 // -------------------------------------------------------------------- get_nn
 // block per row: keys d' = RA (+ row max on not-computed entries); the nn-1 smallest
 // by (d', slot); output values are the un-shifted RA (utils.py:417-428)
-__global__ __launch_bounds__(ROW_THREADS) void k_get_nn(const int64_t *__restrict__ Iptr, const int32_t *__restrict__ Iidx,
-                                                       const double *__restrict__ RA, const uint8_t *__restrict__ ncm,
+__global__ __launch_bounds__(ROW_THREADS) void k_get_nn(const int64_t *__restrict__ Iptr, RowSrc src,
                                                        const int2 *__restrict__ ij, int nn, int64_t *__restrict__ ngi,
                                                        double *__restrict__ ngd, int cap)
 {
     __shared__ RowSelShared sh;
+    __shared__ RowCand rc;
     __shared__ double wmax[ROW_THREADS / 64];
     __shared__ uint32_t cnt_lt;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     const int L = nn - 1;
-    uint64_t *keys = reinterpret_cast<uint64_t *>(dyn);      // [cap]
+    uint64_t *keys = reinterpret_cast<uint64_t *>(dyn);      // [cap] (fallback path only)
     uint64_t *lkey = keys + cap;                             // [L]
     int32_t *lslot = reinterpret_cast<int32_t *>(lkey + L);  // [L]
     const int64_t i = row_of_block(gridDim.x), b = Iptr[i];
     const int len = (int)(Iptr[i + 1] - b);
     if (threadIdx.x == 0) { ngi[i * nn] = i; ngd[i * nn] = 0.0; cnt_lt = 0; }
     // row maximum of RA (utils.py:418)
+    const RowView rv = row_view(src, i, b);
+    const int32_t *Iidx = src.Iidx;
+    const double *RA = src.RA;
+    // ---- first pass: row maximum (utils.py:418) and, at the same time, the candidates among the
+    // COMPUTED entries alone.  Not-computed entries are keyed RA + max: with RA > 0 they sort behind
+    // every computed entry, so when the row has nn-1 computed entries and no not-computed entry with
+    // RA <= 0 (guarantee_nmin's -1 marks) the answer is here already and the second pass is not needed.
+    __shared__ uint32_t ncomp_s, risky_s;
+    if (threadIdx.x == 0) { ncomp_s = 0; risky_s = 0; }
     double mx = -INFINITY;
-    for (int s = threadIdx.x; s < len; s += ROW_THREADS) mx = fmax(mx, RA[Iidx[b + s]]);
+    uint32_t my_comp = 0, my_risky = 0;
+    const int want0 = min(L, len);
+    const int fast0 = want0 > 0 ? row_candidates(rc, len, want0, [&](int s) { return ann_key_asc(rv.val(s)); },
+        [&](int s) { return !rv.unc(s); },
+        [&](int, uint64_t kk, bool computed) {
+            const double d = ann_key_asc_inv(kk);
+            mx = fmax(mx, d);
+            my_comp += computed;
+            my_risky += !computed && !(d > 0.0);
+        }) : -1;
+    if (my_comp) atomicAdd(&ncomp_s, my_comp);
+    if (my_risky) atomicAdd(&risky_s, my_risky);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
     __syncthreads();
     mx = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+    if (want0 > 0 && fast0 >= want0 && (int)ncomp_s >= want0 && risky_s == 0) {
+        for (int e = threadIdx.x; e < fast0; e += ROW_THREADS) {
+            const uint64_t ke = rc.key[e];
+            const int32_t se = rc.slot[e];
+            int r = 0;
+            for (int o = 0; o < fast0; ++o) { const uint64_t ko = rc.key[o]; r += (ko < ke) || (ko == ke && rc.slot[o] < se); }
+            if (r < want0) {
+                const int32_t p = Iidx[b + se];
+                const int2 q = ij[p];
+                ngi[i * nn + 1 + r] = q.x == (int)i ? q.y : q.x;
+                ngd[i * nn + 1 + r] = RA[p];
+            }
+        }
+        for (int e = want0 + threadIdx.x; e < L; e += ROW_THREADS) { ngi[i * nn + 1 + e] = 0; ngd[i * nn + 1 + e] = 0.0; }
+        return;
+    }
+    __syncthreads();
     const bool in_lds = len <= cap;
     auto key_of = [&](int s) -> uint64_t {
-        const int32_t p = Iidx[b + s];
-        double d = RA[p];
-        if (ncm[p]) d += mx;
-        return ann_key_asc(d);
+        const double d = rv.val(s);
+        const bool u = rv.unc(s);
+        return ann_key_asc(u ? d + mx : d);
     };
-    if (in_lds) {
-        for (int s = threadIdx.x; s < len; s += ROW_THREADS) keys[s] = key_of(s);
-        __syncthreads();
+    const int want = min(L, len);
+    {
+        // fast path: the nn-1 smallest by (key, slot) are among the entries below a sampled threshold
+        const int fast = want > 0 ? row_candidates(rc, len, want, key_of, [](int) { return true; },
+                                                   [&](int s, uint64_t kk, bool) { if (in_lds) keys[s] = kk; }) : -1;
+        if (fast >= want && want > 0) {
+            for (int e = threadIdx.x; e < fast; e += ROW_THREADS) {
+                const uint64_t ke = rc.key[e];
+                const int32_t se = rc.slot[e];
+                int r = 0;
+                for (int o = 0; o < fast; ++o) { const uint64_t ko = rc.key[o]; r += (ko < ke) || (ko == ke && rc.slot[o] < se); }
+                if (r < want) {
+                    const int32_t p = Iidx[b + se];
+                    const int2 q = ij[p];
+                    ngi[i * nn + 1 + r] = q.x == (int)i ? q.y : q.x;
+                    ngd[i * nn + 1 + r] = RA[p];
+                }
+            }
+            for (int e = want + threadIdx.x; e < L; e += ROW_THREADS) { ngi[i * nn + 1 + e] = 0; ngd[i * nn + 1 + e] = 0.0; }
+            return;
+        }
+        if (want <= 0 && in_lds) { /* nothing staged, nothing to select */ }
     }
     auto kf = [&](int s) -> uint64_t { return in_lds ? keys[s] : key_of(s); };
-    const int want = min(L, len);
     if (want > 0) {
         // t = np.partition(d, nn-1)[nn-1]; entries <= t, stably sorted, first nn-1.
         // Equivalent: the (nn-1) smallest by (key, slot).
@@ -258,14 +413,15 @@ extern "C" int annchor_neighbor_graph(annchor_ctx *c, int32_t nn, int64_t *ng_id
     int64_t *d_i = direct ? reinterpret_cast<int64_t *>(slot) : c->stage_out.as<int64_t>();
     double *d_d = reinterpret_cast<double *>(d_i + cells);
     ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    RowSrc rsrc;
+    ANN_TRY(ann_transpose_columns(c, &rsrc));
     {
         ProfScope ps(c, "row_topk_graph", (double)c->n * 2 * 13.0 + (double)cells * 16.0);
         const size_t tail = (((size_t)(nn - 1) * 12) + 15) & ~(size_t)15;
-        const int cap = row_lds_cap(c->nx, tail);
+        const int cap = rsrc.T ? 2 : row_lds_cap(c->nx, tail);
         ANN_TRY(row_lds_prepare(c, k_get_nn, (size_t)cap * 8 + tail));
         k_get_nn<<<(int)c->nx, ROW_THREADS, (size_t)cap * 8 + tail, c->stream>>>(
-            c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(), c->RA.as<double>(), c->ncm.as<uint8_t>(), c->ij.as<int2>(), nn, d_i,
-            d_d, cap);
+            c->Iptr.as<int64_t>(), rsrc, c->ij.as<int2>(), nn, d_i, d_d, cap);
     }
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;

@@ -116,3 +116,128 @@ template <typename KeyFn> __device__ uint64_t row_kth_key(RowSelShared &sh, int 
     }
     return sh.prefix;
 }
+
+// ---- fast path of the row selections: candidates below a sampled threshold.
+// The radix descent above walks the whole row once per key byte that varies (float64 distances:
+// seven or eight passes with LDS histogram atomics).  The rows here want their ~16-40 smallest of up
+// to ~10^4 entries, so: take 256 evenly spaced entries, let t0 be the sample's r-th smallest key
+// with r three times what the wanted count corresponds to, stream the row ONCE keeping every entry
+// with key <= t0 (a few dozen), and finish exactly among those.  If fewer than `want` or more than
+// ROWC_CAP entries qualify (ties, adversarial order) the caller falls back to the radix descent.
+#define ROWC_CAP 1024
+struct RowCand {
+    uint64_t key[ROWC_CAP];
+    int32_t slot[ROWC_CAP];
+    uint64_t samp[ROW_THREADS];
+    uint64_t t0;
+    uint32_t count;
+};
+
+// Collects the ELIGIBLE entries with key <= t0 into rc (any order); returns their number, or -1 when
+// it exceeds ROWC_CAP.  Uniform result.  key(s) -> uint64 key of entry s; elig(s) -> bool (entries that
+// may be selected at all, e.g. the not-computed ones); visit(s, key, eligible) is called once for every
+// entry, so callers count / reduce what they need in the same pass.
+template <typename KeyFn, typename EligFn, typename Visit>
+__device__ int row_candidates(RowCand &rc, int len, int want, KeyFn key, EligFn elig, Visit visit)
+{
+    if (threadIdx.x == 0) { rc.count = 0; rc.t0 = ~0ull; }
+    __syncthreads();
+    if (len > ROWC_CAP) {
+        const int s0 = (int)(((int64_t)threadIdx.x * len) / ROW_THREADS);
+        const uint64_t mine = elig(s0) ? key(s0) : ~0ull;   // ineligible entries sort last in the sample
+        rc.samp[threadIdx.x] = mine;
+        __syncthreads();
+        int r = (int)((3ll * want * ROW_THREADS + len - 1) / len) + 3;
+        if (r < ROW_THREADS) {
+            int less = 0;
+            for (int o = 0; o < ROW_THREADS; ++o) {
+                const uint64_t ko = rc.samp[o];
+                less += (ko < mine) || (ko == mine && o < (int)threadIdx.x);
+            }
+            if (less == r) rc.t0 = mine;   // ranks are a permutation: exactly one thread
+        }
+        __syncthreads();
+    }
+    const uint64_t t0 = rc.t0;
+    // four entries per thread per trip, their loads issued together (clamped index: no branch around a load)
+    for (int s0 = threadIdx.x; s0 < len; s0 += 4 * ROW_THREADS) {
+        uint64_t kk[4];
+        bool el[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = min(s0 + u * ROW_THREADS, len - 1);
+            kk[u] = key(s);
+            el[u] = elig(s);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + u * ROW_THREADS;
+            if (s < len) {
+                visit(s, kk[u], el[u]);
+                if (el[u] && kk[u] <= t0) {
+                    const uint32_t o = atomicAdd(&rc.count, 1u);
+                    if (o < ROWC_CAP) { rc.key[o] = kk[u]; rc.slot[o] = s; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t c = rc.count;
+    return c > ROWC_CAP ? -1 : (int)c;
+}
+
+// Where a row kernel takes the values of row i from.  Row i of the CSR index lists first its
+// "column-like" entries -- pairs (j, i), j < i: one 8-byte value in each of `low` different rows of the
+// pair list, i.e. one 64-byte line per value -- then its "row-like" entries (i, j), j > i, which are
+// contiguous in the pair list.  For large pair lists the column-like halves are first transposed into
+// the column-ordered copy T (ann_transpose_columns: tiled, coalesced on both sides), so that both
+// halves stream; small lists (everything L2 / MALL resident) are gathered through Iidx as before.
+struct RowSrc {
+    const double *RA;
+    const uint8_t *ncm;
+    const int32_t *Iidx;
+    const double *T;        // nullptr: gather through Iidx
+    const uint8_t *Tm;
+    const int64_t *rowstart;
+    const int32_t *low;
+};
+
+struct RowView {
+    const double *RA, *Tv;
+    const uint8_t *ncm, *Tm;
+    const int32_t *idx;
+    int low;
+    bool direct;
+    __device__ __forceinline__ double val(int s) const
+    {
+        if (!direct) return RA[idx[s]];
+        const double *p = s < low ? Tv + s : RA + (s - low);   // select the address, one load
+        return *p;
+    }
+    __device__ __forceinline__ bool unc(int s) const
+    {
+        if (!direct) return ncm[idx[s]] != 0;
+        const uint8_t *p = s < low ? Tm + s : ncm + (s - low);
+        return *p != 0;
+    }
+};
+
+__device__ __forceinline__ RowView row_view(const RowSrc &src, int64_t i, int64_t b /* Iptr[i] */)
+{
+    RowView v;
+    v.idx = src.Iidx + b;
+    v.direct = src.T != nullptr;
+    v.low = 0;
+    v.RA = src.RA; v.ncm = src.ncm; v.Tv = nullptr; v.Tm = nullptr;
+    if (v.direct) {
+        const int64_t rs = src.rowstart[i];
+        v.low = src.low[i];
+        v.Tv = src.T + (b - rs);     // colbase(i) = Iptr[i] - rowstart[i]
+        v.Tm = src.Tm + (b - rs);
+        v.RA = src.RA + rs;
+        v.ncm = src.ncm + rs;
+    }
+    return v;
+}
+
+int ann_transpose_columns(annchor_ctx *c, RowSrc *src, bool with_values = true);   // refine.hip: fills T / Tm when the list is large, sets *src

@@ -20,24 +20,40 @@
 #include "rowsel.h"
 
 // ------------------------------------------------------------------- thresholds
-__global__ __launch_bounds__(ROW_THREADS) void k_row_thresh(const int64_t *__restrict__ Iptr, const int32_t *__restrict__ Iidx,
-                                                           const double *__restrict__ RA, uint32_t k,
+__global__ __launch_bounds__(ROW_THREADS) void k_row_thresh(const int64_t *__restrict__ Iptr, RowSrc src, uint32_t k,
                                                            double *__restrict__ thresh, int cap)
 {
     __shared__ RowSelShared sh;
+    __shared__ RowCand rc;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_rt[];
-    uint64_t *keys = reinterpret_cast<uint64_t *>(dyn_rt);   // [cap]
+    uint64_t *keys = reinterpret_cast<uint64_t *>(dyn_rt);   // [cap] (fallback path only)
     const int64_t i = row_of_block(gridDim.x);
     const int64_t b = Iptr[i];
     const int len = (int)(Iptr[i + 1] - b);
     if (len <= 0) { if (threadIdx.x == 0) thresh[i] = -INFINITY; return; }  // empty row (query form): never the max
+    const RowView rv = row_view(src, i, b);
+    const uint32_t kk = k >= (uint32_t)len ? (uint32_t)len - 1 : k;   // clamped like row_kth_key
+    {
+        // fast path: the k+1 smallest are among the entries below a sampled threshold
+        const int cnt = row_candidates(rc, len, (int)kk + 1, [&](int s) { return ann_key_asc(rv.val(s)); }, [](int) { return true; },
+                                       [](int, uint64_t, bool) {});
+        if (cnt > (int)kk) {
+            for (int e = threadIdx.x; e < cnt; e += ROW_THREADS) {
+                const uint64_t ke = rc.key[e];
+                uint32_t less = 0, leq = 0;
+                for (int o = 0; o < cnt; ++o) { const uint64_t ko = rc.key[o]; less += ko < ke; leq += ko <= ke; }
+                if (less <= kk && kk < leq) thresh[i] = ann_key_asc_inv(ke);   // every writer holds the same value
+            }
+            return;
+        }
+    }
     uint64_t res;
     if (len <= cap) {
-        for (int s = threadIdx.x; s < len; s += ROW_THREADS) keys[s] = ann_key_asc(RA[Iidx[b + s]]);
+        for (int s = threadIdx.x; s < len; s += ROW_THREADS) keys[s] = ann_key_asc(rv.val(s));
         __syncthreads();
         res = row_kth_key(sh, len, k, [&](int s) { return keys[s]; });
     } else {
-        res = row_kth_key(sh, len, k, [&](int s) { return ann_key_asc(RA[Iidx[b + s]]); });
+        res = row_kth_key(sh, len, k, [&](int s) { return ann_key_asc(rv.val(s)); });
     }
     if (threadIdx.x == 0) thresh[i] = ann_key_asc_inv(res);
 }
@@ -45,16 +61,16 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row_thresh(const int64_t *__res
 // -------------------------------------------------------------- guarantee_nmin
 // per row: number of computed entries and the L smallest not-computed entries
 // sorted by (value, slot)
-__global__ __launch_bounds__(ROW_THREADS) void k_gn_lists(const int64_t *__restrict__ Iptr, const int32_t *__restrict__ Iidx,
-                                                         const double *__restrict__ RA, const uint8_t *__restrict__ ncm,
+__global__ __launch_bounds__(ROW_THREADS) void k_gn_lists(const int64_t *__restrict__ Iptr, RowSrc src,
                                                          const int2 *__restrict__ ij, int L, double *__restrict__ gl_val,
                                                          int32_t *__restrict__ gl_pos, int32_t *__restrict__ gl_oth,
                                                          int32_t *__restrict__ gl_cnt, int32_t *__restrict__ gl_ncomp, int cap)
 {
     __shared__ RowSelShared sh;
+    __shared__ RowCand rc;
     __shared__ uint32_t cnt_lt, n_unc_s;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    uint64_t *keys = reinterpret_cast<uint64_t *>(dyn);       // [cap]
+    uint64_t *keys = reinterpret_cast<uint64_t *>(dyn);       // [cap] (fallback path only)
     uint64_t *lkey = keys + cap;                              // [L]
     int32_t *lslot = reinterpret_cast<int32_t *>(lkey + L);   // [L]
     const int64_t i = row_of_block(gridDim.x);
@@ -62,24 +78,45 @@ __global__ __launch_bounds__(ROW_THREADS) void k_gn_lists(const int64_t *__restr
     const int len = (int)(Iptr[i + 1] - b);
     const bool in_lds = len <= cap;
     const uint64_t KINF = ~0ull;  // computed entries sort last
+    const RowView rv = row_view(src, i, b);
+    const int32_t *Iidx = src.Iidx;
     auto key_of = [&](int s) -> uint64_t {
-        const int32_t p = Iidx[b + s];
-        return ncm[p] ? ann_key_asc(RA[p]) : KINF;
+        const double v = rv.val(s);      // both loads issued, then the select
+        const bool u = rv.unc(s);
+        return u ? ann_key_asc(v) : KINF;
     };
     if (threadIdx.x == 0) { cnt_lt = 0; n_unc_s = 0; }
     __syncthreads();
     uint32_t my_unc = 0;
-    for (int s = threadIdx.x; s < len; s += ROW_THREADS) {
-        const uint64_t kk = key_of(s);
-        if (in_lds) keys[s] = kk;
-        my_unc += kk != KINF;
-    }
+    // one streaming pass: count the not-computed entries, keep those below a sampled threshold
+    const int fast = row_candidates(rc, len, L, [&](int s) { return ann_key_asc(rv.val(s)); }, [&](int s) { return rv.unc(s); },
+                                    [&](int s, uint64_t kk, bool un) {
+        if (in_lds) keys[s] = un ? kk : KINF;
+        my_unc += un;
+    });
     if (my_unc) atomicAdd(&n_unc_s, my_unc);
     __syncthreads();
     const int n_unc = (int)n_unc_s;
     const int want = min(L, n_unc);
     if (threadIdx.x == 0) { gl_cnt[i] = want; gl_ncomp[i] = len - n_unc; }
     if (want == 0) return;
+    if (fast >= want) {
+        // the `want` smallest by (key, slot) are the candidates of rank < want
+        for (int e = threadIdx.x; e < fast; e += ROW_THREADS) {
+            const uint64_t ke = rc.key[e];
+            const int32_t se = rc.slot[e];
+            int r = 0;
+            for (int o = 0; o < fast; ++o) { const uint64_t ko = rc.key[o]; r += (ko < ke) || (ko == ke && rc.slot[o] < se); }
+            if (r < want) {
+                const int32_t p = Iidx[b + se];
+                const int2 q = ij[p];
+                gl_val[i * L + r] = ann_key_asc_inv(ke);
+                gl_pos[i * L + r] = p;
+                gl_oth[i * L + r] = q.x == (int)i ? q.y : q.x;
+            }
+        }
+        return;
+    }
     auto kf = [&](int s) -> uint64_t { return in_lds ? keys[s] : key_of(s); };
     const uint64_t t = row_kth_key(sh, len, (uint32_t)(want - 1), kf);
     // strictly smaller entries (at most want-1 of them), any order
@@ -682,13 +719,14 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     const int64_t n = c->n, nx = c->nx;
     ANN_TRY(ann_reserve(c, c->thresh, sizeof(double) * (size_t)nx));
     ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    RowSrc rsrc;
+    ANN_TRY(ann_transpose_columns(c, &rsrc));   // large lists: column-ordered copy of the column-like halves (shared by the two row kernels below)
     {
         // algorithmic bytes: every pair value is read from both of its rows: 2n * (8 + 4)
         ProfScope ps(c, "row_kth_threshold", (double)n * 24.0);
-        const int cap = row_lds_cap(nx, 0);
+        const int cap = rsrc.T ? 2 : row_lds_cap(nx, 0);   // streamed rows: no LDS copy (a rare fallback row re-reads global memory)
         ANN_TRY(row_lds_prepare(c, k_row_thresh, (size_t)cap * 8));
-        k_row_thresh<<<(int)nx, ROW_THREADS, (size_t)cap * 8, c->stream>>>(c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(),
-                                                                         c->RA.as<double>(), (uint32_t)n_neighbors,
+        k_row_thresh<<<(int)nx, ROW_THREADS, (size_t)cap * 8, c->stream>>>(c->Iptr.as<int64_t>(), rsrc, (uint32_t)n_neighbors,
                                                                          c->thresh.as<double>(), cap);
     }
     if (nmin > 0) {
@@ -707,10 +745,10 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         {
             ProfScope ps(c, "guarantee_nmin_lists", (double)n * 26.0);
             const size_t tail = (((size_t)L * 12) + 15) & ~(size_t)15;
-            const int cap = row_lds_cap(nx, tail);
+            const int cap = rsrc.T ? 2 : row_lds_cap(nx, tail);
             ANN_TRY(row_lds_prepare(c, k_gn_lists, (size_t)cap * 8 + tail));
             k_gn_lists<<<(int)nx, ROW_THREADS, (size_t)cap * 8 + tail, c->stream>>>(
-                c->Iptr.as<int64_t>(), c->Iidx.as<int32_t>(), c->RA.as<double>(), c->ncm.as<uint8_t>(), c->ij.as<int2>(), L,
+                c->Iptr.as<int64_t>(), rsrc, c->ij.as<int2>(), L,
                 c->gl_val.as<double>(), c->gl_pos.as<int32_t>(), c->gl_pos.as<int32_t>() + (size_t)nx * L,
                 c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(), cap);
         }
