@@ -93,6 +93,7 @@ _SIGNATURES = {
     "annchor_device_alloc": (ctypes.c_int, [_vp, _i64, ctypes.POINTER(_vp)]),
     "annchor_device_free": (ctypes.c_int, [_vp, _vp]),
     "annchor_device_copy": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32]),
+    "annchor_graph_to_coo": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "annchor_field_size": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_i64)]),
     "annchor_download": (ctypes.c_int, [_vp, _i32, _vp, _i64]),
     "annchor_upload": (ctypes.c_int, [_vp, _i32, _vp, _i64]),
@@ -587,6 +588,17 @@ class Engine:
 
     def device_copy(self, dst, src, nbytes, kind):
         self._chk(self.lib.annchor_device_copy(self.h, dst, src, int(nbytes), {"h2d": 1, "d2h": 2, "d2d": 3}[kind]))
+
+    def graph_to_coo(self, idx, dist):
+        """Symmetric COO (rows, cols, vals) of a k-NN graph, every cell once, vals = distance + eps."""
+        idx, dist = _c(idx, np.int64), _c(dist, np.float64)
+        nx, k = idx.shape
+        rows, cols = np.empty(2 * nx * k, dtype=np.int64), np.empty(2 * nx * k, dtype=np.int64)
+        vals = np.empty(2 * nx * k, dtype=np.float64)
+        nnz = _i64()
+        self._chk(self.lib.annchor_graph_to_coo(self.h, _ptr(idx), _ptr(dist), nx, k, _ptr(rows), _ptr(cols), _ptr(vals), ctypes.byref(nnz)))
+        n = nnz.value
+        return rows[:n], cols[:n], vals[:n]
 
     # ---------------------------------------------------------- state access
     def field_size(self, field):

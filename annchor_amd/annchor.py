@@ -570,23 +570,30 @@ class Annchor:
 
     def to_sparse_matrix(self):
         """annchor.py:625-641: DOK sparse distance matrix of the k-NN graph (symmetric; every
-        stored entry carries eps = nextafter(0, 1) so that explicit zeros survive).  Built from
-        flat arrays (the reference fills the DOK cell by cell); where a pair is listed from both
-        sides the later row's value wins, as in the reference's loop order."""
+        stored entry carries eps = nextafter(0, 1) so that explicit zeros survive; where a pair is
+        listed from both sides the later row's value wins, as in the reference's loop order).
+        The symmetric COO form is emitted on the device (annchor_graph_to_coo), each cell once."""
         from scipy.sparse import coo_matrix
 
         idx, dist = self.neighbor_graph
+        nx = idx.shape[0]
+        rows, cols, vals = self._engine.graph_to_coo(idx, dist)
+        return coo_matrix((vals, (rows, cols)), shape=(nx, nx), dtype=np.float64).todok()
+
+    @staticmethod
+    def _sparse_from_graph_host(idx, dist):
+        """The same matrix from flat NumPy arrays (test cross-check of the device emission)."""
+        from scipy.sparse import coo_matrix
+
         nx, k = idx.shape
         eps = np.nextafter(0, 1, dtype=np.float64)
         i = np.repeat(np.arange(nx, dtype=np.int64), k)
         j = idx.ravel().astype(np.int64)
         v = dist.ravel() + eps
-        # reference order of assignments: for i, for j in row i: D[i, j] = D[j, i] = v
         rows = np.stack([i, j], axis=1).ravel()
         cols = np.stack([j, i], axis=1).ravel()
         vals = np.repeat(v, 2)
         key = rows * nx + cols
-        # keep the LAST assignment of every cell
         order = np.argsort(key, kind="stable")
         ks = key[order]
         last = np.ones(ks.shape[0], dtype=bool)

@@ -74,6 +74,64 @@ __global__ __launch_bounds__(256) void k_features(const int2 *__restrict__ ij, i
     ncm[p] = !isa;
 }
 
+
+// Tiled form for large pair lists.  k_features above gathers D[a][j] once per (pair, anchor): 48
+// eight-byte loads per pair from L2, the kernel's limit at scale (21 % of HBM at 127 M pairs).  Here a
+// wave owns 64 consecutive columns j and keeps THEIR anchor distances in registers (na doubles per
+// lane, loaded once, coalesced), then walks FT_ROWS rows i: D[a][i] is wave-uniform (scalar loads),
+// the pair position comes from the keep bitmap's popcount ranks (no read of ij[] at all), and the
+// outputs of a row are consecutive addresses.  Per pair: 2 gathers (the two dad terms) + the stores.
+#define FT_ROWS 16
+template <int NA_MAX> __global__ __launch_bounds__(256) void k_features_tiled(
+    const uint64_t *__restrict__ K, const uint32_t *__restrict__ pref, int kw, const int32_t *__restrict__ low,
+    const int64_t *__restrict__ rowstart, const double *__restrict__ Dt, int64_t nx, int na, const int32_t *__restrict__ cA,
+    const int32_t *__restrict__ anchorRank, double *__restrict__ lb, double *__restrict__ ub, double *__restrict__ dad,
+    uint8_t *__restrict__ anc, uint8_t *__restrict__ ncm)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform for the compiler too: row data goes through scalar loads
+    const int nrb = (int)((nx + FT_ROWS - 1) / FT_ROWS);
+    // task = (row block rb, column word jb) with jb >= first word that can hold j > i; tasks are laid out
+    // row-block major so that neighbouring waves share the rows' scalar loads through the scalar cache
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t rb = task / kw;
+    const int jb = (int)(task - rb * kw);
+    if (rb >= nrb) return;
+    const int64_t i_lo = rb * FT_ROWS, i_hi = min(i_lo + FT_ROWS, nx);
+    if ((int64_t)jb * 64 + 63 <= i_lo) return;   // no column of this word lies right of the block's first row
+    const int64_t j = (int64_t)jb * 64 + lane;
+    const int64_t jc = min(j, nx - 1);
+    double dj[NA_MAX];
+#pragma unroll
+    for (int a = 0; a < NA_MAX; ++a) dj[a] = a < na ? Dt[(size_t)a * nx + jc] : 0.0;
+    const int caj = cA[jc];
+    const bool ancj = anchorRank[jc] >= 0;
+    for (int64_t i = i_lo; i < i_hi; ++i) {
+        const uint64_t bits = K[i * kw + jb];                       // wave-uniform
+        const bool mine = j > i && j < nx && ((bits >> lane) & 1ull);
+        if (!__any(mine)) continue;
+        const int64_t pos = rowstart[i] + ((int64_t)pref[i * kw + jb] + __popcll(bits & ((1ull << lane) - 1ull)) - low[i]);
+        double l = 0.0, u = INFINITY;
+#pragma unroll
+        for (int a = 0; a < NA_MAX; ++a) {
+            if (a < na) {
+                const double di = Dt[(size_t)a * nx + i];           // uniform address: scalar load
+                l = fmax(l, fabs(di - dj[a]));
+                u = fmin(u, di + dj[a]);
+            }
+        }
+        if (mine) {
+            const int cai = cA[i];
+            lb[pos] = l;
+            ub[pos] = u;
+            dad[pos] = (Dt[(size_t)caj * nx + i] + Dt[(size_t)cai * nx + j]) / 2;
+            const uint8_t isa = (anchorRank[i] >= 0) | ancj;
+            anc[pos] = isa;
+            ncm[pos] = !isa;
+        }
+    }
+}
+
 extern "C" int annchor_compute_features(annchor_ctx *c)
 {
     if (!c) return ANNCHOR_EINVAL;
@@ -92,6 +150,20 @@ extern "C" int annchor_compute_features(annchor_ctx *c)
     {
         // algorithmic bytes per pair: 8 (ij) + 3*8 (lb, ub, dad) + 2 (masks)
         ProfScope ps(c, "bounds_dad_features", (double)n * 34.0);
+        static const long long tiled_min = getenv("ANNCHOR_FEATURES_TILED_MIN") ? atoll(getenv("ANNCHOR_FEATURES_TILED_MIN")) : (8ll << 20);
+        if (c->have_bitmap && c->n >= tiled_min && c->na <= 64) {
+            const int kw = (int)((c->nx + 63) / 64);
+            const int64_t tasks = ((c->nx + FT_ROWS - 1) / FT_ROWS) * kw;
+            const unsigned grid = (unsigned)((tasks + 3) / 4);
+#define FT_LAUNCH(NAM) k_features_tiled<NAM><<<grid, 256, 0, c->stream>>>(c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), kw, \
+                c->low.as<int32_t>(), c->rowstart.as<int64_t>(), c->Dt.as<double>(), c->nx, c->na, c->cA.as<int32_t>(), \
+                c->anchorRank.as<int32_t>(), c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>(), c->anc.as<uint8_t>(), \
+                c->ncm.as<uint8_t>())
+            if (c->na <= 16) FT_LAUNCH(16);
+            else if (c->na <= 32) FT_LAUNCH(32);
+            else FT_LAUNCH(64);
+#undef FT_LAUNCH
+        } else
         k_features<<<ann_blocks(c->n, 256), 256, 0, c->stream>>>(c->ij.as<int2>(), c->n, c->Dt.as<double>(), c->nx, c->na,
                                                                 c->cA.as<int32_t>(), c->anchorRank.as<int32_t>(),
                                                                 c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>(),

@@ -534,25 +534,162 @@ struct CutState {
     int64_t e1, e5;         // how many entries equal to the cut are taken
     int64_t ncand, nnext;
     int all1, all5;         // take every not-computed pair
+    // Second key inside the group of pairs whose probability EQUALS the cut (the ECDF takes a few
+    // thousand distinct values for ~10^6 pairs, so that group is hundreds to thousands of pairs; the
+    // reference's argpartition picks among them arbitrarily).  By position the rest of the budget
+    // would all go to the first rows of the pair list; by predicted distance the population the next
+    // model is fitted on gets biased (query recall 0.96-0.98 instead of 1.0 on the reference's digits
+    // test).  So: a fixed pseudo-random order, ann_tie_scramble(position) ascending, then position.
+    // rk = scrambled-position cut inside the group (~0: the whole group is taken); "above the cut" =
+    // prob > t || (prob == t && scramble(p) < rk), "on the cut" = prob == t && scramble(p) == rk
+    // (taken in position order, e of them).
+    unsigned long long rk1, rk5;
+    int64_t tie_n1, tie_n5;       // sizes of the two groups
+    int64_t tie_gt1, tie_gt5;     // pairs with prob > t
+    int tie_overflow;             // a group did not fit TIE_CAP: the host resolves it with the general selection
 };
 
-__global__ __launch_bounds__(CP_THREADS) void k_cut_count(const double *__restrict__ prob, int64_t n,
+#define TIE_CAP 65536
+
+// (position * 0x9E3779B97F4A7C15 mod 2^64) >> 11
+__host__ __device__ __forceinline__ unsigned long long ann_tie_scramble(int64_t p)
+{
+    return ((unsigned long long)p * 0x9E3779B97F4A7C15ull) >> 11;
+}
+
+// groups of the two cuts: sizes, members' scrambled positions, and the number of pairs above each cut
+__global__ __launch_bounds__(256) void k_tie_collect(const double *__restrict__ prob, const double *__restrict__ RA, int64_t n,
+                                                    CutState *__restrict__ cs, unsigned long long *__restrict__ list1,
+                                                    unsigned long long *__restrict__ list5, long long cap)
+{
+    __shared__ unsigned long long acc[2];
+    if (threadIdx.x < 2) acc[threadIdx.x] = 0;
+    __syncthreads();
+    const double t1 = cs->t1, t5 = cs->t5;
+    const bool need1 = !cs->all1, need5 = !cs->all5;
+    unsigned long long g1 = 0, g5 = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x * 4 + threadIdx.x; p0 < n; p0 += stride) {
+        double v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ann_ldc(prob, p0 + (int64_t)e * blockDim.x, n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t p = p0 + (int64_t)e * blockDim.x;
+            if (p >= n || !(v[e] >= 0.0)) continue;
+            g1 += v[e] > t1;
+            g5 += v[e] > t5;
+            if ((need1 && v[e] == t1) || (need5 && v[e] == t5)) {
+                const unsigned long long kk = ann_tie_scramble(p);
+                if (need1 && v[e] == t1) {
+                    const unsigned long long o = atomicAdd((unsigned long long *)&cs->tie_n1, 1ull);
+                    if ((long long)o < cap) list1[o] = kk;
+                }
+                if (need5 && v[e] == t5) {
+                    const unsigned long long o = atomicAdd((unsigned long long *)&cs->tie_n5, 1ull);
+                    if ((long long)o < cap) list5[o] = kk;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { g1 += __shfl_xor(g1, off); g5 += __shfl_xor(g5, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&acc[0], g1); atomicAdd(&acc[1], g5); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (acc[0]) atomicAdd((unsigned long long *)&cs->tie_gt1, acc[0]);
+        if (acc[1]) atomicAdd((unsigned long long *)&cs->tie_gt5, acc[1]);
+    }
+}
+
+__global__ void k_tie_flags(const double *__restrict__ prob, int64_t n, double t, uint8_t *__restrict__ flag, double *__restrict__ scr)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) {
+        flag[p] = prob[p] == t ? 1 : 0;   // prob >= 0 only on not-computed pairs, and t >= 0 here
+        scr[p] = (double)ann_tie_scramble(p);
+    }
+}
+
+// one workgroup: the RefineApprox key of the (K - above)-th smallest member of each group (MSB-first
+// byte radix over the group's keys)
+__global__ __launch_bounds__(1024) void k_tie_select(CutState *__restrict__ cs, const unsigned long long *__restrict__ list1,
+                                                    const unsigned long long *__restrict__ list5, long long cap)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ unsigned long long prefix_s;
+    __shared__ long long krem_s;
+    for (int q = 0; q < 2; ++q) {
+        const bool all = q == 0 ? cs->all1 : cs->all5;
+        const long long cnt = q == 0 ? cs->tie_n1 : cs->tie_n5;
+        const long long e = (q == 0 ? cs->K1 - cs->tie_gt1 : cs->K5 - cs->tie_gt5);   // members to take
+        const unsigned long long *list = q == 0 ? list1 : list5;
+        unsigned long long rk = ~0ull;
+        if (!all && e < cnt) {
+            if (cnt > cap) { rk = 0ull; if (threadIdx.x == 0) cs->tie_overflow = 1; }   // take none for now (the lists hold at most K entries): the host resolves it
+            else if (e <= 0) rk = 0ull;   // nothing of the group is taken (every key is >= 0 == rk: none below, ties at key 0 counted by e = 0)
+            else {
+                if (threadIdx.x == 0) { prefix_s = 0; krem_s = e - 1; }
+                __syncthreads();
+                for (int pass = 0; pass < 8; ++pass) {
+                    const int shift = 56 - 8 * pass;
+                    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+                    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+                    __syncthreads();
+                    const unsigned long long pre = prefix_s;
+                    for (long long t = threadIdx.x; t < cnt; t += 1024) {
+                        const unsigned long long kk = list[t];
+                        if ((kk & himask) == pre) atomicAdd(&hist[(uint32_t)(kk >> shift) & 0xffu], 1u);
+                    }
+                    __syncthreads();
+                    if (threadIdx.x == 0) {
+                        long long k = krem_s;
+                        int d = 0;
+                        for (; d < 255; ++d) { if (k < (long long)hist[d]) break; k -= hist[d]; }
+                        prefix_s = pre | ((unsigned long long)d << shift);
+                        krem_s = k;
+                    }
+                    __syncthreads();
+                }
+                rk = prefix_s;
+            }
+        }
+        if (threadIdx.x == 0) { if (q == 0) cs->rk1 = rk; else cs->rk5 = rk; }
+        __syncthreads();
+    }
+}
+
+// class of a pair against one cut: 2 = above (taken), 1 = on the cut (taken in position order), 0 = below
+__device__ __forceinline__ int cut_class(double v, double t, unsigned long long rk, const double *RA, int64_t p)
+{
+    if (v > t) return 2;
+    if (v != t) return 0;
+    if (rk == ~0ull) return 2;          // the whole group is taken
+    const unsigned long long kk = ann_tie_scramble(p);
+    return kk < rk ? 2 : (kk == rk ? 1 : 0);
+}
+
+__global__ __launch_bounds__(CP_THREADS) void k_cut_count(const double *__restrict__ prob, const double *__restrict__ RA, int64_t n,
                                                          const CutState *__restrict__ cs, uint32_t *__restrict__ blk)
 {
     __shared__ uint32_t acc[4];
     if (threadIdx.x < 4) acc[threadIdx.x] = 0;
     __syncthreads();
     const double t1 = cs->t1, t5 = cs->t5;
+    const unsigned long long rk1 = cs->rk1, rk5 = cs->rk5;
     uint32_t g1 = 0, q1 = 0, g5 = 0, q5 = 0;
     const int64_t base = (int64_t)blockIdx.x * CP_TILE;
     double v[CP_ITEMS];
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; ++k) v[k] = ann_ldc(prob, base + (int64_t)k * CP_THREADS + threadIdx.x, n);   // one batch in flight
 #pragma unroll
-    for (int k = 0; k < CP_ITEMS; ++k)
-        if (base + (int64_t)k * CP_THREADS + threadIdx.x < n && v[k] >= 0.0) {
-            g1 += v[k] > t1; q1 += v[k] == t1; g5 += v[k] > t5; q5 += v[k] == t5;
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        const int64_t p = base + (int64_t)k * CP_THREADS + threadIdx.x;
+        if (p < n && v[k] >= 0.0) {
+            const int c1 = cut_class(v[k], t1, rk1, RA, p), c5 = cut_class(v[k], t5, rk5, RA, p);
+            g1 += c1 == 2; q1 += c1 == 1; g5 += c5 == 2; q5 += c5 == 1;
         }
+    }
     // four 8-bit-per-item counters packed into one wave reduction (each <= 64 * CP_ITEMS = 512 < 2^16)
     unsigned long long pk = (unsigned long long)g1 | ((unsigned long long)q1 << 16) | ((unsigned long long)g5 << 32) |
                             ((unsigned long long)q5 << 48);
@@ -652,21 +789,28 @@ __global__ __launch_bounds__(CS_THREADS) void k_cut_scan(const uint32_t *__restr
     if (threadIdx.x == 0) { cs->e1 = e1; cs->e5 = e5; cs->ncand = (int64_t)(c_out & 0xffffffffull); cs->nnext = (int64_t)(c_out >> 32); }
 }
 
-__global__ __launch_bounds__(CP_THREADS) void k_cut_emit(const double *__restrict__ prob, int64_t n,
+__global__ __launch_bounds__(CP_THREADS) void k_cut_emit(const double *__restrict__ prob, const double *__restrict__ RA, int64_t n,
                                                         const CutState *__restrict__ cs, const int64_t *__restrict__ off,
                                                         int32_t *__restrict__ cand, int32_t *__restrict__ next)
 {
     __shared__ uint32_t wsum[CP_THREADS / 64];
     const double t1 = cs->t1, t5 = cs->t5;
+    const unsigned long long rk1 = cs->rk1, rk5 = cs->rk5;
     const int64_t e1 = cs->e1, e5 = cs->e5;
     const bool both_all = cs->all1 && cs->all5;
     const int64_t base = (int64_t)blockIdx.x * CP_TILE + (int64_t)threadIdx.x * CP_ITEMS;  // thread-contiguous: keeps position order
     double v[CP_ITEMS];
+    int8_t k1[CP_ITEMS], k5[CP_ITEMS];
     uint32_t q1 = 0, q5 = 0;
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; ++k) {
         v[k] = (base + k < n) ? prob[base + k] : -1.0;
-        if (v[k] >= 0.0) { q1 += v[k] == t1; q5 += v[k] == t5; }
+        k1[k] = k5[k] = 0;
+        if (v[k] >= 0.0) {
+            k1[k] = (int8_t)cut_class(v[k], t1, rk1, RA, base + k);
+            k5[k] = (int8_t)cut_class(v[k], t5, rk5, RA, base + k);
+            q1 += k1[k] == 1; q5 += k5[k] == 1;
+        }
     }
     auto scan2 = [&](uint32_t a, uint32_t b, uint32_t *ea, uint32_t *eb) {
         // packs two counters (each < 2^16 per block) into one 32-bit scan
@@ -685,10 +829,10 @@ __global__ __launch_bounds__(CP_THREADS) void k_cut_emit(const double *__restric
     for (int k = 0; k < CP_ITEMS; ++k) {
         bool c1 = false, c5 = false;
         if (v[k] >= 0.0) {
-            c1 = v[k] > t1 || (v[k] == t1 && r1 < e1);
-            c5 = v[k] > t5 || (v[k] == t5 && r5 < e5);
-            r1 += v[k] == t1;
-            r5 += v[k] == t5;
+            c1 = k1[k] == 2 || (k1[k] == 1 && r1 < e1);
+            c5 = k5[k] == 2 || (k5[k] == 1 && r5 < e5);
+            r1 += k1[k] == 1;
+            r5 += k5[k] == 1;
         }
         fc[k] = c1;
         fn[k] = both_all ? c5 : (c5 && !c1);
@@ -833,14 +977,29 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     const int64_t maxc = cs.all1 ? n_unc : cs.K1, maxn = cs.all5 ? n_unc : cs.K5;
     ANN_TRY(ann_reserve(c, c->cand, sizeof(int32_t) * (size_t)(maxc + 1)));
     ANN_TRY(ann_reserve(c, c->next, sizeof(int32_t) * (size_t)(maxn + 1)));
+    cs.rk1 = cs.rk5 = ~0ull;
     ANN_TRY(ann_h2d(c, c->sel_state.p, &cs, sizeof cs));
-    {
+    const bool ties = n_refine > 0 && !(cs.all1 && cs.all5);
+    ANN_TRY(ann_reserve(c, c->tie_lists, sizeof(unsigned long long) * 2 * TIE_CAP));
+    unsigned long long *tl1 = c->tie_lists.as<unsigned long long>(), *tl5 = tl1 + TIE_CAP;
+    auto split = [&]() {
         ProfScope ps(c, "topk_split_compact", (double)n * 16.0 + (double)(maxc + maxn) * 4.0);
-        k_cut_count<<<nb, CP_THREADS, 0, c->stream>>>(c->prob.as<double>(), n, c->sel_state.as<CutState>(), c->blk_cnt.as<uint32_t>());
+        k_cut_count<<<nb, CP_THREADS, 0, c->stream>>>(c->prob.as<double>(), c->RA.as<double>(), n, c->sel_state.as<CutState>(),
+                                                     c->blk_cnt.as<uint32_t>());
         k_cut_scan<<<1, CS_THREADS, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nb, c->sel_state.as<CutState>(), c->blk_off.as<int64_t>());
-        k_cut_emit<<<nb, CP_THREADS, 0, c->stream>>>(c->prob.as<double>(), n, c->sel_state.as<CutState>(), c->blk_off.as<int64_t>(),
-                                                    c->cand.as<int32_t>(), c->next.as<int32_t>());
+        k_cut_emit<<<nb, CP_THREADS, 0, c->stream>>>(c->prob.as<double>(), c->RA.as<double>(), n, c->sel_state.as<CutState>(),
+                                                    c->blk_off.as<int64_t>(), c->cand.as<int32_t>(), c->next.as<int32_t>());
+    };
+    if (ties) {
+        // the groups on the two cuts and their RefineApprox cuts (device only: no host wait)
+        ProfScope ps(c, "topk_tie_groups", (double)n * 8.0);
+        const int tb = (int)std::min<int64_t>(ann_blocks(n, 256 * 4), 256);
+        const char *cap_env = getenv("ANNCHOR_TIE_CAP");   // tests force the large-group route on small inputs
+        const long long cap = cap_env ? std::min<long long>(TIE_CAP, std::max<long long>(1, atoll(cap_env))) : TIE_CAP;
+        k_tie_collect<<<tb, 256, 0, c->stream>>>(c->prob.as<double>(), c->RA.as<double>(), n, c->sel_state.as<CutState>(), tl1, tl5, cap);
+        k_tie_select<<<1, 1024, 0, c->stream>>>(c->sel_state.as<CutState>(), tl1, tl5, cap);
     }
+    split();
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;
     ANN_CHECK_HIP(c, hipGetLastError());
@@ -849,6 +1008,34 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         ANN_TRY(ann_d2h2(c, &cs, c->sel_state.p, sizeof cs, &e, c->tmp2.as<int32_t>() + 8, 4));
         ANN_REQUIRE(c, e == 0, ANNCHOR_ESTATE, "guarantee_nmin: a row has fewer not-computed candidates than it must refine");
     } else {
+        ANN_TRY(ann_d2h(c, &cs, c->sel_state.p, sizeof cs));
+    }
+    if (cs.tie_overflow) {
+        // a group on a cut larger than TIE_CAP (e.g. a third of the pool at probability 0): its RefineApprox
+        // cut comes from the general selection over all pairs, then the split is redone
+        ANN_TRY(ann_reserve(c, c->marked, (size_t)n));
+        for (int q = 0; q < 2; ++q) {
+            const bool all = q == 0 ? cs.all1 : cs.all5;
+            const int64_t cnt = q == 0 ? cs.tie_n1 : cs.tie_n5, e = q == 0 ? cs.K1 - cs.tie_gt1 : cs.K5 - cs.tie_gt5;
+            unsigned long long rk = ~0ull;
+            if (!all && e < cnt) {
+                if (e <= 0) rk = 0ull;
+                else {
+                    ANN_TRY(ann_reserve(c, c->colT, sizeof(double) * (size_t)n));   // scratch: the scrambled positions as doubles (53 bits: exact)
+                    k_tie_flags<<<ann_blocks(n, 256), 256, 0, c->stream>>>(c->prob.as<double>(), n, q == 0 ? cs.t1 : cs.t5, c->marked.as<uint8_t>(),
+                                                                          c->colT.as<double>());
+                    int64_t kq = e - 1;
+                    double rv = 0;
+                    ANN_TRY(ann_kth_smallest(c, c->colT.as<double>(), c->marked.as<uint8_t>(), n, &kq, 1, &rv));
+                    rk = (unsigned long long)rv;
+                }
+            }
+            if (q == 0) cs.rk1 = rk; else cs.rk5 = rk;
+        }
+        cs.tie_overflow = 0; cs.e1 = cs.e5 = 0; cs.ncand = cs.nnext = 0;
+        ANN_TRY(ann_h2d(c, c->sel_state.p, &cs, sizeof cs));
+        split();
+        ANN_CHECK_HIP(c, hipGetLastError());
         ANN_TRY(ann_d2h(c, &cs, c->sel_state.p, sizeof cs));
     }
     c->ncand = cs.ncand;

@@ -140,3 +140,82 @@ extern "C" int annchor_upload(annchor_ctx *c, int32_t field, const void *src, in
     default: ann_set_err(c, "field %d is not uploadable", field); return ANNCHOR_EINVAL;
     }
 }
+
+
+// ------------------------------------------------------------------ to_sparse_matrix (f3)
+// Annchor.to_sparse_matrix (reference annchor/annchor.py:625-641) fills a DOK matrix cell by cell:
+//     for i: for (j, d) in row i of the graph:  D[i, j] = D[j, i] = d + eps
+// (eps = nextafter(0, 1): explicit zeros survive).  A later assignment overwrites an earlier one, so
+// when i lists j AND j lists i, both cells end up with the value of the listing of the LARGER row.
+// Device form: one thread per listing (i, c); a listing is dead iff j > i and row j lists i; live
+// listings emit (i, j, v) and (j, i, v) (once when j == i) at offsets from a prefix sum -- the
+// symmetric matrix in COO form, each cell exactly once, in (i, c) order.
+__global__ void k_sparse_count(const int64_t *__restrict__ idx, int64_t nx, int k, int32_t *__restrict__ cnt)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nx * k) return;
+    const int64_t i = t / k;
+    const int64_t j = idx[t];
+    int out = 0;
+    if (j >= 0 && j < nx) {
+        bool dead = false;
+        if (j > i)
+            for (int c = 0; c < k; ++c) dead |= idx[j * k + c] == i;
+        // a column listed twice in one row: the later listing wins (the loop order of the reference)
+        for (int c = (int)(t - i * k) + 1; c < k; ++c) dead |= idx[i * k + c] == j;
+        out = dead ? 0 : (j == i ? 1 : 2);
+    }
+    cnt[t] = out;
+}
+
+__global__ void k_sparse_emit(const int64_t *__restrict__ idx, const double *__restrict__ dist, int64_t nx, int k,
+                              const int32_t *__restrict__ cnt, const int64_t *__restrict__ off, double eps,
+                              int64_t *__restrict__ rows, int64_t *__restrict__ cols, double *__restrict__ vals)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nx * k) return;
+    const int n = cnt[t];
+    if (n == 0) return;
+    const int64_t i = t / k, j = idx[t], o = off[t];
+    const double v = dist[t] + eps;
+    rows[o] = i; cols[o] = j; vals[o] = v;
+    if (n == 2) { rows[o + 1] = j; cols[o + 1] = i; vals[o + 1] = v; }
+}
+
+extern "C" int annchor_graph_to_coo(annchor_ctx *c, const int64_t *ng_idx, const double *ng_dist, int64_t nx, int32_t k,
+                                    int64_t *rows, int64_t *cols, double *vals, int64_t *nnz)
+{
+    if (!c || !ng_idx || !ng_dist || !rows || !cols || !vals || !nnz || nx < 0 || k < 1) return ANNCHOR_EINVAL;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    const int64_t m = nx * k;
+    *nnz = 0;
+    if (m == 0) return ANNCHOR_OK;
+    ANN_REQUIRE(c, m < (1ll << 31), ANNCHOR_ELIMIT, "graph of %lld cells is too large", (long long)m);
+    void *d_idx = nullptr, *d_dist = nullptr, *d_cnt = nullptr, *d_off = nullptr, *d_out = nullptr;
+    auto release = [&]() { (void)hipFree(d_idx); (void)hipFree(d_dist); (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_out); };
+    int rc = ANNCHOR_OK;
+    do {
+        if (hipMalloc(&d_idx, 8 * (size_t)m) != hipSuccess || hipMalloc(&d_dist, 8 * (size_t)m) != hipSuccess ||
+            hipMalloc(&d_cnt, 4 * (size_t)m) != hipSuccess || hipMalloc(&d_off, 8 * (size_t)(m + 1)) != hipSuccess ||
+            hipMalloc(&d_out, 24 * 2 * (size_t)m) != hipSuccess) { ann_set_err(c, "out of device memory"); rc = ANNCHOR_EHIP; break; }
+        if ((rc = ann_h2d(c, d_idx, ng_idx, 8 * (size_t)m)) != ANNCHOR_OK) break;
+        if ((rc = ann_h2d(c, d_dist, ng_dist, 8 * (size_t)m)) != ANNCHOR_OK) break;
+        k_sparse_count<<<ann_blocks(m, 256), 256, 0, c->stream>>>((const int64_t *)d_idx, nx, k, (int32_t *)d_cnt);
+        if ((rc = ann_exclusive_scan_i32_to_i64(c, (const int32_t *)d_cnt, (int64_t *)d_off, m)) != ANNCHOR_OK) break;
+        int64_t *o_rows = (int64_t *)d_out, *o_cols = o_rows + 2 * m;
+        double *o_vals = (double *)(o_cols + 2 * m);
+        k_sparse_emit<<<ann_blocks(m, 256), 256, 0, c->stream>>>((const int64_t *)d_idx, (const double *)d_dist, nx, k, (const int32_t *)d_cnt,
+                                                                (const int64_t *)d_off, 4.9406564584124654e-324, o_rows, o_cols, o_vals);
+        if (hipGetLastError() != hipSuccess) { ann_set_err(c, "sparse emit launch failed"); rc = ANNCHOR_EHIP; break; }
+        int64_t total = 0;
+        if ((rc = ann_d2h(c, &total, (int64_t *)d_off + m, 8)) != ANNCHOR_OK) break;
+        if (total > 0) {
+            if ((rc = ann_d2h(c, rows, o_rows, 8 * (size_t)total)) != ANNCHOR_OK) break;
+            if ((rc = ann_d2h(c, cols, o_cols, 8 * (size_t)total)) != ANNCHOR_OK) break;
+            if ((rc = ann_d2h(c, vals, o_vals, 8 * (size_t)total)) != ANNCHOR_OK) break;
+        }
+        *nnz = total;
+    } while (0);
+    release();
+    return rc;
+}

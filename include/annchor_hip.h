@@ -310,6 +310,13 @@ int annchor_device_alloc(annchor_ctx *ctx, int64_t bytes, void **dptr);
 int annchor_device_free(annchor_ctx *ctx, void *dptr);
 int annchor_device_copy(annchor_ctx *ctx, void *dst, const void *src, int64_t bytes, int32_t kind /*1 H2D, 2 D2H, 3 D2D*/);
 
+/* Annchor.to_sparse_matrix (annchor/annchor.py:625-641): the symmetric sparse distance matrix of a
+ * k-NN graph (HOST arrays ng_idx int64 [nx, k], ng_dist float64 [nx, k]) in COO form: every cell once,
+ * value = distance + nextafter(0, 1), later assignments of the reference's loop order win.  rows /
+ * cols / vals are HOST arrays with room for 2 * nx * k entries; *nnz entries are written. */
+int annchor_graph_to_coo(annchor_ctx *ctx, const int64_t *ng_idx, const double *ng_dist, int64_t nx, int32_t k,
+                         int64_t *rows, int64_t *cols, double *vals, int64_t *nnz);
+
 /* -------------------------------------------------------------- state access */
 int annchor_field_size(annchor_ctx *ctx, int32_t field, int64_t *n_elems);
 int annchor_download(annchor_ctx *ctx, int32_t field, void *dst, int64_t n_elems);

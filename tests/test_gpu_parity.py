@@ -547,8 +547,8 @@ def test_query_reference_digits_split():
 
 def test_query_reference_strings_split(strings):
     """Annchor.query against the reference's run on the strings split of gen_query (integer
-    metric: every reported distance exact; error count vs brute force within the tie swaps of
-    the reference's own arbitrary argpartition order), and bit-exact against the oracle."""
+    metric: every reported distance exact; error count vs brute force no worse than the reference
+    run's, whose argpartition resolves tie groups arbitrarily), and bit-exact against the oracle."""
     from annchor_amd import Annchor, compare_neighbor_graphs
 
     G = np.load(os.path.join(GOLD, "query_strings.npz"))
@@ -573,4 +573,4 @@ def test_query_reference_strings_split(strings):
         truth = (order, np.take_along_axis(dense[:len(Q)], order, axis=1))
         e_gpu = compare_neighbor_graphs(truth, (gi, gd), nn)
         e_ref = compare_neighbor_graphs(truth, (G[tag + "_e2e_idx"], G[tag + "_e2e_dist"]), nn)
-        assert abs(e_gpu - e_ref) <= 0.02 * len(Q) * nn + 2, (e_gpu, e_ref)
+        assert e_gpu <= e_ref + 0.02 * len(Q) * nn + 2, (e_gpu, e_ref)   # no worse than the reference's run (tie order differs)

@@ -216,3 +216,37 @@ def test_parked_context_shells_are_reused_and_releasable():
     assert _native.release_parked_contexts() == 0
     c = Annchor(X, "levenshtein", **cfg).fit()   # a fresh shell again
     assert np.array_equal(ga[0], c.neighbor_graph[0])
+
+
+def test_to_sparse_matrix_from_device_equals_reference_loop():
+    """annchor.py:625-641: the device-emitted symmetric COO (annchor_graph_to_coo) == the reference's
+    cell-by-cell DOK fill, on a fitted graph and on a random graph whose rows list each other in both
+    directions with DIFFERENT values (so that "later assignment wins" is exercised)."""
+    from scipy.sparse import dok_matrix
+
+    from annchor_amd import Annchor, _native
+    from oracle import metrics as om
+
+    def reference_loop(idx, dist):
+        nx = idx.shape[0]
+        want = dok_matrix((nx, nx), dtype=np.float64)
+        eps = np.nextafter(0, 1)
+        for i, (js, ds) in enumerate(zip(idx, dist)):
+            for j, d in zip(js, ds):
+                want[i, j] = want[j, i] = d + eps
+        return want
+
+    X = np.array(om.load_strings()[0][::8])
+    ann = Annchor(X, "levenshtein", n_anchors=6, n_neighbors=8, n_samples=400, p_work=0.3).fit()
+    got, want = ann.to_sparse_matrix(), reference_loop(*ann.neighbor_graph)
+    assert isinstance(got, dok_matrix) and got.nnz == want.nnz and (got != want).nnz == 0
+    assert got[3, 3] == np.nextafter(0, 1)   # explicit zero survives
+    rng = np.random.default_rng(0)
+    nx, k = 300, 7
+    idx = np.stack([np.r_[i, rng.choice(np.delete(np.arange(nx), i), k - 1, replace=False)] for i in range(nx)])
+    dist = np.sort(rng.random((nx, k)), axis=1)
+    dist[:, 0] = 0
+    rows, cols, vals = _native.Engine(0).graph_to_coo(idx, dist)
+    want = reference_loop(idx, dist)
+    assert len(rows) == want.nnz and len(set(zip(rows.tolist(), cols.tolist()))) == len(rows)   # every cell once
+    assert all(want[r, c] == v for r, c, v in zip(rows.tolist(), cols.tolist(), vals.tolist()))

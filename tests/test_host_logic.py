@@ -317,7 +317,7 @@ def test_to_sparse_matrix_equals_reference_loop():
 
     a = Holder()
     a.neighbor_graph, a.nx = (idx, dist), nx
-    got = Annchor.to_sparse_matrix(a)
+    got = Annchor._sparse_from_graph_host(idx, dist)
     want = dok_matrix((nx, nx), dtype=np.float64)
     eps = np.nextafter(0, 1)
     for i, (js, ds) in enumerate(zip(idx, dist)):
