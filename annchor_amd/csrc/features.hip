@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_features(const int2 *__restrict__ ij, i
 // lane, loaded once, coalesced), then walks FT_ROWS rows i: D[a][i] is wave-uniform (scalar loads),
 // the pair position comes from the keep bitmap's popcount ranks (no read of ij[] at all), and the
 // outputs of a row are consecutive addresses.  Per pair: 2 gathers (the two dad terms) + the stores.
-#define FT_ROWS 16
+#define FT_ROWS 32
 template <int NA_MAX> __global__ __launch_bounds__(256) void k_features_tiled(
     const uint64_t *__restrict__ K, const uint32_t *__restrict__ pref, int kw, const int32_t *__restrict__ low,
     const int64_t *__restrict__ rowstart, const double *__restrict__ Dt, int64_t nx, int na, const int32_t *__restrict__ cA,
@@ -103,33 +103,48 @@ template <int NA_MAX> __global__ __launch_bounds__(256) void k_features_tiled(
     const int64_t jc = min(j, nx - 1);
     double dj[NA_MAX];
 #pragma unroll
-    for (int a = 0; a < NA_MAX; ++a) dj[a] = a < na ? Dt[(size_t)a * nx + jc] : 0.0;
+    for (int a = 0; a < NA_MAX; ++a) dj[a] = Dt[(size_t)min(a, na - 1) * nx + jc];
     const int caj = cA[jc];
-    const bool ancj = anchorRank[jc] >= 0;
     for (int64_t i = i_lo; i < i_hi; ++i) {
         const uint64_t bits = K[i * kw + jb];                       // wave-uniform
         const bool mine = j > i && j < nx && ((bits >> lane) & 1ull);
         if (!__any(mine)) continue;
         const int64_t pos = rowstart[i] + ((int64_t)pref[i * kw + jb] + __popcll(bits & ((1ull << lane) - 1ull)) - low[i]);
         double l = 0.0, u = INFINITY;
+        double di[NA_MAX];
 #pragma unroll
+        for (int a = 0; a < NA_MAX; ++a) di[a] = Dt[(size_t)min(a, na - 1) * nx + i];   // uniform addresses: scalar loads, all in flight;
+#pragma unroll                                                                       // the tail repeats the last anchor (max / min ignore it)
         for (int a = 0; a < NA_MAX; ++a) {
-            if (a < na) {
-                const double di = Dt[(size_t)a * nx + i];           // uniform address: scalar load
-                l = fmax(l, fabs(di - dj[a]));
-                u = fmin(u, di + dj[a]);
-            }
+            l = fmax(l, fabs(di[a] - dj[a]));
+            u = fmin(u, di[a] + dj[a]);
         }
         if (mine) {
             const int cai = cA[i];
             lb[pos] = l;
             ub[pos] = u;
             dad[pos] = (Dt[(size_t)caj * nx + i] + Dt[(size_t)cai * nx + j]) / 2;
-            const uint8_t isa = (anchorRank[i] >= 0) | ancj;
-            anc[pos] = isa;
-            ncm[pos] = !isa;
+            // (the two byte masks are preset by memset and patched for the few anchor rows / columns by
+            // k_anchor_flags: 64-byte pieces of a byte array written from different CUs are partial lines)
         }
     }
+}
+
+// is_anchor / not_computed of the pairs that touch an anchor (annchor.py:286-289): thread per (anchor, point)
+__global__ void k_anchor_flags(const int32_t *__restrict__ A, int nA, int64_t nx, const uint64_t *__restrict__ K,
+                               const uint32_t *__restrict__ pref, int kw, const int32_t *__restrict__ low,
+                               const int64_t *__restrict__ rowstart, uint8_t *__restrict__ anc, uint8_t *__restrict__ ncm)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)nA * nx) return;
+    const int64_t a = A[t / nx], o = t % nx;
+    if (a == o) return;
+    const int64_t i = a < o ? a : o, j = a < o ? o : a;
+    const uint64_t bits = K[i * kw + (j >> 6)];
+    if (!((bits >> (j & 63)) & 1ull)) return;
+    const int64_t pos = rowstart[i] + ((int64_t)pref[i * kw + (j >> 6)] + __popcll(bits & ((1ull << (j & 63)) - 1ull)) - low[i]);
+    anc[pos] = 1;
+    ncm[pos] = 0;
 }
 
 extern "C" int annchor_compute_features(annchor_ctx *c)
@@ -159,8 +174,17 @@ extern "C" int annchor_compute_features(annchor_ctx *c)
                 c->low.as<int32_t>(), c->rowstart.as<int64_t>(), c->Dt.as<double>(), c->nx, c->na, c->cA.as<int32_t>(), \
                 c->anchorRank.as<int32_t>(), c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>(), c->anc.as<uint8_t>(), \
                 c->ncm.as<uint8_t>())
-            if (c->na <= 16) FT_LAUNCH(16);
+            ANN_CHECK_HIP(c, hipMemsetAsync(c->anc.p, 0, n, c->stream));
+            ANN_CHECK_HIP(c, hipMemsetAsync(c->ncm.p, 1, n, c->stream));
+            if (c->nA > 0)
+                k_anchor_flags<<<ann_blocks((int64_t)c->nA * c->nx, 256), 256, 0, c->stream>>>(
+                    c->A.as<int32_t>(), c->nA, c->nx, c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), kw, c->low.as<int32_t>(),
+                    c->rowstart.as<int64_t>(), c->anc.as<uint8_t>(), c->ncm.as<uint8_t>());
+            if (c->na <= 8) FT_LAUNCH(8);
+            else if (c->na <= 16) FT_LAUNCH(16);
+            else if (c->na <= 24) FT_LAUNCH(24);
             else if (c->na <= 32) FT_LAUNCH(32);
+            else if (c->na <= 48) FT_LAUNCH(48);
             else FT_LAUNCH(64);
 #undef FT_LAUNCH
         } else
