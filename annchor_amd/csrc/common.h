@@ -91,7 +91,8 @@ struct annchor_ctx {
     bool cand_marked = false;      // not_computed_mask already cleared for the current candidates
     DevBuf gl_val, gl_pos, gl_cnt, gl_ncomp, marked, markcount;  // guarantee_nmin scratch
     DevBuf sel_hist, sel_state, blk_cnt, blk_off;                // radix select / compaction scratch
-    DevBuf tie_lists;                                            // RefineApprox keys of the pairs on the two probability cuts
+    DevBuf tie_lists, tie_hist;                                  // scrambled positions of the pairs on the two probability cuts; their histogram
+    const void *tie_hist_clean = nullptr;                        // tie_hist known to be zero at this address
     DevBuf sel2, sel_bufA, sel_bufB, sel_seg;                             // filter-then-finish selection: tables, candidates
     const void *sel2_clean = nullptr;                            // sel2 tables known to be zero at this address
     DevBuf errs, errptr;

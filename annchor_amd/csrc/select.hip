@@ -546,7 +546,11 @@ struct CutState {
     unsigned long long rk1, rk5;
     int64_t tie_n1, tie_n5;       // sizes of the two groups
     int64_t tie_gt1, tie_gt5;     // pairs with prob > t
-    int tie_overflow;             // a group did not fit TIE_CAP: the host resolves it with the general selection
+    long long tie_bin1, tie_bin5; // histogram bin of the wanted key (-1: rk is final already)
+    long long tie_rem1, tie_rem5; // wanted rank inside the bin (1-based)
+    long long tie_len1, tie_len5; // members of the bin
+    int64_t tie_got1, tie_got5;   // list cursors
+    int tie_overflow;             // a bin's list did not fit TIE_CAP: the host resolves it with the general selection
 };
 
 #define TIE_CAP 65536
@@ -557,17 +561,28 @@ __host__ __device__ __forceinline__ unsigned long long ann_tie_scramble(int64_t 
     return ((unsigned long long)p * 0x9E3779B97F4A7C15ull) >> 11;
 }
 
-// groups of the two cuts: sizes, members' scrambled positions, and the number of pairs above each cut
-__global__ __launch_bounds__(256) void k_tie_collect(const double *__restrict__ prob, const double *__restrict__ RA, int64_t n,
-                                                    CutState *__restrict__ cs, unsigned long long *__restrict__ list1,
-                                                    unsigned long long *__restrict__ list5, long long cap)
+// ---- the scrambled-position cut inside the group on each probability cut, device only:
+//   k_tie_hist     group sizes, pairs above each cut, histogram of the members' top TIE_HB key bits
+//   k_tie_pick     the histogram bin holding the wanted rank, and the rank inside it
+//   k_tie_collect  the members of that bin (a few dozen: the keys are uniform) into a short list
+//   k_tie_select   the wanted rank of the list (MSB-first byte radix in one workgroup)
+// Groups of any size take this route (the lookahead cut of the strings workload sits in a group of
+// ~5 * 10^5 pairs); only a list longer than TIE_CAP -- keys piling up in one of 4096 bins -- falls back
+// to the host-driven general selection.
+#define TIE_HB 12
+#define TIE_BINS (1 << TIE_HB)
+#define TIE_SHIFT (53 - TIE_HB)
+__global__ __launch_bounds__(256) void k_tie_hist(const double *__restrict__ prob, int64_t n, CutState *__restrict__ cs,
+                                                 uint32_t *__restrict__ ghist /*[2][TIE_BINS]*/)
 {
-    __shared__ unsigned long long acc[2];
-    if (threadIdx.x < 2) acc[threadIdx.x] = 0;
+    __shared__ uint32_t h[2][TIE_BINS];
+    __shared__ unsigned long long acc[4];
+    for (int t = threadIdx.x; t < 2 * TIE_BINS; t += 256) (&h[0][0])[t] = 0;
+    if (threadIdx.x < 4) acc[threadIdx.x] = 0;
     __syncthreads();
     const double t1 = cs->t1, t5 = cs->t5;
     const bool need1 = !cs->all1, need5 = !cs->all5;
-    unsigned long long g1 = 0, g5 = 0;
+    unsigned long long g1 = 0, g5 = 0, n1 = 0, n5 = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
     for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x * 4 + threadIdx.x; p0 < n; p0 += stride) {
         double v[4];
@@ -579,26 +594,161 @@ __global__ __launch_bounds__(256) void k_tie_collect(const double *__restrict__ 
             if (p >= n || !(v[e] >= 0.0)) continue;
             g1 += v[e] > t1;
             g5 += v[e] > t5;
-            if ((need1 && v[e] == t1) || (need5 && v[e] == t5)) {
-                const unsigned long long kk = ann_tie_scramble(p);
-                if (need1 && v[e] == t1) {
-                    const unsigned long long o = atomicAdd((unsigned long long *)&cs->tie_n1, 1ull);
-                    if ((long long)o < cap) list1[o] = kk;
-                }
-                if (need5 && v[e] == t5) {
-                    const unsigned long long o = atomicAdd((unsigned long long *)&cs->tie_n5, 1ull);
-                    if ((long long)o < cap) list5[o] = kk;
-                }
+            const bool m1 = need1 && v[e] == t1, m5 = need5 && v[e] == t5;
+            if (m1 || m5) {
+                const uint32_t bin = (uint32_t)(ann_tie_scramble(p) >> TIE_SHIFT);
+                if (m1) { atomicAdd(&h[0][bin], 1u); ++n1; }
+                if (m5) { atomicAdd(&h[1][bin], 1u); ++n5; }
             }
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { g1 += __shfl_xor(g1, off); g5 += __shfl_xor(g5, off); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&acc[0], g1); atomicAdd(&acc[1], g5); }
+    for (int off = 32; off > 0; off >>= 1) {
+        g1 += __shfl_xor(g1, off); g5 += __shfl_xor(g5, off); n1 += __shfl_xor(n1, off); n5 += __shfl_xor(n5, off);
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&acc[0], g1); atomicAdd(&acc[1], g5); atomicAdd(&acc[2], n1); atomicAdd(&acc[3], n5); }
     __syncthreads();
+    for (int t = threadIdx.x; t < 2 * TIE_BINS; t += 256) {
+        const uint32_t c = (&h[0][0])[t];
+        if (c) atomicAdd(&ghist[t], c);
+    }
     if (threadIdx.x == 0) {
         if (acc[0]) atomicAdd((unsigned long long *)&cs->tie_gt1, acc[0]);
         if (acc[1]) atomicAdd((unsigned long long *)&cs->tie_gt5, acc[1]);
+        if (acc[2]) atomicAdd((unsigned long long *)&cs->tie_n1, acc[2]);
+        if (acc[3]) atomicAdd((unsigned long long *)&cs->tie_n5, acc[3]);
+    }
+}
+
+// one workgroup: for each cut the bin that holds the e-th smallest key of the group (e = K - above) and
+// the rank inside that bin; rk is settled here when the whole group (or none of it) is taken.
+// Leaves the histogram zeroed for the next call.
+__global__ __launch_bounds__(1024) void k_tie_pick(CutState *__restrict__ cs, uint32_t *__restrict__ ghist)
+{
+    __shared__ unsigned long long wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q = 0; q < 2; ++q) {
+        const bool all = q == 0 ? cs->all1 : cs->all5;
+        const long long cnt = q == 0 ? cs->tie_n1 : cs->tie_n5;
+        const long long e = q == 0 ? cs->K1 - cs->tie_gt1 : cs->K5 - cs->tie_gt5;
+        uint32_t *h = ghist + q * TIE_BINS;
+        constexpr int PER = TIE_BINS / 1024;
+        unsigned long long c[PER], mine = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { c[j] = h[threadIdx.x * PER + j]; h[threadIdx.x * PER + j] = 0; mine += c[j]; }
+        unsigned long long inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const unsigned long long up = __shfl_up(inc, off); if (lane >= off) inc += up; }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned long long before = inc - mine;
+        for (int w2 = 0; w2 < wave; ++w2) before += wsum[w2];
+        if (threadIdx.x == 0) {
+            unsigned long long rk = ~0ull;       // whole group taken
+            long long bin = -1;
+            if (!all && e < cnt) { if (e <= 0) rk = 0ull; else bin = -2; }   // -2: to be located below
+            if (q == 0) { cs->rk1 = rk; cs->tie_bin1 = bin; } else { cs->rk5 = rk; cs->tie_bin5 = bin; }
+        }
+        __syncthreads();
+        if (!all && e < cnt && e > 0 && (long long)before < e && (long long)(before + mine) >= e) {
+            long long accb = (long long)before;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                if (accb < e && accb + (long long)c[j] >= e) {
+                    if (q == 0) { cs->tie_bin1 = threadIdx.x * PER + j; cs->tie_rem1 = e - accb; cs->tie_len1 = (long long)c[j]; }
+                    else { cs->tie_bin5 = threadIdx.x * PER + j; cs->tie_rem5 = e - accb; cs->tie_len5 = (long long)c[j]; }
+                }
+                accb += (long long)c[j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// members of the picked bins -> short lists (append order is irrelevant: k_tie_select ranks the keys)
+__global__ __launch_bounds__(256) void k_tie_collect(const double *__restrict__ prob, int64_t n, CutState *__restrict__ cs,
+                                                    unsigned long long *__restrict__ list1, unsigned long long *__restrict__ list5,
+                                                    long long cap)
+{
+    const long long b1 = cs->tie_bin1, b5 = cs->tie_bin5;
+    if (b1 < 0 && b5 < 0) return;
+    const double t1 = cs->t1, t5 = cs->t5;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x * 4 + threadIdx.x; p0 < n; p0 += stride) {
+        double v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ann_ldc(prob, p0 + (int64_t)e * blockDim.x, n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t p = p0 + (int64_t)e * blockDim.x;
+            if (p >= n || !(v[e] >= 0.0)) continue;
+            const bool m1 = b1 >= 0 && v[e] == t1, m5 = b5 >= 0 && v[e] == t5;
+            if (m1 || m5) {
+                const unsigned long long kk = ann_tie_scramble(p);
+                const long long bin = (long long)(kk >> TIE_SHIFT);
+                if (m1 && bin == b1) { const unsigned long long o = atomicAdd((unsigned long long *)&cs->tie_got1, 1ull); if ((long long)o < cap) list1[o] = kk; }
+                if (m5 && bin == b5) { const unsigned long long o = atomicAdd((unsigned long long *)&cs->tie_got5, 1ull); if ((long long)o < cap) list5[o] = kk; }
+            }
+        }
+    }
+}
+
+// one workgroup: the tie_rem-th smallest key of each short list (MSB-first byte radix)
+__global__ __launch_bounds__(1024) void k_tie_select(CutState *__restrict__ cs, const unsigned long long *__restrict__ list1,
+                                                    const unsigned long long *__restrict__ list5, long long cap)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ unsigned long long prefix_s;
+    __shared__ long long krem_s;
+    for (int q = 0; q < 2; ++q) {
+        const long long bin = q == 0 ? cs->tie_bin1 : cs->tie_bin5;
+        if (bin < 0) continue;     // rk already final
+        const long long cnt = q == 0 ? cs->tie_len1 : cs->tie_len5;
+        const long long e = q == 0 ? cs->tie_rem1 : cs->tie_rem5;
+        const unsigned long long *list = q == 0 ? list1 : list5;
+        unsigned long long rk = 0ull;
+        if (cnt > cap) { if (threadIdx.x == 0) cs->tie_overflow = 1; }   // rk = 0: take none for now (the lists hold at most K entries): the host resolves it
+        else {
+            if (threadIdx.x == 0) { prefix_s = 0; krem_s = e - 1; }
+            __syncthreads();
+            for (int pass = 1; pass < 8; ++pass) {   // keys are < 2^53: the top byte is zero
+                const int shift = 56 - 8 * pass;
+                const unsigned long long himask = ~0ull << (shift + 8);
+                if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+                __syncthreads();
+                const unsigned long long pre = prefix_s;
+                for (long long t = threadIdx.x; t < cnt; t += 1024) {
+                    const unsigned long long kk = list[t];
+                    if ((kk & himask) == pre) atomicAdd(&hist[(uint32_t)(kk >> shift) & 0xffu], 1u);
+                }
+                __syncthreads();
+                if (threadIdx.x < 64) {   // one wave locates the digit: 4 bins per lane + a wave scan
+                    uint32_t c4[4], s4 = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { c4[j] = hist[threadIdx.x * 4 + j]; s4 += c4[j]; }
+                    uint32_t inc = s4;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) { const uint32_t up = __shfl_up(inc, off); if ((int)threadIdx.x >= off) inc += up; }
+                    long long k = krem_s;
+                    long long acc4 = (long long)(inc - s4);
+                    if (acc4 <= k && k < acc4 + (long long)s4) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (acc4 <= k && k < acc4 + (long long)c4[j]) {
+                                prefix_s = pre | ((unsigned long long)(threadIdx.x * 4 + j) << shift);
+                                krem_s = k - acc4;
+                            }
+                            acc4 += c4[j];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            rk = prefix_s;
+        }
+        if (threadIdx.x == 0) { if (q == 0) cs->rk1 = rk; else cs->rk5 = rk; }
+        __syncthreads();
     }
 }
 
@@ -608,54 +758,6 @@ __global__ void k_tie_flags(const double *__restrict__ prob, int64_t n, double t
     if (p < n) {
         flag[p] = prob[p] == t ? 1 : 0;   // prob >= 0 only on not-computed pairs, and t >= 0 here
         scr[p] = (double)ann_tie_scramble(p);
-    }
-}
-
-// one workgroup: the RefineApprox key of the (K - above)-th smallest member of each group (MSB-first
-// byte radix over the group's keys)
-__global__ __launch_bounds__(1024) void k_tie_select(CutState *__restrict__ cs, const unsigned long long *__restrict__ list1,
-                                                    const unsigned long long *__restrict__ list5, long long cap)
-{
-    __shared__ uint32_t hist[256];
-    __shared__ unsigned long long prefix_s;
-    __shared__ long long krem_s;
-    for (int q = 0; q < 2; ++q) {
-        const bool all = q == 0 ? cs->all1 : cs->all5;
-        const long long cnt = q == 0 ? cs->tie_n1 : cs->tie_n5;
-        const long long e = (q == 0 ? cs->K1 - cs->tie_gt1 : cs->K5 - cs->tie_gt5);   // members to take
-        const unsigned long long *list = q == 0 ? list1 : list5;
-        unsigned long long rk = ~0ull;
-        if (!all && e < cnt) {
-            if (cnt > cap) { rk = 0ull; if (threadIdx.x == 0) cs->tie_overflow = 1; }   // take none for now (the lists hold at most K entries): the host resolves it
-            else if (e <= 0) rk = 0ull;   // nothing of the group is taken (every key is >= 0 == rk: none below, ties at key 0 counted by e = 0)
-            else {
-                if (threadIdx.x == 0) { prefix_s = 0; krem_s = e - 1; }
-                __syncthreads();
-                for (int pass = 0; pass < 8; ++pass) {
-                    const int shift = 56 - 8 * pass;
-                    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
-                    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
-                    __syncthreads();
-                    const unsigned long long pre = prefix_s;
-                    for (long long t = threadIdx.x; t < cnt; t += 1024) {
-                        const unsigned long long kk = list[t];
-                        if ((kk & himask) == pre) atomicAdd(&hist[(uint32_t)(kk >> shift) & 0xffu], 1u);
-                    }
-                    __syncthreads();
-                    if (threadIdx.x == 0) {
-                        long long k = krem_s;
-                        int d = 0;
-                        for (; d < 255; ++d) { if (k < (long long)hist[d]) break; k -= hist[d]; }
-                        prefix_s = pre | ((unsigned long long)d << shift);
-                        krem_s = k;
-                    }
-                    __syncthreads();
-                }
-                rk = prefix_s;
-            }
-        }
-        if (threadIdx.x == 0) { if (q == 0) cs->rk1 = rk; else cs->rk5 = rk; }
-        __syncthreads();
     }
 }
 
@@ -996,7 +1098,14 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         const int tb = (int)std::min<int64_t>(ann_blocks(n, 256 * 4), 256);
         const char *cap_env = getenv("ANNCHOR_TIE_CAP");   // tests force the large-group route on small inputs
         const long long cap = cap_env ? std::min<long long>(TIE_CAP, std::max<long long>(1, atoll(cap_env))) : TIE_CAP;
-        k_tie_collect<<<tb, 256, 0, c->stream>>>(c->prob.as<double>(), c->RA.as<double>(), n, c->sel_state.as<CutState>(), tl1, tl5, cap);
+        ANN_TRY(ann_reserve(c, c->tie_hist, sizeof(uint32_t) * 2 * TIE_BINS));
+        if (c->tie_hist_clean != c->tie_hist.p) {   // (k_tie_pick leaves it zeroed for the next call)
+            ANN_CHECK_HIP(c, hipMemsetAsync(c->tie_hist.p, 0, sizeof(uint32_t) * 2 * TIE_BINS, c->stream));
+            c->tie_hist_clean = c->tie_hist.p;
+        }
+        k_tie_hist<<<tb, 256, 0, c->stream>>>(c->prob.as<double>(), n, c->sel_state.as<CutState>(), c->tie_hist.as<uint32_t>());
+        k_tie_pick<<<1, 1024, 0, c->stream>>>(c->sel_state.as<CutState>(), c->tie_hist.as<uint32_t>());
+        k_tie_collect<<<tb, 256, 0, c->stream>>>(c->prob.as<double>(), n, c->sel_state.as<CutState>(), tl1, tl5, cap);
         k_tie_select<<<1, 1024, 0, c->stream>>>(c->sel_state.as<CutState>(), tl1, tl5, cap);
     }
     split();

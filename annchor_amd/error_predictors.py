@@ -39,12 +39,28 @@ class SimpleStratifiedErrorRegression:
             self.n_partitions = len(sample_bins) - 1
         self.labels = range(self.n_partitions)
         edges = np.asarray(self.partition_bins, dtype=np.float64)
-        order = np.argsort(values, kind="stable")
-        by_value = values[order]
-        residual = np.asarray(sample_error)[order]
-        first = np.searchsorted(by_value, edges[:-1], side="left")    # first sample >= lower edge
-        last = np.searchsorted(by_value, edges[1:], side="right")     # one past the last sample <= upper edge
-        self.errs = {b: np.sort(residual[first[b]:max(last[b], first[b])]) for b in range(self.n_partitions)}
+        residual = np.asarray(sample_error, dtype=np.float64)
+        # first / last partition a sample belongs to (a sample ON an inner edge belongs to two)
+        lo = np.searchsorted(edges[1:], values, side="left")            # first b with values <= upper edge of b
+        hi = np.searchsorted(edges[:-1], values, side="right") - 1      # last b with lower edge of b <= values
+        P = self.n_partitions
+        lo, hi = np.clip(lo, 0, P - 1), np.clip(hi, 0, P - 1)
+        # group by first partition (stable integer sort: radix), sort each group's residuals; the few
+        # samples sitting ON an inner edge are added to the later partitions they also count for
+        key = lo.astype(np.int16)
+        order = np.argsort(key, kind="stable")
+        grouped = residual[order]
+        cut = np.searchsorted(key[order], np.arange(P + 1), side="left")
+        extra = {}
+        for t in np.flatnonzero(hi > lo):
+            for b in range(int(lo[t]) + 1, int(hi[t]) + 1):
+                extra.setdefault(b, []).append(residual[t])
+        self.errs = {}
+        for b in range(P):
+            members = grouped[cut[b]:cut[b + 1]]
+            if b in extra:
+                members = np.concatenate((members, np.asarray(extra[b], dtype=np.float64)))
+            self.errs[b] = np.sort(members)
 
     def predict(self, features, feature_names):
         values = self._column(features, feature_names)

@@ -190,11 +190,19 @@ def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, r
     return out
 
 
+def _latest_profile(suffix):
+    """Newest committed profiles/rNN*_<suffix> (rounds sort lexicographically)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_" + suffix)))
+    return files[-1] if files else None
+
+
 def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units, FETCH doubled as the gfx950 guide prescribes)."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json: separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, KiB units, FETCH doubled as the gfx950 guide prescribes)."""
     try:
-        T = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        T = json.load(open(_latest_profile("pmc_traffic.json")))
         tot = n = 0
         for name, v in T.items():  # launch-weighted over every instantiation of the kernel
             if name.replace("void ", "").startswith(kernel_prefix):
@@ -208,12 +216,12 @@ def pmc_traffic(kernel_prefix):
 
 
 def pmc_valu_busy():
-    """VALU-busy share of the Levenshtein kernels from the committed PMC pass (profiles/r01_pmc_lev.json,
-    tools/pmc_lev.sh): SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (kernel cycles x 1024 SIMDs)."""
+    """VALU-busy share of the Levenshtein launches from the committed PMC pass (profiles/rNN_pmc_lev.json,
+    tools/pmc_lev2.sh / pmc_lev.sh): SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (kernel cycles x 1024 SIMDs)."""
     try:
-        T = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_lev.json")))
+        T = json.load(open(_latest_profile("pmc_lev.json")))
         return {k: round(v["SQ_ACTIVE_INST_VALU"] * 4 / (v["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
-                for k, v in T.items() if k.startswith("k_lev")}
+                for k, v in T.items() if "k_lev" in k and "SQ_ACTIVE_INST_VALU" in v and v.get("GRBM_GUI_ACTIVE")}
     except Exception:
         return None
 
@@ -368,7 +376,7 @@ def strings_run(args, steps, warmup, world, rank, local, dist, torch, all_cpus, 
                     "note": "integer-ALU bound (string pool is 1 MB, cache resident): HBM fraction is not meaningful "
                             "for this kernel; the HBM-bound pair-list kernels are listed under `kernels`.  `peak` is the "
                             "nominal 2-cycle SIMD-32 rate; these integer ops issue at ~4 cycles per wave instruction "
-                            "(tools/microbench/valu_peak.hip), and the PMC pass shows the pair-list launches 96-99 % VALU busy, the one-wave-deep anchor rounds ~25 %",
+                            "(tools/microbench/valu_peak.hip); `valu_busy_pmc` = the committed PMC pass over isolated launches (pair lists 84 % busy after the round-2 instruction cuts, the one-wave-deep anchor rounds ~25 %)",
                 }
             else:
                 g = kernels[dom]

@@ -1,18 +1,23 @@
 #!/bin/bash
-# One GPU-box pass: tests, bench, rocprofv3 kernel stats, PMC traffic.  Outputs under gpurun_out/refresh/.
+# One GPU-box pass: tests, bench, rocprofv3 kernel stats, PMC traffic (bench workloads and the pair-list
+# kernels at N = 16000), PMC activity of the Levenshtein launches.  Outputs under gpurun_out/refresh/.
 set -u
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/refresh; mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
-timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
+timeout 900 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-scale > $O/bench_under_rocprof.json 2> $O/rocprof.err
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-scale > /dev/null 2> $O/pmc_fetch.err
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-scale > /dev/null 2> $O/pmc_write.err
 PYTHONPATH=$R timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/scale -o r -- python $R/tools/pairlist_scale.py 16000 > $O/pairlist_scale.log 2>&1
+PYTHONPATH=$R timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_scale -o pmc -- python $R/tools/pairlist_scale.py 16000 > /dev/null 2> $O/pmc_fetch_scale.err
+PYTHONPATH=$R timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_scale -o pmc -- python $R/tools/pairlist_scale.py 16000 > /dev/null 2> $O/pmc_write_scale.err
 cd $R
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json
+python tools/pmc_summary.py $O/pmc_fetch_scale $O/pmc_write_scale $O/pmc_traffic_scale.json
+bash tools/pmc_lev2.sh > $O/pmc_lev2.log 2>&1; cp gpurun_out/pmc_lev2/pmc_lev2.json $O/pmc_lev.json 2>/dev/null
 find $O -name "*kernel_stats.csv" | head; find $O -name "*counter_collection.csv" -size +30M -delete
-rm -rf $O/pmc_fetch $O/pmc_write 2>/dev/null
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_fetch_scale $O/pmc_write_scale 2>/dev/null
 find $O/stats $O/scale -name "*kernel_trace.csv" -delete
 du -sh $O
