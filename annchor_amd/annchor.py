@@ -23,7 +23,7 @@ from .distances import DeviceMetric
 from .error_predictors import SimpleStratifiedErrorRegression
 from .pickers import MaxMinAnchorPicker
 from .regressors import SimpleStratifiedLinearRegression
-from .samplers import NothingToSample, SimpleStratifiedSampler
+from .samplers import DeviceStratifiedSampler, NothingToSample, SimpleStratifiedSampler
 from .utils import get_exact_ijs_, get_function_from_input, test_parallelisation
 
 from .distances import euclidean as distances_euclidean  # noqa: E402
@@ -302,7 +302,7 @@ class Annchor:
         """The built-in stratified sampler partitioning on the double anchor distance runs against
         the resident state; any other sampler (or partition feature) gets the NumPy arrays of the
         protocol."""
-        return (type(self.sampler) is SimpleStratifiedSampler
+        return (type(self.sampler) in (SimpleStratifiedSampler, DeviceStratifiedSampler)
                 and self.sampler.partition_feature_name == "double anchor distance")
 
     def get_sample(self):
@@ -426,7 +426,7 @@ class Annchor:
             return self
         origin = time.perf_counter()
         t = self.timings = {}
-        if self._sampler_on_device():
+        if self._sampler_on_device() and type(self.sampler) is SimpleStratifiedSampler:
             # the sampler's MT19937 streams depend on the seeds only: produce them on host
             # threads while the GPU runs the stages before each sampling step
             for it in range(self.niters):

@@ -82,6 +82,7 @@ struct annchor_ctx {
 
     // ---- samples
     DevBuf spos, sy;  // int32 [m], double [m]
+    DevBuf hs_key, hs_pos, hs_misc;   // hashed stratified sampling: per-partition candidate lists, counters / outputs
     int64_t nsamp = 0;
 
     // ---- selection

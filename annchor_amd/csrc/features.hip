@@ -329,6 +329,151 @@ __global__ __launch_bounds__(BC_THREADS) void k_bin_counts(const double *__restr
     }
 }
 
+static int load_bins(annchor_ctx *c, const double *bins, int32_t nbins, BinEdges &be);
+
+// ------------------------------------------------------------ hashed stratified sampling
+// DeviceStratifiedSampler (annchor_amd/samplers.py): the stratified draw of Sampler.sample_partition
+// (reference annchor/samplers.py:44-73, utils.py:543-578) with an ORDER-FREE random choice.  The
+// reference draws `want` members of a partition through a sequential shuffle of its whole population
+// (np.random.choice(..., replace=False): an MT19937 stream as long as the pair list, walked by one
+// thread).  Here every not-computed pair gets a key = splitmix64(seed_key ^ position) and a partition
+// keeps its `want` smallest keys: the same distribution (a uniform random subset), a pure function of
+// (seed, position), computable by any number of threads in any order.
+//   k_hs_collect  pairs with key <= T_b (T_b = 1.5 * want_b / count_b of the key range + slack) -> per-partition lists
+//   k_hs_finish   one workgroup per partition: its `want` smallest (key, position), output by position
+__host__ __device__ __forceinline__ unsigned long long ann_splitmix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+#define HS_CAP 4096   // list entries per partition (want <= HS_CAP / 2)
+struct HsParams {
+    unsigned long long seed_key;
+    unsigned long long thr[MAXBINS];   // key threshold per partition (~0: take every member)
+};
+
+__global__ __launch_bounds__(256) void k_hs_collect(const double *__restrict__ dad, const uint8_t *__restrict__ ncm, int64_t n,
+                                                   BinEdges be, HsParams hp, unsigned long long *__restrict__ lkey,
+                                                   int32_t *__restrict__ lpos, uint32_t *__restrict__ lcnt)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x * 4 + threadIdx.x; p0 < n; p0 += stride) {
+        double v[4];
+        uint8_t f[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = ann_ldc(dad, p0 + (int64_t)e * blockDim.x, n); f[e] = ann_ldc(ncm, p0 + (int64_t)e * blockDim.x, n); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t p = p0 + (int64_t)e * blockDim.x;
+            if (p >= n || !f[e]) continue;
+            const unsigned long long key = ann_splitmix64(hp.seed_key ^ (unsigned long long)p);
+            const int b = sampler_bin(be, v[e]);
+            if (b >= 0 && key <= hp.thr[b]) {
+                const uint32_t o = atomicAdd(&lcnt[b], 1u);
+                if (o < HS_CAP) { lkey[(size_t)b * HS_CAP + o] = key; lpos[(size_t)b * HS_CAP + o] = (int32_t)p; }
+            }
+        }
+    }
+}
+
+// block b: rank the list of partition b by (key, position); members of rank < want are the sample;
+// they are written in ascending position order at out + offset[b]
+__global__ __launch_bounds__(1024) void k_hs_finish(const unsigned long long *__restrict__ lkey, const int32_t *__restrict__ lpos,
+                                                   const uint32_t *__restrict__ lcnt, const int32_t *__restrict__ want,
+                                                   const int32_t *__restrict__ offset, int32_t *__restrict__ out, int32_t *__restrict__ got)
+{
+    __shared__ unsigned long long sk[HS_CAP];
+    __shared__ int32_t sp[HS_CAP];
+    __shared__ int32_t sel[HS_CAP / 2];
+    __shared__ int nsel;
+    const int b = blockIdx.x;
+    const int cnt = (int)min(lcnt[b], (uint32_t)HS_CAP);
+    const int w = min(want[b], cnt);
+    if (threadIdx.x == 0) { nsel = 0; got[b] = lcnt[b] > HS_CAP ? -1 : w; }
+    for (int t = threadIdx.x; t < cnt; t += 1024) { sk[t] = lkey[(size_t)b * HS_CAP + t]; sp[t] = lpos[(size_t)b * HS_CAP + t]; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += 1024) {
+        const unsigned long long k = sk[t];
+        const int32_t p = sp[t];
+        int r = 0;
+        for (int o = 0; o < cnt; ++o) r += (sk[o] < k) || (sk[o] == k && sp[o] < p);
+        if (r < w) sel[atomicAdd(&nsel, 1)] = p;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < w; t += 1024) {   // ascending position inside the partition
+        const int32_t p = sel[t];
+        int r = 0;
+        for (int o = 0; o < w; ++o) r += sel[o] < p;
+        out[offset[b] + r] = p;
+    }
+}
+
+extern "C" int annchor_hash_sample(annchor_ctx *c, const double *bins, int32_t nbins, const int64_t *counts, const int64_t *want,
+                                   uint64_t seed_key, int64_t *positions, int64_t *n_out)
+{
+    if (!c || !bins || !counts || !want || !positions || !n_out) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    BinEdges be;
+    ANN_TRY(load_bins(c, bins, nbins, be));
+    HsParams hp;
+    hp.seed_key = seed_key;
+    std::vector<int32_t> h_want(nbins), h_off(nbins);
+    int64_t total = 0;
+    for (int b = 0; b < nbins; ++b) {
+        ANN_REQUIRE(c, want[b] >= 0 && want[b] <= HS_CAP / 2, ANNCHOR_ELIMIT, "at most %d samples per partition", HS_CAP / 2);
+        const int64_t w = std::min(want[b], counts[b]);
+        h_want[b] = (int32_t)w;
+        h_off[b] = (int32_t)total;
+        total += w;
+        if (counts[b] <= want[b] || counts[b] <= 0) hp.thr[b] = ~0ull;   // the whole partition
+        else {
+            // expected hits = 1.5 * want + 64 of a uniform key: P(fewer than want) is negligible; a short list is retried below
+            const long double frac = std::min<long double>(1.0L, (1.5L * (long double)want[b] + 64.0L) / (long double)counts[b]);
+            hp.thr[b] = frac >= 1.0L ? ~0ull : (unsigned long long)(frac * 18446744073709551615.0L);
+        }
+    }
+    ANN_TRY(ann_reserve(c, c->hs_key, sizeof(unsigned long long) * (size_t)nbins * HS_CAP));
+    ANN_TRY(ann_reserve(c, c->hs_pos, sizeof(int32_t) * (size_t)nbins * HS_CAP));
+    ANN_TRY(ann_reserve(c, c->hs_misc, sizeof(int32_t) * (size_t)(4 * MAXBINS + total + 16)));
+    uint32_t *d_cnt = c->hs_misc.as<uint32_t>();
+    int32_t *d_want = c->hs_misc.as<int32_t>() + MAXBINS, *d_off = d_want + MAXBINS, *d_got = d_off + MAXBINS, *d_out = d_got + MAXBINS;
+    ANN_TRY(ann_h2d(c, d_want, h_want.data(), sizeof(int32_t) * nbins));
+    ANN_TRY(ann_h2d(c, d_off, h_off.data(), sizeof(int32_t) * nbins));
+    std::vector<int32_t> h_got(nbins);
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        ANN_CHECK_HIP(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * MAXBINS, c->stream));
+        {
+            ProfScope ps(c, "hashed_sample_collect", (double)c->n * 9.0);
+            const int blocks = (int)std::min<int64_t>(ann_blocks(c->n, 256 * 4), (int64_t)c->prop.multiProcessorCount * 8);
+            k_hs_collect<<<blocks, 256, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), c->n, be, hp, c->hs_key.as<unsigned long long>(),
+                                                       c->hs_pos.as<int32_t>(), d_cnt);
+            k_hs_finish<<<nbins, 1024, 0, c->stream>>>(c->hs_key.as<unsigned long long>(), c->hs_pos.as<int32_t>(), d_cnt, d_want, d_off, d_out,
+                                                      d_got);
+        }
+        ANN_CHECK_HIP(c, hipGetLastError());
+        ANN_TRY(ann_d2h(c, h_got.data(), d_got, sizeof(int32_t) * nbins));
+        bool redo = false;
+        for (int b = 0; b < nbins; ++b) {
+            if (h_got[b] < 0) {                       // list overflow: tighten the threshold
+                hp.thr[b] = hp.thr[b] / 2; redo = true;
+            } else if (h_got[b] < h_want[b]) {        // too few keys under the threshold: widen it
+                hp.thr[b] = hp.thr[b] > (~0ull >> 1) ? ~0ull : hp.thr[b] * 2; redo = true;
+            }
+        }
+        if (!redo) break;
+        ANN_REQUIRE(c, attempt < 7, ANNCHOR_ESTATE, "hashed sampling did not settle");
+    }
+    std::vector<int32_t> h_out((size_t)total);
+    if (total) ANN_TRY(ann_d2h(c, h_out.data(), d_out, sizeof(int32_t) * (size_t)total));
+    for (int64_t t = 0; t < total; ++t) positions[t] = h_out[(size_t)t];
+    *n_out = total;
+    return ANNCHOR_OK;
+}
+
 static int load_bins(annchor_ctx *c, const double *bins, int32_t nbins, BinEdges &be)
 {
     ANN_REQUIRE(c, nbins >= 1 && nbins <= MAXBINS, ANNCHOR_ELIMIT, "1..%d partitions supported", MAXBINS);

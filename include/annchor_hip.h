@@ -317,6 +317,14 @@ int annchor_device_copy(annchor_ctx *ctx, void *dst, const void *src, int64_t by
 int annchor_graph_to_coo(annchor_ctx *ctx, const int64_t *ng_idx, const double *ng_dist, int64_t nx, int32_t k,
                          int64_t *rows, int64_t *cols, double *vals, int64_t *nnz);
 
+/* DeviceStratifiedSampler (annchor_amd/samplers.py; protocol of annchor/samplers.py:75-110): the
+ * stratified draw with an order-free random choice.  Partition b (bins[b] <= dad < bins[b+1], not
+ * computed; counts[b] members, from annchor_bin_counts) keeps the min(want[b], counts[b]) members with
+ * the smallest key = splitmix64(seed_key ^ position), ties to the smaller position.  positions (HOST,
+ * room for sum of want): the samples, partition by partition, ascending position inside a partition. */
+int annchor_hash_sample(annchor_ctx *ctx, const double *bins, int32_t nbins, const int64_t *counts, const int64_t *want,
+                        uint64_t seed_key, int64_t *positions, int64_t *n_out);
+
 /* -------------------------------------------------------------- state access */
 int annchor_field_size(annchor_ctx *ctx, int32_t field, int64_t *n_elems);
 int annchor_download(annchor_ctx *ctx, int32_t field, void *dst, int64_t n_elems);

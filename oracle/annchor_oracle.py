@@ -235,6 +235,41 @@ def stratified_sample(feats, ncm, n_samples, seed, loop_num, n_partitions=7):
     return ixs, ixs.shape[0], bins
 
 
+def splitmix64(x):
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def hashed_stratified_sample(feats, ncm, n_samples, seed, loop_num, n_partitions=7):
+    """The build's DeviceStratifiedSampler (no reference counterpart: the reference's choice inside a
+    partition is np.random.choice, samplers.py:44-73): same partitions and quotas as
+    stratified_sample, members chosen by the smallest splitmix64((seed + loop_num) ^ position), ties to
+    the smaller position; output partition by partition, ascending position inside a partition."""
+    idx = np.nonzero(ncm)[0]
+    if idx.shape[0] == 0:
+        raise NothingToSample()
+    f = feats[idx, 2]
+    bins, n_samples = stratified_partition(f, n_samples, n_partitions)
+    if n_samples == 0:
+        raise NothingToSample()
+    keys = splitmix64(np.uint64((int(seed) + int(loop_num)) & ((1 << 64) - 1)) ^ idx.astype(np.uint64))
+    out = []
+    for b in range(n_partitions):
+        m = np.nonzero((f >= bins[b]) & (f < bins[b + 1]))[0]
+        want = n_samples // n_partitions + (1 if b < n_samples % n_partitions else 0)
+        if len(m) > want:
+            m = m[np.lexsort((idx[m], keys[m]))[:want]]
+        out.append(np.sort(idx[m]))
+    if min(len(o) for o in out) < 2:
+        raise Exception("Some sampler bins contain too few samples")
+    ixs = np.concatenate(out)
+    return ixs, ixs.shape[0], bins
+
+
 # -------------------------------------------------------------------------- a12
 def ols(X, y):
     """sklearn LinearRegression(fit_intercept=True).fit: centre, lstsq (gelsd)."""
@@ -465,7 +500,7 @@ class OracleAnnchor:
 
     def __init__(self, nx, metric_pairs, n_anchors=20, n_neighbors=15, n_samples=5000,
                  p_work=0.1, random_seed=42, locality=5, loc_thresh=1, loc_min=None,
-                 niters=2, lookahead=5, anchors=None, trace=None):
+                 niters=2, lookahead=5, anchors=None, trace=None, sampler="legacy"):
         self.nx, self.metric_pairs = nx, metric_pairs
         b = budget(nx, n_anchors, n_samples, p_work, n_neighbors, loc_min)
         self.N, self.na, self.p_work, self.loc_min = b["N"], b["na"], b["p_work"], b["loc_min"]
@@ -474,6 +509,7 @@ class OracleAnnchor:
         self.niters, self.lookahead = niters, lookahead
         self.evals = 0
         self.anchors = anchors
+        self.sampler = sampler   # "legacy": NumPy-stream choice (the reference's); "hashed": DeviceStratifiedSampler
         self.trace = trace  # optional dict collecting per-stage snapshots
 
     def _snap(self, key, **kw):
@@ -502,8 +538,8 @@ class OracleAnnchor:
         self.RA = None
         for it in range(self.niters):
             try:
-                self.sample_ixs, self.n_samples, self.bins = stratified_sample(
-                    self.features, self.ncm, self.n_samples, self.random_seed, it)
+                draw = hashed_stratified_sample if self.sampler == "hashed" else stratified_sample
+                self.sample_ixs, self.n_samples, self.bins = draw(self.features, self.ncm, self.n_samples, self.random_seed, it)
             except NothingToSample:
                 if it == 0:
                     raise ValueError("Sampler raised NothingToSample on first iteration.")

@@ -325,3 +325,26 @@ def test_to_sparse_matrix_equals_reference_loop():
             want[i, j] = want[j, i] = d + eps
     assert isinstance(got, dok_matrix) and (got != want).nnz == 0 and got.nnz == want.nnz
     assert got[5, 5] == eps   # explicit zero survives
+
+
+def test_device_stratified_sampler_numpy_protocol_equals_restatement():
+    """DeviceStratifiedSampler through the plain sample() protocol == the oracle's hashed_stratified_sample
+    (same partitions, same keys, same ties), including loop_num progression and sparse partitions."""
+    from annchor_amd.samplers import DeviceStratifiedSampler
+    from oracle import annchor_oracle as O
+
+    names = ["lower bound", "upper bound", "double anchor distance", "is anchor"]
+    rng = np.random.default_rng(3)
+    for trial in range(12):
+        n = int(rng.integers(4000, 30000))
+        f = np.round(rng.normal(10, 4, (n, 4)), int(rng.integers(0, 3)))
+        m = rng.random(n) < 0.85
+        s = DeviceStratifiedSampler()
+        for loop in range(2):
+            ns = int(rng.integers(60, 900))
+            got = s.sample(f, names, ns, m, 42)
+            want = O.hashed_stratified_sample(f, m, ns, 42, loop)
+            assert np.array_equal(got[0], want[0]) and got[1] == want[1] and np.array_equal(got[2], want[2])
+            assert len(np.unique(got[0])) == len(got[0]) and m[got[0]].all()
+            m = m.copy()
+            m[got[0]] = False
