@@ -57,6 +57,7 @@ _SIGNATURES = {
     "annchor_select_by_rank": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _vp]),
     "annchor_sample_pairs": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "annchor_hash_sample": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, ctypes.c_uint64, _vp, ctypes.POINTER(_i64)]),
+    "annchor_hash_sample_pairs": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, ctypes.c_uint64, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "annchor_legacy_prefetch": (ctypes.c_int, [ctypes.c_uint32, _i64]),
     "annchor_legacy_choice_ranks": (ctypes.c_int, [ctypes.c_uint32, _vp, _vp, _i32, _vp, _vp]),
     "annchor_legacy_choice_begin": (ctypes.c_int, [ctypes.c_uint32, _vp, _vp, _i32, ctypes.POINTER(_vp)]),
@@ -424,6 +425,16 @@ class Engine:
         self._chk(self.lib.annchor_hash_sample(self.h, _ptr(bins), len(bins) - 1, _ptr(counts), _ptr(want), int(seed_key) & (2 ** 64 - 1),
                                                _ptr(out), ctypes.byref(n)))
         return out[:n.value]
+
+    def hash_sample_pairs(self, bins, counts, want, seed_key):
+        """hash_sample + gather_features + evaluate_samples in one call (device metric only)."""
+        bins, counts, want = _c(bins, np.float64), _c(counts, np.int64), _c(want, np.int64)
+        m = int(np.minimum(counts, want).sum())
+        pos, feats, y = np.empty(m, dtype=np.int64), np.empty((m, 4), dtype=np.float64), np.empty(m, dtype=np.float64)
+        n = _i64()
+        self._chk(self.lib.annchor_hash_sample_pairs(self.h, _ptr(bins), len(bins) - 1, _ptr(counts), _ptr(want), int(seed_key) & (2 ** 64 - 1),
+                                                     _ptr(pos), _ptr(feats), _ptr(y), ctypes.byref(n)))
+        return pos[:n.value], feats[:n.value], y[:n.value]
 
     def gather_features(self, pos):
         pos = _c(pos, np.int64)

@@ -411,12 +411,10 @@ __global__ __launch_bounds__(1024) void k_hs_finish(const unsigned long long *__
     }
 }
 
-extern "C" int annchor_hash_sample(annchor_ctx *c, const double *bins, int32_t nbins, const int64_t *counts, const int64_t *want,
-                                   uint64_t seed_key, int64_t *positions, int64_t *n_out)
+// the choice itself: sample positions (int32, partition by partition) left on the device at *d_out_p
+static int hash_sample_device(annchor_ctx *c, const double *bins, int32_t nbins, const int64_t *counts, const int64_t *want,
+                              uint64_t seed_key, int32_t **d_out_p, int64_t *n_out)
 {
-    if (!c || !bins || !counts || !want || !positions || !n_out) return ANNCHOR_EINVAL;
-    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
-    ANN_CHECK_HIP(c, hipSetDevice(c->device));
     BinEdges be;
     ANN_TRY(load_bins(c, bins, nbins, be));
     HsParams hp;
@@ -467,6 +465,20 @@ extern "C" int annchor_hash_sample(annchor_ctx *c, const double *bins, int32_t n
         if (!redo) break;
         ANN_REQUIRE(c, attempt < 7, ANNCHOR_ESTATE, "hashed sampling did not settle");
     }
+    *d_out_p = d_out;
+    *n_out = total;
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_hash_sample(annchor_ctx *c, const double *bins, int32_t nbins, const int64_t *counts, const int64_t *want,
+                                   uint64_t seed_key, int64_t *positions, int64_t *n_out)
+{
+    if (!c || !bins || !counts || !want || !positions || !n_out) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    int32_t *d_out = nullptr;
+    int64_t total = 0;
+    ANN_TRY(hash_sample_device(c, bins, nbins, counts, want, seed_key, &d_out, &total));
     std::vector<int32_t> h_out((size_t)total);
     if (total) ANN_TRY(ann_d2h(c, h_out.data(), d_out, sizeof(int32_t) * (size_t)total));
     for (int64_t t = 0; t < total; ++t) positions[t] = h_out[(size_t)t];
@@ -842,6 +854,66 @@ extern "C" int annchor_sample_pairs(annchor_ctx *c, const double *bins, int32_t 
     }
     ANN_REQUIRE(c, !h_bad, ANNCHOR_ESTATE, "sample_pairs: a (bin, rank) entry does not exist (stale counts?)");
     if (c->n_unc >= 0) c->n_unc -= nreq;
+    return ANNCHOR_OK;
+}
+
+__global__ void k_i32_to_i64_pos(const int32_t *__restrict__ in, int64_t m, int64_t *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m) out[t] = in[t];
+}
+
+// annchor_hash_sample + annchor_gather_features + annchor_evaluate_samples in one call (device metric):
+// positions, feature rows and exact distances come back in one transfer.
+extern "C" int annchor_hash_sample_pairs(annchor_ctx *c, const double *bins, int32_t nbins, const int64_t *counts, const int64_t *want,
+                                         uint64_t seed_key, int64_t *positions, double *feats, double *sample_y, int64_t *n_out)
+{
+    if (!c || !bins || !counts || !want || !positions || !feats || !sample_y || !n_out) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_REQUIRE(c, c->metric != ANNCHOR_METRIC_NONE, ANNCHOR_EINVAL, "no device metric bound to this context");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    int32_t *d_pos = nullptr;
+    int64_t m = 0;
+    ANN_TRY(hash_sample_device(c, bins, nbins, counts, want, seed_key, &d_pos, &m));
+    *n_out = m;
+    c->nsamp = m;
+    if (m == 0) return ANNCHOR_OK;
+    const size_t stage_bytes = sizeof(double) * (6 * (size_t)m + 1);
+    ANN_TRY(ann_reserve(c, c->stage_out, stage_bytes));
+    ANN_TRY(ann_reserve(c, c->spos, sizeof(int32_t) * (size_t)m + 16));
+    ANN_TRY(ann_reserve(c, c->sy, sizeof(double) * (size_t)m));
+    int32_t *bad = c->spos.as<int32_t>() + m;
+    ANN_CHECK_HIP(c, hipMemsetAsync(bad, 0, 4, c->stream));
+    ANN_CHECK_HIP(c, hipMemcpyAsync(c->spos.p, d_pos, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToDevice, c->stream));
+    double *st_feats = c->stage_out.as<double>() + m, *st_y = st_feats + 4 * (size_t)m;
+    int64_t *st_bad = reinterpret_cast<int64_t *>(st_y + m);
+    k_i32_to_i64_pos<<<ann_blocks(m, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), m, c->stage_out.as<int64_t>());
+    k_gather_features<<<ann_blocks(m, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), m, c->lb.as<double>(), c->ub.as<double>(),
+                                                                c->dad.as<double>(), c->anc.as<uint8_t>(), st_feats);
+    PairSource src;
+    src.ij = c->ij.as<int2>();
+    src.idx = c->spos.as<int32_t>();
+    src.n = m;
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    ANN_TRY(ann_metric_launch(c, src, c->sy.as<double>(), nullptr, nullptr));
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+    c->call_timed = true;
+    k_clear_flags_stage<<<ann_blocks(m, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), m, c->ncm.as<uint8_t>(), c->sy.as<double>(), bad,
+                                                                  st_y, st_bad);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    if (c->pin && stage_bytes <= annchor_ctx::PIN_DL_BYTES) {   // one transfer, one wait
+        unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
+        ANN_CHECK_HIP(c, hipMemcpyAsync(slot, c->stage_out.p, stage_bytes, hipMemcpyDeviceToHost, c->stream));
+        ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        memcpy(positions, slot, sizeof(int64_t) * (size_t)m);
+        memcpy(feats, slot + sizeof(double) * (size_t)m, sizeof(double) * 4 * (size_t)m);
+        memcpy(sample_y, slot + sizeof(double) * 5 * (size_t)m, sizeof(double) * (size_t)m);
+    } else {
+        ANN_TRY(ann_d2h(c, positions, c->stage_out.p, sizeof(int64_t) * (size_t)m));
+        ANN_TRY(ann_d2h(c, feats, st_feats, sizeof(double) * 4 * (size_t)m));
+        ANN_TRY(ann_d2h(c, sample_y, st_y, sizeof(double) * (size_t)m));
+    }
+    if (c->n_unc >= 0) c->n_unc -= m;
     return ANNCHOR_OK;
 }
 

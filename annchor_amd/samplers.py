@@ -266,12 +266,14 @@ class DeviceStratifiedSampler(SimpleStratifiedSampler):
         self.loop_num += 1
         if np.minimum(ticket["counts"], ticket["want"]).min() < 2:
             raise Exception("Some sampler bins contain too few samples")
-        sample_ixs = engine.hash_sample(sample_bins, ticket["counts"], ticket["want"], ticket["key"])
+        extra = ()
+        if evaluate:   # device metric: positions, feature rows and distances in one device pass
+            sample_ixs, feats, y = engine.hash_sample_pairs(sample_bins, ticket["counts"], ticket["want"], ticket["key"])
+            extra = (feats, y)
+        else:
+            sample_ixs = engine.hash_sample(sample_bins, ticket["counts"], ticket["want"], ticket["key"])
         if ticket["n_samples"] != sample_ixs.shape[0]:
             print("Warning: Some bins contained fewer samples than requested")
-        extra = ()
-        if evaluate:
-            extra = (engine.gather_features(sample_ixs), engine.evaluate_samples(sample_ixs))
         return (sample_ixs, sample_ixs.shape[0], sample_bins) + extra
 
 

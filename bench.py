@@ -96,6 +96,13 @@ def pairlist_at_scale(local, n=16000):
                       "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
     res = _scale_result(ann, n, dt, fams)
     ann._engine.close()   # ~10 GB of device arena: release it now, not whenever the collector runs
+    from annchor_amd.samplers import DeviceStratifiedSampler
+
+    ann = Annchor(X, "euclidean", device=local, sampler=DeviceStratifiedSampler(), **cfg)
+    t = time.perf_counter()
+    ann.fit()
+    res["fit_time_s_device_sampler_plugin"] = time.perf_counter() - t
+    ann._engine.close()
     return res
 
 
@@ -103,7 +110,8 @@ def _scale_result(ann, n, dt, fams):
     return {"workload": "synthetic Euclidean f64 N=%d d=48 n_anchors=24 k=15 p_work=0.05 (pair-list form)" % n,
             "pairs": int(ann.n_pairs), "evals": int(ann.evals), "fit_time_s_profiled": dt,
             "host_stage_ms": {k: round(v * 1e3, 1) for k, v in ann.timings.items()}, "kernels": fams,
-            "note": "fit time at this size is the host-side legacy-RNG sampling (get_sample); the table is the device kernels"}
+            "note": "fit time at this size is the default sampler's host-side NumPy-stream shuffle (get_sample); the table is the device "
+                    "kernels; fit_time_s_device_sampler_plugin = the same fit with the order-free DeviceStratifiedSampler"}
 
 
 def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, recall_rows=10000):
@@ -396,6 +404,30 @@ def strings_run(args, steps, warmup, world, rank, local, dist, torch, all_cpus, 
     return out
 
 
+def device_sampler_block(local):
+    """The headline workload with the DeviceStratifiedSampler plugin (order-free hashed choice on the GPU)
+    in place of the default sampler's NumPy-stream shuffle: a different random sample, so a different
+    draw of the error count; not the headline (the default sampler is the reference's)."""
+    from annchor_amd import Annchor, compare_neighbor_graphs
+    from annchor_amd.samplers import DeviceStratifiedSampler
+
+    X, metric, kwargs, cfg, workload = strings_workload()
+    anns = [Annchor(X, metric, func_kwargs=kwargs, device=local, sampler=DeviceStratifiedSampler(), **cfg) for _ in range(23)]
+    ts = []
+    for a in anns:
+        t = time.perf_counter()
+        a.fit()
+        ts.append(time.perf_counter() - t)
+    G = np.load(os.path.join(ROOT, "tests", "golden", "strings_full.npz"))
+    truth = (G["truth_idx"].astype(np.int64), G["truth_dist"].astype(np.float64))
+    err = compare_neighbor_graphs(truth, anns[-1].neighbor_graph, cfg["n_neighbors"])
+    res = {"workload": workload + ", sampler=DeviceStratifiedSampler()", "fit_time_s": float(np.median(ts[3:])),
+           "errors_vs_bruteforce": int(err), "host_stage_ms": {k: round(v * 1e3, 3) for k, v in anns[-1].timings.items()}}
+    for a in anns:
+        a._engine.close()
+    return res
+
+
 def c4_block(local):
     """BASELINE configs[3]: load_digits Wasserstein (exact EMD), N=1797, n_anchors=20, k=25, p_work=0.16."""
     from annchor_amd import Annchor, compare_neighbor_graphs
@@ -509,6 +541,10 @@ def main():
 
     if world == 1:
         out = strings_run(args, args.steps, args.warmup, world, rank, local, dist, torch, all_cpus, affinity)
+        try:
+            out["c2_device_sampler_plugin"] = device_sampler_block(local)
+        except Exception as e:
+            out["c2_device_sampler_plugin"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
             out["c4_digits_wasserstein"] = c4_block(local)
         except Exception as e:

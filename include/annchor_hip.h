@@ -324,6 +324,11 @@ int annchor_graph_to_coo(annchor_ctx *ctx, const int64_t *ng_idx, const double *
  * room for sum of want): the samples, partition by partition, ascending position inside a partition. */
 int annchor_hash_sample(annchor_ctx *ctx, const double *bins, int32_t nbins, const int64_t *counts, const int64_t *want,
                         uint64_t seed_key, int64_t *positions, int64_t *n_out);
+/* The same choice followed by the samples' feature rows (annchor.py:325-338) and exact distances
+ * (get_exact on the sampled pairs, annchor.py:340) in one call: feats float64 [m, 4], sample_y
+ * float64 [m]; the sampled pairs become computed.  Device metric only. */
+int annchor_hash_sample_pairs(annchor_ctx *ctx, const double *bins, int32_t nbins, const int64_t *counts, const int64_t *want,
+                              uint64_t seed_key, int64_t *positions, double *feats, double *sample_y, int64_t *n_out);
 
 /* -------------------------------------------------------------- state access */
 int annchor_field_size(annchor_ctx *ctx, int32_t field, int64_t *n_elems);
