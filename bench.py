@@ -98,6 +98,7 @@ def pairlist_at_scale(local, n=16000):
     ann._engine.close()   # ~10 GB of device arena: release it now, not whenever the collector runs
     from annchor_amd.samplers import DeviceStratifiedSampler
 
+    Annchor(X, "euclidean", device=local, sampler=DeviceStratifiedSampler(), **cfg).fit()   # warm (the 10 GB arena is re-created)
     ann = Annchor(X, "euclidean", device=local, sampler=DeviceStratifiedSampler(), **cfg)
     t = time.perf_counter()
     ann.fit()
