@@ -213,6 +213,10 @@ class Annchor:
     # ------------------------------------------------------------- lazy NumPy views
     def _view(self, key, loader):
         if key not in self._cache:
+            if getattr(self, "_enemy_extended", False) and key in ("labels", "thresh", "cand", "next", "sid"):
+                raise RuntimeError("get_nearest_enemies() extended IJs / RefineApprox / not_computed_mask / features / I by the "
+                                   "enemy pairs; '%s' of the fitted pair list is no longer aligned with them (read it before, "
+                                   "or refit)" % key)
             self._cache[key] = loader()
         return self._cache[key]
 
@@ -266,6 +270,9 @@ class Annchor:
 
     # --------------------------------------------------------------------- stages
     def _pair_list_stage(self, what):
+        if getattr(self, "_enemy_extended", False):
+            raise RuntimeError("%s: get_nearest_enemies() extended this object's pair list on the host; the fitted device "
+                               "state no longer matches it -- build a new Annchor to run the stages again" % what)
         if self._streamed is not None:
             raise NotImplementedError("%s is a stage of the pair-list form; this object runs the streamed form "
                                       "(fit() does everything; pass streamed=False for the staged pipeline)" % what)

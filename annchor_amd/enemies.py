@@ -178,7 +178,11 @@ def nearest_enemies(ann, y, nn=3, loc_min=100):
     ngi = L.other[top].reshape(nx, nn)
     ngd = RA[pos[top]].reshape(nx, nn)
 
+    # Like the reference (annchor.py:748-781), the object's pair-list views now include the enemy pairs.
+    # The device keeps the fitted (shorter) state, so the views that are loaded lazily from it and the
+    # stage methods no longer describe the same pair list: the object says so instead of mixing lengths.
     ann._cache.update(IJs=IJs, RA=RA, ncm=ncm, features=feats, I=_IndexCSR(ptr, pos))
+    ann._enemy_extended = True
     ann.nearest_enemy_graph = (ngi, ngd)
     return ngi, ngd
 

@@ -25,7 +25,15 @@ Pinning status:
     capture) use NumPy's legacy global RNG with the same seed arithmetic --
     "parity unpinned" for the exact sample set of a real numba run;
   * OLS coefficients: sklearn LinearRegression (regressors.py:33,68) -- pinned by
-    captured coefficients only.
+    captured coefficients only;
+  * query (query_functions.py:10-212, annchor.py:643-683): pinned -- gen_query() in
+    tests/golden/make_golden.py drives the imported reference's helpers stage by stage and
+    Annchor.query end to end (strings split + the digits split of the reference's own test);
+  * order inside groups of equal refinement probability (annchor.py:444-457: np.argpartition,
+    arbitrary): a fixed scrambled-position order here (select_candidates); compared with the
+    reference set-wise (same cut value, same members strictly above it);
+  * hashed_stratified_sample: restates the BUILD's DeviceStratifiedSampler plugin, which has
+    no reference counterpart (the reference's draw is stratified_sample).
 """
 from __future__ import annotations
 
