@@ -276,52 +276,49 @@ __global__ void k_st_transpose_D(const float *__restrict__ D, int64_t n, int na,
     Dt[t] = a < na ? D[(size_t)a * n + p] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void k_st_spread(const float *__restrict__ Dt, int nap, const uint32_t *__restrict__ order, int64_t n,
-                                                  int na, int level, double *__restrict__ ssum, double *__restrict__ ssq)
+// Split coordinate of every segment of a level: the anchor whose distances vary most inside the
+// segment.  One workgroup per segment, no atomics (the sums are reduced in a fixed order, so the
+// choice -- and with it the tiling -- is the same on every run): thread = (sample lane, anchor), a
+// point's anchor vector is one coalesced 128 / 256-byte read of the point-major copy; segments longer
+// than ST_SPLIT_SAMPLE points are judged on that many evenly spaced members.
+#define ST_SPLIT_SAMPLE 2048
+__global__ __launch_bounds__(256) void k_st_split_coord(const float *__restrict__ Dt, int nap, const uint32_t *__restrict__ order,
+                                                       int64_t n, int na, int level, int32_t *__restrict__ coord)
 {
-    // per (segment, anchor): sum and sum of squares of the anchor distances
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = p < n;
-    const int seg = ok ? st_seg_of(p, n, level) : -1;
-    const int seg0 = __shfl(seg, 0), seg63 = __shfl(ok ? seg : seg0, 63);
-    const uint32_t src = ok ? order[p] : 0;
-    const float4 *row = reinterpret_cast<const float4 *>(Dt + (size_t)src * nap);
-    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int a = 0; a < na; ++a) {
-        if ((a & 3) == 0 && ok) q4 = row[a >> 2];
-        const float qv = (a & 3) == 0 ? q4.x : (a & 3) == 1 ? q4.y : (a & 3) == 2 ? q4.z : q4.w;
-        const double v = ok ? (double)qv : 0.0;
-        if (seg0 == seg63 && seg0 >= 0) {  // whole wave inside one segment: reduce first
-            double s1 = v, s2 = v * v;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
-            if ((threadIdx.x & 63) == 0) {
-                atomicAdd(&ssum[(size_t)seg0 * na + a], s1);
-                atomicAdd(&ssq[(size_t)seg0 * na + a], s2);
-            }
-        } else if (ok) {
-            atomicAdd(&ssum[(size_t)seg * na + a], v);
-            atomicAdd(&ssq[(size_t)seg * na + a], v * v);
-        }
-    }
-}
-
-__global__ void k_st_pick_coord(const double *__restrict__ ssum, const double *__restrict__ ssq, int64_t n, int level, int nseg,
-                                int na, int32_t *__restrict__ coord)
-{
-    // split every segment along the anchor coordinate of largest variance
-    const int sgm = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sgm >= nseg) return;
+    __shared__ double s1[256], s2[256];
+    const int sgm = blockIdx.x;
     const int64_t b = ((int64_t)sgm * n + (1ll << level) - 1) >> level, e = ((int64_t)(sgm + 1) * n + (1ll << level) - 1) >> level;
-    const double cnt = (double)(e - b > 0 ? e - b : 1);
-    double best = -1.0;
-    int ba = 0;
-    for (int a = 0; a < na; ++a) {
-        const double m = ssum[(size_t)sgm * na + a] / cnt;
-        const double var = ssq[(size_t)sgm * na + a] / cnt - m * m;
-        if (var > best) { best = var; ba = a; }
+    const int64_t len = e - b;
+    const int A = nap <= 32 ? 32 : 64;        // anchors per sample lane group (na <= 64)
+    const int G = 256 / A;                    // sample lanes
+    const int an = threadIdx.x % A, g = threadIdx.x / A;
+    const int64_t m = len < ST_SPLIT_SAMPLE ? len : ST_SPLIT_SAMPLE;
+    double a1 = 0.0, a2 = 0.0;
+    if (an < na)
+        for (int64_t t = g; t < m; t += G) {
+            const int64_t p = b + (m == len ? t : (t * len) / m);
+            const double v = (double)Dt[(size_t)order[p] * nap + an];
+            a1 += v;
+            a2 += v * v;
+        }
+    s1[threadIdx.x] = a1;
+    s2[threadIdx.x] = a2;
+    __syncthreads();
+    if (threadIdx.x < A) {   // fixed-order reduction over the sample lanes
+        double t1 = 0.0, t2 = 0.0;
+        for (int q = 0; q < G; ++q) { t1 += s1[q * A + threadIdx.x]; t2 += s2[q * A + threadIdx.x]; }
+        const double cnt = (double)(m > 0 ? m : 1);
+        const double mean = t1 / cnt;
+        s1[threadIdx.x] = threadIdx.x < na ? t2 / cnt - mean * mean : -1.0;
     }
-    coord[sgm] = ba;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double best = -1.0;
+        int ba = 0;
+        for (int a = 0; a < na; ++a)
+            if (s1[a] > best) { best = s1[a]; ba = a; }   // first maximum
+        coord[sgm] = ba;
+    }
 }
 
 __global__ void k_st_level_keys(const float *__restrict__ D, const uint32_t *__restrict__ order, int64_t n, int level,
@@ -429,7 +426,6 @@ extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs
     const int max_seg = 1 << levels;
     ANN_TRY(sreserve(c, s->red_val, sizeof(double) * 2 * (size_t)max_seg * s->na));
     ANN_TRY(sreserve(c, s->red_idx, sizeof(int32_t) * (size_t)max_seg));
-    double *ssum = s->red_val.as<double>(), *ssq = ssum + (size_t)max_seg * s->na;
     uint32_t *cur = s->vals.as<uint32_t>(), *nxt = s->vals2.as<uint32_t>();
     k_st_iota<<<ann_blocks(n, 256), 256, 0, c->stream>>>(cur, n);
     const int nap = (s->na + 3) & ~3;
@@ -441,10 +437,7 @@ extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs
     ANN_TRY(sreserve(c, s->cubtmp, tmp_bytes));
     for (int level = 0; level < levels; ++level) {
         const int nseg = 1 << level;
-        ANN_CHECK_HIP(c, hipMemsetAsync(ssum, 0, sizeof(double) * (size_t)nseg * s->na, c->stream));
-        ANN_CHECK_HIP(c, hipMemsetAsync(ssq, 0, sizeof(double) * (size_t)nseg * s->na, c->stream));
-        k_st_spread<<<ann_blocks(n, 256), 256, 0, c->stream>>>(s->Dt.as<float>(), nap, cur, n, s->na, level, ssum, ssq);
-        k_st_pick_coord<<<ann_blocks(nseg, 256), 256, 0, c->stream>>>(ssum, ssq, n, level, nseg, s->na, s->red_idx.as<int32_t>());
+        k_st_split_coord<<<nseg, 256, 0, c->stream>>>(s->Dt.as<float>(), nap, cur, n, s->na, level, s->red_idx.as<int32_t>());
         k_st_level_keys<<<ann_blocks(n, 256), 256, 0, c->stream>>>(s->D.as<float>(), cur, n, level, s->red_idx.as<int32_t>(),
                                                                   s->keys.as<unsigned long long>());
         ANN_CHECK_HIP(c, hipcub::DeviceRadixSort::SortPairs(s->cubtmp.p, tmp_bytes, s->keys.as<unsigned long long>(),

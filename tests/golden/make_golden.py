@@ -19,7 +19,7 @@ The reference needs three third-party modules that are not installed here
 So: vectors for the reference's OWN functions (a0, a6-a17) are genuine reference
 outputs; metric values inside them come from the oracle's metric restatements.
 
-Usage:  python tests/golden/make_golden.py [small|blobs|strings_full|digits_full|enemies|query|all]
+Usage:  python tests/golden/make_golden.py [small|blobs|strings_full|digits_full|enemies|query|graph_sp|all]
 """
 import os
 import sys
@@ -401,8 +401,51 @@ def ev_q_factory(H, A, ntr):
     return ev_q
 
 
+def gen_graph_sp():
+    """The reference's shortest-path example (tests/test_annchor.py:105-145): X = node ids, the metric an
+    arbitrary Python callable.  The fixture holds the reference's data files' arrays (edge list, node sample,
+    its stored exact 15-NN graph) and the reference's fit on them; the all-pairs table the callable reads is
+    checked against networkx's Dijkstra on the reference test's three known answers."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import dijkstra
+    import networkx as nkx
+    from annchor.datasets import load_graph_sp
+
+    data = load_graph_sp()
+    X, ng, G = data["X"], data["neighbor_graph"], data["G"]
+    g = np.load(os.path.join(os.path.dirname(ref.__file__), "data", "graph.npz"))
+    edges, weights = g["edges"], g["weights"]
+    n = int(edges.max()) + 1
+    W = coo_matrix((weights, (edges[:, 0], edges[:, 1])), shape=(n, n)).tocsr()
+    SP = dijkstra(W, directed=False)
+    for i, j in ((0, 0), (2, 5), (300, 701), (10, 4)):
+        assert np.isclose(SP[i, j], nkx.dijkstra_path_length(G, i, j, weight="w"), rtol=0, atol=1e-12), (i, j)
+
+    def sp_dist(i, j):
+        return SP[i, j]
+
+    out = dict(edges=edges.astype(np.int32), weights=weights, X=X.astype(np.int32),
+               ng_idx=ng[0][:, :16].astype(np.int32), ng_dist=ng[1][:, :16].copy())
+    cfg = dict(n_anchors=20, n_neighbors=15, random_seed=42, n_samples=5000, p_work=0.15)
+    t = time.time()
+    ann = ref.Annchor(X, sp_dist, **cfg)
+    ann.fit()
+    err = ref.compare_neighbor_graphs(ng, ann.neighbor_graph, 15)
+    print("graph_sp evals", ann.evals, "pairs", ann.IJs.shape[0], "errors", err, "%.0fs" % (time.time() - t))
+    out["A"] = np.asarray(ann.A, dtype=np.int64)
+    out["D"] = np.ascontiguousarray(ann.D)
+    out["evals"] = np.int64(ann.evals)
+    out["npairs"] = np.int64(ann.IJs.shape[0])
+    out["errors"] = np.int64(err)
+    out["fit_ng_idx"] = ann.neighbor_graph[0].astype(np.int32)
+    out["fit_ng_dist"] = ann.neighbor_graph[1].copy()
+    save("graph_sp", out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("graph_sp", "all"):
+        gen_graph_sp()
     if what in ("small", "all"):
         gen_small()
     if what in ("blobs", "all"):

@@ -574,3 +574,50 @@ def test_query_reference_strings_split(strings):
         e_gpu = compare_neighbor_graphs(truth, (gi, gd), nn)
         e_ref = compare_neighbor_graphs(truth, (G[tag + "_e2e_idx"], G[tag + "_e2e_dist"]), nn)
         assert e_gpu <= e_ref + 0.02 * len(Q) * nn + 2, (e_gpu, e_ref)   # no worse than the reference's run (tie order differs)
+
+
+# ------------------------------------------------------------------ reference e2e tests not covered above
+def test_fit_digits_reference_test_config():
+    """reference tests/test_annchor.py:35-68 (n_anchors=25): anchors, anchor distances and evaluation count
+    of the reference's own run; its bar of < 10 errors."""
+    from annchor_amd import Annchor, compare_neighbor_graphs
+
+    d = om.load_digits()
+    G = np.load(os.path.join(GOLD, "digits_full.npz"))
+    ann = Annchor(d["X"], "wasserstein", func_kwargs={"cost_matrix": d["cost_matrix"]}, n_anchors=25,
+                  n_neighbors=25, n_samples=5000, p_work=0.16, random_seed=42).fit()
+    assert np.array_equal(ann.A, G["test_A"])
+    np.testing.assert_allclose(ann.D, G["test_D"], rtol=0, atol=1e-12)
+    assert ann.evals == int(G["test_evals"])
+    assert compare_neighbor_graphs(d["neighbor_graph"], ann.neighbor_graph, 25) < 10
+
+
+def test_fit_graph_sp_python_metric():
+    """reference tests/test_annchor.py:105-145: an arbitrary Python callable over node ids (shortest-path
+    length).  The callable runs on the host, everything else on the GPU; anchors, anchor distances,
+    evaluation count equal the reference's own run (tests/golden/graph_sp.npz), the graph the restatement's."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import dijkstra
+    from annchor_amd import Annchor, compare_neighbor_graphs
+
+    G = np.load(os.path.join(GOLD, "graph_sp.npz"))
+    e, w = G["edges"].astype(np.int64), G["weights"]
+    n = int(e.max()) + 1
+    SP = dijkstra(coo_matrix((w, (e[:, 0], e[:, 1])), shape=(n, n)).tocsr(), directed=False)
+    assert np.isclose(SP[2, 5], 0.1487023176704947) and np.isclose(SP[300, 701], 1.2342577780314983)
+
+    def sp_dist(i, j):
+        return SP[i, j]
+
+    ann = Annchor(G["X"].astype(np.int64), sp_dist, n_anchors=20, n_neighbors=15, random_seed=42,
+                  n_samples=5000, p_work=0.15).fit()
+    assert np.array_equal(ann.A, G["A"])
+    assert np.array_equal(ann.D, G["D"])
+    assert ann.evals == int(G["evals"]) and ann.n_pairs == int(G["npairs"])
+    X = G["X"].astype(np.int64)
+    ora = O.OracleAnnchor(len(X), lambda IJ: SP[X[IJ[:, 0]], X[IJ[:, 1]]], n_anchors=20, n_neighbors=15,
+                          n_samples=5000, p_work=0.15, random_seed=42).fit()
+    assert np.array_equal(ann.neighbor_graph[1], ora.neighbor_graph[1])
+    assert np.array_equal(ann.neighbor_graph[0], ora.neighbor_graph[0])
+    err = compare_neighbor_graphs((G["ng_idx"].astype(np.int64), G["ng_dist"]), ann.neighbor_graph, 15)
+    assert err <= int(G["errors"]) < 10
