@@ -48,6 +48,11 @@ struct annchor_ctx {
     int64_t nx = 0;
     DevBuf sym, soff, slen;  // strings: symbols (uint8, 16B-aligned starts), int32 offsets, int32 lens
     int alphabet = 0, maxlen = 0;
+    // Levenshtein slot packing: patterns of <= lev_gl0 words fit one more pair per wave than the data
+    // set's longest string allows (0: no such class); lev_frac0 = share of the strings that short
+    int lev_gl0 = 0;
+    double lev_frac0 = 0.0;
+    DevBuf lev_perm;         // int32 [n] pair positions, short patterns first / long ones from the back; + 2 counters
     DevBuf pts;              // points (f32 or f64) row-major [nx, dim]
     int dim = 0;
     DevBuf hist, cost, supp; // histograms f64 [nx, nbins], cost [nbins, nbins], support sizes int32 [nx]

@@ -436,6 +436,21 @@ extern "C" int annchor_set_strings(annchor_ctx *c, const uint8_t *symbols, const
     c->nx = nx;
     c->alphabet = alphabet;
     c->maxlen = maxlen;
+    {   // slot classes of the Levenshtein kernel (lev.hip, k_lev_f): P pairs per wave for the longest string,
+        // P + 1 for pairs whose shorter string has <= 64 / (P + 1) words
+        const int W = (maxlen + 31) / 32 > 0 ? (maxlen + 31) / 32 : 1;
+        c->lev_gl0 = 0;
+        c->lev_frac0 = 0.0;
+        if (W <= 32) {
+            const int gl0 = 64 / (64 / W + 1);
+            if (gl0 >= 1) {
+                int64_t cnt = 0;
+                for (int64_t s = 0; s < nx; ++s) cnt += (lens[s] + 31) / 32 <= gl0;
+                c->lev_gl0 = gl0;
+                c->lev_frac0 = (double)cnt / (double)nx;
+            }
+        }
+    }
     reset_pipeline(c);
     return ANNCHOR_OK;
 }

@@ -256,6 +256,12 @@ struct LevArgsR {
     double *pick_runmin;
     int32_t *pick_out;
     int pick_reset, pick_nx;
+    // two slot classes in one launch (k_lev_f): pairs whose shorter string has <= GL0 words run P0 = 64 / GL0 to a
+    // wave, the rest P = 64 / GL.  perm[0 .. *n0) = list positions of the short class, perm[n-1 .. *n0]
+    // (from the back) those of the long class; perm == nullptr: one class (GL, P), identity order.
+    const int32_t *perm;
+    const int32_t *n0;
+    int GL0, P0;
 };
 
 #define LEVR_PAD 64   // text entries of padding either side of a slot's text (>= lanes per slot)
@@ -525,20 +531,11 @@ __global__ __launch_bounds__(ANN_WAVE) void k_lev_f(LevArgsR ar)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LevArgs &a = ar.b;
     const int lane = threadIdx.x;
-    const int GL = ar.GL, P = a.P, A = a.alphabet;
-    const int g = lane / GL;         // pair slot of this lane
-    const int w = lane - g * GL;     // word of the slot's pattern this lane owns
-    const bool slot_ok = g < P;
+    const int A = a.alphabet;
     // PM: [2 halves][A symbols][32 lanes] uint32; this lane's column
     unsigned char *pm_col = smem + (size_t)(lane >> 5) * A * LEVF_ROW + (size_t)(lane & 31) * 4;
-    // text of a slot: one byte per symbol (its dense code), LEVR_PAD bytes of padding either side so that
-    // the pipelined reads of lanes outside their column range stay inside the slot (values never used)
-    uint8_t *txt_g = smem + a.pm_bytes + (size_t)(slot_ok ? g : 0) * a.text_stride;
-    int *ssum = reinterpret_cast<int *>(smem + a.pm_bytes + (size_t)P * a.text_stride);
-    const int64_t n_tasks = (a.n + P - 1) / P;
-
-    if (slot_ok)
-        for (int e = w * 16; e < a.text_stride; e += GL * 16) *reinterpret_cast<uint4 *>(txt_g + e) = make_uint4(0, 0, 0, 0);
+    const int Pmax = ar.perm ? ar.P0 : a.P;
+    int *ssum = reinterpret_cast<int *>(smem + a.pm_bytes + (size_t)Pmax * a.text_stride);
 
     int picked = -1;
     if (ar.pick_row) {   // fused max-min pick, as in k_lev_r
@@ -572,6 +569,20 @@ __global__ __launch_bounds__(ANN_WAVE) void k_lev_f(LevArgsR ar)
         picked = bi;
         if (blockIdx.x == 0 && lane == 0) *ar.pick_out = bi;
     }
+    const int64_t n_short = ar.perm ? (int64_t)*ar.n0 : 0;
+  for (int cls = ar.perm ? 0 : 1; cls < 2; ++cls) {
+    // class 0: short patterns, P0 slots of GL0 lanes; class 1: the data set's general layout
+    const int GL = cls == 0 ? ar.GL0 : ar.GL, P = cls == 0 ? ar.P0 : a.P;
+    const int64_t n_cls = ar.perm ? (cls == 0 ? n_short : a.n - n_short) : a.n;
+    const int g = lane / GL;         // pair slot of this lane
+    const int w = lane - g * GL;     // word of the slot's pattern this lane owns
+    const bool slot_ok = g < P;
+    // text of a slot: one byte per symbol (its dense code), LEVR_PAD bytes of padding either side so that
+    // the pipelined reads of lanes outside their column range stay inside the slot (values never used)
+    uint8_t *txt_g = smem + a.pm_bytes + (size_t)(slot_ok ? g : 0) * a.text_stride;
+    const int64_t n_tasks = (n_cls + P - 1) / P;
+    if (slot_ok)
+        for (int e = w * 16; e < a.text_stride; e += GL * 16) *reinterpret_cast<uint4 *>(txt_g + e) = make_uint4(0, 0, 0, 0);
     // carry-in constants of this lane: the first lane of a slot sees the row above the pattern
     // (horizontal delta +1: hp carry 1, hn carry 0) instead of the previous slot's last word
     uint32_t hp_or = w == 0 ? 0x80000000u : 0u;
@@ -579,8 +590,10 @@ __global__ __launch_bounds__(ANN_WAVE) void k_lev_f(LevArgsR ar)
     asm volatile("" : "+v"(hp_or), "+v"(hn_and));   // opaque: keeps them operands of v_or_b32_dpp / v_and_b32_dpp (not a select)
 
     for (int64_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
-        const int64_t t_pair = task * P + g;
-        const bool active = slot_ok && t_pair < a.n;
+        const int64_t t_cls = task * P + g;
+        const bool active = slot_ok && t_cls < n_cls;
+        int64_t t_pair = t_cls;
+        if (active && ar.perm) t_pair = cls == 0 ? ar.perm[t_cls] : ar.perm[a.n - 1 - t_cls];
         int si = 0, sj = 0;
         int64_t opos = t_pair;
         if (active) {
@@ -593,7 +606,9 @@ __global__ __launch_bounds__(ANN_WAVE) void k_lev_f(LevArgsR ar)
             }
         }
         const int li = active ? a.slen[si] : 0, lj = active ? a.slen[sj] : 0;
-        const bool swap = li < lj;
+        // the pattern (bit-vector side) is the longer string -- fewer text columns to walk -- except in the
+        // short class, whose point is that the SHORTER string fits the narrow slot
+        const bool swap = cls == 0 ? li > lj : li < lj;
         const int ps = swap ? sj : si, ts = swap ? si : sj;
         const int m = swap ? lj : li, n = swap ? li : lj;
         const uint8_t *pat = a.sym + (active ? a.soff[ps] : 0);
@@ -679,6 +694,45 @@ __global__ __launch_bounds__(ANN_WAVE) void k_lev_f(LevArgsR ar)
         }
         wave_lds_fence();
     }
+  }
+}
+
+// Splits a pair list into the two slot classes of k_lev_f: list position t goes to the front of perm when
+// the shorter string of its pair has <= gl0 words, to the back otherwise (block-wise ranges reserved with
+// two atomic cursors: the order inside a class is arbitrary, every pair's result is stored by position).
+__global__ __launch_bounds__(256) void k_lev_classify(const int2 *__restrict__ ij, const int32_t *__restrict__ idx,
+                                                      const int32_t *__restrict__ slen, int64_t n, int gl0,
+                                                      int32_t *__restrict__ perm, int32_t *__restrict__ cursors)
+{
+    __shared__ int wcnt[2][4];
+    __shared__ int base[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool is_short = false, is_long = false;
+    if (t < n) {
+        const int2 p = ij[idx ? idx[t] : t];
+        const int m = min(slen[p.x], slen[p.y]);
+        is_short = ((m + 31) >> 5) <= gl0;
+        is_long = !is_short;
+    }
+    const unsigned long long bs = __ballot(is_short), bl = __ballot(is_long);
+    if (lane == 0) { wcnt[0][wave] = __popcll(bs); wcnt[1][wave] = __popcll(bl); }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int tot = wcnt[threadIdx.x][0] + wcnt[threadIdx.x][1] + wcnt[threadIdx.x][2] + wcnt[threadIdx.x][3];
+        base[threadIdx.x] = tot ? atomicAdd(&cursors[threadIdx.x], tot) : 0;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (is_short) {
+        int r = base[0] + __popcll(bs & below);
+        for (int q = 0; q < wave; ++q) r += wcnt[0][q];
+        perm[r] = (int32_t)t;
+    } else if (is_long) {
+        int r = base[1] + __popcll(bl & below);
+        for (int q = 0; q < wave; ++q) r += wcnt[1][q];
+        perm[n - 1 - r] = (int32_t)t;
+    }
 }
 
 static int launch_f(annchor_ctx *c, LevArgs a, int64_t npairs, const PairSource &src)
@@ -691,7 +745,27 @@ static int launch_f(annchor_ctx *c, LevArgs a, int64_t npairs, const PairSource 
     a.P = 64 / ar.GL;
     a.pm_bytes = 2 * a.alphabet * LEVF_ROW;
     a.text_stride = 2 * LEVR_PAD + ((c->maxlen + 15) & ~15) + 16;
-    a.wave_bytes = a.pm_bytes + a.P * a.text_stride + 256;
+    // Slot classes: with strings of up to W words a wave holds P = 64 / W pairs, yet the pattern is the
+    // SHORTER string of a pair; pairs whose pattern has <= GL0 = 64 / (P + 1) words run P + 1 to a wave.
+    // Worth one classification launch when the list is long and enough pairs qualify (share of pairs with
+    // a short string on either side, from the length census of annchor_set_strings).
+    ar.perm = nullptr; ar.n0 = nullptr; ar.GL0 = 0; ar.P0 = 0;
+    static const int cls_min = getenv("ANNCHOR_LEV_CLASS_MIN") ? atoi(getenv("ANNCHOR_LEV_CLASS_MIN")) : 4096;
+    if (!src.anchor && c->lev_gl0 > 0 && npairs >= cls_min && npairs < (1ll << 31)) {
+        const double fp = 1.0 - (1.0 - c->lev_frac0) * (1.0 - c->lev_frac0);
+        const int P0 = 64 / c->lev_gl0;
+        const double cost = fp * (double)a.P / (double)P0 + (1.0 - fp);   // waves needed, relative to one class
+        if (cost < 0.93) {
+            ANN_TRY(ann_reserve(c, c->lev_perm, sizeof(int32_t) * ((size_t)npairs + 4)));
+            int32_t *perm = c->lev_perm.as<int32_t>();
+            int32_t *cursors = perm + npairs;
+            ANN_CHECK_HIP(c, hipMemsetAsync(cursors, 0, 2 * sizeof(int32_t), c->stream));
+            k_lev_classify<<<ann_blocks(npairs, 256), 256, 0, c->stream>>>(src.ij, src.idx, a.slen, npairs, c->lev_gl0, perm,
+                                                                           cursors);
+            ar.perm = perm; ar.n0 = cursors; ar.GL0 = c->lev_gl0; ar.P0 = P0;
+        }
+    }
+    a.wave_bytes = a.pm_bytes + (ar.perm ? ar.P0 : a.P) * a.text_stride + 256;
     ar.b = a;
     ar.pick_row = nullptr; ar.pick_runmin = nullptr; ar.pick_out = nullptr; ar.pick_reset = 0; ar.pick_nx = 0;
     if (src.anchor && src.pick_fused && c->nx <= 8192) {

@@ -81,6 +81,30 @@ def test_levenshtein_random_ragged():
     assert list(got) == want
 
 
+def test_levenshtein_slot_classes():
+    """k_lev_f's two slot classes (lists of >= 4096 pairs): longest string 594 symbols = 19 words -> 3 pairs
+    per wave, 4 for pairs whose shorter string has <= 16 words.  Lengths straddle the 512-symbol class
+    boundary; pairs of two long strings, two short ones, mixed, equal and empty strings."""
+    from annchor_amd import _native
+    from annchor_amd.distances import levenshtein
+
+    rng = np.random.default_rng(11)
+    lens = [0, 1, 31, 32, 33, 480, 509, 510, 511, 512, 513, 514, 543, 544, 545, 560, 593, 594]
+    X = ["".join(rng.choice(list("acgt"), n)) for n in lens for _ in range(6)]
+    eng = _native.Engine(0)
+    levenshtein.bind(eng, X)
+    for npairs in (4096, 9001):
+        IJ = rng.integers(0, len(X), (npairs, 2))
+        IJ[:100, 1] = IJ[:100, 0]
+        assert np.array_equal(eng.metric_pairs(IJ), om.PackedStrings(X).pairs(IJ))
+    # all pairs long (empty short class) and all pairs short (empty long class)
+    long_ids = np.array([i for i, x in enumerate(X) if len(x) > 512])
+    short_ids = np.array([i for i, x in enumerate(X) if len(x) <= 512])
+    for ids in (long_ids, short_ids):
+        IJ = ids[rng.integers(0, len(ids), (5000, 2))]
+        assert np.array_equal(eng.metric_pairs(IJ), om.PackedStrings(X).pairs(IJ))
+
+
 @pytest.mark.parametrize("variant", ["0", "1", "2", "4", "9"])
 def test_levenshtein_kernel_variants_ragged(variant, monkeypatch):
     """Every Levenshtein kernel variant (two-column systolic kernel = 0, R words per lane = 1/2/4;
