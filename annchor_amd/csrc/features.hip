@@ -121,9 +121,10 @@ template <int NA_MAX> __global__ __launch_bounds__(256) void k_features_tiled(
         }
         if (mine) {
             const int cai = cA[i];
-            lb[pos] = l;
-            ub[pos] = u;
-            dad[pos] = (Dt[(size_t)caj * nx + i] + Dt[(size_t)cai * nx + j]) / 2;
+            // streamed out: 24 B per pair that no later kernel finds in L2 anyway
+            __builtin_nontemporal_store(l, &lb[pos]);
+            __builtin_nontemporal_store(u, &ub[pos]);
+            __builtin_nontemporal_store((Dt[(size_t)caj * nx + i] + Dt[(size_t)cai * nx + j]) / 2, &dad[pos]);
             // (the two byte masks are preset by memset and patched for the few anchor rows / columns by
             // k_anchor_flags: 64-byte pieces of a byte array written from different CUs are partial lines)
         }
@@ -965,11 +966,11 @@ __global__ __launch_bounds__(256) void k_predict_merge(int64_t n, RegModel m, in
                                                       const double *__restrict__ lb, const double *__restrict__ ub,
                                                       const double *__restrict__ dad, const uint8_t *__restrict__ anc,
                                                       const uint8_t *__restrict__ ncm, double *__restrict__ RA,
-                                                      uint8_t *__restrict__ label)
+                                                      uint8_t *__restrict__ label, int stream)
 {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const double l = lb[p], u = ub[p], d = dad[p];
+    const double l = ann_load(lb + p, stream), u = ann_load(ub + p, stream), d = ann_load(dad + p, stream);
     double pr = reg_predict(m, l, u, d);
     pr = fmin(fmax(pr, l), u);  // np.clip(pred, lb, ub)
     if (!is_metric && anc[p]) {
@@ -979,9 +980,9 @@ __global__ __launch_bounds__(256) void k_predict_merge(int64_t n, RegModel m, in
         const int ri = anchorRank[q.x], rj = anchorRank[q.y];
         pr = (ri > rj) ? Dt[(size_t)ri * nx + q.y] : Dt[(size_t)rj * nx + q.x];
     }
-    if (first || ncm[p]) RA[p] = pr;
+    if (first || ncm[p]) ann_store(RA + p, pr, stream);
     const int lbl = err_label(m, d);
-    label[p] = (uint8_t)(lbl < 0 ? 255 : lbl);
+    ann_store(label + p, (uint8_t)(lbl < 0 ? 255 : lbl), stream);
 }
 
 __global__ void k_sample_predict_scatter(const int32_t *__restrict__ pos, const double *__restrict__ sy, int64_t ms,
@@ -1018,7 +1019,7 @@ extern "C" int annchor_predict_merge(annchor_ctx *c, const double *bins, int32_t
         k_predict_merge<<<ann_blocks(c->n, 256), 256, 0, c->stream>>>(
             c->n, m, first_iteration, is_metric, c->ij.as<int2>(), c->Dt.as<double>(), c->nx, c->anchorRank.as<int32_t>(),
             c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>(), c->anc.as<uint8_t>(), c->ncm.as<uint8_t>(),
-            c->RA.as<double>(), c->label.as<uint8_t>());
+            c->RA.as<double>(), c->label.as<uint8_t>(), c->n >= ANN_STREAM_MIN_PAIRS);
     }
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;

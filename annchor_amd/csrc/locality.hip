@@ -137,7 +137,8 @@ __device__ __forceinline__ uint32_t keep_rank(const uint64_t *K, const uint32_t 
 // word walking its bits wrote 64 scattered 8-byte pieces per store instruction)
 __global__ __launch_bounds__(256) void k_emit_pairs(const uint64_t *__restrict__ K, const uint32_t *__restrict__ pref, int64_t nx, int kw,
                                                    const int32_t *__restrict__ low, const int64_t *__restrict__ rowstart,
-                                                   const int64_t *__restrict__ Iptr, int2 *__restrict__ ij, int32_t *__restrict__ Iidx)
+                                                   const int64_t *__restrict__ Iptr, int2 *__restrict__ ij, int32_t *__restrict__ Iidx,
+                                                   int stream)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -155,11 +156,11 @@ __global__ __launch_bounds__(256) void k_emit_pairs(const uint64_t *__restrict__
         int64_t pos;
         if (j > i) {
             pos = rowstart[i] + ((int64_t)r - low[i]);
-            ij[pos] = make_int2((int)i, (int)j);
+            ann_store(reinterpret_cast<long long *>(ij) + pos, (long long)(((unsigned long long)(uint32_t)j << 32) | (uint32_t)i), stream);
         } else {
             pos = rowstart[j] + ((int64_t)keep_rank(K, pref, kw, j, i) - low[j]);
         }
-        Iidx[Iptr[i] + r] = (int32_t)pos;
+        ann_store(Iidx + Iptr[i] + r, (int32_t)pos, stream);
     }
 }
 
@@ -231,7 +232,7 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
         ProfScope ps(c, "locality_emit_pairs", (double)n * 16 + (double)nx * kw * 12.0);
         k_emit_pairs<<<(int)std::min<int64_t>(ann_blocks(nx * kw * 64, 256), (int64_t)c->prop.multiProcessorCount * 64), 256, 0, c->stream>>>(
             c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), nx, kw, c->low.as<int32_t>(), c->rowstart.as<int64_t>(),
-            c->Iptr.as<int64_t>(), c->ij.as<int2>(), c->Iidx.as<int32_t>());
+            c->Iptr.as<int64_t>(), c->ij.as<int2>(), c->Iidx.as<int32_t>(), c->n >= ANN_STREAM_MIN_PAIRS);
     }
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;

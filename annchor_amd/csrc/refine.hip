@@ -215,7 +215,7 @@ template <bool VALUES> __global__ __launch_bounds__(256) void k_transpose_cols(c
         double v[16];
         uint8_t m[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { v[q] = VALUES ? RA[pos[q]] : 0.0; m[q] = ncm[pos[q]]; }
+        for (int q = 0; q < 16; ++q) { v[q] = VALUES ? __builtin_nontemporal_load(&RA[pos[q]]) : 0.0; m[q] = __builtin_nontemporal_load(&ncm[pos[q]]); }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             if (VALUES) tv[wave * 16 + q][lane] = ok[q] ? v[q] : 0.0;
@@ -232,8 +232,9 @@ template <bool VALUES> __global__ __launch_bounds__(256) void k_transpose_cols(c
         const uint64_t bits = K[i * kw + jb];   // symmetric bitmap: bit j of row i <=> pair (j, i) kept
         if (j_w < i && ((bits >> lane) & 1ull)) {
             const int64_t dst = (Iptr[i] - rowstart[i]) + ((int64_t)pref[i * kw + jb] + __popcll(bits & ((1ull << lane) - 1ull)));
-            if (VALUES) T[dst] = tv[lane][il];
-            Tm[dst] = tm[lane][il];
+            // (this kernel only runs on lists beyond ANN_STREAM_MIN_PAIRS)
+            if (VALUES) __builtin_nontemporal_store(tv[lane][il], &T[dst]);
+            __builtin_nontemporal_store(tm[lane][il], &Tm[dst]);
         }
     }
 }
@@ -244,6 +245,8 @@ int ann_transpose_columns(annchor_ctx *c, RowSrc *src, bool with_values)
 {
     src->RA = c->RA.as<double>(); src->ncm = c->ncm.as<uint8_t>(); src->Iidx = c->Iidx.as<int32_t>();
     src->T = nullptr; src->Tm = nullptr; src->rowstart = c->rowstart.as<int64_t>(); src->low = c->low.as<int32_t>();
+    static const int shrink_min = getenv("ANNCHOR_ROWC_SHRINK_MIN") ? atoi(getenv("ANNCHOR_ROWC_SHRINK_MIN")) : ROWC_SHRINK_MIN;   // tests: small rows too
+    src->shrink_min = shrink_min;
     static const long long min_pairs = getenv("ANNCHOR_TRANSPOSE_MIN") ? atoll(getenv("ANNCHOR_TRANSPOSE_MIN")) : ANN_TRANSPOSE_MIN_PAIRS;
     if (!c->have_bitmap || c->n < min_pairs) return ANNCHOR_OK;
     ANN_TRY(ann_reserve(c, c->colT, sizeof(double) * (size_t)c->n));
@@ -316,11 +319,13 @@ __global__ __launch_bounds__(ROW_THREADS) void k_get_nn(const int64_t *__restric
     __syncthreads();
     mx = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
     if (want0 > 0 && fast0 >= want0 && (int)ncomp_s >= want0 && risky_s == 0) {
-        for (int e = threadIdx.x; e < fast0; e += ROW_THREADS) {
+        const int fast0s = row_cand_shrink(rc, fast0, want0, src.shrink_min);
+        if (fast0s >= want0) {
+        for (int e = threadIdx.x; e < fast0s; e += ROW_THREADS) {
             const uint64_t ke = rc.key[e];
             const int32_t se = rc.slot[e];
             int r = 0;
-            for (int o = 0; o < fast0; ++o) { const uint64_t ko = rc.key[o]; r += (ko < ke) || (ko == ke && rc.slot[o] < se); }
+            for (int o = 0; o < fast0s; ++o) { const uint64_t ko = rc.key[o]; r += (ko < ke) || (ko == ke && rc.slot[o] < se); }
             if (r < want0) {
                 const int32_t p = Iidx[b + se];
                 const int2 q = ij[p];
@@ -330,6 +335,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_get_nn(const int64_t *__restric
         }
         for (int e = want0 + threadIdx.x; e < L; e += ROW_THREADS) { ngi[i * nn + 1 + e] = 0; ngd[i * nn + 1 + e] = 0.0; }
         return;
+        }
     }
     __syncthreads();
     const bool in_lds = len <= cap;
@@ -343,12 +349,13 @@ __global__ __launch_bounds__(ROW_THREADS) void k_get_nn(const int64_t *__restric
         // fast path: the nn-1 smallest by (key, slot) are among the entries below a sampled threshold
         const int fast = want > 0 ? row_candidates(rc, len, want, key_of, [](int) { return true; },
                                                    [&](int s, uint64_t kk, bool) { if (in_lds) keys[s] = kk; }) : -1;
-        if (fast >= want && want > 0) {
-            for (int e = threadIdx.x; e < fast; e += ROW_THREADS) {
+        const int fasts = (fast >= want && want > 0) ? row_cand_shrink(rc, fast, want, src.shrink_min) : -1;
+        if (fasts >= want && want > 0) {
+            for (int e = threadIdx.x; e < fasts; e += ROW_THREADS) {
                 const uint64_t ke = rc.key[e];
                 const int32_t se = rc.slot[e];
                 int r = 0;
-                for (int o = 0; o < fast; ++o) { const uint64_t ko = rc.key[o]; r += (ko < ke) || (ko == ke && rc.slot[o] < se); }
+                for (int o = 0; o < fasts; ++o) { const uint64_t ko = rc.key[o]; r += (ko < ke) || (ko == ke && rc.slot[o] < se); }
                 if (r < want) {
                     const int32_t p = Iidx[b + se];
                     const int2 q = ij[p];

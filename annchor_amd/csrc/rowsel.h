@@ -125,6 +125,9 @@ template <typename KeyFn> __device__ uint64_t row_kth_key(RowSelShared &sh, int 
 // with key <= t0 (a few dozen), and finish exactly among those.  If fewer than `want` or more than
 // ROWC_CAP entries qualify (ties, adversarial order) the caller falls back to the radix descent.
 #define ROWC_CAP 1024
+#ifndef ROWC_U
+#define ROWC_U 8
+#endif
 struct RowCand {
     uint64_t key[ROWC_CAP];
     int32_t slot[ROWC_CAP];
@@ -159,18 +162,19 @@ __device__ int row_candidates(RowCand &rc, int len, int want, KeyFn key, EligFn 
         __syncthreads();
     }
     const uint64_t t0 = rc.t0;
-    // four entries per thread per trip, their loads issued together (clamped index: no branch around a load)
-    for (int s0 = threadIdx.x; s0 < len; s0 += 4 * ROW_THREADS) {
-        uint64_t kk[4];
-        bool el[4];
+    // ROWC_U entries per thread per trip, their loads issued together (clamped index: no branch around a
+    // load): a workgroup keeps ROWC_U x 2 KB of the row in flight
+    for (int s0 = threadIdx.x; s0 < len; s0 += ROWC_U * ROW_THREADS) {
+        uint64_t kk[ROWC_U];
+        bool el[ROWC_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < ROWC_U; ++u) {
             const int s = min(s0 + u * ROW_THREADS, len - 1);
             kk[u] = key(s);
             el[u] = elig(s);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < ROWC_U; ++u) {
             const int s = s0 + u * ROW_THREADS;
             if (s < len) {
                 visit(s, kk[u], el[u]);
@@ -184,6 +188,54 @@ __device__ int row_candidates(RowCand &rc, int len, int want, KeyFn key, EligFn 
     __syncthreads();
     const uint32_t c = rc.count;
     return c > ROWC_CAP ? -1 : (int)c;
+}
+
+// Second cut, inside LDS: the callers rank their candidates against each other (c^2 / 256 LDS reads per
+// thread), and a 16 000-entry row leaves ~400 of them for the 15-40 that are wanted.  The same sampling
+// idea once more: 64 evenly spaced candidates, t1 = their r2-th smallest key with r2 three times the wanted
+// share, keep the candidates with key <= t1 (all ties included).  Every candidate outside the kept set has
+// a larger key than each kept one, so if at least `want` are kept the `want` smallest by (key, slot) are
+// among them.  Returns the new count (uniform); < want means the cut was too tight (caller falls back).
+__device__ __forceinline__ int row_cand_shrink(RowCand &rc, int c, int want, int min_c)
+{
+    if (c <= min_c || c > ROWC_CAP) return c;
+    __syncthreads();
+    if (threadIdx.x < 64) rc.samp[threadIdx.x] = rc.key[(int)(((int64_t)threadIdx.x * c) >> 6)];
+    if (threadIdx.x == 0) rc.t0 = ~0ull;
+    __syncthreads();
+    int r2 = (int)((3ll * want * 64 + c - 1) / c) + 2;
+    if (threadIdx.x < 64 && r2 < 64) {
+        const uint64_t mine = rc.samp[threadIdx.x];
+        int less = 0;
+        for (int o = 0; o < 64; ++o) {
+            const uint64_t ko = rc.samp[o];
+            less += (ko < mine) || (ko == mine && o < (int)threadIdx.x);
+        }
+        if (less == r2) rc.t0 = mine;
+    }
+    __syncthreads();
+    const uint64_t t1 = rc.t0;
+    uint64_t kk[ROWC_CAP / ROW_THREADS];
+    int32_t ss[ROWC_CAP / ROW_THREADS];
+#pragma unroll
+    for (int u = 0; u < ROWC_CAP / ROW_THREADS; ++u) {
+        const int e = threadIdx.x + u * ROW_THREADS;
+        kk[u] = e < c ? rc.key[e] : ~0ull;
+        ss[u] = e < c ? rc.slot[e] : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) rc.count = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < ROWC_CAP / ROW_THREADS; ++u) {
+        const int e = threadIdx.x + u * ROW_THREADS;
+        if (e < c && kk[u] <= t1) {
+            const uint32_t o = atomicAdd(&rc.count, 1u);
+            rc.key[o] = kk[u]; rc.slot[o] = ss[u];
+        }
+    }
+    __syncthreads();
+    return (int)rc.count;
 }
 
 // Where a row kernel takes the values of row i from.  Row i of the CSR index lists first its
@@ -200,7 +252,9 @@ struct RowSrc {
     const uint8_t *Tm;
     const int64_t *rowstart;
     const int32_t *low;
+    int shrink_min;         // candidate sets larger than this get the second cut (row_cand_shrink)
 };
+#define ROWC_SHRINK_MIN 128
 
 struct RowView {
     const double *RA, *Tv;
@@ -216,6 +270,9 @@ struct RowView {
     }
     __device__ __forceinline__ bool unc(int s) const
     {
+#ifdef ROW_NO_MASK   // timing experiment only: what the byte-mask loads cost
+        return (s & 15) != 0;
+#endif
         if (!direct) return ncm[idx[s]] != 0;
         const uint8_t *p = s < low ? Tm + s : ncm + (s - low);
         return *p != 0;

@@ -37,11 +37,12 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row_thresh(const int64_t *__res
         // fast path: the k+1 smallest are among the entries below a sampled threshold
         const int cnt = row_candidates(rc, len, (int)kk + 1, [&](int s) { return ann_key_asc(rv.val(s)); }, [](int) { return true; },
                                        [](int, uint64_t, bool) {});
-        if (cnt > (int)kk) {
-            for (int e = threadIdx.x; e < cnt; e += ROW_THREADS) {
+        const int cnts = cnt > (int)kk ? row_cand_shrink(rc, cnt, (int)kk + 1, src.shrink_min) : -1;
+        if (cnts > (int)kk) {
+            for (int e = threadIdx.x; e < cnts; e += ROW_THREADS) {
                 const uint64_t ke = rc.key[e];
                 uint32_t less = 0, leq = 0;
-                for (int o = 0; o < cnt; ++o) { const uint64_t ko = rc.key[o]; less += ko < ke; leq += ko <= ke; }
+                for (int o = 0; o < cnts; ++o) { const uint64_t ko = rc.key[o]; less += ko < ke; leq += ko <= ke; }
                 if (less <= kk && kk < leq) thresh[i] = ann_key_asc_inv(ke);   // every writer holds the same value
             }
             return;
@@ -100,13 +101,14 @@ __global__ __launch_bounds__(ROW_THREADS) void k_gn_lists(const int64_t *__restr
     const int want = min(L, n_unc);
     if (threadIdx.x == 0) { gl_cnt[i] = want; gl_ncomp[i] = len - n_unc; }
     if (want == 0) return;
-    if (fast >= want) {
+    const int fasts = fast >= want ? row_cand_shrink(rc, fast, want, src.shrink_min) : -1;
+    if (fasts >= want) {
         // the `want` smallest by (key, slot) are the candidates of rank < want
-        for (int e = threadIdx.x; e < fast; e += ROW_THREADS) {
+        for (int e = threadIdx.x; e < fasts; e += ROW_THREADS) {
             const uint64_t ke = rc.key[e];
             const int32_t se = rc.slot[e];
             int r = 0;
-            for (int o = 0; o < fast; ++o) { const uint64_t ko = rc.key[o]; r += (ko < ke) || (ko == ke && rc.slot[o] < se); }
+            for (int o = 0; o < fasts; ++o) { const uint64_t ko = rc.key[o]; r += (ko < ke) || (ko == ke && rc.slot[o] < se); }
             if (r < want) {
                 const int32_t p = Iidx[b + se];
                 const int2 q = ij[p];
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict_
                                              const double *__restrict__ RA, const uint8_t *__restrict__ ncm,
                                              const uint8_t *__restrict__ label, const double *__restrict__ errs,
                                              const int64_t *__restrict__ errptr, int nlabels, int errs_in_lds,
-                                             double *__restrict__ prob)
+                                             double *__restrict__ prob, int stream)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     double *le = reinterpret_cast<double *>(dyn);
@@ -476,10 +478,13 @@ __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict_
         for (int e = 0; e < PI; ++e) {
             const int64_t p = p0 + (int64_t)e * blockDim.x;
             const bool in = p < n;
-            m[e] = in ? ncm[p] : (uint8_t)0;
-            q[e] = in ? ij[p] : make_int2(0, 0);
-            ra[e] = in ? RA[p] : 0.0;
-            lbv[e] = in ? label[p] : (uint8_t)0;
+            const int64_t pc = in ? p : 0;
+            m[e] = ann_load(ncm + pc, stream);
+            const long long qq = ann_load(reinterpret_cast<const long long *>(ij) + pc, stream);
+            q[e] = make_int2((int)(qq & 0xffffffffll), (int)(qq >> 32));
+            ra[e] = ann_load(RA + pc, stream);
+            lbv[e] = ann_load(label + pc, stream);
+            if (!in) { m[e] = 0; q[e] = make_int2(0, 0); lbv[e] = 0; }
         }
         double pv[PI];
 #pragma unroll
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict_
                     pr = 0.0;
                 }
             }
-            prob[p] = pr;
+            ann_store(prob + p, pr, stream);
         }
     }
 }
@@ -1043,7 +1048,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         ProfScope ps(c, "ecdf_probability", (double)n * 26.0);
         k_prob<<<blocks, 256, dyn, c->stream>>>(n, c->ij.as<int2>(), c->thresh.as<double>(), c->RA.as<double>(),
                                                c->ncm.as<uint8_t>(), c->label.as<uint8_t>(), c->errs.as<double>(),
-                                               c->errptr.as<int64_t>(), nlabels, in_lds, c->prob.as<double>());
+                                               c->errptr.as<int64_t>(), nlabels, in_lds, c->prob.as<double>(), n >= ANN_STREAM_MIN_PAIRS);
     }
     ANN_CHECK_HIP(c, hipGetLastError());
     // (the sweep's error flag is read with the final state below: one host wait less)
