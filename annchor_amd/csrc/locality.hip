@@ -64,27 +64,34 @@ __global__ __launch_bounds__(LOC_THREADS) void k_loc_thresh(const uint64_t *__re
     }
 }
 
-// thread per (row, 64-column word): keep bits
-__global__ void k_keep_bits(const uint64_t *__restrict__ sid, const int32_t *__restrict__ thr, int64_t nx, int kw,
-                            uint64_t *__restrict__ K)
+// keep bits: wave per (row, 64-column word) item, lane = column -- the 64 sid / thr reads of a word are one
+// line each and the word is the wave's ballot (a thread per word walking its 64 columns read 64 scattered
+// 8-byte pieces per load instruction)
+__global__ __launch_bounds__(256) void k_keep_bits(const uint64_t *__restrict__ sid, const int32_t *__restrict__ thr, int64_t nx, int kw,
+                                                  uint64_t *__restrict__ K)
 {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nx * kw) return;
-    int64_t i = t / kw;
-    int w = (int)(t - i * kw);
-    const uint64_t mi = sid[i];
-    const int ti = thr[i];
-    uint64_t bits = 0;
-    int64_t j0 = (int64_t)w * 64;
-    for (int b = 0; b < 64; ++b) {
-        int64_t j = j0 + b;
-        if (j >= nx) break;
-        if (j == i) continue;
-        int cc = __popcll(mi & sid[j]);
-        int tj = thr[j];
-        if (cc >= (ti < tj ? ti : tj)) bits |= 1ull << b;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t wave_count = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t items = nx * kw;
+    // a wave takes a run of consecutive words of (mostly) one row: the row's sid / thr stay in scalar registers
+    const int64_t per = (items + wave_count - 1) / wave_count;
+    const int64_t t0 = wave_global * per, t1 = min(t0 + per, items);
+    for (int64_t t = t0; t < t1; ++t) {
+        const int64_t i = t / kw;
+        const int w = (int)(t - i * kw);
+        const uint64_t mi = sid[i];
+        const int ti = thr[i];
+        const int64_t j = (int64_t)w * 64 + lane;
+        bool keep = false;
+        if (j < nx && j != i) {
+            const int cc = __popcll(mi & sid[j]);
+            const int tj = thr[j];
+            keep = cc >= (ti < tj ? ti : tj);
+        }
+        const unsigned long long bits = __ballot(keep);
+        if (lane == 0) K[t] = bits;
     }
-    K[t] = bits;
 }
 
 // one block per row: exclusive prefix of popcounts over the row's words
@@ -138,7 +145,7 @@ __device__ __forceinline__ uint32_t keep_rank(const uint64_t *K, const uint32_t 
 __global__ __launch_bounds__(256) void k_emit_pairs(const uint64_t *__restrict__ K, const uint32_t *__restrict__ pref, int64_t nx, int kw,
                                                    const int32_t *__restrict__ low, const int64_t *__restrict__ rowstart,
                                                    const int64_t *__restrict__ Iptr, int2 *__restrict__ ij, int32_t *__restrict__ Iidx,
-                                                   int stream)
+                                                   int stream, int rows_only)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -158,9 +165,56 @@ __global__ __launch_bounds__(256) void k_emit_pairs(const uint64_t *__restrict__
             pos = rowstart[i] + ((int64_t)r - low[i]);
             ann_store(reinterpret_cast<long long *>(ij) + pos, (long long)(((unsigned long long)(uint32_t)j << 32) | (uint32_t)i), stream);
         } else {
+            if (rows_only) continue;   // column-like entries come from k_emit_cols
             pos = rowstart[j] + ((int64_t)keep_rank(K, pref, kw, j, i) - low[j]);
         }
         ann_store(Iidx + Iptr[i] + r, (int32_t)pos, stream);
+    }
+}
+
+// The column-like half of the CSR index: entry (j, i), j < i, of row i is the position of pair (j, i) in
+// row j's run of the pair list.  Computed where it is cheap -- in row j, from row j's bitmap words -- and
+// handed to row i through a 64 x 64 LDS tile, so that both the bitmap reads and the index writes are whole
+// lines (looked up from row i's side it is two scattered table reads per entry: 4.1 ms at 127 M pairs).
+#define EC_T 64
+__global__ __launch_bounds__(256) void k_emit_cols(const uint64_t *__restrict__ K, const uint32_t *__restrict__ pref, int kw,
+                                                  const int32_t *__restrict__ low, const int64_t *__restrict__ rowstart,
+                                                  const int64_t *__restrict__ Iptr, int64_t nx, int32_t *__restrict__ Iidx, int stream)
+{
+    __shared__ int32_t tp[EC_T][EC_T + 1];
+    // tile (jb, ib), jb <= ib, from the linear block index (row-major over the upper triangle of tiles)
+    const int nb = kw;
+    int64_t t = blockIdx.x;
+    int jb = (int)((2.0 * nb + 1.0 - sqrt((2.0 * nb + 1.0) * (2.0 * nb + 1.0) - 8.0 * (double)t)) * 0.5);
+    while ((int64_t)jb * nb - (int64_t)jb * (jb - 1) / 2 > t) --jb;
+    while ((int64_t)(jb + 1) * nb - (int64_t)(jb + 1) * jb / 2 <= t) ++jb;
+    const int ib = jb + (int)(t - ((int64_t)jb * nb - (int64_t)jb * (jb - 1) / 2));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- row side: wave handles 16 rows j, lane = column i
+    const int64_t i_r = (int64_t)ib * 64 + lane;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const int64_t j = (int64_t)jb * 64 + wave * 16 + q;
+        int32_t pos = 0;
+        if (j < nx) {
+            const uint64_t bits = K[j * kw + ib];
+            if (i_r > j && ((bits >> lane) & 1ull))
+                pos = (int32_t)(rowstart[j] + ((int64_t)pref[j * kw + ib] + __popcll(bits & ((1ull << lane) - 1ull)) - low[j]));
+        }
+        tp[wave * 16 + q][lane] = pos;
+    }
+    __syncthreads();
+    // ---- column side: wave handles 16 columns i, lane = row j
+    const int64_t j_w = (int64_t)jb * 64 + lane;
+    for (int q = 0; q < 16; ++q) {
+        const int il = wave * 16 + q;
+        const int64_t i = (int64_t)ib * 64 + il;
+        if (i >= nx) continue;
+        const uint64_t bits = K[i * kw + jb];   // symmetric bitmap: bit j of row i <=> pair (j, i) kept
+        if (j_w < i && ((bits >> lane) & 1ull)) {
+            const uint32_t r = pref[i * kw + jb] + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));
+            ann_store(Iidx + Iptr[i] + r, tp[lane][il], stream);
+        }
     }
 }
 
@@ -213,7 +267,7 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
         ProfScope ps(c, "locality_keep_bitmap", (double)nx * kw * 12.0);
         k_loc_thresh<<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx, loc_thresh, loc_min,
                                                             c->thr.as<int32_t>());
-        k_keep_bits<<<ann_blocks(nx * kw, 256), 256, 0, c->stream>>>(c->sid.as<uint64_t>(), c->thr.as<int32_t>(), nx, kw,
+        k_keep_bits<<<(int)std::min<int64_t>(ann_blocks(nx * kw * 64, 256), (int64_t)c->prop.multiProcessorCount * 32), 256, 0, c->stream>>>(c->sid.as<uint64_t>(), c->thr.as<int32_t>(), nx, kw,
                                                                     c->Kbits.as<uint64_t>());
         k_row_prefix<<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->Kbits.as<uint64_t>(), nx, kw, c->Kpref.as<uint32_t>(),
                                                             c->deg.as<int32_t>(), c->low.as<int32_t>(),
@@ -230,9 +284,15 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
     ANN_TRY(ann_reserve(c, c->Iidx, sizeof(int32_t) * 2 * (size_t)n));
     {
         ProfScope ps(c, "locality_emit_pairs", (double)n * 16 + (double)nx * kw * 12.0);
+        static const long long tiled_min = getenv("ANNCHOR_EMIT_TILED_MIN") ? atoll(getenv("ANNCHOR_EMIT_TILED_MIN")) : 0;
+        const int stream_hint = n >= ANN_STREAM_MIN_PAIRS, tiled = n >= tiled_min;
         k_emit_pairs<<<(int)std::min<int64_t>(ann_blocks(nx * kw * 64, 256), (int64_t)c->prop.multiProcessorCount * 64), 256, 0, c->stream>>>(
             c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), nx, kw, c->low.as<int32_t>(), c->rowstart.as<int64_t>(),
-            c->Iptr.as<int64_t>(), c->ij.as<int2>(), c->Iidx.as<int32_t>(), c->n >= ANN_STREAM_MIN_PAIRS);
+            c->Iptr.as<int64_t>(), c->ij.as<int2>(), c->Iidx.as<int32_t>(), stream_hint, tiled);
+        if (tiled)
+            k_emit_cols<<<(unsigned)((int64_t)kw * (kw + 1) / 2), 256, 0, c->stream>>>(
+                c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), kw, c->low.as<int32_t>(), c->rowstart.as<int64_t>(),
+                c->Iptr.as<int64_t>(), nx, c->Iidx.as<int32_t>(), stream_hint);
     }
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;
