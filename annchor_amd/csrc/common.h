@@ -96,6 +96,7 @@ struct annchor_ctx {
     int64_t ncand = 0, nnext = 0;
     bool cand_marked = false;      // not_computed_mask already cleared for the current candidates
     DevBuf gl_val, gl_pos, gl_cnt, gl_ncomp, marked, markcount;  // guarantee_nmin scratch
+    DevBuf gn_state;             // guarantee_nmin rounds: mark masks (2), out-of-list mark counts (3), change flags
     DevBuf sel_hist, sel_state, blk_cnt, blk_off;                // radix select / compaction scratch
     DevBuf tie_lists, tie_hist;                                  // scrambled positions of the pairs on the two probability cuts; their histogram
     const void *tie_hist_clean = nullptr;                        // tie_hist known to be zero at this address

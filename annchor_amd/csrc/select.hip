@@ -175,6 +175,105 @@ __global__ void k_gn_twin(int64_t nx, int L, const int32_t *__restrict__ gl_pos,
     gl_twin[t] = tw;
 }
 
+// The sweep as a fixed-point iteration.  utils.py:611-619 walks the rows in order; what row i does depends
+// only on the marks EARLIER rows put on its pairs: m of them, then i marks its unmarked not-computed
+// entries below the (n_todo - m)-th unmarked value.  That is a triangular system -- marks(i) =
+// F_i(marks(0..i-1)) -- whose unique solution is reached by iterating all rows at once from "no marks":
+// after round r every row whose chain of deciding earlier rows is <= r long is final, and a round that
+// changes nothing proves the fixed point.  The chains are short (strings fixture, 1600 rows: 6 rounds
+// + 1), so a handful of fully parallel rounds replace one wave's walk over all rows (0.6 ms of the 5.8 ms
+// fit there, 4.8 ms at 16 000 rows).
+// One wave per row, lane = list entry.  masks: bit e of row i = "row i marks its entry e" (uint32
+// [nx][Lw], two buffers); mout[b][i] = marks of earlier rows on pairs of row i that are outside i's list
+// (three rotating buffers: read, accumulate for the next round, clear for the one after).
+__global__ __launch_bounds__(256) void k_gn_round(int64_t nx, int nmin, int L, int Lw, const double *__restrict__ gl_val,
+                                                 const int32_t *__restrict__ gl_oth, const int32_t *__restrict__ gl_twin,
+                                                 const int32_t *__restrict__ gl_cnt, const int32_t *__restrict__ gl_ncomp,
+                                                 const uint32_t *__restrict__ cur, uint32_t *__restrict__ nxt,
+                                                 const int32_t *__restrict__ mout_cur, int32_t *__restrict__ mout_nxt,
+                                                 int32_t *__restrict__ mout_clr, int32_t *__restrict__ changed, int32_t *__restrict__ err)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= nx) return;
+    if (lane == 0) mout_clr[i] = 0;
+    const int cnt = gl_cnt[i], ncomp = gl_ncomp[i];
+    const int ntodo = nmin - ncomp;
+    const int chunks = (L + 63) / 64;
+    bool active = !(ntodo <= 0 || (cnt == 0 && ncomp == 0));
+    if (active && cnt <= ntodo && cnt < L) { if (lane == 0) *err = 1; active = false; }
+    // marks of earlier rows on this row's entries
+    int m = active ? mout_cur[i] : 0;
+    if (active)
+        for (int ch = 0; ch < chunks; ++ch) {
+            const int e = ch * 64 + lane;
+            bool earlier = false;
+            if (e < cnt) {
+                const int32_t o = gl_oth[i * L + e], tw = gl_twin[i * L + e];
+                earlier = o < i && tw >= 0 && ((cur[(int64_t)o * Lw + (tw >> 5)] >> (tw & 31)) & 1u);
+            }
+            m += __popcll(__ballot(earlier));
+        }
+    const int need = ntodo + 1 - m;
+    double t = 0;
+    bool found = false;
+    if (active && need > 0) {
+        int cum = 0;
+        for (int ch = 0; ch < chunks && !found; ++ch) {
+            const int e = ch * 64 + lane;
+            bool um = false;
+            double v = 0.0;
+            if (e < cnt) {
+                const int32_t o = gl_oth[i * L + e], tw = gl_twin[i * L + e];
+                v = gl_val[i * L + e];
+                um = !(o < i && tw >= 0 && ((cur[(int64_t)o * Lw + (tw >> 5)] >> (tw & 31)) & 1u));
+            }
+            const unsigned long long mb = __ballot(um);
+            const int cm = __popcll(mb);
+            if (cum + cm >= need) {
+                const int want = need - cum - 1;
+                const int myrank = __popcll(mb & ((1ull << lane) - 1ull));
+                const unsigned long long hit = __ballot(um && myrank == want);
+                t = __shfl(v, __ffsll((unsigned long long)hit) - 1);
+                found = true;
+            }
+            cum += cm;
+        }
+        if (!found && lane == 0) *err = 2;
+    }
+    bool diff = false;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const int e = ch * 64 + lane;
+        bool mark = false;
+        int32_t o = 0, tw = -1;
+        if (found && e < cnt) {
+            o = gl_oth[i * L + e]; tw = gl_twin[i * L + e];
+            const bool earlier = o < i && tw >= 0 && ((cur[(int64_t)o * Lw + (tw >> 5)] >> (tw & 31)) & 1u);
+            mark = !earlier && gl_val[i * L + e] < t;
+        }
+        const unsigned long long mb = __ballot(mark);
+        const int w0 = 2 * ch, w1 = 2 * ch + 1;
+        if (lane == 0) {
+            if (w0 < Lw) { const uint32_t v0 = (uint32_t)mb; diff |= cur[i * Lw + w0] != v0; nxt[i * Lw + w0] = v0; }
+            if (w1 < Lw) { const uint32_t v1 = (uint32_t)(mb >> 32); diff |= cur[i * Lw + w1] != v1; nxt[i * Lw + w1] = v1; }
+        }
+        // a mark on a pair that the later row o does not list still counts among o's marked entries
+        if (mark && tw < 0 && o > i) atomicAdd(&mout_nxt[o], 1);
+    }
+    if (lane == 0 && diff) atomicOr(changed, 1);
+}
+
+// the marks of the fixed point go into the pair list (RA = -1)
+__global__ void k_gn_apply(int64_t nx, int L, int Lw, const int32_t *__restrict__ gl_pos, const int32_t *__restrict__ gl_cnt,
+                           const uint32_t *__restrict__ masks, double *__restrict__ RA)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nx * L) return;
+    const int64_t i = t / L;
+    const int e = (int)(t - i * L);
+    if (e < gl_cnt[i] && ((masks[i * Lw + (e >> 5)] >> (e & 31)) & 1u)) RA[gl_pos[t]] = -1.0;
+}
+
 // LDS form of the sequential sweep (utils.py:611-619): all state that one row hands to
 // the next -- "this entry of your list is already -1" flags and the per-row count of -1
 // entries -- lives in LDS; the per-row lists are read-only and prefetched one row ahead.
@@ -1005,7 +1104,40 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         }
         const size_t sweep_lds = (size_t)nx * (((size_t)L + 31) / 32 * 4 + 4);
         const size_t ring_lds = sweep_lds + 2 * (size_t)GN_B * L * 20 + 64 * 20 + 4 * GN_B * 4 + 64 + 16;
-        if (L <= GN_LMAX && ring_lds <= 156 * 1024) {
+        // ANNCHOR_GN_SWEEP = rounds (default) | sequential: the one-wave walks below (tests compare the two)
+        const char *gn_env = getenv("ANNCHOR_GN_SWEEP");
+        if (!gn_env || strcmp(gn_env, "sequential") != 0) {
+            ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 21.0);
+            int32_t *oth = c->gl_pos.as<int32_t>() + (size_t)nx * L, *twin = oth + (size_t)nx * L;
+            k_gn_twin<<<ann_blocks(nx * L, 256), 256, 0, c->stream>>>(nx, L, c->gl_pos.as<int32_t>(), oth,
+                                                                     c->gl_cnt.as<int32_t>(), twin);
+            const int Lw = (L + 31) / 32;
+            const size_t mask_bytes = sizeof(uint32_t) * (size_t)nx * Lw, mout_bytes = sizeof(int32_t) * (size_t)nx;
+            constexpr int GN_BATCH = 10;   // rounds between two looks at the "changed" flags
+            ANN_TRY(ann_reserve(c, c->gn_state, 2 * mask_bytes + 3 * mout_bytes + sizeof(int32_t) * GN_BATCH));
+            uint32_t *masks[2] = {c->gn_state.as<uint32_t>(), c->gn_state.as<uint32_t>() + (size_t)nx * Lw};
+            int32_t *mout[3];
+            for (int q = 0; q < 3; ++q) mout[q] = reinterpret_cast<int32_t *>(c->gn_state.as<char>() + 2 * mask_bytes + q * mout_bytes);
+            int32_t *changed = reinterpret_cast<int32_t *>(c->gn_state.as<char>() + 2 * mask_bytes + 3 * mout_bytes);
+            ANN_CHECK_HIP(c, hipMemsetAsync(c->gn_state.p, 0, 2 * mask_bytes + 3 * mout_bytes, c->stream));
+            int round = 0;
+            bool done = false;
+            while (!done) {
+                ANN_CHECK_HIP(c, hipMemsetAsync(changed, 0, sizeof(int32_t) * GN_BATCH, c->stream));
+                for (int q = 0; q < GN_BATCH; ++q, ++round)
+                    k_gn_round<<<ann_blocks(nx * 64, 256), 256, 0, c->stream>>>(
+                        nx, nmin, L, Lw, c->gl_val.as<double>(), oth, twin, c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
+                        masks[round & 1], masks[(round + 1) & 1], mout[round % 3], mout[(round + 1) % 3], mout[(round + 2) % 3],
+                        changed + q, c->tmp2.as<int32_t>() + 8);
+                int32_t h_changed[GN_BATCH];
+                ANN_TRY(ann_d2h(c, h_changed, changed, sizeof h_changed));
+                // a round without a change: its input (and output) is the fixed point, and so is everything after it
+                done = h_changed[GN_BATCH - 1] == 0;
+                ANN_REQUIRE(c, round <= (int)nx + GN_BATCH, ANNCHOR_EHIP, "guarantee_nmin rounds did not settle");
+            }
+            k_gn_apply<<<ann_blocks(nx * L, 256), 256, 0, c->stream>>>(nx, L, Lw, c->gl_pos.as<int32_t>(), c->gl_cnt.as<int32_t>(),
+                                                                      masks[round & 1], c->RA.as<double>());
+        } else if (L <= GN_LMAX && ring_lds <= 156 * 1024) {
             ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 21.0);
             int32_t *oth = c->gl_pos.as<int32_t>() + (size_t)nx * L, *twin = oth + (size_t)nx * L;
             k_gn_twin<<<ann_blocks(nx * L, 256), 256, 0, c->stream>>>(nx, L, c->gl_pos.as<int32_t>(), oth,

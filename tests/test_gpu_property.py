@@ -88,3 +88,25 @@ def test_wasserstein_kernel_equals_exact_ot(seed, n, bins, integral):
     got = eng.metric_pairs(IJ)
     want = om.Histograms(H, M).pairs(IJ)
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+
+
+def test_guarantee_nmin_rounds_equal_the_sequential_sweep(monkeypatch):
+    """guarantee_nmin (utils.py:600-621) as parallel fixed-point rounds == the row-by-row walk: same graph,
+    same evaluation count, same refined state, on inputs with many ties (integer distances) and without."""
+    from annchor_amd import Annchor
+
+    rng = np.random.default_rng(23)
+    cases = []
+    Z = rng.standard_normal((1800, 4))
+    cases.append((np.round(Z @ rng.standard_normal((4, 12)), 1).astype(np.float64), "euclidean", dict(n_anchors=12, n_neighbors=20, p_work=0.12)))
+    X = ["".join(rng.choice(list("ab"), rng.integers(20, 60))) for _ in range(900)]
+    cases.append((X, "levenshtein", dict(n_anchors=10, n_neighbors=30, p_work=0.2, n_samples=1500)))
+    for data, metric, kw in cases:
+        out = {}
+        for mode in ("rounds", "sequential"):
+            monkeypatch.setenv("ANNCHOR_GN_SWEEP", mode)
+            ann = Annchor(data, metric, random_seed=3, **kw).fit()
+            out[mode] = (ann.neighbor_graph[0].copy(), ann.neighbor_graph[1].copy(), ann.evals, ann.RefineApprox.copy(),
+                         ann.not_computed_mask.copy())
+        for a, b in zip(out["rounds"], out["sequential"]):
+            assert np.array_equal(a, b)
