@@ -1113,7 +1113,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
                                                                      c->gl_cnt.as<int32_t>(), twin);
             const int Lw = (L + 31) / 32;
             const size_t mask_bytes = sizeof(uint32_t) * (size_t)nx * Lw, mout_bytes = sizeof(int32_t) * (size_t)nx;
-            constexpr int GN_BATCH = 10;   // rounds between two looks at the "changed" flags
+            constexpr int GN_BATCH = 8;    // rounds between two looks at the "changed" flags
             ANN_TRY(ann_reserve(c, c->gn_state, 2 * mask_bytes + 3 * mout_bytes + sizeof(int32_t) * GN_BATCH));
             uint32_t *masks[2] = {c->gn_state.as<uint32_t>(), c->gn_state.as<uint32_t>() + (size_t)nx * Lw};
             int32_t *mout[3];
