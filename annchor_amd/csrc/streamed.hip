@@ -281,7 +281,9 @@ __global__ void k_st_transpose_D(const float *__restrict__ D, int64_t n, int na,
 // choice -- and with it the tiling -- is the same on every run): thread = (sample lane, anchor), a
 // point's anchor vector is one coalesced 128 / 256-byte read of the point-major copy; segments longer
 // than ST_SPLIT_SAMPLE points are judged on that many evenly spaced members.
+#ifndef ST_SPLIT_SAMPLE
 #define ST_SPLIT_SAMPLE 2048
+#endif
 __global__ __launch_bounds__(256) void k_st_split_coord(const float *__restrict__ Dt, int nap, const uint32_t *__restrict__ order,
                                                        int64_t n, int na, int level, int32_t *__restrict__ coord)
 {
