@@ -203,7 +203,8 @@ def _latest_profile(suffix):
     """Newest committed profiles/rNN*_<suffix> (rounds sort lexicographically)."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_" + suffix)))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_" + suffix))
+                   if "_scale_" not in os.path.basename(f))   # (the *_scale_* files belong to tools/pairlist_scale.py)
     return files[-1] if files else None
 
 
@@ -230,7 +231,7 @@ def pmc_valu_busy():
     try:
         T = json.load(open(_latest_profile("pmc_lev.json")))
         return {k: round(v["SQ_ACTIVE_INST_VALU"] * 4 / (v["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
-                for k, v in T.items() if "k_lev" in k and "SQ_ACTIVE_INST_VALU" in v and v.get("GRBM_GUI_ACTIVE")}
+                for k, v in T.items() if "k_lev" in k and "classify" not in k and "SQ_ACTIVE_INST_VALU" in v and v.get("GRBM_GUI_ACTIVE")}
     except Exception:
         return None
 
@@ -385,7 +386,7 @@ def strings_run(args, steps, warmup, world, rank, local, dist, torch, all_cpus, 
                     "note": "integer-ALU bound (string pool is 1 MB, cache resident): HBM fraction is not meaningful "
                             "for this kernel; the HBM-bound pair-list kernels are listed under `kernels`.  `peak` is the "
                             "nominal 2-cycle SIMD-32 rate; these integer ops issue at ~4 cycles per wave instruction "
-                            "(tools/microbench/valu_peak.hip); `valu_busy_pmc` = the committed PMC pass over isolated launches (pair lists 84 % busy after the round-2 instruction cuts, the one-wave-deep anchor rounds ~25 %)",
+                            "(tools/microbench/valu_peak.hip); `valu_busy_pmc` = the committed PMC pass over isolated launches (pair lists at the issue ceiling, the one-wave-deep anchor rounds ~20 %)",
                 }
             else:
                 g = kernels[dom]
