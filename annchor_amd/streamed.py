@@ -10,16 +10,18 @@ One process per GPU, rows sharded contiguously: rank r owns rows
                 of (value, index, that row's coordinates) -- (2 + dim) doubles per rank: the
                 arg-max with the first-index tie rule is taken locally and the next anchor's
                 vector is already there (no broadcast from its owner).
-  locality      each rank orders its rows by (nearest anchor, distance to it) into 128-row
-                tiles with per-anchor distance intervals.
-  exchange      all-gather of the ordered shards (rows, norms, ids) and of the interval
-                tables: the one real data exchange of the path (RCCL over xGMI when the
-                process group is `nccl`; staged through host memory otherwise).
-  refine+top-k  each rank evaluates its own row tiles against every column tile that its
+  exchange      ONE all-gather of the raw rows: every rank needs every row as a column anyway.
+                (RCCL over xGMI when the process group is `nccl`; staged through host memory otherwise.)
+  locality      every rank recomputes the anchor distances of all rows (it knows the anchors: no
+                collective) and orders ALL rows into 128-row tiles of a k-d order in anchor space with
+                per-anchor distance intervals -- the same tile structure whatever the number of ranks;
+                rank r owns a contiguous range of the global tile order.
+  refine+top-k  each rank evaluates its own row tiles against the column tiles that its
                 triangle bound cannot exclude (MFMA tile GEMM + in-LDS top-k), within the
-                p_work tile budget.
-  result        each rank holds the graph rows of its shard; `gather_graph()` assembles
-                the full graph on every rank.
+                p_work tile budget; then the join passes, each after an all-gather of the ranks'
+                current neighbour lists.
+  result        the finished rows go back to the ranks that own them (all-to-all); each rank holds
+                the graph rows of its shard; `gather_graph()` assembles the full graph on every rank.
 
 With one rank the collectives are no-ops and no torch import happens.
 """
@@ -31,9 +33,9 @@ JOIN_YIELD = 0.01   # extra join passes run while a pass still replaces more tha
 
 
 # ----------------------------------------------------------------------- comms
-# Everything that crosses ranks on the fit path is a fixed-size numeric buffer: 16 bytes per rank and
-# anchor round (value, index), the anchor's coordinates, the ordered shards / interval tables /
-# neighbour lists (device buffers), the graph shards.  No pickled objects.
+# Everything that crosses ranks on the fit path is a numeric buffer: 16 bytes per rank and anchor round
+# (value, index) with the anchor's coordinates, the raw rows, the neighbour lists (device buffers), the
+# finished graph rows.  No pickled objects.
 class SingleComm:
     rank, world = 0, 1
 
@@ -45,6 +47,12 @@ class SingleComm:
 
     def allgather_host(self, arr):
         return [arr]
+
+    def allgather_rows(self, X, counts):
+        return "host", X, None
+
+    def exchange_rows(self, dest, arrays):
+        return [np.ascontiguousarray(a) for a in arrays]
 
 
 class TorchComm:
@@ -100,6 +108,54 @@ class TorchComm:
         parts = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(parts, t, group=self.group)
         return [p.cpu().numpy() for p in parts]
+
+
+    def allgather_rows(self, X, counts):
+        """Every rank's rows (float32 [counts[r], dim]) concatenated in rank order, on every rank:
+        ("device", pointer, owner tensor) when the group is `nccl`, ("host", array, None) otherwise."""
+        import torch
+
+        most, dim = int(max(counts)), X.shape[1]
+        pad = X if X.shape[0] == most else np.concatenate([X, np.zeros((most - X.shape[0], dim), dtype=X.dtype)])
+        if self.backend == "nccl":
+            t = torch.from_numpy(np.ascontiguousarray(pad)).to("cuda")
+            out = torch.empty((self.world * most, dim), dtype=t.dtype, device=t.device)
+            self.dist.all_gather_into_tensor(out, t, group=self.group)
+            if any(int(c) != most for c in counts):
+                out = torch.cat([out[r * most:r * most + int(counts[r])] for r in range(self.world)])
+            torch.cuda.synchronize(out.device)
+            return "device", out.data_ptr(), out
+        parts = [torch.empty((most, dim), dtype=torch.float32) for _ in range(self.world)]
+        self.dist.all_gather(parts, torch.from_numpy(np.ascontiguousarray(pad)), group=self.group)
+        return "host", np.concatenate([parts[r][:int(counts[r])].numpy() for r in range(self.world)]), None
+
+    def exchange_rows(self, dest, arrays):
+        """Row r of every array goes to rank dest[r]; returns the rows this rank receives (source-rank order).
+        `nccl`: all_to_all_single with split sizes on device tensors; other backends have no all-to-all:
+        padded all-gather, every rank keeps its slice."""
+        import torch
+
+        order = np.argsort(dest, kind="stable")
+        send = np.bincount(dest, minlength=self.world).astype(np.int64)
+        C = self.allgather_f64(send).astype(np.int64)          # C[src, dst]
+        recv = C[:, self.rank]
+        out = []
+        if self.backend == "nccl":
+            for a in arrays:
+                t = torch.from_numpy(np.ascontiguousarray(a[order])).to("cuda")
+                r = torch.empty((int(recv.sum()),) + tuple(a.shape[1:]), dtype=t.dtype, device=t.device)
+                self.dist.all_to_all_single(r, t, output_split_sizes=[int(v) for v in recv],
+                                            input_split_sizes=[int(v) for v in send], group=self.group)
+                out.append(r.cpu().numpy())
+            return out
+        most = int(C.sum(axis=1).max())
+        for a in arrays:
+            pad = np.zeros((most,) + tuple(a.shape[1:]), dtype=a.dtype)
+            pad[:len(order)] = a[order]
+            parts = self.allgather_host(pad)
+            out.append(np.concatenate([parts[src][int(C[src, :self.rank].sum()):int(C[src, :self.rank + 1].sum())]
+                                       for src in range(self.world)]))
+        return out
 
 
 class _DeviceOwner:
@@ -230,38 +286,39 @@ class StreamedAnnchor:
         eng, comm = self._engine, self.comm
         self.get_anchors()
         t1 = time.perf_counter()
-        min_tiles = max((n + TILE - 1) // TILE for _, n in self.shards)
-        ptrs, n_pad, nt, dimp = eng.stream_order(min_tiles)
-        t2 = time.perf_counter()
-        keep = []
-        if comm.world > 1 or self.force_exchange:
-            sizes = {"Xs": n_pad * dimp * 4, "rs": n_pad * 4, "perm": n_pad * 8}
-            allp = {}
-            for name, nbytes in sizes.items():
-                allp[name], owner = comm.allgather_device(eng, ptrs[name], nbytes)
-                keep.append(owner)
-            # interval tables [n_anchors, nt]: gathered rank-major, then joined along the tile axis
-            # ([world][na][nt] -> [na][world * nt]) by a device kernel
-            tab_bytes = self.n_anchors * nt * 4
-            for name in ("lo", "hi", "mid"):
-                gathered, owner = comm.allgather_device(eng, ptrs[name], tab_bytes)
-                d = eng.device_alloc(tab_bytes * max(comm.world, 1))
-                eng.stream_join_tables(gathered, max(comm.world, 1), self.n_anchors, nt, d)
-                allp[name] = d
-                keep.append(_DeviceOwner(eng, d))
-                del owner
-            ptrs = allp
-        t3 = time.perf_counter()
-        n_all, nt_all = n_pad * comm.world, nt * comm.world
-        if comm.world == 1 and not self.force_exchange:
+        sharded = comm.world > 1 or self.force_exchange
+        if sharded:
+            # ONE tile structure for the whole data set, whatever the number of ranks: every rank gets all rows
+            # (one all-gather; it needs them as columns anyway), recomputes their anchor distances from the anchors
+            # it already knows (no collective: 32 streaming passes) and orders them itself; the ranks then own
+            # contiguous ranges of the GLOBAL tile order.  Ordering each shard separately (round 1) made a tile's
+            # cell G times larger -- recall at N = 400 000 fell from 0.990 (1 rank) to 0.968 (2) and 0.942 (4).
+            counts = [n for _, n in self.shards]
+            kind, Xall, owner = comm.allgather_rows(self.X, counts)
+            if kind == "device":
+                eng.stream_bind(None, 0, device_ptr=Xall, shape=(self.n_total, self.dim))
+            else:
+                eng.stream_bind(Xall, 0)
+            del owner, Xall
+            for r in range(self.n_anchors):
+                eng.stream_anchor_round(self.anchor_vectors[r], r, self.n_anchors)
+            tiles_per_rank = -(-((self.n_total + TILE - 1) // TILE) // comm.world)
+            ptrs, n_pad, nt, dimp = eng.stream_order(tiles_per_rank * comm.world)
+            tile_begin, tile_count = comm.rank * tiles_per_rank, tiles_per_rank
+        else:
+            ptrs, n_pad, nt, dimp = eng.stream_order(0)
+            tile_begin, tile_count = 0, nt
+        t2 = t3 = time.perf_counter()
+        n_all, nt_all = n_pad, nt
+        if not sharded:
             row_ids, idx, dist, tile_evals = eng.stream_knn(ptrs, n_all, nt_all, self.n_anchors, dimp, 0, nt, self.n_neighbors,
                                                             self.p_work, n_local=self.n_local, join_passes=self.join_passes,
                                                             join_extra=self.join_extra)
         else:
-            # row-sharded: tile phase, then join passes against the all-gathered neighbour lists
+            # tile phase on the rank's own row tiles, then join passes against the all-gathered neighbour lists
             total, tile_budget, per_pass = self._budget(nt_all)
-            lists, nbytes = eng.stream_knn_begin(ptrs, n_all, nt_all, self.n_anchors, dimp, comm.rank * nt, nt, self.n_neighbors,
-                                                 tile_budget)
+            lists, nbytes = eng.stream_knn_begin(ptrs, n_all, nt_all, self.n_anchors, dimp, tile_begin, tile_count,
+                                                 self.n_neighbors, tile_budget)
             floor_updates = JOIN_YIELD * n_all * (self.n_neighbors - 1)
             for p in range(self.join_passes + self.join_extra if tile_budget < nt_all else 0):
                 if p >= self.join_passes and tile_budget + (p + 1) * max(per_pass, 1) > total:
@@ -272,10 +329,24 @@ class StreamedAnnchor:
                 # every rank takes the same decision: the yield of the pass summed over ranks
                 if p + 1 >= self.join_passes and comm.allgather_f64((upd,)).sum() <= floor_updates:
                     break
-            row_ids, idx, dist, tile_evals = eng.stream_knn_end(n_local=self.n_local)
+            row_ids, idx, dist, tile_evals = eng.stream_knn_end()
+            # rows and neighbours are numbered by their position in the rank-ordered concatenation of the shards:
+            # back to global row ids, and every row back to the rank that owns it
+            starts = np.concatenate([[0], np.cumsum([n for _, n in self.shards])]).astype(np.int64)
+            bases = np.array([b for b, _ in self.shards], dtype=np.int64)
+
+            def to_global(pos):
+                r = np.searchsorted(starts, pos, side="right") - 1
+                return pos - starts[r] + bases[r]
+
+            real = row_ids >= 0
+            pos = row_ids[real]
+            dest = (np.searchsorted(starts, pos, side="right") - 1).astype(np.int64)
+            gid, gidx, gdist = comm.exchange_rows(dest, [to_global(pos), to_global(idx[real]), dist[real]])
+            row_ids, idx, dist = gid, gidx, gdist
         t4 = time.perf_counter()
-        # the ordered column arrays (all ranks' shards) stay alive: query() runs against them
-        self._columns = dict(ptrs=ptrs, n_all=n_all, nt_all=nt_all, dimp=dimp, keep=keep)
+        # the ordered column arrays (every row of the data set) stay alive: query() runs against them
+        self._columns = dict(ptrs=ptrs, n_all=n_all, nt_all=nt_all, dimp=dimp)
         if row_ids is None:   # rows already in this shard's order (emitted on the device)
             ng_idx, ng_dist = idx, dist
         else:                 # tile order + global row ids: reorder on the host
@@ -289,7 +360,7 @@ class StreamedAnnchor:
         self.tile_evals = int(tile_evals)
         self.evals += self.tile_evals * TILE * TILE
         self.n_tiles_total = nt_all
-        self.timings = dict(get_anchors=t1 - t0, order=t2 - t1, exchange=t3 - t2, knn=t4 - t3, total=time.perf_counter() - t0)
+        self.timings = dict(get_anchors=t1 - t0, order=t2 - t1, exchange=0.0, knn=t4 - t3, total=time.perf_counter() - t0)
         return self
 
     def query(self, Q, nn=15, p_work=0.1, device=None):
