@@ -595,9 +595,10 @@ def main():
             "dtype": "f32 (MFMA tile GEMM v_mfma_f32_32x32x2_f32; reported distances recomputed in f64 from the f32 rows)",
             "data": "synthetic (SURVEY.md 8d recipe: 8-d latent manifold in 128-d, float32), generated per shard",
             "config": {"workload": res["workload"], "total_rows": n_per_rank * world,
-                       "parallelism": "rows sharded N/G per GPU; per anchor round one all-gather of (value, index, row); all-gather of "
-                                      "the ordered shards and of the neighbour lists before each join pass (RCCL); final graph gather "
-                                      "not timed (each rank keeps its rows)"},
+                       "parallelism": "rows sharded N/G per GPU; per anchor round one all-gather of (value, index, row); one all-gather of "
+                                      "the raw rows (every rank then builds the same global tile order), all-gather of the neighbour "
+                                      "lists before each join pass, all-to-all of the finished rows to their owners (RCCL); full-graph "
+                                      "gather not timed (each rank keeps its rows)"},
             "recall_at_k": res["recall_at_k"], "rows_per_s": res["rows_per_s"],
             "roofline": res.get("roofline"), "detail": res,
             "cpu_affinity": affinity or "unbound",
