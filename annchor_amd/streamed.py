@@ -368,7 +368,7 @@ class StreamedAnnchor:
         numbering, distances [nq, nn]) -- Annchor.query (annchor.py:643-683) for the streamed
         form: the queries get the fitted anchors' distances, are ordered into tiles like the data,
         and every query tile evaluates its best-ranked ceil(p_work * #tiles) data tiles with the
-        same kernel.  Any rank can answer: after fit() each holds all ordered shards."""
+        same kernel.  Any rank can answer: after fit() each holds all rows in tile order."""
         from . import _native
 
         if not hasattr(self, "_columns"):
