@@ -103,6 +103,7 @@ struct annchor_ctx {
     DevBuf sel2, sel_bufA, sel_bufB, sel_seg;                             // filter-then-finish selection: tables, candidates
     const void *sel2_clean = nullptr;                            // sel2 tables known to be zero at this address
     DevBuf errs, errptr;
+    DevBuf ecdf_index;           // per-label bucket index over the sorted errors (long lists)
     DevBuf cptr, cidx, cval;     // computed-neighbour CSR for update_bounds
     DevBuf tmp0, tmp1, tmp2, tmp3;
     DevBuf scan_tmp;

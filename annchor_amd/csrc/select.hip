@@ -545,12 +545,71 @@ __global__ __launch_bounds__(64) void k_gn_sequential(int64_t nx, int nmin, int 
     }
 }
 
+// Bucket index over a label's sorted errors: nb = 2 * len equal-width buckets over [first, last].
+// bucket(x) is a monotone non-decreasing function of x (float subtraction, multiplication by a non-negative
+// constant, floor and clamping all are), so with T[k] = #{entries with bucket < k} every entry in a bucket
+// below bucket(x) is < x and every entry in a bucket above it is > x: searchsorted(E, x, 'left') lies in
+// [T[k], T[k + 1]], k = bucket(x) -- one table read and a search over the one or two entries of a bucket
+// instead of ~13 probes.  Exact for any input (ties, infinities: they clamp; NaN: bucket 0, as comparisons
+// with NaN are false in the search as well).
+struct EcdfIndex {
+    double emin, scale;
+    int32_t nb, toff;   // buckets of this label, offset of its nb + 1 table entries
+};
+__device__ __forceinline__ int ecdf_bucket(const EcdfIndex &ix, double x)
+{
+    const double t = (x - ix.emin) * ix.scale;
+    if (!(t >= 0.0)) return 0;
+    if (t >= (double)ix.nb) return ix.nb - 1;
+    return (int)t;
+}
+// one block per label
+__global__ __launch_bounds__(256) void k_ecdf_index(const double *__restrict__ errs, const int64_t *__restrict__ errptr,
+                                                   EcdfIndex *__restrict__ index, uint32_t *__restrict__ table)
+{
+    const int b = blockIdx.x;
+    const int64_t lo = errptr[b], hi = errptr[b + 1];
+    const int len = (int)(hi - lo);
+    EcdfIndex ix;
+    ix.nb = len > 0 ? 2 * len : 1;
+    ix.toff = (int32_t)(2 * lo + b);
+    ix.emin = len > 0 ? errs[lo] : 0.0;
+    const double span = len > 0 ? errs[hi - 1] - ix.emin : 0.0;
+    ix.scale = span > 0.0 ? (double)ix.nb / span : 0.0;
+    if (!(ix.scale < INFINITY)) ix.scale = 0.0;
+    uint32_t *T = table + ix.toff;
+    for (int k = threadIdx.x; k <= ix.nb; k += blockDim.x) T[k] = 0u;
+    __syncthreads();
+    // T[k + 1] counts the entries of bucket k; the entries are sorted, so bucket numbers are non-decreasing
+    // along the list and T[k] = index of the first entry whose bucket is >= k: written by the first entry of
+    // every bucket run, gaps filled by a running maximum
+    for (int e = threadIdx.x; e < len; e += blockDim.x) atomicAdd(&T[ecdf_bucket(ix, errs[lo + e]) + 1], 1u);
+    __syncthreads();
+    // inclusive prefix over the nb + 1 counts: a contiguous chunk per thread, chunk totals scanned in LDS
+    __shared__ uint32_t csum[256];
+    const int per = (ix.nb + 1 + 255) / 256;
+    const int k0 = threadIdx.x * per, k1 = min(k0 + per, ix.nb + 1);
+    uint32_t mine = 0;
+    for (int k = k0; k < k1; ++k) mine += T[k];
+    csum[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int q = 0; q < 256; ++q) { const uint32_t v = csum[q]; csum[q] = run; run += v; }
+        index[b] = ix;
+    }
+    __syncthreads();
+    uint32_t run = csum[threadIdx.x];
+    for (int k = k0; k < k1; ++k) { run += T[k]; T[k] = run; }
+}
+
 // -------------------------------------------------------------------- ECDF prob
 __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict__ ij, const double *__restrict__ thresh,
                                              const double *__restrict__ RA, const uint8_t *__restrict__ ncm,
                                              const uint8_t *__restrict__ label, const double *__restrict__ errs,
                                              const int64_t *__restrict__ errptr, int nlabels, int errs_in_lds,
-                                             double *__restrict__ prob, int stream)
+                                             double *__restrict__ prob, int stream, const EcdfIndex *__restrict__ index,
+                                             const uint32_t *__restrict__ table)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     double *le = reinterpret_cast<double *>(dyn);
@@ -596,6 +655,13 @@ __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict_
             b[e] = search ? (int32_t)lptr[lbv[e]] : 0;
             lo[e] = b[e];
             hi[e] = search ? (int32_t)lptr[lbv[e] + 1] : 0;
+            if (index && lo[e] < hi[e]) {   // bucket index: the answer lies inside one bucket
+                const EcdfIndex ix = index[lbv[e]];
+                const int k = ecdf_bucket(ix, pv[e]);
+                const uint32_t t0 = table[ix.toff + k], t1 = table[ix.toff + k + 1];
+                hi[e] = b[e] + (int32_t)t1;
+                lo[e] = b[e] + (int32_t)t0;
+            }
             busy |= lo[e] < hi[e];
         }
         // searchsorted(side='left'): number of entries < pv
@@ -1178,9 +1244,21 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         int blocks = min(ann_blocks(n, 256 * 8), c->prop.multiProcessorCount * 8);
         // algorithmic bytes per pair: 8 (ij) + 8 (RA) + 2 (mask, label) + 8 (prob)
         ProfScope ps(c, "ecdf_probability", (double)n * 26.0);
+        // long lists: a bucket index over every label's errors (one small launch) replaces most of the search
+        static const long long index_min = getenv("ANNCHOR_ECDF_INDEX_MIN") ? atoll(getenv("ANNCHOR_ECDF_INDEX_MIN")) : (4ll << 20);
+        EcdfIndex *index = nullptr;
+        uint32_t *table = nullptr;
+        if (n >= index_min && nlabels > 0 && nerr > 0 && nerr < (1ll << 29)) {
+            const size_t idx_bytes = (sizeof(EcdfIndex) * (size_t)nlabels + 15) & ~(size_t)15;
+            ANN_TRY(ann_reserve(c, c->ecdf_index, idx_bytes + sizeof(uint32_t) * (size_t)(2 * nerr + nlabels + 1)));
+            index = c->ecdf_index.as<EcdfIndex>();
+            table = reinterpret_cast<uint32_t *>(c->ecdf_index.as<char>() + idx_bytes);
+            k_ecdf_index<<<nlabels, 256, 0, c->stream>>>(c->errs.as<double>(), c->errptr.as<int64_t>(), index, table);
+        }
         k_prob<<<blocks, 256, dyn, c->stream>>>(n, c->ij.as<int2>(), c->thresh.as<double>(), c->RA.as<double>(),
                                                c->ncm.as<uint8_t>(), c->label.as<uint8_t>(), c->errs.as<double>(),
-                                               c->errptr.as<int64_t>(), nlabels, in_lds, c->prob.as<double>(), n >= ANN_STREAM_MIN_PAIRS);
+                                               c->errptr.as<int64_t>(), nlabels, in_lds, c->prob.as<double>(), n >= ANN_STREAM_MIN_PAIRS,
+                                               index, table);
     }
     ANN_CHECK_HIP(c, hipGetLastError());
     // (the sweep's error flag is read with the final state below: one host wait less)
