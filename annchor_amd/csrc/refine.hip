@@ -130,6 +130,91 @@ __global__ __launch_bounds__(256) void k_update_bounds(const int32_t *__restrict
     }
 }
 
+// Row-grouped form.  The lookahead list is in pair-list order, so consecutive entries share their first
+// point i: a workgroup takes a run of UBR_CHUNK entries, keeps "slot of c in L_i" for the current i in an LDS
+// table over all points (uint16: L_i has < 65 536 entries; 2 B x nx <= 60 KB at the pair-list form's largest
+// nx) and every wave streams the other point's list L_j past it -- one coalesced key read and one LDS
+// lookup per entry, values fetched for the matches only -- instead of ~10 dependent binary-search probes for
+// every entry of the shorter list.  The table is rebuilt (old entries cleared, new ones written) when i
+// changes inside the run; any order of the list is handled, the sorted one just rebuilds least.
+#define UBR_CHUNK 256
+__global__ __launch_bounds__(256) void k_update_bounds_rows(const int32_t *__restrict__ next, int64_t nnext,
+                                                           const int2 *__restrict__ ij, const int64_t *__restrict__ cptr,
+                                                           const int32_t *__restrict__ cidx, const double *__restrict__ cval,
+                                                           double *__restrict__ lb, double *__restrict__ ub, int nx)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    uint16_t *tab = reinterpret_cast<uint16_t *>(dyn);   // [nx] slot + 1 of point c in the current row's list, 0 = absent
+    __shared__ int first_other;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < (nx + 1) / 2; c += 256) reinterpret_cast<uint32_t *>(tab)[c] = 0u;
+    const int64_t t0 = (int64_t)blockIdx.x * UBR_CHUNK, t1 = min(t0 + UBR_CHUNK, nnext);
+    int cur = -1;
+    int64_t ca0 = 0, ca1 = 0;
+    __syncthreads();
+    for (int64_t t = t0; t < t1;) {
+        const int i = ij[next[t]].x;   // uniform
+        // how many consecutive entries from t share this first point?
+        if (threadIdx.x == 0) first_other = (int)(t1 - t);
+        __syncthreads();
+        {
+            const int64_t tt = t + threadIdx.x;
+            if (tt < t1 && ij[next[tt]].x != i) atomicMin(&first_other, (int)threadIdx.x);
+        }
+        __syncthreads();
+        const int seg = first_other;
+        if (cur != i) {
+            for (int64_t e = ca0 + threadIdx.x; e < ca1; e += 256) tab[cidx[e]] = 0;
+            ca0 = cptr[i]; ca1 = cptr[i + 1];
+            __syncthreads();
+            for (int64_t e = ca0 + threadIdx.x; e < ca1; e += 256) tab[cidx[e]] = (uint16_t)(e - ca0 + 1);
+            cur = i;
+            __syncthreads();
+        }
+        for (int q = wave; q < seg; q += 4) {
+            const int32_t p = next[t + q];
+            const int j = ij[p].y;
+            const int64_t b0 = cptr[j], b1 = cptr[j + 1];
+            double nl = 0.0, nu = INFINITY;
+            // eight key reads in flight per lane (a wave alone keeps 2 KB of the list on its way: one read at a
+            // time the kernel ran at memory latency), then the lookups, then the value reads of the matches
+            constexpr int U = 8;
+            for (int64_t e0 = b0 + lane; e0 < b1; e0 += 64 * U) {
+                int32_t key[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) key[u] = cidx[min(e0 + 64 * u, b1 - 1)];
+                uint32_t sl[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) sl[u] = e0 + 64 * u < b1 ? (uint32_t)tab[key[u]] : 0u;
+                // both values of every entry are requested whether it matches or not (clamped addresses, all in
+                // flight together): a branch per entry around two dependent reads serialised eight round trips
+                double x[U], y[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    x[u] = cval[ca0 + (sl[u] ? sl[u] - 1 : 0)];
+                    y[u] = cval[min(e0 + 64 * u, b1 - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    nu = sl[u] ? fmin(nu, x[u] + y[u]) : nu;
+                    nl = sl[u] ? fmax(nl, fabs(x[u] - y[u])) : nl;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                nu = fmin(nu, __shfl_xor(nu, off));
+                nl = fmax(nl, __shfl_xor(nl, off));
+            }
+            if (lane == 0) {
+                lb[p] = fmax(nl, lb[p]);  // annchor.py:503-510
+                ub[p] = fmin(nu, ub[p]);
+            }
+        }
+        t += seg;
+        __syncthreads();
+    }
+}
+
 extern "C" int annchor_update_bounds(annchor_ctx *c)
 {
     if (!c) return ANNCHOR_EINVAL;
@@ -165,6 +250,19 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
         const int64_t counted = c->n_unc >= 0 ? 2 * (c->n - c->n_unc) : total;   // computed entries, both directions
         const double avg = nx > 0 ? (double)counted / (double)nx : 0.0;
         ProfScope ps(c, "update_bounds_intersect", (double)c->nnext * (2.0 * avg * 12.0 + 36.0));
+        const size_t tab_bytes = (((size_t)nx + 1) / 2) * 4;
+        const char *ube = getenv("ANNCHOR_UPDATE_BOUNDS");   // "pairs" / "rows" force a form (tests compare the two)
+        // long lists only: with ~100 entries per list (C2) the table rebuilds and the 512-entry strides cost more
+        // than they save (0.28 vs 0.14 ms); at 800 entries per list 12.8 vs 18.1 ms
+        const bool rows_form = ube ? strcmp(ube, "rows") == 0 : avg >= 256.0;
+        if (nx < 65536 && tab_bytes <= 150 * 1024 && rows_form) {
+            if (tab_bytes > 64 * 1024)
+                ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_rows, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)tab_bytes));
+            k_update_bounds_rows<<<ann_blocks(c->nnext, UBR_CHUNK), 256, tab_bytes, c->stream>>>(
+                c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(),
+                c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>(), (int)nx);
+        } else
         k_update_bounds<<<ann_blocks(c->nnext * 64, 256), 256, 0, c->stream>>>(
             c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(),
             c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>());

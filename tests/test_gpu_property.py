@@ -105,6 +105,8 @@ def test_guarantee_nmin_rounds_equal_the_sequential_sweep(monkeypatch):
         out = {}
         for mode in ("rounds", "sequential"):
             monkeypatch.setenv("ANNCHOR_GN_SWEEP", mode)
+            # (the second setting also takes the wave-per-pair form of update_bounds instead of the row-grouped one)
+            monkeypatch.setenv("ANNCHOR_UPDATE_BOUNDS", "rows" if mode == "rounds" else "pairs")
             ann = Annchor(data, metric, random_seed=3, **kw).fit()
             out[mode] = (ann.neighbor_graph[0].copy(), ann.neighbor_graph[1].copy(), ann.evals, ann.RefineApprox.copy(),
                          ann.not_computed_mask.copy())
