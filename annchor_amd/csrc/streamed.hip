@@ -524,6 +524,17 @@ template <int DIM, int KMAX> struct KnnShared {
 // The two barriers only hand the single LDS operand buffer from its readers to its writers.
 // Register staging of one 32-column slab; survives from one tile to the next so that the
 // first slab of the next tile is already in flight while the current tile finishes.
+// Which float4 of a 32-column slab thread item q stages: column colr (0..31), first dimension k4.  Inside every
+// group of 32 consecutive items the column varies over 4 and the float4 index over 8, so the four scalar LDS
+// writes of the group land in 32 different banks (row stride DIM + 1 = 1 mod 32: bank = colr + k4 + j); the
+// plain row-major assignment put 32 lanes on 8 banks (a third of the kernel's LDS-busy cycles were conflicts).
+template <int DIM> __device__ __forceinline__ void stage_map(int q, int &colr, int &k4)
+{
+    const int g = q >> 5, r = q & 31;
+    colr = (g & 7) * 4 + (r & 3);
+    k4 = ((g >> 3) * 8 + (r >> 2)) * 4;
+}
+
 template <int DIM> struct SlabStage {
     float4 v[ST_SLAB * DIM / 4 / ST_THREADS];
     float r;
@@ -556,11 +567,15 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
         if constexpr (GATHER) {
             uint32_t ids[NLD];
 #pragma unroll
-            for (int u = 0; u < NLD; ++u) ids[u] = ulist[c0 + (u * ST_THREADS + threadIdx.x) / (DIM / 4)];
+            for (int u = 0; u < NLD; ++u) {
+                int colr, k4;
+                stage_map<DIM>(u * ST_THREADS + threadIdx.x, colr, k4);
+                ids[u] = ulist[c0 + colr];
+            }
 #pragma unroll
             for (int u = 0; u < NLD; ++u) {
-                const int q = u * ST_THREADS + threadIdx.x;
-                const int k4 = (q % (DIM / 4)) * 4;
+                int colr, k4;
+                stage_map<DIM>(u * ST_THREADS + threadIdx.x, colr, k4);
                 const uint32_t src = ids[u] == 0xffffffffu ? 0u : ids[u];
                 stage[u] = *reinterpret_cast<const float4 *>(a.Xs + (size_t)src * DIM + k4);
             }
@@ -572,8 +587,8 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
         } else {
 #pragma unroll
             for (int u = 0; u < NLD; ++u) {
-                const int q = u * ST_THREADS + threadIdx.x;
-                const int colr = q / (DIM / 4), k4 = (q % (DIM / 4)) * 4;
+                int colr, k4;
+                stage_map<DIM>(u * ST_THREADS + threadIdx.x, colr, k4);
                 stage[u] = *reinterpret_cast<const float4 *>(a.Xs + (size_t)(c0 + colr) * DIM + k4);
             }
             if (threadIdx.x < ST_SLAB) stage_r = a.rs[c0 + threadIdx.x];
@@ -630,8 +645,8 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
         ST_PROF(0)
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
-            const int q = u * ST_THREADS + threadIdx.x;
-            const int colr = q / (DIM / 4), k4 = (q % (DIM / 4)) * 4;
+            int colr, k4;
+            stage_map<DIM>(u * ST_THREADS + threadIdx.x, colr, k4);
             sh.Bs[colr][k4] = stage[u].x; sh.Bs[colr][k4 + 1] = stage[u].y; sh.Bs[colr][k4 + 2] = stage[u].z; sh.Bs[colr][k4 + 3] = stage[u].w;
         }
         if (threadIdx.x < ST_SLAB) {

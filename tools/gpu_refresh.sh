@@ -17,6 +17,7 @@ cd $R
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json
 python tools/pmc_summary.py $O/pmc_fetch_scale $O/pmc_write_scale $O/pmc_traffic_scale.json
 bash tools/pmc_lev2.sh > $O/pmc_lev2.log 2>&1; cp gpurun_out/pmc_lev2/pmc_lev2.json $O/pmc_lev.json 2>/dev/null
+bash tools/pmc_st.sh > $O/pmc_st.log 2>&1; cp gpurun_out/pmc_st/pmc_st.json $O/pmc_st.json 2>/dev/null
 find $O -name "*kernel_stats.csv" | head; find $O -name "*counter_collection.csv" -size +30M -delete
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_fetch_scale $O/pmc_write_scale 2>/dev/null
 find $O/stats $O/scale -name "*kernel_trace.csv" -delete
