@@ -496,10 +496,11 @@ struct KnnArgs {
 template <int DIM, int KMAX> struct KnnShared {
     float Bs[ST_SLAB][DIM + 1];
     float rsJ[ST_SLAB];
-    float cand_d[ST_T][ST_SLAB];
-    uint8_t cand_c[ST_T][ST_SLAB];   // column inside the slab
-    float list_d[ST_T][KMAX];
-    int32_t list_c[ST_T][KMAX];
+    // (row strides that are not multiples of the 32 banks: lanes own different rows and touch the same slot)
+    float cand_d[ST_T][ST_SLAB + 1];
+    uint8_t cand_c[ST_T][ST_SLAB + 4];   // column inside the slab
+    float list_d[ST_T][KMAX + 1];
+    int32_t list_c[ST_T][KMAX + 1];
     float thr[ST_T];
     int cnt[ST_T];
     float loI[64], hiI[64], midI[64];
