@@ -645,3 +645,40 @@ def test_fit_graph_sp_python_metric():
     assert np.array_equal(ann.neighbor_graph[0], ora.neighbor_graph[0])
     err = compare_neighbor_graphs((G["ng_idx"].astype(np.int64), G["ng_dist"]), ann.neighbor_graph, 15)
     assert err <= int(G["errors"]) < 10
+
+
+def test_fit_strings_with_duplicates_and_empty_strings_stagewise():
+    """Collisions: a third of the strings are exact copies of others (distance 0 between distinct points,
+    whole tie groups in every order statistic), three are empty, lengths are ragged (0..90) -- every stage
+    equal to the oracle's, which follows the reference's tie rules (np.argmax first index, stable sorts,
+    partition order statistics)."""
+    from annchor_amd import Annchor
+
+    rng = np.random.default_rng(31)
+    base = ["".join(rng.choice(list("abc"), rng.integers(1, 90))) for _ in range(220)]
+    Xs = base + [base[i] for i in rng.integers(0, 220, 110)] + ["", "", ""]
+    order = rng.permutation(len(Xs))
+    Xs = [Xs[i] for i in order]
+    cfg = dict(n_anchors=7, n_neighbors=8, n_samples=600, p_work=0.35, random_seed=5, niters=2)
+    ann = Annchor(np.array(Xs, dtype=object), "levenshtein", **cfg)
+    P = om.PackedStrings(Xs)
+    ora = _staged_compare(ann, lambda tr: O.OracleAnnchor(len(Xs), P.pairs, trace=tr, **cfg))
+    assert (ora.neighbor_graph[1][:, 1] == 0).sum() >= 100   # the copies found each other
+
+
+def test_fit_euclid_integer_grid_with_duplicates_stagewise():
+    """Euclidean on a small integer grid (float64): many exactly equal distances and duplicated points, so the
+    order statistics, the arg-max of the picker and the candidate cuts all sit inside tie groups.  Integer
+    coordinates make the device's and NumPy's distances bit-equal (sums of squares are exact), so the stages
+    are compared exactly like an integer metric's."""
+    from annchor_amd import Annchor
+
+    rng = np.random.default_rng(9)
+    X = rng.integers(0, 6, (520, 3)).astype(np.float64)
+    X[400:] = X[rng.integers(0, 400, 120)]          # exact copies
+    cfg = dict(n_anchors=9, n_neighbors=7, n_samples=500, p_work=0.3, random_seed=11, niters=2)
+    ann = Annchor(X, "euclidean", **cfg)
+    _staged_compare(ann, lambda tr: O.OracleAnnchor(len(X), lambda IJ: om.euclidean_pairs(X, IJ), trace=tr, **cfg),
+                    float_metric=True)
+    idx, dist = ann.neighbor_graph
+    assert np.all(dist[400:, 1] == 0)               # every copy has its original (or another copy) at distance 0
