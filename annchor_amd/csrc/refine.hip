@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_update_bounds_rows(const int32_t *__res
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     x[u] = cval[ca0 + (sl[u] ? sl[u] - 1 : 0)];
-                    y[u] = cval[min(e0 + 64 * u, b1 - 1)];
+                    y[u] = cval[sl[u] ? e0 + 64 * u : ca0];   // no match: a line that is hot anyway (the partner lists miss L2)
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
