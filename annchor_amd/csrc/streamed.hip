@@ -26,7 +26,6 @@
 // (d/2 VGPRs), column tiles are streamed through LDS in 32-column slabs (row stride d+1
 // floats: bank-conflict-free operand reads), accumulators are compared against per-row
 // thresholds in LDS and only the survivors are inserted into the per-row lists.
-#include <hipcub/hipcub.hpp>
 
 #include "common.h"
 
@@ -397,6 +396,137 @@ __global__ __launch_bounds__(ST_T) void k_st_intervals(const float *__restrict__
     }
 }
 
+// ---- stable LSD radix sort of (uint64 key, uint32 value) pairs on bits [0, end_bit): 8-bit digits, per pass a
+// per-tile digit count, an exclusive scan of the (digit, tile) counts and a scatter that ranks every key among the
+// equal digits of its tile in tile order (wave match by eight ballots, waves ordered through LDS counters).
+#define RS_THREADS 256
+#define RS_ITEMS 8
+#define RS_TILE (RS_THREADS * RS_ITEMS)
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_count(const unsigned long long *__restrict__ keys, int64_t n, int shift, int nblk,
+                                                        uint32_t *__restrict__ cnt)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const int64_t t = base + j * RS_THREADS + threadIdx.x;
+        if (t < n) atomicAdd(&h[(uint32_t)(keys[t] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    cnt[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+// counts laid out [256 digits][nblk tiles]: one workgroup per digit row turns the row into its exclusive prefix and
+// leaves the row total in tot[digit]; the scatter kernel adds the prefix of the totals over the digits itself
+__global__ __launch_bounds__(256) void k_rs_scan(uint32_t *__restrict__ cnt, int nblk, uint32_t *__restrict__ tot)
+{
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t carry_s;
+    uint32_t *row = cnt + (size_t)blockIdx.x * nblk;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < nblk; t0 += 256) {
+        const int t = t0 + threadIdx.x;
+        const uint32_t v = t < nblk ? row[t] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t b = carry_s;
+        for (int w = 0; w < wave; ++w) b += wsum[w];
+        if (t < nblk) row[t] = b + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = b + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tot[blockIdx.x] = carry_s;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                          int64_t n, int shift, int nblk, const uint32_t *__restrict__ offs,
+                                                          const uint32_t *__restrict__ tot,
+                                                          unsigned long long *__restrict__ keys_out, uint32_t *__restrict__ vals_out)
+{
+    // A wave owns a contiguous quarter of the tile (RS_ITEMS rows of 64 keys): tile order = wave, row, lane.  Each
+    // wave counts its keys per digit in its own LDS row, one workgroup barrier turns the four rows into every wave's
+    // first position per digit, and from there a wave ranks its rows on its own (match by eight ballots, the group's
+    // first lane advances the wave's counter): two barriers per tile, not three per row.
+    __shared__ uint32_t wc[RS_THREADS / 64][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int w = 0; w < RS_THREADS / 64; ++w) wc[w][threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * (64 * RS_ITEMS);
+    unsigned long long key[RS_ITEMS];
+    uint32_t val[RS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const int64_t t = base + j * 64 + lane;
+        key[j] = t < n ? keys[t] : 0ull;
+        val[j] = t < n ? vals[t] : 0u;
+        if (t < n) atomicAdd(&wc[wave][(uint32_t)(key[j] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    {   // thread = digit: counts -> first positions (keys of smaller digits + earlier tiles of this digit + the waves before)
+        __shared__ uint32_t dsum[4];
+        const uint32_t mine = tot[threadIdx.x];
+        uint32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+        if (lane == 63) dsum[wave] = inc;
+        __syncthreads();
+        uint32_t dbase = inc - mine;
+        for (int w = 0; w < wave; ++w) dbase += dsum[w];
+        uint32_t run = dbase + offs[(size_t)threadIdx.x * nblk + blockIdx.x];
+        for (int w = 0; w < RS_THREADS / 64; ++w) { const uint32_t v = wc[w][threadIdx.x]; wc[w][threadIdx.x] = run; run += v; }
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const bool ok = base + j * 64 + lane < n;
+        const uint32_t d = (uint32_t)(key[j] >> shift) & 255u;
+        unsigned long long same = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bb = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? bb : ~bb;
+        }
+        const int before = __popcll(same & below);
+        uint32_t pos = 0;
+        if (ok) pos = wc[wave][d] + (uint32_t)before;
+        __builtin_amdgcn_wave_barrier();   // every lane of the group has read the counter before its first lane advances it
+        if (ok && before == 0) wc[wave][d] += (uint32_t)__popcll(same);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (ok) { keys_out[pos] = key[j]; vals_out[pos] = val[j]; }
+    }
+}
+
+// Sorted result ends up in (keys_a, vals_a) or (keys_b, vals_b): returns 0 / 1 through *where.
+static int st_radix_sort_pairs(annchor_ctx *c, uint32_t *cnt, unsigned long long *keys_a, unsigned long long *keys_b, uint32_t *vals_a,
+                               uint32_t *vals_b, int64_t n, int end_bit, int *where)
+{
+    const int nblk = (int)((n + RS_TILE - 1) / RS_TILE);
+    int cur = 0;
+    for (int shift = 0; shift < end_bit; shift += 8) {
+        unsigned long long *ki = cur ? keys_b : keys_a, *ko = cur ? keys_a : keys_b;
+        uint32_t *vi = cur ? vals_b : vals_a, *vo = cur ? vals_a : vals_b;
+        k_rs_count<<<nblk, RS_THREADS, 0, c->stream>>>(ki, n, shift, nblk, cnt);
+        k_rs_scan<<<256, 256, 0, c->stream>>>(cnt, nblk, cnt + (size_t)256 * nblk);
+        k_rs_scatter<<<nblk, RS_THREADS, 0, c->stream>>>(ki, vi, n, shift, nblk, cnt, cnt + (size_t)256 * nblk, ko, vo);
+        cur ^= 1;
+    }
+    ANN_CHECK_HIP(c, hipGetLastError());
+    *where = cur;
+    return ANNCHOR_OK;
+}
+
 // Order the local rows by (nearest anchor, distance to it), build the tile-ordered copies
 // and the per-tile anchor-distance intervals.  Returns device pointers so that a
 // multi-GPU host can all-gather them (single GPU: hand them straight back to
@@ -433,19 +563,18 @@ extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs
     const int nap = (s->na + 3) & ~3;
     ANN_TRY(sreserve(c, s->Dt, sizeof(float) * (size_t)n * nap));
     k_st_transpose_D<<<ann_blocks(n * nap, 256), 256, 0, c->stream>>>(s->D.as<float>(), n, s->na, nap, s->Dt.as<float>());
-    size_t tmp_bytes = 0;
-    ANN_CHECK_HIP(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, s->keys.as<unsigned long long>(),
-                                                        s->keys2.as<unsigned long long>(), cur, nxt, (int)n, 0, 64, c->stream));
-    ANN_TRY(sreserve(c, s->cubtmp, tmp_bytes));
+    ANN_REQUIRE(c, n < (1ll << 32), ANNCHOR_ELIMIT, "streamed ordering: %lld rows", (long long)n);
+    ANN_TRY(sreserve(c, s->cubtmp, sizeof(uint32_t) * 256 * ((size_t)((n + RS_TILE - 1) / RS_TILE) + 1)));
     for (int level = 0; level < levels; ++level) {
         const int nseg = 1 << level;
         k_st_split_coord<<<nseg, 256, 0, c->stream>>>(s->Dt.as<float>(), nap, cur, n, s->na, level, s->red_idx.as<int32_t>());
         k_st_level_keys<<<ann_blocks(n, 256), 256, 0, c->stream>>>(s->D.as<float>(), cur, n, level, s->red_idx.as<int32_t>(),
                                                                   s->keys.as<unsigned long long>());
-        ANN_CHECK_HIP(c, hipcub::DeviceRadixSort::SortPairs(s->cubtmp.p, tmp_bytes, s->keys.as<unsigned long long>(),
-                                                            s->keys2.as<unsigned long long>(), cur, nxt, (int)n, 0, 32 + level,
-                                                            c->stream));
-        uint32_t *t = cur; cur = nxt; nxt = t;
+        // (segment, distance to the split anchor): stable sort = every segment ordered along its coordinate
+        int where = 0;
+        ANN_TRY(st_radix_sort_pairs(c, s->cubtmp.as<uint32_t>(), s->keys.as<unsigned long long>(), s->keys2.as<unsigned long long>(), cur,
+                                    nxt, n, 32 + level, &where));
+        if (where) { uint32_t *t = cur; cur = nxt; nxt = t; }
     }
     if (cur != s->vals2.as<uint32_t>())
         ANN_CHECK_HIP(c, hipMemcpyAsync(s->vals2.p, cur, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
