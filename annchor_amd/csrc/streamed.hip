@@ -283,15 +283,15 @@ __global__ void k_st_transpose_D(const float *__restrict__ D, int64_t n, int na,
 #ifndef ST_SPLIT_SAMPLE
 #define ST_SPLIT_SAMPLE 2048
 #endif
-__global__ __launch_bounds__(256) void k_st_split_coord(const float *__restrict__ Dt, int nap, const uint32_t *__restrict__ order,
+__global__ __launch_bounds__(1024) void k_st_split_coord(const float *__restrict__ Dt, int nap, const uint32_t *__restrict__ order,
                                                        int64_t n, int na, int level, int32_t *__restrict__ coord)
 {
-    __shared__ double s1[256], s2[256];
+    __shared__ double s1[1024], s2[1024];
     const int sgm = blockIdx.x;
     const int64_t b = ((int64_t)sgm * n + (1ll << level) - 1) >> level, e = ((int64_t)(sgm + 1) * n + (1ll << level) - 1) >> level;
     const int64_t len = e - b;
     const int A = nap <= 32 ? 32 : 64;        // anchors per sample lane group (na <= 64)
-    const int G = 256 / A;                    // sample lanes
+    const int G = 1024 / A;                    // sample lanes
     const int an = threadIdx.x % A, g = threadIdx.x / A;
     const int64_t m = len < ST_SPLIT_SAMPLE ? len : ST_SPLIT_SAMPLE;
     double a1 = 0.0, a2 = 0.0;
@@ -567,7 +567,7 @@ extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs
     ANN_TRY(sreserve(c, s->cubtmp, sizeof(uint32_t) * 256 * ((size_t)((n + RS_TILE - 1) / RS_TILE) + 1)));
     for (int level = 0; level < levels; ++level) {
         const int nseg = 1 << level;
-        k_st_split_coord<<<nseg, 256, 0, c->stream>>>(s->Dt.as<float>(), nap, cur, n, s->na, level, s->red_idx.as<int32_t>());
+        k_st_split_coord<<<nseg, 1024, 0, c->stream>>>(s->Dt.as<float>(), nap, cur, n, s->na, level, s->red_idx.as<int32_t>());
         k_st_level_keys<<<ann_blocks(n, 256), 256, 0, c->stream>>>(s->D.as<float>(), cur, n, level, s->red_idx.as<int32_t>(),
                                                                   s->keys.as<unsigned long long>());
         // (segment, distance to the split anchor): stable sort = every segment ordered along its coordinate
