@@ -246,12 +246,15 @@ int annchor_neighbor_graph(annchor_ctx *ctx, int32_t n_neighbors, int64_t *ng_id
  *   distances of every local row to `anchor_vec` (host float32 [dim]), running-min update,
  *   local arg-max (local index, first index on ties).  The host combines ranks.
  * annchor_stream_get_row: fetch one local row (the next anchor's coordinates).
- * annchor_stream_order: order rows by (nearest anchor, distance), build 128-row tiles and
- *   their anchor-distance intervals; returns DEVICE pointers (owned by the context) for a
- *   multi-GPU host to all-gather: Xs float32 [n_pad, dim_padded], rs float32 [n_pad],
- *   perm int64 [n_pad] (global ids, -1 on padding), lo/hi/mid float32 [n_anchors, n_tiles]
- *   (per-tile min / max / mean distance to each anchor).
- *   min_tiles pads the shard to a common tile count across ranks.
+ * annchor_stream_order: order the bound rows into 128-row tiles (balanced k-d splits in
+ *   anchor-distance space) with their anchor-distance intervals; returns DEVICE pointers (owned by
+ *   the context): Xs float32 [n_pad, dim_padded], rs float32 [n_pad], perm int64 [n_pad] (global
+ *   ids, -1 on padding), lo/hi/mid float32 [n_anchors, n_tiles] (per-tile min / max / mean distance
+ *   to each anchor).  min_tiles pads the tile count (e.g. to a multiple of the rank count).
+ *   Row-sharded runs (annchor_amd/streamed.py): after the sharded anchor rounds every rank binds ALL
+ *   rows (all-gathered raw shards, device pointer), replays the anchors through
+ *   annchor_stream_anchor_round and orders them itself -- one tile structure whatever the rank
+ *   count -- and owns a contiguous range of the global tile order.
  * annchor_stream_knn: k-NN rows of tiles [tile_begin, tile_begin+tile_count) against all
  *   column tiles (DEVICE pointers, concatenated over ranks); get_ann-shaped HOST outputs
  *   (annchor/annchor.py:514-530): column 0 = self.  Two phases: the budgeted tile phase
@@ -302,7 +305,9 @@ int annchor_stream_query(annchor_ctx *ctx, const void *Xs_all, const void *rs_al
                          const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors, int32_t dim_padded,
                          int32_t nn, double p_work, int64_t *out_idx, double *out_dist, int64_t *tile_evals);
 /* Interval tables after a rank-major all-gather ([world][n_anchors][n_tiles], device) joined along
- * the tile axis ([n_anchors][world * n_tiles], device): the layout the column arguments above use. */
+ * the tile axis ([n_anchors][world * n_tiles], device): the layout the column arguments above use.
+ * (For hosts that order every shard on its own rank and all-gather the ordered shards; the bundled
+ * host no longer does -- see annchor_stream_order.) */
 int annchor_stream_join_tables(annchor_ctx *ctx, const void *gathered, int32_t world, int32_t n_anchors, int32_t n_tiles,
                                void *joined);
 /* Raw device copies for hosts that stage the all-gather through host memory. */
