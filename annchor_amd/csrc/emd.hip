@@ -65,6 +65,28 @@ __device__ __forceinline__ double wave_min_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
+// Minimum of NON-NEGATIVE doubles (+inf allowed): they order like their bit patterns, so the high words are
+// reduced first and the low words among the lanes that hold the minimal high word -- twelve 32-bit DPP minimum
+// steps instead of six 64-bit ones made of two moves and a v_min_f64 each (the kernel is issue bound and this
+// reduction runs once per Dijkstra pop).
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x140, 0xf, 0xf, false));  // row_mirror
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1,3
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2,3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ double wave_min_nonneg_f64(double v)
+{
+    const uint32_t hi = (uint32_t)__double2hiint(v), lo = (uint32_t)__double2loint(v);
+    const uint32_t mh = wave_min_u32(hi);
+    const uint32_t ml = wave_min_u32(hi == mh ? lo : 0xffffffffu);
+    return __hiloint2double((int)mh, (int)ml);
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int lane)
 {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -175,7 +197,9 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
                 if (--guard < 0) { failed = true; break; }
                 // ---- Dijkstra from source s on reduced costs
                 const double us = readlane_f64(u, s);
-                double dist = lane < m ? costL[rs * nb + mycol] - us - v : INFINITY;
+                // (reduced costs are >= 0 up to rounding: clamped, so that the tentative distances are non-negative
+                // doubles -- the invariant the wave minimum below relies on)
+                double dist = lane < m ? fmax(costL[rs * nb + mycol] - us - v, 0.0) : INFINITY;
                 int pred = s;
                 unsigned long long sinkdone = 0, srcdone = 1ull << s;
                 double srcdist = 0.0;   // valid on lanes whose srcdone bit is set
@@ -184,7 +208,7 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
                 double mu = 0.0;
                 for (;;) {
                     const bool open = lane < m && !((sinkdone >> lane) & 1ull);
-                    const double best = wave_min_f64(open ? dist : INFINITY);
+                    const double best = wave_min_nonneg_f64(open ? dist : INFINITY);
                     const unsigned long long hit = __ballot(open && dist == best);
                     if (!hit) break;                       // every sink scanned: only rounding dust left
                     const int js = __ffsll((unsigned long long)hit) - 1;  // first index on ties
@@ -202,7 +226,7 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
                         const int ri = __builtin_amdgcn_readlane(myrow, i);
                         const double ui = readlane_f64(u, i);
                         if (lane < m && !((sinkdone >> lane) & 1ull)) {
-                            const double nd = mu + (costL[ri * nb + mycol] - ui - v);
+                            const double nd = fmax(mu + (costL[ri * nb + mycol] - ui - v), 0.0);
                             if (nd < dist) { dist = nd; pred = i; }
                         }
                     }
