@@ -71,6 +71,7 @@ _SIGNATURES = {
     "annchor_set_labels": (ctypes.c_int, [_vp, _vp]),
     "annchor_select_candidates": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i64, _i32,
                                                  ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "annchor_select_prepare": (ctypes.c_int, [_vp, _i32, _i32]),
     "annchor_mark_candidates": (ctypes.c_int, [_vp]),
     "annchor_refine_candidates": (ctypes.c_int, [_vp]),
     "annchor_set_refined": (ctypes.c_int, [_vp, _vp, _i64]),
@@ -485,6 +486,10 @@ class Engine:
                                                      len(errs_list), int(n_refine), int(lookahead),
                                                      ctypes.byref(nc), ctypes.byref(nn)))
         return nc.value, nn.value
+
+    def select_prepare(self, n_neighbors, nmin):
+        """Thresholds + guarantee_nmin of the next select_candidates, launched ahead (no host wait)."""
+        self._chk(self.lib.annchor_select_prepare(self.h, int(n_neighbors), int(nmin)))
 
     def mark_candidates(self):
         self._chk(self.lib.annchor_mark_candidates(self.h))

@@ -141,7 +141,7 @@ class Annchor:
         self._cosine_streamed = False
         self._anchors_on_device = False
         self._first_merge = True
-        self._sample_ticket, self._pipelined = None, False
+        self._sample_ticket, self._pipelined, self._fit_it = None, False, None
         Xa = X if isinstance(X, np.ndarray) else None
         bundled = self.f is distances_euclidean or self.f is distances_cosine
         defaults = (anchor_picker is None and sampler is None and regression is None and error_predictor is None
@@ -199,7 +199,7 @@ class Annchor:
         self._anchors_on_device = False
         self._cache = {}
         self._first_merge = True
-        self._sample_ticket, self._pipelined = None, False
+        self._sample_ticket, self._pipelined, self._fit_it = None, False, None
         self.timings = {}
 
     # ------------------------------------------------------------ metric boundary
@@ -366,6 +366,11 @@ class Annchor:
     def fit_predict_errors(self):
         """annchor.py:382-393."""
         self._pair_list_stage("fit_predict_errors")
+        if self._pipelined and self._fit_it is not None:
+            # inside fit(): the row thresholds and guarantee_nmin of the coming selection depend on RefineApprox and
+            # the mask only -- launch them now, they run while the error model is fitted on the host
+            nn = self.n_neighbors
+            self._engine.select_prepare(nn, 3 * nn // 2 if self._fit_it == 0 else 0)
         self.error_predictor.fit(self.sample_features, self.feature_names, self.sample_y - self.sample_predict,
                                  sample_bins=self.sample_bins)
         if not self._fused_labels:
@@ -460,7 +465,9 @@ class Annchor:
                 print("Warning: main loop terminated early with nothing " + "left to sample.")
                 break
             stage("fit_predict_regression", self.fit_predict_regression)
+            self._fit_it = it
             stage("fit_predict_errors", self.fit_predict_errors)
+            self._fit_it = None
             stage("select_refine_candidate_pairs", self.select_refine_candidate_pairs, w=1 / niters, it=it)
             if it < niters - 1:
                 stage("update_anchor_points", self.update_anchor_points)

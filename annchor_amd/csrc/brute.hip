@@ -80,7 +80,7 @@ extern "C" int annchor_brute_force(annchor_ctx *c, int32_t k, int64_t *ng_idx, d
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     ANN_TRY(ann_reserve(c, c->ij, sizeof(int2) * (size_t)n));
     ANN_TRY(ann_reserve(c, c->RA, sizeof(double) * (size_t)n));
-    c->n = 0; c->have_bitmap = false; c->have_features = c->have_RA = false;  // the pair-list state of a previous fit is gone
+    c->n = 0; c->have_bitmap = false; c->have_features = c->have_RA = false; c->sel_prepared = false;  // the pair-list state of a previous fit is gone
     const size_t cells = (size_t)nx * k;
     ANN_TRY(ann_reserve(c, c->stage_out, cells * 16));
     int64_t *d_i = c->stage_out.as<int64_t>();

@@ -97,6 +97,12 @@ struct annchor_ctx {
     bool cand_marked = false;      // not_computed_mask already cleared for the current candidates
     DevBuf gl_val, gl_pos, gl_cnt, gl_ncomp, marked, markcount;  // guarantee_nmin scratch
     DevBuf gn_state;             // guarantee_nmin rounds: mark masks (2), out-of-list mark counts (3), change flags
+    // selection stage split in two (annchor_select_prepare): thresholds + guarantee_nmin launched ahead, while the host
+    // fits the error model; reset by everything that changes RefineApprox / the mask
+    bool sel_prepared = false;
+    int sel_k = 0, sel_nmin = 0;
+    bool gn_pending = false;     // rounds launched, convergence not yet looked at
+    int gn_round = 0, gn_L = 0;
     DevBuf sel_hist, sel_state, blk_cnt, blk_off;                // radix select / compaction scratch
     DevBuf tie_lists, tie_hist;                                  // scrambled positions of the pairs on the two probability cuts; their histogram
     const void *tie_hist_clean = nullptr;                        // tie_hist known to be zero at this address

@@ -383,7 +383,7 @@ static void reset_pipeline(annchor_ctx *c)
 {
     c->na = c->nA = 0;
     c->n = 0; c->have_bitmap = false;
-    c->have_features = c->have_RA = false;
+    c->have_features = c->have_RA = false; c->sel_prepared = false;
     c->nsamp = c->ncand = c->nnext = 0;
 }
 

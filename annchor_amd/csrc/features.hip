@@ -198,9 +198,9 @@ extern "C" int annchor_compute_features(annchor_ctx *c)
     c->call_timed = true;
     ANN_CHECK_HIP(c, hipGetLastError());
     c->have_features = true;
-    c->have_RA = false;
+    c->have_RA = false; c->sel_prepared = false;
     c->nsamp = 0;
-    c->n_unc = -1;
+    c->n_unc = -1; c->sel_prepared = false;
     return ANNCHOR_OK;
 }
 
@@ -776,7 +776,7 @@ extern "C" int annchor_evaluate_samples(annchor_ctx *c, const int64_t *pos, int6
     ANN_TRY(upload_positions(c, pos, m, c->spos));
     ANN_TRY(ann_reserve(c, c->sy, sizeof(double) * (size_t)m));
     c->nsamp = m;
-    c->n_unc = -1;   // recount lazily: a custom sampler may hand back already-computed or repeated pairs
+    c->n_unc = -1; c->sel_prepared = false;   // recount lazily: a custom sampler may hand back already-computed or repeated pairs
     if (m == 0) return ANNCHOR_OK;
     PairSource src;
     src.ij = c->ij.as<int2>();
@@ -855,6 +855,7 @@ extern "C" int annchor_sample_pairs(annchor_ctx *c, const double *bins, int32_t 
     }
     ANN_REQUIRE(c, !h_bad, ANNCHOR_ESTATE, "sample_pairs: a (bin, rank) entry does not exist (stale counts?)");
     if (c->n_unc >= 0) c->n_unc -= nreq;
+    c->sel_prepared = false;
     return ANNCHOR_OK;
 }
 
@@ -915,6 +916,7 @@ extern "C" int annchor_hash_sample_pairs(annchor_ctx *c, const double *bins, int
         ANN_TRY(ann_d2h(c, sample_y, st_y, sizeof(double) * (size_t)m));
     }
     if (c->n_unc >= 0) c->n_unc -= m;
+    c->sel_prepared = false;
     return ANNCHOR_OK;
 }
 
@@ -927,7 +929,7 @@ extern "C" int annchor_set_samples(annchor_ctx *c, const int64_t *pos, int64_t m
     ANN_TRY(ann_reserve(c, c->sy, sizeof(double) * (size_t)m));
     ANN_TRY(ann_h2d(c, c->sy.p, sample_y, sizeof(double) * (size_t)m));
     c->nsamp = m;
-    c->n_unc = -1;
+    c->n_unc = -1; c->sel_prepared = false;
     if (m > 0) k_clear_flags<<<ann_blocks(m, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), m, c->ncm.as<uint8_t>());
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
@@ -1023,7 +1025,7 @@ extern "C" int annchor_predict_merge(annchor_ctx *c, const double *bins, int32_t
     }
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;
-    c->have_RA = true;
+    c->have_RA = true; c->sel_prepared = false;
     if (c->nsamp > 0) {
         ANN_TRY(ann_reserve(c, c->stage_out, sizeof(double) * (size_t)c->nsamp));
         k_sample_predict_scatter<<<ann_blocks(c->nsamp, 256), 256, 0, c->stream>>>(
@@ -1077,7 +1079,7 @@ extern "C" int annchor_merge_host_prediction(annchor_ctx *c, const double *pred,
         k_scatter_f64<<<ann_blocks(c->nsamp, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), c->sy.as<double>(), c->nsamp,
                                                                        c->RA.as<double>());
     ANN_CHECK_HIP(c, hipGetLastError());
-    c->have_RA = true;
+    c->have_RA = true; c->sel_prepared = false;
     return ANNCHOR_OK;
 }
 

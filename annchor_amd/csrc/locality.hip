@@ -299,7 +299,7 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
     ANN_CHECK_HIP(c, hipGetLastError());
     c->n = n;
     c->have_bitmap = true;
-    c->have_features = c->have_RA = false;
+    c->have_features = c->have_RA = false; c->sel_prepared = false;
     *n_pairs = n;
     *min_row_len = mn;
     return ANNCHOR_OK;
@@ -401,7 +401,7 @@ extern "C" int annchor_build_query_locality(annchor_ctx *c, int64_t nx_base, int
     ANN_CHECK_HIP(c, hipGetLastError());
     c->n = n;
     c->have_bitmap = false;   // query form: rows are contiguous already, no bitmap
-    c->have_features = c->have_RA = false;
+    c->have_features = c->have_RA = false; c->sel_prepared = false;
     *n_pairs = n;
     *min_row_len = mn;
     return ANNCHOR_OK;

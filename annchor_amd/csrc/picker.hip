@@ -116,7 +116,7 @@ static int begin_anchors(annchor_ctx *c, int32_t na)
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     c->na = na;
     c->n = 0; c->have_bitmap = false;
-    c->have_features = c->have_RA = false;
+    c->have_features = c->have_RA = false; c->sel_prepared = false;
     ANN_TRY(ann_reserve(c, c->Dt, sizeof(double) * (size_t)na * (size_t)c->nx));
     ANN_TRY(ann_reserve(c, c->A, sizeof(int32_t) * (size_t)(na + 1)));
     return ANNCHOR_OK;

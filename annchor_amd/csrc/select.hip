@@ -1121,18 +1121,14 @@ __global__ __launch_bounds__(CP_THREADS) void k_cut_emit(const double *__restric
     }
 }
 
-extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, int32_t nmin, const double *errs,
-                                         const int64_t *err_ptr, int32_t nlabels, int64_t n_refine, int32_t lookahead,
-                                         int64_t *n_cand, int64_t *n_next)
+#define GN_BATCH 8   // guarantee_nmin rounds between two looks at the "changed" flags
+
+// Stage A of the selection: row thresholds and guarantee_nmin (lists, first batch of rounds) -- functions of
+// RefineApprox and the mask only, launched without a host wait.
+static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
 {
-    if (!c || !errs || !err_ptr || !n_cand || !n_next) return ANNCHOR_EINVAL;
-    ANN_REQUIRE(c, c->have_RA, ANNCHOR_EINVAL, "RefineApprox not initialised");
-    ANN_REQUIRE(c, nlabels >= 1 && nlabels <= 255, ANNCHOR_ELIMIT, "1..255 error labels supported");
-    ANN_REQUIRE(c, n_neighbors >= 1 && lookahead >= 1 && n_refine >= 0, ANNCHOR_EINVAL, "bad selection parameters");
-    for (int b = 0; b < nlabels; ++b)
-        ANN_REQUIRE(c, err_ptr[b + 1] > err_ptr[b], ANNCHOR_ESTATE, "error bin %d has no samples", b);
-    ANN_CHECK_HIP(c, hipSetDevice(c->device));
     const int64_t n = c->n, nx = c->nx;
+    c->gn_pending = false;
     ANN_TRY(ann_reserve(c, c->thresh, sizeof(double) * (size_t)nx));
     ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
     RowSrc rsrc;
@@ -1179,30 +1175,23 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
                                                                      c->gl_cnt.as<int32_t>(), twin);
             const int Lw = (L + 31) / 32;
             const size_t mask_bytes = sizeof(uint32_t) * (size_t)nx * Lw, mout_bytes = sizeof(int32_t) * (size_t)nx;
-            constexpr int GN_BATCH = 8;    // rounds between two looks at the "changed" flags
+
             ANN_TRY(ann_reserve(c, c->gn_state, 2 * mask_bytes + 3 * mout_bytes + sizeof(int32_t) * GN_BATCH));
             uint32_t *masks[2] = {c->gn_state.as<uint32_t>(), c->gn_state.as<uint32_t>() + (size_t)nx * Lw};
             int32_t *mout[3];
             for (int q = 0; q < 3; ++q) mout[q] = reinterpret_cast<int32_t *>(c->gn_state.as<char>() + 2 * mask_bytes + q * mout_bytes);
             int32_t *changed = reinterpret_cast<int32_t *>(c->gn_state.as<char>() + 2 * mask_bytes + 3 * mout_bytes);
             ANN_CHECK_HIP(c, hipMemsetAsync(c->gn_state.p, 0, 2 * mask_bytes + 3 * mout_bytes, c->stream));
+            // first batch of rounds now; whether they settled is looked at in select_stage_finish (the host may do other
+            // work in between: annchor_select_prepare)
+            ANN_CHECK_HIP(c, hipMemsetAsync(changed, 0, sizeof(int32_t) * GN_BATCH, c->stream));
             int round = 0;
-            bool done = false;
-            while (!done) {
-                ANN_CHECK_HIP(c, hipMemsetAsync(changed, 0, sizeof(int32_t) * GN_BATCH, c->stream));
-                for (int q = 0; q < GN_BATCH; ++q, ++round)
-                    k_gn_round<<<ann_blocks(nx * 64, 256), 256, 0, c->stream>>>(
-                        nx, nmin, L, Lw, c->gl_val.as<double>(), oth, twin, c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
-                        masks[round & 1], masks[(round + 1) & 1], mout[round % 3], mout[(round + 1) % 3], mout[(round + 2) % 3],
-                        changed + q, c->tmp2.as<int32_t>() + 8);
-                int32_t h_changed[GN_BATCH];
-                ANN_TRY(ann_d2h(c, h_changed, changed, sizeof h_changed));
-                // a round without a change: its input (and output) is the fixed point, and so is everything after it
-                done = h_changed[GN_BATCH - 1] == 0;
-                ANN_REQUIRE(c, round <= (int)nx + GN_BATCH, ANNCHOR_EHIP, "guarantee_nmin rounds did not settle");
-            }
-            k_gn_apply<<<ann_blocks(nx * L, 256), 256, 0, c->stream>>>(nx, L, Lw, c->gl_pos.as<int32_t>(), c->gl_cnt.as<int32_t>(),
-                                                                      masks[round & 1], c->RA.as<double>());
+            for (int q = 0; q < GN_BATCH; ++q, ++round)
+                k_gn_round<<<ann_blocks(nx * 64, 256), 256, 0, c->stream>>>(
+                    nx, nmin, L, Lw, c->gl_val.as<double>(), oth, twin, c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
+                    masks[round & 1], masks[(round + 1) & 1], mout[round % 3], mout[(round + 1) % 3], mout[(round + 2) % 3],
+                    changed + q, c->tmp2.as<int32_t>() + 8);
+            c->gn_pending = true; c->gn_round = round; c->gn_L = L;
         } else if (L <= GN_LMAX && ring_lds <= 156 * 1024) {
             ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 21.0);
             int32_t *oth = c->gl_pos.as<int32_t>() + (size_t)nx * L, *twin = oth + (size_t)nx * L;
@@ -1232,6 +1221,71 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
                                                     c->tmp2.as<int32_t>() + 8);
         }
     }
+    return ANNCHOR_OK;
+}
+
+// The rounds launched by stage A: read their flags, run further batches until one settles, apply the marks.
+static int select_stage_finish(annchor_ctx *c)
+{
+    if (!c->gn_pending) return ANNCHOR_OK;
+    const int64_t nx = c->nx;
+    const int L = c->gn_L, Lw = (L + 31) / 32, nmin = L - 1;
+    const size_t mask_bytes = sizeof(uint32_t) * (size_t)nx * Lw, mout_bytes = sizeof(int32_t) * (size_t)nx;
+    uint32_t *masks[2] = {c->gn_state.as<uint32_t>(), c->gn_state.as<uint32_t>() + (size_t)nx * Lw};
+    int32_t *mout[3];
+    for (int q = 0; q < 3; ++q) mout[q] = reinterpret_cast<int32_t *>(c->gn_state.as<char>() + 2 * mask_bytes + q * mout_bytes);
+    int32_t *changed = reinterpret_cast<int32_t *>(c->gn_state.as<char>() + 2 * mask_bytes + 3 * mout_bytes);
+    int32_t *oth = c->gl_pos.as<int32_t>() + (size_t)nx * L, *twin = oth + (size_t)nx * L;
+    int round = c->gn_round;
+    for (;;) {
+        int32_t h_changed[GN_BATCH];
+        ANN_TRY(ann_d2h(c, h_changed, changed, sizeof h_changed));
+        // a round without a change: its input (and output) is the fixed point, and so is everything after it
+        if (h_changed[GN_BATCH - 1] == 0) break;
+        ANN_REQUIRE(c, round <= (int)nx + GN_BATCH, ANNCHOR_EHIP, "guarantee_nmin rounds did not settle");
+        ANN_CHECK_HIP(c, hipMemsetAsync(changed, 0, sizeof(int32_t) * GN_BATCH, c->stream));
+        for (int q = 0; q < GN_BATCH; ++q, ++round)
+            k_gn_round<<<ann_blocks(nx * 64, 256), 256, 0, c->stream>>>(
+                nx, nmin, L, Lw, c->gl_val.as<double>(), oth, twin, c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
+                masks[round & 1], masks[(round + 1) & 1], mout[round % 3], mout[(round + 1) % 3], mout[(round + 2) % 3],
+                changed + q, c->tmp2.as<int32_t>() + 8);
+    }
+    k_gn_apply<<<ann_blocks(nx * L, 256), 256, 0, c->stream>>>(nx, L, Lw, c->gl_pos.as<int32_t>(), c->gl_cnt.as<int32_t>(),
+                                                              masks[round & 1], c->RA.as<double>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    c->gn_pending = false;
+    return ANNCHOR_OK;
+}
+
+// Thresholds and guarantee_nmin ahead of annchor_select_candidates (same n_neighbors / nmin): the caller fits its
+// error model on the host while they run.  Anything that changes RefineApprox or the mask in between voids it.
+extern "C" int annchor_select_prepare(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
+{
+    if (!c) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_RA, ANNCHOR_EINVAL, "RefineApprox not initialised");
+    ANN_REQUIRE(c, n_neighbors >= 1 && nmin >= 0, ANNCHOR_EINVAL, "bad selection parameters");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(select_stage_a(c, n_neighbors, nmin));
+    c->sel_prepared = true; c->sel_k = n_neighbors; c->sel_nmin = nmin;
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, int32_t nmin, const double *errs,
+                                         const int64_t *err_ptr, int32_t nlabels, int64_t n_refine, int32_t lookahead,
+                                         int64_t *n_cand, int64_t *n_next)
+{
+    if (!c || !errs || !err_ptr || !n_cand || !n_next) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_RA, ANNCHOR_EINVAL, "RefineApprox not initialised");
+    ANN_REQUIRE(c, nlabels >= 1 && nlabels <= 255, ANNCHOR_ELIMIT, "1..255 error labels supported");
+    ANN_REQUIRE(c, n_neighbors >= 1 && lookahead >= 1 && n_refine >= 0, ANNCHOR_EINVAL, "bad selection parameters");
+    for (int b = 0; b < nlabels; ++b)
+        ANN_REQUIRE(c, err_ptr[b + 1] > err_ptr[b], ANNCHOR_ESTATE, "error bin %d has no samples", b);
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    const int64_t n = c->n, nx = c->nx;
+    if (!(c->sel_prepared && c->sel_k == n_neighbors && c->sel_nmin == nmin)) ANN_TRY(select_stage_a(c, n_neighbors, nmin));
+    c->sel_prepared = false;
+    ANN_TRY(select_stage_finish(c));
+    (void)nx;
     // ---- probabilities
     const int64_t nerr = err_ptr[nlabels];
     ANN_TRY(ann_reserve(c, c->errs, sizeof(double) * (size_t)nerr));
@@ -1387,7 +1441,7 @@ extern "C" int annchor_mark_candidates(annchor_ctx *c)
     k_mark_candidates<<<ann_blocks(c->ncand, 256), 256, 0, c->stream>>>(c->cand.as<int32_t>(), c->ncand, c->ncm.as<uint8_t>());
     ANN_CHECK_HIP(c, hipGetLastError());
     if (c->n_unc >= 0) c->n_unc -= c->ncand;
-    c->cand_marked = true;
+    c->cand_marked = true; c->sel_prepared = false;
     return ANNCHOR_OK;
 }
 
@@ -1408,7 +1462,7 @@ extern "C" int annchor_refine_candidates(annchor_ctx *c)
     c->call_timed = true;
     ANN_CHECK_HIP(c, hipGetLastError());
     if (c->n_unc >= 0 && !c->cand_marked) c->n_unc -= c->ncand;
-    c->cand_marked = true;
+    c->cand_marked = true; c->sel_prepared = false;
     return ANNCHOR_OK;
 }
 
@@ -1433,6 +1487,6 @@ extern "C" int annchor_set_refined(annchor_ctx *c, const double *exact, int64_t 
                                                                    c->RA.as<double>(), c->ncm.as<uint8_t>());
     ANN_CHECK_HIP(c, hipGetLastError());
     if (c->n_unc >= 0 && !c->cand_marked) c->n_unc -= n_cand;
-    c->cand_marked = true;
+    c->cand_marked = true; c->sel_prepared = false;
     return ANNCHOR_OK;
 }

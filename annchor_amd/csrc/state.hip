@@ -130,12 +130,12 @@ extern "C" int annchor_upload(annchor_ctx *c, int32_t field, const void *src, in
         return ANNCHOR_OK;
     case ANNCHOR_F_NCM:
         ANN_REQUIRE(c, n_elems == n, ANNCHOR_EINVAL, "ncm: expected %lld elements", (long long)n);
-        c->n_unc = -1;
+        c->n_unc = -1; c->sel_prepared = false;
         return ann_h2d(c, c->ncm.p, src, (size_t)n);
     case ANNCHOR_F_RA:
         ANN_REQUIRE(c, n_elems == n, ANNCHOR_EINVAL, "RA: expected %lld elements", (long long)n);
         ANN_TRY(ann_h2d(c, c->RA.p, src, 8 * (size_t)n));
-        c->have_RA = true;
+        c->have_RA = true; c->sel_prepared = false;
         return ANNCHOR_OK;
     default: ann_set_err(c, "field %d is not uploadable", field); return ANNCHOR_EINVAL;
     }

@@ -212,6 +212,12 @@ int annchor_set_labels(annchor_ctx *ctx, const int64_t *labels);
 int annchor_select_candidates(annchor_ctx *ctx, int32_t n_neighbors, int32_t nmin, const double *errs,
                               const int64_t *err_ptr, int32_t nlabels, int64_t n_refine,
                               int32_t lookahead, int64_t *n_cand, int64_t *n_next);
+/* The part of annchor_select_candidates that depends on RefineApprox and the mask only -- row thresholds
+ * (annchor.py:399-404) and guarantee_nmin (utils.py:600-621) -- launched ahead, without a host wait: the caller
+ * fits its error model (error_predictors.py:26-53, host) while it runs, then calls annchor_select_candidates
+ * with the same n_neighbors / nmin, which picks up from there.  Any call that changes RefineApprox or the mask
+ * in between voids the preparation (the selection then starts from the beginning). */
+int annchor_select_prepare(annchor_ctx *ctx, int32_t n_neighbors, int32_t nmin);
 /* Clear not_computed_mask for the selected candidates ahead of their refinement
  * (annchor.py:473 does it after the metric calls).  Lets the next iteration's sampling
  * statistics (which depend on the mask and dad only, samplers.py:119-140) be taken, and the
