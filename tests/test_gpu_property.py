@@ -112,3 +112,44 @@ def test_guarantee_nmin_rounds_equal_the_sequential_sweep(monkeypatch):
                          ann.not_computed_mask.copy())
         for a, b in zip(out["rounds"], out["sequential"]):
             assert np.array_equal(a, b)
+
+
+def test_select_prepare_is_equivalent_and_voided_by_state_changes():
+    """annchor_select_prepare (thresholds + guarantee_nmin launched ahead of the selection) must not change the
+    result: used as fit() uses it, with mismatching parameters (ignored), and followed by a call that rewrites
+    RefineApprox (voided) -- all equal to the plain staged run."""
+    from annchor_amd import Annchor
+
+    from annchor_amd.datasets import load_strings
+
+    Xs = np.array(load_strings()["X"][::4])
+    cfg = dict(n_anchors=9, n_neighbors=12, n_samples=800, p_work=0.25, random_seed=7, niters=2)
+
+    def run(mode):
+        ann = Annchor(Xs, "levenshtein", **cfg)
+        ann.get_anchors(); ann.get_locality(); ann.get_features()
+        for it in range(ann.niters):
+            ann.get_sample()
+            ann.fit_predict_regression()
+            nn = ann.n_neighbors
+            nmin = 3 * nn // 2 if it == 0 else 0
+            if mode == "prepared":
+                ann._engine.select_prepare(nn, nmin)
+            elif mode == "mismatch":
+                ann._engine.select_prepare(nn + 1, 0)
+            elif mode == "voided":
+                ann._engine.select_prepare(nn, nmin)
+                ann._first_merge = it == 0           # rewrite RefineApprox: the preparation no longer applies
+                ann.fit_predict_regression()
+            ann.fit_predict_errors()
+            ann.select_refine_candidate_pairs(w=1 / ann.niters, it=it)
+            if it < ann.niters - 1:
+                ann.update_anchor_points()
+        ann.get_ann()
+        return ann.neighbor_graph[0].copy(), ann.neighbor_graph[1].copy(), ann.evals, ann.RefineApprox.copy()
+
+    ref = run("plain")
+    for mode in ("prepared", "mismatch", "voided"):
+        got = run(mode)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), mode
