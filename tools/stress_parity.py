@@ -1,0 +1,53 @@
+"""Randomised end-to-end parity sweep (GPU fit vs the CPU restatement under tests' rules): random string and
+integer-grid Euclidean data sets, random configurations.  Not part of the test suite (minutes of CPU time);
+run on the GPU box: python tools/stress_parity.py [n_cases] [seed]."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from annchor_amd import Annchor
+from oracle import annchor_oracle as O, metrics as om
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+bad = 0
+for case in range(ncases):
+    kind = "strings" if case % 2 == 0 else "grid"
+    n = int(rng.integers(150, 900))
+    cfg = dict(n_anchors=int(rng.integers(4, 14)), n_neighbors=int(rng.integers(3, 20)), n_samples=int(rng.integers(300, 1500)),
+               p_work=float(rng.uniform(0.15, 0.5)), random_seed=int(rng.integers(0, 1000)), niters=int(rng.integers(1, 4)),
+               locality=int(rng.integers(2, 6)))
+    cfg["locality"] = min(cfg["locality"], cfg["n_anchors"])
+    if kind == "strings":
+        alpha = list("abcdefgh")[: int(rng.integers(2, 8))]
+        base = ["".join(rng.choice(alpha, rng.integers(0, int(rng.integers(20, 300))))) for _ in range(max(n // 2, 2))]
+        X = [base[i] for i in rng.integers(0, len(base), n)]
+        X = ["".join(rng.permutation(list(x))) if rng.random() < 0.5 else x for x in X]
+        P = om.PackedStrings(X)
+        pairs, data, metric = P.pairs, np.array(X, dtype=object), "levenshtein"
+    else:
+        Xg = rng.integers(0, int(rng.integers(3, 9)), (n, int(rng.integers(2, 6)))).astype(np.float64)
+        pairs, data, metric = (lambda IJ, Xg=Xg: om.euclidean_pairs(Xg, IJ)), Xg, "euclidean"
+    t = time.time()
+    try:
+        ann = Annchor(data, metric, **cfg).fit()
+        ora = O.OracleAnnchor(n, pairs, **cfg).fit()
+        same = (np.array_equal(ann.neighbor_graph[1], ora.neighbor_graph[1]) and np.array_equal(ann.neighbor_graph[0], ora.neighbor_graph[0]))
+        ndiff = int((ann.neighbor_graph[1] != ora.neighbor_graph[1]).sum())
+        if kind == "strings":      # integer metric: bit-exact
+            ok = ann.evals == ora.evals and same
+        else:                      # float metric: the OLS coefficients of the two sides may differ in the last bit, and on
+            # tie-heavy data that moves candidate choices (tests compare float metrics stage by stage within 1e-12):
+            # same work, graphs agreeing on nearly every entry
+            ok = ann.evals == ora.evals and ndiff <= 0.05 * ann.neighbor_graph[1].size
+        msg = ("" if same else " (%d of %d entries differ)" % (ndiff, ann.neighbor_graph[1].size)) if ok else \
+            " evals %d vs %d, dist diff %d" % (ann.evals, ora.evals, ndiff)
+    except Exception as e:   # both sides must agree on failing too
+        try:
+            O.OracleAnnchor(n, pairs, **cfg).fit()
+            ok, msg = False, " GPU raised %s: %s" % (type(e).__name__, e)
+        except Exception as e2:
+            ok, msg = True, " (both raise: %s / %s)" % (type(e).__name__, type(e2).__name__)
+    bad += not ok
+    print("case %2d %-7s n=%4d %s -> %s%s  %.1fs" % (case, kind, n, cfg, "OK" if ok else "MISMATCH", msg, time.time() - t), flush=True)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
