@@ -93,6 +93,17 @@ _SIGNATURES = {
     "annchor_stream_query": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _dbl, _vp, _vp,
                                             ctypes.POINTER(_i64)]),
     "annchor_stream_join_tables": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "annchor_stream_hip_stream": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "annchor_stream_anchor_begin": (ctypes.c_int, [_vp, _i32, _i64, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
+    "annchor_stream_anchor_step": (ctypes.c_int, [_vp, _vp, _i32, _i32]),
+    "annchor_stream_anchor_end": (ctypes.c_int, [_vp, _vp, _vp]),
+    "annchor_stream_rows_begin": (ctypes.c_int, [_vp, _i32, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
+    "annchor_stream_rows_end": (ctypes.c_int, [_vp, _i32, _vp]),
+    "annchor_stream_lists_all": (ctypes.c_int, [_vp, _i32, _i64, ctypes.POINTER(_vp)]),
+    "annchor_stream_route_begin": (ctypes.c_int, [_vp, _i32, _vp, _vp, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "annchor_stream_route_recv": (ctypes.c_int, [_vp, _i64, ctypes.POINTER(_vp)]),
+    "annchor_stream_route_end": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "annchor_stream_graph_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64), ctypes.POINTER(_i32)]),
     "annchor_device_alloc": (ctypes.c_int, [_vp, _i64, ctypes.POINTER(_vp)]),
     "annchor_device_free": (ctypes.c_int, [_vp, _vp]),
     "annchor_device_copy": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32]),
@@ -584,6 +595,74 @@ class Engine:
         self._chk(self.lib.annchor_stream_knn_end(self.h, _ptr(row_ids) if row_ids is not None else None, _ptr(idx), _ptr(dist),
                                                   ctypes.byref(ev)))
         return row_ids, idx, dist, ev.value
+
+    # ---- row-sharded builds: device-resident exchange buffers (include/annchor_hip.h, csrc/sharded.hip)
+    def hip_stream(self):
+        """The context's hipStream_t (an integer address): collectives are ordered on it."""
+        p = _vp()
+        self._chk(self.lib.annchor_stream_hip_stream(self.h, ctypes.byref(p)))
+        return p.value or 0
+
+    def stream_anchor_begin(self, n_anchors, first_global, world=1):
+        """(candidate pointer, gathered pointer, bytes per candidate): this rank's candidate record for the first anchor
+        and the all-gather target of the rounds (device memory)."""
+        p, g, nb = _vp(), _vp(), _i64()
+        self._chk(self.lib.annchor_stream_anchor_begin(self.h, int(n_anchors), int(first_global), int(world), ctypes.byref(p), ctypes.byref(g),
+                                                       ctypes.byref(nb)))
+        return p.value, g.value, nb.value
+
+    def stream_anchor_step(self, gathered, world, rnd):
+        self._chk(self.lib.annchor_stream_anchor_step(self.h, gathered, int(world), int(rnd)))
+
+    def stream_anchor_end(self, n_anchors):
+        A = np.empty(int(n_anchors), dtype=np.int64)
+        V = np.empty((int(n_anchors), self._stream_dim), dtype=np.float32)
+        self._chk(self.lib.annchor_stream_anchor_end(self.h, _ptr(A), _ptr(V)))
+        return A, V
+
+    def stream_rows_begin(self, counts):
+        counts = _c(counts, np.int64)
+        s, r, nb = _vp(), _vp(), _i64()
+        self._chk(self.lib.annchor_stream_rows_begin(self.h, len(counts), _ptr(counts), ctypes.byref(s), ctypes.byref(r), ctypes.byref(nb)))
+        return s.value, r.value, nb.value
+
+    def stream_rows_end(self, counts):
+        counts = _c(counts, np.int64)
+        self._chk(self.lib.annchor_stream_rows_end(self.h, len(counts), _ptr(counts)))
+        self.nx = int(counts.sum())
+
+    def stream_lists_all(self, world, bytes_per_rank):
+        p = _vp()
+        self._chk(self.lib.annchor_stream_lists_all(self.h, int(world), int(bytes_per_rank), ctypes.byref(p)))
+        return p.value
+
+    def stream_route_begin(self, starts, bases):
+        """Finish the build begun with stream_knn_begin; (send pointer, records per destination rank, int64 words per
+        record, tile evaluations)."""
+        starts, bases = _c(starts, np.int64), _c(bases, np.int64)
+        world = len(bases)
+        send, words, ev = _vp(), _i64(), _i64()
+        counts = np.zeros(world, dtype=np.int64)
+        self._chk(self.lib.annchor_stream_route_begin(self.h, world, _ptr(starts), _ptr(bases), ctypes.byref(send), _ptr(counts),
+                                                      ctypes.byref(words), ctypes.byref(ev)))
+        return send.value, counts, words.value, ev.value
+
+    def stream_route_recv(self, n_recv):
+        p = _vp()
+        self._chk(self.lib.annchor_stream_route_recv(self.h, int(n_recv), ctypes.byref(p)))
+        return p.value
+
+    def stream_route_end(self, n_recv, rows_padded, n_own, k):
+        idx = np.empty((int(n_own), int(k)), dtype=np.int64)
+        dist = np.empty((int(n_own), int(k)), dtype=np.float64)
+        self._chk(self.lib.annchor_stream_route_end(self.h, int(n_recv), int(rows_padded), _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def stream_graph_device(self):
+        """(idx pointer, dist pointer, rows_padded, k) of the graph rows stream_route_end left on the device."""
+        pi, pd, rows, k = _vp(), _vp(), _i64(), _i32()
+        self._chk(self.lib.annchor_stream_graph_device(self.h, ctypes.byref(pi), ctypes.byref(pd), ctypes.byref(rows), ctypes.byref(k)))
+        return pi.value, pd.value, rows.value, k.value
 
     def stream_query(self, cols, n_all, nt_all, n_anchors, dim_padded, nn, p_work):
         """nn nearest data rows of every (bound + ordered) query row; cols = the data set's column arrays."""

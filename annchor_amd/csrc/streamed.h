@@ -1,0 +1,111 @@
+// streamed.h -- state and argument blocks shared by streamed.hip (tile kernels, ordering) and
+// sharded.hip (the device-resident multi-rank protocol around them).
+#pragma once
+#include "common.h"
+
+#define ST_T 128
+#define ST_SLAB 32
+#define ST_THREADS 256
+#define ST_KMAX 32
+#define ST_SURV 1024
+#define ST_KEEP 512
+#define ST_EARLY_WINDOW 64   // tiles per yield window of the tile phase (knn_tile_phase)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifdef ST_PROFILE
+#define ST_PROF_DECL long long pf_t = clock64(); long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define ST_PROF(i) { const long long pf_n = clock64(); pf[i] += pf_n - pf_t; pf_t = pf_n; }
+#else
+#define ST_PROF_DECL
+#define ST_PROF(i)
+#endif
+
+// LDS hand-over between lanes of ONE wavefront (a wave's LDS instructions execute in order)
+__device__ __forceinline__ void wave_fence_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+struct StreamState {
+    // local shard (this context's rows), all device memory owned by the context
+    DevBuf X;        // float [n_local][dim]      (copy of the caller's rows)
+    DevBuf keys, keys2, vals, vals2, cubtmp;
+    DevBuf Xs;       // float [n_pad][dimp]       rows in tile order, zero padded
+    DevBuf rs;       // float [n_pad]             squared norms (+inf on padding rows)
+    DevBuf perm;     // int64 [n_pad]             global id of each ordered row (-1 padding)
+    DevBuf lo, hi, mid;  // float [na][nt]        per-tile anchor-distance intervals and means
+    DevBuf avec;     // float [dimp]              current anchor vector
+    DevBuf runmin, red_val, red_idx;
+    DevBuf D;        // float [na][n_local]       distances to anchors (f32)
+    DevBuf Dt;       // float [n_local][na padded to 4]  the same, point-major (ordering gathers)
+    DevBuf out_d2, out_col;
+    DevBuf emit_idx, emit_dist;   // int64 / double [n_local][k]: graph rows in shard order
+    DevBuf scr_key, scr_lb;   // float [tile_count][nt_all]: per-row-tile rank keys / bounds of all column tiles
+    DevBuf evals;
+    DevBuf eval_bits;         // uint32 [tile_count][ceil(nt_all / 32)]: column tiles the tile phase evaluated, per row tile
+    DevBuf out_d2b, out_colb; // second list buffers: a join pass reads the old lists of ALL rows and writes new ones
+    DevBuf ucand, ucount;     // uint32 [tile_count][JN_CAP] / int32 [tile_count]: join candidates per row tile
+    DevBuf rev_cnt, rev_ptr, rev_edges, rev;   // reverse neighbour lists of every ordered row (join passes)
+    int64_t n_local = 0, n_pad = 0, base = 0;
+    int64_t last_tile_evals = 0, last_join_chunks = 0;
+    int dim = 0, dimp = 0, na = 0, nt = 0;
+    struct KnnArgs *run = nullptr;   // arguments of the graph build in progress (begin / join / end)
+    const void *run_perm = nullptr;
+    int run_dimp = 0;
+    // ---- device-resident multi-rank protocol (sharded.hip)
+    DevBuf cand_all;   // double [world][2 + dim]: all-gather target of the candidates
+    DevBuf cand;       // double [2 + dim]: this rank's arg-max candidate of a max-min round (value, global row, its coordinates)
+    DevBuf avecs;      // float [na][dim]: the anchors' coordinates (every rank holds all of them)
+    DevBuf A_dev;      // int64 [na]: global row ids of the anchors
+    DevBuf rows_send, rows_recv, rows_all;   // raw-row exchange: padded shard, [world][most][dim], compacted [n_total][dim]
+    DevBuf lists_all;  // int32 [n_all][K]: every rank's neighbour lists (all-gather target of the join passes)
+    DevBuf route_tab, route_cnt, route_slot, route_send, route_recv;   // finished rows on their way to their owners
+    int64_t own_base = 0, own_n = 0;   // the shard this context was bound to before it took every rank's rows
+    int64_t emit_rows = 0;             // rows of emit_idx / emit_dist (own_n padded to the largest shard)
+    int emit_k = 0;
+};
+
+struct KnnArgs {
+    const float *Xs;      // [n_all][DIM]   all column tiles (every rank's ordered shard, concatenated)
+    const float *rs;      // [n_all]
+    const float *lo, *hi, *mid; // [na][nt_all]
+    int nt_all, na;
+    // row tiles: the same arrays for the k-NN graph; a separate (query) set for annchor_stream_query
+    const float *Rs, *rr, *rlo, *rhi, *rmid;
+    int nt_r;             // tile count of the row tables (stride of rlo / rhi / rmid)
+    int query;            // 1: rows are queries -- no self tile, no self exclusion
+    int tile_begin;       // first row tile of this launch inside the row tile numbering
+    int tile_count;
+    int K;                // neighbours kept per row, self excluded
+    int max_tiles;        // column-tile budget per row tile
+    float *out_d2;        // [tile_count*128][K]
+    int32_t *out_col;     // [tile_count*128][K]   global ordered column index
+    float *scr_key, *scr_lb;   // [tile_count][nt_all] per-row-tile rank keys / valid bounds of every column tile
+    unsigned long long *evals;
+    unsigned long long *prof;   // ST_PROFILE builds only: per-phase cycle sums (8 counters)
+    uint32_t *eval_bits;  // [tile_count][eval_words] evaluated column tiles per row tile (NULL: not recorded)
+    int eval_words;
+    // join passes (k_st_join_cands / k_st_join)
+    const int32_t *lists_all;   // [n_all][K] current neighbour lists of EVERY ordered row (all ranks)
+    const uint32_t *ucand;      // [tile_count][ucap] sorted candidate columns per row tile, 0xffffffff padded to 128
+    const int32_t *ucount;      // [tile_count]
+    int ucap;
+    float *out_d2_new;          // [tile_count*128][K] lists after the pass
+    int32_t *out_col_new;
+    unsigned long long *updates; // list insertions of the pass (its yield: the host stops when it dries up)
+    int early_window, early_tau; // tile phase: stop a row tile when early_window consecutive tiles made < early_tau insertions (0: never)
+};
+
+StreamState *ann_stream_state(annchor_ctx *c, bool create);
+int ann_stream_reserve(annchor_ctx *c, DevBuf &b, size_t bytes);   // individual allocation, grow-only, contents NOT kept
+int ann_stream_padded_dim(int dim);
+// exact float32 distances of the kept neighbours, final order, ids: *d_idx_out int64 [rows][K], *d_dist_out float [rows][K]
+int ann_stream_knn_finish(annchor_ctx *c, StreamState *s, KnnArgs &a, const void *perm_all, int dim_padded, int64_t **d_idx_out,
+                          float **d_dist_out, int64_t *tile_evals);
+void ann_stream_free_run(StreamState *s);
+// distances of all bound rows to avec_dev (device, float [dim]) -> D[round][.], running minimum (reset for rounds 0 and 1),
+// per-workgroup arg-max partials in red_val / red_idx; returns their count.  No host wait.
+int ann_stream_sweep(annchor_ctx *c, StreamState *s, const float *avec_dev, int round, int *n_partials);

@@ -27,64 +27,9 @@
 // floats: bank-conflict-free operand reads), accumulators are compared against per-row
 // thresholds in LDS and only the survivors are inserted into the per-row lists.
 
-#include "common.h"
-
-#define ST_T 128
-#define ST_SLAB 32
-#define ST_THREADS 256
-#define ST_KMAX 32
-#define ST_SURV 1024
-#define ST_KEEP 512
-#define ST_EARLY_WINDOW 64   // tiles per yield window of the tile phase (knn_tile_phase)
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#ifdef ST_PROFILE
-#define ST_PROF_DECL long long pf_t = clock64(); long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define ST_PROF(i) { const long long pf_n = clock64(); pf[i] += pf_n - pf_t; pf_t = pf_n; }
-#else
-#define ST_PROF_DECL
-#define ST_PROF(i)
-#endif
-
-// LDS hand-over between lanes of ONE wavefront (a wave's LDS instructions execute in order)
-__device__ __forceinline__ void wave_fence_lds()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-struct StreamState {
-    // local shard (this context's rows), all device memory owned by the context
-    DevBuf X;        // float [n_local][dim]      (copy of the caller's rows)
-    DevBuf keys, keys2, vals, vals2, cubtmp;
-    DevBuf Xs;       // float [n_pad][dimp]       rows in tile order, zero padded
-    DevBuf rs;       // float [n_pad]             squared norms (+inf on padding rows)
-    DevBuf perm;     // int64 [n_pad]             global id of each ordered row (-1 padding)
-    DevBuf lo, hi, mid;  // float [na][nt]        per-tile anchor-distance intervals and means
-    DevBuf avec;     // float [dimp]              current anchor vector
-    DevBuf runmin, red_val, red_idx;
-    DevBuf D;        // float [na][n_local]       distances to anchors (f32)
-    DevBuf Dt;       // float [n_local][na padded to 4]  the same, point-major (ordering gathers)
-    DevBuf out_d2, out_col;
-    DevBuf emit_idx, emit_dist;   // int64 / double [n_local][k]: graph rows in shard order
-    DevBuf scr_key, scr_lb;   // float [tile_count][nt_all]: per-row-tile rank keys / bounds of all column tiles
-    DevBuf evals;
-    DevBuf eval_bits;         // uint32 [tile_count][ceil(nt_all / 32)]: column tiles the tile phase evaluated, per row tile
-    DevBuf out_d2b, out_colb; // second list buffers: a join pass reads the old lists of ALL rows and writes new ones
-    DevBuf ucand, ucount;     // uint32 [tile_count][JN_CAP] / int32 [tile_count]: join candidates per row tile
-    DevBuf rev_cnt, rev_ptr, rev_edges, rev;   // reverse neighbour lists of every ordered row (join passes)
-    int64_t n_local = 0, n_pad = 0, base = 0;
-    int64_t last_tile_evals = 0, last_join_chunks = 0;
-    int dim = 0, dimp = 0, na = 0, nt = 0;
-    struct KnnArgs *run = nullptr;   // arguments of the graph build in progress (begin / join / end)
-    const void *run_perm = nullptr;
-    int run_dimp = 0;
-};
+#include "streamed.h"
 
 static std::vector<std::pair<annchor_ctx *, StreamState *>> g_states;
-static void ann_stream_free_run(StreamState *s);
 
 static StreamState *state_of(annchor_ctx *c, bool create)
 {
@@ -104,7 +49,9 @@ void ann_stream_release(annchor_ctx *c)
             DevBuf *bufs[] = {&s->X, &s->keys, &s->keys2, &s->vals, &s->vals2, &s->cubtmp, &s->Xs, &s->rs, &s->perm, &s->lo,
                               &s->hi, &s->mid, &s->avec, &s->runmin, &s->red_val, &s->red_idx, &s->D, &s->out_d2, &s->out_col, &s->evals,
                               &s->scr_key, &s->scr_lb, &s->emit_idx, &s->emit_dist, &s->Dt, &s->eval_bits, &s->out_d2b, &s->out_colb,
-                              &s->ucand, &s->ucount, &s->rev_cnt, &s->rev_ptr, &s->rev_edges, &s->rev};
+                              &s->ucand, &s->ucount, &s->rev_cnt, &s->rev_ptr, &s->rev_edges, &s->rev, &s->cand, &s->cand_all, &s->avecs, &s->A_dev,
+                              &s->rows_send, &s->rows_recv, &s->rows_all, &s->lists_all, &s->route_tab, &s->route_cnt, &s->route_slot,
+                              &s->route_send, &s->route_recv};
             for (DevBuf *b : bufs)
                 if (b->p && !b->in_arena) (void)hipFree(b->p);
             ann_stream_free_run(s);
@@ -128,6 +75,9 @@ static int sreserve(annchor_ctx *c, DevBuf &b, size_t bytes)
 }
 
 static int padded_dim(int dim) { return dim <= 32 ? 32 : dim <= 64 ? 64 : dim <= 128 ? 128 : dim <= 256 ? 256 : -1; }
+StreamState *ann_stream_state(annchor_ctx *c, bool create) { return state_of(c, create); }
+int ann_stream_reserve(annchor_ctx *c, DevBuf &b, size_t bytes) { return sreserve(c, b, bytes); }
+int ann_stream_padded_dim(int dim) { return padded_dim(dim); }
 
 // ------------------------------------------------------------------ bind
 extern "C" int annchor_stream_bind(annchor_ctx *c, const float *X, int64_t n_local, int32_t dim, int64_t global_base,
@@ -208,6 +158,24 @@ __global__ __launch_bounds__(256) void k_st_runmin_argmax(const float *__restric
 // One max-min round on the local shard (pickers.py:44-50): distances of all local rows to
 // `anchor_vec`, running-min update (reset for rounds 0 and 1, as the reference's D[1:]
 // quirk demands) and the local arg-max (value, local index; first index on ties).
+int ann_stream_sweep(annchor_ctx *c, StreamState *s, const float *avec_dev, int round, int *n_partials)
+{
+    const int64_t n = s->n_local;
+    const int rblocks = (int)std::min<int64_t>(1024, (n + 1023) / 1024);
+    ANN_TRY(sreserve(c, s->red_val, sizeof(float) * 1024));
+    ANN_TRY(sreserve(c, s->red_idx, sizeof(int64_t) * 1024));
+    float *row = s->D.as<float>() + (size_t)round * n;
+    {
+        ProfScope ps(c, "stream_anchor_one_to_all", (double)n * (s->dim * 4.0 + 4.0));
+        k_st_one_to_all<<<ann_blocks(n * 16, 256), 256, 0, c->stream>>>(s->X.as<float>(), n, s->dim, avec_dev, row);
+    }
+    k_st_runmin_argmax<<<rblocks, 256, 0, c->stream>>>(row, s->runmin.as<float>(), n, round <= 1 ? 1 : 0, s->red_val.as<float>(),
+                                                      s->red_idx.as<int64_t>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    *n_partials = rblocks;
+    return ANNCHOR_OK;
+}
+
 extern "C" int annchor_stream_anchor_round(annchor_ctx *c, const float *anchor_vec, int32_t round, int32_t n_anchors,
                                            double *local_max, int64_t *local_arg)
 {
@@ -220,19 +188,9 @@ extern "C" int annchor_stream_anchor_round(annchor_ctx *c, const float *anchor_v
         s->na = n_anchors;
         ANN_TRY(sreserve(c, s->D, sizeof(float) * (size_t)n_anchors * (size_t)s->n_local));
     }
-    const int64_t n = s->n_local;
-    int rblocks = (int)std::min<int64_t>(1024, (n + 1023) / 1024);
-    ANN_TRY(sreserve(c, s->red_val, sizeof(float) * 1024));
-    ANN_TRY(sreserve(c, s->red_idx, sizeof(int64_t) * 1024));
     ANN_CHECK_HIP(c, hipMemcpyAsync(s->avec.p, anchor_vec, sizeof(float) * (size_t)s->dim, hipMemcpyHostToDevice, c->stream));
-    float *row = s->D.as<float>() + (size_t)round * n;
-    {
-        ProfScope ps(c, "stream_anchor_one_to_all", (double)n * (s->dim * 4.0 + 4.0));
-        k_st_one_to_all<<<ann_blocks(n * 16, 256), 256, 0, c->stream>>>(s->X.as<float>(), n, s->dim, s->avec.as<float>(), row);
-    }
-    k_st_runmin_argmax<<<rblocks, 256, 0, c->stream>>>(row, s->runmin.as<float>(), n, round <= 1 ? 1 : 0, s->red_val.as<float>(),
-                                                      s->red_idx.as<int64_t>());
-    ANN_CHECK_HIP(c, hipGetLastError());
+    int rblocks = 0;
+    ANN_TRY(ann_stream_sweep(c, s, s->avec.as<float>(), round, &rblocks));
     std::vector<float> hv((size_t)rblocks);
     std::vector<int64_t> hi((size_t)rblocks);
     ANN_TRY(ann_d2h(c, hv.data(), s->red_val.p, sizeof(float) * (size_t)rblocks));
@@ -591,36 +549,6 @@ extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs
 }
 
 // ------------------------------------------------------------------ k-NN
-struct KnnArgs {
-    const float *Xs;      // [n_all][DIM]   all column tiles (every rank's ordered shard, concatenated)
-    const float *rs;      // [n_all]
-    const float *lo, *hi, *mid; // [na][nt_all]
-    int nt_all, na;
-    // row tiles: the same arrays for the k-NN graph; a separate (query) set for annchor_stream_query
-    const float *Rs, *rr, *rlo, *rhi, *rmid;
-    int nt_r;             // tile count of the row tables (stride of rlo / rhi / rmid)
-    int query;            // 1: rows are queries -- no self tile, no self exclusion
-    int tile_begin;       // first row tile of this launch inside the row tile numbering
-    int tile_count;
-    int K;                // neighbours kept per row, self excluded
-    int max_tiles;        // column-tile budget per row tile
-    float *out_d2;        // [tile_count*128][K]
-    int32_t *out_col;     // [tile_count*128][K]   global ordered column index
-    float *scr_key, *scr_lb;   // [tile_count][nt_all] per-row-tile rank keys / valid bounds of every column tile
-    unsigned long long *evals;
-    unsigned long long *prof;   // ST_PROFILE builds only: per-phase cycle sums (8 counters)
-    uint32_t *eval_bits;  // [tile_count][eval_words] evaluated column tiles per row tile (NULL: not recorded)
-    int eval_words;
-    // join passes (k_st_join_cands / k_st_join)
-    const int32_t *lists_all;   // [n_all][K] current neighbour lists of EVERY ordered row (all ranks)
-    const uint32_t *ucand;      // [tile_count][ucap] sorted candidate columns per row tile, 0xffffffff padded to 128
-    const int32_t *ucount;      // [tile_count]
-    int ucap;
-    float *out_d2_new;          // [tile_count*128][K] lists after the pass
-    int32_t *out_col_new;
-    unsigned long long *updates; // list insertions of the pass (its yield: the host stops when it dries up)
-    int early_window, early_tau; // tile phase: stop a row tile when early_window consecutive tiles made < early_tau insertions (0: never)
-};
 
 template <int DIM, int KMAX> struct KnnShared {
     float Bs[ST_SLAB][DIM + 1];
@@ -1564,7 +1492,7 @@ extern "C" int annchor_stream_budget(int32_t n_tiles, double p_work, int32_t joi
     return ANNCHOR_OK;
 }
 
-static void ann_stream_free_run(StreamState *s)
+void ann_stream_free_run(StreamState *s)
 {
     delete s->run;
     s->run = nullptr;
@@ -1699,8 +1627,8 @@ static int knn_join_pass(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pad
     return ANNCHOR_OK;
 }
 
-static int knn_finish(annchor_ctx *c, StreamState *s, KnnArgs &a, const void *perm_all, int dim_padded, int64_t **d_idx_out,
-                      float **d_dist_out, int64_t *tile_evals)
+int ann_stream_knn_finish(annchor_ctx *c, StreamState *s, KnnArgs &a, const void *perm_all, int dim_padded, int64_t **d_idx_out,
+                          float **d_dist_out, int64_t *tile_evals)
 {
     const int K = a.K;
     const int64_t rows = (int64_t)a.tile_count * ST_T;
@@ -1825,7 +1753,7 @@ extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void
     }
     int64_t *d_idx = nullptr;
     float *d_dist = nullptr;
-    ANN_TRY(knn_finish(c, s, a, perm_all, dim_padded, &d_idx, &d_dist, tile_evals));
+    ANN_TRY(ann_stream_knn_finish(c, s, a, perm_all, dim_padded, &d_idx, &d_dist, tile_evals));
     return knn_download_graph(c, s, a, perm_all, d_idx, d_dist, row_ids, ng_idx, ng_dist);
 }
 
@@ -1876,7 +1804,7 @@ extern "C" int annchor_stream_knn_end(annchor_ctx *c, int64_t *row_ids, int64_t 
     ANN_REQUIRE(c, s && s->run, ANNCHOR_ESTATE, "annchor_stream_knn_begin not called");
     int64_t *d_idx = nullptr;
     float *d_dist = nullptr;
-    int rc = knn_finish(c, s, *s->run, s->run_perm, s->run_dimp, &d_idx, &d_dist, tile_evals);
+    int rc = ann_stream_knn_finish(c, s, *s->run, s->run_perm, s->run_dimp, &d_idx, &d_dist, tile_evals);
     if (rc == ANNCHOR_OK) rc = knn_download_graph(c, s, *s->run, s->run_perm, d_idx, d_dist, row_ids, ng_idx, ng_dist);
     ann_stream_free_run(s);
     return rc;
@@ -1911,7 +1839,7 @@ extern "C" int annchor_stream_query(annchor_ctx *c, const void *Xs_all, const vo
     int T = 0, tp = 0, pp = 0;
     ANN_TRY(annchor_stream_budget(nt_all, p_work, 0, &T, &tp, &pp));
     ANN_TRY(knn_tile_phase(c, s, a, dim_padded, tp, false));
-    ANN_TRY(knn_finish(c, s, a, perm_all, dim_padded, &d_idx, &d_dist, tile_evals));
+    ANN_TRY(ann_stream_knn_finish(c, s, a, perm_all, dim_padded, &d_idx, &d_dist, tile_evals));
     const int64_t rows = (int64_t)s->nt * ST_T, nq = s->n_local;
     ANN_TRY(sreserve(c, s->emit_idx, sizeof(int64_t) * (size_t)nq * nn));
     ANN_TRY(sreserve(c, s->emit_dist, sizeof(double) * (size_t)nq * nn));

@@ -33,140 +33,116 @@ JOIN_YIELD = 0.01   # extra join passes run while a pass still replaces more tha
 
 
 # ----------------------------------------------------------------------- comms
-# Everything that crosses ranks on the fit path is a numeric buffer: 16 bytes per rank and anchor round
-# (value, index) with the anchor's coordinates, the raw rows, the neighbour lists (device buffers), the
-# finished graph rows.  No pickled objects.
+# Everything that crosses ranks on the fit path is a numeric buffer in DEVICE memory owned by the engine (the
+# arg-max candidates of a max-min round, the raw rows, the neighbour lists, the finished graph rows as records):
+# the comm adapters below receive device pointers.  With an `nccl` process group (RCCL over xGMI) the pointers are
+# wrapped as tensors and the collective runs on the engine's own stream -- no host staging, no host wait; any other
+# backend (gloo: CPU tests, single-GPU rehearsals) runs the SAME collective calls on host copies of the buffers.
+# No pickled objects anywhere.
 class SingleComm:
     rank, world = 0, 1
+    backend = "none"
 
-    def allgather_f64(self, values):
+    def allgather_small(self, values):
         return np.asarray(values, dtype=np.float64)[None, :]
 
-    def allgather_device(self, engine, dptr, nbytes):
-        return dptr, None
+    def allgather_into(self, engine, src, dst, nbytes):
+        engine.device_copy(dst, src, nbytes, "d2d")
 
-    def allgather_host(self, arr):
-        return [arr]
-
-    def allgather_rows(self, X, counts):
-        return "host", X, None
-
-    def exchange_rows(self, dest, arrays):
-        return [np.ascontiguousarray(a) for a in arrays]
+    def alltoall_records(self, engine, send, send_counts, words):
+        n = int(send_counts[0])
+        recv = engine.stream_route_recv(n)
+        if n:
+            engine.device_copy(recv, send, n * words * 8, "d2d")
+        return recv, n
 
 
 class TorchComm:
-    """torch.distributed adapter.  `nccl` groups (RCCL over xGMI) move device buffers directly;
-    any other backend stages through host memory."""
+    """torch.distributed adapter over device pointers.  `nccl` groups (RCCL over xGMI) move the engine's buffers
+    directly, ordered on the engine's stream; any other backend stages through host memory around the same calls."""
+
+    SMALL = 64   # doubles per rank in a control-plane exchange
 
     def __init__(self, group=None):
+        import torch
         import torch.distributed as dist
 
-        self.dist, self.group = dist, group
+        self.torch, self.dist, self.group = torch, dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.backend = dist.get_backend(group)
+        self.on_device = self.backend == "nccl"
+        dev = "cuda" if self.on_device else "cpu"
+        # control plane (shard extents, the join passes' yield, all-to-all counts): preallocated, a few numbers
+        self._small_in = torch.zeros(self.SMALL, dtype=torch.float64, device=dev)
+        self._small_out = torch.zeros(self.SMALL * self.world, dtype=torch.float64, device=dev)
+        self._streams = {}
 
-    def _dev(self):
-        return "cuda" if self.backend == "nccl" else "cpu"
+    # -- plumbing
+    def _stream(self, engine):
+        """Context manager: torch's current stream = the engine's stream (nccl), nothing otherwise."""
+        import contextlib
 
-    def allgather_f64(self, values):
-        """[world, len(values)] float64: every rank's small vector (arg-max candidates, shard extents)."""
-        import torch
+        if not self.on_device:
+            return contextlib.nullcontext()
+        key = (engine.device, engine.hip_stream())
+        if key not in self._streams:
+            self._streams[key] = self.torch.cuda.ExternalStream(key[1], device=self.torch.device("cuda", engine.device))
+        return self.torch.cuda.stream(self._streams[key])
 
-        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self._dev())
-        parts = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(parts, t, group=self.group)
-        return torch.stack(parts).cpu().numpy()
-
-    def allgather_device(self, engine, dptr, nbytes):
-        """All-gather `nbytes` bytes at device pointer `dptr` from every rank; returns the
-        device pointer of the rank-ordered concatenation (+ an owner object to keep alive)."""
-        import torch
-
-        if self.backend == "nccl":
-            inp = device_tensor_u8(dptr, nbytes, engine.device)
-            out = torch.empty(self.world * nbytes, dtype=torch.uint8, device=inp.device)
-            engine.synchronize()                       # the engine's stream produced the buffer
-            self.dist.all_gather_into_tensor(out, inp, group=self.group)
-            torch.cuda.synchronize(inp.device)
-            return out.data_ptr(), out
+    def _tensor_in(self, engine, ptr, nbytes):
+        """uint8 tensor holding `nbytes` bytes at device pointer `ptr`: a view (nccl) or a host copy."""
+        if nbytes == 0:
+            return self.torch.empty(0, dtype=self.torch.uint8, device="cuda" if self.on_device else "cpu")
+        if self.on_device:
+            return device_tensor_u8(ptr, nbytes, engine.device)
         host = np.empty(nbytes, dtype=np.uint8)
-        engine.device_copy(host.ctypes.data, dptr, nbytes, "d2h")
-        parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
-        self.dist.all_gather(parts, torch.from_numpy(host), group=self.group)
-        allh = torch.cat(parts).numpy()
-        out = engine.device_alloc(allh.nbytes)
-        engine.device_copy(out, allh.ctypes.data, allh.nbytes, "h2d")
-        return out, _DeviceOwner(engine, out)
+        engine.device_copy(host.ctypes.data, ptr, nbytes, "d2h")
+        return self.torch.from_numpy(host)
 
-    def allgather_host(self, arr):
-        """Every rank's equally shaped NumPy array, as a list in rank order (tensor all-gather; the
-        arrays ride through device memory when the group is `nccl`)."""
-        import torch
+    def _tensor_out(self, engine, ptr, nbytes):
+        if nbytes == 0 or not self.on_device:
+            return self.torch.empty(nbytes, dtype=self.torch.uint8, device="cuda" if self.on_device else "cpu")
+        return device_tensor_u8(ptr, nbytes, engine.device)
 
-        t = torch.from_numpy(np.ascontiguousarray(arr)).to(self._dev())
-        parts = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(parts, t, group=self.group)
-        return [p.cpu().numpy() for p in parts]
+    def _commit(self, engine, tensor, ptr):
+        """Host-staged backends: write the collective's output back to device memory."""
+        if not self.on_device and tensor.numel():
+            host = np.ascontiguousarray(tensor.numpy())
+            engine.device_copy(ptr, host.ctypes.data, host.nbytes, "h2d")
 
+    # -- control plane
+    def allgather_small(self, values):
+        """[world, len(values)] float64: every rank's few numbers."""
+        v = np.asarray(values, dtype=np.float64).reshape(-1)
+        assert v.size <= self.SMALL
+        self._small_in[:v.size].copy_(self.torch.from_numpy(v))
+        self.dist.all_gather_into_tensor(self._small_out, self._small_in, group=self.group)
+        return self._small_out.view(self.world, self.SMALL)[:, :v.size].cpu().numpy().copy()
 
-    def allgather_rows(self, X, counts):
-        """Every rank's rows (float32 [counts[r], dim]) concatenated in rank order, on every rank:
-        ("device", pointer, owner tensor) when the group is `nccl`, ("host", array, None) otherwise."""
-        import torch
+    # -- data plane
+    def allgather_into(self, engine, src, dst, nbytes):
+        """Every rank's `nbytes` bytes at `src`, concatenated in rank order at `dst` (device pointers)."""
+        with self._stream(engine):
+            inp = self._tensor_in(engine, src, nbytes)
+            out = self._tensor_out(engine, dst, nbytes * self.world)
+            self.dist.all_gather_into_tensor(out, inp, group=self.group)
+            self._commit(engine, out, dst)
 
-        most, dim = int(max(counts)), X.shape[1]
-        pad = X if X.shape[0] == most else np.concatenate([X, np.zeros((most - X.shape[0], dim), dtype=X.dtype)])
-        if self.backend == "nccl":
-            t = torch.from_numpy(np.ascontiguousarray(pad)).to("cuda")
-            out = torch.empty((self.world * most, dim), dtype=t.dtype, device=t.device)
-            self.dist.all_gather_into_tensor(out, t, group=self.group)
-            if any(int(c) != most for c in counts):
-                out = torch.cat([out[r * most:r * most + int(counts[r])] for r in range(self.world)])
-            torch.cuda.synchronize(out.device)
-            return "device", out.data_ptr(), out
-        parts = [torch.empty((most, dim), dtype=torch.float32) for _ in range(self.world)]
-        self.dist.all_gather(parts, torch.from_numpy(np.ascontiguousarray(pad)), group=self.group)
-        return "host", np.concatenate([parts[r][:int(counts[r])].numpy() for r in range(self.world)]), None
-
-    def exchange_rows(self, dest, arrays):
-        """Row r of every array goes to rank dest[r]; returns the rows this rank receives (source-rank order).
-        `nccl`: all_to_all_single with split sizes on device tensors; other backends have no all-to-all:
-        padded all-gather, every rank keeps its slice."""
-        import torch
-
-        order = np.argsort(dest, kind="stable")
-        send = np.bincount(dest, minlength=self.world).astype(np.int64)
-        C = self.allgather_f64(send).astype(np.int64)          # C[src, dst]
-        recv = C[:, self.rank]
-        out = []
-        if self.backend == "nccl":
-            for a in arrays:
-                t = torch.from_numpy(np.ascontiguousarray(a[order])).to("cuda")
-                r = torch.empty((int(recv.sum()),) + tuple(a.shape[1:]), dtype=t.dtype, device=t.device)
-                self.dist.all_to_all_single(r, t, output_split_sizes=[int(v) for v in recv],
-                                            input_split_sizes=[int(v) for v in send], group=self.group)
-                out.append(r.cpu().numpy())
-            return out
-        most = int(C.sum(axis=1).max())
-        for a in arrays:
-            pad = np.zeros((most,) + tuple(a.shape[1:]), dtype=a.dtype)
-            pad[:len(order)] = a[order]
-            parts = self.allgather_host(pad)
-            out.append(np.concatenate([parts[src][int(C[src, :self.rank].sum()):int(C[src, :self.rank + 1].sum())]
-                                       for src in range(self.world)]))
-        return out
-
-
-class _DeviceOwner:
-    def __init__(self, engine, ptr):
-        self.engine, self.ptr = engine, ptr
-
-    def __del__(self):
-        try:
-            self.engine.device_free(self.ptr)
-        except Exception:
-            pass
+    def alltoall_records(self, engine, send, send_counts, words):
+        """Records (`words` int64 words each) grouped by destination rank at `send`: one all_to_all_single with split
+        sizes; returns (device pointer of the received records in source-rank order, their number)."""
+        torch = self.torch
+        C = self.allgather_small(send_counts).astype(np.int64)       # C[src, dst]
+        recv_counts = [int(v) for v in C[:, self.rank]]
+        n_send, n_recv = int(np.sum(send_counts)), int(sum(recv_counts))
+        recv = engine.stream_route_recv(n_recv)
+        with self._stream(engine):
+            inp = self._tensor_in(engine, send, n_send * words * 8).view(torch.int64).view(n_send, words)
+            out = self._tensor_out(engine, recv, n_recv * words * 8).view(torch.int64).view(n_recv, words)
+            self.dist.all_to_all_single(out, inp, output_split_sizes=recv_counts, input_split_sizes=[int(v) for v in send_counts],
+                                        group=self.group)
+            self._commit(engine, out.view(-1).view(torch.uint8), recv)
+        return recv, n_recv
 
 
 class _CAI:
@@ -223,9 +199,12 @@ class StreamedAnnchor:
         self._engine = engine
         self._engine.stream_bind(self.X, self.base)
         self.join_passes, self.join_extra = int(join_passes), int(join_extra)
-        ext = self.comm.allgather_f64((self.base, self.n_local))
+        ext = self.comm.allgather_small((self.base, self.n_local))
         self.shards = [(int(b), int(n)) for b, n in ext]
         self.n_total = int(sum(n for _, n in self.shards))
+        # position in the rank-ordered concatenation of the shards <-> global row id
+        self._starts = np.concatenate([[0], np.cumsum([n for _, n in self.shards])]).astype(np.int64)
+        self._bases = np.array([b for b, _ in self.shards], dtype=np.int64)
         # The budget is spent in whole 128 x 128 tile evaluations: below MIN_TILE_BUDGET of them per row
         # tile it is too coarse to mean anything, so p_work has a floor -- the same treatment the
         # reference gives a p_work too small for its anchors and samples (annchor.py:136-142)
@@ -248,36 +227,29 @@ class StreamedAnnchor:
         return _native.stream_budget(nt_all, self.p_work, self.join_passes)
 
     def get_anchors(self):
-        """Max-min rounds (pickers.py:18-52) over the sharded rows.  One collective per round: every
-        rank contributes its local arg-max (value, global index) TOGETHER with that row's coordinates
-        -- (2 + dim) doubles -- so that after the all-gather every rank knows the winner and already
-        holds the next anchor's vector (no separate broadcast from the owner)."""
+        """Max-min rounds (pickers.py:18-52) over the sharded rows.  Per round every rank leaves its local arg-max --
+        (value, global row, that row's coordinates): 2 + dim doubles -- in a device buffer; ONE all-gather; the engine then
+        picks the winner on the device (largest value, first index) and sweeps its rows with the winner's coordinates,
+        which the all-gather already delivered (no broadcast from the owner).  Nothing waits for the host until the
+        anchors are downloaded at the end."""
         eng, comm, na = self._engine, self.comm, self.n_anchors
         np.random.seed(self.random_seed)
-        ix = int(np.random.randint(self.n_total))  # identical on every rank
-        A = np.zeros(na, dtype=np.int64)
-        self.anchor_vectors = np.zeros((na, self.dim), dtype=np.float32)   # kept for query()
-
-        def exchange(value, index, local_row):
-            mine = np.empty(2 + self.dim, dtype=np.float64)
-            mine[0], mine[1] = value, index
-            mine[2:] = eng.stream_get_row(local_row) if local_row >= 0 else 0.0
-            G = comm.allgather_f64(mine)
-            win = combine_argmax([(G[r, 0], int(G[r, 1])) for r in range(G.shape[0]) if G[r, 1] >= 0])
-            r = [int(G[q, 1]) for q in range(G.shape[0])].index(win)
-            return win, G[r, 2:].astype(np.float32)
-
-        # the first anchor: only its owner has a candidate
-        mine = self.base <= ix < self.base + self.n_local
-        ix, vec = exchange(0.0, ix if mine else -1, ix - self.base if mine else -1)
+        ix = int(self._to_global(np.random.randint(self.n_total)))  # identical on every rank
+        sharded = comm.world > 1 or self.force_exchange
+        cand, gathered, nbytes = eng.stream_anchor_begin(na, ix, comm.world)
         for r in range(na):
-            A[r] = ix
-            self.anchor_vectors[r] = vec
-            lmax, larg = eng.stream_anchor_round(vec, r, na)
-            if r + 1 < na:
-                ix, vec = exchange(float(lmax), int(self.base + larg), int(larg))
-        self.A = A
+            if sharded:
+                comm.allgather_into(eng, cand, gathered, nbytes)
+                eng.stream_anchor_step(gathered, comm.world, r)
+            else:
+                eng.stream_anchor_step(cand, 1, r)
+        self.A, self.anchor_vectors = eng.stream_anchor_end(na)   # anchor_vectors: kept for query()
         self.evals += na * self.n_total
+
+    def _to_global(self, pos):
+        """Positions in the rank-ordered concatenation of the shards -> global row ids."""
+        r = np.searchsorted(self._starts, pos, side="right") - 1
+        return pos - self._starts[r] + self._bases[r]
 
     def fit(self):
         import time
@@ -287,21 +259,16 @@ class StreamedAnnchor:
         self.get_anchors()
         t1 = time.perf_counter()
         sharded = comm.world > 1 or self.force_exchange
+        counts = np.array([n for _, n in self.shards], dtype=np.int64)
         if sharded:
             # ONE tile structure for the whole data set, whatever the number of ranks: every rank gets all rows
-            # (one all-gather; it needs them as columns anyway), recomputes their anchor distances from the anchors
-            # it already knows (no collective: 32 streaming passes) and orders them itself; the ranks then own
-            # contiguous ranges of the GLOBAL tile order.  Ordering each shard separately (round 1) made a tile's
-            # cell G times larger -- recall at N = 400 000 fell from 0.990 (1 rank) to 0.968 (2) and 0.942 (4).
-            counts = [n for _, n in self.shards]
-            kind, Xall, owner = comm.allgather_rows(self.X, counts)
-            if kind == "device":
-                eng.stream_bind(None, 0, device_ptr=Xall, shape=(self.n_total, self.dim))
-            else:
-                eng.stream_bind(Xall, 0)
-            del owner, Xall
-            for r in range(self.n_anchors):
-                eng.stream_anchor_round(self.anchor_vectors[r], r, self.n_anchors)
+            # (one all-gather of the resident shards; it needs them as columns anyway), recomputes their anchor
+            # distances from the anchors it already knows (one pass, no collective) and orders them itself; the ranks
+            # then own contiguous ranges of the GLOBAL tile order.  Ordering each shard separately (round 1) made a
+            # tile's cell G times larger -- recall at N = 400 000 fell from 0.990 (1 rank) to 0.968 (2) and 0.942 (4).
+            send, recv, nbytes = eng.stream_rows_begin(counts)
+            comm.allgather_into(eng, send, recv, nbytes)
+            eng.stream_rows_end(counts)
             tiles_per_rank = -(-((self.n_total + TILE - 1) // TILE) // comm.world)
             ptrs, n_pad, nt, dimp = eng.stream_order(tiles_per_rank * comm.world)
             tile_begin, tile_count = comm.rank * tiles_per_rank, tiles_per_rank
@@ -311,52 +278,35 @@ class StreamedAnnchor:
         t2 = t3 = time.perf_counter()
         n_all, nt_all = n_pad, nt
         if not sharded:
-            row_ids, idx, dist, tile_evals = eng.stream_knn(ptrs, n_all, nt_all, self.n_anchors, dimp, 0, nt, self.n_neighbors,
-                                                            self.p_work, n_local=self.n_local, join_passes=self.join_passes,
-                                                            join_extra=self.join_extra)
+            _, idx, dist, tile_evals = eng.stream_knn(ptrs, n_all, nt_all, self.n_anchors, dimp, 0, nt, self.n_neighbors,
+                                                      self.p_work, n_local=self.n_local, join_passes=self.join_passes,
+                                                      join_extra=self.join_extra)
         else:
             # tile phase on the rank's own row tiles, then join passes against the all-gathered neighbour lists
             total, tile_budget, per_pass = self._budget(nt_all)
             lists, nbytes = eng.stream_knn_begin(ptrs, n_all, nt_all, self.n_anchors, dimp, tile_begin, tile_count,
                                                  self.n_neighbors, tile_budget)
+            lists_all = eng.stream_lists_all(comm.world, nbytes)
             floor_updates = JOIN_YIELD * n_all * (self.n_neighbors - 1)
             for p in range(self.join_passes + self.join_extra if tile_budget < nt_all else 0):
                 if p >= self.join_passes and tile_budget + (p + 1) * max(per_pass, 1) > total:
                     break      # the budget has no room for another pass
-                lists_all, owner = comm.allgather_device(eng, lists, nbytes)
+                comm.allgather_into(eng, lists, lists_all, nbytes)
                 lists, upd = eng.stream_knn_join(lists_all, max(per_pass, 1))
-                del owner
                 # every rank takes the same decision: the yield of the pass summed over ranks
-                if p + 1 >= self.join_passes and comm.allgather_f64((upd,)).sum() <= floor_updates:
+                if p + 1 >= self.join_passes and comm.allgather_small((upd,)).sum() <= floor_updates:
                     break
-            row_ids, idx, dist, tile_evals = eng.stream_knn_end()
-            # rows and neighbours are numbered by their position in the rank-ordered concatenation of the shards:
-            # back to global row ids, and every row back to the rank that owns it
-            starts = np.concatenate([[0], np.cumsum([n for _, n in self.shards])]).astype(np.int64)
-            bases = np.array([b for b, _ in self.shards], dtype=np.int64)
-
-            def to_global(pos):
-                r = np.searchsorted(starts, pos, side="right") - 1
-                return pos - starts[r] + bases[r]
-
-            real = row_ids >= 0
-            pos = row_ids[real]
-            dest = (np.searchsorted(starts, pos, side="right") - 1).astype(np.int64)
-            gid, gidx, gdist = comm.exchange_rows(dest, [to_global(pos), to_global(idx[real]), dist[real]])
-            row_ids, idx, dist = gid, gidx, gdist
+            # the finished rows -- this rank computed its range of the global tile order: rows of arbitrary shards -- go
+            # back to the ranks that own them: records bucketed by owner on the device, ONE all-to-all, scattered into the
+            # shard's own row order, downloaded once
+            send, send_counts, words, tile_evals = eng.stream_route_begin(self._starts, self._bases)
+            recv, n_recv = comm.alltoall_records(eng, send, send_counts, words)
+            idx, dist = eng.stream_route_end(n_recv, int(counts.max()), self.n_local, self.n_neighbors)
         t4 = time.perf_counter()
         # the ordered column arrays (every row of the data set) stay alive: query() runs against them
         self._columns = dict(ptrs=ptrs, n_all=n_all, nt_all=nt_all, dimp=dimp)
-        if row_ids is None:   # rows already in this shard's order (emitted on the device)
-            ng_idx, ng_dist = idx, dist
-        else:                 # tile order + global row ids: reorder on the host
-            real = row_ids >= 0
-            loc = row_ids[real] - self.base
-            k = self.n_neighbors
-            ng_idx = np.zeros((self.n_local, k), dtype=np.int64)
-            ng_dist = np.zeros((self.n_local, k), dtype=np.float64)
-            ng_idx[loc], ng_dist[loc] = idx[real], dist[real]
-        self.neighbor_graph = (ng_idx, ng_dist)
+        self._sharded = sharded
+        self.neighbor_graph = (idx, dist)
         self.tile_evals = int(tile_evals)
         self.evals += self.tile_evals * TILE * TILE
         self.n_tiles_total = nt_all
@@ -387,17 +337,29 @@ class StreamedAnnchor:
         finally:
             qe.close()
         self.evals += int(tile_evals) * TILE * TILE
+        if self._sharded:   # the columns are numbered by position in the rank-ordered concatenation of the shards
+            idx = self._to_global(idx)
         return idx, dist
 
     def gather_graph(self):
-        """Full graph (all shards, global row order) on every rank: the final neighbour-graph
-        gather -- two tensor all-gathers (indices, distances) of shards padded to the largest."""
+        """Full graph (all shards, global row order) on every rank: the final neighbour-graph gather -- two
+        all-gathers (indices, distances) of the shards' device-resident graph rows, padded to the largest shard."""
         k = self.n_neighbors
-        most = max(n for _, n in self.shards)
-        idx = np.full((most, k), -1, dtype=np.int64)
-        dist = np.full((most, k), np.inf, dtype=np.float64)
-        idx[:self.n_local], dist[:self.n_local] = self.neighbor_graph
-        all_idx, all_dist = self.comm.allgather_host(idx), self.comm.allgather_host(dist)
+        if not getattr(self, "_sharded", False):
+            return self.neighbor_graph
+        eng, comm = self._engine, self.comm
+        pi, pd, rows, kk = eng.stream_graph_device()
+        assert kk == k and rows == max(n for _, n in self.shards)
+        out = []
+        for ptr, dtype in ((pi, np.int64), (pd, np.float64)):
+            nbytes = rows * k * 8
+            dst = eng.device_alloc(nbytes * comm.world)
+            try:
+                comm.allgather_into(eng, ptr, dst, nbytes)
+                host = np.empty((comm.world, rows, k), dtype=dtype)
+                eng.device_copy(host.ctypes.data, dst, host.nbytes, "d2h")
+            finally:
+                eng.device_free(dst)
+            out.append(host)
         order = sorted(range(len(self.shards)), key=lambda r: self.shards[r][0])
-        return (np.concatenate([all_idx[r][:self.shards[r][1]] for r in order]),
-                np.concatenate([all_dist[r][:self.shards[r][1]] for r in order]))
+        return tuple(np.concatenate([a[r][:self.shards[r][1]] for r in order]) for a in out)

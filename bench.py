@@ -252,6 +252,27 @@ def cpu_baseline(X, cfg):
                 evals=int(ora.evals))
 
 
+def cpu_baseline_euclid(n, k=15, budget_s=15.0):
+    """CPU baseline for the Euclidean workload: the exact k-NN rows of a bounded sample of rows against all N columns
+    (what the reference's BruteForce does per row, annchor.py:1004-1023, here as blocked float32 NumPy/BLAS GEMMs +
+    argpartition on all cores), extrapolated to N rows.  The reference's Annchor.fit() cannot run this size at all
+    (its pair list alone is ~24 TB at N = 10^6)."""
+    X = euclid_shard(0, n)
+    sq = (X * X).sum(axis=1)
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and done < n:
+        R = X[done:done + 256]
+        d2 = sq[done:done + 256, None] + sq[None, :] - 2.0 * (R @ X.T)
+        part = np.argpartition(d2, k, axis=1)[:, :k]
+        np.take_along_axis(d2, part, axis=1).sort(axis=1)
+        done += len(R)
+    dt = time.perf_counter() - t0
+    rows_per_s = done / dt
+    return dict(value=rows_per_s / n, unit="graphs/s", rows_per_s=rows_per_s, cores=int(os.cpu_count()), kind="port",
+                sample="exact k-NN of %d rows against all %d columns in %.1f s (blocked f32 NumPy GEMM + argpartition), "
+                       "extrapolated to all rows" % (done, n, dt))
+
+
 def strings_run(args, steps, warmup, world, rank, local, dist, torch, all_cpus, affinity):
     """BASELINE configs[1] (the metric's quoted configuration) on every rank; rank 0 returns the line."""
     from annchor_amd import Annchor, compare_neighbor_graphs
@@ -511,6 +532,12 @@ def main():
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank flow)")
     ap.add_argument("--no-numa-bind", action="store_true", help="do not bind the process to the CPUs of the GPU's NUMA node")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0 (implies --backend gloo)")
+    ap.add_argument("--workload", choices=["strings", "euclid"], default=None,
+                    help="headline workload.  strings = BASELINE configs[1] (load_strings Levenshtein, the configuration the metric "
+                         "is quoted on; does not shard: N > 1 runs per-GPU replicas); euclid = BASELINE configs[2] (N = 10^6 rows "
+                         "sharded over the GPUs, strong scaling).  Default: strings at --gpus 1, euclid at --gpus N > 1; "
+                         "`--gpus 1 --workload euclid` prints the N > 1 headline fields for one GPU, the consistent N = 1 point of a "
+                         "1 -> 8 curve")
     args = ap.parse_args()
 
     import torch
@@ -541,8 +568,13 @@ def main():
     affinity = None if args.no_numa_bind else _nat.bind_to_device_numa(local)
 
 
-    if world == 1:
+    workload = args.workload or ("strings" if world == 1 else "euclid")
+    quoted = ("BASELINE.json's metric (k-NN graph build time + recall@k) is quoted on configs[1] = --workload strings "
+              "(the default at --gpus 1); --workload euclid (the default at --gpus N > 1) is configs[2], the workload that shards")
+
+    if workload == "strings" and world == 1:
         out = strings_run(args, args.steps, args.warmup, world, rank, local, dist, torch, all_cpus, affinity)
+        out["config"]["baseline_quoted_on"] = quoted
         try:
             out["c2_device_sampler_plugin"] = device_sampler_block(local)
         except Exception as e:
@@ -571,7 +603,17 @@ def main():
         print(json.dumps(out), flush=True)
         return
 
-    # ---------------------------------------------------------------- N > 1: the row-sharded build
+    if workload == "strings":
+        # the strings workload (1600 points, a chain of dependent launches) does not shard: one independent graph
+        # build per GPU, value = graphs/s over all ranks ("replicas only")
+        st = strings_run(args, args.steps, args.warmup, world, rank, local, dist, torch, all_cpus, affinity)
+        if rank == 0:
+            st["config"]["baseline_quoted_on"] = quoted
+            print(json.dumps(st), flush=True)
+        dist.destroy_process_group()
+        return
+
+    # ---------------------------------------------------------------- the row-sharded build (any number of GPUs)
     import threading
 
     def bail():
@@ -594,15 +636,23 @@ def main():
             "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 (MFMA tile GEMM v_mfma_f32_32x32x2_f32; reported distances recomputed in f64 from the f32 rows)",
             "data": "synthetic (SURVEY.md 8d recipe: 8-d latent manifold in 128-d, float32), generated per shard",
-            "config": {"workload": res["workload"], "total_rows": n_per_rank * world,
-                       "parallelism": "rows sharded N/G per GPU; per anchor round one all-gather of (value, index, row); one all-gather of "
-                                      "the raw rows (every rank then builds the same global tile order), all-gather of the neighbour "
-                                      "lists before each join pass, all-to-all of the finished rows to their owners (RCCL); full-graph "
-                                      "gather not timed (each rank keeps its rows)"},
+            "config": {"workload": res["workload"], "total_rows": n_per_rank * world, "baseline_quoted_on": quoted,
+                       "parallelism": "one GPU" if world == 1 else
+                                      "rows sharded N/G per GPU; every exchange on device buffers over RCCL: per anchor round one "
+                                      "all-gather of (value, row id, coordinates); one all-gather of the raw rows (every rank then builds "
+                                      "the same global tile order), all-gather of the neighbour lists before each join pass, all-to-all "
+                                      "of the finished rows to their owners; full-graph gather not timed (each rank keeps its rows)"},
             "recall_at_k": res["recall_at_k"], "rows_per_s": res["rows_per_s"],
             "roofline": res.get("roofline"), "detail": res,
             "cpu_affinity": affinity or "unbound",
         }
+    if world == 1:
+        dog.cancel()
+        if not args.no_cpu_baseline:
+            os.sched_setaffinity(0, all_cpus)
+            out["cpu_baseline"] = cpu_baseline_euclid(n_per_rank)
+        print(json.dumps(out), flush=True)
+        return
     # the same workload on ONE GPU, measured in this run by rank 0 while the others wait (strong-scaling reference)
     try:
         if rank == 0:

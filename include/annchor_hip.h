@@ -316,7 +316,43 @@ int annchor_stream_query(annchor_ctx *ctx, const void *Xs_all, const void *rs_al
  * host no longer does -- see annchor_stream_order.) */
 int annchor_stream_join_tables(annchor_ctx *ctx, const void *gathered, int32_t world, int32_t n_anchors, int32_t n_tiles,
                                void *joined);
-/* Raw device copies for hosts that stage the all-gather through host memory. */
+/* ---- Row-sharded builds with device-resident exchange buffers (annchor_amd/csrc/sharded.hip; SURVEY.md section 8(e);
+ * no reference counterpart: the reference has no collectives).  One process per GPU; the host hands the DEVICE buffers
+ * below to its collective library (RCCL over xGMI) on the context's stream (annchor_stream_hip_stream) -- no host
+ * round trip per max-min round, no host staging of rows, lists or results.
+ *
+ * Anchors (annchor/pickers.py:44-50 across ranks): _anchor_begin leaves this rank's candidate for the first anchor
+ *   ((0, first_global or -1, that row's coordinates): 2 + dim doubles) in *cand; per round the host all-gathers the
+ *   candidates (rank order) into *gathered (room for world of them; a single rank may pass *cand itself) and calls _anchor_step(gathered, world, round): the winner (largest value, then smallest global
+ *   row) becomes anchor `round`, the local rows are swept with its coordinates (running minimum reset for rounds 0 and 1,
+ *   the reference's D[1:] quirk) and this rank's next candidate replaces *cand.  Nothing waits for the host;
+ *   _anchor_end downloads the anchors' global rows and coordinates.
+ * Rows: _rows_begin gives the all-gather's send buffer (the shard padded with zero rows to the largest shard) and
+ *   receive buffer ([world][most][dim]); _rows_end compacts what arrived, rebinds the context to ALL rows (global_base 0:
+ *   rows are numbered by position in the rank-ordered concatenation) and recomputes every row's anchor distances in one
+ *   pass.  annchor_stream_order then builds the one global tile order on every rank.
+ * Lists: annchor_stream_lists_all = the all-gather target for annchor_stream_knn_join.
+ * Result: _route_begin replaces annchor_stream_knn_end: finished rows become records [global id, k-1 neighbour ids,
+ *   k-1 float64 distances] (int64 words) grouped by owner rank (starts / bases: first position / first global row of
+ *   every rank's shard); the host exchanges them with one all-to-all (send_counts -> receive counts) into the buffer of
+ *   _route_recv; _route_end scatters them into this rank's own row order, keeps the graph rows on the device
+ *   (annchor_stream_graph_device: int64 / float64 [rows_padded][k], padding rows (-1, inf) -- the source of a final
+ *   graph all-gather) and downloads them (get_ann-shaped, annchor.py:514-530). */
+int annchor_stream_hip_stream(annchor_ctx *ctx, void **stream);
+int annchor_stream_anchor_begin(annchor_ctx *ctx, int32_t n_anchors, int64_t first_global, int32_t world, void **cand, void **gathered,
+                                int64_t *cand_bytes);
+int annchor_stream_anchor_step(annchor_ctx *ctx, const void *gathered, int32_t world, int32_t round);
+int annchor_stream_anchor_end(annchor_ctx *ctx, int64_t *A, float *anchor_vectors);
+int annchor_stream_rows_begin(annchor_ctx *ctx, int32_t world, const int64_t *counts, void **send, void **recv, int64_t *bytes_per_rank);
+int annchor_stream_rows_end(annchor_ctx *ctx, int32_t world, const int64_t *counts);
+int annchor_stream_lists_all(annchor_ctx *ctx, int32_t world, int64_t bytes_per_rank, void **all);
+int annchor_stream_route_begin(annchor_ctx *ctx, int32_t world, const int64_t *starts, const int64_t *bases, void **send,
+                               int64_t *send_counts, int64_t *record_words, int64_t *tile_evals);
+int annchor_stream_route_recv(annchor_ctx *ctx, int64_t n_recv, void **recv);
+int annchor_stream_route_end(annchor_ctx *ctx, int64_t n_recv, int64_t rows_padded, int64_t *ng_idx, double *ng_dist);
+int annchor_stream_graph_device(annchor_ctx *ctx, void **idx, void **dist, int64_t *rows_padded, int32_t *k);
+/* Raw device copies for hosts that stage the exchanges through host memory (process groups without device
+ * collectives, e.g. gloo). */
 int annchor_device_alloc(annchor_ctx *ctx, int64_t bytes, void **dptr);
 int annchor_device_free(annchor_ctx *ctx, void *dptr);
 int annchor_device_copy(annchor_ctx *ctx, void *dst, const void *src, int64_t bytes, int32_t kind /*1 H2D, 2 D2H, 3 D2D*/);

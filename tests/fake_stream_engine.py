@@ -29,15 +29,105 @@ class FakeStreamEngine:
     def stream_get_row(self, i):
         return self.X[i].copy()
 
-    def stream_anchor_round(self, vec, rnd, na):
-        if rnd == 0:
-            self.D = np.zeros((na, self.n), dtype=np.float32)
-            self.na = na
+    def _sweep(self, vec, rnd):
         d = np.sqrt(((self.X - vec[None, :]) ** 2).sum(axis=1, dtype=np.float32)).astype(np.float32)
         self.D[rnd] = d
         self.runmin = d.copy() if rnd <= 1 else np.minimum(self.runmin, d)
         arg = int(np.argmax(self.runmin))
         return float(self.runmin[arg]), arg
+
+    def stream_anchor_round(self, vec, rnd, na):
+        if rnd == 0:
+            self.D = np.zeros((na, self.n), dtype=np.float32)
+            self.na = na
+        return self._sweep(np.asarray(vec, dtype=np.float32), rnd)
+
+    # ---- device-resident multi-rank protocol (csrc/sharded.hip), on host memory
+    def hip_stream(self):
+        return 0
+
+    def stream_anchor_begin(self, na, first_global, world=1):
+        self.na, self.D = na, np.zeros((na, self.n), dtype=np.float32)
+        self._A, self._avecs = np.zeros(na, dtype=np.int64), np.zeros((na, self.dim), dtype=np.float32)
+        self._cand = np.zeros(2 + self.dim)
+        mine = self.base <= first_global < self.base + self.n
+        self._cand[1] = first_global if mine else -1
+        if mine:
+            self._cand[2:] = self.X[first_global - self.base]
+        self._cand_all = np.zeros((world, 2 + self.dim))
+        return self._cand.ctypes.data, self._cand_all.ctypes.data, self._cand.nbytes
+
+    def stream_anchor_step(self, gathered, world, rnd):
+        G = _view(gathered, (world, 2 + self.dim), np.float64)
+        best = None
+        for r in range(world):
+            v, i = G[r, 0], int(G[r, 1])
+            if i >= 0 and (best is None or v > best[0] or (v == best[0] and i < best[1])):
+                best = (v, i, r)
+        self._A[rnd] = best[1]
+        self._avecs[rnd] = G[best[2], 2:].astype(np.float32)
+        v, arg = self._sweep(self._avecs[rnd], rnd)
+        self._cand[0], self._cand[1] = v, self.base + arg
+        self._cand[2:] = self.X[arg]
+
+    def stream_anchor_end(self, na):
+        return self._A.copy(), self._avecs.copy()
+
+    def stream_rows_begin(self, counts):
+        most = int(max(counts))
+        self._send = np.zeros((most, self.dim), dtype=np.float32)
+        self._send[:self.n] = self.X
+        self._recv = np.zeros((len(counts), most, self.dim), dtype=np.float32)
+        return self._send.ctypes.data, self._recv.ctypes.data, self._send.nbytes
+
+    def stream_rows_end(self, counts):
+        self.own_base, self.own_n = self.base, self.n
+        self.X = np.concatenate([self._recv[r, :int(c)] for r, c in enumerate(counts)])
+        self.n, self.base = len(self.X), 0
+        self.D = np.stack([np.sqrt(((self.X - v[None, :]) ** 2).sum(axis=1, dtype=np.float32)).astype(np.float32) for v in self._avecs])
+
+    def stream_lists_all(self, world, nbytes):
+        return self._alloc(np.zeros(world * nbytes, dtype=np.uint8))
+
+    def stream_route_begin(self, starts, bases):
+        rid, idx, dist, ev = self.stream_knn(*self._run)
+        starts, bases = np.asarray(starts), np.asarray(bases)
+        k = idx.shape[1]
+
+        def glob(pos):
+            r = np.searchsorted(starts, pos, side="right") - 1
+            return pos - starts[r] + bases[r]
+
+        real = rid >= 0
+        pos = rid[real]
+        dest = np.searchsorted(starts, pos, side="right") - 1
+        order = np.argsort(dest, kind="stable")[::-1]          # any order inside a destination is allowed
+        order = order[np.argsort(dest[order], kind="stable")]
+        rec = np.zeros((len(pos), 1 + 2 * (k - 1)), dtype=np.int64)
+        rec[:, 0] = glob(pos)
+        rec[:, 1:k] = glob(idx[real][:, 1:])
+        rec[:, k:] = dist[real][:, 1:].astype(np.float64).view(np.int64)
+        self._route_send = np.ascontiguousarray(rec[order])
+        self._k = k
+        return self._route_send.ctypes.data, np.bincount(dest, minlength=len(bases)).astype(np.int64), rec.shape[1], ev
+
+    def stream_route_recv(self, n_recv):
+        self._route_recv = np.zeros((max(n_recv, 1), 2 * self._k - 1), dtype=np.int64)
+        return self._route_recv.ctypes.data
+
+    def stream_route_end(self, n_recv, rows_padded, n_own, k):
+        assert n_recv == n_own == self.own_n
+        rec = self._route_recv[:n_recv]
+        self._gi = np.full((rows_padded, k), -1, dtype=np.int64)
+        self._gd = np.full((rows_padded, k), np.inf)
+        loc = rec[:, 0] - self.own_base
+        assert np.all((loc >= 0) & (loc < n_own)) and len(np.unique(loc)) == n_own
+        self._gi[loc, 0], self._gd[loc, 0] = rec[:, 0], 0.0
+        self._gi[loc, 1:], self._gd[loc, 1:] = rec[:, 1:k], rec[:, k:].view(np.float64)
+        return self._gi[:n_own].copy(), self._gd[:n_own].copy()
+
+    def stream_graph_device(self):
+        return self._gi.ctypes.data, self._gd.ctypes.data, self._gi.shape[0], self._gi.shape[1]
 
     def _alloc(self, arr):
         arr = np.ascontiguousarray(arr)

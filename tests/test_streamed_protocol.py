@@ -84,3 +84,64 @@ def test_two_gloo_ranks_equal_one_rank(tmp_path):
     assert int(R["joins"]) == 2   # both join passes ran against the all-gathered neighbour lists
     assert np.array_equal(R["idx"], one.neighbor_graph[0])
     np.testing.assert_allclose(R["dist"], one.neighbor_graph[1], rtol=0, atol=0)
+
+
+def _worker_cuts(rank, world, port, out, n, cuts):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fake_stream_engine import FakeStreamEngine
+    from annchor_amd.streamed import StreamedAnnchor, TorchComm
+
+    X = _data(n=n)
+    Xl = X[cuts[rank]:cuts[rank + 1]]
+    sa = StreamedAnnchor(Xl, n_anchors=6, n_neighbors=5, p_work=1.0, random_seed=42, base=cuts[rank], comm=TorchComm(),
+                         engine=FakeStreamEngine()).fit()
+    own = sa.neighbor_graph
+    assert own[0].shape == (len(Xl), 5) and np.array_equal(own[0][:, 0], np.arange(cuts[rank], cuts[rank + 1]))
+    gi, gd = sa.gather_graph()
+    if rank == 0:
+        np.savez(out, A=sa.A, idx=gi, dist=gd)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,cuts", [
+    (3, 700, [0, 300, 580, 700]),                                     # ragged, every shard a different tile count
+    (4, 1061, [0, 266, 532, 798, 1061]),                              # C5's ratios: equal shards but a shorter last one
+    (8, 1061, [0, 133, 266, 399, 532, 665, 798, 931, 1061]),          # 9 tiles over 8 ranks: 16 with padding, ranks 5-7 own
+])                                                                     # (almost) only padding tiles -> empty all-to-all slices
+def test_many_gloo_ranks_equal_one_rank(tmp_path, world, n, cuts):
+    """4- and 8-rank rehearsal of the row-sharded protocol at BASELINE configs[4]'s shape ratios (N not a multiple of
+    128 x world, uneven last shard, tile count padded to a multiple of the rank count): anchors and graph equal to the
+    one-rank build."""
+    import torch.multiprocessing as mp
+
+    from fake_stream_engine import FakeStreamEngine
+    from annchor_amd.streamed import StreamedAnnchor
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "wn.npz")
+    mp.spawn(_worker_cuts, args=(world, port, out, n, cuts), nprocs=world, join=True)
+    R = np.load(out)
+    one = StreamedAnnchor(_data(n=n), n_anchors=6, n_neighbors=5, p_work=1.0, random_seed=42, engine=FakeStreamEngine()).fit()
+    assert np.array_equal(R["A"], one.A)
+    assert np.array_equal(R["idx"], one.neighbor_graph[0])
+    np.testing.assert_allclose(R["dist"], one.neighbor_graph[1], rtol=0, atol=0)
+
+
+def test_non_contiguous_shard_bases_map_back():
+    """Shards need not be contiguous or in rank order in the global numbering: rows, neighbours and query results are
+    mapped through the (starts, bases) tables (one rank, exchange forced)."""
+    from fake_stream_engine import FakeStreamEngine
+    from annchor_amd.streamed import StreamedAnnchor
+
+    X = _data(n=300)
+    a = StreamedAnnchor(X, n_anchors=4, n_neighbors=4, p_work=1.0, base=1000, engine=FakeStreamEngine(), force_exchange=True).fit()
+    b = StreamedAnnchor(X, n_anchors=4, n_neighbors=4, p_work=1.0, engine=FakeStreamEngine()).fit()
+    assert np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0] + 1000)
+    assert np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1])
+    assert np.array_equal(a.A, b.A + 1000)
