@@ -789,6 +789,223 @@ static int launch_f(annchor_ctx *c, LevArgs a, int64_t npairs, const PairSource 
     return ANNCHOR_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// k_lev_a: the one-to-all launches of the max-min picker (pickers.py:44-50) -- 15 dependent launches of nx pairs
+// each at C2, bound by the LATENCY of one pair's column chain, not by throughput (1600 pairs / 3 per wave = 534
+// waves on 1024 SIMDs, each walking ~500 dependent columns).  The chain is halved: ONE pair per wave, the anchor is
+// the bit-vector pattern, and the two half-waves walk the two halves of the text towards each other --
+//   lanes  0-31: pattern P against T[0:h)            -> F[i]  = lev(P[0:i], T[0:h)),  i = 0..m
+//   lanes 32-63: reversed P against reversed T[h:n)  -> B'[i] = lev(last i symbols of P, T[h:n))
+//   lev(P, T) = min_i F[i] + B'[m - i]                                   (Hirschberg's split at column h)
+// F / B' are the prefix sums of the vertical deltas (vp / vn bits) the bit-parallel recurrence leaves after the
+// last column.  nx waves instead of nx / 3 (1.6 per SIMD at C2), ~n / 2 + words dependent columns instead of
+// n + words.  The text of a wave's pair does not depend on the anchor, so it is staged while the fused arg-max scan
+// of the previous round's distances (which decides the anchor) is still in flight.
+struct LevArgsA {
+    const uint8_t *sym;
+    const int32_t *soff;
+    const int32_t *slen;
+    const int32_t *anchor;    // anchor of this launch when it is not picked here
+    int64_t n;                // targets: pair t = (anchor, t)
+    double *out;
+    int alphabet, text_stride, pm_bytes, fb_stride;
+    const double *pick_row;
+    double *pick_runmin;
+    int32_t *pick_out;
+    int pick_reset, pick_nx;
+};
+
+__global__ __launch_bounds__(ANN_WAVE) void k_lev_a(LevArgsA a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x, half = lane >> 5, w = lane & 31, A = a.alphabet;
+    unsigned char *pm_col = smem + (size_t)half * A * LEVF_ROW + (size_t)w * 4;
+    uint8_t *txt = smem + a.pm_bytes;
+    int16_t *FB = reinterpret_cast<int16_t *>(smem + a.pm_bytes + a.text_stride);   // [2][fb_stride]
+    for (int e = lane * 16; e < a.text_stride; e += 64 * 16) *reinterpret_cast<uint4 *>(txt + e) = make_uint4(0, 0, 0, 0);
+    uint32_t hp_or = w == 0 ? 0x80000000u : 0u;      // first lane of a half: the row above the pattern (see k_lev_f)
+    uint32_t hn_and = w == 0 ? 0u : 0xffffffffu;
+    asm volatile("" : "+v"(hp_or), "+v"(hn_and));
+
+    auto stage_text = [&](int64_t t) {
+        const int n = a.slen[t];
+        const uint8_t *tex = a.sym + a.soff[t];
+        for (int ch = lane; ch < ((n + 15) >> 4); ch += 64)
+            reinterpret_cast<uint4 *>(txt + LEVR_PAD)[ch] = reinterpret_cast<const uint4 *>(tex)[ch];
+        return n;
+    };
+    // ---- the text of the first pair (string blockIdx.x): known before the anchor is -- its loads are in flight
+    // while the scan below decides the anchor
+    int n_first = blockIdx.x < a.n ? stage_text(blockIdx.x) : 0;
+    // ---- the anchor: fused max-min pick over the previous round's distances (every wave for itself)
+    int si;
+    if (a.pick_row) {
+        double bv = -INFINITY;
+        int bi = 0x7fffffff;
+        const int nx = a.pick_nx;
+        for (int j0 = 0; j0 < nx; j0 += 64 * 16) {
+            double d[16], rm[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = min(j0 + e * 64 + lane, nx - 1);
+                d[e] = a.pick_row[j];
+                rm[e] = a.pick_reset ? 0.0 : a.pick_runmin[j];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = j0 + e * 64 + lane;
+                if (j < nx) {
+                    const double v = a.pick_reset ? d[e] : fmin(rm[e], d[e]);
+                    if (blockIdx.x == 0) a.pick_runmin[j] = v;   // other workgroups read it before or after: min(min(r, d), d) == min(r, d)
+                    argmax_combine(bv, bi, v, j);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            argmax_combine(bv, bi, ov, oi);
+        }
+        si = bi;
+        if (blockIdx.x == 0 && lane == 0) *a.pick_out = bi;
+    } else {
+        si = *a.anchor;
+    }
+
+    for (int64_t t = blockIdx.x; t < a.n; t += gridDim.x) {
+        int n = n_first;
+        if (t != blockIdx.x) {
+            wave_lds_fence();   // the previous pair's readers are done
+            n = stage_text(t);
+        }
+        const int m = a.slen[si];
+        const uint8_t *pat = a.sym + a.soff[si];
+        const int Wp = (m + 31) >> 5;
+        // ---- match masks of this lane's pattern word: forward word w, or word w of the reversed pattern
+        for (int c = 0; c < A; ++c) *reinterpret_cast<uint32_t *>(pm_col + (size_t)c * LEVF_ROW) = 0u;
+        if (w < Wp) {
+            const int valid = min(32, m - w * 32);
+            uint32_t sy[32];
+            if (half == 0) {
+                const uint4 *p16 = reinterpret_cast<const uint4 *>(pat + w * 32);
+                const uint4 q0 = p16[0], q1 = p16[1];
+                const uint32_t wd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                for (int k = 0; k < 32; ++k) sy[k] = (wd[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) sy[k] = pat[max(m - 1 - (w * 32 + k), 0)];
+            }
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+                if (k < valid) atomicOr(reinterpret_cast<uint32_t *>(pm_col + (size_t)sy[k] * LEVF_ROW), 1u << k);
+        }
+        wave_lds_fence();
+
+        // ---- columns: forward half T[0:h) left to right, backward half T[h:n) right to left
+        const int h = (n + 1) >> 1;
+        const uint32_t un = m > 0 ? (uint32_t)(half ? n - h : h) : 0u;
+        const int max_steps = m > 0 ? h + Wp - 1 : 0;
+        const int dir = half ? -1 : 1;
+        const uint8_t *tp = txt + LEVR_PAD + (half ? n - 1 + w : -w);   // tp[dir * k] = this lane's symbol at iteration k
+        uint32_t vp = 0xffffffffu, vn = 0u;
+        uint32_t c1 = tp[dir];
+        uint32_t eq = *reinterpret_cast<const uint32_t *>(pm_col + (uint32_t)tp[0] * LEVF_ROW);
+        uint32_t out_hp = 0, out_hn = 0;
+        const uint8_t *tq = tp + 2 * dir;   // symbol two iterations ahead
+        auto column = [&](int k, auto checked) {
+            const uint32_t c2 = *tq;
+            tq += dir;
+            const uint32_t eq_n = *reinterpret_cast<const uint32_t *>(pm_col + c1 * LEVF_ROW);
+            const uint32_t hp_up = dpp_shr1_or(out_hp, hp_or), hn_up = dpp_shr1_and(out_hn, hn_and);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool valid = !decltype(checked)::value || (uint32_t)(k - w) < un;
+            const uint32_t c = hn_up >> 31;
+            const uint32_t x = eq | c;
+            const uint32_t tt = __builtin_amdgcn_bitop3_b32(c, eq, vp, 0xa8);       // (c | eq) & vp
+            const uint32_t sm = tt + vp;
+            const uint32_t d0p = __builtin_amdgcn_bitop3_b32(sm, vp, x, 0xbe);      // (sm ^ vp) | x
+            const uint32_t hp = __builtin_amdgcn_bitop3_b32(vn, d0p, vp, 0xf1);     // vn | ~(d0p | vp)
+            const uint32_t d0 = d0p | vn;
+            const uint32_t hn = d0 & vp;
+            const uint32_t hps = __builtin_amdgcn_alignbit(hp, hp_up, 31);
+            const uint32_t hns = __builtin_amdgcn_alignbit(hn, hn_up, 31);
+            const uint32_t nvp = __builtin_amdgcn_bitop3_b32(hns, d0, hps, 0xf1);   // hns | ~(d0 | hps)
+            const uint32_t nvn = hps & d0;
+            vp = valid ? nvp : vp;
+            vn = valid ? nvn : vn;
+            out_hp = hp;
+            out_hn = hn;
+            __builtin_amdgcn_sched_barrier(0);
+            eq = eq_n;
+            c1 = c2;
+        };
+        // between k = Wp - 1 (every pattern word has started) and n - h (the shorter half has not finished) every
+        // lane that holds a pattern word is on a real column: no validity test there
+        const int k_lo = min(max(Wp - 1, 0), max_steps), k_hi = max(k_lo, min(n - h, max_steps));
+        int k = 0;
+        for (; k < k_lo; ++k) column(k, std::true_type());
+        for (; k + 2 <= k_hi; k += 2) { column(k, std::false_type()); column(k + 1, std::false_type()); }
+        for (; k < k_hi; ++k) column(k, std::false_type());
+        for (; k < max_steps; ++k) column(k, std::true_type());
+
+        // ---- F / B': prefix sums of the vertical deltas down the rows of this half
+        const uint32_t rows = w < Wp - 1 ? 0xffffffffu : (w == Wp - 1 ? (0xffffffffu >> (31 - ((m - 1) & 31))) : 0u);
+        const int part = __popc(vp & rows) - __popc(vn & rows);
+        int incl = part;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const int o = __shfl_up(incl, off, 32);
+            if (w >= off) incl += o;
+        }
+        int val = (int)un + incl - part;     // value at the row above this word's first row (m == 0: un = 0, fixed below)
+        if (m == 0) val = half ? n - h : h;
+        int16_t *fb = FB + (size_t)half * a.fb_stride;
+        if (w == 0) fb[0] = (int16_t)val;
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+            val += (int)((vp >> b) & 1u) - (int)((vn >> b) & 1u);
+            if ((rows >> b) & 1u) fb[w * 32 + b + 1] = (int16_t)val;
+        }
+        wave_lds_fence();
+        int best = 0x7fffffff;
+        for (int i = lane; i <= m; i += 64) best = min(best, (int)FB[i] + (int)FB[a.fb_stride + m - i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off));
+        if (lane == 0) a.out[t] = (double)best;
+    }
+}
+
+static int launch_a(annchor_ctx *c, const PairSource &src, double *d_out)
+{
+    LevArgsA a;
+    a.sym = c->sym.as<uint8_t>(); a.soff = c->soff.as<int32_t>(); a.slen = c->slen.as<int32_t>();
+    a.anchor = src.anchor; a.n = src.n; a.out = d_out; a.alphabet = c->alphabet;
+    a.pm_bytes = 2 * a.alphabet * LEVF_ROW;
+    a.text_stride = 2 * LEVR_PAD + ((c->maxlen + 15) & ~15) + 16;
+    a.fb_stride = (c->maxlen + 2 + 7) & ~7;
+    a.pick_row = nullptr; a.pick_runmin = nullptr; a.pick_out = nullptr; a.pick_reset = 0; a.pick_nx = 0;
+    if (src.pick_fused && c->nx <= 8192) {
+        *src.pick_fused = true;
+        if (src.pick_row) {
+            a.pick_row = src.pick_row; a.pick_runmin = src.pick_runmin; a.pick_out = src.pick_out;
+            a.pick_reset = src.pick_reset; a.pick_nx = (int)c->nx;
+        }
+    }
+    const size_t lds = (size_t)a.pm_bytes + a.text_stride + 2 * sizeof(int16_t) * a.fb_stride;
+    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "alphabet %d x length %d needs %zu B of LDS (> 160 KiB)", c->alphabet,
+                c->maxlen, lds);
+    if (lds > 64 * 1024)
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev_a, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t blocks = src.n;
+    const int64_t max_blocks = (int64_t)c->prop.multiProcessorCount * 32;
+    if (blocks > max_blocks) blocks = max_blocks;
+    k_lev_a<<<(int)blocks, ANN_WAVE, lds, c->stream>>>(a);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
 int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm)
 {
     if (src.n == 0) return ANNCHOR_OK;
@@ -826,6 +1043,13 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
         // tables leave < 2 waves per SIMD.  ANNCHOR_LEV_R = 0 / 2 / 4 select the other variants.
         (void)W;
         int R = force_r >= 0 ? force_r : 9;   // default: k_lev_f (394 vs 415 us per 65 536 pairs, 34 vs 37.5 us per anchor round)
+        // one-to-all launches (anchor rounds): the latency-shaped kernel, unless ANNCHOR_LEV_ANCHOR=0 / a forced variant
+        const char *env_a = getenv("ANNCHOR_LEV_ANCHOR");   // read per launch, like ANNCHOR_LEV_R
+        const bool anchor_split = !(env_a && atoi(env_a) == 0);
+        if (src.anchor && d_out && !d_RA && R == 9 && W <= 32 && anchor_split && c->maxlen < 32000) {
+            ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
+            return launch_a(c, src, d_out);
+        }
         if (R == 9 && W <= 32) {   // k_lev_f (strings up to 1024 symbols: a slot's lanes must map to distinct banks)
             ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
             return launch_f(c, a, src.n, src);

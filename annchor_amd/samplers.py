@@ -208,7 +208,7 @@ def splitmix64(x):
 class DeviceStratifiedSampler(SimpleStratifiedSampler):
     """Stratified sampler with an ORDER-FREE random choice: same partitions, same quotas and the same
     protocol as SimpleStratifiedSampler (samplers.py:75-140), but a partition's members are chosen by
-    key = splitmix64((random_seed + loop_num) ^ pair position) -- the `want` smallest keys -- instead of
+    key = splitmix64(splitmix64(random_seed + loop_num) ^ pair position) -- the `want` smallest keys -- instead of
     through NumPy's sequential shuffle of the partition (an MT19937 stream as long as the pair list,
     walked by one thread: 2 of the 5.8 ms of the strings fit, 0.3 of 0.33 s at 127 M pairs).  A uniform
     random subset either way; NOT the same subset, so graphs differ from the default sampler's by
@@ -216,7 +216,10 @@ class DeviceStratifiedSampler(SimpleStratifiedSampler):
     plain `sample()` protocol the same choice is made in NumPy."""
 
     def seed_key(self, random_seed):
-        return (int(random_seed) + self.loop_num) & _M64
+        """The hash key of one sampling step: splitmix64(random_seed + loop_num).  (Round 2 used random_seed + loop_num
+        itself: consecutive steps' keys then differ in the lowest bit only, so step t + 1 drew exactly the list
+        neighbours -- position ^ 1 -- of step t's members; hashing the seed decorrelates the steps.)"""
+        return int(splitmix64(np.uint64((int(random_seed) + self.loop_num) & _M64)))
 
     def sample_partition(self, indices, n_samples, sample_feature, sample_bins, random_seed):
         P = self.n_partitions

@@ -208,7 +208,9 @@ int annchor_set_labels(annchor_ctx *ctx, const int64_t *labels);
  * select_refine_candidate_pairs (annchor.py:395-473) up to, not including, the
  * metric call: thresh, guarantee_nmin (when nmin > 0), p, ECDF prob (errs:
  * concatenated sorted residuals, err_ptr int64 [nlabels+1]), top-n_refine and
- * lookahead selection with the tie rule (prob desc, pair position asc). */
+ * lookahead selection.  Ties at a cut (np.argpartition is arbitrary there): probability descending, then
+ * the fixed pseudo-random order (position * 0x9E3779B97F4A7C15 mod 2^64) >> 11 ascending, then position
+ * ascending. */
 int annchor_select_candidates(annchor_ctx *ctx, int32_t n_neighbors, int32_t nmin, const double *errs,
                               const int64_t *err_ptr, int32_t nlabels, int64_t n_refine,
                               int32_t lookahead, int64_t *n_cand, int64_t *n_next);

@@ -255,7 +255,7 @@ def splitmix64(x):
 def hashed_stratified_sample(feats, ncm, n_samples, seed, loop_num, n_partitions=7):
     """The build's DeviceStratifiedSampler (no reference counterpart: the reference's choice inside a
     partition is np.random.choice, samplers.py:44-73): same partitions and quotas as
-    stratified_sample, members chosen by the smallest splitmix64((seed + loop_num) ^ position), ties to
+    stratified_sample, members chosen by the smallest splitmix64(splitmix64(seed + loop_num) ^ position), ties to
     the smaller position; output partition by partition, ascending position inside a partition."""
     idx = np.nonzero(ncm)[0]
     if idx.shape[0] == 0:
@@ -264,7 +264,8 @@ def hashed_stratified_sample(feats, ncm, n_samples, seed, loop_num, n_partitions
     bins, n_samples = stratified_partition(f, n_samples, n_partitions)
     if n_samples == 0:
         raise NothingToSample()
-    keys = splitmix64(np.uint64((int(seed) + int(loop_num)) & ((1 << 64) - 1)) ^ idx.astype(np.uint64))
+    step_key = splitmix64(np.uint64((int(seed) + int(loop_num)) & ((1 << 64) - 1)))
+    keys = splitmix64(step_key ^ idx.astype(np.uint64))
     out = []
     for b in range(n_partitions):
         m = np.nonzero((f >= bins[b]) & (f < bins[b + 1]))[0]

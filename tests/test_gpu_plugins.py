@@ -271,9 +271,30 @@ def test_device_stratified_sampler_fit_matches_oracle_and_quality():
     truth = (G["truth_idx"].astype(np.int64), G["truth_dist"].astype(np.float64))
     big = Annchor(np.array(X), "levenshtein", n_anchors=15, n_neighbors=25, p_work=0.12, sampler=DeviceStratifiedSampler()).fit()
     assert big.evals == int(G["c1_evals"])
-    # a different random sample, so a different draw of the error count: at this 15-anchor configuration it moves
-    # between ~320 and ~620 of 40 000 with the sample / tie order (reference run: 504); at the README configuration
-    # (20 anchors) the reference has 0
-    assert compare_neighbor_graphs(truth, big.neighbor_graph, 25) <= 800
-    readme = Annchor(np.array(X), "levenshtein", n_neighbors=25, p_work=0.12, sampler=DeviceStratifiedSampler()).fit()
-    assert compare_neighbor_graphs(truth, readme.neighbor_graph, 25) <= 20   # of 40 000 (measured: 6)
+
+
+def test_device_stratified_sampler_error_distribution_matches_the_legacy_sampler():
+    """The order-free draw must be statistically the same sampler as the reference's (samplers.py:75-140,
+    utils.py:543-578): over 12 seeds at BASELINE configs[1] (15 anchors) and at the README configuration (20 anchors)
+    the error counts of the two samplers against brute force come from the same distribution.  (One seed says
+    nothing: at 15 anchors the count moves between ~30 and ~650 of 40 000 with the seed for EITHER sampler --
+    measured with the oracle, 12 seeds: legacy median 132 / max 346, hashed median 81 / max 639; the reference's own
+    run at seed 42: 504.  README configuration: legacy median 10, hashed 9; reference run: 0.)"""
+    from annchor_amd import Annchor, compare_neighbor_graphs
+    from annchor_amd.samplers import DeviceStratifiedSampler
+    from oracle import metrics as om
+
+    X = np.array(om.load_strings()[0])
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "strings_full.npz"))
+    truth = (G["truth_idx"].astype(np.int64), G["truth_dist"].astype(np.float64))
+    seeds = range(42, 54)
+    for na, ref_run, slack in ((15, 504, 150), (20, 0, 15)):
+        e_leg, e_dev = [], []
+        for s in seeds:
+            cfg = dict(n_anchors=na, n_neighbors=25, p_work=0.12, random_seed=s)
+            e_leg.append(compare_neighbor_graphs(truth, Annchor(X, "levenshtein", **cfg).fit().neighbor_graph, 25))
+            e_dev.append(compare_neighbor_graphs(truth, Annchor(X, "levenshtein", sampler=DeviceStratifiedSampler(), **cfg).fit().neighbor_graph, 25))
+        print("n_anchors=%d legacy %s\n             device %s" % (na, e_leg, e_dev))
+        assert np.median(e_dev) <= max(ref_run, np.median(e_leg) + slack), (e_leg, e_dev)
+        assert np.median(e_dev) <= 1.5 * np.median(e_leg) + slack
+        assert np.mean(e_dev) <= 1.5 * np.mean(e_leg) + slack
