@@ -56,9 +56,16 @@ _SIGNATURES = {
     "annchor_bin_counts": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
     "annchor_select_by_rank": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _vp]),
     "annchor_sample_pairs": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "annchor_sample_pairs_device": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i64]),
+    "annchor_download_samples": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "annchor_fit_regression_device": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32]),
+    "annchor_fit_errors_device": (ctypes.c_int, [_vp]),
+    "annchor_model_download": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "annchor_errors_download": (ctypes.c_int, [_vp, _vp, _i64]),
     "annchor_hash_sample": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, ctypes.c_uint64, _vp, ctypes.POINTER(_i64)]),
     "annchor_hash_sample_pairs": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, ctypes.c_uint64, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "annchor_legacy_prefetch": (ctypes.c_int, [ctypes.c_uint32, _i64]),
+    "annchor_legacy_generate": (ctypes.c_int, [ctypes.c_uint32, _i64]),
     "annchor_legacy_choice_ranks": (ctypes.c_int, [ctypes.c_uint32, _vp, _vp, _i32, _vp, _vp]),
     "annchor_legacy_choice_begin": (ctypes.c_int, [ctypes.c_uint32, _vp, _vp, _i32, ctypes.POINTER(_vp)]),
     "annchor_legacy_choice_end": (ctypes.c_int, [_vp, _vp, _vp]),
@@ -202,6 +209,12 @@ def legacy_prefetch(seed, ndraws):
     """Begin producing the legacy MT19937 stream of `seed` on a background thread."""
     if 0 <= seed < 2 ** 32 and ndraws > 0:
         load_library().annchor_legacy_prefetch(int(seed), int(ndraws))
+
+
+def legacy_generate(seed, ndraws):
+    """Produce the legacy MT19937 stream of `seed` on the calling thread (returns when it is there)."""
+    if 0 <= seed < 2 ** 32 and ndraws > 0:
+        load_library().annchor_legacy_generate(int(seed), int(ndraws))
 
 
 def legacy_choice_ranks(seed, counts, want):
@@ -429,6 +442,40 @@ class Engine:
                                                 _ptr(pos), _ptr(feats), _ptr(y)))
         return pos, feats, y
 
+    # ---- the iteration's models fitted on the device (csrc/model.hip): no host round trip between the stages
+    def sample_pairs_device(self, bins, counts, bin_of, ranks):
+        bins, counts = _c(bins, np.float64), _c(counts, np.int64)
+        bin_of, ranks = _c(bin_of, np.int32), _c(ranks, np.int64)
+        self._chk(self.lib.annchor_sample_pairs_device(self.h, _ptr(bins), len(bins) - 1, _ptr(counts), _ptr(bin_of), _ptr(ranks), len(ranks)))
+        return len(ranks)
+
+    def download_samples(self, m, predict=True):
+        """(positions, feature rows, distances, unclipped predictions) of the device-resident sample."""
+        pos, feats, y = np.empty(m, dtype=np.int64), np.empty((m, 4), dtype=np.float64), np.empty(m, dtype=np.float64)
+        sp = np.empty(m, dtype=np.float64) if predict else None
+        self._chk(self.lib.annchor_download_samples(self.h, _ptr(pos), _ptr(feats), _ptr(y), _ptr(sp)))
+        return pos, feats, y, sp
+
+    def fit_regression_device(self, bins, first, is_metric):
+        bins = _c(bins, np.float64)
+        self._chk(self.lib.annchor_fit_regression_device(self.h, _ptr(bins), len(bins) - 1, int(first), int(is_metric)))
+
+    def fit_errors_device(self):
+        self._chk(self.lib.annchor_fit_errors_device(self.h))
+
+    def model_download(self, nb, with_errors=True):
+        """(W [nb, 3], c [nb], status [nb], err_ptr [nb + 1] or None, flags [3]); waits; clears the sticky flags."""
+        W, c = np.zeros((nb, 3)), np.zeros(nb)
+        status, flags = np.zeros(nb, dtype=np.int32), np.zeros(3, dtype=np.int32)
+        ep = np.zeros(nb + 1, dtype=np.int64) if with_errors else None
+        self._chk(self.lib.annchor_model_download(self.h, _ptr(W), _ptr(c), _ptr(status), _ptr(ep), _ptr(flags)))
+        return W, c, status, ep, flags
+
+    def errors_download(self, n):
+        out = np.empty(int(n), dtype=np.float64)
+        self._chk(self.lib.annchor_errors_download(self.h, _ptr(out), int(n)))
+        return out
+
     def hash_sample(self, bins, counts, want, seed_key):
         """Hashed stratified choice (annchor_hash_sample): positions of the samples, partition by partition."""
         bins, counts, want = _c(bins, np.float64), _c(counts, np.int64), _c(want, np.int64)
@@ -488,11 +535,16 @@ class Engine:
             raise ValueError("error labels must lie in 0..254 (got %d..%d)" % (labels.min(), labels.max()))
         self._chk(self.lib.annchor_set_labels(self.h, _ptr(labels)))
 
-    def select_candidates(self, n_neighbors, nmin, errs_list, n_refine, lookahead):
+    def select_candidates(self, n_neighbors, nmin, errs_list, n_refine, lookahead, n_labels=None):
+        """errs_list None: the residual lists fit_errors_device left on the device (n_labels of them)."""
+        nc, nn = _i64(), _i64()
+        if errs_list is None:
+            self._chk(self.lib.annchor_select_candidates(self.h, int(n_neighbors), int(nmin), None, None, int(n_labels), int(n_refine),
+                                                         int(lookahead), ctypes.byref(nc), ctypes.byref(nn)))
+            return nc.value, nn.value
         ptr = np.zeros(len(errs_list) + 1, dtype=np.int64)
         np.cumsum([len(e) for e in errs_list], out=ptr[1:])
         errs = _c(np.concatenate(errs_list) if len(errs_list) else np.zeros(0), np.float64)
-        nc, nn = _i64(), _i64()
         self._chk(self.lib.annchor_select_candidates(self.h, int(n_neighbors), int(nmin), _ptr(errs), _ptr(ptr),
                                                      len(errs_list), int(n_refine), int(lookahead),
                                                      ctypes.byref(nc), ctypes.byref(nn)))

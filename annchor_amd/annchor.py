@@ -57,6 +57,45 @@ def budget(nx, n_anchors, n_neighbors, n_samples, p_work, loc_min=None, quiet=Tr
     return dict(N=N, na=na, p_work=p_work, loc_min=lm)
 
 
+class _LazyErrs(dict):
+    """error_predictor.errs after a device-fitted iteration: label -> sorted residuals, downloaded on first use."""
+
+    def __init__(self, engine, err_ptr):
+        super().__init__()
+        self._engine, self._ptr, self._loaded = engine, np.asarray(err_ptr, dtype=np.int64), False
+
+    def _load(self):
+        if not self._loaded:
+            self._loaded = True
+            flat = self._engine.errors_download(int(self._ptr[-1]))
+            for b in range(len(self._ptr) - 1):
+                dict.__setitem__(self, b, flat[self._ptr[b]:self._ptr[b + 1]].copy())
+
+    def __getitem__(self, k):
+        self._load()
+        return dict.__getitem__(self, k)
+
+    def __iter__(self):
+        self._load()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._load()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._load()
+        return dict.keys(self)
+
+    def items(self):
+        self._load()
+        return dict.items(self)
+
+    def values(self):
+        self._load()
+        return dict.values(self)
+
+
 class _IndexCSR:
     """Read-only stand-in for the reference's typed dict `I` (utils.py:533-540):
     I[i] -> int64 array of positions in IJs that contain i."""
@@ -96,17 +135,24 @@ class _DeviceExact:
 class Annchor:
     """Quickly computes the approximate k-NN graph for slow metrics (annchor.py:21-115).
 
-    Parameters are those of the reference, plus `device` (GPU ordinal, default 0) and `streamed`
+    Parameters are those of the reference, plus `device` (GPU ordinal, default 0), `streamed`
     (None: float32 Euclidean / cosine data above PAIRLIST_MAX_POINTS points takes the streamed
-    tile-granular form, announced on stdout; True / False force either form).
+    tile-granular form, announced on stdout; True / False force either form) and `ols`: inside fit(),
+    with the default plugins and a device metric, the per-partition least-squares fits of the regression
+    (regressors.py:39-69) run on the GPU ('device': Householder QR in float64, coefficients equal to the
+    reference's LAPACK dgelsd solution to ~1e-13, no host round trip inside an iteration) or on the host
+    with scipy's own dgelsd ('lapack': the reference's coefficients bit for bit on the same LAPACK build).
     """
 
     def __init__(self, X, func, func_kwargs=None, n_anchors=20, n_neighbors=15, n_samples=5000, p_work=0.1,
                  anchor_picker=None, sampler=None, regression=None, error_predictor=None, random_seed=42,
                  locality=5, loc_thresh=1, loc_min=None, verbose=False, is_metric=True, get_exact_ijs=None,
-                 backend="loky", niters=2, lookahead=5, device=0, streamed=None):
+                 backend="loky", niters=2, lookahead=5, device=0, streamed=None, ols="device"):
         self.X = X
         self.nx = len(X)
+        if ols not in ("device", "lapack"):
+            raise ValueError("ols must be 'device' or 'lapack'")
+        self.ols = ols
         self.f = get_function_from_input(func, func_kwargs)
         self.evals = 0
         self.n_anchors = n_anchors
@@ -268,6 +314,46 @@ class Annchor:
     def thresh(self):
         return self._view("thresh", lambda: self._engine.download(_native.F_THRESH))
 
+    # ---- the last sampling step's arrays: inside fit() they stay in device memory with the default plugins (the models
+    # are fitted there, csrc/model.hip) and are downloaded when somebody reads them
+    def _materialise_samples(self):
+        if self.__dict__.get("_samples_on_device"):
+            self.__dict__["_samples_on_device"] = False
+            m = self.__dict__["_samples_m"]
+            pos, feats, y, sp = self._engine.download_samples(m, predict=self.__dict__.get("_predict_on_device", False))
+            d = self.__dict__
+            d["_sample_ixs"], d["_sample_features"], d["_sample_y"] = pos, feats, y
+            if sp is not None:
+                d["_sample_predict"] = sp
+
+    def _sample_attr(name):   # noqa: N805 -- class-body helper
+        def get(self):
+            self._materialise_samples()
+            return self.__dict__.get("_" + name)
+
+        def put(self, value):
+            self.__dict__["_" + name] = value
+
+        return property(get, put)
+
+    sample_ixs = _sample_attr("sample_ixs")
+    sample_features = _sample_attr("sample_features")
+    sample_y = _sample_attr("sample_y")
+    sample_predict = _sample_attr("sample_predict")
+    del _sample_attr
+
+    def _models_on_device(self):
+        """fit() keeps an iteration on the device from the sampling step to the candidate selection when everything
+        in between is the reference's default: device metric, the built-in stratified sampler / regression / error
+        model on the double anchor distance, and ols='device'."""
+        return (self._pipelined and self._device_metric and self.ols == "device" and self._sampler_on_device()
+                and type(self.sampler) is SimpleStratifiedSampler
+                and type(self.regression) is SimpleStratifiedLinearRegression
+                and list(self.regression.reg_feature_names) == ["lower bound", "upper bound", "double anchor distance"]
+                and self.regression.partition_feature_name == "double anchor distance"
+                and type(self.error_predictor) is SimpleStratifiedErrorRegression
+                and self.error_predictor.partition_feature_name == "double anchor distance")
+
     # --------------------------------------------------------------------- stages
     def _pair_list_stage(self, what):
         if getattr(self, "_enemy_extended", False):
@@ -320,6 +406,13 @@ class Annchor:
             ticket, self._sample_ticket = self._sample_ticket, None
             if ticket is None:
                 ticket = self.sampler.begin_device(eng, self.n_samples, self.random_seed, overlap=False)
+            if self._models_on_device():   # ... and everything stays there: the models are fitted on the device
+                _, self.n_samples, self.sample_bins = self.sampler.finish_device(ticket, evaluate="device")
+                self._samples_on_device, self._samples_m, self._predict_on_device = True, self.n_samples, False
+                self._invalidate("ncm")
+                self.evals += self.n_samples
+                return
+            self._samples_on_device = False
             if self._device_metric:   # positions, feature rows and distances in one device pass
                 (self.sample_ixs, self.n_samples, self.sample_bins, self.sample_features,
                  self.sample_y) = self.sampler.finish_device(ticket, evaluate=True)
@@ -344,6 +437,14 @@ class Annchor:
     def fit_predict_regression(self):
         """annchor.py:345-380."""
         self._pair_list_stage("fit_predict_regression")
+        self._model_on_device = False
+        if self.__dict__.get("_samples_on_device") and self._models_on_device() and not self.__dict__.get("_host_model_redo"):
+            # per-partition OLS + predict / clip / merge / label on the device, no host wait (csrc/model.hip)
+            self._engine.fit_regression_device(self.sample_bins, self._first_merge, self.is_metric)
+            self._model_on_device, self._predict_on_device, self._fused_labels = True, True, True
+            self._first_merge = False
+            self._invalidate("RA", "labels")
+            return
         self.regression.fit(self.sample_features, self.feature_names, self.sample_y, sample_bins=self.sample_bins)
         model = self.regression.coefficients() if type(self.regression) is SimpleStratifiedLinearRegression else None
         self._fused_labels = False
@@ -371,6 +472,12 @@ class Annchor:
             # the mask only -- launch them now, they run while the error model is fitted on the host
             nn = self.n_neighbors
             self._engine.select_prepare(nn, 3 * nn // 2 if self._fit_it == 0 else 0)
+        if self.__dict__.get("_model_on_device"):
+            self._engine.fit_errors_device()   # sorted residuals per partition, on the device
+            self._invalidate("labels")
+            if self._fit_it is not None and self.__dict__.get("_make_stream"):
+                self._make_stream(self._fit_it + 1)   # the GPU is busy with this iteration's models: produce the next draw's stream
+            return
         self.error_predictor.fit(self.sample_features, self.feature_names, self.sample_y - self.sample_predict,
                                  sample_bins=self.sample_bins)
         if not self._fused_labels:
@@ -382,15 +489,29 @@ class Annchor:
         """annchor.py:395-473."""
         self._pair_list_stage("select_refine_candidate_pairs")
         nn = self.n_neighbors
-        labels = list(self.error_predictor.labels)
-        errs = [np.asarray(self.error_predictor.errs[lab], dtype=np.float64) for lab in labels]
-        if labels != list(range(len(labels))):
-            raise NotImplementedError("error_predictor.labels must be 0..L-1 (got %r): the device label array "
-                                      "indexes the residual lists by position" % (labels[:8],))
         n_refine = int((self.p_work * self.N - self.na - self.n_samples) * w) + 1  # annchor.py:440
         n_refine = 0 if n_refine < 0 else n_refine
         nmin = 3 * nn // 2 if it == 0 else 0
-        ncand, nnext = self._engine.select_candidates(nn, nmin, errs, n_refine, self.lookahead)
+        if self.__dict__.get("_model_on_device"):
+            nb = len(self.sample_bins) - 1
+            ncand, nnext = self._engine.select_candidates(nn, nmin, None, n_refine, self.lookahead, n_labels=nb)
+            if not self._adopt_device_model(nb):
+                # a partition the device solver does not take (rank deficient, too few rows) or a failed sample step:
+                # redo the iteration's models on the host path (dgelsd) -- nothing has been refined yet
+                self._model_on_device, self._host_model_redo = False, True
+                try:
+                    self.fit_predict_regression()
+                    self.fit_predict_errors()
+                finally:
+                    self._host_model_redo = False
+                return self.select_refine_candidate_pairs(w=w, it=it)
+        else:
+            labels = list(self.error_predictor.labels)
+            errs = [np.asarray(self.error_predictor.errs[lab], dtype=np.float64) for lab in labels]
+            if labels != list(range(len(labels))):
+                raise NotImplementedError("error_predictor.labels must be 0..L-1 (got %r): the device label array "
+                                          "indexes the residual lists by position" % (labels[:8],))
+            ncand, nnext = self._engine.select_candidates(nn, nmin, errs, n_refine, self.lookahead)
         self.n_refine = n_refine
         self._invalidate("RA", "thresh", "cand", "next")
         if self._pipelined and self._device_metric and ncand and it < self.niters - 1 and self._sampler_on_device():
@@ -406,6 +527,23 @@ class Annchor:
             self._engine.set_refined(exact)
         self.evals += ncand
         self._invalidate("RA", "ncm")
+
+    def _adopt_device_model(self, nb):
+        """After a device-fitted iteration: the coefficients into the regression object (what its fit() would have
+        left there) and the sticky flags; False when the host has to redo the models."""
+        W, c, status, ep, flags = self._engine.model_download(nb)
+        if flags[0]:
+            raise _native.NativeError("sample step: a (bin, rank) entry does not exist (stale counts?)")
+        if flags[1] or flags[2] or status.any():
+            self._device_model_refused = (status.copy(), flags.copy())   # (kept for diagnostics / tests)
+            return False
+        reg = self.regression
+        reg.n_partitions, reg.sample_bins, reg.coef_, reg.intercept_ = nb, self.sample_bins, W, c
+        self._device_err_ptr = ep
+        ep_ = self.error_predictor
+        ep_.partition_bins, ep_.n_partitions, ep_.labels = self.sample_bins, nb, range(nb)
+        ep_.errs = _LazyErrs(self._engine, ep)
+        return True
 
     @property
     def nextback(self):
@@ -438,11 +576,19 @@ class Annchor:
             return self
         origin = time.perf_counter()
         t = self.timings = {}
-        if self._sampler_on_device() and type(self.sampler) is SimpleStratifiedSampler:
-            # the sampler's MT19937 streams depend on the seeds only: produce them on host
-            # threads while the GPU runs the stages before each sampling step
-            for it in range(self.niters):
-                _native.legacy_prefetch(self.random_seed + self.sampler.loop_num + it, self.N + self.N // 2 + 4096)
+        legacy_rng = self._sampler_on_device() and type(self.sampler) is SimpleStratifiedSampler
+        ndraws = self.N + self.N // 2 + 4096
+        seed0 = self.random_seed + getattr(self.sampler, "loop_num", 0)
+
+        def make_stream(it):
+            """The sampler's MT19937 stream of iteration `it` depends on the seed only: produced on THIS thread (warm
+            core, ~0.4 ms) at a point where the host would otherwise just wait for the GPU."""
+            if legacy_rng and it < self.niters:
+                s = time.perf_counter()
+                _native.legacy_generate(seed0 + it, ndraws)
+                t["rng_stream"] = t.get("rng_stream", 0.0) + time.perf_counter() - s   # (overlaps GPU work; not a stage)
+
+        self._make_stream = make_stream
 
         def stage(name, fn, *a, **k):
             s = time.perf_counter()
@@ -452,11 +598,28 @@ class Annchor:
                 print("%40s: %6.3f | %6.3f" % (name, time.perf_counter() - s, time.perf_counter() - origin))
 
         self._pipelined = True
+        try:
+            return self._fit_stages(stage, make_stream, t, origin)
+        finally:   # (an exception inside a stage -- NothingToSample, a plugin error -- must not leave the object in pipelined mode)
+            self._pipelined, self._fit_it, self._sample_ticket = False, None, None
+            self._make_stream = None
+
+    def _fit_stages(self, stage, make_stream, t, origin):
         stage("get_anchors", self.get_anchors)
+        legacy_rng = self._sampler_on_device() and type(self.sampler) is SimpleStratifiedSampler
+        ndraws = self.N + self.N // 2 + 4096
+        seed0 = self.random_seed + getattr(self.sampler, "loop_num", 0)
+        fused = self._models_on_device()
+        if self._anchors_on_device:
+            make_stream(0)      # the anchor rounds (a chain of dependent launches) are running: nothing to wait for yet
+        elif legacy_rng:
+            _native.legacy_prefetch(seed0, ndraws)
         stage("get_locality", self.get_locality)
         stage("get_features", self.get_features)
         niters = self.niters
         for it in range(niters):
+            if legacy_rng and not fused and it + 1 < niters:
+                _native.legacy_prefetch(seed0 + it + 1, ndraws)   # host-fitted models keep this thread busy: a producer thread
             try:
                 stage("get_sample", self.get_sample)
             except NothingToSample as err:
@@ -472,7 +635,6 @@ class Annchor:
             if it < niters - 1:
                 stage("update_anchor_points", self.update_anchor_points)
         stage("get_ann", self.get_ann)
-        self._pipelined = False
         t["total"] = time.perf_counter() - origin
         return self
 

@@ -87,6 +87,16 @@ struct annchor_ctx {
 
     // ---- samples
     DevBuf spos, sy;  // int32 [m], double [m]
+    DevBuf sfeat, spred;   // double [m][4] feature rows / double [m] unclipped predictions of the samples (device-resident model fit)
+    // ---- device-resident model of an iteration (model.hip): per-partition OLS coefficients, residual lists
+    DevBuf model;          // DeviceModel
+    DevBuf ols_scratch;    // double [nb][4][m]: a partition's centred design matrix and targets
+    bool model_fitted = false;   // `model` holds this iteration's regression
+    bool errs_on_device = false; // `errs` / `errptr` hold this iteration's sorted residuals (annchor_fit_errors_device)
+    int model_nb = 0;
+    DevBuf dev_flags;      // int32 [16] sticky error flags raised by kernels, read with the selection stage's final state:
+                           // [0] sample step: a (bin, rank) entry did not exist
+    bool dev_flags_clean = false;
     DevBuf hs_key, hs_pos, hs_misc;   // hashed stratified sampling: per-partition candidate lists, counters / outputs
     int64_t nsamp = 0;
 
@@ -215,6 +225,23 @@ template <typename T> __device__ __forceinline__ T ann_load(const T *p, bool str
     return stream ? __builtin_nontemporal_load(p) : *p;
 }
 
+// ---- the stratified regression model (regressors.py:39-103), host- or device-resident
+#define MAXBINS 64
+struct RegModel {
+    double e[MAXBINS + 1];
+    double w[MAXBINS][3];
+    double c[MAXBINS];
+    int nb;
+};
+// the model of one iteration as the device fits it (annchor_fit_regression_device / annchor_fit_errors_device)
+struct DeviceModel {
+    RegModel reg;
+    int32_t status[MAXBINS];     // per partition: 0 ok, 1 (numerically) rank deficient, 2 fewer rows than columns, 3 list too long
+    int32_t err_status;          // residual lists: 0 ok, 1 an empty partition, 2 a partition longer than the sorter takes
+    int64_t rows[MAXBINS];       // samples per regression partition
+    int64_t errptr[MAXBINS + 1]; // offsets of the partitions' sorted residuals in `errs`
+};
+
 // ---- internal cross-file entry points -------------------------------------
 // metric on a device pair list: out[t] (and optionally RA[pos[t]] = d, ncm[pos[t]] = 0)
 struct PairSource {
@@ -251,3 +278,6 @@ int ann_kth_smallest(annchor_ctx *c, const double *vals, const uint8_t *flag, in
                      int nk, double *h_out);
 
 int ann_set_anchor_flags(annchor_ctx *c, const int64_t *hA, int nA);
+// predict + clip + merge + label over all pairs and the samples' unclipped predictions, from a model in DEVICE memory
+int ann_dev_flags(annchor_ctx *c);   // reserve + zero the sticky flags once per context
+int ann_predict_merge_device(annchor_ctx *c, const RegModel *d_model, int first_iteration, int is_metric);

@@ -257,7 +257,6 @@ extern "C" int annchor_kth_uncomputed_dad(annchor_ctx *c, const int64_t *ks, int
     return ann_kth_smallest(c, c->dad.as<double>(), c->ncm.as<uint8_t>(), c->n, ks, nk, out);
 }
 
-#define MAXBINS 64
 struct BinEdges {
     double e[MAXBINS + 1];
     int nb;
@@ -767,6 +766,14 @@ __global__ void k_clear_flags_stage(const int32_t *__restrict__ pos, int64_t m, 
     if (t == 0) *st_bad = *bad;
 }
 
+__global__ void k_clear_flags_sticky(const int32_t *__restrict__ pos, int64_t m, uint8_t *__restrict__ ncm,
+                                     const int32_t *__restrict__ bad, int32_t *__restrict__ flags)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m) ncm[pos[t]] = 0;
+    if (t == 0 && *bad) flags[0] = 1;
+}
+
 extern "C" int annchor_evaluate_samples(annchor_ctx *c, const int64_t *pos, int64_t m, double *sample_y)
 {
     if (!c || (m > 0 && (!pos || !sample_y))) return ANNCHOR_EINVAL;
@@ -865,6 +872,70 @@ __global__ void k_i32_to_i64_pos(const int32_t *__restrict__ in, int64_t m, int6
     if (t < m) out[t] = in[t];
 }
 
+// The same sampling step with everything left on the device (the device-resident model fit of model.hip follows):
+// positions in spos (int32), feature rows in sfeat [m][4], exact distances in sy; a missing (bin, rank) entry raises
+// the sticky flag dev_flags[0], read with the selection stage's final state.
+extern "C" int annchor_sample_pairs_device(annchor_ctx *c, const double *bins, int32_t nbins, const int64_t *counts,
+                                           const int32_t *bin_of, const int64_t *ranks, int64_t nreq)
+{
+    if (!c || !bins || !counts || (nreq > 0 && (!bin_of || !ranks))) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_REQUIRE(c, c->metric != ANNCHOR_METRIC_NONE, ANNCHOR_EINVAL, "no device metric bound to this context");
+    c->nsamp = nreq;
+    if (nreq == 0) return ANNCHOR_OK;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(ann_reserve(c, c->stage_out, sizeof(int64_t) * (size_t)nreq));
+    ANN_TRY(ann_reserve(c, c->spos, sizeof(int32_t) * (size_t)nreq + 16));
+    ANN_TRY(ann_reserve(c, c->sy, sizeof(double) * (size_t)nreq));
+    ANN_TRY(ann_reserve(c, c->sfeat, sizeof(double) * 4 * (size_t)nreq));
+    ANN_TRY(ann_dev_flags(c));
+    int32_t *bad = c->spos.as<int32_t>() + nreq;
+    ANN_TRY(select_by_rank_device(c, bins, nbins, counts, bin_of, ranks, nreq, bad));   // positions -> stage_out[0 .. nreq); *bad = 0
+    k_pos_to_i32<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->stage_out.as<int64_t>(), nreq, c->spos.as<int32_t>(), bad);
+    k_gather_features<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), nreq, c->lb.as<double>(),
+                                                                   c->ub.as<double>(), c->dad.as<double>(), c->anc.as<uint8_t>(),
+                                                                   c->sfeat.as<double>());
+    PairSource src;
+    src.ij = c->ij.as<int2>();
+    src.idx = c->spos.as<int32_t>();
+    src.n = nreq;
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    ANN_TRY(ann_metric_launch(c, src, c->sy.as<double>(), nullptr, nullptr));
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+    c->call_timed = true;
+    k_clear_flags_sticky<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), nreq, c->ncm.as<uint8_t>(), bad,
+                                                                      c->dev_flags.as<int32_t>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    if (c->n_unc >= 0) c->n_unc -= nreq;
+    c->sel_prepared = false;
+    return ANNCHOR_OK;
+}
+
+// The last sampling step's arrays for the host (plugin-visible attributes; not on the fit path): positions int64 [m],
+// feature rows float64 [m][4], distances float64 [m], unclipped predictions float64 [m] (NULL: skip).
+extern "C" int annchor_download_samples(annchor_ctx *c, int64_t *positions, double *feats, double *sample_y, double *sample_predict)
+{
+    if (!c) return ANNCHOR_EINVAL;
+    const int64_t m = c->nsamp;
+    if (m == 0) return ANNCHOR_OK;
+    ANN_REQUIRE(c, c->sfeat.p && c->spos.p && c->sy.p, ANNCHOR_ESTATE, "no device-resident sample on this context");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    if (positions) {
+        ANN_TRY(ann_reserve(c, c->stage_out, sizeof(int64_t) * (size_t)m));
+        k_i32_to_i64_pos<<<ann_blocks(m, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), m, c->stage_out.as<int64_t>());
+        ANN_CHECK_HIP(c, hipGetLastError());
+        ANN_TRY(ann_d2h(c, positions, c->stage_out.p, sizeof(int64_t) * (size_t)m));
+    }
+    if (feats) ANN_TRY(ann_d2h(c, feats, c->sfeat.p, sizeof(double) * 4 * (size_t)m));
+    if (sample_y) ANN_TRY(ann_d2h(c, sample_y, c->sy.p, sizeof(double) * (size_t)m));
+    if (sample_predict) {
+        ANN_REQUIRE(c, c->spred.p, ANNCHOR_ESTATE, "no predictions for the current sample");
+        ANN_TRY(ann_d2h(c, sample_predict, c->spred.p, sizeof(double) * (size_t)m));
+    }
+    return ANNCHOR_OK;
+}
+
+
 // annchor_hash_sample + annchor_gather_features + annchor_evaluate_samples in one call (device metric):
 // positions, feature rows and exact distances come back in one transfer.
 extern "C" int annchor_hash_sample_pairs(annchor_ctx *c, const double *bins, int32_t nbins, const int64_t *counts, const int64_t *want,
@@ -936,13 +1007,6 @@ extern "C" int annchor_set_samples(annchor_ctx *c, const int64_t *pos, int64_t m
 }
 
 // ------------------------------------------------- predict / clip / label / merge
-struct RegModel {
-    double e[MAXBINS + 1];
-    double w[MAXBINS][3];
-    double c[MAXBINS];
-    int nb;
-};
-
 __device__ __forceinline__ double reg_predict(const RegModel &m, double l, double u, double d)
 {
     // regression bin: lo < F <= hi (regressors.py:84-87); pairs outside every bin keep 0
@@ -962,7 +1026,7 @@ __device__ __forceinline__ int err_label(const RegModel &m, double d)
     return b;
 }
 
-__global__ __launch_bounds__(256) void k_predict_merge(int64_t n, RegModel m, int first, int is_metric,
+__global__ __launch_bounds__(256) void k_predict_merge(int64_t n, const RegModel *__restrict__ mp, int first, int is_metric,
                                                       const int2 *__restrict__ ij, const double *__restrict__ Dt,
                                                       int64_t nx, const int32_t *__restrict__ anchorRank,
                                                       const double *__restrict__ lb, const double *__restrict__ ub,
@@ -972,6 +1036,7 @@ __global__ __launch_bounds__(256) void k_predict_merge(int64_t n, RegModel m, in
 {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
+    const RegModel &m = *mp;   // uniform address: scalar loads
     const double l = ann_load(lb + p, stream), u = ann_load(ub + p, stream), d = ann_load(dad + p, stream);
     double pr = reg_predict(m, l, u, d);
     pr = fmin(fmax(pr, l), u);  // np.clip(pred, lb, ub)
@@ -988,15 +1053,40 @@ __global__ __launch_bounds__(256) void k_predict_merge(int64_t n, RegModel m, in
 }
 
 __global__ void k_sample_predict_scatter(const int32_t *__restrict__ pos, const double *__restrict__ sy, int64_t ms,
-                                         RegModel m, const double *__restrict__ lb, const double *__restrict__ ub,
+                                         const RegModel *__restrict__ mp, const double *__restrict__ lb, const double *__restrict__ ub,
                                          const double *__restrict__ dad, double *__restrict__ RA,
                                          double *__restrict__ spred)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ms) return;
+    const RegModel &m = *mp;
     const int32_t p = pos[t];
     spred[t] = reg_predict(m, lb[p], ub[p], dad[p]);  // unclipped (annchor.py:357)
     RA[p] = sy[t];                                    // annchor.py:380
+}
+
+int ann_predict_merge_device(annchor_ctx *c, const RegModel *d_model, int first_iteration, int is_metric)
+{
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    {
+        // algorithmic bytes per pair: 3*8 read (lb, ub, dad) + 1 (mask) + 8 (RA) + 1 (label)
+        ProfScope ps(c, "predict_clip_label_merge", (double)c->n * 34.0);
+        k_predict_merge<<<ann_blocks(c->n, 256), 256, 0, c->stream>>>(
+            c->n, d_model, first_iteration, is_metric, c->ij.as<int2>(), c->Dt.as<double>(), c->nx, c->anchorRank.as<int32_t>(),
+            c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>(), c->anc.as<uint8_t>(), c->ncm.as<uint8_t>(),
+            c->RA.as<double>(), c->label.as<uint8_t>(), c->n >= ANN_STREAM_MIN_PAIRS);
+    }
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+    c->call_timed = true;
+    c->have_RA = true; c->sel_prepared = false;
+    if (c->nsamp > 0) {
+        ANN_TRY(ann_reserve(c, c->spred, sizeof(double) * (size_t)c->nsamp));
+        k_sample_predict_scatter<<<ann_blocks(c->nsamp, 256), 256, 0, c->stream>>>(
+            c->spos.as<int32_t>(), c->sy.as<double>(), c->nsamp, d_model, c->lb.as<double>(), c->ub.as<double>(),
+            c->dad.as<double>(), c->RA.as<double>(), c->spred.as<double>());
+    }
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
 }
 
 extern "C" int annchor_predict_merge(annchor_ctx *c, const double *bins, int32_t nb, const double *W, const double *cc,
@@ -1008,33 +1098,18 @@ extern "C" int annchor_predict_merge(annchor_ctx *c, const double *bins, int32_t
     ANN_REQUIRE(c, first_iteration || c->have_RA, ANNCHOR_EINVAL, "RefineApprox not initialised");
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     RegModel m;
+    memset(&m, 0, sizeof m);
     m.nb = nb;
     for (int k = 0; k <= nb; ++k) m.e[k] = bins[k];
     for (int k = 0; k < nb; ++k) {
         m.w[k][0] = W[3 * k]; m.w[k][1] = W[3 * k + 1]; m.w[k][2] = W[3 * k + 2];
         m.c[k] = cc[k];
     }
-    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
-    {
-        // algorithmic bytes per pair: 3*8 read (lb, ub, dad) + 1 (mask) + 8 (RA) + 1 (label)
-        ProfScope ps(c, "predict_clip_label_merge", (double)c->n * 34.0);
-        k_predict_merge<<<ann_blocks(c->n, 256), 256, 0, c->stream>>>(
-            c->n, m, first_iteration, is_metric, c->ij.as<int2>(), c->Dt.as<double>(), c->nx, c->anchorRank.as<int32_t>(),
-            c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>(), c->anc.as<uint8_t>(), c->ncm.as<uint8_t>(),
-            c->RA.as<double>(), c->label.as<uint8_t>(), c->n >= ANN_STREAM_MIN_PAIRS);
-    }
-    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
-    c->call_timed = true;
-    c->have_RA = true; c->sel_prepared = false;
-    if (c->nsamp > 0) {
-        ANN_TRY(ann_reserve(c, c->stage_out, sizeof(double) * (size_t)c->nsamp));
-        k_sample_predict_scatter<<<ann_blocks(c->nsamp, 256), 256, 0, c->stream>>>(
-            c->spos.as<int32_t>(), c->sy.as<double>(), c->nsamp, m, c->lb.as<double>(), c->ub.as<double>(),
-            c->dad.as<double>(), c->RA.as<double>(), c->stage_out.as<double>());
-        ANN_CHECK_HIP(c, hipGetLastError());
-        if (sample_predict) ANN_TRY(ann_d2h(c, sample_predict, c->stage_out.p, sizeof(double) * (size_t)c->nsamp));
-    }
-    ANN_CHECK_HIP(c, hipGetLastError());
+    ANN_TRY(ann_reserve(c, c->model, sizeof(DeviceModel)));
+    ANN_TRY(ann_h2d(c, c->model.p, &m, sizeof m));   // (DeviceModel begins with its RegModel)
+    c->model_fitted = false; c->errs_on_device = false;
+    ANN_TRY(ann_predict_merge_device(c, c->model.as<RegModel>(), first_iteration, is_metric));
+    if (c->nsamp > 0 && sample_predict) ANN_TRY(ann_d2h(c, sample_predict, c->spred.p, sizeof(double) * (size_t)c->nsamp));
     return ANNCHOR_OK;
 }
 

@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void k_ecdf_index(const double *__restrict__ e
 __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict__ ij, const double *__restrict__ thresh,
                                              const double *__restrict__ RA, const uint8_t *__restrict__ ncm,
                                              const uint8_t *__restrict__ label, const double *__restrict__ errs,
-                                             const int64_t *__restrict__ errptr, int nlabels, int errs_in_lds,
+                                             const int64_t *__restrict__ errptr, int nlabels, int lds_cap_entries,
                                              double *__restrict__ prob, int stream, const EcdfIndex *__restrict__ index,
                                              const uint32_t *__restrict__ table)
 {
@@ -616,6 +616,8 @@ __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict_
     __shared__ int64_t lptr[257];
     for (int t = threadIdx.x; t <= nlabels; t += blockDim.x) lptr[t] = errptr[t];
     __syncthreads();
+    // (the lists' total length is only known on the device when they were fitted there: annchor_fit_errors_device)
+    const bool errs_in_lds = lptr[nlabels] <= (int64_t)lds_cap_entries;
     if (errs_in_lds) {
         const int64_t tot = lptr[nlabels];
         for (int64_t t = threadIdx.x; t < tot; t += blockDim.x) le[t] = errs[t];
@@ -1274,12 +1276,17 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
                                          const int64_t *err_ptr, int32_t nlabels, int64_t n_refine, int32_t lookahead,
                                          int64_t *n_cand, int64_t *n_next)
 {
-    if (!c || !errs || !err_ptr || !n_cand || !n_next) return ANNCHOR_EINVAL;
+    if (!c || (errs && !err_ptr) || !n_cand || !n_next) return ANNCHOR_EINVAL;
     ANN_REQUIRE(c, c->have_RA, ANNCHOR_EINVAL, "RefineApprox not initialised");
+    // errs == NULL: the residual lists annchor_fit_errors_device left in device memory (nlabels = its partitions)
+    const bool dev_errs = errs == nullptr;
+    ANN_REQUIRE(c, !dev_errs || (c->errs_on_device && nlabels == c->model_nb), ANNCHOR_ESTATE,
+                "no device-resident residual lists for %d labels (annchor_fit_errors_device)", nlabels);
     ANN_REQUIRE(c, nlabels >= 1 && nlabels <= 255, ANNCHOR_ELIMIT, "1..255 error labels supported");
     ANN_REQUIRE(c, n_neighbors >= 1 && lookahead >= 1 && n_refine >= 0, ANNCHOR_EINVAL, "bad selection parameters");
-    for (int b = 0; b < nlabels; ++b)
-        ANN_REQUIRE(c, err_ptr[b + 1] > err_ptr[b], ANNCHOR_ESTATE, "error bin %d has no samples", b);
+    if (!dev_errs)
+        for (int b = 0; b < nlabels; ++b)
+            ANN_REQUIRE(c, err_ptr[b + 1] > err_ptr[b], ANNCHOR_ESTATE, "error bin %d has no samples", b);
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     const int64_t n = c->n, nx = c->nx;
     if (!(c->sel_prepared && c->sel_k == n_neighbors && c->sel_nmin == nmin)) ANN_TRY(select_stage_a(c, n_neighbors, nmin));
@@ -1287,14 +1294,21 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     ANN_TRY(select_stage_finish(c));
     (void)nx;
     // ---- probabilities
-    const int64_t nerr = err_ptr[nlabels];
-    ANN_TRY(ann_reserve(c, c->errs, sizeof(double) * (size_t)nerr));
-    ANN_TRY(ann_reserve(c, c->errptr, sizeof(int64_t) * (size_t)(nlabels + 1)));
-    ANN_TRY(ann_h2d(c, c->errs.p, errs, sizeof(double) * (size_t)nerr));
-    ANN_TRY(ann_h2d(c, c->errptr.p, err_ptr, sizeof(int64_t) * (size_t)(nlabels + 1)));
+    // device-resident lists: their exact total is on the device; a sample on an inner edge counts twice, so <= 2 m
+    const int64_t nerr = dev_errs ? 2 * c->nsamp + 64 : err_ptr[nlabels];   // (upper bound when the lists live on the device)
+    if (!dev_errs) {
+        ANN_TRY(ann_reserve(c, c->errs, sizeof(double) * (size_t)nerr));
+        ANN_TRY(ann_reserve(c, c->errptr, sizeof(int64_t) * (size_t)(MAXBINS > nlabels ? MAXBINS + 1 : nlabels + 1)));
+        ANN_TRY(ann_h2d(c, c->errs.p, errs, sizeof(double) * (size_t)nerr));
+        ANN_TRY(ann_h2d(c, c->errptr.p, err_ptr, sizeof(int64_t) * (size_t)(nlabels + 1)));
+        c->errs_on_device = false;
+    }
     {
-        const int in_lds = nerr * 8 <= 60 * 1024;
-        const size_t dyn = in_lds ? (size_t)nerr * 8 : 0;
+        // LDS copy of the lists: exact size known (host lists), or room for the usual case of the device lists (every
+        // sample once + a few on shared edges); the kernel checks the real total against the capacity
+        const int64_t lds_entries = dev_errs ? c->nsamp + 64 : nerr;
+        const int in_lds = lds_entries * 8 <= 60 * 1024;
+        const size_t dyn = in_lds ? (size_t)lds_entries * 8 : 0;
         int blocks = min(ann_blocks(n, 256 * 8), c->prop.multiProcessorCount * 8);
         // algorithmic bytes per pair: 8 (ij) + 8 (RA) + 2 (mask, label) + 8 (prob)
         ProfScope ps(c, "ecdf_probability", (double)n * 26.0);
@@ -1311,7 +1325,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         }
         k_prob<<<blocks, 256, dyn, c->stream>>>(n, c->ij.as<int2>(), c->thresh.as<double>(), c->RA.as<double>(),
                                                c->ncm.as<uint8_t>(), c->label.as<uint8_t>(), c->errs.as<double>(),
-                                               c->errptr.as<int64_t>(), nlabels, in_lds, c->prob.as<double>(), n >= ANN_STREAM_MIN_PAIRS,
+                                               c->errptr.as<int64_t>(), nlabels, in_lds ? (int)lds_entries : 0, c->prob.as<double>(), n >= ANN_STREAM_MIN_PAIRS,
                                                index, table);
     }
     ANN_CHECK_HIP(c, hipGetLastError());

@@ -182,6 +182,11 @@ class SimpleStratifiedSampler(Sampler):
         self.loop_num += 1
         bin_of, ranks = np.concatenate(bin_of), np.concatenate(ranks)
         extra = ()
+        if evaluate == "device":   # positions, feature rows and distances stay in device memory (no host wait)
+            m = engine.sample_pairs_device(sample_bins, ticket["counts"], bin_of, ranks)
+            if n_samples != m:
+                print("Warning: Some bins contained fewer samples than requested")
+            return None, m, sample_bins
         if evaluate:
             sample_ixs, feats, y = engine.sample_pairs(sample_bins, ticket["counts"], bin_of, ranks)
             extra = (feats, y)

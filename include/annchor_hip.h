@@ -156,6 +156,10 @@ int annchor_select_by_rank(annchor_ctx *ctx, const double *bins, int32_t nbins, 
  * depends on the seed only); a later annchor_legacy_choice_ranks(seed, ...) consumes it.
  * Purely an overlap device: results are identical with or without it. */
 int annchor_legacy_prefetch(uint32_t seed, int64_t ndraws);
+/* The same stream generated on the CALLING thread before the call returns (a warm core: ~0.4 ms for the 1.9 M words of
+ * a C2 sampling step, against ~2 ms on a freshly woken producer thread); fit() calls it while the GPU runs a stage the
+ * host would otherwise only wait for. */
+int annchor_legacy_generate(uint32_t seed, int64_t ndraws);
 int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins,
                                 int64_t *ranks_out, int64_t *n_out);
 /* The same draw on the library's persistent worker thread (warm core, warm caches), so that it
@@ -204,10 +208,35 @@ int annchor_merge_host_prediction(annchor_ctx *ctx, const double *pred, int32_t 
                                   int32_t is_metric);
 int annchor_set_labels(annchor_ctx *ctx, const int64_t *labels);
 
+/* ------------------------------------------- a11-a13 with the iteration's models fitted on the device
+ * The same three stages -- get_sample (annchor.py:313-343), fit_predict_regression (annchor.py:345-380,
+ * regressors.py:39-103), fit_predict_errors (annchor.py:382-393, error_predictors.py:26-53) -- without a host round
+ * trip between them, for the reference's default plugins and a device metric:
+ *   annchor_sample_pairs_device   = annchor_sample_pairs, results left in device memory;
+ *   annchor_fit_regression_device = per-partition OLS with intercept on (lb, ub, dad) -> y (Householder QR on the centred
+ *     samples, float64; coefficients agree with the reference's LAPACK dgelsd solution to ~1e-13 relative, not bit for
+ *     bit -- annchor_predict_merge with host-fitted coefficients remains for that), then the fused predict / clip /
+ *     merge / label pass from the coefficients in place;
+ *   annchor_fit_errors_device     = per-partition sorted residuals into the context (annchor_select_candidates with
+ *     errs == NULL reads them there).
+ * Nothing waits for the host.  Problems a kernel finds (a sampled (bin, rank) that does not exist, a partition the QR
+ * does not take -- rank deficient or fewer rows than columns --, an empty residual list) raise sticky flags that
+ * annchor_model_download returns (and clears) together with the fitted coefficients; the caller redoes the step on
+ * the host path then.  annchor_download_samples / annchor_errors_download materialise the sample arrays and the
+ * residual lists for the host (plugin-visible attributes; not on the fit path). */
+int annchor_sample_pairs_device(annchor_ctx *ctx, const double *bins, int32_t nbins, const int64_t *counts, const int32_t *bin_of,
+                                const int64_t *ranks, int64_t nreq);
+int annchor_download_samples(annchor_ctx *ctx, int64_t *positions, double *feats, double *sample_y, double *sample_predict);
+int annchor_fit_regression_device(annchor_ctx *ctx, const double *bins, int32_t nbins, int32_t first_iteration, int32_t is_metric);
+int annchor_fit_errors_device(annchor_ctx *ctx);
+int annchor_model_download(annchor_ctx *ctx, double *W, double *c, int32_t *status, int64_t *err_ptr, int32_t *flags /*[3]*/);
+int annchor_errors_download(annchor_ctx *ctx, double *errs, int64_t n_errs);
+
 /* --------------------------------------------------------------- selection a14
  * select_refine_candidate_pairs (annchor.py:395-473) up to, not including, the
  * metric call: thresh, guarantee_nmin (when nmin > 0), p, ECDF prob (errs:
- * concatenated sorted residuals, err_ptr int64 [nlabels+1]), top-n_refine and
+ * concatenated sorted residuals, err_ptr int64 [nlabels+1]; errs == NULL: the lists
+ * annchor_fit_errors_device left on the device), top-n_refine and
  * lookahead selection.  Ties at a cut (np.argpartition is arbitrary there): probability descending, then
  * the fixed pseudo-random order (position * 0x9E3779B97F4A7C15 mod 2^64) >> 11 ascending, then position
  * ascending. */

@@ -1,0 +1,97 @@
+"""The iteration's models fitted on the device (csrc/model.hip: per-partition OLS by Householder QR, residual lists)
+against the host path (scipy's dgelsd, the reference's solver: annchor/regressors.py:39-69,
+annchor/error_predictors.py:26-53) and against the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(__file__))
+
+from oracle import metrics as om  # noqa: E402
+
+
+def _strings():
+    return np.array(om.load_strings()[0])
+
+
+def _check_same_model(a, b):
+    """a: ols='device', b: ols='lapack' after fit(): same samples, coefficients to 1e-11 relative, same residual lists
+    to 1e-9 absolute, same graph."""
+    assert np.array_equal(a.sample_ixs, b.sample_ixs)
+    assert np.array_equal(a.sample_features, b.sample_features) and np.array_equal(a.sample_y, b.sample_y)
+    assert np.array_equal(a.regression.sample_bins, b.regression.sample_bins)
+    np.testing.assert_allclose(a.regression.coef_, b.regression.coef_, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(a.regression.intercept_, b.regression.intercept_, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(a.sample_predict, b.sample_predict, rtol=0, atol=1e-9)
+    assert list(a.error_predictor.labels) == list(b.error_predictor.labels)
+    for lab in b.error_predictor.labels:
+        np.testing.assert_allclose(a.error_predictor.errs[lab], b.error_predictor.errs[lab], rtol=0, atol=1e-9)
+    assert a.evals == b.evals
+
+
+@pytest.mark.parametrize("cfg", [dict(n_anchors=8, n_neighbors=10, n_samples=700, p_work=0.3, niters=2),
+                                 dict(n_anchors=12, n_neighbors=6, n_samples=300, p_work=0.2, niters=3)])
+def test_device_model_equals_lapack_model_strings_small(cfg):
+    from annchor_amd import Annchor
+
+    X = _strings()[::5]
+    a = Annchor(X, "levenshtein", ols="device", **cfg).fit()
+    b = Annchor(X, "levenshtein", ols="lapack", **cfg).fit()
+    assert a._model_on_device and not b.__dict__.get("_model_on_device")
+    _check_same_model(a, b)
+    assert np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1]) and np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0])
+
+
+def test_device_model_c2_graph_equals_lapack_graph_and_oracle():
+    """BASELINE configs[1]: the default (device-fitted models) gives the graph of the LAPACK path -- which is the
+    oracle's, bit for bit."""
+    from annchor_amd import Annchor
+
+    X = _strings()
+    cfg = dict(n_anchors=15, n_neighbors=25, p_work=0.12, random_seed=42)
+    a = Annchor(X, "levenshtein", **cfg).fit()
+    b = Annchor(X, "levenshtein", ols="lapack", **cfg).fit()
+    assert a.ols == "device" and a._model_on_device
+    _check_same_model(a, b)
+    assert np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1]) and np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0])
+    Go = np.load(os.path.join(os.path.dirname(__file__), "golden", "strings_full_oracle.npz"))
+    assert np.array_equal(a.neighbor_graph[1], Go["c1_ng_dist"].astype(np.float64))
+    assert np.array_equal(a.neighbor_graph[0], Go["c1_ng_idx"].astype(np.int64))
+
+
+def test_device_model_euclid_and_digits():
+    from annchor_amd import Annchor
+    from annchor_amd.datasets import load_digits
+
+    rng = np.random.default_rng(3)
+    X = (rng.standard_normal((1500, 5)) @ rng.standard_normal((5, 24))).astype(np.float64)
+    cfg = dict(n_anchors=10, n_neighbors=8, n_samples=1000, p_work=0.15)
+    a = Annchor(X, "euclidean", **cfg).fit()
+    b = Annchor(X, "euclidean", ols="lapack", **cfg).fit()
+    _check_same_model(a, b)
+    np.testing.assert_allclose(a.neighbor_graph[1], b.neighbor_graph[1], rtol=0, atol=0)
+    D = load_digits()
+    Xd = D["X"][:600]
+    cfg = dict(func_kwargs={"cost_matrix": D["cost_matrix"]}, n_anchors=10, n_neighbors=10, n_samples=1500, p_work=0.2)
+    a = Annchor(Xd, "wasserstein", **cfg).fit()
+    b = Annchor(Xd, "wasserstein", ols="lapack", **cfg).fit()
+    _check_same_model(a, b)
+    np.testing.assert_allclose(a.neighbor_graph[1], b.neighbor_graph[1], rtol=0, atol=0)
+
+
+def test_rank_deficient_partition_falls_back_to_the_host_solver():
+    """Integer grid data: inside a partition every sample can have the same double anchor distance (a constant
+    column after centring) -- the QR flags it, the host redoes the iteration with dgelsd's minimum-norm solution, and
+    the fit equals the LAPACK path's."""
+    from annchor_amd import Annchor
+
+    g = np.arange(12, dtype=np.float64)
+    X = np.stack(np.meshgrid(g, g), axis=-1).reshape(-1, 2)     # 144 grid points, massive ties
+    X = np.concatenate([X, X[:40]])                             # + duplicates
+    cfg = dict(n_anchors=4, n_neighbors=5, n_samples=300, p_work=0.5, locality=3)
+    a = Annchor(X, "euclidean", **cfg).fit()
+    b = Annchor(X, "euclidean", ols="lapack", **cfg).fit()
+    np.testing.assert_allclose(a.neighbor_graph[1], b.neighbor_graph[1], rtol=0, atol=0)
