@@ -34,6 +34,7 @@ _SIGNATURES = {
     "annchor_create_error": (ctypes.c_char_p, []),
     "annchor_device_name": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
     "annchor_device_pci_bus_id": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
+    "annchor_device_mem_info": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "annchor_synchronize": (ctypes.c_int, [_vp]),
     "annchor_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "annchor_set_strings": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32]),
@@ -162,6 +163,24 @@ def release_parked_contexts():
     """Free the runtime shells (stream, pinned staging, device slab) that destroyed engines left
     parked for the next one; returns how many there were."""
     return int(load_library().annchor_release_parked())
+
+
+PAIR_BYTES = 130            # device memory per candidate pair of the pair-list form (DESIGN.md section 2, with scratch)
+PAIR_LIST_MAX = (1 << 30) - 1   # int32 positions into the per-point index (two entries per pair)
+
+
+def pairlist_point_limit(device=0):
+    """Largest data set whose complete pair list (nx (nx - 1) / 2 candidates, the worst case of the locality filter) the
+    pair-list form will materialise on `device`: bounded by the int32 pair positions (2^30 pairs: 46 341 points) and by
+    80 % of the device's free memory at PAIR_BYTES per pair.  None when no device can be asked."""
+    f, t = _i64(), _i64()
+    try:
+        if load_library().annchor_device_mem_info(int(device), ctypes.byref(f), ctypes.byref(t)) != 0:
+            return None
+    except NativeError:
+        return None
+    pairs = min(PAIR_LIST_MAX, int(0.8 * f.value / PAIR_BYTES))
+    return int((1 + (1 + 8 * pairs) ** 0.5) // 2)
 
 
 def bind_to_device_numa(device=0):

@@ -30,7 +30,15 @@ from .distances import euclidean as distances_euclidean  # noqa: E402
 from .distances import cosine as distances_cosine  # noqa: E402
 
 PAIRLIST_MAX_POINTS = 30000   # float32 Euclidean / cosine data above this size takes the streamed (tile-granular) form
-PAIRLIST_HARD_MAX = 30000     # the candidate pair list (~nx^2 / 2 entries x ~100 B) is not materialised above this size
+PAIRLIST_HARD_MAX = None      # override (tests); None: from the device -- 2^30 candidate pairs (int32 positions) and 80 % of its free
+                              # memory at ~130 B per pair: 46 341 points on a 288 GB MI355X (_native.pairlist_point_limit)
+
+
+def pairlist_hard_max(device=0):
+    if PAIRLIST_HARD_MAX is not None:
+        return PAIRLIST_HARD_MAX
+    lim = _native.pairlist_point_limit(device)
+    return 30000 if lim is None else lim
 
 FEATURE_NAMES = ["lower bound", "upper bound", "double anchor distance", "is anchor"]
 
@@ -193,23 +201,32 @@ class Annchor:
         defaults = (anchor_picker is None and sampler is None and regression is None and error_predictor is None
                     and get_exact_ijs is None)
         can_stream = (bundled and defaults and Xa is not None and Xa.ndim == 2 and Xa.dtype == np.float32 and Xa.shape[1] <= 256)
+        if streamed == "cast":
+            # explicit opt-in: float64 (or integer) rows are narrowed to float32 and take the streamed form
+            if not (bundled and defaults and Xa is not None and Xa.ndim == 2 and Xa.shape[1] <= 256):
+                raise ValueError("streamed='cast' needs a numeric [n, dim <= 256] array, the 'euclidean' or 'cosine' metric and "
+                                 "the default plugins")
+            Xa = np.ascontiguousarray(Xa, dtype=np.float32)
+            can_stream, streamed = True, True
         if streamed is True and not can_stream:
             raise ValueError("streamed=True needs a float32 [n, dim <= 256] array, the 'euclidean' or 'cosine' metric and the "
-                             "default plugins (float64 data is not narrowed: convert it yourself if float32 distances are acceptable)")
+                             "default plugins (float64 data is not narrowed behind the caller's back: streamed='cast' narrows it)")
         want_stream = can_stream and (streamed is True or (streamed is None and self.nx > PAIRLIST_MAX_POINTS))
-        if not want_stream and self.nx > PAIRLIST_HARD_MAX:
-            raise ValueError("%d points: the candidate pair list of the reference form (~nx^2/2 entries) is only materialised up to "
-                             "%d points.  Larger sets need the streamed form: float32 [n, dim <= 256] data, 'euclidean' or "
-                             "'cosine', default plugins%s." % (self.nx, PAIRLIST_HARD_MAX,
-                                                             "" if streamed is not False else " (and streamed != False)"))
+        hard_max = PAIRLIST_MAX_POINTS if (want_stream or self.nx <= PAIRLIST_MAX_POINTS) else pairlist_hard_max(device)
+        self._pairlist_hard_max = hard_max
+        if not want_stream and self.nx > hard_max:
+            raise ValueError("%d points: the candidate pair list of the reference form (~nx^2/2 entries at ~130 B) is materialised "
+                             "up to %d points on this device (2^30 pairs / 80 %% of its free memory).  Larger sets need the streamed "
+                             "form: float32 [n, dim <= 256] data ('cast' narrows float64), 'euclidean' or 'cosine', default plugins%s."
+                             % (self.nx, hard_max, "" if streamed is not False else " (and streamed != False)"))
         if want_stream:
             from .streamed import StreamedAnnchor
 
             if streamed is None:
                 print("Note: %d float32 points under '%s': using the streamed (tile-granular) form -- anchors, a p_work tile budget "
                       "and %d neighbour-join passes (niters); n_samples, locality, loc_thresh, loc_min, lookahead and is_metric "
-                      "do not apply to it (streamed=False forces the pair-list form up to %d points)."
-                      % (self.nx, self.f.name, niters, PAIRLIST_HARD_MAX))
+                      "do not apply to it (streamed=False forces the pair-list form)."
+                      % (self.nx, self.f.name, niters))
             Xs = np.ascontiguousarray(Xa)
             if self.f is distances_cosine:
                 # on the unit sphere |u - v|^2 = 2 - 2 cos(u, v): cosine distance = (Euclidean distance)^2 / 2
@@ -481,9 +498,23 @@ class Annchor:
         self.error_predictor.fit(self.sample_features, self.feature_names, self.sample_y - self.sample_predict,
                                  sample_bins=self.sample_bins)
         if not self._fused_labels:
-            labels = self.error_predictor.predict(self.features, self.feature_names)
+            labels = self._label_slots(self.error_predictor.predict(self.features, self.feature_names))
             self._engine.set_labels(labels)
         self._invalidate("labels")
+
+    def _label_slots(self, labels):
+        """error_predictor.predict's labels as POSITIONS in error_predictor.labels -- arbitrary integer keys
+        (error_predictors.py:47 takes any) -- which is how the residual lists are handed to the device."""
+        labels = np.asarray(labels)
+        keys = list(self.error_predictor.labels)
+        if keys == list(range(len(keys))):
+            return labels
+        order = np.argsort(np.asarray(keys), kind="stable")
+        sk = np.asarray(keys)[order]
+        at = np.minimum(np.searchsorted(sk, labels), len(sk) - 1)
+        if not np.array_equal(sk[at], labels):
+            raise ValueError("error_predictor.predict returned a label that is not in error_predictor.labels")
+        return order[at]
 
     def select_refine_candidate_pairs(self, w=0.5, it=0):
         """annchor.py:395-473."""
@@ -506,11 +537,10 @@ class Annchor:
                     self._host_model_redo = False
                 return self.select_refine_candidate_pairs(w=w, it=it)
         else:
-            labels = list(self.error_predictor.labels)
+            labels = list(self.error_predictor.labels)   # (any integer keys: the device labels are positions in this list)
             errs = [np.asarray(self.error_predictor.errs[lab], dtype=np.float64) for lab in labels]
-            if labels != list(range(len(labels))):
-                raise NotImplementedError("error_predictor.labels must be 0..L-1 (got %r): the device label array "
-                                          "indexes the residual lists by position" % (labels[:8],))
+            if labels != list(range(len(labels))) and self._fused_labels:
+                raise NotImplementedError("the fused label pass numbers the partitions 0..L-1; got labels %r" % (labels[:8],))
             ncand, nnext = self._engine.select_candidates(nn, nmin, errs, n_refine, self.lookahead)
         self.n_refine = n_refine
         self._invalidate("RA", "thresh", "cand", "next")
@@ -701,7 +731,7 @@ class Annchor:
         else:
             feats = eng.download(_native.F_FEATURES).reshape(-1, 4)
             eng.merge_host_prediction(np.asarray(self.regression.predict(feats, self.feature_names), dtype=np.float64), True, True)
-            eng.set_labels(self.error_predictor.predict(feats, self.feature_names[:-1]))
+            eng.set_labels(self._label_slots(self.error_predictor.predict(feats, self.feature_names[:-1])))
         labels = list(self.error_predictor.labels)
         errs = [np.asarray(self.error_predictor.errs[lab], dtype=np.float64) for lab in labels]
         n_refine = int((p_work * nbf - na)) + 1                                           # query_functions.py:163-168
@@ -720,7 +750,7 @@ class Annchor:
     # ---------------------------------------------- nearest enemies / selective subset
     def _require_pair_list(self, what):
         if self._streamed is not None:
-            raise NotImplementedError(what + " needs the pair-list form (streamed=False, nx <= %d)" % PAIRLIST_HARD_MAX)
+            raise NotImplementedError(what + " needs the pair-list form (streamed=False)")
 
     def get_nearest_enemies(self, y, nn=3, loc_min=100):
         """annchor.py:685-782: the nn nearest points of a different label for every point;

@@ -106,6 +106,7 @@ struct annchor_ctx {
     int64_t ncand = 0, nnext = 0;
     bool cand_marked = false;      // not_computed_mask already cleared for the current candidates
     DevBuf gl_val, gl_pos, gl_cnt, gl_ncomp, marked, markcount;  // guarantee_nmin scratch
+    DevBuf gn_err;               // guarantee_nmin: int32 error flag of the sweep (read at the end of the selection stage)
     DevBuf gn_state;             // guarantee_nmin rounds: mark masks (2), out-of-list mark counts (3), change flags
     // selection stage split in two (annchor_select_prepare): thresholds + guarantee_nmin launched ahead, while the host
     // fits the error model; reset by everything that changes RefineApprox / the mask

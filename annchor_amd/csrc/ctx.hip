@@ -352,6 +352,17 @@ extern "C" int annchor_device_pci_bus_id(int device, char *buf, int buflen)
     return hipDeviceGetPCIBusId(buf, buflen, device) == hipSuccess ? ANNCHOR_OK : ANNCHOR_EHIP;
 }
 
+// free / total device memory in bytes (the host sizes the pair-list form from it: ~130 B per candidate pair)
+extern "C" int annchor_device_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes)
+{
+    if (!free_bytes || !total_bytes) return ANNCHOR_EINVAL;
+    size_t f = 0, t = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) { (void)hipGetLastError(); return ANNCHOR_EHIP; }
+    *free_bytes = (int64_t)f;
+    *total_bytes = (int64_t)t;
+    return ANNCHOR_OK;
+}
+
 extern "C" const char *annchor_last_error(annchor_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 extern "C" const char *annchor_create_error(void) { return g_create_err.c_str(); }
 

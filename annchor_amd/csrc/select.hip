@@ -1152,10 +1152,10 @@ static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
         ANN_TRY(ann_reserve(c, c->gl_ncomp, sizeof(int32_t) * (size_t)nx));
         ANN_TRY(ann_reserve(c, c->marked, (size_t)n));
         ANN_TRY(ann_reserve(c, c->markcount, sizeof(int32_t) * (size_t)nx));
-        ANN_TRY(ann_reserve(c, c->tmp2, 64));
+        ANN_TRY(ann_reserve(c, c->gn_err, 64));   // the sweep's error flag has a buffer of its own (tmp2 is re-reserved by annchor_bin_counts)
         ANN_CHECK_HIP(c, hipMemsetAsync(c->marked.p, 0, (size_t)n, c->stream));
         ANN_CHECK_HIP(c, hipMemsetAsync(c->markcount.p, 0, sizeof(int32_t) * (size_t)nx, c->stream));
-        ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp2.as<int32_t>() + 8, 0, 4, c->stream));   // sweep error flag (words 0..1: uncomputed count)
+        ANN_CHECK_HIP(c, hipMemsetAsync(c->gn_err.as<int32_t>(), 0, 4, c->stream));   // sweep error flag
         {
             ProfScope ps(c, "guarantee_nmin_lists", (double)n * 26.0);
             const size_t tail = (((size_t)L * 12) + 15) & ~(size_t)15;
@@ -1192,7 +1192,7 @@ static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
                 k_gn_round<<<ann_blocks(nx * 64, 256), 256, 0, c->stream>>>(
                     nx, nmin, L, Lw, c->gl_val.as<double>(), oth, twin, c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
                     masks[round & 1], masks[(round + 1) & 1], mout[round % 3], mout[(round + 1) % 3], mout[(round + 2) % 3],
-                    changed + q, c->tmp2.as<int32_t>() + 8);
+                    changed + q, c->gn_err.as<int32_t>());
             c->gn_pending = true; c->gn_round = round; c->gn_L = L;
         } else if (L <= GN_LMAX && ring_lds <= 156 * 1024) {
             ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 21.0);
@@ -1203,7 +1203,7 @@ static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
                                                  (int)ring_lds));
             k_gn_sweep_ring<<<1, 256, ring_lds, c->stream>>>(nx, nmin, L, c->gl_val.as<double>(), c->gl_pos.as<int32_t>(), oth, twin,
                                                             c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
-                                                            c->RA.as<double>(), c->tmp2.as<int32_t>() + 8);
+                                                            c->RA.as<double>(), c->gn_err.as<int32_t>());
         } else if (sweep_lds <= 150 * 1024) {
             ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 21.0);
             int32_t *oth = c->gl_pos.as<int32_t>() + (size_t)nx * L, *twin = oth + (size_t)nx * L;
@@ -1214,13 +1214,13 @@ static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
                                                      (int)sweep_lds));
             k_gn_sweep_lds<<<1, 64, sweep_lds, c->stream>>>(nx, nmin, L, c->gl_val.as<double>(), c->gl_pos.as<int32_t>(), oth,
                                                            twin, c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
-                                                           c->RA.as<double>(), c->tmp2.as<int32_t>() + 8);
+                                                           c->RA.as<double>(), c->gn_err.as<int32_t>());
         } else {
             ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 13.0);
             k_gn_sequential<<<1, 64, 0, c->stream>>>(nx, nmin, L, c->gl_val.as<double>(), c->gl_pos.as<int32_t>(),
                                                     c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(), c->ij.as<int2>(),
                                                     c->RA.as<double>(), c->marked.as<uint8_t>(), c->markcount.as<int32_t>(),
-                                                    c->tmp2.as<int32_t>() + 8);
+                                                    c->gn_err.as<int32_t>());
         }
     }
     return ANNCHOR_OK;
@@ -1250,7 +1250,7 @@ static int select_stage_finish(annchor_ctx *c)
             k_gn_round<<<ann_blocks(nx * 64, 256), 256, 0, c->stream>>>(
                 nx, nmin, L, Lw, c->gl_val.as<double>(), oth, twin, c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
                 masks[round & 1], masks[(round + 1) & 1], mout[round % 3], mout[(round + 1) % 3], mout[(round + 2) % 3],
-                changed + q, c->tmp2.as<int32_t>() + 8);
+                changed + q, c->gn_err.as<int32_t>());
     }
     k_gn_apply<<<ann_blocks(nx * L, 256), 256, 0, c->stream>>>(nx, L, Lw, c->gl_pos.as<int32_t>(), c->gl_cnt.as<int32_t>(),
                                                               masks[round & 1], c->RA.as<double>());
@@ -1397,7 +1397,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     ANN_CHECK_HIP(c, hipGetLastError());
     if (nmin > 0) {
         int32_t e = 0;
-        ANN_TRY(ann_d2h2(c, &cs, c->sel_state.p, sizeof cs, &e, c->tmp2.as<int32_t>() + 8, 4));
+        ANN_TRY(ann_d2h2(c, &cs, c->sel_state.p, sizeof cs, &e, c->gn_err.as<int32_t>(), 4));
         ANN_REQUIRE(c, e == 0, ANNCHOR_ESTATE, "guarantee_nmin: a row has fewer not-computed candidates than it must refine");
     } else {
         ANN_TRY(ann_d2h(c, &cs, c->sel_state.p, sizeof cs));

@@ -73,6 +73,8 @@ const char *annchor_create_error(void);
 int annchor_device_name(annchor_ctx *ctx, char *buf, int buflen);
 /* PCI bus id of a device ("0000:c1:00.0", buflen >= 16): for binding the process to the GPU's NUMA node. */
 int annchor_device_pci_bus_id(int device, char *buf, int buflen);
+/* Free / total memory of a device in bytes (the host derives the largest pair list it will materialise from it). */
+int annchor_device_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes);
 int annchor_synchronize(annchor_ctx *ctx);
 /* Device-side elapsed time (ms) of the work enqueued by the most recent call,
  * measured with HIP events on the context's stream. */

@@ -112,6 +112,35 @@ def test_custom_sampler_regression_error_plugins_get_reference_arrays():
     assert np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0])
 
 
+def test_error_predictor_with_arbitrary_integer_labels():
+    """error_predictors.py:47 takes any label keys: a predictor whose labels are 10, 20, 30, ... (and listed in
+    descending order) gives the graph of the built-in 0..6 one -- the device label array holds positions in
+    error_predictor.labels."""
+    from annchor_amd import Annchor
+    from annchor_amd.error_predictors import SimpleStratifiedErrorRegression
+
+    class Relabelled(SimpleStratifiedErrorRegression):
+        def fit(self, sample_features, feature_names, sample_error, sample_bins=None):
+            super().fit(sample_features, feature_names, sample_error, sample_bins=sample_bins)
+            P = self.n_partitions
+            self.errs = {10 * (b + 1): self.errs[b] for b in range(P)}
+            self.labels = [10 * (b + 1) for b in reversed(range(P))]
+
+        def predict(self, features, feature_names):
+            return 10 * (super().predict(features, feature_names) + 1)
+
+    X, _ = om.load_strings()
+    Xs = np.array(X[::5])
+    cfg = dict(n_anchors=8, n_neighbors=10, n_samples=700, p_work=0.3, random_seed=42, niters=2)
+    a = Annchor(Xs, "levenshtein", error_predictor=Relabelled(), **cfg).fit()
+    b = Annchor(Xs, "levenshtein", **cfg).fit()
+    assert a.evals == b.evals
+    assert np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1]) and np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0])
+    qa = a.query(Xs[:40], nn=5, p_work=0.4)
+    qb = b.query(Xs[:40], nn=5, p_work=0.4)
+    assert np.array_equal(qa[1], qb[1])
+
+
 def test_is_metric_false_uses_exact_anchor_distances():
     from annchor_amd import Annchor
 

@@ -171,9 +171,11 @@ def test_c3_full_size_recall():
 
 
 def test_dispatch_rules():
-    """float64 data is never narrowed: up to 30 000 points it takes the pair-list form in float64,
-    beyond that the constructor refuses; float32 data can be forced either way."""
-    from annchor_amd import Annchor
+    """float64 data is never narrowed behind the caller's back: it takes the pair-list form in float64 as far as the
+    device holds the candidate list (2^30 pairs / 80 % of free memory: 46 341 points on a 288 GB MI355X), beyond that
+    the constructor refuses -- unless the caller opts into float32 with streamed='cast'; float32 data can be forced
+    either way."""
+    from annchor_amd import Annchor, _native
 
     X32 = latent(2000, 16)
     a = Annchor(X32, "euclidean", n_anchors=6, n_neighbors=5, p_work=0.5, streamed=True).fit()
@@ -183,14 +185,37 @@ def test_dispatch_rules():
         a.get_sample()
     with pytest.raises(ValueError):
         Annchor(X32.astype(np.float64), "euclidean", streamed=True)
-    big = np.zeros((30001, 4))
+    lim = _native.pairlist_point_limit(0)
+    assert 30000 < lim <= 46341
+    big = np.zeros((lim + 1, 4))
     with pytest.raises(ValueError):
         Annchor(big, "euclidean")
+    with pytest.raises(ValueError):
+        Annchor(np.zeros((lim + 1, 4), dtype=np.float32), "euclidean", streamed=False)
     mid = latent(21000, 8).astype(np.float64)
     c = Annchor(mid, "euclidean", n_anchors=8, n_neighbors=5, p_work=0.02)
     assert c._streamed is None   # float64: pair-list form, computed in float64
-    with pytest.raises(ValueError):
-        Annchor(latent(30001, 8), "euclidean", streamed=False)
+    d = Annchor(latent(31000, 8).astype(np.float64), "euclidean", n_anchors=8, n_neighbors=5, p_work=0.02)
+    assert d._streamed is None   # still the pair-list form above 30 000 points (float64 input is not narrowed)
+    e = Annchor(latent(31000, 8).astype(np.float64), "euclidean", n_anchors=8, n_neighbors=5, p_work=0.5, streamed="cast")
+    assert e._streamed is not None   # the explicit opt-in
+
+
+def test_pair_list_form_above_30000_points():
+    """Slow-metric-shaped use above the old 30 000-point cap: float64 Euclidean, 34 000 points (578 M candidate pairs,
+    ~70 GB of pair-list state), order-free sampler; exact rows of a subset as truth."""
+    from annchor_amd import Annchor, compare_neighbor_graphs
+    from annchor_amd.samplers import DeviceStratifiedSampler
+
+    n, k = 34000, 10
+    X = latent(n, 24).astype(np.float64)
+    ann = Annchor(X, "euclidean", n_anchors=20, n_neighbors=k, p_work=0.05, sampler=DeviceStratifiedSampler()).fit()
+    assert ann._streamed is None and ann.n_pairs > 4e8
+    rows = np.random.default_rng(8).choice(n, 300, replace=False)
+    bi, bd = brute(X, rows, k)
+    err = compare_neighbor_graphs((bi, bd), (ann.neighbor_graph[0][rows], ann.neighbor_graph[1][rows]), k)
+    assert err <= 0.01 * len(rows) * k, err
+    ann._engine.close()
 
 
 def test_device_pointer_tensor_view():
