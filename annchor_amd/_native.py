@@ -115,6 +115,12 @@ _SIGNATURES = {
     "annchor_device_alloc": (ctypes.c_int, [_vp, _i64, ctypes.POINTER(_vp)]),
     "annchor_device_free": (ctypes.c_int, [_vp, _vp]),
     "annchor_device_copy": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32]),
+    "annchor_enemies_candidates": (ctypes.c_int, [_vp, _vp, _i32, _i32, ctypes.POINTER(_i64)]),
+    "annchor_enemies_predict": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "annchor_enemies_first": (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _i64, ctypes.POINTER(_i64)]),
+    "annchor_enemies_set_exact": (ctypes.c_int, [_vp, _vp, _i64]),
+    "annchor_enemies_graph": (ctypes.c_int, [_vp, _i32, _vp, _vp]),
+    "annchor_enemies_download": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "annchor_graph_to_coo": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "annchor_field_size": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_i64)]),
     "annchor_download": (ctypes.c_int, [_vp, _i32, _vp, _i64]),
@@ -764,6 +770,54 @@ class Engine:
 
     def device_copy(self, dst, src, nbytes, kind):
         self._chk(self.lib.annchor_device_copy(self.h, dst, src, int(nbytes), {"h2d": 1, "d2h": 2, "d2d": 3}[kind]))
+
+    # ---- nearest enemies (csrc/enemies.hip)
+    def enemies_candidates(self, codes, loc_thresh, loc_min):
+        codes = _c(codes, np.int32)
+        n = _i64()
+        self._chk(self.lib.annchor_enemies_candidates(self.h, _ptr(codes), int(loc_thresh), int(loc_min), ctypes.byref(n)))
+        self._n_enemy_pairs = n.value
+        return n.value
+
+    def enemies_predict(self, bins=None, W=None, c=None, pred=None):
+        if pred is not None:
+            pred = _c(pred, np.float64).reshape(-1)
+            if pred.shape[0] != self._n_enemy_pairs:
+                raise ValueError("regression.predict returned %d values for %d enemy pairs" % (pred.shape[0], self._n_enemy_pairs))
+            self._chk(self.lib.annchor_enemies_predict(self.h, None, 0, None, None, _ptr(pred)))
+            return
+        bins, W, c = _c(bins, np.float64), _c(W, np.float64), _c(c, np.float64)
+        self._chk(self.lib.annchor_enemies_predict(self.h, _ptr(bins), len(bins) - 1, _ptr(W), _ptr(c), None))
+
+    def enemies_first(self, first, nn, evaluate):
+        """evaluate: the todo pairs are evaluated on the device, returns their number; otherwise returns them (int64 [m, 2])."""
+        m = _i64()
+        if evaluate:
+            self._chk(self.lib.annchor_enemies_first(self.h, int(first), int(nn), 1, None, 0, ctypes.byref(m)))
+            return m.value
+        cap = self.nx * int(first)
+        todo = np.empty((cap, 2), dtype=np.int64)
+        self._chk(self.lib.annchor_enemies_first(self.h, int(first), int(nn), 0, _ptr(todo), cap, ctypes.byref(m)))
+        return todo[:m.value]
+
+    def enemies_set_exact(self, exact):
+        exact = _c(exact, np.float64)
+        self._chk(self.lib.annchor_enemies_set_exact(self.h, _ptr(exact), len(exact)))
+
+    def enemies_graph(self, nn):
+        idx = np.empty((self.nx, nn), dtype=np.int64)
+        dist = np.empty((self.nx, nn), dtype=np.float64)
+        self._chk(self.lib.annchor_enemies_graph(self.h, int(nn), _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def enemies_download(self):
+        """(IJs_new [n, 2], features [n, 4], RA [n], ncm bool [n], I_ptr [nx + 1], I_idx [2 n]) of the enemy pairs."""
+        n = self._n_enemy_pairs
+        ij, feats = np.empty((n, 2), dtype=np.int64), np.empty((n, 4), dtype=np.float64)
+        RA, ncm = np.empty(n, dtype=np.float64), np.empty(n, dtype=np.uint8)
+        ptr, idx = np.empty(self.nx + 1, dtype=np.int64), np.empty(2 * n, dtype=np.int64)
+        self._chk(self.lib.annchor_enemies_download(self.h, _ptr(ij), _ptr(feats), _ptr(RA), _ptr(ncm), _ptr(ptr), _ptr(idx)))
+        return ij, feats, RA, ncm.astype(bool), ptr, idx
 
     def graph_to_coo(self, idx, dist):
         """Symmetric COO (rows, cols, vals) of a k-NN graph, every cell once, vals = distance + eps."""

@@ -276,10 +276,16 @@ class Annchor:
     # ------------------------------------------------------------- lazy NumPy views
     def _view(self, key, loader):
         if key not in self._cache:
-            if getattr(self, "_enemy_extended", False) and key in ("labels", "thresh", "cand", "next", "sid"):
-                raise RuntimeError("get_nearest_enemies() extended IJs / RefineApprox / not_computed_mask / features / I by the "
-                                   "enemy pairs; '%s' of the fitted pair list is no longer aligned with them (read it before, "
-                                   "or refit)" % key)
+            if getattr(self, "_enemy_extended", False):
+                if key in ("labels", "thresh", "cand", "next"):
+                    raise RuntimeError("get_nearest_enemies() extended IJs / RefineApprox / not_computed_mask / features / I by the "
+                                       "enemy pairs; '%s' of the fitted pair list is no longer aligned with them (read it before, "
+                                       "or refit)" % key)
+                if key in ("IJs", "RA", "ncm", "features", "I"):   # fitted list + enemy pairs, from the device state
+                    from . import enemies
+
+                    self._cache.update(enemies.extended_views(self))
+                    return self._cache[key]
             self._cache[key] = loader()
         return self._cache[key]
 
@@ -374,8 +380,8 @@ class Annchor:
     # --------------------------------------------------------------------- stages
     def _pair_list_stage(self, what):
         if getattr(self, "_enemy_extended", False):
-            raise RuntimeError("%s: get_nearest_enemies() extended this object's pair list on the host; the fitted device "
-                               "state no longer matches it -- build a new Annchor to run the stages again" % what)
+            raise RuntimeError("%s: get_nearest_enemies() extended this object's pair list by the enemy pairs (and refined "
+                               "entries of the fitted one) -- build a new Annchor to run the stages again" % what)
         if self._streamed is not None:
             raise NotImplementedError("%s is a stage of the pair-list form; this object runs the streamed form "
                                       "(fit() does everything; pass streamed=False for the staged pipeline)" % what)

@@ -7,6 +7,7 @@
 
 static std::string g_create_err;
 void ann_stream_release(annchor_ctx *c);
+void ann_enemies_release(annchor_ctx *c);
 
 const char *ann_set_err(annchor_ctx *c, const char *fmt, ...)
 {
@@ -283,6 +284,7 @@ extern "C" void annchor_destroy(annchor_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     prof_drain(c);
     ann_stream_release(c);
+    ann_enemies_release(c);
     DevBuf *bufs[] = {&c->sym, &c->soff, &c->slen, &c->pts, &c->hist, &c->cost, &c->supp, &c->Dt, &c->A,
                       &c->anchorRank, &c->runmin, &c->redval, &c->redidx, &c->sid, &c->cA, &c->thr, &c->Kbits,
                       &c->Kpref, &c->deg, &c->low, &c->rowstart, &c->Iptr, &c->Iidx, &c->ij, &c->lb, &c->ub,

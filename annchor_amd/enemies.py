@@ -2,9 +2,11 @@
 Nearest-enemy graph, selective subset and alpha-RSS (reference annchor/annchor.py:685-927;
 SURVEY.md section 8, row f4).
 
-Host orchestration in NumPy over the fitted pair-list state (as the reference's is); every
-metric evaluation goes through `ann.get_exact_ijs`, i.e. the HIP metric kernels for the
-built-in metrics.  All arrays are flat / CSR-shaped; nothing here loops over pairs in Python.
+The nearest-enemy graph itself runs on the device (csrc/enemies.hip: label-masked candidate generation,
+features / prediction of the new pairs, exact distances of each row's closest-looking enemies, row top-nn);
+the selective subset and alpha-RSS -- greedy set covers on the k-NN graph, host code in the reference too --
+are NumPy over the (lazily assembled) extended pair-list views, every metric evaluation through
+`ann.get_exact_ijs`, i.e. the HIP metric kernels for the built-in metrics.
 
 Semantics notes (shared with the rest of the build): ties are broken by stable sorts on list
 order (the reference's argsorts are unstable); per-point candidate lists are complete (the
@@ -14,71 +16,6 @@ import numpy as np
 
 ROW_BLOCK = 2048
 FIRST_ENEMIES = 50  # annchor.py:755-756: exact distances for the 50 closest-looking enemies
-
-
-def _pair_keys(IJs, nx):
-    return IJs[:, 0].astype(np.int64) * nx + IJs[:, 1].astype(np.int64)
-
-
-def _anchor_sets_matrix(sid, nx, na):
-    Am = np.zeros((nx, na), dtype=np.float32)
-    np.put_along_axis(Am, np.asarray(sid, dtype=np.int64), 1.0, axis=1)
-    return Am
-
-
-def enemy_candidate_pairs(sid, n_anchors, y, fit_IJs, loc_thresh, loc_min):
-    """New candidate pairs (i < j, sorted by (i, j)): enemies sharing nearest anchors, per
-    get_check with the label filter (utils.py:454-491) + adjust_check (utils.py:437-451), minus
-    the pairs fit() already holds (annchor.py:717-722)."""
-    nx = y.shape[0]
-    Am = _anchor_sets_matrix(sid, nx, n_anchors)
-    thr = np.empty(nx, dtype=np.int64)
-    for r0 in range(0, nx, ROW_BLOCK):  # pass 1: per-row threshold among enemies only
-        r1 = min(nx, r0 + ROW_BLOCK)
-        C = (Am[r0:r1] @ Am.T).astype(np.int32)
-        enemy = y[r0:r1, None] != y[None, :]
-        Cm = np.where(enemy, C, -1)
-        n_enemy = enemy.sum(axis=1)
-        lm = np.minimum(loc_min, n_enemy - 1)
-        Cs = -np.sort(-Cm, axis=1)
-        kth = np.take_along_axis(Cs, lm[:, None], axis=1)[:, 0]
-        thr[r0:r1] = np.minimum(loc_thresh, kth)
-    lowered = bool(np.any(thr < loc_thresh))
-    fit_keys = np.sort(_pair_keys(fit_IJs, nx))
-    out = []
-    for r0 in range(0, nx, ROW_BLOCK):  # pass 2: emit (a, b), a < b
-        r1 = min(nx, r0 + ROW_BLOCK)
-        C = (Am[r0:r1] @ Am.T).astype(np.int32)
-        keep = C >= thr[r0:r1, None]
-        if lowered:  # the smaller index learns the pair from the larger one's list
-            keep |= C >= thr[None, :]
-        keep &= y[r0:r1, None] != y[None, :]
-        keep &= np.arange(nx)[None, :] > np.arange(r0, r1)[:, None]
-        a, b = np.nonzero(keep)
-        keys = (a + r0).astype(np.int64) * nx + b
-        pos = np.searchsorted(fit_keys, keys)
-        known = (pos < fit_keys.shape[0]) & (fit_keys[np.minimum(pos, fit_keys.shape[0] - 1)] == keys)
-        out.append(keys[~known])
-    keys = np.concatenate(out) if out else np.zeros(0, dtype=np.int64)
-    return np.stack([keys // nx, keys % nx], axis=1).astype(np.int64)
-
-
-def pair_features(IJs, D, A, chunk=1 << 18):
-    """[lb, ub, dad, is_anchor] per pair (get_features_IJ, annchor.py:258-303) from the anchor
-    distance table, in bounded chunks."""
-    n = IJs.shape[0]
-    out = np.empty((n, 4))
-    cA = np.argmin(D, axis=1)
-    is_anchor = np.zeros(D.shape[0], dtype=bool)
-    is_anchor[np.asarray(A, dtype=np.int64)] = True
-    for s in range(0, n, chunk):
-        i, j = IJs[s:s + chunk, 0], IJs[s:s + chunk, 1]
-        Di, Dj = D[i], D[j]
-        out[s:s + chunk, 0] = np.abs(Di - Dj).max(axis=1)
-        out[s:s + chunk, 1] = (Di + Dj).min(axis=1)
-        out[s:s + chunk, 2] = (D[i, cA[j]] + D[j, cA[i]]) / 2
-        out[s:s + chunk, 3] = is_anchor[i] | is_anchor[j]
-    return out
 
 
 class RowLists:
@@ -129,10 +66,12 @@ def _rank_in_row(owner_sorted):
 
 
 def nearest_enemies(ann, y, nn=3, loc_min=100):
-    """Annchor.get_nearest_enemies (annchor.py:685-782).  Extends ann's pair-list views
-    (IJs, I, features, not_computed_mask, RefineApprox) in place of the reference's appends and
-    returns (idx int64 [nx, nn], dist float64 [nx, nn])."""
-    from .annchor import _IndexCSR
+    """Annchor.get_nearest_enemies (annchor.py:685-782) on the device (csrc/enemies.hip): label-masked candidate
+    generation (a second bitmap next to the fitted one), features / prediction of the new pairs, exact distances of every
+    row's closest-looking enemies, row top-nn.  The object's pair-list views (IJs, I, features, not_computed_mask,
+    RefineApprox) are extended by the enemy pairs like the reference's attributes -- lazily: they are assembled from the
+    device state when somebody reads them.  Returns (idx int64 [nx, nn], dist float64 [nx, nn])."""
+    from .regressors import SimpleStratifiedLinearRegression
 
     nx = ann.nx
     y = np.asarray(y)
@@ -140,51 +79,48 @@ def nearest_enemies(ann, y, nn=3, loc_min=100):
     labels, counts = np.unique(y, return_counts=True)
     assert len(labels) > 1, "Data must have more than one label"
     assert np.all(counts >= nn), "At least one label occurs fewer times than specified nn=%d" % nn
-
-    IJs0, RA0, ncm0, F0 = ann.IJs, ann.RefineApprox, ann.not_computed_mask, ann.features
-    n0 = IJs0.shape[0]
-    IJn = enemy_candidate_pairs(ann.sid, ann.n_anchors, y, IJs0, ann.loc_thresh, loc_min)
-    Fn = pair_features(IJn, ann.D, ann.A)
-    pred = ann.regression.predict(Fn, ann.feature_names)
-    ilb, iub = ann.feature_names.index("lower bound"), ann.feature_names.index("upper bound")
-    pred = np.clip(pred, Fn[:, ilb], Fn[:, iub])
-    IJs = np.vstack([IJs0, IJn])
-    RA = np.concatenate([RA0, pred])
-    ncm = np.concatenate([ncm0, Fn[:, 3] < 1])
-    feats = np.vstack([F0, Fn])
-    ptr_n, pos_n = rows_of_pairs(IJn, nx)
-    ptr, pos = RowLists.merge(ann.I.ptr, ann.I.idx, ptr_n, pos_n + n0)
-    L = RowLists(ptr, pos, IJs)
-    if np.any(np.diff(ptr) <= nn):
-        raise ValueError("a point has no more than nn=%d candidates" % nn)
-    enemy = y[L.other] != y[L.owner]
-
-    # exact distances for the uncomputed among each row's FIRST_ENEMIES closest-looking enemies
-    e = np.nonzero(enemy)[0]
-    order = e[np.lexsort((RA[pos[e]], L.owner[e]))]
-    head = order[_rank_in_row(L.owner[order]) < FIRST_ENEMIES]
-    todo = pos[head]
-    todo = todo[ncm[todo]]
-    if todo.shape[0] > 0:
-        RA[todo] = ann.get_exact_ijs(ann.f, ann.X, IJs[todo])
-        ncm[todo] = False
-
-    # nn nearest per row: computed enemies first (uncomputed and same-label entries pushed
-    # behind by the row maximum, annchor.py:766-772)
-    mx = np.maximum.reduceat(RA[pos], ptr[:-1])[L.owner]
-    d = RA[pos] + mx * ncm[pos] + mx * (~enemy)
-    order = np.lexsort((d, L.owner))
-    top = order[_rank_in_row(L.owner[order]) < nn]
-    ngi = L.other[top].reshape(nx, nn)
-    ngd = RA[pos[top]].reshape(nx, nn)
-
-    # Like the reference (annchor.py:748-781), the object's pair-list views now include the enemy pairs.
-    # The device keeps the fitted (shorter) state, so the views that are loaded lazily from it and the
-    # stage methods no longer describe the same pair list: the object says so instead of mixing lengths.
-    ann._cache.update(IJs=IJs, RA=RA, ncm=ncm, features=feats, I=_IndexCSR(ptr, pos))
+    eng = ann._engine
+    codes = np.unique(y, return_inverse=True)[1].astype(np.int32)
+    eng.enemies_candidates(codes, ann.loc_thresh, loc_min)
+    model = ann.regression.coefficients() if type(ann.regression) is SimpleStratifiedLinearRegression else None
+    if model is not None:
+        eng.enemies_predict(*model)
+    else:   # a custom regression sees the reference's arrays
+        Fn = eng.enemies_download()[1]
+        eng.enemies_predict(pred=np.asarray(ann.regression.predict(Fn, ann.feature_names), dtype=np.float64))
+    if ann._device_metric:
+        n_eval = eng.enemies_first(FIRST_ENEMIES, nn, True)
+    else:
+        todo = eng.enemies_first(FIRST_ENEMIES, nn, False)
+        n_eval = len(todo)
+        if n_eval:
+            eng.enemies_set_exact(np.asarray(ann.get_exact_ijs(ann.f, ann.X, todo), dtype=np.float64))
+    ann.evals += int(n_eval)
+    ngi, ngd = eng.enemies_graph(nn)
+    # Like the reference (annchor.py:729-740, 748-761), the object's pair-list views now include the enemy pairs and the
+    # exact distances just computed; they are rebuilt from the device state on demand (Annchor._view).  The stage methods
+    # and the views of the fitted list alone (thresh, candidates, ...) are closed from here on.
+    ann._invalidate("IJs", "RA", "ncm", "features", "I")
     ann._enemy_extended = True
     ann.nearest_enemy_graph = (ngi, ngd)
     return ngi, ngd
+
+
+def extended_views(ann):
+    """IJs / RefineApprox / not_computed_mask / features / I of the fitted pair list followed by the enemy pairs
+    (annchor.py:729-740), assembled from the device state."""
+    from . import _native
+    from .annchor import _IndexCSR
+
+    eng = ann._engine
+    IJs0 = eng.download(_native.F_IJS).reshape(-1, 2)
+    n0 = IJs0.shape[0]
+    IJn, Fn, RAn, ncmn, ptr_n, idx_n = eng.enemies_download()
+    ptr0, idx0 = eng.download(_native.F_I_PTR), eng.download(_native.F_I_IDX)
+    ptr, pos = RowLists.merge(ptr0, idx0, ptr_n, idx_n + n0)
+    return dict(IJs=np.vstack([IJs0, IJn]), RA=np.concatenate([eng.download(_native.F_RA), RAn]),
+                ncm=np.concatenate([eng.download(_native.F_NCM).astype(bool), ncmn]),
+                features=np.vstack([eng.download(_native.F_FEATURES).reshape(-1, 4), Fn]), I=_IndexCSR(ptr, pos))
 
 
 def _cover_counts(sorted_d, limit):

@@ -390,6 +390,29 @@ int annchor_device_alloc(annchor_ctx *ctx, int64_t bytes, void **dptr);
 int annchor_device_free(annchor_ctx *ctx, void *dptr);
 int annchor_device_copy(annchor_ctx *ctx, void *dst, const void *src, int64_t bytes, int32_t kind /*1 H2D, 2 D2H, 3 D2D*/);
 
+/* ------------------------------------------------------------- nearest enemies (f4)
+ * Annchor.get_nearest_enemies (annchor/annchor.py:685-782; get_check with the label filter utils.py:454-491,
+ * adjust_check utils.py:437-451, get_IJs_from_check utils.py:502-540) on a fitted pair list, in stages:
+ *   annchor_enemies_candidates  y = dense label codes (HOST int32 [nx]): the enemy pairs sharing nearest anchors
+ *     (per-point threshold among enemies, symmetrised when one was lowered) that fit() does not hold, as a sorted pair
+ *     list + per-point index, with their bounds / dad / anchor flag; *n_new = their number;
+ *   annchor_enemies_predict     their predicted distances, clipped to [lb, ub] (annchor.py:724-728): the fitted
+ *     stratified regression (HOST bins / W / c), or -- pred != NULL -- a custom regression's host predictions;
+ *   annchor_enemies_first       per point the `first` closest-looking enemies among its fitted + new entries; the
+ *     not-computed ones are evaluated exactly (device metric: here; otherwise the pairs are returned in todo_ij and
+ *     annchor_enemies_set_exact takes the values); RefineApprox / not_computed_mask are updated in place (:744-761);
+ *   annchor_enemies_graph       the nn nearest computed enemies per point (:763-781): idx int64 [nx, nn] (the other
+ *     endpoint), dist float64 [nx, nn];
+ *   annchor_enemies_download    the new pairs for the host's views (the reference appends them to IJs, features,
+ *     RefineApprox, not_computed_mask and I, :729-740).
+ * Ties by list order (fitted entries by other endpoint, then new entries by other endpoint). */
+int annchor_enemies_candidates(annchor_ctx *ctx, const int32_t *y, int32_t loc_thresh, int32_t loc_min, int64_t *n_new);
+int annchor_enemies_predict(annchor_ctx *ctx, const double *bins, int32_t nbins, const double *W, const double *c, const double *pred);
+int annchor_enemies_first(annchor_ctx *ctx, int32_t first, int32_t nn, int32_t evaluate, int64_t *todo_ij, int64_t cap, int64_t *n_todo);
+int annchor_enemies_set_exact(annchor_ctx *ctx, const double *exact, int64_t n_todo);
+int annchor_enemies_graph(annchor_ctx *ctx, int32_t nn, int64_t *idx, double *dist);
+int annchor_enemies_download(annchor_ctx *ctx, int64_t *ij, double *feats, double *RA, uint8_t *ncm, int64_t *I_ptr, int64_t *I_idx);
+
 /* Annchor.to_sparse_matrix (annchor/annchor.py:625-641): the symmetric sparse distance matrix of a
  * k-NN graph (HOST arrays ng_idx int64 [nx, k], ng_dist float64 [nx, k]) in COO form: every cell once,
  * value = distance + nextafter(0, 1), later assignments of the reference's loop order win.  rows /
