@@ -52,6 +52,8 @@ struct annchor_ctx {
     // set's longest string allows (0: no such class); lev_frac0 = share of the strings that short
     int lev_gl0 = 0;
     double lev_frac0 = 0.0;
+    DevBuf lev_order;        // int32 [nx]: string ids, strings of <= 16 words first (k_lev_a2: two such pairs share a wave)
+    int lev_nshort = 0;
     DevBuf lev_perm;         // int32 [n] pair positions, short patterns first / long ones from the back; + 2 counters
     DevBuf pts;              // points (f32 or f64) row-major [nx, dim]
     int dim = 0;

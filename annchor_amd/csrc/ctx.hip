@@ -449,6 +449,16 @@ extern "C" int annchor_set_strings(annchor_ctx *c, const uint8_t *symbols, const
     c->nx = nx;
     c->alphabet = alphabet;
     c->maxlen = maxlen;
+    {   // anchor rounds (lev.hip, k_lev_a2): strings of <= 16 words first
+        std::vector<int32_t> ord((size_t)nx);
+        int64_t ns = 0;
+        for (int64_t s = 0; s < nx; ++s) ns += lens[s] <= 512;
+        int64_t a = 0, b = ns;
+        for (int64_t s = 0; s < nx; ++s) ord[(size_t)(lens[s] <= 512 ? a++ : b++)] = (int32_t)s;
+        ANN_TRY(ann_reserve(c, c->lev_order, sizeof(int32_t) * (size_t)nx));
+        ANN_TRY(ann_h2d(c, c->lev_order.p, ord.data(), sizeof(int32_t) * (size_t)nx));
+        c->lev_nshort = (int)ns;
+    }
     {   // slot classes of the Levenshtein kernel (lev.hip, k_lev_f): P pairs per wave for the longest string,
         // P + 1 for pairs whose shorter string has <= 64 / (P + 1) words
         const int W = (maxlen + 31) / 32 > 0 ? (maxlen + 31) / 32 : 1;

@@ -977,6 +977,253 @@ __global__ __launch_bounds__(ANN_WAVE) void k_lev_a(LevArgsA a)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_lev_a2: k_lev_a with the waves packed for ONE wave per SIMD.  k_lev_a's nx waves of half-length chains ran as
+// long as the nx / 3 full-length ones they replaced (36.8 vs 38.6 us per round at C2: 1600 waves on 1024 SIMDs put
+// two on most SIMDs, and one of these waves keeps its SIMD's issue port ~60 % busy on its own).  Here a wave holds
+// FOUR half-chains -- two pairs, slots of 16 lanes -- whenever the shorter string of a pair fits 16 words
+// (<= 512 symbols: it becomes the bit-vector pattern, the longer one the text); pairs of two longer strings keep a wave
+// to themselves (slots of 32 lanes).  Strings are listed short ones first (lev_order, built when they are bound), so
+// wave b knows its pairs without knowing the anchor: C2 = 635 + 330 = 965 waves <= 1024 SIMDs, each walking
+// ~max(len) / 2 + 16 columns.
+struct LevArgsA2 {
+    LevArgsA a;
+    const int32_t *order;   // string ids, <= 16-word strings first
+    int n_short;            // how many of them
+    int buf_stride;         // bytes per staged string
+    int pad;                // zero bytes either side of a staged string: a lane outside its column range reads up to
+                            // max(len) / 2 + 34 symbols past either end (never used, but they index the match-mask table)
+};
+
+__global__ __launch_bounds__(ANN_WAVE) void k_lev_a2(LevArgsA2 aa)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LevArgsA &a = aa.a;
+    const int lane = threadIdx.x, A = a.alphabet;
+    const int ws = (aa.n_short + 1) >> 1;                 // waves of the packed class
+    const bool packed = (int)blockIdx.x < ws;
+    const int GL = packed ? 16 : 32;
+    const int slot = lane / GL, w = lane - slot * GL, pair = slot >> 1, half = slot & 1;
+    const int LP = packed ? 32 : 64;                      // lanes per pair
+    unsigned char *pm_col = smem + (size_t)(lane >> 5) * A * LEVF_ROW + (size_t)(lane & 31) * 4;
+    uint8_t *bufs = smem + a.pm_bytes;                    // [0], [1]: the wave's strings t0 / t1, [2]: the anchor
+    int16_t *FB = reinterpret_cast<int16_t *>(bufs + 3 * aa.buf_stride);   // [pair][half][fb_stride]
+    for (int e = lane * 16; e < 3 * aa.buf_stride; e += 64 * 16) *reinterpret_cast<uint4 *>(bufs + e) = make_uint4(0, 0, 0, 0);
+    uint32_t hp_or = w == 0 ? 0x80000000u : 0u;
+    uint32_t hn_and = w == 0 ? 0u : 0xffffffffu;
+    asm volatile("" : "+v"(hp_or), "+v"(hn_and));
+    // ---- this wave's strings
+    int tq[2] = {-1, -1};
+    if (packed) {
+        tq[0] = aa.order[2 * blockIdx.x];
+        if (2 * (int)blockIdx.x + 1 < aa.n_short) tq[1] = aa.order[2 * blockIdx.x + 1];
+    } else {
+        tq[0] = aa.order[aa.n_short + ((int)blockIdx.x - ws)];
+    }
+    int ln[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (tq[q] >= 0) {
+            ln[q] = a.slen[tq[q]];
+            const uint8_t *src = a.sym + a.soff[tq[q]];
+            for (int ch = lane; ch < ((ln[q] + 15) >> 4); ch += 64)
+                reinterpret_cast<uint4 *>(bufs + q * aa.buf_stride + aa.pad)[ch] = reinterpret_cast<const uint4 *>(src)[ch];
+        }
+    // ---- the anchor (fused max-min pick: every wave for itself, the strings' loads above in flight meanwhile)
+    int si;
+    if (a.pick_row) {
+        double bv = -INFINITY;
+        int bi = 0x7fffffff;
+        const int nx = a.pick_nx;
+        for (int j0 = 0; j0 < nx; j0 += 64 * 16) {
+            double d[16], rm[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = min(j0 + e * 64 + lane, nx - 1);
+                d[e] = a.pick_row[j];
+                rm[e] = a.pick_reset ? 0.0 : a.pick_runmin[j];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = j0 + e * 64 + lane;
+                if (j < nx) {
+                    const double v = a.pick_reset ? d[e] : fmin(rm[e], d[e]);
+                    if (blockIdx.x == 0) a.pick_runmin[j] = v;
+                    argmax_combine(bv, bi, v, j);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            argmax_combine(bv, bi, ov, oi);
+        }
+        si = bi;
+        if (blockIdx.x == 0 && lane == 0) *a.pick_out = bi;
+    } else {
+        si = *a.anchor;
+    }
+    const int la = a.slen[si];
+    {
+        const uint8_t *src = a.sym + a.soff[si];
+        for (int ch = lane; ch < ((la + 15) >> 4); ch += 64)
+            reinterpret_cast<uint4 *>(bufs + 2 * aa.buf_stride + aa.pad)[ch] = reinterpret_cast<const uint4 *>(src)[ch];
+    }
+    wave_lds_fence();
+    // ---- roles of this lane's pair: packed class -- pattern = the shorter string (fits the 16-lane slot); otherwise
+    // pattern = the longer one (fewer text columns)
+    const bool have = pair < 2 && tq[pair < 2 ? pair : 0] >= 0 && (packed || pair == 0);
+    const int lt = have ? ln[pair] : 0;
+    const bool t_is_pattern = packed ? (lt <= la) : (lt > la);
+    const int m = have ? (t_is_pattern ? lt : la) : 0;          // pattern length
+    const int n = have ? (t_is_pattern ? la : lt) : 0;          // text length
+    const uint8_t *pat = bufs + (t_is_pattern ? pair : 2) * aa.buf_stride + aa.pad;
+    const uint8_t *txt = bufs + (t_is_pattern ? 2 : pair) * aa.buf_stride + aa.pad;
+    const int Wp = (m + 31) >> 5;
+    for (int c = 0; c < A; ++c) *reinterpret_cast<uint32_t *>(pm_col + (size_t)c * LEVF_ROW) = 0u;
+    if (have && w < Wp) {
+        const int valid = min(32, m - w * 32);
+        uint32_t sy[32];
+        if (half == 0) {
+            const uint4 *p16 = reinterpret_cast<const uint4 *>(pat + w * 32);
+            const uint4 q0 = p16[0], q1 = p16[1];
+            const uint32_t wd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+            for (int k = 0; k < 32; ++k) sy[k] = (wd[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) sy[k] = pat[max(m - 1 - (w * 32 + k), 0)];
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (k < valid) atomicOr(reinterpret_cast<uint32_t *>(pm_col + (size_t)sy[k] * LEVF_ROW), 1u << k);
+    }
+    wave_lds_fence();
+
+    const int h = (n + 1) >> 1;
+    const uint32_t un = (have && m > 0) ? (uint32_t)(half ? n - h : h) : 0u;
+    int max_steps = (have && m > 0) ? h + Wp - 1 : 0;
+    int k_lo = (have && m > 0) ? Wp - 1 : 0, k_hi = (have && m > 0) ? n - h : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        max_steps = max(max_steps, __shfl_xor(max_steps, off));
+        k_lo = max(k_lo, __shfl_xor(k_lo, off));
+        k_hi = min(k_hi, __shfl_xor(k_hi, off));
+    }
+    max_steps = __builtin_amdgcn_readfirstlane(max_steps);
+    k_lo = min(__builtin_amdgcn_readfirstlane(k_lo), max_steps);
+    k_hi = max(k_lo, min(__builtin_amdgcn_readfirstlane(k_hi), max_steps));
+    const int dir = half ? -1 : 1;
+    const uint8_t *tp = txt + (half ? n - 1 + w : -w);
+    uint32_t vp = 0xffffffffu, vn = 0u;
+    uint32_t c1 = tp[dir];
+    uint32_t eq = *reinterpret_cast<const uint32_t *>(pm_col + (uint32_t)tp[0] * LEVF_ROW);
+    uint32_t out_hp = 0, out_hn = 0;
+    const uint8_t *tnext = tp + 2 * dir;
+    auto column = [&](int k, auto checked) {
+        const uint32_t c2 = *tnext;
+        tnext += dir;
+        const uint32_t eq_n = *reinterpret_cast<const uint32_t *>(pm_col + c1 * LEVF_ROW);
+        const uint32_t hp_up = dpp_shr1_or(out_hp, hp_or), hn_up = dpp_shr1_and(out_hn, hn_and);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool valid = !decltype(checked)::value || (uint32_t)(k - w) < un;
+        const uint32_t c = hn_up >> 31;
+        const uint32_t x = eq | c;
+        const uint32_t tt = __builtin_amdgcn_bitop3_b32(c, eq, vp, 0xa8);
+        const uint32_t sm = tt + vp;
+        const uint32_t d0p = __builtin_amdgcn_bitop3_b32(sm, vp, x, 0xbe);
+        const uint32_t hp = __builtin_amdgcn_bitop3_b32(vn, d0p, vp, 0xf1);
+        const uint32_t d0 = d0p | vn;
+        const uint32_t hn = d0 & vp;
+        const uint32_t hps = __builtin_amdgcn_alignbit(hp, hp_up, 31);
+        const uint32_t hns = __builtin_amdgcn_alignbit(hn, hn_up, 31);
+        const uint32_t nvp = __builtin_amdgcn_bitop3_b32(hns, d0, hps, 0xf1);
+        const uint32_t nvn = hps & d0;
+        vp = valid ? nvp : vp;
+        vn = valid ? nvn : vn;
+        out_hp = hp;
+        out_hn = hn;
+        __builtin_amdgcn_sched_barrier(0);
+        eq = eq_n;
+        c1 = c2;
+    };
+    int k = 0;
+    for (; k < k_lo; ++k) column(k, std::true_type());
+    for (; k + 2 <= k_hi; k += 2) { column(k, std::false_type()); column(k + 1, std::false_type()); }
+    for (; k < k_hi; ++k) column(k, std::false_type());
+    for (; k < max_steps; ++k) column(k, std::true_type());
+
+    // ---- F / B' (prefix sums of the vertical deltas down this half's rows), then min_i F[i] + B'[m - i] per pair
+    const uint32_t rows = !have ? 0u : (w < Wp - 1 ? 0xffffffffu : (w == Wp - 1 ? (0xffffffffu >> (31 - ((m - 1) & 31))) : 0u));
+    const int part = __popc(vp & rows) - __popc(vn & rows);
+    int incl = part;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const int o = __shfl_up(incl, off, 32);
+        if (w >= off) incl += o;
+    }
+    int val = (int)un + incl - part;
+    if (m == 0) val = half ? n - h : h;
+    int16_t *fbp = FB + (size_t)(pair < 2 ? pair : 0) * 2 * a.fb_stride;
+    int16_t *fb = fbp + (size_t)half * a.fb_stride;
+    if (have && w == 0) fb[0] = (int16_t)val;
+#pragma unroll
+    for (int b = 0; b < 32; ++b) {
+        val += (int)((vp >> b) & 1u) - (int)((vn >> b) & 1u);
+        if ((rows >> b) & 1u) fb[w * 32 + b + 1] = (int16_t)val;
+    }
+    wave_lds_fence();
+    int best = 0x7fffffff;
+    const int lp = lane & (LP - 1);
+    if (have)
+        for (int i = lp; i <= m; i += LP) best = min(best, (int)fbp[i] + (int)fbp[a.fb_stride + m - i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        if (off < LP) best = min(best, __shfl_xor(best, off));
+    if (have && lp == 0) a.out[tq[pair]] = (double)best;
+}
+
+static int launch_a2(annchor_ctx *c, const PairSource &src, double *d_out)
+{
+    LevArgsA2 aa;
+    LevArgsA &a = aa.a;
+    a.sym = c->sym.as<uint8_t>(); a.soff = c->soff.as<int32_t>(); a.slen = c->slen.as<int32_t>();
+    a.anchor = src.anchor; a.n = src.n; a.out = d_out; a.alphabet = c->alphabet;
+    a.pm_bytes = 2 * a.alphabet * LEVF_ROW;
+    a.text_stride = 2 * LEVR_PAD + ((c->maxlen + 15) & ~15) + 16;
+    a.fb_stride = (c->maxlen + 2 + 7) & ~7;
+    a.pick_row = nullptr; a.pick_runmin = nullptr; a.pick_out = nullptr; a.pick_reset = 0; a.pick_nx = 0;
+    if (src.pick_fused && c->nx <= 8192) {
+        *src.pick_fused = true;
+        if (src.pick_row) {
+            a.pick_row = src.pick_row; a.pick_runmin = src.pick_runmin; a.pick_out = src.pick_out;
+            a.pick_reset = src.pick_reset; a.pick_nx = (int)c->nx;
+        }
+    }
+    aa.order = c->lev_order.as<int32_t>();
+    aa.n_short = c->lev_nshort;
+    aa.pad = ((c->maxlen / 2 + 48) + 15) & ~15;
+    aa.buf_stride = 2 * aa.pad + ((c->maxlen + 15) & ~15) + 16;
+    size_t lds = (size_t)a.pm_bytes + 3 * (size_t)aa.buf_stride + 4 * sizeof(int16_t) * a.fb_stride;
+    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "alphabet %d x length %d needs %zu B of LDS (> 160 KiB)", c->alphabet,
+                c->maxlen, lds);
+    const int64_t blocks = (c->lev_nshort + 1) / 2 + (c->nx - c->lev_nshort);
+    {
+        // A latency-bound launch wants its waves on DIFFERENT SIMDs: a workgroup is one wave, so asking for a quarter
+        // of a CU's LDS caps a CU at four of them -- one per SIMD -- instead of wherever the dispatcher packs them
+        // (ANNCHOR_LEV_A2_LDS overrides the request; 0 = only what the tables need).
+        const char *e = getenv("ANNCHOR_LEV_A2_LDS");
+        const size_t want = e ? (size_t)atoll(e) : (size_t)40 * 1024;
+        if (blocks <= (int64_t)c->prop.multiProcessorCount * 4 && want > lds && want <= 160 * 1024) lds = want;
+    }
+    if (lds > 64 * 1024)
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev_a2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_lev_a2<<<(int)blocks, ANN_WAVE, lds, c->stream>>>(aa);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
 static int launch_a(annchor_ctx *c, const PairSource &src, double *d_out)
 {
     LevArgsA a;
@@ -1048,6 +1295,8 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
         const bool anchor_split = !(env_a && atoi(env_a) == 0);
         if (src.anchor && d_out && !d_RA && R == 9 && W <= 32 && anchor_split && c->maxlen < 32000) {
             ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
+            // ANNCHOR_LEV_ANCHOR=1: one pair per wave (k_lev_a); default: packed for one wave per SIMD (k_lev_a2)
+            if (!(env_a && atoi(env_a) == 1) && src.n == c->nx && c->lev_order.p) return launch_a2(c, src, d_out);
             return launch_a(c, src, d_out);
         }
         if (R == 9 && W <= 32) {   // k_lev_f (strings up to 1024 symbols: a slot's lanes must map to distinct banks)

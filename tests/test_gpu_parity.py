@@ -153,14 +153,26 @@ def test_levenshtein_anchor_round_kernel_ragged(monkeypatch):
     eng.pick_anchors_selected(anchors)
     got = eng.download(_native.F_D).reshape(nx, len(anchors))
     assert np.array_equal(got, want)
-    monkeypatch.setenv("ANNCHOR_LEV_ANCHOR", "0")   # the pair-list kernel on the same one-to-all launches
-    eng2 = _native.Engine(0)
-    levenshtein.bind(eng2, X)
-    eng2.pick_anchors_selected(anchors)
-    assert np.array_equal(eng2.download(_native.F_D).reshape(nx, len(anchors)), want)
+    for mode in ("0", "1"):   # the pair-list kernel / the one-pair-per-wave split kernel on the same one-to-all launches
+        monkeypatch.setenv("ANNCHOR_LEV_ANCHOR", mode)
+        eng2 = _native.Engine(0)
+        levenshtein.bind(eng2, X)
+        eng2.pick_anchors_selected(anchors)
+        assert np.array_equal(eng2.download(_native.F_D).reshape(nx, len(anchors)), want)
+    # a data set where every string has <= 16 words (all waves packed) and one with none (no wave packed)
+    for lo, hi in ((0, 500), (513, 700)):
+        Y = ["".join(rng.choice(alphabet[:7], n)) for n in rng.integers(lo, hi, 301)]
+        monkeypatch.delenv("ANNCHOR_LEV_ANCHOR", raising=False)
+        e3 = _native.Engine(0)
+        levenshtein.bind(e3, Y)
+        an = [0, 7, 300]
+        e3.pick_anchors_selected(an)
+        Py = om.PackedStrings(Y)
+        w3 = np.stack([Py.pairs(np.stack([np.full(len(Y), a_), np.arange(len(Y))], axis=1)) for a_ in an], axis=1)
+        assert np.array_equal(e3.download(_native.F_D).reshape(len(Y), 3), w3)
 
 
-@pytest.mark.parametrize("variant", ["anchor0"])
+@pytest.mark.parametrize("variant", ["0", "1"])
 def test_anchor_round_kernel_vs_pair_list_kernel_fit(variant, strings, monkeypatch):
     """Max-min picking with the fused arg-max in k_lev_a against the same fit with the anchor rounds on the pair-list
     kernel (ANNCHOR_LEV_ANCHOR=0): same anchors, distances and graph."""
@@ -168,7 +180,7 @@ def test_anchor_round_kernel_vs_pair_list_kernel_fit(variant, strings, monkeypat
     X = np.array(strings[::4])
     cfg = dict(n_anchors=12, n_neighbors=10, n_samples=700, p_work=0.3, random_seed=42)
     ref = Annchor(X, "levenshtein", **cfg).fit()
-    monkeypatch.setenv("ANNCHOR_LEV_ANCHOR", "0")
+    monkeypatch.setenv("ANNCHOR_LEV_ANCHOR", variant)
     alt = Annchor(X, "levenshtein", **cfg).fit()
     assert np.array_equal(ref.A, alt.A) and np.array_equal(ref.D, alt.D)
     assert np.array_equal(ref.neighbor_graph[0], alt.neighbor_graph[0]) and np.array_equal(ref.neighbor_graph[1], alt.neighbor_graph[1])

@@ -7,8 +7,9 @@ from annchor_amd.distances import levenshtein
 from annchor_amd.datasets import load_strings
 
 X = list(load_strings()["X"])
-for mode in ("1", "0", "1", "0"):
+for mode, ldsreq in (("2", "0"), ("2", "40960"), ("2", "53248"), ("2", "0"), ("2", "40960"), ("0", "0")):
     os.environ["ANNCHOR_LEV_ANCHOR"] = mode
+    os.environ["ANNCHOR_LEV_A2_LDS"] = ldsreq
     eng = _native.Engine(0)
     levenshtein.bind(eng, X)
     eng.pick_anchors_maxmin(15, 1126)
@@ -22,6 +23,6 @@ for mode in ("1", "0", "1", "0"):
         ts.append(time.perf_counter() - t0)
     p = eng.prof_get()["levenshtein_pairs"]
     A = eng.download(_native.F_A)
-    print("ANNCHOR_LEV_ANCHOR=%s: %.1f us per launch (events), 15 rounds wall %.1f us (min %.1f), A[:5]=%s" % (
-        mode, p["ms"] / p["launches"] * 1e3, np.median(ts) * 1e6, min(ts) * 1e6, A[:5]))
+    print("LDS request %s ANNCHOR_LEV_ANCHOR=%s: %.1f us per launch (events), 15 rounds wall %.1f us (min %.1f), A[:5]=%s" % (
+        ldsreq, mode, p["ms"] / p["launches"] * 1e3, np.median(ts) * 1e6, min(ts) * 1e6, A[:5]))
     eng.close()
