@@ -246,16 +246,22 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
                                                            c->cidx.as<int32_t>(), c->cval.as<double>());
     }
     {
-        // algorithmic bytes per lookahead pair: both computed lists once, 12 B per entry
         const int64_t counted = c->n_unc >= 0 ? 2 * (c->n - c->n_unc) : total;   // computed entries, both directions
         const double avg = nx > 0 ? (double)counted / (double)nx : 0.0;
-        ProfScope ps(c, "update_bounds_intersect", (double)c->nnext * (2.0 * avg * 12.0 + 36.0));
-        const size_t tab_bytes = (((size_t)nx + 1) / 2) * 4;
         const char *ube = getenv("ANNCHOR_UPDATE_BOUNDS");   // "pairs" / "rows" force a form (tests compare the two)
         // long lists only: with ~100 entries per list (C2) the table rebuilds and the 512-entry strides cost more
         // than they save (0.28 vs 0.14 ms); at 800 entries per list 12.8 vs 18.1 ms
-        const bool rows_form = ube ? strcmp(ube, "rows") == 0 : avg >= 256.0;
-        if (nx < 65536 && tab_bytes <= 150 * 1024 && rows_form) {
+        const bool rows_form = (ube ? strcmp(ube, "rows") == 0 : avg >= 256.0) && nx < 65536 && (((size_t)nx + 1) / 2) * 4 <= 150 * 1024;
+        // Algorithmic bytes (12 B per list entry: key + value).  Wave-per-pair form: both computed lists of every
+        // lookahead pair.  Row-grouped form: the lookahead list is in pair order, so a first point's list is read once
+        // per RUN of pairs (<= one per point and per workgroup chunk) and only the partners' lists once per pair --
+        // pricing it with both lists per pair (round 2) put the fraction above 1.
+        const double runs = (double)std::min<int64_t>(c->nnext, nx + (c->nnext + UBR_CHUNK - 1) / UBR_CHUNK);
+        const double alg = rows_form ? (double)c->nnext * (avg * 12.0 + 36.0) + runs * avg * 12.0
+                                     : (double)c->nnext * (2.0 * avg * 12.0 + 36.0);
+        ProfScope ps(c, "update_bounds_intersect", alg);
+        const size_t tab_bytes = (((size_t)nx + 1) / 2) * 4;
+        if (rows_form) {
             if (tab_bytes > 64 * 1024)
                 ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_rows, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                      (int)tab_bytes));
