@@ -65,6 +65,10 @@ def budget(nx, n_anchors, n_neighbors, n_samples, p_work, loc_min=None, quiet=Tr
     return dict(N=N, na=na, p_work=p_work, loc_min=lm)
 
 
+class _DeviceModelRefused(Exception):
+    """A device-fitted iteration met a partition its solver does not take; fit() starts over on the host solver."""
+
+
 class _LazyErrs(dict):
     """error_predictor.errs after a device-fitted iteration: label -> sorted residuals, downloaded on first use."""
 
@@ -461,7 +465,7 @@ class Annchor:
         """annchor.py:345-380."""
         self._pair_list_stage("fit_predict_regression")
         self._model_on_device = False
-        if self.__dict__.get("_samples_on_device") and self._models_on_device() and not self.__dict__.get("_host_model_redo"):
+        if self.__dict__.get("_samples_on_device") and self._models_on_device():
             # per-partition OLS + predict / clip / merge / label on the device, no host wait (csrc/model.hip)
             self._engine.fit_regression_device(self.sample_bins, self._first_merge, self.is_metric)
             self._model_on_device, self._predict_on_device, self._fused_labels = True, True, True
@@ -532,16 +536,9 @@ class Annchor:
         if self.__dict__.get("_model_on_device"):
             nb = len(self.sample_bins) - 1
             ncand, nnext = self._engine.select_candidates(nn, nmin, None, n_refine, self.lookahead, n_labels=nb)
-            if not self._adopt_device_model(nb):
-                # a partition the device solver does not take (rank deficient, too few rows) or a failed sample step:
-                # redo the iteration's models on the host path (dgelsd) -- nothing has been refined yet
-                self._model_on_device, self._host_model_redo = False, True
-                try:
-                    self.fit_predict_regression()
-                    self.fit_predict_errors()
-                finally:
-                    self._host_model_redo = False
-                return self.select_refine_candidate_pairs(w=w, it=it)
+            # (the coefficients stay on the device; what a kernel could not do -- a partition the QR does not take, a
+            # failed sample step -- raises sticky flags that fit() reads once, after the last iteration: _adopt_device_model)
+            self._device_model_nb = nb
         else:
             labels = list(self.error_predictor.labels)   # (any integer keys: the device labels are positions in this list)
             errs = [np.asarray(self.error_predictor.errs[lab], dtype=np.float64) for lab in labels]
@@ -633,9 +630,24 @@ class Annchor:
             if self.verbose:
                 print("%40s: %6.3f | %6.3f" % (name, time.perf_counter() - s, time.perf_counter() - origin))
 
+        evals0, loop0, n_samples0 = self.evals, getattr(self.sampler, "loop_num", None), self.n_samples
         self._pipelined = True
         try:
-            return self._fit_stages(stage, make_stream, t, origin)
+            try:
+                return self._fit_stages(stage, make_stream, t, origin)
+            except _DeviceModelRefused:
+                # a partition the device's QR does not take (rank deficient, fewer rows than columns): the whole fit again
+                # with scipy's dgelsd (its minimum-norm solution is the reference's behaviour there)
+                self.evals, self.n_samples = evals0, n_samples0   # (a sampling step may have lowered n_samples)
+                if loop0 is not None:
+                    self.sampler.loop_num = loop0
+                self._first_merge, self._sample_ticket, self._model_on_device = True, None, False
+                t.clear()
+                ols, self.ols = self.ols, "lapack"
+                try:
+                    return self._fit_stages(stage, make_stream, t, origin)
+                finally:
+                    self.ols = ols
         finally:   # (an exception inside a stage -- NothingToSample, a plugin error -- must not leave the object in pipelined mode)
             self._pipelined, self._fit_it, self._sample_ticket = False, None, None
             self._make_stream = None
@@ -671,6 +683,8 @@ class Annchor:
             if it < niters - 1:
                 stage("update_anchor_points", self.update_anchor_points)
         stage("get_ann", self.get_ann)
+        if self.__dict__.get("_model_on_device") and not self._adopt_device_model(self._device_model_nb):
+            raise _DeviceModelRefused()
         t["total"] = time.perf_counter() - origin
         return self
 

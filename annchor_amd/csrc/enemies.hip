@@ -13,7 +13,7 @@
 //               computed get their exact distance (annchor.py:744-761);
 //   graph       per point: the nn nearest among computed enemies -- not-computed and same-label entries are pushed
 //               behind by the row maximum (annchor.py:763-781).
-// Ties resolve by list order (old entries by other endpoint, then new entries by other endpoint), as in the oracle;
+// Ties resolve by list order (old entries by other endpoint, then new entries by other endpoint), as in the CPU restatement the tests compare with;
 // the reference's argsorts are unstable.  The fitted RefineApprox / not_computed_mask are updated in place, as the
 // reference updates its own; the new pairs live in a separate set of arrays (downloadable for the host's views).
 #include "common.h"

@@ -40,7 +40,9 @@ def test_device_model_equals_lapack_model_strings_small(cfg):
     X = _strings()[::5]
     a = Annchor(X, "levenshtein", ols="device", **cfg).fit()
     b = Annchor(X, "levenshtein", ols="lapack", **cfg).fit()
-    assert a._model_on_device and not b.__dict__.get("_model_on_device")
+    # (with these few samples a partition can be collinear: the device then refuses and fit() starts over on dgelsd --
+    # either way the models must agree)
+    assert not b.__dict__.get("_model_on_device")
     _check_same_model(a, b)
     assert np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1]) and np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0])
 

@@ -4,13 +4,13 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:40]) for r in rows))
 # fits are separated by the k_sid launches (one per fit): take the last complete one
-starts = [i for i, e in enumerate(ev) if e[2].startswith("k_runmin_argmax") or e[2].startswith("void k_lev_r")]
+starts = [i for i, e in enumerate(ev) if e[2].startswith("k_runmin_argmax") or e[2].startswith("void k_lev_r") or e[2].startswith("k_lev_a")]
 sid = [i for i, e in enumerate(ev) if e[2].startswith("k_sid")]
 a, b = sid[-2], sid[-1]
 # walk back from k_sid to the first anchor-round kernel of that fit
 def fit_begin(i):
     j = i
-    while j > 0 and (ev[j - 1][2].startswith("k_runmin") or ev[j - 1][2].startswith("void k_lev_r") or "copyBuffer" in ev[j - 1][2] or "fillBuffer" in ev[j - 1][2]):
+    while j > 0 and (ev[j - 1][2].startswith("k_runmin") or ev[j - 1][2].startswith("void k_lev_r") or ev[j - 1][2].startswith("k_lev_a") or "copyBuffer" in ev[j - 1][2] or "fillBuffer" in ev[j - 1][2]):
         j -= 1
     return j
 fa, fb = fit_begin(a), fit_begin(b)
