@@ -7,6 +7,7 @@
 #define ST_SLAB 32
 #define ST_THREADS 256
 #define ST_KMAX 32
+#define ST_KMAX_BIG 64
 #define ST_SURV 1024
 #define ST_KEEP 512
 #define ST_EARLY_WINDOW 64   // tiles per yield window of the tile phase (knn_tile_phase)

@@ -1458,7 +1458,8 @@ template <int DIM, int KMAX> static int launch_knn2(annchor_ctx *c, const KnnArg
 
 template <int DIM> static int launch_knn(annchor_ctx *c, const KnnArgs &a, bool join)
 {
-    return a.K <= 16 ? launch_knn2<DIM, 16>(c, a, join) : launch_knn2<DIM, ST_KMAX>(c, a, join);
+    // list capacity by n_neighbors: 16 / 32 entries per row (two workgroups per CU), 64 (the lists alone are 66 KB: one per CU)
+    return a.K <= 16 ? launch_knn2<DIM, 16>(c, a, join) : a.K <= ST_KMAX ? launch_knn2<DIM, ST_KMAX>(c, a, join) : launch_knn2<DIM, ST_KMAX_BIG>(c, a, join);
 }
 
 static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool join)
@@ -1705,7 +1706,7 @@ static int knn_args_graph(annchor_ctx *c, KnnArgs &a, const void *Xs_all, const 
                           const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors, int32_t tile_begin,
                           int32_t tile_count, int32_t k)
 {
-    ANN_REQUIRE(c, k >= 2 && k - 1 <= ST_KMAX, ANNCHOR_ELIMIT, "streamed form supports 2 <= n_neighbors <= %d", ST_KMAX + 1);
+    ANN_REQUIRE(c, k >= 2 && k - 1 <= ST_KMAX_BIG, ANNCHOR_ELIMIT, "streamed form supports 2 <= n_neighbors <= %d", ST_KMAX_BIG + 1);
     ANN_REQUIRE(c, n_all == (int64_t)nt_all * ST_T && tile_begin >= 0 && tile_begin + tile_count <= nt_all, ANNCHOR_EINVAL,
                 "tile range out of bounds");
     ANN_REQUIRE(c, n_all < (1ll << 31), ANNCHOR_ELIMIT, "n_all exceeds 2^31");
@@ -1823,7 +1824,7 @@ extern "C" int annchor_stream_query(annchor_ctx *c, const void *Xs_all, const vo
                                     int64_t *tile_evals)
 {
     if (!c || !Xs_all || !rs_all || !perm_all || !lo_all || !hi_all || !mid_all || !out_idx || !out_dist) return ANNCHOR_EINVAL;
-    ANN_REQUIRE(c, nn >= 1 && nn <= ST_KMAX, ANNCHOR_ELIMIT, "streamed query supports 1 <= nn <= %d", ST_KMAX);
+    ANN_REQUIRE(c, nn >= 1 && nn <= ST_KMAX_BIG, ANNCHOR_ELIMIT, "streamed query supports 1 <= nn <= %d", ST_KMAX_BIG);
     ANN_REQUIRE(c, n_all == (int64_t)nt_all * ST_T && n_all < (1ll << 31), ANNCHOR_EINVAL, "column arrays out of range");
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     StreamState *s = state_of(c, false);
