@@ -38,6 +38,7 @@ _SIGNATURES = {
     "annchor_synchronize": (ctypes.c_int, [_vp]),
     "annchor_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "annchor_set_strings": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32]),
+    "annchor_set_strings_u16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32]),
     "annchor_set_points_f32": (ctypes.c_int, [_vp, _vp, _i64, _i32]),
     "annchor_set_points_f64": (ctypes.c_int, [_vp, _vp, _i64, _i32]),
     "annchor_set_points_cosine_f32": (ctypes.c_int, [_vp, _vp, _i64, _i32]),
@@ -361,8 +362,13 @@ class Engine:
 
     # ------------------------------------------------------------ data set
     def set_strings(self, codes, offs, lens, alphabet):
-        codes, offs, lens = _c(codes, np.uint8), _c(offs, np.int64), _c(lens, np.int32)
-        self._chk(self.lib.annchor_set_strings(self.h, _ptr(codes), _ptr(offs), _ptr(lens), len(lens), int(alphabet)))
+        offs, lens = _c(offs, np.int64), _c(lens, np.int32)
+        if np.asarray(codes).dtype == np.uint16:   # more than 256 distinct symbols: 16-bit codes
+            codes = _c(codes, np.uint16)
+            self._chk(self.lib.annchor_set_strings_u16(self.h, _ptr(codes), _ptr(offs), _ptr(lens), len(lens), int(alphabet)))
+        else:
+            codes = _c(codes, np.uint8)
+            self._chk(self.lib.annchor_set_strings(self.h, _ptr(codes), _ptr(offs), _ptr(lens), len(lens), int(alphabet)))
         self.nx, self.metric = len(lens), METRIC_LEVENSHTEIN
 
     def set_points(self, X, cosine=False):

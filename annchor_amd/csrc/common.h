@@ -48,6 +48,7 @@ struct annchor_ctx {
     int64_t nx = 0;
     DevBuf sym, soff, slen;  // strings: symbols (uint8, 16B-aligned starts), int32 offsets, int32 lens
     int alphabet = 0, maxlen = 0;
+    bool sym_wide = false;   // symbols are 16-bit codes (annchor_set_strings_u16: alphabets of 257..65535 symbols); soff counts symbols
     // Levenshtein slot packing: patterns of <= lev_gl0 words fit one more pair per wave than the data
     // set's longest string allows (0: no such class); lev_frac0 = share of the strings that short
     int lev_gl0 = 0;

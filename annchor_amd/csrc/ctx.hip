@@ -412,6 +412,49 @@ extern "C" int annchor_set_opaque(annchor_ctx *c, int64_t nx)
     return ANNCHOR_OK;
 }
 
+// Strings over more than 256 distinct symbols: 16-bit dense codes 0 .. alphabet - 1, alphabet <= 65 535 (code 0xffff is the
+// kernel's "no symbol").  Evaluated by k_lev_w (lev.hip): match words computed per column instead of looked up.
+extern "C" int annchor_set_strings_u16(annchor_ctx *c, const uint16_t *symbols, const int64_t *offs, const int32_t *lens, int64_t nx,
+                                       int32_t alphabet)
+{
+    if (!c || !symbols || !offs || !lens) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, nx > 1 && nx < (1ll << 31), ANNCHOR_ELIMIT, "nx=%lld out of range", (long long)nx);
+    ANN_REQUIRE(c, alphabet >= 1 && alphabet <= 65535, ANNCHOR_ELIMIT, "alphabet=%d not in 1..65535", alphabet);
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    std::vector<int32_t> o((size_t)nx);
+    size_t total = 0;
+    int maxlen = 0;
+    for (int64_t s = 0; s < nx; ++s) {
+        ANN_REQUIRE(c, lens[s] >= 0, ANNCHOR_EINVAL, "negative length at %lld", (long long)s);
+        o[(size_t)s] = (int32_t)total;
+        total += ((size_t)lens[s] + 7) & ~(size_t)7;      // 16-byte aligned starts
+        if (lens[s] > maxlen) maxlen = lens[s];
+        ANN_REQUIRE(c, total < (1ull << 30), ANNCHOR_ELIMIT, "string pool exceeds 2 GiB");
+    }
+    ANN_REQUIRE(c, maxlen <= 2048, ANNCHOR_ELIMIT, "string length %d exceeds the supported 2048 (16-bit symbols)", maxlen);
+    std::vector<uint16_t> pool(total + 64, 0xffffu);
+    for (int64_t s = 0; s < nx; ++s) {
+        for (int32_t k = 0; k < lens[s]; ++k)
+            ANN_REQUIRE(c, symbols[offs[s] + k] < alphabet, ANNCHOR_EINVAL, "symbol code out of range in string %lld", (long long)s);
+        memcpy(pool.data() + o[(size_t)s], symbols + offs[s], sizeof(uint16_t) * (size_t)lens[s]);
+    }
+    ANN_TRY(ann_arena_init(c, nx));
+    ANN_TRY(ann_reserve(c, c->sym, pool.size() * sizeof(uint16_t)));
+    ANN_TRY(ann_reserve(c, c->soff, sizeof(int32_t) * (size_t)nx));
+    ANN_TRY(ann_reserve(c, c->slen, sizeof(int32_t) * (size_t)nx));
+    ANN_TRY(ann_h2d(c, c->sym.p, pool.data(), pool.size() * sizeof(uint16_t)));
+    ANN_TRY(ann_h2d(c, c->soff.p, o.data(), sizeof(int32_t) * (size_t)nx));
+    ANN_TRY(ann_h2d(c, c->slen.p, lens, sizeof(int32_t) * (size_t)nx));
+    c->metric = ANNCHOR_METRIC_LEVENSHTEIN;
+    c->nx = nx;
+    c->alphabet = alphabet;
+    c->maxlen = maxlen;
+    c->sym_wide = true;
+    c->lev_gl0 = 0; c->lev_frac0 = 0.0; c->lev_nshort = 0;
+    reset_pipeline(c);
+    return ANNCHOR_OK;
+}
+
 extern "C" int annchor_set_strings(annchor_ctx *c, const uint8_t *symbols, const int64_t *offs,
                                    const int32_t *lens, int64_t nx, int32_t alphabet)
 {
@@ -449,6 +492,7 @@ extern "C" int annchor_set_strings(annchor_ctx *c, const uint8_t *symbols, const
     c->nx = nx;
     c->alphabet = alphabet;
     c->maxlen = maxlen;
+    c->sym_wide = false;
     {   // anchor rounds (lev.hip, k_lev_a2): strings of <= 16 words first
         std::vector<int32_t> ord((size_t)nx);
         int64_t ns = 0;

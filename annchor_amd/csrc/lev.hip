@@ -1253,9 +1253,161 @@ static int launch_a(annchor_ctx *c, const PairSource &src, double *d_out)
     return ANNCHOR_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// k_lev_w: alphabets beyond 256 distinct symbols (annchor_set_strings_u16: 16-bit dense codes, up to 65 536 -- any
+// Unicode corpus).  A per-pattern match-mask table would be alphabet x 128 B of LDS per half-wave, so the match word of
+// a column is computed instead: a lane keeps the 32 symbols of its pattern word in 16 registers (two 16-bit codes each)
+// and compares them with the column's text symbol -- ~80 VALU instructions per word-column next to the 15 of the
+// recurrence: about six times slower than k_lev_f, exact for any alphabet.  One slot class (the longer string is the
+// pattern), text staged in LDS as 16-bit codes, no fused arg-max (the picker's separate launch takes over).
+struct LevArgsW {
+    const uint16_t *sym;
+    const int32_t *soff;   // offsets in SYMBOLS, multiples of 8 (16-byte aligned starts)
+    const int32_t *slen;
+    const int2 *ij;
+    const int32_t *idx;
+    const int32_t *anchor;
+    int64_t n;
+    double *out;
+    double *RA;
+    uint8_t *ncm;
+    int GL, P, text_stride;   // lanes per slot, slots per wave, uint16 entries of text per slot
+};
+
+__global__ __launch_bounds__(ANN_WAVE) void k_lev_w(LevArgsW a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x, GL = a.GL, P = a.P;
+    const int g = lane / GL, w = lane - g * GL;
+    const bool slot_ok = g < P;
+    uint16_t *txt_g = reinterpret_cast<uint16_t *>(smem) + (size_t)(slot_ok ? g : 0) * a.text_stride;
+    int *ssum = reinterpret_cast<int *>(smem + (size_t)P * a.text_stride * 2);
+    const int64_t n_tasks = (a.n + P - 1) / P;
+    uint32_t hp_or = w == 0 ? 0x80000000u : 0u;
+    uint32_t hn_and = w == 0 ? 0u : 0xffffffffu;
+    asm volatile("" : "+v"(hp_or), "+v"(hn_and));
+    for (int64_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        const int64_t t_pair = task * P + g;
+        const bool active = slot_ok && t_pair < a.n;
+        int si = 0, sj = 0;
+        int64_t opos = t_pair;
+        if (active) {
+            if (a.anchor) { si = *a.anchor; sj = (int)t_pair; }
+            else {
+                const int64_t q = a.idx ? a.idx[t_pair] : t_pair;
+                const int2 p = a.ij[q];
+                si = p.x; sj = p.y;
+                if (a.idx) opos = q;
+            }
+        }
+        const int li = active ? a.slen[si] : 0, lj = active ? a.slen[sj] : 0;
+        const bool swap = li < lj;                 // pattern = the longer string
+        const int ps = swap ? sj : si, ts = swap ? si : sj;
+        const int m = swap ? lj : li, n = swap ? li : lj;
+        const uint16_t *pat = a.sym + (active ? a.soff[ps] : 0);
+        const uint16_t *tex = a.sym + (active ? a.soff[ts] : 0);
+        const int Wp = (m + 31) >> 5;
+        if (slot_ok && w == 0) ssum[g] = 0;
+        // this lane's 32 pattern symbols, two per register; slots past the pattern's end get a code no text symbol has
+        uint32_t pr[16];
+        {
+            const uint4 *p16 = reinterpret_cast<const uint4 *>(pat + w * 32);
+            const bool has = active && w < Wp;
+            const uint4 z = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+            const uint4 q0 = has ? p16[0] : z, q1 = has ? p16[1] : z, q2 = has ? p16[2] : z, q3 = has ? p16[3] : z;
+            const uint32_t v[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            const int valid = has ? min(32, m - w * 32) : 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                uint32_t x = v[r];
+                if (2 * r >= valid) x |= 0x0000ffffu;        // (0xffff is never a dense code: alphabets hold <= 65 535 symbols)
+                if (2 * r + 1 >= valid) x |= 0xffff0000u;
+                pr[r] = x;
+            }
+        }
+        if (slot_ok)
+            for (int e = w * 8; e < a.text_stride; e += GL * 8) *reinterpret_cast<uint4 *>(txt_g + e) = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        wave_lds_fence();
+        if (active) {
+            const int chunks = (n + 7) >> 3;   // 8 symbols per 16 bytes
+            for (int ch = w; ch < chunks; ch += GL)
+                reinterpret_cast<uint4 *>(txt_g + LEVR_PAD)[ch] = reinterpret_cast<const uint4 *>(tex)[ch];
+        }
+        wave_lds_fence();
+        uint32_t vp = 0xffffffffu, vn = 0u;
+        const uint32_t un = (active && m > 0) ? (uint32_t)n : 0u;
+        int max_steps = (active && m > 0) ? n + Wp - 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) max_steps = max(max_steps, __shfl_xor(max_steps, off));
+        max_steps = __builtin_amdgcn_readfirstlane(max_steps);
+        const uint16_t *tp = txt_g + LEVR_PAD - w;
+        uint32_t out_hp = 0, out_hn = 0;
+        for (int k = 0; k < max_steps; ++k) {
+            const uint32_t c = tp[k];
+            const uint32_t cc = c | (c << 16);
+            uint32_t eq = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t x = pr[r] ^ cc;
+                eq |= ((x & 0xffffu) == 0u ? 1u : 0u) << (2 * r);
+                eq |= ((x >> 16) == 0u ? 1u : 0u) << (2 * r + 1);
+            }
+            const uint32_t hp_up = dpp_shr1_or(out_hp, hp_or), hn_up = dpp_shr1_and(out_hn, hn_and);
+            const bool valid = (uint32_t)(k - w) < un;
+            const uint32_t cin = hn_up >> 31;
+            const uint32_t x = eq | cin;
+            const uint32_t d0 = (((x & vp) + vp) ^ vp) | x | vn;
+            const uint32_t hp = vn | ~(d0 | vp);
+            const uint32_t hn = d0 & vp;
+            const uint32_t hps = __builtin_amdgcn_alignbit(hp, hp_up, 31);
+            const uint32_t hns = __builtin_amdgcn_alignbit(hn, hn_up, 31);
+            const uint32_t nvp = hns | ~(d0 | hps), nvn = hps & d0;
+            vp = valid ? nvp : vp;
+            vn = valid ? nvn : vn;
+            out_hp = hp;
+            out_hn = hn;
+        }
+        if (active) {
+            const uint32_t rows = w < Wp - 1 ? 0xffffffffu : (w == Wp - 1 ? (0xffffffffu >> (31 - ((m - 1) & 31))) : 0u);
+            const int part = __popc(vp & rows) - __popc(vn & rows);
+            if (part) atomicAdd(&ssum[g], part);
+        }
+        wave_lds_fence();
+        if (active && w == 0) {
+            const double d = (double)(n + ssum[g]);
+            if (a.out) a.out[t_pair] = d;
+            if (a.RA) { a.RA[opos] = d; a.ncm[opos] = 0; }
+        }
+        wave_lds_fence();
+    }
+}
+
+static int launch_w(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm)
+{
+    LevArgsW a;
+    a.sym = c->sym.as<uint16_t>(); a.soff = c->soff.as<int32_t>(); a.slen = c->slen.as<int32_t>();
+    a.ij = src.ij; a.idx = src.idx; a.anchor = src.anchor; a.n = src.n; a.out = d_out; a.RA = d_RA; a.ncm = d_ncm;
+    const int W = std::max(1, (c->maxlen + 31) / 32);
+    ANN_REQUIRE(c, W <= 64, ANNCHOR_ELIMIT, "strings longer than 2048 symbols are not supported by this build (max %d)", c->maxlen);
+    a.GL = W; a.P = 64 / W;
+    a.text_stride = 2 * LEVR_PAD + ((c->maxlen + 7) & ~7) + 8;
+    const size_t lds = (size_t)a.P * a.text_stride * 2 + 256;
+    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "strings of %d symbols need %zu B of LDS", c->maxlen, lds);
+    if (lds > 64 * 1024)
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t blocks = (src.n + a.P - 1) / a.P;
+    const int64_t max_blocks = (int64_t)c->prop.multiProcessorCount * 32;
+    if (blocks > max_blocks) blocks = max_blocks;
+    ProfScope ps(c, "levenshtein_pairs", (double)src.n * (4.0 * c->maxlen + 8));
+    k_lev_w<<<(int)blocks, ANN_WAVE, lds, c->stream>>>(a);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
 int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm)
 {
     if (src.n == 0) return ANNCHOR_OK;
+    if (c->sym_wide) return launch_w(c, src, d_out, d_RA, d_ncm);   // > 256 distinct symbols: 16-bit codes
     LevArgs a;
     a.sym = c->sym.as<uint8_t>();
     a.soff = c->soff.as<int32_t>();

@@ -8,14 +8,16 @@ libannchor_hip.so.  Called on two loose objects it evaluates them on the GPU thr
 a scratch context; inside `Annchor` the data set is uploaded once and whole pair
 lists are evaluated per call (`get_exact_ijs`).  There is no CPU implementation.
 """
+import os
+
 import numpy as np
 
 from . import _native
 
 
 def encode_strings(strings):
-    """Python strings -> (codes uint8, offs int64, lens int32, alphabet size).
-    Symbols are mapped to dense codes 0..A-1 (A <= 256)."""
+    """Python strings -> (codes uint8 or uint16, offs int64, lens int32, alphabet size).
+    Symbols are mapped to dense codes 0..A-1: one byte per symbol up to 256 distinct symbols, two bytes up to 65 535."""
     strings = list(strings)
     lens = np.fromiter((len(s) for s in strings), dtype=np.int32, count=len(strings))
     joined = "".join(strings)
@@ -30,14 +32,16 @@ def encode_strings(strings):
     except UnicodeEncodeError:
         raw = np.frombuffer(joined.encode("utf-32-le"), dtype=np.uint32)
         symbols = np.unique(raw)
-        if symbols.size > 256:
-            raise ValueError("levenshtein on the GPU supports at most 256 distinct symbols, got %d" % symbols.size)
-        codes = np.searchsorted(symbols, raw).astype(np.uint8)
+        if symbols.size > 65535:
+            raise ValueError("levenshtein on the GPU supports at most 65 535 distinct symbols, got %d" % symbols.size)
+        codes = np.searchsorted(symbols, raw).astype(np.uint8 if symbols.size <= 256 else np.uint16)
+    if os.environ.get("ANNCHOR_LEV_WIDE"):   # test hook: the 16-bit path on any alphabet
+        codes = codes.astype(np.uint16)
     offs = np.zeros(len(strings), dtype=np.int64)
     if len(strings) > 1:
         np.cumsum(lens[:-1], out=offs[1:])
     if codes.size == 0:
-        codes = np.zeros(1, dtype=np.uint8)
+        codes = np.zeros(1, dtype=codes.dtype)
     return codes, offs, lens, max(1, int(symbols.size))
 
 

@@ -86,6 +86,10 @@ int annchor_last_kernel_ms(annchor_ctx *ctx, float *ms);
  * 0..alphabet-1 (the host maps characters to codes). */
 int annchor_set_strings(annchor_ctx *ctx, const uint8_t *symbols, const int64_t *offs,
                         const int32_t *lens, int64_t nx, int32_t alphabet);
+/* The same for alphabets of 257 .. 65 535 distinct symbols: 16-bit dense codes (a Unicode corpus).  Levenshtein then runs the
+ * kernel that computes its match words per column (about six times slower than the table-driven ones, exact for any alphabet). */
+int annchor_set_strings_u16(annchor_ctx *ctx, const uint16_t *symbols, const int64_t *offs, const int32_t *lens, int64_t nx,
+                            int32_t alphabet);
 int annchor_set_points_f32(annchor_ctx *ctx, const float *X, int64_t nx, int32_t dim);
 int annchor_set_points_f64(annchor_ctx *ctx, const double *X, int64_t nx, int32_t dim);
 /* Same data, metric = cosine distance 1 - u.v / (|u| |v|), clipped to [0, 2]

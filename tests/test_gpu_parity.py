@@ -172,6 +172,67 @@ def test_levenshtein_anchor_round_kernel_ragged(monkeypatch):
         assert np.array_equal(e3.download(_native.F_D).reshape(len(Y), 3), w3)
 
 
+def test_levenshtein_wide_alphabet(monkeypatch):
+    """More than 256 distinct symbols (16-bit codes, k_lev_w: match words computed per column).  (i) The wide kernel forced
+    on the ragged byte-alphabet set must equal the oracle's C restatement; (ii) strings over ~3000 distinct code points
+    (CJK range) against a NumPy DP; (iii) a fit on such strings equals the fit with a Python metric on the host."""
+    from annchor_amd import Annchor, _native
+    from annchor_amd.distances import levenshtein
+
+    rng = np.random.default_rng(31)
+    alphabet = [chr(c) for c in range(60, 120)]
+    lens = list(range(0, 70)) + [95, 96, 97, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 640, 1000]
+    X = ["".join(rng.choice(alphabet[: rng.integers(2, 60)], n)) for n in lens for _ in range(2)] + ["", ""]
+    monkeypatch.setenv("ANNCHOR_LEV_WIDE", "1")
+    eng = _native.Engine(0)
+    levenshtein.bind(eng, X)
+    IJ = rng.integers(0, len(X), (6000, 2))
+    IJ[:100, 1] = IJ[:100, 0]
+    assert np.array_equal(eng.metric_pairs(IJ), om.PackedStrings(X).pairs(IJ))
+    eng.pick_anchors_selected([3, 150, len(X) - 1])
+    P = om.PackedStrings(X)
+    want = np.stack([P.pairs(np.stack([np.full(len(X), a_), np.arange(len(X))], axis=1)) for a_ in (3, 150, len(X) - 1)], axis=1)
+    assert np.array_equal(eng.download(_native.F_D).reshape(len(X), 3), want)
+    monkeypatch.delenv("ANNCHOR_LEV_WIDE")
+
+    def dp(a, b):   # textbook unit-cost DP, one NumPy row at a time
+        a, b = np.array([ord(c) for c in a]), np.array([ord(c) for c in b])
+        prev = np.arange(len(b) + 1)
+        for i in range(len(a)):
+            sub = prev[:-1] + (b != a[i])
+            cur = np.minimum(sub, prev[1:] + 1)
+            cur = np.concatenate([[i + 1], cur])
+            # insertions: cur[j] = min(cur[j], cur[j-1] + 1), a running minimum of (cur[j] - j)
+            cur = np.minimum.accumulate(cur - np.arange(len(b) + 1)) + np.arange(len(b) + 1)
+            prev = cur
+        return int(prev[-1])
+
+    cjk = [chr(c) for c in range(0x4E00, 0x4E00 + 3000)]
+    Y = []
+    for _ in range(120):
+        base = list(rng.choice(cjk, rng.integers(0, 180)))
+        Y.append("".join(base))
+        for _ in range(2):   # near-duplicates: non-trivial distances
+            v = list(base)
+            for _ in range(rng.integers(0, 12)):
+                if v and rng.random() < 0.5:
+                    v.pop(rng.integers(0, len(v)))
+                else:
+                    v.insert(rng.integers(0, len(v) + 1), rng.choice(cjk))
+            Y.append("".join(v))
+    e2 = _native.Engine(0)
+    levenshtein.bind(e2, Y)
+    assert e2.lib is not None
+    IJ2 = rng.integers(0, len(Y), (400, 2))
+    got = e2.metric_pairs(IJ2)
+    assert list(got) == [dp(Y[i], Y[j]) for i, j in IJ2]
+    cfg = dict(n_anchors=6, n_neighbors=6, n_samples=300, p_work=0.4)
+    a = Annchor(np.array(Y, dtype=object), "levenshtein", **cfg).fit()
+    b = Annchor(np.array(Y, dtype=object), dp, **cfg).fit()
+    assert np.array_equal(a.A, b.A) and np.array_equal(a.D, b.D)
+    assert np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1])
+
+
 @pytest.mark.parametrize("variant", ["0", "1"])
 def test_anchor_round_kernel_vs_pair_list_kernel_fit(variant, strings, monkeypatch):
     """Max-min picking with the fused arg-max in k_lev_a against the same fit with the anchor rounds on the pair-list
