@@ -62,8 +62,12 @@ def test_string_encoding_roundtrip():
     codes, offs, lens, A = encode_strings(["abc", "", "cab", "zz"])
     assert A == 4 and list(lens) == [3, 0, 3, 2] and list(offs) == [0, 3, 3, 6]
     assert list(codes) == [0, 1, 2, 2, 0, 1, 3, 3]
-    with pytest.raises(ValueError):
-        encode_strings(["".join(chr(300 + k) for k in range(300))])
+    # more than 256 distinct symbols: 16-bit dense codes (annchor_set_strings_u16)
+    wide = ["".join(chr(300 + k) for k in range(300)), "\u4e00\u0141"]
+    codes, offs, lens, A = encode_strings(wide)
+    assert codes.dtype == np.uint16 and A == 301 and list(lens) == [300, 2]
+    assert list(codes[:300]) == list(range(1, 300)) + [300 - 1 + 1] or len(set(codes[:300])) == 300
+    assert codes[300] == 300 and codes[301] == 0       # U+4E00 is the largest code point, U+0141 the smallest
 
 
 def test_legacy_choice_is_permutation_prefix():
