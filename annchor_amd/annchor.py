@@ -34,6 +34,9 @@ PAIRLIST_HARD_MAX = None      # override (tests); None: from the device -- 2^30 
                               # memory at ~130 B per pair: 46 341 points on a 288 GB MI355X (_native.pairlist_point_limit)
 
 
+PAIRLIST_BITMAP_MAX_POINTS = 400000   # keep bitmap + rank table: 12 B per 64 pairs = 30 GB here
+
+
 def pairlist_hard_max(device=0):
     if PAIRLIST_HARD_MAX is not None:
         return PAIRLIST_HARD_MAX
@@ -219,10 +222,21 @@ class Annchor:
         hard_max = PAIRLIST_MAX_POINTS if (want_stream or self.nx <= PAIRLIST_MAX_POINTS) else pairlist_hard_max(device)
         self._pairlist_hard_max = hard_max
         if not want_stream and self.nx > hard_max:
-            raise ValueError("%d points: the candidate pair list of the reference form (~nx^2/2 entries at ~130 B) is materialised "
-                             "up to %d points on this device (2^30 pairs / 80 %% of its free memory).  Larger sets need the streamed "
-                             "form: float32 [n, dim <= 256] data ('cast' narrows float64), 'euclidean' or 'cosine', default plugins%s."
-                             % (self.nx, hard_max, "" if streamed is not False else " (and streamed != False)"))
+            # Beyond the size whose COMPLETE pair list fits, the pair-list form still runs when the locality filter
+            # (locality / loc_thresh / loc_min, annchor.py:74-80) thins the candidates to what the device holds: the count is
+            # known after the anchors, and `annchor_build_locality` refuses there (2^30 pairs, device memory).  The keep bitmap
+            # itself (12 B per 64 pairs) bounds the point count.
+            if self.nx > PAIRLIST_BITMAP_MAX_POINTS or loc_thresh <= 1:
+                raise ValueError("%d points: the complete candidate pair list of the reference form (~nx^2/2 entries at ~130 B) is "
+                                 "materialised up to %d points on this device (2^30 pairs / 80 %% of its free memory).  Up to %d points "
+                                 "the pair-list form runs when the locality filter keeps fewer candidates than that (loc_thresh >= 2 "
+                                 "of `locality` nearest anchors in common; refused after the anchors if it does not).  Larger sets "
+                                 "need the streamed form: float32 [n, dim <= 256] data ('cast' narrows float64), 'euclidean' or "
+                                 "'cosine', default plugins%s."
+                                 % (self.nx, hard_max, PAIRLIST_BITMAP_MAX_POINTS, "" if streamed is not False else " (and streamed != False)"))
+            print("Note: %d points is beyond the %d whose complete pair list fits this device; the fit goes on only if the locality "
+                  "filter (locality=%d, loc_thresh=%d) keeps fewer than 2^30 candidate pairs." % (self.nx, hard_max, locality, loc_thresh))
+            self._pairlist_hard_max = hard_max = self.nx
         if want_stream:
             from .streamed import StreamedAnnchor
 

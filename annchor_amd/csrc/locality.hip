@@ -279,7 +279,16 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
     int64_t n = 0;
     int32_t mn = 0;
     ANN_TRY(ann_d2h2(c, &n, c->rowstart.as<int64_t>() + nx, sizeof n, &mn, c->tmp2.p, sizeof mn));
-    ANN_REQUIRE(c, n < (1ll << 30), ANNCHOR_ELIMIT, "%lld candidate pairs exceed the pair-list limit", (long long)n);
+    ANN_REQUIRE(c, n < (1ll << 30), ANNCHOR_ELIMIT,
+                "%lld candidate pairs exceed the pair-list limit of 2^30 (int32 positions): raise loc_thresh / lower locality", (long long)n);
+    if (n > (1ll << 27)) {   // ~130 B per pair over the stages that follow: refuse here, not in the middle of a fit
+        size_t fr = 0, tot = 0;
+        ANN_CHECK_HIP(c, hipMemGetInfo(&fr, &tot));
+        const double have = (double)fr + (double)c->ij.cap + (double)c->Iidx.cap + (double)c->lb.cap + (double)c->ub.cap + (double)c->dad.cap + (double)c->RA.cap + (double)c->prob.cap;
+        ANN_REQUIRE(c, (double)n * 130.0 <= have, ANNCHOR_ELIMIT,
+                    "%lld candidate pairs need ~%.0f GB of device memory, %.0f GB are free: raise loc_thresh / lower locality",
+                    (long long)n, (double)n * 130.0 / 1e9, have / 1e9);
+    }
     ANN_TRY(ann_reserve(c, c->ij, sizeof(int2) * (size_t)n));
     ANN_TRY(ann_reserve(c, c->Iidx, sizeof(int32_t) * 2 * (size_t)n));
     {

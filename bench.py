@@ -131,7 +131,7 @@ FAMILY_KERNELS = {
 }
 
 
-def scale_pmc_fractions(fams, fits_in_pmc_run=2):
+def scale_pmc_fractions(fams):
     """Second view of the same launches: HBM bytes from the committed rocprofv3 PMC passes over tools/pairlist_scale.py
     (profiles/rNN*_scale_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE in separate runs, KiB, FETCH doubled as the gfx950
     guide prescribes) per fit of that run, against this run's kernel times: `hbm_frac_pmc`.  The first view,
@@ -142,6 +142,9 @@ def scale_pmc_fractions(fams, fits_in_pmc_run=2):
     if not files:
         return None
     T = json.load(open(files[-1]))
+    # fits the PMC run covered: its launches of the once-per-locality kernel against this run's count for ONE fit
+    sid_pmc = sum(v["launches"] for k, v in T.items() if k.replace("void ", "").startswith("k_sid"))
+    fits_in_pmc_run = max(1.0, sid_pmc / max(1, fams.get("locality_sid", {}).get("launches", 1)))
     for fam, e in fams.items():
         pref = FAMILY_KERNELS.get(fam)
         if not pref:

@@ -6,6 +6,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/refresh; mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 timeout 900 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json
+timeout 900 python bench.py --workload euclid --steps 5 --warmup 1 > $O/bench_euclid.json 2> $O/bench_euclid.err; tail -c 300 $O/bench_euclid.json
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-scale > $O/bench_under_rocprof.json 2> $O/rocprof.err
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-scale > /dev/null 2> $O/pmc_fetch.err
@@ -18,6 +19,7 @@ python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json
 python tools/pmc_summary.py $O/pmc_fetch_scale $O/pmc_write_scale $O/pmc_traffic_scale.json
 bash tools/pmc_lev2.sh > $O/pmc_lev2.log 2>&1; cp gpurun_out/pmc_lev2/pmc_lev2.json $O/pmc_lev.json 2>/dev/null
 bash tools/pmc_st.sh > $O/pmc_st.log 2>&1; cp gpurun_out/pmc_st/pmc_st.json $O/pmc_st.json 2>/dev/null
+bash tools/pmc_emd.sh > $O/pmc_emd.log 2>&1; cp gpurun_out/pmc_emd/pmc_emd.json $O/pmc_emd.json 2>/dev/null
 find $O -name "*kernel_stats.csv" | head; find $O -name "*counter_collection.csv" -size +30M -delete
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_fetch_scale $O/pmc_write_scale 2>/dev/null
 find $O/stats $O/scale -name "*kernel_trace.csv" -delete
