@@ -236,6 +236,45 @@ def test_pair_list_form_above_30000_points():
     ann._engine.close()
 
 
+def test_pair_list_form_beyond_the_complete_list_needs_locality(monkeypatch):
+    """Above the size whose complete pair list fits the device the constructor asks for a locality filter that thins the
+    candidates (refused with the default loc_thresh=1, accepted with loc_thresh >= 2: the count is checked after the anchors)."""
+    import annchor_amd.annchor as A
+    from annchor_amd import Annchor
+
+    monkeypatch.setattr(A, "PAIRLIST_HARD_MAX", 31000)
+    X = latent(32000, 8).astype(np.float64)
+    with pytest.raises(ValueError, match="locality filter"):
+        Annchor(X, "euclidean", n_anchors=8, n_neighbors=5, p_work=0.05, streamed=False)
+    a = Annchor(X, "euclidean", n_anchors=8, n_neighbors=5, p_work=0.05, streamed=False, loc_thresh=2)
+    assert a._streamed is None
+
+
+def test_levenshtein_60000_points_with_locality():
+    """Slow metric beyond 46 341 points: 60 000 clustered strings, the locality filter (3 of the 5 nearest of 40 anchors in
+    common) keeps the candidate list under 2^30 pairs; recall against exact rows of a subset."""
+    from annchor_amd import Annchor, compare_neighbor_graphs
+    from annchor_amd.datasets import synthetic_string_clusters
+    from annchor_amd.samplers import DeviceStratifiedSampler
+
+    n, k = 60000, 15
+    X = synthetic_string_clusters(n)
+    ann = Annchor(X, "levenshtein", n_anchors=40, n_neighbors=k, p_work=0.02, locality=5, loc_thresh=3,
+                  sampler=DeviceStratifiedSampler()).fit()
+    assert ann._streamed is None and 1e8 < ann.n_pairs < 2 ** 30
+    rows = np.random.default_rng(3).choice(n, 100, replace=False)
+    err = 0
+    for r in rows:
+        d = ann._engine.metric_pairs(np.stack([np.full(n, r), np.arange(n)], axis=1))
+        d[r] = -1
+        want = np.sort(d)[:k]
+        want[0] = 0
+        z = np.zeros((1, k), dtype=np.int64)
+        err += compare_neighbor_graphs((z, want[None, :]), (z, ann.neighbor_graph[1][r][None, :]), k)
+    assert err <= 0.08 * len(rows) * k, err
+    ann._engine.close()
+
+
 def test_device_pointer_tensor_view():
     import torch
 

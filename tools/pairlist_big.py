@@ -1,5 +1,7 @@
 """The pair-list form beyond 30 000 points: how far does the materialised candidate list go on one 288 GB GPU?
-usage: pairlist_big.py N [metric]   (metric: euclidean | levenshtein)"""
+usage: pairlist_big.py N [metric] [p_work] [locality] [loc_thresh] [n_anchors]   (metric: euclidean | levenshtein)
+Beyond the size whose complete pair list fits (46 341 points) the locality filter has to thin the candidates: e.g.
+  pairlist_big.py 100000 levenshtein 0.005 5 3 24"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,22 +15,16 @@ if metric == "euclidean":
     Z = rng.standard_normal((n, 6))
     X = (Z @ rng.standard_normal((6, 48)) + 0.05 * rng.standard_normal((n, 48))).astype(np.float64)
 else:
-    # families of mutated strings (like the reference's load_strings), length ~120
-    base = ["".join(rng.choice(list("abcdefghijklmnopqrstuvwxyz"), 120)) for _ in range(n // 50 + 1)]
-    X = []
-    for s in range(n):
-        b = list(base[s % len(base)])
-        for _ in range(rng.integers(0, 30)):
-            p = rng.integers(0, len(b))
-            r = rng.random()
-            if r < 0.4: b[p] = "abcdefghijklmnopqrstuvwxyz"[rng.integers(26)]
-            elif r < 0.7 and len(b) > 60: b.pop(p)
-            else: b.insert(p, "abcdefghijklmnopqrstuvwxyz"[rng.integers(26)])
-        X.append("".join(b))
-    X = np.array(X)
+    from annchor_amd.datasets import synthetic_string_clusters
+    X = synthetic_string_clusters(n, cluster=int(os.environ.get("CLUSTER", 2000)))
 k = 15
+p_work = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
+locality = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+loc_thresh = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+n_anchors = int(sys.argv[6]) if len(sys.argv) > 6 else 24
 t = time.perf_counter()
-ann = Annchor(X, metric, n_anchors=24, n_neighbors=k, p_work=0.05, n_samples=5000, sampler=DeviceStratifiedSampler())
+ann = Annchor(X, metric, n_anchors=n_anchors, n_neighbors=k, p_work=p_work, n_samples=5000, locality=locality, loc_thresh=loc_thresh,
+              sampler=DeviceStratifiedSampler())
 tc = time.perf_counter() - t
 ann._engine.prof_enable(1)
 t = time.perf_counter(); ann.fit(); dt = time.perf_counter() - t
