@@ -262,12 +262,20 @@ __global__ __launch_bounds__(256) void k_sel_pass(const double *__restrict__ val
 #define S2_NB2 1024   // bits 41..32
 #define S2_NB3 2048   // bits 31..21 (long lists only)
 #define S2_CAP 4096   // candidates the finishing workgroup holds in LDS
+#define S3_SAMPLE_MIN (1ll << 23)   // lists this long bracket the wanted ranks from a sample first (one read instead of two)
 #define S2_LEVEL3_MIN (1ll << 22)   // lists this long filter a third time (smooth keys leave ~n / 2^11 candidates per level)
 struct Sel2State {
     uint64_t prefix[SEL_MAXQ];
     int64_t k[SEL_MAXQ];
     int nq, unfinished;
     unsigned long long cnt;
+};
+// Sampled bracket (long lists): what the sample kernel decided and what the bracket pass counted
+struct Sel3Info {
+    uint64_t lo[SEL_MAXQ], hi[SEL_MAXQ];   // key brackets (lo, hi] holding each wanted rank (with overwhelming probability)
+    long long lt[SEL_MAXQ], eq[SEL_MAXQ];  // flagged keys < lo[q] / == lo[q] (a heavy tie on the bracket's edge is counted, not copied)
+    long long drop[SEL_MAXQ];              // flagged keys <= lo[q] outside every bracket: what the wanted rank moves down by
+    long long kept;                        // keys inside the union of the brackets
 };
 struct Sel2Tables {
     uint32_t hist0[S2_NB0];
@@ -279,6 +287,10 @@ struct Sel2Tables {
     unsigned long long vor[2][SEL_MAXQ], vnand[2][SEL_MAXQ];
     // ---- not part of the zeroed region
     Sel2State st1, st2, st3, out;
+    Sel3Info s3;   // (directly behind `out`: one download brings both)
+    // the sample of the bracket path: keys (~0 = not flagged) gathered by S3_WG workgroups, the last one to finish reduces them
+    uint64_t skey[8192];
+    uint32_t sdone;
 };
 #define S2_ZERO_BYTES offsetof(Sel2Tables, st1)
 struct Sel2Sh {
@@ -323,8 +335,9 @@ template <int NB> __device__ __forceinline__ void sel2_step(const uint32_t *hist
     krem = sh.krem;
 }
 
+// (segcnt != nullptr: `vals` is a segmented candidate list -- what the bracket pass kept)
 __global__ __launch_bounds__(S2_T) void k_sel2_hist0(const double *__restrict__ vals, const uint8_t *__restrict__ flag, int64_t n,
-                                                    Sel2Tables *__restrict__ tb)
+                                                    Sel2Tables *__restrict__ tb, const uint32_t *__restrict__ segcnt)
 {
     __shared__ uint32_t lh[S2_NB0];
     for (int t = threadIdx.x; t < S2_NB0; t += S2_T) lh[t] = 0;
@@ -332,6 +345,8 @@ __global__ __launch_bounds__(S2_T) void k_sel2_hist0(const double *__restrict__ 
     const int lane = threadIdx.x & 63;
     const int64_t ntiles = (n + S2_TILE - 1) / S2_TILE;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t lim = segcnt ? segcnt[tile] : (uint32_t)S2_TILE;
+        if (lim == 0) break;   // (segmented input comes packed from the bracket pass: nothing behind an empty segment)
         double v[S2_ITEMS];
         uint8_t f[S2_ITEMS];
 #pragma unroll
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(S2_T) void k_sel2_hist0(const double *__restrict__ 
             const int64_t t = tile * S2_TILE + j * S2_T + threadIdx.x;
             v[j] = ann_ldc(vals, t, n);
             f[j] = flag ? ann_ldc(flag, t, n) : (uint8_t)1;
-            if (t >= n) f[j] = 0;
+            if (t >= n || (uint32_t)(j * S2_T + threadIdx.x) >= lim) f[j] = 0;
         }
 #pragma unroll
         for (int j = 0; j < S2_ITEMS; ++j) {
@@ -380,11 +395,29 @@ __device__ __forceinline__ bool sel2_tied(const unsigned long long *vor, const u
 // The candidate lists are segmented by tile (see above); segcnt_in is the view of the input list.
 // Levels 2 and 3 also gather the tie statistics of their survivors; level 3 does nothing when
 // level 2 already found every bucket to be one repeated value.
-template <int LEVEL> __global__ __launch_bounds__(S2_T, LEVEL == 1 ? 8 : 4) void k_sel2_filter(const double *__restrict__ vals,
+// rank of query q inside the kept list.  A query whose answer is its bracket's lower edge (the rank falls into the keys
+// counted as == lo) needs no selection: it borrows the rank of the first query that does, so that it adds no candidates.
+__device__ __forceinline__ bool sel3_on_edge(const Sel3Info &s, const Sel2Init &init, int q)
+{
+    return init.k[q] >= s.lt[q] && init.k[q] < s.lt[q] + s.eq[q];
+}
+__device__ __forceinline__ int64_t sel3_rank(const Sel3Info &s, const Sel2Init &init, int q)
+{
+    int p = q;
+    if (sel3_on_edge(s, init, q)) {
+        p = -1;
+        for (int o = 0; o < init.nq; ++o)
+            if (p < 0 && !sel3_on_edge(s, init, o)) p = o;
+        if (p < 0) return 0;
+    }
+    return max((int64_t)0, init.k[p] - (int64_t)s.drop[p]);
+}
+
+template <int LEVEL, bool SEG = false> __global__ __launch_bounds__(S2_T, LEVEL == 1 ? 8 : 4) void k_sel2_filter(const double *__restrict__ vals,
                                                                           const uint8_t *__restrict__ flag, int64_t n,
                                                                           const uint32_t *__restrict__ segcnt_in, Sel2Init init,
                                                                           Sel2Tables *__restrict__ tb, double *__restrict__ dst,
-                                                                          uint32_t *__restrict__ segcnt_out)
+                                                                          uint32_t *__restrict__ segcnt_out, int packed)
 {
     constexpr int NBP = LEVEL == 1 ? S2_NB0 : LEVEL == 2 ? S2_NB1 : S2_NB2;
     constexpr int NBN = LEVEL == 1 ? S2_NB1 : LEVEL == 2 ? S2_NB2 : S2_NB3;
@@ -406,7 +439,9 @@ template <int LEVEL> __global__ __launch_bounds__(S2_T, LEVEL == 1 ? 8 : 4) void
         if (q < nq) {
             int digit; int64_t krem;
             const uint32_t *hp = LEVEL == 1 ? tb->hist0 : LEVEL == 2 ? tb->hist1 + q * S2_NB1 : tb->hist2 + q * S2_NB2;
-            sel2_step<NBP>(hp, LEVEL == 1 ? init.k[q] : si->k[q], sh, digit, krem);
+            // (SEG: the input is what the bracket pass kept; the wanted rank moves down by the keys it dropped below the bracket)
+            const int64_t k1 = SEG ? sel3_rank(tb->s3, init, q) : init.k[q];
+            sel2_step<NBP>(hp, LEVEL == 1 ? k1 : si->k[q], sh, digit, krem);
             pre[q] = (LEVEL == 1 ? 0ull : si->prefix[q]) | ((uint64_t)digit << SHP);
             // (workgroup-uniform: keep it in scalar registers)
             pre[q] = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pre[q] >> 32)) << 32) |
@@ -426,8 +461,12 @@ template <int LEVEL> __global__ __launch_bounds__(S2_T, LEVEL == 1 ? 8 : 4) void
     unsigned long long vo[SEL_MAXQ] = {0, 0, 0, 0}, vn[SEL_MAXQ] = {0, 0, 0, 0};
     const int64_t ntiles = (n + S2_TILE - 1) / S2_TILE;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t lim = LEVEL == 1 ? min((int64_t)S2_TILE, n - tile * S2_TILE) : (int64_t)segcnt_in[tile];
+        const int64_t lim = (LEVEL == 1 && !SEG) ? min((int64_t)S2_TILE, n - tile * S2_TILE) : (int64_t)segcnt_in[tile];
         if (lim == 0) {   // an empty segment stays empty
+            if (packed) {   // (the bracket pass packs a workgroup's keys into its first segments: nothing behind an empty one)
+                for (int64_t o = tile + (int64_t)tid * gridDim.x; o < ntiles; o += (int64_t)S2_T * gridDim.x) segcnt_out[o] = 0;
+                break;
+            }
             if (tid == 0) segcnt_out[tile] = 0;
             continue;
         }
@@ -440,7 +479,7 @@ template <int LEVEL> __global__ __launch_bounds__(S2_T, LEVEL == 1 ? 8 : 4) void
             // (clamped, unconditional: the whole batch stays in flight; a tile always has lim >= 1 or is skipped)
             const int64_t tc = o < lim ? t : tile * S2_TILE;
             v[j] = 0.0; f[j] = 0;
-            if (LEVEL == 1 || j * S2_T < lim) {   // (uniform) a short segment fills only its first slices
+            if ((LEVEL == 1 && !SEG) || j * S2_T < lim) {   // (uniform) a short segment fills only its first slices
                 v[j] = vals[tc];
                 f[j] = (LEVEL == 1 && flag) ? flag[tc] : (uint8_t)1;
                 if (o >= lim) f[j] = 0;
@@ -449,7 +488,7 @@ template <int LEVEL> __global__ __launch_bounds__(S2_T, LEVEL == 1 ? 8 : 4) void
         uint32_t keep = 0;
 #pragma unroll
         for (int j = 0; j < S2_ITEMS; ++j) {
-            if (LEVEL != 1 && j * S2_T >= lim) break;
+            if ((LEVEL != 1 || SEG) && j * S2_T >= lim) break;
             const uint64_t key = ann_key_asc(v[j]);
 #pragma unroll
             for (int q = 0; q < SEL_MAXQ; ++q) {
@@ -506,6 +545,274 @@ template <int LEVEL> __global__ __launch_bounds__(S2_T, LEVEL == 1 ? 8 : 4) void
     for (int t = tid; t < nq * NBN; t += S2_T)
         if (lh[t]) atomicAdd(&hnext[t], lh[t]);
     if (LAST && tid < nq && (lor[tid] | lnand[tid])) { atomicOr(&tb->vor[SLOT][tid], lor[tid]); atomicOr(&tb->vnand[SLOT][tid], lnand[tid]); }
+}
+
+// ------------------------------------------------- sampled bracket (long lists)
+// The top 11 key bits are a double's sign and most of its exponent: on real columns (distances of one order of
+// magnitude, probabilities) one or two buckets hold nearly every key, so level 1 above copies nearly the whole list and the
+// selection costs two reads and a write of it.  For long lists a sample decides first where the wanted ranks lie:
+// S3_M keys at a fixed stride, sorted by one workgroup; the sample rank of the k-th flagged key is Binomial(k, S3_M / n) --
+// mean r = k S3_M / n, deviation <= sqrt(r) -- so the sample's order statistics r -+ (5 sqrt(r + 1) + 4) bracket it except
+// with probability < 10^-6.  ONE pass over the list then keeps the keys inside the brackets (a few percent), counts what it
+// drops below each bracket and histograms the top bits of what it keeps; levels 1..3 and the finishing workgroup run on that
+// short list with the ranks moved down accordingly.  The host checks the answer against the bracket (and the moved rank
+// against the kept count) when it downloads it and repeats the selection the plain way if the sample misled -- the result
+// is exact either way.
+#define S3_M 8192
+#define S3_NB 4096
+__device__ __forceinline__ uint32_t sel3_hash(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// One workgroup: S3_M keys, one per stratum of n / S3_M consecutive entries at a hashed offset inside it (a fixed stride
+// aliases with the row structure of a pair list: at 16 000 points the stride is about one row), and two 4096-bin histograms
+// of them -- linear in the key (a log-like scale: good for values over many binades) and linear in the value (good for a
+// bounded range such as probabilities).  The bins holding the sample ranks r -+ w give each bracket edge twice; the tighter
+// one counts.  A lower edge that IS a heavily repeated value (probability 0) excludes that value: its keys are counted.
+#define S3_WG 8   // workgroups gathering the sample (8192 dependent-free but TLB-missing loads: 44 us from one CU)
+__global__ __launch_bounds__(S2_T) void k_sel3_sample(const double *__restrict__ vals, const uint8_t *__restrict__ flag, int64_t n,
+                                                     Sel2Init init, Sel2Tables *__restrict__ tb)
+{
+    __shared__ uint32_t hK[S3_NB], hV[S3_NB];
+    __shared__ unsigned long long kmin_sh, kmax_sh;
+    __shared__ int ms_sh, last_sh;
+    __shared__ uint32_t wsum[2][S2_T / 64];
+    __shared__ int found[SEL_MAXQ][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    static_assert(S3_M == S3_WG * S2_T && S3_M == 8192, "one sample per thread of the gathering workgroups");
+    {
+        const int s = blockIdx.x * S2_T + tid;
+        const int64_t b0 = (int64_t)(((unsigned long long)s * (unsigned long long)n) / S3_M);
+        const int64_t b1 = (int64_t)(((unsigned long long)(s + 1) * (unsigned long long)n) / S3_M);
+        const int64_t pos = b0 + (int64_t)(sel3_hash((uint32_t)s * 2654435761u + 12345u) % (uint32_t)max((int64_t)1, b1 - b0));
+        const bool f = flag ? flag[pos] != 0 : true;
+        const uint64_t k = ann_key_asc(vals[pos]);
+        tb->skey[s] = f ? k : ~0ull;
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last_sh = atomicAdd(&tb->sdone, 1u) == (uint32_t)(gridDim.x - 1);
+    __syncthreads();
+    if (!last_sh) return;
+    __threadfence();
+    if (tid == 0) { kmin_sh = ~0ull; kmax_sh = 0ull; ms_sh = 0; tb->sdone = 0; }
+    for (int t2 = tid; t2 < S3_NB; t2 += S2_T) { hK[t2] = 0; hV[t2] = 0; }
+    __syncthreads();
+    constexpr int PER = S3_M / S2_T;
+    uint64_t key[PER];
+    bool fl[PER];
+    uint64_t mn = ~0ull, mx = 0ull;
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        key[j] = __builtin_nontemporal_load(&tb->skey[j * S2_T + tid]);
+        fl[j] = key[j] != ~0ull;
+        if (fl[j]) { mn = min(mn, key[j]); mx = max(mx, key[j]); ++mine; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = min(mn, (uint64_t)__shfl_xor((unsigned long long)mn, off));
+        mx = max(mx, (uint64_t)__shfl_xor((unsigned long long)mx, off));
+        mine += __shfl_xor(mine, off);
+    }
+    if (lane == 0 && mine) { atomicMin(&kmin_sh, (unsigned long long)mn); atomicMax(&kmax_sh, (unsigned long long)mx); atomicAdd(&ms_sh, mine); }
+    __syncthreads();
+    const int ms = ms_sh;
+    const uint64_t kmin = kmin_sh, kmax = kmax_sh, range = ms ? kmax - kmin : 0ull;
+    const int sK = range ? max(0, 64 - (int)__clzll((long long)range) - 12) : 0;   // (range >> sK) < 4096
+    const double vmin = ann_key_asc_inv(kmin), vmax = ann_key_asc_inv(kmax);
+    const double span = vmax - vmin;
+    const double scale = (ms && span > 0.0 && span < 1e300) ? (double)(S3_NB - 1) / span : 0.0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        // (a heavy tie -- most probabilities are exactly 0 -- puts whole waves on one bin: the leader counts for all who share its bin)
+        const uint32_t bk = fl[j] ? (uint32_t)((key[j] - kmin) >> sK) : 0u;
+        const double x = (ann_key_asc_inv(key[j]) - vmin) * scale;
+        const uint32_t bv = (fl[j] && x >= 0.0) ? (x < (double)(S3_NB - 1) ? (uint32_t)x : (uint32_t)(S3_NB - 1)) : 0u;
+        const unsigned long long am = __ballot(fl[j]);
+        if (!am) continue;
+        const int lead = __ffsll((long long)am) - 1;
+        const uint32_t k0 = __shfl(bk, lead), v0 = __shfl(bv, lead);
+        const unsigned long long mk = __ballot(fl[j] && bk == k0), mv = __ballot(fl[j] && bv == v0);
+        if (lane == lead) { atomicAdd(&hK[k0], (uint32_t)__popcll(mk)); atomicAdd(&hV[v0], (uint32_t)__popcll(mv)); }
+        if (fl[j] && bk != k0) atomicAdd(&hK[bk], 1u);
+        if (fl[j] && bv != v0) atomicAdd(&hV[bv], 1u);
+    }
+    __syncthreads();
+    {   // inclusive scans of both histograms, in place (4 bins per thread)
+        constexpr int BP = S3_NB / S2_T;
+        uint32_t a[BP], b[BP], sa = 0, sb = 0;
+#pragma unroll
+        for (int e = 0; e < BP; ++e) { sa += hK[tid * BP + e]; a[e] = sa; sb += hV[tid * BP + e]; b[e] = sb; }
+        uint32_t ia = sa, ib = sb;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t oa = __shfl_up(ia, off), ob = __shfl_up(ib, off);
+            if (lane >= off) { ia += oa; ib += ob; }
+        }
+        if (lane == 63) { wsum[0][wave] = ia; wsum[1][wave] = ib; }
+        __syncthreads();
+        uint32_t ba = 0, bb = 0;
+        for (int w = 0; w < wave; ++w) { ba += wsum[0][w]; bb += wsum[1][w]; }
+        ba += ia - sa; bb += ib - sb;
+#pragma unroll
+        for (int e = 0; e < BP; ++e) { hK[tid * BP + e] = ba + a[e]; hV[tid * BP + e] = bb + b[e]; }
+    }
+    __syncthreads();
+    if (tid < 4 * SEL_MAXQ) {
+        const int q = tid >> 2, which = tid & 3;   // 0: key map, lower  1: key map, upper  2: value map, lower  3: value map, upper
+        int bin = -1;                              // -1: no bound
+        if (q < init.nq && ms > 0) {
+            const int64_t r = (int64_t)(((unsigned long long)init.k[q] * S3_M) / (unsigned long long)n);
+            const int64_t w = (int64_t)(5.0 * sqrt((double)r + 1.0)) + 4;
+            const int64_t tr = (which & 1) ? r + w : r - w;
+            if (tr >= 0 && tr < ms) {
+                const uint32_t *cum = (which & 2) ? hV : hK;
+                int lo2 = 0, hi2 = S3_NB - 1;      // smallest bin with cum[bin] > tr
+                while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (cum[mid] > (uint32_t)tr) hi2 = mid; else lo2 = mid + 1; }
+                bin = lo2;
+            }
+        }
+        found[q][which] = bin;
+    }
+    __syncthreads();
+    if (tid < SEL_MAXQ) {
+        uint64_t lo = 0, hi = ~0ull;
+        if (tid < init.nq && ms > 0) {
+            const int bKl = found[tid][0], bKh = found[tid][1], bVl = found[tid][2], bVh = found[tid][3];
+            if (bKl >= 0) lo = kmin + ((uint64_t)bKl << sK);
+            if (bVl >= 0 && scale > 0.0) {   // (one bin of slack for the rounding of the edge)
+                const uint64_t e = bVl <= 1 ? kmin : ann_key_asc(vmin + (double)(bVl - 1) / scale);
+                lo = max(lo, min(e, kmax));
+            }
+            if (bKh >= 0) {
+                const uint64_t top = ((uint64_t)(bKh + 1) << sK) - 1;
+                hi = (sK + 12 >= 64 || kmin + top < kmin) ? ~0ull : kmin + top;
+            }
+            if (bVh >= 0 && scale > 0.0 && bVh + 2 < S3_NB - 1) hi = min(hi, max(kmin, ann_key_asc(vmin + (double)(bVh + 2) / scale)));
+            if (hi < lo) { lo = 0; hi = ~0ull; }   // (cannot happen with consistent edges; never trade exactness of the check for it)
+        }
+        tb->s3.lo[tid] = lo; tb->s3.hi[tid] = hi; tb->s3.lt[tid] = 0; tb->s3.eq[tid] = 0; tb->s3.drop[tid] = 0;
+    }
+    if (tid == 0) tb->s3.kept = 0;
+}
+
+// The bracket pass.  Counters are per wave (ballot + popcount: scalar adds), not per thread, and there is no barrier inside
+// the tile loop (a workgroup of 16 waves that meets twice per tile exposes every tile's load latency: 0.57 ms against 0.28 ms
+// for the barrier-free histogram pass over the same bytes): a wave reserves room for its kept keys with one LDS atomic on the
+// workgroup's running count g; slot g lives in the workgroup's (g / S2_TILE)-th output segment (segment ids = the tile ids
+// it reads), so that the levels that follow find a few full segments per workgroup instead of a nearly empty one per tile.
+// (A workgroup never keeps more keys than it reads: the segment exists.)
+template <int NQ> __global__ __launch_bounds__(S2_T, 2) void k_sel3_bracket(const double *__restrict__ vals, const uint8_t *__restrict__ flag,
+                                                                           int64_t n, Sel2Tables *__restrict__ tb, double *__restrict__ dst,
+                                                                           uint32_t *__restrict__ segcnt_out)
+{
+    __shared__ unsigned long long bsum[3 * SEL_MAXQ];
+    __shared__ uint32_t wg_fill;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 3 * SEL_MAXQ) bsum[tid] = 0;
+    if (tid == 0) wg_fill = 0;
+    uint64_t lo[NQ], hi[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { lo[q] = tb->s3.lo[q]; hi[q] = tb->s3.hi[q]; }
+    __syncthreads();
+    uint32_t c_lt[NQ], c_le[NQ], c_kle[NQ];   // (per lane) flagged keys < lo / <= lo / kept keys <= lo
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) c_lt[q] = c_le[q] = c_kle[q] = 0;
+    const int64_t ntiles = (n + S2_TILE - 1) / S2_TILE;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        double v[S2_ITEMS];
+        uint32_t f[S2_ITEMS];
+        static_assert(S2_ITEMS % 2 == 0, "two consecutive keys per load");
+#pragma unroll
+        for (int j = 0; j < S2_ITEMS / 2; ++j) {
+            // two consecutive keys (16 bytes) and their two flags per lane and load: half the load instructions of the
+            // one-key form.  Clamped addresses, values masked afterwards (ann_ldc's reason); the lone last key of an odd
+            // list arrives as the second half of the pair before it.
+            const int64_t e0 = tile * S2_TILE + 2 * ((int64_t)j * S2_T + tid);
+            const bool pair = e0 + 1 < n, lone = e0 + 1 == n;
+            const int64_t pc = pair ? e0 : n - 2;
+            const double2 vv = *reinterpret_cast<const double2 *>(vals + pc);
+            uint32_t ff = 0x0101u;
+            if (flag) ff = *reinterpret_cast<const unsigned short *>(flag + pc);
+            v[2 * j] = pair ? vv.x : vv.y;
+            v[2 * j + 1] = vv.y;
+            f[2 * j] = pair ? (ff & 0xffu) : lone ? (ff >> 8) : 0u;
+            f[2 * j + 1] = pair ? (ff >> 8) : 0u;
+            asm volatile("" : "+v"(f[2 * j]), "+v"(f[2 * j + 1]));   // (values in registers here, not compare masks kept alive in scalar registers)
+        }
+        // one 64-wide slice at a time; the counters take the compare results as carries (per-lane counters, summed at the end)
+        uint32_t keep = 0;   // (per lane: bit j = item j is kept)
+        uint32_t wtot = 0;
+        uint32_t slot[S2_ITEMS];
+#pragma unroll
+        for (int j = 0; j < S2_ITEMS; ++j) {
+            const uint32_t vh = (uint32_t)__double2hiint(v[j]), vl = (uint32_t)__double2loint(v[j]);
+            const uint32_t sm = (uint32_t)((int32_t)vh >> 31);   // ann_key_asc: negative values flip every bit, the others the sign bit
+            const uint64_t key = ((uint64_t)(vh ^ (sm | 0x80000000u)) << 32) | (uint64_t)(vl ^ sm);
+            const bool act = f[j] != 0;
+            bool in = false;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const bool le = act && key <= lo[q];
+                c_lt[q] += (act && key < lo[q]) ? 1u : 0u;
+                c_le[q] += le ? 1u : 0u;
+                // (pinned: left alone the compiler sums the eight slices' compare masks at the end of the tile and spills them all)
+                asm volatile("" : "+v"(c_lt[q]), "+v"(c_le[q]));
+                in = in || (act && !le && key <= hi[q]);
+            }
+            if (NQ > 1) {   // (one bracket: a kept key is never <= its lower edge)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { c_kle[q] += (in && key <= lo[q]) ? 1u : 0u; asm volatile("" : "+v"(c_kle[q])); }
+            }
+            const unsigned long long km = __ballot(in);
+            slot[j] = wtot + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+            wtot += (uint32_t)__popcll(km);
+            keep |= in ? 1u << j : 0u;
+            asm volatile("" : "+v"(keep), "+v"(slot[j]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (wtot) {   // (wave-uniform)
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&wg_fill, wtot);
+            base = __shfl(base, 0);
+#pragma unroll
+            for (int j = 0; j < S2_ITEMS; ++j)
+                if (keep & (1u << j)) {
+                    const uint32_t g = base + slot[j];
+                    dst[((int64_t)blockIdx.x + (int64_t)(g / S2_TILE) * gridDim.x) * S2_TILE + g % S2_TILE] = v[j];
+                }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            c_lt[q] += __shfl_xor(c_lt[q], off); c_le[q] += __shfl_xor(c_le[q], off); c_kle[q] += __shfl_xor(c_kle[q], off);
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (c_lt[q]) atomicAdd(&bsum[q], (unsigned long long)c_lt[q]);
+            if (c_le[q] - c_lt[q]) atomicAdd(&bsum[SEL_MAXQ + q], (unsigned long long)(c_le[q] - c_lt[q]));
+            if (c_le[q] - c_kle[q]) atomicAdd(&bsum[2 * SEL_MAXQ + q], (unsigned long long)(c_le[q] - c_kle[q]));
+        }
+    }
+    __syncthreads();
+    if (tid < 3 * SEL_MAXQ && bsum[tid]) {
+        long long *dstc = tid < SEL_MAXQ ? &tb->s3.lt[tid] : tid < 2 * SEL_MAXQ ? &tb->s3.eq[tid - SEL_MAXQ] : &tb->s3.drop[tid - 2 * SEL_MAXQ];
+        atomicAdd(reinterpret_cast<unsigned long long *>(dstc), bsum[tid]);
+    }
+    if (tid == 0) {
+        uint32_t left = wg_fill;
+        if (left) atomicAdd(reinterpret_cast<unsigned long long *>(&tb->s3.kept), (unsigned long long)left);
+        for (int64_t o = blockIdx.x; o < ntiles; o += gridDim.x) {
+            const uint32_t c = left < (uint32_t)S2_TILE ? left : (uint32_t)S2_TILE;
+            segcnt_out[o] = c;
+            left -= c;
+        }
+    }
 }
 
 // levels = filter levels run (2: hist2 splits bits 41..32, 32 bits left; 3: hist3 splits bits 31..21, 21 left)
@@ -578,6 +885,7 @@ __global__ __launch_bounds__(S2_T) void k_sel2_finish(Sel2Tables *__restrict__ t
             __syncthreads();
             uint32_t wbase = 0, total = 0;
             for (int w = 0; w < S2_T / 64; ++w) { const uint32_t x = sh.wsum[w]; if (w < wave) wbase += x; total += x; }
+            if (total == 0) continue;   // (uniform; packed candidate lists leave most segments empty)
             sbase[tid] = filled + wbase + inc - c;
             scnt[tid] = c;
             __syncthreads();
@@ -644,27 +952,75 @@ int ann_kth_smallest(annchor_ctx *c, const double *vals, const uint8_t *flag, in
     for (int q = 0; q < nk; ++q) init.k[q] = ks[q];
     // few fat workgroups: every one ends with atomics on shared histogram bins (~12.5 ns each, serialised)
     const int grid = (int)(ntiles <= 256 ? ntiles : std::min<int64_t>(S2_MAXWG, std::max<int64_t>(256, ntiles / 4)));
-    Sel2State out;
-    {
-        // algorithmic bytes: one read of the keys and their flags
-        ProfScope ps(c, "radix_select_f64", (double)n * 9.0);
-        k_sel2_hist0<<<grid, S2_T, 0, c->stream>>>(vals, flag, n, tb);
-        double *A = c->sel_bufA.as<double>(), *B = c->sel_bufB.as<double>();
-        k_sel2_filter<1><<<grid, S2_T, 0, c->stream>>>(vals, flag, n, nullptr, init, tb, A, segA);
-        const char *l3 = getenv("ANNCHOR_SEL_LEVEL3_MIN");   // tests reach the three-level route on short lists
-        if (n < (l3 ? atoll(l3) : S2_LEVEL3_MIN)) {
-            k_sel2_filter<2><<<grid, S2_T, 0, c->stream>>>(A, nullptr, n, segA, init, tb, B, segB);
-            k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, B, segB, ntiles, 2);
-        } else {   // (C reuses A's slots: A is dead once B exists)
-            k_sel2_filter<2><<<grid, S2_T, 0, c->stream>>>(A, nullptr, n, segA, init, tb, B, segB);
-            k_sel2_filter<3><<<grid, S2_T, 0, c->stream>>>(B, nullptr, n, segB, init, tb, A, segA);
-            k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, A, segA, ntiles, 3);
+    struct { Sel2State out; Sel3Info s3; } dl;
+    static_assert(offsetof(Sel2Tables, s3) == offsetof(Sel2Tables, out) + sizeof(Sel2State), "s3 sits directly behind out");
+    Sel2State &out = dl.out;
+    const char *l3 = getenv("ANNCHOR_SEL_LEVEL3_MIN");   // tests reach the three-level route on short lists
+    const char *smin = getenv("ANNCHOR_SEL_SAMPLE_MIN");  // ... and the sampled bracket
+    const bool three = n >= (l3 ? atoll(l3) : S2_LEVEL3_MIN);
+    bool sampled = n >= (smin ? atoll(smin) : S3_SAMPLE_MIN) && n >= S3_M;
+    const int grid_full = grid;
+    for (;;) {
+        // (sampled: every workgroup resident at once -- two per CU -- and half as many fixed costs in the short passes that follow)
+        const int grid = sampled ? std::min(grid_full, 2 * c->prop.multiProcessorCount) : grid_full;
+        {
+            // algorithmic bytes: one read of the keys and their flags
+            ProfScope ps(c, "radix_select_f64", (double)n * 9.0);
+            double *A = c->sel_bufA.as<double>(), *B = c->sel_bufB.as<double>();
+            uint32_t *sa = segA, *sb = segB;
+            if (sampled) {
+                k_sel3_sample<<<S3_WG, S2_T, 0, c->stream>>>(vals, flag, n, init, tb);
+                switch (nk) {
+                case 1: k_sel3_bracket<1><<<grid, S2_T, 0, c->stream>>>(vals, flag, n, tb, B, segB); break;
+                case 2: k_sel3_bracket<2><<<grid, S2_T, 0, c->stream>>>(vals, flag, n, tb, B, segB); break;
+                case 3: k_sel3_bracket<3><<<grid, S2_T, 0, c->stream>>>(vals, flag, n, tb, B, segB); break;
+                default: k_sel3_bracket<4><<<grid, S2_T, 0, c->stream>>>(vals, flag, n, tb, B, segB); break;
+                }
+                k_sel2_hist0<<<grid, S2_T, 0, c->stream>>>(B, nullptr, n, tb, segB);
+                k_sel2_filter<1, true><<<grid, S2_T, 0, c->stream>>>(B, nullptr, n, segB, init, tb, A, segA, 1);
+            } else {
+                k_sel2_hist0<<<grid, S2_T, 0, c->stream>>>(vals, flag, n, tb, nullptr);
+                k_sel2_filter<1><<<grid, S2_T, 0, c->stream>>>(vals, flag, n, nullptr, init, tb, A, segA, 0);
+            }
+            k_sel2_filter<2><<<grid, S2_T, 0, c->stream>>>(A, nullptr, n, sa, init, tb, B, sb, sampled);
+            if (!three) {
+                k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, B, sb, ntiles, 2);
+            } else {   // (C reuses A's slots: A is dead once B exists)
+                k_sel2_filter<3><<<grid, S2_T, 0, c->stream>>>(B, nullptr, n, sb, init, tb, A, sa, sampled);
+                k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, A, sa, ntiles, 3);
+            }
         }
+        ANN_CHECK_HIP(c, hipGetLastError());
+        c->sel2_clean = nullptr;
+        ANN_TRY(ann_d2h(c, &dl, &tb->out, sizeof dl));
+        c->sel2_clean = (const void *)tb;
+        if (!sampled) break;
+        // per query: the rank falls into the keys counted as == lo (answer: lo), or above (answer: the selection inside the kept
+        // list, checked against the bracket), or below lo (the sample misled)
+        bool ok = true, need_sel = false;
+        uint64_t ans[SEL_MAXQ];
+        for (int q = 0; q < nk; ++q) {
+            const long long k = ks[q], lt = dl.s3.lt[q], eq = dl.s3.eq[q];
+            if (k >= lt && k < lt + eq) { ans[q] = dl.s3.lo[q]; continue; }
+            need_sel = true;
+            const long long kp = k - dl.s3.drop[q];
+            ans[q] = out.prefix[q];
+            ok = ok && k >= lt + eq && kp >= 0 && kp < dl.s3.kept &&
+                 (out.unfinished || (out.prefix[q] > dl.s3.lo[q] && out.prefix[q] <= dl.s3.hi[q]));
+        }
+        if (getenv("ANNCHOR_SEL_DEBUG"))
+            for (int q = 0; q < nk; ++q)
+                fprintf(stderr, "sel3 n=%lld q=%d k=%lld lt=%lld eq=%lld drop=%lld kept=%lld lo=%016llx hi=%016llx got=%016llx unfinished=%d ok=%d\n",
+                        (long long)n, q, (long long)ks[q], dl.s3.lt[q], dl.s3.eq[q], dl.s3.drop[q], dl.s3.kept, (unsigned long long)dl.s3.lo[q],
+                        (unsigned long long)dl.s3.hi[q], (unsigned long long)out.prefix[q], out.unfinished, (int)ok);
+        if (need_sel && out.unfinished && ok) break;   // (a mixed bucket too long for the finishing workgroup: the byte passes below)
+        if (ok) {
+            for (int q = 0; q < nk; ++q) out.prefix[q] = ans[q];
+            out.unfinished = 0;
+            break;
+        }
+        sampled = false;   // the sample misled (adversarial order): the plain two-read selection
     }
-    ANN_CHECK_HIP(c, hipGetLastError());
-    c->sel2_clean = nullptr;
-    ANN_TRY(ann_d2h(c, &out, &tb->out, sizeof out));
-    c->sel2_clean = (const void *)tb;
     if (out.unfinished) {
         // a mixed bucket longer than the finishing workgroup's LDS: the byte passes over all keys
         ANN_TRY(ann_reserve(c, c->sel_state, sizeof(SelState) * 9));

@@ -46,12 +46,16 @@ def _check(eng, dad, ncm, ks):
     assert np.array_equal(got, want), (ks, got, want)
 
 
+@pytest.mark.parametrize("sampled", [False, True])
 @pytest.mark.parametrize("levels", [2, 3])
-@pytest.mark.parametrize("kind", ["uniform", "normal", "halfint", "tied_one", "mixed_big_bucket", "tiny", "few_values"])
-def test_kth_smallest_vs_numpy(engine_with_pairs, kind, levels, monkeypatch):
+@pytest.mark.parametrize("kind", ["uniform", "normal", "halfint", "tied_one", "mixed_big_bucket", "tiny", "few_values", "sorted",
+                                  "sample_misleads"])
+def test_kth_smallest_vs_numpy(engine_with_pairs, kind, levels, sampled, monkeypatch):
     eng, n, nat = engine_with_pairs
     # lists of 4 M keys and more filter three times before the finishing workgroup; force that here
     monkeypatch.setenv("ANNCHOR_SEL_LEVEL3_MIN", "1" if levels == 3 else str(1 << 40))
+    # ... and lists of 8 M keys and more bracket the wanted ranks from a strided sample first (one read of the list)
+    monkeypatch.setenv("ANNCHOR_SEL_SAMPLE_MIN", "1" if sampled else str(1 << 40))
     rng = np.random.RandomState(11)
     if kind == "uniform":
         dad = rng.rand(n)
@@ -69,6 +73,13 @@ def test_kth_smallest_vs_numpy(engine_with_pairs, kind, levels, monkeypatch):
         dad = (np.full(n, base).view(np.uint64) + ulps).view(np.float64)
     elif kind == "tiny":
         dad = rng.rand(n) * 1e-300
+    elif kind == "sorted":
+        dad = np.sort(rng.randn(n))
+    elif kind == "sample_misleads":
+        # the strided sample (positions s * n // 8192) sees only large values, everything else is small: the brackets miss
+        # the wanted ranks and the selection is repeated the plain way
+        dad = rng.rand(n)
+        dad[(np.arange(8192, dtype=np.int64) * n) // 8192] += 10.0
     else:
         dad = rng.choice(np.array([0.0, 0.25, 1.0, 1e-9, 7.0]), n)
     ncm = rng.rand(n) < 0.7
@@ -79,6 +90,33 @@ def test_kth_smallest_vs_numpy(engine_with_pairs, kind, levels, monkeypatch):
     # back-to-back calls reuse the tables the previous call left zeroed
     _check(eng, dad, ncm, [m // 5])
     _check(eng, dad, ncm, [m // 5, m // 4])
+
+
+def test_kth_smallest_sampled_odd_length(monkeypatch):
+    """The bracket pass reads two consecutive keys per lane: a list of odd length ends in a lone key (246 051 pairs)."""
+    from annchor_amd import Annchor, _native
+    from annchor_amd.datasets import load_strings
+    ann = Annchor(load_strings()["X"][:702], "levenshtein", n_anchors=10, n_neighbors=10, p_work=0.3, niters=1, random_seed=3)
+    ann.get_anchors()
+    ann.get_locality()
+    ann.get_features()
+    eng = ann._engine
+    n = eng.field_size(_native.F_NCM)
+    assert n % 2 == 1
+    monkeypatch.setenv("ANNCHOR_SEL_SAMPLE_MIN", "1")
+    rng = np.random.RandomState(2)
+    dad = rng.rand(n)
+    dad[-1] = 5.0      # the lone last key is the maximum ...
+    for ncm in (np.ones(n, dtype=bool), rng.rand(n) < 0.5):
+        ncm[-1] = True
+        _inject(eng, _native, dad, ncm)
+        m = int(ncm.sum())
+        _check(eng, dad, ncm, [m - 1])
+        _check(eng, dad, ncm, [0, m // 2, m - 1])
+    dad[-1] = -1.0     # ... or the minimum
+    _inject(eng, _native, dad, ncm)
+    _check(eng, dad, ncm, [0, 1, int(ncm.sum()) - 1])
+    eng.close()
 
 
 def test_kth_smallest_all_flagged_and_single(engine_with_pairs):

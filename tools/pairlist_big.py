@@ -30,7 +30,7 @@ ann._engine.prof_enable(1)
 t = time.perf_counter(); ann.fit(); dt = time.perf_counter() - t
 print("N=%d %s pairs=%d ctor %.2f s fit %.3f s evals %d (%.2f %% of all pairs)" % (n, metric, ann.n_pairs, tc, dt, ann.evals, 100.0 * ann.evals / (n * (n - 1) / 2)))
 print("host stage s:", {kk: round(v, 3) for kk, v in ann.timings.items()})
-for name, e in sorted(ann._engine.prof_get().items(), key=lambda kv: -kv[1]["ms"])[:8]:
+for name, e in sorted(ann._engine.prof_get().items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("TOPK", 8))]:
     print("  %-28s %9.2f ms x %d" % (name, e["ms"] / max(1, e["launches"]), e["launches"]))
 # recall on a row subset against exact rows (metric_pairs one-to-all)
 rows = rng.choice(n, 200, replace=False)
