@@ -60,6 +60,7 @@ struct annchor_ctx {
     int dim = 0;
     DevBuf hist, cost, supp; // histograms f64 [nx, nbins], cost [nbins, nbins], support sizes int32 [nx]
     int nbins = 0, max_support = 0;
+    bool cost_is_metric = false; // ground cost: zero diagonal + triangle inequality (common mass of two histograms cancels)
     bool hist_integral = false;  // all masses integer valued and (row sum)^2 < 2^31: exact int32 flows
 
     // ---- anchors

@@ -592,6 +592,23 @@ extern "C" int annchor_set_histograms(annchor_ctx *c, const double *hist, int64_
     c->nbins = nbins;
     c->max_support = maxs;
     c->hist_integral = integral && maxsum * maxsum < 2147483647.0;
+    // Is the ground cost a metric on the bins (zero diagonal, triangle inequality)?  Then mass two histograms hold on the same
+    // bin stays where it is in some optimal plan, and the solver works on the two differences only (csrc/emd.hip).  The
+    // inequality is tested with a relative slack of 2^-40: Euclidean costs computed in floating point miss it by an ulp on
+    // collinear bins, and a violation of eps changes the optimum by at most eps x the moved mass.
+    bool metric_cost = true;
+    for (int i = 0; i < nbins && metric_cost; ++i) {
+        if (cost[i * nbins + i] != 0.0) metric_cost = false;
+        for (int j = 0; j < nbins && metric_cost; ++j) {
+            const double cij = cost[i * nbins + j];
+            if (!(cij >= 0.0)) { metric_cost = false; break; }
+            for (int k = 0; k < nbins; ++k) {
+                const double via = cost[i * nbins + k] + cost[k * nbins + j];
+                if (cij > via + 9.094947017729282e-13 * via) { metric_cost = false; break; }
+            }
+        }
+    }
+    c->cost_is_metric = metric_cost;
     reset_pipeline(c);
     return ANNCHOR_OK;
 }

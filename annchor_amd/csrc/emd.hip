@@ -38,6 +38,7 @@ struct EmdArgs {
     double *RA;
     uint8_t *ncm;
     int32_t *fail;  // set if the iteration guard trips
+    int reduce;     // metric ground cost: solve on the differences of the two (scaled) histograms
 };
 
 // ---- wave-level min over lanes (double), result broadcast; DPP, no LDS traffic
@@ -137,24 +138,32 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
         const double xk = lane < nb ? hx[lane] : 0.0, yk = lane < nb ? hy[lane] : 0.0;
         double sa = 0, sb = 0;
         for (int k = 0; k < nb; ++k) { sa += readlane_f64(xk, k); sb += readlane_f64(yk, k); }
-        const unsigned long long mx = __ballot(xk != 0.0), my = __ballot(yk != 0.0);
+        // masses of bin `lane` in the solver's units: 1 / (sa * sb) (exact integers) or unit total mass
+        T xm, ym;
+        if (INTEGRAL) { xm = (T)(xk * sb); ym = (T)(yk * sa); }
+        else { xm = (T)(xk / sa); ym = (T)(yk / sb); }
+        if (a.reduce) {
+            // metric ground cost (c_kk = 0, triangle inequality): an optimal plan leaves min(x_k, y_k) on bin k, so only the
+            // differences travel -- sources and sinks become disjoint and fewer (two digits share most of their pixels), and
+            // the saturated (k, k) arcs whose backward edges the shortest-path searches would otherwise walk are gone
+            const T d = xm - ym;
+            xm = d > (T)0 ? d : (T)0;
+            ym = d < (T)0 ? -d : (T)0;
+        }
+        const unsigned long long mx = __ballot(xm != (T)0), my = __ballot(ym != (T)0);
         const int n = __popcll(mx), m = __popcll(my);
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (xk != 0.0) rowsL[__popcll(mx & below)] = lane;
-        if (yk != 0.0) colsL[__popcll(my & below)] = lane;
+        if (xm != (T)0) rowsL[__popcll(mx & below)] = lane;
+        if (ym != (T)0) colsL[__popcll(my & below)] = lane;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int myrow = lane < n ? rowsL[lane] : 0;   // source `lane` is histogram bin myrow
         const int mycol = lane < m ? colsL[lane] : 0;   // sink `lane` is histogram bin mycol
-        T a_rem, b_rem;   // supply of source `lane`, demand of sink `lane`
-        if (INTEGRAL) {   // units of 1 / (sa * sb): exact integers
-            a_rem = lane < n ? (T)(hx[myrow] * sb) : (T)0;
-            b_rem = lane < m ? (T)(hy[mycol] * sa) : (T)0;
-        } else {
-            a_rem = lane < n ? (T)(hx[myrow] / sa) : (T)0;
-            b_rem = lane < m ? (T)(hy[mycol] / sb) : (T)0;
-        }
+        // supply of source `lane`, demand of sink `lane`: the masses of their bins
+        T a_rem = __shfl(xm, myrow), b_rem = __shfl(ym, mycol);
+        if (lane >= n) a_rem = (T)0;
+        if (lane >= m) b_rem = (T)0;
         double u = 0.0;                                  // potential of source `lane`
         // v_j = min_i C[i][j] (first minimal source on ties): dual feasible with u = 0, and
         // arc (amin_j, j) is tight for every sink
@@ -290,6 +299,7 @@ int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
     a.out = d_out; a.RA = d_RA; a.ncm = d_ncm;
     ANN_TRY(ann_reserve(c, c->supp, 64));
     a.fail = c->supp.as<int32_t>();
+    a.reduce = c->cost_is_metric && !getenv("ANNCHOR_EMD_NO_REDUCE");
     ANN_CHECK_HIP(c, hipMemsetAsync(a.fail, 0, 4, c->stream));
     const size_t cost_bytes = sizeof(double) * (size_t)a.nb * a.nb;
     const bool integral = c->hist_integral;

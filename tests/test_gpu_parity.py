@@ -573,6 +573,42 @@ def test_wasserstein_non_integer_histograms():
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("kind", ["squared", "asymmetric", "metric_integer"])
+def test_wasserstein_cost_matrix_kinds(kind):
+    """The solver cancels the mass two histograms share on a bin only when the ground cost is a metric (zero diagonal,
+    triangle inequality: checked when the histograms are bound).  A squared-distance cost and an asymmetric cost with a
+    non-zero diagonal keep the full problem; an integer-valued metric cost on integer histograms takes the reduced integer
+    route.  All against the CPU restatement (which never reduces)."""
+    from annchor_amd import _native
+    from annchor_amd.distances import Wasserstein
+
+    rng = np.random.default_rng(11)
+    nb = 20
+    pts = rng.integers(0, 6, (nb, 2)).astype(np.float64)
+    D = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+    if kind == "squared":
+        M = D ** 2
+        X = rng.random((120, nb)) * (rng.random((120, nb)) < 0.7)
+    elif kind == "asymmetric":
+        M = D + rng.random((nb, nb))          # no symmetry, positive diagonal
+        X = rng.random((120, nb)) * (rng.random((120, nb)) < 0.7)
+    else:
+        M = np.abs(pts[:, None, 0] - pts[None, :, 0]) + np.abs(pts[:, None, 1] - pts[None, :, 1])   # L1: a metric (repeated points: zero off-diagonal entries)
+        X = rng.integers(0, 9, (120, nb)).astype(np.float64) * (rng.random((120, nb)) < 0.7)
+    X[:, 0] += 1.0
+    X[7] = X[3]          # identical histograms: nothing left to move
+    X[9] = 2.0 * X[3]    # ... also after normalisation
+    eng = _native.Engine(0)
+    Wasserstein(M).bind(eng, X)
+    IJ = np.vstack([rng.integers(0, 120, (2500, 2)), [[3, 7], [7, 3], [3, 9], [5, 5]]])
+    got = eng.metric_pairs(IJ)
+    want = om.Histograms(X, M).pairs(IJ)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-11 if kind == "squared" else 1e-12)
+    if kind == "metric_integer":
+        assert got[-4] == 0.0 and got[-3] == 0.0 and got[-2] == 0.0 and got[-1] == 0.0
+    eng.close()
+
+
 def test_fit_digits_c4():
     """BASELINE config 4: digits Wasserstein, N=1797, n_anchors=20, k=25, p_work=0.16."""
     from annchor_amd import Annchor, compare_neighbor_graphs
