@@ -56,6 +56,7 @@ _SIGNATURES = {
     "annchor_count_uncomputed": (ctypes.c_int, [_vp, ctypes.POINTER(_i64)]),
     "annchor_kth_uncomputed_dad": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
     "annchor_bin_counts": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
+    "annchor_sampler_stats": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "annchor_select_by_rank": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _vp]),
     "annchor_sample_pairs": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "annchor_sample_pairs_device": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i64]),
@@ -443,6 +444,20 @@ class Engine:
         n = _i64()
         self._chk(self.lib.annchor_count_uncomputed(self.h, ctypes.byref(n)))
         return n.value
+
+    def sampler_stats(self, iq1, iq3, n_partitions):
+        """(q1, q3, edges or None, counts or None): the two quantiles and -- when the library could chain them on the device --
+        the bin edges and populations of a sampling step, in one host wait."""
+        ks = np.array([iq1, iq3], dtype=np.int64)
+        q = np.empty(2, dtype=np.float64)
+        edges = np.empty(n_partitions + 1, dtype=np.float64)
+        counts = np.empty(n_partitions, dtype=np.int64)
+        fused = ctypes.c_int32(0)
+        self._chk(self.lib.annchor_sampler_stats(self.h, _ptr(ks), int(n_partitions), _ptr(q), _ptr(edges), _ptr(counts),
+                                                 ctypes.byref(fused)))
+        if fused.value:
+            return q[0], q[1], edges, counts
+        return q[0], q[1], None, None
 
     def kth_uncomputed_dad(self, ks):
         ks = _c(ks, np.int64)

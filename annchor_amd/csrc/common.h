@@ -88,6 +88,7 @@ struct annchor_ctx {
     DevBuf anc, ncm, label;        // uint8 [n]
     bool have_features = false, have_RA = false;
     int64_t n_unc = -1;            // cached count of not-computed pairs (-1 = unknown: recount)
+    int64_t n_unc_after_features = -1;   // ... what it will be once compute_features has marked the anchor pairs (from build_locality)
 
     // ---- samples
     DevBuf spos, sy;  // int32 [m], double [m]
@@ -101,6 +102,7 @@ struct annchor_ctx {
     DevBuf dev_flags;      // int32 [16] sticky error flags raised by kernels, read with the selection stage's final state:
                            // [0] sample step: a (bin, rank) entry did not exist
     bool dev_flags_clean = false;
+    DevBuf sstats;         // SamplerStats: quantiles, bin edges and bin counts of a sampling step (annchor_sampler_stats)
     DevBuf hs_key, hs_pos, hs_misc;   // hashed stratified sampling: per-partition candidate lists, counters / outputs
     int64_t nsamp = 0;
 
@@ -180,6 +182,10 @@ const char *ann_set_err(annchor_ctx *c, const char *fmt, ...);
 int ann_reserve(annchor_ctx *c, DevBuf &b, size_t bytes);
 int ann_arena_init(annchor_ctx *c, int64_t nx);
 int ann_h2d(annchor_ctx *c, void *dst, const void *src, size_t bytes);
+hipError_t ann_sync(annchor_ctx *c, const char *where);
+int ann_kth_async(annchor_ctx *c, const double *vals, const uint8_t *flag, int64_t n, const int64_t *ks, int nk,
+                  const unsigned long long **d_prefix, const int **d_unfinished);
+void ann_kth_async_done(annchor_ctx *c);
 int ann_d2h(annchor_ctx *c, void *dst, const void *src, size_t bytes);
 int ann_d2h2(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, void *dst2, const void *src2, size_t bytes2);
 

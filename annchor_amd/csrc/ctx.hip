@@ -81,8 +81,16 @@ int ann_h2d(annchor_ctx *c, void *dst, const void *src, size_t bytes)
         return ANNCHOR_OK;
     }
     ANN_CHECK_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));  // pageable host memory: do not retain the pointer
+    ANN_CHECK_HIP(c, ann_sync(c, __func__));  // pageable host memory: do not retain the pointer
     return ANNCHOR_OK;
+}
+
+// Every host wait of the pair-list form goes through here: ANNCHOR_SYNC_TRACE=1 names them on stderr (tools/wait_census.py).
+hipError_t ann_sync(annchor_ctx *c, const char *where)
+{
+    static const bool trace = getenv("ANNCHOR_SYNC_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "sync %s\n", where);
+    return hipStreamSynchronize(c->stream);
 }
 
 int ann_d2h(annchor_ctx *c, void *dst, const void *src, size_t bytes)
@@ -93,12 +101,12 @@ int ann_d2h(annchor_ctx *c, void *dst, const void *src, size_t bytes)
         // the sample's feature rows)
         unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
         ANN_CHECK_HIP(c, hipMemcpyAsync(slot, src, bytes, hipMemcpyDeviceToHost, c->stream));
-        ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        ANN_CHECK_HIP(c, ann_sync(c, __func__));
         memcpy(dst, slot, bytes);
         return ANNCHOR_OK;
     }
     ANN_CHECK_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    ANN_CHECK_HIP(c, ann_sync(c, __func__));
     return ANNCHOR_OK;
 }
 
@@ -110,7 +118,7 @@ int ann_d2h2(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, void *
         unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
         ANN_CHECK_HIP(c, hipMemcpyAsync(slot, src1, bytes1, hipMemcpyDeviceToHost, c->stream));
         ANN_CHECK_HIP(c, hipMemcpyAsync(slot + off2, src2, bytes2, hipMemcpyDeviceToHost, c->stream));
-        ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        ANN_CHECK_HIP(c, ann_sync(c, __func__));
         memcpy(dst1, slot, bytes1);
         memcpy(dst2, slot + off2, bytes2);
         return ANNCHOR_OK;
@@ -188,7 +196,7 @@ extern "C" int annchor_prof_get(annchor_ctx *c, int32_t max_entries, const char 
                                 int64_t *launches, double *alg_bytes)
 {
     if (!c) return ANNCHOR_EINVAL;
-    (void)hipStreamSynchronize(c->stream);
+    (void)ann_sync(c, __func__);
     prof_drain(c);
     int n = 0;
     for (auto &e : c->prof) {
@@ -281,7 +289,7 @@ extern "C" void annchor_destroy(annchor_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)ann_sync(c, __func__);
     prof_drain(c);
     ann_stream_release(c);
     ann_enemies_release(c);
@@ -378,7 +386,7 @@ extern "C" int annchor_device_name(annchor_ctx *c, char *buf, int buflen)
 extern "C" int annchor_synchronize(annchor_ctx *c)
 {
     if (!c) return ANNCHOR_EINVAL;
-    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    ANN_CHECK_HIP(c, ann_sync(c, __func__));
     return ANNCHOR_OK;
 }
 

@@ -200,7 +200,7 @@ extern "C" int annchor_compute_features(annchor_ctx *c)
     c->have_features = true;
     c->have_RA = false; c->sel_prepared = false;
     c->nsamp = 0;
-    c->n_unc = -1; c->sel_prepared = false;
+    c->n_unc = c->n_unc_after_features; c->sel_prepared = false;   // (counted by build_locality; -1 on the query path: recount)
     return ANNCHOR_OK;
 }
 
@@ -275,8 +275,8 @@ __device__ __forceinline__ int sampler_bin(const BinEdges &b, double x)
 #define BC_TILE (BC_THREADS * BC_ITEMS)
 // Few fat workgroups (their closing atomics on the shared bin counters serialise), eight
 // unconditional loads per thread in flight, per-wave LDS counters.
-__global__ __launch_bounds__(BC_THREADS) void k_bin_counts(const double *__restrict__ dad, const uint8_t *__restrict__ ncm,
-                                                          int64_t n, BinEdges be, unsigned long long *__restrict__ counts)
+__device__ __forceinline__ void bin_counts_body(const double *__restrict__ dad, const uint8_t *__restrict__ ncm, int64_t n,
+                                                const BinEdges &be, unsigned long long *__restrict__ counts)
 {
     __shared__ unsigned int lc[BC_THREADS / 64][MAXBINS];
     const int wave = threadIdx.x >> 6;
@@ -327,6 +327,48 @@ __global__ __launch_bounds__(BC_THREADS) void k_bin_counts(const double *__restr
         for (int w = 0; w < BC_THREADS / 64; ++w) s += lc[w][threadIdx.x];
         if (s) atomicAdd(&counts[threadIdx.x], s);
     }
+}
+__global__ __launch_bounds__(BC_THREADS) void k_bin_counts(const double *__restrict__ dad, const uint8_t *__restrict__ ncm,
+                                                          int64_t n, BinEdges be, unsigned long long *__restrict__ counts)
+{
+    bin_counts_body(dad, ncm, n, be, counts);
+}
+
+// ---- the statistics of a sampling step in one round trip (Sampler.get_partition + the bin populations,
+// annchor/samplers.py:75-105, utils.py:536-549): quantiles -> bin edges -> bin counts chained on the device
+struct SamplerStats {
+    BinEdges be;                         // -inf, linspace(q1, q3, nb - 1), +inf
+    double q[2];
+    unsigned long long counts[MAXBINS];
+};
+// np.linspace(q1, q3, num): step = (q3 - q1) / (num - 1), y_i = i * step + q1 (a product and a sum, each rounded; the
+// build does not contract them), the last entry q3 itself; a zero step goes through i / div * delta, which gives q1 too.
+__global__ void k_sampler_edges(const unsigned long long *__restrict__ prefix, int nparts, SamplerStats *__restrict__ st)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double q1 = ann_key_asc_inv(prefix[0]), q3 = ann_key_asc_inv(prefix[1]);
+    st->q[0] = q1; st->q[1] = q3;
+    const int num = nparts - 1, div = num > 1 ? num - 1 : 1;
+    const double delta = q3 - q1, step = delta / (double)div;
+    st->be.nb = nparts;
+    st->be.e[0] = -INFINITY;
+    for (int i = 0; i < num; ++i) {
+        double y;
+        if (step != 0.0) { const double p = (double)i * step; y = p + q1; }
+        else { const double p = ((double)i / (double)div) * delta; y = p + q1; }
+        if (num > 1 && i == num - 1) y = q3;
+        st->be.e[1 + i] = y;
+    }
+    st->be.e[nparts] = INFINITY;
+    for (int b = 0; b < MAXBINS; ++b) st->counts[b] = 0;
+}
+__global__ __launch_bounds__(BC_THREADS) void k_bin_counts_dev(const double *__restrict__ dad, const uint8_t *__restrict__ ncm,
+                                                              int64_t n, SamplerStats *__restrict__ st)
+{
+    __shared__ BinEdges be;
+    if (threadIdx.x == 0) be = st->be;
+    __syncthreads();
+    bin_counts_body(dad, ncm, n, be, st->counts);
 }
 
 static int load_bins(annchor_ctx *c, const double *bins, int32_t nbins, BinEdges &be);
@@ -511,6 +553,45 @@ extern "C" int annchor_bin_counts(annchor_ctx *c, const double *bins, int32_t nb
                                                    c->tmp2.as<unsigned long long>());
     }
     return ann_d2h(c, counts, c->tmp2.p, 8 * (size_t)nbins);
+}
+
+extern "C" int annchor_sampler_stats(annchor_ctx *c, const int64_t *ks, int32_t n_partitions, double *q, double *edges,
+                                     int64_t *counts, int32_t *fused)
+{
+    if (!c || !ks || !q || !edges || !counts || !fused) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_REQUIRE(c, n_partitions >= 2 && n_partitions <= MAXBINS, ANNCHOR_ELIMIT, "2..%d partitions supported", MAXBINS);
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    *fused = 0;
+    const unsigned long long *d_prefix = nullptr;
+    const int *d_unfinished = nullptr;
+    ANN_TRY(ann_kth_async(c, c->dad.as<double>(), c->ncm.as<uint8_t>(), c->n, ks, 2, &d_prefix, &d_unfinished));
+    if (d_prefix) {
+        ANN_TRY(ann_reserve(c, c->sstats, sizeof(SamplerStats)));
+        SamplerStats *st = c->sstats.as<SamplerStats>();
+        k_sampler_edges<<<1, 64, 0, c->stream>>>(d_prefix, n_partitions, st);
+        const int64_t ntiles = (c->n + BC_TILE - 1) / BC_TILE;
+        const int blocks = (int)(ntiles <= 256 ? ntiles : std::min<int64_t>(1024, std::max<int64_t>(256, ntiles / 4)));
+        {
+            ProfScope ps(c, "sampler_bin_counts", (double)c->n * 9.0);
+            k_bin_counts_dev<<<blocks, BC_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), c->n, st);
+        }
+        ANN_CHECK_HIP(c, hipGetLastError());
+        SamplerStats h;
+        int unfinished = 0;
+        ANN_TRY(ann_d2h2(c, &h, st, sizeof h, &unfinished, d_unfinished, sizeof unfinished));
+        ann_kth_async_done(c);
+        if (!unfinished) {
+            q[0] = h.q[0]; q[1] = h.q[1];
+            for (int b = 0; b <= n_partitions; ++b) edges[b] = h.be.e[b];
+            for (int b = 0; b < n_partitions; ++b) counts[b] = (int64_t)h.counts[b];
+            *fused = 1;
+            return ANNCHOR_OK;
+        }
+    }
+    // long lists (the sampled bracket is checked by the host) and mixed buckets the finishing workgroup could not hold: the
+    // quantiles by the general route; the caller computes its edges and asks for the counts
+    return ann_kth_smallest(c, c->dad.as<double>(), c->ncm.as<uint8_t>(), c->n, ks, 2, q);
 }
 
 // ---- rank-in-bin selection: a blocked scan of per-bin membership counts
@@ -849,7 +930,7 @@ extern "C" int annchor_sample_pairs(annchor_ctx *c, const double *bins, int32_t 
     if (c->pin && stage_bytes <= annchor_ctx::PIN_DL_BYTES) {   // one transfer, one wait
         unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
         ANN_CHECK_HIP(c, hipMemcpyAsync(slot, c->stage_out.p, stage_bytes, hipMemcpyDeviceToHost, c->stream));
-        ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        ANN_CHECK_HIP(c, ann_sync(c, __func__));
         memcpy(positions, slot, sizeof(int64_t) * (size_t)nreq);
         memcpy(feats, slot + sizeof(double) * (size_t)nreq, sizeof(double) * 4 * (size_t)nreq);
         memcpy(sample_y, slot + sizeof(double) * 5 * (size_t)nreq, sizeof(double) * (size_t)nreq);
@@ -977,7 +1058,7 @@ extern "C" int annchor_hash_sample_pairs(annchor_ctx *c, const double *bins, int
     if (c->pin && stage_bytes <= annchor_ctx::PIN_DL_BYTES) {   // one transfer, one wait
         unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
         ANN_CHECK_HIP(c, hipMemcpyAsync(slot, c->stage_out.p, stage_bytes, hipMemcpyDeviceToHost, c->stream));
-        ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        ANN_CHECK_HIP(c, ann_sync(c, __func__));
         memcpy(positions, slot, sizeof(int64_t) * (size_t)m);
         memcpy(feats, slot + sizeof(double) * (size_t)m, sizeof(double) * 4 * (size_t)m);
         memcpy(sample_y, slot + sizeof(double) * 5 * (size_t)m, sizeof(double) * (size_t)m);

@@ -234,6 +234,33 @@ __global__ void k_min_i32(const int32_t *__restrict__ v, int64_t n, int32_t *__r
     }
 }
 
+// Candidate pairs with an anchor endpoint: the pairs compute_features marks computed (annchor.py:286-289), counted here so
+// that the number of not-computed pairs after the feature stage rides with this stage's download instead of costing the
+// first sampling step a host wait.  Thread per (anchor slot, point); a pair of two anchors counts from its smaller point, a
+// repeated anchor from its last slot.
+__global__ __launch_bounds__(256) void k_count_anchor_pairs(const int32_t *__restrict__ A, int nA, const int32_t *__restrict__ anchorRank,
+                                                           int64_t nx, const uint64_t *__restrict__ K, int kw,
+                                                           unsigned long long *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = false;
+    if (t < (int64_t)nA * nx) {
+        const int r = (int)(t / nx);
+        const int64_t a = A[r], o = t % nx;
+        if (anchorRank[a] == r && a != o && !(anchorRank[o] >= 0 && o < a)) {
+            const int64_t i = a < o ? a : o, j = a < o ? o : a;
+            hit = (K[i * kw + (j >> 6)] >> (j & 63)) & 1ull;
+        }
+    }
+    const unsigned long long m = __ballot(hit);
+    __shared__ uint32_t s;
+    if (threadIdx.x == 0) s = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s, (uint32_t)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && s) atomicAdd(out, (unsigned long long)s);
+}
+
 extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t loc_thresh, int32_t loc_min,
                                       int64_t *n_pairs, int64_t *min_row_len)
 {
@@ -272,13 +299,20 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
         k_row_prefix<<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->Kbits.as<uint64_t>(), nx, kw, c->Kpref.as<uint32_t>(),
                                                             c->deg.as<int32_t>(), c->low.as<int32_t>(),
                                                             c->tmp1.as<int32_t>());
+        ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp2.p, 0, 16, c->stream));
         k_min_i32<<<1, 1024, 0, c->stream>>>(c->deg.as<int32_t>(), nx, c->tmp2.as<int32_t>());
+        if (c->nA > 0 && c->anchorRank.p)
+            k_count_anchor_pairs<<<ann_blocks((int64_t)c->nA * nx, 256), 256, 0, c->stream>>>(
+                c->A.as<int32_t>(), c->nA, c->anchorRank.as<int32_t>(), nx, c->Kbits.as<uint64_t>(), kw,
+                reinterpret_cast<unsigned long long *>(c->tmp2.as<int32_t>() + 2));
     }
     ANN_TRY(ann_exclusive_scan_i32_to_i64(c, c->tmp1.as<int32_t>(), c->rowstart.as<int64_t>(), nx));
     ANN_TRY(ann_exclusive_scan_i32_to_i64(c, c->deg.as<int32_t>(), c->Iptr.as<int64_t>(), nx));
     int64_t n = 0;
-    int32_t mn = 0;
-    ANN_TRY(ann_d2h2(c, &n, c->rowstart.as<int64_t>() + nx, sizeof n, &mn, c->tmp2.p, sizeof mn));
+    struct { int32_t mn, pad; long long anchor_pairs; } st = {0, 0, 0};
+    ANN_TRY(ann_d2h2(c, &n, c->rowstart.as<int64_t>() + nx, sizeof n, &st, c->tmp2.p, sizeof st));
+    const int32_t mn = st.mn;
+    c->n_unc_after_features = (c->nA > 0 && c->anchorRank.p) ? n - st.anchor_pairs : -1;
     ANN_REQUIRE(c, n < (1ll << 30), ANNCHOR_ELIMIT,
                 "%lld candidate pairs exceed the pair-list limit of 2^30 (int32 positions): raise loc_thresh / lower locality", (long long)n);
     if (n > (1ll << 27)) {   // ~130 B per pair over the stages that follow: refuse here, not in the middle of a fit
@@ -408,6 +442,7 @@ extern "C" int annchor_build_query_locality(annchor_ctx *c, int64_t nx_base, int
         k_qloc_emit<<<(int)nq, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx_base, loc_thresh, c->Iptr.as<int64_t>(),
                                                            c->ij.as<int2>(), c->Iidx.as<int32_t>());
     ANN_CHECK_HIP(c, hipGetLastError());
+    c->n_unc_after_features = -1;
     c->n = n;
     c->have_bitmap = false;   // query form: rows are contiguous already, no bitmap
     c->have_features = c->have_RA = false; c->sel_prepared = false;

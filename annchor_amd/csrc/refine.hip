@@ -538,7 +538,7 @@ extern "C" int annchor_neighbor_graph(annchor_ctx *c, int32_t nn, int64_t *ng_id
     c->call_timed = true;
     ANN_CHECK_HIP(c, hipGetLastError());
     if (direct) {
-        ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        ANN_CHECK_HIP(c, ann_sync(c, __func__));
         memcpy(ng_idx, slot, cells * 8);
         memcpy(ng_dist, slot + cells * 8, cells * 8);
         return ANNCHOR_OK;
@@ -546,7 +546,7 @@ extern "C" int annchor_neighbor_graph(annchor_ctx *c, int32_t nn, int64_t *ng_id
     if (c->pin && cells * 16 <= annchor_ctx::PIN_DL_BYTES) {
         // indices and distances sit back to back: one transfer into the pinned download region
         ANN_CHECK_HIP(c, hipMemcpyAsync(slot, d_i, cells * 16, hipMemcpyDeviceToHost, c->stream));
-        ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        ANN_CHECK_HIP(c, ann_sync(c, __func__));
         memcpy(ng_idx, slot, cells * 8);
         memcpy(ng_dist, slot + cells * 8, cells * 8);
         return ANNCHOR_OK;

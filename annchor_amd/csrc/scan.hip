@@ -929,6 +929,56 @@ __global__ __launch_bounds__(S2_T) void k_sel2_finish(Sel2Tables *__restrict__ t
     for (int t = tid; t < (int)(S2_ZERO_BYTES / 16); t += S2_T) z[t] = make_uint4(0, 0, 0, 0);
 }
 
+// The plain (two-read) selection enqueued without a host wait, for callers that chain device work on the answer
+// (annchor_sampler_stats): the keys of the answers and the "unfinished" flag stay in the tables; the caller downloads the flag
+// with its own results and calls ann_kth_async_done().  Lists long enough for the sampled bracket (whose check is the host's)
+// are not taken here: *d_prefix stays null and the caller uses ann_kth_smallest.
+int ann_kth_async(annchor_ctx *c, const double *vals, const uint8_t *flag, int64_t n, const int64_t *ks, int nk,
+                  const unsigned long long **d_prefix, const int **d_unfinished)
+{
+    *d_prefix = nullptr; *d_unfinished = nullptr;
+    ANN_REQUIRE(c, nk >= 1 && nk <= SEL_MAXQ, ANNCHOR_EINVAL, "kth_smallest: 1..%d ranks per call", SEL_MAXQ);
+    ANN_REQUIRE(c, n > 0, ANNCHOR_EINVAL, "kth_smallest: empty list");
+    const char *smin = getenv("ANNCHOR_SEL_SAMPLE_MIN");
+    if (n >= (smin ? atoll(smin) : S3_SAMPLE_MIN) && n >= S3_M) return ANNCHOR_OK;
+    const int64_t ntiles = std::max<int64_t>((n + S2_TILE - 1) / S2_TILE, 1);
+    ANN_TRY(ann_reserve(c, c->sel2, sizeof(Sel2Tables)));
+    ANN_TRY(ann_reserve(c, c->sel_bufA, sizeof(double) * (size_t)ntiles * S2_TILE));
+    ANN_TRY(ann_reserve(c, c->sel_bufB, sizeof(double) * (size_t)ntiles * S2_TILE));
+    ANN_TRY(ann_reserve(c, c->sel_seg, sizeof(uint32_t) * 2 * (size_t)ntiles));
+    Sel2Tables *tb = c->sel2.as<Sel2Tables>();
+    uint32_t *segA = c->sel_seg.as<uint32_t>(), *segB = segA + ntiles;
+    if (c->sel2_clean != (const void *)tb) {
+        ANN_CHECK_HIP(c, hipMemsetAsync(tb, 0, sizeof(Sel2Tables), c->stream));
+        c->sel2_clean = nullptr;
+    }
+    Sel2Init init;
+    memset(&init, 0, sizeof init);
+    init.nq = nk;
+    for (int q = 0; q < nk; ++q) init.k[q] = ks[q];
+    const int grid = (int)(ntiles <= 256 ? ntiles : std::min<int64_t>(S2_MAXWG, std::max<int64_t>(256, ntiles / 4)));
+    const char *l3 = getenv("ANNCHOR_SEL_LEVEL3_MIN");
+    const bool three = n >= (l3 ? atoll(l3) : S2_LEVEL3_MIN);
+    {
+        ProfScope ps(c, "radix_select_f64", (double)n * 9.0);
+        double *A = c->sel_bufA.as<double>(), *B = c->sel_bufB.as<double>();
+        k_sel2_hist0<<<grid, S2_T, 0, c->stream>>>(vals, flag, n, tb, nullptr);
+        k_sel2_filter<1><<<grid, S2_T, 0, c->stream>>>(vals, flag, n, nullptr, init, tb, A, segA, 0);
+        k_sel2_filter<2><<<grid, S2_T, 0, c->stream>>>(A, nullptr, n, segA, init, tb, B, segB, 0);
+        if (!three) k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, B, segB, ntiles, 2);
+        else {
+            k_sel2_filter<3><<<grid, S2_T, 0, c->stream>>>(B, nullptr, n, segB, init, tb, A, segA, 0);
+            k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, A, segA, ntiles, 3);
+        }
+    }
+    ANN_CHECK_HIP(c, hipGetLastError());
+    c->sel2_clean = nullptr;
+    *d_prefix = reinterpret_cast<const unsigned long long *>(&tb->out.prefix[0]);
+    *d_unfinished = &tb->out.unfinished;
+    return ANNCHOR_OK;
+}
+void ann_kth_async_done(annchor_ctx *c) { c->sel2_clean = (const void *)c->sel2.p; }   // (the finishing workgroup left the tables zeroed)
+
 int ann_kth_smallest(annchor_ctx *c, const double *vals, const uint8_t *flag, int64_t n, const int64_t *ks, int nk,
                      double *h_out)
 {

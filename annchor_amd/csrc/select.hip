@@ -723,7 +723,19 @@ struct CutState {
     long long tie_len1, tie_len5; // members of the bin
     int64_t tie_got1, tie_got5;   // list cursors
     int tie_overflow;             // a bin's list did not fit TIE_CAP: the host resolves it with the general selection
+    int sel_unfinished;           // the cut values came straight from the selection's tables and it could not finish (k_cut_set_t)
 };
+
+// The cut values without a host round trip: the selection's answers (keys) into the state the cut kernels read.
+__global__ void k_cut_set_t(CutState *__restrict__ cs, const unsigned long long *__restrict__ prefix, const int *__restrict__ unfinished,
+                            int need1, int need5, int force_redo)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int q = 0;
+    if (need1) cs->t1 = ann_key_asc_inv(prefix[q++]);
+    if (need5) cs->t5 = ann_key_asc_inv(prefix[q++]);
+    cs->sel_unfinished = *unfinished | force_redo;   // (ANNCHOR_CUT_FORCE_REDO: tests walk the second attempt)
+}
 
 #define TIE_CAP 65536
 
@@ -1340,17 +1352,28 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     cs.all1 = n_refine >= n_unc;
     cs.all5 = cs.all1 || cs.K5 >= n_unc;
     cs.t1 = cs.t5 = INFINITY;
-    if (n_refine > 0 && !(cs.all1 && cs.all5)) {
-        int64_t ks[2];
-        int nk = 0;
-        if (!cs.all1) ks[nk++] = n_unc - cs.K1;
-        if (!cs.all5) ks[nk++] = n_unc - cs.K5;
+    // The cut values stay on the device when the selection can be enqueued without a host wait (lists short of the sampled
+    // bracket): the cut kernels read them from the state, the "could not finish" flag comes back with the final state and the
+    // cut is redone the waiting way if it is set (degenerate keys; never at the reference's configurations).
+    const unsigned long long *d_cut_prefix = nullptr;
+    const int *d_cut_unfinished = nullptr;
+    int64_t cut_ks[2];
+    int cut_nk = 0;
+    auto cut_values_waiting = [&]() -> int {
         double tv[2];
         // flag = ncm: prob >= 0 exactly on not-computed pairs
-        ANN_TRY(ann_kth_smallest(c, c->prob.as<double>(), c->ncm.as<uint8_t>(), n, ks, nk, tv));
-        nk = 0;
-        if (!cs.all1) cs.t1 = tv[nk++];
-        if (!cs.all5) cs.t5 = tv[nk++];
+        ANN_TRY(ann_kth_smallest(c, c->prob.as<double>(), c->ncm.as<uint8_t>(), n, cut_ks, cut_nk, tv));
+        int q = 0;
+        if (!cs.all1) cs.t1 = tv[q++];
+        if (!cs.all5) cs.t5 = tv[q++];
+        return ANNCHOR_OK;
+    };
+    if (n_refine > 0 && !(cs.all1 && cs.all5)) {
+        if (!cs.all1) cut_ks[cut_nk++] = n_unc - cs.K1;
+        if (!cs.all5) cut_ks[cut_nk++] = n_unc - cs.K5;
+        if (!getenv("ANNCHOR_CUT_WAIT"))
+            ANN_TRY(ann_kth_async(c, c->prob.as<double>(), c->ncm.as<uint8_t>(), n, cut_ks, cut_nk, &d_cut_prefix, &d_cut_unfinished));
+        if (!d_cut_prefix) ANN_TRY(cut_values_waiting());
     }
     if (cs.all1) cs.t1 = -1.0;
     if (cs.all5) cs.t5 = -1.0;
@@ -1363,7 +1386,11 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     ANN_TRY(ann_reserve(c, c->cand, sizeof(int32_t) * (size_t)(maxc + 1)));
     ANN_TRY(ann_reserve(c, c->next, sizeof(int32_t) * (size_t)(maxn + 1)));
     cs.rk1 = cs.rk5 = ~0ull;
+    const CutState cs_in = cs;   // (for a second attempt)
     ANN_TRY(ann_h2d(c, c->sel_state.p, &cs, sizeof cs));
+    if (d_cut_prefix)
+        k_cut_set_t<<<1, 64, 0, c->stream>>>(c->sel_state.as<CutState>(), d_cut_prefix, d_cut_unfinished, !cs.all1, !cs.all5,
+                                       getenv("ANNCHOR_CUT_FORCE_REDO") ? 1 : 0);
     const bool ties = n_refine > 0 && !(cs.all1 && cs.all5);
     ANN_TRY(ann_reserve(c, c->tie_lists, sizeof(unsigned long long) * 2 * TIE_CAP));
     unsigned long long *tl1 = c->tie_lists.as<unsigned long long>(), *tl5 = tl1 + TIE_CAP;
@@ -1375,7 +1402,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         k_cut_emit<<<nb, CP_THREADS, 0, c->stream>>>(c->prob.as<double>(), c->RA.as<double>(), n, c->sel_state.as<CutState>(),
                                                     c->blk_off.as<int64_t>(), c->cand.as<int32_t>(), c->next.as<int32_t>());
     };
-    if (ties) {
+    auto tie_groups = [&]() -> int {
         // the groups on the two cuts and their RefineApprox cuts (device only: no host wait)
         ProfScope ps(c, "topk_tie_groups", (double)n * 8.0);
         const int tb = (int)std::min<int64_t>(ann_blocks(n, 256 * 4), 256);
@@ -1390,7 +1417,9 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         k_tie_pick<<<1, 1024, 0, c->stream>>>(c->sel_state.as<CutState>(), c->tie_hist.as<uint32_t>());
         k_tie_collect<<<tb, 256, 0, c->stream>>>(c->prob.as<double>(), n, c->sel_state.as<CutState>(), tl1, tl5, cap);
         k_tie_select<<<1, 1024, 0, c->stream>>>(c->sel_state.as<CutState>(), tl1, tl5, cap);
-    }
+        return ANNCHOR_OK;
+    };
+    if (ties) ANN_TRY(tie_groups());
     split();
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;
@@ -1401,6 +1430,18 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         ANN_REQUIRE(c, e == 0, ANNCHOR_ESTATE, "guarantee_nmin: a row has fewer not-computed candidates than it must refine");
     } else {
         ANN_TRY(ann_d2h(c, &cs, c->sel_state.p, sizeof cs));
+    }
+    if (d_cut_prefix) {
+        ann_kth_async_done(c);
+        if (cs.sel_unfinished) {   // the selection needs its byte passes: cut values the waiting way, then everything above again
+            cs = cs_in;
+            ANN_TRY(cut_values_waiting());
+            ANN_TRY(ann_h2d(c, c->sel_state.p, &cs, sizeof cs));
+            if (ties) ANN_TRY(tie_groups());
+            split();
+            ANN_CHECK_HIP(c, hipGetLastError());
+            ANN_TRY(ann_d2h(c, &cs, c->sel_state.p, sizeof cs));
+        }
     }
     if (cs.tie_overflow) {
         // a group on a cut larger than TIE_CAP (e.g. a third of the pool at probability 0): its RefineApprox

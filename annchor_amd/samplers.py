@@ -103,6 +103,21 @@ class SimpleStratifiedSampler(Sampler):
             print("Warning: n_samples too large for data set size.\n" + "Reducing n_samples to %d." % n_samples)
         return iq1, iq3, n_samples
 
+    def _device_partition(self, engine, iq1, iq3, n_samples):
+        """get_partition's bins and their populations from the device-resident state: one host wait when the library can chain
+        quantiles -> edges -> counts on the device (its edges must be NumPy's, bit for bit), three otherwise."""
+        stats = getattr(engine, "sampler_stats", None)
+        if stats is not None and self.n_partitions >= 2:
+            q1, q3, edges, counts = stats(iq1, iq3, self.n_partitions)
+        else:
+            (q1, q3), edges, counts = engine.kth_uncomputed_dad([iq1, iq3]), None, None
+        sample_bins = np.hstack([-np.inf, np.linspace(q1, q3, self.n_partitions - 1), np.inf])
+        if n_samples == 0:
+            raise NothingToSample()
+        if edges is None or not np.array_equal(edges, sample_bins):
+            counts = engine.bin_counts(sample_bins)
+        return sample_bins, counts
+
     def get_partition(self, sample_feature, n_samples):
         iq1, iq3, n_samples = self._quantile_ranks(sample_feature.shape[0], n_samples, self.n_partitions)
         q1 = np.partition(sample_feature, iq1)[iq1]
@@ -135,11 +150,7 @@ class SimpleStratifiedSampler(Sampler):
             if new_n != n_samples:
                 print("Warning: n_samples has changed from %d to %d." % (n_samples, new_n))
             n_samples = new_n
-            q1, q3 = engine.kth_uncomputed_dad([iq1, iq3])
-            sample_bins = np.hstack([-np.inf, np.linspace(q1, q3, self.n_partitions - 1), np.inf])
-            if n_samples == 0:
-                raise NothingToSample()
-            counts = engine.bin_counts(sample_bins)
+            sample_bins, counts = self._device_partition(engine, iq1, iq3, n_samples)
             bin_size, remainder = n_samples // self.n_partitions, n_samples % self.n_partitions
             want = np.array([bin_size + (nbin < remainder) for nbin in range(self.n_partitions)], dtype=np.int64)
             seed = random_seed + self.loop_num
@@ -255,11 +266,7 @@ class DeviceStratifiedSampler(SimpleStratifiedSampler):
             if new_n != n_samples:
                 print("Warning: n_samples has changed from %d to %d." % (n_samples, new_n))
             n_samples = new_n
-            q1, q3 = engine.kth_uncomputed_dad([iq1, iq3])
-            sample_bins = np.hstack([-np.inf, np.linspace(q1, q3, self.n_partitions - 1), np.inf])
-            if n_samples == 0:
-                raise NothingToSample()
-            counts = engine.bin_counts(sample_bins)
+            sample_bins, counts = self._device_partition(engine, iq1, iq3, n_samples)
             want = n_samples // self.n_partitions + (np.arange(self.n_partitions) < n_samples % self.n_partitions)
             ticket.update(n_samples=n_samples, sample_bins=sample_bins, counts=counts, want=want.astype(np.int64),
                           key=self.seed_key(random_seed))

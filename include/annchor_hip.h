@@ -148,6 +148,12 @@ int annchor_count_uncomputed(annchor_ctx *ctx, int64_t *n_unc);
 int annchor_kth_uncomputed_dad(annchor_ctx *ctx, const int64_t *ks, int32_t nk, double *out);
 /* counts[b] = #{uncomputed pairs with bins[b] <= dad < bins[b+1]} (utils.py:547-549). */
 int annchor_bin_counts(annchor_ctx *ctx, const double *bins, int32_t nbins, int64_t *counts);
+/* Sampler.get_partition + the partition populations in ONE host round trip (samplers.py:75-105): q[0..1] = the ks[0]-th / ks[1]-th
+ * smallest dad among the uncomputed pairs; *fused = 1: edges[0..n_partitions] = {-inf, np.linspace(q[0], q[1], n_partitions - 1),
+ * +inf} computed on the device (the caller compares them with its own np.linspace) and counts[b] as annchor_bin_counts would
+ * give for them; *fused = 0 (very long lists, degenerate keys): only q is set, the caller continues with annchor_bin_counts. */
+int annchor_sampler_stats(annchor_ctx *ctx, const int64_t *ks, int32_t n_partitions, double *q, double *edges, int64_t *counts,
+                          int32_t *fused);
 /* For each request t: the pair position of the ranks[t]-th (0-based, position
  * order) uncomputed pair inside bin bin_of[t]. */
 int annchor_select_by_rank(annchor_ctx *ctx, const double *bins, int32_t nbins, const int32_t *bin_of,

@@ -97,3 +97,19 @@ def test_rank_deficient_partition_falls_back_to_the_host_solver():
     a = Annchor(X, "euclidean", **cfg).fit()
     b = Annchor(X, "euclidean", ols="lapack", **cfg).fit()
     np.testing.assert_allclose(a.neighbor_graph[1], b.neighbor_graph[1], rtol=0, atol=0)
+
+
+def test_host_waits_per_c2_fit():
+    """The host waits for the stream 8 times in a C2 fit (was 13 before the sampling statistics were chained on the device,
+    the cut values stayed there and the not-computed count rode with the locality download): locality sizes, sampling statistics
+    x 2, guarantee_nmin flags, selection state x 2, the graph, the fitted model."""
+    import os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "wait_census.py")], cwd=root, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stderr.splitlines()
+    fit = lines[lines.index("=== fit") + 1:lines.index("=== end")]
+    waits = [ln for ln in fit if ln.startswith("sync ")]
+    assert len(waits) <= 8, fit
