@@ -158,3 +158,24 @@ def test_select_by_rank_vs_numpy(engine_with_pairs, nbins):
     pos = eng.select_by_rank(edges, np.asarray(bin_of, dtype=np.int32), np.asarray(ranks, dtype=np.int64))
     want = np.array([member[b][r] for b, r in zip(bin_of, ranks)])
     assert np.array_equal(pos, want)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "halfint", "constant"])
+def test_sampler_stats_equals_the_three_separate_calls(engine_with_pairs, kind):
+    """annchor_sampler_stats (quantiles -> np.linspace edges -> partition populations chained on the device, one host wait)
+    against kth_uncomputed_dad + np.linspace + bin_counts, for 2..64 partitions; the device's edges must be NumPy's bit for bit."""
+    eng, n, nat = engine_with_pairs
+    rng = np.random.RandomState(4)
+    dad = rng.rand(n) * 37.0 if kind == "uniform" else rng.randint(0, 1200, n) / 2.0 if kind == "halfint" else np.full(n, 2.5)
+    ncm = rng.rand(n) < 0.8
+    _inject(eng, nat, dad, ncm)
+    m = int(ncm.sum())
+    for P in (2, 3, 5, 7, 12, 33, 64):
+        for iq1, iq3 in ((m // 100, 99 * m // 100), (m // 10, 9 * m // 10), (0, m - 1)):
+            q1, q3, edges, counts = eng.sampler_stats(iq1, iq3, P)
+            want_q = eng.kth_uncomputed_dad(np.array([iq1, iq3], dtype=np.int64))
+            assert q1 == want_q[0] and q3 == want_q[1]
+            bins = np.hstack([-np.inf, np.linspace(q1, q3, P - 1), np.inf])
+            assert edges is not None and np.array_equal(edges, bins), (P, edges, bins)
+            assert np.array_equal(counts, eng.bin_counts(bins)), (P, kind)
+            assert counts.sum() == m
