@@ -16,6 +16,8 @@ library and a GPU, constructing an `Annchor` raises.
 import time
 from collections import Counter
 
+import os
+
 import numpy as np
 
 from . import _native
@@ -29,6 +31,11 @@ from .utils import get_exact_ijs_, get_function_from_input, test_parallelisation
 from .distances import euclidean as distances_euclidean  # noqa: E402
 from .distances import cosine as distances_cosine  # noqa: E402
 
+# Where the NEXT sampling step's draw runs once its statistics are known (inside fit()): "defer" = in get_sample, on the calling
+# thread, after the refinement and update_bounds launches are enqueued (they execute meanwhile); "worker" = at once, on the
+# library's persistent worker thread.  Measured in one process (tools/draw_ab.py, C2): 3.94-4.16 ms per fit against 4.38-4.68 -- the
+# second thread's wake-up and its traffic cost the calling thread more than the extra overlap buys.
+_DRAW_OVERLAP = {"worker": True, "defer": "defer"}[os.environ.get("ANNCHOR_DRAW", "defer")]
 PAIRLIST_MAX_POINTS = 30000   # float32 Euclidean / cosine data above this size takes the streamed (tile-granular) form
 PAIRLIST_HARD_MAX = None      # override (tests); None: from the device -- 2^30 candidate pairs (int32 positions) and 80 % of its free
                               # memory at ~130 B per pair: 46 341 points on a 288 GB MI355X (_native.pairlist_point_limit)
@@ -565,7 +572,7 @@ class Annchor:
             # inside fit(): the next sampling step's statistics depend on the mask and dad only,
             # so take them now and let the host draw overlap the refinement kernel
             self._engine.mark_candidates()
-            self._sample_ticket = self.sampler.begin_device(self._engine, self.n_samples, self.random_seed)
+            self._sample_ticket = self.sampler.begin_device(self._engine, self.n_samples, self.random_seed, overlap=_DRAW_OVERLAP)
         if self._device_metric:
             self._engine.refine_candidates()
         elif ncand:

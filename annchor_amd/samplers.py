@@ -160,6 +160,10 @@ class SimpleStratifiedSampler(Sampler):
                 np.random.seed(seed)
                 ticket["per_bin"] = [np.arange(c) if c < w else np.random.permutation(int(c))[:w]
                                      for c, w in zip(counts, want)]
+            elif overlap == "defer" and not _WORKER_ALWAYS:
+                # the caller still has device work to enqueue (refinement, update_bounds): the draw runs in finish_device, on the
+                # calling thread's warm core, while that work executes
+                ticket["deferred"] = (seed, counts, want)
             elif overlap or _WORKER_ALWAYS:
                 ticket["draw"] = _native.legacy_choice_begin(seed, counts, want)
             else:
@@ -180,6 +184,14 @@ class SimpleStratifiedSampler(Sampler):
             except BaseException as err:  # noqa: BLE001
                 if ticket["error"] is None:
                     ticket["error"] = err
+        if ticket["error"] is None and ticket.get("deferred") is not None:
+            from . import _native
+
+            seed, counts, want = ticket.pop("deferred")
+            try:
+                ticket["per_bin"] = _native.legacy_choice_ranks(seed, counts, want)
+            except BaseException as err:  # noqa: BLE001
+                ticket["error"] = err
         if ticket["error"] is not None:
             raise ticket["error"]
         engine, n_samples, sample_bins = ticket["engine"], ticket["n_samples"], ticket["sample_bins"]
