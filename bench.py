@@ -111,7 +111,7 @@ def pairlist_at_scale(local, n=16000):
 # kernel family (ProfScope name) -> kernels of the rocprofv3 PMC passes that belong to it
 FAMILY_KERNELS = {
     "update_bounds_intersect": ("k_update_bounds_rows", "k_update_bounds"),
-    "radix_select_f64": ("k_sel2_",),
+    "radix_select_f64": ("k_sel2_", "k_sel3_"),
     "sampler_select_by_rank": ("k_rb_",),
     "transpose_column_half": ("k_transpose_cols<true>",),
     "transpose_column_half_mask": ("k_transpose_cols<false>",),
