@@ -96,6 +96,7 @@ struct annchor_ctx {
     // ---- device-resident model of an iteration (model.hip): per-partition OLS coefficients, residual lists
     DevBuf model;          // DeviceModel
     DevBuf ols_scratch;    // double [nb][4][m]: a partition's centred design matrix and targets
+    int prof_group_entry = -1;   // >= 0: a ProfGroup of that family is open (its inner scopes record no events)
     bool model_fitted = false;   // `model` holds this iteration's regression
     bool errs_on_device = false; // `errs` / `errptr` hold this iteration's sorted residuals (annchor_fit_errors_device)
     int model_nb = 0;
@@ -191,6 +192,16 @@ int ann_d2h2(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, void *
 
 // profiling scopes: one entry per kernel family
 int ann_prof_entry(annchor_ctx *c, const char *name);
+// One event pair around a run of launches of the same family (the 15 dependent anchor rounds): the scopes of that family
+// opened inside only count their launch and bytes.  38 events per C2 fit -> 10, and no event packets between the rounds.
+struct ProfGroup {
+    annchor_ctx *c;
+    int entry = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfGroup(annchor_ctx *ctx, const char *name);
+    ~ProfGroup();
+};
+
 struct ProfScope {
     annchor_ctx *c;
     int entry = -1;

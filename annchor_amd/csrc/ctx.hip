@@ -160,12 +160,38 @@ ProfScope::ProfScope(annchor_ctx *ctx, const char *name, double alg_bytes) : c(c
     entry = ann_prof_entry(c, name);
     c->prof[entry].launches += 1;
     c->prof[entry].alg_bytes += alg_bytes;
+    if (entry == c->prof_group_entry) { entry = -1; return; }   // timed by the enclosing ProfGroup
     auto get = [&](hipEvent_t *e) {
         if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); return true; }
         return hipEventCreate(e) == hipSuccess;
     };
     if (!get(&a) || !get(&b)) { entry = -1; return; }
     (void)hipEventRecord(a, c->stream);
+}
+
+ProfGroup::ProfGroup(annchor_ctx *ctx, const char *name) : c(ctx)
+{
+    if (!c->prof_on || c->prof_group_entry >= 0) return;
+    if (c->prof_mode == 2) {   // metric kernels only
+        const size_t n = strlen(name);
+        if (n < 6 || strcmp(name + n - 6, "_pairs") != 0) return;
+    }
+    entry = ann_prof_entry(c, name);
+    auto get = [&](hipEvent_t *e) {
+        if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); return true; }
+        return hipEventCreate(e) == hipSuccess;
+    };
+    if (!get(&a) || !get(&b)) { entry = -1; return; }
+    (void)hipEventRecord(a, c->stream);
+    c->prof_group_entry = entry;
+}
+
+ProfGroup::~ProfGroup()
+{
+    if (entry < 0) return;
+    (void)hipEventRecord(b, c->stream);
+    c->pending.push_back({entry, a, b});
+    c->prof_group_entry = -1;
 }
 
 ProfScope::~ProfScope()

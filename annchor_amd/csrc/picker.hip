@@ -9,6 +9,7 @@
 // without any host round trip: round r's one-to-all metric sweep reads its anchor
 // index from device memory, where round r-1's arg-max reduction left it.
 #include "common.h"
+#include <memory>
 
 #define RED_THREADS 256
 
@@ -139,7 +140,11 @@ extern "C" int annchor_pick_anchors_maxmin(annchor_ctx *c, int32_t na, int64_t f
     ANN_TRY(ann_h2d(c, c->A.p, &f, sizeof f));
     ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
     bool fused_prev = false;   // the launch of round r picked its own anchor from row r - 1
+    // (the rounds of a fusing metric are nothing but its launches, back to back: one event pair around the run)
+    const char *family = c->metric == ANNCHOR_METRIC_LEVENSHTEIN ? "levenshtein_pairs" : nullptr;
+    std::unique_ptr<ProfGroup> group;
     for (int r = 0; r < na; ++r) {
+        if (r == 1 && fused_prev && family) group.reset(new ProfGroup(c, family));
         PairSource src;
         src.anchor = c->A.as<int32_t>() + r;
         src.n = nx;
@@ -169,6 +174,7 @@ extern "C" int annchor_pick_anchors_maxmin(annchor_ctx *c, int32_t na, int64_t f
             }
         }
     }
+    group.reset();
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;
     ANN_CHECK_HIP(c, hipGetLastError());

@@ -349,7 +349,7 @@ def strings_run(args, steps, warmup, world, rank, local, dist, torch, all_cpus, 
     timed = anns[args.warmup:]
     if not args.no_kernel_events:
         # inside the timed region only the metric kernels (the roofline kernel) carry HIP events
-        # (38 events per fit); the table of all kernel families comes from untimed fits below
+        # (10 events per fit: one pair around the anchor rounds, one per pair-list launch); the table of all kernel families comes from untimed fits below
         for a in timed:
             a._engine.prof_enable(2)
 
