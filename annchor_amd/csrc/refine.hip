@@ -137,7 +137,11 @@ __global__ __launch_bounds__(256) void k_update_bounds(const int32_t *__restrict
 // lookup per entry, values fetched for the matches only -- instead of ~10 dependent binary-search probes for
 // every entry of the shorter list.  The table is rebuilt (old entries cleared, new ones written) when i
 // changes inside the run; any order of the list is handled, the sorted one just rebuilds least.
+// BITMAP = true (point sets too large for the table: nx >= 65 536): "is c in L_i, and where" from a bit per point plus a
+// running count per 64-bit word -- the lists are sorted by the other endpoint, so the slot of c is its rank among the set
+// bits: count[c / 64] + popcount(bits[c / 64] below c).  0.19 B per point instead of 2 (19 KB at 100 000 points).
 #define UBR_CHUNK 256
+template <bool BITMAP>
 __global__ __launch_bounds__(256) void k_update_bounds_rows(const int32_t *__restrict__ next, int64_t nnext,
                                                            const int2 *__restrict__ ij, const int64_t *__restrict__ cptr,
                                                            const int32_t *__restrict__ cidx, const double *__restrict__ cval,
@@ -145,9 +149,15 @@ __global__ __launch_bounds__(256) void k_update_bounds_rows(const int32_t *__res
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     uint16_t *tab = reinterpret_cast<uint16_t *>(dyn);   // [nx] slot + 1 of point c in the current row's list, 0 = absent
+    const int W = (nx + 63) / 64;
+    unsigned long long *bits = reinterpret_cast<unsigned long long *>(dyn);   // BITMAP: [W] members of the current row's list
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(bits + W);                  //         [W] members in the words before (32 bits: a
+                                                                              //         point may have 65 536 computed neighbours and more)
     __shared__ int first_other;
+    __shared__ uint32_t scan_w[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = threadIdx.x; c < (nx + 1) / 2; c += 256) reinterpret_cast<uint32_t *>(tab)[c] = 0u;
+    if (BITMAP) { for (int c = threadIdx.x; c < W; c += 256) bits[c] = 0ull; }
+    else for (int c = threadIdx.x; c < (nx + 1) / 2; c += 256) reinterpret_cast<uint32_t *>(tab)[c] = 0u;
     const int64_t t0 = (int64_t)blockIdx.x * UBR_CHUNK, t1 = min(t0 + UBR_CHUNK, nnext);
     int cur = -1;
     int64_t ca0 = 0, ca1 = 0;
@@ -164,10 +174,33 @@ __global__ __launch_bounds__(256) void k_update_bounds_rows(const int32_t *__res
         __syncthreads();
         const int seg = first_other;
         if (cur != i) {
-            for (int64_t e = ca0 + threadIdx.x; e < ca1; e += 256) tab[cidx[e]] = 0;
-            ca0 = cptr[i]; ca1 = cptr[i + 1];
-            __syncthreads();
-            for (int64_t e = ca0 + threadIdx.x; e < ca1; e += 256) tab[cidx[e]] = (uint16_t)(e - ca0 + 1);
+            if (BITMAP) {
+                for (int64_t e = ca0 + threadIdx.x; e < ca1; e += 256) bits[cidx[e] >> 6] = 0ull;
+                ca0 = cptr[i]; ca1 = cptr[i + 1];
+                __syncthreads();
+                for (int64_t e = ca0 + threadIdx.x; e < ca1; e += 256) {
+                    const int cc = cidx[e];
+                    atomicOr(&bits[cc >> 6], 1ull << (cc & 63));
+                }
+                __syncthreads();
+                // exclusive counts per word: blocked over the threads (W / 256 consecutive words each) + a block scan
+                const int per = (W + 255) / 256, w0 = threadIdx.x * per, w1 = min(w0 + per, W);
+                uint32_t mine = 0;
+                for (int w = w0; w < w1; ++w) mine += (uint32_t)__popcll(bits[w]);
+                uint32_t inc = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+                if (lane == 63) scan_w[wave] = inc;
+                __syncthreads();
+                uint32_t base = inc - mine;
+                for (int w = 0; w < wave; ++w) base += scan_w[w];
+                for (int w = w0; w < w1; ++w) { wcnt[w] = base; base += (uint32_t)__popcll(bits[w]); }
+            } else {
+                for (int64_t e = ca0 + threadIdx.x; e < ca1; e += 256) tab[cidx[e]] = 0;
+                ca0 = cptr[i]; ca1 = cptr[i + 1];
+                __syncthreads();
+                for (int64_t e = ca0 + threadIdx.x; e < ca1; e += 256) tab[cidx[e]] = (uint16_t)(e - ca0 + 1);
+            }
             cur = i;
             __syncthreads();
         }
@@ -185,7 +218,15 @@ __global__ __launch_bounds__(256) void k_update_bounds_rows(const int32_t *__res
                 for (int u = 0; u < U; ++u) key[u] = cidx[min(e0 + 64 * u, b1 - 1)];
                 uint32_t sl[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) sl[u] = e0 + 64 * u < b1 ? (uint32_t)tab[key[u]] : 0u;
+                for (int u = 0; u < U; ++u) {
+                    if (BITMAP) {
+                        const unsigned long long b = bits[key[u] >> 6];
+                        const int sh = key[u] & 63;
+                        const uint32_t r = wcnt[key[u] >> 6] + (uint32_t)__popcll(b & ((1ull << sh) - 1ull)) + 1u;
+                        sl[u] = (e0 + 64 * u < b1 && ((b >> sh) & 1ull)) ? r : 0u;
+                    } else
+                        sl[u] = e0 + 64 * u < b1 ? (uint32_t)tab[key[u]] : 0u;
+                }
                 // both values of every entry are requested whether it matches or not (clamped addresses, all in
                 // flight together): a branch per entry around two dependent reads serialised eight round trips
                 double x[U], y[U];
@@ -251,7 +292,11 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
         const char *ube = getenv("ANNCHOR_UPDATE_BOUNDS");   // "pairs" / "rows" force a form (tests compare the two)
         // long lists only: with ~100 entries per list (C2) the table rebuilds and the 512-entry strides cost more
         // than they save (0.28 vs 0.14 ms); at 800 entries per list 12.8 vs 18.1 ms
-        const bool rows_form = (ube ? strcmp(ube, "rows") == 0 : avg >= 256.0) && nx < 65536 && (((size_t)nx + 1) / 2) * 4 <= 150 * 1024;
+        const size_t bm_bytes = (((size_t)nx + 63) / 64) * 12 + 16;   // bit per point + uint32 count per word
+        const bool force_bm = ube && strcmp(ube, "bitmap") == 0;
+        const bool table_ok = nx < 65536 && (((size_t)nx + 1) / 2) * 4 <= 150 * 1024;
+        const bool rows_bitmap = (force_bm || (!ube && avg >= 256.0 && !table_ok)) && bm_bytes <= 150 * 1024;
+        const bool rows_form = rows_bitmap || ((ube ? strcmp(ube, "rows") == 0 : avg >= 256.0) && table_ok);
         // Algorithmic bytes (12 B per list entry: key + value).  Wave-per-pair form: both computed lists of every
         // lookahead pair.  Row-grouped form: the lookahead list is in pair order, so a first point's list is read once
         // per RUN of pairs (<= one per point and per workgroup chunk) and only the partners' lists once per pair --
@@ -261,11 +306,18 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
                                      : (double)c->nnext * (2.0 * avg * 12.0 + 36.0);
         ProfScope ps(c, "update_bounds_intersect", alg);
         const size_t tab_bytes = (((size_t)nx + 1) / 2) * 4;
-        if (rows_form) {
+        if (rows_bitmap) {
+            if (bm_bytes > 64 * 1024)
+                ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)bm_bytes));
+            k_update_bounds_rows<true><<<ann_blocks(c->nnext, UBR_CHUNK), 256, bm_bytes, c->stream>>>(
+                c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(),
+                c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>(), (int)nx);
+        } else if (rows_form) {
             if (tab_bytes > 64 * 1024)
-                ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_rows, hipFuncAttributeMaxDynamicSharedMemorySize,
+                ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                      (int)tab_bytes));
-            k_update_bounds_rows<<<ann_blocks(c->nnext, UBR_CHUNK), 256, tab_bytes, c->stream>>>(
+            k_update_bounds_rows<false><<<ann_blocks(c->nnext, UBR_CHUNK), 256, tab_bytes, c->stream>>>(
                 c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(),
                 c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>(), (int)nx);
         } else

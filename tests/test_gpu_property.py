@@ -112,6 +112,13 @@ def test_guarantee_nmin_rounds_equal_the_sequential_sweep(monkeypatch):
                          ann.not_computed_mask.copy())
         for a, b in zip(out["rounds"], out["sequential"]):
             assert np.array_equal(a, b)
+        # the row-grouped form's bitmap-rank variant (point sets of 65 536 and more take it; forced here)
+        monkeypatch.setenv("ANNCHOR_GN_SWEEP", "rounds")
+        monkeypatch.setenv("ANNCHOR_UPDATE_BOUNDS", "bitmap")
+        ann = Annchor(data, metric, random_seed=3, **kw).fit()
+        bm = (ann.neighbor_graph[0], ann.neighbor_graph[1], ann.evals, ann.RefineApprox, ann.not_computed_mask)
+        for a, b in zip(out["rounds"], bm):
+            assert np.array_equal(a, b)
 
 
 def test_select_prepare_is_equivalent_and_voided_by_state_changes():
