@@ -657,8 +657,8 @@ class Annchor:
             try:
                 return self._fit_stages(stage, make_stream, t, origin)
             except _DeviceModelRefused:
-                # a partition the device's QR does not take (rank deficient, fewer rows than columns): the whole fit again
-                # with scipy's dgelsd (its minimum-norm solution is the reference's behaviour there)
+                # a partition the device's solver does not take (fewer rows than columns; a rank-deficient one gets its
+                # minimum-norm solution on the device): the whole fit again with scipy's dgelsd
                 self.evals, self.n_samples = evals0, n_samples0   # (a sampling step may have lowered n_samples)
                 if loop0 is not None:
                     self.sampler.loop_num = loop0

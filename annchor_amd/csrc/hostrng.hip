@@ -248,6 +248,7 @@ void cache_put(uint32_t seed, const std::shared_ptr<Stream> &st)   // g_mu held
 struct BinScratch {
     std::vector<uint32_t> J;
     std::vector<uint8_t> flag;       // flag[x] = 1: position x is tracked (the trace's test: one load and an OR per partner)
+    std::vector<uint64_t> hbits;     // bins too long for `flag` to stay in cache: a hashed bit set of the positions ever tracked
     std::vector<int32_t> slot_of;
 };
 std::vector<std::unique_ptr<BinScratch>> g_scratch;
@@ -310,6 +311,35 @@ void trace_prefix(BinScratch *sc, int64_t c, int64_t k, int64_t *out)
         // is the critical path of a draw; a summary level in front of the bit map made it slower;
         // an AVX-512 gather measured 3x slower on Zen 5); the rare group with a hit is replayed exactly.
         const uint8_t *fl = T.fl;
+        // Long bins (the flag bytes of 18 M pairs are 18 MB: every test a cache miss, ~5 ns per step): the partners are
+        // tested against a hashed set of 2^20 bits (128 KB: L2) holding every position that was EVER tracked (k at the start,
+        // one more per real hit: ~k ln(c / k)); only a partner whose hashed bit is set looks at the exact flags.
+        static const int64_t hashed_min = getenv("ANNCHOR_RNG_HASHED_MIN") ? atoll(getenv("ANNCHOR_RNG_HASHED_MIN")) : (4ll << 20);
+        if (c >= hashed_min) {
+            constexpr int HB = 20;
+            if (sc->hbits.size() < ((size_t)1 << (HB - 6))) sc->hbits.resize((size_t)1 << (HB - 6), 0);
+            uint64_t *hb = sc->hbits.data();
+            auto hslot = [](uint32_t x) -> uint32_t { return (uint32_t)(((uint64_t)x * 0x9E3779B97F4A7C15ull) >> (64 - HB)); };
+            std::vector<uint32_t> touched;
+            touched.reserve((size_t)k * 16);
+            for (int64_t t2 = 0; t2 < k; ++t2) { const uint32_t h = hslot(pos[(size_t)t2]); hb[h >> 6] |= 1ull << (h & 63); touched.push_back(h >> 6); }
+            for (; i + 16 <= c; i += 16) {
+                const uint32_t *q = Jc + (c - 1 - i - 15);
+                uint64_t any = 0;
+                for (int u = 0; u < 16; ++u) { const uint32_t h = hslot(q[u]); any |= hb[h >> 6] >> (h & 63); }
+                if (!(any & 1ull)) continue;
+                for (int64_t s2 = i; s2 < i + 16; ++s2) {
+                    const uint32_t j = partner(Jc, c, s2);
+                    const uint32_t h = hslot(j);
+                    if (!((hb[h >> 6] >> (h & 63)) & 1ull) || !fl[j] || j == (uint32_t)s2) continue;
+                    T.step(s2, j);   // position s2 is tracked from here on
+                    const uint32_t h2 = hslot((uint32_t)s2);
+                    hb[h2 >> 6] |= 1ull << (h2 & 63);
+                    touched.push_back(h2 >> 6);
+                }
+            }
+            for (uint32_t w : touched) hb[w] = 0;
+        }
         for (; i + 16 <= c; i += 16) {
             const uint32_t *q = Jc + (c - 1 - i - 15);
             uint32_t any = 0;

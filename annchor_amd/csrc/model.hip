@@ -40,6 +40,7 @@ __device__ __forceinline__ double block_sum(double v, double *sh /*[OLS_T / 64]*
     return s;
 }
 
+#define OLS_RCOND 1e-13   // relative singular value below which a direction of a rank-deficient partition is dropped
 // One workgroup per partition.  A: this partition's scratch, double [4][cap] (columns lb, ub, dad, y of its rows).
 __global__ __launch_bounds__(OLS_T) void k_ols_bins(const double *__restrict__ sfeat, const double *__restrict__ sy, int64_t m,
                                                    DeviceModel *__restrict__ dm, double *__restrict__ scratch, int64_t cap)
@@ -126,6 +127,55 @@ __global__ __launch_bounds__(OLS_T) void k_ols_bins(const double *__restrict__ s
             w2 = qy[2] / Rd[2];
             w1 = (qy[1] - R12 * w2) / Rd[1];
             w0 = ((qy[0] - R01 * w1) - R02 * w2) / Rd[0];
+        } else {
+            // Rank deficient inside the partition -- typically EXACT: among the closest pairs of Euclidean data both points
+            // share their nearest anchor a*, which also gives the tightest upper bound, so ub = D[a*][i] + D[a*][j] = 2 dad
+            // bit for bit.  What scipy's lstsq (dgelsd) returns there is the minimum-norm solution: the singular value
+            // decomposition of the 3 x 3 factor R by one-sided Jacobi rotations, singular values below OLS_RCOND of the largest
+            // dropped.  (dgelsd drops below machine epsilon; an exactly dependent column arrives at ~1e-16 of the largest in
+            // either code, on one side or the other of that line by rounding luck, and when it lands above, the reference's
+            // coefficients are ~1e15 and its predictions whatever the clip to [lb, ub] leaves.  The wider margin takes the
+            // dependency for what it is.)  Restarting the whole fit with the host solver, as round 3 first did, doubled the
+            // fit time of every Euclidean data set of this kind.
+            double M[3][3] = {{Rd[0], R01, R02}, {0.0, Rd[1], R12}, {0.0, 0.0, Rd[2]}};
+            double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+            bool conv = false;
+            for (int sweep = 0; sweep < 40 && !conv; ++sweep) {
+                conv = true;
+                for (int p = 0; p < 2; ++p)
+                    for (int q = p + 1; q < 3; ++q) {
+                        double al = 0, be = 0, ga = 0;
+                        for (int r = 0; r < 3; ++r) { al += M[r][p] * M[r][p]; be += M[r][q] * M[r][q]; ga += M[r][p] * M[r][q]; }
+                        // (a column 1e-20 of the other is dropped by OLS_RCOND whatever it is orthogonal to; rotating against
+                        // it would chase denormals)
+                        if (ga == 0.0 || al <= 1e-40 * be || be <= 1e-40 * al || fabs(ga) <= 4.5e-16 * sqrt(al * be)) continue;
+                        conv = false;
+                        const double zeta = (be - al) / (2.0 * ga);
+                        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                        for (int r = 0; r < 3; ++r) {
+                            const double mp = M[r][p], mq = M[r][q];
+                            M[r][p] = cs * mp - sn * mq; M[r][q] = sn * mp + cs * mq;
+                            const double vp = V[r][p], vq = V[r][q];
+                            V[r][p] = cs * vp - sn * vq; V[r][q] = sn * vp + cs * vq;
+                        }
+                    }
+            }
+            double sg2[3], smax2 = 0.0;
+            for (int i = 0; i < 3; ++i) {
+                sg2[i] = (M[0][i] * M[0][i] + M[1][i] * M[1][i]) + M[2][i] * M[2][i];
+                smax2 = fmax(smax2, sg2[i]);
+            }
+            if (conv && smax2 > 0.0) {
+                double w[3] = {0, 0, 0};
+                for (int i = 0; i < 3; ++i)
+                    if (sg2[i] > (OLS_RCOND * OLS_RCOND) * smax2) {
+                        const double coef = ((M[0][i] * qy[0] + M[1][i] * qy[1]) + M[2][i] * qy[2]) / sg2[i];
+                        for (int r = 0; r < 3; ++r) w[r] += coef * V[r][i];
+                    }
+                w0 = w[0]; w1 = w[1]; w2 = w[2];
+                st = 0;
+            } else if (smax2 == 0.0) st = 0;   // every feature constant inside the partition: the intercept alone (w = 0)
         }
         dm->status[b] = st;
         dm->reg.w[b][0] = w0; dm->reg.w[b][1] = w1; dm->reg.w[b][2] = w2;

@@ -84,10 +84,11 @@ def test_device_model_euclid_and_digits():
     np.testing.assert_allclose(a.neighbor_graph[1], b.neighbor_graph[1], rtol=0, atol=0)
 
 
-def test_rank_deficient_partition_falls_back_to_the_host_solver():
+def test_rank_deficient_partition_minimum_norm_on_the_device():
     """Integer grid data: inside a partition every sample can have the same double anchor distance (a constant
-    column after centring) -- the QR flags it, the host redoes the iteration with dgelsd's minimum-norm solution, and
-    the fit equals the LAPACK path's."""
+    column after centring), or ub = 2 dad exactly -- the QR sees the dependency and the partition gets dgelsd's answer, the
+    minimum-norm solution, from the singular value decomposition of the 3 x 3 factor, on the device: no restart (one pass
+    through the stages), coefficients equal to the LAPACK path's, the same graph."""
     from annchor_amd import Annchor
 
     g = np.arange(12, dtype=np.float64)
@@ -96,7 +97,26 @@ def test_rank_deficient_partition_falls_back_to_the_host_solver():
     cfg = dict(n_anchors=4, n_neighbors=5, n_samples=300, p_work=0.5, locality=3)
     a = Annchor(X, "euclidean", **cfg).fit()
     b = Annchor(X, "euclidean", ols="lapack", **cfg).fit()
+    assert getattr(a, "_device_model_refused", None) is None and a._model_on_device
     np.testing.assert_allclose(a.neighbor_graph[1], b.neighbor_graph[1], rtol=0, atol=0)
+    np.testing.assert_allclose(a.regression.coef_, b.regression.coef_, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(a.regression.intercept_, b.regression.intercept_, rtol=0, atol=1e-9)
+
+
+def test_exactly_dependent_bounds_do_not_restart_the_fit():
+    """Continuous Euclidean data: among the closest pairs both points share their nearest anchor, which also gives the
+    tightest upper bound -- ub = 2 dad bit for bit inside the first partition.  The fit runs its stages once and agrees with
+    the LAPACK path on (nearly) every neighbour."""
+    from annchor_amd import Annchor, compare_neighbor_graphs
+
+    rng = np.random.default_rng(5)
+    Z = rng.standard_normal((4000, 6))
+    X = (Z @ rng.standard_normal((6, 48)) + 0.05 * rng.standard_normal((4000, 48))).astype(np.float64)
+    cfg = dict(n_anchors=24, n_neighbors=15, p_work=0.1, n_samples=5000)
+    a = Annchor(X, "euclidean", **cfg).fit()
+    assert getattr(a, "_device_model_refused", None) is None and a._model_on_device
+    b = Annchor(X, "euclidean", ols="lapack", **cfg).fit()
+    assert compare_neighbor_graphs(a.neighbor_graph, b.neighbor_graph, 15) <= 0.001 * 4000 * 15
 
 
 def test_host_waits_per_c2_fit():
