@@ -60,6 +60,7 @@ _SIGNATURES = {
     "annchor_select_by_rank": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _vp]),
     "annchor_sample_pairs": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "annchor_sample_pairs_device": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i64]),
+    "annchor_hash_sample_pairs_device": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, ctypes.c_uint64, _vp]),
     "annchor_download_samples": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "annchor_fit_regression_device": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32]),
     "annchor_fit_errors_device": (ctypes.c_int, [_vp]),
@@ -494,6 +495,13 @@ class Engine:
         bin_of, ranks = _c(bin_of, np.int32), _c(ranks, np.int64)
         self._chk(self.lib.annchor_sample_pairs_device(self.h, _ptr(bins), len(bins) - 1, _ptr(counts), _ptr(bin_of), _ptr(ranks), len(ranks)))
         return len(ranks)
+
+    def hash_sample_pairs_device(self, bins, counts, want, seed_key):
+        bins, counts, want = _c(bins, np.float64), _c(counts, np.int64), _c(want, np.int64)
+        m = _i64()
+        self._chk(self.lib.annchor_hash_sample_pairs_device(self.h, _ptr(bins), len(bins) - 1, _ptr(counts), _ptr(want),
+                                                            ctypes.c_uint64(int(seed_key)), ctypes.byref(m)))
+        return int(m.value)
 
     def download_samples(self, m, predict=True):
         """(positions, feature rows, distances, unclipped predictions) of the device-resident sample."""

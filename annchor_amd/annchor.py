@@ -395,7 +395,7 @@ class Annchor:
         in between is the reference's default: device metric, the built-in stratified sampler / regression / error
         model on the double anchor distance, and ols='device'."""
         return (self._pipelined and self._device_metric and self.ols == "device" and self._sampler_on_device()
-                and type(self.sampler) is SimpleStratifiedSampler
+                and type(self.sampler) in (SimpleStratifiedSampler, DeviceStratifiedSampler)
                 and type(self.regression) is SimpleStratifiedLinearRegression
                 and list(self.regression.reg_feature_names) == ["lower bound", "upper bound", "double anchor distance"]
                 and self.regression.partition_feature_name == "double anchor distance"
@@ -586,9 +586,9 @@ class Annchor:
         """After a device-fitted iteration: the coefficients into the regression object (what its fit() would have
         left there) and the sticky flags; False when the host has to redo the models."""
         W, c, status, ep, flags = self._engine.model_download(nb)
-        if flags[0]:
+        if flags[0] == 1:
             raise _native.NativeError("sample step: a (bin, rank) entry does not exist (stale counts?)")
-        if flags[1] or flags[2] or status.any():
+        if flags[0] or flags[1] or flags[2] or status.any():   # (flags[0] == 2: a hashed key list came out short -- retry the waiting way)
             self._device_model_refused = (status.copy(), flags.copy())   # (kept for diagnostics / tests)
             return False
         reg = self.regression

@@ -294,6 +294,11 @@ class DeviceStratifiedSampler(SimpleStratifiedSampler):
         if np.minimum(ticket["counts"], ticket["want"]).min() < 2:
             raise Exception("Some sampler bins contain too few samples")
         extra = ()
+        if evaluate == "device":   # positions, feature rows and distances stay in device memory (no host wait)
+            m = engine.hash_sample_pairs_device(sample_bins, ticket["counts"], ticket["want"], ticket["key"])
+            if ticket["n_samples"] != m:
+                print("Warning: Some bins contained fewer samples than requested")
+            return None, m, sample_bins
         if evaluate:   # device metric: positions, feature rows and distances in one device pass
             sample_ixs, feats, y = engine.hash_sample_pairs(sample_bins, ticket["counts"], ticket["want"], ticket["key"])
             extra = (feats, y)

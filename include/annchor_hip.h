@@ -238,6 +238,11 @@ int annchor_set_labels(annchor_ctx *ctx, const int64_t *labels);
  * residual lists for the host (plugin-visible attributes; not on the fit path). */
 int annchor_sample_pairs_device(annchor_ctx *ctx, const double *bins, int32_t nbins, const int64_t *counts, const int32_t *bin_of,
                                 const int64_t *ranks, int64_t nreq);
+/* The same for DeviceStratifiedSampler's order-free choice (annchor_hash_sample_pairs with the results left in device memory
+ * and no host wait: a partition whose key list came out short or overflowed raises the sticky sample-step flag, read with
+ * annchor_model_download).  *n_out = sum over the partitions of min(want, counts). */
+int annchor_hash_sample_pairs_device(annchor_ctx *ctx, const double *bins, int32_t nbins, const int64_t *counts, const int64_t *want,
+                                     uint64_t seed_key, int64_t *n_out);
 int annchor_download_samples(annchor_ctx *ctx, int64_t *positions, double *feats, double *sample_y, double *sample_predict);
 int annchor_fit_regression_device(annchor_ctx *ctx, const double *bins, int32_t nbins, int32_t first_iteration, int32_t is_metric);
 int annchor_fit_errors_device(annchor_ctx *ctx);
