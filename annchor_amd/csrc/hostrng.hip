@@ -314,7 +314,7 @@ void trace_prefix(BinScratch *sc, int64_t c, int64_t k, int64_t *out)
         // Long bins (the flag bytes of 18 M pairs are 18 MB: every test a cache miss, ~5 ns per step): the partners are
         // tested against a hashed set of 2^20 bits (128 KB: L2) holding every position that was EVER tracked (k at the start,
         // one more per real hit: ~k ln(c / k)); only a partner whose hashed bit is set looks at the exact flags.
-        static const int64_t hashed_min = getenv("ANNCHOR_RNG_HASHED_MIN") ? atoll(getenv("ANNCHOR_RNG_HASHED_MIN")) : (4ll << 20);
+        static const int64_t hashed_min = getenv("ANNCHOR_RNG_HASHED_MIN") ? atoll(getenv("ANNCHOR_RNG_HASHED_MIN")) : (1ll << 20);   // (C2 bins of 620 000 pairs: flags 3.16 ms per fit, hashed 4.2; bins of 3.8 M: 56 vs 50 ms per fit)
         if (c >= hashed_min) {
             constexpr int HB = 20;
             if (sc->hbits.size() < ((size_t)1 << (HB - 6))) sc->hbits.resize((size_t)1 << (HB - 6), 0);
