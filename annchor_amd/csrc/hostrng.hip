@@ -683,7 +683,12 @@ extern "C" int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts,
     // bin start at? -- then the bins, now independent, are scanned (with stores) and traced
     // by one thread each.  The sequential part drops to the count-only scan.
     {
-        static const int64_t par_threshold = getenv("ANNCHOR_RNG_PAR_MIN") ? atoll(getenv("ANNCHOR_RNG_PAR_MIN")) : (4ll << 20);
+        // (Round 2 scanned twice above 4 M draws -- a count pass to find where every bin starts, then scan + trace of the bins in
+        // parallel.  With the faster traces and the pinned helpers the single sequential scan that hands each bin to a helper as
+        // soon as it is scanned wins at every size measured: the populations are uneven -- one bin of 16 M pairs of 27 M -- and the
+        // count pass (4 ms there) only delays that bin's trace.  N = 10 000: 74 -> 67 ms per fit, N = 16 000: 224 -> 194 ms.  Kept
+        // behind ANNCHOR_RNG_PAR_MIN for experiments.)
+        static const int64_t par_threshold = getenv("ANNCHOR_RNG_PAR_MIN") ? atoll(getenv("ANNCHOR_RNG_PAR_MIN")) : (1ll << 60);
         int64_t total = 0;
         int nlive = 0;
         for (int b = 0; b < nbins; ++b)
@@ -714,15 +719,30 @@ extern "C" int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts,
                     if (counts[b] < want[b]) continue;
                     Scan S2{st.get(), start[(size_t)b]};   // every word of the bin is already generated
                     BinScratch *sc = g_scratch[(size_t)b].get();
+                    const double t0 = timing ? ms_since(t_entry) : 0.0;
                     if (use_avx512()) scan_bin_avx512<true>(S2, counts[b], sc->J.data());
                     else scan_bin_scalar<true>(S2, counts[b], sc->J.data());
+                    const double t1 = timing ? ms_since(t_entry) : 0.0;
                     trace_prefix(sc, counts[b], want[b], ranks_out + offs[(size_t)b]);
+                    if (timing)
+                        fprintf(stderr, "[rng]   bin %d (%lld): scan %.3f -> %.3f, trace -> %.3f ms\n", b, (long long)counts[b], t0, t1, ms_since(t_entry));
                 }
             };
-            std::vector<std::thread> pool;
-            for (int t = 1; t < nlive; ++t) pool.emplace_back(work);
-            work();
-            for (auto &th : pool) th.join();
+            // the persistent helpers (warm, inside this thread's last-level cache) instead of one fresh thread per bin: a
+            // thread created per call lands on a sleeping core somewhere on the socket
+            static const bool fresh = getenv("ANNCHOR_RNG_PAR_FRESH") != nullptr;
+            if (fresh) {
+                std::vector<std::thread> pool;
+                for (int t = 1; t < nlive; ++t) pool.emplace_back(work);
+                work();
+                for (auto &th : pool) th.join();
+            } else {
+                const std::function<void()> job = work;
+                g_helpers->start(std::min(nlive - 1, 6));
+                g_helpers->post(&job);
+                work();
+                g_helpers->finish();
+            }
             if (timing)
                 fprintf(stderr, "[rng] parallel: count pass %.3f ms, all bins done %.3f ms, words %zu\n", t_count, ms_since(t_entry), S.cur);
             return ANNCHOR_OK;
