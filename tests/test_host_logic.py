@@ -286,9 +286,9 @@ def test_library_rng_portable_path_matches_numpy():
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
-def test_library_rng_parallel_path_matches_numpy():
-    """Draws above 4 M elements take the two-pass route (count-only pass for the bins' stream
-    offsets, then one thread per bin): same stream, same result."""
+def test_library_rng_long_bins_match_numpy():
+    """Bins of a million pairs and more trace through the hashed tracked set (default route: one sequential scan, the
+    traces on the pinned helpers): same stream, same result."""
     import __graft_entry__ as g
 
     g.build()
@@ -301,6 +301,33 @@ def test_library_rng_parallel_path_matches_numpy():
         np.random.seed(seed)
         ref = [np.arange(c) if c < w else np.random.permutation(int(c))[:w] for c, w in zip(counts, want)]
         assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+
+
+@pytest.mark.parametrize("env", [{"ANNCHOR_RNG_PAR_MIN": "4194304"}, {"ANNCHOR_RNG_PAR_MIN": "4194304", "ANNCHOR_RNG_PAR_FRESH": "1"},
+                                 {"ANNCHOR_RNG_HASHED_MIN": "1000"}, {"ANNCHOR_RNG_HASHED_MIN": "1000000000000"},
+                                 {"ANNCHOR_RNG_PIN": "0", "ANNCHOR_RNG_HELPERS": "1"}])
+def test_library_rng_routes_match_numpy(env):
+    """The routes behind the environment switches (read once per process, hence the subprocess): the count pass + parallel
+    bins of round 2 (pooled helpers or fresh threads), the hashed trace forced on short bins / switched off on long ones,
+    free-running helpers."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, __graft_entry__ as g\n"
+        "g.build()\n"
+        "from annchor_amd import _native\n"
+        "counts, want = [300000, 1500000, 900000, 40, 1200000, 3, 700000], [715, 715, 714, 714, 714, 5, 714]\n"
+        "for seed in (7, 42):\n"
+        "    got = _native.legacy_choice_ranks(seed, counts, want)\n"
+        "    np.random.seed(seed)\n"
+        "    ref = [np.arange(c) if c < w else np.random.permutation(int(c))[:w] for c, w in zip(counts, want)]\n"
+        "    assert all(np.array_equal(a, b) for a, b in zip(got, ref))\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, PYTHONPATH=root, **env), capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
 def test_to_sparse_matrix_equals_reference_loop():
