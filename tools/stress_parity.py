@@ -31,8 +31,10 @@ for case in range(ncases):
         Xg = rng.integers(0, int(rng.integers(3, 9)), (n, int(rng.integers(2, 6)))).astype(np.float64)
         pairs, data, metric = (lambda IJ, Xg=Xg: om.euclidean_pairs(Xg, IJ)), Xg, "euclidean"
     t = time.time()
+    if os.environ.get("STRESS_ONLY") and int(os.environ["STRESS_ONLY"]) != case:
+        continue
     try:
-        ann = Annchor(data, metric, **cfg).fit()
+        ann = Annchor(data, metric, ols=os.environ.get("STRESS_OLS", "device"), **cfg).fit()
         ora = O.OracleAnnchor(n, pairs, **cfg).fit()
         same = (np.array_equal(ann.neighbor_graph[1], ora.neighbor_graph[1]) and np.array_equal(ann.neighbor_graph[0], ora.neighbor_graph[0]))
         ndiff = int((ann.neighbor_graph[1] != ora.neighbor_graph[1]).sum())
@@ -41,7 +43,11 @@ for case in range(ncases):
         else:                      # float metric: the OLS coefficients of the two sides may differ in the last bit, and on
             # tie-heavy data that moves candidate choices (tests compare float metrics stage by stage within 1e-12):
             # same work, graphs agreeing on nearly every entry
-            ok = ann.evals == ora.evals and ndiff <= 0.05 * ann.neighbor_graph[1].size
+            # (a rank-deficient partition gets the minimum-norm solution on the device -- coefficient RATIOS are then small
+            # rationals, different feature triples of lattice data predict the same value mathematically, and which of them
+            # rounding puts first differs between the device's solver and LAPACK: a handful of evaluations; STRESS_OLS=lapack
+            # reproduces the CPU side exactly)
+            ok = abs(ann.evals - ora.evals) <= 0.002 * ora.evals and ndiff <= 0.05 * ann.neighbor_graph[1].size
         msg = ("" if same else " (%d of %d entries differ)" % (ndiff, ann.neighbor_graph[1].size)) if ok else \
             " evals %d vs %d, dist diff %d" % (ann.evals, ora.evals, ndiff)
     except Exception as e:   # both sides must agree on failing too
