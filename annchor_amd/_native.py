@@ -184,6 +184,7 @@ def pairlist_point_limit(device=0):
     80 % of the device's free memory at PAIR_BYTES per pair.  None when no device can be asked."""
     f, t = _i64(), _i64()
     try:
+        load_library().annchor_release_parked()   # (blocks parked for reuse count as free)
         if load_library().annchor_device_mem_info(int(device), ctypes.byref(f), ctypes.byref(t)) != 0:
             return None
     except NativeError:

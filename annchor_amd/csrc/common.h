@@ -96,6 +96,7 @@ struct annchor_ctx {
     // ---- device-resident model of an iteration (model.hip): per-partition OLS coefficients, residual lists
     DevBuf model;          // DeviceModel
     DevBuf ols_scratch;    // double [nb][4][m]: a partition's centred design matrix and targets
+    std::vector<DevBuf *> own_allocs;   // members of this context that ann_reserve gave an allocation of their own (freed by annchor_destroy)
     int prof_group_entry = -1;   // >= 0: a ProfGroup of that family is open (its inner scopes record no events)
     bool model_fitted = false;   // `model` holds this iteration's regression
     bool errs_on_device = false; // `errs` / `errptr` hold this iteration's sorted residuals (annchor_fit_errors_device)

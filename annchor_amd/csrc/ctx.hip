@@ -3,6 +3,8 @@
 #include <cstdlib>
 
 #include "common.h"
+#include <algorithm>
+#include <chrono>
 #include <mutex>
 
 static std::string g_create_err;
@@ -20,25 +22,102 @@ const char *ann_set_err(annchor_ctx *c, const char *fmt, ...)
     return c ? c->err.c_str() : g_create_err.c_str();
 }
 
+// Large device allocations are kept for the next context instead of going back to the driver: a create / fit / close
+// cycle at 127 M pairs allocates and frees ~10 buffers of 0.5-1 GB, and every fifth cycle or so one of those hipMalloc calls
+// took 1.4 s on this stack (free memory constant; tools/repeat_fit.py) against 2 ms otherwise.  Blocks of 16 MB and more,
+// at most POOL_MAX_BYTES of them per process; a request takes the smallest cached block of its device that is large enough
+// and not more than a quarter larger.  annchor_release_parked() returns them to the driver; ANNCHOR_NO_CTX_POOL=1 disables it.
+namespace {
+struct PoolBlock { void *p; size_t bytes; int device; };
+std::mutex g_pool_mu;
+std::vector<PoolBlock> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t POOL_MIN_BLOCK = (size_t)16 << 20, POOL_MAX_BYTES = (size_t)48 << 30;
+bool pool_enabled()
+{
+    static const bool off = getenv("ANNCHOR_NO_CTX_POOL") != nullptr;
+    return !off;
+}
+void *pool_take(int device, size_t want, size_t *got)
+{
+    if (want < POOL_MIN_BLOCK || !pool_enabled()) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (int i = 0; i < (int)g_pool.size(); ++i)
+        if (g_pool[(size_t)i].device == device && g_pool[(size_t)i].bytes >= want && g_pool[(size_t)i].bytes <= want + want / 4 &&
+            (best < 0 || g_pool[(size_t)i].bytes < g_pool[(size_t)best].bytes))
+            best = i;
+    if (best < 0) return nullptr;
+    void *p = g_pool[(size_t)best].p;
+    *got = g_pool[(size_t)best].bytes;
+    g_pool_bytes -= *got;
+    g_pool.erase(g_pool.begin() + best);
+    return p;
+}
+}  // namespace
+void ann_dev_free(annchor_ctx *c, void *p, size_t bytes)
+{
+    if (!p) return;
+    if (bytes >= POOL_MIN_BLOCK && pool_enabled()) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_pool_bytes + bytes <= POOL_MAX_BYTES) {
+            g_pool.push_back({p, bytes, c->device});
+            g_pool_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
 int ann_reserve(annchor_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return ANNCHOR_OK;
     size_t want = (bytes + 255) & ~(size_t)255;
     if (c->arena && c->arena_off + want <= c->arena_size) {
-        if (b.p && !b.in_arena) ANN_CHECK_HIP(c, hipFree(b.p));
+        if (b.p && !b.in_arena) ann_dev_free(c, b.p, b.cap);
         b.p = c->arena + c->arena_off;  // a previous (smaller) arena slice is simply abandoned
         c->arena_off += want;
         b.cap = want;
         b.in_arena = true;
         return ANNCHOR_OK;
     }
-    if (b.p && !b.in_arena) ANN_CHECK_HIP(c, hipFree(b.p));
+    static const bool trace = getenv("ANNCHOR_ALLOC_TRACE") != nullptr;   // stderr line per device allocation slower than 2 ms
+    const auto t0 = std::chrono::steady_clock::now();
+    if (b.p && !b.in_arena) ann_dev_free(c, b.p, b.cap);
+    const auto t1 = std::chrono::steady_clock::now();
     b.p = nullptr;
     b.cap = 0;
     b.in_arena = false;
-    ANN_CHECK_HIP(c, hipMalloc(&b.p, want));
+    size_t got = 0;
+    if (void *cached = pool_take(c->device, want, &got)) { b.p = cached; want = got; }
+    else if (hipMalloc(&b.p, want) != hipSuccess) {
+        // out of memory with blocks parked in the pool: give them back to the driver and ask once more
+        (void)hipGetLastError();
+        b.p = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            for (PoolBlock &pb : g_pool) { (void)hipSetDevice(pb.device); (void)hipFree(pb.p); }
+            g_pool.clear();
+            g_pool_bytes = 0;
+            (void)hipSetDevice(c->device);
+        }
+        ANN_CHECK_HIP(c, hipMalloc(&b.p, want));
+    }
     b.cap = want;
+    {
+        // every member of the context that ever got an allocation of its own is released by annchor_destroy (a hand-kept list
+        // there had fallen 18 buffers behind: ~1.3 GB leaked per context at 127 M pairs, and the device's allocator answered
+        // the next contexts' gigabyte requests in 0.3-1.8 s instead of 2 ms)
+        const char *lo = reinterpret_cast<const char *>(c), *me = reinterpret_cast<const char *>(&b);
+        if (me >= lo && me < lo + sizeof(annchor_ctx) && std::find(c->own_allocs.begin(), c->own_allocs.end(), &b) == c->own_allocs.end())
+            c->own_allocs.push_back(&b);
+    }
+    if (trace) {
+        const double f = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        const double m = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+        if (f + m > 2.0) fprintf(stderr, "alloc %.1f MB: free %.2f ms, malloc %.2f ms\n", (double)want / 1e6, f, m);
+    }
     return ANNCHOR_OK;
 }
 
@@ -52,12 +131,14 @@ int ann_arena_init(annchor_ctx *c, int64_t nx)
         // one slab per context; a slab inherited from a parked context (see annchor_destroy) is kept
         // when it is large enough and nothing has been carved from it yet
         if (c->arena_size >= bytes || c->arena_off != 0) return ANNCHOR_OK;
-        (void)hipFree(c->arena);
+        ann_dev_free(c, c->arena, c->arena_size);
         c->arena = nullptr;
         c->arena_size = 0;
     }
     void *p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return ANNCHOR_OK; }  // optional
+    size_t got = 0;
+    if ((p = pool_take(c->device, bytes, &got)) != nullptr) bytes = got;
+    else if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return ANNCHOR_OK; }  // optional
     c->arena = (char *)p;
     c->arena_size = bytes;
     c->arena_off = 0;
@@ -319,16 +400,9 @@ extern "C" void annchor_destroy(annchor_ctx *c)
     prof_drain(c);
     ann_stream_release(c);
     ann_enemies_release(c);
-    DevBuf *bufs[] = {&c->sym, &c->soff, &c->slen, &c->pts, &c->hist, &c->cost, &c->supp, &c->Dt, &c->A,
-                      &c->anchorRank, &c->runmin, &c->redval, &c->redidx, &c->sid, &c->cA, &c->thr, &c->Kbits,
-                      &c->Kpref, &c->deg, &c->low, &c->rowstart, &c->Iptr, &c->Iidx, &c->ij, &c->lb, &c->ub,
-                      &c->dad, &c->RA, &c->prob, &c->anc, &c->ncm, &c->label, &c->spos, &c->sy, &c->thresh,
-                      &c->cand, &c->next, &c->gl_val, &c->gl_pos, &c->gl_cnt, &c->gl_ncomp, &c->marked,
-                      &c->markcount, &c->sel_hist, &c->sel_state, &c->sel2, &c->sel_bufA, &c->sel_bufB, &c->sel_seg, &c->blk_cnt, &c->blk_off, &c->errs, &c->errptr,
-                      &c->cptr, &c->cidx, &c->cval, &c->tmp0, &c->tmp1, &c->tmp2, &c->tmp3, &c->scan_tmp,
-                      &c->stage_in, &c->stage_out};
-    for (DevBuf *b : bufs)
-        if (b->p && !b->in_arena) (void)hipFree(b->p);
+    for (DevBuf *b : c->own_allocs)
+        if (b->p && !b->in_arena) { ann_dev_free(c, b->p, b->cap); b->p = nullptr; b->cap = 0; }
+    c->own_allocs.clear();
     {
         // park the shell for the next context of this device (at most SHELL_MAX of them, slabs up to
         // SHELL_ARENA_MAX; ANNCHOR_NO_CTX_POOL=1 turns the parking off)
@@ -341,13 +415,13 @@ extern "C" void annchor_destroy(annchor_ctx *c)
             sh.call_a = c->call_a; sh.call_b = c->call_b;
             sh.ev_pool.swap(c->ev_pool);
             sh.arena = c->arena; sh.arena_size = c->arena_size;
-            if (sh.arena && sh.arena_size > SHELL_ARENA_MAX) { (void)hipFree(sh.arena); sh.arena = nullptr; sh.arena_size = 0; }
+            if (sh.arena && sh.arena_size > SHELL_ARENA_MAX) { ann_dev_free(c, sh.arena, sh.arena_size); sh.arena = nullptr; sh.arena_size = 0; }
             g_shells.push_back(std::move(sh));
             delete c;
             return;
         }
     }
-    if (c->arena) (void)hipFree(c->arena);
+    if (c->arena) ann_dev_free(c, c->arena, c->arena_size);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < annchor_ctx::PIN_SLOTS; ++i)
         if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
@@ -365,6 +439,12 @@ extern "C" int annchor_release_parked(void)
     {
         std::lock_guard<std::mutex> lk(g_shell_mu);
         shells.swap(g_shells);
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (PoolBlock &pb : g_pool) { (void)hipSetDevice(pb.device); (void)hipFree(pb.p); }
+        g_pool.clear();
+        g_pool_bytes = 0;
     }
     for (CtxShell &sh : shells) {
         (void)hipSetDevice(sh.device);
