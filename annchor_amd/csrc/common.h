@@ -185,6 +185,8 @@ int ann_reserve(annchor_ctx *c, DevBuf &b, size_t bytes);
 int ann_arena_init(annchor_ctx *c, int64_t nx);
 int ann_h2d(annchor_ctx *c, void *dst, const void *src, size_t bytes);
 hipError_t ann_sync(annchor_ctx *c, const char *where);
+int ann_dev_alloc(annchor_ctx *c, void **p, size_t want, size_t *got);   // hipMalloc / hipFree through the process-wide block pool (ctx.hip)
+void ann_dev_free(annchor_ctx *c, void *p, size_t bytes);
 int ann_kth_async(annchor_ctx *c, const double *vals, const uint8_t *flag, int64_t n, const int64_t *ks, int nk,
                   const unsigned long long **d_prefix, const int **d_unfinished);
 void ann_kth_async_done(annchor_ctx *c);

@@ -55,6 +55,27 @@ void *pool_take(int device, size_t want, size_t *got)
     return p;
 }
 }  // namespace
+// hipMalloc through the pool (want rounded by the caller); *got = the block's real size
+int ann_dev_alloc(annchor_ctx *c, void **p, size_t want, size_t *got)
+{
+    *got = want;
+    if ((*p = pool_take(c->device, want, got)) != nullptr) return ANNCHOR_OK;
+    *got = want;
+    if (hipMalloc(p, want) == hipSuccess) return ANNCHOR_OK;
+    (void)hipGetLastError();
+    *p = nullptr;
+    {
+        // out of memory with blocks parked in the pool: give them back to the driver and ask once more
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (PoolBlock &pb : g_pool) { (void)hipSetDevice(pb.device); (void)hipFree(pb.p); }
+        g_pool.clear();
+        g_pool_bytes = 0;
+        (void)hipSetDevice(c->device);
+    }
+    ANN_CHECK_HIP(c, hipMalloc(p, want));
+    return ANNCHOR_OK;
+}
+
 void ann_dev_free(annchor_ctx *c, void *p, size_t bytes)
 {
     if (!p) return;
@@ -90,20 +111,8 @@ int ann_reserve(annchor_ctx *c, DevBuf &b, size_t bytes)
     b.cap = 0;
     b.in_arena = false;
     size_t got = 0;
-    if (void *cached = pool_take(c->device, want, &got)) { b.p = cached; want = got; }
-    else if (hipMalloc(&b.p, want) != hipSuccess) {
-        // out of memory with blocks parked in the pool: give them back to the driver and ask once more
-        (void)hipGetLastError();
-        b.p = nullptr;
-        {
-            std::lock_guard<std::mutex> lk(g_pool_mu);
-            for (PoolBlock &pb : g_pool) { (void)hipSetDevice(pb.device); (void)hipFree(pb.p); }
-            g_pool.clear();
-            g_pool_bytes = 0;
-            (void)hipSetDevice(c->device);
-        }
-        ANN_CHECK_HIP(c, hipMalloc(&b.p, want));
-    }
+    ANN_TRY(ann_dev_alloc(c, &b.p, want, &got));
+    want = got;
     b.cap = want;
     {
         // every member of the context that ever got an allocation of its own is released by annchor_destroy (a hand-kept list

@@ -65,7 +65,7 @@ void ann_enemies_release(annchor_ctx *c)
                               &s->lb, &s->ub, &s->dad, &s->anc, &s->ncm, &s->RA, &s->todo, &s->todo_ij, &s->todo_d, &s->todo_n, &s->out_i,
                               &s->out_d};
             for (DevBuf *b : bufs)
-                if (b->p && !b->in_arena) (void)hipFree(b->p);
+                if (b->p && !b->in_arena) ann_dev_free(c, b->p, b->cap);
             delete s;
             g_en.erase(g_en.begin() + (long)i);
             return;
@@ -76,11 +76,12 @@ static int en_reserve(annchor_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return ANNCHOR_OK;
-    if (b.p && !b.in_arena) ANN_CHECK_HIP(c, hipFree(b.p));
+    if (b.p && !b.in_arena) ann_dev_free(c, b.p, b.cap);
     b.p = nullptr; b.cap = 0; b.in_arena = false;
-    const size_t want = (bytes + 255) & ~(size_t)255;
-    ANN_CHECK_HIP(c, hipMalloc(&b.p, want));
-    b.cap = want;
+    const size_t want0 = (bytes + 255) & ~(size_t)255;
+    size_t got = 0;
+    ANN_TRY(ann_dev_alloc(c, &b.p, want0, &got));
+    b.cap = got;
     return ANNCHOR_OK;
 }
 

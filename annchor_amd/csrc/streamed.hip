@@ -53,7 +53,7 @@ void ann_stream_release(annchor_ctx *c)
                               &s->rows_send, &s->rows_recv, &s->rows_all, &s->lists_all, &s->route_tab, &s->route_cnt, &s->route_slot,
                               &s->route_send, &s->route_recv};
             for (DevBuf *b : bufs)
-                if (b->p && !b->in_arena) (void)hipFree(b->p);
+                if (b->p && !b->in_arena) ann_dev_free(c, b->p, b->cap);
             ann_stream_free_run(s);
             delete s;
             g_states.erase(g_states.begin() + (long)i);
@@ -66,11 +66,12 @@ static int sreserve(annchor_ctx *c, DevBuf &b, size_t bytes)
     // streamed buffers are large: always individual allocations
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return ANNCHOR_OK;
-    if (b.p && !b.in_arena) ANN_CHECK_HIP(c, hipFree(b.p));
+    if (b.p && !b.in_arena) ann_dev_free(c, b.p, b.cap);
     b.p = nullptr; b.cap = 0; b.in_arena = false;
-    size_t want = (bytes + 255) & ~(size_t)255;
-    ANN_CHECK_HIP(c, hipMalloc(&b.p, want));
-    b.cap = want;
+    const size_t want0 = (bytes + 255) & ~(size_t)255;
+    size_t got = 0;
+    ANN_TRY(ann_dev_alloc(c, &b.p, want0, &got));
+    b.cap = got;
     return ANNCHOR_OK;
 }
 
