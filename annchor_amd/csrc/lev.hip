@@ -1184,6 +1184,219 @@ __global__ __launch_bounds__(ANN_WAVE) void k_lev_a2(LevArgsA2 aa)
     if (have && lp == 0) a.out[tq[pair]] = (double)best;
 }
 
+// k_lev_p2: the packed latency kernel for SHORT pair lists (a sampling step's 5000 pairs, a small refinement): the same two
+// pairs per wave / forward-backward split as k_lev_a2, each pair with its own two strings; pairs come from the class
+// permutation k_lev_classify builds (short patterns first).  Such a launch is 1250 four-pair waves on 1024 SIMDs for k_lev_f --
+// twice a 500-column chain where two waves share a SIMD -- and 2500 half-chain waves here.
+struct LevArgsP2 {
+    const uint8_t *sym;
+    const int32_t *soff;
+    const int32_t *slen;
+    const int2 *ij;
+    const int32_t *idx;
+    const int32_t *perm;      // list positions, short-pattern pairs first, the others from the back
+    const int32_t *cursors;   // [0] pairs of the packed class, [1] the others
+    int64_t n;
+    double *out;
+    double *RA;
+    uint8_t *ncm;
+    int alphabet, pm_bytes, fb_stride, buf_stride, pad;
+};
+
+__global__ __launch_bounds__(ANN_WAVE) void k_lev_p2(LevArgsP2 aa)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LevArgsP2 &a = aa;
+    const int lane = threadIdx.x, A = a.alphabet;
+    const int n_short = a.cursors[0], n_long = a.cursors[1];
+    const int ws = (n_short + 1) >> 1;                    // waves of the packed class
+    const bool packed = (int)blockIdx.x < ws;
+    if (!packed && (int)blockIdx.x - ws >= n_long) return;
+    const int GL = packed ? 16 : 32;
+    const int slot = lane / GL, w = lane - slot * GL, pair = slot >> 1, half = slot & 1;
+    const int LP = packed ? 32 : 64;                      // lanes per pair
+    unsigned char *pm_col = smem + (size_t)(lane >> 5) * A * LEVF_ROW + (size_t)(lane & 31) * 4;
+    uint8_t *bufs = smem + a.pm_bytes;                    // [2 q], [2 q + 1]: the two strings of the wave's pair q
+    int16_t *FB = reinterpret_cast<int16_t *>(bufs + 4 * aa.buf_stride);   // [pair][half][fb_stride]
+    for (int e = lane * 16; e < 4 * aa.buf_stride; e += 64 * 16) *reinterpret_cast<uint4 *>(bufs + e) = make_uint4(0, 0, 0, 0);
+    uint32_t hp_or = w == 0 ? 0x80000000u : 0u;
+    uint32_t hn_and = w == 0 ? 0u : 0xffffffffu;
+    asm volatile("" : "+v"(hp_or), "+v"(hn_and));
+    // ---- this wave's pairs: list positions from the class permutation (short patterns first, long ones from the back)
+    int tq[2] = {-1, -1};
+    if (packed) {
+        tq[0] = a.perm[2 * blockIdx.x];
+        if (2 * (int)blockIdx.x + 1 < n_short) tq[1] = a.perm[2 * blockIdx.x + 1];
+    } else {
+        tq[0] = a.perm[n_short + ((int)blockIdx.x - ws)];
+    }
+    int si[2] = {0, 0}, sj[2] = {0, 0}, li[2] = {0, 0}, lj[2] = {0, 0};
+    int64_t opos[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (tq[q] >= 0) {
+            opos[q] = a.idx ? (int64_t)a.idx[tq[q]] : (int64_t)tq[q];
+            const int2 pq = a.ij[opos[q]];
+            si[q] = pq.x; sj[q] = pq.y;
+        }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (tq[q] >= 0) {
+            li[q] = a.slen[si[q]]; lj[q] = a.slen[sj[q]];
+            const uint8_t *s0 = a.sym + a.soff[si[q]], *s1 = a.sym + a.soff[sj[q]];
+            for (int ch = lane; ch < ((li[q] + 15) >> 4); ch += 64)
+                reinterpret_cast<uint4 *>(bufs + (2 * q) * aa.buf_stride + aa.pad)[ch] = reinterpret_cast<const uint4 *>(s0)[ch];
+            for (int ch = lane; ch < ((lj[q] + 15) >> 4); ch += 64)
+                reinterpret_cast<uint4 *>(bufs + (2 * q + 1) * aa.buf_stride + aa.pad)[ch] = reinterpret_cast<const uint4 *>(s1)[ch];
+        }
+    wave_lds_fence();
+    // ---- roles of this lane's pair: packed class -- pattern = the shorter string (fits the 16-lane slot); otherwise
+    // pattern = the longer one (fewer text columns)
+    const bool have = pair < 2 && tq[pair < 2 ? pair : 0] >= 0 && (packed || pair == 0);
+    const int pq = pair < 2 ? pair : 0;
+    const int l0 = have ? li[pq] : 0, l1 = have ? lj[pq] : 0;
+    // packed class: pattern = the shorter string (fits the 16-lane slot); otherwise the longer one (fewer text columns)
+    const bool first_is_pattern = packed ? (l0 <= l1) : (l0 > l1);
+    const int m = have ? (first_is_pattern ? l0 : l1) : 0;          // pattern length
+    const int n = have ? (first_is_pattern ? l1 : l0) : 0;          // text length
+    const uint8_t *pat = bufs + (2 * pq + (first_is_pattern ? 0 : 1)) * aa.buf_stride + aa.pad;
+    const uint8_t *txt = bufs + (2 * pq + (first_is_pattern ? 1 : 0)) * aa.buf_stride + aa.pad;
+    const int Wp = (m + 31) >> 5;
+    for (int c = 0; c < A; ++c) *reinterpret_cast<uint32_t *>(pm_col + (size_t)c * LEVF_ROW) = 0u;
+    if (have && w < Wp) {
+        const int valid = min(32, m - w * 32);
+        uint32_t sy[32];
+        if (half == 0) {
+            const uint4 *p16 = reinterpret_cast<const uint4 *>(pat + w * 32);
+            const uint4 q0 = p16[0], q1 = p16[1];
+            const uint32_t wd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+            for (int k = 0; k < 32; ++k) sy[k] = (wd[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) sy[k] = pat[max(m - 1 - (w * 32 + k), 0)];
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (k < valid) atomicOr(reinterpret_cast<uint32_t *>(pm_col + (size_t)sy[k] * LEVF_ROW), 1u << k);
+    }
+    wave_lds_fence();
+
+    const int h = (n + 1) >> 1;
+    const uint32_t un = (have && m > 0) ? (uint32_t)(half ? n - h : h) : 0u;
+    int max_steps = (have && m > 0) ? h + Wp - 1 : 0;
+    int k_lo = (have && m > 0) ? Wp - 1 : 0, k_hi = (have && m > 0) ? n - h : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        max_steps = max(max_steps, __shfl_xor(max_steps, off));
+        k_lo = max(k_lo, __shfl_xor(k_lo, off));
+        k_hi = min(k_hi, __shfl_xor(k_hi, off));
+    }
+    max_steps = __builtin_amdgcn_readfirstlane(max_steps);
+    k_lo = min(__builtin_amdgcn_readfirstlane(k_lo), max_steps);
+    k_hi = max(k_lo, min(__builtin_amdgcn_readfirstlane(k_hi), max_steps));
+    const int dir = half ? -1 : 1;
+    const uint8_t *tp = txt + (half ? n - 1 + w : -w);
+    uint32_t vp = 0xffffffffu, vn = 0u;
+    uint32_t c1 = tp[dir];
+    uint32_t eq = *reinterpret_cast<const uint32_t *>(pm_col + (uint32_t)tp[0] * LEVF_ROW);
+    uint32_t out_hp = 0, out_hn = 0;
+    const uint8_t *tnext = tp + 2 * dir;
+    auto column = [&](int k, auto checked) {
+        const uint32_t c2 = *tnext;
+        tnext += dir;
+        const uint32_t eq_n = *reinterpret_cast<const uint32_t *>(pm_col + c1 * LEVF_ROW);
+        const uint32_t hp_up = dpp_shr1_or(out_hp, hp_or), hn_up = dpp_shr1_and(out_hn, hn_and);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool valid = !decltype(checked)::value || (uint32_t)(k - w) < un;
+        const uint32_t c = hn_up >> 31;
+        const uint32_t x = eq | c;
+        const uint32_t tt = __builtin_amdgcn_bitop3_b32(c, eq, vp, 0xa8);
+        const uint32_t sm = tt + vp;
+        const uint32_t d0p = __builtin_amdgcn_bitop3_b32(sm, vp, x, 0xbe);
+        const uint32_t hp = __builtin_amdgcn_bitop3_b32(vn, d0p, vp, 0xf1);
+        const uint32_t d0 = d0p | vn;
+        const uint32_t hn = d0 & vp;
+        const uint32_t hps = __builtin_amdgcn_alignbit(hp, hp_up, 31);
+        const uint32_t hns = __builtin_amdgcn_alignbit(hn, hn_up, 31);
+        const uint32_t nvp = __builtin_amdgcn_bitop3_b32(hns, d0, hps, 0xf1);
+        const uint32_t nvn = hps & d0;
+        vp = valid ? nvp : vp;
+        vn = valid ? nvn : vn;
+        out_hp = hp;
+        out_hn = hn;
+        __builtin_amdgcn_sched_barrier(0);
+        eq = eq_n;
+        c1 = c2;
+    };
+    int k = 0;
+    for (; k < k_lo; ++k) column(k, std::true_type());
+    for (; k + 2 <= k_hi; k += 2) { column(k, std::false_type()); column(k + 1, std::false_type()); }
+    for (; k < k_hi; ++k) column(k, std::false_type());
+    for (; k < max_steps; ++k) column(k, std::true_type());
+
+    // ---- F / B' (prefix sums of the vertical deltas down this half's rows), then min_i F[i] + B'[m - i] per pair
+    const uint32_t rows = !have ? 0u : (w < Wp - 1 ? 0xffffffffu : (w == Wp - 1 ? (0xffffffffu >> (31 - ((m - 1) & 31))) : 0u));
+    const int part = __popc(vp & rows) - __popc(vn & rows);
+    int incl = part;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const int o = __shfl_up(incl, off, 32);
+        if (w >= off) incl += o;
+    }
+    int val = (int)un + incl - part;
+    if (m == 0) val = half ? n - h : h;
+    int16_t *fbp = FB + (size_t)(pair < 2 ? pair : 0) * 2 * a.fb_stride;
+    int16_t *fb = fbp + (size_t)half * a.fb_stride;
+    if (have && w == 0) fb[0] = (int16_t)val;
+#pragma unroll
+    for (int b = 0; b < 32; ++b) {
+        val += (int)((vp >> b) & 1u) - (int)((vn >> b) & 1u);
+        if ((rows >> b) & 1u) fb[w * 32 + b + 1] = (int16_t)val;
+    }
+    wave_lds_fence();
+    int best = 0x7fffffff;
+    const int lp = lane & (LP - 1);
+    if (have)
+        for (int i = lp; i <= m; i += LP) best = min(best, (int)fbp[i] + (int)fbp[a.fb_stride + m - i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        if (off < LP) best = min(best, __shfl_xor(best, off));
+    if (have && lp == 0) {
+        const double d = (double)best;
+        if (a.out) a.out[tq[pq]] = d;
+        if (a.RA) { a.RA[opos[pq]] = d; a.ncm[opos[pq]] = 0; }
+    }
+}
+
+
+static int launch_p2(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm)
+{
+    LevArgsP2 a;
+    a.sym = c->sym.as<uint8_t>(); a.soff = c->soff.as<int32_t>(); a.slen = c->slen.as<int32_t>();
+    a.ij = src.ij; a.idx = src.idx; a.n = src.n; a.out = d_out; a.RA = d_RA; a.ncm = d_ncm;
+    a.alphabet = c->alphabet;
+    a.pm_bytes = 2 * a.alphabet * LEVF_ROW;
+    a.fb_stride = (c->maxlen + 2 + 7) & ~7;
+    a.pad = ((c->maxlen / 2 + 48) + 15) & ~15;
+    a.buf_stride = 2 * a.pad + ((c->maxlen + 15) & ~15) + 16;
+    const size_t lds = (size_t)a.pm_bytes + 4 * (size_t)a.buf_stride + 4 * sizeof(int16_t) * a.fb_stride;
+    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "alphabet %d x length %d needs %zu B of LDS (> 160 KiB)", c->alphabet,
+                c->maxlen, lds);
+    ANN_TRY(ann_reserve(c, c->lev_perm, sizeof(int32_t) * (size_t)(src.n + 2)));
+    int32_t *perm = c->lev_perm.as<int32_t>();
+    int32_t *cursors = perm + src.n;
+    ANN_CHECK_HIP(c, hipMemsetAsync(cursors, 0, 2 * sizeof(int32_t), c->stream));
+    k_lev_classify<<<ann_blocks(src.n, 256), 256, 0, c->stream>>>(src.ij, src.idx, a.slen, src.n, 16, perm, cursors);
+    a.perm = perm; a.cursors = cursors;
+    if (lds > 64 * 1024)
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev_p2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // (the class sizes stay on the device: one wave per list entry is the upper bound, the surplus waves return at once)
+    k_lev_p2<<<(int)src.n, ANN_WAVE, lds, c->stream>>>(a);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
 static int launch_a2(annchor_ctx *c, const PairSource &src, double *d_out)
 {
     LevArgsA2 aa;
@@ -1453,6 +1666,21 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
         }
         if (R == 9 && W <= 32) {   // k_lev_f (strings up to 1024 symbols: a slot's lanes must map to distinct banks)
             ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
+            // short pair lists are latency bound like the anchor rounds: the packed forward / backward kernel
+            // (ANNCHOR_LEV_P2_MAX: longest list that takes it, 0 = never; read per launch)
+            // k_lev_f runs its list in batches of one wave per SIMD (41 us each at C2's lengths, P pairs per wave); the packed
+            // kernel costs ~30 us + 6 us per 1000 pairs (tools/p2_crossover.py): it wins on a list that fills less than ~0.37
+            // of a batch (1000 pairs: 36 vs 41 us) and on one that has just spilled into its second batch (5000 pairs: 60 vs
+            // 78 us), ties at 2500 / 8000 and loses from 12 000 on (99 vs 80 us).  ANNCHOR_LEV_P2_MAX forces it for every list
+            // up to that length (0 = never); read per launch.
+            const char *env_p = getenv("ANNCHOR_LEV_P2_MAX");
+            const int pf = c->lev_gl0 > 0 ? std::max(1, 64 / c->lev_gl0) : a.P;
+            const double cap = (double)c->prop.multiProcessorCount * 4.0 * pf;
+            // (long strings only -- four pairs or fewer per k_lev_f wave: with short strings k_lev_f packs up to 16 pairs per
+            // wave and its chains are short already)
+            const bool p2 = env_p ? src.n <= atoll(env_p)
+                                  : (pf <= 4 && ((double)src.n <= 0.37 * cap || ((double)src.n > cap && (double)src.n <= 1.83 * cap)));
+            if (!src.anchor && src.ij && p2 && src.n >= 64 && c->maxlen < 32000) return launch_p2(c, src, d_out, d_RA, d_ncm);
             return launch_f(c, a, src.n, src);
         }
         if (R == 9) R = 1;

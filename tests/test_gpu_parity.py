@@ -131,6 +131,39 @@ def test_levenshtein_kernel_variants_ragged(variant, monkeypatch):
     assert np.array_equal(eng.metric_pairs(few), want[:7])
 
 
+@pytest.mark.parametrize("n_pairs", [70, 1001, 5000])
+def test_levenshtein_short_list_kernel_ragged(monkeypatch, n_pairs):
+    """Short pair lists of long strings take k_lev_p2 (two pairs per wave, each split into a forward and a backward half;
+    pairs of two strings above 512 symbols a wave of their own).  Forced here for every list (ANNCHOR_LEV_P2_MAX) on strings
+    of every interesting length -- empty, one symbol, around the 32-symbol word boundaries and the 512-symbol class boundary,
+    the longest the kernel takes -- including (i, i) pairs and repeated pairs, against the oracle and against k_lev_f."""
+    from annchor_amd import _native
+    from annchor_amd.distances import levenshtein
+
+    rng = np.random.default_rng(33)
+    alphabet = [chr(c) for c in range(60, 120)]
+    lens = list(range(0, 70)) + [95, 96, 97, 127, 128, 129, 255, 256, 257, 300, 480, 511, 512, 513, 544, 640, 1000, 1023, 1024]
+    X = ["".join(rng.choice(alphabet[: rng.integers(2, 60)], n)) for n in lens for _ in range(2)]
+    X += [X[9], X[150], "", ""]
+    nx = len(X)
+    IJ = rng.integers(0, nx, (n_pairs, 2))
+    IJ[:40, 1] = IJ[:40, 0]          # (i, i)
+    IJ[40:50] = IJ[60:70]            # repeats
+    long_ids = np.flatnonzero(np.array([len(s) for s in X]) > 512)
+    both_long = long_ids[: 2 * (len(long_ids) // 2)].reshape(-1, 2)[:8]
+    IJ[60:60 + len(both_long)] = both_long   # both strings above 512 symbols: the unpacked class
+    want = om.PackedStrings(X).pairs(IJ)
+    out = {}
+    for mode in ("1000000", "0"):
+        monkeypatch.setenv("ANNCHOR_LEV_P2_MAX", mode)
+        eng = _native.Engine(0)
+        levenshtein.bind(eng, X)
+        out[mode] = eng.metric_pairs(IJ)
+        eng.close()
+    assert np.array_equal(out["1000000"], want)
+    assert np.array_equal(out["0"], want)
+
+
 def test_levenshtein_anchor_round_kernel_ragged(monkeypatch):
     """The one-to-all launches of the picker run k_lev_a (one pair per wave, the two half-waves walk the two
     halves of the text towards each other, lev = min_i F[i] + B'[m - i]).  Anchor rows for selected anchors of every
