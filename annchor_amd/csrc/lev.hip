@@ -1209,9 +1209,10 @@ __global__ __launch_bounds__(ANN_WAVE) void k_lev_p2(LevArgsP2 aa)
     const LevArgsP2 &a = aa;
     const int lane = threadIdx.x, A = a.alphabet;
     const int n_short = a.cursors[0], n_long = a.cursors[1];
-    const int ws = (n_short + 1) >> 1;                    // waves of the packed class
-    const bool packed = (int)blockIdx.x < ws;
-    if (!packed && (int)blockIdx.x - ws >= n_long) return;
+    const int ws = (n_short + 1) >> 1;                    // tasks of the packed class (two pairs each), then one per long pair
+    // (the class sizes are known on the device only: the grid is the host's upper bound, a wave takes every gridDim-th task)
+    for (int task = blockIdx.x; task < ws + n_long; task += gridDim.x) {
+    const bool packed = task < ws;
     const int GL = packed ? 16 : 32;
     const int slot = lane / GL, w = lane - slot * GL, pair = slot >> 1, half = slot & 1;
     const int LP = packed ? 32 : 64;                      // lanes per pair
@@ -1225,10 +1226,10 @@ __global__ __launch_bounds__(ANN_WAVE) void k_lev_p2(LevArgsP2 aa)
     // ---- this wave's pairs: list positions from the class permutation (short patterns first, long ones from the back)
     int tq[2] = {-1, -1};
     if (packed) {
-        tq[0] = a.perm[2 * blockIdx.x];
-        if (2 * (int)blockIdx.x + 1 < n_short) tq[1] = a.perm[2 * blockIdx.x + 1];
+        tq[0] = a.perm[2 * task];
+        if (2 * task + 1 < n_short) tq[1] = a.perm[2 * task + 1];
     } else {
-        tq[0] = a.perm[n_short + ((int)blockIdx.x - ws)];
+        tq[0] = a.perm[n_short + (task - ws)];
     }
     int si[2] = {0, 0}, sj[2] = {0, 0}, li[2] = {0, 0}, lj[2] = {0, 0};
     int64_t opos[2] = {0, 0};
@@ -1367,6 +1368,8 @@ __global__ __launch_bounds__(ANN_WAVE) void k_lev_p2(LevArgsP2 aa)
         if (a.out) a.out[tq[pq]] = d;
         if (a.RA) { a.RA[opos[pq]] = d; a.ncm[opos[pq]] = 0; }
     }
+    wave_lds_fence();
+    }   // task
 }
 
 
@@ -1391,8 +1394,13 @@ static int launch_p2(annchor_ctx *c, const PairSource &src, double *d_out, doubl
     a.perm = perm; a.cursors = cursors;
     if (lds > 64 * 1024)
         ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev_p2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // (the class sizes stay on the device: one wave per list entry is the upper bound, the surplus waves return at once)
-    k_lev_p2<<<(int)src.n, ANN_WAVE, lds, c->stream>>>(a);
+    // (the class sizes stay on the device; a pair is in the long class only when BOTH its strings have more than 16 words, and
+    // the strings bound at most L (L + 1) / 2 such pairs when the list has no repeats -- a list that has more is still
+    // complete: the waves stride over the tasks)
+    const int64_t L = c->nx - c->lev_nshort;
+    const int64_t long_bound = std::min<int64_t>(src.n, L * (L + 1) / 2);
+    const int64_t grid = std::min<int64_t>(src.n, (src.n + 1) / 2 + long_bound + 8);
+    k_lev_p2<<<(int)grid, ANN_WAVE, lds, c->stream>>>(a);
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
 }
