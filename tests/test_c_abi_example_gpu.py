@@ -10,6 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _compile(tmp_path):
+    import __graft_entry__ as g
+
+    g.build()   # (the in-tree library the example links against)
     exe = str(tmp_path / "c_abi_fit")
     lib = os.path.join(ROOT, "annchor_amd")
     r = subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_fit.c"),
