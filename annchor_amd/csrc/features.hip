@@ -792,24 +792,32 @@ static int select_by_rank_device(annchor_ctx *c, const double *bins, int32_t nbi
     const int64_t total = base[(size_t)nbins];
     ANN_TRY(ann_reserve(c, c->blk_cnt, sizeof(uint32_t) * (size_t)nblocks * nbins));
     ANN_TRY(ann_reserve(c, c->tmp0, sizeof(int32_t) * (size_t)(total + 1)));  // slotmap
-    ANN_TRY(ann_reserve(c, c->tmp1, sizeof(int64_t) * (size_t)(nbins + 1)));  // binbase
-    ANN_TRY(ann_reserve(c, c->stage_in, (sizeof(int32_t) + sizeof(int64_t)) * (size_t)nreq + 64));
     ANN_TRY(ann_reserve(c, c->stage_out, sizeof(int64_t) * (size_t)nreq));
+    // ranks | bin base offsets | bin ids: one staged upload (three small copies were three launches of ~5 us)
+    ANN_TRY(ann_reserve(c, c->stage_in, (sizeof(int32_t) + sizeof(int64_t)) * (size_t)nreq + sizeof(int64_t) * (size_t)(nbins + 1) + 64));
     int64_t *d_ranks = c->stage_in.as<int64_t>();
-    int32_t *d_binof = reinterpret_cast<int32_t *>(d_ranks + nreq);
-    ANN_TRY(ann_h2d(c, d_ranks, ranks, sizeof(int64_t) * (size_t)nreq));
-    ANN_TRY(ann_h2d(c, d_binof, bin_of, sizeof(int32_t) * (size_t)nreq));
-    ANN_TRY(ann_h2d(c, c->tmp1.p, base.data(), sizeof(int64_t) * (size_t)(nbins + 1)));
+    int64_t *d_base = d_ranks + nreq;
+    int32_t *d_binof = reinterpret_cast<int32_t *>(d_base + nbins + 1);
+    {
+        std::vector<unsigned char> stage(sizeof(int64_t) * (size_t)(nreq + nbins + 1) + sizeof(int32_t) * (size_t)nreq);
+        memcpy(stage.data(), ranks, sizeof(int64_t) * (size_t)nreq);
+        memcpy(stage.data() + sizeof(int64_t) * (size_t)nreq, base.data(), sizeof(int64_t) * (size_t)(nbins + 1));
+        memcpy(stage.data() + sizeof(int64_t) * (size_t)(nreq + nbins + 1), bin_of, sizeof(int32_t) * (size_t)nreq);
+        // (in pieces of one pinned ring slot: a larger pageable copy would make ann_h2d wait for the stream)
+        for (size_t o = 0; o < stage.size(); o += annchor_ctx::PIN_SLOT_BYTES)
+            ANN_TRY(ann_h2d(c, reinterpret_cast<unsigned char *>(d_ranks) + o, stage.data() + o,
+                            std::min(stage.size() - o, (size_t)annchor_ctx::PIN_SLOT_BYTES)));
+    }
     ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp0.p, 0xff, sizeof(int32_t) * (size_t)(total + 1), c->stream));
     {
         ProfScope ps(c, "sampler_select_by_rank", (double)n * 18.0);
-        k_scatter_slots<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(d_binof, d_ranks, nreq, c->tmp1.as<int64_t>(),
+        k_scatter_slots<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(d_binof, d_ranks, nreq, d_base,
                                                                      c->tmp0.as<int32_t>(), c->stage_out.as<int64_t>(), zero_flag);
         k_rb_count<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be,
                                                          c->blk_cnt.as<uint32_t>());
         k_rb_scan<<<nbins, 256, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nblocks, nbins);
         k_rb_emit<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be, c->blk_cnt.as<uint32_t>(),
-                                                c->tmp1.as<int64_t>(), c->tmp0.as<int32_t>(), c->stage_out.as<int64_t>());
+                                                d_base, c->tmp0.as<int32_t>(), c->stage_out.as<int64_t>());
     }
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
@@ -915,6 +923,23 @@ extern "C" int annchor_evaluate_samples(annchor_ctx *c, const int64_t *pos, int6
     return ann_d2h(c, sample_y, c->sy.p, sizeof(double) * (size_t)m);
 }
 
+// k_pos_to_i32 + k_gather_features in one launch (the device-resident sampling step)
+__global__ void k_pos_gather(const int64_t *__restrict__ pos, int64_t m, int32_t *__restrict__ out, int32_t *__restrict__ bad,
+                             const double *__restrict__ lb, const double *__restrict__ ub, const double *__restrict__ dad,
+                             const uint8_t *__restrict__ anc, double *__restrict__ feats)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const int64_t p64 = pos[t];
+    if (p64 < 0) *bad = 1;   // a requested (bin, rank) entry was not found
+    const int32_t p = (int32_t)(p64 < 0 ? 0 : p64);
+    out[t] = p;
+    feats[4 * t + 0] = lb[p];
+    feats[4 * t + 1] = ub[p];
+    feats[4 * t + 2] = dad[p];
+    feats[4 * t + 3] = (double)anc[p];
+}
+
 __global__ void k_pos_to_i32(const int64_t *__restrict__ pos, int64_t m, int32_t *__restrict__ out, int32_t *__restrict__ bad)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1008,10 +1033,9 @@ extern "C" int annchor_sample_pairs_device(annchor_ctx *c, const double *bins, i
     ANN_TRY(ann_dev_flags(c));
     int32_t *bad = c->spos.as<int32_t>() + nreq;
     ANN_TRY(select_by_rank_device(c, bins, nbins, counts, bin_of, ranks, nreq, bad));   // positions -> stage_out[0 .. nreq); *bad = 0
-    k_pos_to_i32<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->stage_out.as<int64_t>(), nreq, c->spos.as<int32_t>(), bad);
-    k_gather_features<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), nreq, c->lb.as<double>(),
-                                                                   c->ub.as<double>(), c->dad.as<double>(), c->anc.as<uint8_t>(),
-                                                                   c->sfeat.as<double>());
+    k_pos_gather<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->stage_out.as<int64_t>(), nreq, c->spos.as<int32_t>(), bad,
+                                                              c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>(),
+                                                              c->anc.as<uint8_t>(), c->sfeat.as<double>());
     PairSource src;
     src.ij = c->ij.as<int2>();
     src.idx = c->spos.as<int32_t>();

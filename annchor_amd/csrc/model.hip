@@ -183,12 +183,14 @@ __global__ __launch_bounds__(OLS_T) void k_ols_bins(const double *__restrict__ s
     }
 }
 
-__global__ void k_model_init(DeviceModel *__restrict__ dm, int nb, int32_t *__restrict__ flags)
+struct ModelEdges { double e[MAXBINS + 1]; };
+// (the partition edges arrive as a kernel argument: no upload of their own)
+__global__ void k_model_init(DeviceModel *__restrict__ dm, int nb, ModelEdges ed)
 {
     const int t = threadIdx.x;
     if (t < MAXBINS) { dm->status[t] = 0; dm->rows[t] = 0; }
+    if (t <= nb) dm->reg.e[t] = ed.e[t];
     if (t == 0) { dm->reg.nb = nb; dm->err_status = 0; }
-    (void)flags;
 }
 
 __global__ void k_model_flags(const DeviceModel *__restrict__ dm, int nb, int32_t *__restrict__ flags)
@@ -216,10 +218,10 @@ extern "C" int annchor_fit_regression_device(annchor_ctx *c, const double *bins,
     ANN_TRY(ann_reserve(c, c->ols_scratch, sizeof(double) * 4 * (size_t)m * (size_t)nb));
     ANN_TRY(ann_dev_flags(c));
     DeviceModel *dm = c->model.as<DeviceModel>();
-    double edges[MAXBINS + 1];
-    for (int k = 0; k <= nb; ++k) edges[k] = bins[k];
-    ANN_TRY(ann_h2d(c, &dm->reg.e[0], edges, sizeof(double) * (size_t)(nb + 1)));
-    k_model_init<<<1, 64, 0, c->stream>>>(dm, nb, c->dev_flags.as<int32_t>());
+    ModelEdges ed;
+    for (int k = 0; k <= MAXBINS; ++k) ed.e[k] = k <= nb ? bins[k] : 0.0;
+    static_assert(MAXBINS + 1 <= 128, "one thread per edge");
+    k_model_init<<<1, 128, 0, c->stream>>>(dm, nb, ed);
     {
         ProfScope ps(c, "ols_partitions", (double)m * 40.0 * nb);
         k_ols_bins<<<nb, OLS_T, 0, c->stream>>>(c->sfeat.as<double>(), c->sy.as<double>(), m, dm, c->ols_scratch.as<double>(), m);

@@ -727,14 +727,16 @@ struct CutState {
 };
 
 // The cut values without a host round trip: the selection's answers (keys) into the state the cut kernels read.
-__global__ void k_cut_set_t(CutState *__restrict__ cs, const unsigned long long *__restrict__ prefix, const int *__restrict__ unfinished,
-                            int need1, int need5, int force_redo)
+// (the host's copy of the state arrives as a kernel argument: no upload of its own)
+__global__ void k_cut_set_t(CutState *__restrict__ cs, CutState init, const unsigned long long *__restrict__ prefix,
+                            const int *__restrict__ unfinished, int need1, int need5, int force_redo)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int q = 0;
-    if (need1) cs->t1 = ann_key_asc_inv(prefix[q++]);
-    if (need5) cs->t5 = ann_key_asc_inv(prefix[q++]);
-    cs->sel_unfinished = *unfinished | force_redo;   // (ANNCHOR_CUT_FORCE_REDO: tests walk the second attempt)
+    if (need1) init.t1 = ann_key_asc_inv(prefix[q++]);
+    if (need5) init.t5 = ann_key_asc_inv(prefix[q++]);
+    init.sel_unfinished = *unfinished | force_redo;   // (ANNCHOR_CUT_FORCE_REDO: tests walk the second attempt)
+    *cs = init;
 }
 
 #define TIE_CAP 65536
@@ -1195,10 +1197,10 @@ static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
             int32_t *mout[3];
             for (int q = 0; q < 3; ++q) mout[q] = reinterpret_cast<int32_t *>(c->gn_state.as<char>() + 2 * mask_bytes + q * mout_bytes);
             int32_t *changed = reinterpret_cast<int32_t *>(c->gn_state.as<char>() + 2 * mask_bytes + 3 * mout_bytes);
-            ANN_CHECK_HIP(c, hipMemsetAsync(c->gn_state.p, 0, 2 * mask_bytes + 3 * mout_bytes, c->stream));
+            // (masks, counters and the round flags behind them: one memset)
+            ANN_CHECK_HIP(c, hipMemsetAsync(c->gn_state.p, 0, 2 * mask_bytes + 3 * mout_bytes + sizeof(int32_t) * GN_BATCH, c->stream));
             // first batch of rounds now; whether they settled is looked at in select_stage_finish (the host may do other
             // work in between: annchor_select_prepare)
-            ANN_CHECK_HIP(c, hipMemsetAsync(changed, 0, sizeof(int32_t) * GN_BATCH, c->stream));
             int round = 0;
             for (int q = 0; q < GN_BATCH; ++q, ++round)
                 k_gn_round<<<ann_blocks(nx * 64, 256), 256, 0, c->stream>>>(
@@ -1387,10 +1389,11 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     ANN_TRY(ann_reserve(c, c->next, sizeof(int32_t) * (size_t)(maxn + 1)));
     cs.rk1 = cs.rk5 = ~0ull;
     const CutState cs_in = cs;   // (for a second attempt)
-    ANN_TRY(ann_h2d(c, c->sel_state.p, &cs, sizeof cs));
     if (d_cut_prefix)
-        k_cut_set_t<<<1, 64, 0, c->stream>>>(c->sel_state.as<CutState>(), d_cut_prefix, d_cut_unfinished, !cs.all1, !cs.all5,
+        k_cut_set_t<<<1, 64, 0, c->stream>>>(c->sel_state.as<CutState>(), cs, d_cut_prefix, d_cut_unfinished, !cs.all1, !cs.all5,
                                        getenv("ANNCHOR_CUT_FORCE_REDO") ? 1 : 0);
+    else
+        ANN_TRY(ann_h2d(c, c->sel_state.p, &cs, sizeof cs));
     const bool ties = n_refine > 0 && !(cs.all1 && cs.all5);
     ANN_TRY(ann_reserve(c, c->tie_lists, sizeof(unsigned long long) * 2 * TIE_CAP));
     unsigned long long *tl1 = c->tie_lists.as<unsigned long long>(), *tl5 = tl1 + TIE_CAP;
