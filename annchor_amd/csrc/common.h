@@ -55,6 +55,8 @@ struct annchor_ctx {
     double lev_frac0 = 0.0;
     DevBuf lev_order;        // int32 [nx]: string ids, strings of <= 16 words first (k_lev_a2: two such pairs share a wave)
     int lev_nshort = 0;
+    DevBuf lev_cursors;      // int32 [2][2]: class counters of k_lev_classify, two slots used in turn (a call zeroes the NEXT call's slot)
+    int lev_cursor_epoch = 0;
     DevBuf lev_perm;         // int32 [n] pair positions, short patterns first / long ones from the back; + 2 counters
     DevBuf pts;              // points (f32 or f64) row-major [nx, dim]
     int dim = 0;

@@ -703,8 +703,12 @@ __global__ __launch_bounds__(ANN_WAVE) void k_lev_f(LevArgsR ar)
 // two atomic cursors: the order inside a class is arbitrary, every pair's result is stored by position).
 __global__ __launch_bounds__(256) void k_lev_classify(const int2 *__restrict__ ij, const int32_t *__restrict__ idx,
                                                       const int32_t *__restrict__ slen, int64_t n, int gl0,
-                                                      int32_t *__restrict__ perm, int32_t *__restrict__ cursors)
+                                                      int32_t *__restrict__ perm, int32_t *__restrict__ cursors,
+                                                      int32_t *__restrict__ next_cursors)
 {
+    // (the counters of the NEXT classification are zeroed here: its slot is idle -- whoever read it finished before this
+    // launch started -- and a memset launch per classification is saved)
+    if (blockIdx.x == 0 && threadIdx.x < 2) next_cursors[threadIdx.x] = 0;
     __shared__ int wcnt[2][4];
     __shared__ int base[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -736,6 +740,20 @@ __global__ __launch_bounds__(256) void k_lev_classify(const int2 *__restrict__ i
     }
 }
 
+// the class counters of the next k_lev_classify launch (zeroed by the previous one, or here on first use) and the slot after it
+static int lev_next_cursors(annchor_ctx *c, int32_t **cur, int32_t **nxt)
+{
+    if (!c->lev_cursors.p) {
+        ANN_TRY(ann_reserve(c, c->lev_cursors, 4 * sizeof(int32_t)));
+        ANN_CHECK_HIP(c, hipMemsetAsync(c->lev_cursors.p, 0, 4 * sizeof(int32_t), c->stream));
+        c->lev_cursor_epoch = 0;
+    }
+    *cur = c->lev_cursors.as<int32_t>() + 2 * (c->lev_cursor_epoch & 1);
+    *nxt = c->lev_cursors.as<int32_t>() + 2 * ((c->lev_cursor_epoch + 1) & 1);
+    ++c->lev_cursor_epoch;
+    return ANNCHOR_OK;
+}
+
 static int launch_f(annchor_ctx *c, LevArgs a, int64_t npairs, const PairSource &src)
 {
     const int W = (c->maxlen + 31) / 32 > 0 ? (c->maxlen + 31) / 32 : 1;
@@ -759,10 +777,10 @@ static int launch_f(annchor_ctx *c, LevArgs a, int64_t npairs, const PairSource 
         if (cost < 0.93) {
             ANN_TRY(ann_reserve(c, c->lev_perm, sizeof(int32_t) * ((size_t)npairs + 4)));
             int32_t *perm = c->lev_perm.as<int32_t>();
-            int32_t *cursors = perm + npairs;
-            ANN_CHECK_HIP(c, hipMemsetAsync(cursors, 0, 2 * sizeof(int32_t), c->stream));
+            int32_t *cursors = nullptr, *next_cursors = nullptr;
+            ANN_TRY(lev_next_cursors(c, &cursors, &next_cursors));
             k_lev_classify<<<ann_blocks(npairs, 256), 256, 0, c->stream>>>(src.ij, src.idx, a.slen, npairs, c->lev_gl0, perm,
-                                                                           cursors);
+                                                                           cursors, next_cursors);
             ar.perm = perm; ar.n0 = cursors; ar.GL0 = c->lev_gl0; ar.P0 = P0;
         }
     }
@@ -1388,9 +1406,9 @@ static int launch_p2(annchor_ctx *c, const PairSource &src, double *d_out, doubl
                 c->maxlen, lds);
     ANN_TRY(ann_reserve(c, c->lev_perm, sizeof(int32_t) * (size_t)(src.n + 2)));
     int32_t *perm = c->lev_perm.as<int32_t>();
-    int32_t *cursors = perm + src.n;
-    ANN_CHECK_HIP(c, hipMemsetAsync(cursors, 0, 2 * sizeof(int32_t), c->stream));
-    k_lev_classify<<<ann_blocks(src.n, 256), 256, 0, c->stream>>>(src.ij, src.idx, a.slen, src.n, 16, perm, cursors);
+    int32_t *cursors = nullptr, *next_cursors = nullptr;
+    ANN_TRY(lev_next_cursors(c, &cursors, &next_cursors));
+    k_lev_classify<<<ann_blocks(src.n, 256), 256, 0, c->stream>>>(src.ij, src.idx, a.slen, src.n, 16, perm, cursors, next_cursors);
     a.perm = perm; a.cursors = cursors;
     if (lds > 64 * 1024)
         ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev_p2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

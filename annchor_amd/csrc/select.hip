@@ -1164,11 +1164,7 @@ static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
         ANN_TRY(ann_reserve(c, c->gl_pos, sizeof(int32_t) * (size_t)nx * L * 3));  // pos | other endpoint | twin
         ANN_TRY(ann_reserve(c, c->gl_cnt, sizeof(int32_t) * (size_t)nx));
         ANN_TRY(ann_reserve(c, c->gl_ncomp, sizeof(int32_t) * (size_t)nx));
-        ANN_TRY(ann_reserve(c, c->marked, (size_t)n));
-        ANN_TRY(ann_reserve(c, c->markcount, sizeof(int32_t) * (size_t)nx));
         ANN_TRY(ann_reserve(c, c->gn_err, 64));   // the sweep's error flag has a buffer of its own (tmp2 is re-reserved by annchor_bin_counts)
-        ANN_CHECK_HIP(c, hipMemsetAsync(c->marked.p, 0, (size_t)n, c->stream));
-        ANN_CHECK_HIP(c, hipMemsetAsync(c->markcount.p, 0, sizeof(int32_t) * (size_t)nx, c->stream));
         ANN_CHECK_HIP(c, hipMemsetAsync(c->gn_err.as<int32_t>(), 0, 4, c->stream));   // sweep error flag
         {
             ProfScope ps(c, "guarantee_nmin_lists", (double)n * 26.0);
@@ -1230,6 +1226,12 @@ static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
                                                            twin, c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
                                                            c->RA.as<double>(), c->gn_err.as<int32_t>());
         } else {
+            // (the row walk's own marks: only this route needs them -- two memsets, one of them a byte per pair, used to run
+            // in front of every selection)
+            ANN_TRY(ann_reserve(c, c->marked, (size_t)n));
+            ANN_TRY(ann_reserve(c, c->markcount, sizeof(int32_t) * (size_t)nx));
+            ANN_CHECK_HIP(c, hipMemsetAsync(c->marked.p, 0, (size_t)n, c->stream));
+            ANN_CHECK_HIP(c, hipMemsetAsync(c->markcount.p, 0, sizeof(int32_t) * (size_t)nx, c->stream));
             ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 13.0);
             k_gn_sequential<<<1, 64, 0, c->stream>>>(nx, nmin, L, c->gl_val.as<double>(), c->gl_pos.as<int32_t>(),
                                                     c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(), c->ij.as<int2>(),
