@@ -230,7 +230,8 @@ __global__ void k_min_i32(const int32_t *__restrict__ v, int64_t n, int32_t *__r
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = min(m, s[w]);
-        *out = m;
+        out[0] = m;
+        out[1] = 0; out[2] = 0; out[3] = 0;   // (the 64-bit counter k_count_anchor_pairs adds to lives in out[2..3])
     }
 }
 
@@ -299,8 +300,7 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
         k_row_prefix<<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->Kbits.as<uint64_t>(), nx, kw, c->Kpref.as<uint32_t>(),
                                                             c->deg.as<int32_t>(), c->low.as<int32_t>(),
                                                             c->tmp1.as<int32_t>());
-        ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp2.p, 0, 16, c->stream));
-        k_min_i32<<<1, 1024, 0, c->stream>>>(c->deg.as<int32_t>(), nx, c->tmp2.as<int32_t>());
+        k_min_i32<<<1, 1024, 0, c->stream>>>(c->deg.as<int32_t>(), nx, c->tmp2.as<int32_t>());   // (also zeroes out[1..3]: the counter below)
         if (c->nA > 0 && c->anchorRank.p)
             k_count_anchor_pairs<<<ann_blocks((int64_t)c->nA * nx, 256), 256, 0, c->stream>>>(
                 c->A.as<int32_t>(), c->nA, c->anchorRank.as<int32_t>(), nx, c->Kbits.as<uint64_t>(), kw,

@@ -43,7 +43,8 @@ __device__ __forceinline__ double block_sum(double v, double *sh /*[OLS_T / 64]*
 #define OLS_RCOND 1e-13   // relative singular value below which a direction of a rank-deficient partition is dropped
 // One workgroup per partition.  A: this partition's scratch, double [4][cap] (columns lb, ub, dad, y of its rows).
 __global__ __launch_bounds__(OLS_T) void k_ols_bins(const double *__restrict__ sfeat, const double *__restrict__ sy, int64_t m,
-                                                   DeviceModel *__restrict__ dm, double *__restrict__ scratch, int64_t cap)
+                                                   DeviceModel *__restrict__ dm, double *__restrict__ scratch, int64_t cap,
+                                                   int32_t *__restrict__ flags)
 {
     __shared__ double sh[OLS_T / 64];
     __shared__ int wcnt[OLS_T / 64];
@@ -75,7 +76,10 @@ __global__ __launch_bounds__(OLS_T) void k_ols_bins(const double *__restrict__ s
     const int n = base_sh;
     if (tid == 0) dm->rows[b] = n;
     if (n < 3) {   // fewer rows than columns: the host decides (dgelsd's minimum-norm solution / the reference's error)
-        if (tid == 0) { dm->status[b] = 2; dm->reg.w[b][0] = dm->reg.w[b][1] = dm->reg.w[b][2] = 0.0; dm->reg.c[b] = 0.0; }
+        if (tid == 0) {
+            dm->status[b] = 2; dm->reg.w[b][0] = dm->reg.w[b][1] = dm->reg.w[b][2] = 0.0; dm->reg.c[b] = 0.0;
+            atomicMax(&flags[1], 2);   // (sticky: a partition the device solver does not take)
+        }
         return;
     }
     // ---- centre (sklearn LinearRegression(fit_intercept=True))
@@ -178,6 +182,7 @@ __global__ __launch_bounds__(OLS_T) void k_ols_bins(const double *__restrict__ s
             } else if (smax2 == 0.0) st = 0;   // every feature constant inside the partition: the intercept alone (w = 0)
         }
         dm->status[b] = st;
+        if (st) atomicMax(&flags[1], st);
         dm->reg.w[b][0] = w0; dm->reg.w[b][1] = w1; dm->reg.w[b][2] = w2;
         dm->reg.c[b] = mean[3] - ((mean[0] * w0 + mean[1] * w1) + mean[2] * w2);
     }
@@ -191,15 +196,6 @@ __global__ void k_model_init(DeviceModel *__restrict__ dm, int nb, ModelEdges ed
     if (t < MAXBINS) { dm->status[t] = 0; dm->rows[t] = 0; }
     if (t <= nb) dm->reg.e[t] = ed.e[t];
     if (t == 0) { dm->reg.nb = nb; dm->err_status = 0; }
-}
-
-__global__ void k_model_flags(const DeviceModel *__restrict__ dm, int nb, int32_t *__restrict__ flags)
-{
-    if (threadIdx.x == 0) {
-        int st = 0;
-        for (int b = 0; b < nb; ++b) st = max(st, dm->status[b]);
-        if (st) flags[1] = st;
-    }
 }
 
 // bins: the partition edges (HOST, float64 [nb + 1]); the samples are the ones annchor_sample_pairs_device left on the
@@ -224,9 +220,9 @@ extern "C" int annchor_fit_regression_device(annchor_ctx *c, const double *bins,
     k_model_init<<<1, 128, 0, c->stream>>>(dm, nb, ed);
     {
         ProfScope ps(c, "ols_partitions", (double)m * 40.0 * nb);
-        k_ols_bins<<<nb, OLS_T, 0, c->stream>>>(c->sfeat.as<double>(), c->sy.as<double>(), m, dm, c->ols_scratch.as<double>(), m);
+        k_ols_bins<<<nb, OLS_T, 0, c->stream>>>(c->sfeat.as<double>(), c->sy.as<double>(), m, dm, c->ols_scratch.as<double>(), m,
+                                                c->dev_flags.as<int32_t>());
     }
-    k_model_flags<<<1, 64, 0, c->stream>>>(dm, nb, c->dev_flags.as<int32_t>());
     ANN_CHECK_HIP(c, hipGetLastError());
     c->model_fitted = true; c->model_nb = nb; c->errs_on_device = false;
     return ann_predict_merge_device(c, &dm->reg, first_iteration, is_metric);
@@ -250,15 +246,31 @@ __global__ __launch_bounds__(256) void k_err_count(const double *__restrict__ sf
     if (threadIdx.x == 0) dm->rows[b] = wc[0] + wc[1] + wc[2] + wc[3];   // (rows is reused: the regression is done with it)
 }
 
-__global__ void k_err_ptr(DeviceModel *__restrict__ dm, int nb, int32_t *__restrict__ flags, int64_t *__restrict__ errptr_out)
+// ascending order-preserving key of a double (NaNs last)
+__device__ __forceinline__ unsigned long long err_key(double v) { return ann_key_asc(v); }
+
+__global__ __launch_bounds__(1024) void k_err_sort(const double *__restrict__ sfeat, const double *__restrict__ sy,
+                                                   const double *__restrict__ spred, int64_t m, DeviceModel *__restrict__ dm,
+                                                   double *__restrict__ errs, int nb, int32_t *__restrict__ flags,
+                                                   int64_t *__restrict__ errptr_out)
 {
-    if (threadIdx.x == 0) {
+    extern __shared__ unsigned long long keys[];   // [P2]
+    __shared__ int wcnt[16];
+    __shared__ int base_sh;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double lo = dm->reg.e[b], hi = dm->reg.e[b + 1];
+    const int n = (int)dm->rows[b];
+    // where this partition's list starts: the counts of the partitions before it (k_err_count ran); partition 0's workgroup
+    // also publishes the offsets and the status (what a launch of its own, k_err_ptr, used to do)
+    int64_t my_at = 0;
+    for (int q = 0; q < b; ++q) my_at += dm->rows[q];
+    if (b == 0 && tid == 0) {
         int64_t at = 0;
         int st = 0;
-        for (int b = 0; b < nb; ++b) {
-            dm->errptr[b] = at;
-            errptr_out[b] = at;
-            const int64_t r = dm->rows[b];
+        for (int q = 0; q < nb; ++q) {
+            dm->errptr[q] = at;
+            errptr_out[q] = at;
+            const int64_t r = dm->rows[q];
             if (r == 0) st = max(st, 1);
             if (r > ERR_CAP) st = max(st, 2);
             at += r;
@@ -268,21 +280,6 @@ __global__ void k_err_ptr(DeviceModel *__restrict__ dm, int nb, int32_t *__restr
         dm->err_status = st;
         if (st) flags[2] = st;
     }
-}
-
-// ascending order-preserving key of a double (NaNs last)
-__device__ __forceinline__ unsigned long long err_key(double v) { return ann_key_asc(v); }
-
-__global__ __launch_bounds__(1024) void k_err_sort(const double *__restrict__ sfeat, const double *__restrict__ sy,
-                                                   const double *__restrict__ spred, int64_t m, const DeviceModel *__restrict__ dm,
-                                                   double *__restrict__ errs)
-{
-    extern __shared__ unsigned long long keys[];   // [P2]
-    __shared__ int wcnt[16];
-    __shared__ int base_sh;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double lo = dm->reg.e[b], hi = dm->reg.e[b + 1];
-    const int n = (int)dm->rows[b];
     if (n == 0 || n > ERR_CAP) return;
     int P2 = 1;
     while (P2 < n) P2 <<= 1;
@@ -319,7 +316,7 @@ __global__ __launch_bounds__(1024) void k_err_sort(const double *__restrict__ sf
             }
             __syncthreads();
         }
-    double *out = errs + dm->errptr[b];
+    double *out = errs + my_at;
     for (int t = tid; t < n; t += 1024) out[t] = ann_key_asc_inv(keys[t]);
 }
 
@@ -340,10 +337,10 @@ extern "C" int annchor_fit_errors_device(annchor_ctx *c)
     {
         ProfScope ps(c, "error_residual_lists", (double)m * 32.0 * nb);
         k_err_count<<<nb, 256, 0, c->stream>>>(c->sfeat.as<double>(), m, dm);
-        k_err_ptr<<<1, 64, 0, c->stream>>>(dm, nb, c->dev_flags.as<int32_t>(), c->errptr.as<int64_t>());
         const size_t lds = sizeof(unsigned long long) * ERR_CAP;
         ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_err_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_err_sort<<<nb, 1024, lds, c->stream>>>(c->sfeat.as<double>(), c->sy.as<double>(), c->spred.as<double>(), m, dm, c->errs.as<double>());
+        k_err_sort<<<nb, 1024, lds, c->stream>>>(c->sfeat.as<double>(), c->sy.as<double>(), c->spred.as<double>(), m, dm, c->errs.as<double>(),
+                                                 nb, c->dev_flags.as<int32_t>(), c->errptr.as<int64_t>());
     }
     ANN_CHECK_HIP(c, hipGetLastError());
     c->errs_on_device = true;
