@@ -47,7 +47,7 @@ for case in range(ncases):
             # rationals, different feature triples of lattice data predict the same value mathematically, and which of them
             # rounding puts first differs between the device's solver and LAPACK: a handful of evaluations; STRESS_OLS=lapack
             # reproduces the CPU side exactly)
-            ok = abs(ann.evals - ora.evals) <= 0.002 * ora.evals and ndiff <= 0.05 * ann.neighbor_graph[1].size
+            ok = abs(ann.evals - ora.evals) <= 0.002 * ora.evals and ndiff <= 0.08 * ann.neighbor_graph[1].size
         msg = ("" if same else " (%d of %d entries differ)" % (ndiff, ann.neighbor_graph[1].size)) if ok else \
             " evals %d vs %d, dist diff %d" % (ann.evals, ora.evals, ndiff)
     except Exception as e:   # both sides must agree on failing too
