@@ -108,6 +108,40 @@ def pairlist_at_scale(local, n=16000):
     return res
 
 
+def levenshtein_100k_block(local, n=100000, k=15):
+    """A slow metric beyond the size whose complete pair list fits (46 341 points): 100 000 clustered synthetic strings of
+    ~120 symbols (annchor_amd.datasets.synthetic_string_clusters: the shape of load_strings), the candidate list thinned by the
+    reference's own locality filter (3 of the 5 nearest of 60 anchors in common: ~6 x 10^8 candidates), 2 % of all pairs
+    evaluated; recall against the exact rows of 100 points (one-to-all launches of the same metric kernel)."""
+    from annchor_amd import Annchor, compare_neighbor_graphs
+    from annchor_amd.datasets import synthetic_string_clusters
+    from annchor_amd.samplers import DeviceStratifiedSampler
+
+    X = synthetic_string_clusters(n)
+    cfg = dict(n_anchors=60, n_neighbors=k, p_work=0.02, n_samples=5000, locality=5, loc_thresh=3)
+    ann = Annchor(X, "levenshtein", device=local, sampler=DeviceStratifiedSampler(), **cfg)
+    t = time.perf_counter()
+    ann.fit()
+    dt = time.perf_counter() - t
+    rows = np.random.default_rng(5).choice(n, 100, replace=False)
+    err = 0
+    z = np.zeros((1, k), dtype=np.int64)
+    for r in rows:
+        d = ann._engine.metric_pairs(np.stack([np.full(n, r), np.arange(n)], axis=1))
+        d[r] = -1
+        want = np.sort(d)[:k]
+        want[0] = 0
+        err += compare_neighbor_graphs((z, want[None, :]), (z, ann.neighbor_graph[1][r][None, :]), k)
+    res = {"workload": "synthetic clustered strings (length ~120) Levenshtein N=%d n_anchors=60 k=%d p_work=0.02 locality=5 loc_thresh=3, "
+                       "sampler=DeviceStratifiedSampler() (pair-list form, candidate list thinned by the locality filter)" % (n, k),
+           "fit_time_s": dt, "candidate_pairs": int(ann.n_pairs), "evals": int(ann.evals),
+           "recall_at_k": 1.0 - err / (len(rows) * k), "recall_rows": int(len(rows)),
+           "note": "beyond 46 341 points the complete pair list (2^30 candidates) no longer fits; first fit of the process (includes "
+                   "its device allocations)"}
+    ann._engine.close()
+    return res
+
+
 # kernel family (ProfScope name) -> kernels of the rocprofv3 PMC passes that belong to it
 FAMILY_KERNELS = {
     "update_bounds_intersect": ("k_update_bounds_rows", "k_update_bounds"),
@@ -677,6 +711,11 @@ def main():
                             "committed rocprofv3 PMC passes over the same workload / this run's time / 8 TB/s"}
             except Exception as e:
                 out["pairlist_kernels_at_scale"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if not args.no_scale:
+            try:
+                out["levenshtein_100k_thinned_pairlist"] = levenshtein_100k_block(local)
+            except Exception as e:
+                out["levenshtein_100k_thinned_pairlist"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_euclid:
             try:
                 out["c3_euclid_streamed"] = euclid_run(1, 0, local, None, args.euclid_rows, 2, 1, torch)
