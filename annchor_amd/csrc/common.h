@@ -132,6 +132,7 @@ struct annchor_ctx {
     DevBuf errs, errptr;
     DevBuf ecdf_index;           // per-label bucket index over the sorted errors (long lists)
     DevBuf cptr, cidx, cval;     // computed-neighbour CSR for update_bounds
+    DevBuf c16, cbnd;            // its 2-byte key copy + per-list position of the first key >= 65 536 (k_update_bounds_bits<true>)
     DevBuf tmp0, tmp1, tmp2, tmp3;
     DevBuf scan_tmp;
 

@@ -130,125 +130,231 @@ __global__ __launch_bounds__(256) void k_update_bounds(const int32_t *__restrict
     }
 }
 
-// Row-grouped form.  The lookahead list is in pair-list order, so consecutive entries share their first
-// point i: a workgroup takes a run of UBR_CHUNK entries, keeps "slot of c in L_i" for the current i in an LDS
-// table over all points (uint16: L_i has < 65 536 entries; 2 B x nx <= 60 KB at the pair-list form's largest
-// nx) and every wave streams the other point's list L_j past it -- one coalesced key read and one LDS
-// lookup per entry, values fetched for the matches only -- instead of ~10 dependent binary-search probes for
-// every entry of the shorter list.  The table is rebuilt (old entries cleared, new ones written) when i
-// changes inside the run; any order of the list is handled, the sorted one just rebuilds least.
-// BITMAP = true (point sets too large for the table: nx >= 65 536): "is c in L_i, and where" from a bit per point plus a
-// running count per 64-bit word -- the lists are sorted by the other endpoint, so the slot of c is its rank among the set
-// bits: count[c / 64] + popcount(bits[c / 64] below c).  0.19 B per point instead of 2 (19 KB at 100 000 points).
-#define UBR_CHUNK 256
-template <bool BITMAP>
-__global__ __launch_bounds__(256) void k_update_bounds_rows(const int32_t *__restrict__ next, int64_t nnext,
+// Row-grouped form.  The lookahead list is in pair-list order, so consecutive entries share their first point i: a workgroup takes a
+// run of UBB_CHUNK entries, keeps "is c in L_i, and where" for the current i in LDS and every wave streams the other points' lists
+// L_j past it -- one coalesced key read and one LDS lookup per entry instead of ~10 dependent binary-search probes for every entry
+// of the shorter list.  The table is rebuilt (old entries cleared, new ones written) when i changes inside the run; any order of the
+// list is handled, the sorted one just rebuilds least.
+// This is the second design of the round.  The first kept a uint16 slot per point (or a 64-bit word + running count per 64 points)
+// and paid ~40 vector instructions per list entry -- 64-bit shifts and popcounts, two value loads issued whether the entry matched
+// or not; the PMC pass over the N = 100 000 Levenshtein fit (2.5 x 10^8 lookahead pairs x ~1000-entry lists) showed VALU 77 % busy
+// AND 0.95 TB of HBM reads (4-byte keys), 308 ms.  Well under 1 % of the entries match.  Now:
+//  * membership of the current first point's list is one 8-byte LDS word per 32 points {bits, members before the word}; an entry
+//    costs a key load, one LDS read and a bit test; everything else happens for MATCHES only: a wave-uniform branch on the ballot,
+//    then rank (= slot in the first point's list) and position go to a small ring in LDS;
+//  * the ring is drained 64 matches at a time (two value loads + two LDS atomics on per-pair accumulators; the sums and differences
+//    are non-negative doubles, so their order is the order of their bit patterns and 64-bit integer min / max do) -- the value loads'
+//    latency is paid once per 64 matches, not once per pair;
+//  * a wave takes the metadata of 64 pairs at a time lane-parallel (next -> ij -> cptr: three dependent reads once per 64 pairs
+//    instead of once per pair) and writes the 64 results back together;
+//  * K16: the partner lists' keys are streamed from a 2-byte copy (low 16 bits; the lists are sorted, so the high bit of a key is
+//    "position >= the list's first entry with key >= 65 536", one number per list) -- half the HBM bytes.  Lists start 8-byte aligned
+//    in that copy (list j at (cptr[j] & ~3) + 4 j: no extra offset array), a lane reads four keys per load.  nx <= 131 072; beyond
+//    that the 4-byte keys are read as before.
+#define UBB_THREADS 512  // eight waves share one table (25 KB at 100 000 points: three workgroups = 24 waves per CU)
+#define UBB_WAVES (UBB_THREADS / 64)
+#define UBB_CHUNK 2048   // lookahead entries per workgroup
+#define UBB_RING 128     // pending matches per wave (drained whenever 64 are waiting)
+#define UBB_EPI 512      // list entries per wave step
+#define UBB_GAP 4        // list j of the 2-byte copy starts at (cptr[j] & ~3) + UBB_GAP j: 8-byte aligned, no overlap, no offset array
+#define UBB_K16_WORDS 4096   // K16 table size: entries read past a list's end (masked) still index inside it whatever their 17 bits are
+__device__ __forceinline__ size_t ubb_off16(int64_t c0, int64_t j) { return (size_t)((c0 & ~(int64_t)3) + UBB_GAP * j); }
+
+// the 2-byte key copy + the per-list position of the first key >= 65 536: one wave per list
+__global__ __launch_bounds__(256) void k_comp_narrow(const int64_t *__restrict__ cptr, const int32_t *__restrict__ cidx, int64_t nx,
+                                                    uint16_t *__restrict__ c16, uint32_t *__restrict__ cbnd)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (j >= nx) return;
+    const int64_t c0 = cptr[j], len = cptr[j + 1] - c0;
+    uint16_t *out = c16 + ubb_off16(c0, j);
+    uint32_t below = 0;
+    for (int64_t e = lane; e < len; e += 64) {
+        const int32_t k = cidx[c0 + e];
+        out[e] = (uint16_t)k;
+        below += k < 65536;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) below += __shfl_xor(below, off);
+    if (lane == 0) cbnd[j] = below;
+}
+
+template <bool K16>
+__global__ __launch_bounds__(UBB_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_update_bounds_bits(const int32_t *__restrict__ next, int64_t nnext,
                                                            const int2 *__restrict__ ij, const int64_t *__restrict__ cptr,
-                                                           const int32_t *__restrict__ cidx, const double *__restrict__ cval,
+                                                           const int32_t *__restrict__ cidx, const uint16_t *__restrict__ c16,
+                                                           const uint32_t *__restrict__ cbnd, const double *__restrict__ cval,
                                                            double *__restrict__ lb, double *__restrict__ ub, int nx)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    uint16_t *tab = reinterpret_cast<uint16_t *>(dyn);   // [nx] slot + 1 of point c in the current row's list, 0 = absent
-    const int W = (nx + 63) / 64;
-    unsigned long long *bits = reinterpret_cast<unsigned long long *>(dyn);   // BITMAP: [W] members of the current row's list
-    uint32_t *wcnt = reinterpret_cast<uint32_t *>(bits + W);                  //         [W] members in the words before (32 bits: a
-                                                                              //         point may have 65 536 computed neighbours and more)
+    uint2 *tabw = reinterpret_cast<uint2 *>(dyn);   // [W] {members of the current first point's list in points 32w .. 32w+31, members before}
+    const int W = (nx + 31) / 32;
     __shared__ int first_other;
-    __shared__ uint32_t scan_w[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (BITMAP) { for (int c = threadIdx.x; c < W; c += 256) bits[c] = 0ull; }
-    else for (int c = threadIdx.x; c < (nx + 1) / 2; c += 256) reinterpret_cast<uint32_t *>(tab)[c] = 0u;
-    const int64_t t0 = (int64_t)blockIdx.x * UBR_CHUNK, t1 = min(t0 + UBR_CHUNK, nnext);
+    __shared__ uint32_t scan_w[UBB_WAVES];
+    __shared__ uint2 ring_all[UBB_WAVES][UBB_RING];         // {slot in the first point's list | pair-in-batch << 20, position in cval}
+    __shared__ unsigned long long accU_all[UBB_WAVES][64], accL_all[UBB_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint2 *ring = ring_all[wave];
+    unsigned long long *accU = accU_all[wave], *accL = accL_all[wave];
+    for (int c = threadIdx.x; c < W; c += UBB_THREADS) tabw[c] = make_uint2(0u, 0u);
+    const int64_t t0 = (int64_t)blockIdx.x * UBB_CHUNK, t1 = min(t0 + UBB_CHUNK, nnext);
     int cur = -1;
     int64_t ca0 = 0, ca1 = 0;
+    constexpr int NK = 8;   // keys per lane and step: K16 two 8-byte loads of four keys, else eight 4-byte loads
     __syncthreads();
     for (int64_t t = t0; t < t1;) {
         const int i = ij[next[t]].x;   // uniform
         // how many consecutive entries from t share this first point?
         if (threadIdx.x == 0) first_other = (int)(t1 - t);
         __syncthreads();
-        {
-            const int64_t tt = t + threadIdx.x;
-            if (tt < t1 && ij[next[tt]].x != i) atomicMin(&first_other, (int)threadIdx.x);
-        }
+        for (int64_t tt = t + threadIdx.x; tt < t1; tt += UBB_THREADS)
+            if (ij[next[tt]].x != i) { atomicMin(&first_other, (int)(tt - t)); break; }
         __syncthreads();
         const int seg = first_other;
         if (cur != i) {
-            if (BITMAP) {
-                for (int64_t e = ca0 + threadIdx.x; e < ca1; e += 256) bits[cidx[e] >> 6] = 0ull;
-                ca0 = cptr[i]; ca1 = cptr[i + 1];
-                __syncthreads();
-                for (int64_t e = ca0 + threadIdx.x; e < ca1; e += 256) {
-                    const int cc = cidx[e];
-                    atomicOr(&bits[cc >> 6], 1ull << (cc & 63));
-                }
-                __syncthreads();
-                // exclusive counts per word: blocked over the threads (W / 256 consecutive words each) + a block scan
-                const int per = (W + 255) / 256, w0 = threadIdx.x * per, w1 = min(w0 + per, W);
-                uint32_t mine = 0;
-                for (int w = w0; w < w1; ++w) mine += (uint32_t)__popcll(bits[w]);
-                uint32_t inc = mine;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
-                if (lane == 63) scan_w[wave] = inc;
-                __syncthreads();
-                uint32_t base = inc - mine;
-                for (int w = 0; w < wave; ++w) base += scan_w[w];
-                for (int w = w0; w < w1; ++w) { wcnt[w] = base; base += (uint32_t)__popcll(bits[w]); }
-            } else {
-                for (int64_t e = ca0 + threadIdx.x; e < ca1; e += 256) tab[cidx[e]] = 0;
-                ca0 = cptr[i]; ca1 = cptr[i + 1];
-                __syncthreads();
-                for (int64_t e = ca0 + threadIdx.x; e < ca1; e += 256) tab[cidx[e]] = (uint16_t)(e - ca0 + 1);
+            for (int64_t e = ca0 + threadIdx.x; e < ca1; e += UBB_THREADS) tabw[cidx[e] >> 5] = make_uint2(0u, 0u);
+            ca0 = cptr[i]; ca1 = cptr[i + 1];
+            __syncthreads();
+            for (int64_t e = ca0 + threadIdx.x; e < ca1; e += UBB_THREADS) {
+                const int cc = cidx[e];
+                atomicOr(&tabw[cc >> 5].x, 1u << (cc & 31));
             }
+            __syncthreads();
+            // members before each word: blocked over the threads (consecutive words each) + a block scan
+            const int per = (W + UBB_THREADS - 1) / UBB_THREADS, w0 = threadIdx.x * per, w1 = min(w0 + per, W);
+            uint32_t mine = 0;
+            for (int w = w0; w < w1; ++w) mine += (uint32_t)__popc(tabw[w].x);
+            uint32_t inc = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+            if (lane == 63) scan_w[wave] = inc;
+            __syncthreads();
+            uint32_t base = inc - mine;
+            for (int w = 0; w < wave; ++w) base += scan_w[w];
+            for (int w = w0; w < w1; ++w) { tabw[w].y = base; base += (uint32_t)__popc(tabw[w].x); }
             cur = i;
             __syncthreads();
         }
-        for (int q = wave; q < seg; q += 4) {
-            const int32_t p = next[t + q];
-            const int j = ij[p].y;
-            const int64_t b0 = cptr[j], b1 = cptr[j + 1];
-            double nl = 0.0, nu = INFINITY;
-            // eight key reads in flight per lane (a wave alone keeps 2 KB of the list on its way: one read at a
-            // time the kernel ran at memory latency), then the lookups, then the value reads of the matches
-            constexpr int U = 8;
-            for (int64_t e0 = b0 + lane; e0 < b1; e0 += 64 * U) {
-                int32_t key[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) key[u] = cidx[min(e0 + 64 * u, b1 - 1)];
-                uint32_t sl[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (BITMAP) {
-                        const unsigned long long b = bits[key[u] >> 6];
-                        const int sh = key[u] & 63;
-                        const uint32_t r = wcnt[key[u] >> 6] + (uint32_t)__popcll(b & ((1ull << sh) - 1ull)) + 1u;
-                        sl[u] = (e0 + 64 * u < b1 && ((b >> sh) & 1ull)) ? r : 0u;
-                    } else
-                        sl[u] = e0 + 64 * u < b1 ? (uint32_t)tab[key[u]] : 0u;
-                }
-                // both values of every entry are requested whether it matches or not (clamped addresses, all in
-                // flight together): a branch per entry around two dependent reads serialised eight round trips
-                double x[U], y[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    x[u] = cval[ca0 + (sl[u] ? sl[u] - 1 : 0)];
-                    y[u] = cval[sl[u] ? e0 + 64 * u : ca0];   // no match: a line that is hot anyway (the partner lists miss L2)
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    nu = sl[u] ? fmin(nu, x[u] + y[u]) : nu;
-                    nl = sl[u] ? fmax(nl, fabs(x[u] - y[u])) : nl;
-                }
+        // this wave's pairs of the run: t + wave + UBB_WAVES m, 64 of them (one per lane) at a time
+        for (int m0 = 0; wave + UBB_WAVES * m0 < seg; m0 += 64) {
+            const int q = wave + UBB_WAVES * (m0 + lane);
+            const bool have = q < seg;
+            int32_t p = 0;
+            int64_t c0 = 0;
+            uint32_t len = 0, bd = 0;
+            size_t o16 = 0;
+            if (have) {
+                p = next[t + q];
+                const int j = ij[p].y;
+                c0 = cptr[j];
+                len = (uint32_t)(cptr[j + 1] - c0);
+                if (K16) { bd = cbnd[j]; o16 = ubb_off16(c0, j); }
             }
+            accU[lane] = 0x7FF0000000000000ull;   // +inf
+            accL[lane] = 0ull;
+            const int npair = min(64, (seg - wave - UBB_WAVES * m0 + UBB_WAVES - 1) / UBB_WAVES);
+            int qhead = 0, qcount = 0;   // uniform
+            auto drain = [&](int nf) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < nf) {
+                    const uint2 e = ring[(qhead + lane) & (UBB_RING - 1)];
+                    const double x = cval[ca0 + (e.x & 0xFFFFFu)], y = cval[e.y];
+                    const int kk = (int)(e.x >> 20);
+                    atomicMin(&accU[kk], (unsigned long long)__double_as_longlong(x + y));
+                    atomicMax(&accL[kk], (unsigned long long)__double_as_longlong(fabs(x - y)));
+                }
+                qhead = (qhead + nf) & (UBB_RING - 1);
+                qcount -= nf;
+            };
+            // the partner lists as ONE stream of (pair, offset) steps: the keys of the next step are requested before the current
+            // step is looked at (a wave that waited out every step's read alone kept 1 KB in flight: 2.4 TB/s over the chip)
+            uint32_t kv[NK];   // K16: kv[0..3] = the two 8-byte reads; else eight keys
+            auto request = [&](int kk, uint32_t off, uint32_t *dst) {
+                const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, kk);
+                const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(K16 ? (uint64_t)o16 : (uint64_t)c0), kk);
+                const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((K16 ? (uint64_t)o16 : (uint64_t)c0) >> 32), kk);
+                const size_t base = ((size_t)bhi << 32) | blo;
+                if (K16) {
+                    const uint2 *src = reinterpret_cast<const uint2 *>(c16 + base);   // 8-byte aligned: four keys per lane and read
+                    const uint32_t last4 = (max(L, 1u) - 1) >> 2;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                nu = fmin(nu, __shfl_xor(nu, off));
-                nl = fmax(nl, __shfl_xor(nl, off));
+                    for (int u = 0; u < 2; ++u) {
+                        const uint2 v = src[min((off >> 2) + 64 * u + lane, last4)];
+                        dst[2 * u] = v.x; dst[2 * u + 1] = v.y;
+                    }
+                } else {
+                    const int32_t *src = cidx + base;
+                    const uint32_t last = max(L, 1u) - 1;
+#pragma unroll
+                    for (int u = 0; u < NK; ++u) dst[u] = (uint32_t)src[min(off + 64 * u + lane, last)];
+                }
+            };
+            int kk = 0;
+            uint32_t off = 0;
+            if (npair > 0) request(0, 0u, kv);
+            while (kk < npair) {
+                const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, kk);
+                int nk = kk;
+                uint32_t noff = off + UBB_EPI;
+                if (noff >= L) { nk = kk + 1; noff = 0; }
+                uint32_t nv[NK];
+#pragma unroll
+                for (int u = 0; u < NK; ++u) nv[u] = 0;
+                if (nk < npair) request(nk, noff, nv);
+                const uint32_t c0lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)c0, kk);   // (positions in cval fit 32 bits: <= 2^31 entries)
+                const uint32_t Lr = L > off ? L - off : 0u;   // entries of this list from off on
+                uint32_t key[NK], lpos[NK];   // key and position (relative to off) of the lane's entries
+                if (K16) {
+                    const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)bd, kk);
+                    const uint32_t Br = B > off ? B - off : 0u;   // entries from Br on carry the high bit
+#pragma unroll
+                    for (int u = 0; u < NK; ++u) {
+                        const uint32_t half = kv[u >> 1];
+                        lpos[u] = 4u * (64u * (u >> 2) + lane) + (u & 3);
+                        key[u] = ((u & 1) ? half >> 16 : half & 0xFFFFu) | (lpos[u] >= Br ? 65536u : 0u);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NK; ++u) { key[u] = kv[u]; lpos[u] = 64u * u + lane; }
+                }
+                uint2 w[NK];
+#pragma unroll
+                for (int u = 0; u < NK; ++u) w[u] = tabw[key[u] >> 5];
+                uint32_t mask = 0;
+#pragma unroll
+                for (int u = 0; u < NK; ++u) mask |= (lpos[u] < Lr ? (w[u].x >> (key[u] & 31)) & 1u : 0u) << u;
+                // matches are rare (well under 1 % of the entries): everything below runs for the lanes that have one
+                unsigned long long bal = __ballot(mask != 0);
+                while (bal) {
+                    if (mask) {
+                        const int u = __ffs(mask) - 1;
+                        mask &= mask - 1;
+                        uint32_t k = key[0], lp = lpos[0];
+#pragma unroll
+                        for (int e = 1; e < NK; ++e) { k = u == e ? key[e] : k; lp = u == e ? lpos[e] : lp; }
+                        const uint2 ww = tabw[k >> 5];
+                        const uint32_t rank = ww.y + (uint32_t)__popc(ww.x & ((1u << (k & 31)) - 1u));
+                        const int at = qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                        ring[(qhead + at) & (UBB_RING - 1)] = make_uint2(rank | ((uint32_t)kk << 20), c0lo + off + lp);
+                    }
+                    qcount += __popcll(bal);
+                    if (qcount >= 64) drain(64);
+                    bal = __ballot(mask != 0);
+                }
+#pragma unroll
+                for (int u = 0; u < NK; ++u) kv[u] = nv[u];
+                kk = nk; off = noff;
             }
-            if (lane == 0) {
-                lb[p] = fmax(nl, lb[p]);  // annchor.py:503-510
-                ub[p] = fmin(nu, ub[p]);
+            if (qcount) drain(qcount);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (have) {
+                lb[p] = fmax(__longlong_as_double((long long)accL[lane]), lb[p]);  // annchor.py:503-510
+                ub[p] = fmin(__longlong_as_double((long long)accU[lane]), ub[p]);
             }
         }
         t += seg;
@@ -292,34 +398,38 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
         const char *ube = getenv("ANNCHOR_UPDATE_BOUNDS");   // "pairs" / "rows" force a form (tests compare the two)
         // long lists only: with ~100 entries per list (C2) the table rebuilds and the 512-entry strides cost more
         // than they save (0.28 vs 0.14 ms); at 800 entries per list 12.8 vs 18.1 ms
-        const size_t bm_bytes = (((size_t)nx + 63) / 64) * 12 + 16;   // bit per point + uint32 count per word
-        const bool force_bm = ube && strcmp(ube, "bitmap") == 0;
-        const bool table_ok = nx < 65536 && (((size_t)nx + 1) / 2) * 4 <= 150 * 1024;
-        const bool rows_bitmap = (force_bm || (!ube && avg >= 256.0 && !table_ok)) && bm_bytes <= 150 * 1024;
-        const bool rows_form = rows_bitmap || ((ube ? strcmp(ube, "rows") == 0 : avg >= 256.0) && table_ok);
+        // the row-grouped bit-table form for long lists ("bits16" / "bits32" force it and its key width, "pairs" the wave-per-pair form)
+        const bool k16 = nx <= 131072 && !(ube && strcmp(ube, "bits32") == 0);
+        const size_t bits_bytes = (k16 ? (size_t)UBB_K16_WORDS : ((size_t)nx + 31) / 32) * 8;
+        const bool rows_form = (ube ? strncmp(ube, "bits", 4) == 0 : avg >= 256.0) && bits_bytes <= 112 * 1024 && nx < (1 << 20);
         // Algorithmic bytes (12 B per list entry: key + value).  Wave-per-pair form: both computed lists of every
         // lookahead pair.  Row-grouped form: the lookahead list is in pair order, so a first point's list is read once
         // per RUN of pairs (<= one per point and per workgroup chunk) and only the partners' lists once per pair --
         // pricing it with both lists per pair (round 2) put the fraction above 1.
-        const double runs = (double)std::min<int64_t>(c->nnext, nx + (c->nnext + UBR_CHUNK - 1) / UBR_CHUNK);
+        const int chunk = UBB_CHUNK;
+        const double runs = (double)std::min<int64_t>(c->nnext, nx + (c->nnext + chunk - 1) / chunk);
         const double alg = rows_form ? (double)c->nnext * (avg * 12.0 + 36.0) + runs * avg * 12.0
                                      : (double)c->nnext * (2.0 * avg * 12.0 + 36.0);
         ProfScope ps(c, "update_bounds_intersect", alg);
-        const size_t tab_bytes = (((size_t)nx + 1) / 2) * 4;
-        if (rows_bitmap) {
-            if (bm_bytes > 64 * 1024)
-                ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)bm_bytes));
-            k_update_bounds_rows<true><<<ann_blocks(c->nnext, UBR_CHUNK), 256, bm_bytes, c->stream>>>(
-                c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(),
-                c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>(), (int)nx);
-        } else if (rows_form) {
-            if (tab_bytes > 64 * 1024)
-                ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)tab_bytes));
-            k_update_bounds_rows<false><<<ann_blocks(c->nnext, UBR_CHUNK), 256, tab_bytes, c->stream>>>(
-                c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(),
-                c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>(), (int)nx);
+        if (rows_form) {
+            if (k16) {
+                ANN_TRY(ann_reserve(c, c->c16, sizeof(uint16_t) * (size_t)(total + UBB_GAP * nx + 16)));
+                ANN_TRY(ann_reserve(c, c->cbnd, sizeof(uint32_t) * (size_t)nx));
+                k_comp_narrow<<<ann_blocks(nx * 64, 256), 256, 0, c->stream>>>(c->cptr.as<int64_t>(), c->cidx.as<int32_t>(), nx,
+                                                                             c->c16.as<uint16_t>(), c->cbnd.as<uint32_t>());
+            }
+            if (bits_bytes > 32 * 1024) {
+                if (k16) ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_bits<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bits_bytes));
+                else ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_bits<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bits_bytes));
+            }
+            if (k16)
+                k_update_bounds_bits<true><<<ann_blocks(c->nnext, UBB_CHUNK), UBB_THREADS, bits_bytes, c->stream>>>(
+                    c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(), c->c16.as<uint16_t>(),
+                    c->cbnd.as<uint32_t>(), c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>(), (int)nx);
+            else
+                k_update_bounds_bits<false><<<ann_blocks(c->nnext, UBB_CHUNK), UBB_THREADS, bits_bytes, c->stream>>>(
+                    c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(), nullptr, nullptr,
+                    c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>(), (int)nx);
         } else
         k_update_bounds<<<ann_blocks(c->nnext * 64, 256), 256, 0, c->stream>>>(
             c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(),

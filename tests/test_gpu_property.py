@@ -106,15 +106,15 @@ def test_guarantee_nmin_rounds_equal_the_sequential_sweep(monkeypatch):
         for mode in ("rounds", "sequential"):
             monkeypatch.setenv("ANNCHOR_GN_SWEEP", mode)
             # (the second setting also takes the wave-per-pair form of update_bounds instead of the row-grouped one)
-            monkeypatch.setenv("ANNCHOR_UPDATE_BOUNDS", "rows" if mode == "rounds" else "pairs")
+            monkeypatch.setenv("ANNCHOR_UPDATE_BOUNDS", "bits16" if mode == "rounds" else "pairs")
             ann = Annchor(data, metric, random_seed=3, **kw).fit()
             out[mode] = (ann.neighbor_graph[0].copy(), ann.neighbor_graph[1].copy(), ann.evals, ann.RefineApprox.copy(),
                          ann.not_computed_mask.copy())
         for a, b in zip(out["rounds"], out["sequential"]):
             assert np.array_equal(a, b)
-        # the row-grouped form's bitmap-rank variant (point sets of 65 536 and more take it; forced here)
+        # the row-grouped form reading 4-byte keys (point sets beyond 131 072 take it; forced here)
         monkeypatch.setenv("ANNCHOR_GN_SWEEP", "rounds")
-        monkeypatch.setenv("ANNCHOR_UPDATE_BOUNDS", "bitmap")
+        monkeypatch.setenv("ANNCHOR_UPDATE_BOUNDS", "bits32")
         ann = Annchor(data, metric, random_seed=3, **kw).fit()
         bm = (ann.neighbor_graph[0], ann.neighbor_graph[1], ann.evals, ann.RefineApprox, ann.not_computed_mask)
         for a, b in zip(out["rounds"], bm):

@@ -53,3 +53,34 @@ def test_no_device_memory_leak_across_contexts():
         assert _native.load_library().annchor_device_mem_info(0, __import__("ctypes").byref(f), __import__("ctypes").byref(t)) == 0
         free.append(f.value)
     assert free[-1] >= free[0] - (64 << 20), free
+
+
+def test_update_bounds_forms_agree_beyond_65536_points(monkeypatch):
+    """The three forms of update_bounds on a thinned list of 70 000 points (2.4 x 10^8 candidates, 4 x 10^7 lookahead pairs): the
+    wave-per-pair binary-search form, the row-grouped form on 2-byte keys (the lists' keys >= 65 536 carry their 17th bit through
+    the per-list split position) and on 4-byte keys must leave bit-identical bounds."""
+    from annchor_amd import Annchor
+    from annchor_amd.samplers import DeviceStratifiedSampler
+
+    n = 70000
+    rng = np.random.default_rng(11)
+    cent = rng.standard_normal((40, 6)) * 4
+    X = np.round(cent[rng.integers(0, 40, n)] + rng.standard_normal((n, 6)), 2)
+    cfg = dict(n_anchors=40, n_neighbors=15, p_work=0.01, n_samples=5000, locality=5, loc_thresh=3, random_seed=2)
+    ref = None
+    for form in ("pairs", "bits16", "bits32"):
+        monkeypatch.setenv("ANNCHOR_UPDATE_BOUNDS", form)
+        ann = Annchor(X, "euclidean", sampler=DeviceStratifiedSampler(), **cfg)
+        ann.get_anchors(); ann.get_locality(); ann.get_features(); ann.get_sample(); ann.fit_predict_regression(); ann.fit_predict_errors()
+        ann.select_refine_candidate_pairs(w=0.5, it=0)
+        before = ann.features[:, :2].copy()
+        ann._invalidate("features")
+        ann.update_anchor_points()
+        cur = ann.features[:, :2].copy()
+        ann._engine.close()
+        assert (cur[:, 0] >= before[:, 0]).all() and (cur[:, 1] <= before[:, 1]).all()
+        assert (cur != before).any()
+        if ref is None:
+            ref = cur
+        else:
+            assert np.array_equal(ref, cur), form

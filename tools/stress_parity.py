@@ -3,7 +3,7 @@ integer-grid Euclidean data sets, random configurations.  Not part of the test s
 run on the GPU box: python tools/stress_parity.py [n_cases] [seed].
 With the long-list kernels forced onto these small inputs (all of them read their thresholds from the environment):
   ANNCHOR_TRANSPOSE_MIN=0 ANNCHOR_FEATURES_TILED_MIN=0 ANNCHOR_ROWC_SHRINK_MIN=16 ANNCHOR_ECDF_INDEX_MIN=0 \\
-  ANNCHOR_LEV_CLASS_MIN=64 ANNCHOR_EMIT_TILED_MIN=0 ANNCHOR_UPDATE_BOUNDS=rows ANNCHOR_TIE_CAP=64 python tools/stress_parity.py 24 99"""
+  ANNCHOR_LEV_CLASS_MIN=64 ANNCHOR_EMIT_TILED_MIN=0 ANNCHOR_UPDATE_BOUNDS=bits16 ANNCHOR_TIE_CAP=64 python tools/stress_parity.py 24 99"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
