@@ -30,6 +30,7 @@ _SIGNATURES = {
     "annchor_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "annchor_destroy": (None, [_vp]),
     "annchor_release_parked": (ctypes.c_int, []),
+    "annchor_parked_bytes": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_i64)]),
     "annchor_last_error": (ctypes.c_char_p, [_vp]),
     "annchor_create_error": (ctypes.c_char_p, []),
     "annchor_device_name": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
@@ -181,15 +182,18 @@ PAIR_LIST_MAX = (1 << 30) - 1   # int32 positions into the per-point index (two 
 def pairlist_point_limit(device=0):
     """Largest data set whose complete pair list (nx (nx - 1) / 2 candidates, the worst case of the locality filter) the
     pair-list form will materialise on `device`: bounded by the int32 pair positions (2^30 pairs: 46 341 points) and by
-    80 % of the device's free memory at PAIR_BYTES per pair.  None when no device can be asked."""
-    f, t = _i64(), _i64()
+    80 % of the device's free memory at PAIR_BYTES per pair.  None when no device can be asked.  Blocks this process keeps
+    parked for reuse count as free -- they are NOT handed back to the driver here: a gigabyte request that follows the release
+    of tens of gigabytes waited ~1.5 s on this stack (every second fit of 100 000 points, tools/lev100k_profile.py)."""
+    f, t, parked = _i64(), _i64(), _i64()
     try:
-        load_library().annchor_release_parked()   # (blocks parked for reuse count as free)
         if load_library().annchor_device_mem_info(int(device), ctypes.byref(f), ctypes.byref(t)) != 0:
+            return None
+        if load_library().annchor_parked_bytes(int(device), ctypes.byref(parked)) != 0:
             return None
     except NativeError:
         return None
-    pairs = min(PAIR_LIST_MAX, int(0.8 * f.value / PAIR_BYTES))
+    pairs = min(PAIR_LIST_MAX, int(0.8 * (f.value + parked.value) / PAIR_BYTES))
     return int((1 + (1 + 8 * pairs) ** 0.5) // 2)
 
 

@@ -25,14 +25,27 @@ const char *ann_set_err(annchor_ctx *c, const char *fmt, ...)
 // Large device allocations are kept for the next context instead of going back to the driver: a create / fit / close
 // cycle at 127 M pairs allocates and frees ~10 buffers of 0.5-1 GB, and every fifth cycle or so one of those hipMalloc calls
 // took 1.4 s on this stack (free memory constant; tools/repeat_fit.py) against 2 ms otherwise.  Blocks of 16 MB and more,
-// at most POOL_MAX_BYTES of them per process; a request takes the smallest cached block of its device that is large enough
+// at most pool_cap() bytes of them per process; a request takes the smallest cached block of its device that is large enough
 // and not more than a quarter larger.  annchor_release_parked() returns them to the driver; ANNCHOR_NO_CTX_POOL=1 disables it.
 namespace {
 struct PoolBlock { void *p; size_t bytes; int device; };
 std::mutex g_pool_mu;
 std::vector<PoolBlock> g_pool;
 size_t g_pool_bytes = 0;
-constexpr size_t POOL_MIN_BLOCK = (size_t)16 << 20, POOL_MAX_BYTES = (size_t)48 << 30;
+constexpr size_t POOL_MIN_BLOCK = (size_t)16 << 20;
+// the cap: half of the device's memory (144 GB here; ANNCHOR_CTX_POOL_GB overrides).  One context on a thinned list of 6 x 10^8
+// pairs owns ~60 GB: with the first cap of 48 GB part of it went back to the driver at every close, and one fit in ten waited
+// 4 s for its allocations (tools/lev100k_profile.py)
+size_t pool_cap()
+{
+    static const size_t cap = [] {
+        if (const char *e = getenv("ANNCHOR_CTX_POOL_GB")) return (size_t)atoll(e) << 30;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return (size_t)48 << 30; }
+        return tot / 2;
+    }();
+    return cap;
+}
 bool pool_enabled()
 {
     static const bool off = getenv("ANNCHOR_NO_CTX_POOL") != nullptr;
@@ -59,8 +72,13 @@ void *pool_take(int device, size_t want, size_t *got)
 int ann_dev_alloc(annchor_ctx *c, void **p, size_t want, size_t *got)
 {
     *got = want;
-    if ((*p = pool_take(c->device, want, got)) != nullptr) return ANNCHOR_OK;
+    static const bool trace_all = getenv("ANNCHOR_ALLOC_TRACE") && atoi(getenv("ANNCHOR_ALLOC_TRACE")) >= 2;
+    if ((*p = pool_take(c->device, want, got)) != nullptr) {
+        if (trace_all && want >= POOL_MIN_BLOCK) fprintf(stderr, "  pool hit  %9.1f MB -> block %9.1f MB (pool now %.1f GB)\n", (double)want / 1e6, (double)*got / 1e6, (double)g_pool_bytes / 1e9);
+        return ANNCHOR_OK;
+    }
     *got = want;
+    if (trace_all && want >= POOL_MIN_BLOCK) fprintf(stderr, "  pool MISS %9.1f MB (pool now %.1f GB)\n", (double)want / 1e6, (double)g_pool_bytes / 1e9);
     if (hipMalloc(p, want) == hipSuccess) return ANNCHOR_OK;
     (void)hipGetLastError();
     *p = nullptr;
@@ -81,9 +99,11 @@ void ann_dev_free(annchor_ctx *c, void *p, size_t bytes)
     if (!p) return;
     if (bytes >= POOL_MIN_BLOCK && pool_enabled()) {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        if (g_pool_bytes + bytes <= POOL_MAX_BYTES) {
+        if (g_pool_bytes + bytes <= pool_cap()) {
             g_pool.push_back({p, bytes, c->device});
             g_pool_bytes += bytes;
+            static const bool trace_all = getenv("ANNCHOR_ALLOC_TRACE") && atoi(getenv("ANNCHOR_ALLOC_TRACE")) >= 2;
+            if (trace_all) fprintf(stderr, "  to pool   %9.1f MB\n", (double)bytes / 1e6);
             return;
         }
     }
@@ -442,6 +462,22 @@ extern "C" void annchor_destroy(annchor_ctx *c)
 }
 
 // free the parked context shells (device slabs, pinned staging, streams); contexts in use are untouched
+extern "C" int annchor_parked_bytes(int device, int64_t *bytes)
+{
+    if (!bytes) return ANNCHOR_EINVAL;
+    size_t tot = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_shell_mu);
+        for (const CtxShell &sh : g_shells) if (sh.device == device && sh.arena) tot += sh.arena_size;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (const PoolBlock &pb : g_pool) if (pb.device == device) tot += pb.bytes;
+    }
+    *bytes = (int64_t)tot;
+    return ANNCHOR_OK;
+}
+
 extern "C" int annchor_release_parked(void)
 {
     std::vector<CtxShell> shells;

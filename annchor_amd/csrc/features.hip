@@ -131,6 +131,84 @@ template <int NA_MAX> __global__ __launch_bounds__(256) void k_features_tiled(
     }
 }
 
+// Anchor-outer form of the tiled kernel (round 3).  k_features_tiled walks rows outside and anchors inside: a row's na anchor
+// distances are na scalar loads from na different cache lines (more SGPRs than a wave has, so in several dependent batches), paid
+// for every (row, 64-column word) that holds a pair -- 152 ms on the thinned list of 100 000 points (12 % of the words' bits set,
+// VALU 42 % busy).  Here a wave owns a 32-row x 64-column tile, keeps the tile's 32 + 32 running bounds per lane in registers
+// and walks the ANCHORS outside: per anchor one coalesced read of the columns' distances and the 32 rows' distances as one
+// contiguous scalar read (anchor-major D: consecutive points).  The tile is evaluated densely -- all N^2 / 2 pairs of 100 000 points
+// x 60 anchors are ~30 ms of fp64 vector work -- and tiles without a pair are skipped; the pairs' positions come from the
+// keep bitmap's popcount ranks as before.
+#define FD_ROWS 32
+__global__ __launch_bounds__(256) void k_features_dense(
+    const uint64_t *__restrict__ K, const uint32_t *__restrict__ pref, int kw, const int32_t *__restrict__ low,
+    const int64_t *__restrict__ rowstart, const double *__restrict__ Dt, int64_t nx, int na, const int32_t *__restrict__ cA,
+    double *__restrict__ lb, double *__restrict__ ub, double *__restrict__ dad)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nrb = (int)((nx + FD_ROWS - 1) / FD_ROWS);
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;   // row-block major: the four waves of a workgroup share their rows' reads
+    const int64_t rb = task / kw;
+    const int jb = (int)(task - rb * kw);
+    if (rb >= nrb) return;
+    const int64_t i_lo = rb * FD_ROWS;
+    const int64_t i_base = min(i_lo, nx - FD_ROWS);   // the last block reads the 32 rows that end at nx (rows below i_lo are another block's)
+    if ((int64_t)jb * 64 + 63 <= i_lo) return;        // no column of this word lies right of the block's first row
+    // the rows' bitmap words, list positions and closest anchors, lane-parallel (row = lane & 31)
+    const int64_t ir = i_base + (lane & 31);
+    const uint64_t raw = ir >= i_lo ? K[ir * kw + jb] : 0ull;
+    const int64_t posb = rowstart[ir] + (int64_t)pref[ir * kw + jb] - low[ir];
+    const int cai_r = cA[ir];
+    {
+        uint64_t live = raw;   // the bits that are pairs of this tile: column > row (columns >= nx are never set)
+        const int64_t d = ir - (int64_t)jb * 64;
+        if (d >= 63) live = 0ull;
+        else if (d >= 0) live &= ~((2ull << d) - 1ull);
+        if (!__any(live != 0ull)) return;
+    }
+    const int64_t j = (int64_t)jb * 64 + lane;
+    const int64_t jc = min(j, nx - 1);
+    double l[FD_ROWS], u[FD_ROWS];
+#pragma unroll
+    for (int r = 0; r < FD_ROWS; ++r) { l[r] = 0.0; u[r] = INFINITY; }
+    double dj = Dt[jc];
+    for (int a = 0; a < na; ++a) {
+        const double *__restrict__ di = Dt + (size_t)a * nx + i_base;   // uniform: one contiguous scalar read per anchor
+        double d[FD_ROWS];
+#pragma unroll
+        for (int r = 0; r < FD_ROWS; ++r) d[r] = di[r];
+        const double djn = Dt[(size_t)min(a + 1, na - 1) * nx + jc];   // the next anchor's column distances, ahead of the arithmetic
+#pragma unroll
+        for (int r = 0; r < FD_ROWS; ++r) {
+            // (the machine's max / min directly: fmax / fmin re-canonicalise the running value -- one more instruction per bound,
+            // row and anchor -- for signalling NaNs that distances never are; same results as k_features_tiled's on everything else)
+            const double x = d[r] - dj, y = d[r] + dj;
+            asm("v_max_f64 %0, %0, |%1|" : "+v"(l[r]) : "v"(x));
+            asm("v_min_f64 %0, %0, %1" : "+v"(u[r]) : "v"(y));
+        }
+        dj = djn;
+    }
+    const int caj = cA[jc];
+    const uint32_t raw_lo = (uint32_t)raw, raw_hi = (uint32_t)(raw >> 32);
+    const uint32_t pos_lo = (uint32_t)posb, pos_hi = (uint32_t)((uint64_t)posb >> 32);
+#pragma unroll
+    for (int r = 0; r < FD_ROWS; ++r) {
+        const int64_t i = i_base + r;
+        const uint64_t bits = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)raw_hi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)raw_lo, r);
+        const bool mine = j > i && j < nx && ((bits >> lane) & 1ull);
+        if (!__any(mine)) continue;
+        const int64_t pb = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)pos_hi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)pos_lo, r));
+        const int cai = __builtin_amdgcn_readlane(cai_r, r);
+        if (mine) {
+            const int64_t pos = pb + __popcll(bits & ((1ull << lane) - 1ull));
+            __builtin_nontemporal_store(l[r], &lb[pos]);
+            __builtin_nontemporal_store(u[r], &ub[pos]);
+            __builtin_nontemporal_store((Dt[(size_t)caj * nx + i] + Dt[(size_t)cai * nx + j]) / 2, &dad[pos]);
+        }
+    }
+}
+
 // is_anchor / not_computed of the pairs that touch an anchor (annchor.py:286-289): thread per (anchor, point)
 __global__ void k_anchor_flags(const int32_t *__restrict__ A, int nA, int64_t nx, const uint64_t *__restrict__ K,
                                const uint32_t *__restrict__ pref, int kw, const int32_t *__restrict__ low,
@@ -181,6 +259,16 @@ extern "C" int annchor_compute_features(annchor_ctx *c)
                 k_anchor_flags<<<ann_blocks((int64_t)c->nA * c->nx, 256), 256, 0, c->stream>>>(
                     c->A.as<int32_t>(), c->nA, c->nx, c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), kw, c->low.as<int32_t>(),
                     c->rowstart.as<int64_t>(), c->anc.as<uint8_t>(), c->ncm.as<uint8_t>());
+            static const char *form = getenv("ANNCHOR_FEATURES_FORM");   // "tiled" / "dense" force a form
+            // thinned lists take the anchor-outer form (dense tiles, empty ones skipped); complete lists the row-outer one
+            const double density = (double)c->n / (0.5 * (double)c->nx * (double)(c->nx - 1));
+            const bool dense_form = c->nx >= FD_ROWS && (form ? strcmp(form, "dense") == 0 : density < 0.5);
+            if (dense_form) {
+                const int64_t dtasks = ((c->nx + FD_ROWS - 1) / FD_ROWS) * kw;
+                k_features_dense<<<(unsigned)((dtasks + 3) / 4), 256, 0, c->stream>>>(c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), kw,
+                    c->low.as<int32_t>(), c->rowstart.as<int64_t>(), c->Dt.as<double>(), c->nx, c->na, c->cA.as<int32_t>(),
+                    c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>());
+            } else
             if (c->na <= 8) FT_LAUNCH(8);
             else if (c->na <= 16) FT_LAUNCH(16);
             else if (c->na <= 24) FT_LAUNCH(24);

@@ -67,6 +67,9 @@ void annchor_destroy(annchor_ctx *ctx);
  * next context on the same device (at most four such shells per process).  This frees them; returns
  * how many there were. */
 int annchor_release_parked(void);
+/* Device memory this process holds for reuse on `device` (parked slabs + cached blocks of closed contexts): memory the next context
+ * gets without asking the driver, so it counts as free when a data set is sized (annchor_amd/_native.py: pairlist_point_limit). */
+int annchor_parked_bytes(int device, int64_t *bytes);
 const char *annchor_last_error(annchor_ctx *ctx);
 /* Non-ctx error text for failures of annchor_create itself. */
 const char *annchor_create_error(void);

@@ -27,9 +27,12 @@ def _run(tmp_path, tag, metric, extra):
 @pytest.mark.parametrize("metric", ["euclidean", "levenshtein"])
 def test_large_list_kernels_equal_small_list_kernels(tmp_path, metric):
     a = _run(tmp_path, "small", metric, {})
-    b = _run(tmp_path, "large", metric, LARGE)
+    b = _run(tmp_path, "large", metric, dict(LARGE, ANNCHOR_FEATURES_FORM="tiled"))
+    # (thinned lists take the anchor-outer form of the tiled feature kernel; forced here on the complete list)
+    d = _run(tmp_path, "large_dense", metric, dict(LARGE, ANNCHOR_FEATURES_FORM="dense"))
     for key in ("A", "D", "evals", "n_pairs", "features", "ncm", "RA", "idx", "dist"):
         assert np.array_equal(a[key], b[key]), key
+        assert np.array_equal(a[key], d[key]), key
 
 
 def test_no_device_memory_leak_across_contexts():

@@ -15,6 +15,8 @@ for rep in range(reps):
         ann._engine.prof_enable(1)
     t = time.perf_counter(); ann.fit(); dt = time.perf_counter() - t
     print("rep %d: N=%d pairs=%d fit %.1f ms evals %d" % (rep, n, ann.n_pairs, dt * 1e3, ann.evals))
+    if dt > 1.0:
+        print("   slow rep, host stage ms:", {k: round(v * 1e3, 1) for k, v in ann.timings.items()})
     if rep < reps - 1:
         ann._engine.close()
 print("host stage ms:", {k: round(v * 1e3, 2) for k, v in ann.timings.items()})
