@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_update_bounds(const int32_t *__restrict
 // This is the second design of the round.  The first kept a uint16 slot per point (or a 64-bit word + running count per 64 points)
 // and paid ~40 vector instructions per list entry -- 64-bit shifts and popcounts, two value loads issued whether the entry matched
 // or not; the PMC pass over the N = 100 000 Levenshtein fit (2.5 x 10^8 lookahead pairs x ~1000-entry lists) showed VALU 77 % busy
-// AND 0.95 TB of HBM reads (4-byte keys), 308 ms.  Well under 1 % of the entries match.  Now:
+// AND 0.95 TB of HBM reads (4-byte keys), 308 ms.  Only ~3 % of the entries match.  Now:
 //  * membership of the current first point's list is one 8-byte LDS word per 32 points {bits, members before the word}; an entry
 //    costs a key load, one LDS read and a bit test; everything else happens for MATCHES only: a wave-uniform branch on the ballot,
 //    then rank (= slot in the first point's list) and position go to a small ring in LDS;
@@ -326,7 +326,8 @@ __global__ __launch_bounds__(UBB_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
                 uint32_t mask = 0;
 #pragma unroll
                 for (int u = 0; u < NK; ++u) mask |= (lpos[u] < Lr ? (w[u].x >> (key[u] & 31)) & 1u : 0u) << u;
-                // matches are rare (well under 1 % of the entries): everything below runs for the lanes that have one
+                // matches are few (3 % of the entries at 100 000 clustered strings, ~15 per step; one step in two has none): everything
+                // below runs for the lanes that have one
                 unsigned long long bal = __ballot(mask != 0);
                 while (bal) {
                     if (mask) {
@@ -448,6 +449,7 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
 // (consecutive kept rows = consecutive positions of T): both sides in whole cache lines, where a
 // row kernel gathering its column-like half directly touches one line per 8-byte value.
 #define TR_T 64
+#define TR_SUPER 16   // tiles per side of a super-tile (one XCD's L2 holds its table lines: 2 x 1024 rows x (128 + 64) B)
 template <bool VALUES> __global__ __launch_bounds__(256) void k_transpose_cols(const uint64_t *__restrict__ K, const uint32_t *__restrict__ pref, int kw,
                                                        const int32_t *__restrict__ low, const int64_t *__restrict__ rowstart,
                                                        const int64_t *__restrict__ Iptr, const double *__restrict__ RA,
@@ -456,13 +458,24 @@ template <bool VALUES> __global__ __launch_bounds__(256) void k_transpose_cols(c
 {
     __shared__ double tv[TR_T][TR_T + 1];
     __shared__ uint8_t tm[TR_T][TR_T + 4];
-    // tile (jb, ib), jb <= ib, from the linear block index (row-major over the upper triangle of tiles)
+    // tile (jb, ib), jb <= ib.  The read side walks bitmap / prefix words of 64 ROWS j at word ib, the write side those of 64 rows i at
+    // word jb: a 128-byte line of either table serves 16 (32) neighbouring tiles, but row-major over the triangle the tiles that share
+    // a write-side line are a whole tile row apart -- 38 GB of L2 fills per launch at 100 000 points for 10 GB of values (PMC).  So
+    // tiles go in 16 x 16 SUPER-TILES, and consecutive workgroup ids land on different XCDs (id % 8), each with its own L2, so a
+    // super-tile is dealt to ONE XCD: id -> (xcd = id % 8, k = id / 8), super-tile (k / 256) * 8 + xcd, tile k % 256 inside it.
     const int nb = kw;   // 64-wide blocks per side == bitmap words per row
-    int64_t t = blockIdx.x;
-    int jb = (int)((2.0 * nb + 1.0 - sqrt((2.0 * nb + 1.0) * (2.0 * nb + 1.0) - 8.0 * (double)t)) * 0.5);
-    while ((int64_t)jb * nb - (int64_t)jb * (jb - 1) / 2 > t) --jb;
-    while ((int64_t)(jb + 1) * nb - (int64_t)(jb + 1) * jb / 2 <= t) ++jb;
-    const int ib = jb + (int)(t - ((int64_t)jb * nb - (int64_t)jb * (jb - 1) / 2));
+    const int S = (nb + TR_SUPER - 1) / TR_SUPER;
+    const int64_t k_in = (int64_t)blockIdx.x >> 3;
+    const int64_t st = (k_in / (TR_SUPER * TR_SUPER)) * 8 + (blockIdx.x & 7);
+    if (st >= (int64_t)S * (S + 1) / 2) return;
+    // super-tile (JB, IB), JB <= IB, row-major over the triangle of super-tiles
+    int JB = (int)((2.0 * S + 1.0 - sqrt((2.0 * S + 1.0) * (2.0 * S + 1.0) - 8.0 * (double)st)) * 0.5);
+    while ((int64_t)JB * S - (int64_t)JB * (JB - 1) / 2 > st) --JB;
+    while ((int64_t)(JB + 1) * S - (int64_t)(JB + 1) * JB / 2 <= st) ++JB;
+    const int IB = JB + (int)(st - ((int64_t)JB * S - (int64_t)JB * (JB - 1) / 2));
+    const int w_in = (int)(k_in % (TR_SUPER * TR_SUPER));
+    const int jb = JB * TR_SUPER + w_in / TR_SUPER, ib = IB * TR_SUPER + w_in % TR_SUPER;
+    if (jb > ib || ib >= nb) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // ---- read: wave handles 16 rows j, lane = column i
     const int64_t i_r = (int64_t)ib * 64 + lane;
@@ -489,15 +502,27 @@ template <bool VALUES> __global__ __launch_bounds__(256) void k_transpose_cols(c
         }
     }
     __syncthreads();
-    // ---- write: wave handles 16 columns i, lane = row j
+    // ---- write: wave handles 16 columns i, lane = row j.  The columns' table words first, lane-parallel (lane q reads column q's:
+    // sixteen dependent scalar round trips one after the other were most of a tile's ~18 us), then handed round by readlane
     const int64_t j_w = (int64_t)jb * 64 + lane;
+    uint32_t cb_lo = 0, cb_hi = 0, cd_lo = 0, cd_hi = 0;
+    {
+        const int64_t i = (int64_t)ib * 64 + wave * 16 + (lane & 15);
+        if (i < nx) {
+            const uint64_t bits = K[i * kw + jb];   // symmetric bitmap: bit j of row i <=> pair (j, i) kept
+            const int64_t dst0 = (Iptr[i] - rowstart[i]) + (int64_t)pref[i * kw + jb];
+            cb_lo = (uint32_t)bits; cb_hi = (uint32_t)(bits >> 32);
+            cd_lo = (uint32_t)dst0; cd_hi = (uint32_t)((uint64_t)dst0 >> 32);
+        }
+    }
+#pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int il = wave * 16 + q;
         const int64_t i = (int64_t)ib * 64 + il;
-        if (i >= nx) continue;
-        const uint64_t bits = K[i * kw + jb];   // symmetric bitmap: bit j of row i <=> pair (j, i) kept
-        if (j_w < i && ((bits >> lane) & 1ull)) {
-            const int64_t dst = (Iptr[i] - rowstart[i]) + ((int64_t)pref[i * kw + jb] + __popcll(bits & ((1ull << lane) - 1ull)));
+        const uint64_t bits = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cb_hi, q) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)cb_lo, q);
+        if (j_w < i && ((bits >> lane) & 1ull)) {   // (columns >= nx hold no bits)
+            const int64_t dst0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cd_hi, q) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)cd_lo, q));
+            const int64_t dst = dst0 + __popcll(bits & ((1ull << lane) - 1ull));
             // (this kernel only runs on lists beyond ANN_STREAM_MIN_PAIRS)
             if (VALUES) __builtin_nontemporal_store(tv[lane][il], &T[dst]);
             __builtin_nontemporal_store(tm[lane][il], &Tm[dst]);
@@ -518,7 +543,9 @@ int ann_transpose_columns(annchor_ctx *c, RowSrc *src, bool with_values)
     ANN_TRY(ann_reserve(c, c->colT, sizeof(double) * (size_t)c->n));
     ANN_TRY(ann_reserve(c, c->colM, (size_t)c->n));
     const int kw = (int)((c->nx + 63) / 64);
-    const int64_t tiles = (int64_t)kw * (kw + 1) / 2;
+    // (grid: the triangle of 16 x 16 super-tiles, 256 workgroups each, dealt to the XCDs in groups of eight)
+    const int64_t S = (kw + TR_SUPER - 1) / TR_SUPER;
+    const int64_t tiles = ((S * (S + 1) / 2 + 7) / 8) * 8 * TR_SUPER * TR_SUPER;
     if (!with_values) {
         ProfScope ps(c, "transpose_column_half_mask", (double)c->n * 2.0);
         k_transpose_cols<false><<<(unsigned)tiles, 256, 0, c->stream>>>(c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), kw, c->low.as<int32_t>(),
