@@ -94,6 +94,42 @@ __global__ __launch_bounds__(256) void k_keep_bits(const uint64_t *__restrict__ 
     }
 }
 
+// Column-stationary form for long tables: k_keep_bits spends ~110 vector instructions per (row, word) -- a 64-bit division, the
+// columns' sid / thr re-read for every row -- and was 80 % VALU-busy for 35 ms at 100 000 points (PMC).  Here a wave owns one word's
+// 64 columns (their sid / thr in registers) and walks a block of 64 rows, whose sid / thr are contiguous scalar reads; the 64
+// ballots are collected one per lane and stored together.  The four waves of a workgroup take neighbouring words of
+// the same rows, so their 8-byte stores fill the same lines.
+__global__ __launch_bounds__(256) void k_keep_bits_cols(const uint64_t *__restrict__ sid, const int32_t *__restrict__ thr, int64_t nx, int kw,
+                                                       uint64_t *__restrict__ K)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t rb = task / kw;
+    const int w = (int)(task - rb * kw);
+    if (rb * 64 >= nx) return;
+    const int64_t i0 = rb * 64, i_base = min(i0, nx - 64);   // (the last block re-walks the 64 rows that end at nx; nx >= 64 here)
+    const int64_t j = (int64_t)w * 64 + lane;
+    const bool jv = j < nx;
+    const uint64_t mj = jv ? sid[j] : 0ull;
+    const int tj = jv ? thr[j] : 0;
+    const uint32_t mj_lo = (uint32_t)mj, mj_hi = (uint32_t)(mj >> 32);
+    int r_lo = 0, r_hi = 0;
+#pragma unroll 16
+    for (int r = 0; r < 64; ++r) {
+        const int64_t i = i_base + r;            // uniform
+        const uint64_t mi = sid[i];
+        const int ti = thr[i];
+        const int cc = __popc((uint32_t)mi & mj_lo) + __popc((uint32_t)(mi >> 32) & mj_hi);
+        const bool keep = jv && j != i && cc >= (ti < tj ? ti : tj);
+        const unsigned long long bits = __ballot(keep);
+        r_lo = lane == r ? (int)(uint32_t)bits : r_lo;
+        r_hi = lane == r ? (int)(uint32_t)(bits >> 32) : r_hi;
+    }
+    const int64_t i = i_base + lane;
+    if (i >= i0) K[i * kw + w] = ((uint64_t)(uint32_t)r_hi << 32) | (uint32_t)r_lo;
+}
+
 // one block per row: exclusive prefix of popcounts over the row's words
 __global__ __launch_bounds__(LOC_THREADS) void k_row_prefix(const uint64_t *__restrict__ K, int64_t nx, int kw,
                                                            uint32_t *__restrict__ pref, int32_t *__restrict__ deg,
@@ -172,23 +208,85 @@ __global__ __launch_bounds__(256) void k_emit_pairs(const uint64_t *__restrict__
     }
 }
 
+// Long-table form of the row half (rows_only): k_emit_pairs pays a 64-bit division and four dependent uniform reads for every
+// (row, word) it looks at -- 20 ms on the 1.6 x 10^8 words of 100 000 points, most of them for words that hold no pair.  Here a
+// wave takes RUNS of 64 consecutive words: their bitmap and prefix words come in one lane-parallel read each, empty words cost
+// nothing, the row's three table entries are re-read only when the row changes.
+__global__ __launch_bounds__(256) void k_emit_rows_run(const uint64_t *__restrict__ K, const uint32_t *__restrict__ pref, int64_t nx, int kw,
+                                                      const int32_t *__restrict__ low, const int64_t *__restrict__ rowstart,
+                                                      const int64_t *__restrict__ Iptr, int2 *__restrict__ ij, int32_t *__restrict__ Iidx,
+                                                      int stream)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t wave_count = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t items = nx * kw;
+    int64_t cur_i = -1, rs = 0, ip = 0;
+    int lo = 0;
+    for (int64_t base = wave_global * 64; base < items; base += wave_count * 64) {
+        const int64_t tt = base + lane;
+        const uint64_t bitsL = tt < items ? K[tt] : 0ull;
+        const uint32_t prefL = tt < items ? pref[tt] : 0u;
+        unsigned long long active = __ballot(bitsL != 0ull);
+        if (!active) continue;
+        const int64_t i0 = base / kw;
+        const int w0 = (int)(base - i0 * kw);
+        const uint32_t b_lo = (uint32_t)bitsL, b_hi = (uint32_t)(bitsL >> 32);
+        while (active) {
+            const int q = __ffsll((long long)active) - 1;   // uniform
+            active &= active - 1;
+            int64_t i = i0;
+            int w = w0 + q;
+            while (w >= kw) { w -= kw; ++i; }
+            const uint64_t bits = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)b_hi, q) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)b_lo, q);
+            const uint32_t pr = (uint32_t)__builtin_amdgcn_readlane((int)prefL, q);
+            if (i != cur_i) { cur_i = i; rs = rowstart[i]; lo = low[i]; ip = Iptr[i]; }
+            const int64_t j = (int64_t)w * 64 + lane;
+            if (((bits >> lane) & 1ull) && j > i) {
+                const uint32_t r = pr + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));   // rank of this column among row i's partners
+                const int64_t pos = rs + ((int64_t)r - lo);
+                ann_store(reinterpret_cast<long long *>(ij) + pos, (long long)(((unsigned long long)(uint32_t)j << 32) | (uint32_t)i), stream);
+                ann_store(Iidx + ip + r, (int32_t)pos, stream);
+            }
+        }
+    }
+}
+
 // The column-like half of the CSR index: entry (j, i), j < i, of row i is the position of pair (j, i) in
 // row j's run of the pair list.  Computed where it is cheap -- in row j, from row j's bitmap words -- and
 // handed to row i through a 64 x 64 LDS tile, so that both the bitmap reads and the index writes are whole
 // lines (looked up from row i's side it is two scattered table reads per entry: 4.1 ms at 127 M pairs).
 #define EC_T 64
+#define EC_SUPER 16
 __global__ __launch_bounds__(256) void k_emit_cols(const uint64_t *__restrict__ K, const uint32_t *__restrict__ pref, int kw,
                                                   const int32_t *__restrict__ low, const int64_t *__restrict__ rowstart,
-                                                  const int64_t *__restrict__ Iptr, int64_t nx, int32_t *__restrict__ Iidx, int stream)
+                                                  const int64_t *__restrict__ Iptr, int64_t nx, int32_t *__restrict__ Iidx, int stream, int supertiles)
 {
     __shared__ int32_t tp[EC_T][EC_T + 1];
-    // tile (jb, ib), jb <= ib, from the linear block index (row-major over the upper triangle of tiles)
+    // tile (jb, ib), jb <= ib: 16 x 16 super-tiles dealt to the XCDs (id % 8), as in k_transpose_cols (refine.hip) -- the column
+    // side's table lines are shared by 16 (32) tiles that row-major order ran a whole tile row apart
     const int nb = kw;
-    int64_t t = blockIdx.x;
-    int jb = (int)((2.0 * nb + 1.0 - sqrt((2.0 * nb + 1.0) * (2.0 * nb + 1.0) - 8.0 * (double)t)) * 0.5);
-    while ((int64_t)jb * nb - (int64_t)jb * (jb - 1) / 2 > t) --jb;
-    while ((int64_t)(jb + 1) * nb - (int64_t)(jb + 1) * jb / 2 <= t) ++jb;
-    const int ib = jb + (int)(t - ((int64_t)jb * nb - (int64_t)jb * (jb - 1) / 2));
+    int jb, ib;
+    if (supertiles) {
+        const int S = (nb + EC_SUPER - 1) / EC_SUPER;
+        const int64_t k_in = (int64_t)blockIdx.x >> 3;
+        const int64_t st = (k_in / (EC_SUPER * EC_SUPER)) * 8 + (blockIdx.x & 7);
+        if (st >= (int64_t)S * (S + 1) / 2) return;
+        int JB = (int)((2.0 * S + 1.0 - sqrt((2.0 * S + 1.0) * (2.0 * S + 1.0) - 8.0 * (double)st)) * 0.5);
+        while ((int64_t)JB * S - (int64_t)JB * (JB - 1) / 2 > st) --JB;
+        while ((int64_t)(JB + 1) * S - (int64_t)(JB + 1) * JB / 2 <= st) ++JB;
+        const int IB = JB + (int)(st - ((int64_t)JB * S - (int64_t)JB * (JB - 1) / 2));
+        const int w_in = (int)(k_in % (EC_SUPER * EC_SUPER));
+        jb = JB * EC_SUPER + w_in / EC_SUPER; ib = IB * EC_SUPER + w_in % EC_SUPER;
+        if (jb > ib || ib >= nb) return;
+    } else {
+        // small point sets (the tables are cache-resident anyway): row-major over the upper triangle of tiles, no idle workgroups
+        const int64_t t = blockIdx.x;
+        jb = (int)((2.0 * nb + 1.0 - sqrt((2.0 * nb + 1.0) * (2.0 * nb + 1.0) - 8.0 * (double)t)) * 0.5);
+        while ((int64_t)jb * nb - (int64_t)jb * (jb - 1) / 2 > t) --jb;
+        while ((int64_t)(jb + 1) * nb - (int64_t)(jb + 1) * jb / 2 <= t) ++jb;
+        ib = jb + (int)(t - ((int64_t)jb * nb - (int64_t)jb * (jb - 1) / 2));
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // ---- row side: wave handles 16 rows j, lane = column i
     const int64_t i_r = (int64_t)ib * 64 + lane;
@@ -204,16 +302,26 @@ __global__ __launch_bounds__(256) void k_emit_cols(const uint64_t *__restrict__ 
         tp[wave * 16 + q][lane] = pos;
     }
     __syncthreads();
-    // ---- column side: wave handles 16 columns i, lane = row j
+    // ---- column side: wave handles 16 columns i, lane = row j; the columns' table words lane-parallel first (lane q reads column q's)
     const int64_t j_w = (int64_t)jb * 64 + lane;
+    uint32_t cb_lo = 0, cb_hi = 0, cd_lo = 0, cd_hi = 0;
+    {
+        const int64_t i = (int64_t)ib * 64 + wave * 16 + (lane & 15);
+        if (i < nx) {
+            const uint64_t bits = K[i * kw + jb];   // symmetric bitmap: bit j of row i <=> pair (j, i) kept
+            const int64_t dst0 = Iptr[i] + (int64_t)pref[i * kw + jb];
+            cb_lo = (uint32_t)bits; cb_hi = (uint32_t)(bits >> 32);
+            cd_lo = (uint32_t)dst0; cd_hi = (uint32_t)((uint64_t)dst0 >> 32);
+        }
+    }
+#pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int il = wave * 16 + q;
         const int64_t i = (int64_t)ib * 64 + il;
-        if (i >= nx) continue;
-        const uint64_t bits = K[i * kw + jb];   // symmetric bitmap: bit j of row i <=> pair (j, i) kept
-        if (j_w < i && ((bits >> lane) & 1ull)) {
-            const uint32_t r = pref[i * kw + jb] + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));
-            ann_store(Iidx + Iptr[i] + r, tp[lane][il], stream);
+        const uint64_t bits = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cb_hi, q) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)cb_lo, q);
+        if (j_w < i && ((bits >> lane) & 1ull)) {   // (columns >= nx hold no bits)
+            const int64_t dst0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cd_hi, q) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)cd_lo, q));
+            ann_store(Iidx + dst0 + __popcll(bits & ((1ull << lane) - 1ull)), tp[lane][il], stream);
         }
     }
 }
@@ -295,6 +403,11 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
         ProfScope ps(c, "locality_keep_bitmap", (double)nx * kw * 12.0);
         k_loc_thresh<<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx, loc_thresh, loc_min,
                                                             c->thr.as<int32_t>());
+        static const long long cols_min = getenv("ANNCHOR_KEEP_COLS_MIN") ? atoll(getenv("ANNCHOR_KEEP_COLS_MIN")) : (1ll << 22);   // bitmap words
+        if (nx >= 64 && nx * kw >= cols_min)
+            k_keep_bits_cols<<<(unsigned)((((nx + 63) / 64) * kw + 3) / 4), 256, 0, c->stream>>>(c->sid.as<uint64_t>(), c->thr.as<int32_t>(), nx, kw,
+                                                                                           c->Kbits.as<uint64_t>());
+        else
         k_keep_bits<<<(int)std::min<int64_t>(ann_blocks(nx * kw * 64, 256), (int64_t)c->prop.multiProcessorCount * 32), 256, 0, c->stream>>>(c->sid.as<uint64_t>(), c->thr.as<int32_t>(), nx, kw,
                                                                     c->Kbits.as<uint64_t>());
         k_row_prefix<<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->Kbits.as<uint64_t>(), nx, kw, c->Kpref.as<uint32_t>(),
@@ -329,13 +442,24 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
         ProfScope ps(c, "locality_emit_pairs", (double)n * 16 + (double)nx * kw * 12.0);
         static const long long tiled_min = getenv("ANNCHOR_EMIT_TILED_MIN") ? atoll(getenv("ANNCHOR_EMIT_TILED_MIN")) : 0;
         const int stream_hint = n >= ANN_STREAM_MIN_PAIRS, tiled = n >= tiled_min;
+        static const long long run_min = getenv("ANNCHOR_EMIT_RUN_MIN") ? atoll(getenv("ANNCHOR_EMIT_RUN_MIN")) : (1ll << 22);   // bitmap words
+        if (tiled && nx * kw >= run_min)
+            k_emit_rows_run<<<(int)std::min<int64_t>(ann_blocks(nx * kw, 256), (int64_t)c->prop.multiProcessorCount * 32), 256, 0, c->stream>>>(
+                c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), nx, kw, c->low.as<int32_t>(), c->rowstart.as<int64_t>(),
+                c->Iptr.as<int64_t>(), c->ij.as<int2>(), c->Iidx.as<int32_t>(), stream_hint);
+        else
         k_emit_pairs<<<(int)std::min<int64_t>(ann_blocks(nx * kw * 64, 256), (int64_t)c->prop.multiProcessorCount * 64), 256, 0, c->stream>>>(
             c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), nx, kw, c->low.as<int32_t>(), c->rowstart.as<int64_t>(),
             c->Iptr.as<int64_t>(), c->ij.as<int2>(), c->Iidx.as<int32_t>(), stream_hint, tiled);
-        if (tiled)
-            k_emit_cols<<<(unsigned)((int64_t)kw * (kw + 1) / 2), 256, 0, c->stream>>>(
+        if (tiled) {
+            const int64_t S = (kw + EC_SUPER - 1) / EC_SUPER;
+            static const int super_min = getenv("ANNCHOR_EMIT_SUPER_MIN") ? atoi(getenv("ANNCHOR_EMIT_SUPER_MIN")) : 4 * EC_SUPER;   // bitmap words per row
+            const int supertiles = kw >= super_min;
+            const int64_t grid = supertiles ? ((S * (S + 1) / 2 + 7) / 8) * 8 * EC_SUPER * EC_SUPER : (int64_t)kw * (kw + 1) / 2;
+            k_emit_cols<<<(unsigned)grid, 256, 0, c->stream>>>(
                 c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), kw, c->low.as<int32_t>(), c->rowstart.as<int64_t>(),
-                c->Iptr.as<int64_t>(), nx, c->Iidx.as<int32_t>(), stream_hint);
+                c->Iptr.as<int64_t>(), nx, c->Iidx.as<int32_t>(), stream_hint, supertiles);
+        }
     }
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;

@@ -119,10 +119,17 @@ def levenshtein_100k_block(local, n=100000, k=15):
 
     X = synthetic_string_clusters(n)
     cfg = dict(n_anchors=60, n_neighbors=k, p_work=0.02, n_samples=5000, locality=5, loc_thresh=3)
-    ann = Annchor(X, "levenshtein", device=local, sampler=DeviceStratifiedSampler(), **cfg)
-    t = time.perf_counter()
-    ann.fit()
-    dt = time.perf_counter() - t
+    # two fits: the first of the process also pays for ~50 GB of first-time device allocations (0.01-1.3 s on a fresh box,
+    # depending on what the device was doing before); the second, what a process that fits repeatedly sees, is the one reported
+    first = None
+    for rep in range(2):
+        ann = Annchor(X, "levenshtein", device=local, sampler=DeviceStratifiedSampler(), **cfg)
+        t = time.perf_counter()
+        ann.fit()
+        dt = time.perf_counter() - t
+        if rep == 0:
+            first = dt
+            ann._engine.close()
     rows = np.random.default_rng(5).choice(n, 100, replace=False)
     err = 0
     z = np.zeros((1, k), dtype=np.int64)
@@ -134,10 +141,10 @@ def levenshtein_100k_block(local, n=100000, k=15):
         err += compare_neighbor_graphs((z, want[None, :]), (z, ann.neighbor_graph[1][r][None, :]), k)
     res = {"workload": "synthetic clustered strings (length ~120) Levenshtein N=%d n_anchors=60 k=%d p_work=0.02 locality=5 loc_thresh=3, "
                        "sampler=DeviceStratifiedSampler() (pair-list form, candidate list thinned by the locality filter)" % (n, k),
-           "fit_time_s": dt, "candidate_pairs": int(ann.n_pairs), "evals": int(ann.evals),
+           "fit_time_s": dt, "first_fit_time_s": first, "candidate_pairs": int(ann.n_pairs), "evals": int(ann.evals),
            "recall_at_k": 1.0 - err / (len(rows) * k), "recall_rows": int(len(rows)),
-           "note": "beyond 46 341 points the complete pair list (2^30 candidates) no longer fits; first fit of the process (includes "
-                   "its device allocations)"}
+           "note": "beyond 46 341 points the complete pair list (2^30 candidates) no longer fits; fit_time_s = second fit of the "
+                   "process (device blocks of the first are reused), first_fit_time_s includes the first-time allocations"}
     ann._engine.close()
     return res
 

@@ -1,5 +1,5 @@
 """The kernels that take over on long pair lists (tiled feature kernel, column-half transposes + streamed
-row kernels, second candidate cut, ECDF bucket index, sampled-bracket selection) must give bit-identical state to the small-list
+row kernels, second candidate cut, ECDF bucket index, sampled-bracket selection, run-based / super-tiled pair emission) must give bit-identical state to the small-list
 kernels.  The thresholds are lowered through the environment so that a 3 M-pair list exercises them; each
 setting runs in its own process (the library reads the thresholds once)."""
 import os
@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LARGE = {"ANNCHOR_TRANSPOSE_MIN": "0", "ANNCHOR_FEATURES_TILED_MIN": "0", "ANNCHOR_ROWC_SHRINK_MIN": "16", "ANNCHOR_ECDF_INDEX_MIN": "0",
-         "ANNCHOR_SEL_SAMPLE_MIN": "1"}
+         "ANNCHOR_SEL_SAMPLE_MIN": "1", "ANNCHOR_EMIT_RUN_MIN": "0", "ANNCHOR_KEEP_COLS_MIN": "0", "ANNCHOR_EMIT_SUPER_MIN": "1"}
 
 
 def _run(tmp_path, tag, metric, extra):
