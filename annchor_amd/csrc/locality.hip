@@ -64,6 +64,53 @@ __global__ __launch_bounds__(LOC_THREADS) void k_loc_thresh(const uint64_t *__re
     }
 }
 
+// Register-counter form for small thresholds (loc_thresh <= 8, the usual 1-5): the histogram above funnels nx LDS atomics per
+// row into the handful of bins popcounts of 5-of-60 masks can take -- 19 ms at 100 000 points.  thr = the largest t <= loc_thresh
+// with #{j : shared(i, j) >= t} >= loc_min + 1 (the same cut: the cumulative histogram from the top), so T running counts per
+// thread do, reduced once per row.
+template <int T>
+__global__ __launch_bounds__(LOC_THREADS) void k_loc_thresh_small(const uint64_t *__restrict__ sid, int64_t nx, int loc_min, int32_t *__restrict__ thr)
+{
+    __shared__ uint32_t part[LOC_THREADS / 64][T];
+    const int64_t i = blockIdx.x;
+    const uint64_t mi = sid[i];
+    const uint32_t mi_lo = (uint32_t)mi, mi_hi = (uint32_t)(mi >> 32);
+    uint32_t c[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) c[t] = 0;
+    for (int64_t j0 = threadIdx.x; j0 < nx; j0 += 4 * LOC_THREADS) {
+        uint64_t mj[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mj[e] = sid[min(j0 + e * LOC_THREADS, nx - 1)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int cc = j0 + e * LOC_THREADS < nx ? __popc(mi_lo & (uint32_t)mj[e]) + __popc(mi_hi & (uint32_t)(mj[e] >> 32)) : 0;
+#pragma unroll
+            for (int t = 0; t < T; ++t) c[t] += cc > t;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c[t] += __shfl_xor(c[t], off);
+    }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int t = 0; t < T; ++t) part[threadIdx.x >> 6][t] = c[t];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t lm = loc_min < nx - 1 ? loc_min : nx - 1;
+        int v = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            uint32_t g = 0;   // #{j : shared >= t + 1}
+            for (int w = 0; w < LOC_THREADS / 64; ++w) g += part[w][t];
+            if ((int64_t)g >= lm + 1) v = t + 1;
+        }
+        thr[i] = v;
+    }
+}
+
 // keep bits: wave per (row, 64-column word) item, lane = column -- the 64 sid / thr reads of a word are one
 // line each and the word is the wave's ballot (a thread per word walking its 64 columns read 64 scattered
 // 8-byte pieces per load instruction)
@@ -401,6 +448,14 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
     }
     {
         ProfScope ps(c, "locality_keep_bitmap", (double)nx * kw * 12.0);
+        static const bool hist_form = getenv("ANNCHOR_LOC_THRESH_HIST") != nullptr;   // tests: the histogram form at any threshold
+        if (loc_thresh >= 1 && loc_thresh <= 8 && !hist_form) {
+            switch (loc_thresh) {
+#define LT_CASE(T) case T: k_loc_thresh_small<T><<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx, loc_min, c->thr.as<int32_t>()); break;
+                LT_CASE(1) LT_CASE(2) LT_CASE(3) LT_CASE(4) LT_CASE(5) LT_CASE(6) LT_CASE(7) LT_CASE(8)
+#undef LT_CASE
+            }
+        } else
         k_loc_thresh<<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx, loc_thresh, loc_min,
                                                             c->thr.as<int32_t>());
         static const long long cols_min = getenv("ANNCHOR_KEEP_COLS_MIN") ? atoll(getenv("ANNCHOR_KEEP_COLS_MIN")) : (1ll << 22);   // bitmap words

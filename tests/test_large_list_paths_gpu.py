@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LARGE = {"ANNCHOR_TRANSPOSE_MIN": "0", "ANNCHOR_FEATURES_TILED_MIN": "0", "ANNCHOR_ROWC_SHRINK_MIN": "16", "ANNCHOR_ECDF_INDEX_MIN": "0",
-         "ANNCHOR_SEL_SAMPLE_MIN": "1", "ANNCHOR_EMIT_RUN_MIN": "0", "ANNCHOR_KEEP_COLS_MIN": "0", "ANNCHOR_EMIT_SUPER_MIN": "1"}
+         "ANNCHOR_SEL_SAMPLE_MIN": "1", "ANNCHOR_EMIT_RUN_MIN": "0", "ANNCHOR_LOC_THRESH_HIST": "1", "ANNCHOR_KEEP_COLS_MIN": "0", "ANNCHOR_EMIT_SUPER_MIN": "1"}
 
 
 def _run(tmp_path, tag, metric, extra):
