@@ -17,6 +17,7 @@ import time
 from collections import Counter
 
 import os
+import sys
 
 import numpy as np
 
@@ -242,7 +243,8 @@ class Annchor:
                                  "'cosine', default plugins%s."
                                  % (self.nx, hard_max, PAIRLIST_BITMAP_MAX_POINTS, "" if streamed is not False else " (and streamed != False)"))
             print("Note: %d points is beyond the %d whose complete pair list fits this device; the fit goes on only if the locality "
-                  "filter (locality=%d, loc_thresh=%d) keeps fewer than 2^30 candidate pairs." % (self.nx, hard_max, locality, loc_thresh))
+                  "filter (locality=%d, loc_thresh=%d) keeps fewer than 2^30 candidate pairs." % (self.nx, hard_max, locality, loc_thresh),
+                  file=sys.stderr)
             self._pairlist_hard_max = hard_max = self.nx
         if want_stream:
             from .streamed import StreamedAnnchor

@@ -636,7 +636,23 @@ def cpu_baseline_python_metric(X, local, n=160):
             "graph_equals_device_metric_run": same}
 
 
+_REAL_STDOUT = None
+
+
+def emit(obj):
+    """The ONE JSON line, on the process's original stdout (see main: everything else is sent to stderr)."""
+    out = _REAL_STDOUT or sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def main():
+    # stdout carries the JSON line and nothing else: the library mirrors the reference's print() notices ("Increasing p_work ...",
+    # the note about point sets beyond the complete pair list), so file descriptor 1 is pointed at stderr for the rest of the run
+    global _REAL_STDOUT
+    _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -728,7 +744,7 @@ def main():
                 out["c3_euclid_streamed"] = euclid_run(1, 0, local, None, args.euclid_rows, 2, 1, torch)
             except Exception as e:
                 out["c3_euclid_streamed"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(out), flush=True)
+        emit(out)
         return
 
     if workload == "strings":
@@ -737,7 +753,7 @@ def main():
         st = strings_run(args, args.steps, args.warmup, world, rank, local, dist, torch, all_cpus, affinity)
         if rank == 0:
             st["config"]["baseline_quoted_on"] = quoted
-            print(json.dumps(st), flush=True)
+            emit(st)
         dist.destroy_process_group()
         return
 
@@ -746,8 +762,8 @@ def main():
 
     def bail():
         if rank == 0:
-            print(json.dumps({"metric": "knn_graph_builds_per_s", "value": 0.0, "unit": "graphs/s", "n_gpus": world,
-                              "error": "timed out after %d s" % args.euclid_timeout}), flush=True)
+            emit({"metric": "knn_graph_builds_per_s", "value": 0.0, "unit": "graphs/s", "n_gpus": world,
+                              "error": "timed out after %d s" % args.euclid_timeout})
         os._exit(1)
 
     dog = threading.Timer(args.euclid_timeout, bail)   # a failed rank would leave the others inside a collective forever
@@ -779,7 +795,7 @@ def main():
         if not args.no_cpu_baseline:
             os.sched_setaffinity(0, all_cpus)
             out["cpu_baseline"] = cpu_baseline_euclid(n_per_rank)
-        print(json.dumps(out), flush=True)
+        emit(out)
         return
     # the same workload on ONE GPU, measured in this run by rank 0 while the others wait (strong-scaling reference)
     try:
@@ -825,7 +841,7 @@ def main():
             out["strings_replicas"] = {"error": "%s: %s" % (type(e).__name__, e)}
     dog.cancel()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     dist.destroy_process_group()
 
 

@@ -3,7 +3,8 @@ integer-grid Euclidean data sets, random configurations.  Not part of the test s
 run on the GPU box: python tools/stress_parity.py [n_cases] [seed].
 With the long-list kernels forced onto these small inputs (all of them read their thresholds from the environment):
   ANNCHOR_TRANSPOSE_MIN=0 ANNCHOR_FEATURES_TILED_MIN=0 ANNCHOR_ROWC_SHRINK_MIN=16 ANNCHOR_ECDF_INDEX_MIN=0 \\
-  ANNCHOR_LEV_CLASS_MIN=64 ANNCHOR_EMIT_TILED_MIN=0 ANNCHOR_UPDATE_BOUNDS=bits16 ANNCHOR_TIE_CAP=64 python tools/stress_parity.py 24 99"""
+  ANNCHOR_LEV_CLASS_MIN=64 ANNCHOR_EMIT_TILED_MIN=0 ANNCHOR_UPDATE_BOUNDS=bits16 ANNCHOR_TIE_CAP=64 \\
+  ANNCHOR_EMIT_RUN_MIN=0 ANNCHOR_EMIT_SUPER_MIN=1 ANNCHOR_KEEP_COLS_MIN=0 ANNCHOR_FEATURES_FORM=dense STRESS_LOC_THRESH=1 python tools/stress_parity.py 24 99"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -20,6 +21,8 @@ for case in range(ncases):
                p_work=float(rng.uniform(0.15, 0.5)), random_seed=int(rng.integers(0, 1000)), niters=int(rng.integers(1, 4)),
                locality=int(rng.integers(2, 6)))
     cfg["locality"] = min(cfg["locality"], cfg["n_anchors"])
+    if os.environ.get("STRESS_LOC_THRESH"):   # thinned candidate lists too (the default threshold 1 keeps nearly every pair)
+        cfg["loc_thresh"] = int(rng.integers(1, cfg["locality"] + 1))
     if kind == "strings":
         alpha = list("abcdefgh")[: int(rng.integers(2, 8))]
         base = ["".join(rng.choice(alpha, rng.integers(0, int(rng.integers(20, 300))))) for _ in range(max(n // 2, 2))]
