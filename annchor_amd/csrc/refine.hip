@@ -152,10 +152,9 @@ __global__ __launch_bounds__(256) void k_update_bounds(const int32_t *__restrict
 //    in that copy (list j at (cptr[j] & ~3) + 4 j: no extra offset array), a lane reads four keys per load.  nx <= 131 072; beyond
 //    that the 4-byte keys are read as before.
 #define UBB_THREADS 512  // eight waves share one table (25 KB at 100 000 points: three workgroups = 24 waves per CU)
-#define UBB_WAVES (UBB_THREADS / 64)
 #define UBB_CHUNK 2048   // lookahead entries per workgroup
+#define UBB_CHUNK_SHORT 256
 #define UBB_RING 128     // pending matches per wave (drained whenever 64 are waiting)
-#define UBB_EPI 512      // list entries per wave step
 #define UBB_GAP 4        // list j of the 2-byte copy starts at (cptr[j] & ~3) + UBB_GAP j: 8-byte aligned, no overlap, no offset array
 #define UBB_K16_WORDS 4096   // K16 table size: entries read past a list's end (masked) still index inside it whatever their 17 bits are
 __device__ __forceinline__ size_t ubb_off16(int64_t c0, int64_t j) { return (size_t)((c0 & ~(int64_t)3) + UBB_GAP * j); }
@@ -180,8 +179,11 @@ __global__ __launch_bounds__(256) void k_comp_narrow(const int64_t *__restrict__
     if (lane == 0) cbnd[j] = below;
 }
 
-template <bool K16>
-__global__ __launch_bounds__(UBB_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_update_bounds_bits(const int32_t *__restrict__ next, int64_t nnext,
+// NK = keys per lane and step (K16: NK / 4 eight-byte reads of four keys, else NK four-byte reads), NT threads share a table, CH lookahead
+// entries per workgroup: <8, 512, 2048> for long lists; <2, 256, 256> on 4-byte keys is the variant sized for short lists (C2: ~100
+// entries, 234 pairs per first point), reachable through ANNCHOR_UPDATE_BOUNDS=short only: it does not beat the wave-per-pair form there
+template <bool K16, int NK, int NT, int CH>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 6 : 4, NT == 512 ? 6 : 8))) void k_update_bounds_bits(const int32_t *__restrict__ next, int64_t nnext,
                                                            const int2 *__restrict__ ij, const int64_t *__restrict__ cptr,
                                                            const int32_t *__restrict__ cidx, const uint16_t *__restrict__ c16,
                                                            const uint32_t *__restrict__ cbnd, const double *__restrict__ cval,
@@ -191,38 +193,39 @@ __global__ __launch_bounds__(UBB_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     uint2 *tabw = reinterpret_cast<uint2 *>(dyn);   // [W] {members of the current first point's list in points 32w .. 32w+31, members before}
     const int W = (nx + 31) / 32;
     __shared__ int first_other;
-    __shared__ uint32_t scan_w[UBB_WAVES];
-    __shared__ uint2 ring_all[UBB_WAVES][UBB_RING];         // {slot in the first point's list | pair-in-batch << 20, position in cval}
-    __shared__ unsigned long long accU_all[UBB_WAVES][64], accL_all[UBB_WAVES][64];
+    constexpr int NW = NT / 64, EPI = 64 * NK;
+    static_assert(!K16 || NK % 4 == 0, "2-byte keys come four per read");
+    __shared__ uint32_t scan_w[NW];
+    __shared__ uint2 ring_all[NW][UBB_RING];         // {slot in the first point's list | pair-in-batch << 20, position in cval}
+    __shared__ unsigned long long accU_all[NW][64], accL_all[NW][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint2 *ring = ring_all[wave];
     unsigned long long *accU = accU_all[wave], *accL = accL_all[wave];
-    for (int c = threadIdx.x; c < W; c += UBB_THREADS) tabw[c] = make_uint2(0u, 0u);
-    const int64_t t0 = (int64_t)blockIdx.x * UBB_CHUNK, t1 = min(t0 + UBB_CHUNK, nnext);
+    for (int c = threadIdx.x; c < W; c += NT) tabw[c] = make_uint2(0u, 0u);
+    const int64_t t0 = (int64_t)blockIdx.x * CH, t1 = min(t0 + CH, nnext);
     int cur = -1;
     int64_t ca0 = 0, ca1 = 0;
-    constexpr int NK = 8;   // keys per lane and step: K16 two 8-byte loads of four keys, else eight 4-byte loads
     __syncthreads();
     for (int64_t t = t0; t < t1;) {
         const int i = ij[next[t]].x;   // uniform
         // how many consecutive entries from t share this first point?
         if (threadIdx.x == 0) first_other = (int)(t1 - t);
         __syncthreads();
-        for (int64_t tt = t + threadIdx.x; tt < t1; tt += UBB_THREADS)
+        for (int64_t tt = t + threadIdx.x; tt < t1; tt += NT)
             if (ij[next[tt]].x != i) { atomicMin(&first_other, (int)(tt - t)); break; }
         __syncthreads();
         const int seg = first_other;
         if (cur != i) {
-            for (int64_t e = ca0 + threadIdx.x; e < ca1; e += UBB_THREADS) tabw[cidx[e] >> 5] = make_uint2(0u, 0u);
+            for (int64_t e = ca0 + threadIdx.x; e < ca1; e += NT) tabw[cidx[e] >> 5] = make_uint2(0u, 0u);
             ca0 = cptr[i]; ca1 = cptr[i + 1];
             __syncthreads();
-            for (int64_t e = ca0 + threadIdx.x; e < ca1; e += UBB_THREADS) {
+            for (int64_t e = ca0 + threadIdx.x; e < ca1; e += NT) {
                 const int cc = cidx[e];
                 atomicOr(&tabw[cc >> 5].x, 1u << (cc & 31));
             }
             __syncthreads();
             // members before each word: blocked over the threads (consecutive words each) + a block scan
-            const int per = (W + UBB_THREADS - 1) / UBB_THREADS, w0 = threadIdx.x * per, w1 = min(w0 + per, W);
+            const int per = (W + NT - 1) / NT, w0 = threadIdx.x * per, w1 = min(w0 + per, W);
             uint32_t mine = 0;
             for (int w = w0; w < w1; ++w) mine += (uint32_t)__popc(tabw[w].x);
             uint32_t inc = mine;
@@ -236,9 +239,9 @@ __global__ __launch_bounds__(UBB_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
             cur = i;
             __syncthreads();
         }
-        // this wave's pairs of the run: t + wave + UBB_WAVES m, 64 of them (one per lane) at a time
-        for (int m0 = 0; wave + UBB_WAVES * m0 < seg; m0 += 64) {
-            const int q = wave + UBB_WAVES * (m0 + lane);
+        // this wave's pairs of the run: t + wave + NW m, 64 of them (one per lane) at a time
+        for (int m0 = 0; wave + NW * m0 < seg; m0 += 64) {
+            const int q = wave + NW * (m0 + lane);
             const bool have = q < seg;
             int32_t p = 0;
             int64_t c0 = 0;
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(UBB_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
             }
             accU[lane] = 0x7FF0000000000000ull;   // +inf
             accL[lane] = 0ull;
-            const int npair = min(64, (seg - wave - UBB_WAVES * m0 + UBB_WAVES - 1) / UBB_WAVES);
+            const int npair = min(64, (seg - wave - NW * m0 + NW - 1) / NW);
             int qhead = 0, qcount = 0;   // uniform
             auto drain = [&](int nf) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(UBB_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
                     const uint2 *src = reinterpret_cast<const uint2 *>(c16 + base);   // 8-byte aligned: four keys per lane and read
                     const uint32_t last4 = (max(L, 1u) - 1) >> 2;
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < NK / 4; ++u) {
                         const uint2 v = src[min((off >> 2) + 64 * u + lane, last4)];
                         dst[2 * u] = v.x; dst[2 * u + 1] = v.y;
                     }
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(UBB_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
             while (kk < npair) {
                 const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, kk);
                 int nk = kk;
-                uint32_t noff = off + UBB_EPI;
+                uint32_t noff = off + EPI;
                 if (noff >= L) { nk = kk + 1; noff = 0; }
                 uint32_t nv[NK];
 #pragma unroll
@@ -399,20 +402,32 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
         const char *ube = getenv("ANNCHOR_UPDATE_BOUNDS");   // "pairs" / "rows" force a form (tests compare the two)
         // long lists only: with ~100 entries per list (C2) the table rebuilds and the 512-entry strides cost more
         // than they save (0.28 vs 0.14 ms); at 800 entries per list 12.8 vs 18.1 ms
-        // the row-grouped bit-table form for long lists ("bits16" / "bits32" force it and its key width, "pairs" the wave-per-pair form)
-        const bool k16 = nx <= 131072 && !(ube && strcmp(ube, "bits32") == 0);
+        // the row-grouped bit-table form ("bits16" / "bits32" / "short" force a variant, "pairs" the wave-per-pair form): long lists on
+        // 2-byte keys (4-byte beyond 131 072 points), 512-entry steps; short lists (C2: ~100 entries) on 4-byte keys, 128-entry steps
+        const bool force_short = ube && strcmp(ube, "short") == 0;
+        const bool long_form = ube ? strncmp(ube, "bits", 4) == 0 : avg >= 256.0;
+        // (measured at C2 -- 375 000 pairs, ~100-entry lists: short 156 us, wave-per-pair 141 us; N = 3000: 0.34 vs 0.22 ms -- ~100 vector
+        // instructions per pair either way, and the wave-per-pair form has 64 x the waves in flight: short lists keep it)
+        const bool short_form = force_short;
+        const bool k16 = long_form && nx <= 131072 && !(ube && strcmp(ube, "bits32") == 0);
         const size_t bits_bytes = (k16 ? (size_t)UBB_K16_WORDS : ((size_t)nx + 31) / 32) * 8;
-        const bool rows_form = (ube ? strncmp(ube, "bits", 4) == 0 : avg >= 256.0) && bits_bytes <= 112 * 1024 && nx < (1 << 20);
+        const bool rows_form = (long_form || short_form) && bits_bytes <= 112 * 1024 && nx < (1 << 20);
         // Algorithmic bytes (12 B per list entry: key + value).  Wave-per-pair form: both computed lists of every
         // lookahead pair.  Row-grouped form: the lookahead list is in pair order, so a first point's list is read once
         // per RUN of pairs (<= one per point and per workgroup chunk) and only the partners' lists once per pair --
         // pricing it with both lists per pair (round 2) put the fraction above 1.
-        const int chunk = UBB_CHUNK;
+        const int chunk = long_form ? UBB_CHUNK : UBB_CHUNK_SHORT;
         const double runs = (double)std::min<int64_t>(c->nnext, nx + (c->nnext + chunk - 1) / chunk);
         const double alg = rows_form ? (double)c->nnext * (avg * 12.0 + 36.0) + runs * avg * 12.0
                                      : (double)c->nnext * (2.0 * avg * 12.0 + 36.0);
         ProfScope ps(c, "update_bounds_intersect", alg);
-        if (rows_form) {
+#define UBB_ARGS c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(), k16 ? c->c16.as<uint16_t>() : nullptr, \
+                 k16 ? c->cbnd.as<uint32_t>() : nullptr, c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>(), (int)nx
+        if (rows_form && !long_form) {
+            if (bits_bytes > 32 * 1024)
+                ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_bits<false, 2, 256, UBB_CHUNK_SHORT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bits_bytes));
+            k_update_bounds_bits<false, 2, 256, UBB_CHUNK_SHORT><<<ann_blocks(c->nnext, UBB_CHUNK_SHORT), 256, bits_bytes, c->stream>>>(UBB_ARGS);
+        } else if (rows_form) {
             if (k16) {
                 ANN_TRY(ann_reserve(c, c->c16, sizeof(uint16_t) * (size_t)(total + UBB_GAP * nx + 16)));
                 ANN_TRY(ann_reserve(c, c->cbnd, sizeof(uint32_t) * (size_t)nx));
@@ -420,18 +435,13 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
                                                                              c->c16.as<uint16_t>(), c->cbnd.as<uint32_t>());
             }
             if (bits_bytes > 32 * 1024) {
-                if (k16) ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_bits<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bits_bytes));
-                else ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_bits<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bits_bytes));
+                if (k16) ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_bits<true, 8, UBB_THREADS, UBB_CHUNK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bits_bytes));
+                else ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_bits<false, 8, UBB_THREADS, UBB_CHUNK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bits_bytes));
             }
-            if (k16)
-                k_update_bounds_bits<true><<<ann_blocks(c->nnext, UBB_CHUNK), UBB_THREADS, bits_bytes, c->stream>>>(
-                    c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(), c->c16.as<uint16_t>(),
-                    c->cbnd.as<uint32_t>(), c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>(), (int)nx);
-            else
-                k_update_bounds_bits<false><<<ann_blocks(c->nnext, UBB_CHUNK), UBB_THREADS, bits_bytes, c->stream>>>(
-                    c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(), nullptr, nullptr,
-                    c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>(), (int)nx);
+            if (k16) k_update_bounds_bits<true, 8, UBB_THREADS, UBB_CHUNK><<<ann_blocks(c->nnext, UBB_CHUNK), UBB_THREADS, bits_bytes, c->stream>>>(UBB_ARGS);
+            else k_update_bounds_bits<false, 8, UBB_THREADS, UBB_CHUNK><<<ann_blocks(c->nnext, UBB_CHUNK), UBB_THREADS, bits_bytes, c->stream>>>(UBB_ARGS);
         } else
+#undef UBB_ARGS
         k_update_bounds<<<ann_blocks(c->nnext * 64, 256), 256, 0, c->stream>>>(
             c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(),
             c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>());

@@ -114,11 +114,12 @@ def test_guarantee_nmin_rounds_equal_the_sequential_sweep(monkeypatch):
             assert np.array_equal(a, b)
         # the row-grouped form reading 4-byte keys (point sets beyond 131 072 take it; forced here)
         monkeypatch.setenv("ANNCHOR_GN_SWEEP", "rounds")
-        monkeypatch.setenv("ANNCHOR_UPDATE_BOUNDS", "bits32")
-        ann = Annchor(data, metric, random_seed=3, **kw).fit()
-        bm = (ann.neighbor_graph[0], ann.neighbor_graph[1], ann.evals, ann.RefineApprox, ann.not_computed_mask)
-        for a, b in zip(out["rounds"], bm):
-            assert np.array_equal(a, b)
+        for form in ("bits32", "short"):   # ("short": 128-entry steps, 256-pair chunks)
+            monkeypatch.setenv("ANNCHOR_UPDATE_BOUNDS", form)
+            ann = Annchor(data, metric, random_seed=3, **kw).fit()
+            bm = (ann.neighbor_graph[0], ann.neighbor_graph[1], ann.evals, ann.RefineApprox, ann.not_computed_mask)
+            for a, b in zip(out["rounds"], bm):
+                assert np.array_equal(a, b), form
 
 
 def test_select_prepare_is_equivalent_and_voided_by_state_changes():
