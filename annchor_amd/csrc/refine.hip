@@ -189,18 +189,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
                                                            const uint32_t *__restrict__ cbnd, const double *__restrict__ cval,
                                                            double *__restrict__ lb, double *__restrict__ ub, int nx)
 {
+    // all of the workgroup's LDS is the dynamic block, the table FIRST: its byte offsets are then plain functions of the key bits
+    // (no base to add per lookup).  [TW] table, then per wave the ring and the two accumulator rows, then the scan / run scratch
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    uint2 *tabw = reinterpret_cast<uint2 *>(dyn);   // [W] {members of the current first point's list in points 32w .. 32w+31, members before}
+    uint2 *tabw = reinterpret_cast<uint2 *>(dyn);   // [TW] {members of the current first point's list in points 32w .. 32w+31, members before}
     const int W = (nx + 31) / 32;
-    __shared__ int first_other;
     constexpr int NW = NT / 64, EPI = 64 * NK;
     static_assert(!K16 || NK % 4 == 0, "2-byte keys come four per read");
-    __shared__ uint32_t scan_w[NW];
-    __shared__ uint2 ring_all[NW][UBB_RING];         // {slot in the first point's list | pair-in-batch << 20, position in cval}
-    __shared__ unsigned long long accU_all[NW][64], accL_all[NW][64];
+    const int TW = K16 ? UBB_K16_WORDS : W;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint2 *ring = ring_all[wave];
-    unsigned long long *accU = accU_all[wave], *accL = accL_all[wave];
+    unsigned char *after = dyn + (size_t)TW * 8;
+    uint2 *ring = reinterpret_cast<uint2 *>(after) + wave * UBB_RING;   // {slot in the first point's list | pair-in-batch << 20, position in cval}
+    unsigned long long *accU = reinterpret_cast<unsigned long long *>(after + NW * UBB_RING * 8) + wave * 64;
+    unsigned long long *accL = reinterpret_cast<unsigned long long *>(after + NW * UBB_RING * 8 + NW * 64 * 8) + wave * 64;
+    uint32_t *scan_w = reinterpret_cast<uint32_t *>(after + NW * UBB_RING * 8 + 2 * NW * 64 * 8);
+    int &first_other = *reinterpret_cast<int *>(scan_w + NW);
     for (int c = threadIdx.x; c < W; c += NT) tabw[c] = make_uint2(0u, 0u);
     const int64_t t0 = (int64_t)blockIdx.x * CH, t1 = min(t0 + CH, nnext);
     int cur = -1;
@@ -310,25 +313,41 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
                 const uint32_t c0lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)c0, kk);   // (positions in cval fit 32 bits: <= 2^31 entries)
                 const uint32_t Lr = L > off ? L - off : 0u;   // entries of this list from off on
                 uint32_t key[NK], lpos[NK];   // key and position (relative to off) of the lane's entries
+                uint2 w[NK];
+                uint32_t mask = 0;
                 if (K16) {
                     const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)bd, kk);
                     const uint32_t Br = B > off ? B - off : 0u;   // entries from Br on carry the high bit
+                    // the table word's byte offset straight from the packed half (bits 5..15 of the key -> bits 3..13, the high bit
+                    // -> 16 384), the tested bit from its low five bits; which of the lane's entries exist is ONE mask per step (the
+                    // lane's entries of a read are four consecutive positions), not a compare per entry
+                    uint32_t bitidx[NK];
 #pragma unroll
                     for (int u = 0; u < NK; ++u) {
                         const uint32_t half = kv[u >> 1];
                         lpos[u] = 4u * (64u * (u >> 2) + lane) + (u & 3);
-                        key[u] = ((u & 1) ? half >> 16 : half & 0xFFFFu) | (lpos[u] >= Br ? 65536u : 0u);
+                        const uint32_t at = (((u & 1) ? half >> 18 : half >> 2) & 0x3FF8u) | (lpos[u] >= Br ? 16384u : 0u);
+                        w[u] = *reinterpret_cast<const uint2 *>(dyn + at);
+                        bitidx[u] = (u & 1) ? half >> 16 : half;
+                        key[u] = 0;   // (rebuilt for the matches only, below)
                     }
+                    uint32_t vm = 0;
+#pragma unroll
+                    for (int g = 0; g < NK / 4; ++g) {
+                        const int nv = min(max((int)Lr - (int)(4u * (64u * g + lane)), 0), 4);
+                        vm |= ((1u << nv) - 1u) << (4 * g);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NK; ++u) mask |= __builtin_amdgcn_ubfe(w[u].x, bitidx[u], 1u) << u;   // (v_bfe_u32 takes the low five bits of the offset)
+                    mask &= vm;
                 } else {
 #pragma unroll
                     for (int u = 0; u < NK; ++u) { key[u] = kv[u]; lpos[u] = 64u * u + lane; }
+#pragma unroll
+                    for (int u = 0; u < NK; ++u) w[u] = tabw[key[u] >> 5];
+#pragma unroll
+                    for (int u = 0; u < NK; ++u) mask |= (lpos[u] < Lr ? (w[u].x >> (key[u] & 31)) & 1u : 0u) << u;
                 }
-                uint2 w[NK];
-#pragma unroll
-                for (int u = 0; u < NK; ++u) w[u] = tabw[key[u] >> 5];
-                uint32_t mask = 0;
-#pragma unroll
-                for (int u = 0; u < NK; ++u) mask |= (lpos[u] < Lr ? (w[u].x >> (key[u] & 31)) & 1u : 0u) << u;
                 // matches are few (3 % of the entries at 100 000 clustered strings, ~15 per step; one step in two has none): everything
                 // below runs for the lanes that have one
                 unsigned long long bal = __ballot(mask != 0);
@@ -336,9 +355,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
                     if (mask) {
                         const int u = __ffs(mask) - 1;
                         mask &= mask - 1;
-                        uint32_t k = key[0], lp = lpos[0];
+                        uint32_t k, lp;
+                        if (K16) {
+                            uint32_t half = kv[0];
 #pragma unroll
-                        for (int e = 1; e < NK; ++e) { k = u == e ? key[e] : k; lp = u == e ? lpos[e] : lp; }
+                            for (int e = 1; e < NK / 2; ++e) half = (u >> 1) == e ? kv[e] : half;
+                            lp = 4u * (64u * (uint32_t)(u >> 2) + lane) + (uint32_t)(u & 3);
+                            const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)bd, kk);
+                            k = ((half >> ((u & 1) * 16)) & 0xFFFFu) | (off + lp >= B ? 65536u : 0u);
+                        } else {
+                            k = key[0]; lp = lpos[0];
+#pragma unroll
+                            for (int e = 1; e < NK; ++e) { k = u == e ? key[e] : k; lp = u == e ? lpos[e] : lp; }
+                        }
                         const uint2 ww = tabw[k >> 5];
                         const uint32_t rank = ww.y + (uint32_t)__popc(ww.x & ((1u << (k & 31)) - 1u));
                         const int at = qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
@@ -410,15 +439,19 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
         // instructions per pair either way, and the wave-per-pair form has 64 x the waves in flight: short lists keep it)
         const bool short_form = force_short;
         const bool k16 = long_form && nx <= 131072 && !(ube && strcmp(ube, "bits32") == 0);
-        const size_t bits_bytes = (k16 ? (size_t)UBB_K16_WORDS : ((size_t)nx + 31) / 32) * 8;
-        const bool rows_form = (long_form || short_form) && bits_bytes <= 112 * 1024 && nx < (1 << 20);
-        // Algorithmic bytes (12 B per list entry: key + value).  Wave-per-pair form: both computed lists of every
-        // lookahead pair.  Row-grouped form: the lookahead list is in pair order, so a first point's list is read once
-        // per RUN of pairs (<= one per point and per workgroup chunk) and only the partners' lists once per pair --
-        // pricing it with both lists per pair (round 2) put the fraction above 1.
+        const int ub_waves = long_form ? UBB_THREADS / 64 : 4;
+        // (table + per wave a 128-entry ring and two 64-entry accumulator rows + scan / run scratch)
+        const size_t bits_bytes = (k16 ? (size_t)UBB_K16_WORDS : ((size_t)nx + 31) / 32) * 8 + (size_t)ub_waves * (UBB_RING * 8 + 2 * 64 * 8 + 4) + 16;
+        const bool rows_form = (long_form || short_form) && bits_bytes <= 128 * 1024 && nx < (1 << 20);
+        // Algorithmic bytes.  Wave-per-pair form: both computed lists of every lookahead pair, 12 B per entry (key + value).
+        // Row-grouped form: the lookahead list is in pair order, so a first point's list (key + value) is read once per RUN of pairs
+        // (<= one per point and per workgroup chunk); of the partners' lists what HAS to be read is the keys, at the width the kernel
+        // streams them (2 B, 4 B beyond 131 072 points) -- values are touched for the few per cent of entries that match, a count the
+        // host does not know, so they are left out (the fraction is a lower bound; round 2 priced both lists per pair at 12 B per
+        // entry and the first row-grouped kernel already came out above 1).
         const int chunk = long_form ? UBB_CHUNK : UBB_CHUNK_SHORT;
         const double runs = (double)std::min<int64_t>(c->nnext, nx + (c->nnext + chunk - 1) / chunk);
-        const double alg = rows_form ? (double)c->nnext * (avg * 12.0 + 36.0) + runs * avg * 12.0
+        const double alg = rows_form ? (double)c->nnext * (avg * (k16 ? 2.0 : 4.0) + 36.0) + runs * avg * 12.0
                                      : (double)c->nnext * (2.0 * avg * 12.0 + 36.0);
         ProfScope ps(c, "update_bounds_intersect", alg);
 #define UBB_ARGS c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(), k16 ? c->c16.as<uint16_t>() : nullptr, \
