@@ -458,7 +458,7 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
         } else
         k_loc_thresh<<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx, loc_thresh, loc_min,
                                                             c->thr.as<int32_t>());
-        static const long long cols_min = getenv("ANNCHOR_KEEP_COLS_MIN") ? atoll(getenv("ANNCHOR_KEEP_COLS_MIN")) : (1ll << 22);   // bitmap words
+        static const long long cols_min = getenv("ANNCHOR_KEEP_COLS_MIN") ? atoll(getenv("ANNCHOR_KEEP_COLS_MIN")) : (1ll << 20);   // bitmap words (N = 16 000: 0.60 -> 0.27 ms)
         if (nx >= 64 && nx * kw >= cols_min)
             k_keep_bits_cols<<<(unsigned)((((nx + 63) / 64) * kw + 3) / 4), 256, 0, c->stream>>>(c->sid.as<uint64_t>(), c->thr.as<int32_t>(), nx, kw,
                                                                                            c->Kbits.as<uint64_t>());
@@ -497,7 +497,7 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
         ProfScope ps(c, "locality_emit_pairs", (double)n * 16 + (double)nx * kw * 12.0);
         static const long long tiled_min = getenv("ANNCHOR_EMIT_TILED_MIN") ? atoll(getenv("ANNCHOR_EMIT_TILED_MIN")) : 0;
         const int stream_hint = n >= ANN_STREAM_MIN_PAIRS, tiled = n >= tiled_min;
-        static const long long run_min = getenv("ANNCHOR_EMIT_RUN_MIN") ? atoll(getenv("ANNCHOR_EMIT_RUN_MIN")) : (1ll << 22);   // bitmap words
+        static const long long run_min = getenv("ANNCHOR_EMIT_RUN_MIN") ? atoll(getenv("ANNCHOR_EMIT_RUN_MIN")) : (1ll << 20);   // bitmap words (N = 16 000: 1.20 -> 0.71 ms)
         if (tiled && nx * kw >= run_min)
             k_emit_rows_run<<<(int)std::min<int64_t>(ann_blocks(nx * kw, 256), (int64_t)c->prop.multiProcessorCount * 32), 256, 0, c->stream>>>(
                 c->Kbits.as<uint64_t>(), c->Kpref.as<uint32_t>(), nx, kw, c->low.as<int32_t>(), c->rowstart.as<int64_t>(),
