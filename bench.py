@@ -514,7 +514,7 @@ def strings_run(args, steps, warmup, world, rank, local, dist, torch, all_cpus, 
             out["cpu_baseline"] = cpu_baseline(X, cfg)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             try:
-                out["cpu_baseline_python_metric"] = cpu_baseline_python_metric(X, local)
+                out["cpu_baseline_python_metric"] = cpu_baseline_python_metric(local)
             except Exception as e:   # never at the cost of the line
                 out["cpu_baseline_python_metric"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if affinity:
@@ -606,7 +606,7 @@ def c4_block(local):
     return res
 
 
-def cpu_baseline_python_metric(X, local, n=160):
+def cpu_baseline_python_metric_leg(X, local, n=160):
     """CPU baseline #2 (BASELINE.md section 3 / configs[0] "plumbing"): Annchor(X, python_callable) -- the
     metric is an arbitrary Python function evaluated on the HOST through the joblib get_exact_ijs
     (reference utils.py:152-175), everything downstream of it on the GPU.  Bounded sample: the first
@@ -636,6 +636,23 @@ def cpu_baseline_python_metric(X, local, n=160):
             "graph_equals_device_metric_run": same}
 
 
+def cpu_baseline_python_metric(local, budget_s=120):
+    """The python-metric leg in a child process with a hard time limit: joblib's loky start-up (one worker per core) normally takes
+    ~15 s of the leg's ~18 s, but on one box of the pool it did not come up at all (TimeoutError after the constructor's 30 s probe,
+    minutes of wall-clock before that) -- the bench line must not wait for it."""
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--python-metric-leg", str(int(local))], capture_output=True, text=True,
+                           timeout=budget_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "abandoned after %d s (joblib / loky workers did not come up on this host)" % budget_s}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "child exited %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else "")}
+    return json.loads(lines[-1])
+
+
 _REAL_STDOUT = None
 
 
@@ -647,6 +664,12 @@ def emit(obj):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--python-metric-leg":
+        from annchor_amd.datasets import load_strings
+
+        res = cpu_baseline_python_metric_leg(load_strings()["X"], int(sys.argv[2]))
+        print(json.dumps(res), flush=True)
+        return
     # stdout carries the JSON line and nothing else: the library mirrors the reference's print() notices ("Increasing p_work ...",
     # the note about point sets beyond the complete pair list), so file descriptor 1 is pointed at stderr for the rest of the run
     global _REAL_STDOUT
