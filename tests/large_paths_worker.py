@@ -13,6 +13,14 @@ if metric == "euclidean":
     Z = rng.standard_normal((n, 5))
     X = (Z @ rng.standard_normal((5, 24)) + 0.05 * rng.standard_normal((n, 24))).astype(np.float64)
     ann = Annchor(X, "euclidean", n_anchors=16, n_neighbors=k, p_work=0.1, n_samples=3000)
+elif metric == "euclidean_thinned":
+    # a locality-thinned list at a size where the thinned-list kernels are the DEFAULT (20 000 points: 6.3 M bitmap words)
+    n, k = 20000, 15
+    cent = rng.standard_normal((30, 6)) * 4
+    X = np.round(cent[rng.integers(0, 30, n)] + rng.standard_normal((n, 6)), 2)
+    from annchor_amd.samplers import DeviceStratifiedSampler
+    ann = Annchor(X, "euclidean", n_anchors=30, n_neighbors=k, p_work=0.02, n_samples=4000, locality=4, loc_thresh=2,
+                  sampler=DeviceStratifiedSampler(), random_seed=4)
 else:
     n, k = 1500, 12
     seeds = ["".join(rng.choice(list("ACGT"), rng.integers(50, 120))) for _ in range(12)]

@@ -35,6 +35,22 @@ def test_large_list_kernels_equal_small_list_kernels(tmp_path, metric):
         assert np.array_equal(a[key], d[key]), key
 
 
+OLDER = {"ANNCHOR_FEATURES_FORM": "tiled", "ANNCHOR_EMIT_RUN_MIN": str(1 << 60), "ANNCHOR_KEEP_COLS_MIN": str(1 << 60),
+         "ANNCHOR_EMIT_SUPER_MIN": str(1 << 30), "ANNCHOR_LOC_THRESH_HIST": "1", "ANNCHOR_UPDATE_BOUNDS": "pairs", "ANNCHOR_COMP_GENERIC": "1"}
+
+
+def test_thinned_list_kernels_equal_older_forms_at_their_own_size(tmp_path):
+    """20 000 points, candidates thinned by the locality filter (2 of the 4 nearest anchors in common): the kernels that take over
+    by default there -- anchor-outer features, run-based / super-tiled emission, column-stationary keep bitmap, register-counter
+    locality threshold, bit-table update_bounds on 2-byte keys, vectorised computed-neighbour CSR -- against the forms they
+    replaced, whole state bit-identical."""
+    a = _run(tmp_path, "new", "euclidean_thinned", {})
+    b = _run(tmp_path, "older", "euclidean_thinned", OLDER)
+    assert 20_000_000 < int(a["n_pairs"]) < 95_000_000   # (under half of all pairs: the anchor-outer feature kernel)
+    for key in ("A", "D", "evals", "n_pairs", "features", "ncm", "RA", "idx", "dist"):
+        assert np.array_equal(a[key], b[key]), key
+
+
 def test_no_device_memory_leak_across_contexts():
     """Every buffer a context allocated outside its slab is released with it: pair lists past the slab's 32 M pairs (here 45 M:
     float64 Euclidean, 9500 points) allocate ~40 buffers of their own; the device's free memory after six create / fit / close
