@@ -155,32 +155,38 @@ __global__ __launch_bounds__(ROW_THREADS) void k_comp_fill_direct(const int64_t 
 
 // one wavefront per lookahead pair
 #define UB_STAGE 1024   // keys of the searched list a wave keeps in LDS
+// G lanes per pair: 64, or 32 / 16 for short lists (two / four pairs per wave: the kernel is a chain of ~6 dependent reads per pair,
+// so what counts at C2 -- 375 000 pairs, ~100-entry lists -- is how many pairs are in flight, not lanes per list: 142 us with 64
+// lanes per pair, 97 with 32, 76 with 16, 110 with 8)
+template <int G>
 __global__ __launch_bounds__(256) void k_update_bounds(const int32_t *__restrict__ next, int64_t nnext,
                                                       const int2 *__restrict__ ij, const int64_t *__restrict__ cptr,
                                                       const int32_t *__restrict__ cidx, const double *__restrict__ cval,
                                                       double *__restrict__ lb, double *__restrict__ ub)
 {
-    __shared__ int32_t stage[4][UB_STAGE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (t >= nnext) return;
-    const int32_t p = next[t];
-    const int2 q = ij[p];
-    int64_t a0 = cptr[q.x], a1 = cptr[q.x + 1], b0 = cptr[q.y], b1 = cptr[q.y + 1];
+    constexpr int GROUPS = 256 / G, STAGE = UB_STAGE * G / 64;   // keys of the searched list a group keeps in LDS
+    __shared__ int32_t stage[GROUPS][STAGE];
+    const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const bool live = t < nnext;
+    const int32_t p = live ? next[t] : 0;
+    const int2 q = live ? ij[p] : make_int2(0, 0);
+    int64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    if (live) { a0 = cptr[q.x]; a1 = cptr[q.x + 1]; b0 = cptr[q.y]; b1 = cptr[q.y + 1]; }
     if (a1 - a0 > b1 - b0) { int64_t x = a0; a0 = b0; b0 = x; x = a1; a1 = b1; b1 = x; }  // walk the shorter list
     double nl = 0.0, nu = INFINITY;
     const int nbk = (int)(b1 - b0);
-    if (nbk <= UB_STAGE) {
+    if (nbk <= STAGE) {
         // the searched list's keys go to LDS (one coalesced pass): ~10 dependent probes per element
         // at LDS latency instead of L2 latency
-        int32_t *sk = stage[wave];
-        for (int e = lane; e < nbk; e += 64) sk[e] = cidx[b0 + e];
+        int32_t *sk = stage[grp];
+        for (int e = lane; e < nbk; e += G) sk[e] = cidx[b0 + e];
         // (a wave's LDS writes are visible to its own later reads -- in-order LDS queue -- the
         // fence only keeps the compiler from moving the reads above the writes)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int64_t e = a0 + lane; e < a1; e += 64) {
+        for (int64_t e = a0 + lane; e < a1; e += G) {
             const int32_t key = cidx[e];
             int lo = 0, hi = nbk;
             while (lo < hi) {
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256) void k_update_bounds(const int32_t *__restrict
             }
         }
     } else {
-        for (int64_t e = a0 + lane; e < a1; e += 64) {
+        for (int64_t e = a0 + lane; e < a1; e += G) {
             const int32_t key = cidx[e];
             int64_t lo = b0, hi = b1;
             while (lo < hi) {
@@ -209,11 +215,11 @@ __global__ __launch_bounds__(256) void k_update_bounds(const int32_t *__restrict
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = G / 2; off > 0; off >>= 1) {
         nu = fmin(nu, __shfl_xor(nu, off));
         nl = fmax(nl, __shfl_xor(nl, off));
     }
-    if (lane == 0) {
+    if (lane == 0 && live) {
         lb[p] = fmax(nl, lb[p]);  // annchor.py:503-510
         ub[p] = fmin(nu, ub[p]);
     }
@@ -571,7 +577,16 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
             else k_update_bounds_bits<false, 8, UBB_THREADS, UBB_CHUNK><<<ann_blocks(c->nnext, UBB_CHUNK), UBB_THREADS, bits_bytes, c->stream>>>(UBB_ARGS);
         } else
 #undef UBB_ARGS
-        k_update_bounds<<<ann_blocks(c->nnext * 64, 256), 256, 0, c->stream>>>(
+        if (ube ? strcmp(ube, "pairs16") == 0 : avg < 192.0)   // ("pairs" / "pairs32" / "pairs16" force the group width)
+            k_update_bounds<16><<<ann_blocks(c->nnext * 16, 256), 256, 0, c->stream>>>(
+            c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(),
+            c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>());
+        else if (ube ? strcmp(ube, "pairs32") == 0 : avg < 256.0)
+            k_update_bounds<32><<<ann_blocks(c->nnext * 32, 256), 256, 0, c->stream>>>(
+            c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(),
+            c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>());
+        else
+        k_update_bounds<64><<<ann_blocks(c->nnext * 64, 256), 256, 0, c->stream>>>(
             c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(),
             c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>());
     }

@@ -114,7 +114,7 @@ def test_guarantee_nmin_rounds_equal_the_sequential_sweep(monkeypatch):
             assert np.array_equal(a, b)
         # the row-grouped form reading 4-byte keys (point sets beyond 131 072 take it; forced here)
         monkeypatch.setenv("ANNCHOR_GN_SWEEP", "rounds")
-        for form in ("bits32", "short"):   # ("short": 128-entry steps, 256-pair chunks)
+        for form in ("bits32", "short", "pairs32", "pairs16"):   # ("short": 128-entry steps, 256-pair chunks; "pairs32" / "pairs16": two / four pairs per wave)
             monkeypatch.setenv("ANNCHOR_UPDATE_BOUNDS", form)
             ann = Annchor(data, metric, random_seed=3, **kw).fit()
             bm = (ann.neighbor_graph[0], ann.neighbor_graph[1], ann.evals, ann.RefineApprox, ann.not_computed_mask)
