@@ -1,0 +1,679 @@
+// knn8.hip -- the tile phase of the streamed k-NN build on the bf16 matrix cores (k_st_knn8): split-bf16 tile GEMMs,
+// 8-wave workgroups, operands by LDS-DMA, exact re-ranking of what is kept.
+//
+// Same algorithm as k_st_knn (streamed.hip): a workgroup owns a 128-row tile, ranks the column tiles, evaluates them as
+// tile GEMMs and keeps the best columns per row in LDS.  What is different, and why (tools/microbench/shadow.hip,
+// pingpong.hip, measured on MI355X):
+//   * v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate and, it turns out, ON the vector ALUs' issue slot: nothing
+//     hides in its shadow (64 cycles per MFMA bare; 84 with two v_fma behind each, 110 with eight), and while a wave
+//     streams MFMAs back to back the SIMD's other wave issues nothing at all.  An f32 tile kernel therefore pays for
+//     every threshold test, LDS write and address computation in full -- k_st_knn's 60 % of the f32 peak is that.
+//   * v_mfma_f32_32x32x16_bf16 is a real matrix pipe: 32 cycles per MFMA with up to four VALU instructions behind
+//     each for free, and sixteen times the f32 rate.  With every float split into two bf16 (x = hi + lo, |x - hi - lo|
+//     <= 2^-17 |x|) a dot product is hi.hi + hi.lo + lo.hi -- three MFMAs per 16 dimensions, 24 per 32 x 32 x 128
+//     block = 768 matrix-pipe cycles against 4096 for the exact f32 stream -- with an error of ~2^-19 |x||y|
+//     (tools/microbench/bf16_split.hip), i.e. ~1e-4 relative on a neighbour's squared distance.
+//   * That error only matters at the boundary of a row's list.  The lists therefore hold K + ST_BF_MARGIN entries chosen
+//     by the split-bf16 distance, and the kernel's epilogue recomputes the EXACT float32 distance sum (x - y)^2 of
+//     everything kept and hands the best K on -- a true neighbour is lost only if MARGIN + 1 others overtake it inside
+//     the error band.  The reported distances are exact float32 as before; the exactness tests (rtol 1e-5 against
+//     float64 brute force with the full budget) hold unchanged.
+//
+// Structure: ONE 512-thread workgroup per CU; waves w and w + 4 sit on the same SIMD, own the SAME 32 rows and
+// alternate by slab (32 columns): in phase s the group s & 1 streams the slab's 24 MFMAs (operands: 16 ds_read_b128),
+// the other group tests ITS previous slab's accumulators against the rows' thresholds, inserts the survivors, merges
+// them into the sorted lists and requests a later slab.  Operand slabs go from global memory straight to LDS
+// (`global_load_lds_dwordx4`: no staging registers, no ds_write pass) into a ring of four slots = the four slabs of a
+// column tile, three slabs ahead of the stream; the LDS image is lane-linear, so the bank-conflict-free layout is made
+// on the SOURCE side: 16-byte unit kq of column c (units 0..DIM/8-1 the hi halves, then the lo halves) sits at unit
+// kq ^ f(c) of the column's run and the operand reads apply the same XOR.
+//
+// Decisions that steer the stream (skip a ranked tile whose bound has fallen behind the thresholds, early stop, budget)
+// are taken by every wave from barrier-separated LDS state, for the tile AFTER the one in the stream and from the
+// thresholds as merged through the tile BEFORE it -- a fixed lag, so runs are reproducible.
+#include "streamed.h"
+
+#define ST8_THREADS 512
+#define ST_BF_MARGIN 2   // list entries beyond K kept by the split-bf16 distance (re-ranked exactly at the end)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ST_PROFILE builds: per-wave cycle sums by segment (a.prof[0..7], printed by knn_tile_phase):
+//   0 MFMA stream (operand reads + MFMA issue)   1 barrier after the stream   2 choice of the next tile
+//   3 threshold test + survivor inserts           4 LDS-DMA requests           5 barrier after the requests
+//   6 merge (+ publish, run prologue / tail)      7 ranking, selection rounds, the rest
+#ifdef ST_PROFILE
+// (ordered: nothing may be scheduled across the time stamp, and it waits for the wave's outstanding LDS / scalar traffic)
+__device__ __forceinline__ long long st8_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return (long long)t;
+}
+#define P8(i) { const long long pf_n = st8_now(); pf[i] += pf_n - pf_t; pf_t = pf_n; }
+// sub-segment stamp: time since the last P8 / PS goes to slot i (8..15) without resetting the P8 clock
+#define PS(i) { const long long pf_n = st8_now(); pf[i] += pf_n - pf_s; pf_s = pf_n; }
+#define PS0 { pf_s = st8_now(); }
+#else
+#define P8(i)
+#define PS(i)
+#define PS0
+#endif
+
+template <int DIM, int KMAX> struct KnnShared8 {
+    float ring[4][ST_SLAB * DIM];   // FIRST (LDS-DMA destinations stay below 64 KB); slot = slab index inside the column tile
+    float cand_d[ST_T][ST_SLAB + 1];
+    uint8_t cand_c[ST_T][ST_SLAB + 4];
+    float list_d[ST_T][KMAX + 1];
+    int32_t list_c[ST_T][KMAX + 1];
+    float thr[ST_T];
+    int cnt[ST_T];
+    float loI[64], hiI[64], midI[64];
+    float surv_lb[ST_SURV];
+    float surv_vb[ST_SURV];
+    int32_t surv_j[ST_SURV];
+    float wave_thr[4];   // worst k-th squared distance per 32-row group, as of the last completed tile
+    int wave_ins[8];     // list insertions per wave (cumulative), as of the last completed tile
+    int nsurv;
+    int sel_bin;
+    uint32_t sel_before;
+};
+
+// swizzle of a column's 16-byte units (see the header comment); UPC = units per column
+template <int UPC> __device__ __forceinline__ int unit_swz(int col) { return UPC >= 16 ? (col & 15) : ((col >> 1) & (UPC - 1)); }
+
+// one 1 KB piece of an operand slab, global -> LDS, no registers: lane l lands at lds_dst + 16 l
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// Phase boundaries.  The LDS-DMA requests are invisible to the compiler's wait bookkeeping: a wave that has streamed
+// MFMAs for a whole phase waits for the requests it issued the phase before (landed long ago) and hands them on with the
+// barrier; the wave that has just issued requests lets them fly across the barrier.
+// (sched_barrier: the memory clobber alone does not keep register-only instructions -- the MFMAs -- on their side.)
+__device__ __forceinline__ void phase_end_after_stream()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void phase_end_after_issue()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int DIM, int KMAX> __global__ __launch_bounds__(ST8_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_st_knn8(KnnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+    KnnShared8<DIM, KMAX> &sh = *reinterpret_cast<KnnShared8<DIM, KMAX> *>(smem8);
+    constexpr int UPC = DIM / 4;            // 16-byte units per column
+    constexpr int NV = UPC / 2;             // operand reads (ds_read_b128) per slab and lane: G hi + G lo
+    constexpr int NPIECE = UPC * ST_SLAB / 64;   // 1 KB pieces per slab
+    constexpr int NI = NPIECE / 4;          // pieces per loading wave
+    static_assert(NI >= 1, "slab smaller than four 1 KB pieces");
+    static_assert(sizeof(sh.ring) <= 65536, "LDS-DMA destinations must stay below 64 KB");
+    static_assert(KMAX <= ST_SLAB + 1, "the exact re-ranking reuses cand_d with row stride KMAX");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, rg = wave & 3;   // slab parity this wave streams; its 32-row group
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem8;
+    int bt;
+    {   // XCD-banded row-tile assignment (block b runs on XCD b % 8): neighbours in the k-d order share an L2
+        const int nb_ = gridDim.x, q = nb_ >> 3, r = nb_ & 7, x = blockIdx.x & 7, y = blockIdx.x >> 3;
+        bt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int I = a.tile_begin + bt;
+    const int64_t grow0 = (int64_t)I * ST_T;
+    const int K = a.K;
+    const int KL = min(KMAX, K + ST_BF_MARGIN);   // list entries kept by the split-bf16 distance
+    const int col = lane & 31, half = lane >> 5;
+    const int rowbase = rg * 32;
+    const int rowq = rowbase + 4 * half;   // C layout: row = rowq + (r & 3) + 8 (r >> 2), col = lane & 31
+    // ---- row operand in registers, split: lane holds row (lane & 31), dimensions 16 g + 8 half .. + 7 of k-step g as
+    // eight bf16 hi parts and eight lo parts
+    constexpr int G = DIM / 16;
+    bf16x8 ah[G], al[G];
+    {
+        const float *xr = a.Rs + (size_t)(grow0 + rowbase + col) * DIM + 8 * half;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4 t0 = *reinterpret_cast<const float4 *>(xr + 16 * g), t1 = *reinterpret_cast<const float4 *>(xr + 16 * g + 4);
+            const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const __bf16 h = (__bf16)x[j];
+                ah[g][j] = h;
+                al[g][j] = (__bf16)(x[j] - (float)h);
+            }
+        }
+    }
+    float ri[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ri[r] = a.rr[grow0 + rowq + (r & 3) + 8 * (r >> 2)];
+    if (threadIdx.x < ST_T) {
+        const int row = threadIdx.x;
+        const bool real = a.rr[grow0 + row] < INFINITY;
+        sh.thr[row] = real ? INFINITY : -1.f;   // padding rows never accept candidates
+        sh.cnt[row] = 0;
+        for (int q = 0; q < KMAX; ++q) { sh.list_d[row][q] = INFINITY; sh.list_c[row][q] = 0x7fffffff; }
+    }
+    if ((int)threadIdx.x < a.na) {
+        sh.loI[threadIdx.x] = a.rlo[(size_t)threadIdx.x * a.nt_r + I];
+        sh.hiI[threadIdx.x] = a.rhi[(size_t)threadIdx.x * a.nt_r + I];
+        sh.midI[threadIdx.x] = a.rmid[(size_t)threadIdx.x * a.nt_r + I];
+    }
+    if (threadIdx.x < 8) sh.wave_ins[threadIdx.x] = 0;
+    if (threadIdx.x < 4) sh.wave_thr[threadIdx.x] = INFINITY;
+    if (threadIdx.x == 0) sh.nsurv = 0;
+    int ins = 0;         // list insertions by this lane's row (lanes < 32)
+    int processed = 0;   // column tiles scheduled so far (uniform)
+    int win_start = 0, win_ins = 0;
+    bool dried = false;
+    uint32_t *ebits = a.eval_bits ? a.eval_bits + (size_t)bt * a.eval_words : nullptr;
+#ifdef ST_PROFILE
+    long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long pf_t = st8_now();
+    long long pf_s = pf_t;
+#endif
+    __syncthreads();
+
+    // ---------------------------------------------------------------- the pieces of a phase
+    // operand slab `slab` of column tile J -> ring slot `slab`: this wave's NI pieces
+    const uint16_t *xb = a.Xb;   // [n_all][2][DIM] bf16: hi parts, then lo parts of every ordered row
+    auto issue_slab = [&](int J, int slab) {
+        const int64_t c0 = (int64_t)J * ST_T + slab * ST_SLAB;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int piece = rg * NI + i;
+            const int u = piece * 64 + lane;
+            const int c = u / UPC, x = u % UPC;
+            const int kq = x ^ unit_swz<UPC>(c);
+            glds16(xb + ((size_t)(c0 + c) * DIM * 2 + kq * 8), lds0 + (uint32_t)(slab * ST_SLAB * DIM * 4 + piece * 1024));
+        }
+    };
+    f32x16 acc;
+    float rj_s = 0.f;   // squared norm of the lane's column in the slab this wave streamed last
+    // 3 DIM / 16 MFMAs of this wave's 32 rows against the 32 columns in ring slot `slab` (columns of tile J); the
+    // columns' squared norms are requested first and used by the test one phase later: a global round trip under load
+    // is thousands of cycles, as long as the stream itself
+    auto stream_slab = [&](int J, int slab) {
+        PS0
+        rj_s = a.rs[(int64_t)J * ST_T + slab * ST_SLAB + col];
+        const float4 *base = reinterpret_cast<const float4 *>(&sh.ring[slab][0]) + col * UPC;
+        const int gsw = half ^ unit_swz<UPC>(col);
+        float4 b[NV];   // b[g]: hi parts of k-step g; b[G + g]: lo parts
+#pragma unroll
+        for (int v = 0; v < NV; ++v) b[v] = base[(2 * v) ^ gsw];
+        // all operand reads first, then the MFMAs back to back (left alone the scheduler sinks each read to its use and
+        // the stream waits out an LDS round trip every few MFMAs)
+        __builtin_amdgcn_sched_group_barrier(0x100, NV, 0);
+        PS(8)    // operand reads landed (the stamp waits for them)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {   // small terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g], __builtin_bit_cast(bf16x8, b[g]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], __builtin_bit_cast(bf16x8, b[G + g]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], __builtin_bit_cast(bf16x8, b[g]), acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * G, 0);
+        PS(9)    // MFMAs issued
+    };
+    // threshold test of the accumulators of slab `slab` of tile J, survivors into the rows' candidate slots, merge
+    // into the sorted lists (lane l < 32 owns row rowbase + l).  `rj`: squared norm of the lane's column.
+    auto test_merge = [&](int J, int slab, float rj) {
+        PS0
+        uint32_t pass = 0;
+        float d2r[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(&sh.thr[rowq + 8 * q]);
+            const float tq[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int g = 4 * q + e;
+                d2r[g] = fmaxf(ri[g] + rj - 2.f * acc[g], 0.f);
+                pass |= (d2r[g] < tq[e] ? 1u : 0u) << g;
+            }
+        }
+        const bool self_tile = !a.query && (int64_t)J * ST_T == grow0;
+        PS(10)   // thresholds read, accumulators there, 16 tests
+        if (pass) {
+            if (self_tile) {   // a point is not its own neighbour
+                const int dcol = slab * ST_SLAB + col - rowq;
+                if (dcol >= 0 && dcol < 32 && (dcol & 4) == 0) pass &= ~(1u << ((dcol & 3) + 4 * (dcol >> 3)));
+            }
+            while (pass) {
+                const int g = __builtin_ctz(pass);
+                pass &= pass - 1;
+                const int rowl = rowq + (g & 3) + 8 * (g >> 2);
+                float d2 = d2r[0];
+#pragma unroll
+                for (int t = 1; t < 16; ++t) d2 = g == t ? d2r[t] : d2;
+                const int slot = atomicAdd(&sh.cnt[rowl], 1);
+                sh.cand_d[rowl][slot] = d2;
+                sh.cand_c[rowl][slot] = (uint8_t)col;
+            }
+        }
+        PS(11)   // survivor inserts
+        wave_fence_lds();
+        P8(3)
+        if (lane < 32) {
+            const int row = rowbase + lane;
+            const int nc = sh.cnt[row];
+            if (nc) {
+                const int32_t col0 = (int32_t)(J * ST_T + slab * ST_SLAB);
+                for (int q = 0; q < nc; ++q) {
+                    const float d = sh.cand_d[row][q];
+                    const int32_t cc = col0 + sh.cand_c[row][q];
+                    // insertion by (d, col); the list is padded with +inf
+                    if (d < sh.list_d[row][KL - 1] || (d == sh.list_d[row][KL - 1] && cc < sh.list_c[row][KL - 1])) {
+                        int p = KL - 1;
+                        while (p > 0 && (d < sh.list_d[row][p - 1] || (d == sh.list_d[row][p - 1] && cc < sh.list_c[row][p - 1]))) {
+                            sh.list_d[row][p] = sh.list_d[row][p - 1];
+                            sh.list_c[row][p] = sh.list_c[row][p - 1];
+                            --p;
+                        }
+                        sh.list_d[row][p] = d;
+                        sh.list_c[row][p] = cc;
+                        ins += p < K;   // the yield that stops the tile phase counts what reaches the K entries handed on
+                    }
+                }
+                sh.cnt[row] = 0;
+                sh.thr[row] = sh.list_d[row][KL - 1];
+            }
+        }
+        wave_fence_lds();
+        P8(6)
+    };
+    // the wave's insertion count (and, for the group that finishes a tile, its rows' worst k-th distance)
+    auto publish = [&](bool with_thr) {
+        int wins = lane < 32 ? ins : 0;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) wins += __shfl_xor(wins, off);
+        if (lane == 0) sh.wave_ins[wave] = wins;
+        if (with_thr) {
+            float t = lane < 32 ? sh.thr[rowbase + lane] : -1.f;   // padding rows: -1
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) t = fmaxf(t, __shfl_xor(t, off));
+            if (lane == 0) sh.wave_thr[rg] = t;
+        }
+    };
+    auto thrmax_now = [&]() { return fmaxf(fmaxf(sh.wave_thr[0], sh.wave_thr[1]), fmaxf(sh.wave_thr[2], sh.wave_thr[3])); };
+
+    // One run of the stream over a list of tiles in rank order: list entry q is (tile `jl(q)`, valid bound `vb(q)`);
+    // entries whose bound has fallen behind the thresholds are skipped.  Uniform: every wave takes the same path.
+    auto run = [&](int ns, auto jl, auto vb) {
+        int q = 0;
+        auto next_tile = [&](int in_stream) -> int {
+            if (a.early_window > 0 && !dried) {
+                const int done = processed - in_stream;   // tiles completed (the one in the stream is not)
+                if (done - win_start >= a.early_window) {
+                    int cur = 0;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) cur += sh.wave_ins[w];
+                    if (cur - win_ins < a.early_tau) dried = true;
+                    else { win_start = done; win_ins = cur; }
+                }
+            }
+            if (dried) return -1;
+            const float tm = thrmax_now();
+            while (q < ns && processed < a.max_tiles) {
+                const int J = jl(q);
+                const float lb = vb(q);
+                ++q;
+                if (lb * lb < tm) {
+                    ++processed;
+                    if (ebits && threadIdx.x == 0) atomicOr(&ebits[J >> 5], 1u << (J & 31));   // (no return value: nothing to wait for)
+                    return J;
+                }
+            }
+            return -1;
+        };
+        P8(7)
+        int J = next_tile(0);
+        if (J < 0) return;
+        // fill: all four slabs of the first tile (group 0: slabs 0, 1; group 1: slabs 2, 3)
+        issue_slab(J, 2 * grp);
+        issue_slab(J, 2 * grp + 1);
+        phase_end_after_stream();
+        P8(6)
+        bool slab3_resident = true;
+        int Jprev = -1;          // group 1: tile whose slab 3 still waits for its test
+        for (;;) {
+            int Jn = -1;
+            // ---- phase 0: group 0 streams slab 0 | group 1 finishes the previous tile, requests slab 3
+            if (grp == 0) {
+                stream_slab(J, 0);
+                P8(0)
+                phase_end_after_stream();
+                P8(1)
+            } else {
+                if (Jprev >= 0) {
+                    test_merge(Jprev, 3, rj_s);
+                    P8(3)
+                    publish(true);
+                    P8(6)
+                }
+                if (!slab3_resident) issue_slab(J, 3);
+                P8(4)
+                phase_end_after_issue();
+                P8(5)
+            }
+            // ---- phase 1: group 1 streams slab 1 | group 0 tests slab 0, the next tile is chosen and requested
+            // (thresholds / insertions as of the tile before J, untouched during this phase: the same choice in every wave)
+            if (grp == 1) {
+                stream_slab(J, 1);
+                P8(0)
+                Jn = next_tile(1);
+                P8(2)
+                phase_end_after_stream();
+                P8(1)
+            } else {
+                Jn = next_tile(1);
+                P8(2)
+                test_merge(J, 0, rj_s);
+                P8(3)
+                if (Jn >= 0) issue_slab(Jn, 0);
+                P8(4)
+                phase_end_after_issue();
+                P8(5)
+            }
+            // ---- phase 2: group 0 streams slab 2 | group 1 tests slab 1
+            if (grp == 0) {
+                stream_slab(J, 2);
+                P8(0)
+                phase_end_after_stream();
+                P8(1)
+            } else {
+                test_merge(J, 1, rj_s);
+                P8(3)
+                if (Jn >= 0) issue_slab(Jn, 1);
+                P8(4)
+                phase_end_after_issue();
+                P8(5)
+            }
+            // ---- phase 3: group 1 streams slab 3 | group 0 tests slab 2
+            if (grp == 1) {
+                stream_slab(J, 3);
+                P8(0)
+                phase_end_after_stream();
+                P8(1)
+            } else {
+                test_merge(J, 2, rj_s);
+                P8(3)
+                publish(false);
+                P8(6)
+                if (Jn >= 0) issue_slab(Jn, 2);
+                P8(4)
+                phase_end_after_issue();
+                P8(5)
+            }
+            Jprev = J;
+            slab3_resident = false;
+            if (Jn < 0) break;
+            J = Jn;
+        }
+        // ---- tail: the last tile's slab 3
+        if (grp == 1) {
+            test_merge(Jprev, 3, rj_s);
+            publish(true);
+        }
+        phase_end_after_stream();
+        P8(6)
+    };
+
+    // ---- phase A: the row tile against itself (gives every row K finite candidates); query rows are not part of the
+    // data set and start from the ranked tiles directly
+    if (!a.query) {
+        const int budget = a.max_tiles;
+        run(1, [&](int) { return I; }, [&](int) { return 0.f; });
+        (void)budget;
+    }
+
+    // ---- phase B: all other column tiles, exactly as k_st_knn ranks and selects them (streamed.hip): rank key and
+    // valid bound of every column tile into a scratch row, then rounds of {3-level radix selection of the next ST_KEEP
+    // tiles in (key, tile) order, collect, sort, stream}
+    float *skey = a.scr_key + (size_t)bt * a.nt_all;
+    float *slb = a.scr_lb + (size_t)bt * a.nt_all;
+    for (int J = threadIdx.x; J < a.nt_all; J += ST8_THREADS) {
+        float lb = 0.f, lbc = 0.f;
+        for (int an = 0; an < a.na; ++an) {
+            const float lj = a.lo[(size_t)an * a.nt_all + J], hj = a.hi[(size_t)an * a.nt_all + J];
+            const float gap = fmaxf(sh.loI[an] - hj, lj - sh.hiI[an]);
+            // slack for the float32 rounding of D (bounds must stay valid lower bounds)
+            lb = fmaxf(lb, gap - 4e-6f * (fabsf(hj) + fabsf(sh.hiI[an])));
+            const float dm = a.mid[(size_t)an * a.nt_all + J] - sh.midI[an];
+            lbc += dm * dm;   // rank key: squared L2 distance between the tiles' mean anchor vectors
+        }
+        skey[J] = ((J == I && !a.query) || !(lbc < INFINITY)) ? INFINITY : lbc;   // +inf: never a candidate
+        slb[J] = lb;
+    }
+    __syncthreads();   // block-scope visibility of the scratch row (same CU)
+    uint32_t *hist = reinterpret_cast<uint32_t *>(&sh.cand_d[0][0]);   // 4096 bins; cand_d is idle between runs
+    static_assert(sizeof(sh.cand_d) >= 4096 * sizeof(uint32_t), "histogram does not fit");
+    uint32_t done_bits = 0;   // (done_bits, done_j): key bits / index of the last tile already considered
+    int done_j = -1;
+    for (;;) {
+        const float thrmax = thrmax_now();
+        uint32_t prefix = 0;
+        uint32_t want = ST_KEEP;
+        bool all = false;
+        for (int level = 0; level < 3 && !all; ++level) {
+            const int shift = level == 0 ? 20 : level == 1 ? 8 : 0;
+            const int nbins = level == 2 ? 256 : 4096;
+            const uint32_t pmask = level == 0 ? 0u : level == 1 ? 0xfff00000u : 0xffffff00u;
+            for (int q = threadIdx.x; q < nbins; q += ST8_THREADS) hist[q] = 0;
+            __syncthreads();
+            for (int J = threadIdx.x; J < a.nt_all; J += ST8_THREADS) {
+                const uint32_t kb = __float_as_uint(skey[J]);
+                const float lb = slb[J];
+                const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
+                if (kb < 0x7f800000u && after_done && lb * lb < thrmax && (kb & pmask) == prefix)
+                    atomicAdd(&hist[(kb >> shift) & (nbins - 1)], 1u);
+            }
+            __syncthreads();
+            // first bin whose cumulative count reaches `want`: thread t owns bins [per t, per (t+1)) (threads beyond the
+            // bins own none); exclusive scan over the threads, then the owner of the crossing walks its bins
+            const int per = nbins >= ST8_THREADS ? nbins / ST8_THREADS : 1;
+            const bool owner = (int)threadIdx.x * per < nbins;
+            uint32_t mine = 0;
+            if (owner)
+                for (int q = 0; q < per; ++q) mine += hist[threadIdx.x * per + q];
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off);
+                if (lane >= off) incl += up;
+            }
+            uint32_t *wtot = reinterpret_cast<uint32_t *>(&sh.surv_lb[0]);   // 8 wave totals (surv_lb is idle here)
+            if (threadIdx.x == 0) sh.sel_bin = -1;
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            uint32_t before = incl - mine;
+            for (int w2 = 0; w2 < wave; ++w2) before += wtot[w2];
+            if (owner && before < want && before + mine >= want) {
+                uint32_t ac = before;
+                int q = threadIdx.x * per;
+                for (;; ++q) { if (ac + hist[q] >= want) break; ac += hist[q]; }
+                sh.sel_bin = q;
+                sh.sel_before = ac;
+            }
+            __syncthreads();
+            if (sh.sel_bin < 0) all = true;
+            else { prefix |= (uint32_t)sh.sel_bin << shift; want -= sh.sel_before; }
+            __syncthreads();
+        }
+        const uint32_t cut_bits = all ? 0x7f7fffffu : prefix;   // take keys <= cut (ties resolved by the sort below)
+        if (threadIdx.x == 0) sh.nsurv = 0;
+        __syncthreads();
+        for (int J = threadIdx.x; J < a.nt_all; J += ST8_THREADS) {
+            const uint32_t kb = __float_as_uint(skey[J]);
+            const float lb = slb[J];
+            const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
+            if (kb < 0x7f800000u && after_done && lb * lb < thrmax && kb <= cut_bits) {
+                const int slot = atomicAdd(&sh.nsurv, 1);
+                if (slot < ST_SURV) { sh.surv_lb[slot] = __uint_as_float(kb); sh.surv_vb[slot] = lb; sh.surv_j[slot] = J; }
+            }
+        }
+        __syncthreads();
+        int ns = min(sh.nsurv, ST_SURV);
+        if (ns == 0) break;
+        {   // sort by (rank key, J): bitonic over ST_SURV slots
+            for (int q = threadIdx.x; q < ST_SURV; q += ST8_THREADS)
+                if (q >= ns) { sh.surv_lb[q] = INFINITY; sh.surv_j[q] = 0x7fffffff; }
+            __syncthreads();
+            for (int k2 = 2; k2 <= ST_SURV; k2 <<= 1)
+                for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                    for (int q = threadIdx.x; q < ST_SURV; q += ST8_THREADS) {
+                        const int p2 = q ^ j2;
+                        if (p2 > q) {
+                            const bool up = (q & k2) == 0;
+                            const float lq = sh.surv_lb[q], lp = sh.surv_lb[p2];
+                            const int jq = sh.surv_j[q], jp = sh.surv_j[p2];
+                            const bool gt = lq > lp || (lq == lp && jq > jp);
+                            if (gt == up) {
+                                sh.surv_lb[q] = lp; sh.surv_lb[p2] = lq; sh.surv_j[q] = jp; sh.surv_j[p2] = jq;
+                                const float t = sh.surv_vb[q]; sh.surv_vb[q] = sh.surv_vb[p2]; sh.surv_vb[p2] = t;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+        }
+        const bool more = !all;          // the selection was cut at ST_KEEP: later tiles remain
+        if (ns > ST_KEEP && more) ns = ST_KEEP;
+        const uint32_t round_last_bits = __float_as_uint(sh.surv_lb[ns - 1]);
+        const int round_last_j = sh.surv_j[ns - 1];
+        __syncthreads();   // hist (cand_d) and the partial sums (surv_lb) are idle again: the stream may run
+        run(ns, [&](int q) { return sh.surv_j[q]; }, [&](int q) { return sh.surv_vb[q]; });
+        done_bits = round_last_bits;
+        done_j = round_last_j;
+        __syncthreads();
+        if (dried) break;
+        if (processed >= a.max_tiles) break;
+        if (!more) break;   // the selection saw every eligible tile
+    }
+    __syncthreads();
+    // ---- exact re-ranking: the lists hold KL >= K columns chosen by the split-bf16 distance (error ~1e-4 relative on a
+    // neighbour's d^2); their exact float32 distances sum (x - y)^2 decide which K are handed on, and in which order
+    {
+        float *ex = &sh.cand_d[0][0];   // [ST_T][KMAX] exact d^2 (cand_d is idle now; row stride KMAX <= ST_SLAB + 1)
+        for (int q = threadIdx.x; q < ST_T * KL; q += ST8_THREADS) {
+            const int row = q / KL, e = q - row * KL;
+            const int32_t cc = sh.list_c[row][e];
+            float d2 = INFINITY;
+            if (cc != 0x7fffffff && sh.list_d[row][e] < INFINITY) {
+                const float4 *x = reinterpret_cast<const float4 *>(a.Rs + (size_t)(grow0 + row) * DIM);
+                const float4 *y = reinterpret_cast<const float4 *>(a.Xs + (size_t)cc * DIM);
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+                for (int t = 0; t < DIM / 4; ++t) {
+                    const float4 u = x[t], v = y[t];
+                    const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z, dw = u.w - v.w;
+                    s0 += dx * dx; s1 += dy * dy; s2 += dz * dz; s3 += dw * dw;
+                }
+                d2 = (s0 + s1) + (s2 + s3);
+            }
+            ex[row * KMAX + e] = d2;
+        }
+        __syncthreads();
+        if (threadIdx.x < ST_T) {   // one thread per row: insertion sort of <= 32 entries by (exact d^2, column)
+            const int row = threadIdx.x;
+            for (int e = 1; e < KL; ++e) {
+                const float d = ex[row * KMAX + e];
+                const int32_t cc = sh.list_c[row][e];
+                int p = e;
+                while (p > 0 && (d < ex[row * KMAX + p - 1] || (d == ex[row * KMAX + p - 1] && cc < sh.list_c[row][p - 1]))) {
+                    ex[row * KMAX + p] = ex[row * KMAX + p - 1];
+                    sh.list_c[row][p] = sh.list_c[row][p - 1];
+                    --p;
+                }
+                ex[row * KMAX + p] = d;
+                sh.list_c[row][p] = cc;
+            }
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < ST_T * K; q += ST8_THREADS) {
+            const int row = q / K, e = q - row * K;
+            const float d2 = ex[row * KMAX + e];
+            a.out_d2[((size_t)bt * ST_T + row) * K + e] = d2;
+            a.out_col[((size_t)bt * ST_T + row) * K + e] = d2 < INFINITY ? sh.list_c[row][e] : 0x7fffffff;
+        }
+    }
+    if (threadIdx.x == 0) atomicAdd(a.evals, (unsigned long long)processed);
+#ifdef ST_PROFILE
+    P8(7)
+    if (lane == 0 && a.prof)
+        for (int i = 0; i < 16; ++i) atomicAdd(a.prof + i, (unsigned long long)pf[i]);
+#endif
+}
+
+template <int DIM, int KMAX> static int launch8(annchor_ctx *c, const KnnArgs &a)
+{
+    const size_t lds = sizeof(KnnShared8<DIM, KMAX>);
+    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "streamed k-NN (8-wave form) needs %zu B of LDS", lds);
+    ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knn8<DIM, KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_st_knn8<DIM, KMAX><<<a.tile_count, ST8_THREADS, lds, c->stream>>>(a);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
+// The tile phase through the 8-wave split-bf16 kernel when the shape fits it (padded dim <= 128: the ring of four slabs is
+// 16 KB x 4 there; K + ST_BF_MARGIN <= 32 list entries; the split copy of the columns exists); *handled = false sends the
+// caller to the exact-f32 kernel k_st_knn.
+int ann_stream_launch_knn8(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool *handled)
+{
+    *handled = true;
+    if (a.K + ST_BF_MARGIN > ST_KMAX || !a.Xb) { *handled = false; return ANNCHOR_OK; }
+    const bool k16 = a.K + ST_BF_MARGIN <= 16;
+    switch (dim_padded) {
+    case 32: return k16 ? launch8<32, 16>(c, a) : launch8<32, ST_KMAX>(c, a);
+    case 64: return k16 ? launch8<64, 16>(c, a) : launch8<64, ST_KMAX>(c, a);
+    case 128: return k16 ? launch8<128, 16>(c, a) : launch8<128, ST_KMAX>(c, a);
+    default: *handled = false; return ANNCHOR_OK;
+    }
+}
+
+// ------------------------------------------------------------------ the split copy of the ordered rows
+// Xb[row] = {bf16 hi parts of the row's dimp floats, then their lo parts}: hi = bf16(x) (round to nearest even),
+// lo = bf16(x - hi); the same bytes per row as the float32 copy.
+__global__ void k_st_split_bf16(const float *__restrict__ Xs, int64_t n4, int dimp, uint16_t *__restrict__ Xb)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 of one row
+    if (t >= n4) return;
+    const int per = dimp / 4;
+    const int64_t row = t / per;
+    const int q = (int)(t - row * per);
+    const float4 v = reinterpret_cast<const float4 *>(Xs)[t];
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    uint16_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 hb = (__bf16)x[j];
+        const __bf16 lb = (__bf16)(x[j] - (float)hb);
+        h[j] = __builtin_bit_cast(uint16_t, hb);
+        l[j] = __builtin_bit_cast(uint16_t, lb);
+    }
+    uint16_t *dst = Xb + (size_t)row * dimp * 2 + 4 * q;
+    *reinterpret_cast<uint2 *>(dst) = uint2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+    *reinterpret_cast<uint2 *>(dst + dimp) = uint2{(uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16)};
+}
+
+int ann_stream_split_rows(annchor_ctx *c, StreamState *s)
+{
+    const int64_t n4 = s->n_pad * (int64_t)(s->dimp / 4);
+    ANN_TRY(ann_stream_reserve(c, s->Xb, sizeof(uint16_t) * 2 * (size_t)s->n_pad * s->dimp));
+    k_st_split_bf16<<<ann_blocks(n4, 256), 256, 0, c->stream>>>(s->Xs.as<float>(), n4, s->dimp, s->Xb.as<uint16_t>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}

@@ -35,6 +35,7 @@ struct StreamState {
     DevBuf X;        // float [n_local][dim]      (copy of the caller's rows)
     DevBuf keys, keys2, vals, vals2, cubtmp;
     DevBuf Xs;       // float [n_pad][dimp]       rows in tile order, zero padded
+    DevBuf Xb;       // bf16 [n_pad][2][dimp]     the same rows split into hi + lo halves (knn8.hip), dimp <= 128 only
     DevBuf rs;       // float [n_pad]             squared norms (+inf on padding rows)
     DevBuf perm;     // int64 [n_pad]             global id of each ordered row (-1 padding)
     DevBuf lo, hi, mid;  // float [na][nt]        per-tile anchor-distance intervals and means
@@ -71,6 +72,7 @@ struct StreamState {
 
 struct KnnArgs {
     const float *Xs;      // [n_all][DIM]   all column tiles (every rank's ordered shard, concatenated)
+    const uint16_t *Xb;   // [n_all][2][DIM] bf16 hi / lo halves of the same rows (NULL: none -- the f32 kernel runs)
     const float *rs;      // [n_all]
     const float *lo, *hi, *mid; // [na][nt_all]
     int nt_all, na;
@@ -101,6 +103,11 @@ struct KnnArgs {
 };
 
 StreamState *ann_stream_state(annchor_ctx *c, bool create);
+// knn8.hip: the tile phase on the bf16 matrix cores (split operands, one 512-thread workgroup per CU); *handled = false
+// when the shape does not fit it (padded dim > 128, more than 30 neighbours, no split copy) and the caller launches k_st_knn
+int ann_stream_launch_knn8(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled);
+int ann_stream_split_rows(annchor_ctx *c, StreamState *s);     // Xb from Xs (after the ordering)
+const void *ann_stream_split_of(const void *Xs);               // the split copy that belongs to an ordered float32 array, or NULL
 int ann_stream_reserve(annchor_ctx *c, DevBuf &b, size_t bytes);   // individual allocation, grow-only, contents NOT kept
 int ann_stream_padded_dim(int dim);
 // exact float32 distances of the kept neighbours, final order, ids: *d_idx_out int64 [rows][K], *d_dist_out float [rows][K]

@@ -51,7 +51,7 @@ void ann_stream_release(annchor_ctx *c)
                               &s->scr_key, &s->scr_lb, &s->emit_idx, &s->emit_dist, &s->Dt, &s->eval_bits, &s->out_d2b, &s->out_colb,
                               &s->ucand, &s->ucount, &s->rev_cnt, &s->rev_ptr, &s->rev_edges, &s->rev, &s->cand, &s->cand_all, &s->avecs, &s->A_dev,
                               &s->rows_send, &s->rows_recv, &s->rows_all, &s->lists_all, &s->route_tab, &s->route_cnt, &s->route_slot,
-                              &s->route_send, &s->route_recv};
+                              &s->route_send, &s->route_recv, &s->Xb};
             for (DevBuf *b : bufs)
                 if (b->p && !b->in_arena) ann_dev_free(c, b->p, b->cap);
             ann_stream_free_run(s);
@@ -77,6 +77,14 @@ static int sreserve(annchor_ctx *c, DevBuf &b, size_t bytes)
 
 static int padded_dim(int dim) { return dim <= 32 ? 32 : dim <= 64 ? 64 : dim <= 128 ? 128 : dim <= 256 ? 256 : -1; }
 StreamState *ann_stream_state(annchor_ctx *c, bool create) { return state_of(c, create); }
+// (the column arrays travel through the C-ABI as bare pointers -- a query engine streams another context's columns --
+// so the split copy is found from the float32 array it was made from)
+const void *ann_stream_split_of(const void *Xs)
+{
+    for (auto &p : g_states)
+        if (p.second->Xs.p == Xs && p.second->Xb.p && p.second->dimp <= 128) return p.second->Xb.p;
+    return nullptr;
+}
 int ann_stream_reserve(annchor_ctx *c, DevBuf &b, size_t bytes) { return sreserve(c, b, bytes); }
 int ann_stream_padded_dim(int dim) { return padded_dim(dim); }
 
@@ -542,6 +550,7 @@ extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs
                                                                       s->rs.as<float>(), s->perm.as<int64_t>());
     k_st_intervals<<<s->nt, ST_T, 0, c->stream>>>(s->D.as<float>(), s->vals2.as<uint32_t>(), n, s->na, s->nt, s->lo.as<float>(),
                                                  s->hi.as<float>(), s->mid.as<float>());
+    if (s->dimp <= 128) ANN_TRY(ann_stream_split_rows(c, s));   // the bf16 hi / lo copy the tile kernel streams (knn8.hip)
     ANN_CHECK_HIP(c, hipGetLastError());
     ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     *Xs = s->Xs.p; *rs = s->rs.p; *perm = s->perm.p; *lo = s->lo.p; *hi = s->hi.p; *mid = s->mid.p;
@@ -1465,6 +1474,15 @@ template <int DIM> static int launch_knn(annchor_ctx *c, const KnnArgs &a, bool 
 
 static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool join)
 {
+    if (!join) {
+        // ANNCHOR_ST_KERNEL=4wave: the two-workgroups-per-CU kernel below for every shape (A/B runs, tests)
+        static const bool four = getenv("ANNCHOR_ST_KERNEL") && !strcmp(getenv("ANNCHOR_ST_KERNEL"), "4wave");
+        if (!four) {
+            bool handled = false;
+            ANN_TRY(ann_stream_launch_knn8(c, a, dim_padded, &handled));
+            if (handled) return ANNCHOR_OK;
+        }
+    }
     switch (dim_padded) {
     case 32: return launch_knn<32>(c, a, join);
     case 64: return launch_knn<64>(c, a, join);
@@ -1543,8 +1561,8 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
     a.prof = nullptr;
 #ifdef ST_PROFILE
     static unsigned long long *d_prof = nullptr;
-    if (!d_prof) (void)hipMalloc(&d_prof, 64);
-    (void)hipMemsetAsync(d_prof, 0, 64, c->stream);
+    if (!d_prof) (void)hipMalloc(&d_prof, 128);
+    (void)hipMemsetAsync(d_prof, 0, 128, c->stream);
     a.prof = d_prof;
 #endif
     ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
@@ -1559,11 +1577,21 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
     {
         unsigned long long hp[8];
         ANN_TRY(ann_d2h(c, hp, a.prof, 64));
-        static const char *names[8] = {"barrier before stash", "stash (incl. global-load wait)", "barrier after stash",
-                                       "MFMA stream + thresholds", "survivor inserts", "merge", "tile end", "candidate scan + rest"};
+        static const char *names4[8] = {"barrier before stash", "stash (incl. global-load wait)", "barrier after stash",
+                                        "MFMA stream + thresholds", "survivor inserts", "merge", "tile end", "candidate scan + rest"};
+        static const char *names8[8] = {"MFMA stream", "barrier after stream", "next-tile choice", "test + inserts", "LDS-DMA requests",
+                                        "barrier after requests", "merge (+ publish / prologue / tail)", "ranking + selection + rest"};
+        const bool four = getenv("ANNCHOR_ST_KERNEL") && !strcmp(getenv("ANNCHOR_ST_KERNEL"), "4wave");
+        const char **names = (four || dim_padded > 128 || a.K > ST_KMAX) ? names4 : names8;
         double tot = 0;
         for (int i = 0; i < 8; ++i) tot += (double)hp[i];
         for (int i = 0; i < 8; ++i) fprintf(stderr, "[st-prof] %-32s %6.2f %%\n", names[i], 100.0 * (double)hp[i] / tot);
+        {   // knn8.hip's extra slots 8..15 (sub-segments; already contained in the eight above)
+            unsigned long long hx[8];
+            ANN_TRY(ann_d2h(c, hx, a.prof + 8, 64));
+            for (int i = 0; i < 8; ++i)
+                if (hx[i]) fprintf(stderr, "[st-prof]    sub %d %36s %6.2f %%\n", i + 8, "", 100.0 * (double)hx[i] / tot);
+        }
     }
 #endif
     return ANNCHOR_OK;
@@ -1711,7 +1739,7 @@ static int knn_args_graph(annchor_ctx *c, KnnArgs &a, const void *Xs_all, const 
     ANN_REQUIRE(c, n_all == (int64_t)nt_all * ST_T && tile_begin >= 0 && tile_begin + tile_count <= nt_all, ANNCHOR_EINVAL,
                 "tile range out of bounds");
     ANN_REQUIRE(c, n_all < (1ll << 31), ANNCHOR_ELIMIT, "n_all exceeds 2^31");
-    a.Xs = (const float *)Xs_all; a.rs = (const float *)rs_all; a.lo = (const float *)lo_all; a.hi = (const float *)hi_all; a.mid = (const float *)mid_all;
+    a.Xs = (const float *)Xs_all; a.Xb = (const uint16_t *)ann_stream_split_of(Xs_all); a.rs = (const float *)rs_all; a.lo = (const float *)lo_all; a.hi = (const float *)hi_all; a.mid = (const float *)mid_all;
     a.Rs = a.Xs; a.rr = a.rs; a.rlo = a.lo; a.rhi = a.hi; a.rmid = a.mid; a.nt_r = nt_all; a.query = 0;
     a.nt_all = nt_all; a.na = n_anchors; a.tile_begin = tile_begin; a.tile_count = tile_count; a.K = k - 1;
     return ANNCHOR_OK;
@@ -1832,7 +1860,7 @@ extern "C" int annchor_stream_query(annchor_ctx *c, const void *Xs_all, const vo
     ANN_REQUIRE(c, s && s->nt > 0 && s->Xs.p && s->na == n_anchors && s->dimp == dim_padded, ANNCHOR_ESTATE,
                 "queries are not ordered (bind, anchor rounds with the data set's anchors, order) or do not match the data set");
     KnnArgs a;
-    a.Xs = (const float *)Xs_all; a.rs = (const float *)rs_all; a.lo = (const float *)lo_all; a.hi = (const float *)hi_all; a.mid = (const float *)mid_all;
+    a.Xs = (const float *)Xs_all; a.Xb = (const uint16_t *)ann_stream_split_of(Xs_all); a.rs = (const float *)rs_all; a.lo = (const float *)lo_all; a.hi = (const float *)hi_all; a.mid = (const float *)mid_all;
     a.Rs = s->Xs.as<float>(); a.rr = s->rs.as<float>(); a.rlo = s->lo.as<float>(); a.rhi = s->hi.as<float>(); a.rmid = s->mid.as<float>();
     a.nt_r = s->nt; a.query = 1;
     a.nt_all = nt_all; a.na = n_anchors; a.tile_begin = 0; a.tile_count = s->nt; a.K = nn;
