@@ -69,6 +69,8 @@ template <int DIM, int KMAX> struct KnnShared8 {
     float list_d[ST_T][KMAX + 1];
     int32_t list_c[ST_T][KMAX + 1];
     float thr[ST_T];
+    float hb[ST_T];      // (|x_row|^2 - thr[row]) / 2: column c passes the row's test iff x_row . x_c > hb[row] + |x_c|^2 / 2
+    float rrow[ST_T];    // |x_row|^2
     int cnt[ST_T];
     float loI[64], hiI[64], midI[64];
     float surv_lb[ST_SURV];
@@ -83,16 +85,6 @@ template <int DIM, int KMAX> struct KnnShared8 {
 
 // swizzle of a column's 16-byte units (see the header comment); UPC = units per column
 template <int UPC> __device__ __forceinline__ int unit_swz(int col) { return UPC >= 16 ? (col & 15) : ((col >> 1) & (UPC - 1)); }
-
-// one 1 KB piece of an operand slab, global -> LDS, no registers: lane l lands at lds_dst + 16 l
-__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
 
 // Phase boundaries.  The LDS-DMA requests are invisible to the compiler's wait bookkeeping: a wave that has streamed
 // MFMAs for a whole phase waits for the requests it issued the phase before (landed long ago) and hands them on with the
@@ -119,7 +111,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST8_THREADS, 2) __attr
     constexpr int NV = UPC / 2;             // operand reads (ds_read_b128) per slab and lane: G hi + G lo
     constexpr int NPIECE = UPC * ST_SLAB / 64;   // 1 KB pieces per slab
     constexpr int NI = NPIECE / 4;          // pieces per loading wave
-    static_assert(NI >= 1, "slab smaller than four 1 KB pieces");
+    static_assert(NI == 1 || NI == 2 || NI == 4, "pieces per loading wave");
     static_assert(sizeof(sh.ring) <= 65536, "LDS-DMA destinations must stay below 64 KB");
     static_assert(KMAX <= ST_SLAB + 1, "the exact re-ranking reuses cand_d with row stride KMAX");
     const int lane = threadIdx.x & 63;
@@ -156,13 +148,12 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST8_THREADS, 2) __attr
             }
         }
     }
-    float ri[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ri[r] = a.rr[grow0 + rowq + (r & 3) + 8 * (r >> 2)];
     if (threadIdx.x < ST_T) {
         const int row = threadIdx.x;
         const bool real = a.rr[grow0 + row] < INFINITY;
         sh.thr[row] = real ? INFINITY : -1.f;   // padding rows never accept candidates
+        sh.hb[row] = real ? -INFINITY : INFINITY;
+        sh.rrow[row] = a.rr[grow0 + row];
         sh.cnt[row] = 0;
         for (int q = 0; q < KMAX; ++q) { sh.list_d[row][q] = INFINITY; sh.list_c[row][q] = 0x7fffffff; }
     }
@@ -188,17 +179,32 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST8_THREADS, 2) __attr
 
     // ---------------------------------------------------------------- the pieces of a phase
     // operand slab `slab` of column tile J -> ring slot `slab`: this wave's NI pieces
-    const uint16_t *xb = a.Xb;   // [n_all][2][DIM] bf16: hi parts, then lo parts of every ordered row
-    auto issue_slab = [&](int J, int slab) {
-        const int64_t c0 = (int64_t)J * ST_T + slab * ST_SLAB;
+    // (the lane -> (column, unit) map of a piece never changes: byte offsets inside a slab's 32 rows, once)
+    uint32_t loff[NI];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int piece = rg * NI + i;
-            const int u = piece * 64 + lane;
-            const int c = u / UPC, x = u % UPC;
-            const int kq = x ^ unit_swz<UPC>(c);
-            glds16(xb + ((size_t)(c0 + c) * DIM * 2 + kq * 8), lds0 + (uint32_t)(slab * ST_SLAB * DIM * 4 + piece * 1024));
-        }
+    for (int i = 0; i < NI; ++i) {
+        const int u = (rg * NI + i) * 64 + lane;
+        const int c = u / UPC, x = u % UPC;
+        loff[i] = (uint32_t)(c * DIM * 4 + ((x ^ unit_swz<UPC>(c)) << 4));
+    }
+    const char *xb = reinterpret_cast<const char *>(a.Xb);   // [n_all][2][DIM] bf16: hi parts, then lo parts of every ordered row
+    auto issue_slab = [&](int J, int slab) {
+        const char *src = xb + ((size_t)J * ST_T + slab * ST_SLAB) * (DIM * 4);              // wave-uniform: an SGPR pair
+        const uint32_t dst = lds0 + (uint32_t)(slab * ST_SLAB * DIM * 4 + rg * NI * 1024);    // this wave's pieces of the slot
+        unsigned keep;
+        if constexpr (NI == 4)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(loff[0]), "v"(loff[1]), "v"(loff[2]), "v"(loff[3]), "s"(src), "s"(dst) : "memory", "scc");
+        else if constexpr (NI == 2)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(loff[0]), "v"(loff[1]), "s"(src), "s"(dst) : "memory", "scc");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(loff[0]), "s"(src), "s"(dst) : "memory");
     };
     f32x16 acc;
     float rj_s = 0.f;   // squared norm of the lane's column in the slab this wave streamed last
@@ -233,16 +239,16 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST8_THREADS, 2) __attr
     auto test_merge = [&](int J, int slab, float rj) {
         PS0
         uint32_t pass = 0;
-        float d2r[16];
+        const float hrj = 0.5f * rj;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 t4 = *reinterpret_cast<const float4 *>(&sh.thr[rowq + 8 * q]);
-            const float tq[4] = {t4.x, t4.y, t4.z, t4.w};
+            const float4 h4 = *reinterpret_cast<const float4 *>(&sh.hb[rowq + 8 * q]);
+            const float hq[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int g = 4 * q + e;
-                d2r[g] = fmaxf(ri[g] + rj - 2.f * acc[g], 0.f);
-                pass |= (d2r[g] < tq[e] ? 1u : 0u) << g;
+                // |x_r|^2 + |x_c|^2 - 2 x_r . x_c < thr_r, rearranged so that the row's part is one LDS word
+                pass |= (acc[g] > hq[e] + hrj ? 1u : 0u) << g;
             }
         }
         const bool self_tile = !a.query && (int64_t)J * ST_T == grow0;
@@ -256,9 +262,10 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST8_THREADS, 2) __attr
                 const int g = __builtin_ctz(pass);
                 pass &= pass - 1;
                 const int rowl = rowq + (g & 3) + 8 * (g >> 2);
-                float d2 = d2r[0];
+                float ag = acc[0];
 #pragma unroll
-                for (int t = 1; t < 16; ++t) d2 = g == t ? d2r[t] : d2;
+                for (int t = 1; t < 16; ++t) ag = g == t ? acc[t] : ag;
+                const float d2 = fmaxf(sh.rrow[rowl] + rj - 2.f * ag, 0.f);
                 const int slot = atomicAdd(&sh.cnt[rowl], 1);
                 sh.cand_d[rowl][slot] = d2;
                 sh.cand_c[rowl][slot] = (uint8_t)col;
@@ -289,7 +296,9 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST8_THREADS, 2) __attr
                     }
                 }
                 sh.cnt[row] = 0;
-                sh.thr[row] = sh.list_d[row][KL - 1];
+                const float t = sh.list_d[row][KL - 1];
+                sh.thr[row] = t;
+                sh.hb[row] = 0.5f * (sh.rrow[row] - t);
             }
         }
         wave_fence_lds();
@@ -369,8 +378,9 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST8_THREADS, 2) __attr
                 phase_end_after_issue();
                 P8(5)
             }
-            // ---- phase 1: group 1 streams slab 1 | group 0 tests slab 0, the next tile is chosen and requested
-            // (thresholds / insertions as of the tile before J, untouched during this phase: the same choice in every wave)
+            // ---- phase 1: group 1 streams slab 1, then chooses the next tile | group 0 tests slab 0
+            // (the choice reads thresholds / insertion counts as of the tile before J, which nobody writes during phases 1
+            // and 2: group 0 repeats it after its stream of phase 2 and gets the same answer, off its critical path)
             if (grp == 1) {
                 stream_slab(J, 1);
                 P8(0)
@@ -379,30 +389,27 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST8_THREADS, 2) __attr
                 phase_end_after_stream();
                 P8(1)
             } else {
-                Jn = next_tile(1);
-                P8(2)
                 test_merge(J, 0, rj_s);
-                P8(3)
-                if (Jn >= 0) issue_slab(Jn, 0);
                 P8(4)
                 phase_end_after_issue();
                 P8(5)
             }
-            // ---- phase 2: group 0 streams slab 2 | group 1 tests slab 1
+            // ---- phase 2: group 0 streams slab 2, then chooses the next tile | group 1 tests slab 1, requests slabs 0, 1 of the next tile
             if (grp == 0) {
                 stream_slab(J, 2);
                 P8(0)
+                Jn = next_tile(1);
+                P8(2)
                 phase_end_after_stream();
                 P8(1)
             } else {
                 test_merge(J, 1, rj_s);
-                P8(3)
-                if (Jn >= 0) issue_slab(Jn, 1);
+                if (Jn >= 0) { issue_slab(Jn, 0); issue_slab(Jn, 1); }
                 P8(4)
                 phase_end_after_issue();
                 P8(5)
             }
-            // ---- phase 3: group 1 streams slab 3 | group 0 tests slab 2
+            // ---- phase 3: group 1 streams slab 3 | group 0 tests slab 2, requests slab 2 of the next tile
             if (grp == 1) {
                 stream_slab(J, 3);
                 P8(0)
@@ -410,9 +417,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST8_THREADS, 2) __attr
                 P8(1)
             } else {
                 test_merge(J, 2, rj_s);
-                P8(3)
                 publish(false);
-                P8(6)
                 if (Jn >= 0) issue_slab(Jn, 2);
                 P8(4)
                 phase_end_after_issue();
