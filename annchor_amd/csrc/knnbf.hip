@@ -1,0 +1,608 @@
+// knnbf.hip -- the tile phase of the streamed k-NN build on the bf16 matrix cores (k_st_knnbf): split-bf16 tile GEMMs,
+// operands by LDS-DMA, exact re-ranking of what is kept.
+//
+// Same algorithm as k_st_knn (streamed.hip): a workgroup owns a 128-row tile, ranks the column tiles, evaluates them as
+// tile GEMMs and keeps the best columns per row in LDS.  What is different, and why (tools/microbench/shadow.hip,
+// pingpong.hip, measured on MI355X):
+//   * v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate and, it turns out, in the vector ALUs' issue slot: nothing
+//     hides in its shadow (64 cycles per MFMA bare; 84 with two v_fma behind each, 110 with eight), so an f32 tile
+//     kernel pays for every threshold test, LDS write and address computation in full -- k_st_knn's 60 % of the f32
+//     peak is that.
+//   * v_mfma_f32_32x32x16_bf16 is a real matrix pipe: 32 cycles per MFMA with up to four VALU instructions behind
+//     each for free, and sixteen times the f32 rate.  With every float split into two bf16 (x = hi + lo, |x - hi - lo|
+//     <= 2^-17 |x|) a dot product is hi.hi + hi.lo + lo.hi -- three MFMAs per 16 dimensions, 24 per 32 x 32 x 128
+//     block = 768 matrix-pipe cycles against 4096 for the exact f32 stream -- with an error of ~2^-19 |x||y|
+//     (tools/microbench/bf16_split.hip), i.e. ~1e-4 relative on a neighbour's squared distance.
+//   * That error only matters at the boundary of a row's list.  The lists therefore hold K + ST_BF_MARGIN entries chosen
+//     by the split-bf16 distance, and the kernel's epilogue recomputes the EXACT float32 distance sum (x - y)^2 of
+//     everything kept and hands the best K on -- a true neighbour is lost only if MARGIN + 1 others overtake it inside
+//     the error band.  The reported distances are exact float32 as before; the exactness tests (rtol 1e-5 against
+//     float64 brute force with the full budget) hold unchanged.
+//   * While a wave streams MFMAs back to back, the SIMD's other wave issues NOTHING (pingpong.hip: a partner's VALU or
+//     LDS work beside a bf16 MFMA chain takes exactly chain + its own time, whatever s_setprio says).  A producer /
+//     consumer split inside a SIMD therefore serialises; what overlaps is one wave's LATENCY (the LDS round trips of a
+//     list merge, a barrier wait) with another wave's issue.  Hence two independent 4-wave workgroups per CU, one wave of
+//     each on every SIMD, each wave doing everything for its 32 rows: stream, test, insert, merge.
+//
+// Per slab (32 columns) and wave: request the NEXT slab (LDS-DMA `global_load_lds_dwordx4`: no staging registers, no
+// ds_write pass; two ring slots), 16 ds_read_b128 of operands, 24 MFMAs, threshold test against one LDS word per row,
+// survivor inserts, list merge, wait for the request, one workgroup barrier.  The LDS image of a slab is lane-linear, so
+// the bank-conflict-free layout is made on the SOURCE side: 16-byte unit kq of column c (units 0..DIM/8-1 the hi halves,
+// then the lo halves) sits at unit kq ^ f(c) of the column's run and the operand reads apply the same XOR.
+//
+// Decisions that steer the stream (skip a ranked tile whose bound has fallen behind the thresholds, early stop, budget)
+// are taken by every wave from barrier-separated LDS state, for the tile AFTER the one in the stream and from the
+// thresholds as merged through the tile BEFORE it -- a fixed lag, so runs are reproducible.
+#include "streamed.h"
+
+#define STB_THREADS 256
+#define ST_BF_MARGIN 2   // list entries beyond K kept by the split-bf16 distance (re-ranked exactly at the end)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ST_PROFILE builds: per-wave cycle sums by segment (a.prof[0..7], printed by knn_tile_phase):
+//   0 MFMA stream (operand reads + MFMA issue)   1 barrier after the stream   2 choice of the next tile
+//   3 threshold test + survivor inserts           4 LDS-DMA requests           5 barrier after the requests
+//   6 merge (+ publish, run prologue / tail)      7 ranking, selection rounds, the rest
+#ifdef ST_PROFILE
+// (ordered: nothing may be scheduled across the time stamp, and it waits for the wave's outstanding LDS / scalar traffic)
+__device__ __forceinline__ long long st8_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return (long long)t;
+}
+#define P8(i) { const long long pf_n = st8_now(); pf[i] += pf_n - pf_t; pf_t = pf_n; }
+// sub-segment stamp: time since the last P8 / PS goes to slot i (8..15) without resetting the P8 clock
+#define PS(i) { const long long pf_n = st8_now(); pf[i] += pf_n - pf_s; pf_s = pf_n; }
+#define PS0 { pf_s = st8_now(); }
+#else
+#define P8(i)
+#define PS(i)
+#define PS0
+#endif
+
+template <int DIM, int KMAX> struct KnnSharedB {
+    static constexpr int SLABF = ST_SLAB * DIM;                                 // floats per operand slab
+    static constexpr int RINGF = 2 * SLABF * 4 >= 12288 ? 2 * SLABF : 12288 / 4;   // (>= sizeof(SelBuf))
+    float ring[RINGF];   // FIRST (LDS-DMA destinations stay below 64 KB); two slots, slot = slab parity.  Between runs the
+                         // selection's sort buffers (SelBuf) live here
+    float cand_d[ST_T][ST_SLAB + 1];   // (between runs: the selection's 4096-bin histogram; at the end: exact distances)
+    uint8_t cand_c[ST_T][ST_SLAB + 4];
+    float list_d[ST_T][KMAX + 1];
+    int32_t list_c[ST_T][KMAX + 1];
+    float thr[ST_T];
+    float hb[ST_T];      // (|x_row|^2 - thr[row]) / 2: column c passes the row's test iff x_row . x_c > hb[row] + |x_c|^2 / 2
+    float rrow[ST_T];    // |x_row|^2
+    int cnt[ST_T];
+    float loI[64], hiI[64], midI[64];
+    float run_vb[ST_KEEP];     // the current round's tiles in rank order: valid bound, tile
+    int32_t run_j[ST_KEEP];
+    float wave_thr[2][4];   // worst k-th squared distance per 32-row group, published at the end of tile n into [n & 1]
+    int wave_ins[2][4];     // list insertions per wave (cumulative), likewise
+    int nsurv;
+    int sel_bin;
+    uint32_t sel_before;
+};
+struct SelBuf {   // candidate tiles of a selection round (aliases the operand ring, idle between runs)
+    float surv_lb[ST_SURV];
+    float surv_vb[ST_SURV];
+    int32_t surv_j[ST_SURV];
+};
+
+// swizzle of a column's 16-byte units (see the header comment); UPC = units per column
+template <int UPC> __device__ __forceinline__ int unit_swz(int col) { return UPC >= 16 ? (col & 15) : ((col >> 1) & (UPC - 1)); }
+
+// End of a slab: the wave's LDS-DMA pieces of the next slab have landed and its LDS traffic is done; the barrier hands the
+// next slab to every wave and this slab's ring slot back to the requests.  (The requests are invisible to the compiler's
+// wait bookkeeping -- inline asm; sched_barrier: the memory clobber alone does not keep register-only instructions on
+// their side.)
+__device__ __forceinline__ void slab_end()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_st_knnbf(KnnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemb[];
+    KnnSharedB<DIM, KMAX> &sh = *reinterpret_cast<KnnSharedB<DIM, KMAX> *>(smemb);
+    constexpr int UPC = DIM / 4;            // 16-byte units per column
+    constexpr int NV = UPC / 2;             // operand reads (ds_read_b128) per slab and lane: G hi + G lo
+    constexpr int NPIECE = UPC * ST_SLAB / 64;   // 1 KB pieces per slab
+    constexpr int NI = NPIECE / 4;          // pieces per loading wave
+    static_assert(NI == 1 || NI == 2 || NI == 4, "pieces per loading wave");
+    static_assert(sizeof(sh.ring) <= 65536, "LDS-DMA destinations must stay below 64 KB");
+    static_assert(sizeof(SelBuf) <= sizeof(sh.ring) && sizeof(SelBuf) == 12288, "selection buffers alias the ring");
+    static_assert(KMAX <= ST_SLAB + 1, "the exact re-ranking reuses cand_d with row stride KMAX");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rg = wave;   // this wave's 32-row group
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smemb;
+    int bt;
+    {   // XCD-banded row-tile assignment (block b runs on XCD b % 8): neighbours in the k-d order share an L2
+        const int nb_ = gridDim.x, q = nb_ >> 3, r = nb_ & 7, x = blockIdx.x & 7, y = blockIdx.x >> 3;
+        bt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int I = a.tile_begin + bt;
+    const int64_t grow0 = (int64_t)I * ST_T;
+    const int K = a.K;
+    const int KL = min(KMAX, K + ST_BF_MARGIN);   // list entries kept by the split-bf16 distance
+    const int col = lane & 31, half = lane >> 5;
+    const int rowbase = rg * 32;
+    const int rowq = rowbase + 4 * half;   // C layout: row = rowq + (r & 3) + 8 (r >> 2), col = lane & 31
+    // ---- row operand in registers, split: lane holds row (lane & 31), dimensions 16 g + 8 half .. + 7 of k-step g as
+    // eight bf16 hi parts and eight lo parts
+    constexpr int G = DIM / 16;
+    bf16x8 ah[G], al[G];
+    {
+        const float *xr = a.Rs + (size_t)(grow0 + rowbase + col) * DIM + 8 * half;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4 t0 = *reinterpret_cast<const float4 *>(xr + 16 * g), t1 = *reinterpret_cast<const float4 *>(xr + 16 * g + 4);
+            const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const __bf16 h = (__bf16)x[j];
+                ah[g][j] = h;
+                al[g][j] = (__bf16)(x[j] - (float)h);
+            }
+        }
+    }
+    if (threadIdx.x < ST_T) {
+        const int row = threadIdx.x;
+        const bool real = a.rr[grow0 + row] < INFINITY;
+        sh.thr[row] = real ? INFINITY : -1.f;   // padding rows never accept candidates
+        sh.hb[row] = real ? -INFINITY : INFINITY;
+        sh.rrow[row] = a.rr[grow0 + row];
+        sh.cnt[row] = 0;
+        for (int q = 0; q < KMAX; ++q) { sh.list_d[row][q] = INFINITY; sh.list_c[row][q] = 0x7fffffff; }
+    }
+    if ((int)threadIdx.x < a.na) {
+        sh.loI[threadIdx.x] = a.rlo[(size_t)threadIdx.x * a.nt_r + I];
+        sh.hiI[threadIdx.x] = a.rhi[(size_t)threadIdx.x * a.nt_r + I];
+        sh.midI[threadIdx.x] = a.rmid[(size_t)threadIdx.x * a.nt_r + I];
+    }
+    if (threadIdx.x < 8) { sh.wave_ins[threadIdx.x >> 2][threadIdx.x & 3] = 0; sh.wave_thr[threadIdx.x >> 2][threadIdx.x & 3] = INFINITY; }
+    if (threadIdx.x == 0) sh.nsurv = 0;
+    int ins = 0;         // list insertions by this lane's row (lanes < 32)
+    int processed = 0;   // column tiles scheduled so far (uniform)
+    int tdone = 0;       // column tiles completed and published (uniform); tile n publishes into slot n & 1
+    int win_start = 0, win_ins = 0;
+    bool dried = false;
+    uint32_t *ebits = a.eval_bits ? a.eval_bits + (size_t)bt * a.eval_words : nullptr;
+#ifdef ST_PROFILE
+    long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long pf_t = st8_now();
+    long long pf_s = pf_t;
+#endif
+    __syncthreads();
+
+    // ---------------------------------------------------------------- the pieces of a phase
+    // operand slab `slab` of column tile J -> ring slot `slab`: this wave's NI pieces
+    // (the lane -> (column, unit) map of a piece never changes: byte offsets inside a slab's 32 rows, once)
+    uint32_t loff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int u = (rg * NI + i) * 64 + lane;
+        const int c = u / UPC, x = u % UPC;
+        loff[i] = (uint32_t)(c * DIM * 4 + ((x ^ unit_swz<UPC>(c)) << 4));
+    }
+    const char *xb = reinterpret_cast<const char *>(a.Xb);   // [n_all][2][DIM] bf16: hi parts, then lo parts of every ordered row
+    auto issue_slab = [&](int J, int slab) {
+        const char *src = xb + ((size_t)J * ST_T + slab * ST_SLAB) * (DIM * 4);              // wave-uniform: an SGPR pair
+        const uint32_t dst = lds0 + (uint32_t)((slab & 1) * ST_SLAB * DIM * 4 + rg * NI * 1024);   // this wave's pieces of the slot
+        unsigned keep;
+        if constexpr (NI == 4)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(loff[0]), "v"(loff[1]), "v"(loff[2]), "v"(loff[3]), "s"(src), "s"(dst) : "memory", "scc");
+        else if constexpr (NI == 2)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(loff[0]), "v"(loff[1]), "s"(src), "s"(dst) : "memory", "scc");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(loff[0]), "s"(src), "s"(dst) : "memory");
+    };
+    f32x16 acc;
+    float rj_s = 0.f;   // squared norm of the lane's column in the slab this wave streamed last
+    // 3 DIM / 16 MFMAs of this wave's 32 rows against the 32 columns in ring slot `slab` (columns of tile J); the
+    // columns' squared norms are requested first and used by the test one phase later: a global round trip under load
+    // is thousands of cycles, as long as the stream itself
+    auto stream_slab = [&](int J, int slab) {
+        PS0
+        rj_s = a.rs[(int64_t)J * ST_T + slab * ST_SLAB + col];
+        const float4 *base = reinterpret_cast<const float4 *>(&sh.ring[(slab & 1) * (ST_SLAB * DIM)]) + col * UPC;
+        const int gsw = half ^ unit_swz<UPC>(col);
+        float4 b[NV];   // b[g]: hi parts of k-step g; b[G + g]: lo parts
+#pragma unroll
+        for (int v = 0; v < NV; ++v) b[v] = base[(2 * v) ^ gsw];
+        // all operand reads first, then the MFMAs back to back (left alone the scheduler sinks each read to its use and
+        // the stream waits out an LDS round trip every few MFMAs)
+        __builtin_amdgcn_sched_group_barrier(0x100, NV, 0);
+        PS(8)    // operand reads landed (the stamp waits for them)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {   // small terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g], __builtin_bit_cast(bf16x8, b[g]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], __builtin_bit_cast(bf16x8, b[G + g]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], __builtin_bit_cast(bf16x8, b[g]), acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * G, 0);
+        PS(9)    // MFMAs issued
+    };
+    // threshold test of the accumulators of slab `slab` of tile J, survivors into the rows' candidate slots, merge
+    // into the sorted lists (lane l < 32 owns row rowbase + l).  `rj`: squared norm of the lane's column.
+    auto test_merge = [&](int J, int slab, float rj) {
+        PS0
+        uint32_t pass = 0;
+        const float hrj = 0.5f * rj;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 h4 = *reinterpret_cast<const float4 *>(&sh.hb[rowq + 8 * q]);
+            const float hq[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int g = 4 * q + e;
+                // |x_r|^2 + |x_c|^2 - 2 x_r . x_c < thr_r, rearranged so that the row's part is one LDS word
+                pass |= (acc[g] > hq[e] + hrj ? 1u : 0u) << g;
+            }
+        }
+        const bool self_tile = !a.query && (int64_t)J * ST_T == grow0;
+        PS(10)   // thresholds read, accumulators there, 16 tests
+        if (pass) {
+            if (self_tile) {   // a point is not its own neighbour
+                const int dcol = slab * ST_SLAB + col - rowq;
+                if (dcol >= 0 && dcol < 32 && (dcol & 4) == 0) pass &= ~(1u << ((dcol & 3) + 4 * (dcol >> 3)));
+            }
+            while (pass) {
+                const int g = __builtin_ctz(pass);
+                pass &= pass - 1;
+                const int rowl = rowq + (g & 3) + 8 * (g >> 2);
+                float ag = acc[0];
+#pragma unroll
+                for (int t = 1; t < 16; ++t) ag = g == t ? acc[t] : ag;
+                const float d2 = fmaxf(sh.rrow[rowl] + rj - 2.f * ag, 0.f);
+                const int slot = atomicAdd(&sh.cnt[rowl], 1);
+                sh.cand_d[rowl][slot] = d2;
+                sh.cand_c[rowl][slot] = (uint8_t)col;
+            }
+        }
+        PS(11)   // survivor inserts
+        wave_fence_lds();
+        P8(3)
+        if (lane < 32) {
+            const int row = rowbase + lane;
+            const int nc = sh.cnt[row];
+            if (nc) {
+                const int32_t col0 = (int32_t)(J * ST_T + slab * ST_SLAB);
+                for (int q = 0; q < nc; ++q) {
+                    const float d = sh.cand_d[row][q];
+                    const int32_t cc = col0 + sh.cand_c[row][q];
+                    // insertion by (d, col); the list is padded with +inf
+                    if (d < sh.list_d[row][KL - 1] || (d == sh.list_d[row][KL - 1] && cc < sh.list_c[row][KL - 1])) {
+                        int p = KL - 1;
+                        while (p > 0 && (d < sh.list_d[row][p - 1] || (d == sh.list_d[row][p - 1] && cc < sh.list_c[row][p - 1]))) {
+                            sh.list_d[row][p] = sh.list_d[row][p - 1];
+                            sh.list_c[row][p] = sh.list_c[row][p - 1];
+                            --p;
+                        }
+                        sh.list_d[row][p] = d;
+                        sh.list_c[row][p] = cc;
+                        ins += p < K;   // the yield that stops the tile phase counts what reaches the K entries handed on
+                    }
+                }
+                sh.cnt[row] = 0;
+                const float t = sh.list_d[row][KL - 1];
+                sh.thr[row] = t;
+                sh.hb[row] = 0.5f * (sh.rrow[row] - t);
+            }
+        }
+        wave_fence_lds();
+        P8(6)
+    };
+    // the wave's insertion count and its rows' worst k-th distance, at the end of a tile
+    auto publish = [&]() {
+        int wins = lane < 32 ? ins : 0;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) wins += __shfl_xor(wins, off);
+        float t = lane < 32 ? sh.thr[rowbase + lane] : -1.f;   // padding rows: -1
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) t = fmaxf(t, __shfl_xor(t, off));
+        if (lane == 0) { sh.wave_ins[(tdone + 1) & 1][wave] = wins; sh.wave_thr[(tdone + 1) & 1][rg] = t; }
+    };
+    // (as of the last tile whose publication a barrier separates from the reader: tile `tdone`)
+    auto thrmax_now = [&]() {
+        const float *w = sh.wave_thr[tdone & 1];
+        return fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
+    };
+
+    // One run of the stream over a list of tiles in rank order: list entry q is (tile `jl(q)`, valid bound `vb(q)`);
+    // entries whose bound has fallen behind the thresholds are skipped.  Uniform: every wave takes the same path.
+    auto run = [&](int ns, auto jl, auto vb) {
+        int q = 0;
+        auto next_tile = [&](int in_stream) -> int {
+            if (a.early_window > 0 && !dried) {
+                const int done = processed - in_stream;   // tiles completed (the one in the stream is not)
+                if (done - win_start >= a.early_window) {
+                    int cur = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) cur += sh.wave_ins[tdone & 1][w];
+                    if (cur - win_ins < a.early_tau) dried = true;
+                    else { win_start = done; win_ins = cur; }
+                }
+            }
+            if (dried) return -1;
+            const float tm = thrmax_now();
+            while (q < ns && processed < a.max_tiles) {
+                const int J = jl(q);
+                const float lb = vb(q);
+                ++q;
+                if (lb * lb < tm) {
+                    ++processed;
+                    if (ebits && threadIdx.x == 0) atomicOr(&ebits[J >> 5], 1u << (J & 31));   // (no return value: nothing to wait for)
+                    return J;
+                }
+            }
+            return -1;
+        };
+        P8(7)
+        int J = next_tile(0);
+        if (J < 0) return;
+        // fill: slab 0 of the first tile
+        issue_slab(J, 0);
+        slab_end();
+        P8(6)
+        for (;;) {
+            int Jn = -1;
+            // ---- slabs 0..2: request the next slab of this tile, stream, test, merge
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) {
+                issue_slab(J, sl + 1);
+                P8(4)
+                stream_slab(J, sl);
+                P8(0)
+                test_merge(J, sl, rj_s);
+                slab_end();
+                P8(1)
+            }
+            // ---- slab 3: the next tile is chosen (thresholds / insertion counts as of the tile before J: published before the
+            // last barrier of that tile and untouched since -- the same choice in every wave) and its slab 0 requested
+            Jn = next_tile(1);
+            P8(2)
+            if (Jn >= 0) issue_slab(Jn, 0);
+            P8(4)
+            stream_slab(J, 3);
+            P8(0)
+            test_merge(J, 3, rj_s);
+            publish();
+            ++tdone;
+            slab_end();
+            P8(1)
+            if (Jn < 0) break;
+            J = Jn;
+        }
+    };
+
+    // ---- phase A: the row tile against itself (gives every row K finite candidates); query rows are not part of the
+    // data set and start from the ranked tiles directly
+    if (!a.query) {
+        const int budget = a.max_tiles;
+        run(1, [&](int) { return I; }, [&](int) { return 0.f; });
+        (void)budget;
+    }
+
+    // ---- phase B: all other column tiles, exactly as k_st_knn ranks and selects them (streamed.hip): rank key and
+    // valid bound of every column tile into a scratch row, then rounds of {3-level radix selection of the next ST_KEEP
+    // tiles in (key, tile) order, collect, sort, stream}
+    float *skey = a.scr_key + (size_t)bt * a.nt_all;
+    float *slb = a.scr_lb + (size_t)bt * a.nt_all;
+    for (int J = threadIdx.x; J < a.nt_all; J += STB_THREADS) {
+        float lb = 0.f, lbc = 0.f;
+        for (int an = 0; an < a.na; ++an) {
+            const float lj = a.lo[(size_t)an * a.nt_all + J], hj = a.hi[(size_t)an * a.nt_all + J];
+            const float gap = fmaxf(sh.loI[an] - hj, lj - sh.hiI[an]);
+            // slack for the float32 rounding of D (bounds must stay valid lower bounds)
+            lb = fmaxf(lb, gap - 4e-6f * (fabsf(hj) + fabsf(sh.hiI[an])));
+            const float dm = a.mid[(size_t)an * a.nt_all + J] - sh.midI[an];
+            lbc += dm * dm;   // rank key: squared L2 distance between the tiles' mean anchor vectors
+        }
+        skey[J] = ((J == I && !a.query) || !(lbc < INFINITY)) ? INFINITY : lbc;   // +inf: never a candidate
+        slb[J] = lb;
+    }
+    __syncthreads();   // block-scope visibility of the scratch row (same CU)
+    uint32_t *hist = reinterpret_cast<uint32_t *>(&sh.cand_d[0][0]);   // 4096 bins; cand_d is idle between runs
+    SelBuf &sb = *reinterpret_cast<SelBuf *>(&sh.ring[0]);           // the ring is idle between runs too
+    static_assert(sizeof(sh.cand_d) >= 4096 * sizeof(uint32_t), "histogram does not fit");
+    uint32_t done_bits = 0;   // (done_bits, done_j): key bits / index of the last tile already considered
+    int done_j = -1;
+    for (;;) {
+        const float thrmax = thrmax_now();
+        uint32_t prefix = 0;
+        uint32_t want = ST_KEEP;
+        bool all = false;
+        for (int level = 0; level < 3 && !all; ++level) {
+            const int shift = level == 0 ? 20 : level == 1 ? 8 : 0;
+            const int nbins = level == 2 ? 256 : 4096;
+            const uint32_t pmask = level == 0 ? 0u : level == 1 ? 0xfff00000u : 0xffffff00u;
+            for (int q = threadIdx.x; q < nbins; q += STB_THREADS) hist[q] = 0;
+            __syncthreads();
+            for (int J = threadIdx.x; J < a.nt_all; J += STB_THREADS) {
+                const uint32_t kb = __float_as_uint(skey[J]);
+                const float lb = slb[J];
+                const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
+                if (kb < 0x7f800000u && after_done && lb * lb < thrmax && (kb & pmask) == prefix)
+                    atomicAdd(&hist[(kb >> shift) & (nbins - 1)], 1u);
+            }
+            __syncthreads();
+            // first bin whose cumulative count reaches `want`: thread t owns bins [per t, per (t+1)) (threads beyond the
+            // bins own none); exclusive scan over the threads, then the owner of the crossing walks its bins
+            const int per = nbins >= STB_THREADS ? nbins / STB_THREADS : 1;
+            const bool owner = (int)threadIdx.x * per < nbins;
+            uint32_t mine = 0;
+            if (owner)
+                for (int q = 0; q < per; ++q) mine += hist[threadIdx.x * per + q];
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off);
+                if (lane >= off) incl += up;
+            }
+            uint32_t *wtot = reinterpret_cast<uint32_t *>(&sb.surv_lb[0]);   // 4 wave totals (surv_lb is idle here)
+            if (threadIdx.x == 0) sh.sel_bin = -1;
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            uint32_t before = incl - mine;
+            for (int w2 = 0; w2 < wave; ++w2) before += wtot[w2];
+            if (owner && before < want && before + mine >= want) {
+                uint32_t ac = before;
+                int q = threadIdx.x * per;
+                for (;; ++q) { if (ac + hist[q] >= want) break; ac += hist[q]; }
+                sh.sel_bin = q;
+                sh.sel_before = ac;
+            }
+            __syncthreads();
+            if (sh.sel_bin < 0) all = true;
+            else { prefix |= (uint32_t)sh.sel_bin << shift; want -= sh.sel_before; }
+            __syncthreads();
+        }
+        const uint32_t cut_bits = all ? 0x7f7fffffu : prefix;   // take keys <= cut (ties resolved by the sort below)
+        if (threadIdx.x == 0) sh.nsurv = 0;
+        __syncthreads();
+        for (int J = threadIdx.x; J < a.nt_all; J += STB_THREADS) {
+            const uint32_t kb = __float_as_uint(skey[J]);
+            const float lb = slb[J];
+            const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
+            if (kb < 0x7f800000u && after_done && lb * lb < thrmax && kb <= cut_bits) {
+                const int slot = atomicAdd(&sh.nsurv, 1);
+                if (slot < ST_SURV) { sb.surv_lb[slot] = __uint_as_float(kb); sb.surv_vb[slot] = lb; sb.surv_j[slot] = J; }
+            }
+        }
+        __syncthreads();
+        int ns = min(sh.nsurv, ST_SURV);
+        if (ns == 0) break;
+        {   // sort by (rank key, J): bitonic over ST_SURV slots
+            for (int q = threadIdx.x; q < ST_SURV; q += STB_THREADS)
+                if (q >= ns) { sb.surv_lb[q] = INFINITY; sb.surv_j[q] = 0x7fffffff; }
+            __syncthreads();
+            for (int k2 = 2; k2 <= ST_SURV; k2 <<= 1)
+                for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                    for (int q = threadIdx.x; q < ST_SURV; q += STB_THREADS) {
+                        const int p2 = q ^ j2;
+                        if (p2 > q) {
+                            const bool up = (q & k2) == 0;
+                            const float lq = sb.surv_lb[q], lp = sb.surv_lb[p2];
+                            const int jq = sb.surv_j[q], jp = sb.surv_j[p2];
+                            const bool gt = lq > lp || (lq == lp && jq > jp);
+                            if (gt == up) {
+                                sb.surv_lb[q] = lp; sb.surv_lb[p2] = lq; sb.surv_j[q] = jp; sb.surv_j[p2] = jq;
+                                const float t = sb.surv_vb[q]; sb.surv_vb[q] = sb.surv_vb[p2]; sb.surv_vb[p2] = t;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+        }
+        const bool more = !all;          // the selection was cut at ST_KEEP: later tiles remain
+        if (ns > ST_KEEP && more) ns = ST_KEEP;
+        const uint32_t round_last_bits = __float_as_uint(sb.surv_lb[ns - 1]);
+        const int round_last_j = sb.surv_j[ns - 1];
+        // the round's tiles leave the ring before the stream takes it back
+        for (int q = threadIdx.x; q < ns; q += STB_THREADS) { sh.run_j[q] = sb.surv_j[q]; sh.run_vb[q] = sb.surv_vb[q]; }
+        __syncthreads();   // hist (cand_d) and the sort buffers (ring) are idle again: the stream may run
+        run(ns, [&](int q) { return sh.run_j[q]; }, [&](int q) { return sh.run_vb[q]; });
+        done_bits = round_last_bits;
+        done_j = round_last_j;
+        __syncthreads();
+        if (dried) break;
+        if (processed >= a.max_tiles) break;
+        if (!more) break;   // the selection saw every eligible tile
+    }
+    __syncthreads();
+    // ---- exact re-ranking: the lists hold KL >= K columns chosen by the split-bf16 distance (error ~1e-4 relative on a
+    // neighbour's d^2); their exact float32 distances sum (x - y)^2 decide which K are handed on, and in which order
+    {
+        float *ex = &sh.cand_d[0][0];   // [ST_T][KMAX] exact d^2 (cand_d is idle now; row stride KMAX <= ST_SLAB + 1)
+        for (int q = threadIdx.x; q < ST_T * KL; q += STB_THREADS) {
+            const int row = q / KL, e = q - row * KL;
+            const int32_t cc = sh.list_c[row][e];
+            float d2 = INFINITY;
+            if (cc != 0x7fffffff && sh.list_d[row][e] < INFINITY) {
+                const float4 *x = reinterpret_cast<const float4 *>(a.Rs + (size_t)(grow0 + row) * DIM);
+                const float4 *y = reinterpret_cast<const float4 *>(a.Xs + (size_t)cc * DIM);
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+                for (int t = 0; t < DIM / 4; ++t) {
+                    const float4 u = x[t], v = y[t];
+                    const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z, dw = u.w - v.w;
+                    s0 += dx * dx; s1 += dy * dy; s2 += dz * dz; s3 += dw * dw;
+                }
+                d2 = (s0 + s1) + (s2 + s3);
+            }
+            ex[row * KMAX + e] = d2;
+        }
+        __syncthreads();
+        if (threadIdx.x < ST_T) {   // one thread per row: insertion sort of <= 32 entries by (exact d^2, column)
+            const int row = threadIdx.x;
+            for (int e = 1; e < KL; ++e) {
+                const float d = ex[row * KMAX + e];
+                const int32_t cc = sh.list_c[row][e];
+                int p = e;
+                while (p > 0 && (d < ex[row * KMAX + p - 1] || (d == ex[row * KMAX + p - 1] && cc < sh.list_c[row][p - 1]))) {
+                    ex[row * KMAX + p] = ex[row * KMAX + p - 1];
+                    sh.list_c[row][p] = sh.list_c[row][p - 1];
+                    --p;
+                }
+                ex[row * KMAX + p] = d;
+                sh.list_c[row][p] = cc;
+            }
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < ST_T * K; q += STB_THREADS) {
+            const int row = q / K, e = q - row * K;
+            const float d2 = ex[row * KMAX + e];
+            a.out_d2[((size_t)bt * ST_T + row) * K + e] = d2;
+            a.out_col[((size_t)bt * ST_T + row) * K + e] = d2 < INFINITY ? sh.list_c[row][e] : 0x7fffffff;
+        }
+    }
+    if (threadIdx.x == 0) atomicAdd(a.evals, (unsigned long long)processed);
+#ifdef ST_PROFILE
+    P8(7)
+    if (lane == 0 && a.prof)
+        for (int i = 0; i < 16; ++i) atomicAdd(a.prof + i, (unsigned long long)pf[i]);
+#endif
+}
+
+template <int DIM, int KMAX> static int launchb(annchor_ctx *c, const KnnArgs &a)
+{
+    const size_t lds = sizeof(KnnSharedB<DIM, KMAX>);
+    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "streamed k-NN (8-wave form) needs %zu B of LDS", lds);
+    ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knnbf<DIM, KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_st_knnbf<DIM, KMAX><<<a.tile_count, STB_THREADS, lds, c->stream>>>(a);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
+// The tile phase through the 8-wave split-bf16 kernel when the shape fits it (padded dim <= 128: the ring of four slabs is
+// 16 KB x 4 there; K + ST_BF_MARGIN <= 32 list entries; the split copy of the columns exists); *handled = false sends the
+// caller to the exact-f32 kernel k_st_knn.
+int ann_stream_launch_knnbf(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool *handled)
+{
+    *handled = true;
+    if (a.K + ST_BF_MARGIN > ST_KMAX || !a.Xb) { *handled = false; return ANNCHOR_OK; }
+    const bool k16 = a.K + ST_BF_MARGIN <= 16;
+    switch (dim_padded) {
+    case 32: return k16 ? launchb<32, 16>(c, a) : launchb<32, ST_KMAX>(c, a);
+    case 64: return k16 ? launchb<64, 16>(c, a) : launchb<64, ST_KMAX>(c, a);
+    case 128: return k16 ? launchb<128, 16>(c, a) : launchb<128, ST_KMAX>(c, a);
+    default: *handled = false; return ANNCHOR_OK;
+    }
+}
+

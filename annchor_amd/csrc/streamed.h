@@ -106,6 +106,7 @@ StreamState *ann_stream_state(annchor_ctx *c, bool create);
 // knn8.hip: the tile phase on the bf16 matrix cores (split operands, one 512-thread workgroup per CU); *handled = false
 // when the shape does not fit it (padded dim > 128, more than 30 neighbours, no split copy) and the caller launches k_st_knn
 int ann_stream_launch_knn8(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled);
+int ann_stream_launch_knnbf(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled);   // knnbf.hip: 4-wave form
 int ann_stream_split_rows(annchor_ctx *c, StreamState *s);     // Xb from Xs (after the ordering)
 const void *ann_stream_split_of(const void *Xs);               // the split copy that belongs to an ordered float32 array, or NULL
 int ann_stream_reserve(annchor_ctx *c, DevBuf &b, size_t bytes);   // individual allocation, grow-only, contents NOT kept

@@ -1475,11 +1475,12 @@ template <int DIM> static int launch_knn(annchor_ctx *c, const KnnArgs &a, bool 
 static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool join)
 {
     if (!join) {
-        // ANNCHOR_ST_KERNEL=4wave: the two-workgroups-per-CU kernel below for every shape (A/B runs, tests)
-        static const bool four = getenv("ANNCHOR_ST_KERNEL") && !strcmp(getenv("ANNCHOR_ST_KERNEL"), "4wave");
-        if (!four) {
+        // ANNCHOR_ST_KERNEL: bf4 (default; knnbf.hip) | bf8 (knn8.hip) | 4wave (the exact-f32 kernel below for every shape)
+        static const char *kern = getenv("ANNCHOR_ST_KERNEL");
+        if (!kern || strcmp(kern, "4wave")) {
             bool handled = false;
-            ANN_TRY(ann_stream_launch_knn8(c, a, dim_padded, &handled));
+            if (kern && !strcmp(kern, "bf8")) ANN_TRY(ann_stream_launch_knn8(c, a, dim_padded, &handled));
+            else ANN_TRY(ann_stream_launch_knnbf(c, a, dim_padded, &handled));
             if (handled) return ANNCHOR_OK;
         }
     }

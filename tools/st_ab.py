@@ -29,7 +29,7 @@ def child(n):
     rows = np.sort(np.random.default_rng(99).choice(n, 10000, replace=False))
     ti, td = sa.query(X[rows], nn=k, p_work=1.0)
     err = compare_neighbor_graphs((ti, td), (sa.neighbor_graph[0][rows], sa.neighbor_graph[1][rows]), k)
-    print(json.dumps(dict(kernel=os.environ.get("ANNCHOR_ST_KERNEL", "8wave"), n=n, runs=res, recall=1 - err / (10000.0 * k))), flush=True)
+    print(json.dumps(dict(kernel=os.environ.get("ANNCHOR_ST_KERNEL", "bf4"), n=n, runs=res, recall=1 - err / (10000.0 * k))), flush=True)
 
 
 if __name__ == "__main__":
@@ -37,6 +37,6 @@ if __name__ == "__main__":
         child(int(sys.argv[2]))
     else:
         n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-        for kern in ("8wave", "4wave"):
+        for kern in (sys.argv[2:] or ["bf4", "bf8", "4wave"]):
             env = dict(os.environ, ANNCHOR_ST_KERNEL=kern)
             subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n)], env=env)
