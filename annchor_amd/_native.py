@@ -100,6 +100,7 @@ _SIGNATURES = {
                                                 ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
     "annchor_stream_knn_join": (ctypes.c_int, [_vp, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
     "annchor_stream_last_counts": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "annchor_stream_last_kernel": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
     "annchor_stream_budget": (ctypes.c_int, [_i32, _dbl, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "annchor_stream_knn_end": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "annchor_stream_query": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _dbl, _vp, _vp,
@@ -238,16 +239,26 @@ def stream_budget(n_tiles, p_work, join_passes):
     return T.value, tp.value, pp.value
 
 
+# A stream is produced AHEAD of its draw only up to this many 32-bit words (1 GB): the ahead-of-time size is a bound from the
+# point count (1.5 x nx (nx - 1) / 2 -- 7.5 x 10^9 words for the thinned lists of 10^5 points, most of which the draw would never
+# read); beyond it the draw itself generates what it consumes, sized from the real bin populations (annchor_legacy_choice_ranks).
+LEGACY_EAGER_MAX_DRAWS = 1 << 28
+
+
 def legacy_prefetch(seed, ndraws):
     """Begin producing the legacy MT19937 stream of `seed` on a background thread."""
-    if 0 <= seed < 2 ** 32 and ndraws > 0:
-        load_library().annchor_legacy_prefetch(int(seed), int(ndraws))
+    if 0 <= seed < 2 ** 32 and 0 < ndraws <= LEGACY_EAGER_MAX_DRAWS:
+        rc = load_library().annchor_legacy_prefetch(int(seed), int(ndraws))
+        if rc != 0:
+            raise NativeError("annchor_legacy_prefetch failed (%d)" % rc)
 
 
 def legacy_generate(seed, ndraws):
     """Produce the legacy MT19937 stream of `seed` on the calling thread (returns when it is there)."""
-    if 0 <= seed < 2 ** 32 and ndraws > 0:
-        load_library().annchor_legacy_generate(int(seed), int(ndraws))
+    if 0 <= seed < 2 ** 32 and 0 < ndraws <= LEGACY_EAGER_MAX_DRAWS:
+        rc = load_library().annchor_legacy_generate(int(seed), int(ndraws))
+        if rc != 0:
+            raise NativeError("annchor_legacy_generate failed (%d)" % rc)
 
 
 def legacy_choice_ranks(seed, counts, want):
@@ -790,6 +801,12 @@ class Engine:
         a, b = _i64(), _i64()
         self._chk(self.lib.annchor_stream_last_counts(self.h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def stream_last_kernel(self):
+        """Kernel of the last build's tile phase: 0 exact float32 tile GEMMs, 1 split-bf16 (4-wave), 2 split-bf16 (8-wave)."""
+        k = ctypes.c_int32()
+        self._chk(self.lib.annchor_stream_last_kernel(self.h, ctypes.byref(k)))
+        return int(k.value)
 
     def stream_join_tables(self, gathered, world, n_anchors, n_tiles, joined):
         self._chk(self.lib.annchor_stream_join_tables(self.h, gathered, int(world), int(n_anchors), int(n_tiles), joined))

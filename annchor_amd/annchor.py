@@ -43,6 +43,13 @@ PAIRLIST_HARD_MAX = None      # override (tests); None: from the device -- 2^30 
 
 
 PAIRLIST_BITMAP_MAX_POINTS = 400000   # keep bitmap + rank table: 12 B per 64 pairs = 30 GB here
+# sampler=None: from this many candidate pairs (nx (nx - 1) / 2: 2829 points) the order-free DeviceStratifiedSampler draws on the GPU;
+# below it the NumPy-stream SimpleStratifiedSampler (graphs bit-identical to the CPU restatement's in tests/).  The reference's own draw
+# (samplers.py:75-140, utils.py:543-578) runs numba's RNG inside njit -- a stream nobody reproduces -- so beyond the sizes whose
+# graphs the tests pin to the NumPy stream there is nothing to be bit-equal to, and walking a stream as long as the pair list
+# on one host thread dominates the fit (N = 16 000: 178 of 193 ms).  sampler="legacy" / "device" force either.
+DEVICE_SAMPLER_MIN_PAIRS = 4_000_000
+DEVICE_MODEL_MAX_PER_BIN = 6144   # samples per partition up to which the iteration's models are fitted on the device (model.hip: ERR_CAP 8192)
 
 
 def pairlist_hard_max(device=0):
@@ -185,7 +192,19 @@ class Annchor:
         self.N, self.na, self.p_work = b["N"], b["na"], b["p_work"]
 
         self.anchor_picker = MaxMinAnchorPicker() if anchor_picker is None else anchor_picker
-        self.sampler = SimpleStratifiedSampler() if sampler is None else sampler
+        if isinstance(sampler, str) and sampler not in ("auto", "legacy", "device"):
+            raise ValueError("sampler must be a Sampler object, None / 'auto', 'legacy' (SimpleStratifiedSampler) or 'device' "
+                             "(DeviceStratifiedSampler)")
+        sampler_auto = sampler is None or (isinstance(sampler, str) and sampler == "auto")
+        if sampler_auto or sampler == "legacy":
+            sampler_obj = SimpleStratifiedSampler()   # (auto: replaced below for large pair lists)
+        elif isinstance(sampler, str):
+            sampler_obj = DeviceStratifiedSampler()
+        else:
+            sampler_obj = sampler
+        self.sampler = sampler_obj
+        if isinstance(sampler, str):
+            sampler = None   # the string forms are the built-in samplers: "default plugins" below
         self.regression = SimpleStratifiedLinearRegression() if regression is None else regression
         self.error_predictor = SimpleStratifiedErrorRegression() if error_predictor is None else error_predictor
 
@@ -246,6 +265,11 @@ class Annchor:
                   "filter (locality=%d, loc_thresh=%d) keeps fewer than 2^30 candidate pairs." % (self.nx, hard_max, locality, loc_thresh),
                   file=sys.stderr)
             self._pairlist_hard_max = hard_max = self.nx
+        if sampler_auto and not want_stream and self.N >= DEVICE_SAMPLER_MIN_PAIRS:
+            self.sampler = DeviceStratifiedSampler()
+            print("Note: %d candidate pairs: the samples are drawn by the order-free DeviceStratifiedSampler on the GPU (the same "
+                  "stratified draw as samplers.py:75-140 with a hashed choice instead of the host's sequential NumPy-stream "
+                  "shuffle of the whole pair list; sampler='legacy' keeps that one)." % self.N)
         if want_stream:
             from .streamed import StreamedAnnchor
 
@@ -397,12 +421,28 @@ class Annchor:
         in between is the reference's default: device metric, the built-in stratified sampler / regression / error
         model on the double anchor distance, and ols='device'."""
         return (self._pipelined and self._device_metric and self.ols == "device" and self._sampler_on_device()
+                and not self.__dict__.get("_device_models_off", False)
                 and type(self.sampler) in (SimpleStratifiedSampler, DeviceStratifiedSampler)
                 and type(self.regression) is SimpleStratifiedLinearRegression
                 and list(self.regression.reg_feature_names) == ["lower bound", "upper bound", "double anchor distance"]
                 and self.regression.partition_feature_name == "double anchor distance"
                 and type(self.error_predictor) is SimpleStratifiedErrorRegression
                 and self.error_predictor.partition_feature_name == "double anchor distance")
+
+    def _device_model_takes(self, ticket):
+        """Limits of csrc/model.hip, checked on the sampling step's own numbers (bin populations and quotas are on the
+        host by now): at least 3 samples in every partition (fewer rows than columns: dgelsd's minimum-norm answer is the
+        host's) and at most DEVICE_MODEL_MAX_PER_BIN -- the residual sorter holds ERR_CAP = 8192 per partition, and a sample
+        on a bin edge belongs to two error partitions (error_predictors.py:50-52: closed on both sides)."""
+        if ticket.get("error") is not None or "counts" not in ticket:
+            return True   # (finish_device raises / nothing to judge)
+        P = self.sampler.n_partitions
+        n = int(ticket["n_samples"])
+        want = ticket.get("want")
+        if want is None:
+            want = n // P + (np.arange(P) < n % P)
+        per_bin = np.minimum(np.asarray(ticket["counts"], dtype=np.int64), np.asarray(want, dtype=np.int64))
+        return bool(per_bin.min() >= 3 and per_bin.max() <= DEVICE_MODEL_MAX_PER_BIN)
 
     # --------------------------------------------------------------------- stages
     def _pair_list_stage(self, what):
@@ -456,6 +496,10 @@ class Annchor:
             ticket, self._sample_ticket = self._sample_ticket, None
             if ticket is None:
                 ticket = self.sampler.begin_device(eng, self.n_samples, self.random_seed, overlap=False)
+            if self._models_on_device() and not self._device_model_takes(ticket):
+                # decided BEFORE the iteration: the models of this fit are fitted on the host (the device kernels would only raise
+                # their flags at the end and the whole fit would start over)
+                self._device_models_off = True
             if self._models_on_device():   # ... and everything stays there: the models are fitted on the device
                 _, self.n_samples, self.sample_bins = self.sampler.finish_device(ticket, evaluate="device")
                 self._samples_on_device, self._samples_m, self._predict_on_device = True, self.n_samples, False
@@ -655,6 +699,7 @@ class Annchor:
 
         evals0, loop0, n_samples0 = self.evals, getattr(self.sampler, "loop_num", None), self.n_samples
         self._pipelined = True
+        self._device_models_off = False
         try:
             try:
                 return self._fit_stages(stage, make_stream, t, origin)

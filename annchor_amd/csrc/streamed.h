@@ -53,6 +53,7 @@ struct StreamState {
     DevBuf rev_cnt, rev_ptr, rev_edges, rev;   // reverse neighbour lists of every ordered row (join passes)
     int64_t n_local = 0, n_pad = 0, base = 0;
     int64_t last_tile_evals = 0, last_join_chunks = 0;
+    int last_kernel = 0;   // tile phase of the last build: 0 k_st_knn (exact f32), 1 k_st_knnbf, 2 k_st_knn8 (split bf16)
     int dim = 0, dimp = 0, na = 0, nt = 0;
     struct KnnArgs *run = nullptr;   // arguments of the graph build in progress (begin / join / end)
     const void *run_perm = nullptr;

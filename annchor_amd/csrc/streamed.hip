@@ -1477,11 +1477,17 @@ static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool 
     if (!join) {
         // ANNCHOR_ST_KERNEL: bf4 (default; knnbf.hip) | bf8 (knn8.hip) | 4wave (the exact-f32 kernel below for every shape)
         static const char *kern = getenv("ANNCHOR_ST_KERNEL");
+        StreamState *st = state_of(c, false);
+        if (st) st->last_kernel = 0;
         if (!kern || strcmp(kern, "4wave")) {
             bool handled = false;
-            if (kern && !strcmp(kern, "bf8")) ANN_TRY(ann_stream_launch_knn8(c, a, dim_padded, &handled));
+            const bool eight = kern && !strcmp(kern, "bf8");
+            if (eight) ANN_TRY(ann_stream_launch_knn8(c, a, dim_padded, &handled));
             else ANN_TRY(ann_stream_launch_knnbf(c, a, dim_padded, &handled));
-            if (handled) return ANNCHOR_OK;
+            if (handled) {
+                if (st) st->last_kernel = eight ? 2 : 1;
+                return ANNCHOR_OK;
+            }
         }
     }
     switch (dim_padded) {
@@ -1689,6 +1695,15 @@ int ann_stream_knn_finish(annchor_ctx *c, StreamState *s, KnnArgs &a, const void
 }
 
 // tile evaluations of the last build's tile phase and 128-column runs of its join passes
+extern "C" int annchor_stream_last_kernel(annchor_ctx *c, int32_t *kind)
+{
+    if (!c || !kind) return ANNCHOR_EINVAL;
+    StreamState *s = state_of(c, false);
+    ANN_REQUIRE(c, s != nullptr, ANNCHOR_ESTATE, "no streamed build on this context");
+    *kind = s->last_kernel;
+    return ANNCHOR_OK;
+}
+
 extern "C" int annchor_stream_last_counts(annchor_ctx *c, int64_t *tile_phase_evals, int64_t *join_chunks)
 {
     if (!c || !tile_phase_evals || !join_chunks) return ANNCHOR_EINVAL;

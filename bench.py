@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 INT32_VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # 78.6 T lane-ops/s (256 CUs x 4 SIMD32 x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md; measured 2495)
 LEV_OPS_PER_WORD_STEP = 17  # Myers/Hyyro recurrence, 32-bit ops per (pattern word x text symbol)
 
 
@@ -96,14 +97,16 @@ def pairlist_at_scale(local, n=16000):
                       "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
     res = _scale_result(ann, n, dt, fams)
     res["pmc_source"] = scale_pmc_fractions(fams)
+    res["sampler"] = type(ann.sampler).__name__ + " (the default at this size: sampler=None)"
     ann._engine.close()   # ~10 GB of device arena: release it now, not whenever the collector runs
-    from annchor_amd.samplers import DeviceStratifiedSampler
-
-    Annchor(X, "euclidean", device=local, sampler=DeviceStratifiedSampler(), **cfg).fit()   # warm (the 10 GB arena is re-created)
-    ann = Annchor(X, "euclidean", device=local, sampler=DeviceStratifiedSampler(), **cfg)
+    # the same fit with the NumPy-stream sampler forced (the default below 4 M candidate pairs): its host-side shuffle of the
+    # whole pair list is what the automatic choice avoids
+    Annchor(X, "euclidean", device=local, sampler="legacy", **cfg).fit()   # warm (the 10 GB arena is re-created)
+    ann = Annchor(X, "euclidean", device=local, sampler="legacy", **cfg)
     t = time.perf_counter()
     ann.fit()
-    res["fit_time_s_device_sampler_plugin"] = time.perf_counter() - t
+    res["fit_time_s_legacy_sampler"] = time.perf_counter() - t
+    res["host_stage_ms_legacy_sampler"] = {k: round(v * 1e3, 1) for k, v in ann.timings.items()}
     ann._engine.close()
     return res
 
@@ -115,34 +118,48 @@ def levenshtein_100k_block(local, n=100000, k=15):
     evaluated; recall against the exact rows of 100 points (one-to-all launches of the same metric kernel)."""
     from annchor_amd import Annchor, compare_neighbor_graphs
     from annchor_amd.datasets import synthetic_string_clusters
-    from annchor_amd.samplers import DeviceStratifiedSampler
-
     X = synthetic_string_clusters(n)
     cfg = dict(n_anchors=60, n_neighbors=k, p_work=0.02, n_samples=5000, locality=5, loc_thresh=3)
     # two fits: the first of the process also pays for ~50 GB of first-time device allocations (0.01-1.3 s on a fresh box,
     # depending on what the device was doing before); the second, what a process that fits repeatedly sees, is the one reported
     first = None
     for rep in range(2):
-        ann = Annchor(X, "levenshtein", device=local, sampler=DeviceStratifiedSampler(), **cfg)
+        ann = Annchor(X, "levenshtein", device=local, **cfg)   # (default sampler: DeviceStratifiedSampler at this size)
         t = time.perf_counter()
         ann.fit()
         dt = time.perf_counter() - t
         if rep == 0:
             first = dt
             ann._engine.close()
-    rows = np.random.default_rng(5).choice(n, 100, replace=False)
+    # recall on 1000 rows: exact rows from one-to-all launches of the metric kernel; 20 of those rows re-computed with the CPU
+    # oracle's C Levenshtein (oracle/lev.c) so that the truth does not rest on the kernel under test alone
+    rows = np.random.default_rng(5).choice(n, 1000, replace=False)
     err = 0
     z = np.zeros((1, k), dtype=np.int64)
+    exact_rows = {}
     for r in rows:
         d = ann._engine.metric_pairs(np.stack([np.full(n, r), np.arange(n)], axis=1))
+        if len(exact_rows) < 20:
+            exact_rows[int(r)] = d.copy()
         d[r] = -1
         want = np.sort(d)[:k]
         want[0] = 0
         err += compare_neighbor_graphs((z, want[None, :]), (z, ann.neighbor_graph[1][r][None, :]), k)
+    oracle_check = None
+    try:
+        from oracle import metrics as om
+
+        P = om.PackedStrings(list(X))
+        bad = 0
+        for r, d in exact_rows.items():
+            bad += int(np.sum(P.pairs(np.stack([np.full(n, r), np.arange(n)], axis=1)) != d))
+        oracle_check = {"rows": len(exact_rows), "mismatching_distances": bad}
+    except Exception as e:   # never at the cost of the line
+        oracle_check = {"error": "%s: %s" % (type(e).__name__, e)}
     res = {"workload": "synthetic clustered strings (length ~120) Levenshtein N=%d n_anchors=60 k=%d p_work=0.02 locality=5 loc_thresh=3, "
-                       "sampler=DeviceStratifiedSampler() (pair-list form, candidate list thinned by the locality filter)" % (n, k),
+                       "default plugins (pair-list form, candidate list thinned by the locality filter)" % (n, k),
            "fit_time_s": dt, "first_fit_time_s": first, "candidate_pairs": int(ann.n_pairs), "evals": int(ann.evals),
-           "recall_at_k": 1.0 - err / (len(rows) * k), "recall_rows": int(len(rows)),
+           "recall_at_k": 1.0 - err / (len(rows) * k), "recall_rows": int(len(rows)), "truth_rows_checked_against_oracle_lev_c": oracle_check,
            "note": "beyond 46 341 points the complete pair list (2^30 candidates) no longer fits; fit_time_s = second fit of the "
                    "process (device blocks of the first are reused), first_fit_time_s includes the first-time allocations"}
     ann._engine.close()
@@ -205,8 +222,8 @@ def _scale_result(ann, n, dt, fams):
     return {"workload": "synthetic Euclidean f64 N=%d d=48 n_anchors=24 k=15 p_work=0.05 (pair-list form)" % n,
             "pairs": int(ann.n_pairs), "evals": int(ann.evals), "fit_time_s_profiled": dt,
             "host_stage_ms": {k: round(v * 1e3, 1) for k, v in ann.timings.items()}, "kernels": fams,
-            "note": "fit time at this size is the default sampler's host-side NumPy-stream shuffle (get_sample); the table is the device "
-                    "kernels; fit_time_s_device_sampler_plugin = the same fit with the order-free DeviceStratifiedSampler"}
+            "note": "default arguments: from 4 M candidate pairs sampler=None is the order-free DeviceStratifiedSampler (GPU draw); "
+                    "fit_time_s_legacy_sampler = the same fit with sampler='legacy' (NumPy-stream shuffle of the pair list on one host thread)"}
 
 
 def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, recall_rows=10000):
@@ -283,12 +300,27 @@ def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, r
             tile_phase_evals, join_chunks = last._engine.stream_last_counts()
             out["join_chunks_rank0"] = int(join_chunks)
             flops = tile_phase_evals * 128.0 * 128.0 * 2.0 * 128.0
-            out["roofline"] = {"kernel": "stream_tile_gemm_topk (k_st_knn, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
-                               "achieved": flops / gemm_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                               "frac": flops / gemm_s / 1e12 / 157.3, "traffic": pmc_traffic("k_st_knn"),
-                               "tile_pairs": int(tile_phase_evals),
-                               "note": "algorithmic flops = tile pairs of the tile phase (<= its budget x row tiles of rank 0) "
-                                       "x 128 x 128 x 2 x d; peak = dense f32 MFMA"}
+            kind = last._engine.stream_last_kernel()
+            if kind == 0:
+                out["roofline"] = {"kernel": "stream_tile_gemm_topk (k_st_knn, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                                   "achieved": flops / gemm_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                                   "frac": flops / gemm_s / 1e12 / 157.3, "traffic": pmc_traffic("k_st_knn<"),
+                                   "tile_pairs": int(tile_phase_evals),
+                                   "note": "algorithmic flops = tile pairs of the tile phase (<= its budget x row tiles of rank 0) "
+                                           "x 128 x 128 x 2 x d; peak = dense f32 MFMA"}
+            else:
+                name = "k_st_knnbf" if kind == 1 else "k_st_knn8"
+                out["roofline"] = {"kernel": "stream_tile_gemm_topk (%s: split-bf16 tile GEMMs, 3 x v_mfma_f32_32x32x16_bf16 per 16 dimensions)" % name,
+                                   "bound": "mfma", "achieved": 3.0 * flops / gemm_s / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": 3.0 * flops / gemm_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(name),
+                                   "tile_pairs": int(tile_phase_evals),
+                                   "f32_equivalent": {"achieved": flops / gemm_s / 1e12, "unit": "TFLOP/s",
+                                                      "of_the_f32_mfma_peak_157.3": flops / gemm_s / 1e12 / 157.3},
+                                   "note": "achieved = MFMA flops issued: every float is split into bf16 hi + lo and a dot product is "
+                                           "hi.hi + hi.lo + lo.hi, i.e. 3 x (tile pairs x 128 x 128 x 2 x d); peak = dense bf16 MFMA "
+                                           "(MI355X_MICROARCH.md: ~2.5 PFLOP/s).  The split products select K + 2 columns per row; their "
+                                           "exact float32 distances decide the K that are kept, so the graph is the exact-f32 kernel's "
+                                           "(f32_equivalent = the algorithmic f32 flops of the same tile pairs / the same time)"}
     last._engine.close()
     return out
 
@@ -801,7 +833,8 @@ def main():
             "value": res["graphs_per_s"], "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["fit_time_s"] * 1e3, "fit_time_s": res["fit_time_s"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (MFMA tile GEMM v_mfma_f32_32x32x2_f32; reported distances recomputed in f64 from the f32 rows)",
+            "dtype": "f32 rows; tile selection on bf16 hi + lo split operands with f32 accumulation (v_mfma_f32_32x32x16_bf16), the kept "
+                     "columns re-ranked by exact f32 distances; reported distances exact f32, widened to f64",
             "data": "synthetic (SURVEY.md 8d recipe: 8-d latent manifold in 128-d, float32), generated per shard",
             "config": {"workload": res["workload"], "total_rows": n_per_rank * world, "baseline_quoted_on": quoted,
                        "parallelism": "one GPU" if world == 1 else

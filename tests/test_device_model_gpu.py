@@ -133,3 +133,30 @@ def test_host_waits_per_c2_fit():
     fit = lines[lines.index("=== fit") + 1:lines.index("=== end")]
     waits = [ln for ln in fit if ln.startswith("sync ")]
     assert len(waits) <= 8, fit
+
+
+def test_many_samples_take_the_host_models_before_the_iteration(monkeypatch):
+    """More samples per partition than the device's residual sorter holds (ERR_CAP = 8192): decided from the sampling step's
+    own numbers BEFORE the iteration -- the models of that fit are fitted on the host -- instead of running the whole fit
+    on unsorted residual lists and starting over.  Same graph as ols='lapack'; and with the limit lowered so that the
+    C2 configuration trips it, no restart happens either."""
+    import annchor_amd.annchor as A
+    from annchor_amd import Annchor
+
+    X = _strings()
+    cfg = dict(n_anchors=10, n_neighbors=15, n_samples=60000, p_work=0.2, random_seed=42)
+    a = Annchor(X, "levenshtein", **cfg)
+    restarts = []
+    orig = A.Annchor._fit_stages
+    monkeypatch.setattr(A.Annchor, "_fit_stages", lambda self, *args: (restarts.append(1), orig(self, *args))[1])
+    a.fit()
+    b = Annchor(X, "levenshtein", ols="lapack", **cfg).fit()
+    assert a._device_models_off and not a.__dict__.get("_model_on_device")
+    assert len(restarts) == 2   # one pass through the stages per fit: no restart
+    assert np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0]) and np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1])
+    monkeypatch.setattr(A, "DEVICE_MODEL_MAX_PER_BIN", 500)
+    del restarts[:]
+    c = Annchor(X, "levenshtein", n_anchors=15, n_neighbors=25, p_work=0.12, random_seed=42).fit()   # 5000 samples: 715 per bin
+    d = Annchor(X, "levenshtein", n_anchors=15, n_neighbors=25, p_work=0.12, random_seed=42, ols="lapack").fit()
+    assert c._device_models_off and len(restarts) == 2
+    assert np.array_equal(c.neighbor_graph[1], d.neighbor_graph[1])

@@ -139,7 +139,8 @@ def test_device_nearest_enemies_20000_points():
     lab = rng.integers(0, 12, n)
     X = (cent[lab] + rng.standard_normal((n, 16))).astype(np.float64)
     y = lab % 3                                        # three labels, four blobs each
-    ann = Annchor(X, "euclidean", n_anchors=20, n_neighbors=10, p_work=0.03, sampler=DeviceStratifiedSampler()).fit()
+    ann = Annchor(X, "euclidean", n_anchors=20, n_neighbors=10, p_work=0.03).fit()   # default arguments
+    assert type(ann.sampler) is DeviceStratifiedSampler   # (2 x 10^8 candidate pairs: the automatic choice)
     ni, nd = ann.get_nearest_enemies(y, nn=3) or ann.nearest_enemy_graph
     assert ni.shape == (n, 3) and np.all(y[ni] != y[:, None]) and np.all(np.diff(nd, axis=1) >= 0)
     rows = rng.choice(n, 400, replace=False)

@@ -654,7 +654,7 @@ def test_fit_digits_c4():
     np.testing.assert_allclose(ann.D, G["c4_D"], rtol=0, atol=1e-12)
     assert ann.evals == int(G["c4_evals"])
     err = compare_neighbor_graphs(d["neighbor_graph"], ann.neighbor_graph, 25)
-    assert err <= 10, err  # reference run: 7 of 44 925; reference test bar: < 10
+    assert err <= 7, err  # no worse than the reference's own run here: 7 of 44 925 (measured: 4); reference test bar: < 10
     # every reported distance within 1e-9 of the exact EMD of the reported neighbour
     idx, dist = ann.neighbor_graph
     IJ = np.stack([np.repeat(np.arange(1797), 24), idx[:, 1:].ravel()], axis=1)

@@ -304,11 +304,15 @@ def test_device_stratified_sampler_fit_matches_oracle_and_quality():
 
 def test_device_stratified_sampler_error_distribution_matches_the_legacy_sampler():
     """The order-free draw must be statistically the same sampler as the reference's (samplers.py:75-140,
-    utils.py:543-578): over 12 seeds at BASELINE configs[1] (15 anchors) and at the README configuration (20 anchors)
-    the error counts of the two samplers against brute force come from the same distribution.  (One seed says
-    nothing: at 15 anchors the count moves between ~30 and ~650 of 40 000 with the seed for EITHER sampler --
-    measured with the oracle, 12 seeds: legacy median 132 / max 346, hashed median 81 / max 639; the reference's own
-    run at seed 42: 504.  README configuration: legacy median 10, hashed 9; reference run: 0.)"""
+    utils.py:543-578): over 24 seeds at BASELINE configs[1] (15 anchors) and at the README configuration (20 anchors)
+    the error counts of the two samplers against brute force come from the same distribution -- a two-sample criterion:
+    the device sampler's median is at most 1.15 x the legacy median + 10, and a one-sided Mann-Whitney rank-sum test does
+    not reject "device errors are not larger" at p = 0.01.  (One seed says nothing: at 15 anchors the count moves between
+    ~30 and ~650 of 40 000 with the seed for EITHER sampler -- measured with the oracle, 12 seeds: legacy median 132 /
+    max 346, hashed median 81 / max 639; the reference's own run at seed 42: 504.  README configuration: legacy median
+    10, hashed 9; reference run: 0.)"""
+    from scipy.stats import mannwhitneyu
+
     from annchor_amd import Annchor, compare_neighbor_graphs
     from annchor_amd.samplers import DeviceStratifiedSampler
     from oracle import metrics as om
@@ -316,14 +320,57 @@ def test_device_stratified_sampler_error_distribution_matches_the_legacy_sampler
     X = np.array(om.load_strings()[0])
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "strings_full.npz"))
     truth = (G["truth_idx"].astype(np.int64), G["truth_dist"].astype(np.float64))
-    seeds = range(42, 54)
-    for na, ref_run, slack in ((15, 504, 150), (20, 0, 15)):
+    seeds = range(42, 66)
+    for na in (15, 20):
         e_leg, e_dev = [], []
         for s in seeds:
             cfg = dict(n_anchors=na, n_neighbors=25, p_work=0.12, random_seed=s)
             e_leg.append(compare_neighbor_graphs(truth, Annchor(X, "levenshtein", **cfg).fit().neighbor_graph, 25))
             e_dev.append(compare_neighbor_graphs(truth, Annchor(X, "levenshtein", sampler=DeviceStratifiedSampler(), **cfg).fit().neighbor_graph, 25))
-        print("n_anchors=%d legacy %s\n             device %s" % (na, e_leg, e_dev))
-        assert np.median(e_dev) <= max(ref_run, np.median(e_leg) + slack), (e_leg, e_dev)
-        assert np.median(e_dev) <= 1.5 * np.median(e_leg) + slack
-        assert np.mean(e_dev) <= 1.5 * np.mean(e_leg) + slack
+        p_larger = mannwhitneyu(e_dev, e_leg, alternative="greater").pvalue
+        print("n_anchors=%d legacy %s\n             device %s\n             medians %g / %g, P(device > legacy by chance) = %.3f"
+              % (na, e_leg, e_dev, np.median(e_leg), np.median(e_dev), p_larger))
+        assert np.median(e_dev) <= 1.15 * np.median(e_leg) + 10, (e_leg, e_dev)
+        assert p_larger > 0.01, (p_larger, e_leg, e_dev)
+
+
+def test_default_sampler_by_size(capsys):
+    """sampler=None: the NumPy-stream sampler below DEVICE_SAMPLER_MIN_PAIRS candidate pairs (graphs bit-identical to the CPU
+    oracle's, pinned elsewhere), the order-free DeviceStratifiedSampler from there on, announced on stdout; the string forms
+    force either.  N = 16 000 Euclidean points (1.3 x 10^8 pairs) with DEFAULT arguments: recall against brute force, and the
+    fit no longer waits for a host-side shuffle of the pair list."""
+    import time
+
+    from annchor_amd import Annchor, BruteForce, compare_neighbor_graphs
+    from annchor_amd.annchor import DEVICE_SAMPLER_MIN_PAIRS
+    from annchor_amd.samplers import DeviceStratifiedSampler, SimpleStratifiedSampler
+
+    rng = np.random.default_rng(5)
+    small = rng.standard_normal((500, 8))
+    assert type(Annchor(small, "euclidean", n_anchors=5, n_neighbors=5, n_samples=300).sampler) is SimpleStratifiedSampler
+    assert type(Annchor(small, "euclidean", n_anchors=5, n_neighbors=5, n_samples=300, sampler="device").sampler) is DeviceStratifiedSampler
+    with pytest.raises(ValueError):
+        Annchor(small, "euclidean", sampler="numpy")
+    n = 16000
+    assert n * (n - 1) // 2 >= DEVICE_SAMPLER_MIN_PAIRS
+    Z = rng.standard_normal((n, 6))
+    X = (Z @ rng.standard_normal((6, 48)) + 0.05 * rng.standard_normal((n, 48))).astype(np.float64)
+    cfg = dict(n_anchors=24, n_neighbors=15, p_work=0.05, n_samples=5000)
+    capsys.readouterr()
+    a = Annchor(X, "euclidean", **cfg)
+    assert type(a.sampler) is DeviceStratifiedSampler and "DeviceStratifiedSampler" in capsys.readouterr().out
+    assert type(Annchor(X, "euclidean", sampler="legacy", **cfg).sampler) is SimpleStratifiedSampler
+    a.fit()
+    b = Annchor(X, "euclidean", **cfg)
+    t = time.perf_counter()
+    b.fit()
+    dt = time.perf_counter() - t
+    rows = np.sort(rng.choice(n, 500, replace=False))
+    d = np.sqrt(np.maximum((X[rows] ** 2).sum(1)[:, None] + (X ** 2).sum(1)[None, :] - 2.0 * X[rows] @ X.T, 0.0))
+    d[np.arange(len(rows)), rows] = 0.0
+    want = np.sort(d, axis=1)[:, :15]
+    err = compare_neighbor_graphs((b.neighbor_graph[0][rows], want), (b.neighbor_graph[0][rows], b.neighbor_graph[1][rows]), 15)
+    print("N=16000 default fit %.1f ms, %d errors of %d" % (dt * 1e3, err, 15 * len(rows)))
+    assert err <= 0.01 * 15 * len(rows), err
+    assert dt < 0.1, dt   # (193 ms with the host-side shuffle; ~28 ms with the GPU draw)
+    a._engine.close(); b._engine.close()
