@@ -168,7 +168,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
     }
     if (threadIdx.x < 8) { sh.wave_ins[threadIdx.x >> 2][threadIdx.x & 3] = 0; sh.wave_thr[threadIdx.x >> 2][threadIdx.x & 3] = INFINITY; }
     if (threadIdx.x == 0) sh.nsurv = 0;
-    int ins = 0;         // list insertions by this lane's row (lanes < 32)
+    int ins = 0;         // list insertions counted by this lane (the first lane of a merge group)
     int processed = 0;   // column tiles scheduled so far (uniform)
     int tdone = 0;       // column tiles completed and published (uniform); tile n publishes into slot n & 1
     int win_start = 0, win_ins = 0;
@@ -278,31 +278,59 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
         PS(11)   // survivor inserts
         wave_fence_lds();
         P8(3)
-        if (lane < 32) {
-            const int row = rowbase + lane;
-            const int nc = sh.cnt[row];
-            if (nc) {
-                const int32_t col0 = (int32_t)(J * ST_T + slab * ST_SLAB);
-                for (int q = 0; q < nc; ++q) {
-                    const float d = sh.cand_d[row][q];
-                    const int32_t cc = col0 + sh.cand_c[row][q];
-                    // insertion by (d, col); the list is padded with +inf
-                    if (d < sh.list_d[row][KL - 1] || (d == sh.list_d[row][KL - 1] && cc < sh.list_c[row][KL - 1])) {
-                        int p = KL - 1;
-                        while (p > 0 && (d < sh.list_d[row][p - 1] || (d == sh.list_d[row][p - 1] && cc < sh.list_c[row][p - 1]))) {
-                            sh.list_d[row][p] = sh.list_d[row][p - 1];
-                            sh.list_c[row][p] = sh.list_c[row][p - 1];
-                            --p;
-                        }
-                        sh.list_d[row][p] = d;
-                        sh.list_c[row][p] = cc;
-                        ins += p < K;   // the yield that stops the tile phase counts what reaches the K entries handed on
-                    }
+        // ---- merge, cooperatively: a group of GL lanes (GL = KMAX: 16 or 32) holds one row's sorted list in registers,
+        // one entry per lane; a candidate's position is a popcount over the group's comparison ballot and the entries behind
+        // it move up by one lane (a DPP row shift for 16-lane groups).  64 / GL rows at a time -- the lane-per-row form
+        // walked every list through dependent LDS round trips (a fifth of the kernel).
+        {
+            constexpr int GL = KMAX;                  // lanes per row
+            constexpr int NG = 64 / GL;               // rows per batch
+            const int grpi = lane / GL, e = lane % GL;
+            const int mycnt = lane < 32 ? sh.cnt[rowbase + lane] : 0;
+            unsigned long long todo = __ballot(mycnt > 0);
+            const int32_t col0 = (int32_t)(J * ST_T + slab * ST_SLAB);
+            while (todo) {
+                int rsel = -1;   // this group's row (relative to rowbase)
+#pragma unroll
+                for (int k = 0; k < NG; ++k) {
+                    const int r = todo ? (int)__builtin_ctzll(todo) : -1;
+                    if (todo) todo &= todo - 1;
+                    rsel = grpi == k ? r : rsel;
                 }
-                sh.cnt[row] = 0;
-                const float t = sh.list_d[row][KL - 1];
-                sh.thr[row] = t;
-                sh.hb[row] = 0.5f * (sh.rrow[row] - t);
+                const int row = rowbase + max(rsel, 0);
+                const bool live = rsel >= 0;
+                const int nc = live ? sh.cnt[row] : 0;
+                float ld = (live && e < KL) ? sh.list_d[row][e] : INFINITY;
+                int32_t lc = (live && e < KL) ? sh.list_c[row][e] : 0x7fffffff;
+                int q = 0;
+                while (__ballot(q < nc)) {
+                    const bool on = q < nc;
+                    const float d = on ? sh.cand_d[row][q] : INFINITY;
+                    const int32_t cc = on ? col0 + sh.cand_c[row][q] : 0x7fffffff;
+                    const bool before = e < KL && (ld < d || (ld == d && lc < cc));   // entries that stay ahead of the candidate
+                    const unsigned long long bb = __ballot(before);
+                    const int pos = __popcll((bb >> (grpi * GL)) & ((GL == 64) ? ~0ull : ((1ull << GL) - 1)));
+                    float pd;
+                    int32_t pc;
+                    if constexpr (GL == 16) {
+                        pd = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ld), 0x111, 0xf, 0xf, false));   // row_shr:1
+                        pc = __builtin_amdgcn_update_dpp(0, lc, 0x111, 0xf, 0xf, false);
+                    } else {
+                        pd = __shfl_up(ld, 1, GL);
+                        pc = __shfl_up(lc, 1, GL);
+                    }
+                    if (on && pos < KL) {
+                        ld = e > pos ? pd : (e == pos ? d : ld);
+                        lc = e > pos ? pc : (e == pos ? cc : lc);
+                        ins += (e == 0 && pos < K) ? 1 : 0;   // the yield that stops the tile phase counts what reaches the K entries handed on
+                    }
+                    ++q;
+                }
+                if (live) {
+                    if (e < KL) { sh.list_d[row][e] = ld; sh.list_c[row][e] = lc; }
+                    if (e == KL - 1) { sh.thr[row] = ld; sh.hb[row] = 0.5f * (sh.rrow[row] - ld); }
+                    if (e == 0) sh.cnt[row] = 0;
+                }
             }
         }
         wave_fence_lds();
@@ -310,9 +338,9 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
     };
     // the wave's insertion count and its rows' worst k-th distance, at the end of a tile
     auto publish = [&]() {
-        int wins = lane < 32 ? ins : 0;
+        int wins = ins;
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) wins += __shfl_xor(wins, off);
+        for (int off = 32; off > 0; off >>= 1) wins += __shfl_xor(wins, off);
         float t = lane < 32 ? sh.thr[rowbase + lane] : -1.f;   // padding rows: -1
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) t = fmaxf(t, __shfl_xor(t, off));
