@@ -210,51 +210,73 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(loff[0]), "s"(src), "s"(dst) : "memory");
     };
-    f32x16 acc;
-    float rj_s = 0.f;   // squared norm of the lane's column in the slab this wave streamed last
-    // 3 DIM / 16 MFMAs of this wave's 32 rows against the 32 columns in ring slot `slab` (columns of tile J); the
-    // columns' squared norms are requested first and used by the test one phase later: a global round trip under load
-    // is thousands of cycles, as long as the stream itself
-    auto stream_slab = [&](int J, int slab) {
+    f32x16 acc0, acc1;          // slabs 0, 2 / slabs 1, 3 of a tile: one is streamed into while the other one is tested
+    float rj_c = 0.f;           // squared norm of the lane's column in the slab being streamed (requested at its start)
+    // the slab whose accumulators wait for their test (the one streamed before the current one)
+    bool pend = false;
+    int pJ = 0, pslab = 0;
+    float prj = 0.f;
+    uint32_t ppass = 0;
+    // 3 DIM / 16 MFMAs of this wave's 32 rows against the 32 columns in ring slot `slab` (columns of tile J) into accC, with
+    // the threshold test of the PREVIOUS slab's accumulators accP in their shadow (the bf16 matrix pipe takes an MFMA
+    // every 32 cycles and up to four vector instructions behind each one for free, tools/microbench/shadow.hip): row r of
+    // the lane's column passes iff x_r . x_c > hb[r] + |x_c|^2 / 2 (hb: one LDS word per row, kept by the merge).  The
+    // columns' squared norms are requested at the start of their slab and used one slab later: a global round trip under
+    // load is thousands of cycles.
+    auto stream_slab = [&](int J, int slab, f32x16 &accC, const f32x16 &accP) {
         PS0
-        rj_s = a.rs[(int64_t)J * ST_T + slab * ST_SLAB + col];
+        rj_c = a.rs[(int64_t)J * ST_T + slab * ST_SLAB + col];
         const float4 *base = reinterpret_cast<const float4 *>(&sh.ring[(slab & 1) * (ST_SLAB * DIM)]) + col * UPC;
         const int gsw = half ^ unit_swz<UPC>(col);
-        float4 b[NV];   // b[g]: hi parts of k-step g; b[G + g]: lo parts
-#pragma unroll
-        for (int v = 0; v < NV; ++v) b[v] = base[(2 * v) ^ gsw];
-        // all operand reads first, then the MFMAs back to back (left alone the scheduler sinks each read to its use and
-        // the stream waits out an LDS round trip every few MFMAs)
-        __builtin_amdgcn_sched_group_barrier(0x100, NV, 0);
-        PS(8)    // operand reads landed (the stamp waits for them)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {   // small terms first
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g], __builtin_bit_cast(bf16x8, b[g]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], __builtin_bit_cast(bf16x8, b[G + g]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], __builtin_bit_cast(bf16x8, b[g]), acc, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 3 * G, 0);
-        PS(9)    // MFMAs issued
-    };
-    // threshold test of the accumulators of slab `slab` of tile J, survivors into the rows' candidate slots, merge
-    // into the sorted lists (lane l < 32 owns row rowbase + l).  `rj`: squared norm of the lane's column.
-    auto test_merge = [&](int J, int slab, float rj) {
-        PS0
-        uint32_t pass = 0;
-        const float hrj = 0.5f * rj;
+        float hq[16];   // (first: LDS data returns in order, and the test must not wait for the operands behind it)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 h4 = *reinterpret_cast<const float4 *>(&sh.hb[rowq + 8 * q]);
-            const float hq[4] = {h4.x, h4.y, h4.z, h4.w};
+            hq[4 * q] = h4.x; hq[4 * q + 1] = h4.y; hq[4 * q + 2] = h4.z; hq[4 * q + 3] = h4.w;
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        float4 b[NV];   // b[g]: hi parts of k-step g; b[G + g]: lo parts
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int g = 4 * q + e;
-                // |x_r|^2 + |x_c|^2 - 2 x_r . x_c < thr_r, rearranged so that the row's part is one LDS word
-                pass |= (acc[g] > hq[e] + hrj ? 1u : 0u) << g;
+        for (int v = 0; v < NV; ++v) b[v] = base[(2 * v) ^ gsw];
+        // all LDS reads first, then MFMAs with the test's vector instructions between them (left alone the scheduler sinks
+        // each read to its use and the stream waits out an LDS round trip every few MFMAs)
+        __builtin_amdgcn_sched_group_barrier(0x100, NV, 0);
+        PS(8)    // operand reads landed (the stamp waits for them)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accC[r] = 0.f;
+        const float hrj = 0.5f * prj;
+        uint32_t pass = 0;
+        constexpr int NM = 3 * G;                       // MFMAs
+        constexpr int TPM = (16 + NM - 1) / NM;         // row tests per MFMA
+#pragma unroll
+        for (int g = 0; g < G; ++g) {   // small terms first
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int m = 3 * g + t;
+                if (t == 0) accC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g], __builtin_bit_cast(bf16x8, b[g]), accC, 0, 0, 0);
+                if (t == 1) accC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], __builtin_bit_cast(bf16x8, b[G + g]), accC, 0, 0, 0);
+                if (t == 2) accC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], __builtin_bit_cast(bf16x8, b[g]), accC, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < TPM; ++u) {
+                    const int r = m * TPM + u;
+                    if (r < 16) pass |= (accP[r] > hq[r] + hrj ? 1u : 0u) << r;
+                }
+                // (pinned by data flow: the tests are pure arithmetic and every scheduling hint -- sched_group_barrier,
+                // sched_barrier -- left them all behind the last MFMA; an empty asm that "uses" the accumulator and the
+                // mask keeps MFMA m and test m on this side of it)
+                asm volatile("" : "+v"(accC), "+v"(pass));
             }
         }
+        ppass = pend ? pass : 0u;
+        PS(9)    // MFMAs issued
+    };
+    // what the shadow test let through (slab pslab of tile pJ, accumulators accP, column norms prj): survivors into the rows'
+    // candidate slots, then the merge into the sorted lists
+    auto insert_merge = [&](const f32x16 &accP) {
+        const int J = pJ, slab = pslab;
+        const float rj = prj;
+        uint32_t pass = ppass;
+        PS0
         const bool self_tile = !a.query && (int64_t)J * ST_T == grow0;
         PS(10)   // thresholds read, accumulators there, 16 tests
         if (pass) {
@@ -266,9 +288,9 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
                 const int g = __builtin_ctz(pass);
                 pass &= pass - 1;
                 const int rowl = rowq + (g & 3) + 8 * (g >> 2);
-                float ag = acc[0];
+                float ag = accP[0];
 #pragma unroll
-                for (int t = 1; t < 16; ++t) ag = g == t ? acc[t] : ag;
+                for (int t = 1; t < 16; ++t) ag = g == t ? accP[t] : ag;
                 const float d2 = fmaxf(sh.rrow[rowl] + rj - 2.f * ag, 0.f);
                 const int slot = atomicAdd(&sh.cnt[rowl], 1);
                 sh.cand_d[rowl][slot] = d2;
@@ -336,6 +358,19 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
         wave_fence_lds();
         P8(6)
     };
+    // the pending slab's test without a stream to hide it in (end of a run)
+    auto test_only = [&](const f32x16 &accP) {
+        uint32_t pass = 0;
+        const float hrj = 0.5f * prj;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 h4 = *reinterpret_cast<const float4 *>(&sh.hb[rowq + 8 * q]);
+            const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pass |= (accP[4 * q + e] > hv[e] + hrj ? 1u : 0u) << (4 * q + e);
+        }
+        ppass = pend ? pass : 0u;
+    };
     // the wave's insertion count and its rows' worst k-th distance, at the end of a tile
     auto publish = [&]() {
         int wins = ins;
@@ -388,35 +423,61 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
         issue_slab(J, 0);
         slab_end();
         P8(6)
+        pend = false;
+        // one slab: request the next one, stream (the previous slab's test in the shadow), insert / merge the previous slab
+        // (the column norms requested at the start of a slab have landed by its end -- slab_end waits for everything -- but the
+        // compiler does not know: without this it parks its own wait, and the whole shadow test behind it, after the MFMAs)
+#define RJ_LANDED asm volatile("" : "+v"(prj));
+        auto step = [&](int Jc, int sl, f32x16 &accC, const f32x16 &accP) {
+            stream_slab(Jc, sl, accC, accP);
+            P8(0)
+            if (pend) insert_merge(accP);
+            pend = true; pJ = Jc; pslab = sl; prj = rj_c;
+        };
         for (;;) {
             int Jn = -1;
-            // ---- slabs 0..2: request the next slab of this tile, stream, test, merge
-#pragma unroll
-            for (int sl = 0; sl < 3; ++sl) {
-                issue_slab(J, sl + 1);
-                P8(4)
-                stream_slab(J, sl);
-                P8(0)
-                test_merge(J, sl, rj_s);
-                slab_end();
-                P8(1)
-            }
+            issue_slab(J, 1);
+            P8(4)
+            step(J, 0, acc0, acc1);
+            slab_end();
+            RJ_LANDED
+            P8(1)
+            issue_slab(J, 2);
+            P8(4)
+            step(J, 1, acc1, acc0);
+            slab_end();
+            RJ_LANDED
+            P8(1)
+            issue_slab(J, 3);
+            P8(4)
+            step(J, 2, acc0, acc1);
+            slab_end();
+            RJ_LANDED
+            P8(1)
             // ---- slab 3: the next tile is chosen (thresholds / insertion counts as of the tile before J: published before the
             // last barrier of that tile and untouched since -- the same choice in every wave) and its slab 0 requested
             Jn = next_tile(1);
             P8(2)
             if (Jn >= 0) issue_slab(Jn, 0);
             P8(4)
-            stream_slab(J, 3);
-            P8(0)
-            test_merge(J, 3, rj_s);
-            publish();
+            step(J, 3, acc1, acc0);
+            publish();     // (the lists as merged through slab 2 of this tile; slab 3's survivors go in during the next slab)
             ++tdone;
             slab_end();
+            RJ_LANDED
             P8(1)
             if (Jn < 0) break;
             J = Jn;
         }
+        // ---- tail: the last slab's test and merge, and the thresholds the selection of the next round reads
+#undef RJ_LANDED
+        test_only(acc1);
+        insert_merge(acc1);
+        pend = false;
+        publish();
+        ++tdone;
+        slab_end();
+        P8(6)
     };
 
     // ---- phase A: the row tile against itself (gives every row K finite candidates); query rows are not part of the
