@@ -100,7 +100,7 @@ _SIGNATURES = {
                                                 ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
     "annchor_stream_knn_join": (ctypes.c_int, [_vp, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
     "annchor_stream_last_counts": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
-    "annchor_stream_last_kernel": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
+    "annchor_stream_last_kernel": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_i64)]),
     "annchor_stream_budget": (ctypes.c_int, [_i32, _dbl, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "annchor_stream_knn_end": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "annchor_stream_query": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _dbl, _vp, _vp,
@@ -802,11 +802,12 @@ class Engine:
         self._chk(self.lib.annchor_stream_last_counts(self.h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
-    def stream_last_kernel(self):
-        """Kernel of the last build's tile phase: 0 exact float32 tile GEMMs, 1 split-bf16 (4-wave), 2 split-bf16 (8-wave)."""
-        k = ctypes.c_int32()
-        self._chk(self.lib.annchor_stream_last_kernel(self.h, ctypes.byref(k)))
-        return int(k.value)
+    def stream_last_kernel(self, with_guard=False):
+        """Kernel of the last build's tile phase: 0 exact float32 tile GEMMs, 1 split-bf16; with_guard: also the number of
+        rows the split kernel flagged as ill-conditioned (more than 1 in 200 repeats the tile phase on the exact kernel)."""
+        k, g = ctypes.c_int32(), _i64()
+        self._chk(self.lib.annchor_stream_last_kernel(self.h, ctypes.byref(k), ctypes.byref(g)))
+        return (int(k.value), int(g.value)) if with_guard else int(k.value)
 
     def stream_join_tables(self, gathered, world, n_anchors, n_tiles, joined):
         self._chk(self.lib.annchor_stream_join_tables(self.h, gathered, int(world), int(n_anchors), int(n_tiles), joined))

@@ -138,29 +138,35 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
     // eight bf16 hi parts and eight lo parts
     constexpr int G = DIM / 16;
     bf16x8 ah[G], al[G];
+    float rr_c;   // this lane's half of |x_row - c|^2 (summed with the other half below)
     {
         const float *xr = a.Rs + (size_t)(grow0 + rowbase + col) * DIM + 8 * half;
+        const float *cv = a.cvec + 8 * half;
+        float acc2 = 0.f;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float4 t0 = *reinterpret_cast<const float4 *>(xr + 16 * g), t1 = *reinterpret_cast<const float4 *>(xr + 16 * g + 4);
-            const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            const float4 c0 = *reinterpret_cast<const float4 *>(cv + 16 * g), c1 = *reinterpret_cast<const float4 *>(cv + 16 * g + 4);
+            const float x[8] = {t0.x - c0.x, t0.y - c0.y, t0.z - c0.z, t0.w - c0.w, t1.x - c1.x, t1.y - c1.y, t1.z - c1.z, t1.w - c1.w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const __bf16 h = (__bf16)x[j];
                 ah[g][j] = h;
                 al[g][j] = (__bf16)(x[j] - (float)h);
+                acc2 += x[j] * x[j];
             }
         }
+        rr_c = acc2 + __shfl_xor(acc2, 32);
     }
     if (threadIdx.x < ST_T) {
         const int row = threadIdx.x;
         const bool real = a.rr[grow0 + row] < INFINITY;
         sh.thr[row] = real ? INFINITY : -1.f;   // padding rows never accept candidates
         sh.hb[row] = real ? -INFINITY : INFINITY;
-        sh.rrow[row] = a.rr[grow0 + row];
         sh.cnt[row] = 0;
         for (int q = 0; q < KMAX; ++q) { sh.list_d[row][q] = INFINITY; sh.list_c[row][q] = 0x7fffffff; }
     }
+    if (lane < 32) sh.rrow[rowbase + lane] = a.rr[grow0 + rowbase + lane] < INFINITY ? rr_c : INFINITY;   // |x_row - c|^2
     if ((int)threadIdx.x < a.na) {
         sh.loI[threadIdx.x] = a.rlo[(size_t)threadIdx.x * a.nt_r + I];
         sh.hiI[threadIdx.x] = a.rhi[(size_t)threadIdx.x * a.nt_r + I];
@@ -225,7 +231,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
     // load is thousands of cycles.
     auto stream_slab = [&](int J, int slab, f32x16 &accC, const f32x16 &accP) {
         PS0
-        rj_c = a.rs[(int64_t)J * ST_T + slab * ST_SLAB + col];
+        rj_c = a.rsb[(int64_t)J * ST_T + slab * ST_SLAB + col];
         const float4 *base = reinterpret_cast<const float4 *>(&sh.ring[(slab & 1) * (ST_SLAB * DIM)]) + col * UPC;
         const int gsw = half ^ unit_swz<UPC>(col);
         float hq[16];   // (first: LDS data returns in order, and the test must not wait for the operands behind it)
@@ -617,6 +623,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
     __syncthreads();
     // ---- exact re-ranking: the lists hold KL >= K columns chosen by the split-bf16 distance (error ~1e-4 relative on a
     // neighbour's d^2); their exact float32 distances sum (x - y)^2 decide which K are handed on, and in which order
+    if (threadIdx.x == 0) sh.nsurv = 0;
     {
         float *ex = &sh.cand_d[0][0];   // [ST_T][KMAX] exact d^2 (cand_d is idle now; row stride KMAX <= ST_SLAB + 1)
         for (int q = threadIdx.x; q < ST_T * KL; q += STB_THREADS) {
@@ -640,6 +647,13 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
         __syncthreads();
         if (threadIdx.x < ST_T) {   // one thread per row: insertion sort of <= 32 entries by (exact d^2, column)
             const int row = threadIdx.x;
+            // guard, part 1: the largest error the split products made on this row's kept entries
+            float eps = 0.f;
+            int nfin = 0;
+            for (int e = 0; e < KL; ++e) {
+                const float ap = sh.list_d[row][e], exv = ex[row * KMAX + e];
+                if (exv < INFINITY) { eps = fmaxf(eps, fabsf(ap - exv)); ++nfin; }
+            }
             for (int e = 1; e < KL; ++e) {
                 const float d = ex[row * KMAX + e];
                 const int32_t cc = sh.list_c[row][e];
@@ -652,6 +666,10 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
                 ex[row * KMAX + p] = d;
                 sh.list_c[row][p] = cc;
             }
+            // guard, part 2: a column left outside the list has an approximate d^2 >= the list's last approximate entry; it can
+            // only belong among the K nearest if its exact d^2 is below the K-th exact one, i.e. if the products were off by more
+            // than the room between the two -- flagged when that room is within twice the measured error
+            if (nfin > K && ex[row * KMAX + K - 1] + 2.f * eps > sh.list_d[row][KL - 1]) atomicAdd(&sh.nsurv, 1);   // (nsurv is idle here)
         }
         __syncthreads();
         for (int q = threadIdx.x; q < ST_T * K; q += STB_THREADS) {
@@ -661,7 +679,10 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
             a.out_col[((size_t)bt * ST_T + row) * K + e] = d2 < INFINITY ? sh.list_c[row][e] : 0x7fffffff;
         }
     }
-    if (threadIdx.x == 0) atomicAdd(a.evals, (unsigned long long)processed);
+    if (threadIdx.x == 0) {
+        atomicAdd(a.evals, (unsigned long long)processed);
+        if (sh.nsurv) atomicAdd(a.evals + 3, (unsigned long long)sh.nsurv);   // slot 3: rows flagged by the guard
+    }
 #ifdef ST_PROFILE
     P8(7)
     if (lane == 0 && a.prof)
@@ -672,20 +693,20 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
 template <int DIM, int KMAX> static int launchb(annchor_ctx *c, const KnnArgs &a)
 {
     const size_t lds = sizeof(KnnSharedB<DIM, KMAX>);
-    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "streamed k-NN (8-wave form) needs %zu B of LDS", lds);
+    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "streamed k-NN (split-bf16 form) needs %zu B of LDS", lds);
     ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knnbf<DIM, KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_st_knnbf<DIM, KMAX><<<a.tile_count, STB_THREADS, lds, c->stream>>>(a);
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
 }
 
-// The tile phase through the 8-wave split-bf16 kernel when the shape fits it (padded dim <= 128: the ring of four slabs is
-// 16 KB x 4 there; K + ST_BF_MARGIN <= 32 list entries; the split copy of the columns exists); *handled = false sends the
-// caller to the exact-f32 kernel k_st_knn.
+// The tile phase through the split-bf16 kernel when the shape fits it (padded dim <= 128: a slab of 32 columns is 16 KB there;
+// K + ST_BF_MARGIN <= 32 list entries; the split copy of the columns exists); *handled = false sends the caller to the
+// exact-f32 kernel k_st_knn.
 int ann_stream_launch_knnbf(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool *handled)
 {
     *handled = true;
-    if (a.K + ST_BF_MARGIN > ST_KMAX || !a.Xb) { *handled = false; return ANNCHOR_OK; }
+    if (a.K + ST_BF_MARGIN > ST_KMAX || !a.Xb || !a.rsb || !a.cvec) { *handled = false; return ANNCHOR_OK; }
     const bool k16 = a.K + ST_BF_MARGIN <= 16;
     switch (dim_padded) {
     case 32: return k16 ? launchb<32, 16>(c, a) : launchb<32, ST_KMAX>(c, a);
@@ -695,3 +716,62 @@ int ann_stream_launch_knnbf(annchor_ctx *c, const KnnArgs &a, int dim_padded, bo
     }
 }
 
+// ------------------------------------------------------------------ the split copy of the ordered rows
+// The expanded form |x|^2 + |y|^2 - 2 x.y loses what |x|^2 exceeds d^2 by, so the rows are centred first: c = mean of
+// the anchors' coordinates (the max-min anchors span the data; every rank knows all of them: no collective).  Distances do not
+// change; the exact re-ranking and the final distances use the original rows.
+__global__ void k_st_centre(const float *__restrict__ avecs, int na, int dim, int dimp, float *__restrict__ cvec)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= dimp) return;
+    float s = 0.f;
+    if (avecs && k < dim)
+        for (int r = 0; r < na; ++r) s += avecs[(size_t)r * dim + k];
+    cvec[k] = (avecs && k < dim && na > 0) ? s / (float)na : 0.f;
+}
+
+// Xb[row] = {bf16 hi parts of the row's dimp centred floats, then their lo parts}: hi = bf16(x) (round to nearest even),
+// lo = bf16(x - hi) -- the same bytes per row as the float32 copy; rsb[row] = |x - c|^2 (+inf on padding rows).
+// dimp / 4 threads per row, one float4 each.
+__global__ __launch_bounds__(256) void k_st_split_bf16(const float *__restrict__ Xs, const float *__restrict__ rs, const float *__restrict__ cvec,
+                                                       int64_t n_pad, int dimp, uint16_t *__restrict__ Xb, float *__restrict__ rsb)
+{
+    const int per = dimp / 4;   // 8, 16 or 32
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = t / per;
+    const int q = (int)(t - row * per);
+    float acc = 0.f;
+    if (row < n_pad) {
+        const float4 v = reinterpret_cast<const float4 *>(Xs)[t], cc = reinterpret_cast<const float4 *>(cvec)[q];
+        const bool real = rs[row] < INFINITY;
+        const float x[4] = {real ? v.x - cc.x : 0.f, real ? v.y - cc.y : 0.f, real ? v.z - cc.z : 0.f, real ? v.w - cc.w : 0.f};
+        uint16_t h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const __bf16 hb = (__bf16)x[j];
+            const __bf16 lb = (__bf16)(x[j] - (float)hb);
+            h[j] = __builtin_bit_cast(uint16_t, hb);
+            l[j] = __builtin_bit_cast(uint16_t, lb);
+            acc += x[j] * x[j];
+        }
+        uint16_t *dst = Xb + (size_t)row * dimp * 2 + 4 * q;
+        *reinterpret_cast<uint2 *>(dst) = uint2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+        *reinterpret_cast<uint2 *>(dst + dimp) = uint2{(uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16)};
+    }
+    for (int off = per >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (row < n_pad && q == 0) rsb[row] = rs[row] < INFINITY ? acc : INFINITY;
+}
+
+int ann_stream_split_rows(annchor_ctx *c, StreamState *s)
+{
+    const int64_t n4 = s->n_pad * (int64_t)(s->dimp / 4);
+    ANN_TRY(ann_stream_reserve(c, s->Xb, sizeof(uint16_t) * 2 * (size_t)s->n_pad * s->dimp));
+    ANN_TRY(ann_stream_reserve(c, s->rsb, sizeof(float) * (size_t)s->n_pad));
+    ANN_TRY(ann_stream_reserve(c, s->cvec, sizeof(float) * (size_t)s->dimp));
+    const bool have = s->avecs.p != nullptr && s->na > 0 && s->avecs.cap >= sizeof(float) * (size_t)s->na * s->dim;
+    k_st_centre<<<ann_blocks(s->dimp, 128), 128, 0, c->stream>>>(have ? s->avecs.as<float>() : nullptr, s->na, s->dim, s->dimp, s->cvec.as<float>());
+    k_st_split_bf16<<<ann_blocks(n4, 256), 256, 0, c->stream>>>(s->Xs.as<float>(), s->rs.as<float>(), s->cvec.as<float>(), s->n_pad, s->dimp,
+                                                               s->Xb.as<uint16_t>(), s->rsb.as<float>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}

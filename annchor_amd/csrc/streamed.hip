@@ -51,7 +51,7 @@ void ann_stream_release(annchor_ctx *c)
                               &s->scr_key, &s->scr_lb, &s->emit_idx, &s->emit_dist, &s->Dt, &s->eval_bits, &s->out_d2b, &s->out_colb,
                               &s->ucand, &s->ucount, &s->rev_cnt, &s->rev_ptr, &s->rev_edges, &s->rev, &s->cand, &s->cand_all, &s->avecs, &s->A_dev,
                               &s->rows_send, &s->rows_recv, &s->rows_all, &s->lists_all, &s->route_tab, &s->route_cnt, &s->route_slot,
-                              &s->route_send, &s->route_recv, &s->Xb};
+                              &s->route_send, &s->route_recv, &s->Xb, &s->rsb, &s->cvec};
             for (DevBuf *b : bufs)
                 if (b->p && !b->in_arena) ann_dev_free(c, b->p, b->cap);
             ann_stream_free_run(s);
@@ -79,11 +79,15 @@ static int padded_dim(int dim) { return dim <= 32 ? 32 : dim <= 64 ? 64 : dim <=
 StreamState *ann_stream_state(annchor_ctx *c, bool create) { return state_of(c, create); }
 // (the column arrays travel through the C-ABI as bare pointers -- a query engine streams another context's columns --
 // so the split copy is found from the float32 array it was made from)
-const void *ann_stream_split_of(const void *Xs)
+bool ann_stream_split_of(const void *Xs, const uint16_t **Xb, const float **rsb, const float **cvec)
 {
     for (auto &p : g_states)
-        if (p.second->Xs.p == Xs && p.second->Xb.p && p.second->dimp <= 128) return p.second->Xb.p;
-    return nullptr;
+        if (p.second->Xs.p == Xs && p.second->Xb.p && p.second->rsb.p && p.second->cvec.p && p.second->dimp <= 128) {
+            *Xb = p.second->Xb.as<uint16_t>(); *rsb = p.second->rsb.as<float>(); *cvec = p.second->cvec.as<float>();
+            return true;
+        }
+    *Xb = nullptr; *rsb = nullptr; *cvec = nullptr;
+    return false;
 }
 int ann_stream_reserve(annchor_ctx *c, DevBuf &b, size_t bytes) { return sreserve(c, b, bytes); }
 int ann_stream_padded_dim(int dim) { return padded_dim(dim); }
@@ -1472,20 +1476,19 @@ template <int DIM> static int launch_knn(annchor_ctx *c, const KnnArgs &a, bool 
     return a.K <= 16 ? launch_knn2<DIM, 16>(c, a, join) : a.K <= ST_KMAX ? launch_knn2<DIM, ST_KMAX>(c, a, join) : launch_knn2<DIM, ST_KMAX_BIG>(c, a, join);
 }
 
-static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool join)
+static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool join, bool exact = false)
 {
     if (!join) {
-        // ANNCHOR_ST_KERNEL: bf4 (default; knnbf.hip) | bf8 (knn8.hip) | 4wave (the exact-f32 kernel below for every shape)
+        // ANNCHOR_ST_KERNEL=4wave: the exact-f32 kernel below for every shape (A/B runs, tests); default: the split-bf16
+        // kernel (knnbf.hip) where the shape fits it
         static const char *kern = getenv("ANNCHOR_ST_KERNEL");
         StreamState *st = state_of(c, false);
         if (st) st->last_kernel = 0;
-        if (!kern || strcmp(kern, "4wave")) {
+        if (!exact && (!kern || strcmp(kern, "4wave"))) {
             bool handled = false;
-            const bool eight = kern && !strcmp(kern, "bf8");
-            if (eight) ANN_TRY(ann_stream_launch_knn8(c, a, dim_padded, &handled));
-            else ANN_TRY(ann_stream_launch_knnbf(c, a, dim_padded, &handled));
+            ANN_TRY(ann_stream_launch_knnbf(c, a, dim_padded, &handled));
             if (handled) {
-                if (st) st->last_kernel = eight ? 2 : 1;
+                if (st) st->last_kernel = 1;
                 return ANNCHOR_OK;
             }
         }
@@ -1577,6 +1580,26 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
         // algorithmic flops are data dependent (tiles that survive the bound): reported by the caller from tile_evals
         ProfScope ps(c, "stream_tile_gemm_topk", 0.0);
         ANN_TRY(launch_by_dim(c, a, dim_padded, false));
+    }
+    s->last_guard_rows = 0;
+    if (s->last_kernel != 0) {
+        // The split-bf16 kernel keeps K + 2 columns per row by a distance that is off by ~2^-19 |x||y| and re-ranks them exactly;
+        // its epilogue counts the rows whose K-th exact distance comes within the MEASURED error of the list's last approximate
+        // entry -- rows where a neighbour may have been left outside the list.  Well-conditioned data flags (almost) none; when
+        // more than 1 row in 200 is flagged (tight clusters far from the centre: |x|^2 >> d^2) the tile phase runs again on
+        // the exact-f32 kernel.
+        unsigned long long flagged = 0;
+        ANN_TRY(ann_d2h(c, &flagged, a.evals + 3, 8));
+        s->last_guard_rows = (int64_t)flagged;
+        static const bool no_fallback = getenv("ANNCHOR_ST_NO_FALLBACK") != nullptr;
+        if ((int64_t)flagged > std::max<int64_t>(8, rows / 200) && !no_fallback) {
+            fprintf(stderr, "annchor: streamed tile phase: %llu of %lld rows have neighbours closer together than the split-bf16 products "
+                            "resolve (|x|^2 >> d^2); running the exact float32 tile kernel instead\n", flagged, (long long)rows);
+            ANN_CHECK_HIP(c, hipMemsetAsync(s->evals.p, 0, 32, c->stream));
+            if (a.eval_bits) ANN_CHECK_HIP(c, hipMemsetAsync(s->eval_bits.p, 0, sizeof(uint32_t) * (size_t)a.tile_count * a.eval_words, c->stream));
+            ProfScope ps(c, "stream_tile_gemm_topk_exact_rerun", 0.0);
+            ANN_TRY(launch_by_dim(c, a, dim_padded, false, true));
+        }
     }
     ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
     c->call_timed = true;
@@ -1695,12 +1718,13 @@ int ann_stream_knn_finish(annchor_ctx *c, StreamState *s, KnnArgs &a, const void
 }
 
 // tile evaluations of the last build's tile phase and 128-column runs of its join passes
-extern "C" int annchor_stream_last_kernel(annchor_ctx *c, int32_t *kind)
+extern "C" int annchor_stream_last_kernel(annchor_ctx *c, int32_t *kind, int64_t *guard_rows)
 {
-    if (!c || !kind) return ANNCHOR_EINVAL;
+    if (!c || !kind || !guard_rows) return ANNCHOR_EINVAL;
     StreamState *s = state_of(c, false);
     ANN_REQUIRE(c, s != nullptr, ANNCHOR_ESTATE, "no streamed build on this context");
     *kind = s->last_kernel;
+    *guard_rows = s->last_guard_rows;
     return ANNCHOR_OK;
 }
 
@@ -1755,7 +1779,7 @@ static int knn_args_graph(annchor_ctx *c, KnnArgs &a, const void *Xs_all, const 
     ANN_REQUIRE(c, n_all == (int64_t)nt_all * ST_T && tile_begin >= 0 && tile_begin + tile_count <= nt_all, ANNCHOR_EINVAL,
                 "tile range out of bounds");
     ANN_REQUIRE(c, n_all < (1ll << 31), ANNCHOR_ELIMIT, "n_all exceeds 2^31");
-    a.Xs = (const float *)Xs_all; a.Xb = (const uint16_t *)ann_stream_split_of(Xs_all); a.rs = (const float *)rs_all; a.lo = (const float *)lo_all; a.hi = (const float *)hi_all; a.mid = (const float *)mid_all;
+    a.Xs = (const float *)Xs_all; (void)ann_stream_split_of(Xs_all, &a.Xb, &a.rsb, &a.cvec); a.rs = (const float *)rs_all; a.lo = (const float *)lo_all; a.hi = (const float *)hi_all; a.mid = (const float *)mid_all;
     a.Rs = a.Xs; a.rr = a.rs; a.rlo = a.lo; a.rhi = a.hi; a.rmid = a.mid; a.nt_r = nt_all; a.query = 0;
     a.nt_all = nt_all; a.na = n_anchors; a.tile_begin = tile_begin; a.tile_count = tile_count; a.K = k - 1;
     return ANNCHOR_OK;
@@ -1876,7 +1900,7 @@ extern "C" int annchor_stream_query(annchor_ctx *c, const void *Xs_all, const vo
     ANN_REQUIRE(c, s && s->nt > 0 && s->Xs.p && s->na == n_anchors && s->dimp == dim_padded, ANNCHOR_ESTATE,
                 "queries are not ordered (bind, anchor rounds with the data set's anchors, order) or do not match the data set");
     KnnArgs a;
-    a.Xs = (const float *)Xs_all; a.Xb = (const uint16_t *)ann_stream_split_of(Xs_all); a.rs = (const float *)rs_all; a.lo = (const float *)lo_all; a.hi = (const float *)hi_all; a.mid = (const float *)mid_all;
+    a.Xs = (const float *)Xs_all; (void)ann_stream_split_of(Xs_all, &a.Xb, &a.rsb, &a.cvec); a.rs = (const float *)rs_all; a.lo = (const float *)lo_all; a.hi = (const float *)hi_all; a.mid = (const float *)mid_all;
     a.Rs = s->Xs.as<float>(); a.rr = s->rs.as<float>(); a.rlo = s->lo.as<float>(); a.rhi = s->hi.as<float>(); a.rmid = s->mid.as<float>();
     a.nt_r = s->nt; a.query = 1;
     a.nt_all = nt_all; a.na = n_anchors; a.tile_begin = 0; a.tile_count = s->nt; a.K = nn;

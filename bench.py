@@ -324,7 +324,8 @@ def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, r
             tile_phase_evals, join_chunks = last._engine.stream_last_counts()
             out["join_chunks_rank0"] = int(join_chunks)
             flops = tile_phase_evals * 128.0 * 128.0 * 2.0 * 128.0
-            kind = last._engine.stream_last_kernel()
+            kind, guard_rows = last._engine.stream_last_kernel(with_guard=True)
+            out["split_kernel_guard_rows_rank0"] = int(guard_rows)   # rows whose list boundary is within the split products' error (> 0.5 %: exact-f32 rerun)
             if kind == 0:
                 out["roofline"] = {"kernel": "stream_tile_gemm_topk (k_st_knn, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
                                    "achieved": flops / gemm_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
@@ -333,11 +334,12 @@ def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, r
                                    "note": "algorithmic flops = tile pairs of the tile phase (<= its budget x row tiles of rank 0) "
                                            "x 128 x 128 x 2 x d; peak = dense f32 MFMA"}
             else:
-                name = "k_st_knnbf" if kind == 1 else "k_st_knn8"
+                name = "k_st_knnbf"
                 out["roofline"] = {"kernel": "stream_tile_gemm_topk (%s: split-bf16 tile GEMMs, 3 x v_mfma_f32_32x32x16_bf16 per 16 dimensions)" % name,
                                    "bound": "mfma", "achieved": 3.0 * flops / gemm_s / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": 3.0 * flops / gemm_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(name),
+                                   "frac": 3.0 * flops / gemm_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(name, largest=True),
                                    "tile_pairs": int(tile_phase_evals),
+                                   "hbm_view": None,
                                    "f32_equivalent": {"achieved": flops / gemm_s / 1e12, "unit": "TFLOP/s",
                                                       "of_the_f32_mfma_peak_157.3": flops / gemm_s / 1e12 / 157.3},
                                    "note": "achieved = MFMA flops issued: every float is split into bf16 hi + lo and a dot product is "
@@ -345,6 +347,14 @@ def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, r
                                            "(MI355X_MICROARCH.md: ~2.5 PFLOP/s).  The split products select K + 2 columns per row; their "
                                            "exact float32 distances decide the K that are kept, so the graph is the exact-f32 kernel's "
                                            "(f32_equivalent = the algorithmic f32 flops of the same tile pairs / the same time)"}
+    if out and out.get("roofline") and out["roofline"].get("traffic") and "hbm_view" in out["roofline"]:
+        r = out["roofline"]
+        # the same launch against the HBM roof: bytes the PMC passes saw leave the fabric per launch / this run's kernel time
+        r["hbm_view"] = {"bound": "hbm", "traffic_GB": round(r["traffic"] / 1e9, 1), "GBps": round(r["traffic"] / gemm_s / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "frac": r["traffic"] / gemm_s / 1e9 / HBM_PEAK_GBS,
+                         "streamed_operand_GB": round(tile_phase_evals * 65536.0 / 1e9, 1),
+                         "note": "64 KB of split-bf16 column operands per tile pair, every one fetched from beyond L2: the kernel is "
+                                 "closer to the HBM roof than to the MFMA roof; traffic from the committed PMC pass"}
     last._engine.close()
     return out
 
@@ -358,18 +368,22 @@ def _latest_profile(suffix):
     return files[-1] if files else None
 
 
-def pmc_traffic(kernel_prefix):
+def pmc_traffic(kernel_prefix, largest=False):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json: separate
-    --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, KiB units, FETCH doubled as the gfx950 guide prescribes)."""
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, KiB units, FETCH doubled as the gfx950 guide prescribes).
+    largest=True: of the matching instantiations the one with the most bytes per launch (the streamed tile kernel is
+    also launched, with another list capacity, by the recall check's full-budget query)."""
     try:
         T = json.load(open(_latest_profile("pmc_traffic.json")))
         tot = n = 0
+        best = 0
         for name, v in T.items():  # launch-weighted over every instantiation of the kernel
             if name.replace("void ", "").startswith(kernel_prefix):
                 tot += v["hbm_bytes_per_launch_corrected"] * v["launches"]
                 n += v["launches"]
+                best = max(best, int(v["hbm_bytes_per_launch_corrected"]))
         if n:
-            return int(tot / n)
+            return best if largest else int(tot / n)
     except Exception:
         pass
     return None

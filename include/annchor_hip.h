@@ -353,11 +353,14 @@ int annchor_stream_knn_end(annchor_ctx *ctx, int64_t *row_ids, int64_t *ng_idx, 
 /* Split of the last build's tile_evals: tile evaluations of the tile phase, 128-column runs of the join passes. */
 int annchor_stream_last_counts(annchor_ctx *ctx, int64_t *tile_phase_evals, int64_t *join_chunks);
 /* Which kernel evaluated the last build's tile phase: 0 = exact float32 tile GEMMs (v_mfma_f32_32x32x2_f32; padded
- * dim 256, more than 30 neighbours), 1 = split-bf16 tile GEMMs (three v_mfma_f32_32x32x16_bf16 per 16 dimensions, K + 2
- * columns kept per row and re-ranked by their exact float32 distances; csrc/knnbf.hip), 2 = the same arithmetic in the
- * 8-wave form (csrc/knn8.hip, ANNCHOR_ST_KERNEL=bf8).  The reported neighbour distances are exact float32 in every case
- * (the metric of the reference on float32 rows: distances.py:8-13). */
-int annchor_stream_last_kernel(annchor_ctx *ctx, int32_t *kind);
+ * dim 256, more than 30 neighbours, or the fallback below), 1 = split-bf16 tile GEMMs (three v_mfma_f32_32x32x16_bf16 per
+ * 16 dimensions on centred rows, K + 2 columns kept per row and re-ranked by their exact float32 distances;
+ * csrc/knnbf.hip).  *guard_rows = rows the split kernel flagged: its K-th exact distance came within twice the measured
+ * error of the products of the list's last approximate entry, i.e. a neighbour may have stayed outside the list; when
+ * more than 1 row in 200 is flagged the tile phase is repeated on the exact kernel (kind 0 is reported then).  The
+ * reported neighbour distances are exact float32 in every case (the metric of the reference on float32 rows:
+ * distances.py:8-13). */
+int annchor_stream_last_kernel(annchor_ctx *ctx, int32_t *kind, int64_t *guard_rows);
 /* Queries against a fitted data set in the streamed form (Annchor.query, annchor.py:643-683 ->
  * query_functions.py:183-212, for data sets beyond the pair-list form).  The context holds
  * the QUERY rows: bound with annchor_stream_bind (global_base 0), given the data set's anchor

@@ -563,3 +563,54 @@ def test_fused_anchor_distances_equal_the_sweeps():
         qa, da = a.query(X[:64], nn=4, p_work=1.0)
         qb, db = b.query(X[:64], nn=4, p_work=1.0)
         assert np.array_equal(qa, qb) and np.array_equal(da, db)
+
+
+def _truth_rows(X, rows, k):
+    """exact float64 distances (direct differences) of `rows` to all points, k smallest incl. the row itself"""
+    Xd = X.astype(np.float64)
+    out = []
+    for r in rows:
+        d = np.sqrt(((Xd - Xd[r][None, :]) ** 2).sum(axis=1))
+        d[r] = 0.0
+        out.append(np.sort(d)[:k])
+    return np.array(out)
+
+
+def test_split_bf16_tile_kernel_centres_the_rows():
+    """The tile kernel evaluates |x|^2 + |y|^2 - 2 x.y on bf16 hi + lo halves (csrc/knnbf.hip): rows far from the origin
+    would lose their neighbours' distances in |x|^2.  The split copy is centred on the anchors' mean, so a data set shifted
+    by 1000 in every coordinate gives the exact graph like the unshifted one (full budget, rtol 1e-5 against float64
+    differences of the same float32 rows), on the split kernel, with (almost) no row flagged by its guard."""
+    from annchor_amd.streamed import StreamedAnnchor
+
+    n, k = 6000, 15
+    X = (latent(n, 128) + 1000.0).astype(np.float32)
+    sa = StreamedAnnchor(X, n_anchors=16, n_neighbors=k, p_work=1.0).fit()
+    kind, flagged = sa._engine.stream_last_kernel(with_guard=True)
+    assert kind == 1 and flagged <= n // 200, (kind, flagged)
+    rows = np.random.default_rng(0).choice(n, 500, replace=False)
+    np.testing.assert_allclose(sa.neighbor_graph[1][rows], _truth_rows(X, rows, k), rtol=1e-5, atol=1e-6)
+
+
+def test_split_bf16_guard_falls_back_to_the_exact_kernel():
+    """Tight clusters far from the centre (|x - c|^2 ~ 10^4 d^2): the split products (error ~2^-19 |x||y|) no longer
+    resolve the neighbours' distances.  The kernel's guard -- K-th exact distance within twice the measured error of the
+    list's last approximate entry -- flags the rows, and the tile phase is repeated on the exact-f32 kernel; on
+    well-conditioned data of the same size nothing is flagged."""
+    from annchor_amd import compare_neighbor_graphs
+    from annchor_amd.streamed import StreamedAnnchor
+
+    rng = np.random.default_rng(3)
+    n, k, d = 20000, 10, 16
+    cent = rng.standard_normal((400, d)) * 30.0
+    X = (cent[rng.integers(0, 400, n)] + 0.3 * rng.standard_normal((n, d))).astype(np.float32)
+    sa = StreamedAnnchor(X, n_anchors=12, n_neighbors=k, p_work=1.0).fit()
+    kind, flagged = sa._engine.stream_last_kernel(with_guard=True)
+    assert kind == 0 and flagged > n // 200, (kind, flagged)   # flagged, and re-run on the exact kernel
+    rows = rng.choice(n, 400, replace=False)
+    bd = _truth_rows(X, rows, k)
+    err = compare_neighbor_graphs((sa.neighbor_graph[0][rows], bd), (sa.neighbor_graph[0][rows], sa.neighbor_graph[1][rows]), k)
+    assert err <= 0.01 * len(rows) * k, err
+    good = StreamedAnnchor(latent(n, 64), n_anchors=12, n_neighbors=k, p_work=0.3).fit()
+    kind, flagged = good._engine.stream_last_kernel(with_guard=True)
+    assert kind == 1 and flagged <= n // 1000, (kind, flagged)

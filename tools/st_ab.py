@@ -1,5 +1,5 @@
 """A/B of the streamed tile kernel at C3 (N = 10^6, d = 128): one child process per ANNCHOR_ST_KERNEL setting
-(8wave = knn8.hip's ping-pong, 4wave = k_st_knn); prints fit time, tile-kernel time / TFLOP/s and recall on 10 000 rows."""
+(bf4 = knnbf.hip's split-bf16 kernel, the default; 4wave = the exact-f32 k_st_knn); prints fit time, tile-kernel time / TFLOP/s and recall on 10 000 rows."""
 import json, os, subprocess, sys, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,6 +37,6 @@ if __name__ == "__main__":
         child(int(sys.argv[2]))
     else:
         n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-        for kern in (sys.argv[2:] or ["bf4", "bf8", "4wave"]):
+        for kern in (sys.argv[2:] or ["bf4", "4wave"]):
             env = dict(os.environ, ANNCHOR_ST_KERNEL=kern)
             subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n)], env=env)
