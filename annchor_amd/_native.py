@@ -803,7 +803,7 @@ class Engine:
         return a.value, b.value
 
     def stream_last_kernel(self, with_guard=False):
-        """Kernel of the last build's tile phase: 0 exact float32 tile GEMMs, 1 split-bf16; with_guard: also the number of
+        """Kernel of the last build's tile phase: 0 exact float32 tile GEMMs, 1 split-fp16; with_guard: also the number of
         rows the split kernel flagged as ill-conditioned (more than 1 in 200 repeats the tile phase on the exact kernel)."""
         k, g = ctypes.c_int32(), _i64()
         self._chk(self.lib.annchor_stream_last_kernel(self.h, ctypes.byref(k), ctypes.byref(g)))

@@ -1,34 +1,39 @@
-// knnbf.hip -- the tile phase of the streamed k-NN build on the bf16 matrix cores (k_st_knnbf): split-bf16 tile GEMMs,
+// knnbf.hip -- the tile phase of the streamed k-NN build on the 16-bit matrix cores (k_st_knnbf): split-fp16 tile GEMMs,
 // operands by LDS-DMA, exact re-ranking of what is kept.
 //
 // Same algorithm as k_st_knn (streamed.hip): a workgroup owns a 128-row tile, ranks the column tiles, evaluates them as
 // tile GEMMs and keeps the best columns per row in LDS.  What is different, and why (tools/microbench/shadow.hip,
-// pingpong.hip, measured on MI355X):
+// pingpong.hip, f16_split.hip, measured on MI355X):
 //   * v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate and, it turns out, in the vector ALUs' issue slot: nothing
 //     hides in its shadow (64 cycles per MFMA bare; 84 with two v_fma behind each, 110 with eight), so an f32 tile
 //     kernel pays for every threshold test, LDS write and address computation in full -- k_st_knn's 60 % of the f32
 //     peak is that.
-//   * v_mfma_f32_32x32x16_bf16 is a real matrix pipe: 32 cycles per MFMA with up to four VALU instructions behind
-//     each for free, and sixteen times the f32 rate.  With every float split into two bf16 (x = hi + lo, |x - hi - lo|
-//     <= 2^-17 |x|) a dot product is hi.hi + hi.lo + lo.hi -- three MFMAs per 16 dimensions, 24 per 32 x 32 x 128
-//     block = 768 matrix-pipe cycles against 4096 for the exact f32 stream -- with an error of ~2^-19 |x||y|
-//     (tools/microbench/bf16_split.hip), i.e. ~1e-4 relative on a neighbour's squared distance.
-//   * That error only matters at the boundary of a row's list.  The lists therefore hold K + ST_BF_MARGIN entries chosen
-//     by the split-bf16 distance, and the kernel's epilogue recomputes the EXACT float32 distance sum (x - y)^2 of
-//     everything kept and hands the best K on -- a true neighbour is lost only if MARGIN + 1 others overtake it inside
-//     the error band.  The reported distances are exact float32 as before; the exactness tests (rtol 1e-5 against
-//     float64 brute force with the full budget) hold unchanged.
+//   * v_mfma_f32_32x32x16_f16 / _bf16 is a real matrix pipe: 32 cycles per MFMA with up to four VALU instructions behind
+//     each for free, and sixteen times the f32 rate.  With every float split into two fp16 (x = hi + lo: 22 bits of
+//     mantissa) a dot product is hi.hi + hi.lo + lo.hi -- three MFMAs per 16 dimensions, 24 per 32 x 32 x 128 block =
+//     768 matrix-pipe cycles against 4096 for the exact f32 stream -- with a measured error of 2^-22 |x||y| (rms 2^-24.7):
+//     the accuracy of the f32 MFMA stream itself (2^-21.5, rms 2^-23.9; split bf16: 2^-19).  fp16's range is handled once
+//     per data set: the rows are centred (c = mean of the anchors) and scaled by the power of two that puts the largest
+//     |coordinate| in (2^12, 2^13] -- exact operations; what underflows below 2^-24 is 37 octaves under the largest value.
+//   * What error is left only matters at the boundary of a row's list.  The lists hold K + ST_BF_MARGIN entries chosen by
+//     the split distance, and the kernel's epilogue recomputes the EXACT float32 distance sum (x - y)^2 of everything kept
+//     (from the original rows) and hands the best K on; it also counts the rows whose K-th exact distance lies within twice
+//     the measured error of the list's last approximate entry -- if more than 1 row in 200 is flagged (neighbours closer
+//     together than float32 products of |x|^2 resolve) the host repeats the tile phase on k_st_knn.  The reported
+//     distances are exact float32 as before; the exactness tests (rtol 1e-5 against float64 brute force with the full
+//     budget) hold unchanged.
 //   * While a wave streams MFMAs back to back, the SIMD's other wave issues NOTHING (pingpong.hip: a partner's VALU or
-//     LDS work beside a bf16 MFMA chain takes exactly chain + its own time, whatever s_setprio says).  A producer /
+//     LDS work beside an MFMA chain takes exactly chain + its own time, whatever s_setprio says).  A producer /
 //     consumer split inside a SIMD therefore serialises; what overlaps is one wave's LATENCY (the LDS round trips of a
 //     list merge, a barrier wait) with another wave's issue.  Hence two independent 4-wave workgroups per CU, one wave of
 //     each on every SIMD, each wave doing everything for its 32 rows: stream, test, insert, merge.
 //
 // Per slab (32 columns) and wave: request the NEXT slab (LDS-DMA `global_load_lds_dwordx4`: no staging registers, no
-// ds_write pass; two ring slots), 16 ds_read_b128 of operands, 24 MFMAs, threshold test against one LDS word per row,
-// survivor inserts, list merge, wait for the request, one workgroup barrier.  The LDS image of a slab is lane-linear, so
-// the bank-conflict-free layout is made on the SOURCE side: 16-byte unit kq of column c (units 0..DIM/8-1 the hi halves,
-// then the lo halves) sits at unit kq ^ f(c) of the column's run and the operand reads apply the same XOR.
+// ds_write pass; two ring slots), 16 ds_read_b128 of operands, 24 MFMAs with the previous slab's threshold test in their
+// shadow, survivor inserts, a cooperative list merge, wait for the request, one workgroup barrier.  The LDS image of a slab
+// is lane-linear, so the bank-conflict-free layout is made on the SOURCE side: 16-byte unit kq of column c (units
+// 0..DIM/8-1 the hi halves, then the lo halves) sits at unit kq ^ f(c) of the column's run and the operand reads apply the
+// same XOR.
 //
 // Decisions that steer the stream (skip a ranked tile whose bound has fallen behind the thresholds, early stop, budget)
 // are taken by every wave from barrier-separated LDS state, for the tile AFTER the one in the stream and from the
@@ -36,9 +41,9 @@
 #include "streamed.h"
 
 #define STB_THREADS 256
-#define ST_BF_MARGIN 2   // list entries beyond K kept by the split-bf16 distance (re-ranked exactly at the end)
+#define ST_BF_MARGIN 2   // list entries beyond K kept by the split-fp16 distance (re-ranked exactly at the end)
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // ST_PROFILE builds: per-wave cycle sums by segment (a.prof[0..7], printed by knn_tile_phase):
 //   0 MFMA stream (operand reads + MFMA issue)   1 barrier after the stream   2 choice of the next tile
@@ -130,15 +135,17 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
     const int I = a.tile_begin + bt;
     const int64_t grow0 = (int64_t)I * ST_T;
     const int K = a.K;
-    const int KL = min(KMAX, K + ST_BF_MARGIN);   // list entries kept by the split-bf16 distance
+    const int KL = min(KMAX, K + ST_BF_MARGIN);   // list entries kept by the split-fp16 distance
     const int col = lane & 31, half = lane >> 5;
     const int rowbase = rg * 32;
     const int rowq = rowbase + 4 * half;   // C layout: row = rowq + (r & 3) + 8 (r >> 2), col = lane & 31
     // ---- row operand in registers, split: lane holds row (lane & 31), dimensions 16 g + 8 half .. + 7 of k-step g as
-    // eight bf16 hi parts and eight lo parts
+    // eight fp16 hi parts and eight lo parts of the centred, scaled values
     constexpr int G = DIM / 16;
-    bf16x8 ah[G], al[G];
-    float rr_c;   // this lane's half of |x_row - c|^2 (summed with the other half below)
+    f16x8 ah[G], al[G];
+    const float scale = a.cvec[DIM];              // power of two: the centred data's largest |coordinate| becomes <= 2^13
+    const float inv_scale2 = 1.f / (scale * scale);
+    float rr_c;   // this lane's half of |scale (x_row - c)|^2 (summed with the other half below)
     {
         const float *xr = a.Rs + (size_t)(grow0 + rowbase + col) * DIM + 8 * half;
         const float *cv = a.cvec + 8 * half;
@@ -147,13 +154,16 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
         for (int g = 0; g < G; ++g) {
             const float4 t0 = *reinterpret_cast<const float4 *>(xr + 16 * g), t1 = *reinterpret_cast<const float4 *>(xr + 16 * g + 4);
             const float4 c0 = *reinterpret_cast<const float4 *>(cv + 16 * g), c1 = *reinterpret_cast<const float4 *>(cv + 16 * g + 4);
-            const float x[8] = {t0.x - c0.x, t0.y - c0.y, t0.z - c0.z, t0.w - c0.w, t1.x - c1.x, t1.y - c1.y, t1.z - c1.z, t1.w - c1.w};
+            const float xu[8] = {t0.x - c0.x, t0.y - c0.y, t0.z - c0.z, t0.w - c0.w, t1.x - c1.x, t1.y - c1.y, t1.z - c1.z, t1.w - c1.w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const __bf16 h = (__bf16)x[j];
+                // (query rows may lie outside the data's range: clamped into fp16's -- their selection is then approximate,
+                // the distances of what is selected stay exact)
+                const float x = fminf(fmaxf(xu[j] * scale, -60000.f), 60000.f);
+                const _Float16 h = (_Float16)x;
                 ah[g][j] = h;
-                al[g][j] = (__bf16)(x[j] - (float)h);
-                acc2 += x[j] * x[j];
+                al[g][j] = (_Float16)(x - (float)h);
+                acc2 += x * x;
             }
         }
         rr_c = acc2 + __shfl_xor(acc2, 32);
@@ -197,7 +207,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
         const int c = u / UPC, x = u % UPC;
         loff[i] = (uint32_t)(c * DIM * 4 + ((x ^ unit_swz<UPC>(c)) << 4));
     }
-    const char *xb = reinterpret_cast<const char *>(a.Xb);   // [n_all][2][DIM] bf16: hi parts, then lo parts of every ordered row
+    const char *xb = reinterpret_cast<const char *>(a.Xb);   // [n_all][2][DIM] fp16: hi parts, then lo parts of every ordered row (centred, scaled)
     auto issue_slab = [&](int J, int slab) {
         const char *src = xb + ((size_t)J * ST_T + slab * ST_SLAB) * (DIM * 4);              // wave-uniform: an SGPR pair
         const uint32_t dst = lds0 + (uint32_t)((slab & 1) * ST_SLAB * DIM * 4 + rg * NI * 1024);   // this wave's pieces of the slot
@@ -224,7 +234,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
     float prj = 0.f;
     uint32_t ppass = 0;
     // 3 DIM / 16 MFMAs of this wave's 32 rows against the 32 columns in ring slot `slab` (columns of tile J) into accC, with
-    // the threshold test of the PREVIOUS slab's accumulators accP in their shadow (the bf16 matrix pipe takes an MFMA
+    // the threshold test of the PREVIOUS slab's accumulators accP in their shadow (the 16-bit matrix pipe takes an MFMA
     // every 32 cycles and up to four vector instructions behind each one for free, tools/microbench/shadow.hip): row r of
     // the lane's column passes iff x_r . x_c > hb[r] + |x_c|^2 / 2 (hb: one LDS word per row, kept by the merge).  The
     // columns' squared norms are requested at the start of their slab and used one slab later: a global round trip under
@@ -259,9 +269,9 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int m = 3 * g + t;
-                if (t == 0) accC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g], __builtin_bit_cast(bf16x8, b[g]), accC, 0, 0, 0);
-                if (t == 1) accC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], __builtin_bit_cast(bf16x8, b[G + g]), accC, 0, 0, 0);
-                if (t == 2) accC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], __builtin_bit_cast(bf16x8, b[g]), accC, 0, 0, 0);
+                if (t == 0) accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g], __builtin_bit_cast(f16x8, b[g]), accC, 0, 0, 0);
+                if (t == 1) accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], __builtin_bit_cast(f16x8, b[G + g]), accC, 0, 0, 0);
+                if (t == 2) accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], __builtin_bit_cast(f16x8, b[g]), accC, 0, 0, 0);
 #pragma unroll
                 for (int u = 0; u < TPM; ++u) {
                     const int r = m * TPM + u;
@@ -385,7 +395,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
         float t = lane < 32 ? sh.thr[rowbase + lane] : -1.f;   // padding rows: -1
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) t = fmaxf(t, __shfl_xor(t, off));
-        if (lane == 0) { sh.wave_ins[(tdone + 1) & 1][wave] = wins; sh.wave_thr[(tdone + 1) & 1][rg] = t; }
+        if (lane == 0) { sh.wave_ins[(tdone + 1) & 1][wave] = wins; sh.wave_thr[(tdone + 1) & 1][rg] = t * inv_scale2; }   // (the lists are in scaled units, the tile bounds are not)
     };
     // (as of the last tile whose publication a barrier separates from the reader: tile `tdone`)
     auto thrmax_now = [&]() {
@@ -621,7 +631,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
         if (!more) break;   // the selection saw every eligible tile
     }
     __syncthreads();
-    // ---- exact re-ranking: the lists hold KL >= K columns chosen by the split-bf16 distance (error ~1e-4 relative on a
+    // ---- exact re-ranking: the lists hold KL >= K columns chosen by the split-fp16 distance (error ~1e-5 relative on a
     // neighbour's d^2); their exact float32 distances sum (x - y)^2 decide which K are handed on, and in which order
     if (threadIdx.x == 0) sh.nsurv = 0;
     {
@@ -651,7 +661,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
             float eps = 0.f;
             int nfin = 0;
             for (int e = 0; e < KL; ++e) {
-                const float ap = sh.list_d[row][e], exv = ex[row * KMAX + e];
+                const float ap = sh.list_d[row][e] * inv_scale2, exv = ex[row * KMAX + e];   // (the lists are in scaled units)
                 if (exv < INFINITY) { eps = fmaxf(eps, fabsf(ap - exv)); ++nfin; }
             }
             for (int e = 1; e < KL; ++e) {
@@ -669,7 +679,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
             // guard, part 2: a column left outside the list has an approximate d^2 >= the list's last approximate entry; it can
             // only belong among the K nearest if its exact d^2 is below the K-th exact one, i.e. if the products were off by more
             // than the room between the two -- flagged when that room is within twice the measured error
-            if (nfin > K && ex[row * KMAX + K - 1] + 2.f * eps > sh.list_d[row][KL - 1]) atomicAdd(&sh.nsurv, 1);   // (nsurv is idle here)
+            if (nfin > K && ex[row * KMAX + K - 1] + 2.f * eps > sh.list_d[row][KL - 1] * inv_scale2) atomicAdd(&sh.nsurv, 1);   // (nsurv is idle here)
         }
         __syncthreads();
         for (int q = threadIdx.x; q < ST_T * K; q += STB_THREADS) {
@@ -693,14 +703,14 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
 template <int DIM, int KMAX> static int launchb(annchor_ctx *c, const KnnArgs &a)
 {
     const size_t lds = sizeof(KnnSharedB<DIM, KMAX>);
-    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "streamed k-NN (split-bf16 form) needs %zu B of LDS", lds);
+    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "streamed k-NN (split-fp16 form) needs %zu B of LDS", lds);
     ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knnbf<DIM, KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_st_knnbf<DIM, KMAX><<<a.tile_count, STB_THREADS, lds, c->stream>>>(a);
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
 }
 
-// The tile phase through the split-bf16 kernel when the shape fits it (padded dim <= 128: a slab of 32 columns is 16 KB there;
+// The tile phase through the split-fp16 kernel when the shape fits it (padded dim <= 128: a slab of 32 columns is 16 KB there;
 // K + ST_BF_MARGIN <= 32 list entries; the split copy of the columns exists); *handled = false sends the caller to the
 // exact-f32 kernel k_st_knn.
 int ann_stream_launch_knnbf(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool *handled)
@@ -723,6 +733,7 @@ int ann_stream_launch_knnbf(annchor_ctx *c, const KnnArgs &a, int dim_padded, bo
 __global__ void k_st_centre(const float *__restrict__ avecs, int na, int dim, int dimp, float *__restrict__ cvec)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) { cvec[dimp] = 0.f; cvec[dimp + 1] = 0.f; }   // [dimp]: largest |x - c| (then the scale), as float bits for atomicMax
     if (k >= dimp) return;
     float s = 0.f;
     if (avecs && k < dim)
@@ -730,26 +741,56 @@ __global__ void k_st_centre(const float *__restrict__ avecs, int na, int dim, in
     cvec[k] = (avecs && k < dim && na > 0) ? s / (float)na : 0.f;
 }
 
-// Xb[row] = {bf16 hi parts of the row's dimp centred floats, then their lo parts}: hi = bf16(x) (round to nearest even),
-// lo = bf16(x - hi) -- the same bytes per row as the float32 copy; rsb[row] = |x - c|^2 (+inf on padding rows).
-// dimp / 4 threads per row, one float4 each.
-__global__ __launch_bounds__(256) void k_st_split_bf16(const float *__restrict__ Xs, const float *__restrict__ rs, const float *__restrict__ cvec,
-                                                       int64_t n_pad, int dimp, uint16_t *__restrict__ Xb, float *__restrict__ rsb)
+// largest |coordinate| of the centred rows (non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void k_st_absmax(const float *__restrict__ Xs, const float *__restrict__ rs, int64_t n4, int dimp,
+                                                   float *__restrict__ cvec)
+{
+    const int per = dimp / 4;
+    float m = 0.f;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / per;
+        if (!(rs[row] < INFINITY)) continue;
+        const float4 v = reinterpret_cast<const float4 *>(Xs)[t], cc = reinterpret_cast<const float4 *>(cvec)[t - row * per];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x - cc.x), fabsf(v.y - cc.y))), fmaxf(fabsf(v.z - cc.z), fabsf(v.w - cc.w)));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int *>(cvec + dimp + 1), __float_as_uint(m));
+}
+
+// the power of two that brings the largest |coordinate| to (2^12, 2^13]: fp16 holds 65504, a row's squared norm stays far
+// inside float32, and scaling by a power of two is exact
+__global__ void k_st_scale(float *__restrict__ cvec, int dimp)
+{
+    const float m = cvec[dimp + 1];
+    int e = 0;
+    if (m > 0.f && m < INFINITY) { (void)frexpf(m, &e); e = 13 - e; }   // m = f 2^e', f in [0.5, 1): m 2^(13 - e') in [2^12, 2^13)
+    cvec[dimp] = ldexpf(1.f, max(-100, min(100, e)));
+}
+
+// Xb[row] = {fp16 hi parts of the row's dimp centred, scaled floats, then their lo parts}: hi = fp16(x) (round to nearest
+// even), lo = fp16(x - hi) -- the same bytes per row as the float32 copy; three MFMAs (hi.hi + hi.lo + lo.hi) then
+// reproduce x.y to ~2^-22 |x||y|, the accuracy of the exact f32 MFMA stream (tools/microbench/f16_split.hip).
+// rsb[row] = |scale (x - c)|^2 (+inf on padding rows).  dimp / 4 threads per row, one float4 each.
+__global__ __launch_bounds__(256) void k_st_split_f16(const float *__restrict__ Xs, const float *__restrict__ rs, const float *__restrict__ cvec,
+                                                      int64_t n_pad, int dimp, uint16_t *__restrict__ Xb, float *__restrict__ rsb)
 {
     const int per = dimp / 4;   // 8, 16 or 32
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t row = t / per;
     const int q = (int)(t - row * per);
+    const float scale = cvec[dimp];
     float acc = 0.f;
     if (row < n_pad) {
         const float4 v = reinterpret_cast<const float4 *>(Xs)[t], cc = reinterpret_cast<const float4 *>(cvec)[q];
         const bool real = rs[row] < INFINITY;
-        const float x[4] = {real ? v.x - cc.x : 0.f, real ? v.y - cc.y : 0.f, real ? v.z - cc.z : 0.f, real ? v.w - cc.w : 0.f};
+        const float x[4] = {real ? (v.x - cc.x) * scale : 0.f, real ? (v.y - cc.y) * scale : 0.f, real ? (v.z - cc.z) * scale : 0.f,
+                            real ? (v.w - cc.w) * scale : 0.f};
         uint16_t h[4], l[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const __bf16 hb = (__bf16)x[j];
-            const __bf16 lb = (__bf16)(x[j] - (float)hb);
+            const _Float16 hb = (_Float16)x[j];
+            const _Float16 lb = (_Float16)(x[j] - (float)hb);
             h[j] = __builtin_bit_cast(uint16_t, hb);
             l[j] = __builtin_bit_cast(uint16_t, lb);
             acc += x[j] * x[j];
@@ -767,11 +808,14 @@ int ann_stream_split_rows(annchor_ctx *c, StreamState *s)
     const int64_t n4 = s->n_pad * (int64_t)(s->dimp / 4);
     ANN_TRY(ann_stream_reserve(c, s->Xb, sizeof(uint16_t) * 2 * (size_t)s->n_pad * s->dimp));
     ANN_TRY(ann_stream_reserve(c, s->rsb, sizeof(float) * (size_t)s->n_pad));
-    ANN_TRY(ann_stream_reserve(c, s->cvec, sizeof(float) * (size_t)s->dimp));
+    ANN_TRY(ann_stream_reserve(c, s->cvec, sizeof(float) * (size_t)(s->dimp + 2)));
     const bool have = s->avecs.p != nullptr && s->na > 0 && s->avecs.cap >= sizeof(float) * (size_t)s->na * s->dim;
     k_st_centre<<<ann_blocks(s->dimp, 128), 128, 0, c->stream>>>(have ? s->avecs.as<float>() : nullptr, s->na, s->dim, s->dimp, s->cvec.as<float>());
-    k_st_split_bf16<<<ann_blocks(n4, 256), 256, 0, c->stream>>>(s->Xs.as<float>(), s->rs.as<float>(), s->cvec.as<float>(), s->n_pad, s->dimp,
-                                                               s->Xb.as<uint16_t>(), s->rsb.as<float>());
+    k_st_absmax<<<(int)std::min<int64_t>(ann_blocks(n4, 256), 4096), 256, 0, c->stream>>>(s->Xs.as<float>(), s->rs.as<float>(), n4, s->dimp,
+                                                                                        s->cvec.as<float>());
+    k_st_scale<<<1, 1, 0, c->stream>>>(s->cvec.as<float>(), s->dimp);
+    k_st_split_f16<<<ann_blocks(n4, 256), 256, 0, c->stream>>>(s->Xs.as<float>(), s->rs.as<float>(), s->cvec.as<float>(), s->n_pad, s->dimp,
+                                                              s->Xb.as<uint16_t>(), s->rsb.as<float>());
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
 }

@@ -35,9 +35,9 @@ struct StreamState {
     DevBuf X;        // float [n_local][dim]      (copy of the caller's rows)
     DevBuf keys, keys2, vals, vals2, cubtmp;
     DevBuf Xs;       // float [n_pad][dimp]       rows in tile order, zero padded
-    DevBuf Xb;       // bf16 [n_pad][2][dimp]     the same rows, centred, split into hi + lo halves (knnbf.hip), dimp <= 128 only
-    DevBuf rsb;      // float [n_pad]             squared norms of the centred rows (+inf on padding rows)
-    DevBuf cvec;     // float [dimp]              the centre: mean of the anchors' coordinates (zeros without anchors)
+    DevBuf Xb;       // fp16 [n_pad][2][dimp]     the same rows, centred and scaled, split into hi + lo halves (knnbf.hip), dimp <= 128 only
+    DevBuf rsb;      // float [n_pad]             squared norms of the centred, scaled rows (+inf on padding rows)
+    DevBuf cvec;     // float [dimp + 2]          the centre: mean of the anchors' coordinates (zeros without anchors); [dimp] the power-of-two scale
     DevBuf rs;       // float [n_pad]             squared norms (+inf on padding rows)
     DevBuf perm;     // int64 [n_pad]             global id of each ordered row (-1 padding)
     DevBuf lo, hi, mid;  // float [na][nt]        per-tile anchor-distance intervals and means
@@ -55,8 +55,8 @@ struct StreamState {
     DevBuf rev_cnt, rev_ptr, rev_edges, rev;   // reverse neighbour lists of every ordered row (join passes)
     int64_t n_local = 0, n_pad = 0, base = 0;
     int64_t last_tile_evals = 0, last_join_chunks = 0;
-    int last_kernel = 0;   // tile phase of the last build: 0 k_st_knn (exact f32), 1 k_st_knnbf (split bf16)
-    int64_t last_guard_rows = 0;   // rows the split-bf16 kernel flagged (error band of the split products reaches the list boundary)
+    int last_kernel = 0;   // tile phase of the last build: 0 k_st_knn (exact f32), 1 k_st_knnbf (split fp16)
+    int64_t last_guard_rows = 0;   // rows the split-fp16 kernel flagged (error band of the split products reaches the list boundary)
     int dim = 0, dimp = 0, na = 0, nt = 0;
     struct KnnArgs *run = nullptr;   // arguments of the graph build in progress (begin / join / end)
     const void *run_perm = nullptr;
@@ -76,9 +76,9 @@ struct StreamState {
 
 struct KnnArgs {
     const float *Xs;      // [n_all][DIM]   all column tiles (every rank's ordered shard, concatenated)
-    const uint16_t *Xb;   // [n_all][2][DIM] bf16 hi / lo halves of the same rows minus cvec (NULL: none -- the f32 kernel runs)
+    const uint16_t *Xb;   // [n_all][2][DIM] fp16 hi / lo halves of scale * (the same rows - cvec) (NULL: none -- the f32 kernel runs)
     const float *rsb;     // [n_all] squared norms of the centred rows
-    const float *cvec;    // [DIM] what was subtracted (the row operand is centred in the kernel)
+    const float *cvec;    // [DIM + 1] what was subtracted, then the scale (the row operand is centred and scaled in the kernel)
     const float *rs;      // [n_all]
     const float *lo, *hi, *mid; // [na][nt_all]
     int nt_all, na;
@@ -109,7 +109,7 @@ struct KnnArgs {
 };
 
 StreamState *ann_stream_state(annchor_ctx *c, bool create);
-// knnbf.hip: the tile phase on the bf16 matrix cores (split operands, two 4-wave workgroups per CU); *handled = false
+// knnbf.hip: the tile phase on the 16-bit matrix cores (split operands, two 4-wave workgroups per CU); *handled = false
 // when the shape does not fit it (padded dim > 128, more than 30 neighbours, no split copy) and the caller launches k_st_knn
 int ann_stream_launch_knnbf(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled);
 int ann_stream_split_rows(annchor_ctx *c, StreamState *s);     // Xb from Xs (after the ordering)

@@ -554,7 +554,7 @@ extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs
                                                                       s->rs.as<float>(), s->perm.as<int64_t>());
     k_st_intervals<<<s->nt, ST_T, 0, c->stream>>>(s->D.as<float>(), s->vals2.as<uint32_t>(), n, s->na, s->nt, s->lo.as<float>(),
                                                  s->hi.as<float>(), s->mid.as<float>());
-    if (s->dimp <= 128) ANN_TRY(ann_stream_split_rows(c, s));   // the bf16 hi / lo copy the tile kernel streams (knn8.hip)
+    if (s->dimp <= 128) ANN_TRY(ann_stream_split_rows(c, s));   // the fp16 hi / lo copy the tile kernel streams (knnbf.hip)
     ANN_CHECK_HIP(c, hipGetLastError());
     ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     *Xs = s->Xs.p; *rs = s->rs.p; *perm = s->perm.p; *lo = s->lo.p; *hi = s->hi.p; *mid = s->mid.p;
@@ -1479,7 +1479,7 @@ template <int DIM> static int launch_knn(annchor_ctx *c, const KnnArgs &a, bool 
 static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool join, bool exact = false)
 {
     if (!join) {
-        // ANNCHOR_ST_KERNEL=4wave: the exact-f32 kernel below for every shape (A/B runs, tests); default: the split-bf16
+        // ANNCHOR_ST_KERNEL=4wave: the exact-f32 kernel below for every shape (A/B runs, tests); default: the split-fp16
         // kernel (knnbf.hip) where the shape fits it
         static const char *kern = getenv("ANNCHOR_ST_KERNEL");
         StreamState *st = state_of(c, false);
@@ -1583,7 +1583,7 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
     }
     s->last_guard_rows = 0;
     if (s->last_kernel != 0) {
-        // The split-bf16 kernel keeps K + 2 columns per row by a distance that is off by ~2^-19 |x||y| and re-ranks them exactly;
+        // The split-fp16 kernel keeps K + 2 columns per row by a distance that is off by ~2^-22 |x||y| and re-ranks them exactly;
         // its epilogue counts the rows whose K-th exact distance comes within the MEASURED error of the list's last approximate
         // entry -- rows where a neighbour may have been left outside the list.  Well-conditioned data flags (almost) none; when
         // more than 1 row in 200 is flagged (tight clusters far from the centre: |x|^2 >> d^2) the tile phase runs again on
@@ -1593,7 +1593,7 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
         s->last_guard_rows = (int64_t)flagged;
         static const bool no_fallback = getenv("ANNCHOR_ST_NO_FALLBACK") != nullptr;
         if ((int64_t)flagged > std::max<int64_t>(8, rows / 200) && !no_fallback) {
-            fprintf(stderr, "annchor: streamed tile phase: %llu of %lld rows have neighbours closer together than the split-bf16 products "
+            fprintf(stderr, "annchor: streamed tile phase: %llu of %lld rows have neighbours closer together than float32-grade products of |x|^2 "
                             "resolve (|x|^2 >> d^2); running the exact float32 tile kernel instead\n", flagged, (long long)rows);
             ANN_CHECK_HIP(c, hipMemsetAsync(s->evals.p, 0, 32, c->stream));
             if (a.eval_bits) ANN_CHECK_HIP(c, hipMemsetAsync(s->eval_bits.p, 0, sizeof(uint32_t) * (size_t)a.tile_count * a.eval_words, c->stream));

@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 INT32_VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # 78.6 T lane-ops/s (256 CUs x 4 SIMD32 x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
-BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md; measured 2495)
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA (MI355X_MICROARCH.md; measured 2495)
 LEV_OPS_PER_WORD_STEP = 17  # Myers/Hyyro recurrence, 32-bit ops per (pattern word x text symbol)
 
 
@@ -335,16 +335,16 @@ def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, r
                                            "x 128 x 128 x 2 x d; peak = dense f32 MFMA"}
             else:
                 name = "k_st_knnbf"
-                out["roofline"] = {"kernel": "stream_tile_gemm_topk (%s: split-bf16 tile GEMMs, 3 x v_mfma_f32_32x32x16_bf16 per 16 dimensions)" % name,
+                out["roofline"] = {"kernel": "stream_tile_gemm_topk (%s: split-fp16 tile GEMMs, 3 x v_mfma_f32_32x32x16_f16 per 16 dimensions)" % name,
                                    "bound": "mfma", "achieved": 3.0 * flops / gemm_s / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": 3.0 * flops / gemm_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(name, largest=True),
                                    "tile_pairs": int(tile_phase_evals),
                                    "hbm_view": None,
                                    "f32_equivalent": {"achieved": flops / gemm_s / 1e12, "unit": "TFLOP/s",
                                                       "of_the_f32_mfma_peak_157.3": flops / gemm_s / 1e12 / 157.3},
-                                   "note": "achieved = MFMA flops issued: every float is split into bf16 hi + lo and a dot product is "
-                                           "hi.hi + hi.lo + lo.hi, i.e. 3 x (tile pairs x 128 x 128 x 2 x d); peak = dense bf16 MFMA "
-                                           "(MI355X_MICROARCH.md: ~2.5 PFLOP/s).  The split products select K + 2 columns per row; their "
+                                   "note": "achieved = MFMA flops issued: every float is split into fp16 hi + lo (centred, scaled by a power of two) and a dot product is "
+                                           "hi.hi + hi.lo + lo.hi, i.e. 3 x (tile pairs x 128 x 128 x 2 x d); peak = dense fp16 / bf16 MFMA "
+                                           "(MI355X_MICROARCH.md: ~2.5 PFLOP/s).  The split products are as accurate as the f32 MFMA stream (2^-22 |x||y|, tools/microbench/f16_split.hip) and select K + 2 columns per row; their "
                                            "exact float32 distances decide the K that are kept, so the graph is the exact-f32 kernel's "
                                            "(f32_equivalent = the algorithmic f32 flops of the same tile pairs / the same time)"}
     if out and out.get("roofline") and out["roofline"].get("traffic") and "hbm_view" in out["roofline"]:
@@ -353,7 +353,7 @@ def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, r
         r["hbm_view"] = {"bound": "hbm", "traffic_GB": round(r["traffic"] / 1e9, 1), "GBps": round(r["traffic"] / gemm_s / 1e9, 1),
                          "peak": HBM_PEAK_GBS, "frac": r["traffic"] / gemm_s / 1e9 / HBM_PEAK_GBS,
                          "streamed_operand_GB": round(tile_phase_evals * 65536.0 / 1e9, 1),
-                         "note": "64 KB of split-bf16 column operands per tile pair, every one fetched from beyond L2: the kernel is "
+                         "note": "64 KB of split-fp16 column operands per tile pair, every one fetched from beyond L2: the kernel is "
                                  "closer to the HBM roof than to the MFMA roof; traffic from the committed PMC pass"}
     last._engine.close()
     return out
@@ -876,7 +876,7 @@ def main():
             "value": res["graphs_per_s"], "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["fit_time_s"] * 1e3, "fit_time_s": res["fit_time_s"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 rows; tile selection on bf16 hi + lo split operands with f32 accumulation (v_mfma_f32_32x32x16_bf16), the kept "
+            "dtype": "f32 rows; tile selection on fp16 hi + lo split operands with f32 accumulation (v_mfma_f32_32x32x16_f16: products to 2^-22 |x||y|, the accuracy of the f32 MFMA stream), the kept "
                      "columns re-ranked by exact f32 distances; reported distances exact f32, widened to f64",
             "data": "synthetic (SURVEY.md 8d recipe: 8-d latent manifold in 128-d, float32), generated per shard",
             "config": {"workload": res["workload"], "total_rows": n_per_rank * world, "baseline_quoted_on": quoted,

@@ -353,8 +353,8 @@ int annchor_stream_knn_end(annchor_ctx *ctx, int64_t *row_ids, int64_t *ng_idx, 
 /* Split of the last build's tile_evals: tile evaluations of the tile phase, 128-column runs of the join passes. */
 int annchor_stream_last_counts(annchor_ctx *ctx, int64_t *tile_phase_evals, int64_t *join_chunks);
 /* Which kernel evaluated the last build's tile phase: 0 = exact float32 tile GEMMs (v_mfma_f32_32x32x2_f32; padded
- * dim 256, more than 30 neighbours, or the fallback below), 1 = split-bf16 tile GEMMs (three v_mfma_f32_32x32x16_bf16 per
- * 16 dimensions on centred rows, K + 2 columns kept per row and re-ranked by their exact float32 distances;
+ * dim 256, more than 30 neighbours, or the fallback below), 1 = split-fp16 tile GEMMs (three v_mfma_f32_32x32x16_f16 per
+ * 16 dimensions on centred, power-of-two scaled rows: products to ~2^-22 |x||y|, the accuracy of the f32 MFMA stream; K + 2 columns kept per row and re-ranked by their exact float32 distances;
  * csrc/knnbf.hip).  *guard_rows = rows the split kernel flagged: its K-th exact distance came within twice the measured
  * error of the products of the list's last approximate entry, i.e. a neighbour may have stayed outside the list; when
  * more than 1 row in 200 is flagged the tile phase is repeated on the exact kernel (kind 0 is reported then).  The

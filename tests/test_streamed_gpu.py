@@ -576,9 +576,10 @@ def _truth_rows(X, rows, k):
     return np.array(out)
 
 
-def test_split_bf16_tile_kernel_centres_the_rows():
-    """The tile kernel evaluates |x|^2 + |y|^2 - 2 x.y on bf16 hi + lo halves (csrc/knnbf.hip): rows far from the origin
-    would lose their neighbours' distances in |x|^2.  The split copy is centred on the anchors' mean, so a data set shifted
+def test_split_fp16_tile_kernel_centres_the_rows():
+    """The tile kernel evaluates |x|^2 + |y|^2 - 2 x.y on fp16 hi + lo halves (csrc/knnbf.hip): rows far from the origin
+    would lose their neighbours' distances in |x|^2 (and leave fp16's range).  The split copy is centred on the anchors' mean
+    and scaled by a power of two, so a data set shifted
     by 1000 in every coordinate gives the exact graph like the unshifted one (full budget, rtol 1e-5 against float64
     differences of the same float32 rows), on the split kernel, with (almost) no row flagged by its guard."""
     from annchor_amd.streamed import StreamedAnnchor
@@ -592,9 +593,9 @@ def test_split_bf16_tile_kernel_centres_the_rows():
     np.testing.assert_allclose(sa.neighbor_graph[1][rows], _truth_rows(X, rows, k), rtol=1e-5, atol=1e-6)
 
 
-def test_split_bf16_guard_falls_back_to_the_exact_kernel():
-    """Tight clusters far from the centre (|x - c|^2 ~ 10^4 d^2): the split products (error ~2^-19 |x||y|) no longer
-    resolve the neighbours' distances.  The kernel's guard -- K-th exact distance within twice the measured error of the
+def test_split_fp16_guard_falls_back_to_the_exact_kernel():
+    """Tight clusters far from the centre (|x - c|^2 ~ 10^4 d^2): float32-grade products of |x|^2 (the split products are
+    good to ~2^-22 |x||y|, like the f32 MFMA stream) no longer resolve the neighbours' distances.  The kernel's guard -- K-th exact distance within twice the measured error of the
     list's last approximate entry -- flags the rows, and the tile phase is repeated on the exact-f32 kernel; on
     well-conditioned data of the same size nothing is flagged."""
     from annchor_amd import compare_neighbor_graphs
