@@ -83,6 +83,7 @@ template <int DIM, int KMAX> struct KnnSharedB {
     float rrow[ST_T];    // |x_row|^2
     int cnt[ST_T];
     float loI[64], hiI[64], midI[64];
+    uint32_t slab_id[4][ST_SLAB];   // join passes: ordered column index of each column of a slab (slot = slab & 3)
     float run_vb[ST_KEEP];     // the current round's tiles in rank order: valid bound, tile
     int32_t run_j[ST_KEEP];
     float wave_thr[2][4];   // worst k-th squared distance per 32-row group, published at the end of tile n into [n & 1]
@@ -111,7 +112,9 @@ __device__ __forceinline__ void slab_end()
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_st_knnbf(KnnArgs a)
+// JOIN: a join pass (streamed.hip: k_st_join_cands has collected the row tile's candidate columns) -- the "tiles" are runs of
+// 128 gathered columns of the candidate list, the lists start from the previous phase's, nothing is ranked or pruned.
+template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_st_knnbf(KnnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smemb[];
     KnnSharedB<DIM, KMAX> &sh = *reinterpret_cast<KnnSharedB<DIM, KMAX> *>(smemb);
@@ -171,12 +174,29 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
     if (threadIdx.x < ST_T) {
         const int row = threadIdx.x;
         const bool real = a.rr[grow0 + row] < INFINITY;
-        sh.thr[row] = real ? INFINITY : -1.f;   // padding rows never accept candidates
-        sh.hb[row] = real ? -INFINITY : INFINITY;
         sh.cnt[row] = 0;
-        for (int q = 0; q < KMAX; ++q) { sh.list_d[row][q] = INFINITY; sh.list_c[row][q] = 0x7fffffff; }
+        if constexpr (JOIN) {
+            // the lists as the previous phase left them (exact d^2, original units -> scaled); the KL - K spare entries start
+            // as copies of the K-th value without a column, so that the row's threshold is its current K-th distance
+            float last = INFINITY;
+            for (int q = 0; q < KMAX; ++q) {
+                const bool have = q < K;
+                const float d = have ? a.out_d2[((size_t)bt * ST_T + row) * K + q] * (scale * scale) : last;
+                sh.list_d[row][q] = q < KL ? d : INFINITY;
+                sh.list_c[row][q] = have ? a.lists_all[((size_t)grow0 + row) * K + q] : 0x7fffffff;
+                if (have) last = d;
+            }
+            sh.thr[row] = real ? last : -1.f;
+        } else {
+            sh.thr[row] = real ? INFINITY : -1.f;   // padding rows never accept candidates
+            for (int q = 0; q < KMAX; ++q) { sh.list_d[row][q] = INFINITY; sh.list_c[row][q] = 0x7fffffff; }
+        }
     }
-    if (lane < 32) sh.rrow[rowbase + lane] = a.rr[grow0 + rowbase + lane] < INFINITY ? rr_c : INFINITY;   // |x_row - c|^2
+    if (lane < 32) {
+        const bool real = a.rr[grow0 + rowbase + lane] < INFINITY;
+        sh.rrow[rowbase + lane] = real ? rr_c : INFINITY;   // |scale (x_row - c)|^2
+        // (hb = (rrow - thr) / 2; thr of this row was written by thread rowbase + lane above: another wave -> after the barrier)
+    }
     if ((int)threadIdx.x < a.na) {
         sh.loI[threadIdx.x] = a.rlo[(size_t)threadIdx.x * a.nt_r + I];
         sh.hiI[threadIdx.x] = a.rhi[(size_t)threadIdx.x * a.nt_r + I];
@@ -189,12 +209,18 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
     int tdone = 0;       // column tiles completed and published (uniform); tile n publishes into slot n & 1
     int win_start = 0, win_ins = 0;
     bool dried = false;
-    uint32_t *ebits = a.eval_bits ? a.eval_bits + (size_t)bt * a.eval_words : nullptr;
+    uint32_t *ebits = (!JOIN && a.eval_bits) ? a.eval_bits + (size_t)bt * a.eval_words : nullptr;   // (a join pass only reads them)
 #ifdef ST_PROFILE
     long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long pf_t = st8_now();
     long long pf_s = pf_t;
 #endif
+    __syncthreads();
+    if (threadIdx.x < ST_T) {
+        const int row = threadIdx.x;
+        const float t = sh.thr[row];
+        sh.hb[row] = t < 0.f ? INFINITY : (t < INFINITY ? 0.5f * (sh.rrow[row] - t) : -INFINITY);
+    }
     __syncthreads();
 
     // ---------------------------------------------------------------- the pieces of a phase
@@ -208,7 +234,26 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
         loff[i] = (uint32_t)(c * DIM * 4 + ((x ^ unit_swz<UPC>(c)) << 4));
     }
     const char *xb = reinterpret_cast<const char *>(a.Xb);   // [n_all][2][DIM] fp16: hi parts, then lo parts of every ordered row (centred, scaled)
+    const uint32_t *ulist = JOIN ? a.ucand + (size_t)bt * a.ucap : nullptr;   // join: sorted candidate columns, 0xffffffff padded to 128
     auto issue_slab = [&](int J, int slab) {
+        if constexpr (JOIN) {
+            // gathered columns: every lane's source is its own column's row (per-lane 64-bit addresses)
+            const uint32_t dst = lds0 + (uint32_t)((slab & 1) * ST_SLAB * DIM * 4 + rg * NI * 1024);
+            const int64_t c0 = (int64_t)J * ST_T + slab * ST_SLAB;
+            const char *srcs[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int u = (rg * NI + i) * 64 + lane;
+                const uint32_t id = ulist[c0 + u / UPC];
+                srcs[i] = xb + (size_t)(id == 0xffffffffu ? 0u : id) * (DIM * 4) + (loff[i] - (uint32_t)((u / UPC) * DIM * 4));
+            }
+            unsigned keep;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(srcs[i]), "s"(dst + (uint32_t)(i * 1024)) : "memory");
+            return;
+        }
         const char *src = xb + ((size_t)J * ST_T + slab * ST_SLAB) * (DIM * 4);              // wave-uniform: an SGPR pair
         const uint32_t dst = lds0 + (uint32_t)((slab & 1) * ST_SLAB * DIM * 4 + rg * NI * 1024);   // this wave's pieces of the slot
         unsigned keep;
@@ -241,7 +286,13 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
     // load is thousands of cycles.
     auto stream_slab = [&](int J, int slab, f32x16 &accC, const f32x16 &accP) {
         PS0
-        rj_c = a.rsb[(int64_t)J * ST_T + slab * ST_SLAB + col];
+        if constexpr (JOIN) {
+            const uint32_t id = ulist[(int64_t)J * ST_T + slab * ST_SLAB + col];
+            rj_c = id == 0xffffffffu ? INFINITY : a.rsb[id];   // (padding never passes: x.y > hb + inf is false)
+            if (wave == 0 && lane < ST_SLAB) sh.slab_id[slab & 3][lane] = id;
+        } else {
+            rj_c = a.rsb[(int64_t)J * ST_T + slab * ST_SLAB + col];
+        }
         const float4 *base = reinterpret_cast<const float4 *>(&sh.ring[(slab & 1) * (ST_SLAB * DIM)]) + col * UPC;
         const int gsw = half ^ unit_swz<UPC>(col);
         float hq[16];   // (first: LDS data returns in order, and the test must not wait for the operands behind it)
@@ -293,7 +344,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
         const float rj = prj;
         uint32_t pass = ppass;
         PS0
-        const bool self_tile = !a.query && (int64_t)J * ST_T == grow0;
+        const bool self_tile = !JOIN && !a.query && (int64_t)J * ST_T == grow0;
         PS(10)   // thresholds read, accumulators there, 16 tests
         if (pass) {
             if (self_tile) {   // a point is not its own neighbour
@@ -344,10 +395,19 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
                 while (__ballot(q < nc)) {
                     const bool on = q < nc;
                     const float d = on ? sh.cand_d[row][q] : INFINITY;
-                    const int32_t cc = on ? col0 + sh.cand_c[row][q] : 0x7fffffff;
+                    int32_t cc;
+                    if constexpr (JOIN) cc = on ? (int32_t)sh.slab_id[slab & 3][sh.cand_c[row][q]] : 0x7fffffff;
+                    else cc = on ? col0 + sh.cand_c[row][q] : 0x7fffffff;
                     const bool before = e < KL && (ld < d || (ld == d && lc < cc));   // entries that stay ahead of the candidate
                     const unsigned long long bb = __ballot(before);
-                    const int pos = __popcll((bb >> (grpi * GL)) & ((GL == 64) ? ~0ull : ((1ull << GL) - 1)));
+                    const unsigned long long gmask = (GL == 64) ? ~0ull : ((1ull << GL) - 1);
+                    const int pos = __popcll((bb >> (grpi * GL)) & gmask);
+                    bool skip = false;
+                    if constexpr (JOIN) {
+                        // gathered columns: the row itself and columns the row already lists may come by
+                        const unsigned long long dup = __ballot(e < KL && lc == cc);
+                        skip = ((dup >> (grpi * GL)) & gmask) != 0 || (int64_t)cc == grow0 + row;
+                    }
                     float pd;
                     int32_t pc;
                     if constexpr (GL == 16) {
@@ -357,7 +417,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
                         pd = __shfl_up(ld, 1, GL);
                         pc = __shfl_up(lc, 1, GL);
                     }
-                    if (on && pos < KL) {
+                    if (on && !skip && pos < KL) {
                         ld = e > pos ? pd : (e == pos ? d : ld);
                         lc = e > pos ? pc : (e == pos ? cc : lc);
                         ins += (e == 0 && pos < K) ? 1 : 0;   // the yield that stops the tile phase counts what reaches the K entries handed on
@@ -408,7 +468,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
     auto run = [&](int ns, auto jl, auto vb) {
         int q = 0;
         auto next_tile = [&](int in_stream) -> int {
-            if (a.early_window > 0 && !dried) {
+            if (!JOIN && a.early_window > 0 && !dried) {
                 const int done = processed - in_stream;   // tiles completed (the one in the stream is not)
                 if (done - win_start >= a.early_window) {
                     int cur = 0;
@@ -420,7 +480,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
             }
             if (dried) return -1;
             const float tm = thrmax_now();
-            while (q < ns && processed < a.max_tiles) {
+            while (q < ns && (JOIN || processed < a.max_tiles)) {
                 const int J = jl(q);
                 const float lb = vb(q);
                 ++q;
@@ -498,12 +558,16 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
 
     // ---- phase A: the row tile against itself (gives every row K finite candidates); query rows are not part of the
     // data set and start from the ranked tiles directly
-    if (!a.query) {
-        const int budget = a.max_tiles;
+    if constexpr (JOIN) {
+        const int nu = a.ucount[bt];
+        const int nchunks = (nu + ST_T - 1) / ST_T;
+        run(nchunks, [&](int q) { return q; }, [&](int) { return 0.f; });
+        processed = nchunks;
+    } else if (!a.query) {
         run(1, [&](int) { return I; }, [&](int) { return 0.f; });
-        (void)budget;
     }
 
+    if constexpr (!JOIN) {
     // ---- phase B: all other column tiles, exactly as k_st_knn ranks and selects them (streamed.hip): rank key and
     // valid bound of every column tile into a scratch row, then rounds of {3-level radix selection of the next ST_KEEP
     // tiles in (key, tile) order, collect, sort, stream}
@@ -630,6 +694,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
         if (processed >= a.max_tiles) break;
         if (!more) break;   // the selection saw every eligible tile
     }
+    }   // (!JOIN)
     __syncthreads();
     // ---- exact re-ranking: the lists hold KL >= K columns chosen by the split-fp16 distance (error ~1e-5 relative on a
     // neighbour's d^2); their exact float32 distances sum (x - y)^2 decide which K are handed on, and in which order
@@ -679,17 +744,25 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
             // guard, part 2: a column left outside the list has an approximate d^2 >= the list's last approximate entry; it can
             // only belong among the K nearest if its exact d^2 is below the K-th exact one, i.e. if the products were off by more
             // than the room between the two -- flagged when that room is within twice the measured error
-            if (nfin > K && ex[row * KMAX + K - 1] + 2.f * eps > sh.list_d[row][KL - 1] * inv_scale2) atomicAdd(&sh.nsurv, 1);   // (nsurv is idle here)
+            if (!JOIN && nfin > K && ex[row * KMAX + K - 1] + 2.f * eps > sh.list_d[row][KL - 1] * inv_scale2) atomicAdd(&sh.nsurv, 1);   // (nsurv is idle here)
         }
         __syncthreads();
         for (int q = threadIdx.x; q < ST_T * K; q += STB_THREADS) {
             const int row = q / K, e = q - row * K;
             const float d2 = ex[row * KMAX + e];
-            a.out_d2[((size_t)bt * ST_T + row) * K + e] = d2;
-            a.out_col[((size_t)bt * ST_T + row) * K + e] = d2 < INFINITY ? sh.list_c[row][e] : 0x7fffffff;
+            float *od = JOIN ? a.out_d2_new : a.out_d2;
+            int32_t *oc = JOIN ? a.out_col_new : a.out_col;
+            od[((size_t)bt * ST_T + row) * K + e] = d2;
+            oc[((size_t)bt * ST_T + row) * K + e] = d2 < INFINITY ? sh.list_c[row][e] : 0x7fffffff;
         }
     }
-    if (threadIdx.x == 0) {
+    if constexpr (JOIN) {
+        if (threadIdx.x == 0) atomicAdd(a.evals + 2, (unsigned long long)processed);   // slot 2: join chunks (0: tile phase, 1: pass yield)
+        int wins = ins;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wins += __shfl_xor(wins, off);
+        if (lane == 0 && wins) atomicAdd(a.updates, (unsigned long long)wins);
+    } else if (threadIdx.x == 0) {
         atomicAdd(a.evals, (unsigned long long)processed);
         if (sh.nsurv) atomicAdd(a.evals + 3, (unsigned long long)sh.nsurv);   // slot 3: rows flagged by the guard
     }
@@ -700,12 +773,17 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(STB_THREADS, 2) __attr
 #endif
 }
 
-template <int DIM, int KMAX> static int launchb(annchor_ctx *c, const KnnArgs &a)
+template <int DIM, int KMAX> static int launchb(annchor_ctx *c, const KnnArgs &a, bool join)
 {
     const size_t lds = sizeof(KnnSharedB<DIM, KMAX>);
     ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "streamed k-NN (split-fp16 form) needs %zu B of LDS", lds);
-    ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knnbf<DIM, KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_st_knnbf<DIM, KMAX><<<a.tile_count, STB_THREADS, lds, c->stream>>>(a);
+    if (join) {
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knnbf<DIM, KMAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_st_knnbf<DIM, KMAX, true><<<a.tile_count, STB_THREADS, lds, c->stream>>>(a);
+    } else {
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knnbf<DIM, KMAX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_st_knnbf<DIM, KMAX, false><<<a.tile_count, STB_THREADS, lds, c->stream>>>(a);
+    }
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
 }
@@ -713,15 +791,15 @@ template <int DIM, int KMAX> static int launchb(annchor_ctx *c, const KnnArgs &a
 // The tile phase through the split-fp16 kernel when the shape fits it (padded dim <= 128: a slab of 32 columns is 16 KB there;
 // K + ST_BF_MARGIN <= 32 list entries; the split copy of the columns exists); *handled = false sends the caller to the
 // exact-f32 kernel k_st_knn.
-int ann_stream_launch_knnbf(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool *handled)
+int ann_stream_launch_knnbf(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool *handled, bool join)
 {
     *handled = true;
     if (a.K + ST_BF_MARGIN > ST_KMAX || !a.Xb || !a.rsb || !a.cvec) { *handled = false; return ANNCHOR_OK; }
     const bool k16 = a.K + ST_BF_MARGIN <= 16;
     switch (dim_padded) {
-    case 32: return k16 ? launchb<32, 16>(c, a) : launchb<32, ST_KMAX>(c, a);
-    case 64: return k16 ? launchb<64, 16>(c, a) : launchb<64, ST_KMAX>(c, a);
-    case 128: return k16 ? launchb<128, 16>(c, a) : launchb<128, ST_KMAX>(c, a);
+    case 32: return k16 ? launchb<32, 16>(c, a, join) : launchb<32, ST_KMAX>(c, a, join);
+    case 64: return k16 ? launchb<64, 16>(c, a, join) : launchb<64, ST_KMAX>(c, a, join);
+    case 128: return k16 ? launchb<128, 16>(c, a, join) : launchb<128, ST_KMAX>(c, a, join);
     default: *handled = false; return ANNCHOR_OK;
     }
 }

@@ -111,7 +111,7 @@ struct KnnArgs {
 StreamState *ann_stream_state(annchor_ctx *c, bool create);
 // knnbf.hip: the tile phase on the 16-bit matrix cores (split operands, two 4-wave workgroups per CU); *handled = false
 // when the shape does not fit it (padded dim > 128, more than 30 neighbours, no split copy) and the caller launches k_st_knn
-int ann_stream_launch_knnbf(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled);
+int ann_stream_launch_knnbf(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled, bool join = false);
 int ann_stream_split_rows(annchor_ctx *c, StreamState *s);     // Xb from Xs (after the ordering)
 // the split copy (+ centred norms, centre) that belongs to an ordered float32 array; false: none
 bool ann_stream_split_of(const void *Xs, const uint16_t **Xb, const float **rsb, const float **cvec);

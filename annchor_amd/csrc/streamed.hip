@@ -1478,17 +1478,19 @@ template <int DIM> static int launch_knn(annchor_ctx *c, const KnnArgs &a, bool 
 
 static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool join, bool exact = false)
 {
-    if (!join) {
-        // ANNCHOR_ST_KERNEL=4wave: the exact-f32 kernel below for every shape (A/B runs, tests); default: the split-fp16
-        // kernel (knnbf.hip) where the shape fits it
+    {
+        // ANNCHOR_ST_KERNEL=4wave: the exact-f32 kernels below for every shape (A/B runs, tests); default: the split-fp16
+        // kernel (knnbf.hip) where the shape fits it -- the join passes follow the tile phase's kernel (a tile phase that fell
+        // back to the exact kernel is followed by exact join passes)
         static const char *kern = getenv("ANNCHOR_ST_KERNEL");
         StreamState *st = state_of(c, false);
-        if (st) st->last_kernel = 0;
-        if (!exact && (!kern || strcmp(kern, "4wave"))) {
+        if (!join && st) st->last_kernel = 0;
+        const bool want_split = !exact && (!kern || strcmp(kern, "4wave")) && (!join || (st && st->last_kernel == 1));
+        if (want_split) {
             bool handled = false;
-            ANN_TRY(ann_stream_launch_knnbf(c, a, dim_padded, &handled));
+            ANN_TRY(ann_stream_launch_knnbf(c, a, dim_padded, &handled, join));
             if (handled) {
-                if (st) st->last_kernel = 1;
+                if (!join && st) st->last_kernel = 1;
                 return ANNCHOR_OK;
             }
         }
