@@ -213,17 +213,29 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
                 unsigned long long sinkdone = 0, srcdone = 1ull << s;
                 double srcdist = 0.0;   // valid on lanes whose srcdone bit is set
                 int srcfrom = -1;
-                int jend = -1;
                 double mu = 0.0;
+                // The search does not stop at the first sink with demand left: it goes on until the demand it has met covers
+                // what source s still has to place (or every sink is scanned).  One shortest-path tree then carries several
+                // augmentations -- a source whose mass splits over two or three sinks used to start its search over for each of
+                // them and re-scan the same near sinks.
+                int prank = -1;         // order in which THIS lane's sink was reached, among the sinks with demand left
+                int nhit = 0;
+                T need = as;
                 for (;;) {
                     const bool open = lane < m && !((sinkdone >> lane) & 1ull);
                     const double best = wave_min_nonneg_f64(open ? dist : INFINITY);
                     const unsigned long long hit = __ballot(open && dist == best);
-                    if (!hit) break;                       // every sink scanned: only rounding dust left
+                    if (!hit) break;                       // every sink scanned
                     const int js = __ffsll((unsigned long long)hit) - 1;  // first index on ties
                     sinkdone |= 1ull << js;
                     mu = best;
-                    if (rl(b_rem, js) > (T)0) { jend = js; break; }
+                    const T bj = rl(b_rem, js);
+                    if (bj > (T)0) {
+                        if (lane == js) prank = nhit;
+                        ++nhit;
+                        need -= tmin(need, bj);
+                        if (!(need > (T)0)) break;
+                    }
                     // sources with flow into js that are not scanned yet
                     const T fcol = lane < n ? F[lane * S + js] : (T)0;
                     unsigned long long todo = __ballot(lane < n && fcol > (T)0 && !((srcdone >> lane) & 1ull));
@@ -240,32 +252,37 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
                         }
                     }
                 }
-                if (jend < 0) { dust = true; break; }
-                // ---- potentials
+                if (nhit == 0) { dust = true; break; }     // only rounding dust left
+                // ---- potentials: every scanned node against the last distance popped -- the tree's arcs are tight afterwards
                 if ((srcdone >> lane) & 1ull) u += mu - srcdist;
                 if ((sinkdone >> lane) & 1ull) v -= mu - dist;
-                // ---- bottleneck along the path, then augment
-                T delta = tmin(as, rl(b_rem, jend));
-                for (int j = jend;;) {
-                    const int i = __builtin_amdgcn_readlane(pred, j);
-                    if (i == s) break;
-                    const int jj = __builtin_amdgcn_readlane(srcfrom, i);
-                    delta = tmin(delta, F[i * S + jj]);   // uniform address: LDS broadcast
-                    j = jj;
+                // ---- augment along the tree to every sink reached with demand left, nearest first; a path's bottleneck is taken
+                // from the flows as the earlier augmentations of this search left them
+                for (int k = 0; k < nhit; ++k) {
+                    const int jend = __ffsll((unsigned long long)__ballot(prank == k)) - 1;
+                    T delta = tmin(rl(a_rem, s), rl(b_rem, jend));
+                    for (int j = jend; delta > (T)0;) {
+                        const int i = __builtin_amdgcn_readlane(pred, j);
+                        if (i == s) break;
+                        const int jj = __builtin_amdgcn_readlane(srcfrom, i);
+                        delta = tmin(delta, F[i * S + jj]);   // uniform address: LDS broadcast
+                        j = jj;
+                    }
+                    if (!(delta > (T)0)) continue;
+                    for (int j = jend;;) {
+                        const int i = __builtin_amdgcn_readlane(pred, j);
+                        if (lane == 0) F[i * S + j] += delta;
+                        if (i == s) break;
+                        const int jj = __builtin_amdgcn_readlane(srcfrom, i);
+                        if (lane == 0) F[i * S + jj] -= delta;
+                        j = jj;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if (lane == s) a_rem -= delta;
+                    if (lane == jend) b_rem -= delta;
                 }
-                for (int j = jend;;) {
-                    const int i = __builtin_amdgcn_readlane(pred, j);
-                    if (lane == 0) F[i * S + j] += delta;
-                    if (i == s) break;
-                    const int jj = __builtin_amdgcn_readlane(srcfrom, i);
-                    if (lane == 0) F[i * S + jj] -= delta;
-                    j = jj;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                if (lane == s) a_rem -= delta;
-                if (lane == jend) b_rem -= delta;
             }
         }
         // ---- objective
