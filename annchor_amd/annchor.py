@@ -643,6 +643,7 @@ class Annchor:
         ep_ = self.error_predictor
         ep_.partition_bins, ep_.n_partitions, ep_.labels = self.sample_bins, nb, range(nb)
         ep_.errs = _LazyErrs(self._engine, ep)
+        ep_.errs._load()   # now: a later predict_merge / select_candidates with host lists (or closing the engine) overwrites the device copy
         return True
 
     @property

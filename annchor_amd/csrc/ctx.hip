@@ -98,6 +98,9 @@ void ann_dev_free(annchor_ctx *c, void *p, size_t bytes)
 {
     if (!p) return;
     if (bytes >= POOL_MIN_BLOCK && pool_enabled()) {
+        // (the hipFree this replaces waited for the device: kernels queued on this context's stream may still read the block,
+        // and the next taker may be another context with another stream)
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
         std::lock_guard<std::mutex> lk(g_pool_mu);
         if (g_pool_bytes + bytes <= pool_cap()) {
             g_pool.push_back({p, bytes, c->device});

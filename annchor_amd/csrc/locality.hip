@@ -486,7 +486,9 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
     if (n > (1ll << 27)) {   // ~130 B per pair over the stages that follow: refuse here, not in the middle of a fit
         size_t fr = 0, tot = 0;
         ANN_CHECK_HIP(c, hipMemGetInfo(&fr, &tot));
-        const double have = (double)fr + (double)c->ij.cap + (double)c->Iidx.cap + (double)c->lb.cap + (double)c->ub.cap + (double)c->dad.cap + (double)c->RA.cap + (double)c->prob.cap;
+        int64_t parked = 0;   // blocks this process keeps in its pool count as free (ann_dev_alloc hands them out or flushes them)
+        (void)annchor_parked_bytes(c->device, &parked);
+        const double have = (double)fr + (double)parked + (double)c->ij.cap + (double)c->Iidx.cap + (double)c->lb.cap + (double)c->ub.cap + (double)c->dad.cap + (double)c->RA.cap + (double)c->prob.cap;
         ANN_REQUIRE(c, (double)n * 130.0 <= have, ANNCHOR_ELIMIT,
                     "%lld candidate pairs need ~%.0f GB of device memory, %.0f GB are free: raise loc_thresh / lower locality",
                     (long long)n, (double)n * 130.0 / 1e9, have / 1e9);

@@ -256,6 +256,15 @@ class StreamedAnnchor:
 
         t0 = time.perf_counter()
         eng, comm = self._engine, self.comm
+        out = None
+        if self.n_local * self.n_neighbors >= (1 << 20):
+            # the graph's host arrays, allocated and page-faulted on a helper thread while the GPU works (_native.GraphBuffers)
+            try:
+                from ._native import GraphBuffers
+
+                out = GraphBuffers(self.n_local, self.n_neighbors)
+            except ImportError:   # (the CPU protocol tests run against a stand-in engine without the library)
+                out = None
         self.get_anchors()
         t1 = time.perf_counter()
         sharded = comm.world > 1 or self.force_exchange
@@ -280,7 +289,7 @@ class StreamedAnnchor:
         if not sharded:
             _, idx, dist, tile_evals = eng.stream_knn(ptrs, n_all, nt_all, self.n_anchors, dimp, 0, nt, self.n_neighbors,
                                                       self.p_work, n_local=self.n_local, join_passes=self.join_passes,
-                                                      join_extra=self.join_extra)
+                                                      join_extra=self.join_extra, **({"out": out} if out is not None else {}))
         else:
             # tile phase on the rank's own row tiles, then join passes against the all-gathered neighbour lists
             total, tile_budget, per_pass = self._budget(nt_all)
@@ -301,7 +310,8 @@ class StreamedAnnchor:
             # shard's own row order, downloaded once
             send, send_counts, words, tile_evals = eng.stream_route_begin(self._starts, self._bases)
             recv, n_recv = comm.alltoall_records(eng, send, send_counts, words)
-            idx, dist = eng.stream_route_end(n_recv, int(counts.max()), self.n_local, self.n_neighbors)
+            idx, dist = eng.stream_route_end(n_recv, int(counts.max()), self.n_local, self.n_neighbors,
+                                             **({"out": out} if out is not None else {}))
         t4 = time.perf_counter()
         # the ordered column arrays (every row of the data set) stay alive: query() runs against them
         self._columns = dict(ptrs=ptrs, n_all=n_all, nt_all=nt_all, dimp=dimp)
