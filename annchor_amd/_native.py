@@ -67,6 +67,7 @@ _SIGNATURES = {
     "annchor_fit_errors_device": (ctypes.c_int, [_vp]),
     "annchor_model_download": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "annchor_errors_download": (ctypes.c_int, [_vp, _vp, _i64]),
+    "annchor_model_download_with_errors": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, ctypes.POINTER(_i64)]),
     "annchor_hash_sample": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, ctypes.c_uint64, _vp, ctypes.POINTER(_i64)]),
     "annchor_hash_sample_pairs": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, ctypes.c_uint64, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "annchor_legacy_prefetch": (ctypes.c_int, [ctypes.c_uint32, _i64]),
@@ -570,6 +571,17 @@ class Engine:
         ep = np.zeros(nb + 1, dtype=np.int64) if with_errors else None
         self._chk(self.lib.annchor_model_download(self.h, _ptr(W), _ptr(c), _ptr(status), _ptr(ep), _ptr(flags)))
         return W, c, status, ep, flags
+
+    def model_download_with_errors(self, nb, cap):
+        """model_download + errors_download behind one wait: (W, c, status, err_ptr, flags, errs or None)."""
+        W, c = np.zeros((nb, 3)), np.zeros(nb)
+        status, flags = np.zeros(nb, dtype=np.int32), np.zeros(3, dtype=np.int32)
+        ep = np.zeros(nb + 1, dtype=np.int64)
+        errs = np.empty(int(cap), dtype=np.float64)
+        n = _i64()
+        self._chk(self.lib.annchor_model_download_with_errors(self.h, _ptr(W), _ptr(c), _ptr(status), _ptr(ep), _ptr(flags), _ptr(errs),
+                                                             int(cap), ctypes.byref(n)))
+        return W, c, status, ep, flags, (errs[:n.value] if n.value >= 0 else None)
 
     def errors_download(self, n):
         out = np.empty(int(n), dtype=np.float64)

@@ -87,45 +87,6 @@ class _DeviceModelRefused(Exception):
     """A device-fitted iteration met a partition its solver does not take; fit() starts over on the host solver."""
 
 
-class _LazyErrs(dict):
-    """error_predictor.errs after a device-fitted iteration: label -> sorted residuals, downloaded on first use."""
-
-    def __init__(self, engine, err_ptr):
-        super().__init__()
-        self._engine, self._ptr, self._loaded = engine, np.asarray(err_ptr, dtype=np.int64), False
-
-    def _load(self):
-        if not self._loaded:
-            self._loaded = True
-            flat = self._engine.errors_download(int(self._ptr[-1]))
-            for b in range(len(self._ptr) - 1):
-                dict.__setitem__(self, b, flat[self._ptr[b]:self._ptr[b + 1]].copy())
-
-    def __getitem__(self, k):
-        self._load()
-        return dict.__getitem__(self, k)
-
-    def __iter__(self):
-        self._load()
-        return dict.__iter__(self)
-
-    def __len__(self):
-        self._load()
-        return dict.__len__(self)
-
-    def keys(self):
-        self._load()
-        return dict.keys(self)
-
-    def items(self):
-        self._load()
-        return dict.items(self)
-
-    def values(self):
-        self._load()
-        return dict.values(self)
-
-
 class _IndexCSR:
     """Read-only stand-in for the reference's typed dict `I` (utils.py:533-540):
     I[i] -> int64 array of positions in IJs that contain i."""
@@ -631,10 +592,12 @@ class Annchor:
     def _adopt_device_model(self, nb):
         """After a device-fitted iteration: the coefficients into the regression object (what its fit() would have
         left there) and the sticky flags; False when the host has to redo the models."""
-        W, c, status, ep, flags = self._engine.model_download(nb)
+        # (coefficients, flags and the sorted residual lists behind ONE wait: a later predict_merge / select_candidates with
+        # host lists, or closing the engine, would overwrite the device copy of the lists)
+        W, c, status, ep, flags, flat = self._engine.model_download_with_errors(nb, 2 * int(self.n_samples) + 16)
         if flags[0] == 1:
             raise _native.NativeError("sample step: a (bin, rank) entry does not exist (stale counts?)")
-        if flags[0] or flags[1] or flags[2] or status.any():   # (flags[0] == 2: a hashed key list came out short -- retry the waiting way)
+        if flags[0] or flags[1] or flags[2] or status.any() or flat is None:   # (flags[0] == 2: a hashed key list came out short -- retry the waiting way)
             self._device_model_refused = (status.copy(), flags.copy())   # (kept for diagnostics / tests)
             return False
         reg = self.regression
@@ -642,8 +605,7 @@ class Annchor:
         self._device_err_ptr = ep
         ep_ = self.error_predictor
         ep_.partition_bins, ep_.n_partitions, ep_.labels = self.sample_bins, nb, range(nb)
-        ep_.errs = _LazyErrs(self._engine, ep)
-        ep_.errs._load()   # now: a later predict_merge / select_candidates with host lists (or closing the engine) overwrites the device copy
+        ep_.errs = {b: flat[ep[b]:ep[b + 1]].copy() for b in range(nb)}
         return True
 
     @property

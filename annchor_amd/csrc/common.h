@@ -55,6 +55,9 @@ struct annchor_ctx {
     double lev_frac0 = 0.0;
     DevBuf lev_order;        // int32 [nx]: string ids, strings of <= 16 words first (k_lev_a2: two such pairs share a wave)
     int lev_nshort = 0;
+    DevBuf lev_ap;           // k_lev_ap (all anchor rounds in one launch): u64 [2][1024] arrival slots, then the abort word
+    DevBuf lev_ap_min;       // uint16 [nx]: running minima of the rescue form
+    uint32_t lev_ap_epoch = 0;
     DevBuf lev_cursors;      // int32 [2][2]: class counters of k_lev_classify, two slots used in turn (a call zeroes the NEXT call's slot)
     int lev_cursor_epoch = 0;
     DevBuf lev_perm;         // int32 [n] pair positions, short patterns first / long ones from the back; + 2 counters
@@ -296,6 +299,8 @@ __device__ __forceinline__ void argmax_combine(double &v, int &i, double ov, int
 }
 int ann_metric_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
 int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
+// every round of the max-min picker in ONE launch (lev.hip, k_lev_ap); *done = false: not taken, the caller runs the rounds one by one
+int ann_lev_anchor_rounds(annchor_ctx *c, int32_t na, int32_t first, bool *done);
 int ann_euclid_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
 int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
 

@@ -1391,6 +1391,315 @@ __global__ __launch_bounds__(ANN_WAVE) void k_lev_p2(LevArgsP2 aa)
 }
 
 
+// ---------------------------------------------------------------------------------------
+// k_lev_ap: EVERY round of the max-min picker (pickers.py:44-50) in one launch.  The rounds are a chain -- round r + 1's
+// anchor is the arg-max over round r's distances -- and as 15 launches of k_lev_a2 each of them pays a dispatch gap, the
+// staging of the wave's own strings, a match-mask build and an arg-max scan of the whole row (~15 of 26 us per round at C2).
+// Here the waves of k_lev_a2 (two short strings or one long string per wave, one wave per SIMD) stay resident:
+//   * a wave's own strings are ALWAYS the bit-vector patterns (they fit their slots by construction), the anchor is the text:
+//     the match-mask tables are built once, a round stages only the anchor's symbols, and every wave of a round walks
+//     the same number of columns (len(anchor) / 2 + words) -- nobody waits at the barrier for a longer text;
+//   * a wave owns the running minima of its own points (registers): the arg-max is a max over one 32-bit key per wave
+//     [running minimum : 16 | 0xffff - point : 16] (np.argmax: first maximal index), and the grid barrier IS that
+//     reduction -- every wave stores (round tag, key) to its arrival slot; <= 16 collector waves poll 64 slots each until they
+//     carry the round's tag and publish the maximum, everybody polls the collectors' slots; no atomics (12.5 ns each on one
+//     address, serialised);
+//   * anchorRank (picker.hip: k_fill_i32 + k_anchor_rank) falls out: a wave knows every round's anchor.
+// All waves must be resident (the launcher checks the occupancy).  Should they not be -- another process holding CUs -- a
+// wave that polls longer than the time limit raises the abort word and everybody leaves; the RESCUE instantiation,
+// enqueued behind every persistent launch, then redoes the rounds as ONE workgroup (no residency assumption) and returns
+// at once otherwise.
+struct LevArgsAP {
+    const uint8_t *sym;
+    const int32_t *soff;
+    const int32_t *slen;
+    const int32_t *order;         // string ids, <= 16-word strings first
+    double *Dt;                   // [na][nx]
+    int32_t *A;                   // [na]
+    int32_t *rank;                // [nx]: round of the LAST occurrence in A, -1 otherwise
+    unsigned long long *slots;    // [4][slot_stride]: (tag << 32) | key; arrival slots of even / odd rounds, then the collectors' partial maxima
+    uint32_t *abort_epoch;        // epoch of the last launch that gave up
+    uint16_t *rescue_min;         // [nx]: running minima of the rescue form
+    long long timeout_ticks;      // wall_clock64 ticks (100 MHz)
+    long long *dbg;               // -DLEV_AP_PROFILE: [wave][round][8] s_memtime stamps
+    uint32_t epoch;
+    int n_short, nx, na, first, ntasks, slot_stride;
+    int alphabet, pm_bytes, fb_stride, buf_stride, pad, wave_bytes;
+};
+
+template <bool RESCUE> __global__ __launch_bounds__(RESCUE ? 512 : ANN_WAVE) void k_lev_ap(LevArgsAP a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    __shared__ uint32_t s_best;
+    __shared__ int32_t s_A[64];
+    {
+        const uint32_t ab = __hip_atomic_load(a.abort_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (RESCUE ? ab != a.epoch : ab == a.epoch) return;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    unsigned char *smem = smem_all + (size_t)wv * a.wave_bytes;
+    const int A = a.alphabet, nx = a.nx;
+    unsigned char *pm_col = smem + (size_t)(lane >> 5) * A * LEVF_ROW + (size_t)(lane & 31) * 4;
+    uint8_t *bufs = smem + a.pm_bytes;                    // [0], [1]: the wave's strings, [2]: the anchor
+    int16_t *FB = reinterpret_cast<int16_t *>(bufs + 3 * a.buf_stride);   // [pair][half][fb_stride]
+    const int ws = (a.n_short + 1) >> 1;                  // tasks of the packed class
+    // ---- the task's shape (persistent form: bound once, before round 0)
+    int tq0 = -1, tq1 = -1, w = 0, pair = 0, half = 0, LP = 64, m = 0, Wp = 0, mytq = -1;
+    bool have = false;
+    uint32_t hp_or = 0, hn_and = 0, rows = 0;
+    uint32_t rm0 = 0xffffu, rm1 = 0xffffu;               // running minima of the wave's points (persistent form)
+    int rk0 = -1, rk1 = -1;
+    int si = a.first;
+    for (int r = 0; r < a.na; ++r) {
+        if (RESCUE) {
+            if (threadIdx.x == 0) { s_best = 0; s_A[r] = si; }
+            __syncthreads();
+        }
+#ifdef LEV_AP_PROFILE
+#define AP_STAMP(i) do { if (!RESCUE && lane == 0) a.dbg[((size_t)blockIdx.x * 64 + r) * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define AP_STAMP(i) do { } while (0)
+#endif
+        AP_STAMP(0);
+        if ((RESCUE ? threadIdx.x : blockIdx.x + lane) == 0) a.A[r] = si;
+        const int la = a.slen[si];
+        const uint8_t *asrc = a.sym + a.soff[si];
+        uint32_t mykey = 0;
+        for (int vb = RESCUE ? wv : (int)blockIdx.x; vb < a.ntasks; vb += RESCUE ? nwv : a.ntasks) {
+            if (RESCUE || r == 0) {
+                const bool packed = vb < ws;
+                const int GL = packed ? 16 : 32;
+                const int slot = lane / GL;
+                w = lane - slot * GL; pair = slot >> 1; half = slot & 1; LP = packed ? 32 : 64;
+                hp_or = w == 0 ? 0x80000000u : 0u;
+                hn_and = w == 0 ? 0u : 0xffffffffu;
+                asm volatile("" : "+v"(hp_or), "+v"(hn_and));
+                tq0 = tq1 = -1;
+                if (packed) {
+                    tq0 = a.order[2 * vb];
+                    if (2 * vb + 1 < a.n_short) tq1 = a.order[2 * vb + 1];
+                } else {
+                    tq0 = a.order[a.n_short + (vb - ws)];
+                }
+                for (int e = lane * 16; e < 3 * a.buf_stride; e += 64 * 16) *reinterpret_cast<uint4 *>(bufs + e) = make_uint4(0, 0, 0, 0);
+                int ln0 = 0, ln1 = 0;
+                {
+                    ln0 = a.slen[tq0];
+                    const uint8_t *src = a.sym + a.soff[tq0];
+                    for (int ch = lane; ch < ((ln0 + 15) >> 4); ch += 64)
+                        reinterpret_cast<uint4 *>(bufs + a.pad)[ch] = reinterpret_cast<const uint4 *>(src)[ch];
+                }
+                if (tq1 >= 0) {
+                    ln1 = a.slen[tq1];
+                    const uint8_t *src = a.sym + a.soff[tq1];
+                    for (int ch = lane; ch < ((ln1 + 15) >> 4); ch += 64)
+                        reinterpret_cast<uint4 *>(bufs + a.buf_stride + a.pad)[ch] = reinterpret_cast<const uint4 *>(src)[ch];
+                }
+                wave_lds_fence();
+                have = pair == 0 || (packed && pair == 1 && tq1 >= 0);
+                mytq = !have ? -1 : (pair == 0 ? tq0 : tq1);
+                m = !have ? 0 : (pair == 0 ? ln0 : ln1);          // the wave's own string is the pattern
+                Wp = (m + 31) >> 5;
+                const uint8_t *pat = bufs + pair * a.buf_stride + a.pad;
+                for (int c = 0; c < A; ++c) *reinterpret_cast<uint32_t *>(pm_col + (size_t)c * LEVF_ROW) = 0u;
+                if (have && w < Wp) {
+                    const int valid = min(32, m - w * 32);
+                    uint32_t sy[32];
+                    if (half == 0) {
+                        const uint4 *p16 = reinterpret_cast<const uint4 *>(pat + w * 32);
+                        const uint4 q0 = p16[0], q1 = p16[1];
+                        const uint32_t wd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                        for (int k = 0; k < 32; ++k) sy[k] = (wd[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 32; ++k) sy[k] = pat[max(m - 1 - (w * 32 + k), 0)];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 32; ++k)
+                        if (k < valid) atomicOr(reinterpret_cast<uint32_t *>(pm_col + (size_t)sy[k] * LEVF_ROW), 1u << k);
+                }
+                rows = !have ? 0u : (w < Wp - 1 ? 0xffffffffu : (w == Wp - 1 ? (0xffffffffu >> (31 - ((m - 1) & 31))) : 0u));
+            }
+            // ---- the round's text: the anchor (stale bytes behind a shorter anchor are symbols of the previous one: they index
+            // the match-mask table and are never used)
+            for (int ch = lane; ch < ((la + 15) >> 4); ch += 64)
+                reinterpret_cast<uint4 *>(bufs + 2 * a.buf_stride + a.pad)[ch] = reinterpret_cast<const uint4 *>(asrc)[ch];
+            wave_lds_fence();
+            AP_STAMP(1);
+            const uint8_t *txt = bufs + 2 * a.buf_stride + a.pad;
+            const int n = have ? la : 0;
+            const int h = (n + 1) >> 1;
+            const uint32_t un = (have && m > 0) ? (uint32_t)(half ? n - h : h) : 0u;
+            int max_steps = (have && m > 0) ? h + Wp - 1 : 0;
+            int k_lo = (have && m > 0) ? Wp - 1 : 0, k_hi = (have && m > 0) ? n - h : 0x7fffffff;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                max_steps = max(max_steps, __shfl_xor(max_steps, off));
+                k_lo = max(k_lo, __shfl_xor(k_lo, off));
+                k_hi = min(k_hi, __shfl_xor(k_hi, off));
+            }
+            max_steps = __builtin_amdgcn_readfirstlane(max_steps);
+            k_lo = min(__builtin_amdgcn_readfirstlane(k_lo), max_steps);
+            k_hi = max(k_lo, min(__builtin_amdgcn_readfirstlane(k_hi), max_steps));
+            const int dir = half ? -1 : 1;
+            const uint8_t *tp = txt + (half ? n - 1 + w : -w);
+            uint32_t vp = 0xffffffffu, vn = 0u;
+            uint32_t c1 = tp[dir];
+            uint32_t eq = *reinterpret_cast<const uint32_t *>(pm_col + (uint32_t)tp[0] * LEVF_ROW);
+            uint32_t out_hp = 0, out_hn = 0;
+            const uint8_t *tnext = tp + 2 * dir;
+            auto column = [&](int k, auto checked) {
+                const uint32_t c2 = *tnext;
+                tnext += dir;
+                const uint32_t eq_n = *reinterpret_cast<const uint32_t *>(pm_col + c1 * LEVF_ROW);
+                const uint32_t hp_up = dpp_shr1_or(out_hp, hp_or), hn_up = dpp_shr1_and(out_hn, hn_and);
+                __builtin_amdgcn_sched_barrier(0);
+                const bool valid = !decltype(checked)::value || (uint32_t)(k - w) < un;
+                const uint32_t c = hn_up >> 31;
+                const uint32_t x = eq | c;
+                const uint32_t tt = __builtin_amdgcn_bitop3_b32(c, eq, vp, 0xa8);
+                const uint32_t sm = tt + vp;
+                const uint32_t d0p = __builtin_amdgcn_bitop3_b32(sm, vp, x, 0xbe);
+                const uint32_t hp = __builtin_amdgcn_bitop3_b32(vn, d0p, vp, 0xf1);
+                const uint32_t d0 = d0p | vn;
+                const uint32_t hn = d0 & vp;
+                const uint32_t hps = __builtin_amdgcn_alignbit(hp, hp_up, 31);
+                const uint32_t hns = __builtin_amdgcn_alignbit(hn, hn_up, 31);
+                const uint32_t nvp = __builtin_amdgcn_bitop3_b32(hns, d0, hps, 0xf1);
+                const uint32_t nvn = hps & d0;
+                vp = valid ? nvp : vp;
+                vn = valid ? nvn : vn;
+                out_hp = hp;
+                out_hn = hn;
+                __builtin_amdgcn_sched_barrier(0);
+                eq = eq_n;
+                c1 = c2;
+            };
+            AP_STAMP(2);
+            int k = 0;
+            for (; k < k_lo; ++k) column(k, std::true_type());
+            for (; k + 2 <= k_hi; k += 2) { column(k, std::false_type()); column(k + 1, std::false_type()); }
+            for (; k < k_hi; ++k) column(k, std::false_type());
+            for (; k < max_steps; ++k) column(k, std::true_type());
+            AP_STAMP(3);
+
+            // ---- F / B' (prefix sums of the vertical deltas down this half's rows), then min_i F[i] + B'[m - i] per pair
+            const int part = __popc(vp & rows) - __popc(vn & rows);
+            int incl = part;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                const int o = __shfl_up(incl, off, 32);
+                if (w >= off) incl += o;
+            }
+            int val = (int)un + incl - part;
+            if (m == 0) val = half ? n - h : h;
+            int16_t *fbp = FB + (size_t)pair * 2 * a.fb_stride;
+            int16_t *fb = fbp + (size_t)half * a.fb_stride;
+            if (have && w == 0) fb[0] = (int16_t)val;
+#pragma unroll
+            for (int b = 0; b < 32; ++b) {
+                val += (int)((vp >> b) & 1u) - (int)((vn >> b) & 1u);
+                if ((rows >> b) & 1u) fb[w * 32 + b + 1] = (int16_t)val;
+            }
+            wave_lds_fence();
+            int best = 0x7fffffff;
+            const int lp = lane & (LP - 1);
+            if (have)
+                for (int i = lp; i <= m; i += LP) best = min(best, (int)fbp[i] + (int)fbp[a.fb_stride + m - i]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                if (off < LP) best = min(best, __shfl_xor(best, off));
+            if (have && lp == 0) a.Dt[(size_t)r * nx + mytq] = (double)best;
+            wave_lds_fence();   // (FB and the text are rewritten by the next task / round)
+            AP_STAMP(4);
+            // ---- running minima (pickers.py:47-50: over row 0 alone for the second anchor, over rows 1..r afterwards)
+            if (RESCUE) {
+                if (have && lp == 0) {
+                    uint32_t v = (uint32_t)best;
+                    if (r > 1) v = min(v, (uint32_t)a.rescue_min[mytq]);
+                    a.rescue_min[mytq] = (uint16_t)v;
+                    atomicMax(&s_best, (v << 16) | (uint32_t)(0xffff - mytq));
+                }
+            } else {
+                const uint32_t d0 = (uint32_t)__shfl(best, 0), d1 = (uint32_t)__shfl(best, 32);
+                rm0 = r <= 1 ? d0 : min(rm0, d0);
+                rm1 = r <= 1 ? d1 : min(rm1, d1);
+                mykey = (rm0 << 16) | (uint32_t)(0xffff - tq0);
+                if (tq1 >= 0) mykey = max(mykey, (rm1 << 16) | (uint32_t)(0xffff - tq1));
+                if (si == tq0) rk0 = r;
+                if (si == tq1) rk1 = r;
+            }
+        }
+        if (r + 1 == a.na) break;
+        if (RESCUE) {
+            __syncthreads();
+            si = 0xffff - (int)(s_best & 0xffffu);
+            __syncthreads();
+        } else {
+            // ---- arrive + arg-max in two hops: wave g < ceil(ntasks / 64) collects the slots of waves 64 g .. 64 g + 63 (one load
+            // per lane) and publishes their maximum; everybody polls those <= 16 partial slots.  (Everybody polling every slot
+            // -- 965 waves x 7.7 KB per poll on 120 cache lines -- cost 5.6 us per round; this is two short hops.)
+            const uint32_t tag = a.epoch * 64u + (uint32_t)r;
+            unsigned long long *sl = a.slots + (size_t)(r & 1) * a.slot_stride;
+            unsigned long long *pl = sl + 2 * a.slot_stride;          // partial maxima [2][slot_stride] behind the arrival slots
+            const int ngroups = (a.ntasks + 63) >> 6;
+            if (lane == 0)
+                __hip_atomic_store(sl + blockIdx.x, ((unsigned long long)tag << 32) | mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long t0 = wall_clock64();
+            AP_STAMP(5);
+            uint32_t mx;
+            bool collected = (int)blockIdx.x >= ngroups;             // nothing to collect / done
+            int polls = 0;
+            for (;;) {
+                if (!collected) {
+                    const unsigned long long v = __hip_atomic_load(sl + min((int)blockIdx.x * 64 + lane, a.ntasks - 1), __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all((uint32_t)(v >> 32) == tag)) {
+                        uint32_t gm = (uint32_t)v;
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) gm = max(gm, (uint32_t)__shfl_xor((int)gm, off));
+                        if (lane == 0)
+                            __hip_atomic_store(pl + blockIdx.x, ((unsigned long long)tag << 32) | gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        collected = true;
+                    }
+                }
+                if (collected) {
+                    const unsigned long long v = __hip_atomic_load(pl + min(lane, ngroups - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mx = (uint32_t)v;
+                    if (__all((uint32_t)(v >> 32) == tag)) break;
+                }
+                // (the abort word and the clock every 8th poll: a second dependent load would double the poll period)
+                if ((++polls & 7) == 0 || a.timeout_ticks == 0) {
+                    if (__hip_atomic_load(a.abort_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch) return;
+                    if (wall_clock64() - t0 > a.timeout_ticks) {
+                        if (lane == 0) __hip_atomic_store(a.abort_epoch, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return;
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+            si = 0xffff - (int)(mx & 0xffffu);
+            AP_STAMP(6);
+        }
+    }
+    // ---- anchorRank
+    if (RESCUE) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < nx; j += blockDim.x) a.rank[j] = -1;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int r = 0; r < a.na; ++r) a.rank[s_A[r]] = r;   // a later occurrence overrides an earlier one (annchor.py:288-289)
+    } else {
+        // (the last round's anchor is in si; the loop above recorded rounds 0 .. na - 1 as it ran them)
+        if (lane == 0) {
+            a.rank[tq0] = rk0;
+            if (tq1 >= 0) a.rank[tq1] = rk1;
+        }
+    }
+}
+
 static int launch_p2(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm)
 {
     LevArgsP2 a;
@@ -1460,6 +1769,104 @@ static int launch_a2(annchor_ctx *c, const PairSource &src, double *d_out)
         ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev_a2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_lev_a2<<<(int)blocks, ANN_WAVE, lds, c->stream>>>(aa);
     ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
+// All anchor rounds in one launch (k_lev_ap) when the data set allows it: byte alphabet, every string within a 32-lane slot,
+// point ids and distances within 16 bits, and every wave of the launch resident at once.
+int ann_lev_anchor_rounds(annchor_ctx *c, int32_t na, int32_t first, bool *done)
+{
+    *done = false;
+    {
+        const char *e = getenv("ANNCHOR_LEV_PERSIST");   // 0: the rounds one by one (A/B runs, tests); read per call
+        if (e && atoi(e) == 0) return ANNCHOR_OK;
+        const char *e_a = getenv("ANNCHOR_LEV_ANCHOR"), *e_r = getenv("ANNCHOR_LEV_R");
+        if ((e_a && atoi(e_a) != 2) || e_r) return ANNCHOR_OK;   // a forced kernel variant means the per-round path
+    }
+    if (c->metric != ANNCHOR_METRIC_LEVENSHTEIN || c->sym_wide || !c->lev_order.p) return ANNCHOR_OK;
+    if ((c->maxlen + 31) / 32 > 32 || c->nx > 8192 || na < 1 || na > 64) return ANNCHOR_OK;
+    LevArgsAP a;
+    a.ntasks = (c->lev_nshort + 1) / 2 + (int)(c->nx - c->lev_nshort);
+    if (a.ntasks > 1024) return ANNCHOR_OK;
+    a.alphabet = c->alphabet;
+    a.pm_bytes = 2 * a.alphabet * LEVF_ROW;
+    a.fb_stride = (c->maxlen + 2 + 7) & ~7;
+    a.pad = ((c->maxlen / 2 + 48) + 15) & ~15;
+    a.buf_stride = 2 * a.pad + ((c->maxlen + 15) & ~15) + 16;
+    a.wave_bytes = (int)(((size_t)a.pm_bytes + 3 * (size_t)a.buf_stride + 4 * sizeof(int16_t) * a.fb_stride + 15) & ~(size_t)15);
+    size_t lds = (size_t)a.wave_bytes;
+    if (lds > 160 * 1024) return ANNCHOR_OK;
+    // one wave per SIMD, as for k_lev_a2: a quarter of a CU's LDS per single-wave workgroup
+    if (a.ntasks <= c->prop.multiProcessorCount * 4 && lds < (size_t)40 * 1024) lds = (size_t)40 * 1024;
+    if (lds > 64 * 1024)
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev_ap<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    ANN_CHECK_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lev_ap<false>, ANN_WAVE, lds));
+    if ((int64_t)per_cu * c->prop.multiProcessorCount < a.ntasks) return ANNCHOR_OK;
+    // the rescue form: one workgroup of up to 8 waves
+    int rwaves = (int)std::min<size_t>(8, (160 * 1024 - 1024) / (size_t)a.wave_bytes);
+    if (rwaves < 1) return ANNCHOR_OK;
+    const size_t rlds = (size_t)rwaves * a.wave_bytes;
+    if (rlds > 64 * 1024)
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev_ap<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+    a.slot_stride = 1024;
+    const size_t slot_bytes = sizeof(unsigned long long) * 4 * (size_t)a.slot_stride;
+    if (!c->lev_ap.p) {
+        ANN_TRY(ann_reserve(c, c->lev_ap, slot_bytes + 64));
+        ANN_CHECK_HIP(c, hipMemsetAsync(c->lev_ap.p, 0, slot_bytes + 64, c->stream));
+        c->lev_ap_epoch = 0;
+    }
+    ANN_TRY(ann_reserve(c, c->lev_ap_min, sizeof(uint16_t) * (size_t)c->nx));
+    ANN_TRY(ann_reserve(c, c->anchorRank, sizeof(int32_t) * (size_t)c->nx));
+    a.sym = c->sym.as<uint8_t>(); a.soff = c->soff.as<int32_t>(); a.slen = c->slen.as<int32_t>();
+    a.order = c->lev_order.as<int32_t>();
+    a.Dt = c->Dt.as<double>(); a.A = c->A.as<int32_t>(); a.rank = c->anchorRank.as<int32_t>();
+    a.slots = c->lev_ap.as<unsigned long long>();
+    a.abort_epoch = reinterpret_cast<uint32_t *>(c->lev_ap.as<unsigned char>() + slot_bytes);
+    a.rescue_min = c->lev_ap_min.as<uint16_t>();
+    {
+        const char *e = getenv("ANNCHOR_LEV_PERSIST_TIMEOUT_US");   // (tests force the rescue form with 0)
+        a.timeout_ticks = (e ? atoll(e) : 20000ll) * 100;
+    }
+    a.dbg = nullptr;
+#ifdef LEV_AP_PROFILE
+    {
+        static long long *dbg = nullptr;
+        if (!dbg) (void)hipMalloc(&dbg, sizeof(long long) * 1024 * 64 * 8);
+        a.dbg = dbg;
+    }
+#endif
+    a.epoch = ++c->lev_ap_epoch;
+    if ((a.epoch & 0x3ffffffu) == 0) a.epoch = c->lev_ap_epoch = 1;   // (tag = epoch * 64 + round stays within 32 bits)
+    a.n_short = c->lev_nshort; a.nx = (int)c->nx; a.na = na; a.first = first;
+    {
+        const double word_bytes = (double)na * (double)c->nx * (2.0 * c->maxlen + 8);
+        ProfScope ps(c, "levenshtein_pairs", word_bytes);
+        k_lev_ap<false><<<a.ntasks, ANN_WAVE, lds, c->stream>>>(a);
+        k_lev_ap<true><<<1, rwaves * ANN_WAVE, rlds, c->stream>>>(a);
+    }
+    ANN_CHECK_HIP(c, hipGetLastError());
+#ifdef LEV_AP_PROFILE
+    {
+        static int calls = 0;
+        if (++calls == 5) {
+            std::vector<long long> h((size_t)1024 * 64 * 8);
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipMemcpy(h.data(), a.dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            const char *nm[6] = {"stage anchor", "loop setup", "columns", "prefix+combine", "key", "barrier"};
+            for (int b : {0, 1, 500, 700, a.ntasks - 1}) {
+                fprintf(stderr, "k_lev_ap wave %d:", b);
+                for (int ph = 0; ph < 6; ++ph) {
+                    double sum = 0;
+                    for (int r = 0; r + 1 < na; ++r) sum += (double)(h[((size_t)b * 64 + r) * 8 + ph + 1] - h[((size_t)b * 64 + r) * 8 + ph]);
+                    fprintf(stderr, " %s %.0f", nm[ph], sum / (na - 1));
+                }
+                fprintf(stderr, " | round %.0f (s_memtime ticks per round)\n", (double)(h[((size_t)b * 64 + na - 2) * 8 + 6] - h[(size_t)b * 64 * 8]) / (na - 1));
+            }
+        }
+    }
+#endif
+    *done = true;
     return ANNCHOR_OK;
 }
 

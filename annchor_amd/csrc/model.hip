@@ -373,6 +373,45 @@ extern "C" int annchor_model_download(annchor_ctx *c, double *W, double *cc, int
     return ANNCHOR_OK;
 }
 
+// annchor_model_download and annchor_errors_download behind ONE wait: the residual lists (at most 2 x n_samples doubles:
+// a sample on a bin edge belongs to two partitions) are copied whole, *n_errs = err_ptr[nb] of them are meaningful.
+extern "C" int annchor_model_download_with_errors(annchor_ctx *c, double *W, double *cc, int32_t *status, int64_t *err_ptr, int32_t *flags,
+                                                  double *errs, int64_t errs_cap, int64_t *n_errs)
+{
+    if (!c || !W || !cc || !status || !flags || !err_ptr || !errs || !n_errs) return ANNCHOR_EINVAL;
+    ANN_REQUIRE(c, c->model.p && c->model_nb > 0, ANNCHOR_ESTATE, "no model on this context");
+    ANN_REQUIRE(c, c->errs_on_device && c->errs.p, ANNCHOR_ESTATE, "no device-resident residual lists");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    const size_t eb = sizeof(double) * (size_t)std::min<int64_t>(errs_cap, 2 * c->nsamp);
+    const size_t off_f = (sizeof(DeviceModel) + 63) & ~(size_t)63, off_e = off_f + 64;
+    if (!c->pin || off_e + eb > annchor_ctx::PIN_DL_BYTES) {   // (large sample sets: the two-wait way)
+        ANN_TRY(annchor_model_download(c, W, cc, status, err_ptr, flags));
+        *n_errs = err_ptr[c->model_nb];
+        ANN_REQUIRE(c, *n_errs <= errs_cap, ANNCHOR_EINVAL, "residual lists hold %lld entries, room for %lld", (long long)*n_errs, (long long)errs_cap);
+        return annchor_errors_download(c, errs, *n_errs);
+    }
+    ANN_TRY(ann_dev_flags(c));
+    unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
+    ANN_CHECK_HIP(c, hipMemcpyAsync(slot, c->model.p, sizeof(DeviceModel), hipMemcpyDeviceToHost, c->stream));
+    ANN_CHECK_HIP(c, hipMemcpyAsync(slot + off_f, c->dev_flags.p, sizeof(int32_t) * 16, hipMemcpyDeviceToHost, c->stream));
+    if (eb) ANN_CHECK_HIP(c, hipMemcpyAsync(slot + off_e, c->errs.p, eb, hipMemcpyDeviceToHost, c->stream));
+    ANN_CHECK_HIP(c, ann_sync(c, __func__));
+    const DeviceModel &h = *reinterpret_cast<const DeviceModel *>(slot);
+    const int32_t *f = reinterpret_cast<const int32_t *>(slot + off_f);
+    for (int b = 0; b < c->model_nb; ++b) {
+        W[3 * b] = h.reg.w[b][0]; W[3 * b + 1] = h.reg.w[b][1]; W[3 * b + 2] = h.reg.w[b][2];
+        cc[b] = h.reg.c[b];
+        status[b] = h.status[b];
+    }
+    for (int b = 0; b <= c->model_nb; ++b) err_ptr[b] = h.errptr[b];
+    flags[0] = f[0]; flags[1] = f[1]; flags[2] = f[2];
+    *n_errs = err_ptr[c->model_nb];
+    if (*n_errs < 0 || (size_t)*n_errs * sizeof(double) > eb) *n_errs = -1;   // (a failed step: the flags say so; no list to hand out)
+    else memcpy(errs, slot + off_e, sizeof(double) * (size_t)*n_errs);
+    if (f[0] | f[1] | f[2]) ANN_CHECK_HIP(c, hipMemsetAsync(c->dev_flags.p, 0, sizeof(int32_t) * 16, c->stream));
+    return ANNCHOR_OK;
+}
+
 // the sorted residuals of annchor_fit_errors_device (float64 [n_errs], n_errs = err_ptr[nb])
 extern "C" int annchor_errors_download(annchor_ctx *c, double *errs, int64_t n_errs)
 {

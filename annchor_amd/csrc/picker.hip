@@ -137,6 +137,17 @@ extern "C" int annchor_pick_anchors_maxmin(annchor_ctx *c, int32_t na, int64_t f
     ANN_TRY(ann_reserve(c, c->redval, sizeof(double) * (size_t)rblocks));
     ANN_TRY(ann_reserve(c, c->redidx, sizeof(int) * (size_t)rblocks));
     int32_t f = (int32_t)first;
+    if (c->metric == ANNCHOR_METRIC_LEVENSHTEIN) {
+        // every round in one launch where the data set allows it (lev.hip: k_lev_ap); A and anchorRank come out of it
+        ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+        bool done = false;
+        ANN_TRY(ann_lev_anchor_rounds(c, na, f, &done));
+        if (done) {
+            ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+            c->call_timed = true;
+            return ANNCHOR_OK;
+        }
+    }
     ANN_TRY(ann_h2d(c, c->A.p, &f, sizeof f));
     ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
     bool fused_prev = false;   // the launch of round r picked its own anchor from row r - 1

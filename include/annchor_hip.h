@@ -251,6 +251,10 @@ int annchor_fit_regression_device(annchor_ctx *ctx, const double *bins, int32_t 
 int annchor_fit_errors_device(annchor_ctx *ctx);
 int annchor_model_download(annchor_ctx *ctx, double *W, double *c, int32_t *status, int64_t *err_ptr, int32_t *flags /*[3]*/);
 int annchor_errors_download(annchor_ctx *ctx, double *errs, int64_t n_errs);
+/* Both behind one host wait (what fit() calls after its last iteration): errs has room for errs_cap doubles (2 x n_samples
+ * always suffices); *n_errs = err_ptr[nbins], or -1 when the flags report a failed step. */
+int annchor_model_download_with_errors(annchor_ctx *ctx, double *W, double *c, int32_t *status, int64_t *err_ptr, int32_t *flags /*[3]*/,
+                                       double *errs, int64_t errs_cap, int64_t *n_errs);
 
 /* --------------------------------------------------------------- selection a14
  * select_refine_candidate_pairs (annchor.py:395-473) up to, not including, the

@@ -205,6 +205,67 @@ def test_levenshtein_anchor_round_kernel_ragged(monkeypatch):
         assert np.array_equal(e3.download(_native.F_D).reshape(len(Y), 3), w3)
 
 
+def test_levenshtein_anchor_rounds_one_launch(monkeypatch):
+    """k_lev_ap: every round of the max-min picker in one launch (resident waves, the arrival slots are the arg-max).  A and D
+    against the oracle's picker (pickers.py:44-50 incl. the D[1:] quirk and np.argmax's first index) and against the
+    round-by-round launches, on ragged strings (duplicates, empties, all slot shapes); the rescue form (forced by a zero
+    time limit: the first poll that finds a slot missing gives up) must give the same; a fit through either has the same graph."""
+    from annchor_amd import Annchor, _native
+    from annchor_amd.distances import levenshtein
+
+    rng = np.random.default_rng(77)
+    alphabet = [chr(c) for c in range(60, 120)]
+    sets = []
+    lens = list(range(0, 70)) + [95, 96, 97, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 640, 1000, 1023, 1024]
+    X = ["".join(rng.choice(alphabet[: rng.integers(2, 60)], n)) for n in lens for _ in range(2)]
+    sets.append(X + [X[9], X[150], "", ""])
+    sets.append(["".join(rng.choice(alphabet[:7], n)) for n in rng.integers(0, 500, 301)])      # every wave packed (odd count)
+    sets.append(["".join(rng.choice(alphabet[:5], n)) for n in rng.integers(513, 700, 150)])    # no wave packed
+    sets.append(["".join(rng.choice(alphabet[:3], n)) for n in rng.integers(1, 12, 900)])       # many ties
+    for X in sets:
+        nx = len(X)
+        P = om.PackedStrings(X)
+        for na, first in ((1, 0), (2, nx - 1), (3, 5), (17, nx // 2)):
+            # (O.maxmin_anchors with the first index given instead of drawn)
+            D = np.full((na, nx), np.inf)
+            A = np.zeros(na, dtype=np.int64)
+            ix = first
+            for i in range(na):
+                A[i] = ix
+                D[i] = P.pairs(np.stack([np.full(nx, ix), np.arange(nx)], axis=1))
+                ix = int(np.argmax(D[:1].min(axis=0))) if i == 0 else int(np.argmax(D[1:i + 1].min(axis=0)))
+            for mode in ("default", "loop", "rescue"):
+                monkeypatch.delenv("ANNCHOR_LEV_PERSIST", raising=False)
+                monkeypatch.delenv("ANNCHOR_LEV_PERSIST_TIMEOUT_US", raising=False)
+                if mode == "loop":
+                    monkeypatch.setenv("ANNCHOR_LEV_PERSIST", "0")
+                if mode == "rescue":
+                    monkeypatch.setenv("ANNCHOR_LEV_PERSIST_TIMEOUT_US", "0")
+                eng = _native.Engine(0)
+                levenshtein.bind(eng, X)
+                for _ in range(2):   # (twice: the arrival slots carry the previous launch's tags)
+                    eng.pick_anchors_maxmin(na, first)
+                    assert np.array_equal(eng.download(_native.F_A), A), (mode, na, first)
+                    assert np.array_equal(eng.download(_native.F_D).reshape(nx, na), D.T), (mode, na, first)
+                eng.close()
+    monkeypatch.delenv("ANNCHOR_LEV_PERSIST", raising=False)
+    monkeypatch.delenv("ANNCHOR_LEV_PERSIST_TIMEOUT_US", raising=False)
+    X = sets[0]
+    graphs = []
+    for mode in ("default", "loop", "rescue"):
+        if mode == "loop":
+            monkeypatch.setenv("ANNCHOR_LEV_PERSIST", "0")
+        if mode == "rescue":
+            monkeypatch.delenv("ANNCHOR_LEV_PERSIST", raising=False)
+            monkeypatch.setenv("ANNCHOR_LEV_PERSIST_TIMEOUT_US", "0")
+        ann = Annchor(X, "levenshtein", n_anchors=9, n_neighbors=5, n_samples=400, p_work=0.3, random_seed=3)
+        ann.fit()
+        graphs.append((ann.neighbor_graph[0].copy(), ann.neighbor_graph[1].copy(), np.asarray(ann.A).copy()))
+    for g in graphs[1:]:
+        assert np.array_equal(g[2], graphs[0][2])
+        assert np.array_equal(g[0], graphs[0][0]) and np.array_equal(g[1], graphs[0][1])
+
+
 def test_levenshtein_wide_alphabet(monkeypatch):
     """More than 256 distinct symbols (16-bit codes, k_lev_w: match words computed per column).  (i) The wide kernel forced
     on the ragged byte-alphabet set must equal the oracle's C restatement; (ii) strings over ~3000 distinct code points
