@@ -730,12 +730,13 @@ extern "C" int annchor_set_histograms(annchor_ctx *c, const double *hist, int64_
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     int maxs = 0;
     bool integral = true;
-    double maxsum = 0;
+    double maxsum = 0, maxval = 0;
     for (int64_t s = 0; s < nx; ++s) {
         int k = 0;
         double sum = 0;
         for (int b = 0; b < nbins; ++b) {
             const double v = hist[s * nbins + b];
+            if (v > maxval) maxval = v;
             k += v != 0;
             sum += v;
             if (v < 0 || v != (double)(int64_t)v) integral = false;
@@ -754,6 +755,7 @@ extern "C" int annchor_set_histograms(annchor_ctx *c, const double *hist, int64_
     c->nbins = nbins;
     c->max_support = maxs;
     c->hist_integral = integral && maxsum * maxsum < 2147483647.0;
+    c->hist_fits_i16 = c->hist_integral && maxval * maxsum < 32767.0;   // a flow is at most (a mass) x (the other histogram's sum)
     // Is the ground cost a metric on the bins (zero diagonal, triangle inequality)?  Then mass two histograms hold on the same
     // bin stays where it is in some optimal plan, and the solver works on the two differences only (csrc/emd.hip).  The
     // inequality is tested with a relative slack of 2^-40: Euclidean costs computed in floating point miss it by an ulp on
@@ -771,6 +773,8 @@ extern "C" int annchor_set_histograms(annchor_ctx *c, const double *hist, int64_
         }
     }
     c->cost_is_metric = metric_cost;
+    c->cost_max = 0.0;
+    for (int i = 0; i < nbins * nbins; ++i) c->cost_max = std::max(c->cost_max, fabs(cost[i]));
     reset_pipeline(c);
     return ANNCHOR_OK;
 }

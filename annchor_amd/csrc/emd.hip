@@ -27,7 +27,7 @@ struct EmdArgs {
     const double *hist;
     const double *cost;
     int nb;
-    int S;          // padded row stride of the flow slab (odd)
+    int S;          // padded row stride of the flow slab (odd); 0: per solve, (number of sinks) | 1
     int waves;      // waves per block
     int slab_bytes; // LDS bytes per wave (flow slab + support index lists)
     const int2 *ij;
@@ -37,8 +37,10 @@ struct EmdArgs {
     double *out;
     double *RA;
     uint8_t *ncm;
-    int32_t *fail;  // set if the iteration guard trips
+    int32_t *fail;  // set if the iteration guard trips; fail[1]: the launch's work counter (next unclaimed solve)
     int reduce;     // metric ground cost: solve on the differences of the two (scaled) histograms
+    long long *dbg; // -DEMD_PROFILE
+    double eps;     // k_emd_ns: an arc enters the basis when its reduced cost is below -eps (2^-43 x the largest ground cost)
 };
 
 // ---- wave-level min over lanes (double), result broadcast; DPP, no LDS traffic
@@ -103,24 +105,41 @@ __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_rea
 __device__ __forceinline__ double tmin(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ int tmin(int a, int b) { return a < b ? a : b; }
 
-template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
+// -DEMD_PROFILE: per-solve cycle counts by phase (small launches only), printed for the slowest solve of a launch
+#ifdef EMD_PROFILE
+#define EP_DECL long long ep_t = (long long)__builtin_readcyclecounter(), ep_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int ep_cnt[4] = {0, 0, 0, 0}
+#define EP(i) do { const long long ep_n = (long long)__builtin_readcyclecounter(); ep_acc[i] += ep_n - ep_t; ep_t = ep_n; } while (0)
+#define EP_CNT(i) (++ep_cnt[i])
+#else
+#define EP_DECL do { } while (0)
+#define EP(i) do { } while (0)
+#define EP_CNT(i) do { } while (0)
+#endif
+
+// T: masses and flows in registers; FT: the flow slab's storage type (int16 when every flow fits: half the LDS per wave again)
+template <typename T, typename FT> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
 {
     constexpr bool INTEGRAL = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int nb = a.nb, S = a.S;
+    const int nb = a.nb;
     double *costL = reinterpret_cast<double *>(smem);                       // [nb][nb]
     unsigned char *slab = reinterpret_cast<unsigned char *>(costL + nb * nb) + (size_t)wave * a.slab_bytes;
-    T *F = reinterpret_cast<T *>(slab);                                     // [<=64][S] flow slab
+    FT *F = reinterpret_cast<FT *>(slab);                                   // [<=64][S] flow slab
     int *rowsL = reinterpret_cast<int *>(slab + a.slab_bytes - 2 * EMD_MAXB * sizeof(int));  // [64] support of x
     int *colsL = rowsL + EMD_MAXB;                                          // [64] support of y
     for (int t = threadIdx.x; t < nb * nb; t += blockDim.x) costL[t] = a.cost[t];
     __syncthreads();
 
+    // Solves are claimed one at a time from a counter: their durations differ by an order of magnitude (near pairs need a few
+    // searches, far pairs scan the whole graph every time), and a fixed share per wave left most of the chip waiting for the
+    // unluckiest wave of a launch.
     const int64_t wave_global = (int64_t)blockIdx.x * a.waves + wave;
-    const int64_t wave_stride = (int64_t)gridDim.x * a.waves;
-    for (int64_t t = wave_global; t < a.n; t += wave_stride) {
+    const int64_t wave_total = (int64_t)gridDim.x * a.waves;
+    for (int64_t t = wave_global;;) {
+        if (t >= a.n) break;
+        EP_DECL;
         int pi, pj;
         int64_t opos = t;
         if (a.anchor) { pi = *a.anchor; pj = (int)t; }
@@ -152,6 +171,7 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
         }
         const unsigned long long mx = __ballot(xm != (T)0), my = __ballot(ym != (T)0);
         const int n = __popcll(mx), m = __popcll(my);
+        const int S = a.S ? a.S : (m | 1);
         const unsigned long long below = (1ull << lane) - 1ull;
         if (xm != (T)0) rowsL[__popcll(mx & below)] = lane;
         if (ym != (T)0) colsL[__popcll(my & below)] = lane;
@@ -178,7 +198,7 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
         }
         // zero the flow slab
         for (int i = 0; i < n; ++i)
-            if (lane < m) F[i * S + lane] = (T)0;
+            if (lane < m) F[i * S + lane] = (FT)0;
         __builtin_amdgcn_wave_barrier();
         // greedy start on the tight arcs (complementary slackness holds: flow only where the
         // reduced cost is zero).  For near-by histograms most mass sits on identical bins
@@ -187,7 +207,7 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
             const int i = __builtin_amdgcn_readlane(amin, j);
             const T f = tmin(rl(a_rem, i), rl(b_rem, j));
             if (f > (T)0) {
-                if (lane == 0) F[i * S + j] = f;
+                if (lane == 0) F[i * S + j] = (FT)f;
                 if (lane == i) a_rem -= f;
                 if (lane == j) b_rem -= f;
             }
@@ -196,6 +216,7 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
+        EP(0);
         int guard = 64 * (n + m) + 1024;
         bool failed = false, dust = false;
         for (int s = 0; s < n && !dust && !failed; ++s) {
@@ -221,10 +242,24 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
                 int prank = -1;         // order in which THIS lane's sink was reached, among the sinks with demand left
                 int nhit = 0;
                 T need = as;
+                EP(1); EP_CNT(0);
                 for (;;) {
                     const bool open = lane < m && !((sinkdone >> lane) & 1ull);
-                    const double best = wave_min_nonneg_f64(open ? dist : INFINITY);
-                    const unsigned long long hit = __ballot(open && dist == best);
+                    // nearest open sink: non-negative doubles order like their bit patterns -- minimum of the high words first;
+                    // only when several open sinks share it (equal distances: tight arcs at 0, symmetric costs) do the low words
+                    // need their own reduction
+                    const uint32_t dhi = open ? (uint32_t)__double2hiint(dist) : 0x7ff00000u, dlo = (uint32_t)__double2loint(dist);
+                    const uint32_t mh = wave_min_u32(dhi);
+                    unsigned long long hit = __ballot(open && dhi == mh);
+                    double best;
+                    if (hit & (hit - 1)) {
+                        const uint32_t ml = wave_min_u32(open && dhi == mh ? dlo : 0xffffffffu);
+                        hit = __ballot(open && dhi == mh && dlo == ml);
+                        best = __hiloint2double((int)mh, (int)ml);
+                    } else {
+                        best = hit ? readlane_f64(dist, __ffsll((unsigned long long)hit) - 1) : INFINITY;
+                    }
+                    EP(2); EP_CNT(1);
                     if (!hit) break;                       // every sink scanned
                     const int js = __ffsll((unsigned long long)hit) - 1;  // first index on ties
                     sinkdone |= 1ull << js;
@@ -237,9 +272,11 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
                         if (!(need > (T)0)) break;
                     }
                     // sources with flow into js that are not scanned yet
-                    const T fcol = lane < n ? F[lane * S + js] : (T)0;
+                    const T fcol = lane < n ? (T)F[lane * S + js] : (T)0;
                     unsigned long long todo = __ballot(lane < n && fcol > (T)0 && !((srcdone >> lane) & 1ull));
+                    EP(3);
                     while (todo) {
+                        EP_CNT(2);
                         const int i = __ffsll((unsigned long long)todo) - 1;
                         todo &= todo - 1;
                         srcdone |= 1ull << i;
@@ -251,11 +288,13 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
                             if (nd < dist) { dist = nd; pred = i; }
                         }
                     }
+                    EP(4);
                 }
                 if (nhit == 0) { dust = true; break; }     // only rounding dust left
                 // ---- potentials: every scanned node against the last distance popped -- the tree's arcs are tight afterwards
                 if ((srcdone >> lane) & 1ull) u += mu - srcdist;
                 if ((sinkdone >> lane) & 1ull) v -= mu - dist;
+                EP(5);
                 // ---- augment along the tree to every sink reached with demand left, nearest first; a path's bottleneck is taken
                 // from the flows as the earlier augmentations of this search left them
                 for (int k = 0; k < nhit; ++k) {
@@ -265,16 +304,16 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
                         const int i = __builtin_amdgcn_readlane(pred, j);
                         if (i == s) break;
                         const int jj = __builtin_amdgcn_readlane(srcfrom, i);
-                        delta = tmin(delta, F[i * S + jj]);   // uniform address: LDS broadcast
+                        delta = tmin(delta, (T)F[i * S + jj]);   // uniform address: LDS broadcast
                         j = jj;
                     }
                     if (!(delta > (T)0)) continue;
                     for (int j = jend;;) {
                         const int i = __builtin_amdgcn_readlane(pred, j);
-                        if (lane == 0) F[i * S + j] += delta;
+                        if (lane == 0) F[i * S + j] = (FT)((T)F[i * S + j] + delta);
                         if (i == s) break;
                         const int jj = __builtin_amdgcn_readlane(srcfrom, i);
-                        if (lane == 0) F[i * S + jj] -= delta;
+                        if (lane == 0) F[i * S + jj] = (FT)((T)F[i * S + jj] - delta);
                         j = jj;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -282,7 +321,9 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     if (lane == s) a_rem -= delta;
                     if (lane == jend) b_rem -= delta;
+                    EP_CNT(3);
                 }
+                EP(6);
             }
         }
         // ---- objective
@@ -300,6 +341,266 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd(EmdArgs a)
             if (a.RA) { a.RA[opos] = tot; a.ncm[opos] = 0; }
         }
         __builtin_amdgcn_wave_barrier();
+#ifdef EMD_PROFILE
+        EP(7);
+        if (a.dbg && t < 4096 && lane == 0) {
+            for (int q = 0; q < 8; ++q) a.dbg[t * 16 + q] = ep_acc[q];
+            for (int q = 0; q < 4; ++q) a.dbg[t * 16 + 8 + q] = ep_cnt[q];
+            a.dbg[t * 16 + 12] = n; a.dbg[t * 16 + 13] = m;
+        }
+#endif
+        {   // the next solve: the first wave_total ones were handed out by position
+            int nxt = 0;
+            if (lane == 0) nxt = atomicAdd(a.fail + 1, 1);
+            t = wave_total + (int64_t)__builtin_amdgcn_readfirstlane(nxt);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_emd_ns: the same LP by the transportation simplex on a spanning-tree basis, for metric ground costs (the common mass of
+// the two histograms cancels: sources and sinks are disjoint bins, n + m <= 64 -- ONE LANE PER NODE).
+//
+// Why: the shortest-path solver above does ~200-350 Dijkstra pops per solve on the digits (up to 1700 on far pairs: ~100
+// searches of ~17 pops), each a dependent chain of a DPP minimum, an LDS column read and LDS row reads; an anchor round lasts as
+// long as its slowest solve.  The simplex needs 20-30 pivots (at most ~75; tools/sim/emd_simplex_sim.cpp counts them on the same
+// pairs) and keeps the whole basis in registers:
+//   * lane k < n is source k, lane n + j sink j; per lane: histogram bin, parent in the basis tree, flow on the arc to the
+//     parent (always source -> sink), potential, and the SET OF NODES BELOW IT as a 64-bit mask (`sub`);
+//   * pricing (Dantzig): every sink lane scans the sources (one LDS cost read each, independent), one wave minimum;
+//   * the cycle of the entering arc (x, y) needs no tree walk: the ancestors of x are the lanes whose `sub` holds bit x (one
+//     ballot), likewise y; the cycle's arcs are the lanes in exactly one of the two sets; which of them lose flow follows from
+//     the node type and the side; theta and the leaving arc are one wave minimum, the flow update one masked add;
+//   * the part of the tree cut off by the leaving arc is `sub` of its lower node (one readlane): potentials shift by the
+//     entering arc's reduced cost there, the `sub` masks of the old / new ancestors lose / gain it, and the parent pointers
+//     along the short path from the entering arc's end to the leaving arc are reversed;
+//   * start: row-minimum rule (each step closes exactly one line: a spanning tree with n + m - 1 arcs, degenerate ones
+//     included), potentials in reverse closing order.
+// No flow slab: LDS holds the ground costs and 512 B per wave.  Degenerate pivots are rare (< 1 %); should Dantzig's rule not
+// finish within its cap the loop continues under Bland's rule (lowest index in, lowest index out), which cannot cycle.
+struct EmdNsLimits { int dantzig_cap, total_cap; };
+
+template <typename T> __device__ __forceinline__ T wave_min_nonneg(T v);
+template <> __device__ __forceinline__ int wave_min_nonneg<int>(int v) { return (int)wave_min_u32((uint32_t)v); }
+template <> __device__ __forceinline__ double wave_min_nonneg<double>(double v) { return wave_min_nonneg_f64(v); }
+__device__ __forceinline__ unsigned long long rl64(unsigned long long v, int lane)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <typename T> __global__ __launch_bounds__(1024) void k_emd_ns(EmdArgs a)
+{
+    constexpr bool INTEGRAL = sizeof(T) == 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nb = a.nb;
+    double *costL = reinterpret_cast<double *>(smem);                       // [nb][nb]
+    int *rowsL = reinterpret_cast<int *>(costL + nb * nb) + (size_t)wave * 2 * EMD_MAXB;   // [64] support of x, [64] support of y
+    int *colsL = rowsL + EMD_MAXB;
+    for (int t = threadIdx.x; t < nb * nb; t += blockDim.x) costL[t] = a.cost[t];
+    __syncthreads();
+    const double eps = a.eps;
+    const unsigned long long lanebit = 1ull << lane;
+
+    const int64_t wave_global = (int64_t)blockIdx.x * a.waves + wave;
+    const int64_t wave_total = (int64_t)gridDim.x * a.waves;
+    for (int64_t t = wave_global;;) {
+        if (t >= a.n) break;
+        EP_DECL;
+        int pi, pj;
+        int64_t opos = t;
+        if (a.anchor) { pi = *a.anchor; pj = (int)t; }
+        else {
+            int64_t q = a.idx ? a.idx[t] : t;
+            int2 p = a.ij[q];
+            pi = p.x; pj = p.y;
+            if (a.idx) opos = q;
+        }
+        pi = __builtin_amdgcn_readfirstlane(pi);
+        pj = __builtin_amdgcn_readfirstlane(pj);
+        const double *hx = a.hist + (size_t)pi * nb, *hy = a.hist + (size_t)pj * nb;
+        const double xk = lane < nb ? hx[lane] : 0.0, yk = lane < nb ? hy[lane] : 0.0;
+        double sa = 0, sb = 0;
+        for (int k = 0; k < nb; ++k) { sa += readlane_f64(xk, k); sb += readlane_f64(yk, k); }
+        T xm, ym;
+        if (INTEGRAL) { xm = (T)(xk * sb); ym = (T)(yk * sa); }
+        else { xm = (T)(xk / sa); ym = (T)(yk / sb); }
+        {   // the common mass stays where it is (metric cost): only the differences travel
+            const T d = xm - ym;
+            xm = d > (T)0 ? d : (T)0;
+            ym = d < (T)0 ? -d : (T)0;
+        }
+        const unsigned long long mx = __ballot(xm != (T)0), my = __ballot(ym != (T)0);
+        const int n = __popcll(mx), m = __popcll(my), N = n + m;
+        double tot = 0.0;
+        bool failed = false;
+        if (n > 0 && m > 0) {
+            const unsigned long long below = lanebit - 1ull;
+            if (xm != (T)0) rowsL[__popcll(mx & below)] = lane;
+            if (ym != (T)0) colsL[__popcll(my & below)] = lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // ---- nodes: lane k < n = source k, lane n + j = sink j
+            const bool is_src = lane < n, is_snk = lane >= n && lane < N;
+            const int bin = is_src ? rowsL[lane] : (is_snk ? colsL[lane - n] : 0);
+            __builtin_amdgcn_wave_barrier();
+            const T mass_x = __shfl(xm, bin), mass_y = __shfl(ym, bin);
+            T rem = is_src ? mass_x : (is_snk ? mass_y : (T)0);       // supply / demand still to place (start rule)
+            const unsigned long long allmask = N == 64 ? ~0ull : ((1ull << N) - 1ull);
+            const unsigned long long srcmask = (1ull << n) - 1ull, snkmask = allmask & ~srcmask;
+            int parent = -1;
+            T pflow = (T)0;
+            double pot = 0.0, pcost = 0.0;
+            unsigned long long sub = lane < N ? lanebit : 0ull;
+            int ord = -1;
+            // ---- start: row-minimum rule.  The first open source takes its cheapest open sink; the assignment exhausts one of
+            // the two, which closes and hangs below the other (never the last source while several sinks are open: with the totals
+            // balanced their demands are zero then, and they close one by one on degenerate arcs).
+            unsigned long long open = allmask;
+            int step = 0;
+            EP(0);
+            while (open & (open - 1)) {
+                const unsigned long long osrc = open & srcmask;
+                const int i = __ffsll(osrc) - 1;                       // (an open source always exists while two lines are open)
+                const int bi = __builtin_amdgcn_readlane(bin, i);
+                const bool cand = is_snk && ((open >> lane) & 1ull);
+                const double c = cand ? costL[bi * nb + bin] : INFINITY;
+                const double cmin = wave_min_nonneg_f64(c);
+                const int j = __ffsll((unsigned long long)__ballot(cand && c == cmin)) - 1;
+                const T ai = rl(rem, i), bj = rl(rem, j);
+                const T f = tmin(ai, bj);
+                const unsigned long long osnk = open & snkmask;
+                const bool last_src = (osrc & (osrc - 1)) == 0, last_snk = (osnk & (osnk - 1)) == 0;
+                // (the exhausted line closes; never the last line of its kind while several of the other kind are open -- with
+                // balanced totals what those still hold is zero, or rounding dust for non-integer masses)
+                const bool close_src = (ai - f > (T)0) ? (last_snk && !last_src) : !(last_src && !last_snk);
+                const int cn = close_src ? i : j, on = close_src ? j : i;
+                if (lane == i || lane == j) rem -= f;
+                const unsigned long long csub = rl64(sub, cn);
+                if (lane == cn) { parent = on; pflow = f; pcost = cmin; ord = step; }
+                if (lane == on) sub |= csub;
+                open &= ~(1ull << cn);
+                ++step;
+            }
+            EP(1);
+            // potentials: the root (the line left open) at 0, the others in reverse closing order -- u_i + v_j = c_ij on tree arcs
+            for (int s = step - 1; s >= 0; --s) {
+                const int cn = __ffsll((unsigned long long)__ballot(ord == s)) - 1;
+                const int pn = __builtin_amdgcn_readlane(parent, cn);
+                const double pp = readlane_f64(pot, pn);
+                if (lane == cn) pot = pcost - pp;
+            }
+            EP(2);
+            // ---- pivots
+            const int dantzig_cap = 16 * N + 64, total_cap = dantzig_cap + 4096;
+            int piv = 0;
+            for (;; ++piv) {
+                if (piv >= total_cap) { failed = true; break; }
+                const bool bland = piv >= dantzig_cap;
+                // pricing: reduced costs of the arcs into this lane's sink
+                double best = 0.0;
+                int besti = -1;
+                for (int i = 0; i < n; ++i) {
+                    const int bi = __builtin_amdgcn_readlane(bin, i);
+                    const double ui = readlane_f64(pot, i);
+                    const double rc = (costL[bi * nb + bin] - ui) - pot;
+                    if (bland ? (besti < 0 && rc < -eps) : (rc < best)) { best = rc; besti = i; }
+                }
+                EP(3); EP_CNT(0);
+                int x, y;
+                double rcin;
+                if (!bland) {
+                    rcin = wave_min_f64(is_snk ? best : 0.0);
+                    if (!(rcin < -eps)) break;                         // optimal
+                    y = __ffsll((unsigned long long)__ballot(is_snk && best == rcin)) - 1;
+                } else {
+                    const unsigned long long cands = __ballot(is_snk && besti >= 0);
+                    if (!cands) break;
+                    y = __ffsll(cands) - 1;
+                    rcin = readlane_f64(best, y);
+                }
+                x = __builtin_amdgcn_readlane(besti, y);
+                // ---- the cycle: tree path x ~> y plus the entering arc.  Ancestors (incl. the node itself) by `sub`.
+                const unsigned long long AX = __ballot((sub >> x) & 1ull), AY = __ballot((sub >> y) & 1ull);
+                const unsigned long long xs = AX & ~AY, ys = AY & ~AX;
+                // theta enters on x -> y and travels y ~> top ~> x: upwards on y's side (a sink below a source loses), downwards on
+                // x's side (a source below a sink loses)
+                const unsigned long long dec = (xs & srcmask) | (ys & snkmask);
+                const bool in_dec = (dec >> lane) & 1ull;
+                T theta;
+                int leave;
+                if (INTEGRAL) {
+                    theta = wave_min_nonneg<T>(in_dec ? pflow : (T)0x7fffffff);
+                } else {
+                    theta = wave_min_nonneg<T>(in_dec ? pflow : (T)INFINITY);
+                }
+                {
+                    const unsigned long long ties = __ballot(in_dec && pflow == theta);
+                    leave = __ffsll(ties) - 1;
+                    if (bland && (ties & (ties - 1))) {
+                        // lowest arc index (sink-major) among the ties
+                        const int asrc = is_src ? lane : parent, asnk = is_src ? parent : lane;
+                        const uint32_t aidx = ((ties >> lane) & 1ull) ? (uint32_t)(asnk * 64 + asrc) : 0xffffffffu;
+                        const uint32_t amin = wave_min_u32(aidx);
+                        leave = __ffsll((unsigned long long)__ballot(aidx == amin)) - 1;
+                    }
+                }
+                if (((xs | ys) >> lane) & 1ull) pflow += in_dec ? -theta : theta;
+                EP(4);
+                // ---- the tree: T2 = what hangs below the leaving arc; it re-attaches through the entering arc
+                const unsigned long long T2 = rl64(sub, leave);
+                const bool on_x = (xs >> leave) & 1ull;
+                const int q = on_x ? x : y, p = on_x ? y : x;
+                if ((T2 >> lane) & 1ull) pot += (is_src == (q < n)) ? rcin : -rcin;
+                else if ((sub >> leave) & 1ull) sub &= ~T2;              // old ancestors of the cut part
+                if (!((T2 >> lane) & 1ull) && ((sub >> p) & 1ull)) sub |= T2;   // its new ancestors: p and everything above p
+                int w = q, cpar = p;
+                T cflow = theta;
+                unsigned long long prevsub = 0ull;
+                for (;;) {
+                    const int opar = __builtin_amdgcn_readlane(parent, w);
+                    const T oflow = rl(pflow, w);
+                    const unsigned long long osub = rl64(sub, w);
+                    if (lane == w) { parent = cpar; pflow = cflow; sub = T2 & ~prevsub; }
+                    if (w == leave) break;
+                    cpar = w; cflow = oflow; prevsub = osub; w = opar;
+                    EP_CNT(1);
+                }
+                EP(5);
+            }
+            // ---- objective: flow x cost over the tree arcs
+            {
+                const int pb = __shfl(bin, parent < 0 ? lane : parent);
+                const double cst = (lane < N && parent >= 0) ? costL[(is_src ? bin : pb) * nb + (is_src ? pb : bin)] : 0.0;
+                tot = (lane < N && parent >= 0) ? (double)pflow * cst : 0.0;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+            if (INTEGRAL) tot /= sa * sb;
+        }
+        if (failed) { tot = NAN; if (lane == 0) *a.fail = 1; }
+        if (lane == 0) {
+            if (a.out) a.out[t] = tot;
+            if (a.RA) { a.RA[opos] = tot; a.ncm[opos] = 0; }
+        }
+        __builtin_amdgcn_wave_barrier();
+#ifdef EMD_PROFILE
+        EP(6);
+        if (a.dbg && t < 4096 && lane == 0) {
+            for (int q = 0; q < 8; ++q) a.dbg[t * 16 + q] = ep_acc[q];
+            for (int q = 0; q < 4; ++q) a.dbg[t * 16 + 8 + q] = ep_cnt[q];
+            a.dbg[t * 16 + 12] = n; a.dbg[t * 16 + 13] = m;
+        }
+#endif
+        {
+            int nxt = 0;
+            if (lane == 0) nxt = atomicAdd(a.fail + 1, 1);
+            t = wave_total + (int64_t)__builtin_amdgcn_readfirstlane(nxt);
+        }
     }
 }
 
@@ -310,31 +611,124 @@ int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
     a.hist = c->hist.as<double>();
     a.cost = c->cost.as<double>();
     a.nb = c->nbins;
-    int S = c->max_support | 1;  // odd stride: conflict-free column reads
-    a.S = S;
     a.ij = src.ij; a.idx = src.idx; a.anchor = src.anchor; a.n = src.n;
     a.out = d_out; a.RA = d_RA; a.ncm = d_ncm;
     ANN_TRY(ann_reserve(c, c->supp, 64));
     a.fail = c->supp.as<int32_t>();
     a.reduce = c->cost_is_metric && !getenv("ANNCHOR_EMD_NO_REDUCE");
-    ANN_CHECK_HIP(c, hipMemsetAsync(a.fail, 0, 4, c->stream));
+    ANN_CHECK_HIP(c, hipMemsetAsync(a.fail, 0, 8, c->stream));
     const size_t cost_bytes = sizeof(double) * (size_t)a.nb * a.nb;
     const bool integral = c->hist_integral;
-    const size_t slab = (((integral ? 4 : 8) * (size_t)c->max_support * S + 2 * EMD_MAXB * sizeof(int)) + 15) & ~(size_t)15;
+    {
+        // metric ground cost: the transportation simplex with one lane per node (ANNCHOR_EMD_SOLVER=ssp keeps the shortest-path solver)
+        const char *e = getenv("ANNCHOR_EMD_SOLVER");
+        if (a.reduce && !(e && !strcmp(e, "ssp"))) {
+            a.eps = c->cost_max * 1.1368683772161603e-13;   // 2^-43
+            a.S = 0; a.slab_bytes = 0; a.dbg = nullptr;
+            int waves = 16;
+            const int64_t spread = (src.n + 2 * (int64_t)c->prop.multiProcessorCount - 1) / (2 * (int64_t)c->prop.multiProcessorCount);
+            if (spread < waves) waves = (int)std::max<int64_t>(spread, 1);
+            if (const char *w = getenv("ANNCHOR_EMD_WAVES")) { const int ww = atoi(w); if (ww >= 1 && ww < waves) waves = ww; }
+            a.waves = waves;
+            const size_t lds = cost_bytes + (size_t)waves * 2 * EMD_MAXB * sizeof(int);
+            const void *fn = integral ? (const void *)k_emd_ns<int> : (const void *)k_emd_ns<double>;
+            ANN_CHECK_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            int64_t blocks = (src.n + waves - 1) / waves;
+            const int64_t resident = (int64_t)c->prop.multiProcessorCount * std::max<int64_t>(1, std::min<int64_t>(32 / waves, (int64_t)(160 * 1024 / lds)));
+            if (blocks > resident) blocks = resident;
+#ifdef EMD_PROFILE
+            static long long *dbg = nullptr;
+            if (!dbg) (void)hipMalloc(&dbg, sizeof(long long) * 4096 * 16);
+            if (src.n <= 4096) { a.dbg = dbg; (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 4096 * 16, c->stream); }
+#endif
+            ProfScope ps(c, "wasserstein_pairs", (double)src.n * (2.0 * a.nb * 8 + 8));
+            if (integral) k_emd_ns<int><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
+            else k_emd_ns<double><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
+            ANN_CHECK_HIP(c, hipGetLastError());
+#ifdef EMD_PROFILE
+            if (a.dbg) {
+                static int calls = 0;
+                if (++calls % 20 == 7) {
+                    std::vector<long long> h((size_t)4096 * 16);
+                    (void)hipStreamSynchronize(c->stream);
+                    (void)hipMemcpy(h.data(), dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+                    int64_t worst = 0; long long wt = 0; double tot[8] = {0};
+                    for (int64_t t = 0; t < src.n; ++t) { long long sum = 0; for (int q = 0; q < 8; ++q) { sum += h[t * 16 + q]; tot[q] += h[t * 16 + q]; } if (sum > wt) { wt = sum; worst = t; } }
+                    const char *nm[7] = {"setup", "start basis", "potentials", "pricing", "cycle+theta", "tree update", "objective"};
+                    fprintf(stderr, "k_emd_ns launch of %lld solves, %d waves per block: slowest solve %lld: %lld cycles, n %lld m %lld, pivots %lld path steps %lld\n",
+                            (long long)src.n, waves, (long long)worst, wt, h[worst * 16 + 12], h[worst * 16 + 13], h[worst * 16 + 8], h[worst * 16 + 9]);
+                    for (int q = 0; q < 7; ++q) fprintf(stderr, "   %-14s slowest %8lld   mean %8.0f\n", nm[q], h[worst * 16 + q], tot[q] / (double)src.n);
+                }
+            }
+#endif
+            return ANNCHOR_OK;
+        }
+    }
+    a.eps = 0.0;
+    const bool narrow = integral && c->hist_fits_i16 && !getenv("ANNCHOR_EMD_WIDE_FLOWS");
+    // Flow slab: n sources x (m | 1) sinks.  The supports of the raw histograms bound n and m by max_support; with the common
+    // mass cancelled the two supports are disjoint (n + m <= bins), which halves the worst case again.
+    size_t entries = 0;
+    if (a.reduce) {
+        a.S = 0;   // stride per solve
+        for (int n = 1; n <= c->max_support; ++n) {
+            const int m = std::min(c->max_support, a.nb - n);
+            if (m >= 1) entries = std::max(entries, (size_t)n * (size_t)(m | 1));
+        }
+        if (!entries) entries = 1;
+    } else {
+        a.S = c->max_support | 1;  // odd stride: conflict-free column reads
+        entries = (size_t)c->max_support * a.S;
+    }
+    const size_t esz = narrow ? 2 : integral ? 4 : 8;
+    const size_t slab = ((esz * entries + 2 * EMD_MAXB * sizeof(int)) + 15) & ~(size_t)15;
     a.slab_bytes = (int)slab;
-    int waves = (int)((160 * 1024 - cost_bytes) / slab);
+    // The solver is latency bound (one DPP minimum per Dijkstra pop on the critical path): as many waves per SIMD as the LDS
+    // takes.  A workgroup holds at most 16 waves, so two workgroups per CU, each with its own copy of the ground costs.
+    int per_cu = 2;
+    int waves = (int)(((160 * 1024) / per_cu - cost_bytes) / slab);
+    if (waves < 8) { per_cu = 1; waves = (int)((160 * 1024 - cost_bytes) / slab); }
     if (waves > 16) waves = 16;
+    // a small launch (an anchor round: one solve per point) is as slow as its slowest solve: spread it over every SIMD of the
+    // chip instead of filling a few CUs
+    {
+        const int64_t spread = (src.n + 2 * (int64_t)c->prop.multiProcessorCount - 1) / (2 * (int64_t)c->prop.multiProcessorCount);
+        if (spread < waves) waves = (int)std::max<int64_t>(spread, 1);
+    }
     if (const char *w = getenv("ANNCHOR_EMD_WAVES")) { const int ww = atoi(w); if (ww >= 1 && ww < waves) waves = ww; }   // tuning / occupancy experiments
     ANN_REQUIRE(c, waves >= 1, ANNCHOR_ELIMIT, "histogram support %d needs more LDS than a CU has", c->max_support);
     a.waves = waves;
     const size_t lds = cost_bytes + slab * waves;
-    const void *fn = integral ? (const void *)k_emd<int> : (const void *)k_emd<double>;
+    const void *fn = narrow ? (const void *)k_emd<int, int16_t> : integral ? (const void *)k_emd<int, int> : (const void *)k_emd<double, double>;
     ANN_CHECK_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t blocks = (src.n + waves - 1) / waves;
-    if (blocks > c->prop.multiProcessorCount) blocks = c->prop.multiProcessorCount;  // one resident block per CU (LDS bound)
+    if (blocks > (int64_t)per_cu * c->prop.multiProcessorCount) blocks = (int64_t)per_cu * c->prop.multiProcessorCount;  // resident blocks only (LDS bound)
+    a.dbg = nullptr;
+#ifdef EMD_PROFILE
+    static long long *dbg = nullptr;
+    if (!dbg) (void)hipMalloc(&dbg, sizeof(long long) * 4096 * 16);
+    if (src.n <= 4096) { a.dbg = dbg; (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 4096 * 16, c->stream); }
+#endif
     ProfScope ps(c, "wasserstein_pairs", (double)src.n * (2.0 * a.nb * 8 + 8));
-    if (integral) k_emd<int><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
-    else k_emd<double><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
+    if (narrow) k_emd<int, int16_t><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
+    else if (integral) k_emd<int, int><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
+    else k_emd<double, double><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
+#ifdef EMD_PROFILE
+    if (a.dbg) {
+        static int calls = 0;
+        if (++calls % 20 == 7) {
+            std::vector<long long> h((size_t)4096 * 16);
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipMemcpy(h.data(), dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            int64_t worst = 0; long long wt = 0; double tot[8] = {0};
+            for (int64_t t = 0; t < src.n; ++t) { long long sum = 0; for (int q = 0; q < 8; ++q) { sum += h[t * 16 + q]; tot[q] += h[t * 16 + q]; } if (sum > wt) { wt = sum; worst = t; } }
+            const char *nm[8] = {"setup", "search init", "pop min", "column+ballot", "relax", "potentials", "augment", "objective"};
+            fprintf(stderr, "k_emd launch of %lld solves, %d waves per block: slowest solve %lld: %lld cycles, n %lld m %lld, searches %lld pops %lld relaxed %lld augmentations %lld\n",
+                    (long long)src.n, waves, (long long)worst, wt, h[worst * 16 + 12], h[worst * 16 + 13], h[worst * 16 + 8], h[worst * 16 + 9], h[worst * 16 + 10], h[worst * 16 + 11]);
+            for (int q = 0; q < 8; ++q) fprintf(stderr, "   %-14s slowest %8lld   mean %8.0f\n", nm[q], h[worst * 16 + q], tot[q] / (double)src.n);
+        }
+    }
+#endif
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
 }
