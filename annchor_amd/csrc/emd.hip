@@ -40,6 +40,7 @@ struct EmdArgs {
     int32_t *fail;  // set if the iteration guard trips; fail[1]: the launch's work counter (next unclaimed solve)
     int reduce;     // metric ground cost: solve on the differences of the two (scaled) histograms
     long long *dbg; // -DEMD_PROFILE
+    int dantzig_cap; // k_emd_ns: pivots under Dantzig's rule before Bland's takes over (-1: 16 (n + m) + 64; tests force 0)
     double eps;     // k_emd_ns: an arc enters the basis when its reduced cost is below -eps (2^-43 x the largest ground cost)
 };
 
@@ -378,7 +379,7 @@ template <typename T, typename FT> __global__ __launch_bounds__(1024) void k_emd
 //     included), potentials in reverse closing order.
 // No flow slab: LDS holds the ground costs and 512 B per wave.  Degenerate pivots are rare (< 1 %); should Dantzig's rule not
 // finish within its cap the loop continues under Bland's rule (lowest index in, lowest index out), which cannot cycle.
-struct EmdNsLimits { int dantzig_cap, total_cap; };
+#define EMD_NS_WAVE_BYTES (2 * EMD_MAXB * (int)sizeof(int) + 64 * (int)sizeof(double))
 
 template <typename T> __device__ __forceinline__ T wave_min_nonneg(T v);
 template <> __device__ __forceinline__ int wave_min_nonneg<int>(int v) { return (int)wave_min_u32((uint32_t)v); }
@@ -398,8 +399,11 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd_ns(EmdArgs a
     const int wave = threadIdx.x >> 6;
     const int nb = a.nb;
     double *costL = reinterpret_cast<double *>(smem);                       // [nb][nb]
-    int *rowsL = reinterpret_cast<int *>(costL + nb * nb) + (size_t)wave * 2 * EMD_MAXB;   // [64] support of x, [64] support of y
+    // per wave: [64] support of x, [64] support of y (ints), [64] potentials by node (doubles)
+    unsigned char *wv = reinterpret_cast<unsigned char *>(costL + nb * nb) + (size_t)wave * EMD_NS_WAVE_BYTES;
+    int *rowsL = reinterpret_cast<int *>(wv);
     int *colsL = rowsL + EMD_MAXB;
+    double *potL = reinterpret_cast<double *>(wv + 2 * EMD_MAXB * sizeof(int));
     for (int t = threadIdx.x; t < nb * nb; t += blockDim.x) costL[t] = a.cost[t];
     __syncthreads();
     const double eps = a.eps;
@@ -447,6 +451,26 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd_ns(EmdArgs a
             // ---- nodes: lane k < n = source k, lane n + j = sink j
             const bool is_src = lane < n, is_snk = lane >= n && lane < N;
             const int bin = is_src ? rowsL[lane] : (is_snk ? colsL[lane - n] : 0);
+            // ---- the arcs, dealt over the lanes: arc a = slot * 64 + lane is (source a / m, sink a % m); its ground cost and the
+            // LDS offsets of its ends' potentials stay in registers for the whole solve (<= 16 slots: n m <= 1024)
+            const int nm = n * m;
+            double ac[16];
+            int aij[16];
+            {
+                const float inv_m = 1.0f / (float)m;
+#pragma unroll
+                for (int sl = 0; sl < 16; ++sl) {
+                    ac[sl] = 0.0; aij[sl] = -1;
+                    if (sl * 64 < nm) {
+                        const int aidx = sl * 64 + lane;
+                        const int ac_ = min(aidx, nm - 1);
+                        const int ai = (int)(((float)ac_ + 0.5f) * inv_m);
+                        const int aj = ac_ - ai * m;
+                        ac[sl] = costL[rowsL[ai] * nb + colsL[aj]];
+                        if (aidx < nm) aij[sl] = (ai << 16) | (n + aj);
+                    }
+                }
+            }
             __builtin_amdgcn_wave_barrier();
             const T mass_x = __shfl(xm, bin), mass_y = __shfl(ym, bin);
             T rem = is_src ? mass_x : (is_snk ? mass_y : (T)0);       // supply / demand still to place (start rule)
@@ -469,8 +493,16 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd_ns(EmdArgs a
                 const int bi = __builtin_amdgcn_readlane(bin, i);
                 const bool cand = is_snk && ((open >> lane) & 1ull);
                 const double c = cand ? costL[bi * nb + bin] : INFINITY;
-                const double cmin = wave_min_nonneg_f64(c);
-                const int j = __ffsll((unsigned long long)__ballot(cand && c == cmin)) - 1;
+                // (minimum of the high words first; the low words only when several candidates share it)
+                const uint32_t chi = (uint32_t)__double2hiint(c);
+                const uint32_t mh = wave_min_u32(chi);
+                unsigned long long hitc = __ballot(cand && chi == mh);
+                if (hitc & (hitc - 1)) {
+                    const uint32_t ml = wave_min_u32(cand && chi == mh ? (uint32_t)__double2loint(c) : 0xffffffffu);
+                    hitc = __ballot(cand && chi == mh && (uint32_t)__double2loint(c) == ml);
+                }
+                const int j = __ffsll(hitc) - 1;
+                const double cmin = readlane_f64(c, j);
                 const T ai = rl(rem, i), bj = rl(rem, j);
                 const T f = tmin(ai, bj);
                 const unsigned long long osnk = open & snkmask;
@@ -496,34 +528,59 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd_ns(EmdArgs a
             }
             EP(2);
             // ---- pivots
-            const int dantzig_cap = 16 * N + 64, total_cap = dantzig_cap + 4096;
+            const int dantzig_cap = a.dantzig_cap >= 0 ? a.dantzig_cap : 16 * N + 64, total_cap = dantzig_cap + 4096;
             int piv = 0;
             for (;; ++piv) {
                 if (piv >= total_cap) { failed = true; break; }
                 const bool bland = piv >= dantzig_cap;
-                // pricing: reduced costs of the arcs into this lane's sink
+                // pricing: every lane its <= 16 arcs; the ends' potentials through LDS (independent reads, one wait)
+                potL[lane] = pot;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 double best = 0.0;
-                int besti = -1;
-                for (int i = 0; i < n; ++i) {
-                    const int bi = __builtin_amdgcn_readlane(bin, i);
-                    const double ui = readlane_f64(pot, i);
-                    const double rc = (costL[bi * nb + bin] - ui) - pot;
-                    if (bland ? (besti < 0 && rc < -eps) : (rc < best)) { best = rc; besti = i; }
+                int bestij = -1;
+                // (four slots per uniform branch: their eight LDS reads are in flight together)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g * 256 < nm) {
+                        double pu[4], pv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int e = aij[4 * g + q] < 0 ? 0 : aij[4 * g + q];
+                            pu[q] = potL[e >> 16];
+                            pv[q] = potL[e & 0xffff];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const double rc = (ac[4 * g + q] - pu[q]) - pv[q];
+                            const bool take = aij[4 * g + q] >= 0 && (bland ? (bestij < 0 && rc < -eps) : (rc < best));
+                            if (take) { best = rc; bestij = aij[4 * g + q]; }
+                        }
+                    }
                 }
+                __builtin_amdgcn_wave_barrier();
                 EP(3); EP_CNT(0);
                 int x, y;
                 double rcin;
-                if (!bland) {
-                    rcin = wave_min_f64(is_snk ? best : 0.0);
-                    if (!(rcin < -eps)) break;                         // optimal
-                    y = __ffsll((unsigned long long)__ballot(is_snk && best == rcin)) - 1;
-                } else {
-                    const unsigned long long cands = __ballot(is_snk && besti >= 0);
-                    if (!cands) break;
-                    y = __ffsll(cands) - 1;
-                    rcin = readlane_f64(best, y);
+                {
+                    int from;
+                    if (!bland) {
+                        rcin = wave_min_f64(best);
+                        if (!(rcin < -eps)) break;                     // optimal
+                        from = __ffsll((unsigned long long)__ballot(bestij >= 0 && best == rcin)) - 1;
+                    } else {
+                        // lowest arc index: a lane's first hit is its lowest slot; arcs are numbered slot * 64 + lane
+                        const unsigned long long cands = __ballot(bestij >= 0);
+                        if (!cands) break;
+                        const uint32_t key = bestij >= 0 ? (uint32_t)((bestij >> 16) * 64 + (bestij & 0xffff)) : 0xffffffffu;
+                        const uint32_t kmin = wave_min_u32(key);
+                        from = __ffsll((unsigned long long)__ballot(key == kmin)) - 1;
+                        rcin = readlane_f64(best, from);
+                    }
+                    const int e = __builtin_amdgcn_readlane(bestij, from);
+                    x = e >> 16; y = e & 0xffff;
                 }
-                x = __builtin_amdgcn_readlane(besti, y);
                 // ---- the cycle: tree path x ~> y plus the entering arc.  Ancestors (incl. the node itself) by `sub`.
                 const unsigned long long AX = __ballot((sub >> x) & 1ull), AY = __ballot((sub >> y) & 1ull);
                 const unsigned long long xs = AX & ~AY, ys = AY & ~AX;
@@ -625,16 +682,20 @@ int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
         if (a.reduce && !(e && !strcmp(e, "ssp"))) {
             a.eps = c->cost_max * 1.1368683772161603e-13;   // 2^-43
             a.S = 0; a.slab_bytes = 0; a.dbg = nullptr;
+            a.dantzig_cap = -1;
+            if (const char *dc = getenv("ANNCHOR_EMD_DANTZIG_CAP")) a.dantzig_cap = atoi(dc);
             int waves = 16;
             const int64_t spread = (src.n + 2 * (int64_t)c->prop.multiProcessorCount - 1) / (2 * (int64_t)c->prop.multiProcessorCount);
             if (spread < waves) waves = (int)std::max<int64_t>(spread, 1);
             if (const char *w = getenv("ANNCHOR_EMD_WAVES")) { const int ww = atoi(w); if (ww >= 1 && ww < waves) waves = ww; }
             a.waves = waves;
-            const size_t lds = cost_bytes + (size_t)waves * 2 * EMD_MAXB * sizeof(int);
+            const size_t lds = cost_bytes + (size_t)waves * EMD_NS_WAVE_BYTES;
             const void *fn = integral ? (const void *)k_emd_ns<int> : (const void *)k_emd_ns<double>;
             ANN_CHECK_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             int64_t blocks = (src.n + waves - 1) / waves;
-            const int64_t resident = (int64_t)c->prop.multiProcessorCount * std::max<int64_t>(1, std::min<int64_t>(32 / waves, (int64_t)(160 * 1024 / lds)));
+            int per_cu = 1;   // resident workgroups only: the waves claim their solves from a counter
+            ANN_CHECK_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, waves * 64, lds));
+            const int64_t resident = (int64_t)c->prop.multiProcessorCount * std::max(per_cu, 1);
             if (blocks > resident) blocks = resident;
 #ifdef EMD_PROFILE
             static long long *dbg = nullptr;

@@ -667,6 +667,53 @@ def test_wasserstein_non_integer_histograms():
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("solver", ["simplex", "simplex_bland", "ssp", "ssp_wide_flows"])
+def test_wasserstein_solver_variants(monkeypatch, solver):
+    """Metric ground costs take the transportation simplex (k_emd_ns: one lane per node, Dantzig pricing); forced here: the same
+    kernel under Bland's rule from the first pivot (its anti-cycling fallback), and the successive-shortest-path kernel with int16 /
+    int32 flow slabs.  Each against the oracle: digits (integer masses; near, far and identical pairs, the one-to-all form of the
+    anchor rounds), float histograms on a 64-bin non-grid metric with full supports (n + m = 64 nodes), two-bin histograms."""
+    from annchor_amd import _native
+    from annchor_amd.distances import Wasserstein
+
+    if solver == "simplex_bland":
+        monkeypatch.setenv("ANNCHOR_EMD_DANTZIG_CAP", "0")
+    if solver.startswith("ssp"):
+        monkeypatch.setenv("ANNCHOR_EMD_SOLVER", "ssp")
+    if solver == "ssp_wide_flows":
+        monkeypatch.setenv("ANNCHOR_EMD_WIDE_FLOWS", "1")
+    d = om.load_digits()
+    X, M, (ngi, _) = d["X"], d["cost_matrix"], d["neighbor_graph"]
+    rng = np.random.default_rng(11)
+    eng = _native.Engine(0)
+    Wasserstein(M).bind(eng, X)
+    rows = rng.integers(0, 1797, 3000)
+    IJ = np.concatenate([np.stack([rows, ngi[rows, rng.integers(0, 100, 3000)].astype(np.int64)], axis=1), rng.integers(0, 1797, (3000, 2))])
+    IJ[:5, 1] = IJ[:5, 0]
+    H = om.Histograms(X, M)
+    np.testing.assert_allclose(eng.metric_pairs(IJ), H.pairs(IJ), rtol=0, atol=1e-12)
+    eng.pick_anchors_selected([7, 1500])
+    D = eng.download(_native.F_D).reshape(1797, 2)
+    for col, a_ in enumerate((7, 1500)):
+        np.testing.assert_allclose(D[:, col], H.pairs(np.stack([np.full(1797, a_), np.arange(1797)], axis=1)), rtol=0, atol=1e-12)
+    eng.close()
+    nb = 64
+    pts = rng.random((nb, 2))
+    M2 = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+    Y = rng.random((120, nb)) * (rng.random((120, nb)) < 0.7)
+    Y[:, 0] += 0.05
+    Y[3] = rng.random(nb) + 0.1      # full supports: after the common mass cancels every bin is a source or a sink
+    Y[4] = rng.random(nb) + 0.1
+    Y[5] = 0; Y[5, 9] = 1.0          # one bin against everything
+    Y[6] = 0; Y[6, 9] = 0.3; Y[6, 40] = 0.7
+    e2 = _native.Engine(0)
+    Wasserstein(M2).bind(e2, Y)
+    IJ2 = rng.integers(0, 120, (2500, 2))
+    IJ2[:4] = [[3, 4], [5, 6], [5, 3], [6, 6]]
+    np.testing.assert_allclose(e2.metric_pairs(IJ2), om.Histograms(Y, M2).pairs(IJ2), rtol=0, atol=1e-12)
+    e2.close()
+
+
 @pytest.mark.parametrize("kind", ["squared", "asymmetric", "metric_integer"])
 def test_wasserstein_cost_matrix_kinds(kind):
     """The solver cancels the mass two histograms share on a bin only when the ground cost is a metric (zero diagonal,

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-ANNCHOR_HIP_LIB=$PWD/tools/_variants/libemd_prof.so timeout 300 python tools/c4_time.py 2>&1 | tail -19
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "solver_variants" 2>&1 | tail -8
