@@ -66,6 +66,7 @@ struct annchor_ctx {
     DevBuf hist, cost, supp; // histograms f64 [nx, nbins], cost [nbins, nbins], support sizes int32 [nx]
     int nbins = 0, max_support = 0;
     double cost_max = 0.0;       // largest ground cost
+    int emd_epoch = 0;           // launches of the exact-OT kernels (their two work counters take turns)
     bool cost_is_metric = false; // ground cost: zero diagonal + triangle inequality (common mass of two histograms cancels)
     bool hist_integral = false;  // all masses integer valued and (row sum)^2 < 2^31: exact int32 flows
     bool hist_fits_i16 = false;  // ... and (largest mass) x (largest row sum) < 2^15: every flow fits int16

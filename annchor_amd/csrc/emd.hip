@@ -37,7 +37,9 @@ struct EmdArgs {
     double *out;
     double *RA;
     uint8_t *ncm;
-    int32_t *fail;  // set if the iteration guard trips; fail[1]: the launch's work counter (next unclaimed solve)
+    int32_t *fail;  // set if the iteration guard trips (sticky)
+    int32_t *work;  // the launch's work counter (next unclaimed solve); *work_next: the next launch's, zeroed by this one
+    int32_t *work_next;
     int reduce;     // metric ground cost: solve on the differences of the two (scaled) histograms
     long long *dbg; // -DEMD_PROFILE
     int dantzig_cap; // k_emd_ns: pivots under Dantzig's rule before Bland's takes over (-1: 16 (n + m) + 64; tests force 0)
@@ -131,6 +133,7 @@ template <typename T, typename FT> __global__ __launch_bounds__(1024) void k_emd
     int *rowsL = reinterpret_cast<int *>(slab + a.slab_bytes - 2 * EMD_MAXB * sizeof(int));  // [64] support of x
     int *colsL = rowsL + EMD_MAXB;                                          // [64] support of y
     for (int t = threadIdx.x; t < nb * nb; t += blockDim.x) costL[t] = a.cost[t];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.work_next = 0;   // (two counters used in turn: no memset between launches)
     __syncthreads();
 
     // Solves are claimed one at a time from a counter: their durations differ by an order of magnitude (near pairs need a few
@@ -352,7 +355,7 @@ template <typename T, typename FT> __global__ __launch_bounds__(1024) void k_emd
 #endif
         {   // the next solve: the first wave_total ones were handed out by position
             int nxt = 0;
-            if (lane == 0) nxt = atomicAdd(a.fail + 1, 1);
+            if (lane == 0) nxt = atomicAdd(a.work, 1);
             t = wave_total + (int64_t)__builtin_amdgcn_readfirstlane(nxt);
         }
     }
@@ -405,6 +408,7 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd_ns(EmdArgs a
     int *colsL = rowsL + EMD_MAXB;
     double *potL = reinterpret_cast<double *>(wv + 2 * EMD_MAXB * sizeof(int));
     for (int t = threadIdx.x; t < nb * nb; t += blockDim.x) costL[t] = a.cost[t];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.work_next = 0;   // (two counters used in turn: no memset between launches)
     __syncthreads();
     const double eps = a.eps;
     const unsigned long long lanebit = 1ull << lane;
@@ -655,7 +659,7 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd_ns(EmdArgs a
 #endif
         {
             int nxt = 0;
-            if (lane == 0) nxt = atomicAdd(a.fail + 1, 1);
+            if (lane == 0) nxt = atomicAdd(a.work, 1);
             t = wave_total + (int64_t)__builtin_amdgcn_readfirstlane(nxt);
         }
     }
@@ -670,10 +674,16 @@ int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
     a.nb = c->nbins;
     a.ij = src.ij; a.idx = src.idx; a.anchor = src.anchor; a.n = src.n;
     a.out = d_out; a.RA = d_RA; a.ncm = d_ncm;
-    ANN_TRY(ann_reserve(c, c->supp, 64));
+    if (!c->supp.p) {
+        ANN_TRY(ann_reserve(c, c->supp, 64));
+        ANN_CHECK_HIP(c, hipMemsetAsync(c->supp.p, 0, 64, c->stream));
+        c->emd_epoch = 0;
+    }
     a.fail = c->supp.as<int32_t>();
+    a.work = a.fail + 4 + (c->emd_epoch & 1);
+    a.work_next = a.fail + 4 + ((c->emd_epoch + 1) & 1);
+    ++c->emd_epoch;
     a.reduce = c->cost_is_metric && !getenv("ANNCHOR_EMD_NO_REDUCE");
-    ANN_CHECK_HIP(c, hipMemsetAsync(a.fail, 0, 8, c->stream));
     const size_t cost_bytes = sizeof(double) * (size_t)a.nb * a.nb;
     const bool integral = c->hist_integral;
     {
