@@ -325,8 +325,8 @@ class Annchor:
     @property
     def sid(self):
         def load():
-            m = self._engine.download(_native.F_SID)
-            return np.array([[a for a in range(self.n_anchors) if (int(w) >> a) & 1] for w in m])
+            m = self._engine.download(_native.F_SID).reshape(self.nx, -1)   # 1 / 2 / 4 mask words per point (<= 64 / 128 / 256 anchors)
+            return np.array([[a for a in range(self.n_anchors) if (int(w[a >> 6]) >> (a & 63)) & 1] for w in m])
         return self._view("sid", load)
 
     @property

@@ -79,7 +79,8 @@ struct annchor_ctx {
     DevBuf runmin, redval, redidx;
 
     // ---- locality
-    DevBuf sid, cA, thr;          // uint64 [nx], int32 [nx], int32 [nx]
+    DevBuf sid, cA, thr;          // uint64 [nx][sid_nw], int32 [nx], int32 [nx]
+    int sid_nw = 1;               // 64-bit words per anchor mask (ann_sid_words(na))
     DevBuf Kbits, Kpref;          // uint64 [nx][kw], uint32 [nx][kw]
     DevBuf deg, low, rowstart;    // int32 [nx], int32 [nx], int64 [nx+1]
     DevBuf Iptr, Iidx;            // int64 [nx+1], int32 [2n]
@@ -294,6 +295,35 @@ struct PairSource {
     int pick_reset = 0;
     bool *pick_fused = nullptr;
 };
+
+// sid[i]: the `locality` nearest anchors of point i as a bit mask of NW 64-bit words (NW = 1, 2 or 4: up to 256 anchors),
+// stored [nx][NW]; shared nearest anchors of two points = popcount of the AND
+#define ANN_MAX_ANCHORS 256
+template <int NW> struct Sid { uint64_t w[NW]; };
+template <int NW> __device__ __forceinline__ Sid<NW> sid_ld(const uint64_t *__restrict__ sid, int64_t i)
+{
+    Sid<NW> s;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s.w[w] = sid[i * NW + w];
+    return s;
+}
+template <int NW> __device__ __forceinline__ Sid<NW> sid_zero()
+{
+    Sid<NW> s;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s.w[w] = 0ull;
+    return s;
+}
+template <int NW> __device__ __forceinline__ int sid_common(const Sid<NW> &a, const Sid<NW> &b)
+{
+    int c = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) c += __popcll(a.w[w] & b.w[w]);
+    return c;
+}
+static inline int ann_sid_words(int na) { return na <= 64 ? 1 : na <= 128 ? 2 : 4; }
+// KERNEL_CALL(NW) for the context's mask width
+#define ANN_SID_DISPATCH(nw, CALL) do { if ((nw) == 1) { CALL(1); } else if ((nw) == 2) { CALL(2); } else { CALL(4); } } while (0)
 
 // np.argmax: first maximal index
 __device__ __forceinline__ void argmax_combine(double &v, int &i, double ov, int oi)

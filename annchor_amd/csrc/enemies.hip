@@ -87,24 +87,25 @@ static int en_reserve(annchor_ctx *c, DevBuf &b, size_t bytes)
 
 // ------------------------------------------------------------------ candidates
 // one block per row: histogram of c_ij over the ENEMIES j, then the (loc_min + 1)-th largest (utils.py:472-480 with f)
+template <int NW>
 __global__ __launch_bounds__(LOC_THREADS) void k_en_thresh(const uint64_t *__restrict__ sid, const int32_t *__restrict__ y, int64_t nx,
                                                           int loc_thresh, int loc_min, int32_t *__restrict__ thr, int32_t *__restrict__ flags)
 {
-    __shared__ uint32_t hist[65];
-    for (int t = threadIdx.x; t < 65; t += blockDim.x) hist[t] = 0;
+    __shared__ uint32_t hist[ANN_MAX_ANCHORS + 1];
+    for (int t = threadIdx.x; t < ANN_MAX_ANCHORS + 1; t += blockDim.x) hist[t] = 0;
     __syncthreads();
     const int64_t i = blockIdx.x;
-    const uint64_t mi = sid[i];
+    const Sid<NW> mi = sid_ld<NW>(sid, i);
     const int32_t yi = y[i];
     for (int64_t j = threadIdx.x; j < nx; j += blockDim.x)
-        if (y[j] != yi) atomicAdd(&hist[__popcll(mi & sid[j])], 1u);
+        if (y[j] != yi) atomicAdd(&hist[sid_common<NW>(mi, sid_ld<NW>(sid, j))], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
         int64_t ne = 0;
-        for (int v = 0; v <= 64; ++v) ne += hist[v];
+        for (int v = 0; v <= ANN_MAX_ANCHORS; ++v) ne += hist[v];
         const int64_t lm = loc_min < ne - 1 ? loc_min : ne - 1;
         int64_t cum = 0;
-        int v = 64;
+        int v = ANN_MAX_ANCHORS;
         for (; v >= 0; --v) {
             cum += hist[v];
             if (cum >= lm + 1) break;
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(LOC_THREADS) void k_en_thresh(const uint64_t *__res
 }
 
 // new-pair bits: wave per (row, 64-column word), lane = column
+template <int NW>
 __global__ __launch_bounds__(256) void k_en_keep_bits(const uint64_t *__restrict__ sid, const int32_t *__restrict__ y,
                                                      const int32_t *__restrict__ thr, const int32_t *__restrict__ flags,
                                                      const uint64_t *__restrict__ Kfit, int64_t nx, int kw, uint64_t *__restrict__ N)
@@ -130,14 +132,14 @@ __global__ __launch_bounds__(256) void k_en_keep_bits(const uint64_t *__restrict
     for (int64_t t = t0; t < t1; ++t) {
         const int64_t i = t / kw;
         const int w = (int)(t - i * kw);
-        const uint64_t mi = sid[i];
+        const Sid<NW> mi = sid_ld<NW>(sid, i);
         const int ti = thr[i];
         const int32_t yi = y[i];
         const uint64_t fit = Kfit[t];
         const int64_t j = (int64_t)w * 64 + lane;
         bool keep = false;
         if (j < nx && j != i && y[j] != yi && !((fit >> lane) & 1ull)) {
-            const int cc = __popcll(mi & sid[j]);
+            const int cc = sid_common<NW>(mi, sid_ld<NW>(sid, j));
             const int tj = thr[j];
             // row of the smaller index decides; when a threshold was lowered the larger index's row counts too
             const int t_small = i < j ? ti : tj, t_large = i < j ? tj : ti;
@@ -170,11 +172,13 @@ extern "C" int annchor_enemies_candidates(annchor_ctx *c, const int32_t *y, int3
     ANN_CHECK_HIP(c, hipMemsetAsync(s->flags.p, 0, sizeof(int32_t) * 4, c->stream));
     {
         ProfScope ps(c, "enemy_keep_bitmap", (double)nx * kw * 20.0);
-        k_en_thresh<<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), s->y.as<int32_t>(), nx, loc_thresh, loc_min,
-                                                           s->thr.as<int32_t>(), s->flags.as<int32_t>());
-        k_en_keep_bits<<<(int)std::min<int64_t>(ann_blocks(nx * kw * 64, 256), (int64_t)c->prop.multiProcessorCount * 32), 256, 0, c->stream>>>(
-            c->sid.as<uint64_t>(), s->y.as<int32_t>(), s->thr.as<int32_t>(), s->flags.as<int32_t>(), c->Kbits.as<uint64_t>(), nx, kw,
-            s->N.as<uint64_t>());
+#define ENT_CALL(NW) k_en_thresh<NW><<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), s->y.as<int32_t>(), nx, loc_thresh, loc_min, s->thr.as<int32_t>(), s->flags.as<int32_t>())
+        ANN_SID_DISPATCH(c->sid_nw, ENT_CALL);
+#undef ENT_CALL
+#define ENK_CALL(NW) k_en_keep_bits<NW><<<(int)std::min<int64_t>(ann_blocks(nx * kw * 64, 256), (int64_t)c->prop.multiProcessorCount * 32), 256, 0, c->stream>>>( \
+            c->sid.as<uint64_t>(), s->y.as<int32_t>(), s->thr.as<int32_t>(), s->flags.as<int32_t>(), c->Kbits.as<uint64_t>(), nx, kw, s->N.as<uint64_t>())
+        ANN_SID_DISPATCH(c->sid_nw, ENK_CALL);
+#undef ENK_CALL
         k_row_prefix<<<(int)nx, LOC_THREADS, 0, c->stream>>>(s->N.as<uint64_t>(), nx, kw, s->Npref.as<uint32_t>(), s->deg.as<int32_t>(),
                                                             s->low.as<int32_t>(), s->up.as<int32_t>());
     }

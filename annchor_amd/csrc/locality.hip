@@ -5,7 +5,7 @@
 // (annchor/utils.py:437-540) and check_locality_size (utils.py:592-597).
 //
 // The reference materialises a dense one-hot matrix and Python dicts; here
-//   * sid[i]   = the `locality` nearest anchors of point i as a 64-bit mask
+//   * sid[i]   = the `locality` nearest anchors of point i as a bit mask (1, 2 or 4 64-bit words: up to 256 anchors)
 //                (ties resolve to the smaller anchor index),
 //   * c_ij     = popcount(sid[i] & sid[j])            (= sum(A[sid[i], :])[j]),
 //   * thr_i    = min(loc_thresh, (loc_min+1)-th largest c_i.)   (utils.py:472-480),
@@ -16,45 +16,49 @@
 // endpoint (the reference's order inside a group is arbitrary -- unstable argsort).
 #include "common.h"
 
-__global__ void k_sid(const double *__restrict__ Dt, int64_t nx, int na, int locality, uint64_t *__restrict__ sid,
-                      int32_t *__restrict__ cA)
+template <int NW> __global__ void k_sid(const double *__restrict__ Dt, int64_t nx, int na, int locality, uint64_t *__restrict__ sid,
+                                        int32_t *__restrict__ cA)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nx) return;
-    uint64_t mask = 0;
+    Sid<NW> mask = sid_zero<NW>();
     int first = 0;
     for (int r = 0; r < locality; ++r) {
         double best = INFINITY;
         int ba = -1;
         for (int a = 0; a < na; ++a) {
-            if ((mask >> a) & 1ull) continue;
+            if ((mask.w[NW == 1 ? 0 : a >> 6] >> (a & 63)) & 1ull) continue;
             double v = Dt[(size_t)a * nx + i];
             if (ba < 0 || v < best) { best = v; ba = a; }  // strict <: smaller index wins ties
         }
         if (ba < 0) break;
         if (r == 0) first = ba;
-        mask |= 1ull << ba;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            if (w == (ba >> 6)) mask.w[w] |= 1ull << (ba & 63);
     }
-    sid[i] = mask;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sid[i * NW + w] = mask.w[w];
     cA[i] = first;  // np.argmin(D[i]) -- first minimal index (utils.py:375)
 }
 
 #define LOC_THREADS 256
 // one block per row: histogram of c_ij over all j, then the (loc_min+1)-th largest
+template <int NW>
 __global__ __launch_bounds__(LOC_THREADS) void k_loc_thresh(const uint64_t *__restrict__ sid, int64_t nx, int loc_thresh,
                                                            int loc_min, int32_t *__restrict__ thr)
 {
-    __shared__ uint32_t hist[65];
-    for (int t = threadIdx.x; t < 65; t += blockDim.x) hist[t] = 0;
+    __shared__ uint32_t hist[ANN_MAX_ANCHORS + 1];
+    for (int t = threadIdx.x; t < ANN_MAX_ANCHORS + 1; t += blockDim.x) hist[t] = 0;
     __syncthreads();
     const int64_t i = blockIdx.x;
-    const uint64_t mi = sid[i];
-    for (int64_t j = threadIdx.x; j < nx; j += blockDim.x) atomicAdd(&hist[__popcll(mi & sid[j])], 1u);
+    const Sid<NW> mi = sid_ld<NW>(sid, i);
+    for (int64_t j = threadIdx.x; j < nx; j += blockDim.x) atomicAdd(&hist[sid_common<NW>(mi, sid_ld<NW>(sid, j))], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
         int64_t lm = loc_min < nx - 1 ? loc_min : nx - 1;
         int64_t cum = 0;
-        int v = 64;
+        int v = ANN_MAX_ANCHORS;
         for (; v >= 0; --v) {
             cum += hist[v];
             if (cum >= lm + 1) break;
@@ -68,23 +72,22 @@ __global__ __launch_bounds__(LOC_THREADS) void k_loc_thresh(const uint64_t *__re
 // row into the handful of bins popcounts of 5-of-60 masks can take -- 19 ms at 100 000 points.  thr = the largest t <= loc_thresh
 // with #{j : shared(i, j) >= t} >= loc_min + 1 (the same cut: the cumulative histogram from the top), so T running counts per
 // thread do, reduced once per row.
-template <int T>
+template <int T, int NW>
 __global__ __launch_bounds__(LOC_THREADS) void k_loc_thresh_small(const uint64_t *__restrict__ sid, int64_t nx, int loc_min, int32_t *__restrict__ thr)
 {
     __shared__ uint32_t part[LOC_THREADS / 64][T];
     const int64_t i = blockIdx.x;
-    const uint64_t mi = sid[i];
-    const uint32_t mi_lo = (uint32_t)mi, mi_hi = (uint32_t)(mi >> 32);
+    const Sid<NW> mi = sid_ld<NW>(sid, i);
     uint32_t c[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) c[t] = 0;
     for (int64_t j0 = threadIdx.x; j0 < nx; j0 += 4 * LOC_THREADS) {
-        uint64_t mj[4];
+        Sid<NW> mj[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) mj[e] = sid[min(j0 + e * LOC_THREADS, nx - 1)];
+        for (int e = 0; e < 4; ++e) mj[e] = sid_ld<NW>(sid, min(j0 + e * LOC_THREADS, nx - 1));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int cc = j0 + e * LOC_THREADS < nx ? __popc(mi_lo & (uint32_t)mj[e]) + __popc(mi_hi & (uint32_t)(mj[e] >> 32)) : 0;
+            const int cc = j0 + e * LOC_THREADS < nx ? sid_common<NW>(mi, mj[e]) : 0;
 #pragma unroll
             for (int t = 0; t < T; ++t) c[t] += cc > t;
         }
@@ -114,6 +117,7 @@ __global__ __launch_bounds__(LOC_THREADS) void k_loc_thresh_small(const uint64_t
 // keep bits: wave per (row, 64-column word) item, lane = column -- the 64 sid / thr reads of a word are one
 // line each and the word is the wave's ballot (a thread per word walking its 64 columns read 64 scattered
 // 8-byte pieces per load instruction)
+template <int NW>
 __global__ __launch_bounds__(256) void k_keep_bits(const uint64_t *__restrict__ sid, const int32_t *__restrict__ thr, int64_t nx, int kw,
                                                   uint64_t *__restrict__ K)
 {
@@ -127,12 +131,12 @@ __global__ __launch_bounds__(256) void k_keep_bits(const uint64_t *__restrict__ 
     for (int64_t t = t0; t < t1; ++t) {
         const int64_t i = t / kw;
         const int w = (int)(t - i * kw);
-        const uint64_t mi = sid[i];
+        const Sid<NW> mi = sid_ld<NW>(sid, i);
         const int ti = thr[i];
         const int64_t j = (int64_t)w * 64 + lane;
         bool keep = false;
         if (j < nx && j != i) {
-            const int cc = __popcll(mi & sid[j]);
+            const int cc = sid_common<NW>(mi, sid_ld<NW>(sid, j));
             const int tj = thr[j];
             keep = cc >= (ti < tj ? ti : tj);
         }
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(256) void k_keep_bits(const uint64_t *__restrict__ 
 // 64 columns (their sid / thr in registers) and walks a block of 64 rows, whose sid / thr are contiguous scalar reads; the 64
 // ballots are collected one per lane and stored together.  The four waves of a workgroup take neighbouring words of
 // the same rows, so their 8-byte stores fill the same lines.
+template <int NW>
 __global__ __launch_bounds__(256) void k_keep_bits_cols(const uint64_t *__restrict__ sid, const int32_t *__restrict__ thr, int64_t nx, int kw,
                                                        uint64_t *__restrict__ K)
 {
@@ -158,16 +163,15 @@ __global__ __launch_bounds__(256) void k_keep_bits_cols(const uint64_t *__restri
     const int64_t i0 = rb * 64, i_base = min(i0, nx - 64);   // (the last block re-walks the 64 rows that end at nx; nx >= 64 here)
     const int64_t j = (int64_t)w * 64 + lane;
     const bool jv = j < nx;
-    const uint64_t mj = jv ? sid[j] : 0ull;
+    const Sid<NW> mj = jv ? sid_ld<NW>(sid, j) : sid_zero<NW>();
     const int tj = jv ? thr[j] : 0;
-    const uint32_t mj_lo = (uint32_t)mj, mj_hi = (uint32_t)(mj >> 32);
     int r_lo = 0, r_hi = 0;
 #pragma unroll 16
     for (int r = 0; r < 64; ++r) {
         const int64_t i = i_base + r;            // uniform
-        const uint64_t mi = sid[i];
+        const Sid<NW> mi = sid_ld<NW>(sid, i);
         const int ti = thr[i];
-        const int cc = __popc((uint32_t)mi & mj_lo) + __popc((uint32_t)(mi >> 32) & mj_hi);
+        const int cc = sid_common<NW>(mi, mj);
         const bool keep = jv && j != i && cc >= (ti < tj ? ti : tj);
         const unsigned long long bits = __ballot(keep);
         r_lo = lane == r ? (int)(uint32_t)bits : r_lo;
@@ -429,7 +433,8 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
     ANN_REQUIRE(c, (double)nx * kw * 12.0 < 64e9, ANNCHOR_ELIMIT,
                 "nx=%lld is too large for the pair-list form (use the streamed form)", (long long)nx);
     if (locality > c->na) locality = c->na;
-    ANN_TRY(ann_reserve(c, c->sid, sizeof(uint64_t) * (size_t)nx));
+    const int nw = c->sid_nw = ann_sid_words(c->na);
+    ANN_TRY(ann_reserve(c, c->sid, sizeof(uint64_t) * (size_t)nx * nw));
     ANN_TRY(ann_reserve(c, c->cA, sizeof(int32_t) * (size_t)nx));
     ANN_TRY(ann_reserve(c, c->thr, sizeof(int32_t) * (size_t)nx));
     ANN_TRY(ann_reserve(c, c->Kbits, sizeof(uint64_t) * (size_t)nx * kw));
@@ -443,28 +448,36 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
     ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
     {
         ProfScope ps(c, "locality_sid", (double)nx * (c->na * 8.0 + 12));
-        k_sid<<<ann_blocks(nx, 256), 256, 0, c->stream>>>(c->Dt.as<double>(), nx, c->na, locality, c->sid.as<uint64_t>(),
-                                                         c->cA.as<int32_t>());
+#define SID_CALL(NW) k_sid<NW><<<ann_blocks(nx, 256), 256, 0, c->stream>>>(c->Dt.as<double>(), nx, c->na, locality, c->sid.as<uint64_t>(), c->cA.as<int32_t>())
+        ANN_SID_DISPATCH(nw, SID_CALL);
+#undef SID_CALL
     }
     {
         ProfScope ps(c, "locality_keep_bitmap", (double)nx * kw * 12.0);
         static const bool hist_form = getenv("ANNCHOR_LOC_THRESH_HIST") != nullptr;   // tests: the histogram form at any threshold
         if (loc_thresh >= 1 && loc_thresh <= 8 && !hist_form) {
             switch (loc_thresh) {
-#define LT_CASE(T) case T: k_loc_thresh_small<T><<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx, loc_min, c->thr.as<int32_t>()); break;
+#define LT_NW(NW) k_loc_thresh_small<LT_T, NW><<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx, loc_min, c->thr.as<int32_t>())
+#define LT_CASE(T) case T: { constexpr int LT_T = T; ANN_SID_DISPATCH(nw, LT_NW); } break;
                 LT_CASE(1) LT_CASE(2) LT_CASE(3) LT_CASE(4) LT_CASE(5) LT_CASE(6) LT_CASE(7) LT_CASE(8)
 #undef LT_CASE
+#undef LT_NW
             }
-        } else
-        k_loc_thresh<<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx, loc_thresh, loc_min,
-                                                            c->thr.as<int32_t>());
+        } else {
+#define LTH_CALL(NW) k_loc_thresh<NW><<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx, loc_thresh, loc_min, c->thr.as<int32_t>())
+            ANN_SID_DISPATCH(nw, LTH_CALL);
+#undef LTH_CALL
+        }
         static const long long cols_min = getenv("ANNCHOR_KEEP_COLS_MIN") ? atoll(getenv("ANNCHOR_KEEP_COLS_MIN")) : (1ll << 20);   // bitmap words (N = 16 000: 0.60 -> 0.27 ms)
-        if (nx >= 64 && nx * kw >= cols_min)
-            k_keep_bits_cols<<<(unsigned)((((nx + 63) / 64) * kw + 3) / 4), 256, 0, c->stream>>>(c->sid.as<uint64_t>(), c->thr.as<int32_t>(), nx, kw,
-                                                                                           c->Kbits.as<uint64_t>());
-        else
-        k_keep_bits<<<(int)std::min<int64_t>(ann_blocks(nx * kw * 64, 256), (int64_t)c->prop.multiProcessorCount * 32), 256, 0, c->stream>>>(c->sid.as<uint64_t>(), c->thr.as<int32_t>(), nx, kw,
-                                                                    c->Kbits.as<uint64_t>());
+        if (nx >= 64 && nx * kw >= cols_min) {
+#define KBC_CALL(NW) k_keep_bits_cols<NW><<<(unsigned)((((nx + 63) / 64) * kw + 3) / 4), 256, 0, c->stream>>>(c->sid.as<uint64_t>(), c->thr.as<int32_t>(), nx, kw, c->Kbits.as<uint64_t>())
+            ANN_SID_DISPATCH(nw, KBC_CALL);
+#undef KBC_CALL
+        } else {
+#define KB_CALL(NW) k_keep_bits<NW><<<(int)std::min<int64_t>(ann_blocks(nx * kw * 64, 256), (int64_t)c->prop.multiProcessorCount * 32), 256, 0, c->stream>>>(c->sid.as<uint64_t>(), c->thr.as<int32_t>(), nx, kw, c->Kbits.as<uint64_t>())
+            ANN_SID_DISPATCH(nw, KB_CALL);
+#undef KB_CALL
+        }
         k_row_prefix<<<(int)nx, LOC_THREADS, 0, c->stream>>>(c->Kbits.as<uint64_t>(), nx, kw, c->Kpref.as<uint32_t>(),
                                                             c->deg.as<int32_t>(), c->low.as<int32_t>(),
                                                             c->tmp1.as<int32_t>());
@@ -537,6 +550,7 @@ extern "C" int annchor_build_locality(annchor_ctx *c, int32_t locality, int32_t 
 // (no loc_min widening on the query side).  Pairs are (i, nx_base + j), sorted by (j, i): the
 // entries of a query row are contiguous, so I is the identity over each row's range and
 // rows of X are empty.
+template <int NW>
 __global__ __launch_bounds__(LOC_THREADS) void k_qloc_count(const uint64_t *__restrict__ sid, int64_t nxb, int loc_thresh,
                                                            int32_t *__restrict__ cnt)
 {
@@ -544,14 +558,15 @@ __global__ __launch_bounds__(LOC_THREADS) void k_qloc_count(const uint64_t *__re
     if (threadIdx.x == 0) acc = 0;
     __syncthreads();
     const int64_t q = nxb + blockIdx.x;
-    const uint64_t mq = sid[q];
+    const Sid<NW> mq = sid_ld<NW>(sid, q);
     uint32_t s = 0;
-    for (int64_t i = threadIdx.x; i < nxb; i += blockDim.x) s += (int)__popcll(mq & sid[i]) >= loc_thresh;
+    for (int64_t i = threadIdx.x; i < nxb; i += blockDim.x) s += sid_common<NW>(mq, sid_ld<NW>(sid, i)) >= loc_thresh;
     if (s) atomicAdd(&acc, s);
     __syncthreads();
     if (threadIdx.x == 0) cnt[q] = (int32_t)acc;
 }
 
+template <int NW>
 __global__ __launch_bounds__(LOC_THREADS) void k_qloc_emit(const uint64_t *__restrict__ sid, int64_t nxb, int loc_thresh,
                                                           const int64_t *__restrict__ Iptr, int2 *__restrict__ ij,
                                                           int32_t *__restrict__ Iidx)
@@ -559,14 +574,14 @@ __global__ __launch_bounds__(LOC_THREADS) void k_qloc_emit(const uint64_t *__res
     __shared__ uint32_t wsum[LOC_THREADS / 64];
     __shared__ uint32_t run_s;
     const int64_t q = nxb + blockIdx.x;
-    const uint64_t mq = sid[q];
+    const Sid<NW> mq = sid_ld<NW>(sid, q);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) run_s = 0;
     __syncthreads();
     const int64_t base = Iptr[q];
     for (int64_t b0 = 0; b0 < nxb; b0 += LOC_THREADS) {
         const int64_t i = b0 + threadIdx.x;
-        const uint32_t f = (i < nxb && (int)__popcll(mq & sid[i]) >= loc_thresh) ? 1u : 0u;
+        const uint32_t f = (i < nxb && sid_common<NW>(mq, sid_ld<NW>(sid, min(i, nxb - 1))) >= loc_thresh) ? 1u : 0u;
         const unsigned long long m = __ballot(f);
         if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
         __syncthreads();
@@ -598,17 +613,21 @@ extern "C" int annchor_build_query_locality(annchor_ctx *c, int64_t nx_base, int
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     const int64_t nx = c->nx, nq = nx - nx_base;
     if (locality > c->na) locality = c->na;
-    ANN_TRY(ann_reserve(c, c->sid, sizeof(uint64_t) * (size_t)nx));
+    const int nw = c->sid_nw = ann_sid_words(c->na);
+    ANN_TRY(ann_reserve(c, c->sid, sizeof(uint64_t) * (size_t)nx * nw));
     ANN_TRY(ann_reserve(c, c->cA, sizeof(int32_t) * (size_t)nx));
     ANN_TRY(ann_reserve(c, c->deg, sizeof(int32_t) * (size_t)nx));
     ANN_TRY(ann_reserve(c, c->Iptr, sizeof(int64_t) * (size_t)(nx + 1)));
     ANN_TRY(ann_reserve(c, c->tmp2, sizeof(int32_t) * 4));
-    k_sid<<<ann_blocks(nx, 256), 256, 0, c->stream>>>(c->Dt.as<double>(), nx, c->na, locality, c->sid.as<uint64_t>(),
-                                                     c->cA.as<int32_t>());
+#define SID_CALL(NW) k_sid<NW><<<ann_blocks(nx, 256), 256, 0, c->stream>>>(c->Dt.as<double>(), nx, c->na, locality, c->sid.as<uint64_t>(), c->cA.as<int32_t>())
+    ANN_SID_DISPATCH(nw, SID_CALL);
+#undef SID_CALL
     k_zero_i32<<<ann_blocks(nx, 256), 256, 0, c->stream>>>(c->deg.as<int32_t>(), nx);
     {
         ProfScope ps(c, "query_locality", (double)nq * nx_base * 8.0);
-        k_qloc_count<<<(int)nq, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx_base, loc_thresh, c->deg.as<int32_t>());
+#define QC_CALL(NW) k_qloc_count<NW><<<(int)nq, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx_base, loc_thresh, c->deg.as<int32_t>())
+        ANN_SID_DISPATCH(nw, QC_CALL);
+#undef QC_CALL
     }
     k_min_i32<<<1, 1024, 0, c->stream>>>(c->deg.as<int32_t>() + nx_base, nq, c->tmp2.as<int32_t>());
     ANN_TRY(ann_exclusive_scan_i32_to_i64(c, c->deg.as<int32_t>(), c->Iptr.as<int64_t>(), nx));
@@ -619,9 +638,11 @@ extern "C" int annchor_build_query_locality(annchor_ctx *c, int64_t nx_base, int
     ANN_REQUIRE(c, n < (1ll << 30), ANNCHOR_ELIMIT, "%lld query pairs exceed the pair-list limit", (long long)n);
     ANN_TRY(ann_reserve(c, c->ij, sizeof(int2) * (size_t)(n + 1)));
     ANN_TRY(ann_reserve(c, c->Iidx, sizeof(int32_t) * (size_t)(n + 1)));
-    if (n > 0)
-        k_qloc_emit<<<(int)nq, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx_base, loc_thresh, c->Iptr.as<int64_t>(),
-                                                           c->ij.as<int2>(), c->Iidx.as<int32_t>());
+    if (n > 0) {
+#define QE_CALL(NW) k_qloc_emit<NW><<<(int)nq, LOC_THREADS, 0, c->stream>>>(c->sid.as<uint64_t>(), nx_base, loc_thresh, c->Iptr.as<int64_t>(), c->ij.as<int2>(), c->Iidx.as<int32_t>())
+        ANN_SID_DISPATCH(nw, QE_CALL);
+#undef QE_CALL
+    }
     ANN_CHECK_HIP(c, hipGetLastError());
     c->n_unc_after_features = -1;
     c->n = n;

@@ -113,7 +113,7 @@ static int anchor_flags_from_device_A(annchor_ctx *c)
 static int begin_anchors(annchor_ctx *c, int32_t na)
 {
     ANN_REQUIRE(c, c->nx > 0, ANNCHOR_EINVAL, "no data set bound");
-    ANN_REQUIRE(c, na >= 1 && na <= 64, ANNCHOR_ELIMIT, "n_anchors=%d: this build supports 1..64", na);
+    ANN_REQUIRE(c, na >= 1 && na <= ANN_MAX_ANCHORS, ANNCHOR_ELIMIT, "n_anchors=%d: this build supports 1..%d", na, ANN_MAX_ANCHORS);
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     c->na = na;
     c->n = 0; c->have_bitmap = false;

@@ -39,7 +39,7 @@ static int field_elems(annchor_ctx *c, int32_t f, int64_t *n)
     switch (f) {
     case ANNCHOR_F_D: *n = c->nx * c->na; return ANNCHOR_OK;
     case ANNCHOR_F_A: *n = c->nA; return ANNCHOR_OK;
-    case ANNCHOR_F_SID: *n = c->n > 0 ? c->nx : 0; return ANNCHOR_OK;
+    case ANNCHOR_F_SID: *n = c->n > 0 ? c->nx * c->sid_nw : 0; return ANNCHOR_OK;   // (sid_nw words per point: 1 up to 64 anchors)
     case ANNCHOR_F_IJS: *n = 2 * c->n; return ANNCHOR_OK;
     case ANNCHOR_F_I_PTR: *n = c->n > 0 ? c->nx + 1 : 0; return ANNCHOR_OK;
     case ANNCHOR_F_I_IDX: *n = 2 * c->n; return ANNCHOR_OK;

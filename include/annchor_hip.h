@@ -45,7 +45,7 @@ enum { ANNCHOR_METRIC_NONE = 0, ANNCHOR_METRIC_LEVENSHTEIN = 1, ANNCHOR_METRIC_E
 enum {
     ANNCHOR_F_D = 1,        /* float64 [nx, na]  anchor distances (row-major as the reference's D) */
     ANNCHOR_F_A = 2,        /* int64   [nA]      anchor indices                                    */
-    ANNCHOR_F_SID = 3,      /* uint64  [nx]      nearest-anchor bitmask (bit a = anchor a in sid)   */
+    ANNCHOR_F_SID = 3,      /* uint64  [nx][w]   nearest-anchor bitmask (bit a = anchor a in sid); w = 1 / 2 / 4 words for <= 64 / 128 / 256 anchors */
     ANNCHOR_F_IJS = 4,      /* int64   [n, 2]    candidate pairs                                   */
     ANNCHOR_F_I_PTR = 5,    /* int64   [nx+1]    CSR offsets of I                                  */
     ANNCHOR_F_I_IDX = 6,    /* int64   [2n]      CSR pair positions of I                           */

@@ -500,6 +500,40 @@ def test_fit_euclid_small_matches_oracle_stagewise():
     np.testing.assert_allclose(ann.neighbor_graph[1], ora.neighbor_graph[1], rtol=1e-12)
 
 
+@pytest.mark.parametrize("n_anchors,locality", [(70, 9), (130, 5), (200, 40)])
+def test_fit_more_than_64_anchors_matches_oracle_stagewise(strings, n_anchors, locality):
+    """More anchors than one 64-bit mask word holds (the reference takes any n_anchors, annchor.py:117-148): the nearest-anchor
+    sets become 2- or 4-word masks (up to 256 anchors).  Every stage against the oracle, strings and float64 points; the
+    query path and the nearest-enemy candidates run on the same masks."""
+    from annchor_amd import Annchor
+
+    Xs = strings[::3]
+    cfg = dict(n_anchors=n_anchors, n_neighbors=10, n_samples=900, p_work=0.6, random_seed=7, niters=2, locality=locality,
+               loc_thresh=max(1, locality // 4))
+    ann = Annchor(np.array(Xs), "levenshtein", **cfg)
+    P = om.PackedStrings(Xs)
+    _staged_compare(ann, lambda tr: O.OracleAnnchor(len(Xs), P.pairs, trace=tr, **cfg))
+    sid = ann.sid
+    want = O.nearest_anchor_sets(ann.D, locality)
+    assert all(set(a) == set(b) for a, b in zip(sid, want))
+    rng = np.random.default_rng(n_anchors)
+    X = rng.standard_normal((700, 6))
+    cfg2 = dict(n_anchors=n_anchors, n_neighbors=8, n_samples=600, p_work=0.5, random_seed=3, niters=2, locality=locality)
+    b = Annchor(X, "euclidean", **cfg2)
+    _staged_compare(b, lambda tr: O.OracleAnnchor(len(X), lambda IJ: om.euclidean_pairs(X, IJ), trace=tr, **cfg2), float_metric=True)
+    # query: the device path equals the oracle's query on the fitted state
+    Q = rng.standard_normal((40, 6))
+    qi, qd = b.query(Q, nn=5, p_work=0.9)
+    d_all = np.sqrt(((Q[:, None, :] - X[None]) ** 2).sum(-1))
+    truth = np.sort(d_all, axis=1)[:, :5]
+    assert np.mean(np.isclose(qd, truth, rtol=1e-9)) > 0.8     # (an approximate search: few of many anchors are shared)
+    # nearest enemies run on the same masks
+    y = (X[:, 0] > 0).astype(np.int64)
+    b.get_nearest_enemies(y, nn=2)
+    ne_truth = np.array([np.sort(np.sqrt(((X[i] - X[y != y[i]]) ** 2).sum(-1)))[0] for i in range(len(X))])
+    assert np.mean(np.isclose(np.asarray(b.nearest_enemy_graph[1])[:, 0], ne_truth, rtol=1e-9)) > 0.8
+
+
 def test_fit_strings_c2_full(strings):
     """BASELINE config 2: N=1600, n_anchors=15, k=25, p_work=0.12."""
     from annchor_amd import Annchor, compare_neighbor_graphs
