@@ -116,6 +116,12 @@ _SIGNATURES = {
     "annchor_stream_lists_all": (ctypes.c_int, [_vp, _i32, _i64, ctypes.POINTER(_vp)]),
     "annchor_stream_route_begin": (ctypes.c_int, [_vp, _i32, _vp, _vp, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "annchor_stream_route_recv": (ctypes.c_int, [_vp, _i64, ctypes.POINTER(_vp)]),
+    "annchor_comm_unique_id": (ctypes.c_int, [_vp]),
+    "annchor_comm_init": (ctypes.c_int, [_vp, _vp, _i32, _i32]),
+    "annchor_comm_destroy": (ctypes.c_int, [_vp]),
+    "annchor_comm_allgather": (ctypes.c_int, [_vp, _vp, _vp, _i64]),
+    "annchor_comm_alltoall_records": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32]),
+    "annchor_stream_anchor_rounds": (ctypes.c_int, [_vp, _i32]),
     "annchor_stream_route_end": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "annchor_stream_graph_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64), ctypes.POINTER(_i32)]),
     "annchor_device_alloc": (ctypes.c_int, [_vp, _i64, ctypes.POINTER(_vp)]),
@@ -244,6 +250,16 @@ def stream_budget(n_tiles, p_work, join_passes):
 # point count (1.5 x nx (nx - 1) / 2 -- 7.5 x 10^9 words for the thinned lists of 10^5 points, most of which the draw would never
 # read); beyond it the draw itself generates what it consumes, sized from the real bin populations (annchor_legacy_choice_ranks).
 LEGACY_EAGER_MAX_DRAWS = 1 << 28
+
+
+def comm_unique_id():
+    """128 bytes from which the ranks of a job build their in-library RCCL communicator (call on ONE rank, hand the bytes
+    to the others by any means: Engine.comm_init)."""
+    buf = (ctypes.c_uint8 * 128)()
+    rc = load_library().annchor_comm_unique_id(buf)
+    if rc != 0:
+        raise NativeError("annchor_comm_unique_id failed (%d): RCCL not loadable?" % rc)
+    return bytes(buf)
 
 
 def legacy_prefetch(seed, ndraws):
@@ -781,6 +797,25 @@ class Engine:
 
     def stream_anchor_step(self, gathered, world, rnd):
         self._chk(self.lib.annchor_stream_anchor_step(self.h, gathered, int(world), int(rnd)))
+
+    def stream_anchor_rounds(self, n_anchors):
+        """All max-min rounds in one call (collectives from inside the library when the context has a communicator)."""
+        self._chk(self.lib.annchor_stream_anchor_rounds(self.h, int(n_anchors)))
+
+    # ---- in-library RCCL (csrc/comm.hip)
+    def comm_init(self, unique_id, world, rank):
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._chk(self.lib.annchor_comm_init(self.h, buf, int(world), int(rank)))
+
+    def comm_destroy(self):
+        self._chk(self.lib.annchor_comm_destroy(self.h))
+
+    def comm_allgather(self, send, recv, nbytes):
+        self._chk(self.lib.annchor_comm_allgather(self.h, send, recv, int(nbytes)))
+
+    def comm_alltoall_records(self, send, send_counts, recv, recv_counts, words):
+        sc, rc = _c(send_counts, np.int64), _c(recv_counts, np.int64)
+        self._chk(self.lib.annchor_comm_alltoall_records(self.h, send, _ptr(sc), recv, _ptr(rc), int(words)))
 
     def stream_anchor_end(self, n_anchors):
         A = np.empty(int(n_anchors), dtype=np.int64)

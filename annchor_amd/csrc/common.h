@@ -71,6 +71,10 @@ struct annchor_ctx {
     bool hist_integral = false;  // all masses integer valued and (row sum)^2 < 2^31: exact int32 flows
     bool hist_fits_i16 = false;  // ... and (largest mass) x (largest row sum) < 2^15: every flow fits int16
 
+    // ---- in-library RCCL communicator (comm.hip): ncclComm_t, set by annchor_comm_init
+    void *comm = nullptr;
+    int comm_world = 1, comm_rank = 0;
+
     // ---- anchors
     int na = 0, nA = 0;
     DevBuf Dt;          // double [na][nx]   (anchor-major: lane-coalesced over points)

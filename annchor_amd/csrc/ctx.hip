@@ -10,6 +10,7 @@
 static std::string g_create_err;
 void ann_stream_release(annchor_ctx *c);
 void ann_enemies_release(annchor_ctx *c);
+void ann_comm_release(annchor_ctx *c);
 
 const char *ann_set_err(annchor_ctx *c, const char *fmt, ...)
 {
@@ -430,6 +431,7 @@ extern "C" void annchor_destroy(annchor_ctx *c)
     (void)hipSetDevice(c->device);
     (void)ann_sync(c, __func__);
     prof_drain(c);
+    ann_comm_release(c);
     ann_stream_release(c);
     ann_enemies_release(c);
     for (DevBuf *b : c->own_allocs)

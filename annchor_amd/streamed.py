@@ -145,6 +145,59 @@ class TorchComm:
         return recv, n_recv
 
 
+class RcclComm:
+    """Collectives from INSIDE the library (csrc/comm.hip: RCCL loaded with dlopen, enqueued on the engine's stream by the same
+    C calls that enqueue the kernels): no torch on the data path, and the anchor rounds of a fit are one C call.  The
+    communicator needs a 128-byte id made on one rank (`_native.comm_unique_id()`) and handed to the others --
+    `RcclComm.from_torch(engine)` does that over an existing torch.distributed group of any backend (128 bytes, once)."""
+
+    backend = "rccl"
+
+    def __init__(self, engine, world, rank, unique_id):
+        self.engine, self.world, self.rank = engine, int(world), int(rank)
+        engine.comm_init(unique_id, world, rank)
+        self._small = engine.device_alloc(8 * 64 * (self.world + 1))
+
+    @classmethod
+    def from_torch(cls, engine, group=None):
+        import torch.distributed as dist
+        from . import _native
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [_native.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(engine, world, rank, box[0])
+
+    def close(self):
+        if self._small:
+            self.engine.device_free(self._small)
+            self._small = 0
+        self.engine.comm_destroy()
+
+    def allgather_small(self, values):
+        v = np.zeros(64, dtype=np.float64)
+        vals = np.asarray(values, dtype=np.float64).reshape(-1)
+        assert vals.size <= 64
+        v[:vals.size] = vals
+        eng = self.engine
+        eng.device_copy(self._small, v.ctypes.data, 512, "h2d")
+        eng.comm_allgather(self._small, self._small + 512, 512)
+        out = np.empty((self.world, 64), dtype=np.float64)
+        eng.device_copy(out.ctypes.data, self._small + 512, out.nbytes, "d2h")
+        return out[:, :vals.size].copy()
+
+    def allgather_into(self, engine, src, dst, nbytes):
+        engine.comm_allgather(src, dst, nbytes)
+
+    def alltoall_records(self, engine, send, send_counts, words):
+        C = self.allgather_small(send_counts).astype(np.int64)       # C[src, dst]
+        recv_counts = C[:, self.rank].copy()
+        n_recv = int(recv_counts.sum())
+        recv = engine.stream_route_recv(n_recv)
+        engine.comm_alltoall_records(send, np.asarray(send_counts, dtype=np.int64), recv, recv_counts, words)
+        return recv, n_recv
+
+
 class _CAI:
     """Minimal __cuda_array_interface__ carrier for a raw device pointer."""
 
@@ -237,7 +290,12 @@ class StreamedAnnchor:
         ix = int(self._to_global(np.random.randint(self.n_total)))  # identical on every rank
         sharded = comm.world > 1 or self.force_exchange
         cand, gathered, nbytes = eng.stream_anchor_begin(na, ix, comm.world)
-        for r in range(na):
+        if getattr(comm, "backend", None) == "rccl" or (not sharded and hasattr(eng, "stream_anchor_rounds")):
+            eng.stream_anchor_rounds(na)   # every round -- collective, pick, sweep -- enqueued by one C call
+            na_done = na
+        else:
+            na_done = 0
+        for r in range(na_done, na):
             if sharded:
                 comm.allgather_into(eng, cand, gathered, nbytes)
                 eng.stream_anchor_step(gathered, comm.world, r)

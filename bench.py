@@ -234,11 +234,22 @@ def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, r
 
     X = euclid_shard(rank, n_per_rank)
     comm = TorchComm() if world > 1 else SingleComm()
+    shared_engine = None
+    if world > 1 and os.environ.get("ANNCHOR_BENCH_COMM") == "rccl" and dist_mod.get_backend() == "nccl":
+        # opt-in: the collectives from inside the library (csrc/comm.hip) on ONE engine kept for all fits; torch.distributed
+        # only hands the 128-byte communicator id around.  (Default: torch.distributed on device pointers -- neither path has
+        # run with more than one GPU yet; this one takes Python out of the 32 anchor rounds.)
+        from annchor_amd import _native
+        from annchor_amd.streamed import RcclComm
+
+        shared_engine = _native.Engine(local)
+        comm = RcclComm.from_torch(shared_engine)
     k, pw, na = 15, 0.1, 32
     times, last = [], None
     red_dev = "cuda" if (dist_mod is not None and dist_mod.get_backend() == "nccl") else "cpu"
     for it in range(warmup + steps):
-        sa = StreamedAnnchor(X, n_anchors=na, n_neighbors=k, p_work=pw, base=rank * n_per_rank, comm=comm, device=local)
+        sa = StreamedAnnchor(X, n_anchors=na, n_neighbors=k, p_work=pw, base=rank * n_per_rank, comm=comm, device=local,
+                             **({"engine": shared_engine} if shared_engine is not None else {}))
         sa._engine.prof_enable(True)
         torch.cuda.synchronize()
         if dist_mod is not None:
@@ -255,7 +266,7 @@ def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, r
             dt = float(tt.item())
         if it >= warmup:
             times.append(dt)
-        if last is not None:
+        if last is not None and shared_engine is None:
             last._engine.close()
         last = sa
     tiles_all = last.tile_evals

@@ -406,6 +406,23 @@ int annchor_stream_hip_stream(annchor_ctx *ctx, void **stream);
 int annchor_stream_anchor_begin(annchor_ctx *ctx, int32_t n_anchors, int64_t first_global, int32_t world, void **cand, void **gathered,
                                 int64_t *cand_bytes);
 int annchor_stream_anchor_step(annchor_ctx *ctx, const void *gathered, int32_t world, int32_t round);
+
+/* ------------------------------------------------------------ in-library collectives (csrc/comm.hip)
+ * RCCL called from inside the library, on the context's stream, so that the row-sharded build's rounds never return to
+ * the host language: rank 0 makes a 128-byte id (annchor_comm_unique_id), the host hands it to every rank by whatever it
+ * has (torch.distributed / MPI broadcast, a file), every rank calls annchor_comm_init on its context.  RCCL is loaded
+ * with dlopen at first use (ANNCHOR_RCCL_LIB overrides the name); nothing here is touched by single-GPU use.
+ *   annchor_comm_allgather          every rank's nbytes at send -> rank order at recv (device pointers)
+ *   annchor_comm_alltoall_records   records of `words` 8-byte words grouped by destination -> source-rank order
+ *   annchor_stream_anchor_rounds    ALL max-min rounds after annchor_stream_anchor_begin: per round the all-gather of the
+ *                                   candidates, the winner's pick, the sweep (no communicator: one rank, no collective) */
+int annchor_comm_unique_id(uint8_t *id128);
+int annchor_comm_init(annchor_ctx *ctx, const uint8_t *id128, int32_t world, int32_t rank);
+int annchor_comm_destroy(annchor_ctx *ctx);
+int annchor_comm_allgather(annchor_ctx *ctx, const void *send, void *recv, int64_t nbytes);
+int annchor_comm_alltoall_records(annchor_ctx *ctx, const void *send, const int64_t *send_counts, void *recv,
+                                  const int64_t *recv_counts, int32_t words);
+int annchor_stream_anchor_rounds(annchor_ctx *ctx, int32_t n_anchors);
 int annchor_stream_anchor_end(annchor_ctx *ctx, int64_t *A, float *anchor_vectors);
 int annchor_stream_rows_begin(annchor_ctx *ctx, int32_t world, const int64_t *counts, void **send, void **recv, int64_t *bytes_per_rank);
 int annchor_stream_rows_end(annchor_ctx *ctx, int32_t world, const int64_t *counts);

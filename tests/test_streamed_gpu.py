@@ -420,6 +420,31 @@ def test_nccl_collective_path_single_rank():
         dist.destroy_process_group()
 
 
+def test_in_library_rccl_single_rank():
+    """The collectives from inside the library (csrc/comm.hip: RCCL by dlopen, enqueued on the engine's stream; the anchor
+    rounds as ONE C call) with a one-rank communicator made from a unique id -- no torch anywhere: every branch of the sharded
+    path (candidate all-gathers inside annchor_stream_anchor_rounds, rows, neighbour lists, the all-to-all of the finished
+    rows as grouped send / recv, gather_graph) gives the graph of the collective-free build."""
+    from annchor_amd import _native
+    from annchor_amd.streamed import RcclComm, StreamedAnnchor
+
+    X = latent(5000, 48)
+    eng = _native.Engine(0)
+    comm = RcclComm(eng, 1, 0, _native.comm_unique_id())
+    try:
+        a = StreamedAnnchor(X, n_anchors=8, n_neighbors=10, p_work=0.5, comm=comm, engine=eng, force_exchange=True).fit()
+        b = StreamedAnnchor(X, n_anchors=8, n_neighbors=10, p_work=0.5).fit()
+        assert np.array_equal(a.A, b.A)
+        assert np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0])
+        assert np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1])
+        gi, gd = a.gather_graph()
+        assert np.array_equal(gi, a.neighbor_graph[0]) and np.array_equal(gd, a.neighbor_graph[1])
+        assert np.array_equal(comm.allgather_small((3.0, 4.5)), [[3.0, 4.5]])
+    finally:
+        comm.close()
+        eng.close()
+
+
 def test_streamed_query_matches_brute_force():
     """Annchor.query for the streamed form: exact with the full budget; with a partial budget the
     recall depends on how dense the query batch is (the budget is spent per 128-query tile)."""

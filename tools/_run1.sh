@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "more_than_64" 2>&1 | tail -25
+timeout 900 python -m pytest tests/test_streamed_gpu.py -x -q -m gpu -k "rccl or nccl" 2>&1 | tail -25
