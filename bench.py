@@ -676,16 +676,17 @@ def c4_block(local):
         kernel_s = (emd["ms"] if emd else 0.0) * 1e-3
         peak_wave_instr = 256 * 4 * 2.4e9 / 2.0             # nominal: one wave64 VALU instruction per SIMD per 2 cycles
         res["roofline_issue"] = {
-            "kernel": "wasserstein_pairs (k_emd: successive shortest paths, one wave per solve)", "bound": "valu_issue",
+            "kernel": "wasserstein_pairs (k_emd_ns: transportation simplex on a spanning-tree basis, one lane per node, one wave per solve)",
+            "bound": "valu_issue",
             "valu_instr_per_solve": round(valu), "salu_instr_per_solve": round(salu), "lds_instr_per_solve": round(lds),
             "valu_busy_pmc": round(P["SQ_ACTIVE_INST_VALU"] * 4 / (cyc * 1024), 3),
             "any_inst_busy_pmc": round(P["SQ_ACTIVE_INST_ANY"] * 4 / (cyc * 1024), 3),
             "achieved": solves / kernel_s / 1e6 if kernel_s > 0 else None, "unit": "M solves/s",
             "peak": peak_wave_instr / valu / 1e6, "frac": (solves / kernel_s) / (peak_wave_instr / valu) if kernel_s > 0 else None,
             "source": os.path.basename(f),
-            "note": "peak = nominal VALU issue rate (1024 SIMDs x 2.4 GHz / 2 cycles) / VALU instructions per solve; the integer / "
-                    "DPP mix of this kernel issues at 2.4-4.3 cycles per instruction (tools/microbench/valu_peak.hip), and a wave's "
-                    "dependent chain (64-lane DPP minima) leaves the VALU ~40 % busy at 16 waves per CU"}
+            "note": "peak = nominal VALU issue rate (1024 SIMDs x 2.4 GHz / 2 cycles) / VALU instructions per solve (PMC pass of this "
+                    "workload); the 20 anchor rounds are launches of 1797 solves that last as long as their slowest solve (latency, "
+                    "not issue), the two refinement launches (~110 000 solves each) are the issue-bound part"}
     except Exception as e:   # no PMC file committed yet
         res["roofline_issue"] = {"error": "%s: %s" % (type(e).__name__, e)}
     ann._engine.close()
