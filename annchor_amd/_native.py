@@ -72,6 +72,7 @@ _SIGNATURES = {
     "annchor_hash_sample_pairs": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, ctypes.c_uint64, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "annchor_legacy_prefetch": (ctypes.c_int, [ctypes.c_uint32, _i64]),
     "annchor_legacy_generate": (ctypes.c_int, [ctypes.c_uint32, _i64]),
+    "annchor_legacy_generate_at_next_wait": (ctypes.c_int, [_vp, ctypes.c_uint32, _i64, _i64]),
     "annchor_legacy_choice_ranks": (ctypes.c_int, [ctypes.c_uint32, _vp, _vp, _i32, _vp, _vp]),
     "annchor_legacy_choice_begin": (ctypes.c_int, [ctypes.c_uint32, _vp, _vp, _i32, ctypes.POINTER(_vp)]),
     "annchor_legacy_choice_end": (ctypes.c_int, [_vp, _vp, _vp]),
@@ -797,6 +798,11 @@ class Engine:
 
     def stream_anchor_step(self, gathered, world, rnd):
         self._chk(self.lib.annchor_stream_anchor_step(self.h, gathered, int(world), int(rnd)))
+
+    def legacy_generate_at_next_wait(self, seed, ndraws, chunk=0):
+        """The legacy MT19937 stream of `seed` on this thread at the context's next host waits, `chunk` words per wait (returns at once)."""
+        if 0 <= seed < 2 ** 32 and 0 < ndraws <= LEGACY_EAGER_MAX_DRAWS:
+            self._chk(self.lib.annchor_legacy_generate_at_next_wait(self.h, int(seed), int(ndraws), int(chunk)))
 
     def stream_anchor_rounds(self, n_anchors):
         """All max-min rounds in one call (collectives from inside the library when the context has a communicator)."""

@@ -690,7 +690,11 @@ class Annchor:
         seed0 = self.random_seed + getattr(self.sampler, "loop_num", 0)
         fused = self._models_on_device()
         if self._anchors_on_device:
-            make_stream(0)      # the anchor rounds (a chain of dependent launches) are running: nothing to wait for yet
+            # the anchor rounds are running: nothing to wait for yet.  The first draw's stream is produced at the engine's next
+            # host wait -- inside get_locality, AFTER its kernels are queued behind the rounds (producing it here left the GPU idle
+            # from the end of the rounds to the end of the generation once the rounds had become one persistent launch)
+            if legacy_rng:
+                self._engine.legacy_generate_at_next_wait(seed0, ndraws)   # (in one piece: two pieces over the next two waits measured slower)
         elif legacy_rng:
             _native.legacy_prefetch(seed0, ndraws)
         stage("get_locality", self.get_locality)

@@ -71,6 +71,10 @@ struct annchor_ctx {
     bool hist_integral = false;  // all masses integer valued and (row sum)^2 < 2^31: exact int32 flows
     bool hist_fits_i16 = false;  // ... and (largest mass) x (largest row sum) < 2^15: every flow fits int16
 
+    // ---- host work parked for this context's next host wait (annchor_legacy_generate_at_next_wait)
+    uint32_t idle_gen_seed = 0;
+    int64_t idle_gen_n = 0, idle_gen_done = 0, idle_gen_chunk = 0;
+
     // ---- in-library RCCL communicator (comm.hip): ncclComm_t, set by annchor_comm_init
     void *comm = nullptr;
     int comm_world = 1, comm_rank = 0;
@@ -338,6 +342,7 @@ int ann_metric_launch(annchor_ctx *c, const PairSource &src, double *d_out, doub
 int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
 // every round of the max-min picker in ONE launch (lev.hip, k_lev_ap); *done = false: not taken, the caller runs the rounds one by one
 int ann_lev_anchor_rounds(annchor_ctx *c, int32_t na, int32_t first, bool *done);
+int ann_legacy_generate_upto(uint32_t seed, int64_t ndraws, int64_t upto);   // hostrng.hip
 int ann_euclid_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
 int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
 

@@ -204,7 +204,26 @@ hipError_t ann_sync(annchor_ctx *c, const char *where)
 {
     static const bool trace = getenv("ANNCHOR_SYNC_TRACE") != nullptr;
     if (trace) fprintf(stderr, "sync %s\n", where);
+    if (c->idle_gen_n > c->idle_gen_done) {
+        // host work parked for exactly this moment: the stream has just been given work and the caller is about to wait for it
+        c->idle_gen_done = std::min(c->idle_gen_n, c->idle_gen_done + c->idle_gen_chunk);
+        (void)ann_legacy_generate_upto(c->idle_gen_seed, c->idle_gen_n, c->idle_gen_done);
+    }
     return hipStreamSynchronize(c->stream);
+}
+
+// The legacy sampler's MT19937 stream of `seed` (it depends on the seed only) produced on the calling thread at this context's NEXT
+// host waits, `chunk` words per wait (<= 0: all at the first), i.e. after the caller has enqueued whatever it enqueues before it
+// must wait: fit() parks the first draw's stream behind the anchor rounds -- annchor_build_locality's kernels are queued before the
+// generation starts, and the second piece runs while the GPU emits the pair list and the features.
+extern "C" int annchor_legacy_generate_at_next_wait(annchor_ctx *c, uint32_t seed, int64_t ndraws, int64_t chunk)
+{
+    if (!c || ndraws < 0) return ANNCHOR_EINVAL;
+    c->idle_gen_seed = seed;
+    c->idle_gen_n = ndraws;
+    c->idle_gen_done = 0;
+    c->idle_gen_chunk = chunk > 0 ? chunk : ndraws;
+    return ANNCHOR_OK;
 }
 
 int ann_d2h(annchor_ctx *c, void *dst, const void *src, size_t bytes)

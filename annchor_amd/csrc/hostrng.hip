@@ -638,6 +638,30 @@ extern "C" int annchor_legacy_generate(uint32_t seed, int64_t ndraws)
     return ANNCHOR_OK;
 }
 
+// ... in pieces: words [0, upto) of the stream on the calling thread (the stream is created at the first call; the draw that
+// consumes it extends it inline should a piece be missing).  ctx.hip parks these pieces at a context's host waits.
+int ann_legacy_generate_upto(uint32_t seed, int64_t ndraws, int64_t upto)
+{
+    if (ndraws <= 0 || ndraws > (1ll << 33)) return ANNCHOR_EINVAL;
+    std::shared_ptr<Stream> s;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (getenv("ANNCHOR_RNG_NO_CACHE")) g_cache.clear();
+        for (auto &e : g_cache)
+            if (e.first == seed && e.second->ready.load() >= (size_t)ndraws) return ANNCHOR_OK;   // already generated
+        auto it = g_streams.find(seed);
+        if (it != g_streams.end() && it->second->cap_blocks * 624 >= (size_t)ndraws) s = it->second;
+        else {
+            s = std::make_shared<Stream>();
+            s->start(seed, (size_t)ndraws, false);
+            g_streams[seed] = s;
+        }
+    }
+    if (s->producer.joinable()) return ANNCHOR_OK;   // a producer thread has it
+    s->need((size_t)std::min(upto, ndraws));
+    return ANNCHOR_OK;
+}
+
 extern "C" int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins,
                                            int64_t *ranks_out, int64_t *n_out)
 {

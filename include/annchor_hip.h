@@ -175,6 +175,9 @@ int annchor_legacy_prefetch(uint32_t seed, int64_t ndraws);
  * a C2 sampling step, against ~2 ms on a freshly woken producer thread); fit() calls it while the GPU runs a stage the
  * host would otherwise only wait for. */
 int annchor_legacy_generate(uint32_t seed, int64_t ndraws);
+/* ... on the calling thread at the context's NEXT host waits, `chunk` words per wait (<= 0: all at the first): after the caller's
+ * next enqueues, while the GPU works on them */
+int annchor_legacy_generate_at_next_wait(annchor_ctx *ctx, uint32_t seed, int64_t ndraws, int64_t chunk);
 int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins,
                                 int64_t *ranks_out, int64_t *n_out);
 /* The same draw on the library's persistent worker thread (warm core, warm caches), so that it
