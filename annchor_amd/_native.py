@@ -88,6 +88,7 @@ _SIGNATURES = {
     "annchor_select_prepare": (ctypes.c_int, [_vp, _i32, _i32]),
     "annchor_mark_candidates": (ctypes.c_int, [_vp]),
     "annchor_refine_candidates": (ctypes.c_int, [_vp]),
+    "annchor_park_refine": (ctypes.c_int, [_vp, _i32]),
     "annchor_set_refined": (ctypes.c_int, [_vp, _vp, _i64]),
     "annchor_update_bounds": (ctypes.c_int, [_vp]),
     "annchor_neighbor_graph": (ctypes.c_int, [_vp, _i32, _vp, _vp]),
@@ -688,6 +689,10 @@ class Engine:
 
     def refine_candidates(self):
         self._chk(self.lib.annchor_refine_candidates(self.h))
+
+    def park_refine(self, action):
+        """1: the next sampler_stats call queues the refinement launch behind its download; 2: launch it now if still parked."""
+        self._chk(self.lib.annchor_park_refine(self.h, int(action)))
 
     def set_refined(self, exact):
         exact = _c(exact, np.float64)

@@ -579,8 +579,13 @@ class Annchor:
             # inside fit(): the next sampling step's statistics depend on the mask and dad only,
             # so take them now and let the host draw overlap the refinement kernel
             self._engine.mark_candidates()
-            self._sample_ticket = self.sampler.begin_device(self._engine, self.n_samples, self.random_seed, overlap=_DRAW_OVERLAP)
-        if self._device_metric:
+            # (the refinement launch rides behind the statistics' download: the host waits for the statistics alone)
+            self._engine.park_refine(1)
+            try:
+                self._sample_ticket = self.sampler.begin_device(self._engine, self.n_samples, self.random_seed, overlap=_DRAW_OVERLAP)
+            finally:
+                self._engine.park_refine(2)
+        elif self._device_metric:
             self._engine.refine_candidates()
         elif ncand:
             mapback = self._engine.download(_native.F_CAND)

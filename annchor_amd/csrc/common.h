@@ -71,6 +71,10 @@ struct annchor_ctx {
     bool hist_integral = false;  // all masses integer valued and (row sum)^2 < 2^31: exact int32 flows
     bool hist_fits_i16 = false;  // ... and (largest mass) x (largest row sum) < 2^15: every flow fits int16
 
+    // ---- the refinement launch parked behind the next sampling step's statistics (annchor_park_refine)
+    bool park_refine = false;
+    hipEvent_t dl_ev = nullptr;   // marks the end of a download the host waits for while later work is already queued
+
     // ---- host work parked for this context's next host wait (annchor_legacy_generate_at_next_wait)
     uint32_t idle_gen_seed = 0;
     int64_t idle_gen_n = 0, idle_gen_done = 0, idle_gen_chunk = 0;
@@ -209,6 +213,7 @@ int ann_kth_async(annchor_ctx *c, const double *vals, const uint8_t *flag, int64
                   const unsigned long long **d_prefix, const int **d_unfinished);
 void ann_kth_async_done(annchor_ctx *c);
 int ann_d2h(annchor_ctx *c, void *dst, const void *src, size_t bytes);
+int ann_d2h2_then(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, void *dst2, const void *src2, size_t bytes2, int (*then)(annchor_ctx *));
 int ann_d2h2(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, void *dst2, const void *src2, size_t bytes2);
 
 // profiling scopes: one entry per kernel family

@@ -260,6 +260,29 @@ int ann_d2h2(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, void *
     return ann_d2h(c, dst2, src2, bytes2);
 }
 
+// two small downloads the host waits for while MORE work is queued behind them: the copies go to the pinned slot, an event marks
+// their end, `then` enqueues what follows (it must not wait), the host waits for the event only
+int ann_d2h2_then(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, void *dst2, const void *src2, size_t bytes2, int (*then)(annchor_ctx *))
+{
+    const size_t off2 = (bytes1 + 63) & ~(size_t)63;
+    if (!c->pin || off2 + bytes2 > annchor_ctx::PIN_DL_BYTES) {
+        ANN_TRY(ann_d2h2(c, dst1, src1, bytes1, dst2, src2, bytes2));
+        return then(c);
+    }
+    if (!c->dl_ev) ANN_CHECK_HIP(c, hipEventCreate(&c->dl_ev));
+    unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
+    ANN_CHECK_HIP(c, hipMemcpyAsync(slot, src1, bytes1, hipMemcpyDeviceToHost, c->stream));
+    ANN_CHECK_HIP(c, hipMemcpyAsync(slot + off2, src2, bytes2, hipMemcpyDeviceToHost, c->stream));
+    ANN_CHECK_HIP(c, hipEventRecord(c->dl_ev, c->stream));
+    const int rc = then(c);
+    static const bool trace = getenv("ANNCHOR_SYNC_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "sync %s\n", __func__);
+    ANN_CHECK_HIP(c, hipEventSynchronize(c->dl_ev));
+    memcpy(dst1, slot, bytes1);
+    memcpy(dst2, slot + off2, bytes2);
+    return rc;
+}
+
 // ------------------------------------------------------------------ profiling
 int ann_prof_entry(annchor_ctx *c, const char *name)
 {
@@ -456,6 +479,7 @@ extern "C" void annchor_destroy(annchor_ctx *c)
     for (DevBuf *b : c->own_allocs)
         if (b->p && !b->in_arena) { ann_dev_free(c, b->p, b->cap); b->p = nullptr; b->cap = 0; }
     c->own_allocs.clear();
+    if (c->dl_ev) { c->ev_pool.push_back(c->dl_ev); c->dl_ev = nullptr; }
     {
         // park the shell for the next context of this device (at most SHELL_MAX of them, slabs up to
         // SHELL_ARENA_MAX; ANNCHOR_NO_CTX_POOL=1 turns the parking off)

@@ -703,6 +703,13 @@ extern "C" int annchor_sampler_stats(annchor_ctx *c, const int64_t *ks, int32_t 
         ANN_CHECK_HIP(c, hipGetLastError());
         SamplerStats h;
         int unfinished = 0;
+        if (c->park_refine) {
+            // fit(): the refinement launch of the iteration that just chose its candidates is queued BEHIND this download -- the host
+            // waits for the statistics only and starts the draw while the GPU refines (queueing it after the wait left the GPU idle
+            // for the host's wake-up and the trip through the host language: ~70 us per iteration)
+            c->park_refine = false;
+            ANN_TRY(ann_d2h2_then(c, &h, st, sizeof h, &unfinished, d_unfinished, sizeof unfinished, annchor_refine_candidates));
+        } else
         ANN_TRY(ann_d2h2(c, &h, st, sizeof h, &unfinished, d_unfinished, sizeof unfinished));
         ann_kth_async_done(c);
         if (!unfinished) {

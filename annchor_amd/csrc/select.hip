@@ -1505,6 +1505,17 @@ extern "C" int annchor_mark_candidates(annchor_ctx *c)
     return ANNCHOR_OK;
 }
 
+// action 1: park the refinement launch -- the next annchor_sampler_stats queues it behind its download; action 2: launch it now
+// if it is still parked (the statistics took another route)
+extern "C" int annchor_park_refine(annchor_ctx *c, int32_t action)
+{
+    if (!c || (action != 1 && action != 2)) return ANNCHOR_EINVAL;
+    if (action == 1) { c->park_refine = true; return ANNCHOR_OK; }
+    if (!c->park_refine) return ANNCHOR_OK;
+    c->park_refine = false;
+    return annchor_refine_candidates(c);
+}
+
 extern "C" int annchor_refine_candidates(annchor_ctx *c)
 {
     if (!c) return ANNCHOR_EINVAL;

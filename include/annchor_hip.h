@@ -285,6 +285,10 @@ int annchor_mark_candidates(annchor_ctx *ctx);
 /* Evaluate the metric on the selected candidates and write back
  * (annchor.py:467-473). */
 int annchor_refine_candidates(annchor_ctx *ctx);
+/* fit() pipelining: action 1 parks the refinement launch so that the next annchor_sampler_stats (the NEXT iteration's sampling
+ * statistics, which depend on the candidate marks only) queues it behind its download and waits for the statistics alone;
+ * action 2 launches it now if it is still parked. */
+int annchor_park_refine(annchor_ctx *ctx, int32_t action);
 /* Same, host-evaluated metric: exact float64 [n_cand] in ANNCHOR_F_CAND order. */
 int annchor_set_refined(annchor_ctx *ctx, const double *exact, int64_t n_cand);
 
