@@ -71,6 +71,12 @@ struct annchor_ctx {
     bool hist_integral = false;  // all masses integer valued and (row sum)^2 < 2^31: exact int32 flows
     bool hist_fits_i16 = false;  // ... and (largest mass) x (largest row sum) < 2^15: every flow fits int16
 
+    // ---- the fitted model + residual lists downloaded with the graph (model.hip: ann_model_prefetch_*): what
+    // annchor_model_download_with_errors returns without another wait
+    std::vector<unsigned char> model_cache;
+    bool model_cache_valid = false;
+    size_t model_cache_errs = 0;   // bytes of residual lists in the cache
+
     // ---- the refinement launch parked behind the next sampling step's statistics (annchor_park_refine)
     bool park_refine = false;
     hipEvent_t dl_ev = nullptr;   // marks the end of a download the host waits for while later work is already queued
@@ -348,6 +354,10 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
 // every round of the max-min picker in ONE launch (lev.hip, k_lev_ap); *done = false: not taken, the caller runs the rounds one by one
 int ann_lev_anchor_rounds(annchor_ctx *c, int32_t na, int32_t first, bool *done);
 int ann_legacy_generate_upto(uint32_t seed, int64_t ndraws, int64_t upto);   // hostrng.hip
+// model.hip: the device-fitted model, its flags and residual lists copied (async) to pinned memory at `at` (room bytes; *used = 0:
+// nothing to fetch / no room) and, after the caller's wait, kept in the context for annchor_model_download_with_errors
+int ann_model_prefetch_begin(annchor_ctx *c, unsigned char *at, size_t room, size_t *used);
+void ann_model_prefetch_end(annchor_ctx *c, const unsigned char *at, size_t used);
 int ann_euclid_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
 int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double *d_RA, uint8_t *d_ncm);
 

@@ -1383,7 +1383,7 @@ extern "C" int annchor_predict_merge(annchor_ctx *c, const double *bins, int32_t
     }
     ANN_TRY(ann_reserve(c, c->model, sizeof(DeviceModel)));
     ANN_TRY(ann_h2d(c, c->model.p, &m, sizeof m));   // (DeviceModel begins with its RegModel)
-    c->model_fitted = false; c->errs_on_device = false;
+    c->model_fitted = false; c->errs_on_device = false; c->model_cache_valid = false;
     ANN_TRY(ann_predict_merge_device(c, c->model.as<RegModel>(), first_iteration, is_metric));
     if (c->nsamp > 0 && sample_predict) ANN_TRY(ann_d2h(c, sample_predict, c->spred.p, sizeof(double) * (size_t)c->nsamp));
     return ANNCHOR_OK;

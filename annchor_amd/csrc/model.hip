@@ -224,7 +224,7 @@ extern "C" int annchor_fit_regression_device(annchor_ctx *c, const double *bins,
                                                 c->dev_flags.as<int32_t>());
     }
     ANN_CHECK_HIP(c, hipGetLastError());
-    c->model_fitted = true; c->model_nb = nb; c->errs_on_device = false;
+    c->model_fitted = true; c->model_nb = nb; c->errs_on_device = false; c->model_cache_valid = false;
     return ann_predict_merge_device(c, &dm->reg, first_iteration, is_metric);
 }
 
@@ -343,7 +343,7 @@ extern "C" int annchor_fit_errors_device(annchor_ctx *c)
                                                  nb, c->dev_flags.as<int32_t>(), c->errptr.as<int64_t>());
     }
     ANN_CHECK_HIP(c, hipGetLastError());
-    c->errs_on_device = true;
+    c->errs_on_device = true; c->model_cache_valid = false;
     return ANNCHOR_OK;
 }
 
@@ -373,6 +373,31 @@ extern "C" int annchor_model_download(annchor_ctx *c, double *W, double *cc, int
     return ANNCHOR_OK;
 }
 
+// The same three copies queued early -- annchor_neighbor_graph issues them before its kernel, into the tail of the pinned region
+// its graph arrives in -- so that the end of a fit has ONE host wait (graph + model) instead of two.
+int ann_model_prefetch_begin(annchor_ctx *c, unsigned char *at, size_t room, size_t *used)
+{
+    *used = 0;
+    c->model_cache_valid = false;
+    if (!(c->model_fitted && c->errs_on_device && c->model.p && c->errs.p && c->model_nb > 0)) return ANNCHOR_OK;
+    const size_t eb = sizeof(double) * 2 * (size_t)c->nsamp;
+    const size_t off_f = (sizeof(DeviceModel) + 63) & ~(size_t)63, off_e = off_f + 64;
+    if (off_e + eb > room) return ANNCHOR_OK;
+    ANN_TRY(ann_dev_flags(c));
+    ANN_CHECK_HIP(c, hipMemcpyAsync(at, c->model.p, sizeof(DeviceModel), hipMemcpyDeviceToHost, c->stream));
+    ANN_CHECK_HIP(c, hipMemcpyAsync(at + off_f, c->dev_flags.p, sizeof(int32_t) * 16, hipMemcpyDeviceToHost, c->stream));
+    if (eb) ANN_CHECK_HIP(c, hipMemcpyAsync(at + off_e, c->errs.p, eb, hipMemcpyDeviceToHost, c->stream));
+    c->model_cache_errs = eb;
+    *used = off_e + eb;
+    return ANNCHOR_OK;
+}
+void ann_model_prefetch_end(annchor_ctx *c, const unsigned char *at, size_t used)
+{
+    if (!used) return;
+    c->model_cache.assign(at, at + used);
+    c->model_cache_valid = true;
+}
+
 // annchor_model_download and annchor_errors_download behind ONE wait: the residual lists (at most 2 x n_samples doubles:
 // a sample on a bin edge belongs to two partitions) are copied whole, *n_errs = err_ptr[nb] of them are meaningful.
 extern "C" int annchor_model_download_with_errors(annchor_ctx *c, double *W, double *cc, int32_t *status, int64_t *err_ptr, int32_t *flags,
@@ -382,20 +407,28 @@ extern "C" int annchor_model_download_with_errors(annchor_ctx *c, double *W, dou
     ANN_REQUIRE(c, c->model.p && c->model_nb > 0, ANNCHOR_ESTATE, "no model on this context");
     ANN_REQUIRE(c, c->errs_on_device && c->errs.p, ANNCHOR_ESTATE, "no device-resident residual lists");
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
-    const size_t eb = sizeof(double) * (size_t)std::min<int64_t>(errs_cap, 2 * c->nsamp);
+    size_t eb = sizeof(double) * (size_t)std::min<int64_t>(errs_cap, 2 * c->nsamp);
     const size_t off_f = (sizeof(DeviceModel) + 63) & ~(size_t)63, off_e = off_f + 64;
-    if (!c->pin || off_e + eb > annchor_ctx::PIN_DL_BYTES) {   // (large sample sets: the two-wait way)
+    const bool cached = c->model_cache_valid && c->model_cache.size() >= off_e + c->model_cache_errs;
+    c->model_cache_valid = false;
+    if (!cached && (!c->pin || off_e + eb > annchor_ctx::PIN_DL_BYTES)) {   // (large sample sets: the two-wait way)
         ANN_TRY(annchor_model_download(c, W, cc, status, err_ptr, flags));
         *n_errs = err_ptr[c->model_nb];
         ANN_REQUIRE(c, *n_errs <= errs_cap, ANNCHOR_EINVAL, "residual lists hold %lld entries, room for %lld", (long long)*n_errs, (long long)errs_cap);
         return annchor_errors_download(c, errs, *n_errs);
     }
     ANN_TRY(ann_dev_flags(c));
-    unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
-    ANN_CHECK_HIP(c, hipMemcpyAsync(slot, c->model.p, sizeof(DeviceModel), hipMemcpyDeviceToHost, c->stream));
-    ANN_CHECK_HIP(c, hipMemcpyAsync(slot + off_f, c->dev_flags.p, sizeof(int32_t) * 16, hipMemcpyDeviceToHost, c->stream));
-    if (eb) ANN_CHECK_HIP(c, hipMemcpyAsync(slot + off_e, c->errs.p, eb, hipMemcpyDeviceToHost, c->stream));
-    ANN_CHECK_HIP(c, ann_sync(c, __func__));
+    const unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
+    if (cached) {   // fetched with the graph (ann_model_prefetch_*): no wait here
+        slot = c->model_cache.data();
+        eb = c->model_cache_errs;
+    } else {
+        unsigned char *dst = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
+        ANN_CHECK_HIP(c, hipMemcpyAsync(dst, c->model.p, sizeof(DeviceModel), hipMemcpyDeviceToHost, c->stream));
+        ANN_CHECK_HIP(c, hipMemcpyAsync(dst + off_f, c->dev_flags.p, sizeof(int32_t) * 16, hipMemcpyDeviceToHost, c->stream));
+        if (eb) ANN_CHECK_HIP(c, hipMemcpyAsync(dst + off_e, c->errs.p, eb, hipMemcpyDeviceToHost, c->stream));
+        ANN_CHECK_HIP(c, ann_sync(c, __func__));
+    }
     const DeviceModel &h = *reinterpret_cast<const DeviceModel *>(slot);
     const int32_t *f = reinterpret_cast<const int32_t *>(slot + off_f);
     for (int b = 0; b < c->model_nb; ++b) {
@@ -406,7 +439,7 @@ extern "C" int annchor_model_download_with_errors(annchor_ctx *c, double *W, dou
     for (int b = 0; b <= c->model_nb; ++b) err_ptr[b] = h.errptr[b];
     flags[0] = f[0]; flags[1] = f[1]; flags[2] = f[2];
     *n_errs = err_ptr[c->model_nb];
-    if (*n_errs < 0 || (size_t)*n_errs * sizeof(double) > eb) *n_errs = -1;   // (a failed step: the flags say so; no list to hand out)
+    if (*n_errs < 0 || (size_t)*n_errs * sizeof(double) > eb || *n_errs > errs_cap) *n_errs = -1;   // (a failed step: the flags say so; no list to hand out)
     else memcpy(errs, slot + off_e, sizeof(double) * (size_t)*n_errs);
     if (f[0] | f[1] | f[2]) ANN_CHECK_HIP(c, hipMemsetAsync(c->dev_flags.p, 0, sizeof(int32_t) * 16, c->stream));
     return ANNCHOR_OK;

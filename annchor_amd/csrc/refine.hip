@@ -866,6 +866,17 @@ extern "C" int annchor_neighbor_graph(annchor_ctx *c, int32_t nn, int64_t *ng_id
     ANN_TRY(ann_reserve(c, c->stage_out, cells * 16));
     int64_t *d_i = direct ? reinterpret_cast<int64_t *>(slot) : c->stage_out.as<int64_t>();
     double *d_d = reinterpret_cast<double *>(d_i + cells);
+    // the device-fitted model of the last iteration (coefficients, flags, residual lists) rides with the graph: its copies are
+    // queued here, before the kernel, into the tail of the pinned region -- the fit then ends with ONE host wait
+    size_t mp_used = 0;
+    unsigned char *mp_at = nullptr;
+    if (direct) {
+        const size_t base = (cells * 16 + 255) & ~(size_t)255;
+        if (base < annchor_ctx::PIN_DL_BYTES) {
+            mp_at = slot + base;
+            ANN_TRY(ann_model_prefetch_begin(c, mp_at, annchor_ctx::PIN_DL_BYTES - base, &mp_used));
+        }
+    }
     ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
     RowSrc rsrc;
     ANN_TRY(ann_transpose_columns(c, &rsrc));
@@ -882,6 +893,7 @@ extern "C" int annchor_neighbor_graph(annchor_ctx *c, int32_t nn, int64_t *ng_id
     ANN_CHECK_HIP(c, hipGetLastError());
     if (direct) {
         ANN_CHECK_HIP(c, ann_sync(c, __func__));
+        ann_model_prefetch_end(c, mp_at, mp_used);
         memcpy(ng_idx, slot, cells * 8);
         memcpy(ng_dist, slot + cells * 8, cells * 8);
         return ANNCHOR_OK;

@@ -1317,7 +1317,7 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         ANN_TRY(ann_reserve(c, c->errptr, sizeof(int64_t) * (size_t)(MAXBINS > nlabels ? MAXBINS + 1 : nlabels + 1)));
         ANN_TRY(ann_h2d(c, c->errs.p, errs, sizeof(double) * (size_t)nerr));
         ANN_TRY(ann_h2d(c, c->errptr.p, err_ptr, sizeof(int64_t) * (size_t)(nlabels + 1)));
-        c->errs_on_device = false;
+        c->errs_on_device = false; c->model_cache_valid = false;
     }
     {
         // LDS copy of the lists: exact size known (host lists), or room for the usual case of the device lists (every
