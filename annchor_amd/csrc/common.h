@@ -63,7 +63,8 @@ struct annchor_ctx {
     DevBuf lev_perm;         // int32 [n] pair positions, short patterns first / long ones from the back; + 2 counters
     DevBuf pts;              // points (f32 or f64) row-major [nx, dim]
     int dim = 0;
-    DevBuf hist, cost, supp; // histograms f64 [nx, nbins], cost [nbins, nbins], support sizes int32 [nx]
+    DevBuf hist, cost, supp; // histograms f64 [nx, nbins] (nbins <= 64), cost [nbins, nbins], the exact-OT kernels' flags / counters
+    DevBuf hs_bin, hs_val, hs_cnt;   // nbins > 64: the non-zero entries of every histogram, int32 [nx][32] bins (ascending), f64 [nx][32] masses, int32 [nx]
     int nbins = 0, max_support = 0;
     double cost_max = 0.0;       // largest ground cost
     int emd_epoch = 0;           // launches of the exact-OT kernels (their two work counters take turns)

@@ -771,7 +771,7 @@ extern "C" int annchor_set_histograms(annchor_ctx *c, const double *hist, int64_
 {
     if (!c || !hist || !cost) return ANNCHOR_EINVAL;
     ANN_REQUIRE(c, nx > 1 && nx < (1ll << 31), ANNCHOR_ELIMIT, "nx=%lld out of range", (long long)nx);
-    ANN_REQUIRE(c, nbins >= 1 && nbins <= 64, ANNCHOR_ELIMIT, "nbins=%d: this build supports 1..64 bins", nbins);
+    ANN_REQUIRE(c, nbins >= 1 && nbins <= 1024, ANNCHOR_ELIMIT, "nbins=%d: this build supports 1..1024 bins", nbins);
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     int maxs = 0;
     bool integral = true;
@@ -790,10 +790,33 @@ extern "C" int annchor_set_histograms(annchor_ctx *c, const double *hist, int64_
         ANN_REQUIRE(c, k > 0, ANNCHOR_EINVAL, "histogram %lld is empty", (long long)s);
         if (k > maxs) maxs = k;
     }
+    // more than 64 bins: sparse histograms only (at most 32 non-zero entries each, kept as (bin, mass) lists: the two supports of a
+    // solve are then at most 64 nodes, one lane each); the metric test below must hold as well
+    ANN_REQUIRE(c, nbins <= 64 || maxs <= 32, ANNCHOR_ELIMIT,
+                "histograms of %d bins: at most 32 non-zero entries each are supported beyond 64 bins (largest support here: %d)", nbins, maxs);
     ANN_TRY(ann_arena_init(c, nx));
-    ANN_TRY(ann_reserve(c, c->hist, sizeof(double) * (size_t)nx * nbins));
     ANN_TRY(ann_reserve(c, c->cost, sizeof(double) * (size_t)nbins * nbins));
-    ANN_TRY(ann_h2d(c, c->hist.p, hist, sizeof(double) * (size_t)nx * nbins));
+    if (nbins <= 64) {
+        ANN_TRY(ann_reserve(c, c->hist, sizeof(double) * (size_t)nx * nbins));
+        ANN_TRY(ann_h2d(c, c->hist.p, hist, sizeof(double) * (size_t)nx * nbins));
+    } else {
+        std::vector<int32_t> hb((size_t)nx * 32, 0), hc((size_t)nx, 0);
+        std::vector<double> hv((size_t)nx * 32, 0.0);
+        for (int64_t s = 0; s < nx; ++s) {
+            int k = 0;
+            for (int b = 0; b < nbins; ++b) {
+                const double v = hist[s * nbins + b];
+                if (v != 0) { hb[(size_t)s * 32 + k] = b; hv[(size_t)s * 32 + k] = v; ++k; }
+            }
+            hc[(size_t)s] = k;
+        }
+        ANN_TRY(ann_reserve(c, c->hs_bin, sizeof(int32_t) * hb.size()));
+        ANN_TRY(ann_reserve(c, c->hs_val, sizeof(double) * hv.size()));
+        ANN_TRY(ann_reserve(c, c->hs_cnt, sizeof(int32_t) * hc.size()));
+        ANN_TRY(ann_h2d(c, c->hs_bin.p, hb.data(), sizeof(int32_t) * hb.size()));
+        ANN_TRY(ann_h2d(c, c->hs_val.p, hv.data(), sizeof(double) * hv.size()));
+        ANN_TRY(ann_h2d(c, c->hs_cnt.p, hc.data(), sizeof(int32_t) * hc.size()));
+    }
     ANN_TRY(ann_h2d(c, c->cost.p, cost, sizeof(double) * (size_t)nbins * nbins));
     c->metric = ANNCHOR_METRIC_WASSERSTEIN;
     c->nx = nx;
@@ -817,6 +840,8 @@ extern "C" int annchor_set_histograms(annchor_ctx *c, const double *hist, int64_
             }
         }
     }
+    ANN_REQUIRE(c, nbins <= 64 || metric_cost, ANNCHOR_ELIMIT,
+                "histograms of %d bins need a metric ground cost (zero diagonal, triangle inequality): the solver for other costs takes up to 64 bins", nbins);
     c->cost_is_metric = metric_cost;
     c->cost_max = 0.0;
     for (int i = 0; i < nbins * nbins; ++i) c->cost_max = std::max(c->cost_max, fabs(cost[i]));

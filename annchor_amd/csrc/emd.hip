@@ -43,6 +43,9 @@ struct EmdArgs {
     int reduce;     // metric ground cost: solve on the differences of the two (scaled) histograms
     long long *dbg; // -DEMD_PROFILE
     int dantzig_cap; // k_emd_ns: pivots under Dantzig's rule before Bland's takes over (-1: 16 (n + m) + 64; tests force 0)
+    const int32_t *hs_bin;   // k_emd_ns<.., true>: [nx][32] bins of the non-zero entries (ascending), their masses, their number
+    const double *hs_val;
+    const int32_t *hs_cnt;
     double eps;     // k_emd_ns: an arc enters the basis when its reduced cost is below -eps (2^-43 x the largest ground cost)
 };
 
@@ -394,20 +397,25 @@ __device__ __forceinline__ unsigned long long rl64(unsigned long long v, int lan
     return ((unsigned long long)hi << 32) | lo;
 }
 
-template <typename T> __global__ __launch_bounds__(1024) void k_emd_ns(EmdArgs a)
+// SPARSE: histograms of more than 64 bins with at most 32 non-zero entries each (annchor_set_histograms keeps them as (bin, mass)
+// lists): lanes 0..31 take x's entries, lanes 32..63 y's; the ground costs stay in global memory (read at the start of a solve, in
+// the start rule and for the objective -- never per pivot)
+template <typename T, bool SPARSE> __global__ __launch_bounds__(1024) void k_emd_ns(EmdArgs a)
 {
     constexpr bool INTEGRAL = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nb = a.nb;
-    double *costL = reinterpret_cast<double *>(smem);                       // [nb][nb]
+    double *costL = reinterpret_cast<double *>(smem);                       // [nb][nb] (not SPARSE)
     // per wave: [64] support of x, [64] support of y (ints), [64] potentials by node (doubles)
-    unsigned char *wv = reinterpret_cast<unsigned char *>(costL + nb * nb) + (size_t)wave * EMD_NS_WAVE_BYTES;
+    unsigned char *wv = reinterpret_cast<unsigned char *>(costL + (SPARSE ? 0 : nb * nb)) + (size_t)wave * EMD_NS_WAVE_BYTES;
+    auto COST = [&](int ra, int cb) -> double { return SPARSE ? a.cost[(size_t)ra * nb + cb] : costL[ra * nb + cb]; };
     int *rowsL = reinterpret_cast<int *>(wv);
     int *colsL = rowsL + EMD_MAXB;
     double *potL = reinterpret_cast<double *>(wv + 2 * EMD_MAXB * sizeof(int));
-    for (int t = threadIdx.x; t < nb * nb; t += blockDim.x) costL[t] = a.cost[t];
+    if (!SPARSE)
+        for (int t = threadIdx.x; t < nb * nb; t += blockDim.x) costL[t] = a.cost[t];
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.work_next = 0;   // (two counters used in turn: no memset between launches)
     __syncthreads();
     const double eps = a.eps;
@@ -429,14 +437,43 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd_ns(EmdArgs a
         }
         pi = __builtin_amdgcn_readfirstlane(pi);
         pj = __builtin_amdgcn_readfirstlane(pj);
-        const double *hx = a.hist + (size_t)pi * nb, *hy = a.hist + (size_t)pj * nb;
-        const double xk = lane < nb ? hx[lane] : 0.0, yk = lane < nb ? hy[lane] : 0.0;
         double sa = 0, sb = 0;
-        for (int k = 0; k < nb; ++k) { sa += readlane_f64(xk, k); sb += readlane_f64(yk, k); }
         T xm, ym;
-        if (INTEGRAL) { xm = (T)(xk * sb); ym = (T)(yk * sa); }
-        else { xm = (T)(xk / sa); ym = (T)(yk / sb); }
-        {   // the common mass stays where it is (metric cost): only the differences travel
+        int ebin = lane;   // histogram bin of the entry this lane holds (dense: bin = lane)
+        if constexpr (SPARSE) {
+            const int side = lane >> 5, e = lane & 31;
+            const int cx = a.hs_cnt[pi], cy = a.hs_cnt[pj];
+            const int pidx = side ? pj : pi, cnt = side ? cy : cx;
+            ebin = e < cnt ? a.hs_bin[(size_t)pidx * 32 + e] : -1 - lane;   // (empty slots: distinct negative numbers, matching nothing)
+            const double ev = e < cnt ? a.hs_val[(size_t)pidx * 32 + e] : 0.0;
+            for (int k = 0; k < cx; ++k) sa += readlane_f64(ev, k);          // entries are in bin order: the dense loop's sums
+            for (int k = 0; k < cy; ++k) sb += readlane_f64(ev, 32 + k);
+            T mine;
+            if (INTEGRAL) mine = (T)(ev * (side ? sa : sb));
+            else mine = (T)(ev / (side ? sb : sa));
+            // the other histogram's mass on the same bin
+            T other = (T)0;
+            for (int k = 0; k < cy; ++k) {
+                const int b = __builtin_amdgcn_readlane(ebin, 32 + k);
+                const T v = rl(mine, 32 + k);
+                if (side == 0 && ebin == b) other = v;
+            }
+            for (int k = 0; k < cx; ++k) {
+                const int b = __builtin_amdgcn_readlane(ebin, k);
+                const T v = rl(mine, k);
+                if (side == 1 && ebin == b) other = v;
+            }
+            const T d = mine - other;     // the common mass stays where it is (metric cost)
+            const T pos = d > (T)0 ? d : (T)0;
+            xm = side == 0 ? pos : (T)0;
+            ym = side == 1 ? pos : (T)0;
+        } else {
+            const double *hx = a.hist + (size_t)pi * nb, *hy = a.hist + (size_t)pj * nb;
+            const double xk = lane < nb ? hx[lane] : 0.0, yk = lane < nb ? hy[lane] : 0.0;
+            for (int k = 0; k < nb; ++k) { sa += readlane_f64(xk, k); sb += readlane_f64(yk, k); }
+            if (INTEGRAL) { xm = (T)(xk * sb); ym = (T)(yk * sa); }
+            else { xm = (T)(xk / sa); ym = (T)(yk / sb); }
+            // the common mass stays where it is (metric cost): only the differences travel
             const T d = xm - ym;
             xm = d > (T)0 ? d : (T)0;
             ym = d < (T)0 ? -d : (T)0;
@@ -454,7 +491,17 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd_ns(EmdArgs a
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             // ---- nodes: lane k < n = source k, lane n + j = sink j
             const bool is_src = lane < n, is_snk = lane >= n && lane < N;
-            const int bin = is_src ? rowsL[lane] : (is_snk ? colsL[lane - n] : 0);
+            const int holder = is_src ? rowsL[lane] : (is_snk ? colsL[lane - n] : 0);   // the lane that holds this node's entry
+            const int ebin_of = __shfl(ebin, holder);   // (every lane takes part: a holder lane may lie beyond the N node lanes)
+            const int bin = lane < N ? ebin_of : 0;
+            if constexpr (SPARSE) {   // the lists now carry the nodes' bins (dense: they already do)
+                __builtin_amdgcn_wave_barrier();
+                if (is_src) rowsL[lane] = bin;
+                if (is_snk) colsL[lane - n] = bin;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
             // ---- the arcs, dealt over the lanes: arc a = slot * 64 + lane is (source a / m, sink a % m); its ground cost and the
             // LDS offsets of its ends' potentials stay in registers for the whole solve (<= 16 slots: n m <= 1024)
             const int nm = n * m;
@@ -470,13 +517,13 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd_ns(EmdArgs a
                         const int ac_ = min(aidx, nm - 1);
                         const int ai = (int)(((float)ac_ + 0.5f) * inv_m);
                         const int aj = ac_ - ai * m;
-                        ac[sl] = costL[rowsL[ai] * nb + colsL[aj]];
+                        ac[sl] = COST(rowsL[ai], colsL[aj]);
                         if (aidx < nm) aij[sl] = (ai << 16) | (n + aj);
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            const T mass_x = __shfl(xm, bin), mass_y = __shfl(ym, bin);
+            const T mass_x = __shfl(xm, holder), mass_y = __shfl(ym, holder);
             T rem = is_src ? mass_x : (is_snk ? mass_y : (T)0);       // supply / demand still to place (start rule)
             const unsigned long long allmask = N == 64 ? ~0ull : ((1ull << N) - 1ull);
             const unsigned long long srcmask = (1ull << n) - 1ull, snkmask = allmask & ~srcmask;
@@ -496,7 +543,7 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd_ns(EmdArgs a
                 const int i = __ffsll(osrc) - 1;                       // (an open source always exists while two lines are open)
                 const int bi = __builtin_amdgcn_readlane(bin, i);
                 const bool cand = is_snk && ((open >> lane) & 1ull);
-                const double c = cand ? costL[bi * nb + bin] : INFINITY;
+                const double c = cand ? COST(bi, bin) : INFINITY;
                 // (minimum of the high words first; the low words only when several candidates share it)
                 const uint32_t chi = (uint32_t)__double2hiint(c);
                 const uint32_t mh = wave_min_u32(chi);
@@ -636,7 +683,7 @@ template <typename T> __global__ __launch_bounds__(1024) void k_emd_ns(EmdArgs a
             // ---- objective: flow x cost over the tree arcs
             {
                 const int pb = __shfl(bin, parent < 0 ? lane : parent);
-                const double cst = (lane < N && parent >= 0) ? costL[(is_src ? bin : pb) * nb + (is_src ? pb : bin)] : 0.0;
+                const double cst = (lane < N && parent >= 0) ? COST(is_src ? bin : pb, is_src ? pb : bin) : 0.0;
                 tot = (lane < N && parent >= 0) ? (double)pflow * cst : 0.0;
             }
 #pragma unroll
@@ -699,8 +746,11 @@ int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
             if (spread < waves) waves = (int)std::max<int64_t>(spread, 1);
             if (const char *w = getenv("ANNCHOR_EMD_WAVES")) { const int ww = atoi(w); if (ww >= 1 && ww < waves) waves = ww; }
             a.waves = waves;
-            const size_t lds = cost_bytes + (size_t)waves * EMD_NS_WAVE_BYTES;
-            const void *fn = integral ? (const void *)k_emd_ns<int> : (const void *)k_emd_ns<double>;
+            const bool sparse = a.nb > EMD_MAXB;
+            a.hs_bin = c->hs_bin.as<int32_t>(); a.hs_val = c->hs_val.as<double>(); a.hs_cnt = c->hs_cnt.as<int32_t>();
+            const size_t lds = (sparse ? 0 : cost_bytes) + (size_t)waves * EMD_NS_WAVE_BYTES;
+            const void *fn = sparse ? (integral ? (const void *)k_emd_ns<int, true> : (const void *)k_emd_ns<double, true>)
+                                    : (integral ? (const void *)k_emd_ns<int, false> : (const void *)k_emd_ns<double, false>);
             ANN_CHECK_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             int64_t blocks = (src.n + waves - 1) / waves;
             int per_cu = 1;   // resident workgroups only: the waves claim their solves from a counter
@@ -712,9 +762,14 @@ int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
             if (!dbg) (void)hipMalloc(&dbg, sizeof(long long) * 4096 * 16);
             if (src.n <= 4096) { a.dbg = dbg; (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 4096 * 16, c->stream); }
 #endif
-            ProfScope ps(c, "wasserstein_pairs", (double)src.n * (2.0 * a.nb * 8 + 8));
-            if (integral) k_emd_ns<int><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
-            else k_emd_ns<double><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
+            ProfScope ps(c, "wasserstein_pairs", (double)src.n * (2.0 * std::min(a.nb, 64) * 8 + 8));
+            if (sparse) {
+                if (integral) k_emd_ns<int, true><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
+                else k_emd_ns<double, true><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
+            } else {
+                if (integral) k_emd_ns<int, false><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
+                else k_emd_ns<double, false><<<(int)blocks, waves * 64, lds, c->stream>>>(a);
+            }
             ANN_CHECK_HIP(c, hipGetLastError());
 #ifdef EMD_PROFILE
             if (a.dbg) {
@@ -735,6 +790,7 @@ int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
             return ANNCHOR_OK;
         }
     }
+    ANN_REQUIRE(c, a.nb <= EMD_MAXB, ANNCHOR_ELIMIT, "histograms of %d bins need a metric ground cost (the shortest-path solver takes up to %d bins)", a.nb, EMD_MAXB);
     a.eps = 0.0;
     const bool narrow = integral && c->hist_fits_i16 && !getenv("ANNCHOR_EMD_WIDE_FLOWS");
     // Flow slab: n sources x (m | 1) sinks.  The supports of the raw histograms bound n and m by max_support; with the common

@@ -100,7 +100,9 @@ int annchor_set_points_f64(annchor_ctx *ctx, const double *X, int64_t nx, int32_
 int annchor_set_points_cosine_f32(annchor_ctx *ctx, const float *X, int64_t nx, int32_t dim);
 int annchor_set_points_cosine_f64(annchor_ctx *ctx, const double *X, int64_t nx, int32_t dim);
 /* Wasserstein: hist float64 [nx, nbins], cost float64 [nbins, nbins]
- * (annchor/utils.py:75-86, func_kwargs['cost_matrix']). */
+ * (annchor/utils.py:75-86, func_kwargs['cost_matrix']).  Up to 64 bins: any histograms, any cost matrix.  65 .. 1024 bins:
+ * histograms with at most 32 non-zero entries each under a metric ground cost (zero diagonal, triangle inequality) -- kept as
+ * (bin, mass) lists; anything else returns ANNCHOR_ELIMIT. */
 int annchor_set_histograms(annchor_ctx *ctx, const double *hist, int64_t nx, int32_t nbins,
                            const double *cost);
 /* Data set without a device metric (user metric evaluated on the host). */

@@ -748,6 +748,54 @@ def test_wasserstein_solver_variants(monkeypatch, solver):
     e2.close()
 
 
+@pytest.mark.parametrize("integral", [True, False])
+def test_wasserstein_more_than_64_bins_sparse(integral):
+    """Histograms of more than 64 bins (the reference takes any: utils.py:75-86) run when each has at most 32 non-zero entries
+    and the ground cost is a metric: the simplex kernel takes the (bin, mass) lists -- x's entries on lanes 0..31, y's on 32..63,
+    costs from global memory.  200 bins on a 2-d point cloud against the oracle (pairs with overlapping, disjoint, identical and
+    one-bin supports; the one-to-all form); a small fit against brute force; the two refusals (support > 32, non-metric cost)."""
+    from annchor_amd import Annchor, BruteForce, _native, compare_neighbor_graphs
+    from annchor_amd.distances import Wasserstein
+
+    rng = np.random.default_rng(5 + integral)
+    nb, nx = 200, 400
+    pts = rng.random((nb, 2)) * 10
+    M = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+    X = np.zeros((nx, nb))
+    for i in range(nx):
+        k = int(rng.integers(1, 33))
+        centre = rng.integers(0, nb)
+        near = np.argsort(M[centre])[:60]
+        sup = rng.choice(near, k, replace=False)
+        X[i, sup] = rng.integers(1, 40, k) if integral else rng.random(k) + 0.01
+    X[7] = 0; X[7, 13] = 5 if integral else 0.7            # one bin
+    X[8] = X[9]                                            # identical pair
+    X[10] = 0; X[10, :32] = np.arange(1, 33)               # the fullest support
+    X[11] = 0; X[11, 32:64] = np.arange(1, 33)             # ... against a disjoint one: 64 nodes
+    eng = _native.Engine(0)
+    Wasserstein(M).bind(eng, X)
+    IJ = rng.integers(0, nx, (4000, 2))
+    IJ[:5] = [[7, 20], [8, 9], [10, 11], [11, 10], [7, 7]]
+    H = om.Histograms(X, M)
+    got = eng.metric_pairs(IJ)
+    np.testing.assert_allclose(got, H.pairs(IJ), rtol=0, atol=1e-11)
+    assert got[1] == 0 and got[4] == 0
+    eng.pick_anchors_selected([10, 200])
+    D = eng.download(_native.F_D).reshape(nx, 2)
+    for col, a_ in enumerate((10, 200)):
+        np.testing.assert_allclose(D[:, col], H.pairs(np.stack([np.full(nx, a_), np.arange(nx)], axis=1)), rtol=0, atol=1e-11)
+    eng.close()
+    f = Wasserstein(M)
+    ann = Annchor(X, f, n_anchors=8, n_neighbors=6, n_samples=300, p_work=0.6, random_seed=1).fit()
+    bf = BruteForce(X, Wasserstein(M)).fit(6)
+    assert compare_neighbor_graphs(bf.neighbor_graph, ann.neighbor_graph, 6) <= 0.03 * nx * 6
+    Xbad = X.copy(); Xbad[0, :40] = 1.0
+    with pytest.raises(Exception, match="32 non-zero"):
+        Wasserstein(M).bind(_native.Engine(0), Xbad)
+    with pytest.raises(Exception, match="metric ground cost"):
+        Wasserstein(M ** 2).bind(_native.Engine(0), X)
+
+
 @pytest.mark.parametrize("kind", ["squared", "asymmetric", "metric_integer"])
 def test_wasserstein_cost_matrix_kinds(kind):
     """The solver cancels the mass two histograms share on a bin only when the ground cost is a metric (zero diagonal,
