@@ -43,6 +43,11 @@ struct EmdArgs {
     int reduce;     // metric ground cost: solve on the differences of the two (scaled) histograms
     long long *dbg; // -DEMD_PROFILE
     int dantzig_cap; // k_emd_ns: pivots under Dantzig's rule before Bland's takes over (-1: 16 (n + m) + 64; tests force 0)
+    // max-min picking fused into a one-to-all launch (PairSource::pick_*): the launch derives its own anchor from the previous round's row
+    const double *pick_row;
+    double *pick_runmin;
+    int32_t *pick_out;
+    int pick_reset, pick_nx;
     const int32_t *hs_bin;   // k_emd_ns<.., true>: [nx][32] bins of the non-zero entries (ascending), their masses, their number
     const double *hs_val;
     const int32_t *hs_cnt;
@@ -420,6 +425,27 @@ template <typename T, bool SPARSE> __global__ __launch_bounds__(1024) void k_emd
     __syncthreads();
     const double eps = a.eps;
     const unsigned long long lanebit = 1ull << lane;
+    // ---- the anchor of a max-min round (pickers.py:47-50): every wave derives it for itself from the previous round's row --
+    // running minimum (idempotent: workgroup 0 also stores it), first arg-max -- so the picker needs no launch of its own
+    int picked = -1;
+    if (a.pick_row) {
+        double bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int j = lane; j < a.pick_nx; j += 64) {
+            const double d = a.pick_row[j];
+            const double v = a.pick_reset ? d : fmin(a.pick_runmin[j], d);
+            if (blockIdx.x == 0 && wave == 0) a.pick_runmin[j] = v;
+            argmax_combine(bv, bi, v, j);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            argmax_combine(bv, bi, ov, oi);
+        }
+        picked = bi;
+        if (blockIdx.x == 0 && threadIdx.x == 0) *a.pick_out = bi;
+    }
 
     const int64_t wave_global = (int64_t)blockIdx.x * a.waves + wave;
     const int64_t wave_total = (int64_t)gridDim.x * a.waves;
@@ -428,7 +454,7 @@ template <typename T, bool SPARSE> __global__ __launch_bounds__(1024) void k_emd
         EP_DECL;
         int pi, pj;
         int64_t opos = t;
-        if (a.anchor) { pi = *a.anchor; pj = (int)t; }
+        if (a.anchor) { pi = picked >= 0 ? picked : *a.anchor; pj = (int)t; }
         else {
             int64_t q = a.idx ? a.idx[t] : t;
             int2 p = a.ij[q];
@@ -721,6 +747,7 @@ int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
     a.nb = c->nbins;
     a.ij = src.ij; a.idx = src.idx; a.anchor = src.anchor; a.n = src.n;
     a.out = d_out; a.RA = d_RA; a.ncm = d_ncm;
+    a.pick_row = nullptr; a.pick_runmin = nullptr; a.pick_out = nullptr; a.pick_reset = 0; a.pick_nx = 0;
     if (!c->supp.p) {
         ANN_TRY(ann_reserve(c, c->supp, 64));
         ANN_CHECK_HIP(c, hipMemsetAsync(c->supp.p, 0, 64, c->stream));
@@ -739,6 +766,13 @@ int ann_emd_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
         if (a.reduce && !(e && !strcmp(e, "ssp"))) {
             a.eps = c->cost_max * 1.1368683772161603e-13;   // 2^-43
             a.S = 0; a.slab_bytes = 0; a.dbg = nullptr;
+            if (src.anchor && src.pick_fused && c->nx <= 65536) {
+                *src.pick_fused = true;
+                if (src.pick_row) {
+                    a.pick_row = src.pick_row; a.pick_runmin = src.pick_runmin; a.pick_out = src.pick_out;
+                    a.pick_reset = src.pick_reset; a.pick_nx = (int)c->nx;
+                }
+            }
             a.dantzig_cap = -1;
             if (const char *dc = getenv("ANNCHOR_EMD_DANTZIG_CAP")) a.dantzig_cap = atoi(dc);
             int waves = 16;
