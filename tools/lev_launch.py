@@ -19,5 +19,8 @@ for _ in range(5):
     eng.metric_pairs(one)
 # the picker's own one-to-all launches (k_lev_a2: two pairs per wave, forward / backward half-chains)
 eng.pick_anchors_selected([7, 1126, 543, 2, 640])
+# the max-min picker's 15 rounds as ONE persistent launch (k_lev_ap; ANNCHOR_LEV_R set = a forced variant: the per-round path)
+for _ in range(3):
+    eng.pick_anchors_maxmin(15, 1126)
 p = eng.prof_get()["levenshtein_pairs"]
 print("R=%s: %.1f us avg over %d launches" % (os.environ.get("ANNCHOR_LEV_R", "auto"), p["ms"] / p["launches"] * 1e3, p["launches"]))

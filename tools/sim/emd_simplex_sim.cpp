@@ -8,6 +8,8 @@
 #include <vector>
 #include <algorithm>
 static int NB;
+static int BLOCK = 0;   // > 0: block pricing -- most negative arc of the current block of BLOCK row-major arcs, blocks taken round robin
+static long PRICED = 0;
 static const double *COST;
 struct Cnt { long pivots = 0, cyc = 0, solves = 0, maxpiv = 0, depth = 0, degenerate = 0, capped = 0; };
 static double solve(const double *hx, const double *hy, Cnt &c, int init_rule)
@@ -69,7 +71,20 @@ static double solve(const double *hx, const double *hy, Cnt &c, int init_rule)
         if (piv > 5000) { c.capped++; break; }
         // pricing: most negative reduced cost
         double best = -1e-12; int ei = -1, ej = -1;
-        for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) { double rc = C(i, j) - pot[i] - pot[n + j]; if (rc < best) { best = rc; ei = i; ej = j; } }
+        if (BLOCK <= 0) {
+            for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) { double rc = C(i, j) - pot[i] - pot[n + j]; if (rc < best) { best = rc; ei = i; ej = j; } }
+            PRICED += (long)n * m;
+        } else {
+            static int cur = 0;
+            const int nm = n * m, nblk = (nm + BLOCK - 1) / BLOCK;
+            if (piv == 0) cur = 0;
+            for (int tries = 0; tries < nblk && ei < 0; ++tries) {
+                const int b = cur % nblk;
+                for (int a = b * BLOCK; a < std::min(nm, (b + 1) * BLOCK); ++a) { int i = a / m, j = a % m; double rc = C(i, j) - pot[i] - pot[n + j]; if (rc < best) { best = rc; ei = i; ej = j; } }
+                PRICED += std::min(nm, (b + 1) * BLOCK) - b * BLOCK;
+                if (ei < 0) ++cur;
+            }
+        }
         if (ei < 0) break;
         // cycle: entering arc ei -> n + ej carries +theta; walk both ends up to the common ancestor
         int x = ei, y = n + ej;
@@ -125,16 +140,18 @@ int main(int argc, char **argv)
     std::vector<int> ij((size_t)np * 2);
     fread(H.data(), 8, H.size(), f); fread(cost.data(), 8, cost.size(), f); fread(ij.data(), 4, ij.size(), f); fread(want.data(), 8, np, f);
     COST = cost.data();
-    for (int rule = 0; rule < 2; ++rule)
+    for (int blk : {0, 512, 256, 128})
+    for (int rule = 1; rule < 2; ++rule)
       for (int cls = 0; cls < 2; ++cls) {
+        BLOCK = blk; PRICED = 0;
         Cnt c; double maxerr = 0;
         for (int p = 0; p < np; ++p) {
             if ((std::isnan(want[p]) ? 1 : 0) != cls) continue;
             double d = solve(&H[(size_t)ij[2 * p] * nb], &H[(size_t)ij[2 * p + 1] * nb], c, rule);
             if (!std::isnan(want[p])) maxerr = std::max(maxerr, fabs(d - want[p]));
         }
-        printf("init rule %d %s: pivots per solve %.1f (max %ld), cycle length %.1f, final tree depth %.1f, degenerate pivots %.1f %%, capped %ld | err vs stored %.1e\n",
-               rule, cls ? "far " : "near", (double)c.pivots / c.solves, c.maxpiv, (double)c.cyc / std::max(c.pivots, 1l), (double)c.depth / c.solves,
+        printf("block %d, arcs priced per solve %.0f | init rule %d %s: pivots per solve %.1f (max %ld), cycle length %.1f, final tree depth %.1f, degenerate pivots %.1f %%, capped %ld | err vs stored %.1e\n",
+               BLOCK, (double)PRICED / c.solves, rule, cls ? "far " : "near", (double)c.pivots / c.solves, c.maxpiv, (double)c.cyc / std::max(c.pivots, 1l), (double)c.depth / c.solves,
                100.0 * c.degenerate / std::max(c.pivots, 1l), c.capped, maxerr);
       }
 }
