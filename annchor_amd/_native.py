@@ -68,6 +68,8 @@ _SIGNATURES = {
     "annchor_model_download": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "annchor_errors_download": (ctypes.c_int, [_vp, _vp, _i64]),
     "annchor_model_download_with_errors": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, ctypes.POINTER(_i64)]),
+    "annchor_sample_pairs_device_draw": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, ctypes.c_uint32, ctypes.POINTER(_i64), ctypes.POINTER(_i32)]),
+    "annchor_legacy_choice_ranks_device": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp, _vp, _i32, _vp, ctypes.POINTER(_i32)]),
     "annchor_hash_sample": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, ctypes.c_uint64, _vp, ctypes.POINTER(_i64)]),
     "annchor_hash_sample_pairs": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, ctypes.c_uint64, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "annchor_legacy_prefetch": (ctypes.c_int, [ctypes.c_uint32, _i64]),
@@ -605,6 +607,27 @@ class Engine:
         out = np.empty(int(n), dtype=np.float64)
         self._chk(self.lib.annchor_errors_download(self.h, _ptr(out), int(n)))
         return out
+
+    def sample_pairs_device_draw(self, bins, counts, want, seed):
+        """The legacy draw + the sampling step in one call, the draw's trace on the device: (taken, number of samples)."""
+        bins, counts, want = _c(bins, np.float64), _c(counts, np.int64), _c(want, np.int64)
+        n, taken = _i64(), _i32()
+        self._chk(self.lib.annchor_sample_pairs_device_draw(self.h, _ptr(bins), len(bins) - 1, _ptr(counts), _ptr(want), int(seed),
+                                                           ctypes.byref(n), ctypes.byref(taken)))
+        return bool(taken.value), int(n.value)
+
+    def legacy_choice_ranks_device(self, seed, counts, want):
+        """legacy_choice_ranks through the device-side trace (tests): list of per-bin rank arrays, or None when not applicable."""
+        counts, want = _c(counts, np.int64), _c(want, np.int64)
+        n_out = np.minimum(counts, want)
+        out = np.full(int(n_out.sum()), -1, dtype=np.int64)
+        taken = _i32()
+        self._chk(self.lib.annchor_legacy_choice_ranks_device(self.h, int(seed), _ptr(counts), _ptr(want), len(counts), _ptr(out),
+                                                             ctypes.byref(taken)))
+        if not taken.value:
+            return None
+        offs = np.concatenate([[0], np.cumsum(n_out)])
+        return [out[offs[b]:offs[b + 1]] for b in range(len(counts))]
 
     def hash_sample(self, bins, counts, want, seed_key):
         """Hashed stratified choice (annchor_hash_sample): positions of the samples, partition by partition."""

@@ -456,7 +456,8 @@ class Annchor:
         if self._sampler_on_device():
             ticket, self._sample_ticket = self._sample_ticket, None
             if ticket is None:
-                ticket = self.sampler.begin_device(eng, self.n_samples, self.random_seed, overlap=False)
+                ticket = self.sampler.begin_device(eng, self.n_samples, self.random_seed, overlap=False,
+                                                   **({"device_trace": True} if self._models_on_device() else {}))
             if self._models_on_device() and not self._device_model_takes(ticket):
                 # decided BEFORE the iteration: the models of this fit are fitted on the host (the device kernels would only raise
                 # their flags at the end and the whole fit would start over)
@@ -582,7 +583,8 @@ class Annchor:
             # (the refinement launch rides behind the statistics' download: the host waits for the statistics alone)
             self._engine.park_refine(1)
             try:
-                self._sample_ticket = self.sampler.begin_device(self._engine, self.n_samples, self.random_seed, overlap=_DRAW_OVERLAP)
+                self._sample_ticket = self.sampler.begin_device(self._engine, self.n_samples, self.random_seed, overlap=_DRAW_OVERLAP,
+                                                                **({"device_trace": True} if self._models_on_device() else {}))
             finally:
                 self._engine.park_refine(2)
         elif self._device_metric:

@@ -120,6 +120,7 @@ struct annchor_ctx {
 
     // ---- samples
     DevBuf spos, sy;  // int32 [m], double [m]
+    DevBuf draw_J, draw_next, draw_q1;   // the legacy draw's swap partners (uint32, stream order per bin) and the trace's next[] (features.hip)
     DevBuf sfeat, spred;   // double [m][4] feature rows / double [m] unclipped predictions of the samples (device-resident model fit)
     // ---- device-resident model of an iteration (model.hip): per-partition OLS coefficients, residual lists
     DevBuf model;          // DeviceModel
@@ -355,6 +356,8 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
 // every round of the max-min picker in ONE launch (lev.hip, k_lev_ap); *done = false: not taken, the caller runs the rounds one by one
 int ann_lev_anchor_rounds(annchor_ctx *c, int32_t na, int32_t first, bool *done);
 int ann_legacy_generate_upto(uint32_t seed, int64_t ndraws, int64_t upto);   // hostrng.hip
+int ann_legacy_scan(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins, uint32_t *J, const int64_t *joff,
+                    void (*after_bin)(int, void *), void *user);   // hostrng.hip
 // model.hip: the device-fitted model, its flags and residual lists copied (async) to pinned memory at `at` (room bytes; *used = 0:
 // nothing to fetch / no room) and, after the caller's wait, kept in the context for annchor_model_download_with_errors
 int ann_model_prefetch_begin(annchor_ctx *c, unsigned char *at, size_t room, size_t *used);

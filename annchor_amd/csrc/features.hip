@@ -15,6 +15,7 @@
 // regression predict is evaluated as ((w0*lb + w1*ub) + w2*dad) + c with
 // contraction disabled so that host and device agree bit for bit.
 #include "common.h"
+#include <mutex>
 
 #pragma clang fp contract(off)
 
@@ -1144,6 +1145,339 @@ extern "C" int annchor_sample_pairs_device(annchor_ctx *c, const double *bins, i
     ANN_CHECK_HIP(c, hipGetLastError());
     if (c->n_unc >= 0) c->n_unc -= nreq;
     c->sel_prepared = false;
+    return ANNCHOR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The legacy sampler's draw with its backward trace on the DEVICE (round 4).  np.random.choice(ixmask, size, replace=False)
+// of the reference (utils.py:543-578) is permutation(c)[:k] of NumPy's legacy stream: a Fisher-Yates shuffle of the whole bin
+// (c - 1 rejection-sampled partners) of which only the first k entries are used.  The host library walks the stream (the
+// rejection scan is sequential: 0.22 ms at C2) and used to undo the swaps for the k kept positions on helper threads -- the
+// two large bins' traces ran until 0.5 ms after the scan started, with the GPU idle behind them.  Here the host only scans:
+// every bin's partners J go to pinned memory and are copied to the device on a side stream as soon as the bin is scanned, and
+// the trace is three kernels:
+//   * undoing the swaps (i, j_i) in reverse execution order i = 1 .. c - 1 moves a kept slot only when i is its position or
+//     j_i is; for i >= k the first case cannot occur (position i is untouched before its own step), so a slot at position q
+//     moves to the FIRST i >= k, i > q with j_i == q -- and again from there.  `next[v]` = min { i >= k : j_i == v, i != v } is
+//     one atomicMin per step (k_tr_steps); a slot's path is a short chase through it (~ln(c / k) hops, k_tr_chase);
+//   * the first k - 1 steps involve kept positions only: every slot scans them once (partners in LDS, all slots in lockstep):
+//     at i == p the slot moves to j_p, afterwards to i whenever j_i is where it sits.
+// The chase's result (the rank of the chosen element inside the bin's population) is written straight into the slot map the
+// rank -> pair-position kernels read: no ranks on the host, none uploaded.  Same partners, same trace: the samples and their
+// order are those of annchor_legacy_choice_ranks (tests compare the two on random populations).
+#define TR_KMAX 8192   // kept entries per bin the chain kernel holds in LDS
+struct TraceBins {
+    int64_t c[MAXBINS];       // population
+    int64_t k[MAXBINS];       // entries kept (min(want, c))
+    int64_t joff[MAXBINS];    // offset of the bin's partners in J / of its next[] (-1: not shuffled, the whole bin is taken)
+    int64_t base[MAXBINS];    // offset of the bin in the slot map (prefix of the populations)
+    int64_t offs[MAXBINS];    // offset of the bin's requests (prefix of k)
+    int64_t step0[MAXBINS + 1];   // prefix of the phase-2 steps (c - k per shuffled bin): the scatter's flat index
+    int nbins;
+};
+
+// One launch, two kinds of workgroups.  Blocks [0, nbins): the first k - 1 steps of a bin (partners in LDS, every kept slot scans
+// them once, all slots in lockstep) -> the slots' positions at time k - 1 (q1).  The other blocks: next[joff + v] = min { i in [k, c) :
+// j_i == v, i != v } by one atomicMin per step (J holds the partners in stream order: J[t] belongs to i = c - 1 - t).  The two
+// halves are independent; the chase (k_tr_chase) needs both.
+__global__ __launch_bounds__(1024) void k_tr_steps(TraceBins tb, const uint32_t *__restrict__ J, uint32_t *__restrict__ next,
+                                                  uint32_t *__restrict__ q1, int scatter_blocks)
+{
+    extern __shared__ uint32_t jl[];   // jl[i] = j_i for i in [1, k)
+    if ((int)blockIdx.x >= tb.nbins) {
+        const int64_t total = tb.step0[tb.nbins];
+        const int64_t stride = (int64_t)scatter_blocks * blockDim.x;
+        for (int64_t g = (int64_t)(blockIdx.x - tb.nbins) * blockDim.x + threadIdx.x; g < total; g += stride) {
+            int b = 0;
+            while (g >= tb.step0[b + 1]) ++b;
+            const int64_t t = g - tb.step0[b];            // t in [0, c - k): i = c - 1 - t >= k
+            const uint32_t i = (uint32_t)(tb.c[b] - 1 - t);
+            const uint32_t j = J[tb.joff[b] + t];
+            if (j != i) atomicMin(&next[tb.joff[b] + j], i);
+        }
+        return;
+    }
+    const int b = blockIdx.x;
+    const int64_t c = tb.c[b], k = tb.k[b];
+    const bool shuffled = tb.joff[b] >= 0;
+    if (shuffled)
+        for (int64_t i = 1 + threadIdx.x; i < k; i += blockDim.x) jl[i] = J[tb.joff[b] + (c - 1 - i)];
+    __syncthreads();
+    for (int64_t p0 = 0; p0 < k; p0 += blockDim.x) {
+        const int64_t p = p0 + threadIdx.x;
+        uint32_t q = (uint32_t)p;
+        if (shuffled) {
+            // nothing happens to a slot before its own step; at i == p it moves to j_p, afterwards to i whenever j_i is where it sits
+            int64_t i = p0 < 1 ? 1 : p0;
+            for (; i + 8 <= k; i += 8) {
+                uint32_t jv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) jv[u] = jl[i + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (i + u == p) q = jv[u];
+                    else if (i + u > p && jv[u] == q) q = (uint32_t)(i + u);
+                }
+            }
+            for (; i < k; ++i) {
+                const uint32_t j = jl[i];
+                if (i == p) q = j;
+                else if (i > p && j == q) q = (uint32_t)i;
+            }
+        }
+        if (p < k) q1[tb.offs[b] + p] = q;
+    }
+}
+
+// one thread per kept slot: from its position at time k - 1 through next[] to the end; the rank goes into the slot map
+__global__ __launch_bounds__(256) void k_tr_chase(TraceBins tb, const uint32_t *__restrict__ next, const uint32_t *__restrict__ q1, int64_t nreq,
+                                                 int32_t *__restrict__ slotmap, int64_t *__restrict__ positions, int32_t *__restrict__ flag)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && flag) *flag = 0;
+    if (t >= nreq) return;
+    int b = 0;
+    while (b + 1 < tb.nbins && t >= tb.offs[b + 1]) ++b;
+    uint32_t q = q1[t];
+    if (tb.joff[b] >= 0) {
+        const uint32_t *nx = next + tb.joff[b];
+        for (;;) {
+            const uint32_t n2 = nx[q];
+            if (n2 == 0xffffffffu) break;
+            q = n2;
+        }
+    }
+    slotmap[tb.base[b] + q] = (int32_t)t;
+    positions[t] = -1;
+}
+
+static hipStream_t g_draw_copy_stream[16] = {};
+static hipEvent_t g_draw_copy_event[16] = {};
+static uint32_t *g_draw_pin = nullptr;
+static size_t g_draw_pin_words = 0;
+static std::mutex g_draw_mu;
+
+// the two trace launches: q1 (positions after the first k - 1 steps) sits behind next[] in draw_next
+static int trace_launch(annchor_ctx *c, const TraceBins &tb, int64_t kmax, int64_t nreq, int32_t *bad)
+{
+    const int nbins = tb.nbins;
+    const int64_t steps = tb.step0[nbins];
+    const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(256, (kmax + 63) / 64 * 64));
+    const int scatter_blocks = steps > 0 ? (int)std::min<int64_t>(ann_blocks(steps, threads), (int64_t)c->prop.multiProcessorCount * 2) : 0;
+    const size_t lds = sizeof(uint32_t) * (size_t)(kmax + 1);
+    if (lds > 64 * 1024)
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_tr_steps, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint32_t *q1 = c->draw_q1.as<uint32_t>();
+    k_tr_steps<<<nbins + scatter_blocks, threads, lds, c->stream>>>(tb, c->draw_J.as<uint32_t>(), c->draw_next.as<uint32_t>(), q1, scatter_blocks);
+    k_tr_chase<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(tb, c->draw_next.as<uint32_t>(), q1, nreq, c->tmp0.as<int32_t>(),
+                                                           c->stage_out.as<int64_t>(), bad);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
+struct DrawUpload {
+    annchor_ctx *c;
+    hipStream_t copy;
+    uint32_t *d_J;
+    const int64_t *counts;
+    const int64_t *joff;
+    int rc;
+};
+static void draw_after_bin(int b, void *user)
+{
+    DrawUpload *u = static_cast<DrawUpload *>(user);
+    if (hipMemcpyAsync(u->d_J + u->joff[b], g_draw_pin + u->joff[b], sizeof(uint32_t) * (size_t)u->counts[b], hipMemcpyHostToDevice, u->copy) != hipSuccess)
+        u->rc = ANNCHOR_EHIP;
+}
+
+// The built-in sampling step with the legacy draw (SimpleStratifiedSampler): annchor_legacy_choice_ranks + annchor_sample_pairs_device
+// in one call, the draw's trace on the device.  *taken = 0: a bin keeps more than TR_KMAX entries, the seed is outside the legacy
+// range ... -- the caller draws on the host as before.  *n_out = number of samples (sum of min(want, counts)).
+extern "C" int annchor_sample_pairs_device_draw(annchor_ctx *c, const double *bins, int32_t nbins, const int64_t *counts,
+                                                const int64_t *want, uint32_t seed, int64_t *n_out, int32_t *taken)
+{
+    if (!c || !bins || !counts || !want || !n_out || !taken) return ANNCHOR_EINVAL;
+    *taken = 0;
+    ANN_REQUIRE(c, c->have_features, ANNCHOR_EINVAL, "features not computed");
+    ANN_REQUIRE(c, c->metric != ANNCHOR_METRIC_NONE, ANNCHOR_EINVAL, "no device metric bound to this context");
+    ANN_REQUIRE(c, nbins >= 1 && nbins <= MAXBINS, ANNCHOR_ELIMIT, "at most %d partitions", MAXBINS);
+    if (c->device < 0 || c->device >= 16 || getenv("ANNCHOR_DRAW_TRACE_HOST")) return ANNCHOR_OK;
+    TraceBins tb;
+    memset(&tb, 0, sizeof tb);
+    tb.nbins = nbins;
+    int64_t nreq = 0, total = 0, jwords = 0, kmax = 0;
+    for (int b = 0; b < nbins; ++b) {
+        if (counts[b] < 0 || want[b] < 0 || counts[b] >= (1ll << 31)) return ANNCHOR_OK;
+        tb.c[b] = counts[b];
+        tb.k[b] = std::min(counts[b], want[b]);
+        tb.base[b] = total;
+        tb.offs[b] = nreq;
+        tb.step0[b] = 0;
+        const bool shuffled = counts[b] >= want[b] && counts[b] >= 2;
+        tb.joff[b] = shuffled ? jwords : -1;
+        if (shuffled) jwords += counts[b] + 32;
+        kmax = std::max(kmax, tb.k[b]);
+        nreq += tb.k[b];
+        total += counts[b];
+    }
+    if (kmax > TR_KMAX) return ANNCHOR_OK;
+    {
+        int64_t s = 0;
+        for (int b = 0; b < nbins; ++b) { tb.step0[b] = s; if (tb.joff[b] >= 0) s += tb.c[b] - tb.k[b]; }
+        tb.step0[nbins] = s;
+    }
+    c->nsamp = nreq;
+    *n_out = nreq;
+    *taken = 1;
+    if (nreq == 0) return ANNCHOR_OK;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    BinEdges be;
+    ANN_TRY(load_bins(c, bins, nbins, be));
+    const int64_t n = c->n;
+    const int nblocks = ann_blocks(n, RB_TILE);
+    ANN_TRY(ann_reserve(c, c->blk_cnt, sizeof(uint32_t) * (size_t)nblocks * nbins));
+    ANN_TRY(ann_reserve(c, c->tmp0, sizeof(int32_t) * (size_t)(total + 1)));  // slotmap
+    ANN_TRY(ann_reserve(c, c->stage_out, sizeof(int64_t) * (size_t)nreq));
+    ANN_TRY(ann_reserve(c, c->stage_in, sizeof(int64_t) * (size_t)(nbins + 1) + 64));
+    ANN_TRY(ann_reserve(c, c->spos, sizeof(int32_t) * (size_t)nreq + 16));
+    ANN_TRY(ann_reserve(c, c->sy, sizeof(double) * (size_t)nreq));
+    ANN_TRY(ann_reserve(c, c->sfeat, sizeof(double) * 4 * (size_t)nreq));
+    ANN_TRY(ann_reserve(c, c->draw_J, sizeof(uint32_t) * (size_t)std::max<int64_t>(jwords, 1)));
+    ANN_TRY(ann_reserve(c, c->draw_next, sizeof(uint32_t) * (size_t)std::max<int64_t>(jwords, 1)));
+    ANN_TRY(ann_reserve(c, c->draw_q1, sizeof(uint32_t) * (size_t)std::max<int64_t>(nreq, 1)));
+    ANN_TRY(ann_dev_flags(c));
+    int32_t *bad = c->spos.as<int32_t>() + nreq;
+    int64_t *d_base = c->stage_in.as<int64_t>();
+    {
+        std::vector<int64_t> base((size_t)nbins + 1);
+        for (int b = 0; b < nbins; ++b) base[(size_t)b] = tb.base[b];
+        base[(size_t)nbins] = total;
+        ANN_TRY(ann_h2d(c, d_base, base.data(), sizeof(int64_t) * (size_t)(nbins + 1)));
+    }
+    // queued at once, ahead of the host's scan: the two fills
+    ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp0.p, 0xff, sizeof(int32_t) * (size_t)(total + 1), c->stream));
+    if (jwords) ANN_CHECK_HIP(c, hipMemsetAsync(c->draw_next.p, 0xff, sizeof(uint32_t) * (size_t)jwords, c->stream));
+    {
+        // ---- the host's half: scan into pinned memory, every bin's partners uploaded on the side stream as soon as they are complete
+        std::lock_guard<std::mutex> lk(g_draw_mu);
+        hipStream_t &copy = g_draw_copy_stream[c->device];
+        hipEvent_t &ev = g_draw_copy_event[c->device];
+        if (!copy) {
+            ANN_CHECK_HIP(c, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+            ANN_CHECK_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        } else {
+            ANN_CHECK_HIP(c, hipEventSynchronize(ev));   // (the previous draw's uploads have left the pinned buffer)
+        }
+        if (g_draw_pin_words < (size_t)jwords) {
+            if (g_draw_pin) (void)hipHostFree(g_draw_pin);
+            g_draw_pin = nullptr;
+            g_draw_pin_words = 0;
+            const size_t words = (size_t)jwords + (size_t)jwords / 4 + 4096;
+            ANN_CHECK_HIP(c, hipHostMalloc((void **)&g_draw_pin, sizeof(uint32_t) * words, hipHostMallocDefault));
+            g_draw_pin_words = words;
+        }
+        DrawUpload up{c, copy, c->draw_J.as<uint32_t>(), counts, tb.joff, ANNCHOR_OK};
+        ANN_TRY(ann_legacy_scan(seed, counts, want, nbins, g_draw_pin, tb.joff, draw_after_bin, &up));
+        ANN_REQUIRE(c, up.rc == ANNCHOR_OK, ANNCHOR_EHIP, "upload of the draw's partners failed");
+        ANN_CHECK_HIP(c, hipEventRecord(ev, copy));
+        ANN_CHECK_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));
+    }
+    {
+        ProfScope ps(c, "sampler_draw_trace", (double)jwords * 8.0);
+        ANN_TRY(trace_launch(c, tb, kmax, nreq, bad));
+    }
+    {
+        ProfScope ps(c, "sampler_select_by_rank", (double)n * 18.0);
+        k_rb_count<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be, c->blk_cnt.as<uint32_t>());
+        k_rb_scan<<<nbins, 256, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nblocks, nbins);
+        k_rb_emit<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be, c->blk_cnt.as<uint32_t>(), d_base,
+                                                        c->tmp0.as<int32_t>(), c->stage_out.as<int64_t>());
+    }
+    k_pos_gather<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->stage_out.as<int64_t>(), nreq, c->spos.as<int32_t>(), bad,
+                                                              c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>(),
+                                                              c->anc.as<uint8_t>(), c->sfeat.as<double>());
+    PairSource src;
+    src.ij = c->ij.as<int2>();
+    src.idx = c->spos.as<int32_t>();
+    src.n = nreq;
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    ANN_TRY(ann_metric_launch(c, src, c->sy.as<double>(), nullptr, nullptr));
+    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+    c->call_timed = true;
+    k_clear_flags_sticky<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), nreq, c->ncm.as<uint8_t>(), bad,
+                                                                      c->dev_flags.as<int32_t>());
+    ANN_CHECK_HIP(c, hipGetLastError());
+    if (c->n_unc >= 0) c->n_unc -= nreq;
+    c->sel_prepared = false;
+    return ANNCHOR_OK;
+}
+
+// The draw's ranks alone through the device trace (tests: against annchor_legacy_choice_ranks): ranks_out[offs_b + p] for every
+// bin, bin by bin, in slot order.  Needs a context (device, stream), no data set.
+extern "C" int annchor_legacy_choice_ranks_device(annchor_ctx *c, uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins,
+                                                  int64_t *ranks_out, int32_t *taken)
+{
+    if (!c || !counts || !want || !ranks_out || !taken) return ANNCHOR_EINVAL;
+    *taken = 0;
+    ANN_REQUIRE(c, nbins >= 1 && nbins <= MAXBINS, ANNCHOR_ELIMIT, "at most %d partitions", MAXBINS);
+    if (c->device < 0 || c->device >= 16) return ANNCHOR_OK;
+    TraceBins tb;
+    memset(&tb, 0, sizeof tb);
+    tb.nbins = nbins;
+    int64_t nreq = 0, total = 0, jwords = 0, kmax = 0;
+    for (int b = 0; b < nbins; ++b) {
+        if (counts[b] < 0 || want[b] < 0 || counts[b] >= (1ll << 31)) return ANNCHOR_OK;
+        tb.c[b] = counts[b]; tb.k[b] = std::min(counts[b], want[b]); tb.base[b] = total; tb.offs[b] = nreq;
+        const bool shuffled = counts[b] >= want[b] && counts[b] >= 2;
+        tb.joff[b] = shuffled ? jwords : -1;
+        if (shuffled) jwords += counts[b] + 32;
+        kmax = std::max(kmax, tb.k[b]); nreq += tb.k[b]; total += counts[b];
+    }
+    if (kmax > TR_KMAX) return ANNCHOR_OK;
+    { int64_t s = 0; for (int b = 0; b < nbins; ++b) { tb.step0[b] = s; if (tb.joff[b] >= 0) s += tb.c[b] - tb.k[b]; } tb.step0[nbins] = s; }
+    *taken = 1;
+    if (nreq == 0) return ANNCHOR_OK;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(ann_reserve(c, c->tmp0, sizeof(int32_t) * (size_t)(total + 1)));
+    ANN_TRY(ann_reserve(c, c->stage_out, sizeof(int64_t) * (size_t)nreq));
+    ANN_TRY(ann_reserve(c, c->draw_J, sizeof(uint32_t) * (size_t)std::max<int64_t>(jwords, 1)));
+    ANN_TRY(ann_reserve(c, c->draw_next, sizeof(uint32_t) * (size_t)std::max<int64_t>(jwords, 1)));
+    ANN_TRY(ann_reserve(c, c->draw_q1, sizeof(uint32_t) * (size_t)std::max<int64_t>(nreq, 1)));
+    ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp0.p, 0xff, sizeof(int32_t) * (size_t)(total + 1), c->stream));
+    if (jwords) ANN_CHECK_HIP(c, hipMemsetAsync(c->draw_next.p, 0xff, sizeof(uint32_t) * (size_t)jwords, c->stream));
+    {
+        std::lock_guard<std::mutex> lk(g_draw_mu);
+        hipStream_t &copy = g_draw_copy_stream[c->device];
+        hipEvent_t &ev = g_draw_copy_event[c->device];
+        if (!copy) {
+            ANN_CHECK_HIP(c, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+            ANN_CHECK_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        } else {
+            ANN_CHECK_HIP(c, hipEventSynchronize(ev));
+        }
+        if (g_draw_pin_words < (size_t)jwords) {
+            if (g_draw_pin) (void)hipHostFree(g_draw_pin);
+            g_draw_pin = nullptr; g_draw_pin_words = 0;
+            const size_t words = (size_t)jwords + (size_t)jwords / 4 + 4096;
+            ANN_CHECK_HIP(c, hipHostMalloc((void **)&g_draw_pin, sizeof(uint32_t) * words, hipHostMallocDefault));
+            g_draw_pin_words = words;
+        }
+        DrawUpload up{c, copy, c->draw_J.as<uint32_t>(), counts, tb.joff, ANNCHOR_OK};
+        ANN_TRY(ann_legacy_scan(seed, counts, want, nbins, g_draw_pin, tb.joff, draw_after_bin, &up));
+        ANN_REQUIRE(c, up.rc == ANNCHOR_OK, ANNCHOR_EHIP, "upload of the draw's partners failed");
+        ANN_CHECK_HIP(c, hipEventRecord(ev, copy));
+        ANN_CHECK_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));
+    }
+    ANN_TRY(trace_launch(c, tb, kmax, nreq, nullptr));
+    ANN_CHECK_HIP(c, hipGetLastError());
+    // ranks from the slot map: slotmap[base_b + rank] = request index
+    std::vector<int32_t> sm((size_t)total + 1);
+    ANN_TRY(ann_d2h(c, sm.data(), c->tmp0.p, sizeof(int32_t) * (size_t)(total + 1)));
+    for (int b = 0; b < nbins; ++b)
+        for (int64_t r = 0; r < tb.c[b]; ++r) {
+            const int32_t t = sm[(size_t)(tb.base[b] + r)];
+            if (t >= 0) ranks_out[t] = r;
+        }
     return ANNCHOR_OK;
 }
 

@@ -662,6 +662,39 @@ int ann_legacy_generate_upto(uint32_t seed, int64_t ndraws, int64_t upto)
     return ANNCHOR_OK;
 }
 
+// The forward half of the draw alone, for the device-side trace (csrc/drawtrace.hip): the swap partners of every bin that is
+// shuffled (counts[b] >= want[b]) in stream order into J + joff[b] (counts[b] words, 32 words of slack behind them); after_bin is
+// called as soon as a bin's partners are complete -- the caller queues their upload while the scan moves on.  Same stream, same
+// draws as annchor_legacy_choice_ranks.
+int ann_legacy_scan(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins, uint32_t *J, const int64_t *joff,
+                    void (*after_bin)(int, void *), void *user)
+{
+    std::shared_ptr<Stream> st;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_streams.find(seed);
+        if (it != g_streams.end()) { st = it->second; g_streams.erase(it); }
+        else st = cache_take(seed);
+    }
+    if (!st) {
+        st = std::make_shared<Stream>();
+        int64_t tot = 0;
+        for (int b = 0; b < nbins; ++b) tot += counts[b] >= want[b] ? counts[b] : 0;
+        st->start(seed, (size_t)(tot + tot / 2 + 1024), false);
+    }
+    std::lock_guard<std::mutex> call_lk(g_call_mu);
+    Scan S{st.get(), 0};
+    for (int b = 0; b < nbins; ++b) {
+        if (counts[b] < want[b] || counts[b] < 2) continue;   // utils.py:553-554: the whole bin, no draw (one element: nothing to draw)
+        if (use_avx512()) scan_bin_avx512<true>(S, counts[b], J + joff[b]);
+        else scan_bin_scalar<true>(S, counts[b], J + joff[b]);
+        if (after_bin) after_bin(b, user);
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    cache_put(seed, st);
+    return ANNCHOR_OK;
+}
+
 extern "C" int annchor_legacy_choice_ranks(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins,
                                            int64_t *ranks_out, int64_t *n_out)
 {

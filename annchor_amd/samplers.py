@@ -18,6 +18,7 @@ import numpy as np
 
 
 _WORKER_ALWAYS = os.environ.get("ANNCHOR_DRAW_WORKER_ALWAYS", "0") == "1"
+_TRACE_ON_HOST = os.environ.get("ANNCHOR_DRAW_TRACE", "device") == "host"   # the draw's backward trace on helper threads, as before round 4
 
 
 class NothingToSample(Exception):
@@ -129,7 +130,7 @@ class SimpleStratifiedSampler(Sampler):
         """Same result as sample(), computed against the device-resident state."""
         return self.finish_device(self.begin_device(engine, n_samples, random_seed, overlap=False))
 
-    def begin_device(self, engine, n_samples, random_seed, overlap=True):
+    def begin_device(self, engine, n_samples, random_seed, overlap=True, device_trace=False):
         """First half of sample_device: the statistics the draw depends on (number of
         not-computed pairs, dad quantiles, bin counts -- functions of not_computed_mask and dad
         only), then the draw itself.  Annchor.fit() calls this as soon as the refinement candidates
@@ -160,6 +161,11 @@ class SimpleStratifiedSampler(Sampler):
                 np.random.seed(seed)
                 ticket["per_bin"] = [np.arange(c) if c < w else np.random.permutation(int(c))[:w]
                                      for c, w in zip(counts, want)]
+            elif device_trace and hasattr(engine, "sample_pairs_device_draw") and not _TRACE_ON_HOST:
+                # fit() with the models on the device: finish_device makes the draw and the sampling step one library call -- the
+                # host walks the stream, the backward trace runs on the GPU (annchor_sample_pairs_device_draw)
+                ticket["deferred"] = (seed, counts, want)
+                ticket["device_trace"] = True
             elif overlap == "defer" and not _WORKER_ALWAYS:
                 # the caller still has device work to enqueue (refinement, update_bounds): the draw runs in finish_device, on the
                 # calling thread's warm core, while that work executes
@@ -184,6 +190,19 @@ class SimpleStratifiedSampler(Sampler):
             except BaseException as err:  # noqa: BLE001
                 if ticket["error"] is None:
                     ticket["error"] = err
+        if (ticket["error"] is None and evaluate == "device" and ticket.get("device_trace") and ticket.get("deferred") is not None):
+            seed, counts, want = ticket["deferred"]
+            engine, n_samples, sample_bins = ticket["engine"], ticket["n_samples"], ticket["sample_bins"]
+            if int(np.minimum(counts, want).min()) < 2:
+                self.loop_num += 1
+                raise Exception("Some sampler bins contain too few samples")
+            taken, m = engine.sample_pairs_device_draw(sample_bins, counts, want, seed)
+            if taken:
+                ticket.pop("deferred")
+                self.loop_num += 1
+                if n_samples != m:
+                    print("Warning: Some bins contained fewer samples than requested")
+                return None, m, sample_bins
         if ticket["error"] is None and ticket.get("deferred") is not None:
             from . import _native
 
@@ -266,7 +285,7 @@ class DeviceStratifiedSampler(SimpleStratifiedSampler):
             raise Exception("Some sampler bins contain too few samples")
         return np.concatenate(picked)
 
-    def begin_device(self, engine, n_samples, random_seed, overlap=True):
+    def begin_device(self, engine, n_samples, random_seed, overlap=True, device_trace=False):   # (device_trace: the legacy sampler's switch)
         ticket = {"engine": engine, "error": None}
         try:
             if self.partition_feature_name != "double anchor distance":

@@ -251,6 +251,16 @@ int annchor_sample_pairs_device(annchor_ctx *ctx, const double *bins, int32_t nb
  * annchor_model_download).  *n_out = sum over the partitions of min(want, counts). */
 int annchor_hash_sample_pairs_device(annchor_ctx *ctx, const double *bins, int32_t nbins, const int64_t *counts, const int64_t *want,
                                      uint64_t seed_key, int64_t *n_out);
+/* The built-in sampling step with the LEGACY draw (SimpleStratifiedSampler: NumPy's stream, utils.py:543-578) in one call, the
+ * draw's backward trace on the device: the host walks the stream (the rejection scan), every bin's swap partners are uploaded on a
+ * side stream as they complete, three kernels undo the swaps for the kept entries and write the chosen ranks into the slot map
+ * the rank -> position kernels read.  Same samples, same order as annchor_legacy_choice_ranks + annchor_sample_pairs_device.
+ * *taken = 0: not applicable here (a partition keeps more than 8192 entries): draw on the host.  The second form returns
+ * the ranks alone (tests). */
+int annchor_sample_pairs_device_draw(annchor_ctx *ctx, const double *bins, int32_t nbins, const int64_t *counts, const int64_t *want,
+                                     uint32_t seed, int64_t *n_out, int32_t *taken);
+int annchor_legacy_choice_ranks_device(annchor_ctx *ctx, uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins,
+                                       int64_t *ranks_out, int32_t *taken);
 int annchor_download_samples(annchor_ctx *ctx, int64_t *positions, double *feats, double *sample_y, double *sample_predict);
 int annchor_fit_regression_device(annchor_ctx *ctx, const double *bins, int32_t nbins, int32_t first_iteration, int32_t is_metric);
 int annchor_fit_errors_device(annchor_ctx *ctx);

@@ -374,3 +374,34 @@ def test_default_sampler_by_size(capsys):
     assert err <= 0.01 * 15 * len(rows), err
     assert dt < 0.1, dt   # (193 ms with the host-side shuffle; ~28 ms with the GPU draw)
     a._engine.close(); b._engine.close()
+
+
+def test_legacy_draw_trace_on_device_equals_host():
+    """The legacy sampler's draw with its backward trace on the GPU (annchor_legacy_choice_ranks_device: host rejection scan,
+    partners uploaded per bin, next[] by atomicMin, chains) against the host trace (annchor_legacy_choice_ranks, itself pinned to
+    NumPy's np.random.seed / permutation in the CPU tests): same ranks in the same order, over random populations -- bins that
+    are taken whole, that hold exactly the quota, of 0 / 1 / 2 members, one large bin among small ones, quotas of 1."""
+    from annchor_amd import _native
+
+    rng = np.random.default_rng(123)
+    eng = _native.Engine(0)
+    cases = [([5, 0, 1, 2, 3, 700, 12], [3, 3, 3, 3, 3, 3, 3]),
+             ([1000, 40, 40000, 7, 100000], [40, 40, 40, 40, 40]),
+             ([715, 716, 714, 200000, 3], [715, 715, 715, 715, 715]),
+             ([250000, 180000], [1, 1]),
+             ([9000], [8192])]
+    for _ in range(12):
+        nb = int(rng.integers(1, 9))
+        counts = [int(rng.integers(0, 6)) if rng.random() < 0.2 else int(rng.integers(2, 10 ** rng.integers(1, 6))) for _ in range(nb)]
+        want = [int(rng.integers(1, 800))] * nb
+        cases.append((counts, want))
+    for counts, want in cases:
+        for seed in (42, int(rng.integers(0, 2 ** 32))):
+            host = _native.legacy_choice_ranks(seed, counts, want)
+            dev = eng.legacy_choice_ranks_device(seed, counts, want)
+            assert dev is not None
+            assert len(host) == len(dev)
+            for b, (h, d) in enumerate(zip(host, dev)):
+                assert np.array_equal(np.asarray(h), d), (counts, want, seed, b)
+    assert eng.legacy_choice_ranks_device(1, [100000], [9000]) is None   # beyond the chain kernel's LDS: the caller draws on the host
+    eng.close()
