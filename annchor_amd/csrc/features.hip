@@ -1365,9 +1365,9 @@ extern "C" int annchor_sample_pairs_device_draw(annchor_ctx *c, const double *bi
         if (!copy) {
             ANN_CHECK_HIP(c, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
             ANN_CHECK_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        } else {
-            ANN_CHECK_HIP(c, hipEventSynchronize(ev));   // (the previous draw's uploads have left the pinned buffer)
         }
+        for (int dv = 0; dv < 16; ++dv)   // (the previous draws' uploads -- of any device -- have left the pinned buffer)
+            if (g_draw_copy_event[dv]) ANN_CHECK_HIP(c, hipEventSynchronize(g_draw_copy_event[dv]));
         if (g_draw_pin_words < (size_t)jwords) {
             if (g_draw_pin) (void)hipHostFree(g_draw_pin);
             g_draw_pin = nullptr;
@@ -1452,9 +1452,9 @@ extern "C" int annchor_legacy_choice_ranks_device(annchor_ctx *c, uint32_t seed,
         if (!copy) {
             ANN_CHECK_HIP(c, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
             ANN_CHECK_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        } else {
-            ANN_CHECK_HIP(c, hipEventSynchronize(ev));
         }
+        for (int dv = 0; dv < 16; ++dv)
+            if (g_draw_copy_event[dv]) ANN_CHECK_HIP(c, hipEventSynchronize(g_draw_copy_event[dv]));
         if (g_draw_pin_words < (size_t)jwords) {
             if (g_draw_pin) (void)hipHostFree(g_draw_pin);
             g_draw_pin = nullptr; g_draw_pin_words = 0;
