@@ -1358,6 +1358,13 @@ extern "C" int annchor_sample_pairs_device_draw(annchor_ctx *c, const double *bi
     ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp0.p, 0xff, sizeof(int32_t) * (size_t)(total + 1), c->stream));
     if (jwords) ANN_CHECK_HIP(c, hipMemsetAsync(c->draw_next.p, 0xff, sizeof(uint32_t) * (size_t)jwords, c->stream));
     {
+        // ... and the half of the rank -> position conversion that does not need the ranks (per-tile counts of every partition
+        // and their scan): it runs while the host walks the stream
+        ProfScope ps(c, "sampler_select_by_rank", (double)n * 9.0);
+        k_rb_count<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be, c->blk_cnt.as<uint32_t>());
+        k_rb_scan<<<nbins, 256, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nblocks, nbins);
+    }
+    {
         // ---- the host's half: scan into pinned memory, every bin's partners uploaded on the side stream as soon as they are complete
         std::lock_guard<std::mutex> lk(g_draw_mu);
         hipStream_t &copy = g_draw_copy_stream[c->device];
@@ -1387,9 +1394,7 @@ extern "C" int annchor_sample_pairs_device_draw(annchor_ctx *c, const double *bi
         ANN_TRY(trace_launch(c, tb, kmax, nreq, bad));
     }
     {
-        ProfScope ps(c, "sampler_select_by_rank", (double)n * 18.0);
-        k_rb_count<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be, c->blk_cnt.as<uint32_t>());
-        k_rb_scan<<<nbins, 256, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nblocks, nbins);
+        ProfScope ps(c, "sampler_select_by_rank", (double)n * 9.0);
         k_rb_emit<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be, c->blk_cnt.as<uint32_t>(), d_base,
                                                         c->tmp0.as<int32_t>(), c->stage_out.as<int64_t>());
     }
