@@ -7,6 +7,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
 
 #include "../../include/annchor_hip.h"
 
@@ -356,8 +357,12 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
 // every round of the max-min picker in ONE launch (lev.hip, k_lev_ap); *done = false: not taken, the caller runs the rounds one by one
 int ann_lev_anchor_rounds(annchor_ctx *c, int32_t na, int32_t first, bool *done);
 int ann_legacy_generate_upto(uint32_t seed, int64_t ndraws, int64_t upto);   // hostrng.hip
+static inline long long ann_now_ns()
+{
+    return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 int ann_legacy_scan(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins, uint32_t *J, const int64_t *joff,
-                    void (*after_bin)(int, void *), void *user);   // hostrng.hip
+                    void (*after_bin)(int, void *), void *user, unsigned long long *progress = nullptr);   // hostrng.hip
 // model.hip: the device-fitted model, its flags and residual lists copied (async) to pinned memory at `at` (room bytes; *used = 0:
 // nothing to fetch / no room) and, after the caller's wait, kept in the context for annchor_model_download_with_errors
 int ann_model_prefetch_begin(annchor_ctx *c, unsigned char *at, size_t room, size_t *used);

@@ -203,13 +203,18 @@ int ann_h2d(annchor_ctx *c, void *dst, const void *src, size_t bytes)
 hipError_t ann_sync(annchor_ctx *c, const char *where)
 {
     static const bool trace = getenv("ANNCHOR_SYNC_TRACE") != nullptr;
+    static const bool timing = getenv("ANNCHOR_SYNC_TIMING") != nullptr;   // monotonic-clock stamps of every wait (tools/host_timeline.py)
     if (trace) fprintf(stderr, "sync %s\n", where);
+    const long long t_in = timing ? ann_now_ns() : 0;
     if (c->idle_gen_n > c->idle_gen_done) {
         // host work parked for exactly this moment: the stream has just been given work and the caller is about to wait for it
         c->idle_gen_done = std::min(c->idle_gen_n, c->idle_gen_done + c->idle_gen_chunk);
         (void)ann_legacy_generate_upto(c->idle_gen_seed, c->idle_gen_n, c->idle_gen_done);
     }
-    return hipStreamSynchronize(c->stream);
+    const long long t_w = timing ? ann_now_ns() : 0;
+    const hipError_t rc = hipStreamSynchronize(c->stream);
+    if (timing) fprintf(stderr, "T wait %s %lld %lld %lld\n", where, t_in, t_w, ann_now_ns());
+    return rc;
 }
 
 // The legacy sampler's MT19937 stream of `seed` (it depends on the seed only) produced on the calling thread at this context's NEXT
@@ -276,8 +281,11 @@ int ann_d2h2_then(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, v
     ANN_CHECK_HIP(c, hipEventRecord(c->dl_ev, c->stream));
     const int rc = then(c);
     static const bool trace = getenv("ANNCHOR_SYNC_TRACE") != nullptr;
+    static const bool timing = getenv("ANNCHOR_SYNC_TIMING") != nullptr;
     if (trace) fprintf(stderr, "sync %s\n", __func__);
+    const long long t_w = timing ? ann_now_ns() : 0;
     ANN_CHECK_HIP(c, hipEventSynchronize(c->dl_ev));
+    if (timing) fprintf(stderr, "T wait %s %lld %lld %lld\n", __func__, t_w, t_w, ann_now_ns());
     memcpy(dst1, slot, bytes1);
     memcpy(dst2, slot + off2, bytes2);
     return rc;

@@ -803,15 +803,18 @@ __global__ __launch_bounds__(256) void k_rb_scan(uint32_t *__restrict__ blkcnt, 
 // four waves owns 512 consecutive ones (eight coalesced 64-wide chunks, all loaded up front),
 // counts its bins into LDS so that every wave knows where its ranks start, then ranks its own
 // elements with ballots (position order inside a chunk = lane order).
+struct RbBase { int64_t v[MAXBINS]; };   // the partitions' offsets in the slot map by value (binbase == nullptr): no upload in front of the launch
 __global__ __launch_bounds__(RB_THREADS) void k_rb_emit(const double *__restrict__ dad, const uint8_t *__restrict__ ncm, int64_t n,
                                                        BinEdges be, const uint32_t *__restrict__ blkoff,
-                                                       const int64_t *__restrict__ binbase, const int32_t *__restrict__ slotmap,
+                                                       const int64_t *__restrict__ binbase, RbBase rb, const int32_t *__restrict__ slotmap,
                                                        int64_t *__restrict__ positions)
 {
     constexpr int CH = RB_TILE / RB_THREADS;   // chunks of 64 per wave
     __shared__ uint32_t wcnt[RB_THREADS / 64][MAXBINS];
+    __shared__ int64_t sbase[MAXBINS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int t = threadIdx.x; t < (RB_THREADS / 64) * MAXBINS; t += RB_THREADS) (&wcnt[0][0])[t] = 0;
+    if ((int)threadIdx.x < be.nb) sbase[threadIdx.x] = binbase ? binbase[threadIdx.x] : rb.v[threadIdx.x];
     __syncthreads();
     const int64_t wbase = (int64_t)blockIdx.x * RB_TILE + (int64_t)wave * (CH * 64);
     int b[CH];
@@ -847,7 +850,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_emit(const double *__restrict
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch)
         if (b[ch] >= 0) {
-            const int32_t slot = slotmap[binbase[b[ch]] + rank[ch]];
+            const int32_t slot = slotmap[sbase[b[ch]] + rank[ch]];
             if (slot >= 0) positions[slot] = wbase + ch * 64 + lane;
         }
 }
@@ -913,7 +916,7 @@ static int select_by_rank_device(annchor_ctx *c, const double *bins, int32_t nbi
                                                          c->blk_cnt.as<uint32_t>());
         k_rb_scan<<<nbins, 256, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nblocks, nbins);
         k_rb_emit<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be, c->blk_cnt.as<uint32_t>(),
-                                                d_base, c->tmp0.as<int32_t>(), c->stage_out.as<int64_t>());
+                                                d_base, RbBase(), c->tmp0.as<int32_t>(), c->stage_out.as<int64_t>());
     }
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
@@ -1020,15 +1023,20 @@ extern "C" int annchor_evaluate_samples(annchor_ctx *c, const int64_t *pos, int6
 }
 
 // k_pos_to_i32 + k_gather_features in one launch (the device-resident sampling step)
+// CLEAR: the samples also leave the not-computed mask and a missing entry raises the sticky flag at once (what k_clear_flags_sticky
+// does behind the metric launch: the metric kernels do not read the mask)
+template <bool CLEAR = false>
 __global__ void k_pos_gather(const int64_t *__restrict__ pos, int64_t m, int32_t *__restrict__ out, int32_t *__restrict__ bad,
                              const double *__restrict__ lb, const double *__restrict__ ub, const double *__restrict__ dad,
-                             const uint8_t *__restrict__ anc, double *__restrict__ feats)
+                             const uint8_t *__restrict__ anc, double *__restrict__ feats, uint8_t *__restrict__ ncm = nullptr,
+                             int32_t *__restrict__ flags = nullptr)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     const int64_t p64 = pos[t];
-    if (p64 < 0) *bad = 1;   // a requested (bin, rank) entry was not found
+    if (p64 < 0) { *bad = 1; if (CLEAR) flags[0] = 1; }   // a requested (bin, rank) entry was not found
     const int32_t p = (int32_t)(p64 < 0 ? 0 : p64);
+    if (CLEAR) ncm[p] = 0;
     out[t] = p;
     feats[4 * t + 0] = lb[p];
     feats[4 * t + 1] = ub[p];
@@ -1129,7 +1137,7 @@ extern "C" int annchor_sample_pairs_device(annchor_ctx *c, const double *bins, i
     ANN_TRY(ann_dev_flags(c));
     int32_t *bad = c->spos.as<int32_t>() + nreq;
     ANN_TRY(select_by_rank_device(c, bins, nbins, counts, bin_of, ranks, nreq, bad));   // positions -> stage_out[0 .. nreq); *bad = 0
-    k_pos_gather<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->stage_out.as<int64_t>(), nreq, c->spos.as<int32_t>(), bad,
+    k_pos_gather<false><<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->stage_out.as<int64_t>(), nreq, c->spos.as<int32_t>(), bad,
                                                               c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>(),
                                                               c->anc.as<uint8_t>(), c->sfeat.as<double>());
     PairSource src;
@@ -1178,28 +1186,79 @@ struct TraceBins {
 
 // One launch, two kinds of workgroups.  Blocks [0, nbins): the first k - 1 steps of a bin (partners in LDS, every kept slot scans
 // them once, all slots in lockstep) -> the slots' positions at time k - 1 (q1).  The other blocks: next[joff + v] = min { i in [k, c) :
-// j_i == v, i != v } by one atomicMin per step (J holds the partners in stream order: J[t] belongs to i = c - 1 - t).  The two
-// halves are independent; the chase (k_tr_chase) needs both.
+// j_i == v, i != v } by one atomicMin per step (J holds the partners in stream order: J[t] belongs to i = c - 1 - t), a chunk of
+// TR_CHUNK steps at a time.  The two halves are independent; the chase (k_tr_chase) needs both.
+// STREAMED form (progress != nullptr): the launch is queued BEFORE the host walks the stream.  J is the host's pinned buffer and
+// *progress the number of partner words the host has completed so far (all shuffled bins in order, c - 1 words per bin; release
+// store every PUB_EVERY words, hostrng.hip): a workgroup waits until the words of its chunk (of its whole bin for the lockstep
+// half) are there, reads them over the fabric and goes on -- the trace finishes a few microseconds after the scan instead of a
+// last upload + 45 us of scatter later.  One thread polls (system scope), napping about a third of what the host still needs at
+// 8 words / ns; a wait longer than the limit raises flags[0] = 3 and lets the workgroup go (the chase terminates on any next[]:
+// its chains only ascend).
+#define TR_CHUNK 16384
+__device__ __forceinline__ bool tr_wait(const unsigned long long *progress, unsigned long long need, long long timeout_ticks,
+                                        int32_t *flags)
+{
+    const long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned long long p = __hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p >= need) return true;
+        if (wall_clock64() - t0 > timeout_ticks) {
+            if (flags) flags[0] = 3;
+            return false;
+        }
+        const int naps = (int)min((unsigned long long)((need - p) >> 14), 64ull) + 1;
+        for (int q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(32);
+    }
+}
+// partner words complete before bin b starts (joff counts 33 words of slack and header per shuffled bin on top of its c - 1)
+__device__ __forceinline__ int64_t tr_words_before(const TraceBins &tb, int b)
+{
+    int sb = 0;
+    for (int o = 0; o < b; ++o) sb += tb.joff[o] >= 0;
+    return tb.joff[b] - 33ll * sb;
+}
 __global__ __launch_bounds__(1024) void k_tr_steps(TraceBins tb, const uint32_t *__restrict__ J, uint32_t *__restrict__ next,
-                                                  uint32_t *__restrict__ q1, int scatter_blocks)
+                                                  uint32_t *__restrict__ q1, int scatter_blocks, int chunk,
+                                                  const unsigned long long *__restrict__ progress, long long timeout_ticks,
+                                                  int32_t *__restrict__ flags)
 {
     extern __shared__ uint32_t jl[];   // jl[i] = j_i for i in [1, k)
+    __shared__ int ok_s;
     if ((int)blockIdx.x >= tb.nbins) {
         const int64_t total = tb.step0[tb.nbins];
-        const int64_t stride = (int64_t)scatter_blocks * blockDim.x;
-        for (int64_t g = (int64_t)(blockIdx.x - tb.nbins) * blockDim.x + threadIdx.x; g < total; g += stride) {
-            int b = 0;
-            while (g >= tb.step0[b + 1]) ++b;
-            const int64_t t = g - tb.step0[b];            // t in [0, c - k): i = c - 1 - t >= k
-            const uint32_t i = (uint32_t)(tb.c[b] - 1 - t);
-            const uint32_t j = J[tb.joff[b] + t];
-            if (j != i) atomicMin(&next[tb.joff[b] + j], i);
+        for (int64_t g0 = (int64_t)(blockIdx.x - tb.nbins) * chunk; g0 < total; g0 += (int64_t)scatter_blocks * chunk) {
+            const int64_t g1 = min(g0 + (int64_t)chunk, total);
+            if (progress) {
+                if (threadIdx.x == 0) {
+                    int b = 0;
+                    while (g1 - 1 >= tb.step0[b + 1]) ++b;
+                    ok_s = tr_wait(progress, (unsigned long long)(tr_words_before(tb, b) + (g1 - 1 - tb.step0[b]) + 1), timeout_ticks, flags);
+                }
+                __syncthreads();
+                const bool ok = ok_s != 0;
+                __syncthreads();
+                if (!ok) return;
+            }
+            for (int64_t g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
+                int b = 0;
+                while (g >= tb.step0[b + 1]) ++b;
+                const int64_t t = g - tb.step0[b];            // t in [0, c - k): i = c - 1 - t >= k
+                const uint32_t i = (uint32_t)(tb.c[b] - 1 - t);
+                const uint32_t j = J[tb.joff[b] + t];
+                if (j != i) atomicMin(&next[tb.joff[b] + j], i);
+            }
         }
         return;
     }
     const int b = blockIdx.x;
     const int64_t c = tb.c[b], k = tb.k[b];
     const bool shuffled = tb.joff[b] >= 0;
+    if (progress && shuffled) {
+        if (threadIdx.x == 0) ok_s = tr_wait(progress, (unsigned long long)(tr_words_before(tb, b) + c - 1), timeout_ticks, flags);
+        __syncthreads();
+        if (!ok_s) return;
+    }
     if (shuffled)
         for (int64_t i = 1 + threadIdx.x; i < k; i += blockDim.x) jl[i] = J[tb.joff[b] + (c - 1 - i)];
     __syncthreads();
@@ -1253,27 +1312,10 @@ __global__ __launch_bounds__(256) void k_tr_chase(TraceBins tb, const uint32_t *
 
 static hipStream_t g_draw_copy_stream[16] = {};
 static hipEvent_t g_draw_copy_event[16] = {};
-static uint32_t *g_draw_pin = nullptr;
+static uint32_t *g_draw_pin = nullptr;     // [0, TR_PIN_HEAD): the scan's progress word; the partners behind it
 static size_t g_draw_pin_words = 0;
 static std::mutex g_draw_mu;
-
-// the two trace launches: q1 (positions after the first k - 1 steps) sits behind next[] in draw_next
-static int trace_launch(annchor_ctx *c, const TraceBins &tb, int64_t kmax, int64_t nreq, int32_t *bad)
-{
-    const int nbins = tb.nbins;
-    const int64_t steps = tb.step0[nbins];
-    const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(256, (kmax + 63) / 64 * 64));
-    const int scatter_blocks = steps > 0 ? (int)std::min<int64_t>(ann_blocks(steps, threads), (int64_t)c->prop.multiProcessorCount * 2) : 0;
-    const size_t lds = sizeof(uint32_t) * (size_t)(kmax + 1);
-    if (lds > 64 * 1024)
-        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_tr_steps, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    uint32_t *q1 = c->draw_q1.as<uint32_t>();
-    k_tr_steps<<<nbins + scatter_blocks, threads, lds, c->stream>>>(tb, c->draw_J.as<uint32_t>(), c->draw_next.as<uint32_t>(), q1, scatter_blocks);
-    k_tr_chase<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(tb, c->draw_next.as<uint32_t>(), q1, nreq, c->tmp0.as<int32_t>(),
-                                                           c->stage_out.as<int64_t>(), bad);
-    ANN_CHECK_HIP(c, hipGetLastError());
-    return ANNCHOR_OK;
-}
+#define TR_PIN_HEAD 64
 
 struct DrawUpload {
     annchor_ctx *c;
@@ -1286,8 +1328,130 @@ struct DrawUpload {
 static void draw_after_bin(int b, void *user)
 {
     DrawUpload *u = static_cast<DrawUpload *>(user);
-    if (hipMemcpyAsync(u->d_J + u->joff[b], g_draw_pin + u->joff[b], sizeof(uint32_t) * (size_t)u->counts[b], hipMemcpyHostToDevice, u->copy) != hipSuccess)
+    if (hipMemcpyAsync(u->d_J + u->joff[b], g_draw_pin + TR_PIN_HEAD + u->joff[b], sizeof(uint32_t) * (size_t)u->counts[b], hipMemcpyHostToDevice,
+                       u->copy) != hipSuccess)
         u->rc = ANNCHOR_EHIP;
+}
+
+static void trace_tb_fill(TraceBins &tb, int nbins, const int64_t *counts, const int64_t *want, int64_t *nreq, int64_t *total, int64_t *jwords,
+                          int64_t *kmax, bool *ok)
+{
+    memset(&tb, 0, sizeof tb);
+    tb.nbins = nbins;
+    *nreq = *total = *jwords = *kmax = 0;
+    *ok = false;
+    for (int b = 0; b < nbins; ++b) {
+        if (counts[b] < 0 || want[b] < 0 || counts[b] >= (1ll << 31)) return;
+        tb.c[b] = counts[b];
+        tb.k[b] = std::min(counts[b], want[b]);
+        tb.base[b] = *total;
+        tb.offs[b] = *nreq;
+        const bool shuffled = counts[b] >= want[b] && counts[b] >= 2;
+        tb.joff[b] = shuffled ? *jwords : -1;
+        if (shuffled) *jwords += counts[b] + 32;
+        *kmax = std::max(*kmax, tb.k[b]);
+        *nreq += tb.k[b];
+        *total += counts[b];
+    }
+    int64_t s = 0;
+    for (int b = 0; b < nbins; ++b) { tb.step0[b] = s; if (tb.joff[b] >= 0) s += tb.c[b] - tb.k[b]; }
+    tb.step0[nbins] = s;
+    *ok = *kmax <= TR_KMAX;
+}
+
+// The host's scan and the device's trace of one draw.  `queue_rest` enqueues what follows the trace on the context's stream (the
+// rank -> position kernels, the metric launch).  Streamed form (default): the trace kernel goes to the side stream FIRST and reads the
+// partners from pinned memory while the host produces them, the chase and `queue_rest` are queued behind it, and the host's scan
+// is the last thing the call does -- nothing is left to enqueue when it ends, and during a fit's second draw the trace runs beside
+// the refinement kernels instead of behind them.  ANNCHOR_DRAW_STREAM=0 (or more than 32 M partner words): partners uploaded bin by
+// bin on the side stream as each bin is scanned, the trace and `queue_rest` queued after the scan.
+// The draw buffers (next[], q1, the pinned partners) belong to one draw at a time: a caller holds valid `counts` only after the
+// previous draw's mask update has reached the host, i.e. after its trace.
+template <typename Rest>
+static int draw_scan_and_trace(annchor_ctx *c, const TraceBins &tb, uint32_t seed, const int64_t *counts, const int64_t *want, int64_t jwords,
+                               int64_t kmax, int64_t nreq, int32_t *bad, int32_t *flags, Rest queue_rest)
+{
+    const int nbins = tb.nbins;
+    const int64_t steps = tb.step0[nbins];
+    const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(256, (kmax + 63) / 64 * 64));
+    const size_t lds = sizeof(uint32_t) * (size_t)(kmax + 1);
+    if (lds > 64 * 1024)
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_tr_steps, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint32_t *q1 = c->draw_q1.as<uint32_t>();
+    std::lock_guard<std::mutex> lk(g_draw_mu);
+    hipStream_t &copy = g_draw_copy_stream[c->device];
+    hipEvent_t &ev = g_draw_copy_event[c->device];
+    if (!copy) {
+        ANN_CHECK_HIP(c, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+        ANN_CHECK_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    for (int dv = 0; dv < 16; ++dv)   // (the previous draws' readers -- of any device -- have left the pinned buffer)
+        if (g_draw_copy_event[dv]) ANN_CHECK_HIP(c, hipEventSynchronize(g_draw_copy_event[dv]));
+    if (g_draw_pin_words < (size_t)jwords + TR_PIN_HEAD) {
+        if (g_draw_pin) (void)hipHostFree(g_draw_pin);
+        g_draw_pin = nullptr;
+        g_draw_pin_words = 0;
+        const size_t words = (size_t)jwords + (size_t)jwords / 4 + 4096 + TR_PIN_HEAD;
+        ANN_CHECK_HIP(c, hipHostMalloc((void **)&g_draw_pin, sizeof(uint32_t) * words, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+        g_draw_pin_words = words;
+    }
+    unsigned long long *progress = reinterpret_cast<unsigned long long *>(g_draw_pin);
+    uint32_t *pinJ = g_draw_pin + TR_PIN_HEAD;
+    const char *e_st = getenv("ANNCHOR_DRAW_STREAM");
+    void *dev_pin = nullptr;
+    bool streamed = !(e_st && atoi(e_st) == 0) && jwords <= (32ll << 20) && jwords > 0;
+    if (streamed && hipHostGetDevicePointer(&dev_pin, g_draw_pin, 0) != hipSuccess) { (void)hipGetLastError(); streamed = false; }
+    if (streamed) {
+        const char *e_to = getenv("ANNCHOR_DRAW_STREAM_TIMEOUT_MS");
+        const long long ticks = (e_to ? atoll(e_to) : 5000ll) * 100000ll;   // wall_clock64: 100 MHz
+        __atomic_store_n(progress, 0ull, __ATOMIC_RELEASE);
+        const int scatter_blocks = steps > 0 ? (int)std::min<int64_t>((steps + TR_CHUNK - 1) / TR_CHUNK, 64) : 0;
+        ANN_CHECK_HIP(c, hipMemsetAsync(c->draw_next.p, 0xff, sizeof(uint32_t) * (size_t)jwords, copy));
+        k_tr_steps<<<nbins + scatter_blocks, threads, lds, copy>>>(tb, reinterpret_cast<const uint32_t *>(dev_pin) + TR_PIN_HEAD, c->draw_next.as<uint32_t>(), q1,
+                                                                  scatter_blocks, TR_CHUNK, reinterpret_cast<const unsigned long long *>(dev_pin), ticks, flags);
+        ANN_CHECK_HIP(c, hipGetLastError());
+        ANN_CHECK_HIP(c, hipEventRecord(ev, copy));
+        // (from here on the trace kernel is waiting for this thread: the scan cannot fail short of running out of memory.  What
+        // follows the trace is queued AFTER the scan: while the host scans the GPU has nothing else to do in a fit's first draw,
+        // and every launch in front of the scan -- ~5 us of host time each -- would only start the scan later)
+        static const bool timing = getenv("ANNCHOR_SYNC_TIMING") != nullptr;
+        const long long t_s = timing ? ann_now_ns() : 0;
+        const int rc = ann_legacy_scan(seed, counts, want, nbins, pinJ, tb.joff, nullptr, nullptr, progress);
+        if (timing) fprintf(stderr, "T scan streamed %lld %lld %lld\n", t_s, t_s, ann_now_ns());
+        if (rc != ANNCHOR_OK) { __atomic_store_n(progress, ~0ull, __ATOMIC_RELEASE); return rc; }   // let the kernel go; the call fails
+        ANN_CHECK_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));
+        k_tr_chase<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(tb, c->draw_next.as<uint32_t>(), q1, nreq, c->tmp0.as<int32_t>(),
+                                                               c->stage_out.as<int64_t>(), bad);
+        ANN_CHECK_HIP(c, hipGetLastError());
+        return queue_rest();
+    }
+    ANN_TRY(ann_reserve(c, c->draw_J, sizeof(uint32_t) * (size_t)std::max<int64_t>(jwords, 1)));
+    if (jwords) ANN_CHECK_HIP(c, hipMemsetAsync(c->draw_next.p, 0xff, sizeof(uint32_t) * (size_t)jwords, c->stream));
+    DrawUpload up{c, copy, c->draw_J.as<uint32_t>(), counts, tb.joff, ANNCHOR_OK};
+    static const bool timing = getenv("ANNCHOR_SYNC_TIMING") != nullptr;
+    const long long t_s = timing ? ann_now_ns() : 0;
+    ANN_TRY(ann_legacy_scan(seed, counts, want, nbins, pinJ, tb.joff, draw_after_bin, &up));
+    if (timing) fprintf(stderr, "T scan uploaded %lld %lld %lld\n", t_s, t_s, ann_now_ns());
+    ANN_REQUIRE(c, up.rc == ANNCHOR_OK, ANNCHOR_EHIP, "upload of the draw's partners failed");
+    ANN_CHECK_HIP(c, hipEventRecord(ev, copy));
+    ANN_CHECK_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));
+    const int scatter_blocks = steps > 0 ? (int)std::min<int64_t>(ann_blocks(steps, threads), (int64_t)c->prop.multiProcessorCount * 2) : 0;
+    k_tr_steps<<<nbins + scatter_blocks, threads, lds, c->stream>>>(tb, c->draw_J.as<uint32_t>(), c->draw_next.as<uint32_t>(), q1, scatter_blocks, threads,
+                                                                   nullptr, 0, nullptr);
+    k_tr_chase<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(tb, c->draw_next.as<uint32_t>(), q1, nreq, c->tmp0.as<int32_t>(),
+                                                           c->stage_out.as<int64_t>(), bad);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return queue_rest();
+}
+
+// fills the slot map with -1 (and, for fill2_n > 0, a second array): one launch in front of the rank -> position kernels
+__global__ __launch_bounds__(256) void k_fill_i32(int32_t *__restrict__ a, int64_t n, int32_t v)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; t < n; t += stride) {
+        if (t + 4 <= n && (reinterpret_cast<uintptr_t>(a + t) & 15) == 0) *reinterpret_cast<int4 *>(a + t) = make_int4(v, v, v, v);
+        else for (int64_t u = t; u < n && u < t + 4; ++u) a[u] = v;
+    }
 }
 
 // The built-in sampling step with the legacy draw (SimpleStratifiedSampler): annchor_legacy_choice_ranks + annchor_sample_pairs_device
@@ -1303,29 +1467,10 @@ extern "C" int annchor_sample_pairs_device_draw(annchor_ctx *c, const double *bi
     ANN_REQUIRE(c, nbins >= 1 && nbins <= MAXBINS, ANNCHOR_ELIMIT, "at most %d partitions", MAXBINS);
     if (c->device < 0 || c->device >= 16 || getenv("ANNCHOR_DRAW_TRACE_HOST")) return ANNCHOR_OK;
     TraceBins tb;
-    memset(&tb, 0, sizeof tb);
-    tb.nbins = nbins;
     int64_t nreq = 0, total = 0, jwords = 0, kmax = 0;
-    for (int b = 0; b < nbins; ++b) {
-        if (counts[b] < 0 || want[b] < 0 || counts[b] >= (1ll << 31)) return ANNCHOR_OK;
-        tb.c[b] = counts[b];
-        tb.k[b] = std::min(counts[b], want[b]);
-        tb.base[b] = total;
-        tb.offs[b] = nreq;
-        tb.step0[b] = 0;
-        const bool shuffled = counts[b] >= want[b] && counts[b] >= 2;
-        tb.joff[b] = shuffled ? jwords : -1;
-        if (shuffled) jwords += counts[b] + 32;
-        kmax = std::max(kmax, tb.k[b]);
-        nreq += tb.k[b];
-        total += counts[b];
-    }
-    if (kmax > TR_KMAX) return ANNCHOR_OK;
-    {
-        int64_t s = 0;
-        for (int b = 0; b < nbins; ++b) { tb.step0[b] = s; if (tb.joff[b] >= 0) s += tb.c[b] - tb.k[b]; }
-        tb.step0[nbins] = s;
-    }
+    bool ok = false;
+    trace_tb_fill(tb, nbins, counts, want, &nreq, &total, &jwords, &kmax, &ok);
+    if (!ok) return ANNCHOR_OK;
     c->nsamp = nreq;
     *n_out = nreq;
     *taken = 1;
@@ -1338,80 +1483,49 @@ extern "C" int annchor_sample_pairs_device_draw(annchor_ctx *c, const double *bi
     ANN_TRY(ann_reserve(c, c->blk_cnt, sizeof(uint32_t) * (size_t)nblocks * nbins));
     ANN_TRY(ann_reserve(c, c->tmp0, sizeof(int32_t) * (size_t)(total + 1)));  // slotmap
     ANN_TRY(ann_reserve(c, c->stage_out, sizeof(int64_t) * (size_t)nreq));
-    ANN_TRY(ann_reserve(c, c->stage_in, sizeof(int64_t) * (size_t)(nbins + 1) + 64));
     ANN_TRY(ann_reserve(c, c->spos, sizeof(int32_t) * (size_t)nreq + 16));
     ANN_TRY(ann_reserve(c, c->sy, sizeof(double) * (size_t)nreq));
     ANN_TRY(ann_reserve(c, c->sfeat, sizeof(double) * 4 * (size_t)nreq));
-    ANN_TRY(ann_reserve(c, c->draw_J, sizeof(uint32_t) * (size_t)std::max<int64_t>(jwords, 1)));
     ANN_TRY(ann_reserve(c, c->draw_next, sizeof(uint32_t) * (size_t)std::max<int64_t>(jwords, 1)));
     ANN_TRY(ann_reserve(c, c->draw_q1, sizeof(uint32_t) * (size_t)std::max<int64_t>(nreq, 1)));
     ANN_TRY(ann_dev_flags(c));
     int32_t *bad = c->spos.as<int32_t>() + nreq;
-    int64_t *d_base = c->stage_in.as<int64_t>();
+    RbBase rbase;
+    for (int b = 0; b < nbins; ++b) rbase.v[b] = tb.base[b];
+    // queued at once, ahead of the host's scan: the slot map's fill and the half of the rank -> position conversion that does not
+    // need the ranks (per-tile counts of every partition and their scan)
+    k_fill_i32<<<std::min(ann_blocks(total + 1, 1024), 1024), 256, 0, c->stream>>>(c->tmp0.as<int32_t>(), total + 1, -1);
     {
-        std::vector<int64_t> base((size_t)nbins + 1);
-        for (int b = 0; b < nbins; ++b) base[(size_t)b] = tb.base[b];
-        base[(size_t)nbins] = total;
-        ANN_TRY(ann_h2d(c, d_base, base.data(), sizeof(int64_t) * (size_t)(nbins + 1)));
-    }
-    // queued at once, ahead of the host's scan: the two fills
-    ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp0.p, 0xff, sizeof(int32_t) * (size_t)(total + 1), c->stream));
-    if (jwords) ANN_CHECK_HIP(c, hipMemsetAsync(c->draw_next.p, 0xff, sizeof(uint32_t) * (size_t)jwords, c->stream));
-    {
-        // ... and the half of the rank -> position conversion that does not need the ranks (per-tile counts of every partition
-        // and their scan): it runs while the host walks the stream
         ProfScope ps(c, "sampler_select_by_rank", (double)n * 9.0);
         k_rb_count<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be, c->blk_cnt.as<uint32_t>());
         k_rb_scan<<<nbins, 256, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nblocks, nbins);
     }
-    {
-        // ---- the host's half: scan into pinned memory, every bin's partners uploaded on the side stream as soon as they are complete
-        std::lock_guard<std::mutex> lk(g_draw_mu);
-        hipStream_t &copy = g_draw_copy_stream[c->device];
-        hipEvent_t &ev = g_draw_copy_event[c->device];
-        if (!copy) {
-            ANN_CHECK_HIP(c, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
-            ANN_CHECK_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    auto queue_rest = [&]() -> int {
+        {
+            ProfScope ps(c, "sampler_select_by_rank", (double)n * 9.0);
+            k_rb_emit<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be, c->blk_cnt.as<uint32_t>(), nullptr, rbase,
+                                                            c->tmp0.as<int32_t>(), c->stage_out.as<int64_t>());
         }
-        for (int dv = 0; dv < 16; ++dv)   // (the previous draws' uploads -- of any device -- have left the pinned buffer)
-            if (g_draw_copy_event[dv]) ANN_CHECK_HIP(c, hipEventSynchronize(g_draw_copy_event[dv]));
-        if (g_draw_pin_words < (size_t)jwords) {
-            if (g_draw_pin) (void)hipHostFree(g_draw_pin);
-            g_draw_pin = nullptr;
-            g_draw_pin_words = 0;
-            const size_t words = (size_t)jwords + (size_t)jwords / 4 + 4096;
-            ANN_CHECK_HIP(c, hipHostMalloc((void **)&g_draw_pin, sizeof(uint32_t) * words, hipHostMallocDefault));
-            g_draw_pin_words = words;
-        }
-        DrawUpload up{c, copy, c->draw_J.as<uint32_t>(), counts, tb.joff, ANNCHOR_OK};
-        ANN_TRY(ann_legacy_scan(seed, counts, want, nbins, g_draw_pin, tb.joff, draw_after_bin, &up));
-        ANN_REQUIRE(c, up.rc == ANNCHOR_OK, ANNCHOR_EHIP, "upload of the draw's partners failed");
-        ANN_CHECK_HIP(c, hipEventRecord(ev, copy));
-        ANN_CHECK_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));
-    }
+        // (the samples leave the not-computed mask here: the metric kernels do not read it)
+        k_pos_gather<true><<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->stage_out.as<int64_t>(), nreq, c->spos.as<int32_t>(), bad,
+                                                                        c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>(),
+                                                                        c->anc.as<uint8_t>(), c->sfeat.as<double>(), c->ncm.as<uint8_t>(),
+                                                                        c->dev_flags.as<int32_t>());
+        PairSource src;
+        src.ij = c->ij.as<int2>();
+        src.idx = c->spos.as<int32_t>();
+        src.n = nreq;
+        ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+        ANN_TRY(ann_metric_launch(c, src, c->sy.as<double>(), nullptr, nullptr));
+        ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
+        c->call_timed = true;
+        ANN_CHECK_HIP(c, hipGetLastError());
+        return ANNCHOR_OK;
+    };
     {
         ProfScope ps(c, "sampler_draw_trace", (double)jwords * 8.0);
-        ANN_TRY(trace_launch(c, tb, kmax, nreq, bad));
+        ANN_TRY(draw_scan_and_trace(c, tb, seed, counts, want, jwords, kmax, nreq, bad, c->dev_flags.as<int32_t>(), queue_rest));
     }
-    {
-        ProfScope ps(c, "sampler_select_by_rank", (double)n * 9.0);
-        k_rb_emit<<<nblocks, RB_THREADS, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), n, be, c->blk_cnt.as<uint32_t>(), d_base,
-                                                        c->tmp0.as<int32_t>(), c->stage_out.as<int64_t>());
-    }
-    k_pos_gather<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->stage_out.as<int64_t>(), nreq, c->spos.as<int32_t>(), bad,
-                                                              c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>(),
-                                                              c->anc.as<uint8_t>(), c->sfeat.as<double>());
-    PairSource src;
-    src.ij = c->ij.as<int2>();
-    src.idx = c->spos.as<int32_t>();
-    src.n = nreq;
-    ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
-    ANN_TRY(ann_metric_launch(c, src, c->sy.as<double>(), nullptr, nullptr));
-    ANN_CHECK_HIP(c, hipEventRecord(c->call_b, c->stream));
-    c->call_timed = true;
-    k_clear_flags_sticky<<<ann_blocks(nreq, 256), 256, 0, c->stream>>>(c->spos.as<int32_t>(), nreq, c->ncm.as<uint8_t>(), bad,
-                                                                      c->dev_flags.as<int32_t>());
-    ANN_CHECK_HIP(c, hipGetLastError());
     if (c->n_unc >= 0) c->n_unc -= nreq;
     c->sel_prepared = false;
     return ANNCHOR_OK;
@@ -1427,57 +1541,28 @@ extern "C" int annchor_legacy_choice_ranks_device(annchor_ctx *c, uint32_t seed,
     ANN_REQUIRE(c, nbins >= 1 && nbins <= MAXBINS, ANNCHOR_ELIMIT, "at most %d partitions", MAXBINS);
     if (c->device < 0 || c->device >= 16) return ANNCHOR_OK;
     TraceBins tb;
-    memset(&tb, 0, sizeof tb);
-    tb.nbins = nbins;
     int64_t nreq = 0, total = 0, jwords = 0, kmax = 0;
-    for (int b = 0; b < nbins; ++b) {
-        if (counts[b] < 0 || want[b] < 0 || counts[b] >= (1ll << 31)) return ANNCHOR_OK;
-        tb.c[b] = counts[b]; tb.k[b] = std::min(counts[b], want[b]); tb.base[b] = total; tb.offs[b] = nreq;
-        const bool shuffled = counts[b] >= want[b] && counts[b] >= 2;
-        tb.joff[b] = shuffled ? jwords : -1;
-        if (shuffled) jwords += counts[b] + 32;
-        kmax = std::max(kmax, tb.k[b]); nreq += tb.k[b]; total += counts[b];
-    }
-    if (kmax > TR_KMAX) return ANNCHOR_OK;
-    { int64_t s = 0; for (int b = 0; b < nbins; ++b) { tb.step0[b] = s; if (tb.joff[b] >= 0) s += tb.c[b] - tb.k[b]; } tb.step0[nbins] = s; }
+    bool ok = false;
+    trace_tb_fill(tb, nbins, counts, want, &nreq, &total, &jwords, &kmax, &ok);
+    if (!ok) return ANNCHOR_OK;
     *taken = 1;
     if (nreq == 0) return ANNCHOR_OK;
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     ANN_TRY(ann_reserve(c, c->tmp0, sizeof(int32_t) * (size_t)(total + 1)));
     ANN_TRY(ann_reserve(c, c->stage_out, sizeof(int64_t) * (size_t)nreq));
-    ANN_TRY(ann_reserve(c, c->draw_J, sizeof(uint32_t) * (size_t)std::max<int64_t>(jwords, 1)));
     ANN_TRY(ann_reserve(c, c->draw_next, sizeof(uint32_t) * (size_t)std::max<int64_t>(jwords, 1)));
     ANN_TRY(ann_reserve(c, c->draw_q1, sizeof(uint32_t) * (size_t)std::max<int64_t>(nreq, 1)));
-    ANN_CHECK_HIP(c, hipMemsetAsync(c->tmp0.p, 0xff, sizeof(int32_t) * (size_t)(total + 1), c->stream));
-    if (jwords) ANN_CHECK_HIP(c, hipMemsetAsync(c->draw_next.p, 0xff, sizeof(uint32_t) * (size_t)jwords, c->stream));
-    {
-        std::lock_guard<std::mutex> lk(g_draw_mu);
-        hipStream_t &copy = g_draw_copy_stream[c->device];
-        hipEvent_t &ev = g_draw_copy_event[c->device];
-        if (!copy) {
-            ANN_CHECK_HIP(c, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
-            ANN_CHECK_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        }
-        for (int dv = 0; dv < 16; ++dv)
-            if (g_draw_copy_event[dv]) ANN_CHECK_HIP(c, hipEventSynchronize(g_draw_copy_event[dv]));
-        if (g_draw_pin_words < (size_t)jwords) {
-            if (g_draw_pin) (void)hipHostFree(g_draw_pin);
-            g_draw_pin = nullptr; g_draw_pin_words = 0;
-            const size_t words = (size_t)jwords + (size_t)jwords / 4 + 4096;
-            ANN_CHECK_HIP(c, hipHostMalloc((void **)&g_draw_pin, sizeof(uint32_t) * words, hipHostMallocDefault));
-            g_draw_pin_words = words;
-        }
-        DrawUpload up{c, copy, c->draw_J.as<uint32_t>(), counts, tb.joff, ANNCHOR_OK};
-        ANN_TRY(ann_legacy_scan(seed, counts, want, nbins, g_draw_pin, tb.joff, draw_after_bin, &up));
-        ANN_REQUIRE(c, up.rc == ANNCHOR_OK, ANNCHOR_EHIP, "upload of the draw's partners failed");
-        ANN_CHECK_HIP(c, hipEventRecord(ev, copy));
-        ANN_CHECK_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));
-    }
-    ANN_TRY(trace_launch(c, tb, kmax, nreq, nullptr));
-    ANN_CHECK_HIP(c, hipGetLastError());
+    ANN_TRY(ann_dev_flags(c));
+    k_fill_i32<<<std::min(ann_blocks(total + 1, 1024), 1024), 256, 0, c->stream>>>(c->tmp0.as<int32_t>(), total + 1, -1);
+    ANN_TRY(draw_scan_and_trace(c, tb, seed, counts, want, jwords, kmax, nreq, nullptr, c->dev_flags.as<int32_t>(), []() -> int { return ANNCHOR_OK; }));
     // ranks from the slot map: slotmap[base_b + rank] = request index
     std::vector<int32_t> sm((size_t)total + 1);
-    ANN_TRY(ann_d2h(c, sm.data(), c->tmp0.p, sizeof(int32_t) * (size_t)(total + 1)));
+    int32_t fl[16];
+    ANN_TRY(ann_d2h2(c, sm.data(), c->tmp0.p, sizeof(int32_t) * (size_t)(total + 1), fl, c->dev_flags.p, sizeof fl));
+    if (fl[0] == 3) {
+        ANN_CHECK_HIP(c, hipMemsetAsync(c->dev_flags.p, 0, sizeof(int32_t) * 16, c->stream));
+        ANN_REQUIRE(c, false, ANNCHOR_EHIP, "draw trace: the host's partner stream did not arrive in time");
+    }
     for (int b = 0; b < nbins; ++b)
         for (int64_t r = 0; r < tb.c[b]; ++r) {
             const int32_t t = sm[(size_t)(tb.base[b] + r)];

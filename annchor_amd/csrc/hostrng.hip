@@ -364,9 +364,15 @@ void trace_prefix(BinScratch *sc, int64_t c, int64_t k, int64_t *out)
 // is accepted and one with value > i is rejected whatever the exact i is, so the W
 // masks/compares are independent of the running index; the (rare) window holding a value in
 // (i-W, i] falls through to the exact loop.
+#define PUB_EVERY 16384   // stream words between two publications of the streamed trace's progress
 struct Scan {
     Stream *st;
     size_t cur;
+    // (streamed trace: the number of partner words written so far -- all bins -- is published every PUB_EVERY words for a kernel
+    // that reads them from pinned memory while the scan moves on; nullptr otherwise)
+    unsigned long long *pub = nullptr;
+    unsigned long long pub_base = 0;
+    inline void publish(size_t t) const { if (pub) __atomic_store_n(pub, pub_base + t, __ATOMIC_RELEASE); }
     inline const uint32_t *fill(size_t *avail)
     {
         *avail = st->ready.load(std::memory_order_acquire);
@@ -387,6 +393,10 @@ template <bool STORE> void scan_bin_scalar(Scan &S, int64_t c, uint32_t *Jc)
             size_t avail;
             const uint32_t *buf = S.fill(&avail);
             size_t p = S.cur;
+            if (STORE && S.pub) {
+                S.publish(t);
+                if (avail > p + PUB_EVERY) avail = p + PUB_EVERY;
+            }
             while (p + 8 <= avail && i >= lo + 8) {
                 const uint32_t hi_t = i, lo_t = i - 8;
                 uint32_t v[8];
@@ -427,6 +437,10 @@ template <bool STORE> __attribute__((target("avx512f,avx512bw,popcnt"))) void sc
             size_t avail;
             const uint32_t *buf = S.fill(&avail);
             size_t p = S.cur;
+            if (STORE && S.pub) {   // a piece of the stream at a time: the words written are published between two pieces
+                S.publish(t);
+                if (avail > p + PUB_EVERY) avail = p + PUB_EVERY;
+            }
             // The thresholds of a 16-draw block come from the running index TWO blocks back (i2):
             // the index now is in [i2 - 32, i2] and stays within 16 of that inside the block, so a
             // draw <= i2 - 48 is accepted and one > i2 rejected whatever happened in between.  The
@@ -667,7 +681,7 @@ int ann_legacy_generate_upto(uint32_t seed, int64_t ndraws, int64_t upto)
 // called as soon as a bin's partners are complete -- the caller queues their upload while the scan moves on.  Same stream, same
 // draws as annchor_legacy_choice_ranks.
 int ann_legacy_scan(uint32_t seed, const int64_t *counts, const int64_t *want, int32_t nbins, uint32_t *J, const int64_t *joff,
-                    void (*after_bin)(int, void *), void *user)
+                    void (*after_bin)(int, void *), void *user, unsigned long long *progress)
 {
     std::shared_ptr<Stream> st;
     {
@@ -684,10 +698,13 @@ int ann_legacy_scan(uint32_t seed, const int64_t *counts, const int64_t *want, i
     }
     std::lock_guard<std::mutex> call_lk(g_call_mu);
     Scan S{st.get(), 0};
+    S.pub = progress;   // (*progress: partner words complete, counted over the shuffled bins in order -- c - 1 per bin)
     for (int b = 0; b < nbins; ++b) {
         if (counts[b] < want[b] || counts[b] < 2) continue;   // utils.py:553-554: the whole bin, no draw (one element: nothing to draw)
         if (use_avx512()) scan_bin_avx512<true>(S, counts[b], J + joff[b]);
         else scan_bin_scalar<true>(S, counts[b], J + joff[b]);
+        S.pub_base += (unsigned long long)(counts[b] - 1);
+        S.publish(0);
         if (after_bin) after_bin(b, user);
     }
     std::lock_guard<std::mutex> lk(g_mu);

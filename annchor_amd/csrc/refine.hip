@@ -883,7 +883,8 @@ extern "C" int annchor_neighbor_graph(annchor_ctx *c, int32_t nn, int64_t *ng_id
     {
         ProfScope ps(c, "row_topk_graph", (double)c->n * 2 * 13.0 + (double)cells * 16.0);
         const size_t tail = (((size_t)(nn - 1) * 12) + 15) & ~(size_t)15;
-        const int cap = rsrc.T ? 2 : row_lds_cap(c->nx, tail);
+        int cap = 2;
+        if (!rsrc.T) ANN_TRY(row_pick_cap(c, k_get_nn, c->nx, c->nx, tail, &cap));
         ANN_TRY(row_lds_prepare(c, k_get_nn, (size_t)cap * 8 + tail));
         k_get_nn<<<(int)c->nx, ROW_THREADS, (size_t)cap * 8 + tail, c->stream>>>(
             c->Iptr.as<int64_t>(), rsrc, c->ij.as<int2>(), nn, d_i, d_d, cap);

@@ -4,6 +4,8 @@
 // 8-bit radix descent on an LDS histogram (exact, tie-safe, no sort).
 #pragma once
 #include "common.h"
+#include <mutex>
+#include <vector>
 
 #define ROW_THREADS 256
 
@@ -32,6 +34,42 @@ template <typename K> static inline int row_lds_prepare(annchor_ctx *c, K kernel
 {
     if (dyn_bytes > 64 * 1024)
         ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes));
+    return ANNCHOR_OK;
+}
+
+// The LDS copy of the row serves the fallback passes only (the sampled fast path streams the row once), and it can cost a
+// launch its residency: 1600 rows of 1599 entries are 28 KB per workgroup -- five per CU, 1280 of the 1600 resident, a second
+// round of workgroups for the rest (row_kth 38 us, guarantee_nmin lists 74 us, the graph 73 us at C2).  When the launch's
+// workgroups are not all resident with the copy and more of them are without it, the copy is dropped (cap = 2: a fallback row
+// re-reads global memory, as the streamed rows of the large lists always do).  ANNCHOR_ROW_LDS_COPY=1 keeps it.
+template <typename K> static inline int row_pick_cap(annchor_ctx *c, K kernel, int64_t nblocks, int64_t max_row_len, size_t other_dyn_bytes, int *cap)
+{
+    const int full = row_lds_cap(max_row_len, other_dyn_bytes);
+    *cap = full;
+    const char *e_keep = getenv("ANNCHOR_ROW_LDS_COPY");   // (read per call: A/B runs inside one process)
+    const bool keep = e_keep && atoi(e_keep) == 1;
+    if (keep || full <= 2) return ANNCHOR_OK;
+    struct Memo { const void *k; size_t dyn; int per_cu; };
+    static std::vector<Memo> memo;
+    static std::mutex mu;
+    auto resident = [&](size_t dyn, int *out) -> int {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto &m : memo) if (m.k == (const void *)kernel && m.dyn == dyn) { *out = m.per_cu; return ANNCHOR_OK; }
+        }
+        ANN_TRY(row_lds_prepare(c, kernel, dyn));
+        int per_cu = 0;
+        ANN_CHECK_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, ROW_THREADS, dyn));
+        std::lock_guard<std::mutex> lk(mu);
+        memo.push_back({(const void *)kernel, dyn, per_cu});
+        *out = per_cu;
+        return ANNCHOR_OK;
+    };
+    int with_copy = 0, without = 0;
+    ANN_TRY(resident((size_t)full * 8 + other_dyn_bytes, &with_copy));
+    if ((int64_t)with_copy * c->prop.multiProcessorCount >= nblocks) return ANNCHOR_OK;
+    ANN_TRY(resident((size_t)2 * 8 + other_dyn_bytes, &without));
+    if (without > with_copy) *cap = 2;
     return ANNCHOR_OK;
 }
 

@@ -1152,7 +1152,8 @@ static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
     {
         // algorithmic bytes: every pair value is read from both of its rows: 2n * (8 + 4)
         ProfScope ps(c, "row_kth_threshold", (double)n * 24.0);
-        const int cap = rsrc.T ? 2 : row_lds_cap(nx, 0);   // streamed rows: no LDS copy (a rare fallback row re-reads global memory)
+        int cap = 2;   // streamed rows: no LDS copy (a rare fallback row re-reads global memory)
+        if (!rsrc.T) ANN_TRY(row_pick_cap(c, k_row_thresh, nx, nx, 0, &cap));
         ANN_TRY(row_lds_prepare(c, k_row_thresh, (size_t)cap * 8));
         k_row_thresh<<<(int)nx, ROW_THREADS, (size_t)cap * 8, c->stream>>>(c->Iptr.as<int64_t>(), rsrc, (uint32_t)n_neighbors,
                                                                          c->thresh.as<double>(), cap);
@@ -1169,7 +1170,8 @@ static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
         {
             ProfScope ps(c, "guarantee_nmin_lists", (double)n * 26.0);
             const size_t tail = (((size_t)L * 12) + 15) & ~(size_t)15;
-            const int cap = rsrc.T ? 2 : row_lds_cap(nx, tail);
+            int cap = 2;
+            if (!rsrc.T) ANN_TRY(row_pick_cap(c, k_gn_lists, nx, nx, tail, &cap));
             ANN_TRY(row_lds_prepare(c, k_gn_lists, (size_t)cap * 8 + tail));
             k_gn_lists<<<(int)nx, ROW_THREADS, (size_t)cap * 8 + tail, c->stream>>>(
                 c->Iptr.as<int64_t>(), rsrc, c->ij.as<int2>(), L,
