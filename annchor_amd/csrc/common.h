@@ -134,6 +134,8 @@ struct annchor_ctx {
     DevBuf dev_flags;      // int32 [16] sticky error flags raised by kernels, read with the selection stage's final state:
                            // [0] sample step: a (bin, rank) entry did not exist
     bool dev_flags_clean = false;
+    bool gn_err_clean = false;    // the sweep's error flag is known to be zero
+    bool state_prewarmed = false; // ann_prewarm_state carved and cleared the small zero-initialised state
     DevBuf sstats;         // SamplerStats: quantiles, bin edges and bin counts of a sampling step (annchor_sampler_stats)
     DevBuf hs_key, hs_pos, hs_misc;   // hashed stratified sampling: per-partition candidate lists, counters / outputs
     int64_t nsamp = 0;
@@ -144,7 +146,6 @@ struct annchor_ctx {
     int64_t ncand = 0, nnext = 0;
     bool cand_marked = false;      // not_computed_mask already cleared for the current candidates
     DevBuf gl_val, gl_pos, gl_cnt, gl_ncomp, marked, markcount;  // guarantee_nmin scratch
-    DevBuf gn_err;               // guarantee_nmin: int32 error flag of the sweep (read at the end of the selection stage)
     DevBuf gn_state;             // guarantee_nmin rounds: mark masks (2), out-of-list mark counts (3), change flags
     // selection stage split in two (annchor_select_prepare): thresholds + guarantee_nmin launched ahead, while the host
     // fits the error model; reset by everything that changes RefineApprox / the mask
@@ -152,7 +153,8 @@ struct annchor_ctx {
     int sel_k = 0, sel_nmin = 0;
     bool gn_pending = false;     // rounds launched, convergence not yet looked at
     int gn_round = 0, gn_L = 0;
-    DevBuf sel_hist, sel_state, blk_cnt, blk_off;                // radix select / compaction scratch
+    DevBuf sel_hist, sel_state, blk_cnt, blk_off;                // radix select / compaction scratch (sel_state: the cut state + the sweep's error flag)
+    DevBuf sel_pass_state;                                       // the byte-pass selection's own state (scan.hip)
     DevBuf tie_lists, tie_hist;                                  // scrambled positions of the pairs on the two probability cuts; their histogram
     const void *tie_hist_clean = nullptr;                        // tie_hist known to be zero at this address
     DevBuf sel2, sel_bufA, sel_bufB, sel_seg;                             // filter-then-finish selection: tables, candidates
@@ -214,15 +216,20 @@ const char *ann_set_err(annchor_ctx *c, const char *fmt, ...);
 
 int ann_reserve(annchor_ctx *c, DevBuf &b, size_t bytes);
 int ann_arena_init(annchor_ctx *c, int64_t nx);
+int ann_prewarm_state(annchor_ctx *c);   // ctx.hip
+size_t ann_sel2_table_bytes();           // scan.hip
+size_t ann_tie_hist_bytes();             // select.hip
+size_t ann_sel_state_bytes();            // select.hip
 int ann_h2d(annchor_ctx *c, void *dst, const void *src, size_t bytes);
 hipError_t ann_sync(annchor_ctx *c, const char *where);
 int ann_dev_alloc(annchor_ctx *c, void **p, size_t want, size_t *got);   // hipMalloc / hipFree through the process-wide block pool (ctx.hip)
 void ann_dev_free(annchor_ctx *c, void *p, size_t bytes);
+struct Sel2Epilogue;   // selstate.h: what the selection's finishing workgroup writes for the consumer chained behind it
 int ann_kth_async(annchor_ctx *c, const double *vals, const uint8_t *flag, int64_t n, const int64_t *ks, int nk,
-                  const unsigned long long **d_prefix, const int **d_unfinished);
+                  const unsigned long long **d_prefix, const int **d_unfinished, const Sel2Epilogue *epi = nullptr);
 void ann_kth_async_done(annchor_ctx *c);
 int ann_d2h(annchor_ctx *c, void *dst, const void *src, size_t bytes);
-int ann_d2h2_then(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, void *dst2, const void *src2, size_t bytes2, int (*then)(annchor_ctx *));
+int ann_d2h_then(annchor_ctx *c, void *dst, const void *src, size_t bytes, int (*then)(annchor_ctx *));
 int ann_d2h2(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, void *dst2, const void *src2, size_t bytes2);
 
 // profiling scopes: one entry per kernel family

@@ -178,6 +178,37 @@ int ann_arena_init(annchor_ctx *c, int64_t nx)
     return ANNCHOR_OK;
 }
 
+// The small pieces of state the kernels expect to find ZERO the first time they run (sticky flags, the selection tables, the tie
+// histogram, the classification cursors, the arrival slots of the persistent anchor launch): carved from the slab back to back
+// when the data set is bound and cleared by ONE memset there, instead of six first-use memsets inside every first fit of a
+// context (~5 us of host time each, most of them in front of a kernel the GPU is waiting for).  Without a slab (or once it is
+// full) the first-use memsets remain.
+int ann_prewarm_state(annchor_ctx *c)
+{
+    if (!c->arena || c->state_prewarmed) return ANNCHOR_OK;
+    const size_t slot_bytes = sizeof(unsigned long long) * 4 * 1024 + 64;   // lev.hip: ann_lev_anchor_rounds
+    struct Piece { DevBuf *b; size_t bytes; };
+    Piece pieces[] = {{&c->dev_flags, sizeof(int32_t) * 16}, {&c->lev_cursors, 4 * sizeof(int32_t)}, {&c->sel_state, ann_sel_state_bytes()},
+                      {&c->sel2, ann_sel2_table_bytes()},    {&c->tie_hist, ann_tie_hist_bytes()},   {&c->lev_ap, slot_bytes}};
+    size_t need = 0;
+    for (auto &q : pieces) {
+        if (q.b->p) return ANNCHOR_OK;   // (already in use: leave everything to the first-use path)
+        need += (q.bytes + 255) & ~(size_t)255;
+    }
+    if (c->arena_off + need > c->arena_size) return ANNCHOR_OK;
+    char *first = c->arena + c->arena_off;
+    for (auto &q : pieces) ANN_TRY(ann_reserve(c, *q.b, q.bytes));
+    ANN_CHECK_HIP(c, hipMemsetAsync(first, 0, need, c->stream));
+    c->dev_flags_clean = true;
+    c->lev_cursor_epoch = 0;
+    c->gn_err_clean = true;
+    c->sel2_clean = c->sel2.p;
+    c->tie_hist_clean = c->tie_hist.p;
+    c->lev_ap_epoch = 0;
+    c->state_prewarmed = true;
+    return ANNCHOR_OK;
+}
+
 int ann_h2d(annchor_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (bytes == 0) return ANNCHOR_OK;
@@ -265,19 +296,17 @@ int ann_d2h2(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, void *
     return ann_d2h(c, dst2, src2, bytes2);
 }
 
-// two small downloads the host waits for while MORE work is queued behind them: the copies go to the pinned slot, an event marks
-// their end, `then` enqueues what follows (it must not wait), the host waits for the event only
-int ann_d2h2_then(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, void *dst2, const void *src2, size_t bytes2, int (*then)(annchor_ctx *))
+// a small download the host waits for while MORE work is queued behind it: the copy goes to the pinned slot, an event marks
+// its end, `then` enqueues what follows (it must not wait), the host waits for the event only
+int ann_d2h_then(annchor_ctx *c, void *dst, const void *src, size_t bytes, int (*then)(annchor_ctx *))
 {
-    const size_t off2 = (bytes1 + 63) & ~(size_t)63;
-    if (!c->pin || off2 + bytes2 > annchor_ctx::PIN_DL_BYTES) {
-        ANN_TRY(ann_d2h2(c, dst1, src1, bytes1, dst2, src2, bytes2));
+    if (!c->pin || bytes > annchor_ctx::PIN_DL_BYTES) {
+        ANN_TRY(ann_d2h(c, dst, src, bytes));
         return then(c);
     }
     if (!c->dl_ev) ANN_CHECK_HIP(c, hipEventCreate(&c->dl_ev));
     unsigned char *slot = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES;
-    ANN_CHECK_HIP(c, hipMemcpyAsync(slot, src1, bytes1, hipMemcpyDeviceToHost, c->stream));
-    ANN_CHECK_HIP(c, hipMemcpyAsync(slot + off2, src2, bytes2, hipMemcpyDeviceToHost, c->stream));
+    ANN_CHECK_HIP(c, hipMemcpyAsync(slot, src, bytes, hipMemcpyDeviceToHost, c->stream));
     ANN_CHECK_HIP(c, hipEventRecord(c->dl_ev, c->stream));
     const int rc = then(c);
     static const bool trace = getenv("ANNCHOR_SYNC_TRACE") != nullptr;
@@ -286,8 +315,7 @@ int ann_d2h2_then(annchor_ctx *c, void *dst1, const void *src1, size_t bytes1, v
     const long long t_w = timing ? ann_now_ns() : 0;
     ANN_CHECK_HIP(c, hipEventSynchronize(c->dl_ev));
     if (timing) fprintf(stderr, "T wait %s %lld %lld %lld\n", __func__, t_w, t_w, ann_now_ns());
-    memcpy(dst1, slot, bytes1);
-    memcpy(dst2, slot + off2, bytes2);
+    memcpy(dst, slot, bytes);
     return rc;
 }
 
@@ -621,6 +649,7 @@ extern "C" int annchor_set_opaque(annchor_ctx *c, int64_t nx)
     ANN_REQUIRE(c, nx > 1 && nx < (1ll << 31), ANNCHOR_ELIMIT, "nx=%lld out of range", (long long)nx);
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     ANN_TRY(ann_arena_init(c, nx));
+    ANN_TRY(ann_prewarm_state(c));
     c->metric = ANNCHOR_METRIC_NONE;
     c->nx = nx;
     reset_pipeline(c);
@@ -654,6 +683,7 @@ extern "C" int annchor_set_strings_u16(annchor_ctx *c, const uint16_t *symbols, 
         memcpy(pool.data() + o[(size_t)s], symbols + offs[s], sizeof(uint16_t) * (size_t)lens[s]);
     }
     ANN_TRY(ann_arena_init(c, nx));
+    ANN_TRY(ann_prewarm_state(c));
     ANN_TRY(ann_reserve(c, c->sym, pool.size() * sizeof(uint16_t)));
     ANN_TRY(ann_reserve(c, c->soff, sizeof(int32_t) * (size_t)nx));
     ANN_TRY(ann_reserve(c, c->slen, sizeof(int32_t) * (size_t)nx));
@@ -697,6 +727,7 @@ extern "C" int annchor_set_strings(annchor_ctx *c, const uint8_t *symbols, const
         memcpy(pool.data() + o[(size_t)s], symbols + offs[s], (size_t)lens[s]);
     }
     ANN_TRY(ann_arena_init(c, nx));
+    ANN_TRY(ann_prewarm_state(c));
     ANN_TRY(ann_reserve(c, c->sym, pool.size()));
     ANN_TRY(ann_reserve(c, c->soff, sizeof(int32_t) * (size_t)nx));
     ANN_TRY(ann_reserve(c, c->slen, sizeof(int32_t) * (size_t)nx));
@@ -745,6 +776,7 @@ static int set_points(annchor_ctx *c, const void *X, int64_t nx, int32_t dim, si
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     size_t bytes = esz * (size_t)nx * (size_t)dim;
     ANN_TRY(ann_arena_init(c, nx));
+    ANN_TRY(ann_prewarm_state(c));
     ANN_TRY(ann_reserve(c, c->pts, bytes));
     ANN_TRY(ann_h2d(c, c->pts.p, X, bytes));
     c->metric = metric;
@@ -803,6 +835,7 @@ extern "C" int annchor_set_histograms(annchor_ctx *c, const double *hist, int64_
     ANN_REQUIRE(c, nbins <= 64 || maxs <= 32, ANNCHOR_ELIMIT,
                 "histograms of %d bins: at most 32 non-zero entries each are supported beyond 64 bins (largest support here: %d)", nbins, maxs);
     ANN_TRY(ann_arena_init(c, nx));
+    ANN_TRY(ann_prewarm_state(c));
     ANN_TRY(ann_reserve(c, c->cost, sizeof(double) * (size_t)nbins * nbins));
     if (nbins <= 64) {
         ANN_TRY(ann_reserve(c, c->hist, sizeof(double) * (size_t)nx * nbins));

@@ -15,6 +15,7 @@
 // regression predict is evaluated as ((w0*lb + w1*ub) + w2*dad) + c with
 // contraction disabled so that host and device agree bit for bit.
 #include "common.h"
+#include "selstate.h"
 #include <mutex>
 
 #pragma clang fp contract(off)
@@ -346,10 +347,6 @@ extern "C" int annchor_kth_uncomputed_dad(annchor_ctx *c, const int64_t *ks, int
     return ann_kth_smallest(c, c->dad.as<double>(), c->ncm.as<uint8_t>(), c->n, ks, nk, out);
 }
 
-struct BinEdges {
-    double e[MAXBINS + 1];
-    int nb;
-};
 
 // sampler bin: lo <= x < hi   (utils.py:547-549); -1 if none
 __device__ __forceinline__ int sampler_bin(const BinEdges &b, double x)
@@ -423,34 +420,6 @@ __global__ __launch_bounds__(BC_THREADS) void k_bin_counts(const double *__restr
     bin_counts_body(dad, ncm, n, be, counts);
 }
 
-// ---- the statistics of a sampling step in one round trip (Sampler.get_partition + the bin populations,
-// annchor/samplers.py:75-105, utils.py:536-549): quantiles -> bin edges -> bin counts chained on the device
-struct SamplerStats {
-    BinEdges be;                         // -inf, linspace(q1, q3, nb - 1), +inf
-    double q[2];
-    unsigned long long counts[MAXBINS];
-};
-// np.linspace(q1, q3, num): step = (q3 - q1) / (num - 1), y_i = i * step + q1 (a product and a sum, each rounded; the
-// build does not contract them), the last entry q3 itself; a zero step goes through i / div * delta, which gives q1 too.
-__global__ void k_sampler_edges(const unsigned long long *__restrict__ prefix, int nparts, SamplerStats *__restrict__ st)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double q1 = ann_key_asc_inv(prefix[0]), q3 = ann_key_asc_inv(prefix[1]);
-    st->q[0] = q1; st->q[1] = q3;
-    const int num = nparts - 1, div = num > 1 ? num - 1 : 1;
-    const double delta = q3 - q1, step = delta / (double)div;
-    st->be.nb = nparts;
-    st->be.e[0] = -INFINITY;
-    for (int i = 0; i < num; ++i) {
-        double y;
-        if (step != 0.0) { const double p = (double)i * step; y = p + q1; }
-        else { const double p = ((double)i / (double)div) * delta; y = p + q1; }
-        if (num > 1 && i == num - 1) y = q3;
-        st->be.e[1 + i] = y;
-    }
-    st->be.e[nparts] = INFINITY;
-    for (int b = 0; b < MAXBINS; ++b) st->counts[b] = 0;
-}
 __global__ __launch_bounds__(BC_THREADS) void k_bin_counts_dev(const double *__restrict__ dad, const uint8_t *__restrict__ ncm,
                                                               int64_t n, SamplerStats *__restrict__ st)
 {
@@ -690,11 +659,16 @@ extern "C" int annchor_sampler_stats(annchor_ctx *c, const int64_t *ks, int32_t 
     *fused = 0;
     const unsigned long long *d_prefix = nullptr;
     const int *d_unfinished = nullptr;
-    ANN_TRY(ann_kth_async(c, c->dad.as<double>(), c->ncm.as<uint8_t>(), c->n, ks, 2, &d_prefix, &d_unfinished));
+    ANN_TRY(ann_reserve(c, c->sstats, sizeof(SamplerStats)));
+    SamplerStats *st = c->sstats.as<SamplerStats>();
+    {
+        // (quantiles -> edges -> zeroed counters: written by the selection's finishing workgroup itself)
+        Sel2Epilogue ep;
+        memset(&ep, 0, sizeof ep);
+        ep.kind = 1; ep.st = st; ep.nparts = n_partitions;
+        ANN_TRY(ann_kth_async(c, c->dad.as<double>(), c->ncm.as<uint8_t>(), c->n, ks, 2, &d_prefix, &d_unfinished, &ep));
+    }
     if (d_prefix) {
-        ANN_TRY(ann_reserve(c, c->sstats, sizeof(SamplerStats)));
-        SamplerStats *st = c->sstats.as<SamplerStats>();
-        k_sampler_edges<<<1, 64, 0, c->stream>>>(d_prefix, n_partitions, st);
         const int64_t ntiles = (c->n + BC_TILE - 1) / BC_TILE;
         const int blocks = (int)(ntiles <= 256 ? ntiles : std::min<int64_t>(1024, std::max<int64_t>(256, ntiles / 4)));
         {
@@ -703,15 +677,15 @@ extern "C" int annchor_sampler_stats(annchor_ctx *c, const int64_t *ks, int32_t 
         }
         ANN_CHECK_HIP(c, hipGetLastError());
         SamplerStats h;
-        int unfinished = 0;
         if (c->park_refine) {
             // fit(): the refinement launch of the iteration that just chose its candidates is queued BEHIND this download -- the host
             // waits for the statistics only and starts the draw while the GPU refines (queueing it after the wait left the GPU idle
             // for the host's wake-up and the trip through the host language: ~70 us per iteration)
             c->park_refine = false;
-            ANN_TRY(ann_d2h2_then(c, &h, st, sizeof h, &unfinished, d_unfinished, sizeof unfinished, annchor_refine_candidates));
+            ANN_TRY(ann_d2h_then(c, &h, st, sizeof h, annchor_refine_candidates));
         } else
-        ANN_TRY(ann_d2h2(c, &h, st, sizeof h, &unfinished, d_unfinished, sizeof unfinished));
+        ANN_TRY(ann_d2h(c, &h, st, sizeof h));
+        const int unfinished = h.unfinished;
         ann_kth_async_done(c);
         if (!unfinished) {
             q[0] = h.q[0]; q[1] = h.q[1];

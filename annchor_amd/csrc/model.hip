@@ -42,15 +42,24 @@ __device__ __forceinline__ double block_sum(double v, double *sh /*[OLS_T / 64]*
 
 #define OLS_RCOND 1e-13   // relative singular value below which a direction of a rank-deficient partition is dropped
 // One workgroup per partition.  A: this partition's scratch, double [4][cap] (columns lb, ub, dad, y of its rows).
+struct ModelEdges { double e[MAXBINS + 1]; };
+// (the model's header -- edges, partition count, statuses -- is written here too: workgroup 0 for the shared part, every
+// workgroup for its own partition; k_model_init used to be a launch of its own in front)
 __global__ __launch_bounds__(OLS_T) void k_ols_bins(const double *__restrict__ sfeat, const double *__restrict__ sy, int64_t m,
                                                    DeviceModel *__restrict__ dm, double *__restrict__ scratch, int64_t cap,
-                                                   int32_t *__restrict__ flags)
+                                                   int32_t *__restrict__ flags, ModelEdges ed, int nb)
 {
     __shared__ double sh[OLS_T / 64];
     __shared__ int wcnt[OLS_T / 64];
     __shared__ int base_sh;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double lo = dm->reg.e[b], hi = dm->reg.e[b + 1];
+    const double lo = ed.e[b], hi = ed.e[b + 1];
+    if (tid == 0) dm->status[b] = 0;
+    if (b == 0) {
+        if (tid >= nb && tid < MAXBINS) { dm->status[tid] = 0; dm->rows[tid] = 0; }
+        if (tid <= nb) dm->reg.e[tid] = ed.e[tid];
+        if (tid == 0) { dm->reg.nb = nb; dm->err_status = 0; }
+    }
     double *A = scratch + (size_t)b * 4 * cap;
     double *col[4] = {A, A + cap, A + 2 * cap, A + 3 * cap};
     // ---- rows of the partition, compacted in sample order (deterministic)
@@ -188,16 +197,6 @@ __global__ __launch_bounds__(OLS_T) void k_ols_bins(const double *__restrict__ s
     }
 }
 
-struct ModelEdges { double e[MAXBINS + 1]; };
-// (the partition edges arrive as a kernel argument: no upload of their own)
-__global__ void k_model_init(DeviceModel *__restrict__ dm, int nb, ModelEdges ed)
-{
-    const int t = threadIdx.x;
-    if (t < MAXBINS) { dm->status[t] = 0; dm->rows[t] = 0; }
-    if (t <= nb) dm->reg.e[t] = ed.e[t];
-    if (t == 0) { dm->reg.nb = nb; dm->err_status = 0; }
-}
-
 // bins: the partition edges (HOST, float64 [nb + 1]); the samples are the ones annchor_sample_pairs_device left on the
 // device.  Enqueues the fit and the fused predict / clip / merge / label pass; no host wait.  A partition the device
 // solver does not take (status != 0) raises dev_flags[1]; the caller reads it with annchor_model_status.
@@ -216,12 +215,11 @@ extern "C" int annchor_fit_regression_device(annchor_ctx *c, const double *bins,
     DeviceModel *dm = c->model.as<DeviceModel>();
     ModelEdges ed;
     for (int k = 0; k <= MAXBINS; ++k) ed.e[k] = k <= nb ? bins[k] : 0.0;
-    static_assert(MAXBINS + 1 <= 128, "one thread per edge");
-    k_model_init<<<1, 128, 0, c->stream>>>(dm, nb, ed);
+    static_assert(MAXBINS + 1 <= OLS_T, "one thread per edge");
     {
         ProfScope ps(c, "ols_partitions", (double)m * 40.0 * nb);
         k_ols_bins<<<nb, OLS_T, 0, c->stream>>>(c->sfeat.as<double>(), c->sy.as<double>(), m, dm, c->ols_scratch.as<double>(), m,
-                                                c->dev_flags.as<int32_t>());
+                                                c->dev_flags.as<int32_t>(), ed, nb);
     }
     ANN_CHECK_HIP(c, hipGetLastError());
     c->model_fitted = true; c->model_nb = nb; c->errs_on_device = false; c->model_cache_valid = false;

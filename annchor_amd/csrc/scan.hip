@@ -5,6 +5,7 @@
 // The second one implements np.partition(x[mask], k)[k] as used by
 // SimpleStratifiedSampler.get_partition (reference annchor/samplers.py:119-140).
 #include "common.h"
+#include "selstate.h"
 
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 8
@@ -817,7 +818,7 @@ template <int NQ> __global__ __launch_bounds__(S2_T, 2) void k_sel3_bracket(cons
 
 // levels = filter levels run (2: hist2 splits bits 41..32, 32 bits left; 3: hist3 splits bits 31..21, 21 left)
 __global__ __launch_bounds__(S2_T) void k_sel2_finish(Sel2Tables *__restrict__ tb, const double *__restrict__ cand,
-                                                     const uint32_t *__restrict__ segcnt, int64_t nseg, int levels)
+                                                     const uint32_t *__restrict__ segcnt, int64_t nseg, int levels, Sel2Epilogue ep)
 {
     __shared__ uint64_t keys[S2_CAP];
     __shared__ uint32_t lh[SEL_MAXQ * 256];
@@ -923,6 +924,7 @@ __global__ __launch_bounds__(S2_T) void k_sel2_finish(Sel2Tables *__restrict__ t
     if (tid == 0) {
         for (int q = 0; q < SEL_MAXQ; ++q) { tb->out.prefix[q] = pre[q]; tb->out.k[q] = kk[q]; }
         tb->out.nq = nq; tb->out.unfinished = (fits || tied) ? 0 : 1; tb->out.cnt = cnt;
+        if (ep.kind) sel2_epilogue(ep, pre, (fits || tied) ? 0 : 1);   // the chained consumer's state (selstate.h)
     }
     // leave the tables zeroed for the next selection (saves a memset launch per call)
     uint4 *z = reinterpret_cast<uint4 *>(tb);
@@ -934,7 +936,7 @@ __global__ __launch_bounds__(S2_T) void k_sel2_finish(Sel2Tables *__restrict__ t
 // with its own results and calls ann_kth_async_done().  Lists long enough for the sampled bracket (whose check is the host's)
 // are not taken here: *d_prefix stays null and the caller uses ann_kth_smallest.
 int ann_kth_async(annchor_ctx *c, const double *vals, const uint8_t *flag, int64_t n, const int64_t *ks, int nk,
-                  const unsigned long long **d_prefix, const int **d_unfinished)
+                  const unsigned long long **d_prefix, const int **d_unfinished, const Sel2Epilogue *epi)
 {
     *d_prefix = nullptr; *d_unfinished = nullptr;
     ANN_REQUIRE(c, nk >= 1 && nk <= SEL_MAXQ, ANNCHOR_EINVAL, "kth_smallest: 1..%d ranks per call", SEL_MAXQ);
@@ -965,10 +967,12 @@ int ann_kth_async(annchor_ctx *c, const double *vals, const uint8_t *flag, int64
         k_sel2_hist0<<<grid, S2_T, 0, c->stream>>>(vals, flag, n, tb, nullptr);
         k_sel2_filter<1><<<grid, S2_T, 0, c->stream>>>(vals, flag, n, nullptr, init, tb, A, segA, 0);
         k_sel2_filter<2><<<grid, S2_T, 0, c->stream>>>(A, nullptr, n, segA, init, tb, B, segB, 0);
-        if (!three) k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, B, segB, ntiles, 2);
+        Sel2Epilogue ep;
+        if (epi) ep = *epi; else memset(&ep, 0, sizeof ep);
+        if (!three) k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, B, segB, ntiles, 2, ep);
         else {
             k_sel2_filter<3><<<grid, S2_T, 0, c->stream>>>(B, nullptr, n, segB, init, tb, A, segA, 0);
-            k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, A, segA, ntiles, 3);
+            k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, A, segA, ntiles, 3, ep);
         }
     }
     ANN_CHECK_HIP(c, hipGetLastError());
@@ -977,6 +981,7 @@ int ann_kth_async(annchor_ctx *c, const double *vals, const uint8_t *flag, int64
     *d_unfinished = &tb->out.unfinished;
     return ANNCHOR_OK;
 }
+size_t ann_sel2_table_bytes() { return sizeof(Sel2Tables); }
 void ann_kth_async_done(annchor_ctx *c) { c->sel2_clean = (const void *)c->sel2.p; }   // (the finishing workgroup left the tables zeroed)
 
 int ann_kth_smallest(annchor_ctx *c, const double *vals, const uint8_t *flag, int64_t n, const int64_t *ks, int nk,
@@ -1002,6 +1007,8 @@ int ann_kth_smallest(annchor_ctx *c, const double *vals, const uint8_t *flag, in
     for (int q = 0; q < nk; ++q) init.k[q] = ks[q];
     // few fat workgroups: every one ends with atomics on shared histogram bins (~12.5 ns each, serialised)
     const int grid = (int)(ntiles <= 256 ? ntiles : std::min<int64_t>(S2_MAXWG, std::max<int64_t>(256, ntiles / 4)));
+    Sel2Epilogue no_ep;
+    memset(&no_ep, 0, sizeof no_ep);
     struct { Sel2State out; Sel3Info s3; } dl;
     static_assert(offsetof(Sel2Tables, s3) == offsetof(Sel2Tables, out) + sizeof(Sel2State), "s3 sits directly behind out");
     Sel2State &out = dl.out;
@@ -1034,10 +1041,10 @@ int ann_kth_smallest(annchor_ctx *c, const double *vals, const uint8_t *flag, in
             }
             k_sel2_filter<2><<<grid, S2_T, 0, c->stream>>>(A, nullptr, n, sa, init, tb, B, sb, sampled);
             if (!three) {
-                k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, B, sb, ntiles, 2);
+                k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, B, sb, ntiles, 2, no_ep);
             } else {   // (C reuses A's slots: A is dead once B exists)
                 k_sel2_filter<3><<<grid, S2_T, 0, c->stream>>>(B, nullptr, n, sb, init, tb, A, sa, sampled);
-                k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, A, sa, ntiles, 3);
+                k_sel2_finish<<<1, S2_T, 0, c->stream>>>(tb, A, sa, ntiles, 3, no_ep);
             }
         }
         ANN_CHECK_HIP(c, hipGetLastError());
@@ -1073,25 +1080,25 @@ int ann_kth_smallest(annchor_ctx *c, const double *vals, const uint8_t *flag, in
     }
     if (out.unfinished) {
         // a mixed bucket longer than the finishing workgroup's LDS: the byte passes over all keys
-        ANN_TRY(ann_reserve(c, c->sel_state, sizeof(SelState) * 9));
+        ANN_TRY(ann_reserve(c, c->sel_pass_state, sizeof(SelState) * 9));
         ANN_TRY(ann_reserve(c, c->sel_hist, sizeof(uint32_t) * 8 * SEL_MAXQ * 256));
         SelState h;
         memset(&h, 0, sizeof h);
         h.nq = nk;
         for (int q = 0; q < nk; ++q) h.k[q] = ks[q];
         h.vor = ~0ull; h.vand = 0ull;   // no byte is known to be uniform
-        ANN_TRY(ann_h2d(c, c->sel_state.p, &h, sizeof h));
+        ANN_TRY(ann_h2d(c, c->sel_pass_state.p, &h, sizeof h));
         ANN_CHECK_HIP(c, hipMemsetAsync(c->sel_hist.p, 0, sizeof(uint32_t) * 8 * SEL_MAXQ * 256, c->stream));
         int blocks = (int)std::min<int64_t>((n + 256 * 8 - 1) / (256 * 8), c->prop.multiProcessorCount * 4);
         if (blocks < 1) blocks = 1;
         {
             ProfScope ps(c, "radix_select_f64_bytewise", (double)n * 9.0);
             for (int pass = 0; pass < 8; ++pass)
-                k_sel_pass<<<blocks, 256, 0, c->stream>>>(vals, flag, n, c->sel_state.as<SelState>(), c->sel_hist.as<uint32_t>(), pass, 0);
-            k_sel_pass<<<1, 256, 0, c->stream>>>(vals, flag, n, c->sel_state.as<SelState>(), c->sel_hist.as<uint32_t>(), 8, 0);
+                k_sel_pass<<<blocks, 256, 0, c->stream>>>(vals, flag, n, c->sel_pass_state.as<SelState>(), c->sel_hist.as<uint32_t>(), pass, 0);
+            k_sel_pass<<<1, 256, 0, c->stream>>>(vals, flag, n, c->sel_pass_state.as<SelState>(), c->sel_hist.as<uint32_t>(), 8, 0);
         }
         ANN_CHECK_HIP(c, hipGetLastError());
-        ANN_TRY(ann_d2h(c, &h, c->sel_state.as<SelState>() + 8, sizeof h));
+        ANN_TRY(ann_d2h(c, &h, c->sel_pass_state.as<SelState>() + 8, sizeof h));
         for (int q = 0; q < nk; ++q) out.prefix[q] = h.prefix[q];
     }
     for (int q = 0; q < nk; ++q) {

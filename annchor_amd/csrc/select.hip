@@ -18,6 +18,7 @@
 // sweep that remains touches nmin+1 entries per row and runs in a single wavefront.
 #include "common.h"
 #include "rowsel.h"
+#include "selstate.h"
 
 // ------------------------------------------------------------------- thresholds
 __global__ __launch_bounds__(ROW_THREADS) void k_row_thresh(const int64_t *__restrict__ Iptr, RowSrc src, uint32_t k,
@@ -700,44 +701,6 @@ __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict_
 #define CP_ITEMS 8
 #define CP_TILE (CP_THREADS * CP_ITEMS)
 
-struct CutState {
-    double t1, t5;          // cut values (prob of the K1-th / K5-th largest)
-    int64_t K1, K5;         // requested counts
-    int64_t e1, e5;         // how many entries equal to the cut are taken
-    int64_t ncand, nnext;
-    int all1, all5;         // take every not-computed pair
-    // Second key inside the group of pairs whose probability EQUALS the cut (the ECDF takes a few
-    // thousand distinct values for ~10^6 pairs, so that group is hundreds to thousands of pairs; the
-    // reference's argpartition picks among them arbitrarily).  By position the rest of the budget
-    // would all go to the first rows of the pair list; by predicted distance the population the next
-    // model is fitted on gets biased (query recall 0.96-0.98 instead of 1.0 on the reference's digits
-    // test).  So: a fixed pseudo-random order, ann_tie_scramble(position) ascending, then position.
-    // rk = scrambled-position cut inside the group (~0: the whole group is taken); "above the cut" =
-    // prob > t || (prob == t && scramble(p) < rk), "on the cut" = prob == t && scramble(p) == rk
-    // (taken in position order, e of them).
-    unsigned long long rk1, rk5;
-    int64_t tie_n1, tie_n5;       // sizes of the two groups
-    int64_t tie_gt1, tie_gt5;     // pairs with prob > t
-    long long tie_bin1, tie_bin5; // histogram bin of the wanted key (-1: rk is final already)
-    long long tie_rem1, tie_rem5; // wanted rank inside the bin (1-based)
-    long long tie_len1, tie_len5; // members of the bin
-    int64_t tie_got1, tie_got5;   // list cursors
-    int tie_overflow;             // a bin's list did not fit TIE_CAP: the host resolves it with the general selection
-    int sel_unfinished;           // the cut values came straight from the selection's tables and it could not finish (k_cut_set_t)
-};
-
-// The cut values without a host round trip: the selection's answers (keys) into the state the cut kernels read.
-// (the host's copy of the state arrives as a kernel argument: no upload of its own)
-__global__ void k_cut_set_t(CutState *__restrict__ cs, CutState init, const unsigned long long *__restrict__ prefix,
-                            const int *__restrict__ unfinished, int need1, int need5, int force_redo)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int q = 0;
-    if (need1) init.t1 = ann_key_asc_inv(prefix[q++]);
-    if (need5) init.t5 = ann_key_asc_inv(prefix[q++]);
-    init.sel_unfinished = *unfinished | force_redo;   // (ANNCHOR_CUT_FORCE_REDO: tests walk the second attempt)
-    *cs = init;
-}
 
 #define TIE_CAP 65536
 
@@ -1137,6 +1100,12 @@ __global__ __launch_bounds__(CP_THREADS) void k_cut_emit(const double *__restric
     }
 }
 
+// the selection's device state: CutState, then (at SEL_ERR_OFF) the int32 error flag of the guarantee_nmin sweep
+#define SEL_ERR_OFF 256
+#define SEL_STATE_BYTES (SEL_ERR_OFF + 256)
+static_assert(sizeof(CutState) <= SEL_ERR_OFF, "the error flag sits behind the cut state");
+static inline int32_t *gn_err_ptr(annchor_ctx *c) { return reinterpret_cast<int32_t *>(c->sel_state.as<char>() + SEL_ERR_OFF); }
+size_t ann_sel_state_bytes() { return SEL_STATE_BYTES; }
 #define GN_BATCH 8   // guarantee_nmin rounds between two looks at the "changed" flags
 
 // Stage A of the selection: row thresholds and guarantee_nmin (lists, first batch of rounds) -- functions of
@@ -1165,8 +1134,11 @@ static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
         ANN_TRY(ann_reserve(c, c->gl_pos, sizeof(int32_t) * (size_t)nx * L * 3));  // pos | other endpoint | twin
         ANN_TRY(ann_reserve(c, c->gl_cnt, sizeof(int32_t) * (size_t)nx));
         ANN_TRY(ann_reserve(c, c->gl_ncomp, sizeof(int32_t) * (size_t)nx));
-        ANN_TRY(ann_reserve(c, c->gn_err, 64));   // the sweep's error flag has a buffer of its own (tmp2 is re-reserved by annchor_bin_counts)
-        ANN_CHECK_HIP(c, hipMemsetAsync(c->gn_err.as<int32_t>(), 0, 4, c->stream));   // sweep error flag
+        ANN_TRY(ann_reserve(c, c->sel_state, SEL_STATE_BYTES));   // (the sweep's error flag sits behind the cut state: one download brings both)
+        if (!c->gn_err_clean) {   // sweep error flag (it stays zero unless a sweep fails: cleared again only then)
+            ANN_CHECK_HIP(c, hipMemsetAsync(gn_err_ptr(c), 0, 4, c->stream));
+        }
+        c->gn_err_clean = false;   // (until the flag has been read back as zero)
         {
             ProfScope ps(c, "guarantee_nmin_lists", (double)n * 26.0);
             const size_t tail = (((size_t)L * 12) + 15) & ~(size_t)15;
@@ -1204,7 +1176,7 @@ static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
                 k_gn_round<<<ann_blocks(nx * 64, 256), 256, 0, c->stream>>>(
                     nx, nmin, L, Lw, c->gl_val.as<double>(), oth, twin, c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
                     masks[round & 1], masks[(round + 1) & 1], mout[round % 3], mout[(round + 1) % 3], mout[(round + 2) % 3],
-                    changed + q, c->gn_err.as<int32_t>());
+                    changed + q, gn_err_ptr(c));
             c->gn_pending = true; c->gn_round = round; c->gn_L = L;
         } else if (L <= GN_LMAX && ring_lds <= 156 * 1024) {
             ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 21.0);
@@ -1215,7 +1187,7 @@ static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
                                                  (int)ring_lds));
             k_gn_sweep_ring<<<1, 256, ring_lds, c->stream>>>(nx, nmin, L, c->gl_val.as<double>(), c->gl_pos.as<int32_t>(), oth, twin,
                                                             c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
-                                                            c->RA.as<double>(), c->gn_err.as<int32_t>());
+                                                            c->RA.as<double>(), gn_err_ptr(c));
         } else if (sweep_lds <= 150 * 1024) {
             ProfScope ps(c, "guarantee_nmin_sweep", (double)nx * L * 21.0);
             int32_t *oth = c->gl_pos.as<int32_t>() + (size_t)nx * L, *twin = oth + (size_t)nx * L;
@@ -1226,7 +1198,7 @@ static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
                                                      (int)sweep_lds));
             k_gn_sweep_lds<<<1, 64, sweep_lds, c->stream>>>(nx, nmin, L, c->gl_val.as<double>(), c->gl_pos.as<int32_t>(), oth,
                                                            twin, c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
-                                                           c->RA.as<double>(), c->gn_err.as<int32_t>());
+                                                           c->RA.as<double>(), gn_err_ptr(c));
         } else {
             // (the row walk's own marks: only this route needs them -- two memsets, one of them a byte per pair, used to run
             // in front of every selection)
@@ -1238,7 +1210,7 @@ static int select_stage_a(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
             k_gn_sequential<<<1, 64, 0, c->stream>>>(nx, nmin, L, c->gl_val.as<double>(), c->gl_pos.as<int32_t>(),
                                                     c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(), c->ij.as<int2>(),
                                                     c->RA.as<double>(), c->marked.as<uint8_t>(), c->markcount.as<int32_t>(),
-                                                    c->gn_err.as<int32_t>());
+                                                    gn_err_ptr(c));
         }
     }
     return ANNCHOR_OK;
@@ -1268,7 +1240,7 @@ static int select_stage_finish(annchor_ctx *c)
             k_gn_round<<<ann_blocks(nx * 64, 256), 256, 0, c->stream>>>(
                 nx, nmin, L, Lw, c->gl_val.as<double>(), oth, twin, c->gl_cnt.as<int32_t>(), c->gl_ncomp.as<int32_t>(),
                 masks[round & 1], masks[(round + 1) & 1], mout[round % 3], mout[(round + 1) % 3], mout[(round + 2) % 3],
-                changed + q, c->gn_err.as<int32_t>());
+                changed + q, gn_err_ptr(c));
     }
     k_gn_apply<<<ann_blocks(nx * L, 256), 256, 0, c->stream>>>(nx, L, Lw, c->gl_pos.as<int32_t>(), c->gl_cnt.as<int32_t>(),
                                                               masks[round & 1], c->RA.as<double>());
@@ -1279,6 +1251,8 @@ static int select_stage_finish(annchor_ctx *c)
 
 // Thresholds and guarantee_nmin ahead of annchor_select_candidates (same n_neighbors / nmin): the caller fits its
 // error model on the host while they run.  Anything that changes RefineApprox or the mask in between voids it.
+size_t ann_tie_hist_bytes() { return sizeof(uint32_t) * 2 * TIE_BINS; }
+
 extern "C" int annchor_select_prepare(annchor_ctx *c, int32_t n_neighbors, int32_t nmin)
 {
     if (!c) return ANNCHOR_EINVAL;
@@ -1374,30 +1348,32 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
         if (!cs.all5) cs.t5 = tv[q++];
         return ANNCHOR_OK;
     };
-    if (n_refine > 0 && !(cs.all1 && cs.all5)) {
-        if (!cs.all1) cut_ks[cut_nk++] = n_unc - cs.K1;
-        if (!cs.all5) cut_ks[cut_nk++] = n_unc - cs.K5;
-        if (!getenv("ANNCHOR_CUT_WAIT"))
-            ANN_TRY(ann_kth_async(c, c->prob.as<double>(), c->ncm.as<uint8_t>(), n, cut_ks, cut_nk, &d_cut_prefix, &d_cut_unfinished));
-        if (!d_cut_prefix) ANN_TRY(cut_values_waiting());
-    }
     if (cs.all1) cs.t1 = -1.0;
     if (cs.all5) cs.t5 = -1.0;
     if (n_refine == 0) { cs.all1 = cs.all5 = 0; cs.t1 = cs.t5 = INFINITY; cs.K1 = cs.K5 = 0; }
     const int nb = ann_blocks(n, CP_TILE);
-    ANN_TRY(ann_reserve(c, c->sel_state, sizeof(CutState) + 256));
+    ANN_TRY(ann_reserve(c, c->sel_state, SEL_STATE_BYTES));
     ANN_TRY(ann_reserve(c, c->blk_cnt, sizeof(uint32_t) * 4 * (size_t)nb));
     ANN_TRY(ann_reserve(c, c->blk_off, sizeof(int64_t) * 4 * (size_t)nb));
     const int64_t maxc = cs.all1 ? n_unc : cs.K1, maxn = cs.all5 ? n_unc : cs.K5;
     ANN_TRY(ann_reserve(c, c->cand, sizeof(int32_t) * (size_t)(maxc + 1)));
     ANN_TRY(ann_reserve(c, c->next, sizeof(int32_t) * (size_t)(maxn + 1)));
     cs.rk1 = cs.rk5 = ~0ull;
+    if (n_refine > 0 && !(cs.all1 && cs.all5)) {
+        if (!cs.all1) cut_ks[cut_nk++] = n_unc - cs.K1;
+        if (!cs.all5) cut_ks[cut_nk++] = n_unc - cs.K5;
+        if (!getenv("ANNCHOR_CUT_WAIT")) {
+            // (the selection's finishing workgroup writes the state the cut kernels read: the host's copy of it rides as a kernel argument)
+            Sel2Epilogue ep;
+            memset(&ep, 0, sizeof ep);
+            ep.kind = 2; ep.cs = c->sel_state.as<CutState>(); ep.cs_init = cs; ep.need1 = !cs.all1; ep.need5 = !cs.all5;
+            ep.force_redo = getenv("ANNCHOR_CUT_FORCE_REDO") ? 1 : 0;
+            ANN_TRY(ann_kth_async(c, c->prob.as<double>(), c->ncm.as<uint8_t>(), n, cut_ks, cut_nk, &d_cut_prefix, &d_cut_unfinished, &ep));
+        }
+        if (!d_cut_prefix) ANN_TRY(cut_values_waiting());
+    }
     const CutState cs_in = cs;   // (for a second attempt)
-    if (d_cut_prefix)
-        k_cut_set_t<<<1, 64, 0, c->stream>>>(c->sel_state.as<CutState>(), cs, d_cut_prefix, d_cut_unfinished, !cs.all1, !cs.all5,
-                                       getenv("ANNCHOR_CUT_FORCE_REDO") ? 1 : 0);
-    else
-        ANN_TRY(ann_h2d(c, c->sel_state.p, &cs, sizeof cs));
+    if (!d_cut_prefix) ANN_TRY(ann_h2d(c, c->sel_state.p, &cs, sizeof cs));
     const bool ties = n_refine > 0 && !(cs.all1 && cs.all5);
     ANN_TRY(ann_reserve(c, c->tie_lists, sizeof(unsigned long long) * 2 * TIE_CAP));
     unsigned long long *tl1 = c->tie_lists.as<unsigned long long>(), *tl5 = tl1 + TIE_CAP;
@@ -1432,8 +1408,12 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     c->call_timed = true;
     ANN_CHECK_HIP(c, hipGetLastError());
     if (nmin > 0) {
+        unsigned char both[SEL_ERR_OFF + 4];
+        ANN_TRY(ann_d2h(c, both, c->sel_state.p, sizeof both));
         int32_t e = 0;
-        ANN_TRY(ann_d2h2(c, &cs, c->sel_state.p, sizeof cs, &e, c->gn_err.as<int32_t>(), 4));
+        memcpy(&cs, both, sizeof cs);
+        memcpy(&e, both + SEL_ERR_OFF, 4);
+        c->gn_err_clean = e == 0;
         ANN_REQUIRE(c, e == 0, ANNCHOR_ESTATE, "guarantee_nmin: a row has fewer not-computed candidates than it must refine");
     } else {
         ANN_TRY(ann_d2h(c, &cs, c->sel_state.p, sizeof cs));
