@@ -602,11 +602,11 @@ class Annchor:
         # (coefficients, flags and the sorted residual lists behind ONE wait: a later predict_merge / select_candidates with
         # host lists, or closing the engine, would overwrite the device copy of the lists)
         W, c, status, ep, flags, flat = self._engine.model_download_with_errors(nb, 2 * int(self.n_samples) + 16)
-        if flags[0] == 1:
-            raise _native.NativeError("sample step: a (bin, rank) entry does not exist (stale counts?)")
         if flags[0] == 3:
             raise _native.NativeError("sample step: the draw's trace kernel gave up waiting for the host's partner stream "
                                       "(ANNCHOR_DRAW_STREAM_TIMEOUT_MS; ANNCHOR_DRAW_STREAM=0 uploads the partners instead)")
+        if flags[0] == 1:
+            raise _native.NativeError("sample step: a (bin, rank) entry does not exist (stale counts?)")
         if flags[0] or flags[1] or flags[2] or status.any() or flat is None:   # (flags[0] == 2: a hashed key list came out short -- retry the waiting way)
             self._device_model_refused = (status.copy(), flags.copy())   # (kept for diagnostics / tests)
             return False

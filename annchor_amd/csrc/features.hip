@@ -1008,7 +1008,7 @@ __global__ void k_pos_gather(const int64_t *__restrict__ pos, int64_t m, int32_t
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     const int64_t p64 = pos[t];
-    if (p64 < 0) { *bad = 1; if (CLEAR) flags[0] = 1; }   // a requested (bin, rank) entry was not found
+    if (p64 < 0) { *bad = 1; if (CLEAR) atomicMax(&flags[0], 1); }   // a requested (bin, rank) entry was not found (a trace that gave up -- 3 -- stays visible)
     const int32_t p = (int32_t)(p64 < 0 ? 0 : p64);
     if (CLEAR) ncm[p] = 0;
     out[t] = p;
@@ -1178,7 +1178,7 @@ __device__ __forceinline__ bool tr_wait(const unsigned long long *progress, unsi
         const unsigned long long p = __hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         if (p >= need) return true;
         if (wall_clock64() - t0 > timeout_ticks) {
-            if (flags) flags[0] = 3;
+            if (flags) atomicMax(&flags[0], 3);
             return false;
         }
         const int naps = (int)min((unsigned long long)((need - p) >> 14), 64ull) + 1;

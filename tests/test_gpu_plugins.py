@@ -405,3 +405,44 @@ def test_legacy_draw_trace_on_device_equals_host():
                 assert np.array_equal(np.asarray(h), d), (counts, want, seed, b)
     assert eng.legacy_choice_ranks_device(1, [100000], [9000]) is None   # beyond the chain kernel's LDS: the caller draws on the host
     eng.close()
+
+
+def test_streamed_draw_equals_uploaded_draw_and_fails_loudly(monkeypatch):
+    """The legacy draw's trace kernel reads the swap partners from pinned memory while the host scans (default); ANNCHOR_DRAW_STREAM=0
+    uploads them partition by partition and queues the trace after the scan: same graph, bit for bit.  A trace kernel whose wait
+    for the host runs out (time limit 0: the first unsuccessful poll gives up) raises the sticky flag and the fit fails -- no graph
+    from a draw that did not complete."""
+    from annchor_amd import Annchor, _native
+    from annchor_amd.datasets import load_strings
+
+    X = load_strings()["X"][::2]
+    cfg = dict(n_anchors=12, n_neighbors=15, p_work=0.2, random_seed=7)
+    monkeypatch.setenv("ANNCHOR_RNG_NO_CACHE", "1")
+    graphs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ANNCHOR_DRAW_STREAM", mode)
+        a = Annchor(X, "levenshtein", **cfg).fit()
+        graphs[mode] = a.neighbor_graph
+        a._engine.close()
+    assert np.array_equal(graphs["1"][0], graphs["0"][0]) and np.array_equal(graphs["1"][1], graphs["0"][1])
+    # (the draw's ranks through both forms: the test entry of the trace)
+    eng = _native.Engine(0)
+    counts, want = [30000, 500, 120000, 64], [200, 200, 200, 200]
+    host = _native.legacy_choice_ranks(99, counts, want)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ANNCHOR_DRAW_STREAM", mode)
+        dev = eng.legacy_choice_ranks_device(99, counts, want)
+        for h, d in zip(host, dev):
+            assert np.array_equal(np.asarray(h), d), mode
+    monkeypatch.setenv("ANNCHOR_DRAW_STREAM", "1")
+    monkeypatch.setenv("ANNCHOR_DRAW_STREAM_TIMEOUT_MS", "0")
+    with pytest.raises(_native.NativeError, match="partner stream"):
+        eng.legacy_choice_ranks_device(99, counts, want)
+    monkeypatch.delenv("ANNCHOR_DRAW_STREAM_TIMEOUT_MS")
+    dev = eng.legacy_choice_ranks_device(99, counts, want)   # the context is usable again (flag cleared)
+    for h, d in zip(host, dev):
+        assert np.array_equal(np.asarray(h), d)
+    eng.close()
+    monkeypatch.setenv("ANNCHOR_DRAW_STREAM_TIMEOUT_MS", "0")
+    with pytest.raises(_native.NativeError, match="trace kernel gave up"):
+        Annchor(X, "levenshtein", **cfg).fit()
