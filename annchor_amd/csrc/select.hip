@@ -721,6 +721,7 @@ __host__ __device__ __forceinline__ unsigned long long ann_tie_scramble(int64_t 
 #define TIE_HB 12
 #define TIE_BINS (1 << TIE_HB)
 #define TIE_SHIFT (53 - TIE_HB)
+#define TIE_U 8   // probabilities in flight per thread in the two streaming passes (with five workgroups per CU: 20 MB chip-wide)
 __global__ __launch_bounds__(256) void k_tie_hist(const double *__restrict__ prob, int64_t n, CutState *__restrict__ cs,
                                                  uint32_t *__restrict__ ghist /*[2][TIE_BINS]*/)
 {
@@ -732,13 +733,13 @@ __global__ __launch_bounds__(256) void k_tie_hist(const double *__restrict__ pro
     const double t1 = cs->t1, t5 = cs->t5;
     const bool need1 = !cs->all1, need5 = !cs->all5;
     unsigned long long g1 = 0, g5 = 0, n1 = 0, n5 = 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
-    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x * 4 + threadIdx.x; p0 < n; p0 += stride) {
-        double v[4];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * TIE_U;
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x * TIE_U + threadIdx.x; p0 < n; p0 += stride) {
+        double v[TIE_U];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = ann_ldc(prob, p0 + (int64_t)e * blockDim.x, n);
+        for (int e = 0; e < TIE_U; ++e) v[e] = ann_ldc(prob, p0 + (int64_t)e * blockDim.x, n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < TIE_U; ++e) {
             const int64_t p = p0 + (int64_t)e * blockDim.x;
             if (p >= n || !(v[e] >= 0.0)) continue;
             g1 += v[e] > t1;
@@ -823,13 +824,13 @@ __global__ __launch_bounds__(256) void k_tie_collect(const double *__restrict__ 
     const long long b1 = cs->tie_bin1, b5 = cs->tie_bin5;
     if (b1 < 0 && b5 < 0) return;
     const double t1 = cs->t1, t5 = cs->t5;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
-    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x * 4 + threadIdx.x; p0 < n; p0 += stride) {
-        double v[4];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * TIE_U;
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x * TIE_U + threadIdx.x; p0 < n; p0 += stride) {
+        double v[TIE_U];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = ann_ldc(prob, p0 + (int64_t)e * blockDim.x, n);
+        for (int e = 0; e < TIE_U; ++e) v[e] = ann_ldc(prob, p0 + (int64_t)e * blockDim.x, n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < TIE_U; ++e) {
             const int64_t p = p0 + (int64_t)e * blockDim.x;
             if (p >= n || !(v[e] >= 0.0)) continue;
             const bool m1 = b1 >= 0 && v[e] == t1, m5 = b5 >= 0 && v[e] == t5;
@@ -1388,7 +1389,9 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     auto tie_groups = [&]() -> int {
         // the groups on the two cuts and their RefineApprox cuts (device only: no host wait)
         ProfScope ps(c, "topk_tie_groups", (double)n * 8.0);
-        const int tb = (int)std::min<int64_t>(ann_blocks(n, 256 * 4), 256);
+        // (the two streaming passes: as many workgroups as the histogram's 32 KB of LDS lets a CU hold -- 256 of them, one per CU
+        // with 8 KB in flight each, read a 1 GB column at 1.8 TB/s)
+        const int tb = (int)std::min<int64_t>(ann_blocks(n, 256 * TIE_U), (int64_t)c->prop.multiProcessorCount * 5);
         const char *cap_env = getenv("ANNCHOR_TIE_CAP");   // tests force the large-group route on small inputs
         const long long cap = cap_env ? std::min<long long>(TIE_CAP, std::max<long long>(1, atoll(cap_env))) : TIE_CAP;
         ANN_TRY(ann_reserve(c, c->tie_hist, sizeof(uint32_t) * 2 * TIE_BINS));

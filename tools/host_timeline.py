@@ -1,22 +1,29 @@
 """Host-side timeline of one C2 fit without a profiler attached: every stage of fit() (enter / exit) and every host wait of the
 library (ANNCHOR_SYNC_TIMING=1: when the wait began, how long it blocked), on one monotonic clock.  A wait that returns at once
 means the GPU was idle waiting for the host before it; a long one means the host was ahead.
-usage: host_timeline.py [ENV=VALUE ...]"""
+usage: host_timeline.py [digits] [ENV=VALUE ...]     (digits: BASELINE configs[3], exact-OT Wasserstein, instead of the strings)"""
 import os, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("ANNCHOR_RNG_NO_CACHE", "1")
 os.environ["ANNCHOR_SYNC_TIMING"] = "1"
+digits = "digits" in sys.argv[1:]
 for kv in sys.argv[1:]:
-    k, v = kv.split("=", 1)
-    os.environ[k] = v
+    if "=" in kv:
+        k, v = kv.split("=", 1)
+        os.environ[k] = v
 log = tempfile.NamedTemporaryFile(prefix="timeline", suffix=".log", delete=False)
 os.dup2(log.fileno(), 2)   # the library's stderr lines
 import numpy as np
 from annchor_amd import Annchor, _native
-from annchor_amd.datasets import load_strings
+from annchor_amd.datasets import load_strings, load_digits
 _native.bind_to_device_numa(0)
-X = load_strings()["X"]
-cfg = dict(n_anchors=15, n_neighbors=25, p_work=0.12, random_seed=42)
+if digits:
+    d = load_digits()
+    X, metric, kw = d["X"], "wasserstein", {"func_kwargs": {"cost_matrix": d["cost_matrix"]}}
+    cfg = dict(n_anchors=20, n_neighbors=25, n_samples=5000, p_work=0.16, random_seed=42)
+else:
+    X, metric, kw = load_strings()["X"], "levenshtein", {}
+    cfg = dict(n_anchors=15, n_neighbors=25, p_work=0.12, random_seed=42)
 STAGES = ["get_anchors", "get_locality", "get_features", "get_sample", "fit_predict_regression", "fit_predict_errors",
           "select_refine_candidate_pairs", "update_anchor_points", "get_ann"]
 marks = []
@@ -29,7 +36,7 @@ def wrap(obj, name):
         finally:
             marks.append((name, t0, time.monotonic_ns()))
     setattr(obj, name, g)
-anns = [Annchor(X, "levenshtein", **cfg) for _ in range(12)]
+anns = [Annchor(X, metric, **kw, **cfg) for _ in range(12)]
 spans = []
 for a in anns:
     for s in STAGES:
