@@ -1545,14 +1545,24 @@ template <bool RESCUE> __global__ __launch_bounds__(RESCUE ? 512 : ANN_WAVE) voi
             const int dir = half ? -1 : 1;
             const uint8_t *tp = txt + (half ? n - 1 + w : -w);
             uint32_t vp = 0xffffffffu, vn = 0u;
-            uint32_t c1 = tp[dir];
-            uint32_t eq = *reinterpret_cast<const uint32_t *>(pm_col + (uint32_t)tp[0] * LEVF_ROW);
+            // LDS reads run ahead of the recurrence: the match mask of column k + 2 and the symbol of column k + 5 are requested in
+            // column k (a wave alone on its SIMD has only its own ~100 cycles per column to cover an LDS round trip: with one
+            // column of lead it waited on most of them).  Three registers per queue, each column overwriting the one it has just
+            // consumed: after three columns every value sits where it started, so the main loop (three columns per trip) has no
+            // copies; the few checked columns at either end rotate by moves.
+            //   E0 = mask(k), E1 = mask(k + 1), (E2 free);  S2 = symbol(k + 2), S0 = symbol(k + 3), S1 = symbol(k + 4)
+            uint32_t E0 = *reinterpret_cast<const uint32_t *>(pm_col + (uint32_t)tp[0] * LEVF_ROW);
+            uint32_t E1 = *reinterpret_cast<const uint32_t *>(pm_col + (uint32_t)tp[dir] * LEVF_ROW);
+            uint32_t E2 = 0;
+            uint32_t S2 = tp[2 * dir], S0 = tp[3 * dir], S1 = tp[4 * dir];
+            const uint8_t *tnext = tp + 5 * dir;
             uint32_t out_hp = 0, out_hn = 0;
-            const uint8_t *tnext = tp + 2 * dir;
-            auto column = [&](int k, auto checked) {
-                const uint32_t c2 = *tnext;
+            auto column = [&](uint32_t &Ecur, uint32_t &Enew, uint32_t &Saddr, int k, auto checked) {
+                const unsigned char *ea = pm_col + Saddr * LEVF_ROW;
+                Saddr = *tnext;
                 tnext += dir;
-                const uint32_t eq_n = *reinterpret_cast<const uint32_t *>(pm_col + c1 * LEVF_ROW);
+                Enew = *reinterpret_cast<const uint32_t *>(ea);
+                const uint32_t eq = Ecur;
                 const uint32_t hp_up = dpp_shr1_or(out_hp, hp_or), hn_up = dpp_shr1_and(out_hn, hn_and);
                 __builtin_amdgcn_sched_barrier(0);
                 const bool valid = !decltype(checked)::value || (uint32_t)(k - w) < un;
@@ -1573,15 +1583,22 @@ template <bool RESCUE> __global__ __launch_bounds__(RESCUE ? 512 : ANN_WAVE) voi
                 out_hp = hp;
                 out_hn = hn;
                 __builtin_amdgcn_sched_barrier(0);
-                eq = eq_n;
-                c1 = c2;
+            };
+            auto column1 = [&](int k, auto checked) {   // one column, the queues rotated back into place
+                column(E0, E2, S2, k, checked);
+                const uint32_t e = E0; E0 = E1; E1 = E2; E2 = e;
+                const uint32_t t = S2; S2 = S0; S0 = S1; S1 = t;
             };
             AP_STAMP(2);
             int k = 0;
-            for (; k < k_lo; ++k) column(k, std::true_type());
-            for (; k + 2 <= k_hi; k += 2) { column(k, std::false_type()); column(k + 1, std::false_type()); }
-            for (; k < k_hi; ++k) column(k, std::false_type());
-            for (; k < max_steps; ++k) column(k, std::true_type());
+            for (; k < k_lo; ++k) column1(k, std::true_type());
+            for (; k + 3 <= k_hi; k += 3) {
+                column(E0, E2, S2, k, std::false_type());
+                column(E1, E0, S0, k + 1, std::false_type());
+                column(E2, E1, S1, k + 2, std::false_type());
+            }
+            for (; k < k_hi; ++k) column1(k, std::false_type());
+            for (; k < max_steps; ++k) column1(k, std::true_type());
             AP_STAMP(3);
 
             // ---- F / B' (prefix sums of the vertical deltas down this half's rows), then min_i F[i] + B'[m - i] per pair
