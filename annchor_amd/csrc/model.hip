@@ -226,24 +226,7 @@ extern "C" int annchor_fit_regression_device(annchor_ctx *c, const double *bins,
     return ann_predict_merge_device(c, &dm->reg, first_iteration, is_metric);
 }
 
-// ---- residual lists: count per partition (closed intervals), then one workgroup per partition compacts and sorts
-__global__ __launch_bounds__(256) void k_err_count(const double *__restrict__ sfeat, int64_t m, DeviceModel *__restrict__ dm)
-{
-    __shared__ int wc[4];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double lo = dm->reg.e[b], hi = dm->reg.e[b + 1];
-    int cnt = 0;
-    for (int64_t t = threadIdx.x; t < m; t += 256) {
-        const double d = sfeat[4 * t + 2];
-        cnt += (d >= lo && d <= hi) ? 1 : 0;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-    if (lane == 0) wc[wave] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) dm->rows[b] = wc[0] + wc[1] + wc[2] + wc[3];   // (rows is reused: the regression is done with it)
-}
-
+// ---- residual lists: one workgroup per partition counts, compacts and sorts
 // ascending order-preserving key of a double (NaNs last)
 __device__ __forceinline__ unsigned long long err_key(double v) { return ann_key_asc(v); }
 
@@ -255,20 +238,32 @@ __global__ __launch_bounds__(1024) void k_err_sort(const double *__restrict__ sf
     extern __shared__ unsigned long long keys[];   // [P2]
     __shared__ int wcnt[16];
     __shared__ int base_sh;
+    __shared__ int pcnt[MAXBINS];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double lo = dm->reg.e[b], hi = dm->reg.e[b + 1];
-    const int n = (int)dm->rows[b];
-    // where this partition's list starts: the counts of the partitions before it (k_err_count ran); partition 0's workgroup
-    // also publishes the offsets and the status (what a launch of its own, k_err_ptr, used to do)
+    // every partition's population (closed intervals: a sample on an inner edge counts for both neighbours), counted by every
+    // workgroup for itself -- m samples x nb edges, a few microseconds; k_err_count used to be a launch of its own in front
+    if (tid < MAXBINS) pcnt[tid] = 0;
+    __syncthreads();
+    for (int64_t t = tid; t < m; t += 1024) {
+        const double d = sfeat[4 * t + 2];
+        for (int q = 0; q < nb; ++q)
+            if (d >= dm->reg.e[q] && d <= dm->reg.e[q + 1]) atomicAdd(&pcnt[q], 1);
+    }
+    __syncthreads();
+    const int n = pcnt[b];
+    if (tid == 0) dm->rows[b] = n;   // (rows is reused: the regression is done with it)
+    // where this partition's list starts: the counts of the partitions before it; partition 0's workgroup also publishes the
+    // offsets and the status (what a launch of its own, k_err_ptr, used to do)
     int64_t my_at = 0;
-    for (int q = 0; q < b; ++q) my_at += dm->rows[q];
+    for (int q = 0; q < b; ++q) my_at += pcnt[q];
     if (b == 0 && tid == 0) {
         int64_t at = 0;
         int st = 0;
         for (int q = 0; q < nb; ++q) {
             dm->errptr[q] = at;
             errptr_out[q] = at;
-            const int64_t r = dm->rows[q];
+            const int64_t r = pcnt[q];
             if (r == 0) st = max(st, 1);
             if (r > ERR_CAP) st = max(st, 2);
             at += r;
@@ -334,7 +329,6 @@ extern "C" int annchor_fit_errors_device(annchor_ctx *c)
     ANN_TRY(ann_reserve(c, c->errptr, sizeof(int64_t) * (size_t)(MAXBINS + 1)));
     {
         ProfScope ps(c, "error_residual_lists", (double)m * 32.0 * nb);
-        k_err_count<<<nb, 256, 0, c->stream>>>(c->sfeat.as<double>(), m, dm);
         const size_t lds = sizeof(unsigned long long) * ERR_CAP;
         ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_err_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_err_sort<<<nb, 1024, lds, c->stream>>>(c->sfeat.as<double>(), c->sy.as<double>(), c->spred.as<double>(), m, dm, c->errs.as<double>(),
