@@ -1175,8 +1175,11 @@ __device__ __forceinline__ bool tr_wait(const unsigned long long *progress, unsi
 {
     const long long t0 = wall_clock64();
     for (;;) {
-        const unsigned long long p = __hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (p >= need) return true;
+        // (relaxed: the partners live in fine-grained host memory, which no cache of the device holds -- an acquire here would
+        // invalidate the XCD's L2 at every poll, under the refinement kernels of a fit's second draw; the loads that follow are
+        // issued after this one has returned)
+        const unsigned long long p = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p >= need) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return true; }
         if (wall_clock64() - t0 > timeout_ticks) {
             if (flags) atomicMax(&flags[0], 3);
             return false;
