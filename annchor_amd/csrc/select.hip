@@ -721,7 +721,7 @@ __host__ __device__ __forceinline__ unsigned long long ann_tie_scramble(int64_t 
 #define TIE_HB 12
 #define TIE_BINS (1 << TIE_HB)
 #define TIE_SHIFT (53 - TIE_HB)
-#define TIE_U 8   // probabilities in flight per thread in the two streaming passes (with five workgroups per CU: 20 MB chip-wide)
+#define TIE_U 8   // probabilities in flight per thread in the two streaming passes (with three workgroups per CU: 12 MB chip-wide)
 __global__ __launch_bounds__(256) void k_tie_hist(const double *__restrict__ prob, int64_t n, CutState *__restrict__ cs,
                                                  uint32_t *__restrict__ ghist /*[2][TIE_BINS]*/)
 {
@@ -1389,9 +1389,10 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     auto tie_groups = [&]() -> int {
         // the groups on the two cuts and their RefineApprox cuts (device only: no host wait)
         ProfScope ps(c, "topk_tie_groups", (double)n * 8.0);
-        // (the two streaming passes: as many workgroups as the histogram's 32 KB of LDS lets a CU hold -- 256 of them, one per CU
-        // with 8 KB in flight each, read a 1 GB column at 1.8 TB/s)
-        const int tb = (int)std::min<int64_t>(ann_blocks(n, 256 * TIE_U), (int64_t)c->prop.multiProcessorCount * 5);
+        // (the two streaming passes: 256 workgroups, one per CU with 8 KB in flight each, read a 1 GB column at 1.8 TB/s)
+        // three per CU: every workgroup ends with up to 8192 global atomics (its histogram), so more of them read faster and
+        // flush longer -- 1 / 2 / 3 / 5 per CU: 1.06 / 0.91 / 0.88 / 0.92 ms per call at 127 M pairs
+        const int tb = (int)std::min<int64_t>(ann_blocks(n, 256 * TIE_U), (int64_t)c->prop.multiProcessorCount * 3);
         const char *cap_env = getenv("ANNCHOR_TIE_CAP");   // tests force the large-group route on small inputs
         const long long cap = cap_env ? std::min<long long>(TIE_CAP, std::max<long long>(1, atoll(cap_env))) : TIE_CAP;
         ANN_TRY(ann_reserve(c, c->tie_hist, sizeof(uint32_t) * 2 * TIE_BINS));
