@@ -797,6 +797,9 @@ def main():
 
         if args.share_gpu:
             args.backend, local = "gloo", 0
+            # (rehearsal only: several processes on one GPU cannot all keep the persistent anchor launch's waves resident -- each
+            # fit would sit out its 20 ms time limit and take the one-workgroup rescue form; one process per GPU is the real layout)
+            os.environ.setdefault("ANNCHOR_LEV_PERSIST", "0")
         torch.cuda.set_device(local)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
