@@ -37,6 +37,7 @@ _SIGNATURES = {
     "annchor_device_pci_bus_id": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
     "annchor_device_mem_info": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "annchor_synchronize": (ctypes.c_int, [_vp]),
+    "annchor_lev_persist_state": (ctypes.c_int, [ctypes.c_int]),
     "annchor_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "annchor_set_strings": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32]),
     "annchor_set_strings_u16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32]),
@@ -280,6 +281,12 @@ def legacy_generate(seed, ndraws):
         rc = load_library().annchor_legacy_generate(int(seed), int(ndraws))
         if rc != 0:
             raise NativeError("annchor_legacy_generate failed (%d)" % rc)
+
+
+def lev_persist_state(set=-1):
+    """The picker's persistent anchor launch: 1 armed, 0 switched off (the library does that itself after two launches that gave
+    up -- a GPU shared with another process); set=1 re-arms, set=0 switches it off."""
+    return int(load_library().annchor_lev_persist_state(int(set)))
 
 
 def legacy_choice_ranks(seed, counts, want):

@@ -59,6 +59,7 @@ struct annchor_ctx {
     DevBuf lev_ap;           // k_lev_ap (all anchor rounds in one launch): u64 [2][1024] arrival slots, then the abort word
     DevBuf lev_ap_min;       // uint16 [nx]: running minima of the rescue form
     uint32_t lev_ap_epoch = 0;
+    uint32_t lev_ap_probe_epoch = 0;   // a copy of the abort word is on its way to the pinned tail: looked at after the next host wait (lev.hip)
     DevBuf lev_cursors;      // int32 [2][2]: class counters of k_lev_classify, two slots used in turn (a call zeroes the NEXT call's slot)
     int lev_cursor_epoch = 0;
     DevBuf lev_perm;         // int32 [n] pair positions, short patterns first / long ones from the back; + 2 counters
@@ -182,6 +183,7 @@ struct annchor_ctx {
     static constexpr int PIN_SLOTS = 8;
     static constexpr size_t PIN_SLOT_BYTES = 64 * 1024;
     static constexpr size_t PIN_DL_BYTES = 1024 * 1024;   // downloads up to this size go through pinned memory
+    static constexpr size_t PIN_TAIL_BYTES = 64;          // behind the download region: the persistent anchor launch's abort word (lev.hip)
     unsigned char *pin = nullptr;            // PIN_SLOTS slots: ring for uploads; then PIN_DL_BYTES for downloads
     hipEvent_t pin_ev[PIN_SLOTS] = {};
     bool pin_busy[PIN_SLOTS] = {};
@@ -217,6 +219,7 @@ const char *ann_set_err(annchor_ctx *c, const char *fmt, ...);
 int ann_reserve(annchor_ctx *c, DevBuf &b, size_t bytes);
 int ann_arena_init(annchor_ctx *c, int64_t nx);
 int ann_prewarm_state(annchor_ctx *c);   // ctx.hip
+void ann_lev_ap_probe(annchor_ctx *c);   // lev.hip: after a host wait -- did the last persistent anchor launch give up?
 size_t ann_sel2_table_bytes();           // scan.hip
 size_t ann_tie_hist_bytes();             // select.hip
 size_t ann_sel_state_bytes();            // select.hip

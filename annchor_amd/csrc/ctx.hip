@@ -245,6 +245,7 @@ hipError_t ann_sync(annchor_ctx *c, const char *where)
     const long long t_w = timing ? ann_now_ns() : 0;
     const hipError_t rc = hipStreamSynchronize(c->stream);
     if (timing) fprintf(stderr, "T wait %s %lld %lld %lld\n", where, t_in, t_w, ann_now_ns());
+    if (c->lev_ap_probe_epoch) ann_lev_ap_probe(c);
     return rc;
 }
 
@@ -316,6 +317,7 @@ int ann_d2h_then(annchor_ctx *c, void *dst, const void *src, size_t bytes, int (
     ANN_CHECK_HIP(c, hipEventSynchronize(c->dl_ev));
     if (timing) fprintf(stderr, "T wait %s %lld %lld %lld\n", __func__, t_w, t_w, ann_now_ns());
     memcpy(dst, slot, bytes);
+    // (the probe's copy was queued before this download's: it has landed; a launch queued by `then` is a later one)
     return rc;
 }
 
@@ -496,7 +498,7 @@ extern "C" int annchor_create(int device, annchor_ctx **out)
     (void)hipEventCreate(&c->call_a);
     (void)hipEventCreate(&c->call_b);
     if (getenv("ANNCHOR_NO_PIN") ||
-        hipHostMalloc((void **)&c->pin, annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES + annchor_ctx::PIN_DL_BYTES, hipHostMallocDefault) != hipSuccess)
+        hipHostMalloc((void **)&c->pin, annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES + annchor_ctx::PIN_DL_BYTES + annchor_ctx::PIN_TAIL_BYTES, hipHostMallocDefault) != hipSuccess)
         c->pin = nullptr;   // fall back to pageable transfers
     for (int i = 0; i < annchor_ctx::PIN_SLOTS; ++i) (void)hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming);
     *out = c;

@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include <atomic>
 #include <type_traits>
 
 #define LEV_THREADS 256
@@ -1789,6 +1790,34 @@ static int launch_a2(annchor_ctx *c, const PairSource &src, double *d_out)
     return ANNCHOR_OK;
 }
 
+// A persistent launch that gives up (its waves were not all resident: another process holds CUs) costs its whole time limit before
+// the rescue form runs -- 20 ms against a 0.3 ms launch.  The abort word is copied to the context's pinned tail behind every
+// persistent launch and looked at after the next host wait; two launches of a process that gave up (time limit not forced by the
+// environment) switch the persistent form off for the process, with one line on stderr.  annchor_lev_persist_state(1) re-arms.
+static std::atomic<int> g_lev_ap_strikes{0};
+static std::atomic<int> g_lev_ap_off{0};
+void ann_lev_ap_probe(annchor_ctx *c)
+{
+    const uint32_t epoch = c->lev_ap_probe_epoch;
+    c->lev_ap_probe_epoch = 0;
+    if (!c->pin || !epoch) return;
+    const unsigned char *tail = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES + annchor_ctx::PIN_DL_BYTES;
+    uint32_t seen;
+    memcpy(&seen, tail, 4);
+    if (seen != epoch) return;
+    if (getenv("ANNCHOR_LEV_PERSIST_TIMEOUT_US") && !getenv("ANNCHOR_LEV_PERSIST_LEARN")) return;   // a forced time limit (tests) teaches nothing
+    if (g_lev_ap_strikes.fetch_add(1) + 1 >= 2 && !g_lev_ap_off.exchange(1))
+        fprintf(stderr, "annchor_hip: the persistent anchor launch gave up twice (its waves were not all resident: is the GPU shared?); "
+                        "the picker's rounds run as separate launches from now on (annchor_lev_persist_state(1) re-arms)\n");
+}
+// set: 0 = off, 1 = on (strikes forgotten), anything else = query; returns 1 when the persistent form is armed
+extern "C" int annchor_lev_persist_state(int set)
+{
+    if (set == 0) g_lev_ap_off.store(1);
+    if (set == 1) { g_lev_ap_off.store(0); g_lev_ap_strikes.store(0); }
+    return g_lev_ap_off.load() ? 0 : 1;
+}
+
 // All anchor rounds in one launch (k_lev_ap) when the data set allows it: byte alphabet, every string within a 32-lane slot,
 // point ids and distances within 16 bits, and every wave of the launch resident at once.
 int ann_lev_anchor_rounds(annchor_ctx *c, int32_t na, int32_t first, bool *done)
@@ -1797,6 +1826,7 @@ int ann_lev_anchor_rounds(annchor_ctx *c, int32_t na, int32_t first, bool *done)
     {
         const char *e = getenv("ANNCHOR_LEV_PERSIST");   // 0: the rounds one by one (A/B runs, tests); read per call
         if (e && atoi(e) == 0) return ANNCHOR_OK;
+        if (g_lev_ap_off.load()) return ANNCHOR_OK;      // (it gave up twice in this process)
         const char *e_a = getenv("ANNCHOR_LEV_ANCHOR"), *e_r = getenv("ANNCHOR_LEV_R");
         if ((e_a && atoi(e_a) != 2) || e_r) return ANNCHOR_OK;   // a forced kernel variant means the per-round path
     }
@@ -1861,6 +1891,11 @@ int ann_lev_anchor_rounds(annchor_ctx *c, int32_t na, int32_t first, bool *done)
         ProfScope ps(c, "levenshtein_pairs", word_bytes);
         k_lev_ap<false><<<a.ntasks, ANN_WAVE, lds, c->stream>>>(a);
         k_lev_ap<true><<<1, rwaves * ANN_WAVE, rlds, c->stream>>>(a);
+    }
+    if (c->pin) {   // did it give up?  (looked at after the next host wait: ann_lev_ap_probe)
+        unsigned char *tail = c->pin + (size_t)annchor_ctx::PIN_SLOTS * annchor_ctx::PIN_SLOT_BYTES + annchor_ctx::PIN_DL_BYTES;
+        ANN_CHECK_HIP(c, hipMemcpyAsync(tail, a.abort_epoch, 4, hipMemcpyDeviceToHost, c->stream));
+        c->lev_ap_probe_epoch = a.epoch;
     }
     ANN_CHECK_HIP(c, hipGetLastError());
 #ifdef LEV_AP_PROFILE

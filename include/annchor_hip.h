@@ -297,6 +297,12 @@ int annchor_mark_candidates(annchor_ctx *ctx);
 /* Evaluate the metric on the selected candidates and write back
  * (annchor.py:467-473). */
 int annchor_refine_candidates(annchor_ctx *ctx);
+/* The max-min picker's Levenshtein rounds run as ONE persistent launch when every wave of it can be resident (reference: the
+ * loop of annchor/pickers.py:44-50).  A launch that gives up (GPU shared with another process) falls back to a one-workgroup form
+ * after its time limit; after two such launches the library switches the persistent form off for the process.
+ * set = 0: switch it off, 1: re-arm it, other: query.  Returns 1 when it is armed. */
+int annchor_lev_persist_state(int set);
+
 /* fit() pipelining: action 1 parks the refinement launch so that the next annchor_sampler_stats (the NEXT iteration's sampling
  * statistics, which depend on the candidate marks only) queues it behind its download and waits for the statistics alone;
  * action 2 launches it now if it is still parked. */

@@ -266,6 +266,47 @@ def test_levenshtein_anchor_rounds_one_launch(monkeypatch):
         assert np.array_equal(g[0], graphs[0][0]) and np.array_equal(g[1], graphs[0][1])
 
 
+def test_persistent_anchor_launch_switches_itself_off(monkeypatch):
+    """A persistent anchor launch that gives up costs its whole time limit before the rescue form runs.  The library looks at the
+    abort word after the next host wait and, after two such launches, runs the picker's rounds as separate launches for the rest
+    of the process (here: time limit 0 with ANNCHOR_LEV_PERSIST_LEARN so that the forced give-ups count); re-arming restores it.
+    Results are the same throughout."""
+    from annchor_amd import _native
+    from annchor_amd.distances import levenshtein
+
+    rng = np.random.default_rng(5)
+    X = ["".join(rng.choice(list("abcdefg"), n)) for n in rng.integers(5, 300, 400)]
+    assert _native.lev_persist_state(1) == 1
+    eng = _native.Engine(0)
+    levenshtein.bind(eng, X)
+    eng.pick_anchors_maxmin(6, 3)
+    ref = (eng.download(_native.F_A).copy(), eng.download(_native.F_D).copy())
+    def launches(e):
+        e.prof_enable(True)
+        e.prof_reset()
+        e.pick_anchors_maxmin(6, 3)
+        e.synchronize()
+        n = e.prof_get()["levenshtein_pairs"]["launches"]
+        e.prof_enable(False)
+        return n
+    assert launches(eng) == 1                      # one persistent launch (the rescue instantiation is not a profiled launch)
+    monkeypatch.setenv("ANNCHOR_LEV_PERSIST_TIMEOUT_US", "0")
+    monkeypatch.setenv("ANNCHOR_LEV_PERSIST_LEARN", "1")
+    try:
+        for _ in range(3):                         # every launch gives up; each download below is a host wait that looks at the word
+            eng.pick_anchors_maxmin(6, 3)
+            assert np.array_equal(eng.download(_native.F_A), ref[0]) and np.array_equal(eng.download(_native.F_D), ref[1])
+        assert _native.lev_persist_state() == 0    # switched off after the second
+        monkeypatch.delenv("ANNCHOR_LEV_PERSIST_TIMEOUT_US")
+        monkeypatch.delenv("ANNCHOR_LEV_PERSIST_LEARN")
+        assert launches(eng) == 6                  # the rounds one by one
+        assert np.array_equal(eng.download(_native.F_A), ref[0]) and np.array_equal(eng.download(_native.F_D), ref[1])
+    finally:
+        assert _native.lev_persist_state(1) == 1   # re-armed for the tests that follow
+    assert launches(eng) == 1
+    eng.close()
+
+
 def test_levenshtein_wide_alphabet(monkeypatch):
     """More than 256 distinct symbols (16-bit codes, k_lev_w: match words computed per column).  (i) The wide kernel forced
     on the ragged byte-alphabet set must equal the oracle's C restatement; (ii) strings over ~3000 distinct code points
