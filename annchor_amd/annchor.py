@@ -230,7 +230,9 @@ class Annchor:
             self.sampler = DeviceStratifiedSampler()
             print("Note: %d candidate pairs: the samples are drawn by the order-free DeviceStratifiedSampler on the GPU (the same "
                   "stratified draw as samplers.py:75-140 with a hashed choice instead of the host's sequential NumPy-stream "
-                  "shuffle of the whole pair list; sampler='legacy' keeps that one)." % self.N)
+                  "shuffle of the whole pair list; sampler='legacy' keeps that one).  The choice is made here, on nx (nx - 1) / 2 "
+                  ">= %d (nx >= 2829), before the locality filter fixes the real candidate count." % (self.N, DEVICE_SAMPLER_MIN_PAIRS),
+                  file=sys.stderr)
         if want_stream:
             from .streamed import StreamedAnnchor
 

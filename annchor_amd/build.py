@@ -25,6 +25,10 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "annchor_hip.h"))
 
+    sources = [os.path.join(CSRC, n + ".hip") for n in SOURCES]
+    if not force and not _stale(LIB, sources + headers):
+        return LIB   # (the GPU box receives the library without the object files: .gpurunignore)
+
     def compile_one(name):
         src, obj = os.path.join(CSRC, name + ".hip"), os.path.join(OBJ, name + ".o")
         if force or _stale(obj, [src] + headers):

@@ -134,14 +134,23 @@ extern "C" int annchor_comm_alltoall_records(annchor_ctx *c, const void *send, c
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     const size_t rec = (size_t)words * 8;
     ANN_CHECK_RCCL(c, g_rccl.GroupStart());
+    // the first failure is remembered and the group is ALWAYS closed: a return between GroupStart and GroupEnd would leave the
+    // communicator's next collective inside a dangling group
     size_t so = 0, ro = 0;
-    for (int r = 0; r < c->comm_world; ++r) {
+    RcclResult first = 0;
+    const char *where = "";
+    for (int r = 0; r < c->comm_world && first == 0; ++r) {
         const size_t sb = (size_t)send_counts[r] * rec, rb = (size_t)recv_counts[r] * rec;
-        if (sb) ANN_CHECK_RCCL(c, g_rccl.Send((const char *)send + so, sb, kRcclInt8, r, (RcclComm)c->comm, c->stream));
-        if (rb) ANN_CHECK_RCCL(c, g_rccl.Recv((char *)recv + ro, rb, kRcclInt8, r, (RcclComm)c->comm, c->stream));
+        if (sb && first == 0) { first = g_rccl.Send((const char *)send + so, sb, kRcclInt8, r, (RcclComm)c->comm, c->stream); where = "Send"; }
+        if (rb && first == 0) { first = g_rccl.Recv((char *)recv + ro, rb, kRcclInt8, r, (RcclComm)c->comm, c->stream); where = "Recv"; }
         so += sb; ro += rb;
     }
-    ANN_CHECK_RCCL(c, g_rccl.GroupEnd());
+    const RcclResult end = g_rccl.GroupEnd();
+    if (first == 0 && end != 0) { first = end; where = "GroupEnd"; }
+    if (first != 0) {
+        c->err = std::string("RCCL: ") + g_rccl.GetErrorString(first) + " at " + where + " (alltoall_records)";
+        return ANNCHOR_EHIP;
+    }
     return ANNCHOR_OK;
 }
 

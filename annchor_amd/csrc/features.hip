@@ -1175,11 +1175,14 @@ __device__ __forceinline__ bool tr_wait(const unsigned long long *progress, unsi
 {
     const long long t0 = wall_clock64();
     for (;;) {
-        // (relaxed: the partners live in fine-grained host memory, which no cache of the device holds -- an acquire here would
-        // invalidate the XCD's L2 at every poll, under the refinement kernels of a fit's second draw; the loads that follow are
-        // issued after this one has returned)
+        // (the POLL is relaxed: an acquire at every poll would invalidate the XCD's L2 again and again under the refinement
+        // kernels of a fit's second draw.  The one SYSTEM-scope acquire behind the successful poll is what orders the
+        // workgroup's plain loads of J after the host's release store: chunk and bin boundaries are not line-aligned, so a
+        // line fetched for a neighbouring chunk before the host finished it must not be served from a device cache -- that
+        // the pinned buffer is uncached today is a property of the mapping, not of the memory model.  One fence per chunk /
+        // bin; the workgroup barrier behind tr_wait carries it to the other waves of the workgroup.)
         const unsigned long long p = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (p >= need) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return true; }
+        if (p >= need) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); return true; }
         if (wall_clock64() - t0 > timeout_ticks) {
             if (flags) atomicMax(&flags[0], 3);
             return false;
@@ -1324,6 +1327,9 @@ static void trace_tb_fill(TraceBins &tb, int nbins, const int64_t *counts, const
         tb.base[b] = *total;
         tb.offs[b] = *nreq;
         const bool shuffled = counts[b] >= want[b] && counts[b] >= 2;
+        // a shuffled bin of which nothing is kept (k = 0) still consumes its c - 1 stream words on the host, but its phase-2
+        // walk would cover t = c - 1, one word past the partners: leave such draws to the host trace (ok stays false)
+        if (shuffled && tb.k[b] < 1) return;
         tb.joff[b] = shuffled ? *jwords : -1;
         if (shuffled) *jwords += counts[b] + 32;
         *kmax = std::max(*kmax, tb.k[b]);

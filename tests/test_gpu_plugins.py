@@ -336,7 +336,7 @@ def test_device_stratified_sampler_error_distribution_matches_the_legacy_sampler
 
 def test_default_sampler_by_size(capsys):
     """sampler=None: the NumPy-stream sampler below DEVICE_SAMPLER_MIN_PAIRS candidate pairs (graphs bit-identical to the CPU
-    oracle's, pinned elsewhere), the order-free DeviceStratifiedSampler from there on, announced on stdout; the string forms
+    oracle's, pinned elsewhere), the order-free DeviceStratifiedSampler from there on, announced on stderr; the string forms
     force either.  N = 16 000 Euclidean points (1.3 x 10^8 pairs) with DEFAULT arguments: recall against brute force, and the
     fit no longer waits for a host-side shuffle of the pair list."""
     import time
@@ -358,7 +358,7 @@ def test_default_sampler_by_size(capsys):
     cfg = dict(n_anchors=24, n_neighbors=15, p_work=0.05, n_samples=5000)
     capsys.readouterr()
     a = Annchor(X, "euclidean", **cfg)
-    assert type(a.sampler) is DeviceStratifiedSampler and "DeviceStratifiedSampler" in capsys.readouterr().out
+    assert type(a.sampler) is DeviceStratifiedSampler and "DeviceStratifiedSampler" in capsys.readouterr().err
     assert type(Annchor(X, "euclidean", sampler="legacy", **cfg).sampler) is SimpleStratifiedSampler
     a.fit()
     b = Annchor(X, "euclidean", **cfg)
