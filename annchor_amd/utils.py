@@ -11,6 +11,7 @@ reference does -- that host path is what the north star calls the CPU baseline f
 user-supplied metrics; everything downstream of the metric still runs on the GPU.
 """
 import os
+import time
 from multiprocessing.context import TimeoutError
 
 import numpy as np
@@ -42,20 +43,85 @@ def get_function_from_input(func, func_kwargs):
     return f
 
 
+MIN_CHUNK = 32          # pairs per task at least: below that the pickling of the task outweighs the metric
+CHUNKS_PER_JOB = 4      # tasks per worker and call: slack for pairs of unequal cost
+
+
+def host_jobs():
+    """Worker processes of the host evaluator: every core (utils.py:152-175 uses CPU_COUNT), ANNCHOR_HOST_JOBS overrides."""
+    try:
+        return max(1, int(os.environ.get("ANNCHOR_HOST_JOBS", CPU_COUNT or 1)))
+    except ValueError:
+        return CPU_COUNT or 1
+
+
+def _take(X, idx):
+    """X[idx] for an array, a list of the members otherwise (what a task is handed: its own points, never all of X)."""
+    if isinstance(X, np.ndarray):
+        return X[idx]
+    return [X[int(i)] for i in idx]
+
+
+def _eval_chunk(f, xi, xj):
+    t = time.perf_counter()
+    out = np.array([f(a, b) for a, b in zip(xi, xj)], dtype=np.float64)
+    return out, time.perf_counter() - t
+
+
+WORKER_MIN_SECONDS = 0.05   # a worker process is started (tens of ms each under loky) only for at least this much metric time
+
+
 def get_exact_ijs_(f, parallel=True, verbose=False, backend="loky"):
-    """Host evaluator for arbitrary Python metrics: np.array([f(X[i], X[j]) for i, j in IJ])."""
+    """Host evaluator for arbitrary Python metrics: np.array([f(X[i], X[j]) for i, j in IJ]) (utils.py:110-177).
+
+    Same signature, backends and result as the reference's; what differs is the unit of submission.  The reference hands
+    joblib one task per PAIR (utils.py:152-175): every evaluation then pays the pickling of f and two points, a queue
+    round trip and a future, and its pool is always one process per core (measured with that form here: 240
+    evaluations/s on 256 cores for a Levenshtein callable, ~15 s of it loky starting 256 workers).  This evaluator
+    submits CHUNKS -- ceil(len(IJ) / (4 n_jobs)) pairs, at least MIN_CHUNK -- each carrying only the points of its own
+    pairs, and sizes the pool by the work: the cost of one evaluation is known from the first call on (its first two
+    pairs are evaluated on the calling thread; afterwards every chunk reports its time), and a call uses
+    ceil(metric seconds / WORKER_MIN_SECONDS) workers, never fewer than an earlier call of the same evaluator did (loky
+    grows a pool in place; shrinking it would restart workers) and never more than the cores / the chunks.  The
+    per-task timeout grows with the chunk (30 s for the constructor's 20-pair probe, as in the reference, so a pool that
+    does not come up is still reported)."""
     if not parallel:
         def get_exact(f, X, IJ):
             return np.array([f(X[i], X[j]) for i, j in IJ], dtype=np.float64)
         return get_exact
 
+    state = {"t_pair": None, "workers": 2}
+
     def get_exact(f, X, IJ):
         from joblib import Parallel, delayed
-        if len(IJ) == 0:
+        IJ = np.asarray(IJ)
+        n = len(IJ)
+        if n == 0:
             return np.zeros(0)
-        return np.array(Parallel(n_jobs=CPU_COUNT, backend=backend, timeout=30)(
-            delayed(f)(X[i], X[j]) for i, j in IJ), dtype=np.float64)
+        IJ = IJ.reshape(n, 2)
+        head = []
+        if state["t_pair"] is None and n > 4:
+            t = time.perf_counter()
+            head = [f(X[i], X[j]) for i, j in IJ[:2]]
+            state["t_pair"] = (time.perf_counter() - t) / 2
+        rest = IJ[len(head):]
+        m = len(rest)
+        jobs = host_jobs()
+        if state["t_pair"] is not None:
+            state["workers"] = max(state["workers"], min(jobs, int(np.ceil(m * state["t_pair"] / WORKER_MIN_SECONDS))))
+        workers = min(jobs, state["workers"]) if state["t_pair"] is not None else jobs
+        chunk = max(MIN_CHUNK, -(-m // (CHUNKS_PER_JOB * workers)))
+        if chunk >= m and m >= 2:
+            chunk = -(-m // 2)      # (two tasks at least: the pool itself is exercised, see test_parallelisation)
+        cuts = list(range(0, m, chunk))
+        parts = Parallel(n_jobs=max(1, min(workers, len(cuts))), backend=backend, timeout=max(30.0, 0.25 * chunk))(
+            delayed(_eval_chunk)(f, _take(X, rest[c:c + chunk, 0]), _take(X, rest[c:c + chunk, 1])) for c in cuts)
+        spent = sum(p[1] for p in parts)
+        if m:
+            state["t_pair"] = spent / m if state["t_pair"] is None else 0.5 * (state["t_pair"] + spent / m)
+        return np.concatenate([np.asarray(head, dtype=np.float64)] + [p[0] for p in parts])
 
+    get_exact.state = state
     return get_exact
 
 

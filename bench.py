@@ -693,33 +693,59 @@ def c4_block(local):
     return res
 
 
-def cpu_baseline_python_metric_leg(X, local, n=160):
-    """CPU baseline #2 (BASELINE.md section 3 / configs[0] "plumbing"): Annchor(X, python_callable) -- the
-    metric is an arbitrary Python function evaluated on the HOST through the joblib get_exact_ijs
-    (reference utils.py:152-175), everything downstream of it on the GPU.  Bounded sample: the first
-    n strings (a pure-Python Levenshtein costs ~25 ms per pair of 500-symbol strings), all cores."""
+def py_myers_levenshtein(a, b):
+    """A user-style Python metric: Myers / Hyyro bit-vector edit distance on Python's big integers (pattern a as one
+    len(a)-bit integer, one step per symbol of b; ~0.5 ms per pair of 500-symbol strings -- the textbook two-row DP in
+    pure Python costs ~60 ms per pair, which would make configs[0] at N = 1600 a 40 s leg on 256 cores)."""
+    m = len(a)
+    if m == 0:
+        return float(len(b))
+    peq = {}
+    for i, ch in enumerate(a):
+        peq[ch] = peq.get(ch, 0) | (1 << i)
+    mask = (1 << m) - 1
+    top = 1 << (m - 1)
+    pv, mv, score = mask, 0, m
+    for ch in b:
+        eq = peq.get(ch, 0)
+        xv = eq | mv
+        xh = (((eq & pv) + pv) ^ pv) | eq
+        ph = mv | (~(xh | pv) & mask)
+        mh = pv & xh
+        if ph & top:
+            score += 1
+        elif mh & top:
+            score -= 1
+        ph = ((ph << 1) | 1) & mask
+        mh = (mh << 1) & mask
+        pv = mh | (~(xv | ph) & mask)
+        mv = ph & xv
+    return float(score)
+
+
+def cpu_baseline_python_metric_leg(X, local, n=None):
+    """CPU baseline #2 (BASELINE.md section 3 / configs[0] "plumbing"): Annchor(X, python_callable) at configs[0] AS WRITTEN
+    (load_strings, N = 1600, n_anchors = 15, k = 25, p_work = 0.12: 158 626 metric evaluations) -- the metric is an arbitrary
+    Python function evaluated on the HOST through the chunked joblib get_exact_ijs (annchor_amd/utils.py; the reference's
+    per-pair form: utils.py:152-175), everything downstream of it on the GPU."""
     from annchor_amd import Annchor
 
-    def py_lev(a, b):   # textbook two-row DP
-        prev = list(range(len(b) + 1))
-        for i, ca in enumerate(a, 1):
-            cur = [i]
-            for j, cb in enumerate(b, 1):
-                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
-            prev = cur
-        return float(prev[-1])
-
-    Xs = np.array(list(X[:: max(1, len(X) // n)][:n]))
-    cfg = dict(n_anchors=6, n_neighbors=8, n_samples=300, p_work=0.3, random_seed=42)
+    Xs = np.array(list(X if n is None else X[:: max(1, len(X) // n)][:n]))
+    cfg = dict(n_anchors=15, n_neighbors=25, n_samples=5000, p_work=0.12, random_seed=42) if n is None else \
+        dict(n_anchors=6, n_neighbors=8, n_samples=300, p_work=0.3, random_seed=42)
     t = time.perf_counter()
-    ann = Annchor(Xs, py_lev, device=local, **cfg)
+    ann = Annchor(Xs, py_myers_levenshtein, device=local, **cfg)
+    t_ctor = time.perf_counter() - t
     ann.fit()
     dt = time.perf_counter() - t
     dev = Annchor(Xs, "levenshtein", device=local, **cfg).fit()
-    same = bool(np.array_equal(ann.neighbor_graph[1], dev.neighbor_graph[1]))
-    return {"value": ann.evals / dt, "unit": "metric evaluations/s", "fit_time_s": dt, "evals": int(ann.evals), "cores": int(os.cpu_count()),
-            "kind": "port", "sample": "Annchor(X[:%d strings], python Levenshtein callable) incl. constructor: host metric via joblib "
-                                      "(loky, all cores), pipeline on the GPU" % len(Xs),
+    same = bool(np.array_equal(ann.neighbor_graph[1], dev.neighbor_graph[1]) and np.array_equal(ann.neighbor_graph[0], dev.neighbor_graph[0]))
+    st = getattr(ann.get_exact_ijs, "state", {})
+    return {"value": ann.evals / dt, "unit": "metric evaluations/s", "fit_time_s": dt, "constructor_s": t_ctor, "evals": int(ann.evals),
+            "cores": int(os.cpu_count()), "workers_used": int(st.get("workers", 0)), "metric_s_per_pair": st.get("t_pair"),
+            "kind": "port", "sample": "Annchor(load_strings X[:%d], python big-integer Myers Levenshtein callable, n_anchors=%d k=%d p_work=%g) "
+                                      "incl. constructor and pool start: host metric via chunked joblib (loky), pipeline on the GPU"
+                                      % (len(Xs), cfg["n_anchors"], cfg["n_neighbors"], cfg["p_work"]),
             "graph_equals_device_metric_run": same}
 
 
