@@ -512,7 +512,7 @@ def strings_run(args, steps, warmup, world, rank, local, dist, torch, all_cpus, 
             "ms_per_step": ms_per_step,
             "fit_time_s": ms_per_step / 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "n/a" if world == 1 else "weak",   # (one GPU: nothing scales; N > 1 replicas: per-GPU work fixed)
             "vs_baseline": None,
             "dtype": "int32 bit-vectors (Levenshtein) + f64 (bounds/regression/selection)",
             "data": "reference fixture (annchor/data/edit_data.npz: 1600 synthetic strings, length 378-594)",
@@ -783,12 +783,6 @@ def main():
         res = cpu_baseline_python_metric_leg(load_strings()["X"], int(sys.argv[2]))
         print(json.dumps(res), flush=True)
         return
-    # stdout carries the JSON line and nothing else: the library mirrors the reference's print() notices ("Increasing p_work ...",
-    # the note about point sets beyond the complete pair list), so file descriptor 1 is pointed at stderr for the rest of the run
-    global _REAL_STDOUT
-    _REAL_STDOUT = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
-    sys.stdout = sys.stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -811,6 +805,25 @@ def main():
                          "`--gpus 1 --workload euclid` prints the N > 1 headline fields for one GPU, the consistent N = 1 point of a "
                          "1 -> 8 curve")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: this process becomes the launcher of its N ranks (one per GPU, the command line the
+        # driver uses) and passes their ONE JSON line through
+        import socket
+        import subprocess
+
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+    # stdout carries the JSON line and nothing else: the library mirrors the reference's print() notices ("Increasing p_work ...",
+    # the note about point sets beyond the complete pair list), so file descriptor 1 is pointed at stderr for the rest of the run
+    global _REAL_STDOUT
+    _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
 
     import torch
 
@@ -920,7 +933,10 @@ def main():
             "dtype": "f32 rows; tile selection on fp16 hi + lo split operands with f32 accumulation (v_mfma_f32_32x32x16_f16: products to 2^-22 |x||y|, the accuracy of the f32 MFMA stream), the kept "
                      "columns re-ranked by exact f32 distances; reported distances exact f32, widened to f64",
             "data": "synthetic (SURVEY.md 8d recipe: 8-d latent manifold in 128-d, float32), generated per shard",
-            "config": {"workload": res["workload"], "total_rows": n_per_rank * world, "baseline_quoted_on": quoted,
+            "config": {"workload": res["workload"] + ("" if world == 1 and args.workload == "euclid" else
+                                                      " -- NOT the --gpus 1 default workload (configs[1] strings, which does not shard): the "
+                                                      "one-GPU point of THIS curve is value_single_gpu_same_workload, or `--gpus 1 --workload euclid`"),
+                       "total_rows": n_per_rank * world, "baseline_quoted_on": quoted,
                        "parallelism": "one GPU" if world == 1 else
                                       "rows sharded N/G per GPU; every exchange on device buffers over RCCL: per anchor round one "
                                       "all-gather of (value, row id, coordinates); one all-gather of the raw rows (every rank then builds "
@@ -954,6 +970,9 @@ def main():
                 sa._engine.close()
             one = float(np.mean(ts[1:]))
             out["single_gpu_same_workload"] = {"fit_time_s": one, "value": 1.0 / one}
+            # ONE curve for a reader of SCALE_rNN.json: the same workload's one-GPU point, measured in this run, at top level (the plain
+            # `--gpus 1` line is another workload -- configs[1], which does not shard -- and must not be divided into this one)
+            out["value_single_gpu_same_workload"] = 1.0 / one
             out["speedup_vs_single_gpu"] = one / res["fit_time_s"]
             out["scaling_efficiency_vs_single_gpu"] = one / res["fit_time_s"] / world
             del Xall

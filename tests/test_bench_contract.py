@@ -42,9 +42,10 @@ def test_bench_two_ranks_sharing_the_gpu_headlines_the_row_sharded_build():
     sk.bind(("127.0.0.1", 0))
     port = sk.getsockname()[1]
     sk.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--share-gpu", "--euclid-rows", "200000"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+                        "--share-gpu", "--euclid-rows", "200000"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, lines
@@ -54,4 +55,29 @@ def test_bench_two_ranks_sharing_the_gpu_headlines_the_row_sharded_build():
     assert b["value"] > 0 and abs(b["value"] - 1e3 / b["ms_per_step"]) / b["value"] < 1e-6
     assert b["recall_at_k"] >= 0.9
     assert b["single_gpu_same_workload"]["fit_time_s"] > 0
+    assert abs(b["value_single_gpu_same_workload"] - 1.0 / b["single_gpu_same_workload"]["fit_time_s"]) < 1e-9
+    assert "NOT the --gpus 1 default workload" in b["config"]["workload"]
     assert b["strings_replicas"]["errors_vs_bruteforce"] <= 504
+
+
+@pytest.mark.gpu
+def test_bench_plain_shell_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2 --share-gpu --backend gloo` from a plain shell (no launcher, no WORLD_SIZE): the process
+    starts its two ranks itself and passes their one JSON line through."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--steps", "1",
+                        "--warmup", "1", "--euclid-rows", "100000"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["value"] > 0 and b["value_single_gpu_same_workload"] > 0
+
+
+def test_bench_self_launch_command_line():
+    """CPU: the launcher branch builds the driver's command line (torch.distributed.run, one process per GPU, 127.0.0.1) and is
+    taken only without WORLD_SIZE."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'args.gpus > 1 and "WORLD_SIZE" not in os.environ' in src
+    assert '"--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1"' in src
+    assert "assert args.gpus == world" in src   # (a launcher that was given another world size is still refused)
