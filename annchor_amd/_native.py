@@ -105,6 +105,10 @@ _SIGNATURES = {
     "annchor_stream_knn_begin": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                                 ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
     "annchor_stream_knn_join": (ctypes.c_int, [_vp, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
+    "annchor_stream_join_rev_begin": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
+    "annchor_stream_order_begin": (ctypes.c_int, [_vp, _i32, _i32, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
+    "annchor_stream_order_end": (ctypes.c_int, [_vp] + [ctypes.POINTER(_vp)] * 6 + [ctypes.POINTER(_i64), ctypes.POINTER(_i32),
+                                                                                       ctypes.POINTER(_i32)]),
     "annchor_stream_last_counts": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "annchor_stream_last_kernel": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_i64)]),
     "annchor_stream_budget": (ctypes.c_int, [_i32, _dbl, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
@@ -118,6 +122,7 @@ _SIGNATURES = {
     "annchor_stream_anchor_end": (ctypes.c_int, [_vp, _vp, _vp]),
     "annchor_stream_rows_begin": (ctypes.c_int, [_vp, _i32, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
     "annchor_stream_rows_end": (ctypes.c_int, [_vp, _i32, _vp]),
+    "annchor_stream_anchor_dists_begin": (ctypes.c_int, [_vp, _i32, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
     "annchor_stream_lists_all": (ctypes.c_int, [_vp, _i32, _i64, ctypes.POINTER(_vp)]),
     "annchor_stream_route_begin": (ctypes.c_int, [_vp, _i32, _vp, _vp, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "annchor_stream_route_recv": (ctypes.c_int, [_vp, _i64, ctypes.POINTER(_vp)]),
@@ -769,6 +774,22 @@ class Engine:
         names = ("Xs", "rs", "perm", "lo", "hi", "mid")
         return {k: p.value for k, p in zip(names, ptrs)}, n_pad.value, nt.value, dimp.value
 
+    def stream_order_begin(self, min_tiles, tile_begin, tile_count):
+        """The level sorts of the k-d order restricted to the caller's tile range; (device pointer of its slice of the order,
+        the all-gather target, bytes per rank)."""
+        ol, oa, nb = _vp(), _vp(), _i64()
+        self._chk(self.lib.annchor_stream_order_begin(self.h, int(min_tiles), int(tile_begin), int(tile_count), ctypes.byref(ol), ctypes.byref(oa),
+                                                      ctypes.byref(nb)))
+        return ol.value, oa.value, nb.value
+
+    def stream_order_end(self):
+        ptrs = [_vp() for _ in range(6)]
+        n_pad, nt, dimp = _i64(), _i32(), _i32()
+        self._chk(self.lib.annchor_stream_order_end(self.h, *[ctypes.byref(p) for p in ptrs], ctypes.byref(n_pad), ctypes.byref(nt),
+                                                    ctypes.byref(dimp)))
+        names = ("Xs", "rs", "perm", "lo", "hi", "mid")
+        return {k: p.value for k, p in zip(names, ptrs)}, n_pad.value, nt.value, dimp.value
+
     def stream_knn(self, ptrs, n_all, nt_all, n_anchors, dim_padded, tile_begin, tile_count, k, p_work, n_local=None, join_passes=0, join_extra=0,
                    out=None):
         """n_local given: graph rows come back in the bound shard's own row order ([n_local, k],
@@ -804,6 +825,13 @@ class Engine:
         lp, upd = _vp(), _i64()
         self._chk(self.lib.annchor_stream_knn_join(self.h, lists_all, int(per_pass), ctypes.byref(lp), ctypes.byref(upd)))
         return lp.value, upd.value
+
+    def stream_join_rev_begin(self, lists_all):
+        """Reverse neighbour lists of this rank's columns from the all-gathered lists; (device pointer of the slice -- inside the
+        gather target --, the gather target, bytes per rank)."""
+        rl, ra, nb = _vp(), _vp(), _i64()
+        self._chk(self.lib.annchor_stream_join_rev_begin(self.h, lists_all, ctypes.byref(rl), ctypes.byref(ra), ctypes.byref(nb)))
+        return rl.value, ra.value, nb.value
 
     def stream_knn_end(self, n_local=None):
         tile_count, k = self._knn_shape
@@ -868,6 +896,14 @@ class Engine:
         counts = _c(counts, np.int64)
         s, r, nb = _vp(), _vp(), _i64()
         self._chk(self.lib.annchor_stream_rows_begin(self.h, len(counts), _ptr(counts), ctypes.byref(s), ctypes.byref(r), ctypes.byref(nb)))
+        return s.value, r.value, nb.value
+
+    def stream_anchor_dists_begin(self, counts):
+        """Send / receive buffers and bytes per rank of the all-gather of the ranks' own anchor distances."""
+        counts = _c(counts, np.int64)
+        s, r, nb = _vp(), _vp(), _i64()
+        self._chk(self.lib.annchor_stream_anchor_dists_begin(self.h, len(counts), _ptr(counts), ctypes.byref(s), ctypes.byref(r),
+                                                             ctypes.byref(nb)))
         return s.value, r.value, nb.value
 
     def stream_rows_end(self, counts):

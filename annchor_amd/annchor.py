@@ -271,6 +271,8 @@ class Annchor:
                 self.get_exact_ijs = get_exact_ijs_(self.f, verbose=self.verbose, backend=backend)
             else:
                 self.get_exact_ijs = get_exact_ijs
+        if hasattr(self.get_exact_ijs, "state"):   # the built-in host evaluator sizes its pool by the evaluations ahead of it
+            self.get_exact_ijs.state["expected_pairs"] = int(self.p_work * self.N)
         test_parallelisation(self.get_exact_ijs, self.f, self.X, self.nx, backend, s=20)
         self.get_exact_query_ijs = None
         self._anchors_on_device = False
@@ -893,6 +895,8 @@ class BruteForce:
             self.get_exact_ijs = get_exact_ijs_(self.f, verbose=self.verbose, backend=backend)
         else:
             self.get_exact_ijs = get_exact_ijs
+        if hasattr(self.get_exact_ijs, "state"):
+            self.get_exact_ijs.state["expected_pairs"] = self.nx * (self.nx - 1) // 2
         test_parallelisation(self.get_exact_ijs, self.f, self.X, self.nx, backend, s=20)
 
     def fit(self, n_neighbors=None):

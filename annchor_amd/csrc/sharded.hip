@@ -229,8 +229,42 @@ extern "C" int annchor_stream_rows_begin(annchor_ctx *c, int32_t world, const in
     return ANNCHOR_OK;
 }
 
+// The anchor distances of this rank's rows -- the max-min sweeps left them in D [na][n_local] -- on their way to every
+// rank: *send float [na][most] (D itself when the shard is the largest, a padded copy otherwise), *recv float
+// [world][na][most]; the host all-gathers *bytes_per_rank bytes.  This is the "all-gather of anchor feature vectors":
+// annchor_stream_rows_end then assembles D [na][total] from the gathered slices instead of recomputing the distances
+// of every rank's rows on every rank.  Call between the anchor rounds and annchor_stream_rows_end.
+extern "C" int annchor_stream_anchor_dists_begin(annchor_ctx *c, int32_t world, const int64_t *counts, void **send, void **recv,
+                                                 int64_t *bytes_per_rank)
+{
+    if (!c || !counts || !send || !recv || !bytes_per_rank) return ANNCHOR_EINVAL;
+    StreamState *s = ann_stream_state(c, false);
+    ANN_REQUIRE(c, s && s->n_local > 0 && s->na > 0 && s->D.p, ANNCHOR_ESTATE, "anchor rounds first");
+    ANN_REQUIRE(c, world >= 1 && world <= SH_MAX_WORLD, ANNCHOR_ELIMIT, "1 <= world <= %d", SH_MAX_WORLD);
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    int64_t most = 0;
+    for (int r = 0; r < world; ++r) most = std::max(most, counts[r]);
+    ANN_REQUIRE(c, s->n_local <= most, ANNCHOR_EINVAL, "this rank's shard (%lld rows) is larger than every count", (long long)s->n_local);
+    const size_t bytes = sizeof(float) * (size_t)s->na * (size_t)most;
+    ANN_TRY(ann_stream_reserve(c, s->D_recv, bytes * (size_t)world));
+    if (s->n_local == most) {
+        *send = s->D.p;
+    } else {
+        ANN_TRY(ann_stream_reserve(c, s->D_send, bytes));
+        ANN_CHECK_HIP(c, hipMemsetAsync(s->D_send.p, 0, bytes, c->stream));
+        ANN_CHECK_HIP(c, hipMemcpy2DAsync(s->D_send.p, sizeof(float) * (size_t)most, s->D.p, sizeof(float) * (size_t)s->n_local,
+                                          sizeof(float) * (size_t)s->n_local, (size_t)s->na, hipMemcpyDeviceToDevice, c->stream));
+        *send = s->D_send.p;
+    }
+    s->D_gathered = true;
+    *recv = s->D_recv.p;
+    *bytes_per_rank = (int64_t)bytes;
+    return ANNCHOR_OK;
+}
+
 // After the all-gather: the context takes ALL rows (rank order, padding dropped; global_base 0 -- rows are numbered by
-// their position in the concatenation) and recomputes their anchor distances from the anchors it already holds.
+// their position in the concatenation).  Their anchor distances: assembled from the ranks' gathered slices
+// (annchor_stream_anchor_dists_begin), or -- a host that did not exchange them -- recomputed from the anchors every rank holds.
 extern "C" int annchor_stream_rows_end(annchor_ctx *c, int32_t world, const int64_t *counts)
 {
     if (!c || !counts) return ANNCHOR_EINVAL;
@@ -261,6 +295,25 @@ extern "C" int annchor_stream_rows_end(annchor_ctx *c, int32_t world, const int6
     s->base = 0;
     c->nx = total;
     ANN_TRY(ann_stream_reserve(c, s->runmin, sizeof(float) * (size_t)total));
+    static const bool recompute = getenv("ANNCHOR_SH_RECOMPUTE_D") && atoi(getenv("ANNCHOR_SH_RECOMPUTE_D")) != 0;
+    const bool gathered = s->D_gathered && !recompute;
+    s->D_gathered = false;
+    if (gathered) {
+        // D_recv [world][na][most] -> D [na][total]: one strided copy per rank (the send buffer may be D itself: the
+        // all-gather has read it by now -- stream order -- so D can be re-reserved)
+        ANN_TRY(ann_stream_reserve(c, s->D, sizeof(float) * (size_t)s->na * (size_t)total));
+        ProfScope ps(c, "stream_anchor_dists_assemble", (double)total * s->na * 8.0);
+        int64_t at = 0;
+        for (int r = 0; r < world; ++r) {
+            if (counts[r])
+                ANN_CHECK_HIP(c, hipMemcpy2DAsync(s->D.as<float>() + at, sizeof(float) * (size_t)total,
+                                                  s->D_recv.as<float>() + (size_t)r * s->na * (size_t)most, sizeof(float) * (size_t)most,
+                                                  sizeof(float) * (size_t)counts[r], (size_t)s->na, hipMemcpyDeviceToDevice, c->stream));
+            at += counts[r];
+        }
+        ANN_CHECK_HIP(c, hipGetLastError());
+        return ANNCHOR_OK;
+    }
     ANN_TRY(ann_stream_reserve(c, s->D, sizeof(float) * (size_t)s->na * (size_t)total));
     {
         ProfScope ps(c, "stream_all_anchor_distances", (double)total * (s->dim * 4.0 + s->na * 4.0));

@@ -52,7 +52,7 @@ struct StreamState {
     DevBuf eval_bits;         // uint32 [tile_count][ceil(nt_all / 32)]: column tiles the tile phase evaluated, per row tile
     DevBuf out_d2b, out_colb; // second list buffers: a join pass reads the old lists of ALL rows and writes new ones
     DevBuf ucand, ucount;     // uint32 [tile_count][JN_CAP] / int32 [tile_count]: join candidates per row tile
-    DevBuf rev_cnt, rev_ptr, rev_edges, rev;   // reverse neighbour lists of every ordered row (join passes)
+    DevBuf rev_cnt, rev_ptr, rev_edges;   // scratch of the reverse neighbour lists (join passes): counts, CSR pointers, edge records of the own columns
     int64_t n_local = 0, n_pad = 0, base = 0;
     int64_t last_tile_evals = 0, last_join_chunks = 0;
     int last_kernel = 0;   // tile phase of the last build: 0 k_st_knn (exact f32), 1 k_st_knnbf (split fp16)
@@ -69,6 +69,13 @@ struct StreamState {
     DevBuf rows_send, rows_recv, rows_all;   // raw-row exchange: padded shard, [world][most][dim], compacted [n_total][dim]
     DevBuf lists_all;  // int32 [n_all][K]: every rank's neighbour lists (all-gather target of the join passes)
     DevBuf route_tab, route_cnt, route_slot, route_send, route_recv;   // finished rows on their way to their owners
+    DevBuf order_all;  // uint32 [n_pad]: the ranks' slices of the k-d order (all-gather target of annchor_stream_order_begin)
+    uint32_t *order_cur = nullptr;     // the order buffer annchor_stream_order_begin finished in (vals or vals2)
+    int order_tile_begin = 0, order_tile_count = 0;
+    DevBuf rev_all;    // int32 [n_all][JN_RK]: the ranks' reverse-list slices (all-gather target of annchor_stream_join_rev_begin)
+    bool rev_gathered = false;         // rev_all holds the reverse lists of the lists the next join pass is given
+    DevBuf D_send, D_recv;   // float [na][most] / [world][na][most]: anchor distances of the own rows on their way to every rank
+    bool D_gathered = false;
     int64_t own_base = 0, own_n = 0;   // the shard this context was bound to before it took every rank's rows
     int64_t emit_rows = 0;             // rows of emit_idx / emit_dist (own_n padded to the largest shard)
     int emit_k = 0;

@@ -49,9 +49,9 @@ void ann_stream_release(annchor_ctx *c)
             DevBuf *bufs[] = {&s->X, &s->keys, &s->keys2, &s->vals, &s->vals2, &s->cubtmp, &s->Xs, &s->rs, &s->perm, &s->lo,
                               &s->hi, &s->mid, &s->avec, &s->runmin, &s->red_val, &s->red_idx, &s->D, &s->out_d2, &s->out_col, &s->evals,
                               &s->scr_key, &s->scr_lb, &s->emit_idx, &s->emit_dist, &s->Dt, &s->eval_bits, &s->out_d2b, &s->out_colb,
-                              &s->ucand, &s->ucount, &s->rev_cnt, &s->rev_ptr, &s->rev_edges, &s->rev, &s->cand, &s->cand_all, &s->avecs, &s->A_dev,
+                              &s->ucand, &s->ucount, &s->rev_cnt, &s->rev_ptr, &s->rev_edges, &s->cand, &s->cand_all, &s->avecs, &s->A_dev,
                               &s->rows_send, &s->rows_recv, &s->rows_all, &s->lists_all, &s->route_tab, &s->route_cnt, &s->route_slot,
-                              &s->route_send, &s->route_recv, &s->Xb, &s->rsb, &s->cvec};
+                              &s->route_send, &s->route_recv, &s->Xb, &s->rsb, &s->cvec, &s->order_all, &s->rev_all, &s->D_send, &s->D_recv};
             for (DevBuf *b : bufs)
                 if (b->p && !b->in_arena) ann_dev_free(c, b->p, b->cap);
             ann_stream_free_run(s);
@@ -232,7 +232,7 @@ extern "C" int annchor_stream_get_row(annchor_ctx *c, int64_t local_idx, float *
 // is sorted along the anchor coordinate on which its points spread most, so that after
 // ceil(log2(#tiles)) levels each 128-row tile is a small box in several anchor coordinates:
 // tight [lo, hi] intervals, hence strong triangle bounds between tiles.
-__device__ __forceinline__ int st_seg_of(int64_t p, int64_t n, int level) { return (int)((p << level) / n); }
+__host__ __device__ __forceinline__ int st_seg_of(int64_t p, int64_t n, int level) { return (int)((p << level) / n); }
 
 // point-major copy of the anchor distances: a point's whole anchor vector is one contiguous
 // (16-byte aligned) run, so the per-level gathers through `order` touch one or two cache lines
@@ -255,10 +255,10 @@ __global__ void k_st_transpose_D(const float *__restrict__ D, int64_t n, int na,
 #define ST_SPLIT_SAMPLE 2048
 #endif
 __global__ __launch_bounds__(1024) void k_st_split_coord(const float *__restrict__ Dt, int nap, const uint32_t *__restrict__ order,
-                                                       int64_t n, int na, int level, int32_t *__restrict__ coord)
+                                                       int64_t n, int na, int level, int seg0, int32_t *__restrict__ coord)
 {
     __shared__ double s1[1024], s2[1024];
-    const int sgm = blockIdx.x;
+    const int sgm = seg0 + blockIdx.x;
     const int64_t b = ((int64_t)sgm * n + (1ll << level) - 1) >> level, e = ((int64_t)(sgm + 1) * n + (1ll << level) - 1) >> level;
     const int64_t len = e - b;
     const int A = nap <= 32 ? 32 : 64;        // anchors per sample lane group (na <= 64)
@@ -294,10 +294,10 @@ __global__ __launch_bounds__(1024) void k_st_split_coord(const float *__restrict
 }
 
 __global__ void k_st_level_keys(const float *__restrict__ D, const uint32_t *__restrict__ order, int64_t n, int level,
-                                const int32_t *__restrict__ coord, unsigned long long *__restrict__ keys)
+                                const int32_t *__restrict__ coord, unsigned long long *__restrict__ keys, int64_t p0, int64_t p1)
 {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
+    const int64_t p = p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= p1) return;
     const int sgm = st_seg_of(p, n, level);
     const float v = D[(size_t)coord[sgm] * n + order[p]];
     keys[p] = ((unsigned long long)sgm << 32) | (unsigned long long)__float_as_uint(v);
@@ -498,14 +498,27 @@ static int st_radix_sort_pairs(annchor_ctx *c, uint32_t *cnt, unsigned long long
     return ANNCHOR_OK;
 }
 
-// Order the local rows by (nearest anchor, distance to it), build the tile-ordered copies
-// and the per-tile anchor-distance intervals.  Returns device pointers so that a
-// multi-GPU host can all-gather them (single GPU: hand them straight back to
-// annchor_stream_knn).
-extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs, void **rs, void **perm, void **lo, void **hi,
-                                    void **mid, int64_t *n_pad, int32_t *n_tiles, int32_t *dim_padded)
+// Order the bound rows into 128-row tiles of the k-d order and build the tile-ordered copies and the per-tile
+// anchor-distance intervals.  Two steps, so that a row-sharded run orders only what it owns:
+//
+//   annchor_stream_order_begin(min_tiles, tile_begin, tile_count)   the level sorts, restricted at every level to the
+//       segments that intersect the caller's tile range: level l cuts the order into 2^l equal position ranges, the
+//       ranges are nested, so the rows of the caller's positions [tile_begin, tile_begin + tile_count) x 128 at level
+//       l + 1 come out of the level-l segments that contain them and of nothing else.  A rank that owns 1 / G of the
+//       tiles sorts n / G + (at most two segments: 2 n / 2^l) keys at level l instead of n: the sum over the levels is
+//       ~(levels / G + 2) n keys instead of levels x n.  The positions of its range -- and only those -- hold the final
+//       order; *order_local / *order_bytes describe that slice (uint32 [tile_count x 128], device) and *order_all the
+//       all-gather target (uint32 [n_tiles x 128]) a multi-rank host gathers the slices into (rank r's slice at
+//       r x tile_count x 128: the ranks own equal, contiguous tile ranges).  tile_count == n_tiles (one rank): the
+//       whole order, nothing to gather.
+//   annchor_stream_order_end()   gathers the rows into tile order (every rank holds every row as a column), the
+//       squared norms, the global ids, the tiles' anchor-distance intervals and the fp16 split copy.
+//
+// The tile structure is a function of the data alone: the same whatever the number of ranks.
+extern "C" int annchor_stream_order_begin(annchor_ctx *c, int32_t min_tiles, int32_t tile_begin, int32_t tile_count, void **order_local,
+                                          void **order_all, int64_t *order_bytes)
 {
-    if (!c || !Xs || !rs || !perm || !lo || !hi || !mid || !n_pad || !n_tiles || !dim_padded) return ANNCHOR_EINVAL;
+    if (!c || !order_local || !order_all || !order_bytes) return ANNCHOR_EINVAL;
     StreamState *s = state_of(c, false);
     ANN_REQUIRE(c, s && s->na > 0, ANNCHOR_EINVAL, "anchor rounds not run");
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
@@ -513,17 +526,17 @@ extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs
     s->nt = (int)((n + ST_T - 1) / ST_T);
     if (s->nt < min_tiles) s->nt = min_tiles;  // common tile count across ranks; extra tiles are pure padding
     s->n_pad = (int64_t)s->nt * ST_T;
+    if (tile_count <= 0) { tile_begin = 0; tile_count = s->nt; }
+    ANN_REQUIRE(c, tile_begin >= 0 && tile_begin + tile_count <= s->nt, ANNCHOR_EINVAL, "tile range [%d, %d) outside the %d tiles",
+                tile_begin, tile_begin + tile_count, s->nt);
+    ANN_REQUIRE(c, n < (1ll << 32), ANNCHOR_ELIMIT, "streamed ordering: %lld rows", (long long)n);
     ANN_TRY(sreserve(c, s->keys, 8 * (size_t)n));
     ANN_TRY(sreserve(c, s->keys2, 8 * (size_t)n));
-    ANN_TRY(sreserve(c, s->vals, 4 * (size_t)n));
-    ANN_TRY(sreserve(c, s->vals2, 4 * (size_t)n));
-    ANN_TRY(sreserve(c, s->Xs, sizeof(float) * (size_t)s->n_pad * s->dimp));
-    ANN_TRY(sreserve(c, s->rs, sizeof(float) * (size_t)s->n_pad));
-    ANN_TRY(sreserve(c, s->perm, sizeof(int64_t) * (size_t)s->n_pad));
-    ANN_TRY(sreserve(c, s->lo, sizeof(float) * (size_t)s->na * s->nt));
-    ANN_TRY(sreserve(c, s->hi, sizeof(float) * (size_t)s->na * s->nt));
-    ANN_TRY(sreserve(c, s->mid, sizeof(float) * (size_t)s->na * s->nt));
-    ProfScope ps(c, "stream_order_tiles", (double)n * (s->dim * 8.0 + s->na * 8.0 + 40.0));
+    ANN_TRY(sreserve(c, s->vals, 4 * (size_t)s->n_pad));    // (n_pad: a rank's slice may reach past the last row)
+    ANN_TRY(sreserve(c, s->vals2, 4 * (size_t)s->n_pad));
+    ANN_TRY(sreserve(c, s->order_all, 4 * (size_t)s->n_pad));
+    const int64_t pb = std::min<int64_t>((int64_t)tile_begin * ST_T, n), pe = std::min<int64_t>((int64_t)(tile_begin + tile_count) * ST_T, n);
+    ProfScope ps(c, "stream_order_tiles", (double)(pe - pb) * (s->na * 8.0 + 40.0));
     int levels = 0;
     while (((int64_t)ST_T << levels) < n) ++levels;   // segments end up <= one tile long
     const int max_seg = 1 << levels;
@@ -534,32 +547,73 @@ extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs
     const int nap = (s->na + 3) & ~3;
     ANN_TRY(sreserve(c, s->Dt, sizeof(float) * (size_t)n * nap));
     k_st_transpose_D<<<ann_blocks(n * nap, 256), 256, 0, c->stream>>>(s->D.as<float>(), n, s->na, nap, s->Dt.as<float>());
-    ANN_REQUIRE(c, n < (1ll << 32), ANNCHOR_ELIMIT, "streamed ordering: %lld rows", (long long)n);
     ANN_TRY(sreserve(c, s->cubtmp, sizeof(uint32_t) * 256 * ((size_t)((n + RS_TILE - 1) / RS_TILE) + 1)));
-    for (int level = 0; level < levels; ++level) {
-        const int nseg = 1 << level;
-        k_st_split_coord<<<nseg, 1024, 0, c->stream>>>(s->Dt.as<float>(), nap, cur, n, s->na, level, s->red_idx.as<int32_t>());
-        k_st_level_keys<<<ann_blocks(n, 256), 256, 0, c->stream>>>(s->D.as<float>(), cur, n, level, s->red_idx.as<int32_t>(),
-                                                                  s->keys.as<unsigned long long>());
-        // (segment, distance to the split anchor): stable sort = every segment ordered along its coordinate
+    for (int level = 0; level < levels && pe > pb; ++level) {
+        // the segments of this level that hold the positions [pb, pe): positions [lb, le)
+        const int seg_lo = st_seg_of(pb, n, level), seg_hi = st_seg_of(pe - 1, n, level);
+        const int64_t lb = ((int64_t)seg_lo * n + (1ll << level) - 1) >> level, le = ((int64_t)(seg_hi + 1) * n + (1ll << level) - 1) >> level;
+        k_st_split_coord<<<seg_hi - seg_lo + 1, 1024, 0, c->stream>>>(s->Dt.as<float>(), nap, cur, n, s->na, level, seg_lo, s->red_idx.as<int32_t>());
+        k_st_level_keys<<<ann_blocks(le - lb, 256), 256, 0, c->stream>>>(s->D.as<float>(), cur, n, level, s->red_idx.as<int32_t>(),
+                                                                        s->keys.as<unsigned long long>(), lb, le);
+        // (segment, distance to the split anchor): stable sort = every segment ordered along its coordinate.  The sort runs on
+        // the sub-arrays [lb, le): outside them the two order buffers drift apart, which no later level reads (nested ranges)
         int where = 0;
-        ANN_TRY(st_radix_sort_pairs(c, s->cubtmp.as<uint32_t>(), s->keys.as<unsigned long long>(), s->keys2.as<unsigned long long>(), cur,
-                                    nxt, n, 32 + level, &where));
+        ANN_TRY(st_radix_sort_pairs(c, s->cubtmp.as<uint32_t>(), s->keys.as<unsigned long long>() + lb, s->keys2.as<unsigned long long>() + lb,
+                                    cur + lb, nxt + lb, le - lb, 32 + level, &where));
         if (where) { uint32_t *t = cur; cur = nxt; nxt = t; }
     }
-    if (cur != s->vals2.as<uint32_t>())
-        ANN_CHECK_HIP(c, hipMemcpyAsync(s->vals2.p, cur, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
-    k_st_gather<<<ann_blocks(s->n_pad * 16, 256), 256, 0, c->stream>>>(s->X.as<float>(), s->vals2.as<uint32_t>(), n, s->n_pad,
-                                                                      s->dim, s->dimp, s->base, s->Xs.as<float>(),
-                                                                      s->rs.as<float>(), s->perm.as<int64_t>());
-    k_st_intervals<<<s->nt, ST_T, 0, c->stream>>>(s->D.as<float>(), s->vals2.as<uint32_t>(), n, s->na, s->nt, s->lo.as<float>(),
-                                                 s->hi.as<float>(), s->mid.as<float>());
-    if (s->dimp <= 128) ANN_TRY(ann_stream_split_rows(c, s));   // the fp16 hi / lo copy the tile kernel streams (knnbf.hip)
+    ANN_CHECK_HIP(c, hipGetLastError());
+    s->order_cur = cur;
+    s->order_tile_begin = tile_begin;
+    s->order_tile_count = tile_count;
+    *order_local = cur + (size_t)tile_begin * ST_T;
+    *order_all = s->order_all.p;
+    *order_bytes = (int64_t)sizeof(uint32_t) * tile_count * ST_T;
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_stream_order_end(annchor_ctx *c, void **Xs, void **rs, void **perm, void **lo, void **hi, void **mid, int64_t *n_pad,
+                                        int32_t *n_tiles, int32_t *dim_padded)
+{
+    if (!c || !Xs || !rs || !perm || !lo || !hi || !mid || !n_pad || !n_tiles || !dim_padded) return ANNCHOR_EINVAL;
+    StreamState *s = state_of(c, false);
+    ANN_REQUIRE(c, s && s->na > 0 && s->order_cur, ANNCHOR_ESTATE, "annchor_stream_order_begin first");
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    const int64_t n = s->n_local;
+    // the complete order: the context's own buffer (one rank: its range was everything) or the gathered slices
+    const uint32_t *order = s->order_tile_count == s->nt ? s->order_cur : s->order_all.as<uint32_t>();
+    s->order_cur = nullptr;
+    ANN_TRY(sreserve(c, s->Xs, sizeof(float) * (size_t)s->n_pad * s->dimp));
+    ANN_TRY(sreserve(c, s->rs, sizeof(float) * (size_t)s->n_pad));
+    ANN_TRY(sreserve(c, s->perm, sizeof(int64_t) * (size_t)s->n_pad));
+    ANN_TRY(sreserve(c, s->lo, sizeof(float) * (size_t)s->na * s->nt));
+    ANN_TRY(sreserve(c, s->hi, sizeof(float) * (size_t)s->na * s->nt));
+    ANN_TRY(sreserve(c, s->mid, sizeof(float) * (size_t)s->na * s->nt));
+    {
+        // every rank holds every row as a column: this part is per rank whatever the number of ranks
+        ProfScope ps(c, "stream_order_gather_rows", (double)n * (s->dim * 4.0 + s->dimp * 8.0 + s->na * 4.0 + 16.0));
+        k_st_gather<<<ann_blocks(s->n_pad * 16, 256), 256, 0, c->stream>>>(s->X.as<float>(), order, n, s->n_pad, s->dim, s->dimp, s->base,
+                                                                          s->Xs.as<float>(), s->rs.as<float>(), s->perm.as<int64_t>());
+        k_st_intervals<<<s->nt, ST_T, 0, c->stream>>>(s->D.as<float>(), order, n, s->na, s->nt, s->lo.as<float>(), s->hi.as<float>(),
+                                                     s->mid.as<float>());
+        if (s->dimp <= 128) ANN_TRY(ann_stream_split_rows(c, s));   // the fp16 hi / lo copy the tile kernel streams (knnbf.hip)
+    }
     ANN_CHECK_HIP(c, hipGetLastError());
     ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     *Xs = s->Xs.p; *rs = s->rs.p; *perm = s->perm.p; *lo = s->lo.p; *hi = s->hi.p; *mid = s->mid.p;
     *n_pad = s->n_pad; *n_tiles = s->nt; *dim_padded = s->dimp;
     return ANNCHOR_OK;
+}
+
+// both steps for a context that orders everything itself (one rank; queries)
+extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs, void **rs, void **perm, void **lo, void **hi,
+                                    void **mid, int64_t *n_pad, int32_t *n_tiles, int32_t *dim_padded)
+{
+    if (!c || !Xs || !rs || !perm || !lo || !hi || !mid || !n_pad || !n_tiles || !dim_padded) return ANNCHOR_EINVAL;
+    void *ol = nullptr, *oa = nullptr;
+    int64_t ob = 0;
+    ANN_TRY(annchor_stream_order_begin(c, min_tiles, 0, 0, &ol, &oa, &ob));
+    return annchor_stream_order_end(c, Xs, rs, perm, lo, hi, mid, n_pad, n_tiles, dim_padded);
 }
 
 // ------------------------------------------------------------------ k-NN
@@ -1172,33 +1226,36 @@ __device__ __forceinline__ void jn_sort64(unsigned long long *v, int P)
 }
 
 // ---- reverse neighbour lists: rev[c] = the (at most JN_RK) rows that list c, those that rank it
-// highest first (key = position in the lister's list, then the lister's index: deterministic)
-__global__ void k_st_rev_count(const int32_t *__restrict__ lists_all, int64_t n_edges, int32_t *__restrict__ cnt)
+// highest first (key = position in the lister's list, then the lister's index: deterministic).
+// Built for the columns [col0, col0 + ncols) only: every edge of every list is read (coalesced), the atomics, the
+// edge records and the selection are those of the own columns -- a rank of a row-sharded run builds the reverse
+// lists of the column range it owns and the ranks all-gather the slices (annchor_stream_join_rev_begin).
+__global__ void k_st_rev_count(const int32_t *__restrict__ lists_all, int64_t n_edges, int64_t col0, int64_t ncols, int32_t *__restrict__ cnt)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_edges) return;
-    const int32_t dst = lists_all[t];
-    if (dst != 0x7fffffff) atomicAdd(&cnt[dst], 1);
+    const int64_t dst = (int64_t)lists_all[t] - col0;
+    if (dst >= 0 && dst < ncols) atomicAdd(&cnt[dst], 1);      // (0x7fffffff = no entry: outside every range)
 }
 
-__global__ void k_st_rev_fill(const int32_t *__restrict__ lists_all, int64_t n_edges, int K, const int64_t *__restrict__ ptr,
-                              int32_t *__restrict__ cursor, unsigned long long *__restrict__ edges)
+__global__ void k_st_rev_fill(const int32_t *__restrict__ lists_all, int64_t n_edges, int K, int64_t col0, int64_t ncols,
+                              const int64_t *__restrict__ ptr, int32_t *__restrict__ cursor, unsigned long long *__restrict__ edges)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_edges) return;
-    const int32_t dst = lists_all[t];
-    if (dst == 0x7fffffff) return;
+    const int64_t dst = (int64_t)lists_all[t] - col0;
+    if (dst < 0 || dst >= ncols) return;
     const int64_t src = t / K;
     const int e = (int)(t - src * K);
     const int pos = atomicAdd(&cursor[dst], 1);
     edges[ptr[dst] + pos] = ((unsigned long long)e << 32) | (unsigned long long)src;
 }
 
-__global__ void k_st_rev_select(const int64_t *__restrict__ ptr, const unsigned long long *__restrict__ edges, int64_t n_all,
+__global__ void k_st_rev_select(const int64_t *__restrict__ ptr, const unsigned long long *__restrict__ edges, int64_t ncols,
                                 int32_t *__restrict__ rev)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_all) return;
+    if (c >= ncols) return;
     const int64_t b = ptr[c], e = ptr[c + 1];
     unsigned long long last = 0;
     bool first = true;
@@ -1655,6 +1712,34 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
     return ANNCHOR_OK;
 }
 
+// reverse lists of the columns [col0, col0 + ncols) from the lists of every ordered row: count, scan, fill, select (the
+// lists are short: K on average) -> out [col0 .. col0 + ncols)[JN_RK] of an int32 [n_all][JN_RK] buffer
+static int knn_reverse_lists(annchor_ctx *c, StreamState *s, const int32_t *lists_all, int64_t n_all, int K, int64_t col0, int64_t ncols,
+                             DevBuf &out)
+{
+    ProfScope ps(c, "stream_join_reverse_lists", (double)n_all * K * 8.0 + (double)ncols * K * 24.0);
+    const int64_t n_edges = n_all * K;
+    ANN_TRY(sreserve(c, out, sizeof(int32_t) * (size_t)n_all * JN_RK));
+    if (ncols <= 0) return ANNCHOR_OK;
+    ANN_TRY(sreserve(c, s->rev_cnt, sizeof(int32_t) * (size_t)(ncols + 1)));
+    ANN_TRY(sreserve(c, s->rev_ptr, sizeof(int64_t) * (size_t)(ncols + 1)));
+    // edges into the own columns: n_edges x ncols / n_all on average; a rank whose columns are listed more often than that
+    // (hubs) needs more, so the count pass decides
+    ANN_CHECK_HIP(c, hipMemsetAsync(s->rev_cnt.p, 0, sizeof(int32_t) * (size_t)(ncols + 1), c->stream));
+    k_st_rev_count<<<ann_blocks(n_edges, 256), 256, 0, c->stream>>>(lists_all, n_edges, col0, ncols, s->rev_cnt.as<int32_t>());
+    ANN_TRY(ann_exclusive_scan_i32_to_i64(c, s->rev_cnt.as<int32_t>(), s->rev_ptr.as<int64_t>(), ncols));   // ptr has ncols + 1 entries
+    int64_t own_edges = n_edges;
+    if (ncols < n_all) ANN_TRY(ann_d2h(c, &own_edges, s->rev_ptr.as<int64_t>() + ncols, sizeof(int64_t)));
+    ANN_TRY(sreserve(c, s->rev_edges, sizeof(unsigned long long) * (size_t)std::max<int64_t>(own_edges, 1)));
+    ANN_CHECK_HIP(c, hipMemsetAsync(s->rev_cnt.p, 0, sizeof(int32_t) * (size_t)(ncols + 1), c->stream));
+    k_st_rev_fill<<<ann_blocks(n_edges, 256), 256, 0, c->stream>>>(lists_all, n_edges, K, col0, ncols, s->rev_ptr.as<int64_t>(),
+                                                                  s->rev_cnt.as<int32_t>(), s->rev_edges.as<unsigned long long>());
+    k_st_rev_select<<<ann_blocks(ncols, 256), 256, 0, c->stream>>>(s->rev_ptr.as<int64_t>(), s->rev_edges.as<unsigned long long>(), ncols,
+                                                                  out.as<int32_t>() + (size_t)col0 * JN_RK);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
 // lists_all: current lists of every ordered row of every rank, int32 [n_all][K] (single rank: the
 // context's own list buffer).  The new lists replace the context's own (a.out_col / a.out_d2).
 static int knn_join_pass(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_padded, const int32_t *lists_all, int per_pass,
@@ -1673,29 +1758,15 @@ static int knn_join_pass(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pad
     a.lists_all = lists_all;
     a.ucand = s->ucand.as<uint32_t>(); a.ucount = s->ucount.as<int32_t>(); a.ucap = JN_CAP;
     a.out_d2_new = nd.as<float>(); a.out_col_new = nc.as<int32_t>();
-    {
-        // reverse lists of every ordered row: count, scan, fill, select (the lists are short: K on average)
-        ProfScope ps(c, "stream_join_reverse_lists", (double)n_all * K * 24.0);
-        const int64_t n_edges = n_all * K;
-        ANN_TRY(sreserve(c, s->rev_cnt, sizeof(int32_t) * (size_t)(n_all + 1)));
-        ANN_TRY(sreserve(c, s->rev_ptr, sizeof(int64_t) * (size_t)(n_all + 1)));
-        ANN_TRY(sreserve(c, s->rev_edges, sizeof(unsigned long long) * (size_t)n_edges));
-        ANN_TRY(sreserve(c, s->rev, sizeof(int32_t) * (size_t)n_all * JN_RK));
-        ANN_CHECK_HIP(c, hipMemsetAsync(s->rev_cnt.p, 0, sizeof(int32_t) * (size_t)(n_all + 1), c->stream));
-        k_st_rev_count<<<ann_blocks(n_edges, 256), 256, 0, c->stream>>>(lists_all, n_edges, s->rev_cnt.as<int32_t>());
-        ANN_TRY(ann_exclusive_scan_i32_to_i64(c, s->rev_cnt.as<int32_t>(), s->rev_ptr.as<int64_t>(), n_all));   // ptr has n_all + 1 entries
-        ANN_CHECK_HIP(c, hipMemsetAsync(s->rev_cnt.p, 0, sizeof(int32_t) * (size_t)(n_all + 1), c->stream));
-        k_st_rev_fill<<<ann_blocks(n_edges, 256), 256, 0, c->stream>>>(lists_all, n_edges, K, s->rev_ptr.as<int64_t>(),
-                                                                      s->rev_cnt.as<int32_t>(), s->rev_edges.as<unsigned long long>());
-        k_st_rev_select<<<ann_blocks(n_all, 256), 256, 0, c->stream>>>(s->rev_ptr.as<int64_t>(), s->rev_edges.as<unsigned long long>(),
-                                                                      n_all, s->rev.as<int32_t>());
-    }
+    if (!s->rev_gathered)      // one rank (or a host that does not gather the slices): the reverse lists of every column, here
+        ANN_TRY(knn_reverse_lists(c, s, lists_all, n_all, K, 0, n_all, s->rev_all));
+    s->rev_gathered = false;   // (they belong to THESE lists: the next pass builds its own)
     {
         ProfScope ps(c, "stream_join_candidates", (double)rows * (K + JN_RK) * 4.0 * (K + JN_RK + 1));
         const size_t lds = sizeof(uint32_t) * (JN_CAP + JN_B1 + 8);
         ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_join_cands, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int max_cols = std::max(1, std::min(per_pass * ST_T, JN_CAP));
-        k_st_join_cands<<<a.tile_count, ST_THREADS, lds, c->stream>>>(lists_all, s->rev.as<int32_t>(), K, a.tile_begin, a.eval_bits,
+        k_st_join_cands<<<a.tile_count, ST_THREADS, lds, c->stream>>>(lists_all, s->rev_all.as<int32_t>(), K, a.tile_begin, a.eval_bits,
                                                                       a.eval_words, max_cols, s->ucand.as<uint32_t>(),
                                                                       s->ucount.as<int32_t>());
     }
@@ -1891,6 +1962,28 @@ extern "C" int annchor_stream_knn_join(annchor_ctx *c, const void *lists_all, in
     ANN_TRY(knn_join_pass(c, s, *s->run, s->run_dimp, (const int32_t *)lists_all, per_pass, updates));
     ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     *lists_local = s->run->out_col;
+    return ANNCHOR_OK;
+}
+
+// Row-sharded join pass, first half: the reverse neighbour lists of THIS rank's columns (its tile range of the global
+// order) from the all-gathered lists.  *rev_local: int32 [tile_count x 128][JN_RK] (device; the rank's slice inside the
+// gather target), *rev_all: int32 [n_all][JN_RK], *rev_bytes: bytes per rank.  The host all-gathers the slices into
+// *rev_all (rank r's at r x *rev_bytes) and calls annchor_stream_knn_join with the same lists_all; without that call
+// the join pass builds every column's reverse list itself.
+extern "C" int annchor_stream_join_rev_begin(annchor_ctx *c, const void *lists_all, void **rev_local, void **rev_all, int64_t *rev_bytes)
+{
+    if (!c || !lists_all || !rev_local || !rev_all || !rev_bytes) return ANNCHOR_EINVAL;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    StreamState *s = state_of(c, false);
+    ANN_REQUIRE(c, s && s->run, ANNCHOR_ESTATE, "annchor_stream_knn_begin not called");
+    const KnnArgs &a = *s->run;
+    const int64_t n_all = (int64_t)a.nt_all * ST_T, col0 = (int64_t)a.tile_begin * ST_T, ncols = (int64_t)a.tile_count * ST_T;
+    ANN_TRY(knn_reverse_lists(c, s, (const int32_t *)lists_all, n_all, a.K, col0, ncols, s->rev_all));
+    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    s->rev_gathered = true;
+    *rev_local = s->rev_all.as<int32_t>() + (size_t)col0 * JN_RK;
+    *rev_all = s->rev_all.p;
+    *rev_bytes = (int64_t)sizeof(int32_t) * ncols * JN_RK;
     return ANNCHOR_OK;
 }
 

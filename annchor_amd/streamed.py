@@ -12,14 +12,16 @@ One process per GPU, rows sharded contiguously: rank r owns rows
                 vector is already there (no broadcast from its owner).
   exchange      ONE all-gather of the raw rows: every rank needs every row as a column anyway.
                 (RCCL over xGMI when the process group is `nccl`; staged through host memory otherwise.)
-  locality      every rank recomputes the anchor distances of all rows (it knows the anchors: no
-                collective) and orders ALL rows into 128-row tiles of a k-d order in anchor space with
-                per-anchor distance intervals -- the same tile structure whatever the number of ranks;
-                rank r owns a contiguous range of the global tile order.
+  features      ONE all-gather of the ranks' anchor distances (n_anchors floats per row: the sweeps of the
+                max-min rounds left them on the device) -- nothing is recomputed.
+  locality      the rows are ordered into 128-row tiles of a k-d order in anchor space with per-anchor
+                distance intervals -- the same tile structure whatever the number of ranks; rank r owns a
+                contiguous range of the global tile order and sorts, level by level, only the segments
+                that hold its range; ONE all-gather of the order's slices (4 bytes per row).
   refine+top-k  each rank evaluates its own row tiles against the column tiles that its
                 triangle bound cannot exclude (MFMA tile GEMM + in-LDS top-k), within the
                 p_work tile budget; then the join passes, each after an all-gather of the ranks'
-                current neighbour lists.
+                current neighbour lists and of the reverse lists of the columns each rank owns.
   result        the finished rows go back to the ranks that own them (all-to-all); each rank holds
                 the graph rows of its shard; `gather_graph()` assembles the full graph on every rank.
 
@@ -47,7 +49,8 @@ class SingleComm:
         return np.asarray(values, dtype=np.float64)[None, :]
 
     def allgather_into(self, engine, src, dst, nbytes):
-        engine.device_copy(dst, src, nbytes, "d2d")
+        if src != dst:     # (an in-place gather of one rank's slice is already where it belongs)
+            engine.device_copy(dst, src, nbytes, "d2d")
 
     def alltoall_records(self, engine, send, send_counts, words):
         n = int(send_counts[0])
@@ -335,10 +338,19 @@ class StreamedAnnchor:
             # tile's cell G times larger -- recall at N = 400 000 fell from 0.990 (1 rank) to 0.968 (2) and 0.942 (4).
             send, recv, nbytes = eng.stream_rows_begin(counts)
             comm.allgather_into(eng, send, recv, nbytes)
+            # the anchor distances of the own rows (the max-min sweeps left them on the device): ONE all-gather of
+            # n_anchors floats per row instead of every rank recomputing every row's
+            send, recv, nbytes = eng.stream_anchor_dists_begin(counts)
+            comm.allgather_into(eng, send, recv, nbytes)
             eng.stream_rows_end(counts)
             tiles_per_rank = -(-((self.n_total + TILE - 1) // TILE) // comm.world)
-            ptrs, n_pad, nt, dimp = eng.stream_order(tiles_per_rank * comm.world)
             tile_begin, tile_count = comm.rank * tiles_per_rank, tiles_per_rank
+            # the k-d order: a rank sorts, level by level, only the segments that hold its own tile range; the slices of the
+            # order (4 bytes per row) are all-gathered and every rank gathers the rows into tile order (it holds every row
+            # as a column anyway)
+            send, recv, nbytes = eng.stream_order_begin(tiles_per_rank * comm.world, tile_begin, tile_count)
+            comm.allgather_into(eng, send, recv, nbytes)
+            ptrs, n_pad, nt, dimp = eng.stream_order_end()
         else:
             ptrs, n_pad, nt, dimp = eng.stream_order(0)
             tile_begin, tile_count = 0, nt
@@ -359,6 +371,9 @@ class StreamedAnnchor:
                 if p >= self.join_passes and tile_budget + (p + 1) * max(per_pass, 1) > total:
                     break      # the budget has no room for another pass
                 comm.allgather_into(eng, lists, lists_all, nbytes)
+                # reverse neighbour lists: each rank builds those of the columns it owns, the slices are all-gathered in place
+                rev, rev_all, rbytes = eng.stream_join_rev_begin(lists_all)
+                comm.allgather_into(eng, rev, rev_all, rbytes)
                 lists, upd = eng.stream_knn_join(lists_all, max(per_pass, 1))
                 # every rank takes the same decision: the yield of the pass summed over ranks
                 if p + 1 >= self.join_passes and comm.allgather_small((upd,)).sum() <= floor_updates:

@@ -68,7 +68,7 @@ def _eval_chunk(f, xi, xj):
     return out, time.perf_counter() - t
 
 
-WORKER_MIN_SECONDS = 0.05   # a worker process is started (tens of ms each under loky) only for at least this much metric time
+WORKER_SPAWN_SECONDS = 0.05   # what one more loky worker costs the parent (measured: 256 workers ~12.8 s)
 
 
 def get_exact_ijs_(f, parallel=True, verbose=False, backend="loky"):
@@ -80,9 +80,12 @@ def get_exact_ijs_(f, parallel=True, verbose=False, backend="loky"):
     evaluations/s on 256 cores for a Levenshtein callable, ~15 s of it loky starting 256 workers).  This evaluator
     submits CHUNKS -- ceil(len(IJ) / (4 n_jobs)) pairs, at least MIN_CHUNK -- each carrying only the points of its own
     pairs, and sizes the pool by the work: the cost of one evaluation is known from the first call on (its first two
-    pairs are evaluated on the calling thread; afterwards every chunk reports its time), and a call uses
-    ceil(metric seconds / WORKER_MIN_SECONDS) workers, never fewer than an earlier call of the same evaluator did (loky
-    grows a pool in place; shrinking it would restart workers) and never more than the cores / the chunks.  The
+    pairs are evaluated on the calling thread; afterwards every chunk reports its time), and w workers cost
+    w x WORKER_SPAWN_SECONDS to start and finish T seconds of metric in T / w, so a call uses sqrt(T / spawn) of them --
+    T = the evaluations still expected (`state["expected_pairs"]`: Annchor sets it to its budget p_work N; this call's
+    pairs otherwise) -- never fewer than an earlier call of the same evaluator did (loky grows a pool in place;
+    shrinking it would restart workers) and never more than the cores / the chunks.  With 256 workers for every call
+    the same fit spent 12 of its 14 s starting processes.  The
     per-task timeout grows with the chunk (30 s for the constructor's 20-pair probe, as in the reference, so a pool that
     does not come up is still reported)."""
     if not parallel:
@@ -90,7 +93,7 @@ def get_exact_ijs_(f, parallel=True, verbose=False, backend="loky"):
             return np.array([f(X[i], X[j]) for i, j in IJ], dtype=np.float64)
         return get_exact
 
-    state = {"t_pair": None, "workers": 2}
+    state = {"t_pair": None, "workers": 2, "expected_pairs": 0, "done": 0}
 
     def get_exact(f, X, IJ):
         from joblib import Parallel, delayed
@@ -108,7 +111,8 @@ def get_exact_ijs_(f, parallel=True, verbose=False, backend="loky"):
         m = len(rest)
         jobs = host_jobs()
         if state["t_pair"] is not None:
-            state["workers"] = max(state["workers"], min(jobs, int(np.ceil(m * state["t_pair"] / WORKER_MIN_SECONDS))))
+            horizon = max(m, state["expected_pairs"] - state["done"]) * state["t_pair"]
+            state["workers"] = max(state["workers"], min(jobs, int(np.ceil(np.sqrt(horizon / WORKER_SPAWN_SECONDS)))))
         workers = min(jobs, state["workers"]) if state["t_pair"] is not None else jobs
         chunk = max(MIN_CHUNK, -(-m // (CHUNKS_PER_JOB * workers)))
         if chunk >= m and m >= 2:
@@ -116,6 +120,7 @@ def get_exact_ijs_(f, parallel=True, verbose=False, backend="loky"):
         cuts = list(range(0, m, chunk))
         parts = Parallel(n_jobs=max(1, min(workers, len(cuts))), backend=backend, timeout=max(30.0, 0.25 * chunk))(
             delayed(_eval_chunk)(f, _take(X, rest[c:c + chunk, 0]), _take(X, rest[c:c + chunk, 1])) for c in cuts)
+        state["done"] += n
         spent = sum(p[1] for p in parts)
         if m:
             state["t_pair"] = spent / m if state["t_pair"] is None else 0.5 * (state["t_pair"] + spent / m)

@@ -362,6 +362,17 @@ int annchor_stream_anchor_round(annchor_ctx *ctx, const float *anchor_vec, int32
 int annchor_stream_get_row(annchor_ctx *ctx, int64_t local_idx, float *out);
 int annchor_stream_order(annchor_ctx *ctx, int32_t min_tiles, void **Xs, void **rs, void **perm, void **lo, void **hi,
                          void **mid, int64_t *n_pad, int32_t *n_tiles, int32_t *dim_padded);
+/* The ordering in two steps, for row-sharded runs (no reference counterpart: annchor/utils.py:494-540 materialises every
+ * pair; this is the streamed form's locality stage).  _order_begin runs the k-d level sorts restricted at
+ * every level to the segments that hold the caller's tile range [tile_begin, tile_begin + tile_count) (tile_count <= 0:
+ * all tiles) -- a rank that owns 1 / G of the tiles sorts ~(levels / G + 2) n keys instead of levels x n -- and returns
+ * its slice of the order (*order_local: uint32 [tile_count x 128], device), the all-gather target (*order_all: uint32
+ * [n_tiles x 128]; rank r's slice at r x *order_bytes) and the slice's size.  _order_end (after the all-gather; at once
+ * when the range was everything) gathers the rows into tile order and returns annchor_stream_order's outputs. */
+int annchor_stream_order_begin(annchor_ctx *ctx, int32_t min_tiles, int32_t tile_begin, int32_t tile_count, void **order_local,
+                               void **order_all, int64_t *order_bytes);
+int annchor_stream_order_end(annchor_ctx *ctx, void **Xs, void **rs, void **perm, void **lo, void **hi, void **mid, int64_t *n_pad,
+                             int32_t *n_tiles, int32_t *dim_padded);
 int annchor_stream_knn(annchor_ctx *ctx, const void *Xs_all, const void *rs_all, const void *perm_all, const void *lo_all,
                        const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors, int32_t dim_padded,
                        int32_t tile_begin, int32_t tile_count, int32_t k, double p_work, int32_t join_passes, int32_t join_extra,
@@ -371,6 +382,13 @@ int annchor_stream_knn_begin(annchor_ctx *ctx, const void *Xs_all, const void *r
                              int32_t dim_padded, int32_t tile_begin, int32_t tile_count, int32_t k, int32_t tile_budget,
                              void **lists_local, int64_t *lists_bytes);
 int annchor_stream_knn_join(annchor_ctx *ctx, const void *lists_all, int32_t per_pass, void **lists_local, int64_t *updates);
+/* Row-sharded join pass, first half (the streamed analogue of update_anchor_points' computed-neighbour lists,
+ * annchor/annchor.py:475-512, restricted to the columns a rank owns): the reverse neighbour lists of this rank's tile range
+ * from the all-gathered lists.  *rev_local: int32 [tile_count x 128][15] (device: the rank's slice INSIDE the gather
+ * target, i.e. an in-place all-gather), *rev_all: int32 [n_all][15], *rev_bytes: bytes per rank.  The host all-gathers the
+ * slices and calls annchor_stream_knn_join with the same lists_all; a host that skips this call gets every column's
+ * reverse list built by the join pass itself (one rank). */
+int annchor_stream_join_rev_begin(annchor_ctx *ctx, const void *lists_all, void **rev_local, void **rev_all, int64_t *rev_bytes);
 /* The work budget of the streamed form.  p_work is the share of THIS form's brute force -- n_tiles
  * tile evaluations per row tile -- that one row tile may spend, all phases included:
  * total = ceil(p_work * n_tiles) = tile_phase + join_passes * per_pass (per_pass = runs of 128
@@ -418,8 +436,11 @@ int annchor_stream_join_tables(annchor_ctx *ctx, const void *gathered, int32_t w
  *   _anchor_end downloads the anchors' global rows and coordinates.
  * Rows: _rows_begin gives the all-gather's send buffer (the shard padded with zero rows to the largest shard) and
  *   receive buffer ([world][most][dim]); _rows_end compacts what arrived, rebinds the context to ALL rows (global_base 0:
- *   rows are numbered by position in the rank-ordered concatenation) and recomputes every row's anchor distances in one
- *   pass.  annchor_stream_order then builds the one global tile order on every rank.
+ *   rows are numbered by position in the rank-ordered concatenation).  Anchor distances: _anchor_dists_begin (between the
+ *   anchor rounds and _rows_end) gives the send / receive buffers of the all-gather of the ranks' own anchor distances
+ *   (float [n_anchors][most] per rank -- the "all-gather of anchor feature vectors"); _rows_end assembles D [n_anchors][total]
+ *   from them (a host that skips the exchange gets them recomputed from the anchors, every row on every rank).
+ *   annchor_stream_order_begin / _end then build the one global tile order, each rank ordering its own tile range.
  * Lists: annchor_stream_lists_all = the all-gather target for annchor_stream_knn_join.
  * Result: _route_begin replaces annchor_stream_knn_end: finished rows become records [global id, k-1 neighbour ids,
  *   k-1 float64 distances] (int64 words) grouped by owner rank (starts / bases: first position / first global row of
@@ -450,6 +471,8 @@ int annchor_comm_alltoall_records(annchor_ctx *ctx, const void *send, const int6
 int annchor_stream_anchor_rounds(annchor_ctx *ctx, int32_t n_anchors);
 int annchor_stream_anchor_end(annchor_ctx *ctx, int64_t *A, float *anchor_vectors);
 int annchor_stream_rows_begin(annchor_ctx *ctx, int32_t world, const int64_t *counts, void **send, void **recv, int64_t *bytes_per_rank);
+int annchor_stream_anchor_dists_begin(annchor_ctx *ctx, int32_t world, const int64_t *counts, void **send, void **recv,
+                                      int64_t *bytes_per_rank);
 int annchor_stream_rows_end(annchor_ctx *ctx, int32_t world, const int64_t *counts);
 int annchor_stream_lists_all(annchor_ctx *ctx, int32_t world, int64_t bytes_per_rank, void **all);
 int annchor_stream_route_begin(annchor_ctx *ctx, int32_t world, const int64_t *starts, const int64_t *bases, void **send,

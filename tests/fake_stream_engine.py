@@ -80,11 +80,25 @@ class FakeStreamEngine:
         self._recv = np.zeros((len(counts), most, self.dim), dtype=np.float32)
         return self._send.ctypes.data, self._recv.ctypes.data, self._send.nbytes
 
+    def stream_anchor_dists_begin(self, counts):
+        most = int(max(counts))
+        self._dsend = np.zeros((self.na, most), dtype=np.float32)
+        self._dsend[:, :self.n] = self.D
+        self._drecv = np.zeros((len(counts), self.na, most), dtype=np.float32)
+        self._d_gathered = True
+        return self._dsend.ctypes.data, self._drecv.ctypes.data, self._dsend.nbytes
+
     def stream_rows_end(self, counts):
         self.own_base, self.own_n = self.base, self.n
         self.X = np.concatenate([self._recv[r, :int(c)] for r, c in enumerate(counts)])
         self.n, self.base = len(self.X), 0
-        self.D = np.stack([np.sqrt(((self.X - v[None, :]) ** 2).sum(axis=1, dtype=np.float32)).astype(np.float32) for v in self._avecs])
+        D = np.stack([np.sqrt(((self.X - v[None, :]) ** 2).sum(axis=1, dtype=np.float32)).astype(np.float32) for v in self._avecs])
+        if getattr(self, "_d_gathered", False):    # the ranks' own anchor distances, all-gathered: what a recomputation gives
+            self.D = np.concatenate([self._drecv[r][:, :int(c)] for r, c in enumerate(counts)], axis=1)
+            assert np.array_equal(self.D, D), "gathered anchor distances are not in rank order"
+            self._d_gathered = False
+        else:
+            self.D = D
 
     def stream_lists_all(self, world, nbytes):
         return self._alloc(np.zeros(world * nbytes, dtype=np.uint8))
@@ -134,10 +148,37 @@ class FakeStreamEngine:
         self._keep[arr.ctypes.data] = arr
         return arr.ctypes.data
 
-    def stream_order(self, min_tiles=0):
+    def _full_order(self):
         cA = np.argmin(self.D, axis=0)
         rad = self.D[cA, np.arange(self.n)]
-        order = np.lexsort((np.arange(self.n), rad, cA))
+        return np.lexsort((np.arange(self.n), rad, cA))
+
+    def stream_order_begin(self, min_tiles, tile_begin, tile_count):
+        """The rank's slice of the order goes through the all-gather; stream_order_end builds everything from the gathered
+        slices only (so a slice in the wrong place shows up as a wrong graph)."""
+        nt = max((self.n + TILE - 1) // TILE, min_tiles)
+        full = np.full(nt * TILE, 0xFFFFFFFF, dtype=np.uint32)
+        full[:self.n] = self._full_order()
+        self._oslice = np.ascontiguousarray(full[tile_begin * TILE:(tile_begin + tile_count) * TILE])
+        self._oall = np.full(nt * TILE, 0xFFFFFFFF, dtype=np.uint32)
+        self._omin = min_tiles
+        return self._oslice.ctypes.data, self._oall.ctypes.data, self._oslice.nbytes
+
+    def stream_order_end(self):
+        order = self._oall[:self.n].astype(np.int64)
+        assert np.array_equal(np.sort(order), np.arange(self.n)), "gathered order is not a permutation"
+        return self.stream_order(self._omin, order=order)
+
+    def stream_join_rev_begin(self, lists_all):
+        ptrs, n_all, nt_all, na, dimp, tile_begin, tile_count, k, p_work = self._run
+        self._rev_all = np.full((n_all, 15), -1, dtype=np.int32)
+        self._rev_all[tile_begin * TILE:(tile_begin + tile_count) * TILE] = tile_begin
+        sl = self._rev_all[tile_begin * TILE:(tile_begin + tile_count) * TILE]
+        return sl.ctypes.data, self._rev_all.ctypes.data, sl.nbytes
+
+    def stream_order(self, min_tiles=0, order=None):
+        if order is None:
+            order = self._full_order()
         nt = max((self.n + TILE - 1) // TILE, min_tiles)
         n_pad = nt * TILE
         Xs = np.zeros((n_pad, self.dim), dtype=np.float32)
@@ -181,6 +222,9 @@ class FakeStreamEngine:
         every = _view(lists_all, (n_all, k - 1), np.int32)
         mine = every[tile_begin * TILE:(tile_begin + tile_count) * TILE]
         assert np.all(mine == tile_begin), "all-gathered lists are not in rank order"
+        tiles = np.arange(n_all) // TILE // tile_count * tile_count      # first tile of the rank that owns each row
+        assert np.array_equal(self._rev_all[:, 0], tiles) and np.array_equal(self._rev_all[:, -1], tiles), \
+            "all-gathered reverse lists are not in rank order"
         self.joins = getattr(self, "joins", 0) + 1
         return self._lists, 0
 
