@@ -266,13 +266,30 @@ __global__ __launch_bounds__(1024) void k_st_split_coord(const float *__restrict
     const int an = threadIdx.x % A, g = threadIdx.x / A;
     const int64_t m = len < ST_SPLIT_SAMPLE ? len : ST_SPLIT_SAMPLE;
     double a1 = 0.0, a2 = 0.0;
-    if (an < na)
-        for (int64_t t = g; t < m; t += G) {
-            const int64_t p = b + (m == len ? t : (t * len) / m);
-            const double v = (double)Dt[(size_t)order[p] * nap + an];
-            a1 += v;
-            a2 += v * v;
+    if (an < na) {
+        // a lane's samples are a chain of two dependent gathers each (order[p], then the point's anchor distance): eight samples'
+        // reads are issued together -- one at a time a top-level segment (one workgroup, 64 samples per lane) took ~200 us of pure
+        // memory latency per level -- and summed in the order they always were (the choice of the split anchor stays the same)
+        for (int64_t t0 = g; t0 < m; t0 += 8 * (int64_t)G) {
+            uint32_t src[8];
+            float v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t t = t0 + (int64_t)u * G;
+                const int64_t p = b + (m == len ? min(t, m - 1) : (min(t, m - 1) * len) / m);
+                src[u] = order[p];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v8[u] = Dt[(size_t)src[u] * nap + an];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (t0 + (int64_t)u * G < m) {
+                    const double v = (double)v8[u];
+                    a1 += v;
+                    a2 += v * v;
+                }
         }
+    }
     s1[threadIdx.x] = a1;
     s2[threadIdx.x] = a2;
     __syncthreads();
@@ -335,35 +352,47 @@ __global__ void k_st_gather(const float *__restrict__ X, const uint32_t *__restr
     }
 }
 
-__global__ __launch_bounds__(ST_T) void k_st_intervals(const float *__restrict__ D, const uint32_t *__restrict__ order, int64_t n,
+// block = tile, thread = row of the tile: the row's whole anchor vector is one contiguous read of the point-major copy Dt (the
+// anchor-major D cost one scattered 4-byte read per (row, anchor): 4.6 ms at N = 8 x 10^6), the tile's minimum / maximum / mean
+// per anchor are taken by one thread per anchor over an LDS transpose
+__global__ __launch_bounds__(ST_T) void k_st_intervals(const float *__restrict__ Dt, int nap, const uint32_t *__restrict__ order, int64_t n,
                                                       int na, int nt, float *__restrict__ lo, float *__restrict__ hi,
                                                       float *__restrict__ mid)
 {
-    // block = tile, thread = row of the tile
+    __shared__ float sv[ST_T][65];   // [row][anchor], padded: the per-anchor passes read columns
     const int t = blockIdx.x;
     const int64_t s = (int64_t)t * ST_T + threadIdx.x;
-    __shared__ float smin[ST_T / 64], smax[ST_T / 64], ssm[ST_T / 64];
-    __shared__ int scnt[ST_T / 64];
     const bool ok = s < n;
-    const uint32_t src = ok ? order[s] : 0;
-    for (int a = 0; a < na; ++a) {
-        float v = ok ? D[(size_t)a * n + src] : 0.f;
-        float mn = ok ? v : INFINITY, mx = ok ? v : -INFINITY, sm = ok ? v : 0.f;
-        int cn = ok ? 1 : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off));
-            sm += __shfl_xor(sm, off); cn += __shfl_xor(cn, off);
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(Dt + (size_t)(ok ? order[s] : 0u) * nap);
+        for (int q = 0; q < nap / 4; ++q) {
+            const float4 v = ok ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            sv[threadIdx.x][4 * q] = v.x; sv[threadIdx.x][4 * q + 1] = v.y; sv[threadIdx.x][4 * q + 2] = v.z; sv[threadIdx.x][4 * q + 3] = v.w;
         }
-        if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; ssm[threadIdx.x >> 6] = sm; scnt[threadIdx.x >> 6] = cn; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            lo[(size_t)a * nt + t] = fminf(smin[0], smin[1]);
-            hi[(size_t)a * nt + t] = fmaxf(smax[0], smax[1]);
-            const int cc = scnt[0] + scnt[1];
-            mid[(size_t)a * nt + t] = cc ? (ssm[0] + ssm[1]) / (float)cc : INFINITY;   // mean anchor distance of the tile
+    }
+    __syncthreads();
+    const int rows = (int)min<int64_t>(ST_T, max<int64_t>(n - (int64_t)t * ST_T, 0));
+    if ((int)threadIdx.x < na) {
+        const int a = threadIdx.x;
+        float mn = INFINITY, mx = -INFINITY;
+        for (int r = 0; r < rows; ++r) { const float v = sv[r][a]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+        lo[(size_t)a * nt + t] = mn;
+        hi[(size_t)a * nt + t] = mx;
+    }
+    __syncthreads();
+    // the sums in the association the wave reductions they replace had (rows pair up by xor 32, 16, .. 1 inside each 64-row
+    // half, then the two halves; missing rows count 0): the mean keeps its bits, and with it the rank key of every tile pair
+    for (int off = 32; off > 0; off >>= 1) {
+        for (int idx = threadIdx.x; idx < 2 * off * na; idx += ST_T) {
+            const int a = idx % na, rr = idx / na;
+            const int r = (rr >= off ? 64 : 0) + (rr % off);
+            sv[r][a] += sv[r + off][a];
         }
         __syncthreads();
+    }
+    if ((int)threadIdx.x < na) {
+        const int a = threadIdx.x;
+        mid[(size_t)a * nt + t] = rows ? (sv[0][a] + sv[64][a]) / (float)rows : INFINITY;   // mean anchor distance of the tile
     }
 }
 
@@ -594,8 +623,8 @@ extern "C" int annchor_stream_order_end(annchor_ctx *c, void **Xs, void **rs, vo
         ProfScope ps(c, "stream_order_gather_rows", (double)n * (s->dim * 4.0 + s->dimp * 8.0 + s->na * 4.0 + 16.0));
         k_st_gather<<<ann_blocks(s->n_pad * 16, 256), 256, 0, c->stream>>>(s->X.as<float>(), order, n, s->n_pad, s->dim, s->dimp, s->base,
                                                                           s->Xs.as<float>(), s->rs.as<float>(), s->perm.as<int64_t>());
-        k_st_intervals<<<s->nt, ST_T, 0, c->stream>>>(s->D.as<float>(), order, n, s->na, s->nt, s->lo.as<float>(), s->hi.as<float>(),
-                                                     s->mid.as<float>());
+        k_st_intervals<<<s->nt, ST_T, 0, c->stream>>>(s->Dt.as<float>(), (s->na + 3) & ~3, order, n, s->na, s->nt, s->lo.as<float>(),
+                                                     s->hi.as<float>(), s->mid.as<float>());
         if (s->dimp <= 128) ANN_TRY(ann_stream_split_rows(c, s));   // the fp16 hi / lo copy the tile kernel streams (knnbf.hip)
     }
     ANN_CHECK_HIP(c, hipGetLastError());
@@ -1257,19 +1286,23 @@ __global__ void k_st_rev_select(const int64_t *__restrict__ ptr, const unsigned 
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncols) return;
     const int64_t b = ptr[c], e = ptr[c + 1];
-    unsigned long long last = 0;
-    bool first = true;
-    for (int r = 0; r < JN_RK; ++r) {
-        unsigned long long best = ~0ull;
-        for (int64_t q = b; q < e; ++q) {
-            const unsigned long long kq = edges[q];
-            if ((first || kq > last) && kq < best) best = kq;
+    // the JN_RK smallest keys, ascending, in registers: every edge is read once and bubbles in by compare-exchange (keys are
+    // distinct: position << 32 | lister); JN_RK rounds over the list re-read every edge JN_RK times
+    unsigned long long best[JN_RK];
+#pragma unroll
+    for (int r = 0; r < JN_RK; ++r) best[r] = ~0ull;
+    for (int64_t q = b; q < e; ++q) {
+        unsigned long long k = edges[q];
+        if (k >= best[JN_RK - 1]) continue;
+#pragma unroll
+        for (int r = 0; r < JN_RK; ++r) {
+            const unsigned long long lo = k < best[r] ? k : best[r], hi = k < best[r] ? best[r] : k;
+            best[r] = lo;
+            k = hi;
         }
-        rev[c * JN_RK + r] = best == ~0ull ? 0x7fffffff : (int32_t)(best & 0xffffffffull);
-        if (best == ~0ull) { for (int r2 = r + 1; r2 < JN_RK; ++r2) rev[c * JN_RK + r2] = 0x7fffffff; break; }
-        last = best;
-        first = false;
     }
+#pragma unroll
+    for (int r = 0; r < JN_RK; ++r) rev[c * JN_RK + r] = best[r] == ~0ull ? 0x7fffffff : (int32_t)(best[r] & 0xffffffffull);
 }
 
 // Candidate columns of one row tile: first hop = the current neighbours and reverse neighbours of
@@ -1723,14 +1756,12 @@ static int knn_reverse_lists(annchor_ctx *c, StreamState *s, const int32_t *list
     if (ncols <= 0) return ANNCHOR_OK;
     ANN_TRY(sreserve(c, s->rev_cnt, sizeof(int32_t) * (size_t)(ncols + 1)));
     ANN_TRY(sreserve(c, s->rev_ptr, sizeof(int64_t) * (size_t)(ncols + 1)));
-    // edges into the own columns: n_edges x ncols / n_all on average; a rank whose columns are listed more often than that
-    // (hubs) needs more, so the count pass decides
+    // (room for every edge: the own columns receive n_edges x ncols / n_all of them on average, a rank that owns hubs more --
+    // knowing how many would take a host wait per pass)
+    ANN_TRY(sreserve(c, s->rev_edges, sizeof(unsigned long long) * (size_t)std::max<int64_t>(n_edges, 1)));
     ANN_CHECK_HIP(c, hipMemsetAsync(s->rev_cnt.p, 0, sizeof(int32_t) * (size_t)(ncols + 1), c->stream));
     k_st_rev_count<<<ann_blocks(n_edges, 256), 256, 0, c->stream>>>(lists_all, n_edges, col0, ncols, s->rev_cnt.as<int32_t>());
     ANN_TRY(ann_exclusive_scan_i32_to_i64(c, s->rev_cnt.as<int32_t>(), s->rev_ptr.as<int64_t>(), ncols));   // ptr has ncols + 1 entries
-    int64_t own_edges = n_edges;
-    if (ncols < n_all) ANN_TRY(ann_d2h(c, &own_edges, s->rev_ptr.as<int64_t>() + ncols, sizeof(int64_t)));
-    ANN_TRY(sreserve(c, s->rev_edges, sizeof(unsigned long long) * (size_t)std::max<int64_t>(own_edges, 1)));
     ANN_CHECK_HIP(c, hipMemsetAsync(s->rev_cnt.p, 0, sizeof(int32_t) * (size_t)(ncols + 1), c->stream));
     k_st_rev_fill<<<ann_blocks(n_edges, 256), 256, 0, c->stream>>>(lists_all, n_edges, K, col0, ncols, s->rev_ptr.as<int64_t>(),
                                                                   s->rev_cnt.as<int32_t>(), s->rev_edges.as<unsigned long long>());
