@@ -54,7 +54,7 @@ struct StreamState {
     DevBuf ucand, ucount;     // uint32 [tile_count][JN_CAP] / int32 [tile_count]: join candidates per row tile
     DevBuf rev_cnt, rev_ptr, rev_edges;   // scratch of the reverse neighbour lists (join passes): counts, CSR pointers, edge records of the own columns
     int64_t n_local = 0, n_pad = 0, base = 0;
-    int64_t last_tile_evals = 0, last_join_chunks = 0;
+    int64_t last_tile_evals = 0, last_join_chunks = 0, last_fetched_tiles = 0;
     int last_kernel = 0;   // tile phase of the last build: 0 k_st_knn (exact f32), 1 k_st_knnbf (split fp16)
     int64_t last_guard_rows = 0;   // rows the split-fp16 kernel flagged (error band of the split products reaches the list boundary)
     int dim = 0, dimp = 0, na = 0, nt = 0;
@@ -119,6 +119,9 @@ StreamState *ann_stream_state(annchor_ctx *c, bool create);
 // knnbf.hip: the tile phase on the 16-bit matrix cores (split operands, two 4-wave workgroups per CU); *handled = false
 // when the shape does not fit it (padded dim > 128, more than 30 neighbours, no split copy) and the caller launches k_st_knn
 int ann_stream_launch_knnbf(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled, bool join = false);
+// tools/experiments/knnbf2.hip (builds with -DST_PAIR_KERNEL only): the same tile phase with two adjacent row tiles per 8-wave
+// workgroup sharing one column stream (graph builds, padded dim <= 128, K + 2 <= 16); *handled = false otherwise
+int ann_stream_launch_knnbf2(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled);
 int ann_stream_split_rows(annchor_ctx *c, StreamState *s);     // Xb from Xs (after the ordering)
 // the split copy (+ centred norms, centre) that belongs to an ordered float32 array; false: none
 bool ann_stream_split_of(const void *Xs, const uint16_t **Xb, const float **rsb, const float **cvec);

@@ -1604,6 +1604,17 @@ static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool 
         const bool want_split = !exact && (!kern || strcmp(kern, "4wave")) && (!join || (st && st->last_kernel == 1));
         if (want_split) {
             bool handled = false;
+#ifdef ST_PAIR_KERNEL
+            // experiment (tools/experiments/knnbf2.hip, not part of the library): two adjacent row tiles per workgroup on one
+            // column stream; ANNCHOR_ST_KERNEL=bf4 keeps one row tile per workgroup
+            if (!join && !(kern && !strcmp(kern, "bf4"))) {
+                ANN_TRY(ann_stream_launch_knnbf2(c, a, dim_padded, &handled));
+                if (handled) {
+                    if (st) st->last_kernel = 1;
+                    return ANNCHOR_OK;
+                }
+            }
+#endif
             ANN_TRY(ann_stream_launch_knnbf(c, a, dim_padded, &handled, join));
             if (handled) {
                 if (!join && st) st->last_kernel = 1;
@@ -1660,7 +1671,7 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
     ANN_TRY(sreserve(c, s->out_d2, sizeof(float) * (size_t)rows * K));
     ANN_TRY(sreserve(c, s->out_col, sizeof(int32_t) * (size_t)rows * K));
     ANN_TRY(sreserve(c, s->evals, 64));
-    ANN_CHECK_HIP(c, hipMemsetAsync(s->evals.p, 0, 32, c->stream));
+    ANN_CHECK_HIP(c, hipMemsetAsync(s->evals.p, 0, 64, c->stream));
     a.max_tiles = std::max(1, std::min(tile_budget, a.nt_all));
     a.out_d2 = s->out_d2.as<float>(); a.out_col = s->out_col.as<int32_t>();
     ANN_TRY(sreserve(c, s->scr_key, sizeof(float) * (size_t)a.tile_count * (size_t)a.nt_all));
@@ -1707,13 +1718,17 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
         // more than 1 row in 200 is flagged (tight clusters far from the centre: |x|^2 >> d^2) the tile phase runs again on
         // the exact-f32 kernel.
         unsigned long long flagged = 0;
-        ANN_TRY(ann_d2h(c, &flagged, a.evals + 3, 8));
+        unsigned long long fl2[2] = {0, 0};
+        ANN_TRY(ann_d2h(c, fl2, a.evals + 3, 16));
+        flagged = fl2[0];
+        s->last_fetched_tiles = (int64_t)fl2[1];   // slot 4: column tiles the paired kernel fetched (0: one row tile per workgroup)
+        if (getenv("ANNCHOR_ST_VERBOSE")) fprintf(stderr, "annchor: tile phase fetched %llu column tiles\n", fl2[1]);
         s->last_guard_rows = (int64_t)flagged;
         static const bool no_fallback = getenv("ANNCHOR_ST_NO_FALLBACK") != nullptr;
         if ((int64_t)flagged > std::max<int64_t>(8, rows / 200) && !no_fallback) {
             fprintf(stderr, "annchor: streamed tile phase: %llu of %lld rows have neighbours closer together than float32-grade products of |x|^2 "
                             "resolve (|x|^2 >> d^2); running the exact float32 tile kernel instead\n", flagged, (long long)rows);
-            ANN_CHECK_HIP(c, hipMemsetAsync(s->evals.p, 0, 32, c->stream));
+            ANN_CHECK_HIP(c, hipMemsetAsync(s->evals.p, 0, 64, c->stream));
             if (a.eval_bits) ANN_CHECK_HIP(c, hipMemsetAsync(s->eval_bits.p, 0, sizeof(uint32_t) * (size_t)a.tile_count * a.eval_words, c->stream));
             ProfScope ps(c, "stream_tile_gemm_topk_exact_rerun", 0.0);
             ANN_TRY(launch_by_dim(c, a, dim_padded, false, true));
@@ -1730,7 +1745,9 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
         static const char *names8[8] = {"MFMA stream", "barrier after stream", "next-tile choice", "test + inserts", "LDS-DMA requests",
                                         "barrier after requests", "merge (+ publish / prologue / tail)", "ranking + selection + rest"};
         const bool four = getenv("ANNCHOR_ST_KERNEL") && !strcmp(getenv("ANNCHOR_ST_KERNEL"), "4wave");
-        const char **names = (four || dim_padded > 128 || a.K > ST_KMAX) ? names4 : names8;
+        static const char *names2[8] = {"operand reads + MFMA stream", "survivor inserts + merge", "waits in front of a slab", "next-tile choice",
+                                        "selection rounds", "merge of the round lists", "prologue + ranking", "epilogue + rest"};
+        const char **names = s->last_fetched_tiles > 0 ? names2 : (four || dim_padded > 128 || a.K > ST_KMAX) ? names4 : names8;
         double tot = 0;
         for (int i = 0; i < 8; ++i) tot += (double)hp[i];
         for (int i = 0; i < 8; ++i) fprintf(stderr, "[st-prof] %-32s %6.2f %%\n", names[i], 100.0 * (double)hp[i] / tot);
