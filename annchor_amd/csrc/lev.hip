@@ -63,189 +63,6 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// LDS layout per wave and slot set: [P][alphabet][G] uint32 PM, [P][text_stride] bytes text,
-// [P] int sums.  ILP independent slot sets share one instruction stream (each lane serves
-// word w of slot g in every set): the dependent VALU chain of one set fills the issue bubbles
-// of the other, which is what the latency-bound one-to-all rounds (few waves per SIMD) need.
-template <int ILP> __global__ __launch_bounds__(LEV_THREADS) void k_lev(LevArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int G = a.G, P = a.P, A = a.alphabet;
-    const int g = lane / G;          // pair slot of this lane
-    const int w = lane - g * G;      // word index inside the slot
-    const bool slot_ok = g < P;
-    uint32_t *pm_g[ILP];
-    unsigned char *txt_g[ILP];
-    int *ssum[ILP];
-#pragma unroll
-    for (int u = 0; u < ILP; ++u) {
-        unsigned char *base = smem + ((size_t)wave * ILP + u) * a.wave_bytes;
-        pm_g[u] = reinterpret_cast<uint32_t *>(base) + (size_t)(slot_ok ? g : 0) * A * G;
-        txt_g[u] = base + a.pm_bytes + (size_t)(slot_ok ? g : 0) * a.text_stride;
-        ssum[u] = reinterpret_cast<int *>(base + a.pm_bytes + (size_t)P * a.text_stride);
-    }
-    const int PP = P * ILP;  // pairs per wave task
-    const int64_t n_tasks = (a.n + PP - 1) / PP;
-    const int64_t wave_global = (int64_t)blockIdx.x * LEV_WAVES + wave;
-    const int64_t wave_stride = (int64_t)gridDim.x * LEV_WAVES;
-    const int tmax = (a.text_stride >> 1) - 1;
-
-    for (int64_t task = wave_global; task < n_tasks; task += wave_stride) {
-        int64_t t_pair[ILP], opos[ILP];
-        bool active[ILP];
-        int m[ILP], n[ILP], Wp[ILP];
-#pragma unroll
-        for (int u = 0; u < ILP; ++u) {
-            t_pair[u] = task * PP + u * P + g;
-            active[u] = slot_ok && t_pair[u] < a.n;
-            int si = 0, sj = 0;
-            opos[u] = t_pair[u];
-            if (active[u]) {
-                if (a.anchor) { si = *a.anchor; sj = (int)t_pair[u]; }
-                else {
-                    int64_t q = a.idx ? a.idx[t_pair[u]] : t_pair[u];
-                    int2 p = a.ij[q];
-                    si = p.x; sj = p.y;
-                    if (a.idx) opos[u] = q;
-                }
-            }
-            const int li = active[u] ? a.slen[si] : 0, lj = active[u] ? a.slen[sj] : 0;
-            // pattern = longer string (the slot reserves lanes for it anyway), text = shorter
-            const bool swap = li < lj;
-            const int ps = swap ? sj : si, ts = swap ? si : sj;
-            m[u] = swap ? lj : li; n[u] = swap ? li : lj;
-            const uint8_t *pat = a.sym + (active[u] ? a.soff[ps] : 0);
-            const uint8_t *tex = a.sym + (active[u] ? a.soff[ts] : 0);
-            Wp[u] = (m[u] + 31) >> 5;
-            if (slot_ok && w == 0) ssum[u][g] = 0;
-            // ---- build PM column of this lane: zero, then OR in the 32 pattern symbols
-            if (slot_ok)
-                for (int c = 0; c < A; ++c) pm_g[u][c * G + w] = 0u;
-            if (active[u] && w < Wp[u]) {
-                const uint4 *p16 = reinterpret_cast<const uint4 *>(pat + w * 32);
-                uint4 q0 = p16[0], q1 = p16[1];  // starts are 16B aligned and padded
-                uint32_t wd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-                const int valid = min(32, m[u] - w * 32);
-#pragma unroll
-                for (int k = 0; k < 32; ++k) {
-                    uint32_t c = (wd[k >> 2] >> ((k & 3) * 8)) & 0xffu;
-                    if (k < valid) atomicOr(&pm_g[u][c * G + w], 1u << k);
-                }
-            }
-            // ---- stage the text: lanes of the slot copy 16B chunks
-            if (active[u]) {
-                const int chunks = (n[u] + 15) >> 4;
-                for (int ch = w; ch < chunks; ch += G)
-                    reinterpret_cast<uint4 *>(txt_g[u])[ch] = reinterpret_cast<const uint4 *>(tex)[ch];
-            }
-        }
-        wave_lds_fence();
-
-        // ---- systolic sweep, two text columns per iteration.  At iteration k lane w handles
-        // columns 2(k-w) and 2(k-w)+1; the four carry bits of the lane above arrive in one
-        // register through one DPP move.  Validity is a function of (k - w, n) alone, so no
-        // flag travels with the data and the loop body is branch-free.
-        uint32_t vp[ILP], vn[ILP], un[ILP], carry[ILP], c1[ILP], eqA[ILP], eqB[ILP];
-        const uint32_t *pm_w[ILP];
-        const uint16_t *txt2[ILP];
-        int max_steps = 0;
-#pragma unroll
-        for (int u = 0; u < ILP; ++u) {
-            vp[u] = 0xffffffffu; vn[u] = 0u; carry[u] = 0u;
-            const bool run = active[u] && m[u] > 0;
-            un[u] = run ? (uint32_t)n[u] : 0u;
-            max_steps = max(max_steps, run ? ((n[u] + 1) >> 1) + Wp[u] - 1 : 0);
-            pm_w[u] = pm_g[u] + w;
-            txt2[u] = reinterpret_cast<const uint16_t *>(txt_g[u]);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) max_steps = max(max_steps, __shfl_xor(max_steps, off));
-        max_steps = __builtin_amdgcn_readfirstlane(max_steps);
-        // Two-deep software pipeline over LDS: the text pair of iteration k+2 and the match
-        // masks of iteration k+1 are requested while iteration k computes, so neither LDS
-        // latency sits on the loop-carried dependency (which is the DPP carry chain only).
-#pragma unroll
-        for (int u = 0; u < ILP; ++u) {
-            const uint32_t c0 = txt2[u][min(max(0 - w, 0), tmax)];
-            c1[u] = txt2[u][min(max(1 - w, 0), tmax)];
-            eqA[u] = pm_w[u][(c0 & 0xffu) * G];
-            eqB[u] = pm_w[u][(c0 >> 8) * G];
-        }
-        for (int k = 0; k < max_steps; ++k) {
-            uint32_t c2[ILP], eqA_n[ILP], eqB_n[ILP], in[ILP];
-#pragma unroll
-            for (int u = 0; u < ILP; ++u) {
-                c2[u] = txt2[u][min(max(k + 2 - w, 0), tmax)];
-                eqA_n[u] = pm_w[u][(c1[u] & 0xffu) * G];
-                eqB_n[u] = pm_w[u][(c1[u] >> 8) * G];
-                in[u] = dpp_wave_shr1(carry[u]);
-            }
-            // keep the LDS requests above the arithmetic (hipcc otherwise rotates the loop and
-            // waits for each request right where it was issued)
-            __builtin_amdgcn_sched_barrier(0);
-            const uint32_t col = (uint32_t)(k - w) * 2u;  // huge when k < w
-#pragma unroll
-            for (int u = 0; u < ILP; ++u) {
-                const uint32_t cin = (w == 0) ? 0x5u : in[u];  // top row of the DP: +1 horizontal delta, never -1
-                const bool vA = col < un[u], vB = (col + 1u) < un[u];
-                // ---- column A
-                uint32_t hpc = cin & 1u, hnc = (cin >> 1) & 1u;
-                uint32_t x = eqA[u] | hnc;
-                uint32_t d0 = (((x & vp[u]) + vp[u]) ^ vp[u]) | x | vn[u];
-                uint32_t hp = vn[u] | ~(d0 | vp[u]);
-                uint32_t hn = d0 & vp[u];
-                const uint32_t hpoA = hp >> 31, hnoA = hn >> 31;
-                hp = (hp << 1) | hpc;
-                hn = (hn << 1) | hnc;
-                uint32_t nvp = hn | ~(d0 | hp), nvn = hp & d0;
-                vp[u] = vA ? nvp : vp[u]; vn[u] = vA ? nvn : vn[u];
-                // ---- column B
-                hpc = (cin >> 2) & 1u; hnc = (cin >> 3) & 1u;
-                x = eqB[u] | hnc;
-                d0 = (((x & vp[u]) + vp[u]) ^ vp[u]) | x | vn[u];
-                hp = vn[u] | ~(d0 | vp[u]);
-                hn = d0 & vp[u];
-                const uint32_t hpoB = hp >> 31, hnoB = hn >> 31;
-                hp = (hp << 1) | hpc;
-                hn = (hn << 1) | hnc;
-                nvp = hn | ~(d0 | hp); nvn = hp & d0;
-                vp[u] = vB ? nvp : vp[u]; vn[u] = vB ? nvn : vn[u];
-                carry[u] = hpoA | (hnoA << 1) | (hpoB << 2) | (hnoB << 3);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // consume the prefetched values only down here
-#pragma unroll
-            for (int u = 0; u < ILP; ++u) { eqA[u] = eqA_n[u]; eqB[u] = eqB_n[u]; c1[u] = c2[u]; }
-        }
-        // D[m][n] = D[0][n] + sum of the vertical deltas of the last column
-        //         = n + popcount(VP & rows) - popcount(VN & rows), summed over the slot's words
-#pragma unroll
-        for (int u = 0; u < ILP; ++u)
-            if (active[u] && w < Wp[u]) {
-                const uint32_t rows = (w == Wp[u] - 1) ? (0xffffffffu >> (31 - ((m[u] - 1) & 31))) : 0xffffffffu;
-                const int part = __popc(vp[u] & rows) - __popc(vn[u] & rows);
-                if (part) atomicAdd(&ssum[u][g], part);
-            }
-        wave_lds_fence();
-#pragma unroll
-        for (int u = 0; u < ILP; ++u)
-            if (active[u] && w == 0) {
-                const double d = (double)(n[u] + ssum[u][g]);  // m == 0: no word contributes, d = n
-                if (a.out) a.out[t_pair[u]] = d;
-                if (a.RA) { a.RA[opos[u]] = d; a.ncm[opos[u]] = 0; }
-            }
-        wave_lds_fence();
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// R words per lane.  The kernels above spend ~35 instructions per (word, column) step, most
-// of it moving carries between lanes (extract, pack, DPP, unpack) and re-testing validity per
-// word.  Here a lane owns R consecutive pattern words and walks them in registers: the
-// horizontal carries between its own words never leave the VGPRs (one v_alignbit_b32 shifts a
-// word and pulls in the top bit of the word below), only the last word's hp/hn cross to the
-// next lane (two DPP moves per column), the match masks of the R words come from one vector
 // LDS read, and validity is tested once per column.  ~14 instructions per step.
 struct LevArgsR {
     LevArgs b;
@@ -808,18 +625,6 @@ static int launch_f(annchor_ctx *c, LevArgs a, int64_t npairs, const PairSource 
     return ANNCHOR_OK;
 }
 
-// ---------------------------------------------------------------------------------------
-// k_lev_a: the one-to-all launches of the max-min picker (pickers.py:44-50) -- 15 dependent launches of nx pairs
-// each at C2, bound by the LATENCY of one pair's column chain, not by throughput (1600 pairs / 3 per wave = 534
-// waves on 1024 SIMDs, each walking ~500 dependent columns).  The chain is halved: ONE pair per wave, the anchor is
-// the bit-vector pattern, and the two half-waves walk the two halves of the text towards each other --
-//   lanes  0-31: pattern P against T[0:h)            -> F[i]  = lev(P[0:i], T[0:h)),  i = 0..m
-//   lanes 32-63: reversed P against reversed T[h:n)  -> B'[i] = lev(last i symbols of P, T[h:n))
-//   lev(P, T) = min_i F[i] + B'[m - i]                                   (Hirschberg's split at column h)
-// F / B' are the prefix sums of the vertical deltas (vp / vn bits) the bit-parallel recurrence leaves after the
-// last column.  nx waves instead of nx / 3 (1.6 per SIMD at C2), ~n / 2 + words dependent columns instead of
-// n + words.  The text of a wave's pair does not depend on the anchor, so it is staged while the fused arg-max scan
-// of the previous round's distances (which decides the anchor) is still in flight.
 struct LevArgsA {
     const uint8_t *sym;
     const int32_t *soff;
@@ -833,168 +638,6 @@ struct LevArgsA {
     int32_t *pick_out;
     int pick_reset, pick_nx;
 };
-
-__global__ __launch_bounds__(ANN_WAVE) void k_lev_a(LevArgsA a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x, half = lane >> 5, w = lane & 31, A = a.alphabet;
-    unsigned char *pm_col = smem + (size_t)half * A * LEVF_ROW + (size_t)w * 4;
-    uint8_t *txt = smem + a.pm_bytes;
-    int16_t *FB = reinterpret_cast<int16_t *>(smem + a.pm_bytes + a.text_stride);   // [2][fb_stride]
-    for (int e = lane * 16; e < a.text_stride; e += 64 * 16) *reinterpret_cast<uint4 *>(txt + e) = make_uint4(0, 0, 0, 0);
-    uint32_t hp_or = w == 0 ? 0x80000000u : 0u;      // first lane of a half: the row above the pattern (see k_lev_f)
-    uint32_t hn_and = w == 0 ? 0u : 0xffffffffu;
-    asm volatile("" : "+v"(hp_or), "+v"(hn_and));
-
-    auto stage_text = [&](int64_t t) {
-        const int n = a.slen[t];
-        const uint8_t *tex = a.sym + a.soff[t];
-        for (int ch = lane; ch < ((n + 15) >> 4); ch += 64)
-            reinterpret_cast<uint4 *>(txt + LEVR_PAD)[ch] = reinterpret_cast<const uint4 *>(tex)[ch];
-        return n;
-    };
-    // ---- the text of the first pair (string blockIdx.x): known before the anchor is -- its loads are in flight
-    // while the scan below decides the anchor
-    int n_first = blockIdx.x < a.n ? stage_text(blockIdx.x) : 0;
-    // ---- the anchor: fused max-min pick over the previous round's distances (every wave for itself)
-    int si;
-    if (a.pick_row) {
-        double bv = -INFINITY;
-        int bi = 0x7fffffff;
-        const int nx = a.pick_nx;
-        for (int j0 = 0; j0 < nx; j0 += 64 * 16) {
-            double d[16], rm[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int j = min(j0 + e * 64 + lane, nx - 1);
-                d[e] = a.pick_row[j];
-                rm[e] = a.pick_reset ? 0.0 : a.pick_runmin[j];
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int j = j0 + e * 64 + lane;
-                if (j < nx) {
-                    const double v = a.pick_reset ? d[e] : fmin(rm[e], d[e]);
-                    if (blockIdx.x == 0) a.pick_runmin[j] = v;   // other workgroups read it before or after: min(min(r, d), d) == min(r, d)
-                    argmax_combine(bv, bi, v, j);
-                }
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ov = __shfl_xor(bv, off);
-            const int oi = __shfl_xor(bi, off);
-            argmax_combine(bv, bi, ov, oi);
-        }
-        si = bi;
-        if (blockIdx.x == 0 && lane == 0) *a.pick_out = bi;
-    } else {
-        si = *a.anchor;
-    }
-
-    for (int64_t t = blockIdx.x; t < a.n; t += gridDim.x) {
-        int n = n_first;
-        if (t != blockIdx.x) {
-            wave_lds_fence();   // the previous pair's readers are done
-            n = stage_text(t);
-        }
-        const int m = a.slen[si];
-        const uint8_t *pat = a.sym + a.soff[si];
-        const int Wp = (m + 31) >> 5;
-        // ---- match masks of this lane's pattern word: forward word w, or word w of the reversed pattern
-        for (int c = 0; c < A; ++c) *reinterpret_cast<uint32_t *>(pm_col + (size_t)c * LEVF_ROW) = 0u;
-        if (w < Wp) {
-            const int valid = min(32, m - w * 32);
-            uint32_t sy[32];
-            if (half == 0) {
-                const uint4 *p16 = reinterpret_cast<const uint4 *>(pat + w * 32);
-                const uint4 q0 = p16[0], q1 = p16[1];
-                const uint32_t wd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-#pragma unroll
-                for (int k = 0; k < 32; ++k) sy[k] = (wd[k >> 2] >> ((k & 3) * 8)) & 0xffu;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 32; ++k) sy[k] = pat[max(m - 1 - (w * 32 + k), 0)];
-            }
-#pragma unroll
-            for (int k = 0; k < 32; ++k)
-                if (k < valid) atomicOr(reinterpret_cast<uint32_t *>(pm_col + (size_t)sy[k] * LEVF_ROW), 1u << k);
-        }
-        wave_lds_fence();
-
-        // ---- columns: forward half T[0:h) left to right, backward half T[h:n) right to left
-        const int h = (n + 1) >> 1;
-        const uint32_t un = m > 0 ? (uint32_t)(half ? n - h : h) : 0u;
-        const int max_steps = m > 0 ? h + Wp - 1 : 0;
-        const int dir = half ? -1 : 1;
-        const uint8_t *tp = txt + LEVR_PAD + (half ? n - 1 + w : -w);   // tp[dir * k] = this lane's symbol at iteration k
-        uint32_t vp = 0xffffffffu, vn = 0u;
-        uint32_t c1 = tp[dir];
-        uint32_t eq = *reinterpret_cast<const uint32_t *>(pm_col + (uint32_t)tp[0] * LEVF_ROW);
-        uint32_t out_hp = 0, out_hn = 0;
-        const uint8_t *tq = tp + 2 * dir;   // symbol two iterations ahead
-        auto column = [&](int k, auto checked) {
-            const uint32_t c2 = *tq;
-            tq += dir;
-            const uint32_t eq_n = *reinterpret_cast<const uint32_t *>(pm_col + c1 * LEVF_ROW);
-            const uint32_t hp_up = dpp_shr1_or(out_hp, hp_or), hn_up = dpp_shr1_and(out_hn, hn_and);
-            __builtin_amdgcn_sched_barrier(0);
-            const bool valid = !decltype(checked)::value || (uint32_t)(k - w) < un;
-            const uint32_t c = hn_up >> 31;
-            const uint32_t x = eq | c;
-            const uint32_t tt = __builtin_amdgcn_bitop3_b32(c, eq, vp, 0xa8);       // (c | eq) & vp
-            const uint32_t sm = tt + vp;
-            const uint32_t d0p = __builtin_amdgcn_bitop3_b32(sm, vp, x, 0xbe);      // (sm ^ vp) | x
-            const uint32_t hp = __builtin_amdgcn_bitop3_b32(vn, d0p, vp, 0xf1);     // vn | ~(d0p | vp)
-            const uint32_t d0 = d0p | vn;
-            const uint32_t hn = d0 & vp;
-            const uint32_t hps = __builtin_amdgcn_alignbit(hp, hp_up, 31);
-            const uint32_t hns = __builtin_amdgcn_alignbit(hn, hn_up, 31);
-            const uint32_t nvp = __builtin_amdgcn_bitop3_b32(hns, d0, hps, 0xf1);   // hns | ~(d0 | hps)
-            const uint32_t nvn = hps & d0;
-            vp = valid ? nvp : vp;
-            vn = valid ? nvn : vn;
-            out_hp = hp;
-            out_hn = hn;
-            __builtin_amdgcn_sched_barrier(0);
-            eq = eq_n;
-            c1 = c2;
-        };
-        // between k = Wp - 1 (every pattern word has started) and n - h (the shorter half has not finished) every
-        // lane that holds a pattern word is on a real column: no validity test there
-        const int k_lo = min(max(Wp - 1, 0), max_steps), k_hi = max(k_lo, min(n - h, max_steps));
-        int k = 0;
-        for (; k < k_lo; ++k) column(k, std::true_type());
-        for (; k + 2 <= k_hi; k += 2) { column(k, std::false_type()); column(k + 1, std::false_type()); }
-        for (; k < k_hi; ++k) column(k, std::false_type());
-        for (; k < max_steps; ++k) column(k, std::true_type());
-
-        // ---- F / B': prefix sums of the vertical deltas down the rows of this half
-        const uint32_t rows = w < Wp - 1 ? 0xffffffffu : (w == Wp - 1 ? (0xffffffffu >> (31 - ((m - 1) & 31))) : 0u);
-        const int part = __popc(vp & rows) - __popc(vn & rows);
-        int incl = part;
-#pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            const int o = __shfl_up(incl, off, 32);
-            if (w >= off) incl += o;
-        }
-        int val = (int)un + incl - part;     // value at the row above this word's first row (m == 0: un = 0, fixed below)
-        if (m == 0) val = half ? n - h : h;
-        int16_t *fb = FB + (size_t)half * a.fb_stride;
-        if (w == 0) fb[0] = (int16_t)val;
-#pragma unroll
-        for (int b = 0; b < 32; ++b) {
-            val += (int)((vp >> b) & 1u) - (int)((vn >> b) & 1u);
-            if ((rows >> b) & 1u) fb[w * 32 + b + 1] = (int16_t)val;
-        }
-        wave_lds_fence();
-        int best = 0x7fffffff;
-        for (int i = lane; i <= m; i += 64) best = min(best, (int)FB[i] + (int)FB[a.fb_stride + m - i]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off));
-        if (lane == 0) a.out[t] = (double)best;
-    }
-}
 
 // ---------------------------------------------------------------------------------------
 // k_lev_a2: k_lev_a with the waves packed for ONE wave per SIMD.  k_lev_a's nx waves of half-length chains ran as
@@ -1922,35 +1565,6 @@ int ann_lev_anchor_rounds(annchor_ctx *c, int32_t na, int32_t first, bool *done)
     return ANNCHOR_OK;
 }
 
-static int launch_a(annchor_ctx *c, const PairSource &src, double *d_out)
-{
-    LevArgsA a;
-    a.sym = c->sym.as<uint8_t>(); a.soff = c->soff.as<int32_t>(); a.slen = c->slen.as<int32_t>();
-    a.anchor = src.anchor; a.n = src.n; a.out = d_out; a.alphabet = c->alphabet;
-    a.pm_bytes = 2 * a.alphabet * LEVF_ROW;
-    a.text_stride = 2 * LEVR_PAD + ((c->maxlen + 15) & ~15) + 16;
-    a.fb_stride = (c->maxlen + 2 + 7) & ~7;
-    a.pick_row = nullptr; a.pick_runmin = nullptr; a.pick_out = nullptr; a.pick_reset = 0; a.pick_nx = 0;
-    if (src.pick_fused && c->nx <= 8192) {
-        *src.pick_fused = true;
-        if (src.pick_row) {
-            a.pick_row = src.pick_row; a.pick_runmin = src.pick_runmin; a.pick_out = src.pick_out;
-            a.pick_reset = src.pick_reset; a.pick_nx = (int)c->nx;
-        }
-    }
-    const size_t lds = (size_t)a.pm_bytes + a.text_stride + 2 * sizeof(int16_t) * a.fb_stride;
-    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "alphabet %d x length %d needs %zu B of LDS (> 160 KiB)", c->alphabet,
-                c->maxlen, lds);
-    if (lds > 64 * 1024)
-        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev_a, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int64_t blocks = src.n;
-    const int64_t max_blocks = (int64_t)c->prop.multiProcessorCount * 32;
-    if (blocks > max_blocks) blocks = max_blocks;
-    k_lev_a<<<(int)blocks, ANN_WAVE, lds, c->stream>>>(a);
-    ANN_CHECK_HIP(c, hipGetLastError());
-    return ANNCHOR_OK;
-}
-
 // ---------------------------------------------------------------------------------------
 // k_lev_w: alphabets beyond 256 distinct symbols (annchor_set_strings_u16: 16-bit dense codes, up to 65 536 -- any
 // Unicode corpus).  A per-pattern match-mask table would be alphabet x 128 B of LDS per half-wave, so the match word of
@@ -2127,27 +1741,23 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
     a.text_stride = ((c->maxlen + 15) & ~15) + 16;
     a.pm_bytes = (int)((((size_t)a.P * a.alphabet * G * 4) + 15) & ~(size_t)15);
     a.wave_bytes = a.pm_bytes + a.P * a.text_stride + 256;  // + per-slot sums (<= 64 ints)
-    // kernel choice: R words per lane (default), R by launch size: few pairs -> more lanes per
-    // pair (shorter critical path), many pairs -> more words per lane (fewer instructions)
-    const char *env_r = getenv("ANNCHOR_LEV_R");   // test / tuning override, read per launch
-    const int force_r = env_r ? atoi(env_r) : -1;
+    // kernel choice.  Live kernels: k_lev_ap (the picker's rounds as one persistent launch) with k_lev_a2 as its round-by-round
+    // form, k_lev_f / k_lev_p2 (pair lists, strings up to 1024 symbols), k_lev_r<1> (longer strings), k_lev_w (wide alphabets).
+    // Retired in round 5 (measured slower everywhere, kept until then for A/B runs): the two-columns-per-iteration kernel k_lev,
+    // k_lev_r with 2 / 4 words per lane, the one-pair-per-wave anchor kernel k_lev_a.
+    const char *env_r = getenv("ANNCHOR_LEV_R");   // tests: 1 forces k_lev_r<1> on short strings too; read per launch
     {
         const int W = (c->maxlen + 31) / 32;
-        // measured on MI355X (tools/lev_ab.py, strings of ~500 symbols): one word per lane with
-        // the lean per-column bookkeeping of k_lev_r wins for the small anchor-round launches
-        // (38 us vs 44 us for the two-columns-per-iteration kernel below) and for the large
-        // refine launches (420 us vs 600 us); R = 2 / 4 cut instructions further but their
-        // tables leave < 2 waves per SIMD.  ANNCHOR_LEV_R = 0 / 2 / 4 select the other variants.
-        (void)W;
-        int R = force_r >= 0 ? force_r : 9;   // default: k_lev_f (394 vs 415 us per 65 536 pairs, 34 vs 37.5 us per anchor round)
+        const int R = env_r && atoi(env_r) == 1 ? 1 : 9;   // default: k_lev_f (394 vs 415 us per 65 536 pairs, 34 vs 37.5 us per anchor round)
         // one-to-all launches (anchor rounds): the latency-shaped kernel, unless ANNCHOR_LEV_ANCHOR=0 / a forced variant
         const char *env_a = getenv("ANNCHOR_LEV_ANCHOR");   // read per launch, like ANNCHOR_LEV_R
         const bool anchor_split = !(env_a && atoi(env_a) == 0);
         if (src.anchor && d_out && !d_RA && R == 9 && W <= 32 && anchor_split && c->maxlen < 32000) {
-            ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
-            // ANNCHOR_LEV_ANCHOR=1: one pair per wave (k_lev_a); default: packed for one wave per SIMD (k_lev_a2)
-            if (!(env_a && atoi(env_a) == 1) && src.n == c->nx && c->lev_order.p) return launch_a2(c, src, d_out);
-            return launch_a(c, src, d_out);
+            // (whole rounds of the picker; any other one-to-all launch takes the pair-list kernel below)
+            if (src.n == c->nx && c->lev_order.p) {
+                ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
+                return launch_a2(c, src, d_out);
+            }
         }
         if (R == 9 && W <= 32) {   // k_lev_f (strings up to 1024 symbols: a slot's lanes must map to distinct banks)
             ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
@@ -2168,27 +1778,8 @@ int ann_lev_launch(annchor_ctx *c, const PairSource &src, double *d_out, double 
             if (!src.anchor && src.ij && p2 && src.n >= 64 && c->maxlen < 32000) return launch_p2(c, src, d_out, d_RA, d_ncm);
             return launch_f(c, a, src.n, src);
         }
-        if (R == 9) R = 1;
-        if (R == 1 || R == 2 || R == 4) {
-            ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
-            return R == 1 ? launch_r<1>(c, a, src.n, src) : R == 2 ? launch_r<2>(c, a, src.n, src) : launch_r<4>(c, a, src.n, src);
-        }
+        // strings of more than 1024 symbols (or ANNCHOR_LEV_R=1): one word per lane, slots of up to 64 lanes
+        ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
+        return launch_r<1>(c, a, src.n, src);
     }
-    // the two-columns-per-iteration kernel, one word per lane, one slot set per lane.  (The
-    // template's second slot set per lane -- two independent dependency chains -- measured
-    // slower: a wave already issues at the VALU's rate, tools/microbench/valu_peak.hip.)
-    const size_t lds = (size_t)a.wave_bytes * LEV_WAVES;
-    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "alphabet %d x length %d needs %zu B of LDS (> 160 KiB)", c->alphabet,
-                c->maxlen, lds);
-    if (lds > 64 * 1024)
-        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_lev<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t tasks = (src.n + a.P - 1) / a.P;
-    int64_t blocks = (tasks + LEV_WAVES - 1) / LEV_WAVES;
-    const int max_blocks = c->prop.multiProcessorCount * 8;
-    if (blocks > max_blocks) blocks = max_blocks;
-    // algorithmic work: one byte per symbol of both strings is all that must be read
-    ProfScope ps(c, "levenshtein_pairs", (double)src.n * (2.0 * c->maxlen + 8));
-    k_lev<1><<<(int)blocks, LEV_THREADS, lds, c->stream>>>(a);
-    ANN_CHECK_HIP(c, hipGetLastError());
-    return ANNCHOR_OK;
 }

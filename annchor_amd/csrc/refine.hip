@@ -248,7 +248,6 @@ __global__ __launch_bounds__(256) void k_update_bounds(const int32_t *__restrict
 //    that the 4-byte keys are read as before.
 #define UBB_THREADS 512  // eight waves share one table (25 KB at 100 000 points: three workgroups = 24 waves per CU)
 #define UBB_CHUNK 2048   // lookahead entries per workgroup
-#define UBB_CHUNK_SHORT 256
 #define UBB_RING 128     // pending matches per wave (drained whenever 64 are waiting)
 #define UBB_GAP 4        // list j of the 2-byte copy starts at (cptr[j] & ~3) + UBB_GAP j: 8-byte aligned, no overlap, no offset array
 #define UBB_K16_WORDS 4096   // K16 table size: entries read past a list's end (masked) still index inside it whatever their 17 bits are
@@ -275,8 +274,7 @@ __global__ __launch_bounds__(256) void k_comp_narrow(const int64_t *__restrict__
 }
 
 // NK = keys per lane and step (K16: NK / 4 eight-byte reads of four keys, else NK four-byte reads), NT threads share a table, CH lookahead
-// entries per workgroup: <8, 512, 2048> for long lists; <2, 256, 256> on 4-byte keys is the variant sized for short lists (C2: ~100
-// entries, 234 pairs per first point), reachable through ANNCHOR_UPDATE_BOUNDS=short only: it does not beat the wave-per-pair form there
+// entries per workgroup: <8, 512, 2048>
 template <bool K16, int NK, int NT, int CH>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 6 : 4, NT == 512 ? 6 : 8))) void k_update_bounds_bits(const int32_t *__restrict__ next, int64_t nnext,
                                                            const int2 *__restrict__ ij, const int64_t *__restrict__ cptr,
@@ -533,36 +531,30 @@ extern "C" int annchor_update_bounds(annchor_ctx *c)
         const char *ube = getenv("ANNCHOR_UPDATE_BOUNDS");   // "pairs" / "rows" force a form (tests compare the two)
         // long lists only: with ~100 entries per list (C2) the table rebuilds and the 512-entry strides cost more
         // than they save (0.28 vs 0.14 ms); at 800 entries per list 12.8 vs 18.1 ms
-        // the row-grouped bit-table form ("bits16" / "bits32" / "short" force a variant, "pairs" the wave-per-pair form): long lists on
+        // the row-grouped bit-table form ("bits16" / "bits32" force a variant, "pairs" the wave-per-pair form): long lists on
         // 2-byte keys (4-byte beyond 131 072 points), 512-entry steps; short lists (C2: ~100 entries) on 4-byte keys, 128-entry steps
-        const bool force_short = ube && strcmp(ube, "short") == 0;
         const bool long_form = ube ? strncmp(ube, "bits", 4) == 0 : avg >= 256.0;
-        // (measured at C2 -- 375 000 pairs, ~100-entry lists: short 156 us, wave-per-pair 141 us; N = 3000: 0.34 vs 0.22 ms -- ~100 vector
-        // instructions per pair either way, and the wave-per-pair form has 64 x the waves in flight: short lists keep it)
-        const bool short_form = force_short;
+        // (a row-grouped variant sized for short lists -- 128-entry steps, 256-pair chunks -- measured 156 us against the wave-per-pair
+        // form's 141 us at C2 and 0.34 against 0.22 ms at N = 3000: retired in round 5; short lists keep the wave-per-pair form)
         const bool k16 = long_form && nx <= 131072 && !(ube && strcmp(ube, "bits32") == 0);
-        const int ub_waves = long_form ? UBB_THREADS / 64 : 4;
+        const int ub_waves = UBB_THREADS / 64;
         // (table + per wave a 128-entry ring and two 64-entry accumulator rows + scan / run scratch)
         const size_t bits_bytes = (k16 ? (size_t)UBB_K16_WORDS : ((size_t)nx + 31) / 32) * 8 + (size_t)ub_waves * (UBB_RING * 8 + 2 * 64 * 8 + 4) + 16;
-        const bool rows_form = (long_form || short_form) && bits_bytes <= 128 * 1024 && nx < (1 << 20);
+        const bool rows_form = long_form && bits_bytes <= 128 * 1024 && nx < (1 << 20);
         // Algorithmic bytes.  Wave-per-pair form: both computed lists of every lookahead pair, 12 B per entry (key + value).
         // Row-grouped form: the lookahead list is in pair order, so a first point's list (key + value) is read once per RUN of pairs
         // (<= one per point and per workgroup chunk); of the partners' lists what HAS to be read is the keys, at the width the kernel
         // streams them (2 B, 4 B beyond 131 072 points) -- values are touched for the few per cent of entries that match, a count the
         // host does not know, so they are left out (the fraction is a lower bound; round 2 priced both lists per pair at 12 B per
         // entry and the first row-grouped kernel already came out above 1).
-        const int chunk = long_form ? UBB_CHUNK : UBB_CHUNK_SHORT;
+        const int chunk = UBB_CHUNK;
         const double runs = (double)std::min<int64_t>(c->nnext, nx + (c->nnext + chunk - 1) / chunk);
         const double alg = rows_form ? (double)c->nnext * (avg * (k16 ? 2.0 : 4.0) + 36.0) + runs * avg * 12.0
                                      : (double)c->nnext * (2.0 * avg * 12.0 + 36.0);
         ProfScope ps(c, "update_bounds_intersect", alg);
 #define UBB_ARGS c->next.as<int32_t>(), c->nnext, c->ij.as<int2>(), c->cptr.as<int64_t>(), c->cidx.as<int32_t>(), k16 ? c->c16.as<uint16_t>() : nullptr, \
                  k16 ? c->cbnd.as<uint32_t>() : nullptr, c->cval.as<double>(), c->lb.as<double>(), c->ub.as<double>(), (int)nx
-        if (rows_form && !long_form) {
-            if (bits_bytes > 32 * 1024)
-                ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_update_bounds_bits<false, 2, 256, UBB_CHUNK_SHORT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bits_bytes));
-            k_update_bounds_bits<false, 2, 256, UBB_CHUNK_SHORT><<<ann_blocks(c->nnext, UBB_CHUNK_SHORT), 256, bits_bytes, c->stream>>>(UBB_ARGS);
-        } else if (rows_form) {
+        if (rows_form) {
             if (k16) {
                 ANN_TRY(ann_reserve(c, c->c16, sizeof(uint16_t) * (size_t)(total + UBB_GAP * nx + 16)));
                 ANN_TRY(ann_reserve(c, c->cbnd, sizeof(uint32_t) * (size_t)nx));

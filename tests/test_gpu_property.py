@@ -13,7 +13,7 @@ SETTINGS = dict(max_examples=25, deadline=None, suppress_health_check=list(Healt
 
 @settings(**SETTINGS)
 @given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(2, 60), max_len=st.integers(0, 300), alpha=st.integers(1, 40),
-       variant=st.sampled_from(["0", "1", "2", "4"]))
+       variant=st.sampled_from(["1", "9"]))
 def test_levenshtein_kernel_equals_dp(seed, n, max_len, alpha, variant):
     import os
 
@@ -114,7 +114,7 @@ def test_guarantee_nmin_rounds_equal_the_sequential_sweep(monkeypatch):
             assert np.array_equal(a, b)
         # the row-grouped form reading 4-byte keys (point sets beyond 131 072 take it; forced here)
         monkeypatch.setenv("ANNCHOR_GN_SWEEP", "rounds")
-        for form in ("bits32", "short", "pairs32", "pairs16"):   # ("short": 128-entry steps, 256-pair chunks; "pairs32" / "pairs16": two / four pairs per wave)
+        for form in ("bits32", "pairs32", "pairs16"):   # ("pairs32" / "pairs16": two / four pairs per wave)
             monkeypatch.setenv("ANNCHOR_UPDATE_BOUNDS", form)
             ann = Annchor(data, metric, random_seed=3, **kw).fit()
             bm = (ann.neighbor_graph[0], ann.neighbor_graph[1], ann.evals, ann.RefineApprox, ann.not_computed_mask)
