@@ -170,22 +170,22 @@ def test_c3_full_size_recall():
     # no neighbour listed twice, never the row itself
     srt = np.sort(idx[rows], axis=1)
     assert np.all(srt[:, 1:] != srt[:, :-1])
-    # the 10 000-row truth above comes from the tile kernel itself (full budget); cross-check it, and the graph, against
-    # an INDEPENDENT float64 NumPy brute force on 500 of those rows (columns streamed through the host in blocks)
-    sub = rows[::20]
-    Xs64 = X[sub].astype(np.float64)
-    best = np.full((len(sub), k), np.inf)
-    for c0 in range(0, n, 50000):
-        Xc = X[c0:c0 + 50000].astype(np.float64)
-        d2 = np.maximum((Xs64 ** 2).sum(1)[:, None] + (Xc ** 2).sum(1)[None, :] - 2.0 * Xs64 @ Xc.T, 0.0)
-        best = np.sort(np.concatenate([best, d2], axis=1), axis=1)[:, :k]
-    bd = np.sqrt(best)
-    bd[:, 0] = 0.0                                       # the row itself (cancellation noise of the expanded form)
-    np.testing.assert_allclose(td[::20][:, 1:], bd[:, 1:], rtol=2e-5, atol=1e-5)   # kernel truth == NumPy truth
+    # HEADLINE recall: against an INDEPENDENT float64 brute force (plain torch float64 matrix products on the GPU: none of this
+    # build's kernels) on 2 500 of those rows; the 10 000-row figure above uses the tile kernel itself (full budget) as truth
+    # and is cross-checked here against the independent one
+    from test_c5_gpu import truth_f64
     from annchor_amd import compare_neighbor_graphs
 
-    e_np = compare_neighbor_graphs((idx[sub], bd), (idx[sub], dist[sub]), k)
-    assert 1 - e_np / (len(sub) * float(k)) >= 0.99
+    sel = np.arange(0, len(rows), 4)
+    sub = rows[sel]
+    bd = truth_f64(X[sub], [X], k)
+    bd[:, 0] = 0.0                                       # the row itself (cancellation noise of the expanded form)
+    np.testing.assert_allclose(td[sel][:, 1:], bd[:, 1:], rtol=2e-5, atol=1e-5)   # kernel truth == float64 truth
+    e_ind = compare_neighbor_graphs((idx[sub], bd), (idx[sub], dist[sub]), k)
+    recall_ind = 1 - e_ind / (len(sub) * float(k))
+    print("C3: recall@15 %.4f on %d rows against the independent float64 truth (%.4f on %d rows against the tile kernel's own)"
+          % (recall_ind, len(sub), recall, len(rows)))
+    assert recall_ind >= 0.99
 
 
 def test_dispatch_rules():
