@@ -49,6 +49,7 @@ PAIRLIST_BITMAP_MAX_POINTS = 400000   # keep bitmap + rank table: 12 B per 64 pa
 # graphs the tests pin to the NumPy stream there is nothing to be bit-equal to, and walking a stream as long as the pair list
 # on one host thread dominates the fit (N = 16 000: 178 of 193 ms).  sampler="legacy" / "device" force either.
 DEVICE_SAMPLER_MIN_PAIRS = 4_000_000
+STREAM_MAX_DIM = 1024   # streamed form: rows of up to 1024 dimensions (beyond 128 the k-blocked tile kernel, csrc/knnbk.hip)
 DEVICE_MODEL_MAX_PER_BIN = 6144   # samples per partition up to which the iteration's models are fitted on the device (model.hip: ERR_CAP 8192)
 
 
@@ -195,16 +196,16 @@ class Annchor:
         bundled = self.f is distances_euclidean or self.f is distances_cosine
         defaults = (anchor_picker is None and sampler is None and regression is None and error_predictor is None
                     and get_exact_ijs is None)
-        can_stream = (bundled and defaults and Xa is not None and Xa.ndim == 2 and Xa.dtype == np.float32 and Xa.shape[1] <= 256)
+        can_stream = (bundled and defaults and Xa is not None and Xa.ndim == 2 and Xa.dtype == np.float32 and Xa.shape[1] <= STREAM_MAX_DIM)
         if streamed == "cast":
             # explicit opt-in: float64 (or integer) rows are narrowed to float32 and take the streamed form
-            if not (bundled and defaults and Xa is not None and Xa.ndim == 2 and Xa.shape[1] <= 256):
-                raise ValueError("streamed='cast' needs a numeric [n, dim <= 256] array, the 'euclidean' or 'cosine' metric and "
+            if not (bundled and defaults and Xa is not None and Xa.ndim == 2 and Xa.shape[1] <= STREAM_MAX_DIM):
+                raise ValueError("streamed='cast' needs a numeric [n, dim <= 1024] array, the 'euclidean' or 'cosine' metric and "
                                  "the default plugins")
             Xa = np.ascontiguousarray(Xa, dtype=np.float32)
             can_stream, streamed = True, True
         if streamed is True and not can_stream:
-            raise ValueError("streamed=True needs a float32 [n, dim <= 256] array, the 'euclidean' or 'cosine' metric and the "
+            raise ValueError("streamed=True needs a float32 [n, dim <= 1024] array, the 'euclidean' or 'cosine' metric and the "
                              "default plugins (float64 data is not narrowed behind the caller's back: streamed='cast' narrows it)")
         want_stream = can_stream and (streamed is True or (streamed is None and self.nx > PAIRLIST_MAX_POINTS))
         hard_max = PAIRLIST_MAX_POINTS if (want_stream or self.nx <= PAIRLIST_MAX_POINTS) else pairlist_hard_max(device)
@@ -219,7 +220,7 @@ class Annchor:
                                  "materialised up to %d points on this device (2^30 pairs / 80 %% of its free memory).  Up to %d points "
                                  "the pair-list form runs when the locality filter keeps fewer candidates than that (loc_thresh >= 2 "
                                  "of `locality` nearest anchors in common; refused after the anchors if it does not).  Larger sets "
-                                 "need the streamed form: float32 [n, dim <= 256] data ('cast' narrows float64), 'euclidean' or "
+                                 "need the streamed form: float32 [n, dim <= 1024] data ('cast' narrows float64), 'euclidean' or "
                                  "'cosine', default plugins%s."
                                  % (self.nx, hard_max, PAIRLIST_BITMAP_MAX_POINTS, "" if streamed is not False else " (and streamed != False)"))
             print("Note: %d points is beyond the %d whose complete pair list fits this device; the fit goes on only if the locality "

@@ -1,46 +1,22 @@
-// knnbf.hip -- the tile phase of the streamed k-NN build on the 16-bit matrix cores (k_st_knnbf): split-fp16 tile GEMMs,
-// operands by LDS-DMA, exact re-ranking of what is kept.
+// knnbk.hip -- k_st_knnbk: the split-fp16 tile kernel of knnbf.hip for rows of MORE than 128 dimensions (padded dim 256 .. 1024,
+// a multiple of 128), k-blocked.
 //
-// Same algorithm as k_st_knn (streamed.hip): a workgroup owns a 128-row tile, ranks the column tiles, evaluates them as
-// tile GEMMs and keeps the best columns per row in LDS.  What is different, and why (tools/microbench/shadow.hip,
-// pingpong.hip, f16_split.hip, measured on MI355X):
-//   * v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate and, it turns out, in the vector ALUs' issue slot: nothing
-//     hides in its shadow (64 cycles per MFMA bare; 84 with two v_fma behind each, 110 with eight), so an f32 tile
-//     kernel pays for every threshold test, LDS write and address computation in full -- k_st_knn's 60 % of the f32
-//     peak is that.
-//   * v_mfma_f32_32x32x16_f16 / _bf16 is a real matrix pipe: 32 cycles per MFMA with up to four VALU instructions behind
-//     each for free, and sixteen times the f32 rate.  With every float split into two fp16 (x = hi + lo: 22 bits of
-//     mantissa) a dot product is hi.hi + hi.lo + lo.hi -- three MFMAs per 16 dimensions, 24 per 32 x 32 x 128 block =
-//     768 matrix-pipe cycles against 4096 for the exact f32 stream -- with a measured error of 2^-22 |x||y| (rms 2^-24.7):
-//     the accuracy of the f32 MFMA stream itself (2^-21.5, rms 2^-23.9; split bf16: 2^-19).  fp16's range is handled once
-//     per data set: the rows are centred (c = mean of the anchors) and scaled by the power of two that puts the largest
-//     |coordinate| in (2^12, 2^13] -- exact operations; what underflows below 2^-24 is 37 octaves under the largest value.
-//   * What error is left only matters at the boundary of a row's list.  The lists hold K + ST_BF_MARGIN entries chosen by
-//     the split distance, and the kernel's epilogue recomputes the EXACT float32 distance sum (x - y)^2 of everything kept
-//     (from the original rows) and hands the best K on; it also counts the rows whose K-th exact distance lies within twice
-//     the measured error of the list's last approximate entry -- if more than 1 row in 200 is flagged (neighbours closer
-//     together than float32 products of |x|^2 resolve) the host repeats the tile phase on k_st_knn.  The reported
-//     distances are exact float32 as before; the exactness tests (rtol 1e-5 against float64 brute force with the full
-//     budget) hold unchanged.
-//   * While a wave streams MFMAs back to back, the SIMD's other wave issues NOTHING (pingpong.hip: a partner's VALU or
-//     LDS work beside an MFMA chain takes exactly chain + its own time, whatever s_setprio says).  A producer /
-//     consumer split inside a SIMD therefore serialises; what overlaps is one wave's LATENCY (the LDS round trips of a
-//     list merge, a barrier wait) with another wave's issue.  Hence two independent 4-wave workgroups per CU, one wave of
-//     each on every SIMD, each wave doing everything for its 32 rows: stream, test, insert, merge.
-//
-// Per slab (32 columns) and wave: request the NEXT slab (LDS-DMA `global_load_lds_dwordx4`: no staging registers, no
-// ds_write pass; two ring slots), 16 ds_read_b128 of operands, 24 MFMAs with the previous slab's threshold test in their
-// shadow, survivor inserts, a cooperative list merge, wait for the request, one workgroup barrier.  The LDS image of a slab
-// is lane-linear, so the bank-conflict-free layout is made on the SOURCE side: 16-byte unit kq of column c (units
-// 0..DIM/8-1 the hi halves, then the lo halves) sits at unit kq ^ f(c) of the column's run and the operand reads apply the
-// same XOR.
-//
-// Decisions that steer the stream (skip a ranked tile whose bound has fallen behind the thresholds, early stop, budget)
-// are taken by every wave from barrier-separated LDS state, for the tile AFTER the one in the stream and from the
-// thresholds as merged through the tile BEFORE it -- a fixed lag, so runs are reproducible.
+// k_st_knnbk keeps a wave's 32 rows x 128 dimensions as fp16 hi / lo operands in registers for the whole kernel and finishes a
+// 32 x 32 block of dot products per column slab.  Beyond 128 dimensions the operands do not fit, so the dimensions are cut into
+// NKB = dim / 128 blocks and a column TILE (128 columns = 4 slabs) is finished block by block: four accumulators (one per slab)
+// stay in registers across the blocks; per block the wave converts its rows' 128 dimensions of that block to hi / lo operands
+// (from the float32 rows, centred and scaled as in knnbf.hip) and streams the block's four column slabs -- the same 16 KB
+// LDS-DMA slabs, the same ring, the same operand layout (a slab of block kb = the block's 128 hi halves and 128 lo halves of 32
+// columns: two 256-byte runs of every column's row in the split copy).  After the last block the four slabs are tested against
+// the rows' thresholds and merged into the lists exactly as knnbf.hip does it slab by slab.  Rows are read once per column tile
+// (NKB x 64 KB per workgroup) beside the columns' NKB x 64 KB: twice the bytes per flop of the 128-dimension kernel.
+// Everything else -- ranking of the column tiles, selection rounds, pruning, early stop, budget, the join passes' gathered
+// columns, the exact float32 re-ranking of the K + 2 kept columns and the guard count -- is knnbf.hip's code, with the padded
+// dimension a run-time number.  (The exact-f32 kernel k_st_knn stops at padded dim 256: beyond it there is no fallback for
+// data the guard flags as ill-conditioned -- the caller is told through annchor_stream_last_kernel.)
 #include "streamed.h"
 
-#define STB_THREADS 256
+#define STBK_THREADS 256
 #define ST_BF_MARGIN 2   // list entries beyond K kept by the split-fp16 distance (re-ranked exactly at the end)
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -51,7 +27,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 //   6 merge (+ publish, run prologue / tail)      7 ranking, selection rounds, the rest
 #ifdef ST_PROFILE
 // (ordered: nothing may be scheduled across the time stamp, and it waits for the wave's outstanding LDS / scalar traffic)
-__device__ __forceinline__ long long st8_now()
+__device__ __forceinline__ long long stk_now()
 {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -59,19 +35,19 @@ __device__ __forceinline__ long long st8_now()
     __builtin_amdgcn_sched_barrier(0);
     return (long long)t;
 }
-#define P8(i) { const long long pf_n = st8_now(); pf[i] += pf_n - pf_t; pf_t = pf_n; }
+#define P8(i) { const long long pf_n = stk_now(); pf[i] += pf_n - pf_t; pf_t = pf_n; }
 // sub-segment stamp: time since the last P8 / PS goes to slot i (8..15) without resetting the P8 clock
-#define PS(i) { const long long pf_n = st8_now(); pf[i] += pf_n - pf_s; pf_s = pf_n; }
-#define PS0 { pf_s = st8_now(); }
+#define PS(i) { const long long pf_n = stk_now(); pf[i] += pf_n - pf_s; pf_s = pf_n; }
+#define PS0 { pf_s = stk_now(); }
 #else
 #define P8(i)
 #define PS(i)
 #define PS0
 #endif
 
-template <int DIM, int KMAX> struct KnnSharedB {
+template <int DIM, int KMAX> struct KnnSharedK {
     static constexpr int SLABF = ST_SLAB * DIM;                                 // floats per operand slab
-    static constexpr int RINGF = 2 * SLABF * 4 >= 12288 ? 2 * SLABF : 12288 / 4;   // (>= sizeof(SelBuf))
+    static constexpr int RINGF = 2 * SLABF * 4 >= 12288 ? 2 * SLABF : 12288 / 4;   // (>= sizeof(SelBufK))
     float ring[RINGF];   // FIRST (LDS-DMA destinations stay below 64 KB); two slots, slot = slab parity.  Between runs the
                          // selection's sort buffers (SelBuf) live here
     float cand_d[ST_T][ST_SLAB + 1];   // (between runs: the selection's 4096-bin histogram; at the end: exact distances)
@@ -83,7 +59,7 @@ template <int DIM, int KMAX> struct KnnSharedB {
     float rrow[ST_T];    // |x_row|^2
     int cnt[ST_T];
     float loI[64], hiI[64], midI[64];
-    uint32_t slab_id[4][ST_SLAB];   // join passes: ordered column index of each column of a slab (slot = slab & 3)
+    uint32_t slab_id[8][ST_SLAB];   // join passes: ordered column index of each column of the tile's four slabs, by tile parity
     float run_vb[ST_KEEP];     // the current round's tiles in rank order: valid bound, tile
     int32_t run_j[ST_KEEP];
     float wave_thr[2][4];   // worst k-th squared distance per 32-row group, published at the end of tile n into [n & 1]
@@ -92,20 +68,20 @@ template <int DIM, int KMAX> struct KnnSharedB {
     int sel_bin;
     uint32_t sel_before;
 };
-struct SelBuf {   // candidate tiles of a selection round (aliases the operand ring, idle between runs)
+struct SelBufK {   // candidate tiles of a selection round (aliases the operand ring, idle between runs)
     float surv_lb[ST_SURV];
     float surv_vb[ST_SURV];
     int32_t surv_j[ST_SURV];
 };
 
 // swizzle of a column's 16-byte units (see the header comment); UPC = units per column
-template <int UPC> __device__ __forceinline__ int unit_swz(int col) { return UPC >= 16 ? (col & 15) : ((col >> 1) & (UPC - 1)); }
+template <int UPC> __device__ __forceinline__ int unit_swzk(int col) { return UPC >= 16 ? (col & 15) : ((col >> 1) & (UPC - 1)); }
 
 // End of a slab: the wave's LDS-DMA pieces of the next slab have landed and its LDS traffic is done; the barrier hands the
 // next slab to every wave and this slab's ring slot back to the requests.  (The requests are invisible to the compiler's
 // wait bookkeeping -- inline asm; sched_barrier: the memory clobber alone does not keep register-only instructions on
 // their side.)
-__device__ __forceinline__ void slab_end()
+__device__ __forceinline__ void slab_endk()
 {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -114,17 +90,19 @@ __device__ __forceinline__ void slab_end()
 
 // JOIN: a join pass (streamed.hip: k_st_join_cands has collected the row tile's candidate columns) -- the "tiles" are runs of
 // 128 gathered columns of the candidate list, the lists start from the previous phase's, nothing is ranked or pruned.
-template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_st_knnbf(KnnArgs a)
+template <int KMAX, bool JOIN = false> __global__ __launch_bounds__(STBK_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_st_knnbk(KnnArgs a)
 {
+    constexpr int DIM = 128;                // dimensions per block; a.dimr (a multiple of DIM) = the rows' padded dimension
+    const int dimr = __builtin_amdgcn_readfirstlane(a.dimr), nkb = dimr / DIM;
     extern __shared__ __attribute__((aligned(16))) unsigned char smemb[];
-    KnnSharedB<DIM, KMAX> &sh = *reinterpret_cast<KnnSharedB<DIM, KMAX> *>(smemb);
+    KnnSharedK<DIM, KMAX> &sh = *reinterpret_cast<KnnSharedK<DIM, KMAX> *>(smemb);
     constexpr int UPC = DIM / 4;            // 16-byte units per column
     constexpr int NV = UPC / 2;             // operand reads (ds_read_b128) per slab and lane: G hi + G lo
     constexpr int NPIECE = UPC * ST_SLAB / 64;   // 1 KB pieces per slab
     constexpr int NI = NPIECE / 4;          // pieces per loading wave
     static_assert(NI == 1 || NI == 2 || NI == 4, "pieces per loading wave");
     static_assert(sizeof(sh.ring) <= 65536, "LDS-DMA destinations must stay below 64 KB");
-    static_assert(sizeof(SelBuf) <= sizeof(sh.ring) && sizeof(SelBuf) == 12288, "selection buffers alias the ring");
+    static_assert(sizeof(SelBufK) <= sizeof(sh.ring) && sizeof(SelBufK) == 12288, "selection buffers alias the ring");
     static_assert(KMAX <= ST_SLAB + 1, "the exact re-ranking reuses cand_d with row stride KMAX");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -146,12 +124,14 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     // eight fp16 hi parts and eight lo parts of the centred, scaled values
     constexpr int G = DIM / 16;
     f16x8 ah[G], al[G];
-    const float scale = a.cvec[DIM];              // power of two: the centred data's largest |coordinate| becomes <= 2^13
+    const float scale = a.cvec[dimr];              // power of two: the centred data's largest |coordinate| becomes <= 2^13
     const float inv_scale2 = 1.f / (scale * scale);
-    float rr_c;   // this lane's half of |scale (x_row - c)|^2 (summed with the other half below)
-    {
-        const float *xr = a.Rs + (size_t)(grow0 + rowbase + col) * DIM + 8 * half;
-        const float *cv = a.cvec + 8 * half;
+    const float *xrow = a.Rs + (size_t)(grow0 + rowbase + col) * dimr + 8 * half;
+    // block kb of the wave's rows -> operand registers (hi / lo halves of the centred, scaled values); returns the lane's share
+    // of the block's squared norm
+    auto load_rows = [&](int kb) __attribute__((always_inline)) -> float {
+        const float *xr = xrow + kb * DIM;
+        const float *cv = a.cvec + kb * DIM + 8 * half;
         float acc2 = 0.f;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -169,6 +149,12 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
                 acc2 += x * x;
             }
         }
+        return acc2;
+    };
+    float rr_c;   // |scale (x_row - c)|^2 over all blocks
+    {
+        float acc2 = 0.f;
+        for (int kb = 0; kb < nkb; ++kb) acc2 += load_rows(kb);
         rr_c = acc2 + __shfl_xor(acc2, 32);
     }
     if (threadIdx.x < ST_T) {
@@ -212,7 +198,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     uint32_t *ebits = (!JOIN && a.eval_bits) ? a.eval_bits + (size_t)bt * a.eval_words : nullptr;   // (a join pass only reads them)
 #ifdef ST_PROFILE
     long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    long long pf_t = st8_now();
+    long long pf_t = stk_now();
     long long pf_s = pf_t;
 #endif
     __syncthreads();
@@ -226,26 +212,31 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     // ---------------------------------------------------------------- the pieces of a phase
     // operand slab `slab` of column tile J -> ring slot `slab`: this wave's NI pieces
     // (the lane -> (column, unit) map of a piece never changes: byte offsets inside a slab's 32 rows, once)
-    uint32_t loff[NI];
+    uint32_t loff[NI], lrow[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int u = (rg * NI + i) * 64 + lane;
         const int c = u / UPC, x = u % UPC;
-        loff[i] = (uint32_t)(c * DIM * 4 + ((x ^ unit_swz<UPC>(c)) << 4));
+        const int xs = x ^ unit_swzk<UPC>(c);   // the source unit that lands at unit x: 0..15 hi halves, 16..31 lo halves of the block
+        lrow[i] = (uint32_t)(c * dimr * 4);
+        loff[i] = lrow[i] + (uint32_t)(xs < 16 ? xs * 16 : dimr * 2 + (xs - 16) * 16);   // (+ 256 kb: block kb of the row)
     }
-    const char *xb = reinterpret_cast<const char *>(a.Xb);   // [n_all][2][DIM] fp16: hi parts, then lo parts of every ordered row (centred, scaled)
+    const char *xb = reinterpret_cast<const char *>(a.Xb);   // [n_all][2][dimr] fp16: hi parts, then lo parts of every ordered row (centred, scaled)
     const uint32_t *ulist = JOIN ? a.ucand + (size_t)bt * a.ucap : nullptr;   // join: sorted candidate columns, 0xffffffff padded to 128
-    auto issue_slab = [&](int J, int slab) {
+    // operand slab `slab` of column tile J, dimension block kb -> ring slot `slot`: this wave's NI pieces
+    auto issue_slab = [&](int J, int slab, int kb, int slot) __attribute__((always_inline)) {
+        // (uniform by construction; the loops they live in end on values read from LDS, which the compiler cannot know to be)
+        J = __builtin_amdgcn_readfirstlane(J); kb = __builtin_amdgcn_readfirstlane(kb); slot = __builtin_amdgcn_readfirstlane(slot);
+        const uint32_t dst = lds0 + (uint32_t)(slot * ST_SLAB * DIM * 4 + rg * NI * 1024);
         if constexpr (JOIN) {
             // gathered columns: every lane's source is its own column's row (per-lane 64-bit addresses)
-            const uint32_t dst = lds0 + (uint32_t)((slab & 1) * ST_SLAB * DIM * 4 + rg * NI * 1024);
             const int64_t c0 = (int64_t)J * ST_T + slab * ST_SLAB;
             const char *srcs[NI];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int u = (rg * NI + i) * 64 + lane;
                 const uint32_t id = ulist[c0 + u / UPC];
-                srcs[i] = xb + (size_t)(id == 0xffffffffu ? 0u : id) * (DIM * 4) + (loff[i] - (uint32_t)((u / UPC) * DIM * 4));
+                srcs[i] = xb + (size_t)(id == 0xffffffffu ? 0u : id) * ((size_t)dimr * 4) + (loff[i] - lrow[i]) + (size_t)kb * 256;
             }
             unsigned keep;
 #pragma unroll
@@ -254,92 +245,55 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
                              : "=&s"(keep) : "v"(srcs[i]), "s"(dst + (uint32_t)(i * 1024)) : "memory");
             return;
         }
-        const char *src = xb + ((size_t)J * ST_T + slab * ST_SLAB) * (DIM * 4);              // wave-uniform: an SGPR pair
-        const uint32_t dst = lds0 + (uint32_t)((slab & 1) * ST_SLAB * DIM * 4 + rg * NI * 1024);   // this wave's pieces of the slot
+        const unsigned long long sa64 = (unsigned long long)(uintptr_t)(xb + ((size_t)J * ST_T + slab * ST_SLAB) * ((size_t)dimr * 4) + (size_t)kb * 256);
+        const char *src = reinterpret_cast<const char *>(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sa64 >> 32)) << 32) |
+                                                         (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sa64));   // wave-uniform: an SGPR pair
         unsigned keep;
-        if constexpr (NI == 4)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
-                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
-                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(loff[0]), "v"(loff[1]), "v"(loff[2]), "v"(loff[3]), "s"(src), "s"(dst) : "memory", "scc");
-        else if constexpr (NI == 2)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(loff[0]), "v"(loff[1]), "s"(src), "s"(dst) : "memory", "scc");
-        else
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(loff[0]), "s"(src), "s"(dst) : "memory");
+        static_assert(NI == 4, "128-dimension blocks: four pieces per wave");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(loff[0]), "v"(loff[1]), "v"(loff[2]), "v"(loff[3]), "s"(src), "s"(dst) : "memory", "scc");
     };
-    f32x16 acc0, acc1;          // slabs 0, 2 / slabs 1, 3 of a tile: one is streamed into while the other one is tested
-    float rj_c = 0.f;           // squared norm of the lane's column in the slab being streamed (requested at its start)
-    // the slab whose accumulators wait for their test (the one streamed before the current one)
+    f32x16 acc[4];              // the four slabs of the column tile in the stream: summed over the dimension blocks
+    float rj4[4] = {0.f, 0.f, 0.f, 0.f};   // squared norms of the lane's column in each of them (requested at the tile's first block)
+    // the slab whose accumulators are being tested / merged
     bool pend = false;
-    int pJ = 0, pslab = 0;
+    int pJ = 0, pslab = 0, ppar = 0, tpar = 0;   // (tpar: parity of the tile in the stream -- the join passes' column ids are double-buffered by it)
     float prj = 0.f;
     uint32_t ppass = 0;
-    // 3 DIM / 16 MFMAs of this wave's 32 rows against the 32 columns in ring slot `slab` (columns of tile J) into accC, with
-    // the threshold test of the PREVIOUS slab's accumulators accP in their shadow (the 16-bit matrix pipe takes an MFMA
-    // every 32 cycles and up to four vector instructions behind each one for free, tools/microbench/shadow.hip): row r of
-    // the lane's column passes iff x_r . x_c > hb[r] + |x_c|^2 / 2 (hb: one LDS word per row, kept by the merge).  The
-    // columns' squared norms are requested at the start of their slab and used one slab later: a global round trip under
-    // load is thousands of cycles.
-    auto stream_slab = [&](int J, int slab, f32x16 &accC, const f32x16 &accP) {
-        PS0
-        if constexpr (JOIN) {
-            const uint32_t id = ulist[(int64_t)J * ST_T + slab * ST_SLAB + col];
-            rj_c = id == 0xffffffffu ? INFINITY : a.rsb[id];   // (padding never passes: x.y > hb + inf is false)
-            if (wave == 0 && lane < ST_SLAB) sh.slab_id[slab & 3][lane] = id;
-        } else {
-            rj_c = a.rsb[(int64_t)J * ST_T + slab * ST_SLAB + col];
-        }
-        const float4 *base = reinterpret_cast<const float4 *>(&sh.ring[(slab & 1) * (ST_SLAB * DIM)]) + col * UPC;
-        const int gsw = half ^ unit_swz<UPC>(col);
-        float hq[16];   // (first: LDS data returns in order, and the test must not wait for the operands behind it)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 h4 = *reinterpret_cast<const float4 *>(&sh.hb[rowq + 8 * q]);
-            hq[4 * q] = h4.x; hq[4 * q + 1] = h4.y; hq[4 * q + 2] = h4.z; hq[4 * q + 3] = h4.w;
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    // 3 DIM / 16 MFMAs of this wave's 32 rows (block operands ah / al) against the 32 columns in ring slot `slot` into accC
+    auto mfma_slab = [&](int slot, f32x16 &accC) __attribute__((always_inline)) {
+        const float4 *base = reinterpret_cast<const float4 *>(&sh.ring[slot * (ST_SLAB * DIM)]) + col * UPC;
+        const int gsw = half ^ unit_swzk<UPC>(col);
         float4 b[NV];   // b[g]: hi parts of k-step g; b[G + g]: lo parts
 #pragma unroll
         for (int v = 0; v < NV; ++v) b[v] = base[(2 * v) ^ gsw];
-        // all LDS reads first, then MFMAs with the test's vector instructions between them (left alone the scheduler sinks
-        // each read to its use and the stream waits out an LDS round trip every few MFMAs)
         __builtin_amdgcn_sched_group_barrier(0x100, NV, 0);
-        PS(8)    // operand reads landed (the stamp waits for them)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accC[r] = 0.f;
-        const float hrj = 0.5f * prj;
-        uint32_t pass = 0;
-        constexpr int NM = 3 * G;                       // MFMAs
-        constexpr int TPM = (16 + NM - 1) / NM;         // row tests per MFMA
 #pragma unroll
         for (int g = 0; g < G; ++g) {   // small terms first
+            accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g], __builtin_bit_cast(f16x8, b[g]), accC, 0, 0, 0);
+            accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], __builtin_bit_cast(f16x8, b[G + g]), accC, 0, 0, 0);
+            accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], __builtin_bit_cast(f16x8, b[g]), accC, 0, 0, 0);
+        }
+    };
+    // the norms (and, join passes, the ids) of the four slabs' columns of tile J
+    auto tile_norms = [&](int J) __attribute__((always_inline)) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int m = 3 * g + t;
-                if (t == 0) accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g], __builtin_bit_cast(f16x8, b[g]), accC, 0, 0, 0);
-                if (t == 1) accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], __builtin_bit_cast(f16x8, b[G + g]), accC, 0, 0, 0);
-                if (t == 2) accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], __builtin_bit_cast(f16x8, b[g]), accC, 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < TPM; ++u) {
-                    const int r = m * TPM + u;
-                    if (r < 16) pass |= (accP[r] > hq[r] + hrj ? 1u : 0u) << r;
-                }
-                // (pinned by data flow: the tests are pure arithmetic and every scheduling hint -- sched_group_barrier,
-                // sched_barrier -- left them all behind the last MFMA; an empty asm that "uses" the accumulator and the
-                // mask keeps MFMA m and test m on this side of it)
-                asm volatile("" : "+v"(accC), "+v"(pass));
+        for (int sl = 0; sl < 4; ++sl) {
+            if constexpr (JOIN) {
+                const uint32_t id = ulist[(int64_t)J * ST_T + sl * ST_SLAB + col];
+                rj4[sl] = id == 0xffffffffu ? INFINITY : a.rsb[id];   // (padding never passes: x.y > hb + inf is false)
+                if (wave == 0 && lane < ST_SLAB) sh.slab_id[(tpar << 2) + sl][lane] = id;
+            } else {
+                rj4[sl] = a.rsb[(int64_t)J * ST_T + sl * ST_SLAB + col];
             }
         }
-        ppass = pend ? pass : 0u;
-        PS(9)    // MFMAs issued
     };
     // what the shadow test let through (slab pslab of tile pJ, accumulators accP, column norms prj): survivors into the rows'
     // candidate slots, then the merge into the sorted lists
-    auto insert_merge = [&](const f32x16 &accP) {
+    auto insert_merge = [&](const f32x16 &accP) __attribute__((always_inline)) {
         const int J = pJ, slab = pslab;
         const float rj = prj;
         uint32_t pass = ppass;
@@ -396,7 +350,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
                     const bool on = q < nc;
                     const float d = on ? sh.cand_d[row][q] : INFINITY;
                     int32_t cc;
-                    if constexpr (JOIN) cc = on ? (int32_t)sh.slab_id[slab & 3][sh.cand_c[row][q]] : 0x7fffffff;
+                    if constexpr (JOIN) cc = on ? (int32_t)sh.slab_id[(ppar << 2) + slab][sh.cand_c[row][q]] : 0x7fffffff;
                     else cc = on ? col0 + sh.cand_c[row][q] : 0x7fffffff;
                     const bool before = e < KL && (ld < d || (ld == d && lc < cc));   // entries that stay ahead of the candidate
                     const unsigned long long bb = __ballot(before);
@@ -435,7 +389,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
         P8(6)
     };
     // the pending slab's test without a stream to hide it in (end of a run)
-    auto test_only = [&](const f32x16 &accP) {
+    auto test_only = [&](const f32x16 &accP) __attribute__((always_inline)) {
         uint32_t pass = 0;
         const float hrj = 0.5f * prj;
 #pragma unroll
@@ -465,7 +419,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
 
     // One run of the stream over a list of tiles in rank order: list entry q is (tile `jl(q)`, valid bound `vb(q)`);
     // entries whose bound has fallen behind the thresholds are skipped.  Uniform: every wave takes the same path.
-    auto run = [&](int ns, auto jl, auto vb) {
+    auto run = [&](int ns, auto jl, auto vb) __attribute__((always_inline)) {
         int q = 0;
         auto next_tile = [&](int in_stream) -> int {
             if (!JOIN && a.early_window > 0 && !dried) {
@@ -495,64 +449,61 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
         P8(7)
         int J = next_tile(0);
         if (J < 0) return;
-        // fill: slab 0 of the first tile
-        issue_slab(J, 0);
-        slab_end();
+        // fill: block 0 of slab 0 of the first tile
+        int sidx = 0;   // slab counter of the run: ring slot = sidx & 1
+        issue_slab(J, 0, 0, 0);
+        (void)load_rows(0);
+        slab_endk();
         P8(6)
-        pend = false;
-        // one slab: request the next one, stream (the previous slab's test in the shadow), insert / merge the previous slab
-        // (the column norms requested at the start of a slab have landed by its end -- slab_end waits for everything -- but the
-        // compiler does not know: without this it parks its own wait, and the whole shadow test behind it, after the MFMAs)
-#define RJ_LANDED asm volatile("" : "+v"(prj));
-        auto step = [&](int Jc, int sl, f32x16 &accC, const f32x16 &accP) {
-            stream_slab(Jc, sl, accC, accP);
-            P8(0)
-            if (pend) insert_merge(accP);
-            pend = true; pJ = Jc; pslab = sl; prj = rj_c;
-        };
         for (;;) {
+            tile_norms(J);
             int Jn = -1;
-            issue_slab(J, 1);
-            P8(4)
-            step(J, 0, acc0, acc1);
-            slab_end();
-            RJ_LANDED
-            P8(1)
-            issue_slab(J, 2);
-            P8(4)
-            step(J, 1, acc1, acc0);
-            slab_end();
-            RJ_LANDED
-            P8(1)
-            issue_slab(J, 3);
-            P8(4)
-            step(J, 2, acc0, acc1);
-            slab_end();
-            RJ_LANDED
-            P8(1)
-            // ---- slab 3: the next tile is chosen (thresholds / insertion counts as of the tile before J: published before the
-            // last barrier of that tile and untouched since -- the same choice in every wave) and its slab 0 requested
-            Jn = next_tile(1);
-            P8(2)
-            if (Jn >= 0) issue_slab(Jn, 0);
-            P8(4)
-            step(J, 3, acc1, acc0);
-            publish();     // (the lists as merged through slab 2 of this tile; slab 3's survivors go in during the next slab)
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[sl][r] = 0.f;
+            for (int kb = 0; kb < nkb; ++kb) {
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    // the next slab of the sequence: the block's next slab, the next block's first, or the next tile's
+                    if (sl < 3) issue_slab(J, sl + 1, kb, (sidx + 1) & 1);
+                    else if (kb + 1 < nkb) issue_slab(J, 0, kb + 1, (sidx + 1) & 1);
+                    else {
+                        // the next tile is chosen from the thresholds / insertion counts as of the tile before J (published before
+                        // that tile's last barrier and untouched since: the same choice in every wave)
+                        Jn = next_tile(1);
+                        P8(2)
+                        if (Jn >= 0) issue_slab(Jn, 0, 0, (sidx + 1) & 1);
+                    }
+                    P8(4)
+                    mfma_slab(sidx & 1, acc[sl]);
+                    // the rows' next block of operands (the same rows' block 0 for the next tile): requested behind the block's last
+                    // MFMAs, waited for together with the slab request at the barrier
+                    if (sl == 3) (void)load_rows(kb + 1 < nkb ? kb + 1 : 0);
+                    P8(0)
+                    ++sidx;
+                    slab_endk();
+                    P8(1)
+                }
+            }
+            // the tile's four slabs: test against the rows' thresholds, survivors in, merge -- slab after slab, each against the
+            // lists as the one before left them
+            pend = true;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                pJ = J; pslab = sl; prj = rj4[sl]; ppar = tpar;
+                test_only(acc[sl]);
+                insert_merge(acc[sl]);
+            }
+            pend = false;
+            publish();
             ++tdone;
-            slab_end();
-            RJ_LANDED
-            P8(1)
+            tpar ^= 1;
+            P8(6)
             if (Jn < 0) break;
             J = Jn;
         }
-        // ---- tail: the last slab's test and merge, and the thresholds the selection of the next round reads
-#undef RJ_LANDED
-        test_only(acc1);
-        insert_merge(acc1);
-        pend = false;
-        publish();
-        ++tdone;
-        slab_end();
+        slab_endk();   // (every wave has left the ring and the lists: the selection takes them back)
         P8(6)
     };
 
@@ -573,7 +524,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     // tiles in (key, tile) order, collect, sort, stream}
     float *skey = a.scr_key + (size_t)bt * a.nt_all;
     float *slb = a.scr_lb + (size_t)bt * a.nt_all;
-    for (int J = threadIdx.x; J < a.nt_all; J += STB_THREADS) {
+    for (int J = threadIdx.x; J < a.nt_all; J += STBK_THREADS) {
         float lb = 0.f, lbc = 0.f;
         for (int an = 0; an < a.na; ++an) {
             const float lj = a.lo[(size_t)an * a.nt_all + J], hj = a.hi[(size_t)an * a.nt_all + J];
@@ -588,7 +539,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     }
     __syncthreads();   // block-scope visibility of the scratch row (same CU)
     uint32_t *hist = reinterpret_cast<uint32_t *>(&sh.cand_d[0][0]);   // 4096 bins; cand_d is idle between runs
-    SelBuf &sb = *reinterpret_cast<SelBuf *>(&sh.ring[0]);           // the ring is idle between runs too
+    SelBufK &sb = *reinterpret_cast<SelBufK *>(&sh.ring[0]);           // the ring is idle between runs too
     static_assert(sizeof(sh.cand_d) >= 4096 * sizeof(uint32_t), "histogram does not fit");
     uint32_t done_bits = 0;   // (done_bits, done_j): key bits / index of the last tile already considered
     int done_j = -1;
@@ -601,9 +552,9 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
             const int shift = level == 0 ? 20 : level == 1 ? 8 : 0;
             const int nbins = level == 2 ? 256 : 4096;
             const uint32_t pmask = level == 0 ? 0u : level == 1 ? 0xfff00000u : 0xffffff00u;
-            for (int q = threadIdx.x; q < nbins; q += STB_THREADS) hist[q] = 0;
+            for (int q = threadIdx.x; q < nbins; q += STBK_THREADS) hist[q] = 0;
             __syncthreads();
-            for (int J = threadIdx.x; J < a.nt_all; J += STB_THREADS) {
+            for (int J = threadIdx.x; J < a.nt_all; J += STBK_THREADS) {
                 const uint32_t kb = __float_as_uint(skey[J]);
                 const float lb = slb[J];
                 const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
@@ -613,7 +564,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
             __syncthreads();
             // first bin whose cumulative count reaches `want`: thread t owns bins [per t, per (t+1)) (threads beyond the
             // bins own none); exclusive scan over the threads, then the owner of the crossing walks its bins
-            const int per = nbins >= STB_THREADS ? nbins / STB_THREADS : 1;
+            const int per = nbins >= STBK_THREADS ? nbins / STBK_THREADS : 1;
             const bool owner = (int)threadIdx.x * per < nbins;
             uint32_t mine = 0;
             if (owner)
@@ -645,7 +596,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
         const uint32_t cut_bits = all ? 0x7f7fffffu : prefix;   // take keys <= cut (ties resolved by the sort below)
         if (threadIdx.x == 0) sh.nsurv = 0;
         __syncthreads();
-        for (int J = threadIdx.x; J < a.nt_all; J += STB_THREADS) {
+        for (int J = threadIdx.x; J < a.nt_all; J += STBK_THREADS) {
             const uint32_t kb = __float_as_uint(skey[J]);
             const float lb = slb[J];
             const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
@@ -658,12 +609,12 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
         int ns = min(sh.nsurv, ST_SURV);
         if (ns == 0) break;
         {   // sort by (rank key, J): bitonic over ST_SURV slots
-            for (int q = threadIdx.x; q < ST_SURV; q += STB_THREADS)
+            for (int q = threadIdx.x; q < ST_SURV; q += STBK_THREADS)
                 if (q >= ns) { sb.surv_lb[q] = INFINITY; sb.surv_j[q] = 0x7fffffff; }
             __syncthreads();
             for (int k2 = 2; k2 <= ST_SURV; k2 <<= 1)
                 for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-                    for (int q = threadIdx.x; q < ST_SURV; q += STB_THREADS) {
+                    for (int q = threadIdx.x; q < ST_SURV; q += STBK_THREADS) {
                         const int p2 = q ^ j2;
                         if (p2 > q) {
                             const bool up = (q & k2) == 0;
@@ -684,7 +635,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
         const uint32_t round_last_bits = __float_as_uint(sb.surv_lb[ns - 1]);
         const int round_last_j = sb.surv_j[ns - 1];
         // the round's tiles leave the ring before the stream takes it back
-        for (int q = threadIdx.x; q < ns; q += STB_THREADS) { sh.run_j[q] = sb.surv_j[q]; sh.run_vb[q] = sb.surv_vb[q]; }
+        for (int q = threadIdx.x; q < ns; q += STBK_THREADS) { sh.run_j[q] = sb.surv_j[q]; sh.run_vb[q] = sb.surv_vb[q]; }
         __syncthreads();   // hist (cand_d) and the sort buffers (ring) are idle again: the stream may run
         run(ns, [&](int q) { return sh.run_j[q]; }, [&](int q) { return sh.run_vb[q]; });
         done_bits = round_last_bits;
@@ -701,16 +652,16 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     if (threadIdx.x == 0) sh.nsurv = 0;
     {
         float *ex = &sh.cand_d[0][0];   // [ST_T][KMAX] exact d^2 (cand_d is idle now; row stride KMAX <= ST_SLAB + 1)
-        for (int q = threadIdx.x; q < ST_T * KL; q += STB_THREADS) {
+        for (int q = threadIdx.x; q < ST_T * KL; q += STBK_THREADS) {
             const int row = q / KL, e = q - row * KL;
             const int32_t cc = sh.list_c[row][e];
             float d2 = INFINITY;
             if (cc != 0x7fffffff && sh.list_d[row][e] < INFINITY) {
-                const float4 *x = reinterpret_cast<const float4 *>(a.Rs + (size_t)(grow0 + row) * DIM);
-                const float4 *y = reinterpret_cast<const float4 *>(a.Xs + (size_t)cc * DIM);
+                const float4 *x = reinterpret_cast<const float4 *>(a.Rs + (size_t)(grow0 + row) * dimr);
+                const float4 *y = reinterpret_cast<const float4 *>(a.Xs + (size_t)cc * dimr);
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
-                for (int t = 0; t < DIM / 4; ++t) {
+                for (int t = 0; t < dimr / 4; ++t) {
                     const float4 u = x[t], v = y[t];
                     const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z, dw = u.w - v.w;
                     s0 += dx * dx; s1 += dy * dy; s2 += dz * dz; s3 += dw * dw;
@@ -747,7 +698,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
             if (!JOIN && nfin > K && ex[row * KMAX + K - 1] + 2.f * eps > sh.list_d[row][KL - 1] * inv_scale2) atomicAdd(&sh.nsurv, 1);   // (nsurv is idle here)
         }
         __syncthreads();
-        for (int q = threadIdx.x; q < ST_T * K; q += STB_THREADS) {
+        for (int q = threadIdx.x; q < ST_T * K; q += STBK_THREADS) {
             const int row = q / K, e = q - row * K;
             const float d2 = ex[row * KMAX + e];
             float *od = JOIN ? a.out_d2_new : a.out_d2;
@@ -773,130 +724,29 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
 #endif
 }
 
-template <int DIM, int KMAX> static int launchb(annchor_ctx *c, const KnnArgs &a, bool join)
+template <int KMAX> static int launchk(annchor_ctx *c, const KnnArgs &a, bool join)
 {
-    const size_t lds = sizeof(KnnSharedB<DIM, KMAX>);
-    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "streamed k-NN (split-fp16 form) needs %zu B of LDS", lds);
+    const size_t lds = sizeof(KnnSharedK<128, KMAX>);
+    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "streamed k-NN (k-blocked split-fp16 form) needs %zu B of LDS", lds);
     if (join) {
-        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knnbf<DIM, KMAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_st_knnbf<DIM, KMAX, true><<<a.tile_count, STB_THREADS, lds, c->stream>>>(a);
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knnbk<KMAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_st_knnbk<KMAX, true><<<a.tile_count, STBK_THREADS, lds, c->stream>>>(a);
     } else {
-        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knnbf<DIM, KMAX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_st_knnbf<DIM, KMAX, false><<<a.tile_count, STB_THREADS, lds, c->stream>>>(a);
+        ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knnbk<KMAX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_st_knnbk<KMAX, false><<<a.tile_count, STBK_THREADS, lds, c->stream>>>(a);
     }
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
 }
 
-// The tile phase through the split-fp16 kernel when the shape fits it (padded dim <= 128: a slab of 32 columns is 16 KB there;
-// K + ST_BF_MARGIN <= 32 list entries; the split copy of the columns exists); *handled = false sends the caller to the
-// exact-f32 kernel k_st_knn.
-int ann_stream_launch_knnbf(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool *handled, bool join)
+// The tile phase / a join pass for rows of padded dimension 256 .. 1024 (a multiple of 128) when K + 2 <= 32 list entries and the
+// split copy of the columns exists; *handled = false otherwise (padded dim 256: the caller's exact-f32 kernel takes it).
+int ann_stream_launch_knnbk(annchor_ctx *c, const KnnArgs &a0, int dim_padded, bool *handled, bool join)
 {
+    *handled = false;
+    if (dim_padded < 256 || dim_padded > 1024 || (dim_padded & 127) || a0.K + ST_BF_MARGIN > ST_KMAX || !a0.Xb || !a0.rsb || !a0.cvec) return ANNCHOR_OK;
     *handled = true;
-    if (a.K + ST_BF_MARGIN > ST_KMAX || !a.Xb || !a.rsb || !a.cvec) { *handled = false; return ANNCHOR_OK; }
-    const bool k16 = a.K + ST_BF_MARGIN <= 16;
-    switch (dim_padded) {
-    case 32: return k16 ? launchb<32, 16>(c, a, join) : launchb<32, ST_KMAX>(c, a, join);
-    case 64: return k16 ? launchb<64, 16>(c, a, join) : launchb<64, ST_KMAX>(c, a, join);
-    case 128: return k16 ? launchb<128, 16>(c, a, join) : launchb<128, ST_KMAX>(c, a, join);
-    default: *handled = false; return ANNCHOR_OK;
-    }
-}
-
-// ------------------------------------------------------------------ the split copy of the ordered rows
-// The expanded form |x|^2 + |y|^2 - 2 x.y loses what |x|^2 exceeds d^2 by, so the rows are centred first: c = mean of
-// the anchors' coordinates (the max-min anchors span the data; every rank knows all of them: no collective).  Distances do not
-// change; the exact re-ranking and the final distances use the original rows.
-__global__ void k_st_centre(const float *__restrict__ avecs, int na, int dim, int dimp, float *__restrict__ cvec)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0) { cvec[dimp] = 0.f; cvec[dimp + 1] = 0.f; }   // [dimp]: largest |x - c| (then the scale), as float bits for atomicMax
-    if (k >= dimp) return;
-    float s = 0.f;
-    if (avecs && k < dim)
-        for (int r = 0; r < na; ++r) s += avecs[(size_t)r * dim + k];
-    cvec[k] = (avecs && k < dim && na > 0) ? s / (float)na : 0.f;
-}
-
-// largest |coordinate| of the centred rows (non-negative floats order like their bit patterns)
-__global__ __launch_bounds__(256) void k_st_absmax(const float *__restrict__ Xs, const float *__restrict__ rs, int64_t n4, int dimp,
-                                                   float *__restrict__ cvec)
-{
-    const int per = dimp / 4;
-    float m = 0.f;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = t / per;
-        if (!(rs[row] < INFINITY)) continue;
-        const float4 v = reinterpret_cast<const float4 *>(Xs)[t], cc = reinterpret_cast<const float4 *>(cvec)[t - row * per];
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x - cc.x), fabsf(v.y - cc.y))), fmaxf(fabsf(v.z - cc.z), fabsf(v.w - cc.w)));
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int *>(cvec + dimp + 1), __float_as_uint(m));
-}
-
-// the power of two that brings the largest |coordinate| to (2^12, 2^13]: fp16 holds 65504, a row's squared norm stays far
-// inside float32, and scaling by a power of two is exact
-__global__ void k_st_scale(float *__restrict__ cvec, int dimp)
-{
-    const float m = cvec[dimp + 1];
-    int e = 0;
-    if (m > 0.f && m < INFINITY) { (void)frexpf(m, &e); e = 13 - e; }   // m = f 2^e', f in [0.5, 1): m 2^(13 - e') in [2^12, 2^13)
-    cvec[dimp] = ldexpf(1.f, max(-100, min(100, e)));
-}
-
-// Xb[row] = {fp16 hi parts of the row's dimp centred, scaled floats, then their lo parts}: hi = fp16(x) (round to nearest
-// even), lo = fp16(x - hi) -- the same bytes per row as the float32 copy; three MFMAs (hi.hi + hi.lo + lo.hi) then
-// reproduce x.y to ~2^-22 |x||y|, the accuracy of the exact f32 MFMA stream (tools/microbench/f16_split.hip).
-// rsb[row] = |scale (x - c)|^2 (+inf on padding rows).  dimp / 4 threads per row, one float4 each.
-__global__ __launch_bounds__(256) void k_st_split_f16(const float *__restrict__ Xs, const float *__restrict__ rs, const float *__restrict__ cvec,
-                                                      int64_t n_pad, int dimp, uint16_t *__restrict__ Xb, float *__restrict__ rsb)
-{
-    // min(32, dimp / 4) threads per row, a float4 each per 128 dimensions (dimp 32 / 64: 8 / 16 threads, one float4 each)
-    const int per = dimp >= 128 ? 32 : dimp / 4;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t row = t / per;
-    const int q0 = (int)(t - row * per);
-    const float scale = cvec[dimp];
-    float acc = 0.f;
-    if (row < n_pad) {
-        const bool real = rs[row] < INFINITY;
-        for (int q = q0; q < dimp / 4; q += per) {
-            const float4 v = reinterpret_cast<const float4 *>(Xs + (size_t)row * dimp)[q], cc = reinterpret_cast<const float4 *>(cvec)[q];
-            const float x[4] = {real ? (v.x - cc.x) * scale : 0.f, real ? (v.y - cc.y) * scale : 0.f, real ? (v.z - cc.z) * scale : 0.f,
-                                real ? (v.w - cc.w) * scale : 0.f};
-            uint16_t h[4], l[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const _Float16 hb = (_Float16)x[j];
-                const _Float16 lb = (_Float16)(x[j] - (float)hb);
-                h[j] = __builtin_bit_cast(uint16_t, hb);
-                l[j] = __builtin_bit_cast(uint16_t, lb);
-                acc += x[j] * x[j];
-            }
-            uint16_t *dst = Xb + (size_t)row * dimp * 2 + 4 * q;
-            *reinterpret_cast<uint2 *>(dst) = uint2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
-            *reinterpret_cast<uint2 *>(dst + dimp) = uint2{(uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16)};
-        }
-    }
-    for (int off = per >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if (row < n_pad && q0 == 0) rsb[row] = rs[row] < INFINITY ? acc : INFINITY;
-}
-
-int ann_stream_split_rows(annchor_ctx *c, StreamState *s)
-{
-    const int64_t n4 = s->n_pad * (int64_t)(s->dimp / 4);
-    ANN_TRY(ann_stream_reserve(c, s->Xb, sizeof(uint16_t) * 2 * (size_t)s->n_pad * s->dimp));
-    ANN_TRY(ann_stream_reserve(c, s->rsb, sizeof(float) * (size_t)s->n_pad));
-    ANN_TRY(ann_stream_reserve(c, s->cvec, sizeof(float) * (size_t)(s->dimp + 2)));
-    const bool have = s->avecs.p != nullptr && s->na > 0 && s->avecs.cap >= sizeof(float) * (size_t)s->na * s->dim;
-    k_st_centre<<<ann_blocks(s->dimp, 128), 128, 0, c->stream>>>(have ? s->avecs.as<float>() : nullptr, s->na, s->dim, s->dimp, s->cvec.as<float>());
-    k_st_absmax<<<(int)std::min<int64_t>(ann_blocks(n4, 256), 4096), 256, 0, c->stream>>>(s->Xs.as<float>(), s->rs.as<float>(), n4, s->dimp,
-                                                                                        s->cvec.as<float>());
-    k_st_scale<<<1, 1, 0, c->stream>>>(s->cvec.as<float>(), s->dimp);
-    k_st_split_f16<<<ann_blocks(s->n_pad * (s->dimp >= 128 ? 32 : s->dimp / 4), 256), 256, 0, c->stream>>>(s->Xs.as<float>(), s->rs.as<float>(), s->cvec.as<float>(), s->n_pad, s->dimp,
-                                                              s->Xb.as<uint16_t>(), s->rsb.as<float>());
-    ANN_CHECK_HIP(c, hipGetLastError());
-    return ANNCHOR_OK;
+    KnnArgs a = a0;
+    a.dimr = dim_padded;
+    return a.K + ST_BF_MARGIN <= 16 ? launchk<16>(c, a, join) : launchk<ST_KMAX>(c, a, join);
 }

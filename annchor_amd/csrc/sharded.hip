@@ -318,6 +318,8 @@ extern "C" int annchor_stream_rows_end(annchor_ctx *c, int32_t world, const int6
     {
         ProfScope ps(c, "stream_all_anchor_distances", (double)total * (s->dim * 4.0 + s->na * 4.0));
         const size_t lds = sizeof(float) * (size_t)s->na * s->dim;
+        ANN_REQUIRE(c, lds <= 150 * 1024, ANNCHOR_ELIMIT, "%d anchors x %d dimensions do not fit the recomputation's LDS: exchange the anchor "
+                    "distances instead (annchor_stream_anchor_dists_begin)", s->na, s->dim);
         const int blocks = (int)std::min<int64_t>(ann_blocks(total * 16, 256), 256 * 16);
         const bool vec = (s->dim & 3) == 0;
         const int nv = vec ? (s->dim + 63) / 64 : 0;
@@ -331,7 +333,8 @@ extern "C" int annchor_stream_rows_end(annchor_ctx *c, int32_t world, const int6
         case 1: SH_LAUNCH(1); break;
         case 2: SH_LAUNCH(2); break;
         case 3: SH_LAUNCH(3); break;
-        default: SH_LAUNCH(4); break;
+        case 4: SH_LAUNCH(4); break;
+        default: SH_LAUNCH(0); break;   // (more than 256 dimensions: the scalar form)
         }
 #undef SH_LAUNCH
     }

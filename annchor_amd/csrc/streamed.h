@@ -35,7 +35,7 @@ struct StreamState {
     DevBuf X;        // float [n_local][dim]      (copy of the caller's rows)
     DevBuf keys, keys2, vals, vals2, cubtmp;
     DevBuf Xs;       // float [n_pad][dimp]       rows in tile order, zero padded
-    DevBuf Xb;       // fp16 [n_pad][2][dimp]     the same rows, centred and scaled, split into hi + lo halves (knnbf.hip), dimp <= 128 only
+    DevBuf Xb;       // fp16 [n_pad][2][dimp]     the same rows, centred and scaled, split into hi + lo halves (knnbf.hip, knnbk.hip)
     DevBuf rsb;      // float [n_pad]             squared norms of the centred, scaled rows (+inf on padding rows)
     DevBuf cvec;     // float [dimp + 2]          the centre: mean of the anchors' coordinates (zeros without anchors); [dimp] the power-of-two scale
     DevBuf rs;       // float [n_pad]             squared norms (+inf on padding rows)
@@ -113,6 +113,7 @@ struct KnnArgs {
     int32_t *out_col_new;
     unsigned long long *updates; // list insertions of the pass (its yield: the host stops when it dries up)
     int early_window, early_tau; // tile phase: stop a row tile when early_window consecutive tiles made < early_tau insertions (0: never)
+    int dimr;                    // knnbk.hip: the rows' padded dimension (a multiple of 128), set by its launcher
 };
 
 StreamState *ann_stream_state(annchor_ctx *c, bool create);
@@ -122,6 +123,8 @@ int ann_stream_launch_knnbf(annchor_ctx *c, const struct KnnArgs &a, int dim_pad
 // tools/experiments/knnbf2.hip (builds with -DST_PAIR_KERNEL only): the same tile phase with two adjacent row tiles per 8-wave
 // workgroup sharing one column stream (graph builds, padded dim <= 128, K + 2 <= 16); *handled = false otherwise
 int ann_stream_launch_knnbf2(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled);
+// knnbk.hip: the k-blocked split-fp16 kernel for padded dim 256 .. 1024 (tile phase and join passes, graph builds and queries)
+int ann_stream_launch_knnbk(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled, bool join = false);
 int ann_stream_split_rows(annchor_ctx *c, StreamState *s);     // Xb from Xs (after the ordering)
 // the split copy (+ centred norms, centre) that belongs to an ordered float32 array; false: none
 bool ann_stream_split_of(const void *Xs, const uint16_t **Xb, const float **rsb, const float **cvec);

@@ -75,14 +75,15 @@ static int sreserve(annchor_ctx *c, DevBuf &b, size_t bytes)
     return ANNCHOR_OK;
 }
 
-static int padded_dim(int dim) { return dim <= 32 ? 32 : dim <= 64 ? 64 : dim <= 128 ? 128 : dim <= 256 ? 256 : -1; }
+// 32 / 64 / 128 / 256, then multiples of 128 up to 1024 (the k-blocked kernel of knnbk.hip)
+static int padded_dim(int dim) { return dim <= 32 ? 32 : dim <= 64 ? 64 : dim <= 128 ? 128 : dim <= 1024 ? (dim + 127) & ~127 : -1; }
 StreamState *ann_stream_state(annchor_ctx *c, bool create) { return state_of(c, create); }
 // (the column arrays travel through the C-ABI as bare pointers -- a query engine streams another context's columns --
 // so the split copy is found from the float32 array it was made from)
 bool ann_stream_split_of(const void *Xs, const uint16_t **Xb, const float **rsb, const float **cvec)
 {
     for (auto &p : g_states)
-        if (p.second->Xs.p == Xs && p.second->Xb.p && p.second->rsb.p && p.second->cvec.p && p.second->dimp <= 128) {
+        if (p.second->Xs.p == Xs && p.second->Xb.p && p.second->rsb.p && p.second->cvec.p) {
             *Xb = p.second->Xb.as<uint16_t>(); *rsb = p.second->rsb.as<float>(); *cvec = p.second->cvec.as<float>();
             return true;
         }
@@ -98,7 +99,7 @@ extern "C" int annchor_stream_bind(annchor_ctx *c, const float *X, int64_t n_loc
 {
     if (!c || !X) return ANNCHOR_EINVAL;
     ANN_REQUIRE(c, n_local >= 1 && n_local < (1ll << 31), ANNCHOR_ELIMIT, "n_local=%lld out of range", (long long)n_local);
-    ANN_REQUIRE(c, padded_dim(dim) > 0, ANNCHOR_ELIMIT, "streamed form supports dim <= 256 (got %d)", dim);
+    ANN_REQUIRE(c, padded_dim(dim) > 0, ANNCHOR_ELIMIT, "streamed form supports dim <= 1024 (got %d)", dim);
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     StreamState *s = state_of(c, true);
     s->n_local = n_local; s->dim = dim; s->dimp = padded_dim(dim); s->base = global_base; s->na = 0;
@@ -106,7 +107,7 @@ extern "C" int annchor_stream_bind(annchor_ctx *c, const float *X, int64_t n_loc
     ANN_TRY(sreserve(c, s->X, bytes));
     ANN_CHECK_HIP(c, hipMemcpyAsync(s->X.p, X, bytes, x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
-    ANN_TRY(sreserve(c, s->avec, sizeof(float) * 256));
+    ANN_TRY(sreserve(c, s->avec, sizeof(float) * 1024));
     ANN_TRY(sreserve(c, s->runmin, sizeof(float) * (size_t)n_local));
     c->metric = ANNCHOR_METRIC_EUCLIDEAN_F32;
     c->nx = n_local;
@@ -625,7 +626,7 @@ extern "C" int annchor_stream_order_end(annchor_ctx *c, void **Xs, void **rs, vo
                                                                           s->Xs.as<float>(), s->rs.as<float>(), s->perm.as<int64_t>());
         k_st_intervals<<<s->nt, ST_T, 0, c->stream>>>(s->Dt.as<float>(), (s->na + 3) & ~3, order, n, s->na, s->nt, s->lo.as<float>(),
                                                      s->hi.as<float>(), s->mid.as<float>());
-        if (s->dimp <= 128) ANN_TRY(ann_stream_split_rows(c, s));   // the fp16 hi / lo copy the tile kernel streams (knnbf.hip)
+        ANN_TRY(ann_stream_split_rows(c, s));   // the fp16 hi / lo copy the tile kernels stream (knnbf.hip, knnbk.hip)
     }
     ANN_CHECK_HIP(c, hipGetLastError());
     ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
@@ -1616,12 +1617,15 @@ static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool 
             }
 #endif
             ANN_TRY(ann_stream_launch_knnbf(c, a, dim_padded, &handled, join));
+            if (!handled) ANN_TRY(ann_stream_launch_knnbk(c, a, dim_padded, &handled, join));   // padded dim 256 .. 1024: k-blocked
             if (handled) {
                 if (!join && st) st->last_kernel = 1;
                 return ANNCHOR_OK;
             }
         }
     }
+    ANN_REQUIRE(c, dim_padded <= 256, ANNCHOR_ELIMIT, "padded dim %d: beyond 256 dimensions only the split-fp16 kernel exists (needs n_neighbors <= 31)%s",
+                dim_padded, exact ? "; the data is too ill-conditioned for it (rows far from the anchors' centre with neighbours very close together)" : "");
     switch (dim_padded) {
     case 32: return launch_knn<32>(c, a, join);
     case 64: return launch_knn<64>(c, a, join);
@@ -1725,7 +1729,12 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
         if (getenv("ANNCHOR_ST_VERBOSE")) fprintf(stderr, "annchor: tile phase fetched %llu column tiles\n", fl2[1]);
         s->last_guard_rows = (int64_t)flagged;
         static const bool no_fallback = getenv("ANNCHOR_ST_NO_FALLBACK") != nullptr;
-        if ((int64_t)flagged > std::max<int64_t>(8, rows / 200) && !no_fallback) {
+        if ((int64_t)flagged > std::max<int64_t>(8, rows / 200) && !no_fallback && dim_padded > 256) {
+            // (the exact-f32 tile kernel stops at padded dim 256: the caller sees the count through annchor_stream_last_kernel)
+            fprintf(stderr, "annchor: streamed tile phase: %llu of %lld rows have neighbours closer together than float32-grade products of |x|^2 "
+                            "resolve (|x|^2 >> d^2); beyond 256 dimensions there is no exact-f32 tile kernel to repeat the phase on -- the lists "
+                            "of those rows may miss a neighbour (reported distances stay exact)\n", flagged, (long long)rows);
+        } else if ((int64_t)flagged > std::max<int64_t>(8, rows / 200) && !no_fallback) {
             fprintf(stderr, "annchor: streamed tile phase: %llu of %lld rows have neighbours closer together than float32-grade products of |x|^2 "
                             "resolve (|x|^2 >> d^2); running the exact float32 tile kernel instead\n", flagged, (long long)rows);
             ANN_CHECK_HIP(c, hipMemsetAsync(s->evals.p, 0, 64, c->stream));

@@ -55,6 +55,58 @@ def test_exact_when_budget_does_not_bind(n, d, na, k):
     assert sa.tile_evals <= nt * nt
 
 
+@pytest.mark.parametrize("n,d,na,k", [(3000, 300, 8, 10), (2500, 384, 8, 15), (2000, 512, 6, 25), (1500, 768, 6, 8), (1300, 1024, 5, 15)])
+def test_exact_beyond_256_dimensions(n, d, na, k):
+    """Rows of 257 .. 1024 dimensions (padded to a multiple of 128) take the k-blocked split-fp16 kernel (csrc/knnbk.hip: the
+    column tile finished block by block, four accumulators per wave): with the budget not binding the graph is the exact k-NN
+    graph -- against a float64 brute force at rtol 1e-5, like every other shape (the reference's euclidean takes any dimension:
+    distances.py:8-13); the query path runs the same kernel."""
+    from annchor_amd.streamed import StreamedAnnchor
+
+    X = latent(n, d)
+    sa = StreamedAnnchor(X, n_anchors=na, n_neighbors=k, p_work=1.0).fit()
+    assert sa._engine.stream_last_kernel() == 1   # the split-fp16 kernel ran (no silent fall-back)
+    idx, dist = sa.neighbor_graph
+    rows = np.random.default_rng(0).choice(n, 400, replace=False)
+    bi, bd = brute(X, rows, k)
+    assert np.array_equal(idx[:, 0], np.arange(n)) and np.all(dist[:, 0] == 0)
+    np.testing.assert_allclose(dist[rows], bd, rtol=1e-5, atol=1e-6)
+    for r in rows[:40]:
+        dd = np.sqrt(((X[idx[r]].astype(np.float64) - X[r].astype(np.float64)) ** 2).sum(axis=1))
+        np.testing.assert_allclose(dd, dist[r], rtol=1e-5, atol=1e-6)
+    assert np.all(np.diff(dist, axis=1) >= 0)
+    qi, qd = sa.query(X[rows[:64]] + 0.01, nn=5, p_work=1.0)
+    Xd = X.astype(np.float64)
+    for t, r in enumerate(rows[:64]):
+        d_all = np.sqrt(((Xd - (X[r] + np.float32(0.01)).astype(np.float64)[None, :]) ** 2).sum(axis=1))
+        np.testing.assert_allclose(qd[t], np.sort(d_all)[:5], rtol=1e-5, atol=1e-6)
+
+
+def test_budgeted_recall_768_dimensions():
+    """A binding budget with join passes at d = 768 (the k-blocked kernel in its tile-phase and gathered-column forms):
+    recall@15 against the float64 brute force on 1 000 rows, the budget, distances at rtol 1e-5."""
+    from annchor_amd import compare_neighbor_graphs
+    from annchor_amd.streamed import StreamedAnnchor
+
+    n, d, k = 60000, 768, 15
+    X = latent(n, d)
+    sa = StreamedAnnchor(X, n_anchors=24, n_neighbors=k, p_work=0.2).fit()
+    nt = (n + 127) // 128
+    assert sa.tile_evals <= int(np.ceil(0.2 * nt)) * nt
+    idx, dist = sa.neighbor_graph
+    rows = np.sort(np.random.default_rng(5).choice(n, 1000, replace=False))
+    from test_c5_gpu import truth_f64
+
+    bd = truth_f64(X[rows], [X], k)
+    bd[:, 0] = 0.0
+    err = compare_neighbor_graphs((idx[rows], bd), (idx[rows], dist[rows]), k)
+    recall = 1 - err / (len(rows) * float(k))
+    print("d = 768, N = %d: recall@15 %.4f, fit %.3f s" % (n, recall, sa.timings["total"]))
+    assert recall >= 0.97, recall
+    dd = np.sqrt(((X[idx[rows]].astype(np.float64) - X[rows].astype(np.float64)[:, None, :]) ** 2).sum(-1))
+    np.testing.assert_allclose(dd, dist[rows], rtol=1e-5, atol=1e-5)
+
+
 def test_budgeted_with_joins_more_than_33_neighbours():
     """n_neighbors = 48 with a binding budget and join passes (the 64-entry list kernels): the joins must help, the
     recall is that of a 48-neighbour ball in 8 dimensions cut by 128-point tiles (0.936 measured at this budget)."""
