@@ -103,7 +103,7 @@ template <int KMAX, bool JOIN = false> __global__ __launch_bounds__(STBK_THREADS
     static_assert(NI == 1 || NI == 2 || NI == 4, "pieces per loading wave");
     static_assert(sizeof(sh.ring) <= 65536, "LDS-DMA destinations must stay below 64 KB");
     static_assert(sizeof(SelBufK) <= sizeof(sh.ring) && sizeof(SelBufK) == 12288, "selection buffers alias the ring");
-    static_assert(KMAX <= ST_SLAB + 1, "the exact re-ranking reuses cand_d with row stride KMAX");
+    static_assert(KMAX <= ST_SLAB + 1 || sizeof(sh.ring) >= sizeof(float) * ST_T * KMAX, "the exact re-ranking's scratch: cand_d, or the ring for 64-entry lists");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rg = wave;   // this wave's 32-row group
@@ -651,7 +651,7 @@ template <int KMAX, bool JOIN = false> __global__ __launch_bounds__(STBK_THREADS
     // neighbour's d^2); their exact float32 distances sum (x - y)^2 decide which K are handed on, and in which order
     if (threadIdx.x == 0) sh.nsurv = 0;
     {
-        float *ex = &sh.cand_d[0][0];   // [ST_T][KMAX] exact d^2 (cand_d is idle now; row stride KMAX <= ST_SLAB + 1)
+        float *ex = KMAX <= ST_SLAB + 1 ? &sh.cand_d[0][0] : &sh.ring[0];   // [ST_T][KMAX] exact d^2 (cand_d / the ring are idle now)
         for (int q = threadIdx.x; q < ST_T * KL; q += STBK_THREADS) {
             const int row = q / KL, e = q - row * KL;
             const int32_t cc = sh.list_c[row][e];
@@ -740,13 +740,14 @@ template <int KMAX> static int launchk(annchor_ctx *c, const KnnArgs &a, bool jo
 }
 
 // The tile phase / a join pass for rows of padded dimension 256 .. 1024 (a multiple of 128) when K + 2 <= 32 list entries and the
-// split copy of the columns exists; *handled = false otherwise (padded dim 256: the caller's exact-f32 kernel takes it).
+// split copy of the columns exists; *handled = false otherwise (padded dim 256: the caller's exact-f32 kernel takes it).  Lists of 16 / 32 / 64 entries: up to 62 neighbours.
 int ann_stream_launch_knnbk(annchor_ctx *c, const KnnArgs &a0, int dim_padded, bool *handled, bool join)
 {
     *handled = false;
-    if (dim_padded < 256 || dim_padded > 1024 || (dim_padded & 127) || a0.K + ST_BF_MARGIN > ST_KMAX || !a0.Xb || !a0.rsb || !a0.cvec) return ANNCHOR_OK;
+    if (dim_padded < 256 || dim_padded > 1024 || (dim_padded & 127) || a0.K + ST_BF_MARGIN > ST_KMAX_BIG || !a0.Xb || !a0.rsb || !a0.cvec) return ANNCHOR_OK;
     *handled = true;
     KnnArgs a = a0;
     a.dimr = dim_padded;
-    return a.K + ST_BF_MARGIN <= 16 ? launchk<16>(c, a, join) : launchk<ST_KMAX>(c, a, join);
+    // (64-entry lists: 125 KB of LDS, one workgroup per CU -- up to 62 neighbours + self)
+    return a.K + ST_BF_MARGIN <= 16 ? launchk<16>(c, a, join) : a.K + ST_BF_MARGIN <= ST_KMAX ? launchk<ST_KMAX>(c, a, join) : launchk<ST_KMAX_BIG>(c, a, join);
 }

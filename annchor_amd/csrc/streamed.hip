@@ -1624,7 +1624,7 @@ static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool 
             }
         }
     }
-    ANN_REQUIRE(c, dim_padded <= 256, ANNCHOR_ELIMIT, "padded dim %d: beyond 256 dimensions only the split-fp16 kernel exists (needs n_neighbors <= 31)%s",
+    ANN_REQUIRE(c, dim_padded <= 256, ANNCHOR_ELIMIT, "padded dim %d: beyond 256 dimensions only the split-fp16 kernel exists (n_neighbors <= 63)%s",
                 dim_padded, exact ? "; the data is too ill-conditioned for it (rows far from the anchors' centre with neighbours very close together)" : "");
     switch (dim_padded) {
     case 32: return launch_knn<32>(c, a, join);

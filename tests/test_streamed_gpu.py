@@ -55,7 +55,7 @@ def test_exact_when_budget_does_not_bind(n, d, na, k):
     assert sa.tile_evals <= nt * nt
 
 
-@pytest.mark.parametrize("n,d,na,k", [(3000, 300, 8, 10), (2500, 384, 8, 15), (2000, 512, 6, 25), (1500, 768, 6, 8), (1300, 1024, 5, 15)])
+@pytest.mark.parametrize("n,d,na,k", [(3000, 300, 8, 10), (2500, 384, 8, 15), (2000, 512, 6, 25), (1500, 768, 6, 8), (1300, 1024, 5, 15), (1500, 384, 6, 50), (900, 640, 4, 63)])
 def test_exact_beyond_256_dimensions(n, d, na, k):
     """Rows of 257 .. 1024 dimensions (padded to a multiple of 128) take the k-blocked split-fp16 kernel (csrc/knnbk.hip: the
     column tile finished block by block, four accumulators per wave): with the budget not binding the graph is the exact k-NN
