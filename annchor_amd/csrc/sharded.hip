@@ -387,13 +387,23 @@ __global__ __launch_bounds__(256) void k_sh_route_count(const int64_t *__restric
     if (threadIdx.x < tab->world && h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 
-__global__ void k_sh_route_slot(const int32_t *__restrict__ dest, int64_t rows, unsigned long long *__restrict__ cursor,
-                                int64_t *__restrict__ slot)
+// slot of every finished row inside its destination's run of the send buffer: rows are ranked inside their workgroup through
+// LDS, a workgroup reserves its rows' room with ONE global atomic per destination (one atomic per row on a handful of addresses
+// serialises: 33 ms for 4 x 10^6 rows and two destinations)
+__global__ __launch_bounds__(256) void k_sh_route_slot(const int32_t *__restrict__ dest, int64_t rows, unsigned long long *__restrict__ cursor,
+                                                      int64_t *__restrict__ slot)
 {
+    __shared__ unsigned int cnt[SH_MAX_WORLD];
+    __shared__ unsigned long long base[SH_MAX_WORLD];
+    if (threadIdx.x < SH_MAX_WORLD) cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const int d = dest[r];
-    slot[r] = d < 0 ? -1 : (int64_t)atomicAdd(&cursor[d], 1ull);
+    const int d = r < rows ? dest[r] : -1;
+    const unsigned int mine = d >= 0 ? atomicAdd(&cnt[d], 1u) : 0u;
+    __syncthreads();
+    if (threadIdx.x < SH_MAX_WORLD && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+    __syncthreads();
+    if (r < rows) slot[r] = d < 0 ? -1 : (int64_t)(base[d] + mine);
 }
 
 // record of a row: [global id, K neighbour ids (global; -1 = none), K distances (float64 bits)]

@@ -20,6 +20,13 @@ python tools/pmc_summary.py $O/pmc_fetch_scale $O/pmc_write_scale $O/pmc_traffic
 bash tools/pmc_lev2.sh > $O/pmc_lev2.log 2>&1; cp gpurun_out/pmc_lev2/pmc_lev2.json $O/pmc_lev.json 2>/dev/null
 bash tools/pmc_st.sh > $O/pmc_st.log 2>&1; cp gpurun_out/pmc_st/pmc_st.json $O/pmc_st.json 2>/dev/null
 bash tools/pmc_emd.sh > $O/pmc_emd.log 2>&1; cp gpurun_out/pmc_emd/pmc_emd.json $O/pmc_emd.json 2>/dev/null
+# row-sharded build: per-rank stage times with the ranks' GPU work serialised (the scaling model's input), C3 and C5
+timeout 600 python tools/serial_ranks.py --n 1000000 --worlds 1,2,4,8 --out $O/serial_ranks_c3.json > $O/serial_ranks_c3.log 2>&1
+timeout 900 python tools/serial_ranks.py --n 8000000 --worlds 1,2,4,8 --out $O/serial_ranks_c5.json > $O/serial_ranks_c5.log 2>&1
+python tools/scaling_model.py $O/serial_ranks_c3.json > $O/scaling_model_c3.json; python tools/scaling_model.py $O/serial_ranks_c5.json > $O/scaling_model_c5.json
+python tools/scaling_model.py $O/serial_ranks_c5.json --md > $O/scaling_model_c5.md; python tools/scaling_model.py $O/serial_ranks_c3.json --md > $O/scaling_model_c3.md
+# rows of more than 128 dimensions (k-blocked kernel)
+for d in 256 768; do timeout 300 python tools/dim_probe.py 1000000 $d 2>/dev/null | tail -1 > $O/dim_probe_$d.json; done
 find $O -name "*kernel_stats.csv" | head; find $O -name "*counter_collection.csv" -size +30M -delete
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_fetch_scale $O/pmc_write_scale 2>/dev/null
 find $O/stats $O/scale -name "*kernel_trace.csv" -delete
