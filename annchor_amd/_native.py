@@ -827,8 +827,7 @@ class Engine:
         return lp.value, upd.value
 
     def stream_join_rev_begin(self, lists_all):
-        """Reverse neighbour lists of this rank's columns from the all-gathered lists; (device pointer of the slice -- inside the
-        gather target --, the gather target, bytes per rank)."""
+        """Reverse neighbour lists of this rank's columns from the all-gathered lists; (device pointer of the slice, the gather target, bytes per rank)."""
         rl, ra, nb = _vp(), _vp(), _i64()
         self._chk(self.lib.annchor_stream_join_rev_begin(self.h, lists_all, ctypes.byref(rl), ctypes.byref(ra), ctypes.byref(nb)))
         return rl.value, ra.value, nb.value

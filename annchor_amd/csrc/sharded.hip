@@ -301,6 +301,9 @@ extern "C" int annchor_stream_rows_end(annchor_ctx *c, int32_t world, const int6
     if (gathered) {
         // D_recv [world][na][most] -> D [na][total]: one strided copy per rank (the send buffer may be D itself: the
         // all-gather has read it by now -- stream order -- so D can be re-reserved)
+        // (D may have been the all-gather's send buffer and the collective runs asynchronously on this stream under RCCL: it must
+        // have read D before D's block is let go -- the parked-block pool would hand it out again without a device-wide wait)
+        ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
         ANN_TRY(ann_stream_reserve(c, s->D, sizeof(float) * (size_t)s->na * (size_t)total));
         ProfScope ps(c, "stream_anchor_dists_assemble", (double)total * s->na * 8.0);
         int64_t at = 0;

@@ -73,6 +73,7 @@ struct StreamState {
     uint32_t *order_cur = nullptr;     // the order buffer annchor_stream_order_begin finished in (vals or vals2)
     int order_tile_begin = 0, order_tile_count = 0;
     DevBuf rev_all;    // int32 [n_all][JN_RK]: the ranks' reverse-list slices (all-gather target of annchor_stream_join_rev_begin)
+    DevBuf rev_slice;  // int32 [tile_count x 128][JN_RK]: this rank's slice (the all-gather's input)
     bool rev_gathered = false;         // rev_all holds the reverse lists of the lists the next join pass is given
     DevBuf D_send, D_recv;   // float [na][most] / [world][na][most]: anchor distances of the own rows on their way to every rank
     bool D_gathered = false;

@@ -51,7 +51,7 @@ void ann_stream_release(annchor_ctx *c)
                               &s->scr_key, &s->scr_lb, &s->emit_idx, &s->emit_dist, &s->Dt, &s->eval_bits, &s->out_d2b, &s->out_colb,
                               &s->ucand, &s->ucount, &s->rev_cnt, &s->rev_ptr, &s->rev_edges, &s->cand, &s->cand_all, &s->avecs, &s->A_dev,
                               &s->rows_send, &s->rows_recv, &s->rows_all, &s->lists_all, &s->route_tab, &s->route_cnt, &s->route_slot,
-                              &s->route_send, &s->route_recv, &s->Xb, &s->rsb, &s->cvec, &s->order_all, &s->rev_all, &s->D_send, &s->D_recv};
+                              &s->route_send, &s->route_recv, &s->Xb, &s->rsb, &s->cvec, &s->order_all, &s->rev_all, &s->rev_slice, &s->D_send, &s->D_recv};
             for (DevBuf *b : bufs)
                 if (b->p && !b->in_arena) ann_dev_free(c, b->p, b->cap);
             ann_stream_free_run(s);
@@ -1774,11 +1774,10 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
 // reverse lists of the columns [col0, col0 + ncols) from the lists of every ordered row: count, scan, fill, select (the
 // lists are short: K on average) -> out [col0 .. col0 + ncols)[JN_RK] of an int32 [n_all][JN_RK] buffer
 static int knn_reverse_lists(annchor_ctx *c, StreamState *s, const int32_t *lists_all, int64_t n_all, int K, int64_t col0, int64_t ncols,
-                             DevBuf &out)
+                             int32_t *dst /* [ncols][JN_RK]: the first own column's entries */)
 {
     ProfScope ps(c, "stream_join_reverse_lists", (double)n_all * K * 8.0 + (double)ncols * K * 24.0);
     const int64_t n_edges = n_all * K;
-    ANN_TRY(sreserve(c, out, sizeof(int32_t) * (size_t)n_all * JN_RK));
     if (ncols <= 0) return ANNCHOR_OK;
     ANN_TRY(sreserve(c, s->rev_cnt, sizeof(int32_t) * (size_t)(ncols + 1)));
     ANN_TRY(sreserve(c, s->rev_ptr, sizeof(int64_t) * (size_t)(ncols + 1)));
@@ -1792,7 +1791,7 @@ static int knn_reverse_lists(annchor_ctx *c, StreamState *s, const int32_t *list
     k_st_rev_fill<<<ann_blocks(n_edges, 256), 256, 0, c->stream>>>(lists_all, n_edges, K, col0, ncols, s->rev_ptr.as<int64_t>(),
                                                                   s->rev_cnt.as<int32_t>(), s->rev_edges.as<unsigned long long>());
     k_st_rev_select<<<ann_blocks(ncols, 256), 256, 0, c->stream>>>(s->rev_ptr.as<int64_t>(), s->rev_edges.as<unsigned long long>(), ncols,
-                                                                  out.as<int32_t>() + (size_t)col0 * JN_RK);
+                                                                  dst);
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
 }
@@ -1815,8 +1814,9 @@ static int knn_join_pass(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pad
     a.lists_all = lists_all;
     a.ucand = s->ucand.as<uint32_t>(); a.ucount = s->ucount.as<int32_t>(); a.ucap = JN_CAP;
     a.out_d2_new = nd.as<float>(); a.out_col_new = nc.as<int32_t>();
+    ANN_TRY(sreserve(c, s->rev_all, sizeof(int32_t) * (size_t)n_all * JN_RK));
     if (!s->rev_gathered)      // one rank (or a host that does not gather the slices): the reverse lists of every column, here
-        ANN_TRY(knn_reverse_lists(c, s, lists_all, n_all, K, 0, n_all, s->rev_all));
+        ANN_TRY(knn_reverse_lists(c, s, lists_all, n_all, K, 0, n_all, s->rev_all.as<int32_t>()));
     s->rev_gathered = false;   // (they belong to THESE lists: the next pass builds its own)
     {
         ProfScope ps(c, "stream_join_candidates", (double)rows * (K + JN_RK) * 4.0 * (K + JN_RK + 1));
@@ -2023,8 +2023,7 @@ extern "C" int annchor_stream_knn_join(annchor_ctx *c, const void *lists_all, in
 }
 
 // Row-sharded join pass, first half: the reverse neighbour lists of THIS rank's columns (its tile range of the global
-// order) from the all-gathered lists.  *rev_local: int32 [tile_count x 128][JN_RK] (device; the rank's slice inside the
-// gather target), *rev_all: int32 [n_all][JN_RK], *rev_bytes: bytes per rank.  The host all-gathers the slices into
+// order) from the all-gathered lists.  *rev_local: int32 [tile_count x 128][JN_RK] (device; the rank's slice), *rev_all: int32 [n_all][JN_RK], *rev_bytes: bytes per rank.  The host all-gathers the slices into
 // *rev_all (rank r's at r x *rev_bytes) and calls annchor_stream_knn_join with the same lists_all; without that call
 // the join pass builds every column's reverse list itself.
 extern "C" int annchor_stream_join_rev_begin(annchor_ctx *c, const void *lists_all, void **rev_local, void **rev_all, int64_t *rev_bytes)
@@ -2035,10 +2034,14 @@ extern "C" int annchor_stream_join_rev_begin(annchor_ctx *c, const void *lists_a
     ANN_REQUIRE(c, s && s->run, ANNCHOR_ESTATE, "annchor_stream_knn_begin not called");
     const KnnArgs &a = *s->run;
     const int64_t n_all = (int64_t)a.nt_all * ST_T, col0 = (int64_t)a.tile_begin * ST_T, ncols = (int64_t)a.tile_count * ST_T;
-    ANN_TRY(knn_reverse_lists(c, s, (const int32_t *)lists_all, n_all, a.K, col0, ncols, s->rev_all));
+    // (the slice has its own buffer: an all-gather whose input lies inside its output is legal for RCCL, but nothing is gained
+    // by depending on it)
+    ANN_TRY(sreserve(c, s->rev_all, sizeof(int32_t) * (size_t)n_all * JN_RK));
+    ANN_TRY(sreserve(c, s->rev_slice, sizeof(int32_t) * (size_t)std::max<int64_t>(ncols, 1) * JN_RK));
+    ANN_TRY(knn_reverse_lists(c, s, (const int32_t *)lists_all, n_all, a.K, col0, ncols, s->rev_slice.as<int32_t>()));
     ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     s->rev_gathered = true;
-    *rev_local = s->rev_all.as<int32_t>() + (size_t)col0 * JN_RK;
+    *rev_local = s->rev_slice.p;
     *rev_all = s->rev_all.p;
     *rev_bytes = (int64_t)sizeof(int32_t) * ncols * JN_RK;
     return ANNCHOR_OK;

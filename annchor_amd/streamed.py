@@ -371,7 +371,7 @@ class StreamedAnnchor:
                 if p >= self.join_passes and tile_budget + (p + 1) * max(per_pass, 1) > total:
                     break      # the budget has no room for another pass
                 comm.allgather_into(eng, lists, lists_all, nbytes)
-                # reverse neighbour lists: each rank builds those of the columns it owns, the slices are all-gathered in place
+                # reverse neighbour lists: each rank builds those of the columns it owns, the slices are all-gathered
                 rev, rev_all, rbytes = eng.stream_join_rev_begin(lists_all)
                 comm.allgather_into(eng, rev, rev_all, rbytes)
                 lists, upd = eng.stream_knn_join(lists_all, max(per_pass, 1))

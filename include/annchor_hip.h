@@ -384,8 +384,7 @@ int annchor_stream_knn_begin(annchor_ctx *ctx, const void *Xs_all, const void *r
 int annchor_stream_knn_join(annchor_ctx *ctx, const void *lists_all, int32_t per_pass, void **lists_local, int64_t *updates);
 /* Row-sharded join pass, first half (the streamed analogue of update_anchor_points' computed-neighbour lists,
  * annchor/annchor.py:475-512, restricted to the columns a rank owns): the reverse neighbour lists of this rank's tile range
- * from the all-gathered lists.  *rev_local: int32 [tile_count x 128][15] (device: the rank's slice INSIDE the gather
- * target, i.e. an in-place all-gather), *rev_all: int32 [n_all][15], *rev_bytes: bytes per rank.  The host all-gathers the
+ * from the all-gathered lists.  *rev_local: int32 [tile_count x 128][15] (device: the rank's slice), *rev_all: int32 [n_all][15], *rev_bytes: bytes per rank.  The host all-gathers the
  * slices and calls annchor_stream_knn_join with the same lists_all; a host that skips this call gets every column's
  * reverse list built by the join pass itself (one rank). */
 int annchor_stream_join_rev_begin(annchor_ctx *ctx, const void *lists_all, void **rev_local, void **rev_all, int64_t *rev_bytes);
