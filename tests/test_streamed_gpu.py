@@ -692,3 +692,61 @@ def test_split_fp16_guard_falls_back_to_the_exact_kernel():
     good = StreamedAnnchor(latent(n, 64), n_anchors=12, n_neighbors=k, p_work=0.3).fit()
     kind, flagged = good._engine.stream_last_kernel(with_guard=True)
     assert kind == 1 and flagged <= n // 1000, (kind, flagged)
+
+
+def test_guard_beyond_256_dimensions_reports_instead_of_falling_back(capfd):
+    """Beyond 256 dimensions there is no exact-f32 tile kernel to repeat the tile phase on: ill-conditioned data (tight clusters far
+    from the centre) is reported -- the flagged-row count through annchor_stream_last_kernel, a warning on stderr -- and the build
+    goes on with the split kernel's lists; the reported distances are exact float32 as always."""
+    from annchor_amd.streamed import StreamedAnnchor
+
+    rng = np.random.default_rng(3)
+    n, k, d = 12000, 10, 300
+    cent = rng.standard_normal((300, d)) * 30.0
+    X = (cent[rng.integers(0, 300, n)] + 0.02 * rng.standard_normal((n, d))).astype(np.float32)
+    sa = StreamedAnnchor(X, n_anchors=10, n_neighbors=k, p_work=1.0).fit()
+    kind, flagged = sa._engine.stream_last_kernel(with_guard=True)
+    assert kind == 1
+    if flagged > n // 200:
+        assert "no exact-f32 tile kernel" in capfd.readouterr().err
+    idx, dist = sa.neighbor_graph
+    rows = rng.choice(n, 200, replace=False)
+    dd = np.sqrt(((X[idx[rows]].astype(np.float64) - X[rows].astype(np.float64)[:, None, :]) ** 2).sum(-1))
+    np.testing.assert_allclose(dd, dist[rows], rtol=1e-5, atol=1e-5)
+
+
+def _worker_dims(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from annchor_amd.streamed import StreamedAnnchor, TorchComm
+
+    X = latent(5000, 300)
+    cuts = [0, 2700, 5000]
+    sa = StreamedAnnchor(X[cuts[rank]:cuts[rank + 1]], n_anchors=10, n_neighbors=10, p_work=1.0, base=cuts[rank],
+                         comm=TorchComm(), device=0).fit()
+    gi, gd = sa.gather_graph()
+    if rank == 0:
+        np.savez(out, A=sa.A, idx=gi, dist=gd)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_beyond_256_dimensions(tmp_path):
+    """The row-sharded build on rows of 300 dimensions (the k-blocked kernel in the tile phase and the join passes): two ranks
+    give the one-rank graph."""
+    import torch.multiprocessing as mp
+
+    from annchor_amd.streamed import StreamedAnnchor
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "wd.npz")
+    mp.spawn(_worker_dims, args=(2, port, out), nprocs=2, join=True)
+    R = np.load(out)
+    one = StreamedAnnchor(latent(5000, 300), n_anchors=10, n_neighbors=10, p_work=1.0).fit()
+    assert np.array_equal(R["A"], one.A)
+    np.testing.assert_allclose(R["dist"], one.neighbor_graph[1], rtol=1e-6, atol=1e-6)
+    assert (R["idx"] == one.neighbor_graph[0]).mean() > 0.999
