@@ -1175,14 +1175,15 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
 #define JN_CAP 8192      // candidate columns per row tile (LDS sort buffer)
 #define JN_B1 8192       // first-hop ids per row tile (128 rows x (K + JN_RK) <= 6144)
 #define JN_RK 15         // reverse neighbours kept per point (the closest by list position)
+#define JN_THREADS 1024  // threads of k_st_join_cands: its time is bitonic stages (~340 per row tile) -- 16 waves make a stage a quarter as long as 4 did
 #define ANNCHOR_JOIN_YIELD 0.01   // extra join passes run while a pass still replaces more than this share of the list entries
 
-// ascending bitonic sort of P (a power of two) uint32 keys in LDS by one 256-thread workgroup
+// ascending bitonic sort of P (a power of two) uint32 keys in LDS by the workgroup
 __device__ __forceinline__ void jn_sort(uint32_t *v, int P)
 {
     for (int k2 = 2; k2 <= P; k2 <<= 1)
         for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            for (int t = threadIdx.x; t < (P >> 1); t += ST_THREADS) {
+            for (int t = threadIdx.x; t < (P >> 1); t += JN_THREADS) {
                 const int q = ((t & ~(j2 - 1)) << 1) | (t & (j2 - 1));   // element with bit j2 clear
                 const int p2 = q | j2;
                 const uint32_t x = v[q], y = v[p2];
@@ -1199,7 +1200,7 @@ __device__ __forceinline__ void jn_sort(uint32_t *v, int P)
 // cnt_out != NULL: also the multiplicity of every distinct key (run length in the sorted input), same order
 template <int PER> __device__ __forceinline__ int jn_unique(uint32_t *v, int P, uint32_t *wsum /*[5]*/, uint32_t *cnt_out = nullptr)
 {
-    const int per = P / ST_THREADS;   // <= PER
+    const int per = P / JN_THREADS;   // <= PER
     const int b = threadIdx.x * per;
     uint32_t r[PER];
     uint16_t rc[PER];
@@ -1228,7 +1229,7 @@ template <int PER> __device__ __forceinline__ int jn_unique(uint32_t *v, int P, 
     if (lane == 63) wsum[wave] = (uint32_t)inc;
     __syncthreads();
     int base = inc - mine, tot = 0;
-    for (int w2 = 0; w2 < ST_THREADS / 64; ++w2) { if (w2 < wave) base += (int)wsum[w2]; tot += (int)wsum[w2]; }
+    for (int w2 = 0; w2 < JN_THREADS / 64; ++w2) { if (w2 < wave) base += (int)wsum[w2]; tot += (int)wsum[w2]; }
 #pragma unroll
     for (int e = 0; e < PER; ++e)
         if (r[e] != 0xffffffffu) {
@@ -1244,7 +1245,7 @@ __device__ __forceinline__ void jn_sort64(unsigned long long *v, int P)
 {
     for (int k2 = 2; k2 <= P; k2 <<= 1)
         for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            for (int t = threadIdx.x; t < (P >> 1); t += ST_THREADS) {
+            for (int t = threadIdx.x; t < (P >> 1); t += JN_THREADS) {
                 const int q = ((t & ~(j2 - 1)) << 1) | (t & (j2 - 1));
                 const int p2 = q | j2;
                 const unsigned long long x = v[q], y = v[p2];
@@ -1309,7 +1310,7 @@ __global__ void k_st_rev_select(const int64_t *__restrict__ ptr, const unsigned 
 // Candidate columns of one row tile: first hop = the current neighbours and reverse neighbours of
 // its 128 rows; second hop = their neighbours and reverse neighbours (and the first hop itself),
 // minus everything inside column tiles this row tile has already evaluated; sorted, distinct.
-__global__ __launch_bounds__(ST_THREADS) void k_st_join_cands(const int32_t *__restrict__ lists_all, const int32_t *__restrict__ rev,
+__global__ __launch_bounds__(JN_THREADS) void k_st_join_cands(const int32_t *__restrict__ lists_all, const int32_t *__restrict__ rev,
                                                              int K, int tile_begin, const uint32_t *__restrict__ eval_bits,
                                                              int eval_words, int max_cols, uint32_t *__restrict__ ucand,
                                                              int32_t *__restrict__ ucount)
@@ -1317,7 +1318,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_st_join_cands(const int32_t *__r
     extern __shared__ __attribute__((aligned(16))) unsigned char jsm[];
     uint32_t *buf = reinterpret_cast<uint32_t *>(jsm);   // [JN_CAP]
     uint32_t *b1 = buf + JN_CAP;                         // [JN_B1]
-    uint32_t *wsum = b1 + JN_B1;                         // [8]
+    uint32_t *wsum = b1 + JN_B1;                         // [JN_THREADS / 64 + 1]
     __shared__ int nsurv_s;
     const int bt = blockIdx.x, I = tile_begin + bt;
     const int64_t grow0 = (int64_t)I * ST_T;
@@ -1327,16 +1328,16 @@ __global__ __launch_bounds__(ST_THREADS) void k_st_join_cands(const int32_t *__r
     };
     // ---- first hop
     const int n0 = ST_T * KK;
-    int P0 = 256;
+    int P0 = JN_THREADS;
     while (P0 < n0) P0 <<= 1;
-    for (int t = threadIdx.x; t < P0; t += ST_THREADS) {
+    for (int t = threadIdx.x; t < P0; t += JN_THREADS) {
         int32_t id = 0x7fffffff;
         if (t < n0) id = base_of((uint32_t)(grow0 + t / KK), t % KK);
         b1[t] = id == 0x7fffffff ? 0xffffffffu : (uint32_t)id;
     }
     __syncthreads();
     jn_sort(b1, P0);
-    int n1 = jn_unique<JN_B1 / ST_THREADS>(b1, P0, wsum);
+    int n1 = jn_unique<JN_B1 / JN_THREADS>(b1, P0, wsum);
     // ---- second hop, filtered, appended in any order (sorted below)
     const uint32_t *eb = eval_bits + (size_t)bt * eval_words;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1349,12 +1350,12 @@ __global__ __launch_bounds__(ST_THREADS) void k_st_join_cands(const int32_t *__r
         // LDS atomic per wave and step (the order of the list is arbitrary; it is sorted below).
         const float inv_kk1 = 1.0f / (float)(KK + 1);
         const int lane_j = threadIdx.x & 63;
-        for (int t0 = threadIdx.x; t0 - (int)threadIdx.x < n2; t0 += ST_THREADS * 8) {
+        for (int t0 = threadIdx.x; t0 - (int)threadIdx.x < n2; t0 += JN_THREADS * 8) {
             int32_t id[8];
             uint32_t ew[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int t = min(t0 + u * ST_THREADS, n2 - 1);
+                const int t = min(t0 + u * JN_THREADS, n2 - 1);
                 const int q = (int)(((float)t + 0.5f) * inv_kk1);      // t / (KK + 1), exact for t < 2^22
                 const int e = t - q * (KK + 1);
                 const uint32_t c = b1[q];
@@ -1368,7 +1369,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_st_join_cands(const int32_t *__r
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const bool in = t0 + u * ST_THREADS < n2 && id[u] != 0x7fffffff;
+                const bool in = t0 + u * JN_THREADS < n2 && id[u] != 0x7fffffff;
                 const int J = in ? id[u] >> 7 : 0;
                 const bool keep = in && !((ew[u] >> (J & 31)) & 1u);
                 const unsigned long long kb = __ballot(keep);
@@ -1387,31 +1388,31 @@ __global__ __launch_bounds__(ST_THREADS) void k_st_join_cands(const int32_t *__r
         __syncthreads();
     }
     const int ns = min(nsurv_s, JN_CAP);
-    int P = 256;
+    int P = JN_THREADS;
     while (P < ns) P <<= 1;
-    for (int t = ns + threadIdx.x; t < P; t += ST_THREADS) buf[t] = 0xffffffffu;
+    for (int t = ns + threadIdx.x; t < P; t += JN_THREADS) buf[t] = 0xffffffffu;
     __syncthreads();
     jn_sort(buf, P);
-    int nu = jn_unique<JN_CAP / ST_THREADS>(buf, P, wsum, b1);   // b1 (free by now) receives the multiplicities
+    int nu = jn_unique<JN_CAP / JN_THREADS>(buf, P, wsum, b1);   // b1 (free by now) receives the multiplicities
     if (nu > max_cols) {
         // More candidates than this pass may evaluate: keep the max_cols reached over the most
         // two-hop paths from the tile's rows (the tile analogue of ranking pairs by their
         // probability and refining the top of the list, annchor.py:444-457), ties to the smaller index.
-        constexpr int PER64 = JN_CAP / ST_THREADS;
+        constexpr int PER64 = JN_CAP / JN_THREADS;
         uint32_t ids[PER64], cn[PER64];
 #pragma unroll
         for (int e = 0; e < PER64; ++e) {
-            const int t = e * ST_THREADS + threadIdx.x;
+            const int t = e * JN_THREADS + threadIdx.x;
             ids[e] = t < nu ? buf[t] : 0xffffffffu;
             cn[e] = t < nu ? b1[t] : 0u;
         }
         __syncthreads();
         unsigned long long *k64 = reinterpret_cast<unsigned long long *>(jsm);   // [JN_CAP] over buf + b1
-        int P64 = 256;
+        int P64 = JN_THREADS;
         while (P64 < nu) P64 <<= 1;
 #pragma unroll
         for (int e = 0; e < PER64; ++e) {
-            const int t = e * ST_THREADS + threadIdx.x;
+            const int t = e * JN_THREADS + threadIdx.x;
             if (t < P64) k64[t] = t < nu ? ((unsigned long long)(0xffffffffu - cn[e]) << 32) | ids[e] : ~0ull;
         }
         __syncthreads();
@@ -1419,15 +1420,15 @@ __global__ __launch_bounds__(ST_THREADS) void k_st_join_cands(const int32_t *__r
         uint32_t keep[PER64];
 #pragma unroll
         for (int e = 0; e < PER64; ++e) {
-            const int t = e * ST_THREADS + threadIdx.x;
+            const int t = e * JN_THREADS + threadIdx.x;
             keep[e] = t < max_cols ? (uint32_t)(k64[t] & 0xffffffffull) : 0xffffffffu;
         }
         __syncthreads();
-        int P2 = 256;
+        int P2 = JN_THREADS;
         while (P2 < max_cols) P2 <<= 1;
 #pragma unroll
         for (int e = 0; e < PER64; ++e) {
-            const int t = e * ST_THREADS + threadIdx.x;
+            const int t = e * JN_THREADS + threadIdx.x;
             if (t < P2) buf[t] = keep[e];
         }
         __syncthreads();
@@ -1436,7 +1437,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_st_join_cands(const int32_t *__r
     }
     const int padded = (nu + ST_T - 1) / ST_T * ST_T;
     uint32_t *dst = ucand + (size_t)bt * JN_CAP;
-    for (int t = threadIdx.x; t < padded; t += ST_THREADS) dst[t] = t < nu ? buf[t] : 0xffffffffu;
+    for (int t = threadIdx.x; t < padded; t += JN_THREADS) dst[t] = t < nu ? buf[t] : 0xffffffffu;
     if (threadIdx.x == 0) ucount[bt] = nu;
 }
 
@@ -1820,10 +1821,10 @@ static int knn_join_pass(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pad
     s->rev_gathered = false;   // (they belong to THESE lists: the next pass builds its own)
     {
         ProfScope ps(c, "stream_join_candidates", (double)rows * (K + JN_RK) * 4.0 * (K + JN_RK + 1));
-        const size_t lds = sizeof(uint32_t) * (JN_CAP + JN_B1 + 8);
+        const size_t lds = sizeof(uint32_t) * (JN_CAP + JN_B1 + JN_THREADS / 64 + 8);
         ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_join_cands, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int max_cols = std::max(1, std::min(per_pass * ST_T, JN_CAP));
-        k_st_join_cands<<<a.tile_count, ST_THREADS, lds, c->stream>>>(lists_all, s->rev_all.as<int32_t>(), K, a.tile_begin, a.eval_bits,
+        k_st_join_cands<<<a.tile_count, JN_THREADS, lds, c->stream>>>(lists_all, s->rev_all.as<int32_t>(), K, a.tile_begin, a.eval_bits,
                                                                       a.eval_words, max_cols, s->ucand.as<uint32_t>(),
                                                                       s->ucount.as<int32_t>());
     }
