@@ -573,6 +573,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     // tiles in (key, tile) order, collect, sort, stream}
     float *skey = a.scr_key + (size_t)bt * a.nt_all;
     float *slb = a.scr_lb + (size_t)bt * a.nt_all;
+    if (!a.pre_ranked)   // (k_st_rank_pairs has filled the scratch rows: streamed.hip)
     for (int J = threadIdx.x; J < a.nt_all; J += STB_THREADS) {
         float lb = 0.f, lbc = 0.f;
         for (int an = 0; an < a.na; ++an) {

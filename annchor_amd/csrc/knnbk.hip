@@ -524,6 +524,7 @@ template <int KMAX, bool JOIN = false> __global__ __launch_bounds__(STBK_THREADS
     // tiles in (key, tile) order, collect, sort, stream}
     float *skey = a.scr_key + (size_t)bt * a.nt_all;
     float *slb = a.scr_lb + (size_t)bt * a.nt_all;
+    if (!a.pre_ranked)   // (k_st_rank_pairs has filled the scratch rows: streamed.hip)
     for (int J = threadIdx.x; J < a.nt_all; J += STBK_THREADS) {
         float lb = 0.f, lbc = 0.f;
         for (int an = 0; an < a.na; ++an) {

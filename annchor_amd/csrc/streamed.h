@@ -115,6 +115,7 @@ struct KnnArgs {
     unsigned long long *updates; // list insertions of the pass (its yield: the host stops when it dries up)
     int early_window, early_tau; // tile phase: stop a row tile when early_window consecutive tiles made < early_tau insertions (0: never)
     int dimr;                    // knnbk.hip: the rows' padded dimension (a multiple of 128), set by its launcher
+    int pre_ranked;              // scr_key / scr_lb already hold every (row tile, column tile) pair's rank key and bound (k_st_rank_pairs)
 };
 
 StreamState *ann_stream_state(annchor_ctx *c, bool create);

@@ -1006,6 +1006,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
     // bitonic sort, independent of how the keys are distributed.
     float *skey = a.scr_key + (size_t)bt * a.nt_all;
     float *slb = a.scr_lb + (size_t)bt * a.nt_all;
+    if (!a.pre_ranked)
     for (int J = threadIdx.x; J < a.nt_all; J += ST_THREADS) {
         float lb = 0.f, lbc = 0.f;
         for (int an = 0; an < a.na; ++an) {
@@ -1669,6 +1670,62 @@ void ann_stream_free_run(StreamState *s)
 //   knn_tile_phase  budgeted tile evaluation (k_st_knn); the lists stay on the device
 //   knn_join_pass   one pass over the neighbours' neighbours (k_st_join_cands + k_st_join)
 //   knn_finish      exact float32 distances of the kept neighbours, final order, ids
+// Rank key and valid bound of EVERY (row tile, column tile) pair of a launch, ahead of the tile kernel:
+//   scr_lb[I][J]  = max over anchors of the gap between the two tiles' intervals (the triangle bound of utils.py:274-301 on
+//                   intervals, with the slack for the float32 rounding of the anchor distances),
+//   scr_key[I][J] = squared distance between the tiles' mean anchor vectors (+inf: never a candidate).
+// The tile kernels used to do this themselves, each workgroup for its row tile against all column tiles: na x 12 bytes per
+// pair from the tables, O(n_tiles^2) -- at N = 8 x 10^6 (62 500 tiles) 24 MB per row tile and more than half of the tile
+// kernel's wave cycles (-DST_PROFILE), for ~660 tiles evaluated per row tile.  Pruning it does not work: the box of 64
+// neighbouring tiles' means bounds nothing in a 32-anchor embedding of 8-dimensional data (58-96 % of the runs would have to be
+// ranked to prove a selection round's cut), and ranking runs by their centroid costs recall (C3 0.9972 -> 0.990: the early
+// stop fires on the worse order).  So the work stays O(n_tiles^2) but becomes a tiled pass: a workgroup takes RK_I row tiles x
+// RK_J column tiles, a thread keeps ONE column tile's 3 x na table entries in registers (coalesced reads) and meets the row
+// tiles' entries as LDS broadcasts -- 12 bytes of table traffic per pair instead of 384, the same arithmetic in the same order
+// (the keys and bounds, hence the selection rounds and the graph, are bit for bit what the in-kernel ranking produced).
+#define RK_I 32
+#define RK_J 256
+template <int NA> __global__ __launch_bounds__(RK_J) void k_st_rank_pairs(KnnArgs a)
+{
+    __shared__ float rowt[RK_I][NA][3];   // [row tile][anchor]{lo, hi, mid} of the block's row tiles
+    const int J = blockIdx.x * RK_J + threadIdx.x;
+    const int i0 = blockIdx.y * RK_I, ni = min(RK_I, a.tile_count - i0);
+    for (int t = threadIdx.x; t < ni * a.na; t += RK_J) {
+        const int i = t / a.na, an = t - i * a.na;
+        const int I = a.tile_begin + i0 + i;
+        rowt[i][an][0] = a.rlo[(size_t)an * a.nt_r + I];
+        rowt[i][an][1] = a.rhi[(size_t)an * a.nt_r + I];
+        rowt[i][an][2] = a.rmid[(size_t)an * a.nt_r + I];
+    }
+    float lj[NA], hj[NA], mj[NA];
+    const bool have = J < a.nt_all;
+#pragma unroll
+    for (int an = 0; an < NA; ++an) {
+        const bool ok = have && an < a.na;
+        lj[an] = ok ? a.lo[(size_t)an * a.nt_all + J] : 0.f;
+        hj[an] = ok ? a.hi[(size_t)an * a.nt_all + J] : 0.f;
+        mj[an] = ok ? a.mid[(size_t)an * a.nt_all + J] : 0.f;
+    }
+    __syncthreads();
+    if (!have) return;
+    for (int i = 0; i < ni; ++i) {
+        const int I = a.tile_begin + i0 + i;
+        float lb = 0.f, lbc = 0.f;
+#pragma unroll
+        for (int an = 0; an < NA; ++an)
+            if (an < a.na) {
+                const float loI = rowt[i][an][0], hiI = rowt[i][an][1], midI = rowt[i][an][2];
+                const float gap = fmaxf(loI - hj[an], lj[an] - hiI);
+                // slack for the float32 rounding of D (bounds must stay valid lower bounds)
+                lb = fmaxf(lb, gap - 4e-6f * (fabsf(hj[an]) + fabsf(hiI)));
+                const float dm = mj[an] - midI;
+                lbc += dm * dm;   // rank key: squared L2 distance between the tiles' mean anchor vectors
+            }
+        a.scr_key[(size_t)(i0 + i) * a.nt_all + J] = ((J == I && !a.query) || !(lbc < INFINITY)) ? INFINITY : lbc;   // +inf: never a candidate
+        a.scr_lb[(size_t)(i0 + i) * a.nt_all + J] = lb;
+    }
+}
+
 static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_padded, int tile_budget, bool record_tiles)
 {
     const int K = a.K;
@@ -1710,6 +1767,15 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
     a.prof = d_prof;
 #endif
     ANN_CHECK_HIP(c, hipEventRecord(c->call_a, c->stream));
+    a.pre_ranked = 0;
+    if (a.na <= 64 && !getenv("ANNCHOR_ST_RANK_IN_KERNEL")) {   // (the switch: every workgroup ranks its own row tile, as before round 5)
+        ProfScope ps(c, "stream_rank_tile_pairs", (double)a.tile_count * a.nt_all * 8.0);
+        const dim3 grid((unsigned)((a.nt_all + RK_J - 1) / RK_J), (unsigned)((a.tile_count + RK_I - 1) / RK_I));
+        if (a.na <= 32) k_st_rank_pairs<32><<<grid, RK_J, 0, c->stream>>>(a);
+        else k_st_rank_pairs<64><<<grid, RK_J, 0, c->stream>>>(a);
+        ANN_CHECK_HIP(c, hipGetLastError());
+        a.pre_ranked = 1;
+    }
     {
         // algorithmic flops are data dependent (tiles that survive the bound): reported by the caller from tile_evals
         ProfScope ps(c, "stream_tile_gemm_topk", 0.0);

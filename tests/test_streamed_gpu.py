@@ -750,3 +750,24 @@ def test_two_ranks_beyond_256_dimensions(tmp_path):
     assert np.array_equal(R["A"], one.A)
     np.testing.assert_allclose(R["dist"], one.neighbor_graph[1], rtol=1e-6, atol=1e-6)
     assert (R["idx"] == one.neighbor_graph[0]).mean() > 0.999
+
+
+def test_tiled_ranking_pass_equals_the_in_kernel_ranking(monkeypatch):
+    """The rank keys and bounds of all (row tile, column tile) pairs come from one tiled pass ahead of the tile kernel
+    (k_st_rank_pairs: 12 bytes of table traffic per pair instead of 384 -- the O(n_tiles^2) ranking was more than half of the tile
+    kernel at N = 8 x 10^6).  Same arithmetic in the same order: the graph is bit for bit the one of the in-kernel ranking
+    (ANNCHOR_ST_RANK_IN_KERNEL=1), for the 128-dimension kernel, the k-blocked one, the exact-f32 one and the query path."""
+    from annchor_amd.streamed import StreamedAnnchor
+
+    for n, d, k, pw in ((150000, 128, 15, 0.1), (40000, 300, 15, 0.25), (30000, 64, 40, 0.3), (20000, 20, 8, 1.0)):
+        X = latent(n, d)
+        monkeypatch.delenv("ANNCHOR_ST_RANK_IN_KERNEL", raising=False)
+        a = StreamedAnnchor(X, n_anchors=24, n_neighbors=k, p_work=pw).fit()
+        qa = a.query(X[:300] + 0.01, nn=5, p_work=0.3)
+        monkeypatch.setenv("ANNCHOR_ST_RANK_IN_KERNEL", "1")
+        b = StreamedAnnchor(X, n_anchors=24, n_neighbors=k, p_work=pw).fit()
+        qb = b.query(X[:300] + 0.01, nn=5, p_work=0.3)
+        assert a.tile_evals == b.tile_evals, (n, d)
+        assert np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0]) and np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1]), (n, d)
+        assert np.array_equal(qa[0], qb[0]) and np.array_equal(qa[1], qb[1]), (n, d)
+        a._engine.close(); b._engine.close()
