@@ -593,68 +593,121 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     static_assert(sizeof(sh.cand_d) >= 4096 * sizeof(uint32_t), "histogram does not fit");
     uint32_t done_bits = 0;   // (done_bits, done_j): key bits / index of the last tile already considered
     int done_j = -1;
+    // SHORT LIST (round 5).  A selection round sweeps the scratch row four times (three histogram levels + the collection): at
+    // 62 500 column tiles that is 2 MB per round and row tile, a fifth of the kernel's wave cycles once the ranking had left it.
+    // Instead: ONE histogram sweep of the key's top 12 bits finds the key bound below which ~4 ST_KEEP eligible tiles lie, ONE
+    // more sweep copies those (key, bound, tile) to a short list, and the rounds select from the list -- the same tiles in the
+    // same order: every eligible tile below the key bound is in the list, and the list is rebuilt behind the cursor when a round
+    // finds fewer than ST_KEEP eligible tiles in it while tiles beyond its bound remain.
+    uint32_t *clk = a.scr_cl ? a.scr_cl + (size_t)bt * 3 * ST_CL_CAP : nullptr;   // [3][ST_CL_CAP]: key bits, bound bits, tile
+    int cl_n = 0;                               // (uniform)
+    bool cl_valid = false, cl_complete = false;
+    // entries (key bits, valid bound, tile) of the short list or of the whole scratch row, thread-strided
+    auto sweep = [&](bool from_list, auto f) {
+        if (from_list) {
+            for (int q = threadIdx.x; q < cl_n; q += STB_THREADS) f(clk[q], __uint_as_float(clk[ST_CL_CAP + q]), (int)clk[2 * ST_CL_CAP + q]);
+        } else {
+            for (int J = threadIdx.x; J < a.nt_all; J += STB_THREADS) f(__float_as_uint(skey[J]), slb[J], J);
+        }
+    };
+    // first bin whose cumulative count reaches `want` among nbins bins of `hist`: thread t owns bins [per t, per (t+1)); the
+    // bin in sh.sel_bin (-1: the total stays below `want`), the count before it in sh.sel_before
+    auto find_bin = [&](int nbins, uint32_t want) {
+        const int per = nbins >= STB_THREADS ? nbins / STB_THREADS : 1;
+        const bool owner = (int)threadIdx.x * per < nbins;
+        uint32_t mine = 0;
+        if (owner)
+            for (int q = 0; q < per; ++q) mine += hist[threadIdx.x * per + q];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        uint32_t *wtot = reinterpret_cast<uint32_t *>(&sb.surv_lb[0]);   // 4 wave totals (surv_lb is idle here)
+        if (threadIdx.x == 0) sh.sel_bin = -1;
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+        for (int w2 = 0; w2 < wave; ++w2) before += wtot[w2];
+        if (owner && before < want && before + mine >= want) {
+            uint32_t ac = before;
+            int q = threadIdx.x * per;
+            for (;; ++q) { if (ac + hist[q] >= want) break; ac += hist[q]; }
+            sh.sel_bin = q;
+            sh.sel_before = ac;
+        }
+        __syncthreads();
+    };
     for (;;) {
         const float thrmax = thrmax_now();
         uint32_t prefix = 0;
         uint32_t want = ST_KEEP;
-        bool all = false;
-        for (int level = 0; level < 3 && !all; ++level) {
-            const int shift = level == 0 ? 20 : level == 1 ? 8 : 0;
-            const int nbins = level == 2 ? 256 : 4096;
-            const uint32_t pmask = level == 0 ? 0u : level == 1 ? 0xfff00000u : 0xffffff00u;
-            for (int q = threadIdx.x; q < nbins; q += STB_THREADS) hist[q] = 0;
-            __syncthreads();
-            for (int J = threadIdx.x; J < a.nt_all; J += STB_THREADS) {
-                const uint32_t kb = __float_as_uint(skey[J]);
-                const float lb = slb[J];
-                const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
-                if (kb < 0x7f800000u && after_done && lb * lb < thrmax && (kb & pmask) == prefix)
-                    atomicAdd(&hist[(kb >> shift) & (nbins - 1)], 1u);
+        bool all = false, use_list = false;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (clk && !cl_valid) {
+                // ---- (re)build the short list behind the cursor
+                for (int q = threadIdx.x; q < 4096; q += STB_THREADS) hist[q] = 0;
+                __syncthreads();
+                sweep(false, [&](uint32_t kb, float lb, int J) {
+                    const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
+                    if (kb < 0x7f800000u && after_done && lb * lb < thrmax) atomicAdd(&hist[kb >> 20], 1u);
+                });
+                __syncthreads();
+                find_bin(4096, ST_CL_TARGET);
+                const int bb = sh.sel_bin;
+                cl_complete = bb < 0;                                  // fewer than the target in all: the list holds every eligible tile
+                const uint32_t through = cl_complete ? 0u : sh.sel_before + hist[bb];
+                __syncthreads();
+                if (cl_complete || through <= ST_CL_CAP) {   // (else: a bin of equal leading key bits larger than the list -- the row is swept this round)
+                    const uint32_t bound_bits = cl_complete ? 0x7f800000u : (uint32_t)(bb + 1) << 20;
+                    if (threadIdx.x == 0) sh.nsurv = 0;
+                    __syncthreads();
+                    sweep(false, [&](uint32_t kb, float lb, int J) {
+                        const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
+                        if (kb < bound_bits && after_done && lb * lb < thrmax) {
+                            const int slot = atomicAdd(&sh.nsurv, 1);
+                            if (slot < ST_CL_CAP) { clk[slot] = kb; clk[ST_CL_CAP + slot] = __float_as_uint(lb); clk[2 * ST_CL_CAP + slot] = (uint32_t)J; }
+                        }
+                    });
+                    __syncthreads();
+                    cl_n = min(sh.nsurv, ST_CL_CAP);
+                    cl_valid = true;
+                    __syncthreads();
+                }
             }
-            __syncthreads();
-            // first bin whose cumulative count reaches `want`: thread t owns bins [per t, per (t+1)) (threads beyond the
-            // bins own none); exclusive scan over the threads, then the owner of the crossing walks its bins
-            const int per = nbins >= STB_THREADS ? nbins / STB_THREADS : 1;
-            const bool owner = (int)threadIdx.x * per < nbins;
-            uint32_t mine = 0;
-            if (owner)
-                for (int q = 0; q < per; ++q) mine += hist[threadIdx.x * per + q];
-            uint32_t incl = mine;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t up = __shfl_up(incl, off);
-                if (lane >= off) incl += up;
+            use_list = clk && cl_valid;
+            prefix = 0; want = ST_KEEP; all = false;
+            for (int level = 0; level < 3 && !all; ++level) {
+                const int shift = level == 0 ? 20 : level == 1 ? 8 : 0;
+                const int nbins = level == 2 ? 256 : 4096;
+                const uint32_t pmask = level == 0 ? 0u : level == 1 ? 0xfff00000u : 0xffffff00u;
+                for (int q = threadIdx.x; q < nbins; q += STB_THREADS) hist[q] = 0;
+                __syncthreads();
+                sweep(use_list, [&](uint32_t kb, float lb, int J) {
+                    const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
+                    if (kb < 0x7f800000u && after_done && lb * lb < thrmax && (kb & pmask) == prefix)
+                        atomicAdd(&hist[(kb >> shift) & (nbins - 1)], 1u);
+                });
+                __syncthreads();
+                find_bin(nbins, want);
+                if (sh.sel_bin < 0) all = true;
+                else { prefix |= (uint32_t)sh.sel_bin << shift; want -= sh.sel_before; }
+                __syncthreads();
             }
-            uint32_t *wtot = reinterpret_cast<uint32_t *>(&sb.surv_lb[0]);   // 4 wave totals (surv_lb is idle here)
-            if (threadIdx.x == 0) sh.sel_bin = -1;
-            if (lane == 63) wtot[wave] = incl;
-            __syncthreads();
-            uint32_t before = incl - mine;
-            for (int w2 = 0; w2 < wave; ++w2) before += wtot[w2];
-            if (owner && before < want && before + mine >= want) {
-                uint32_t ac = before;
-                int q = threadIdx.x * per;
-                for (;; ++q) { if (ac + hist[q] >= want) break; ac += hist[q]; }
-                sh.sel_bin = q;
-                sh.sel_before = ac;
-            }
-            __syncthreads();
-            if (sh.sel_bin < 0) all = true;
-            else { prefix |= (uint32_t)sh.sel_bin << shift; want -= sh.sel_before; }
-            __syncthreads();
+            if (!use_list || !all || cl_complete) break;
+            cl_valid = false;   // fewer than ST_KEEP eligible tiles left in the list, and tiles beyond its bound remain: rebuild, select again
         }
         const uint32_t cut_bits = all ? 0x7f7fffffu : prefix;   // take keys <= cut (ties resolved by the sort below)
         if (threadIdx.x == 0) sh.nsurv = 0;
         __syncthreads();
-        for (int J = threadIdx.x; J < a.nt_all; J += STB_THREADS) {
-            const uint32_t kb = __float_as_uint(skey[J]);
-            const float lb = slb[J];
+        sweep(use_list, [&](uint32_t kb, float lb, int J) {
             const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
             if (kb < 0x7f800000u && after_done && lb * lb < thrmax && kb <= cut_bits) {
                 const int slot = atomicAdd(&sh.nsurv, 1);
                 if (slot < ST_SURV) { sb.surv_lb[slot] = __uint_as_float(kb); sb.surv_vb[slot] = lb; sb.surv_j[slot] = J; }
             }
-        }
+        });
         __syncthreads();
         int ns = min(sh.nsurv, ST_SURV);
         if (ns == 0) break;

@@ -11,6 +11,8 @@
 #define ST_SURV 1024
 #define ST_KEEP 512
 #define ST_EARLY_WINDOW 64   // tiles per yield window of the tile phase (knn_tile_phase)
+#define ST_CL_CAP 4096        // entries of a row tile's short list of column tiles (knnbf.hip)
+#define ST_CL_TARGET 2048     // eligible tiles a rebuilt short list aims for (4 ST_KEEP)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -48,6 +50,7 @@ struct StreamState {
     DevBuf out_d2, out_col;
     DevBuf emit_idx, emit_dist;   // int64 / double [n_local][k]: graph rows in shard order
     DevBuf scr_key, scr_lb;   // float [tile_count][nt_all]: per-row-tile rank keys / bounds of all column tiles
+    DevBuf scr_cl;            // uint32 [tile_count][3][ST_CL_CAP]: per-row-tile short lists of the selection rounds
     DevBuf evals;
     DevBuf eval_bits;         // uint32 [tile_count][ceil(nt_all / 32)]: column tiles the tile phase evaluated, per row tile
     DevBuf out_d2b, out_colb; // second list buffers: a join pass reads the old lists of ALL rows and writes new ones
@@ -115,6 +118,7 @@ struct KnnArgs {
     unsigned long long *updates; // list insertions of the pass (its yield: the host stops when it dries up)
     int early_window, early_tau; // tile phase: stop a row tile when early_window consecutive tiles made < early_tau insertions (0: never)
     int dimr;                    // knnbk.hip: the rows' padded dimension (a multiple of 128), set by its launcher
+    uint32_t *scr_cl;            // [tile_count][3][ST_CL_CAP] per row tile: the selection rounds' short list (NULL: the rounds sweep the scratch rows)
     int pre_ranked;              // scr_key / scr_lb already hold every (row tile, column tile) pair's rank key and bound (k_st_rank_pairs)
 };
 

@@ -51,7 +51,7 @@ void ann_stream_release(annchor_ctx *c)
                               &s->scr_key, &s->scr_lb, &s->emit_idx, &s->emit_dist, &s->Dt, &s->eval_bits, &s->out_d2b, &s->out_colb,
                               &s->ucand, &s->ucount, &s->rev_cnt, &s->rev_ptr, &s->rev_edges, &s->cand, &s->cand_all, &s->avecs, &s->A_dev,
                               &s->rows_send, &s->rows_recv, &s->rows_all, &s->lists_all, &s->route_tab, &s->route_cnt, &s->route_slot,
-                              &s->route_send, &s->route_recv, &s->Xb, &s->rsb, &s->cvec, &s->order_all, &s->rev_all, &s->rev_slice, &s->D_send, &s->D_recv};
+                              &s->route_send, &s->route_recv, &s->Xb, &s->rsb, &s->cvec, &s->order_all, &s->rev_all, &s->rev_slice, &s->D_send, &s->D_recv, &s->scr_cl};
             for (DevBuf *b : bufs)
                 if (b->p && !b->in_arena) ann_dev_free(c, b->p, b->cap);
             ann_stream_free_run(s);
@@ -1739,6 +1739,12 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
     ANN_TRY(sreserve(c, s->scr_key, sizeof(float) * (size_t)a.tile_count * (size_t)a.nt_all));
     ANN_TRY(sreserve(c, s->scr_lb, sizeof(float) * (size_t)a.tile_count * (size_t)a.nt_all));
     a.scr_key = s->scr_key.as<float>(); a.scr_lb = s->scr_lb.as<float>();
+    a.scr_cl = nullptr;
+    static const int cl_min = getenv("ANNCHOR_ST_SHORT_LIST_MIN") ? atoi(getenv("ANNCHOR_ST_SHORT_LIST_MIN")) : 2 * ST_CL_CAP;   // (tests lower it)
+    if (a.nt_all > cl_min && !getenv("ANNCHOR_ST_NO_SHORT_LIST")) {   // (short rows are swept as they are)
+        ANN_TRY(sreserve(c, s->scr_cl, sizeof(uint32_t) * 3 * ST_CL_CAP * (size_t)a.tile_count));
+        a.scr_cl = s->scr_cl.as<uint32_t>();
+    }
     a.evals = s->evals.as<unsigned long long>();
     a.eval_bits = nullptr;
     a.eval_words = (a.nt_all + 31) / 32;

@@ -771,3 +771,34 @@ def test_tiled_ranking_pass_equals_the_in_kernel_ranking(monkeypatch):
         assert np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0]) and np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1]), (n, d)
         assert np.array_equal(qa[0], qb[0]) and np.array_equal(qa[1], qb[1]), (n, d)
         a._engine.close(); b._engine.close()
+
+
+def test_short_list_selection_equals_the_row_sweeps(monkeypatch):
+    """Beyond 8192 column tiles the selection rounds of the 128-dimension tile kernel select from a short list (one histogram
+    sweep + one copy sweep of the scratch row per ~2048 eligible tiles) instead of sweeping the row four times per round: the same
+    tiles in the same order, the same graph bit for bit (forced here at small sizes; ANNCHOR_ST_NO_SHORT_LIST=1 = the sweeps)."""
+    import subprocess
+
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_streamed_gpu import latent
+from annchor_amd.streamed import StreamedAnnchor
+out = []
+for n, d, k, pw in ((200000, 128, 15, 0.1), (60000, 64, 12, 0.5), (30000, 32, 8, 1.0)):
+    sa = StreamedAnnchor(latent(n, d), n_anchors=24, n_neighbors=k, p_work=pw).fit()
+    out.append((sa.tile_evals, sa.neighbor_graph[0], sa.neighbor_graph[1]))
+np.savez(sys.argv[1], **{"a%%d_%%d" %% (i, j): np.asarray(v) for i, o in enumerate(out) for j, v in enumerate(o)})
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+
+    res = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, env in (("list", {"ANNCHOR_ST_SHORT_LIST_MIN": "0"}), ("sweep", {"ANNCHOR_ST_NO_SHORT_LIST": "1"})):
+            out = os.path.join(tmp, name + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res.append(dict(np.load(out)))
+    assert res[0].keys() == res[1].keys()
+    for key in res[0]:
+        assert np.array_equal(res[0][key], res[1][key]), key
