@@ -18,6 +18,7 @@ LAT_US = 25.0
 KIND = {   # stage -> how it is partitioned
     "stream_tile_gemm_topk": "rows sharded",
     "stream_join_candidates": "rows sharded",
+    "stream_rank_tile_pairs": "rows sharded",
     "stream_join_gemm_topk": "rows sharded",
     "stream_join_reverse_lists": "columns sharded (+ one read of every list entry)",
     "stream_order_tiles": "own tile range per level (+ the top log2 G levels in full)",
