@@ -113,6 +113,9 @@ _SIGNATURES = {
     "annchor_stream_last_kernel": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_i64)]),
     "annchor_stream_budget": (ctypes.c_int, [_i32, _dbl, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "annchor_stream_knn_end": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
+    "annchor_stream_knn_run": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _i32, _i32,
+                                               ctypes.POINTER(_i64)]),
+    "annchor_stream_knn_fetch": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "annchor_stream_query": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _dbl, _vp, _vp,
                                             ctypes.POINTER(_i64)]),
     "annchor_stream_join_tables": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
@@ -796,17 +799,18 @@ class Engine:
         row_ids is None); otherwise in tile order with row_ids (global id per row, -1 = padding).  out: GraphBuffers."""
         rows = tile_count * 128 if n_local is None else int(n_local)
         row_ids = np.zeros(rows, dtype=np.int64) if n_local is None else None
+        ev = _i64()
+        self._chk(self.lib.annchor_stream_knn_run(self.h, ptrs["Xs"], ptrs["rs"], ptrs["perm"], ptrs["lo"], ptrs["hi"], ptrs["mid"], int(n_all),
+                                                  int(nt_all), int(n_anchors), int(dim_padded), int(tile_begin), int(tile_count),
+                                                  int(k), float(p_work), int(join_passes), int(join_extra), ctypes.byref(ev)))
+        # (the result arrays only now: at N = 8 x 10^6 the helper thread needs longer for its 1.9 GB than the anchor rounds and
+        # the ordering take)
         if out is not None:
             idx, dist = out.take(rows, k)
         else:
             idx = np.empty((rows, k), dtype=np.int64)
             dist = np.empty((rows, k), dtype=np.float64)
-        ev = _i64()
-        self._chk(self.lib.annchor_stream_knn(self.h, ptrs["Xs"], ptrs["rs"], ptrs["perm"], ptrs["lo"], ptrs["hi"], ptrs["mid"], int(n_all),
-                                              int(nt_all), int(n_anchors), int(dim_padded), int(tile_begin), int(tile_count),
-                                              int(k), float(p_work), int(join_passes), int(join_extra),
-                                              _ptr(row_ids) if row_ids is not None else None,
-                                              _ptr(idx), _ptr(dist), ctypes.byref(ev)))
+        self._chk(self.lib.annchor_stream_knn_fetch(self.h, _ptr(row_ids) if row_ids is not None else None, _ptr(idx), _ptr(dist)))
         return row_ids, idx, dist, ev.value
 
     def stream_knn_begin(self, ptrs, n_all, nt_all, n_anchors, dim_padded, tile_begin, tile_count, k, tile_budget):

@@ -515,7 +515,15 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
             issue_slab(J, 1);
             P8(4)
             step(J, 0, acc0, acc1);
+#ifdef ST_PROFILE
+            PS0
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            PS(12)   // own requests landed
             slab_end();
+            PS(13)   // the other waves arrived
+#else
+            slab_end();
+#endif
             RJ_LANDED
             P8(1)
             issue_slab(J, 2);

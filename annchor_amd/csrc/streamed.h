@@ -64,6 +64,9 @@ struct StreamState {
     struct KnnArgs *run = nullptr;   // arguments of the graph build in progress (begin / join / end)
     const void *run_perm = nullptr;
     int run_dimp = 0;
+    bool run_finished = false;   // annchor_stream_knn_run: the finished graph waits on the device (fin_idx / fin_dist) for _fetch
+    int64_t *fin_idx = nullptr;
+    float *fin_dist = nullptr;
     // ---- device-resident multi-rank protocol (sharded.hip)
     DevBuf cand_all;   // double [world][2 + dim]: all-gather target of the candidates
     DevBuf cand;       // double [2 + dim]: this rank's arg-max candidate of a max-min round (value, global row, its coordinates)

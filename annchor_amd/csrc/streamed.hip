@@ -1661,6 +1661,7 @@ void ann_stream_free_run(StreamState *s)
 {
     delete s->run;
     s->run = nullptr;
+    s->run_finished = false;
 }
 
 // The graph build of row tiles [tile_begin, tile_begin + tile_count) against ALL column tiles runs
@@ -2025,15 +2026,18 @@ static int knn_args_graph(annchor_ctx *c, KnnArgs &a, const void *Xs_all, const 
 // order (row = global id - global_base of annchor_stream_bind), written by a device kernel and
 // copied out in one piece -- no host-side reordering.  tile_evals counts 128 x 128 pair blocks
 // (tile phase + join passes).
-extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void *rs_all, const void *perm_all,
-                                  const void *lo_all, const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors,
-                                  int32_t dim_padded, int32_t tile_begin, int32_t tile_count, int32_t k, double p_work,
-                                  int32_t join_passes, int32_t join_extra, int64_t *row_ids, int64_t *ng_idx, double *ng_dist,
-                                  int64_t *tile_evals)
+// annchor_stream_knn = annchor_stream_knn_run (everything on the device; the graph stays there) + annchor_stream_knn_fetch
+// (the download): a host that prepares its result arrays on another thread while the GPU works (1.9 GB to allocate and
+// touch at N = 8 x 10^6) calls the halves itself and needs the arrays only for the second.
+extern "C" int annchor_stream_knn_run(annchor_ctx *c, const void *Xs_all, const void *rs_all, const void *perm_all,
+                                      const void *lo_all, const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors,
+                                      int32_t dim_padded, int32_t tile_begin, int32_t tile_count, int32_t k, double p_work,
+                                      int32_t join_passes, int32_t join_extra, int64_t *tile_evals)
 {
-    if (!c || !Xs_all || !rs_all || !perm_all || !lo_all || !hi_all || !mid_all || !ng_idx || !ng_dist) return ANNCHOR_EINVAL;
+    if (!c || !Xs_all || !rs_all || !perm_all || !lo_all || !hi_all || !mid_all) return ANNCHOR_EINVAL;
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     StreamState *s = state_of(c, true);
+    ann_stream_free_run(s);
     KnnArgs a;
     ANN_TRY(knn_args_graph(c, a, Xs_all, rs_all, lo_all, hi_all, mid_all, n_all, nt_all, n_anchors, tile_begin, tile_count, k));
     ANN_REQUIRE(c, join_passes >= 0 && join_extra >= 0 && (join_passes + join_extra == 0 || tile_count == nt_all), ANNCHOR_EINVAL,
@@ -2050,10 +2054,35 @@ extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void
         ANN_TRY(knn_join_pass(c, s, a, dim_padded, a.out_col, std::max(pp, 1), &upd));
         if (p + 1 >= join_passes && (double)upd <= floor_updates) break;
     }
-    int64_t *d_idx = nullptr;
-    float *d_dist = nullptr;
-    ANN_TRY(ann_stream_knn_finish(c, s, a, perm_all, dim_padded, &d_idx, &d_dist, tile_evals));
-    return knn_download_graph(c, s, a, perm_all, d_idx, d_dist, row_ids, ng_idx, ng_dist);
+    ANN_TRY(ann_stream_knn_finish(c, s, a, perm_all, dim_padded, &s->fin_idx, &s->fin_dist, tile_evals));
+    s->run = new KnnArgs(a);
+    s->run_perm = perm_all;
+    s->run_dimp = dim_padded;
+    s->run_finished = true;
+    return ANNCHOR_OK;
+}
+
+extern "C" int annchor_stream_knn_fetch(annchor_ctx *c, int64_t *row_ids, int64_t *ng_idx, double *ng_dist)
+{
+    if (!c || !ng_idx || !ng_dist) return ANNCHOR_EINVAL;
+    ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    StreamState *s = state_of(c, false);
+    ANN_REQUIRE(c, s && s->run && s->run_finished, ANNCHOR_ESTATE, "annchor_stream_knn_run not called");
+    const int rc = knn_download_graph(c, s, *s->run, s->run_perm, s->fin_idx, s->fin_dist, row_ids, ng_idx, ng_dist);
+    ann_stream_free_run(s);
+    return rc;
+}
+
+extern "C" int annchor_stream_knn(annchor_ctx *c, const void *Xs_all, const void *rs_all, const void *perm_all,
+                                  const void *lo_all, const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors,
+                                  int32_t dim_padded, int32_t tile_begin, int32_t tile_count, int32_t k, double p_work,
+                                  int32_t join_passes, int32_t join_extra, int64_t *row_ids, int64_t *ng_idx, double *ng_dist,
+                                  int64_t *tile_evals)
+{
+    if (!c || !ng_idx || !ng_dist) return ANNCHOR_EINVAL;
+    ANN_TRY(annchor_stream_knn_run(c, Xs_all, rs_all, perm_all, lo_all, hi_all, mid_all, n_all, nt_all, n_anchors, dim_padded, tile_begin,
+                                   tile_count, k, p_work, join_passes, join_extra, tile_evals));
+    return annchor_stream_knn_fetch(c, row_ids, ng_idx, ng_dist);
 }
 
 // The same build in steps, for row-sharded runs: after _begin (tile phase) and after every _join

@@ -377,6 +377,13 @@ int annchor_stream_knn(annchor_ctx *ctx, const void *Xs_all, const void *rs_all,
                        const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors, int32_t dim_padded,
                        int32_t tile_begin, int32_t tile_count, int32_t k, double p_work, int32_t join_passes, int32_t join_extra,
                        int64_t *row_ids, int64_t *ng_idx, double *ng_dist, int64_t *tile_evals);
+/* annchor_stream_knn in two halves: _run leaves the finished graph on the device, _fetch downloads it (same outputs as
+ * annchor_stream_knn) -- for hosts that prepare the result arrays on another thread while the GPU works. */
+int annchor_stream_knn_run(annchor_ctx *ctx, const void *Xs_all, const void *rs_all, const void *perm_all, const void *lo_all,
+                           const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors,
+                           int32_t dim_padded, int32_t tile_begin, int32_t tile_count, int32_t k, double p_work, int32_t join_passes,
+                           int32_t join_extra, int64_t *tile_evals);
+int annchor_stream_knn_fetch(annchor_ctx *ctx, int64_t *row_ids, int64_t *ng_idx, double *ng_dist);
 int annchor_stream_knn_begin(annchor_ctx *ctx, const void *Xs_all, const void *rs_all, const void *perm_all, const void *lo_all,
                              const void *hi_all, const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors,
                              int32_t dim_padded, int32_t tile_begin, int32_t tile_count, int32_t k, int32_t tile_budget,
