@@ -699,7 +699,10 @@ __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict_
 // ----------------------------------------------------- top-K split + compaction
 #define CP_THREADS 256
 #define CP_ITEMS 8
-#define CP_TILE (CP_THREADS * CP_ITEMS)
+#define CP_SUBTILE (CP_THREADS * CP_ITEMS)
+// sub-tiles per workgroup (a tile = nsub x 2048 pairs): 4 on long lists -- the single-workgroup scan of the tile counters
+// (k_cut_scan) walked 62 K tiles of 2048 at 127 M pairs in 175 us --, 1 on short ones (C2: 625 workgroups of one sub-tile)
+static inline int cp_nsub(int64_t n) { return n >= (16ll << 20) ? 4 : 1; }
 
 
 #define TIE_CAP 65536
@@ -816,14 +819,31 @@ __global__ __launch_bounds__(1024) void k_tie_pick(CutState *__restrict__ cs, ui
     }
 }
 
-// members of the picked bins -> short lists (append order is irrelevant: k_tie_select ranks the keys)
+// members of the picked bins -> short lists (append order is irrelevant: k_tie_select ranks the keys).  A workgroup keeps its
+// finds in LDS and reserves their slots with ONE atomic per list at the end: an atomic on one global address costs ~12.5 ns,
+// serialised over the whole chip (tools/microbench/atomics.hip) -- with a group of 10^8 pairs on the cut the picked bin holds
+// 3 x 10^4 of them, and appending them one by one made this pass 0.58 ms where the histogram pass over the same column takes 0.19.
+#define TIE_LCAP 1024
 __global__ __launch_bounds__(256) void k_tie_collect(const double *__restrict__ prob, int64_t n, CutState *__restrict__ cs,
                                                     unsigned long long *__restrict__ list1, unsigned long long *__restrict__ list5,
                                                     long long cap)
 {
+    __shared__ unsigned long long lbuf[2][TIE_LCAP];
+    __shared__ uint32_t lcnt[2];
+    __shared__ unsigned long long lbase[2];
     const long long b1 = cs->tie_bin1, b5 = cs->tie_bin5;
     if (b1 < 0 && b5 < 0) return;
+    if (threadIdx.x < 2) lcnt[threadIdx.x] = 0;
+    __syncthreads();
     const double t1 = cs->t1, t5 = cs->t5;
+    auto put = [&](int q, unsigned long long kk) {
+        const uint32_t o = atomicAdd(&lcnt[q], 1u);
+        if (o < TIE_LCAP) lbuf[q][o] = kk;
+        else {   // (more finds than the staging holds: straight to the list)
+            const unsigned long long g = atomicAdd((unsigned long long *)(q == 0 ? &cs->tie_got1 : &cs->tie_got5), 1ull);
+            if ((long long)g < cap) (q == 0 ? list1 : list5)[g] = kk;
+        }
+    };
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * TIE_U;
     for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x * TIE_U + threadIdx.x; p0 < n; p0 += stride) {
         double v[TIE_U];
@@ -837,10 +857,22 @@ __global__ __launch_bounds__(256) void k_tie_collect(const double *__restrict__ 
             if (m1 || m5) {
                 const unsigned long long kk = ann_tie_scramble(p);
                 const long long bin = (long long)(kk >> TIE_SHIFT);
-                if (m1 && bin == b1) { const unsigned long long o = atomicAdd((unsigned long long *)&cs->tie_got1, 1ull); if ((long long)o < cap) list1[o] = kk; }
-                if (m5 && bin == b5) { const unsigned long long o = atomicAdd((unsigned long long *)&cs->tie_got5, 1ull); if ((long long)o < cap) list5[o] = kk; }
+                if (m1 && bin == b1) put(0, kk);
+                if (m5 && bin == b5) put(1, kk);
             }
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const uint32_t m = min(lcnt[threadIdx.x], (uint32_t)TIE_LCAP);
+        lbase[threadIdx.x] = m ? atomicAdd((unsigned long long *)(threadIdx.x == 0 ? &cs->tie_got1 : &cs->tie_got5), (unsigned long long)m) : 0ull;
+    }
+    __syncthreads();
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t m = min(lcnt[q], (uint32_t)TIE_LCAP);
+        unsigned long long *list = q == 0 ? list1 : list5;
+        for (uint32_t t = threadIdx.x; t < m; t += blockDim.x)
+            if ((long long)(lbase[q] + t) < cap) list[lbase[q] + t] = lbuf[q][t];
     }
 }
 
@@ -922,7 +954,7 @@ __device__ __forceinline__ int cut_class(double v, double t, unsigned long long 
 }
 
 __global__ __launch_bounds__(CP_THREADS) void k_cut_count(const double *__restrict__ prob, const double *__restrict__ RA, int64_t n,
-                                                         const CutState *__restrict__ cs, uint32_t *__restrict__ blk)
+                                                         const CutState *__restrict__ cs, uint32_t *__restrict__ blk, int nsub)
 {
     __shared__ uint32_t acc[4];
     if (threadIdx.x < 4) acc[threadIdx.x] = 0;
@@ -930,19 +962,22 @@ __global__ __launch_bounds__(CP_THREADS) void k_cut_count(const double *__restri
     const double t1 = cs->t1, t5 = cs->t5;
     const unsigned long long rk1 = cs->rk1, rk5 = cs->rk5;
     uint32_t g1 = 0, q1 = 0, g5 = 0, q5 = 0;
-    const int64_t base = (int64_t)blockIdx.x * CP_TILE;
-    double v[CP_ITEMS];
+    for (int sub = 0; sub < nsub; ++sub) {
+        const int64_t base = ((int64_t)blockIdx.x * nsub + sub) * CP_SUBTILE;
+        if (base >= n) break;
+        double v[CP_ITEMS];
 #pragma unroll
-    for (int k = 0; k < CP_ITEMS; ++k) v[k] = ann_ldc(prob, base + (int64_t)k * CP_THREADS + threadIdx.x, n);   // one batch in flight
+        for (int k = 0; k < CP_ITEMS; ++k) v[k] = ann_ldc(prob, base + (int64_t)k * CP_THREADS + threadIdx.x, n);   // one batch in flight
 #pragma unroll
-    for (int k = 0; k < CP_ITEMS; ++k) {
-        const int64_t p = base + (int64_t)k * CP_THREADS + threadIdx.x;
-        if (p < n && v[k] >= 0.0) {
-            const int c1 = cut_class(v[k], t1, rk1, RA, p), c5 = cut_class(v[k], t5, rk5, RA, p);
-            g1 += c1 == 2; q1 += c1 == 1; g5 += c5 == 2; q5 += c5 == 1;
+        for (int k = 0; k < CP_ITEMS; ++k) {
+            const int64_t p = base + (int64_t)k * CP_THREADS + threadIdx.x;
+            if (p < n && v[k] >= 0.0) {
+                const int c1 = cut_class(v[k], t1, rk1, RA, p), c5 = cut_class(v[k], t5, rk5, RA, p);
+                g1 += c1 == 2; q1 += c1 == 1; g5 += c5 == 2; q5 += c5 == 1;
+            }
         }
     }
-    // four 8-bit-per-item counters packed into one wave reduction (each <= 64 * CP_ITEMS = 512 < 2^16)
+    // four per-lane counters packed into one wave reduction (each <= 64 * CP_ITEMS * nsub = 2048 < 2^16)
     unsigned long long pk = (unsigned long long)g1 | ((unsigned long long)q1 << 16) | ((unsigned long long)g5 << 32) |
                             ((unsigned long long)q5 << 48);
 #pragma unroll
@@ -1043,61 +1078,71 @@ __global__ __launch_bounds__(CS_THREADS) void k_cut_scan(const uint32_t *__restr
 
 __global__ __launch_bounds__(CP_THREADS) void k_cut_emit(const double *__restrict__ prob, const double *__restrict__ RA, int64_t n,
                                                         const CutState *__restrict__ cs, const int64_t *__restrict__ off,
-                                                        int32_t *__restrict__ cand, int32_t *__restrict__ next)
+                                                        int32_t *__restrict__ cand, int32_t *__restrict__ next, int nsub)
 {
     __shared__ uint32_t wsum[CP_THREADS / 64];
     const double t1 = cs->t1, t5 = cs->t5;
     const unsigned long long rk1 = cs->rk1, rk5 = cs->rk5;
     const int64_t e1 = cs->e1, e5 = cs->e5;
     const bool both_all = cs->all1 && cs->all5;
-    const int64_t base = (int64_t)blockIdx.x * CP_TILE + (int64_t)threadIdx.x * CP_ITEMS;  // thread-contiguous: keeps position order
-    double v[CP_ITEMS];
-    int8_t k1[CP_ITEMS], k5[CP_ITEMS];
-    uint32_t q1 = 0, q5 = 0;
-#pragma unroll
-    for (int k = 0; k < CP_ITEMS; ++k) {
-        v[k] = (base + k < n) ? prob[base + k] : -1.0;
-        k1[k] = k5[k] = 0;
-        if (v[k] >= 0.0) {
-            k1[k] = (int8_t)cut_class(v[k], t1, rk1, RA, base + k);
-            k5[k] = (int8_t)cut_class(v[k], t5, rk5, RA, base + k);
-            q1 += k1[k] == 1; q5 += k5[k] == 1;
-        }
-    }
-    auto scan2 = [&](uint32_t a, uint32_t b, uint32_t *ea, uint32_t *eb) {
-        // packs two counters (each < 2^16 per block) into one 32-bit scan
+    auto scan2 = [&](uint32_t a, uint32_t b, uint32_t *ea, uint32_t *eb, uint32_t *ta, uint32_t *tb) {
+        // packs two counters (each < 2^16 per sub-tile) into one 32-bit scan
         uint32_t tot;
         const uint32_t packed = row_block_scan((a << 16) | b, wsum, &tot);
         __syncthreads();
         *ea = packed >> 16;
         *eb = packed & 0xffffu;
+        *ta = tot >> 16;
+        *tb = tot & 0xffffu;
     };
-    uint32_t x1, x5;
-    scan2(q1, q5, &x1, &x5);
-    int64_t r1 = off[(size_t)blockIdx.x * 4] + x1, r5 = off[(size_t)blockIdx.x * 4 + 1] + x5;
-    uint8_t fc[CP_ITEMS], fn[CP_ITEMS];
-    uint32_t nc = 0, nn = 0;
+    // running offsets of the tile: class-1 ranks of the two cuts, write cursors of the two lists
+    int64_t R1 = off[(size_t)blockIdx.x * 4], R5 = off[(size_t)blockIdx.x * 4 + 1];
+    int64_t WC = off[(size_t)blockIdx.x * 4 + 2], WN = off[(size_t)blockIdx.x * 4 + 3];
+    for (int sub = 0; sub < nsub; ++sub) {
+        const int64_t sbase = ((int64_t)blockIdx.x * nsub + sub) * CP_SUBTILE;
+        if (sbase >= n) break;   // (uniform)
+        const int64_t base = sbase + (int64_t)threadIdx.x * CP_ITEMS;  // thread-contiguous: keeps position order
+        double v[CP_ITEMS];
+        int8_t k1[CP_ITEMS], k5[CP_ITEMS];
+        uint32_t q1 = 0, q5 = 0;
 #pragma unroll
-    for (int k = 0; k < CP_ITEMS; ++k) {
-        bool c1 = false, c5 = false;
-        if (v[k] >= 0.0) {
-            c1 = k1[k] == 2 || (k1[k] == 1 && r1 < e1);
-            c5 = k5[k] == 2 || (k5[k] == 1 && r5 < e5);
-            r1 += k1[k] == 1;
-            r5 += k5[k] == 1;
+        for (int k = 0; k < CP_ITEMS; ++k) {
+            v[k] = (base + k < n) ? prob[base + k] : -1.0;
+            k1[k] = k5[k] = 0;
+            if (v[k] >= 0.0) {
+                k1[k] = (int8_t)cut_class(v[k], t1, rk1, RA, base + k);
+                k5[k] = (int8_t)cut_class(v[k], t5, rk5, RA, base + k);
+                q1 += k1[k] == 1; q5 += k5[k] == 1;
+            }
         }
-        fc[k] = c1;
-        fn[k] = both_all ? c5 : (c5 && !c1);
-        nc += fc[k];
-        nn += fn[k];
-    }
-    uint32_t oc, on;
-    scan2(nc, nn, &oc, &on);
-    int64_t wc = off[(size_t)blockIdx.x * 4 + 2] + oc, wn = off[(size_t)blockIdx.x * 4 + 3] + on;
+        uint32_t x1, x5, tq1, tq5;
+        scan2(q1, q5, &x1, &x5, &tq1, &tq5);
+        int64_t r1 = R1 + x1, r5 = R5 + x5;
+        uint8_t fc[CP_ITEMS], fn[CP_ITEMS];
+        uint32_t nc = 0, nn = 0;
 #pragma unroll
-    for (int k = 0; k < CP_ITEMS; ++k) {
-        if (fc[k]) cand[wc++] = (int32_t)(base + k);
-        if (fn[k]) next[wn++] = (int32_t)(base + k);
+        for (int k = 0; k < CP_ITEMS; ++k) {
+            bool c1 = false, c5 = false;
+            if (v[k] >= 0.0) {
+                c1 = k1[k] == 2 || (k1[k] == 1 && r1 < e1);
+                c5 = k5[k] == 2 || (k5[k] == 1 && r5 < e5);
+                r1 += k1[k] == 1;
+                r5 += k5[k] == 1;
+            }
+            fc[k] = c1;
+            fn[k] = both_all ? c5 : (c5 && !c1);
+            nc += fc[k];
+            nn += fn[k];
+        }
+        uint32_t oc, on, tc, tn;
+        scan2(nc, nn, &oc, &on, &tc, &tn);
+        int64_t wc = WC + oc, wn = WN + on;
+#pragma unroll
+        for (int k = 0; k < CP_ITEMS; ++k) {
+            if (fc[k]) cand[wc++] = (int32_t)(base + k);
+            if (fn[k]) next[wn++] = (int32_t)(base + k);
+        }
+        R1 += tq1; R5 += tq5; WC += tc; WN += tn;
     }
 }
 
@@ -1352,7 +1397,8 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     if (cs.all1) cs.t1 = -1.0;
     if (cs.all5) cs.t5 = -1.0;
     if (n_refine == 0) { cs.all1 = cs.all5 = 0; cs.t1 = cs.t5 = INFINITY; cs.K1 = cs.K5 = 0; }
-    const int nb = ann_blocks(n, CP_TILE);
+    const int nsub = cp_nsub(n);
+    const int nb = ann_blocks(n, (int64_t)CP_SUBTILE * nsub);
     ANN_TRY(ann_reserve(c, c->sel_state, SEL_STATE_BYTES));
     ANN_TRY(ann_reserve(c, c->blk_cnt, sizeof(uint32_t) * 4 * (size_t)nb));
     ANN_TRY(ann_reserve(c, c->blk_off, sizeof(int64_t) * 4 * (size_t)nb));
@@ -1381,10 +1427,10 @@ extern "C" int annchor_select_candidates(annchor_ctx *c, int32_t n_neighbors, in
     auto split = [&]() {
         ProfScope ps(c, "topk_split_compact", (double)n * 16.0 + (double)(maxc + maxn) * 4.0);
         k_cut_count<<<nb, CP_THREADS, 0, c->stream>>>(c->prob.as<double>(), c->RA.as<double>(), n, c->sel_state.as<CutState>(),
-                                                     c->blk_cnt.as<uint32_t>());
+                                                     c->blk_cnt.as<uint32_t>(), nsub);
         k_cut_scan<<<1, CS_THREADS, 0, c->stream>>>(c->blk_cnt.as<uint32_t>(), nb, c->sel_state.as<CutState>(), c->blk_off.as<int64_t>());
         k_cut_emit<<<nb, CP_THREADS, 0, c->stream>>>(c->prob.as<double>(), c->RA.as<double>(), n, c->sel_state.as<CutState>(),
-                                                    c->blk_off.as<int64_t>(), c->cand.as<int32_t>(), c->next.as<int32_t>());
+                                                    c->blk_off.as<int64_t>(), c->cand.as<int32_t>(), c->next.as<int32_t>(), nsub);
     };
     auto tie_groups = [&]() -> int {
         // the groups on the two cuts and their RefineApprox cuts (device only: no host wait)
