@@ -455,23 +455,39 @@ struct HsParams {
     unsigned long long thr[MAXBINS];   // key threshold per partition (~0: take every member)
 };
 
+// (The first form looked every pair's partition up -- a search over the edges -- and then loaded that partition's threshold
+// from the kernel arguments: a dependent global load per pair, 0.55 ms for 127 M pairs where the column streams in 0.25.  A
+// pair whose key exceeds the LARGEST threshold cannot be taken whatever its partition: nearly all of them, and for those the
+// hash is all there is to do; edges and thresholds wait in LDS for the rest.)
+#define HS_U 8
 __global__ __launch_bounds__(256) void k_hs_collect(const double *__restrict__ dad, const uint8_t *__restrict__ ncm, int64_t n,
                                                    BinEdges be, HsParams hp, unsigned long long *__restrict__ lkey,
                                                    int32_t *__restrict__ lpos, uint32_t *__restrict__ lcnt)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
-    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x * 4 + threadIdx.x; p0 < n; p0 += stride) {
-        double v[4];
-        uint8_t f[4];
+    __shared__ double se[MAXBINS + 1];
+    __shared__ unsigned long long sthr[MAXBINS];
+    for (int t = threadIdx.x; t <= be.nb; t += blockDim.x) se[t] = be.e[t];
+    for (int t = threadIdx.x; t < be.nb; t += blockDim.x) sthr[t] = hp.thr[t];
+    unsigned long long tmax = 0;
+    for (int b = 0; b < be.nb; ++b) tmax = hp.thr[b] > tmax ? hp.thr[b] : tmax;   // (uniform)
+    __syncthreads();
+    const int nb = be.nb;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * HS_U;
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x * HS_U + threadIdx.x; p0 < n; p0 += stride) {
+        double v[HS_U];
+        uint8_t f[HS_U];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = ann_ldc(dad, p0 + (int64_t)e * blockDim.x, n); f[e] = ann_ldc(ncm, p0 + (int64_t)e * blockDim.x, n); }
+        for (int e = 0; e < HS_U; ++e) { v[e] = ann_ldc(dad, p0 + (int64_t)e * blockDim.x, n); f[e] = ann_ldc(ncm, p0 + (int64_t)e * blockDim.x, n); }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < HS_U; ++e) {
             const int64_t p = p0 + (int64_t)e * blockDim.x;
             if (p >= n || !f[e]) continue;
             const unsigned long long key = ann_splitmix64(hp.seed_key ^ (unsigned long long)p);
-            const int b = sampler_bin(be, v[e]);
-            if (b >= 0 && key <= hp.thr[b]) {
+            if (key > tmax) continue;
+            int b = -1;
+            for (int k = 0; k < nb; ++k)
+                if (v[e] >= se[k] && v[e] < se[k + 1]) { b = k; break; }   // (sampler_bin over the LDS copy)
+            if (b >= 0 && key <= sthr[b]) {
                 const uint32_t o = atomicAdd(&lcnt[b], 1u);
                 if (o < HS_CAP) { lkey[(size_t)b * HS_CAP + o] = key; lpos[(size_t)b * HS_CAP + o] = (int32_t)p; }
             }
@@ -577,7 +593,7 @@ static int hash_sample_device(annchor_ctx *c, const double *bins, int32_t nbins,
         ANN_CHECK_HIP(c, hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * MAXBINS, c->stream));
         {
             ProfScope ps(c, "hashed_sample_collect", (double)c->n * 9.0);
-            const int blocks = (int)std::min<int64_t>(ann_blocks(c->n, 256 * 4), (int64_t)c->prop.multiProcessorCount * 8);
+            const int blocks = (int)std::min<int64_t>(ann_blocks(c->n, 256 * HS_U), (int64_t)c->prop.multiProcessorCount * 8);
             k_hs_collect<<<blocks, 256, 0, c->stream>>>(c->dad.as<double>(), c->ncm.as<uint8_t>(), c->n, be, hp, c->hs_key.as<unsigned long long>(),
                                                        c->hs_pos.as<int32_t>(), d_cnt);
             k_hs_finish<<<nbins, 1024, 0, c->stream>>>(c->hs_key.as<unsigned long long>(), c->hs_pos.as<int32_t>(), d_cnt, d_want, d_off, d_out,
