@@ -115,23 +115,14 @@ __global__ __launch_bounds__(ROW_THREADS) void k_comp_fill_direct(const int64_t 
         uint32_t tot;
         uint32_t ex = row_block_scan(z, wsum, &tot);
         if (z) {
-            // only the computed entries (a few per cent) look their pair up: position -> pair -> value is a chain of dependent
-            // gathers, and the lanes of a wave hold their computed entries at different e -- walked entry by entry the wave
-            // paid up to 16 chains one after the other (0.77 ms at 16 000 rows); three rounds of independent loads instead
             const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
-            int32_t pp[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) pp[e] = (((wd[e >> 2] >> (8 * (e & 3))) & 0xFFu) == 0u) ? Iidx[k0 + e] : -1;
-            int2 qq[16];
-            double rr[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                if (pp[e] >= 0) { qq[e] = ij[pp[e]]; rr[e] = RA[pp[e]]; }
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if (pp[e] >= 0) {
-                    cidx[w + ex] = qq[e].x == (int)i ? qq[e].y : qq[e].x;
-                    cval[w + ex] = rr[e];
+                if (((wd[e >> 2] >> (8 * (e & 3))) & 0xFFu) == 0u) {
+                    const int32_t p = Iidx[k0 + e];   // only the computed entries (a few per cent) look their pair up
+                    const int2 q = ij[p];
+                    cidx[w + ex] = q.x == (int)i ? q.y : q.x;
+                    cval[w + ex] = RA[p];
                     ++ex;
                 }
         }
