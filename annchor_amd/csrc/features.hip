@@ -1729,6 +1729,7 @@ __device__ __forceinline__ int err_label(const RegModel &m, double d)
     return b;
 }
 
+#define PM_U 4
 __global__ __launch_bounds__(256) void k_predict_merge(int64_t n, const RegModel *__restrict__ mp, int first, int is_metric,
                                                       const int2 *__restrict__ ij, const double *__restrict__ Dt,
                                                       int64_t nx, const int32_t *__restrict__ anchorRank,
@@ -1737,22 +1738,37 @@ __global__ __launch_bounds__(256) void k_predict_merge(int64_t n, const RegModel
                                                       const uint8_t *__restrict__ ncm, double *__restrict__ RA,
                                                       uint8_t *__restrict__ label, int stream)
 {
-    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
+    // four pairs per thread: their twelve column reads are in flight together (one pair per thread and 500 000 workgroups of
+    // 256 pairs: 1.04 ms per call at 127 M pairs, 0.52 of the HBM rate)
     const RegModel &m = *mp;   // uniform address: scalar loads
-    const double l = ann_load(lb + p, stream), u = ann_load(ub + p, stream), d = ann_load(dad + p, stream);
-    double pr = reg_predict(m, l, u, d);
-    pr = fmin(fmax(pr, l), u);  // np.clip(pred, lb, ub)
-    if (!is_metric && anc[p]) {
-        // annchor.py:368-372: anchor pairs take their exact value from D; a later
-        // anchor in A overrides an earlier one
-        const int2 q = ij[p];
-        const int ri = anchorRank[q.x], rj = anchorRank[q.y];
-        pr = (ri > rj) ? Dt[(size_t)ri * nx + q.y] : Dt[(size_t)rj * nx + q.x];
+    const int64_t p0 = (int64_t)blockIdx.x * (PM_U * 256) + threadIdx.x;
+    double l[PM_U], u[PM_U], d[PM_U];
+    uint8_t an[PM_U], nc[PM_U];
+#pragma unroll
+    for (int e = 0; e < PM_U; ++e) {
+        const int64_t p = p0 + (int64_t)e * 256;
+        const int64_t pc = p < n ? p : n - 1;
+        l[e] = ann_load(lb + pc, stream); u[e] = ann_load(ub + pc, stream); d[e] = ann_load(dad + pc, stream);
+        an[e] = is_metric ? (uint8_t)0 : anc[pc];
+        nc[e] = first ? (uint8_t)1 : ncm[pc];
     }
-    if (first || ncm[p]) ann_store(RA + p, pr, stream);
-    const int lbl = err_label(m, d);
-    ann_store(label + p, (uint8_t)(lbl < 0 ? 255 : lbl), stream);
+#pragma unroll
+    for (int e = 0; e < PM_U; ++e) {
+        const int64_t p = p0 + (int64_t)e * 256;
+        if (p >= n) continue;
+        double pr = reg_predict(m, l[e], u[e], d[e]);
+        pr = fmin(fmax(pr, l[e]), u[e]);  // np.clip(pred, lb, ub)
+        if (an[e]) {
+            // annchor.py:368-372: anchor pairs take their exact value from D; a later
+            // anchor in A overrides an earlier one
+            const int2 q = ij[p];
+            const int ri = anchorRank[q.x], rj = anchorRank[q.y];
+            pr = (ri > rj) ? Dt[(size_t)ri * nx + q.y] : Dt[(size_t)rj * nx + q.x];
+        }
+        if (nc[e]) ann_store(RA + p, pr, stream);
+        const int lbl = err_label(m, d[e]);
+        ann_store(label + p, (uint8_t)(lbl < 0 ? 255 : lbl), stream);
+    }
 }
 
 __global__ void k_sample_predict_scatter(const int32_t *__restrict__ pos, const double *__restrict__ sy, int64_t ms,
@@ -1774,7 +1790,7 @@ int ann_predict_merge_device(annchor_ctx *c, const RegModel *d_model, int first_
     {
         // algorithmic bytes per pair: 3*8 read (lb, ub, dad) + 1 (mask) + 8 (RA) + 1 (label)
         ProfScope ps(c, "predict_clip_label_merge", (double)c->n * 34.0);
-        k_predict_merge<<<ann_blocks(c->n, 256), 256, 0, c->stream>>>(
+        k_predict_merge<<<ann_blocks(c->n, 256 * PM_U), 256, 0, c->stream>>>(
             c->n, d_model, first_iteration, is_metric, c->ij.as<int2>(), c->Dt.as<double>(), c->nx, c->anchorRank.as<int32_t>(),
             c->lb.as<double>(), c->ub.as<double>(), c->dad.as<double>(), c->anc.as<uint8_t>(), c->ncm.as<uint8_t>(),
             c->RA.as<double>(), c->label.as<uint8_t>(), c->n >= ANN_STREAM_MIN_PAIRS);

@@ -615,7 +615,10 @@ __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict_
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     double *le = reinterpret_cast<double *>(dyn);
     __shared__ int64_t lptr[257];
+    __shared__ EcdfIndex lix[256];   // (the labels' bucket indices: three gathers per pair less for the vector memory pipeline)
     for (int t = threadIdx.x; t <= nlabels; t += blockDim.x) lptr[t] = errptr[t];
+    if (index)
+        for (int t = threadIdx.x; t < nlabels; t += blockDim.x) lix[t] = index[t];
     __syncthreads();
     // (the lists' total length is only known on the device when they were fitted there: annchor_fit_errors_device)
     const bool errs_in_lds = lptr[nlabels] <= (int64_t)lds_cap_entries;
@@ -659,7 +662,7 @@ __global__ __launch_bounds__(256) void k_prob(int64_t n, const int2 *__restrict_
             lo[e] = b[e];
             hi[e] = search ? (int32_t)lptr[lbv[e] + 1] : 0;
             if (index && lo[e] < hi[e]) {   // bucket index: the answer lies inside one bucket
-                const EcdfIndex ix = index[lbv[e]];
+                const EcdfIndex ix = lix[lbv[e]];
                 const int k = ecdf_bucket(ix, pv[e]);
                 const uint32_t t0 = table[ix.toff + k], t1 = table[ix.toff + k + 1];
                 hi[e] = b[e] + (int32_t)t1;
