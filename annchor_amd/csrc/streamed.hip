@@ -1179,20 +1179,70 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
 #define JN_THREADS 1024  // threads of k_st_join_cands: its time is bitonic stages (~340 per row tile) -- 16 waves make a stage a quarter as long as 4 did
 #define ANNCHOR_JOIN_YIELD 0.01   // extra join passes run while a pass still replaces more than this share of the list entries
 
-// ascending bitonic sort of P (a power of two) uint32 keys in LDS by the workgroup
+// ascending bitonic sort of P (a power of two, JN_THREADS <= P <= 8 JN_THREADS) uint32 keys in LDS by the workgroup.
+// Thread t keeps elements [t E, t E + E) in registers (E = P / JN_THREADS): compare-exchange distances below E stay inside the
+// thread, distances below 64 E inside the wave (one shuffle per element), and only the longer ones go through LDS with a
+// barrier on either side -- 10 of the 91 stages at P = 8192.  (Every stage through LDS with a barrier behind it made the two
+// sorts two thirds of k_st_join_cands' time.)  The network is the same, so is the result.
+template <int E> __device__ __forceinline__ void jn_sort_reg(uint32_t *v)
+{
+    constexpr int P = E * JN_THREADS;
+    const int t = threadIdx.x;
+    uint32_t r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) r[e] = v[t * E + e];
+    for (int k2 = 2; k2 <= P; k2 <<= 1) {
+        int j2 = k2 >> 1;
+        for (; j2 >= 64 * E; j2 >>= 1) {
+            __syncthreads();   // (the previous stage's readers are done with the array)
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[t * E + e] = r[e];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = t * E + e;
+                const uint32_t o = v[i ^ j2];
+                const bool keep_min = ((i & k2) == 0) == ((i & j2) == 0);
+                r[e] = keep_min ? min(r[e], o) : max(r[e], o);
+            }
+        }
+        for (; j2 >= E; j2 >>= 1) {
+            const int lx = j2 / E;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = t * E + e;
+                const uint32_t o = __shfl_xor(r[e], lx);
+                const bool keep_min = ((i & k2) == 0) == ((i & j2) == 0);
+                r[e] = keep_min ? min(r[e], o) : max(r[e], o);
+            }
+        }
+#pragma unroll
+        for (int jj = E / 2; jj > 0; jj >>= 1) {
+            if (jj <= j2) {   // (uniform: the stages of this k2 that are left)
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if ((e & jj) == 0) {
+                        const bool up = (((t * E + e) & k2) == 0);
+                        const uint32_t a = r[e], b = r[e | jj];
+                        r[e] = up ? min(a, b) : max(a, b);
+                        r[e | jj] = up ? max(a, b) : min(a, b);
+                    }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[t * E + e] = r[e];
+    __syncthreads();
+}
 __device__ __forceinline__ void jn_sort(uint32_t *v, int P)
 {
-    for (int k2 = 2; k2 <= P; k2 <<= 1)
-        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            for (int t = threadIdx.x; t < (P >> 1); t += JN_THREADS) {
-                const int q = ((t & ~(j2 - 1)) << 1) | (t & (j2 - 1));   // element with bit j2 clear
-                const int p2 = q | j2;
-                const uint32_t x = v[q], y = v[p2];
-                const bool up = (q & k2) == 0;
-                if ((x > y) == up) { v[q] = y; v[p2] = x; }
-            }
-            __syncthreads();
-        }
+    switch (P / JN_THREADS) {
+    case 1: jn_sort_reg<1>(v); break;
+    case 2: jn_sort_reg<2>(v); break;
+    case 4: jn_sort_reg<4>(v); break;
+    default: jn_sort_reg<8>(v); break;
+    }
 }
 
 // in-place compaction of the distinct keys != 0xffffffff of a sorted array; returns their number
@@ -1308,14 +1358,40 @@ __global__ void k_st_rev_select(const int64_t *__restrict__ ptr, const unsigned 
     for (int r = 0; r < JN_RK; ++r) rev[c * JN_RK + r] = best[r] == ~0ull ? 0x7fffffff : (int32_t)(best[r] & 0xffffffffull);
 }
 
+// -DJN_PROFILE: cycle sums of k_st_join_cands' phases (first-hop gather, sort, unique, second hop, sort, unique, selection, output), printed per launch
+static unsigned long long *jn_prof_buffer(annchor_ctx *c)
+{
+#ifdef JN_PROFILE
+    static unsigned long long *buf = nullptr;
+    if (!buf) { (void)hipMalloc(&buf, 64); (void)hipMemset(buf, 0, 64); }
+    else {
+        unsigned long long h[8];
+        (void)hipMemcpy(h, buf, 64, hipMemcpyDeviceToHost);
+        double tot = 0; for (int i = 0; i < 8; ++i) tot += (double)h[i];
+        fprintf(stderr, "[jn-prof]"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %5.1f%%", 100.0 * (double)h[i] / tot); fprintf(stderr, "  (Mcycles %.1f)\n", tot / 1e6);
+        (void)hipMemset(buf, 0, 64);
+    }
+    return buf;
+#else
+    (void)c;
+    return nullptr;
+#endif
+}
+
 // Candidate columns of one row tile: first hop = the current neighbours and reverse neighbours of
 // its 128 rows; second hop = their neighbours and reverse neighbours (and the first hop itself),
 // minus everything inside column tiles this row tile has already evaluated; sorted, distinct.
 __global__ __launch_bounds__(JN_THREADS) void k_st_join_cands(const int32_t *__restrict__ lists_all, const int32_t *__restrict__ rev,
                                                              int K, int tile_begin, const uint32_t *__restrict__ eval_bits,
                                                              int eval_words, int max_cols, uint32_t *__restrict__ ucand,
-                                                             int32_t *__restrict__ ucount)
+                                                             int32_t *__restrict__ ucount, unsigned long long *__restrict__ jprof)
 {
+#ifdef JN_PROFILE
+    long long jt = clock64();
+#define JP(i) { __syncthreads(); const long long n_ = clock64(); if (threadIdx.x == 0 && jprof) atomicAdd(jprof + i, (unsigned long long)(n_ - jt)); jt = n_; }
+#else
+#define JP(i)
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char jsm[];
     uint32_t *buf = reinterpret_cast<uint32_t *>(jsm);   // [JN_CAP]
     uint32_t *b1 = buf + JN_CAP;                         // [JN_B1]
@@ -1337,8 +1413,11 @@ __global__ __launch_bounds__(JN_THREADS) void k_st_join_cands(const int32_t *__r
         b1[t] = id == 0x7fffffff ? 0xffffffffu : (uint32_t)id;
     }
     __syncthreads();
+    JP(0)
     jn_sort(b1, P0);
+    JP(1)
     int n1 = jn_unique<JN_B1 / JN_THREADS>(b1, P0, wsum);
+    JP(2)
     // ---- second hop, filtered, appended in any order (sorted below)
     const uint32_t *eb = eval_bits + (size_t)bt * eval_words;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1388,13 +1467,16 @@ __global__ __launch_bounds__(JN_THREADS) void k_st_join_cands(const int32_t *__r
         n1 = JN_CAP / (KK + 1);   // overflow (which entries an atomic append drops is arbitrary): keep a prefix that always fits
         __syncthreads();
     }
+    JP(3)
     const int ns = min(nsurv_s, JN_CAP);
     int P = JN_THREADS;
     while (P < ns) P <<= 1;
     for (int t = ns + threadIdx.x; t < P; t += JN_THREADS) buf[t] = 0xffffffffu;
     __syncthreads();
     jn_sort(buf, P);
+    JP(4)
     int nu = jn_unique<JN_CAP / JN_THREADS>(buf, P, wsum, b1);   // b1 (free by now) receives the multiplicities
+    JP(5)
     if (nu > max_cols) {
         // More candidates than this pass may evaluate: keep the max_cols reached over the most
         // two-hop paths from the tile's rows (the tile analogue of ranking pairs by their
@@ -1436,10 +1518,13 @@ __global__ __launch_bounds__(JN_THREADS) void k_st_join_cands(const int32_t *__r
         jn_sort(buf, P2);   // back to index order (row gathers of neighbouring indices share pages)
         nu = max_cols;
     }
+    JP(6)
     const int padded = (nu + ST_T - 1) / ST_T * ST_T;
     uint32_t *dst = ucand + (size_t)bt * JN_CAP;
     for (int t = threadIdx.x; t < padded; t += JN_THREADS) dst[t] = t < nu ? buf[t] : 0xffffffffu;
     if (threadIdx.x == 0) ucount[bt] = nu;
+    JP(7)
+#undef JP
 }
 
 template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 128 ? 2 : 1)) void k_st_join(KnnArgs a)
@@ -1899,7 +1984,7 @@ static int knn_join_pass(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pad
         const int max_cols = std::max(1, std::min(per_pass * ST_T, JN_CAP));
         k_st_join_cands<<<a.tile_count, JN_THREADS, lds, c->stream>>>(lists_all, s->rev_all.as<int32_t>(), K, a.tile_begin, a.eval_bits,
                                                                       a.eval_words, max_cols, s->ucand.as<uint32_t>(),
-                                                                      s->ucount.as<int32_t>());
+                                                                      s->ucount.as<int32_t>(), jn_prof_buffer(c));
     }
     a.updates = s->evals.as<unsigned long long>() + 1;
     ANN_CHECK_HIP(c, hipMemsetAsync(a.updates, 0, 8, c->stream));
