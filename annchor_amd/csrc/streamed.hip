@@ -1178,6 +1178,13 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
 #define JN_RK 15         // reverse neighbours kept per point (the closest by list position)
 #define JN_THREADS 1024  // threads of k_st_join_cands: its time is bitonic stages (~340 per row tile) -- 16 waves make a stage a quarter as long as 4 did
 #define ANNCHOR_JOIN_YIELD 0.01   // extra join passes run while a pass still replaces more than this share of the list entries
+// The tile phase's early stop: a row tile stops when a window of ST_EARLY_WINDOW ranked tiles replaced fewer than this share of its
+// 128 x K list entries.  1 % until the join passes' overflow handling was repaired (round 5: recall at C3 0.99715 -> 0.99852, at
+// C5 0.9943 -> 0.9954 at the same cost); 1.25 % spends part of that -- tile phase -5 % (C3) / -8 % (C5) at recall 0.9984 / 0.9946,
+// no lower than before the repair at either size.  (C3, 10 000 rows against the tile kernel's own truth, and C5, 1000 rows against
+// float64: 1 % 0.99852 / 0.9954, 1.5 % 0.99826 / 0.99353, 2 % 0.99787 / 0.99193, 3 % 0.99659 / 0.98573; ANNCHOR_ST_EARLY_TAU sets
+// the count directly.)
+#define ANNCHOR_TILE_YIELD 0.0125
 
 // ascending bitonic sort of P (a power of two, JN_THREADS <= P <= 8 JN_THREADS) uint32 keys in LDS by the workgroup.
 // Thread t keeps elements [t E, t E + E) in registers (E = P / JN_THREADS): compare-exchange distances below E stay inside the
@@ -1363,13 +1370,14 @@ static unsigned long long *jn_prof_buffer(annchor_ctx *c)
 {
 #ifdef JN_PROFILE
     static unsigned long long *buf = nullptr;
-    if (!buf) { (void)hipMalloc(&buf, 64); (void)hipMemset(buf, 0, 64); }
+    if (!buf) { (void)hipMalloc(&buf, 128); (void)hipMemset(buf, 0, 128); }
     else {
-        unsigned long long h[8];
-        (void)hipMemcpy(h, buf, 64, hipMemcpyDeviceToHost);
+        unsigned long long h[16];
+        (void)hipMemcpy(h, buf, 128, hipMemcpyDeviceToHost);
         double tot = 0; for (int i = 0; i < 8; ++i) tot += (double)h[i];
         fprintf(stderr, "[jn-prof]"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %5.1f%%", 100.0 * (double)h[i] / tot); fprintf(stderr, "  (Mcycles %.1f)\n", tot / 1e6);
-        (void)hipMemset(buf, 0, 64);
+        if (h[11]) fprintf(stderr, "[jn-prof] row tiles %llu, overflowing %llu, mean first-hop ids %.0f, mean survivors of the full second hop %.0f\n", h[11], h[8], (double)h[9] / (double)h[11], (double)h[10] / (double)h[11]);
+        (void)hipMemset(buf, 0, 128);
     }
     return buf;
 #else
@@ -1403,13 +1411,19 @@ __global__ __launch_bounds__(JN_THREADS) void k_st_join_cands(const int32_t *__r
     auto base_of = [&](uint32_t c, int e) -> int32_t {
         return e < K ? lists_all[(size_t)c * K + e] : rev[(size_t)c * JN_RK + (e - K)];
     };
-    // ---- first hop
-    const int n0 = ST_T * KK;
+    // ---- first hop: at most JN_B1 / 128 = 64 entries per row -- the reverse neighbours and the closest K0 list entries (beyond
+    // n_neighbors = 50 the lists are longer than that; before the cap their first hop overran b1 and what the hardware drops
+    // from an out-of-range LDS write was silently missing from the candidates)
+    const int K0 = min(K, JN_B1 / ST_T - (rev ? JN_RK : 0)), KK0 = K0 + (rev ? JN_RK : 0);
+    const int n0 = ST_T * KK0;
     int P0 = JN_THREADS;
     while (P0 < n0) P0 <<= 1;
     for (int t = threadIdx.x; t < P0; t += JN_THREADS) {
         int32_t id = 0x7fffffff;
-        if (t < n0) id = base_of((uint32_t)(grow0 + t / KK), t % KK);
+        if (t < n0) {
+            const int r = t / KK0, e = t % KK0;
+            id = base_of((uint32_t)(grow0 + r), e < K0 ? e : K + (e - K0));
+        }
         b1[t] = id == 0x7fffffff ? 0xffffffffu : (uint32_t)id;
     }
     __syncthreads();
@@ -1423,12 +1437,16 @@ __global__ __launch_bounds__(JN_THREADS) void k_st_join_cands(const int32_t *__r
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (threadIdx.x == 0) nsurv_s = 0;
         __syncthreads();
-        const int n2 = n1 * (KK + 1);
+        // (second attempt, after an overflow: every first-hop id still takes part, with itself and only its closest W2 - 1 list
+        // entries -- n1 W2 <= JN_CAP fits whatever the filter lets through.  The first form kept a PREFIX of the sorted first-hop
+        // ids: at n_neighbors = 62 the join passes then found nothing the tile phase had not)
+        const int W2 = attempt == 0 ? KK + 1 : max(1, min(JN_CAP / max(n1, 1), K + 1));
+        const int n2 = n1 * W2;
         // Eight entries per thread and step, their two dependent global reads (the neighbour's list entry, then the evaluated-tile
         // word of its tile) issued as batches: with one entry per step every iteration waited out both round trips alone (two waves
         // per SIMD: nothing to hide them behind) -- 5.5 ms per pass at C3, most of it this loop.  Survivors are appended with one
         // LDS atomic per wave and step (the order of the list is arbitrary; it is sorted below).
-        const float inv_kk1 = 1.0f / (float)(KK + 1);
+        const float inv_kk1 = 1.0f / (float)W2;
         const int lane_j = threadIdx.x & 63;
         for (int t0 = threadIdx.x; t0 - (int)threadIdx.x < n2; t0 += JN_THREADS * 8) {
             int32_t id[8];
@@ -1436,10 +1454,12 @@ __global__ __launch_bounds__(JN_THREADS) void k_st_join_cands(const int32_t *__r
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int t = min(t0 + u * JN_THREADS, n2 - 1);
-                const int q = (int)(((float)t + 0.5f) * inv_kk1);      // t / (KK + 1), exact for t < 2^22
-                const int e = t - q * (KK + 1);
+                const int q = (int)(((float)t + 0.5f) * inv_kk1);      // t / W2, exact for t < 2^22
+                const int e = t - q * W2;
                 const uint32_t c = b1[q];
-                const int32_t *src = e < K ? lists_all + (size_t)c * K + e : (rev && e < KK ? rev + (size_t)c * JN_RK + (e - K) : nullptr);
+                const int32_t *src;
+                if (attempt == 0) src = e < K ? lists_all + (size_t)c * K + e : (rev && e < KK ? rev + (size_t)c * JN_RK + (e - K) : nullptr);
+                else src = e < W2 - 1 ? lists_all + (size_t)c * K + e : nullptr;
                 id[u] = src ? *src : (int32_t)c;
             }
 #pragma unroll
@@ -1463,8 +1483,14 @@ __global__ __launch_bounds__(JN_THREADS) void k_st_join_cands(const int32_t *__r
             }
         }
         __syncthreads();
+#ifdef JN_PROFILE
+        if (threadIdx.x == 0 && jprof && attempt == 0) {
+            atomicAdd(jprof + 11, 1ull); atomicAdd(jprof + 9, (unsigned long long)n1); atomicAdd(jprof + 10, (unsigned long long)nsurv_s);
+            if (nsurv_s > JN_CAP) atomicAdd(jprof + 8, 1ull);
+        }
+#endif
         if (nsurv_s <= JN_CAP) break;
-        n1 = JN_CAP / (KK + 1);   // overflow (which entries an atomic append drops is arbitrary): keep a prefix that always fits
+        // overflow (which entries an atomic append drops is arbitrary): once more, narrower (above)
         __syncthreads();
     }
     JP(3)
@@ -1844,12 +1870,12 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
     a.updates = nullptr;
     {
         // A row tile stops spending its tile budget when ST_EARLY_WINDOW consecutive ranked tiles replaced fewer
-        // than ANNCHOR_JOIN_YIELD (1 %) of its 128 x K list entries -- the same yield rule that ends the join
+        // than ANNCHOR_TILE_YIELD of its 128 x K list entries -- the yield rule that ends the join
         // passes.  Only builds followed by join passes stop early (the passes pick up what the tail of the
         // ranking would have found: C3 0.292 -> ~0.25 s at recall 0.9989 -> ~0.9985); the budget stays an upper bound.
         const char *ew = getenv("ANNCHOR_ST_EARLY_WINDOW"), *et = getenv("ANNCHOR_ST_EARLY_TAU");
         a.early_window = record_tiles ? (ew ? atoi(ew) : ST_EARLY_WINDOW) : 0;
-        a.early_tau = et ? atoi(et) : std::max(1, (int)std::lround(ANNCHOR_JOIN_YIELD * ST_T * a.K));
+        a.early_tau = et ? atoi(et) : std::max(1, (int)std::lround(ANNCHOR_TILE_YIELD * ST_T * a.K));
     }
     a.prof = nullptr;
 #ifdef ST_PROFILE

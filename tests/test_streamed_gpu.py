@@ -124,6 +124,24 @@ def test_budgeted_with_joins_more_than_33_neighbours():
         StreamedAnnchor(X[:2000], n_anchors=4, n_neighbors=70, p_work=1.0).fit()   # > 65: refused loudly
 
 
+def test_budgeted_with_joins_at_62_neighbours():
+    """n_neighbors = 62: the lists (61 entries + 15 reverse neighbours per row) are longer than the 64 first-hop entries per row
+    the join's candidate kernel holds -- it takes the reverse neighbours and the closest 49 (before the cap the first hop overran its
+    buffer and the candidates were an arbitrary subset).  The joins must help, and the pass must be deterministic."""
+    from annchor_amd.streamed import StreamedAnnchor
+
+    n, k = 40000, 62
+    X = latent(n, 64)
+    sa = StreamedAnnchor(X, n_anchors=16, n_neighbors=k, p_work=0.3).fit()
+    rows = np.random.default_rng(6).choice(n, 600, replace=False)
+    err, _ = _recall_rows(sa, X, rows, k)
+    sa0 = StreamedAnnchor(X, n_anchors=16, n_neighbors=k, p_work=0.3, join_passes=0, join_extra=0).fit()
+    err0, _ = _recall_rows(sa0, X, rows, k)
+    assert err < err0 and err <= 0.10 * len(rows) * k, (err, err0)
+    sb = StreamedAnnchor(X, n_anchors=16, n_neighbors=k, p_work=0.3).fit()
+    assert np.array_equal(sa.neighbor_graph[0], sb.neighbor_graph[0])
+
+
 def test_anchors_follow_the_reference_picker():
     from annchor_amd.streamed import StreamedAnnchor
     from oracle import annchor_oracle as O
