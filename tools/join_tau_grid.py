@@ -1,0 +1,52 @@
+"""C3-size grid over (join passes, early-stop count of the tile phase): fit time, kernel times, recall on 10 000 rows against the
+tile kernel's own full-budget truth.  One child process per cell (the early-stop count is read once per process).
+
+  python tools/join_tau_grid.py [n] [passes,passes,...] [tau,tau,...]
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def child(n, passes):
+    import numpy as np
+
+    from annchor_amd import compare_neighbor_graphs
+    from annchor_amd.streamed import StreamedAnnchor
+    from bench import euclid_shard
+
+    X = euclid_shard(0, n)
+    k = 15
+    best = None
+    for rep in range(3):
+        sa = StreamedAnnchor(X, n_anchors=32, n_neighbors=k, p_work=0.1, join_passes=passes)
+        sa._engine.prof_enable(True)
+        t = time.perf_counter(); sa.fit(); dt = time.perf_counter() - t
+        prof = {a: round(v["ms"], 1) for a, v in sa._engine.prof_get().items() if v["ms"] > 1.0}
+        if best is None or dt < best[0]:
+            best = (dt, prof)
+        if rep < 2:
+            sa._engine.close()
+    rows = np.sort(np.random.default_rng(99).choice(n, 10000, replace=False))
+    ti, td = sa.query(X[rows], nn=k, p_work=1.0)
+    err = compare_neighbor_graphs((ti, td), (sa.neighbor_graph[0][rows], sa.neighbor_graph[1][rows]), k)
+    print(json.dumps(dict(passes=passes, tau=os.environ.get("ANNCHOR_ST_EARLY_TAU"), fit_s=round(best[0], 4), recall=round(1 - err / (10000.0 * k), 5),
+                          tile=best[1].get("stream_tile_gemm_topk"), cands=best[1].get("stream_join_candidates"), join=best[1].get("stream_join_gemm_topk"))), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        child(int(sys.argv[2]), int(sys.argv[3]))
+    else:
+        n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+        passes = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["2", "3"])]
+        taus = sys.argv[3].split(",") if len(sys.argv) > 3 else ["22", "36", "54"]
+        for p in passes:
+            for tau in taus:
+                env = dict(os.environ, ANNCHOR_ST_EARLY_TAU=tau)
+                subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n), str(p)], env=env, check=False)
