@@ -1759,7 +1759,8 @@ extern "C" int annchor_stream_budget(int32_t n_tiles, double p_work, int32_t joi
     const double mt = p_work >= 1.0 ? (double)n_tiles : std::ceil(p_work * (double)n_tiles);
     const int T = (int)std::max(1.0, std::min(mt, (double)n_tiles));
     static const int div_ = getenv("ANNCHOR_JOIN_DIV") ? atoi(getenv("ANNCHOR_JOIN_DIV")) : 8;
-    int pp = std::min(24, std::max(1, T / div_));
+    static const int pp_max = getenv("ANNCHOR_JOIN_PP_MAX") ? atoi(getenv("ANNCHOR_JOIN_PP_MAX")) : 24;   // runs of 128 gathered columns per pass and row tile
+    int pp = std::min(pp_max, std::max(1, T / div_));
     if (join_passes == 0) pp = 0;
     int tp = T - pp * join_passes;
     if (tp < 1) tp = 1;

@@ -49,4 +49,5 @@ if __name__ == "__main__":
         for p in passes:
             for tau in taus:
                 env = dict(os.environ, ANNCHOR_ST_EARLY_TAU=tau)
+                print("JOIN_PP_MAX", env.get("ANNCHOR_JOIN_PP_MAX"), flush=True)
                 subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n), str(p)], env=env, check=False)
