@@ -129,7 +129,22 @@ template <int KMAX, bool JOIN = false> __global__ __launch_bounds__(STBK_THREADS
     const float *xrow = a.Rs + (size_t)(grow0 + rowbase + col) * dimr + 8 * half;
     // block kb of the wave's rows -> operand registers (hi / lo halves of the centred, scaled values); returns the lane's share
     // of the block's squared norm
+    // Data rows are columns too: their split operands already sit in the column copy (a.Xb: [row][hi: dimr halves | lo: dimr
+    // halves]) -- two 16-byte loads per k-step instead of eight floats, a subtraction, a scaling and two conversions per value, for
+    // every block of every tile (the conversions were a third of the kernel at d = 768).  Query rows (another context's, maybe
+    // outside the data's range) are converted here as before.
+    const bool rows_split = !a.query && a.Rs == a.Xs;   // (uniform)
+    const char *xbrow = reinterpret_cast<const char *>(a.Xb) + (size_t)(grow0 + rowbase + col) * dimr * 4 + 16 * half;
     auto load_rows = [&](int kb) __attribute__((always_inline)) -> float {
+        if (rows_split) {
+            const char *hp = xbrow + (size_t)kb * (DIM * 2);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                ah[g] = *reinterpret_cast<const f16x8 *>(hp + 32 * g);
+                al[g] = *reinterpret_cast<const f16x8 *>(hp + (size_t)dimr * 2 + 32 * g);
+            }
+            return 0.f;
+        }
         const float *xr = xrow + kb * DIM;
         const float *cv = a.cvec + kb * DIM + 8 * half;
         float acc2 = 0.f;
@@ -156,6 +171,7 @@ template <int KMAX, bool JOIN = false> __global__ __launch_bounds__(STBK_THREADS
         float acc2 = 0.f;
         for (int kb = 0; kb < nkb; ++kb) acc2 += load_rows(kb);
         rr_c = acc2 + __shfl_xor(acc2, 32);
+        if (rows_split) rr_c = a.rsb[grow0 + rowbase + col];   // (the split pass's own sum: a row's norm as a row = its norm as a column)
     }
     if (threadIdx.x < ST_T) {
         const int row = threadIdx.x;
