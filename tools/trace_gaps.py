@@ -24,12 +24,10 @@ def main():
     if not ops:
         print("no ops")
         return
-    # the last fit: from the last k_st_anchor-like burst; simply take ops after the largest gap (the constructor's upload)
-    t_end = ops[-1][1]
-    # walk back to the last COPY of > 1 GB-ish duration (the upload of X): the fit starts after it
+    # the last fit: what follows the last host-to-device copy of more than 2 ms (the constructor's upload of the rows)
     start_i = 0
-    for i, (s, e, n) in enumerate(ops):
-        if n.startswith("COPY") and e - s > 30e6 and "HOST_TO_DEVICE" in n.upper().replace(" ", "_"):
+    for i, (s_, e_, n_) in enumerate(ops):
+        if n_.startswith("COPY") and "HOST_TO_DEVICE" in n_ and e_ - s_ > 2e6:
             start_i = i + 1
     ops = ops[start_i:]
     print("ops in the last fit:", len(ops), "span ms:", (ops[-1][1] - ops[0][0]) / 1e6)
