@@ -8,6 +8,7 @@
 #define ST_THREADS 256
 #define ST_KMAX 32
 #define ST_KMAX_BIG 64
+#define ST_KMAX_HUGE 128   // exact-f32 kernels only (dims <= 256): two workgroups per row tile, each keeping the lists of 64 rows
 #define ST_SURV 1024
 #define ST_KEEP 512
 #define ST_EARLY_WINDOW 64   // tiles per yield window of the tile phase (knn_tile_phase)

@@ -648,14 +648,23 @@ extern "C" int annchor_stream_order(annchor_ctx *c, int32_t min_tiles, void **Xs
 
 // ------------------------------------------------------------------ k-NN
 
+// Lists of more than 64 entries (n_neighbors 66 .. 128): 128 rows x 129 entries x 8 bytes do not fit beside the operand buffers, so
+// a row tile is taken by TWO workgroups, each with the lists of 64 of its rows (the other 64 rows never accept a candidate: their
+// thresholds are -1, like padding rows); both stream and multiply everything -- half the throughput, for list lengths the
+// reference takes (n_neighbors is unbounded there: annchor.py:136) and the split-fp16 kernels do not.
+template <int KMAX> struct KnnHalf {
+    static constexpr bool ON = KMAX > ST_KMAX_BIG;
+    static constexpr int LROWS = ON ? ST_T / 2 : ST_T;
+    __device__ static __forceinline__ int lr(int row) { return ON ? (row & (ST_T / 2 - 1)) : row; }   // list slot of a row
+};
 template <int DIM, int KMAX> struct KnnShared {
     float Bs[ST_SLAB][DIM + 1];
     float rsJ[ST_SLAB];
     // (row strides that are not multiples of the 32 banks: lanes own different rows and touch the same slot)
     float cand_d[ST_T][ST_SLAB + 1];
     uint8_t cand_c[ST_T][ST_SLAB + 4];   // column inside the slab
-    float list_d[ST_T][KMAX + 1];
-    int32_t list_c[ST_T][KMAX + 1];
+    float list_d[KnnHalf<KMAX>::LROWS][KMAX + 1];
+    int32_t list_c[KnnHalf<KMAX>::LROWS][KMAX + 1];
     float thr[ST_T];
     int cnt[ST_T];
     float loI[64], hiI[64], midI[64];
@@ -758,6 +767,7 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
         wave_fence_lds();
         if (lane < 32) {
             const int row = rowbase_wave + lane;
+            const int lr = KnnHalf<KMAX>::lr(row);   // (rows without lists -- the other workgroup's half -- never have candidates)
             const int nc = sh.cnt[row];
             if (nc) {
                 for (int q = 0; q < nc; ++q) {
@@ -767,26 +777,26 @@ __device__ __forceinline__ float knn_process_tile(KnnShared<DIM, KMAX> &sh, cons
                         // gathered columns: the point itself and columns the row already lists may come by
                         cc = (int32_t)sh.slab_id[par][sh.cand_c[row][q]];
                         bool skip = (int64_t)cc == grow0 + row;
-                        for (int e = 0; e < K && !skip; ++e) skip = sh.list_c[row][e] == cc;
+                        for (int e = 0; e < K && !skip; ++e) skip = sh.list_c[lr][e] == cc;
                         if (skip) continue;
                     } else {
                         cc = (int32_t)(col0 + sh.cand_c[row][q]);
                     }
                     // insertion by (d, col); list is padded with +inf
-                    if (d < sh.list_d[row][K - 1] || (d == sh.list_d[row][K - 1] && cc < sh.list_c[row][K - 1])) {
+                    if (d < sh.list_d[lr][K - 1] || (d == sh.list_d[lr][K - 1] && cc < sh.list_c[lr][K - 1])) {
                         ++st.ins;   // (the yield of the tile / pass: early stop of the tile phase, extra join passes)
                         int p = K - 1;
-                        while (p > 0 && (d < sh.list_d[row][p - 1] || (d == sh.list_d[row][p - 1] && cc < sh.list_c[row][p - 1]))) {
-                            sh.list_d[row][p] = sh.list_d[row][p - 1];
-                            sh.list_c[row][p] = sh.list_c[row][p - 1];
+                        while (p > 0 && (d < sh.list_d[lr][p - 1] || (d == sh.list_d[lr][p - 1] && cc < sh.list_c[lr][p - 1]))) {
+                            sh.list_d[lr][p] = sh.list_d[lr][p - 1];
+                            sh.list_c[lr][p] = sh.list_c[lr][p - 1];
                             --p;
                         }
-                        sh.list_d[row][p] = d;
-                        sh.list_c[row][p] = cc;
+                        sh.list_d[lr][p] = d;
+                        sh.list_c[lr][p] = cc;
                     }
                 }
                 sh.cnt[row] = 0;
-                sh.thr[row] = sh.list_d[row][K - 1];
+                sh.thr[row] = sh.list_d[lr][K - 1];
             }
         }
         wave_fence_lds();
@@ -935,9 +945,13 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
     // XCD-banded row-tile assignment (block b runs on XCD b % 8): the workgroups resident on
     // one XCD own consecutive row tiles of the k-d order, whose column-tile lists overlap, so
     // the streamed column tiles are shared through that XCD's L2
+    using Half = KnnHalf<KMAX>;
+    const int hsel = Half::ON ? (int)(blockIdx.x & 1) : 0;            // which 64 rows' lists this workgroup keeps (lists beyond 64 entries)
+    const int bid = Half::ON ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    auto own = [&](int row) { return !Half::ON || (row >> 6) == hsel; };
     int bt;
     {
-        const int nb_ = gridDim.x, q = nb_ >> 3, r = nb_ & 7, x = blockIdx.x & 7, y = blockIdx.x >> 3;
+        const int nb_ = Half::ON ? (int)(gridDim.x >> 1) : (int)gridDim.x, q = nb_ >> 3, r = nb_ & 7, x = bid & 7, y = bid >> 3;
         bt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
     }
     const int I = a.tile_begin + bt;
@@ -956,9 +970,10 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
     if (threadIdx.x < ST_T) {
         const int row = threadIdx.x;
         const bool real = a.rr[grow0 + row] < INFINITY;
-        sh.thr[row] = real ? INFINITY : -1.f;  // padding rows never accept candidates
+        sh.thr[row] = real && own(row) ? INFINITY : -1.f;  // padding rows (and the other workgroup's half) never accept candidates
         sh.cnt[row] = 0;
-        for (int q = 0; q < KMAX; ++q) { sh.list_d[row][q] = INFINITY; sh.list_c[row][q] = 0x7fffffff; }
+        if (own(row))
+            for (int q = 0; q < KMAX; ++q) { sh.list_d[Half::lr(row)][q] = INFINITY; sh.list_c[Half::lr(row)][q] = 0x7fffffff; }
     }
     if ((int)threadIdx.x < a.na) {
         sh.loI[threadIdx.x] = a.rlo[(size_t)threadIdx.x * a.nt_r + I];
@@ -989,7 +1004,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
     // column tiles this row tile has evaluated (a join pass skips candidates inside them): this
     // workgroup is the only writer of its bitmap row
     uint32_t *ebits = a.eval_bits ? a.eval_bits + (size_t)bt * a.eval_words : nullptr;
-    if (ebits && !a.query && threadIdx.x == 0) ebits[I >> 5] |= 1u << (I & 31);
+    if (ebits && !a.query && threadIdx.x == 0) atomicOr(&ebits[I >> 5], 1u << (I & 31));   // (two writers when the lists are split)
 
     // ---- phase B: all other column tiles.  A tile is ELIGIBLE while its interval bound lb
     // (a valid lower bound of every pair distance) is below the worst k-th distance of the
@@ -1128,12 +1143,12 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
 #endif
                 thrmax = knn_process_tile<DIM, KMAX>(sh, a, J, Jn, st, areg, ri, wave * 32, grow0, K, pf_ptr);
                 ++processed;
-                if (ebits && threadIdx.x == 0) ebits[J >> 5] |= 1u << (J & 31);
+                if (ebits && threadIdx.x == 0) atomicOr(&ebits[J >> 5], 1u << (J & 31));
                 if (a.early_window > 0 && processed - win_start >= a.early_window) {
                     // the ranked tiles have stopped improving the lists: the rest of the budget would buy (almost)
                     // nothing that the join passes do not find for a fraction of the cost
                     const int cur = sh.wave_ins[0] + sh.wave_ins[1] + sh.wave_ins[2] + sh.wave_ins[3];
-                    if (cur - win_ins < a.early_tau) { dried = true; break; }
+                    if (cur - win_ins < (Half::ON ? (a.early_tau + 1) / 2 : a.early_tau)) { dried = true; break; }   // (the yield of 64 rows)
                     win_start = processed; win_ins = cur;
                 }
 #ifdef ST_PROFILE
@@ -1152,8 +1167,9 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
     // ---- write the lists
     for (int q = threadIdx.x; q < ST_T * K; q += ST_THREADS) {
         const int row = q / K, e = q - row * K;
-        a.out_d2[((size_t)bt * ST_T + row) * K + e] = sh.list_d[row][e];
-        a.out_col[((size_t)bt * ST_T + row) * K + e] = sh.list_c[row][e];
+        if (!own(row)) continue;
+        a.out_d2[((size_t)bt * ST_T + row) * K + e] = sh.list_d[Half::lr(row)][e];
+        a.out_col[((size_t)bt * ST_T + row) * K + e] = sh.list_c[Half::lr(row)][e];
     }
     if (threadIdx.x == 0) atomicAdd(a.evals, (unsigned long long)processed);
 #ifdef ST_PROFILE
@@ -1558,9 +1574,13 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KnnShared<DIM, KMAX> &sh = *reinterpret_cast<KnnShared<DIM, KMAX> *>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    using Half = KnnHalf<KMAX>;
+    const int hsel = Half::ON ? (int)(blockIdx.x & 1) : 0;
+    const int bid = Half::ON ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    auto own = [&](int row) { return !Half::ON || (row >> 6) == hsel; };
     int bt;
     {
-        const int nb_ = gridDim.x, q = nb_ >> 3, r = nb_ & 7, x = blockIdx.x & 7, y = blockIdx.x >> 3;
+        const int nb_ = Half::ON ? (int)(gridDim.x >> 1) : (int)gridDim.x, q = nb_ >> 3, r = nb_ & 7, x = bid & 7, y = bid >> 3;
         bt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
     }
     const int I = a.tile_begin + bt;
@@ -1578,14 +1598,15 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
     // the lists as the previous phase left them
     for (int q = threadIdx.x; q < ST_T * KMAX; q += ST_THREADS) {
         const int row = q / KMAX, e = q - row * KMAX;
-        sh.list_d[row][e] = e < K ? a.out_d2[((size_t)bt * ST_T + row) * K + e] : INFINITY;
-        sh.list_c[row][e] = e < K ? a.lists_all[((size_t)grow0 + row) * K + e] : 0x7fffffff;
+        if (!own(row)) continue;
+        sh.list_d[Half::lr(row)][e] = e < K ? a.out_d2[((size_t)bt * ST_T + row) * K + e] : INFINITY;
+        sh.list_c[Half::lr(row)][e] = e < K ? a.lists_all[((size_t)grow0 + row) * K + e] : 0x7fffffff;
     }
     __syncthreads();
     if (threadIdx.x < ST_T) {
         const int row = threadIdx.x;
         const bool real = a.rr[grow0 + row] < INFINITY;
-        sh.thr[row] = real ? sh.list_d[row][K - 1] : -1.f;
+        sh.thr[row] = real && own(row) ? sh.list_d[Half::lr(row)][K - 1] : -1.f;
         sh.cnt[row] = 0;
     }
     const int nu = a.ucount[bt];
@@ -1600,8 +1621,9 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
     __syncthreads();
     for (int q = threadIdx.x; q < ST_T * K; q += ST_THREADS) {
         const int row = q / K, e = q - row * K;
-        a.out_d2_new[((size_t)bt * ST_T + row) * K + e] = sh.list_d[row][e];
-        a.out_col_new[((size_t)bt * ST_T + row) * K + e] = sh.list_c[row][e];
+        if (!own(row)) continue;
+        a.out_d2_new[((size_t)bt * ST_T + row) * K + e] = sh.list_d[Half::lr(row)][e];
+        a.out_col_new[((size_t)bt * ST_T + row) * K + e] = sh.list_c[Half::lr(row)][e];
     }
     if (threadIdx.x == 0) atomicAdd(a.evals + 2, (unsigned long long)nchunks);   // slot 2: join chunks (0: tile phase, 1: pass yield)
     int ins = st.ins;
@@ -1691,10 +1713,10 @@ template <int DIM, int KMAX> static int launch_knn2(annchor_ctx *c, const KnnArg
     ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "streamed k-NN needs %zu B of LDS", lds);
     if (join) {
         ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_join<DIM, KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_st_join<DIM, KMAX><<<a.tile_count, ST_THREADS, lds, c->stream>>>(a);
+        k_st_join<DIM, KMAX><<<a.tile_count * (KnnHalf<KMAX>::ON ? 2 : 1), ST_THREADS, lds, c->stream>>>(a);
     } else {
         ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knn<DIM, KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_st_knn<DIM, KMAX><<<a.tile_count, ST_THREADS, lds, c->stream>>>(a);
+        k_st_knn<DIM, KMAX><<<a.tile_count * (KnnHalf<KMAX>::ON ? 2 : 1), ST_THREADS, lds, c->stream>>>(a);
     }
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
@@ -1703,7 +1725,7 @@ template <int DIM, int KMAX> static int launch_knn2(annchor_ctx *c, const KnnArg
 template <int DIM> static int launch_knn(annchor_ctx *c, const KnnArgs &a, bool join)
 {
     // list capacity by n_neighbors: 16 / 32 entries per row (two workgroups per CU), 64 (the lists alone are 66 KB: one per CU)
-    return a.K <= 16 ? launch_knn2<DIM, 16>(c, a, join) : a.K <= ST_KMAX ? launch_knn2<DIM, ST_KMAX>(c, a, join) : launch_knn2<DIM, ST_KMAX_BIG>(c, a, join);
+    return a.K <= 16 ? launch_knn2<DIM, 16>(c, a, join) : a.K <= ST_KMAX ? launch_knn2<DIM, ST_KMAX>(c, a, join) : a.K <= ST_KMAX_BIG ? launch_knn2<DIM, ST_KMAX_BIG>(c, a, join) : launch_knn2<DIM, ST_KMAX_HUGE>(c, a, join);
 }
 
 static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool join, bool exact = false)
@@ -2052,6 +2074,7 @@ int ann_stream_knn_finish(annchor_ctx *c, StreamState *s, KnnArgs &a, const void
     if (tile_evals) {
         unsigned long long ev[3] = {0, 0, 0};
         ANN_TRY(ann_d2h(c, ev, s->evals.p, 24));
+        if (a.K > ST_KMAX_BIG) { ev[0] /= 2; ev[2] /= 2; }   // (two workgroups per row tile, 64 rows' lists each: both count what they stream)
         *tile_evals = (int64_t)(ev[0] + ev[2]);
         s->last_tile_evals = (int64_t)ev[0];
         s->last_join_chunks = (int64_t)ev[2];
@@ -2117,7 +2140,8 @@ static int knn_args_graph(annchor_ctx *c, KnnArgs &a, const void *Xs_all, const 
                           const void *mid_all, int64_t n_all, int32_t nt_all, int32_t n_anchors, int32_t tile_begin,
                           int32_t tile_count, int32_t k)
 {
-    ANN_REQUIRE(c, k >= 2 && k - 1 <= ST_KMAX_BIG, ANNCHOR_ELIMIT, "streamed form supports 2 <= n_neighbors <= %d", ST_KMAX_BIG + 1);
+    ANN_REQUIRE(c, k >= 2 && k - 1 < ST_KMAX_HUGE, ANNCHOR_ELIMIT, "streamed form supports 2 <= n_neighbors <= %d (beyond 256 dimensions: <= %d)", ST_KMAX_HUGE,
+                ST_KMAX_BIG - 1);
     ANN_REQUIRE(c, n_all == (int64_t)nt_all * ST_T && tile_begin >= 0 && tile_begin + tile_count <= nt_all, ANNCHOR_EINVAL,
                 "tile range out of bounds");
     ANN_REQUIRE(c, n_all < (1ll << 31), ANNCHOR_ELIMIT, "n_all exceeds 2^31");
@@ -2288,7 +2312,7 @@ extern "C" int annchor_stream_query(annchor_ctx *c, const void *Xs_all, const vo
                                     int64_t *tile_evals)
 {
     if (!c || !Xs_all || !rs_all || !perm_all || !lo_all || !hi_all || !mid_all || !out_idx || !out_dist) return ANNCHOR_EINVAL;
-    ANN_REQUIRE(c, nn >= 1 && nn <= ST_KMAX_BIG, ANNCHOR_ELIMIT, "streamed query supports 1 <= nn <= %d", ST_KMAX_BIG);
+    ANN_REQUIRE(c, nn >= 1 && nn < ST_KMAX_HUGE, ANNCHOR_ELIMIT, "streamed query supports 1 <= nn <= %d (beyond 256 dimensions: <= %d)", ST_KMAX_HUGE - 1, ST_KMAX_BIG - 2);
     ANN_REQUIRE(c, n_all == (int64_t)nt_all * ST_T && n_all < (1ll << 31), ANNCHOR_EINVAL, "column arrays out of range");
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     StreamState *s = state_of(c, false);

@@ -32,7 +32,8 @@ def brute(X, rows, k):
 
 
 @pytest.mark.parametrize("n,d,na,k", [(5000, 128, 16, 15), (3003, 20, 8, 8), (1000, 64, 4, 33), (260, 200, 5, 5),
-                                      (2500, 64, 8, 50), (1500, 128, 6, 65), (900, 256, 4, 40)])   # > 33 neighbours: 64-entry lists
+                                      (2500, 64, 8, 50), (1500, 128, 6, 65), (900, 256, 4, 40),   # > 33 neighbours: 64-entry lists
+                                      (2000, 64, 6, 66), (1500, 128, 5, 100), (1100, 20, 4, 128), (700, 256, 4, 90)])   # > 65: two workgroups per row tile
 def test_exact_when_budget_does_not_bind(n, d, na, k):
     from annchor_amd.streamed import StreamedAnnchor
 
@@ -121,7 +122,28 @@ def test_budgeted_with_joins_more_than_33_neighbours():
     err0, _ = _recall_rows(sa0, X, rows, k)
     assert err < err0 and err <= 0.08 * len(rows) * k, (err, err0)
     with pytest.raises(Exception):
-        StreamedAnnchor(X[:2000], n_anchors=4, n_neighbors=70, p_work=1.0).fit()   # > 65: refused loudly
+        StreamedAnnchor(X[:2000], n_anchors=4, n_neighbors=129, p_work=1.0).fit()   # > 128: refused loudly
+    with pytest.raises(Exception):
+        StreamedAnnchor(latent(1500, 300), n_anchors=4, n_neighbors=70, p_work=1.0).fit()   # beyond 256 dimensions: <= 63
+
+
+def test_budgeted_with_joins_at_100_neighbours():
+    """n_neighbors = 100 (lists of 99: the exact-f32 kernels with two workgroups per row tile, each keeping 64 rows' lists) with a
+    binding budget and join passes: the joins must help, the evaluation count stays within the budget, the run is deterministic."""
+    from annchor_amd.streamed import StreamedAnnchor
+
+    n, k = 30000, 100
+    X = latent(n, 64)
+    sa = StreamedAnnchor(X, n_anchors=16, n_neighbors=k, p_work=0.3).fit()
+    rows = np.random.default_rng(7).choice(n, 400, replace=False)
+    err, _ = _recall_rows(sa, X, rows, k)
+    sa0 = StreamedAnnchor(X, n_anchors=16, n_neighbors=k, p_work=0.3, join_passes=0, join_extra=0).fit()
+    err0, _ = _recall_rows(sa0, X, rows, k)
+    assert err < err0 and err <= 0.12 * len(rows) * k, (err, err0)
+    nt = (n + 127) // 128
+    assert sa.tile_evals <= int(np.ceil(0.3 * nt)) * nt + nt
+    sb = StreamedAnnchor(X, n_anchors=16, n_neighbors=k, p_work=0.3).fit()
+    assert np.array_equal(sa.neighbor_graph[0], sb.neighbor_graph[0])
 
 
 def test_budgeted_with_joins_at_62_neighbours():
@@ -416,6 +438,44 @@ def _worker_budgeted(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _worker_budgeted_k80(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from annchor_amd.streamed import StreamedAnnchor, TorchComm
+
+    X = latent(24000, 64)
+    cuts = [0, 13000, 24000]
+    sa = StreamedAnnchor(X[cuts[rank]:cuts[rank + 1]], n_anchors=12, n_neighbors=80, p_work=0.3, base=cuts[rank],
+                         comm=TorchComm(), device=0).fit()
+    gi, gd = sa.gather_graph()
+    if rank == 0:
+        np.savez(out, idx=gi, dist=gd)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_budgeted_at_80_neighbours(tmp_path):
+    """The row-sharded protocol (lists all-gathered between join passes, finished rows routed to their owners) with lists of
+    79 entries -- the split-list exact kernels: the two-rank graph equals the one-rank graph (one global tile order)."""
+    import torch.multiprocessing as mp
+
+    from annchor_amd.streamed import StreamedAnnchor
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "w80.npz")
+    mp.spawn(_worker_budgeted_k80, args=(2, port, out), nprocs=2, join=True)
+    R = np.load(out)
+    one = StreamedAnnchor(latent(24000, 64), n_anchors=12, n_neighbors=80, p_work=0.3).fit()
+    assert R["idx"].shape == (24000, 80)
+    same = (R["idx"] == one.neighbor_graph[0]).mean()
+    assert same > 0.999, same
+    np.testing.assert_allclose(R["dist"], one.neighbor_graph[1], rtol=1e-6, atol=1e-6)
+
+
 def test_two_ranks_budgeted_with_join_passes(tmp_path):
     """Row-sharded build with a binding budget: tile phase per rank, neighbour lists all-gathered
     before each join pass (annchor_stream_knn_begin / _join / _end), graph gathered at the end.
@@ -542,6 +602,10 @@ def test_streamed_query_matches_brute_force():
     # a single query row, and the Annchor front end (dispatches large Euclidean data to this form)
     i1, d1 = sa.query(Q[:1], nn=3, p_work=1.0)
     np.testing.assert_allclose(d1[0], bd[0, :3], rtol=1e-5, atol=1e-6)
+    # 100 neighbours per query: lists beyond 64 entries (two workgroups per query tile)
+    i100, d100 = sa.query(Q[:300], nn=100, p_work=1.0)
+    b100 = np.sqrt(np.sort(d2[:300], axis=1)[:, :100])
+    np.testing.assert_allclose(d100, b100, rtol=1e-5, atol=2e-5)
     ann = Annchor(X, "euclidean", n_anchors=16, n_neighbors=8, p_work=1.0, streamed=True).fit()
     i3, d3 = ann.query(Q[:100], nn=k, p_work=1.0)
     np.testing.assert_allclose(d3, bd[:100], rtol=1e-5, atol=1e-6)
