@@ -235,16 +235,21 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     }
     const char *xb = reinterpret_cast<const char *>(a.Xb);   // [n_all][2][DIM] fp16: hi parts, then lo parts of every ordered row (centred, scaled)
     const uint32_t *ulist = JOIN ? a.ucand + (size_t)bt * a.ucap : nullptr;   // join: sorted candidate columns, 0xffffffff padded to 128
+    uint32_t jn_id[NI];       // join passes: the column ids behind the wave's pieces of the slab after the one last requested
+    int64_t jn_c0 = -1;       // ... and that slab's first column (-1: none requested)
     auto issue_slab = [&](int J, int slab) {
         if constexpr (JOIN) {
-            // gathered columns: every lane's source is its own column's row (per-lane 64-bit addresses)
+            // gathered columns: every lane's source is its own column's row (per-lane 64-bit addresses).  The columns' ids were
+            // requested while the slab before this one was requested (the slabs of a pass come in a fixed order): read here, they
+            // were an L2 round trip in front of every slab's requests
             const uint32_t dst = lds0 + (uint32_t)((slab & 1) * ST_SLAB * DIM * 4 + rg * NI * 1024);
             const int64_t c0 = (int64_t)J * ST_T + slab * ST_SLAB;
             const char *srcs[NI];
+            const bool have_ids = jn_c0 == c0;   // (uniform)
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int u = (rg * NI + i) * 64 + lane;
-                const uint32_t id = ulist[c0 + u / UPC];
+                const uint32_t id = have_ids ? jn_id[i] : ulist[c0 + u / UPC];
                 srcs[i] = xb + (size_t)(id == 0xffffffffu ? 0u : id) * (DIM * 4) + (loff[i] - (uint32_t)((u / UPC) * DIM * 4));
             }
             unsigned keep;
@@ -252,6 +257,14 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
             for (int i = 0; i < NI; ++i)
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(srcs[i]), "s"(dst + (uint32_t)(i * 1024)) : "memory");
+            // the ids of the slab that follows in the pass's order (the next slab of the tile, or slab 0 of the next run of columns)
+            const int64_t n0 = c0 + ST_SLAB;
+            jn_c0 = -1;
+            if (n0 + ST_SLAB <= (int64_t)a.ucap) {
+                jn_c0 = n0;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) jn_id[i] = ulist[n0 + ((rg * NI + i) * 64 + lane) / UPC];
+            }
             return;
         }
         const char *src = xb + ((size_t)J * ST_T + slab * ST_SLAB) * (DIM * 4);              // wave-uniform: an SGPR pair
