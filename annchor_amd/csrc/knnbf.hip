@@ -235,6 +235,8 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     }
     const char *xb = reinterpret_cast<const char *>(a.Xb);   // [n_all][2][DIM] fp16: hi parts, then lo parts of every ordered row (centred, scaled)
     const uint32_t *ulist = JOIN ? a.ucand + (size_t)bt * a.ucap : nullptr;   // join: sorted candidate columns, 0xffffffff padded to 128
+    uint32_t js_id = 0;       // join passes: the lane's column id in the slab after the one being streamed, and that slab's first column
+    int64_t js_c0 = -1;
     uint32_t jn_id[NI];       // join passes: the column ids behind the wave's pieces of the slab after the one last requested
     int64_t jn_c0 = -1;       // ... and that slab's first column (-1: none requested)
     auto issue_slab = [&](int J, int slab) {
@@ -300,9 +302,14 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     auto stream_slab = [&](int J, int slab, f32x16 &accC, const f32x16 &accP) {
         PS0
         if constexpr (JOIN) {
-            const uint32_t id = ulist[(int64_t)J * ST_T + slab * ST_SLAB + col];
+            // (the lane's column id: requested while the slab before was streamed -- id -> norm is a chain of two global reads, and
+            // the LDS write of the id waited out the first of them at the head of every slab: 27 % of the pass's wave cycles)
+            const int64_t s0 = (int64_t)J * ST_T + slab * ST_SLAB;
+            const uint32_t id = js_c0 == s0 ? js_id : ulist[s0 + col];
             rj_c = id == 0xffffffffu ? INFINITY : a.rsb[id];   // (padding never passes: x.y > hb + inf is false)
             if (wave == 0 && lane < ST_SLAB) sh.slab_id[slab & 3][lane] = id;
+            js_c0 = -1;
+            if (s0 + 2 * ST_SLAB <= (int64_t)a.ucap) { js_c0 = s0 + ST_SLAB; js_id = ulist[js_c0 + col]; }
         } else {
             rj_c = a.rsb[(int64_t)J * ST_T + slab * ST_SLAB + col];
         }

@@ -2037,11 +2037,29 @@ static int knn_join_pass(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pad
     }
     a.updates = s->evals.as<unsigned long long>() + 1;
     ANN_CHECK_HIP(c, hipMemsetAsync(a.updates, 0, 8, c->stream));
+#ifdef ST_PROFILE
+    static unsigned long long *dj_prof = nullptr;
+    if (!dj_prof) (void)hipMalloc(&dj_prof, 128);
+    (void)hipMemsetAsync(dj_prof, 0, 128, c->stream);
+    a.prof = dj_prof;
+#endif
     {
         ProfScope ps(c, "stream_join_gemm_topk", 0.0);
         ANN_TRY(launch_by_dim(c, a, dim_padded, true));
     }
     ANN_CHECK_HIP(c, hipGetLastError());
+#ifdef ST_PROFILE
+    {
+        unsigned long long hp[16];
+        (void)hipMemcpy(hp, dj_prof, 128, hipMemcpyDeviceToHost);
+        double tot = 0;
+        for (int i = 0; i < 8; ++i) tot += (double)hp[i];
+        static const char *nm[8] = {"MFMA stream", "barrier after stream", "next-tile choice", "test + inserts", "LDS-DMA requests", "barrier after requests", "merge (+ publish / prologue / tail)", "the rest"};
+        if (tot > 0) for (int i = 0; i < 8; ++i) fprintf(stderr, "[st-prof join] %-36s %6.2f %%\n", nm[i], 100.0 * (double)hp[i] / tot);
+        if (tot > 0) for (int i = 8; i < 16; ++i) if (hp[i]) fprintf(stderr, "[st-prof join]    sub %d %6.2f %%\n", i, 100.0 * (double)hp[i] / tot);
+        a.prof = nullptr;
+    }
+#endif
     a.out_d2 = a.out_d2_new; a.out_col = a.out_col_new;
     if (updates) {
         unsigned long long u = 0;
