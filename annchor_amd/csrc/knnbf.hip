@@ -787,7 +787,18 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
             const int row = q / KL, e = q - row * KL;
             const int32_t cc = sh.list_c[row][e];
             float d2 = INFINITY;
-            if (cc != 0x7fffffff && sh.list_d[row][e] < INFINITY) {
+            bool known = false;
+            if constexpr (JOIN) {
+                // a column the row already listed before this pass: its exact d^2 is in the previous lists (a pass replaces a few
+                // per cent of the entries; re-reading two 512-byte rows for every kept entry was a quarter of the pass)
+                if (cc != 0x7fffffff) {
+                    const int32_t *ol = a.lists_all + ((size_t)grow0 + row) * K;
+                    const float *od = a.out_d2 + ((size_t)bt * ST_T + row) * K;
+                    for (int t = 0; t < K; ++t)
+                        if (ol[t] == cc) { known = true; d2 = od[t]; }
+                }
+            }
+            if (!known && cc != 0x7fffffff && sh.list_d[row][e] < INFINITY) {
                 const float4 *x = reinterpret_cast<const float4 *>(a.Rs + (size_t)(grow0 + row) * DIM);
                 const float4 *y = reinterpret_cast<const float4 *>(a.Xs + (size_t)cc * DIM);
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
