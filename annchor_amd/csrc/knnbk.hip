@@ -673,7 +673,17 @@ template <int KMAX, bool JOIN = false> __global__ __launch_bounds__(STBK_THREADS
             const int row = q / KL, e = q - row * KL;
             const int32_t cc = sh.list_c[row][e];
             float d2 = INFINITY;
-            if (cc != 0x7fffffff && sh.list_d[row][e] < INFINITY) {
+            bool known = false;
+            if constexpr (JOIN) {
+                // (a column the row already listed before this pass: its exact d^2 is in the previous lists -- knnbf.hip)
+                if (cc != 0x7fffffff) {
+                    const int32_t *ol = a.lists_all + ((size_t)grow0 + row) * K;
+                    const float *od = a.out_d2 + ((size_t)bt * ST_T + row) * K;
+                    for (int t = 0; t < K; ++t)
+                        if (ol[t] == cc) { known = true; d2 = od[t]; }
+                }
+            }
+            if (!known && cc != 0x7fffffff && sh.list_d[row][e] < INFINITY) {
                 const float4 *x = reinterpret_cast<const float4 *>(a.Rs + (size_t)(grow0 + row) * dimr);
                 const float4 *y = reinterpret_cast<const float4 *>(a.Xs + (size_t)cc * dimr);
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
