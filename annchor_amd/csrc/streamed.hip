@@ -1659,6 +1659,20 @@ __global__ __launch_bounds__(256) void k_st_finalize(const float *__restrict__ X
     }
 }
 
+// The split-fp16 kernels hand on EXACT float32 sums (x - y)^2 of the original rows (their re-ranking epilogue): the distances
+// are their square roots -- no second pass over 2 x 512 bytes per kept entry (19 ms at N = 8 x 10^6).  float32 accumulation, like
+// the reference's np.linalg.norm on float32 rows (distances.py:8-13); ANNCHOR_ST_FINALIZE_F64=1 keeps the float64 pass.
+__global__ void k_st_finalize_from_d2(const int64_t *__restrict__ perm_all, int64_t n, const float *__restrict__ d2, const int32_t *__restrict__ col,
+                                      int64_t *__restrict__ oidx, float *__restrict__ odist)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int32_t cc = col[t];
+    const bool ok = cc != 0x7fffffff;
+    odist[t] = ok ? sqrtf(d2[t]) : INFINITY;
+    oidx[t] = ok ? perm_all[cc] : -1;
+}
+
 __global__ void k_st_rowsort(int64_t rows, int K, int64_t *__restrict__ oidx, float *__restrict__ odist)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2081,6 +2095,10 @@ int ann_stream_knn_finish(annchor_ctx *c, StreamState *s, KnnArgs &a, const void
     float *d_dist = s->keys2.as<float>();
     {
         ProfScope ps(c, "stream_finalize", (double)rows * K * (2.0 * dim_padded * 4 + 16));
+        static const bool f64_pass = getenv("ANNCHOR_ST_FINALIZE_F64") != nullptr;
+        if (s->last_kernel == 1 && !f64_pass)
+            k_st_finalize_from_d2<<<ann_blocks(rows * K, 256), 256, 0, c->stream>>>((const int64_t *)perm_all, rows * K, a.out_d2, a.out_col, d_idx, d_dist);
+        else
         k_st_finalize<<<ann_blocks(rows * K * 16, 256), 256, 0, c->stream>>>(a.Xs, a.Rs, (const int64_t *)perm_all, dim_padded,
                                                                              (int64_t)a.tile_begin * ST_T, rows, K, a.out_col, d_idx,
                                                                              d_dist);
