@@ -1192,6 +1192,7 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
 #define JN_CAP 8192      // candidate columns per row tile (LDS sort buffer)
 #define JN_B1 8192       // first-hop ids per row tile (128 rows x (K + JN_RK) <= 6144)
 #define JN_RK 15         // reverse neighbours kept per point (the closest by list position)
+#define JN_EB_WORDS 4096  // evaluated-tile bitmap words k_st_join_cands keeps in LDS (row tiles up to 131 072)
 #define JN_THREADS 1024  // threads of k_st_join_cands: its time is bitonic stages (~340 per row tile) -- 16 waves make a stage a quarter as long as 4 did
 #define ANNCHOR_JOIN_YIELD 0.01   // extra join passes run while a pass still replaces more than this share of the list entries
 // The tile phase's early stop: a row tile stops when a window of ST_EARLY_WINDOW ranked tiles replaced fewer than this share of its
@@ -1449,7 +1450,15 @@ __global__ __launch_bounds__(JN_THREADS) void k_st_join_cands(const int32_t *__r
     int n1 = jn_unique<JN_B1 / JN_THREADS>(b1, P0, wsum);
     JP(2)
     // ---- second hop, filtered, appended in any order (sorted below)
+    // the row tile's evaluated-tile bitmap (1 KB at N = 10^6, 8 KB at 8 x 10^6) next to the sort buffers: the second hop's filter
+    // was the second of two dependent global reads per entry
     const uint32_t *eb = eval_bits + (size_t)bt * eval_words;
+    if (eval_words <= JN_EB_WORDS) {
+        uint32_t *ebl = wsum + JN_THREADS / 64 + 8;
+        for (int t = threadIdx.x; t < eval_words; t += JN_THREADS) ebl[t] = eb[t];
+        eb = ebl;
+        __syncthreads();
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (threadIdx.x == 0) nsurv_s = 0;
         __syncthreads();
@@ -2042,7 +2051,7 @@ static int knn_join_pass(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pad
     s->rev_gathered = false;   // (they belong to THESE lists: the next pass builds its own)
     {
         ProfScope ps(c, "stream_join_candidates", (double)rows * (K + JN_RK) * 4.0 * (K + JN_RK + 1));
-        const size_t lds = sizeof(uint32_t) * (JN_CAP + JN_B1 + JN_THREADS / 64 + 8);
+        const size_t lds = sizeof(uint32_t) * (JN_CAP + JN_B1 + JN_THREADS / 64 + 8 + (a.eval_words <= JN_EB_WORDS ? a.eval_words : 0));
         ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_join_cands, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int max_cols = std::max(1, std::min(per_pass * ST_T, JN_CAP));
         k_st_join_cands<<<a.tile_count, JN_THREADS, lds, c->stream>>>(lists_all, s->rev_all.as<int32_t>(), K, a.tile_begin, a.eval_bits,
