@@ -771,7 +771,8 @@ template <int KMAX> static int launchk(annchor_ctx *c, const KnnArgs &a, bool jo
 int ann_stream_launch_knnbk(annchor_ctx *c, const KnnArgs &a0, int dim_padded, bool *handled, bool join)
 {
     *handled = false;
-    if (dim_padded < 256 || dim_padded > 1024 || (dim_padded & 127) || a0.K + ST_BF_MARGIN > ST_KMAX_BIG || !a0.Xb || !a0.rsb || !a0.cvec) return ANNCHOR_OK;
+    static const bool bk128 = getenv("ANNCHOR_ST_KERNEL") && !strcmp(getenv("ANNCHOR_ST_KERNEL"), "bk");   // A/B: the k-blocked kernel on 128 dimensions (one block)
+    if (dim_padded < (bk128 ? 128 : 256) || dim_padded > 1024 || (dim_padded & 127) || a0.K + ST_BF_MARGIN > ST_KMAX_BIG || !a0.Xb || !a0.rsb || !a0.cvec) return ANNCHOR_OK;
     *handled = true;
     KnnArgs a = a0;
     a.dimr = dim_padded;

@@ -1774,7 +1774,7 @@ static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool 
                 }
             }
 #endif
-            ANN_TRY(ann_stream_launch_knnbf(c, a, dim_padded, &handled, join));
+            if (!(kern && !strcmp(kern, "bk") && dim_padded == 128)) ANN_TRY(ann_stream_launch_knnbf(c, a, dim_padded, &handled, join));
             if (!handled) ANN_TRY(ann_stream_launch_knnbk(c, a, dim_padded, &handled, join));   // padded dim 256 .. 1024: k-blocked
             if (handled) {
                 if (!join && st) st->last_kernel = 1;
