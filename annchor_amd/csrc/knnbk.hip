@@ -240,18 +240,23 @@ template <int KMAX, bool JOIN = false> __global__ __launch_bounds__(STBK_THREADS
     const char *xb = reinterpret_cast<const char *>(a.Xb);   // [n_all][2][dimr] fp16: hi parts, then lo parts of every ordered row (centred, scaled)
     const uint32_t *ulist = JOIN ? a.ucand + (size_t)bt * a.ucap : nullptr;   // join: sorted candidate columns, 0xffffffff padded to 128
     // operand slab `slab` of column tile J, dimension block kb -> ring slot `slot`: this wave's NI pieces
+    uint32_t jn_id[NI];       // join passes: the column ids behind the wave's pieces of the slab that follows the one last requested
+    int64_t jn_c0 = -1;
     auto issue_slab = [&](int J, int slab, int kb, int slot) __attribute__((always_inline)) {
         // (uniform by construction; the loops they live in end on values read from LDS, which the compiler cannot know to be)
         J = __builtin_amdgcn_readfirstlane(J); kb = __builtin_amdgcn_readfirstlane(kb); slot = __builtin_amdgcn_readfirstlane(slot);
         const uint32_t dst = lds0 + (uint32_t)(slot * ST_SLAB * DIM * 4 + rg * NI * 1024);
         if constexpr (JOIN) {
             // gathered columns: every lane's source is its own column's row (per-lane 64-bit addresses)
+            // (the ids: requested with the slab before this one, as in knnbf.hip -- the order of a pass is fixed: the tile's next
+            // slab, the next block's first, the next run's first)
             const int64_t c0 = (int64_t)J * ST_T + slab * ST_SLAB;
             const char *srcs[NI];
+            const bool have_ids = jn_c0 == c0;   // (uniform)
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int u = (rg * NI + i) * 64 + lane;
-                const uint32_t id = ulist[c0 + u / UPC];
+                const uint32_t id = have_ids ? jn_id[i] : ulist[c0 + u / UPC];
                 srcs[i] = xb + (size_t)(id == 0xffffffffu ? 0u : id) * ((size_t)dimr * 4) + (loff[i] - lrow[i]) + (size_t)kb * 256;
             }
             unsigned keep;
@@ -259,6 +264,13 @@ template <int KMAX, bool JOIN = false> __global__ __launch_bounds__(STBK_THREADS
             for (int i = 0; i < NI; ++i)
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(srcs[i]), "s"(dst + (uint32_t)(i * 1024)) : "memory");
+            const int64_t n0 = slab < 3 ? c0 + ST_SLAB : (kb + 1 < nkb ? (int64_t)J * ST_T : (int64_t)(J + 1) * ST_T);
+            jn_c0 = -1;
+            if (n0 + ST_SLAB <= (int64_t)a.ucap) {
+                jn_c0 = n0;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) jn_id[i] = ulist[n0 + ((rg * NI + i) * 64 + lane) / UPC];
+            }
             return;
         }
         const unsigned long long sa64 = (unsigned long long)(uintptr_t)(xb + ((size_t)J * ST_T + slab * ST_SLAB) * ((size_t)dimr * 4) + (size_t)kb * 256);
