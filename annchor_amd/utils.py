@@ -44,6 +44,7 @@ def get_function_from_input(func, func_kwargs):
 
 
 MIN_CHUNK = 32          # pairs per task at least: below that the pickling of the task outweighs the metric
+PAIR_TIMEOUT_SECONDS = 30.0   # the reference's joblib timeout per task = per pair (utils.py:152-175)
 CHUNKS_PER_JOB = 4      # tasks per worker and call: slack for pairs of unequal cost
 
 
@@ -86,8 +87,8 @@ def get_exact_ijs_(f, parallel=True, verbose=False, backend="loky"):
     pairs otherwise) -- never fewer than an earlier call of the same evaluator did (loky grows a pool in place;
     shrinking it would restart workers) and never more than the cores / the chunks.  With 256 workers for every call
     the same fit spent 12 of its 14 s starting processes.  The
-    per-task timeout grows with the chunk (30 s for the constructor's 20-pair probe, as in the reference, so a pool that
-    does not come up is still reported)."""
+    per-task timeout is the reference's 30 s per pair times the pairs of a chunk: a metric the reference finishes
+    (< 30 s per evaluation) never times out here either, and a pool that does not come up is still reported."""
     if not parallel:
         def get_exact(f, X, IJ):
             return np.array([f(X[i], X[j]) for i, j in IJ], dtype=np.float64)
@@ -114,11 +115,17 @@ def get_exact_ijs_(f, parallel=True, verbose=False, backend="loky"):
             horizon = max(m, state["expected_pairs"] - state["done"]) * state["t_pair"]
             state["workers"] = max(state["workers"], min(jobs, int(np.ceil(np.sqrt(horizon / WORKER_SPAWN_SECONDS)))))
         workers = min(jobs, state["workers"]) if state["t_pair"] is not None else jobs
-        chunk = max(MIN_CHUNK, -(-m // (CHUNKS_PER_JOB * workers)))
+        # (a slow metric -- a second or more per pair -- is balanced pair by pair: the task overhead no longer matters)
+        min_chunk = MIN_CHUNK if not state["t_pair"] else max(1, min(MIN_CHUNK, int(1.0 / state["t_pair"])))
+        chunk = max(min_chunk, -(-m // (CHUNKS_PER_JOB * workers)))
         if chunk >= m and m >= 2:
             chunk = -(-m // 2)      # (two tasks at least: the pool itself is exercised, see test_parallelisation)
         cuts = list(range(0, m, chunk))
-        parts = Parallel(n_jobs=max(1, min(workers, len(cuts))), backend=backend, timeout=max(30.0, 0.25 * chunk))(
+        state["last_chunk"], state["last_timeout"] = chunk, PAIR_TIMEOUT_SECONDS * max(1, chunk)
+        # 30 s per PAIR as in the reference (utils.py:152-175: one task per pair, timeout=30): a chunk of c pairs gets 30 c;
+        # n_jobs is the monotonic pool size whatever the number of chunks (a smaller n_jobs would shrink loky's reusable
+        # executor and the next large call would start its workers again)
+        parts = Parallel(n_jobs=max(1, workers), backend=backend, timeout=PAIR_TIMEOUT_SECONDS * max(1, chunk))(
             delayed(_eval_chunk)(f, _take(X, rest[c:c + chunk, 0]), _take(X, rest[c:c + chunk, 1])) for c in cuts)
         state["done"] += n
         spent = sum(p[1] for p in parts)

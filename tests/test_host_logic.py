@@ -83,6 +83,30 @@ def test_host_evaluator_chunks_equal_the_per_pair_form(backend):
     assert gs(len_diff, Xs, np.zeros((0, 2), dtype=np.int64)).shape == (0,)
 
 
+def slow_abs(a, b):
+    import time
+
+    time.sleep(0.12)
+    return float(abs(a - b))
+
+
+def test_host_evaluator_slow_metric_gets_the_reference_allowance(monkeypatch):
+    """A metric that costs seconds per pair finishes: the per-task timeout is the reference's 30 s per PAIR
+    (utils.py:152-175) times the pairs of the task, and slow metrics are submitted in small chunks.  (a
+    chunk of >= 32 pairs with timeout max(30, 0.25 chunk) raised TimeoutError mid-fit for a 1 s / pair metric.)  Run
+    here with the allowance scaled to 0.2 s per pair: 70 pairs of a 0.12 s metric pass, and every chunk stays small."""
+    from annchor_amd import utils
+
+    monkeypatch.setattr(utils, "PAIR_TIMEOUT_SECONDS", 0.2 * 30)   # (x30: joblib adds its own start-up; the point is the scaling)
+    X = np.arange(50.0)
+    rng = np.random.default_rng(2)
+    IJ = rng.integers(0, 50, size=(70, 2))
+    ge = utils.get_exact_ijs_(slow_abs, backend="threading")
+    got = ge(slow_abs, X, IJ)
+    assert np.array_equal(got, np.abs(X[IJ[:, 0]] - X[IJ[:, 1]]))
+    assert ge.state["last_chunk"] <= 8 and ge.state["last_timeout"] >= 0.2 * 30 * ge.state["last_chunk"]
+
+
 def abs_sum(a, b):
     return float(np.abs(a - b).sum())
 
