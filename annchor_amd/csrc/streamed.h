@@ -112,6 +112,7 @@ struct KnnArgs {
     unsigned long long *prof;   // ST_PROFILE builds only: per-phase cycle sums (8 counters)
     uint32_t *eval_bits;  // [tile_count][eval_words] evaluated column tiles per row tile (NULL: not recorded)
     int eval_words;
+    int eval_halves;      // bitmap rows per row tile: 2 when the lists are split over two workgroups (n_neighbors > 65), else 1
     // join passes (k_st_join_cands / k_st_join)
     const int32_t *lists_all;   // [n_all][K] current neighbour lists of EVERY ordered row (all ranks)
     const uint32_t *ucand;      // [tile_count][ucap] sorted candidate columns per row tile, 0xffffffff padded to 128

@@ -1003,8 +1003,10 @@ template <int DIM, int KMAX> __global__ __launch_bounds__(ST_THREADS, (DIM <= 12
     }
     // column tiles this row tile has evaluated (a join pass skips candidates inside them): this
     // workgroup is the only writer of its bitmap row
-    uint32_t *ebits = a.eval_bits ? a.eval_bits + (size_t)bt * a.eval_words : nullptr;
-    if (ebits && !a.query && threadIdx.x == 0) atomicOr(&ebits[I >> 5], 1u << (I & 31));   // (two writers when the lists are split)
+    // (lists split over two workgroups: each half has its own threshold, early stop and budget, hence its own set of
+    // evaluated tiles and its own bitmap row -- the join passes skip a candidate only where BOTH halves evaluated its tile)
+    uint32_t *ebits = a.eval_bits ? a.eval_bits + ((size_t)bt * (Half::ON ? 2 : 1) + hsel) * a.eval_words : nullptr;
+    if (ebits && !a.query && threadIdx.x == 0) atomicOr(&ebits[I >> 5], 1u << (I & 31));
 
     // ---- phase B: all other column tiles.  A tile is ELIGIBLE while its interval bound lb
     // (a valid lower bound of every pair distance) is below the worst k-th distance of the
@@ -1408,7 +1410,7 @@ static unsigned long long *jn_prof_buffer(annchor_ctx *c)
 // minus everything inside column tiles this row tile has already evaluated; sorted, distinct.
 __global__ __launch_bounds__(JN_THREADS) void k_st_join_cands(const int32_t *__restrict__ lists_all, const int32_t *__restrict__ rev,
                                                              int K, int tile_begin, const uint32_t *__restrict__ eval_bits,
-                                                             int eval_words, int max_cols, uint32_t *__restrict__ ucand,
+                                                             int eval_words, int eval_halves, int max_cols, uint32_t *__restrict__ ucand,
                                                              int32_t *__restrict__ ucount, unsigned long long *__restrict__ jprof)
 {
 #ifdef JN_PROFILE
@@ -1452,11 +1454,15 @@ __global__ __launch_bounds__(JN_THREADS) void k_st_join_cands(const int32_t *__r
     // ---- second hop, filtered, appended in any order (sorted below)
     // the row tile's evaluated-tile bitmap (1 KB at N = 10^6, 8 KB at 8 x 10^6) next to the sort buffers: the second hop's filter
     // was the second of two dependent global reads per entry
-    const uint32_t *eb = eval_bits + (size_t)bt * eval_words;
+    // (eval_halves = 2: the lists of the row tile were kept by two workgroups of 64 rows, each with its own bitmap row; a tile
+    // counts as evaluated where both rows say so)
+    const uint32_t *eb = eval_bits + (size_t)bt * eval_halves * eval_words;
+    int eb_and = eval_halves == 2 ? eval_words : 0;   // offset of the word to AND with (0: the word itself)
     if (eval_words <= JN_EB_WORDS) {
         uint32_t *ebl = wsum + JN_THREADS / 64 + 8;
-        for (int t = threadIdx.x; t < eval_words; t += JN_THREADS) ebl[t] = eb[t];
+        for (int t = threadIdx.x; t < eval_words; t += JN_THREADS) ebl[t] = eb[t] & eb[t + eb_and];
         eb = ebl;
+        eb_and = 0;
         __syncthreads();
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1490,7 +1496,7 @@ __global__ __launch_bounds__(JN_THREADS) void k_st_join_cands(const int32_t *__r
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int J = id[u] == 0x7fffffff ? 0 : id[u] >> 7;   // ST_T = 128
-                ew[u] = eb[J >> 5];
+                ew[u] = eb[J >> 5] & eb[(J >> 5) + eb_and];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1906,8 +1912,9 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
     a.evals = s->evals.as<unsigned long long>();
     a.eval_bits = nullptr;
     a.eval_words = (a.nt_all + 31) / 32;
+    a.eval_halves = (a.K > ST_KMAX_BIG) ? 2 : 1;   // (KnnHalf: two workgroups per row tile, a bitmap row each)
     if (record_tiles) {
-        const size_t nb = sizeof(uint32_t) * (size_t)a.tile_count * a.eval_words;
+        const size_t nb = sizeof(uint32_t) * (size_t)a.tile_count * a.eval_halves * a.eval_words;
         ANN_TRY(sreserve(c, s->eval_bits, nb));
         ANN_CHECK_HIP(c, hipMemsetAsync(s->eval_bits.p, 0, nb, c->stream));
         a.eval_bits = s->eval_bits.as<uint32_t>();
@@ -1969,7 +1976,7 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
             fprintf(stderr, "annchor: streamed tile phase: %llu of %lld rows have neighbours closer together than float32-grade products of |x|^2 "
                             "resolve (|x|^2 >> d^2); running the exact float32 tile kernel instead\n", flagged, (long long)rows);
             ANN_CHECK_HIP(c, hipMemsetAsync(s->evals.p, 0, 64, c->stream));
-            if (a.eval_bits) ANN_CHECK_HIP(c, hipMemsetAsync(s->eval_bits.p, 0, sizeof(uint32_t) * (size_t)a.tile_count * a.eval_words, c->stream));
+            if (a.eval_bits) ANN_CHECK_HIP(c, hipMemsetAsync(s->eval_bits.p, 0, sizeof(uint32_t) * (size_t)a.tile_count * a.eval_halves * a.eval_words, c->stream));
             ProfScope ps(c, "stream_tile_gemm_topk_exact_rerun", 0.0);
             ANN_TRY(launch_by_dim(c, a, dim_padded, false, true));
         }
@@ -2055,7 +2062,7 @@ static int knn_join_pass(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pad
         ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_join_cands, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int max_cols = std::max(1, std::min(per_pass * ST_T, JN_CAP));
         k_st_join_cands<<<a.tile_count, JN_THREADS, lds, c->stream>>>(lists_all, s->rev_all.as<int32_t>(), K, a.tile_begin, a.eval_bits,
-                                                                      a.eval_words, max_cols, s->ucand.as<uint32_t>(),
+                                                                      a.eval_words, a.eval_halves, max_cols, s->ucand.as<uint32_t>(),
                                                                       s->ucount.as<int32_t>(), jn_prof_buffer(c));
     }
     a.updates = s->evals.as<unsigned long long>() + 1;

@@ -884,3 +884,49 @@ np.savez(sys.argv[1], **{"a%%d_%%d" %% (i, j): np.asarray(v) for i, o in enumera
     assert res[0].keys() == res[1].keys()
     for key in res[0]:
         assert np.array_equal(res[0][key], res[1][key]), key
+
+
+def test_float32_finalize_equals_the_float64_pass_on_near_ties():
+    """The split-fp16 kernels hand on exact float32 sums (x - y)^2 of the original rows and the reported distance is their
+    square root (no float64 finalize pass: csrc/streamed.hip, knn_finish).  That rests on every surviving list entry carrying an
+    exact sum through the join passes (entries a pass keeps are copied by column id).  Lattice data -- thousands of exactly
+    tied distances -- through two join passes: the default output against ANNCHOR_ST_FINALIZE_F64=1 (the float64 recomputation
+    of the same lists): distances agree to float32 rounding (rtol 3e-7), rows are sorted, and where the two orders differ the
+    distances at those positions tie within that rounding."""
+    import subprocess
+    import tempfile
+
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from annchor_amd.streamed import StreamedAnnchor
+rng = np.random.default_rng(11)
+out = []
+for n, d, k, pw in ((60000, 24, 15, 0.12), (40000, 100, 10, 0.2)):
+    X = rng.integers(0, 4, size=(n, d)).astype(np.float32)     # lattice: squared distances are small integers, ties everywhere
+    X[:, :4] += (0.001 * rng.standard_normal((n, 4))).astype(np.float32)
+    sa = StreamedAnnchor(X, n_anchors=16, n_neighbors=k, p_work=pw).fit()
+    out.append((sa.neighbor_graph[0], sa.neighbor_graph[1], np.array(sa._engine.stream_last_kernel(with_guard=True))))
+np.savez(sys.argv[1], **{"a%%d_%%d" %% (i, j): np.asarray(v) for i, o in enumerate(out) for j, v in enumerate(o)})
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    res = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, env in (("f32", {}), ("f64", {"ANNCHOR_ST_FINALIZE_F64": "1"})):
+            out = os.path.join(tmp, name + ".npz")
+            envd = dict(os.environ, **env)
+            if not env:
+                envd.pop("ANNCHOR_ST_FINALIZE_F64", None)
+            r = subprocess.run([sys.executable, "-c", code, out], env=envd, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res.append(dict(np.load(out)))
+    for i in range(2):
+        ia, da, ka = res[0]["a%d_0" % i], res[0]["a%d_1" % i], res[0]["a%d_2" % i]
+        ib, db = res[1]["a%d_0" % i], res[1]["a%d_1" % i]
+        assert ka[0] == 1, ka            # the split kernel ran (the float32 finalize is its path)
+        np.testing.assert_allclose(da, db, rtol=3e-7, atol=1e-7)
+        assert np.all(np.diff(da[:, 1:], axis=1) >= 0) and np.all(np.diff(db[:, 1:], axis=1) >= 0)
+        for r_ in range(len(ia)):
+            assert set(ia[r_]) == set(ib[r_]) or np.allclose(np.sort(da[r_]), np.sort(db[r_]), rtol=3e-7, atol=1e-7), r_
+        diff = ia != ib
+        if diff.any():
+            np.testing.assert_allclose(da[diff], db[diff], rtol=3e-7, atol=1e-7)
