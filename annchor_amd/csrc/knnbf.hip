@@ -42,6 +42,8 @@
 
 #define STB_THREADS 256
 #define ST_BF_MARGIN 2   // list entries beyond K kept by the split-fp16 distance (re-ranked exactly at the end)
+#define ST3_CS 8         // three-slot form: candidate slots per row and slab
+#define ST3_DIRECT 6     // three-slot form: up to this many survivors per wave and slab go straight into their lists
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -69,13 +71,20 @@ __device__ __forceinline__ long long st8_now()
 #define PS0
 #endif
 
-template <int DIM, int KMAX> struct KnnSharedB {
+// R3 (round 6): a ring of THREE slots, slabs requested two ahead, the slab barrier replaced by per-wave progress flags (the
+// waves of a workgroup may drift a slab apart), the columns' norms by LDS-DMA beside the operands, eight candidate slots per
+// row and slab (a row with more survivors -- the first tiles of a row tile -- merges in rounds).  See `run3` below.
+template <int DIM, int KMAX, bool R3 = false> struct KnnSharedB {
     static constexpr int SLABF = ST_SLAB * DIM;                                 // floats per operand slab
-    static constexpr int RINGF = 2 * SLABF * 4 >= 12288 ? 2 * SLABF : 12288 / 4;   // (>= sizeof(SelBuf))
-    float ring[RINGF];   // FIRST (LDS-DMA destinations stay below 64 KB); two slots, slot = slab parity.  Between runs the
-                         // selection's sort buffers (SelBuf) live here
-    float cand_d[ST_T][ST_SLAB + 1];   // (between runs: the selection's 4096-bin histogram; at the end: exact distances)
-    uint8_t cand_c[ST_T][ST_SLAB + 4];
+    static constexpr int NSLOT = R3 ? 3 : 2;
+    static constexpr int CS = R3 ? ST3_CS : ST_SLAB;                            // candidate slots per row and slab
+    static constexpr int RINGF = NSLOT * SLABF * 4 >= 12288 ? NSLOT * SLABF : 12288 / 4;   // (>= sizeof(SelBuf))
+    float ring[RINGF];   // FIRST (LDS-DMA destinations stay below 64 KB); slot = slab parity (R3: slab sequence number mod 3).
+                         // Between runs the selection's sort buffers (SelBuf) live here (R3: and its histogram; at the end
+                         // the exact distances)
+    float norms[R3 ? 3 * 64 : 4];      // R3: squared norms of the columns of the slab in each slot (LDS-DMA destination)
+    float cand_d[ST_T][CS + 1];        // (two-slot form -- between runs: the selection's 4096-bin histogram; at the end: exact distances)
+    uint8_t cand_c[ST_T][R3 ? CS : ST_SLAB + 4];
     float list_d[ST_T][KMAX + 1];
     int32_t list_c[ST_T][KMAX + 1];
     float thr[ST_T];
@@ -88,6 +97,9 @@ template <int DIM, int KMAX> struct KnnSharedB {
     int32_t run_j[ST_KEEP];
     float wave_thr[2][4];   // worst k-th squared distance per 32-row group, published at the end of tile n into [n & 1]
     int wave_ins[2][4];     // list insertions per wave (cumulative), likewise
+    uint32_t run_ev[ST_KEEP / 32];            // R3: entries of the current run's tile list that were evaluated (thread 0 writes)
+    alignas(16) int f_loaded[4];              // R3: per wave, the last slab (sequence number) whose pieces it requested have landed
+    alignas(16) int f_done[4];                // R3: per wave, the last slab whose operands it has read
     int nsurv;
     int sel_bin;
     uint32_t sel_before;
@@ -114,10 +126,12 @@ __device__ __forceinline__ void slab_end()
 
 // JOIN: a join pass (streamed.hip: k_st_join_cands has collected the row tile's candidate columns) -- the "tiles" are runs of
 // 128 gathered columns of the candidate list, the lists start from the previous phase's, nothing is ranked or pruned.
-template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_st_knnbf(KnnArgs a)
+template <int DIM, int KMAX, bool JOIN = false, bool R3 = false> __global__ __launch_bounds__(STB_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_st_knnbf(KnnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smemb[];
-    KnnSharedB<DIM, KMAX> &sh = *reinterpret_cast<KnnSharedB<DIM, KMAX> *>(smemb);
+    using Sh = KnnSharedB<DIM, KMAX, R3>;
+    Sh &sh = *reinterpret_cast<Sh *>(smemb);
+    static_assert(!(JOIN && R3), "the join passes run the two-slot form");
     constexpr int UPC = DIM / 4;            // 16-byte units per column
     constexpr int NV = UPC / 2;             // operand reads (ds_read_b128) per slab and lane: G hi + G lo
     constexpr int NPIECE = UPC * ST_SLAB / 64;   // 1 KB pieces per slab
@@ -125,7 +139,9 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     static_assert(NI == 1 || NI == 2 || NI == 4, "pieces per loading wave");
     static_assert(sizeof(sh.ring) <= 65536, "LDS-DMA destinations must stay below 64 KB");
     static_assert(sizeof(SelBuf) <= sizeof(sh.ring) && sizeof(SelBuf) == 12288, "selection buffers alias the ring");
-    static_assert(KMAX <= ST_SLAB + 1, "the exact re-ranking reuses cand_d with row stride KMAX");
+    static_assert(R3 || KMAX <= ST_SLAB + 1, "the exact re-ranking reuses cand_d with row stride KMAX");
+    static_assert(!R3 || (sizeof(sh.ring) >= 12288 + 16384 && sizeof(sh.ring) >= sizeof(float) * ST_T * KMAX), "R3: histogram and exact distances alias the ring");
+    static_assert(!R3 || sizeof(sh.ring) + sizeof(sh.norms) <= 65536, "LDS-DMA destinations must stay below 64 KB");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rg = wave;   // this wave's 32-row group
@@ -204,6 +220,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     }
     if (threadIdx.x < 8) { sh.wave_ins[threadIdx.x >> 2][threadIdx.x & 3] = 0; sh.wave_thr[threadIdx.x >> 2][threadIdx.x & 3] = INFINITY; }
     if (threadIdx.x == 0) sh.nsurv = 0;
+    if (R3 && threadIdx.x < 8) (&sh.f_loaded[0])[threadIdx.x] = -1;   // (f_loaded[4], f_done[4]: nothing requested, nothing read)
     int ins = 0;         // list insertions counted by this lane (the first lane of a merge group)
     int processed = 0;   // column tiles scheduled so far (uniform)
     int tdone = 0;       // column tiles completed and published (uniform); tile n publishes into slot n & 1
@@ -286,6 +303,17 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(loff[0]), "s"(src), "s"(dst) : "memory");
     };
+    int cur_slot = 0;           // R3: ring slot of the slab being streamed (uniform)
+    float hqr[16];              // R3: hb of the lane's 16 rows, kept across slabs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hqr[r] = 0.f;
+    bool hq_stale = true;       // R3: a merge of this wave has changed hb since hqr was read (uniform)
+    unsigned long long pany = 0;   // R3: OR over the rows of the pending slab's test masks (lanes = columns with a survivor)
+    int seq = 0;                // R3: sequence number of the slab being streamed (uniform; monotonic over the kernel)
+    const uint32_t flag_addr = lds0 + (uint32_t)((const unsigned char *)&sh.f_loaded[0] - smemb);
+    auto set_flag = [&](int which, int v) {   // R3 -- which: 0 = f_loaded[wave], 1 = f_done[wave]
+        if (lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(flag_addr + (uint32_t)(which * 16 + wave * 4)), "v"(v) : "memory");
+    };
     f32x16 acc0, acc1;          // slabs 0, 2 / slabs 1, 3 of a tile: one is streamed into while the other one is tested
     float rj_c = 0.f;           // squared norm of the lane's column in the slab being streamed (requested at its start)
     // the slab whose accumulators wait for their test (the one streamed before the current one)
@@ -299,7 +327,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     // the lane's column passes iff x_r . x_c > hb[r] + |x_c|^2 / 2 (hb: one LDS word per row, kept by the merge).  The
     // columns' squared norms are requested at the start of their slab and used one slab later: a global round trip under
     // load is thousands of cycles.
-    auto stream_slab = [&](int J, int slab, f32x16 &accC, const f32x16 &accP) {
+    auto stream_slab = [&](int J, int slab, f32x16 &accC, const f32x16 &accP) __attribute__((always_inline)) {
         PS0
         if constexpr (JOIN) {
             // (the lane's column id: requested while the slab before was streamed -- id -> norm is a chain of two global reads, and
@@ -310,18 +338,32 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
             if (wave == 0 && lane < ST_SLAB) sh.slab_id[slab & 3][lane] = id;
             js_c0 = -1;
             if (s0 + 2 * ST_SLAB <= (int64_t)a.ucap) { js_c0 = s0 + ST_SLAB; js_id = ulist[js_c0 + col]; }
+        } else if constexpr (R3) {
+            rj_c = sh.norms[cur_slot * 64 + col];   // (came with the operands)
         } else {
             rj_c = a.rsb[(int64_t)J * ST_T + slab * ST_SLAB + col];
         }
-        const float4 *base = reinterpret_cast<const float4 *>(&sh.ring[(slab & 1) * (ST_SLAB * DIM)]) + col * UPC;
+        const float4 *base = reinterpret_cast<const float4 *>(&sh.ring[(R3 ? cur_slot : (slab & 1)) * (ST_SLAB * DIM)]) + col * UPC;
         const int gsw = half ^ unit_swz<UPC>(col);
         float hq[16];   // (first: LDS data returns in order, and the test must not wait for the operands behind it)
+        if constexpr (R3) {
+            // the rows' thresholds stay in registers from slab to slab; read again after a merge of this wave changed them
+            if (hq_stale) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 h4 = *reinterpret_cast<const float4 *>(&sh.hb[rowq + 8 * q]);
+                    hqr[4 * q] = h4.x; hqr[4 * q + 1] = h4.y; hqr[4 * q + 2] = h4.z; hqr[4 * q + 3] = h4.w;
+                }
+                hq_stale = false;
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 h4 = *reinterpret_cast<const float4 *>(&sh.hb[rowq + 8 * q]);
             hq[4 * q] = h4.x; hq[4 * q + 1] = h4.y; hq[4 * q + 2] = h4.z; hq[4 * q + 3] = h4.w;
         }
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        }
         float4 b[NV];   // b[g]: hi parts of k-step g; b[G + g]: lo parts
 #pragma unroll
         for (int v = 0; v < NV; ++v) b[v] = base[(2 * v) ^ gsw];
@@ -329,12 +371,45 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
         // each read to its use and the stream waits out an LDS round trip every few MFMAs)
         __builtin_amdgcn_sched_group_barrier(0x100, NV, 0);
         PS(8)    // operand reads landed (the stamp waits for them)
+        constexpr int NM = 3 * G;                       // MFMAs
+        constexpr int TPM = (16 + NM - 1) / NM;         // row tests per MFMA
+        if constexpr (R3) {
+            // R3: the accumulators start from -|x_c|^2 / 2 (the column's norm came with the operands), so the row test is ONE
+            // compare per row, x_r . x_c - |x_c|^2 / 2 > hb[r], written to a wave mask (v_cmp into an SGPR pair) of which only
+            // the OR over the rows is kept: 16 vector instructions per slab in the MFMAs' shadow instead of 64 (add, compare,
+            // select, or -- the two waves of a SIMD take turns at the issue port, and beside an MFMA stream its own wave's
+            // vector instructions are the only ones that issue: instruction count is what the tile phase's time is made of).
+            // The rare slab with a survivor rebuilds the per-lane row masks in insert_merge.
+            const float nh = -0.5f * rj_c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accC[r] = nh;
+            unsigned long long any = 0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {   // small terms first
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int m = 3 * g + t;
+                    if (t == 0) accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g], __builtin_bit_cast(f16x8, b[g]), accC, 0, 0, 0);
+                    if (t == 1) accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], __builtin_bit_cast(f16x8, b[G + g]), accC, 0, 0, 0);
+                    if (t == 2) accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], __builtin_bit_cast(f16x8, b[g]), accC, 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < TPM; ++u) {
+                        const int r = m * TPM + u;
+                        if (r < 16) any |= __ballot(accP[r] > hqr[r]);
+                    }
+                    asm volatile("" : "+v"(accC));
+                    // every operand read of the slab has been issued by now (the write below is a memory barrier to the compiler,
+                    // and LDS serves a wave's instructions in order): the slot may be requested again once every wave says so
+                    if (m == 2) set_flag(1, seq);
+                }
+            }
+            pany = pend ? any : 0ull;
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) accC[r] = 0.f;
         const float hrj = 0.5f * prj;
         uint32_t pass = 0;
-        constexpr int NM = 3 * G;                       // MFMAs
-        constexpr int TPM = (16 + NM - 1) / NM;         // row tests per MFMA
 #pragma unroll
         for (int g = 0; g < G; ++g) {   // small terms first
 #pragma unroll
@@ -359,10 +434,63 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     };
     // what the shadow test let through (slab pslab of tile pJ, accumulators accP, column norms prj): survivors into the rows'
     // candidate slots, then the merge into the sorted lists
-    auto insert_merge = [&](const f32x16 &accP) {
+    auto insert_merge = [&](const f32x16 &accP) __attribute__((always_inline)) {
         const int J = pJ, slab = pslab;
         const float rj = prj;
         uint32_t pass = ppass;
+        if constexpr (R3) {
+            if (!pany) return;   // (uniform) no row of this wave let a column of the slab through: nothing to insert, nothing to merge
+            hq_stale = true;
+            // A warm row tile lets one or two columns per wave and slab through (a row's 16-entry list takes ~100 insertions over
+            // ~66 000 streamed columns): the candidate slots, their counters and the batched merge below are machinery for the
+            // first tiles, when every column passes.  Few survivors go straight into their lists, one at a time and wave-uniform:
+            // the survivor's row test mask names lane and register, its accumulator comes by v_readlane, lanes e = 0 .. 15 hold the
+            // row's list, the position is a popcount of the comparison ballot, the tail moves up by a DPP row shift.
+            // (how many: the columns with a survivor -- a column that passes for several rows counts once)
+            const bool self_t = !a.query && (int64_t)J * ST_T == grow0;
+            if (!self_t && __popcll(pany) <= ST3_DIRECT) {
+                static_assert(!R3 || KMAX == 16, "the direct insert keeps a list in one 16-lane row");
+                const int32_t col0 = (int32_t)(J * ST_T + slab * ST_SLAB);
+                const int e = lane & 15;
+                uint32_t lp = 0;   // the lane's rows with a survivor
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lp |= (accP[r] > hqr[r] ? 1u : 0u) << r;
+                unsigned long long lanes = __ballot(lp != 0);
+                while (lanes) {   // (uniform) lanes = columns with a survivor
+                    const int l = (int)__builtin_ctzll(lanes);
+                    lanes &= lanes - 1;
+                    uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)lp, l);
+                    while (pl) {   // (uniform) that column's rows
+                        const int r = __builtin_ctz(pl);
+                        pl &= pl - 1;
+                        const float av = accP[r];   // (r is uniform: a relative register read, not a select chain)
+                        const float dv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, av), l));
+                        const int rowl = rowbase + 4 * (l >> 5) + (r & 3) + 8 * (r >> 2);
+                        const int32_t cc = col0 + (l & 31);
+                        const float rr = sh.rrow[rowl];
+                        const float ld = e < KL ? sh.list_d[rowl][e] : INFINITY;
+                        const int32_t lc = e < KL ? sh.list_c[rowl][e] : 0x7fffffff;
+                        const float d2 = fmaxf(rr - 2.f * dv, 0.f);
+                        const bool before = e < KL && (ld < d2 || (ld == d2 && lc < cc));
+                        const int pos = __popcll(__ballot(before) & 0xffffull);
+                        if (pos < KL) {   // (uniform)
+                            const float pd = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ld), 0x111, 0xf, 0xf, false));   // row_shr:1
+                            const int32_t pc = __builtin_amdgcn_update_dpp(0, lc, 0x111, 0xf, 0xf, false);
+                            const float nd = e > pos ? pd : (e == pos ? d2 : ld);
+                            const int32_t nc = e > pos ? pc : (e == pos ? cc : lc);
+                            if (lane < 16 && e >= pos && e < KL) { sh.list_d[rowl][e] = nd; sh.list_c[rowl][e] = nc; }
+                            if (lane == KL - 1) { sh.thr[rowl] = nd; sh.hb[rowl] = 0.5f * (rr - nd); }
+                            ins += (lane == 0 && pos < K) ? 1 : 0;
+                        }
+                    }
+                }
+                wave_fence_lds();
+                return;
+            }
+            pass = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pass |= (accP[r] > hqr[r] ? 1u : 0u) << r;
+        }
         PS0
         const bool self_tile = !JOIN && !a.query && (int64_t)J * ST_T == grow0;
         PS(10)   // thresholds read, accumulators there, 16 tests
@@ -371,6 +499,13 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
                 const int dcol = slab * ST_SLAB + col - rowq;
                 if (dcol >= 0 && dcol < 32 && (dcol & 4) == 0) pass &= ~(1u << ((dcol & 3) + 4 * (dcol >> 3)));
             }
+        }
+        // (R3: Sh::CS = 8 candidate slots per row; a survivor that finds them taken waits for the next round of {insert, merge} --
+        // the first tiles of a row tile, when every column still passes)
+        uint32_t defer;
+        do {
+        defer = 0;
+        {
             while (pass) {
                 const int g = __builtin_ctz(pass);
                 pass &= pass - 1;
@@ -378,10 +513,15 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
                 float ag = accP[0];
 #pragma unroll
                 for (int t = 1; t < 16; ++t) ag = g == t ? accP[t] : ag;
-                const float d2 = fmaxf(sh.rrow[rowl] + rj - 2.f * ag, 0.f);
+                const float d2 = R3 ? fmaxf(sh.rrow[rowl] - 2.f * ag, 0.f)    // (R3: ag = x_r . x_c - |x_c|^2 / 2)
+                                    : fmaxf(sh.rrow[rowl] + rj - 2.f * ag, 0.f);
                 const int slot = atomicAdd(&sh.cnt[rowl], 1);
-                sh.cand_d[rowl][slot] = d2;
-                sh.cand_c[rowl][slot] = (uint8_t)col;
+                if (!R3 || slot < Sh::CS) {
+                    sh.cand_d[rowl][slot] = d2;
+                    sh.cand_c[rowl][slot] = (uint8_t)col;
+                } else {
+                    defer |= 1u << g;
+                }
             }
         }
         PS(11)   // survivor inserts
@@ -408,7 +548,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
                 }
                 const int row = rowbase + max(rsel, 0);
                 const bool live = rsel >= 0;
-                const int nc = live ? sh.cnt[row] : 0;
+                const int nc = live ? (R3 ? min(sh.cnt[row], Sh::CS) : sh.cnt[row]) : 0;
                 float ld = (live && e < KL) ? sh.list_d[row][e] : INFINITY;
                 int32_t lc = (live && e < KL) ? sh.list_c[row][e] : 0x7fffffff;
                 int q = 0;
@@ -452,10 +592,12 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
             }
         }
         wave_fence_lds();
+        pass = defer;
+        } while (R3 && __ballot(defer != 0));
         P8(6)
     };
     // the pending slab's test without a stream to hide it in (end of a run)
-    auto test_only = [&](const f32x16 &accP) {
+    auto test_only = [&](const f32x16 &accP) __attribute__((always_inline)) {
         uint32_t pass = 0;
         const float hrj = 0.5f * prj;
 #pragma unroll
@@ -463,12 +605,14 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
             const float4 h4 = *reinterpret_cast<const float4 *>(&sh.hb[rowq + 8 * q]);
             const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pass |= (accP[4 * q + e] > hv[e] + hrj ? 1u : 0u) << (4 * q + e);
+            for (int e = 0; e < 4; ++e) pass |= (accP[4 * q + e] > hv[e] + (R3 ? 0.f : hrj) ? 1u : 0u) << (4 * q + e);
+            if constexpr (R3) { hqr[4 * q] = hv[0]; hqr[4 * q + 1] = hv[1]; hqr[4 * q + 2] = hv[2]; hqr[4 * q + 3] = hv[3]; }
         }
         ppass = pend ? pass : 0u;
+        if constexpr (R3) pany = pend ? __ballot(pass != 0) : 0ull;   // (insert_merge rebuilds the same row masks from hqr)
     };
     // the wave's insertion count and its rows' worst k-th distance, at the end of a tile
-    auto publish = [&]() {
+    auto publish = [&]() __attribute__((always_inline)) {
         int wins = ins;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) wins += __shfl_xor(wins, off);
@@ -584,6 +728,149 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
         P8(6)
     };
 
+    // ---------------------------------------------------------------- R3: the stream without workgroup barriers
+    // Slabs carry a sequence number `seq` (monotonic over the kernel); slab s lives in ring slot s % 3 and is requested two
+    // slabs ahead.  Per wave and slab s:   its own pieces of slab s + 1 (requested a whole slab ago) have landed: f_loaded[wave]
+    // = s + 1  ->  wait until every wave has READ slab s - 1 (its slot is the one slab s + 2 goes to) and LANDED its pieces
+    // of slab s  ->  request slab s + 2  ->  operand reads + MFMAs of slab s (slab s - 1's test in their shadow; f_done[wave]
+    // = s as soon as the reads are issued)  ->  inserts / merge of slab s - 1.  What a wave waits for is that the others have
+    // issued their reads of the slab BEFORE: the MFMAs, the test and the merge of a slab -- two thirds of it -- are slack, where
+    // the two-slot form met at a barrier after every slab (27 % of its wave cycles).  The only vector-memory operations inside a run are the
+    // LDS-DMA requests (the columns' norms are one more request per slab; the evaluated-tile bits are kept in LDS
+    // and flushed at the end of the run), so vmcnt counts exactly them.  The tile after J is chosen at J's slab 2 (its slab 0
+    // is requested there) from the state published at the end of the tile before J, as in the two-slot form: f_done >= s - 1
+    // implies every wave has finished that tile's last slab, publication included (LDS serves a wave's instructions in order).
+    constexpr int OPS = NI + 1;
+    const uint32_t norm_addr = lds0 + (uint32_t)((const unsigned char *)&sh.norms[0] - smemb);
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    auto issue3 = [&](int Jv, int slab, int sq) __attribute__((always_inline)) {
+        // (uniform values; under register pressure the compiler keeps some of them in vector registers, and the requests want their
+        // source in a scalar register pair)
+        auto scalar_ptr = [](const void *ptr) -> const char * {
+            const uint64_t v = (uint64_t)(uintptr_t)ptr;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+            return reinterpret_cast<const char *>((uintptr_t)(((uint64_t)hi << 32) | lo));
+        };
+        const int J = __builtin_amdgcn_readfirstlane(Jv);
+        const int slot = __builtin_amdgcn_readfirstlane(sq % 3);
+        const char *src = scalar_ptr(xb + ((size_t)J * ST_T + slab * ST_SLAB) * (DIM * 4));
+        const uint32_t dst = lds0 + (uint32_t)(slot * ST_SLAB * DIM * 4 + rg * NI * 1024);      // this wave's pieces of the slot
+        unsigned keep;
+        if constexpr (NI == 4)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(loff[0]), "v"(loff[1]), "v"(loff[2]), "v"(loff[3]), "s"(src), "s"(dst) : "memory", "scc");
+        else if constexpr (NI == 2)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(loff[0]), "v"(loff[1]), "s"(src), "s"(dst) : "memory", "scc");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(loff[0]), "s"(src), "s"(dst) : "memory");
+        // the 32 columns' squared norms: every wave requests them (the same 128 bytes to the same place: one request more per
+        // wave and slab keeps vmcnt the same for all of them; lanes 32 .. 63 repeat lanes 0 .. 31)
+        const char *nsrc = scalar_ptr(a.rsb + (size_t)J * ST_T + slab * ST_SLAB);
+        const uint32_t noff = (uint32_t)((lane & 31) * 4);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(noff), "s"(nsrc), "s"(norm_addr + (uint32_t)(slot * 256)) : "memory");
+    };
+    auto wait_flags = [&](int need) __attribute__((always_inline)) {   // every wave has read slab need - 1 and its pieces of slab need have landed
+        for (;;) {
+            i32x4 L, D;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(L), "=&v"(D) : "v"(flag_addr) : "memory");
+            const int ml = min(min(L[0], L[1]), min(L[2], L[3])), md = min(min(D[0], D[1]), min(D[2], D[3]));
+            if (__builtin_amdgcn_readfirstlane((ml >= need && md >= need - 1) ? 1 : 0)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto run3 = [&](int ns, auto jl, auto vb) __attribute__((always_inline)) {
+        int q = 0;
+        if (threadIdx.x == 0)
+            for (int t = 0; t < ST_KEEP / 32; ++t) sh.run_ev[t] = 0;
+        auto next_tile = [&](int in_stream) -> int {
+            if (a.early_window > 0 && !dried) {
+                const int done = processed - in_stream;   // tiles completed (the one in the stream is not)
+                if (done - win_start >= a.early_window) {
+                    int cur = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) cur += sh.wave_ins[tdone & 1][w];
+                    if (cur - win_ins < a.early_tau) dried = true;
+                    else { win_start = done; win_ins = cur; }
+                }
+            }
+            if (dried) return -1;
+            const float tm = thrmax_now();
+            while (q < ns && processed < a.max_tiles) {
+                const int J = jl(q);
+                const float lb = vb(q);
+                ++q;
+                if (lb * lb < tm) {
+                    ++processed;
+                    if (ebits && threadIdx.x == 0) sh.run_ev[(q - 1) >> 5] |= 1u << ((q - 1) & 31);   // (flushed at the end of the run)
+                    return __builtin_amdgcn_readfirstlane(J);   // (uniform, and the requests want it in a scalar register)
+                }
+            }
+            return -1;
+        };
+        int J = next_tile(0);
+        if (J < 0) return;
+        // fill: slabs 0 and 1 of the first tile (the ring is idle: a workgroup barrier precedes every run)
+        issue3(J, 0, seq);
+        issue3(J, 1, seq + 1);
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(OPS) : "memory");
+        set_flag(0, seq);
+        pend = false;
+        // one slab of the stream: (Ji, si) = the slab to request (two ahead; Ji < 0: the run ends before it), have_next: slab
+        // seq + 1 exists (it was requested one slab ago)
+        auto top3 = [&](bool have_next) __attribute__((always_inline)) {
+            // the wave's own pieces of slab seq + 1 were requested a whole slab ago: landed (nothing else is outstanding)
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+            if (have_next) set_flag(0, seq + 1);
+            wait_flags(seq);
+        };
+        auto slab3 = [&](int Jc, int sl, f32x16 &accC, const f32x16 &accP, int Ji, int si) __attribute__((always_inline)) {
+            if (Ji >= 0) issue3(Ji, si, seq + 2);
+            cur_slot = seq % 3;
+            stream_slab(Jc, sl, accC, accP);   // (f_done[wave] = seq behind its third MFMA)
+            if (pend) insert_merge(accP);
+            pend = true; pJ = Jc; pslab = sl; prj = rj_c;
+            if (sl == 3) { publish(); ++tdone; }   // (the lists as merged through slab 2 of this tile)
+            ++seq;
+        };
+        for (;;) {
+            top3(true);
+            slab3(J, 0, acc0, acc1, J, 2);
+            top3(true);
+            slab3(J, 1, acc1, acc0, J, 3);
+            top3(true);
+            const int Jn = next_tile(1);
+            slab3(J, 2, acc0, acc1, Jn, 0);
+            top3(Jn >= 0);
+            slab3(J, 3, acc1, acc0, Jn, 1);
+            if (Jn < 0) break;
+            J = Jn;
+        }
+        // ---- tail: the last slab's test and merge, and the thresholds the selection of the next round reads
+        test_only(acc1);
+        insert_merge(acc1);
+        pend = false;
+        publish();
+        ++tdone;
+        __syncthreads();
+        if (ebits)
+            for (int t = threadIdx.x; t < ns; t += STB_THREADS)
+                if ((sh.run_ev[t >> 5] >> (t & 31)) & 1u) {
+                    const int Jt = jl(t);
+                    atomicOr(&ebits[Jt >> 5], 1u << (Jt & 31));
+                }
+    };
+    auto run_tiles = [&](int ns, auto jl, auto vb) {
+        if constexpr (R3) run3(ns, jl, vb);
+        else run(ns, jl, vb);
+    };
+
     // ---- phase A: the row tile against itself (gives every row K finite candidates); query rows are not part of the
     // data set and start from the ranked tiles directly
     if constexpr (JOIN) {
@@ -592,7 +879,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
         run(nchunks, [&](int q) { return q; }, [&](int) { return 0.f; });
         processed = nchunks;
     } else if (!a.query) {
-        run(1, [&](int) { return I; }, [&](int) { return 0.f; });
+        run_tiles(1, [&](int) { return I; }, [&](int) { return 0.f; });
     }
 
     if constexpr (!JOIN) {
@@ -616,9 +903,10 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
         slb[J] = lb;
     }
     __syncthreads();   // block-scope visibility of the scratch row (same CU)
-    uint32_t *hist = reinterpret_cast<uint32_t *>(&sh.cand_d[0][0]);   // 4096 bins; cand_d is idle between runs
+    uint32_t *hist = R3 ? reinterpret_cast<uint32_t *>(&sh.ring[12288 / 4])      // R3: behind the sort buffers in the idle ring
+                        : reinterpret_cast<uint32_t *>(&sh.cand_d[0][0]);        // 4096 bins; cand_d is idle between runs
     SelBuf &sb = *reinterpret_cast<SelBuf *>(&sh.ring[0]);           // the ring is idle between runs too
-    static_assert(sizeof(sh.cand_d) >= 4096 * sizeof(uint32_t), "histogram does not fit");
+    static_assert(R3 || sizeof(sh.cand_d) >= 4096 * sizeof(uint32_t), "histogram does not fit");
     uint32_t done_bits = 0;   // (done_bits, done_j): key bits / index of the last tile already considered
     int done_j = -1;
     // SHORT LIST (round 5).  A selection round sweeps the scratch row four times (three histogram levels + the collection): at
@@ -768,7 +1056,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
         // the round's tiles leave the ring before the stream takes it back
         for (int q = threadIdx.x; q < ns; q += STB_THREADS) { sh.run_j[q] = sb.surv_j[q]; sh.run_vb[q] = sb.surv_vb[q]; }
         __syncthreads();   // hist (cand_d) and the sort buffers (ring) are idle again: the stream may run
-        run(ns, [&](int q) { return sh.run_j[q]; }, [&](int q) { return sh.run_vb[q]; });
+        run_tiles(ns, [&](int q) { return sh.run_j[q]; }, [&](int q) { return sh.run_vb[q]; });
         done_bits = round_last_bits;
         done_j = round_last_j;
         __syncthreads();
@@ -782,7 +1070,7 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
     // neighbour's d^2); their exact float32 distances sum (x - y)^2 decide which K are handed on, and in which order
     if (threadIdx.x == 0) sh.nsurv = 0;
     {
-        float *ex = &sh.cand_d[0][0];   // [ST_T][KMAX] exact d^2 (cand_d is idle now; row stride KMAX <= ST_SLAB + 1)
+        float *ex = R3 ? &sh.ring[0] : &sh.cand_d[0][0];   // [ST_T][KMAX] exact d^2 (cand_d -- R3: the ring -- is idle now; row stride KMAX <= ST_SLAB + 1)
         for (int q = threadIdx.x; q < ST_T * KL; q += STB_THREADS) {
             const int row = q / KL, e = q - row * KL;
             const int32_t cc = sh.list_c[row][e];
@@ -866,6 +1154,17 @@ template <int DIM, int KMAX, bool JOIN = false> __global__ __launch_bounds__(STB
 #endif
 }
 
+// the three-slot form (R3): 128 dimensions, 16-entry lists, tile phase and queries (not the join passes)
+template <int DIM, int KMAX> static int launchb3(annchor_ctx *c, const KnnArgs &a)
+{
+    const size_t lds = sizeof(KnnSharedB<DIM, KMAX, true>);
+    ANN_REQUIRE(c, lds <= 80 * 1024, ANNCHOR_ELIMIT, "streamed k-NN (three-slot form) needs %zu B of LDS", lds);
+    ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knnbf<DIM, KMAX, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_st_knnbf<DIM, KMAX, false, true><<<a.tile_count, STB_THREADS, lds, c->stream>>>(a);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}
+
 template <int DIM, int KMAX> static int launchb(annchor_ctx *c, const KnnArgs &a, bool join)
 {
     const size_t lds = sizeof(KnnSharedB<DIM, KMAX>);
@@ -889,6 +1188,8 @@ int ann_stream_launch_knnbf(annchor_ctx *c, const KnnArgs &a, int dim_padded, bo
     *handled = true;
     if (a.K + ST_BF_MARGIN > ST_KMAX || !a.Xb || !a.rsb || !a.cvec) { *handled = false; return ANNCHOR_OK; }
     const bool k16 = a.K + ST_BF_MARGIN <= 16;
+    static const char *kern = getenv("ANNCHOR_ST_KERNEL");
+    if (kern && !strcmp(kern, "bf3") && !join && k16 && dim_padded == 128) return launchb3<128, 16>(c, a);
     switch (dim_padded) {
     case 32: return k16 ? launchb<32, 16>(c, a, join) : launchb<32, ST_KMAX>(c, a, join);
     case 64: return k16 ? launchb<64, 16>(c, a, join) : launchb<64, ST_KMAX>(c, a, join);
