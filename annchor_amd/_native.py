@@ -132,6 +132,11 @@ _SIGNATURES = {
     "annchor_comm_unique_id": (ctypes.c_int, [_vp]),
     "annchor_comm_init": (ctypes.c_int, [_vp, _vp, _i32, _i32]),
     "annchor_comm_destroy": (ctypes.c_int, [_vp]),
+    "annchor_comm_set_timeout": (ctypes.c_int, [_vp, ctypes.c_double]),
+    "annchor_comm_preflight": (ctypes.c_int, [_vp, ctypes.c_double]),
+    "annchor_comm_init_side": (ctypes.c_int, [_vp, _vp]),
+    "annchor_comm_allgather_begin": (ctypes.c_int, [_vp, _vp, _vp, _i64]),
+    "annchor_comm_side_join": (ctypes.c_int, [_vp]),
     "annchor_comm_allgather": (ctypes.c_int, [_vp, _vp, _vp, _i64]),
     "annchor_comm_alltoall_records": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32]),
     "annchor_stream_anchor_rounds": (ctypes.c_int, [_vp, _i32]),
@@ -881,6 +886,22 @@ class Engine:
 
     def comm_destroy(self):
         self._chk(self.lib.annchor_comm_destroy(self.h))
+
+    def comm_set_timeout(self, seconds):
+        self._chk(self.lib.annchor_comm_set_timeout(self.h, float(seconds)))
+
+    def comm_preflight(self, seconds=60.0):
+        self._chk(self.lib.annchor_comm_preflight(self.h, float(seconds)))
+
+    def comm_init_side(self, unique_id):
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._chk(self.lib.annchor_comm_init_side(self.h, buf))
+
+    def comm_allgather_begin(self, send, recv, nbytes):
+        self._chk(self.lib.annchor_comm_allgather_begin(self.h, send, recv, int(nbytes)))
+
+    def comm_side_join(self):
+        self._chk(self.lib.annchor_comm_side_join(self.h))
 
     def comm_allgather(self, send, recv, nbytes):
         self._chk(self.lib.annchor_comm_allgather(self.h, send, recv, int(nbytes)))

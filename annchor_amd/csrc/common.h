@@ -91,6 +91,17 @@ struct annchor_ctx {
     // ---- in-library RCCL communicator (comm.hip): ncclComm_t, set by annchor_comm_init
     void *comm = nullptr;
     int comm_world = 1, comm_rank = 0;
+    // a second communicator on its own stream for ONE large all-gather that overlaps the engine stream's work (the raw rows of the
+    // row-sharded build beside the anchor rounds and the k-d order); comm_side_pending: the engine stream has not waited for it yet
+    void *comm_side = nullptr;
+    hipStream_t comm_side_stream = nullptr;
+    hipEvent_t comm_side_ev = nullptr, comm_main_ev = nullptr;
+    bool comm_side_pending = false;
+    // dead-peer guard: host waits of a context with a communicator run under a watchdog (comm.hip) that aborts the communicators
+    // when a wait lasts longer than comm_timeout_s (a peer that never enters a collective leaves RCCL's kernel spinning forever)
+    double comm_timeout_s = 300.0;
+    bool comm_aborted = false;
+    void *comm_watch = nullptr;
 
     // ---- anchors
     int na = 0, nA = 0;

@@ -11,6 +11,7 @@ static std::string g_create_err;
 void ann_stream_release(annchor_ctx *c);
 void ann_enemies_release(annchor_ctx *c);
 void ann_comm_release(annchor_ctx *c);
+hipError_t ann_comm_guarded_sync(annchor_ctx *c, hipStream_t stream, const char *where);   // comm.hip
 
 const char *ann_set_err(annchor_ctx *c, const char *fmt, ...)
 {
@@ -19,6 +20,8 @@ const char *ann_set_err(annchor_ctx *c, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
+    // (a collective's timeout is the cause of whatever HIP reports after the communicator's abort: keep saying so)
+    if (c && c->comm_aborted && c->err.rfind("collective timed out", 0) == 0) return c->err.c_str();
     if (c) c->err = buf; else g_create_err = buf;
     return c ? c->err.c_str() : g_create_err.c_str();
 }
@@ -243,7 +246,7 @@ hipError_t ann_sync(annchor_ctx *c, const char *where)
         (void)ann_legacy_generate_upto(c->idle_gen_seed, c->idle_gen_n, c->idle_gen_done);
     }
     const long long t_w = timing ? ann_now_ns() : 0;
-    const hipError_t rc = hipStreamSynchronize(c->stream);
+    const hipError_t rc = c->comm ? ann_comm_guarded_sync(c, c->stream, where) : hipStreamSynchronize(c->stream);
     if (timing) fprintf(stderr, "T wait %s %lld %lld %lld\n", where, t_in, t_w, ann_now_ns());
     if (c->lev_ap_probe_epoch) ann_lev_ap_probe(c);
     return rc;

@@ -277,9 +277,12 @@ extern "C" int annchor_stream_rows_end(annchor_ctx *c, int32_t world, const int6
     const size_t row_bytes = sizeof(float) * (size_t)s->dim;
     s->own_base = s->base;
     s->own_n = s->n_local;
+    // (the rows' all-gather may still be running on the side stream -- annchor_comm_allgather_begin --: the engine stream waits
+    // for it where it first touches the gathered rows: here when they must be compacted, else in annchor_stream_order_end)
     if (total == most * world) {
         std::swap(s->X, s->rows_recv);            // already contiguous
     } else {
+        ANN_TRY(ann_comm_side_join(c));
         ANN_TRY(ann_stream_reserve(c, s->rows_all, row_bytes * (size_t)total));
         int64_t at = 0;
         for (int r = 0; r < world; ++r) {
@@ -303,7 +306,7 @@ extern "C" int annchor_stream_rows_end(annchor_ctx *c, int32_t world, const int6
         // all-gather has read it by now -- stream order -- so D can be re-reserved)
         // (D may have been the all-gather's send buffer and the collective runs asynchronously on this stream under RCCL: it must
         // have read D before D's block is let go -- the parked-block pool would hand it out again without a device-wide wait)
-        ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        ANN_CHECK_HIP(c, ann_stream_wait(c, __func__));
         ANN_TRY(ann_stream_reserve(c, s->D, sizeof(float) * (size_t)s->na * (size_t)total));
         ProfScope ps(c, "stream_anchor_dists_assemble", (double)total * s->na * 8.0);
         int64_t at = 0;
@@ -317,6 +320,7 @@ extern "C" int annchor_stream_rows_end(annchor_ctx *c, int32_t world, const int6
         ANN_CHECK_HIP(c, hipGetLastError());
         return ANNCHOR_OK;
     }
+    ANN_TRY(ann_comm_side_join(c));   // (the recomputation reads every row)
     ANN_TRY(ann_stream_reserve(c, s->D, sizeof(float) * (size_t)s->na * (size_t)total));
     {
         ProfScope ps(c, "stream_all_anchor_distances", (double)total * (s->dim * 4.0 + s->na * 4.0));
@@ -487,7 +491,7 @@ extern "C" int annchor_stream_route_begin(annchor_ctx *c, int32_t world, const i
     ANN_TRY(ann_stream_reserve(c, s->route_slot, (sizeof(int64_t) + sizeof(int32_t)) * (size_t)rows));
     ANN_TRY(ann_stream_reserve(c, s->route_send, sizeof(int64_t) * (size_t)rows * W));
     ANN_CHECK_HIP(c, hipMemcpyAsync(s->route_tab.p, &tab, sizeof(tab), hipMemcpyHostToDevice, c->stream));
-    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));   // `tab` lives on this stack frame
+    ANN_CHECK_HIP(c, ann_stream_wait(c, __func__));   // `tab` lives on this stack frame
     unsigned long long *cnt = s->route_cnt.as<unsigned long long>(), *cursor = cnt + SH_MAX_WORLD;
     int64_t *slot = s->route_slot.as<int64_t>();
     int32_t *dest = reinterpret_cast<int32_t *>(slot + rows);

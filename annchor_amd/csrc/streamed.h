@@ -128,6 +128,14 @@ struct KnnArgs {
 };
 
 StreamState *ann_stream_state(annchor_ctx *c, bool create);
+// comm.hip: hipStreamSynchronize under the dead-peer watchdog; the engine stream's wait for a side-stream all-gather in flight
+hipError_t ann_comm_guarded_sync(annchor_ctx *c, hipStream_t stream, const char *where);
+int ann_comm_side_join(annchor_ctx *c);
+// every host wait of the streamed form: guarded when the context holds a communicator (a dead peer must not block it for good)
+inline hipError_t ann_stream_wait(annchor_ctx *c, const char *where)
+{
+    return c->comm ? ann_comm_guarded_sync(c, c->stream, where) : hipStreamSynchronize(c->stream);
+}
 // knnbf.hip: the tile phase on the 16-bit matrix cores (split operands, two 4-wave workgroups per CU); *handled = false
 // when the shape does not fit it (padded dim > 128, more than 30 neighbours, no split copy) and the caller launches k_st_knn
 int ann_stream_launch_knnbf(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled, bool join = false);

@@ -106,7 +106,7 @@ extern "C" int annchor_stream_bind(annchor_ctx *c, const float *X, int64_t n_loc
     const size_t bytes = sizeof(float) * (size_t)n_local * dim;
     ANN_TRY(sreserve(c, s->X, bytes));
     ANN_CHECK_HIP(c, hipMemcpyAsync(s->X.p, X, bytes, x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    ANN_CHECK_HIP(c, ann_stream_wait(c, __func__));
     ANN_TRY(sreserve(c, s->avec, sizeof(float) * 1024));
     ANN_TRY(sreserve(c, s->runmin, sizeof(float) * (size_t)n_local));
     c->metric = ANNCHOR_METRIC_EUCLIDEAN_F32;
@@ -224,6 +224,7 @@ extern "C" int annchor_stream_get_row(annchor_ctx *c, int64_t local_idx, float *
     StreamState *s = state_of(c, false);
     ANN_REQUIRE(c, s && local_idx >= 0 && local_idx < s->n_local, ANNCHOR_EINVAL, "row out of range");
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
+    ANN_TRY(ann_comm_side_join(c));
     return ann_d2h(c, out, s->X.as<float>() + (size_t)local_idx * s->dim, sizeof(float) * (size_t)s->dim);
 }
 
@@ -619,6 +620,7 @@ extern "C" int annchor_stream_order_end(annchor_ctx *c, void **Xs, void **rs, vo
     ANN_TRY(sreserve(c, s->lo, sizeof(float) * (size_t)s->na * s->nt));
     ANN_TRY(sreserve(c, s->hi, sizeof(float) * (size_t)s->na * s->nt));
     ANN_TRY(sreserve(c, s->mid, sizeof(float) * (size_t)s->na * s->nt));
+    ANN_TRY(ann_comm_side_join(c));   // the gathered rows (their all-gather may have run beside the anchor rounds and the ordering)
     {
         // every rank holds every row as a column: this part is per rank whatever the number of ranks
         ProfScope ps(c, "stream_order_gather_rows", (double)n * (s->dim * 4.0 + s->dimp * 8.0 + s->na * 4.0 + 16.0));
@@ -629,7 +631,7 @@ extern "C" int annchor_stream_order_end(annchor_ctx *c, void **Xs, void **rs, vo
         ANN_TRY(ann_stream_split_rows(c, s));   // the fp16 hi / lo copy the tile kernels stream (knnbf.hip, knnbk.hip)
     }
     ANN_CHECK_HIP(c, hipGetLastError());
-    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    ANN_CHECK_HIP(c, ann_stream_wait(c, __func__));
     *Xs = s->Xs.p; *rs = s->rs.p; *perm = s->perm.p; *lo = s->lo.p; *hi = s->hi.p; *mid = s->mid.p;
     *n_pad = s->n_pad; *n_tiles = s->nt; *dim_padded = s->dimp;
     return ANNCHOR_OK;
@@ -2293,7 +2295,7 @@ extern "C" int annchor_stream_knn_begin(annchor_ctx *c, const void *Xs_all, cons
     if (rc != ANNCHOR_OK) { ann_stream_free_run(s); return rc; }
     s->run_perm = perm_all;
     s->run_dimp = dim_padded;
-    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    ANN_CHECK_HIP(c, ann_stream_wait(c, __func__));
     *lists_local = a->out_col;
     *lists_bytes = (int64_t)sizeof(int32_t) * tile_count * ST_T * (k - 1);
     return ANNCHOR_OK;
@@ -2307,7 +2309,7 @@ extern "C" int annchor_stream_knn_join(annchor_ctx *c, const void *lists_all, in
     ANN_REQUIRE(c, s && s->run, ANNCHOR_ESTATE, "annchor_stream_knn_begin not called");
     ANN_REQUIRE(c, per_pass >= 1, ANNCHOR_EINVAL, "per_pass must be >= 1");
     ANN_TRY(knn_join_pass(c, s, *s->run, s->run_dimp, (const int32_t *)lists_all, per_pass, updates));
-    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    ANN_CHECK_HIP(c, ann_stream_wait(c, __func__));
     *lists_local = s->run->out_col;
     return ANNCHOR_OK;
 }
@@ -2329,7 +2331,7 @@ extern "C" int annchor_stream_join_rev_begin(annchor_ctx *c, const void *lists_a
     ANN_TRY(sreserve(c, s->rev_all, sizeof(int32_t) * (size_t)n_all * JN_RK));
     ANN_TRY(sreserve(c, s->rev_slice, sizeof(int32_t) * (size_t)std::max<int64_t>(ncols, 1) * JN_RK));
     ANN_TRY(knn_reverse_lists(c, s, (const int32_t *)lists_all, n_all, a.K, col0, ncols, s->rev_slice.as<int32_t>()));
-    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    ANN_CHECK_HIP(c, ann_stream_wait(c, __func__));
     s->rev_gathered = true;
     *rev_local = s->rev_slice.p;
     *rev_all = s->rev_all.p;
@@ -2412,7 +2414,7 @@ extern "C" int annchor_stream_join_tables(annchor_ctx *c, const void *gathered, 
     const int64_t tot = (int64_t)world * n_anchors * n_tiles;
     k_st_join_tables<<<ann_blocks(tot, 256), 256, 0, c->stream>>>((const float *)gathered, world, n_anchors, n_tiles, (float *)joined);
     ANN_CHECK_HIP(c, hipGetLastError());
-    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    ANN_CHECK_HIP(c, ann_stream_wait(c, __func__));
     return ANNCHOR_OK;
 }
 
@@ -2439,6 +2441,6 @@ extern "C" int annchor_device_copy(annchor_ctx *c, void *dst, const void *src, i
     ANN_CHECK_HIP(c, hipSetDevice(c->device));
     hipMemcpyKind kk = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     ANN_CHECK_HIP(c, hipMemcpyAsync(dst, src, (size_t)bytes, kk, c->stream));
-    ANN_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    ANN_CHECK_HIP(c, ann_stream_wait(c, __func__));
     return ANNCHOR_OK;
 }

@@ -27,6 +27,8 @@ One process per GPU, rows sharded contiguously: rank r owns rows
 
 With one rank the collectives are no-ops and no torch import happens.
 """
+import os
+
 import numpy as np
 
 TILE = 128
@@ -152,24 +154,48 @@ class RcclComm:
     """Collectives from INSIDE the library (csrc/comm.hip: RCCL loaded with dlopen, enqueued on the engine's stream by the same
     C calls that enqueue the kernels): no torch on the data path, and the anchor rounds of a fit are one C call.  The
     communicator needs a 128-byte id made on one rank (`_native.comm_unique_id()`) and handed to the others --
-    `RcclComm.from_torch(engine)` does that over an existing torch.distributed group of any backend (128 bytes, once)."""
+    `RcclComm.from_torch(engine)` does that over an existing torch.distributed group of any backend (128 bytes, once).
+
+    `side_id`: a second id for a second communicator on a stream of its own -- the rows' all-gather of a fit then runs beside
+    the anchor rounds and the k-d order (`allgather_begin`; csrc/comm.hip).  `preflight`: a checked 1 KB all-gather on every
+    communicator under its own timeout (a mis-wired job fails here, loudly).  `timeout`: host waits of the engine longer than
+    this abort the communicators and raise (a dead peer rank no longer blocks the others for good; default 300 s,
+    ANNCHOR_COMM_TIMEOUT_S)."""
 
     backend = "rccl"
 
-    def __init__(self, engine, world, rank, unique_id):
+    def __init__(self, engine, world, rank, unique_id, side_id=None, preflight=60.0, timeout=None):
         self.engine, self.world, self.rank = engine, int(world), int(rank)
+        self._small = 0
         engine.comm_init(unique_id, world, rank)
-        self._small = engine.device_alloc(8 * 64 * (self.world + 1))
+        try:
+            if timeout is not None:
+                engine.comm_set_timeout(timeout)
+            self.overlap = False
+            if side_id is not None and os.environ.get("ANNCHOR_COMM_OVERLAP", "1") != "0":
+                engine.comm_init_side(side_id)
+                self.overlap = True
+            if preflight:
+                engine.comm_preflight(preflight)
+            self._small = engine.device_alloc(8 * 64 * (self.world + 1))
+        except Exception:
+            engine.comm_destroy()
+            raise
 
     @classmethod
-    def from_torch(cls, engine, group=None):
+    def from_torch(cls, engine, group=None, **kw):
         import torch.distributed as dist
         from . import _native
 
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [_native.comm_unique_id() if rank == 0 else None]
+        box = [(_native.comm_unique_id(), _native.comm_unique_id()) if rank == 0 else None]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        return cls(engine, world, rank, box[0])
+        return cls(engine, world, rank, box[0][0], side_id=box[0][1], **kw)
+
+    def allgather_begin(self, engine, src, dst, nbytes):
+        """The all-gather on the side communicator's stream, beside whatever the engine enqueues next; the library waits for it
+        where it first needs the result (annchor_stream_rows_end / _order_end)."""
+        engine.comm_allgather_begin(src, dst, nbytes)
 
     def close(self):
         if self._small:
@@ -199,6 +225,47 @@ class RcclComm:
         recv = engine.stream_route_recv(n_recv)
         engine.comm_alltoall_records(send, np.asarray(send_counts, dtype=np.int64), recv, recv_counts, words)
         return recv, n_recv
+
+
+def make_comm(engine=None, group=None, prefer=None, verbose=True):
+    """The communicator of a multi-rank build for the current torch.distributed job (one rank / no job: SingleComm).
+
+    `nccl` groups (RCCL over xGMI): the collectives run from INSIDE the library on `engine` (RcclComm: two communicators,
+    pre-flight, dead-peer timeout) -- the default when an engine is given; if RCCL cannot be loaded, a communicator cannot be
+    made or the pre-flight fails ON ANY RANK, every rank falls back to torch.distributed on device pointers (TorchComm) and
+    says so.  Other backends (gloo: CPU tests, rehearsals on one GPU) use TorchComm.  `prefer` / ANNCHOR_COMM = "torch" | "rccl"
+    overrides.  The torch path's collectives are guarded by torch.distributed's own timeout (init_process_group(timeout=...))."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return SingleComm()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return SingleComm()
+    prefer = prefer or os.environ.get("ANNCHOR_COMM")
+    want_rccl = dist.get_backend(group) == "nccl" and engine is not None and prefer != "torch"
+    if prefer == "rccl" and not want_rccl:
+        raise RuntimeError("ANNCHOR_COMM=rccl needs an nccl process group and an engine")
+    if not want_rccl:
+        return TorchComm(group)
+    import torch
+
+    comm, err = None, ""
+    try:
+        comm = RcclComm.from_torch(engine, group)
+    except Exception as e:   # dlopen / ncclCommInitRank / pre-flight
+        err = "%s: %s" % (type(e).__name__, e)
+    ok = torch.tensor([1.0 if comm is not None else 0.0], device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if float(ok.item()) >= 1.0:
+        return comm
+    if comm is not None:
+        comm.close()
+    if verbose and (err or dist.get_rank(group) == 0):
+        print("annchor: in-library RCCL communicator not available on every rank%s; falling back to torch.distributed collectives"
+              % ((" (this rank: %s)" % err) if err else ""), flush=True)
+    if prefer == "rccl":
+        raise RuntimeError("ANNCHOR_COMM=rccl: the in-library communicator could not be made (%s)" % (err or "another rank failed"))
+    return TorchComm(group)
 
 
 class _CAI:
@@ -326,18 +393,25 @@ class StreamedAnnchor:
                 out = GraphBuffers(self.n_local, self.n_neighbors)
             except ImportError:   # (the CPU protocol tests run against a stand-in engine without the library)
                 out = None
-        self.get_anchors()
-        t1 = time.perf_counter()
         sharded = comm.world > 1 or self.force_exchange
         counts = np.array([n for _, n in self.shards], dtype=np.int64)
+        rows_early = sharded and getattr(comm, "overlap", False) and hasattr(eng, "comm_allgather_begin")
+        if rows_early:
+            # the rows' all-gather (half of a fit's collective bytes) starts NOW, on the side communicator's stream: it runs beside
+            # the anchor rounds, the anchor distances' all-gather and the k-d order -- none of them reads the gathered rows
+            send, recv, nbytes = eng.stream_rows_begin(counts)
+            comm.allgather_begin(eng, send, recv, nbytes)
+        self.get_anchors()
+        t1 = time.perf_counter()
         if sharded:
             # ONE tile structure for the whole data set, whatever the number of ranks: every rank gets all rows
             # (one all-gather of the resident shards; it needs them as columns anyway), recomputes their anchor
             # distances from the anchors it already knows (one pass, no collective) and orders them itself; the ranks
             # then own contiguous ranges of the GLOBAL tile order.  Ordering each shard separately (round 1) made a
             # tile's cell G times larger -- recall at N = 400 000 fell from 0.990 (1 rank) to 0.968 (2) and 0.942 (4).
-            send, recv, nbytes = eng.stream_rows_begin(counts)
-            comm.allgather_into(eng, send, recv, nbytes)
+            if not rows_early:
+                send, recv, nbytes = eng.stream_rows_begin(counts)
+                comm.allgather_into(eng, send, recv, nbytes)
             # the anchor distances of the own rows (the max-min sweeps left them on the device): ONE all-gather of
             # n_anchors floats per row instead of every rank recomputing every row's
             send, recv, nbytes = eng.stream_anchor_dists_begin(counts)

@@ -233,17 +233,24 @@ def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, r
     from annchor_amd.streamed import SingleComm, StreamedAnnchor, TorchComm
 
     X = euclid_shard(rank, n_per_rank)
-    comm = TorchComm() if world > 1 else SingleComm()
-    shared_engine = None
-    if world > 1 and os.environ.get("ANNCHOR_BENCH_COMM") == "rccl" and dist_mod.get_backend() == "nccl":
-        # opt-in: the collectives from inside the library (csrc/comm.hip) on ONE engine kept for all fits; torch.distributed
-        # only hands the 128-byte communicator id around.  (Default: torch.distributed on device pointers -- neither path has
-        # run with more than one GPU yet; this one takes Python out of the 32 anchor rounds.)
-        from annchor_amd import _native
-        from annchor_amd.streamed import RcclComm
+    # multi-rank: ONE engine kept for all fits and the collectives from inside the library on it (csrc/comm.hip: RCCL on the engine's
+    # stream, a second communicator for the rows' all-gather beside the anchor rounds, pre-flight, dead-peer timeout); if that
+    # cannot be set up on every rank, torch.distributed on device pointers (make_comm says so).  ANNCHOR_BENCH_COMM=torch forces
+    # the torch path.  Neither has run on more than one GPU before the driver's scaling run.
+    from annchor_amd.streamed import make_comm
 
-        shared_engine = _native.Engine(local)
-        comm = RcclComm.from_torch(shared_engine)
+    comm, shared_engine = SingleComm(), None
+    if world > 1:
+        if dist_mod.get_backend() == "nccl" and os.environ.get("ANNCHOR_BENCH_COMM") != "torch":
+            from annchor_amd import _native
+
+            shared_engine = _native.Engine(local)
+            comm = make_comm(shared_engine)
+            if getattr(comm, "backend", "") != "rccl":
+                shared_engine.close()
+                shared_engine = None
+        else:
+            comm = TorchComm()
     k, pw, na = 15, 0.1, 32
     times, last = [], None
     red_dev = "cuda" if (dist_mod is not None and dist_mod.get_backend() == "nccl") else "cpu"

@@ -471,6 +471,22 @@ int annchor_stream_anchor_step(annchor_ctx *ctx, const void *gathered, int32_t w
 int annchor_comm_unique_id(uint8_t *id128);
 int annchor_comm_init(annchor_ctx *ctx, const uint8_t *id128, int32_t world, int32_t rank);
 int annchor_comm_destroy(annchor_ctx *ctx);
+/* Robustness of a multi-rank job (no reference counterpart: the reference has no collectives):
+ *   annchor_comm_set_timeout   host waits of a context with a communicator run under a watchdog: one that lasts longer than
+ *                              `seconds` (default 300; ANNCHOR_COMM_TIMEOUT_S; <= 0: off) aborts the communicators
+ *                              (ncclCommAbort) and the call fails with "collective timed out" -- a dead peer no longer blocks
+ *                              the other ranks for good
+ *   annchor_comm_preflight     1 KB all-gather of (rank, position) bytes on every communicator of the context, checked, under
+ *                              a timeout of its own: a mis-wired job fails here, loudly
+ *   annchor_comm_init_side     a second communicator (its own 128-byte id) on a stream of its own
+ *   annchor_comm_allgather_begin   ONE large all-gather beside the engine stream's work (the raw rows of the row-sharded
+ *                              build beside the anchor rounds and the k-d order); the library waits for it where it first needs
+ *                              the rows (annchor_stream_rows_end / _order_end); annchor_comm_side_join for other users */
+int annchor_comm_set_timeout(annchor_ctx *ctx, double seconds);
+int annchor_comm_preflight(annchor_ctx *ctx, double seconds);
+int annchor_comm_init_side(annchor_ctx *ctx, const uint8_t *id128);
+int annchor_comm_allgather_begin(annchor_ctx *ctx, const void *send, void *recv, int64_t nbytes);
+int annchor_comm_side_join(annchor_ctx *ctx);
 int annchor_comm_allgather(annchor_ctx *ctx, const void *send, void *recv, int64_t nbytes);
 int annchor_comm_alltoall_records(annchor_ctx *ctx, const void *send, const int64_t *send_counts, void *recv,
                                   const int64_t *recv_counts, int32_t words);

@@ -575,6 +575,64 @@ def test_in_library_rccl_single_rank():
         eng.close()
 
 
+def test_in_library_rccl_side_communicator_preflight_and_overlap():
+    """RcclComm with a second communicator on a stream of its own: the pre-flight (a checked 1 KB all-gather on both communicators),
+    then a fit whose rows' all-gather is started BEFORE the anchor rounds on the side stream (`allgather_begin`) and joined where
+    the library first reads the gathered rows -- equal shards (joined in annchor_stream_order_end) and a shard that is not the largest
+    of the declared counts cannot be made with one rank, so the compaction branch is exercised through annchor_comm_side_join by
+    hand.  Same graph as the collective-free build; two fits on the same engine."""
+    from annchor_amd import _native
+    from annchor_amd.streamed import RcclComm, StreamedAnnchor
+
+    X = latent(6000, 128)
+    eng = _native.Engine(0)
+    comm = RcclComm(eng, 1, 0, _native.comm_unique_id(), side_id=_native.comm_unique_id(), preflight=30.0, timeout=120.0)
+    try:
+        assert comm.overlap
+        b = StreamedAnnchor(X, n_anchors=8, n_neighbors=10, p_work=0.5).fit()
+        for _ in range(2):
+            a = StreamedAnnchor(X, n_anchors=8, n_neighbors=10, p_work=0.5, comm=comm, engine=eng, force_exchange=True).fit()
+            assert np.array_equal(a.A, b.A)
+            assert np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0])
+            assert np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1])
+        # the side all-gather by hand: begin, other work on the engine stream, join, read
+        n = 1 << 20
+        src, dst = eng.device_alloc(n), eng.device_alloc(n)
+        host = np.arange(n, dtype=np.uint8)
+        eng.device_copy(src, host.ctypes.data, n, "h2d")
+        comm.allgather_begin(eng, src, dst, n)
+        eng.comm_side_join()
+        out = np.zeros(n, dtype=np.uint8)
+        eng.device_copy(out.ctypes.data, dst, n, "d2h")
+        assert np.array_equal(out, host)
+        eng.device_free(src); eng.device_free(dst)
+    finally:
+        comm.close()
+        eng.close()
+
+
+def test_in_library_rccl_dead_peer_guard():
+    """A host wait of an engine with a communicator that lasts longer than the timeout aborts the communicators and raises
+    "collective timed out" instead of blocking for good (csrc/comm.hip: the watchdog armed around every host wait).  A peer cannot be
+    killed on one GPU, so the wait is made long instead: a 2 x 10^6-row build's tile phase against a 20 ms limit."""
+    from annchor_amd import _native
+    from annchor_amd.streamed import RcclComm, StreamedAnnchor
+
+    X = latent(2_000_000, 128)
+    eng = _native.Engine(0)
+    comm = RcclComm(eng, 1, 0, _native.comm_unique_id(), preflight=30.0)
+    try:
+        eng.comm_set_timeout(0.02)
+        with pytest.raises(Exception, match="collective timed out"):
+            StreamedAnnchor(X, n_anchors=32, n_neighbors=15, p_work=0.1, comm=comm, engine=eng, force_exchange=True).fit()
+    finally:
+        try:
+            comm.close()
+        except Exception:
+            pass
+        eng.close()
+
+
 def test_streamed_query_matches_brute_force():
     """Annchor.query for the streamed form: exact with the full budget; with a partial budget the
     recall depends on how dense the query batch is (the budget is spent per 128-query tile)."""

@@ -145,3 +145,57 @@ def test_non_contiguous_shard_bases_map_back():
     assert np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0] + 1000)
     assert np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1])
     assert np.array_equal(a.A, b.A + 1000)
+
+
+def _worker_early(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fake_stream_engine import FakeStreamEngine
+    from annchor_amd.streamed import StreamedAnnchor, TorchComm, make_comm
+
+    class EarlyRows(TorchComm):   # the shape of RcclComm's side communicator: the rows' gather is asked for before the anchor rounds
+        overlap = True
+        begun = 0
+
+        def allgather_begin(self, engine, src, dst, nbytes):
+            self.begun += 1
+            self.allgather_into(engine, src, dst, nbytes)
+
+    assert isinstance(make_comm(), TorchComm)          # a gloo job: torch.distributed on host copies
+    eng = FakeStreamEngine()
+    eng.comm_allgather_begin = None                     # (an engine that has the side path)
+    cuts = [0, 410, 700]   # (ragged shards: the send buffer is a padded copy)
+    X = _data()
+    comm = EarlyRows()
+    sa = StreamedAnnchor(X[cuts[rank]:cuts[rank + 1]], n_anchors=6, n_neighbors=5, p_work=1.0, random_seed=42, base=cuts[rank], comm=comm,
+                         engine=eng).fit()
+    assert comm.begun == 1
+    gi, gd = sa.gather_graph()
+    if rank == 0:
+        np.savez(out, A=sa.A, idx=gi, dist=gd)
+    dist.destroy_process_group()
+
+
+def test_rows_gather_started_before_the_anchor_rounds(tmp_path):
+    """fit() with a communicator that can run the rows' all-gather beside the anchor rounds (RcclComm's side communicator,
+    csrc/comm.hip) asks for it FIRST -- stream_rows_begin + allgather_begin, then the rounds, the anchor distances' gather and the
+    ordering -- and gives the graph of the one-rank build; make_comm() picks TorchComm for a gloo job and SingleComm without one."""
+    import torch.multiprocessing as mp
+
+    from fake_stream_engine import FakeStreamEngine
+    from annchor_amd.streamed import SingleComm, StreamedAnnchor, make_comm
+
+    assert isinstance(make_comm(), SingleComm)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "early.npz")
+    mp.spawn(_worker_early, args=(2, port, out), nprocs=2, join=True)
+    R = np.load(out)
+    one = StreamedAnnchor(_data(), n_anchors=6, n_neighbors=5, p_work=1.0, random_seed=42, engine=FakeStreamEngine()).fit()
+    assert np.array_equal(R["A"], one.A)
+    assert np.array_equal(R["idx"], one.neighbor_graph[0])
+    np.testing.assert_allclose(R["dist"], one.neighbor_graph[1], rtol=0, atol=0)
