@@ -1146,6 +1146,7 @@ template <int DIM, int KMAX, bool JOIN = false, bool R3 = false> __global__ __la
     } else if (threadIdx.x == 0) {
         atomicAdd(a.evals, (unsigned long long)processed);
         if (sh.nsurv) atomicAdd(a.evals + 3, (unsigned long long)sh.nsurv);   // slot 3: rows flagged by the guard
+        if (a.guard_tiles) a.guard_tiles[bt] = (uint32_t)sh.nsurv;                // ... and per row tile: those are done again exactly (repair.hip)
     }
 #ifdef ST_PROFILE
     P8(7)

@@ -1922,6 +1922,9 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
         a.eval_bits = s->eval_bits.as<uint32_t>();
     }
     a.lists_all = nullptr; a.ucand = nullptr; a.ucount = nullptr; a.ucap = JN_CAP; a.out_d2_new = nullptr; a.out_col_new = nullptr;
+    ANN_TRY(sreserve(c, s->guard_tiles, sizeof(uint32_t) * (size_t)a.tile_count));
+    ANN_CHECK_HIP(c, hipMemsetAsync(s->guard_tiles.p, 0, sizeof(uint32_t) * (size_t)a.tile_count, c->stream));
+    a.guard_tiles = s->guard_tiles.as<uint32_t>();
     a.updates = nullptr;
     {
         // A row tile stops spending its tile budget when ST_EARLY_WINDOW consecutive ranked tiles replaced fewer
@@ -1955,6 +1958,7 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
         ANN_TRY(launch_by_dim(c, a, dim_padded, false));
     }
     s->last_guard_rows = 0;
+    s->last_repaired = false;
     if (s->last_kernel != 0) {
         // The split-fp16 kernel keeps K + 2 columns per row by a distance that is off by ~2^-22 |x||y| and re-ranks them exactly;
         // its epilogue counts the rows whose K-th exact distance comes within the MEASURED error of the list's last approximate
@@ -1969,7 +1973,21 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
         if (getenv("ANNCHOR_ST_VERBOSE")) fprintf(stderr, "annchor: tile phase fetched %llu column tiles\n", fl2[1]);
         s->last_guard_rows = (int64_t)flagged;
         static const bool no_fallback = getenv("ANNCHOR_ST_NO_FALLBACK") != nullptr;
-        if ((int64_t)flagged > std::max<int64_t>(8, rows / 200) && !no_fallback && dim_padded > 256) {
+        // (round 6) Every row tile that holds a flagged row is done again with float32 DIFFERENCES (repair.hip: the reference's own
+        // arithmetic, annchor/distances.py:8-13) over the column tiles it evaluated: exact whatever the conditioning and the
+        // dimension -- before, <= 1 row in 200 was let through, beyond that the phase was repeated on the exact-f32 MFMA kernel (the
+        // same expanded form in float32: not exact on such data either) and beyond 256 dimensions only a warning was printed.
+        // ANNCHOR_ST_FALLBACK=rerun keeps the old behaviour for A/B runs.
+        static const bool rerun = getenv("ANNCHOR_ST_FALLBACK") && !strcmp(getenv("ANNCHOR_ST_FALLBACK"), "rerun");
+        if (flagged > 0 && !no_fallback && !rerun) {
+            if ((int64_t)flagged > std::max<int64_t>(8, rows / 200))
+                fprintf(stderr, "annchor: streamed tile phase: %llu of %lld rows have neighbours closer together than float32-grade products of |x|^2 "
+                                "resolve (|x|^2 >> d^2); their row tiles are evaluated again with float32 differences (exact, slower)\n",
+                        flagged, (long long)rows);
+            ProfScope ps(c, "stream_tile_exact_repair", 0.0);
+            ANN_TRY(ann_stream_repair_flagged(c, a, dim_padded, a.guard_tiles));
+            s->last_repaired = true;
+        } else if ((int64_t)flagged > std::max<int64_t>(8, rows / 200) && !no_fallback && dim_padded > 256) {
             // (the exact-f32 tile kernel stops at padded dim 256: the caller sees the count through annchor_stream_last_kernel)
             fprintf(stderr, "annchor: streamed tile phase: %llu of %lld rows have neighbours closer together than float32-grade products of |x|^2 "
                             "resolve (|x|^2 >> d^2); beyond 256 dimensions there is no exact-f32 tile kernel to repeat the phase on -- the lists "

@@ -810,34 +810,41 @@ def test_split_fp16_tile_kernel_centres_the_rows():
     np.testing.assert_allclose(sa.neighbor_graph[1][rows], _truth_rows(X, rows, k), rtol=1e-5, atol=1e-6)
 
 
-def test_split_fp16_guard_falls_back_to_the_exact_kernel():
+def test_split_fp16_guard_repairs_flagged_rows_exactly(monkeypatch):
     """Tight clusters far from the centre (|x - c|^2 ~ 10^4 d^2): float32-grade products of |x|^2 (the split products are
-    good to ~2^-22 |x||y|, like the f32 MFMA stream) no longer resolve the neighbours' distances.  The kernel's guard -- K-th exact distance within twice the measured error of the
-    list's last approximate entry -- flags the rows, and the tile phase is repeated on the exact-f32 kernel; on
-    well-conditioned data of the same size nothing is flagged."""
+    good to ~2^-22 |x||y|, like the f32 MFMA stream) no longer resolve the neighbours' distances.  The kernel's guard -- K-th exact
+    distance within twice the measured error of the list's last approximate entry -- flags the rows, and their row tiles are done
+    again with float32 DIFFERENCES (csrc/repair.hip: the reference's np.linalg.norm(x - y), distances.py:8-13): the graph is the
+    float64 brute-force graph (no errors at all on 400 rows; the old fallback -- the phase repeated on the exact-f32 MFMA kernel,
+    ANNCHOR_ST_FALLBACK=rerun -- evaluates the same expanded form and was allowed 1 % errors here).  On well-conditioned data of
+    the same size nothing is flagged."""
     from annchor_amd import compare_neighbor_graphs
     from annchor_amd.streamed import StreamedAnnchor
 
+    monkeypatch.delenv("ANNCHOR_ST_FALLBACK", raising=False)
     rng = np.random.default_rng(3)
     n, k, d = 20000, 10, 16
     cent = rng.standard_normal((400, d)) * 30.0
     X = (cent[rng.integers(0, 400, n)] + 0.3 * rng.standard_normal((n, d))).astype(np.float32)
     sa = StreamedAnnchor(X, n_anchors=12, n_neighbors=k, p_work=1.0).fit()
     kind, flagged = sa._engine.stream_last_kernel(with_guard=True)
-    assert kind == 0 and flagged > n // 200, (kind, flagged)   # flagged, and re-run on the exact kernel
+    assert kind == 1 and flagged > n // 200, (kind, flagged)   # flagged by the split kernel, repaired in place
     rows = rng.choice(n, 400, replace=False)
     bd = _truth_rows(X, rows, k)
     err = compare_neighbor_graphs((sa.neighbor_graph[0][rows], bd), (sa.neighbor_graph[0][rows], sa.neighbor_graph[1][rows]), k)
-    assert err <= 0.01 * len(rows) * k, err
+    assert err == 0, err
+    np.testing.assert_allclose(sa.neighbor_graph[1][rows], bd, rtol=1e-5, atol=1e-6)
     good = StreamedAnnchor(latent(n, 64), n_anchors=12, n_neighbors=k, p_work=0.3).fit()
     kind, flagged = good._engine.stream_last_kernel(with_guard=True)
     assert kind == 1 and flagged <= n // 1000, (kind, flagged)
 
 
-def test_guard_beyond_256_dimensions_reports_instead_of_falling_back(capfd):
-    """Beyond 256 dimensions there is no exact-f32 tile kernel to repeat the tile phase on: ill-conditioned data (tight clusters far
-    from the centre) is reported -- the flagged-row count through annchor_stream_last_kernel, a warning on stderr -- and the build
-    goes on with the split kernel's lists; the reported distances are exact float32 as always."""
+def test_guard_beyond_256_dimensions_repairs_exactly():
+    """Beyond 256 dimensions there is no exact-f32 tile kernel: ill-conditioned data (tight clusters far from the centre) used to be
+    reported and returned from the split selection.  Now the flagged rows' row tiles are evaluated again with float32 differences
+    (csrc/repair.hip, any dimension): the graph equals the float64 brute force on the ill-conditioned set -- indices (no errors) and
+    distances at rtol 1e-5 -- for the graph build and for queries."""
+    from annchor_amd import compare_neighbor_graphs
     from annchor_amd.streamed import StreamedAnnchor
 
     rng = np.random.default_rng(3)
@@ -847,12 +854,21 @@ def test_guard_beyond_256_dimensions_reports_instead_of_falling_back(capfd):
     sa = StreamedAnnchor(X, n_anchors=10, n_neighbors=k, p_work=1.0).fit()
     kind, flagged = sa._engine.stream_last_kernel(with_guard=True)
     assert kind == 1
-    if flagged > n // 200:
-        assert "no exact-f32 tile kernel" in capfd.readouterr().err
     idx, dist = sa.neighbor_graph
-    rows = rng.choice(n, 200, replace=False)
+    rows = rng.choice(n, 300, replace=False)
+    bd = _truth_rows(X, rows, k)
+    err = compare_neighbor_graphs((idx[rows], bd), (idx[rows], dist[rows]), k)
+    assert err == 0, (err, flagged)
+    np.testing.assert_allclose(dist[rows], bd, rtol=1e-5, atol=1e-5)
     dd = np.sqrt(((X[idx[rows]].astype(np.float64) - X[rows].astype(np.float64)[:, None, :]) ** 2).sum(-1))
     np.testing.assert_allclose(dd, dist[rows], rtol=1e-5, atol=1e-5)
+    # queries: perturbed data rows against the same clusters
+    Q = (X[rows[:100]] + 0.01 * rng.standard_normal((100, d))).astype(np.float32)
+    qi, qd = sa.query(Q, nn=5, p_work=1.0)
+    Xd = X.astype(np.float64)
+    for t in range(100):
+        dq = np.sqrt(((Xd - Q[t].astype(np.float64)[None, :]) ** 2).sum(axis=1))
+        np.testing.assert_allclose(qd[t], np.sort(dq)[:5], rtol=1e-5, atol=1e-5)
 
 
 def _worker_dims(rank, world, port, out):
