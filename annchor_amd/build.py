@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libannchor_hip.so")
-SOURCES = ["ctx", "lev", "euclid", "emd", "picker", "scan", "locality", "features", "select", "refine", "state", "brute", "hostrng", "hostols", "streamed", "knnbf", "knnbk", "sharded", "model", "enemies", "comm", "repair"]
+SOURCES = ["ctx", "lev", "euclid", "emd", "picker", "scan", "locality", "features", "select", "refine", "state", "brute", "hostrng", "hostols", "streamed", "knnbf", "knnh", "knnbk", "sharded", "model", "enemies", "comm", "repair"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-ffp-contract=off"]
 
 

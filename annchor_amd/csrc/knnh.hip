@@ -1,0 +1,768 @@
+// knnh.hip -- the tile phase of the streamed k-NN build as a two-stage filter (k_st_knnh, round 6): fp16 matrix products
+// decide which column MAY belong to a row's list, float32 differences decide whether it does.
+//
+// What the round's measurements say about k_st_knnbf (knnbf.hip): a SIMD issues for ONE of its two waves at a time -- beside an
+// MFMA stream only the streaming wave's own vector instructions issue (tools/microbench/pingpong.hip) -- so a slab costs the sum of
+// what both waves issue: 768 matrix-pipe cycles (24 MFMAs: hi.hi + hi.lo + lo.hi of the split operands) + ~127 vector
+// instructions + ~30 LDS instructions, twice (PMC: 2035 cycles per wave and slab on a SIMD).  Dropping two of the three MFMAs in a
+// timing experiment took 15 ms off the 70 ms tile phase: the matrix pipe's share is real time, not hidden.  Hence:
+//   * STAGE 1, on the matrix cores: x.y from the fp16 hi halves alone -- 8 MFMAs per 32 x 32 x 128 block instead of 24, half the
+//     operand bytes through HBM, L2 and LDS (256 B per column).  The error of that product is bounded: |x.y - hi.hi| <=
+//     2^-10 (1 + 2^-11) |x||y| <= beta (|x|^2 + |y|^2) / 2 with beta = 1.05 x 2^-10 (both hi halves are within 2^-11 relative of their
+//     floats; the 5 % cover the float32 accumulation of 128 exact products and the arithmetic of the test), so
+//         d^2(x, y) < thr   implies   hi.hi - (1 - beta) |y|^2 / 2  >  ((1 - beta) |x|^2 - thr) / 2 :
+//     the accumulators start from the column term, the row term is one LDS word per row, the test is ONE v_cmp per row into a wave
+//     mask, in the MFMAs' shadow.  A column that fails it is provably not among the row's K nearest so far.
+//   * STAGE 2, on the vector ALUs, for what passes (a few columns per wave and 64-column slab once the lists are warm): the exact
+//     float32 sum (x - y)^2 of the ORIGINAL rows -- the reference's own arithmetic (np.linalg.norm(x - y), annchor/distances.py:8-13)
+//     -- by the whole wave (two coalesced 512-byte loads, a DPP reduction), then a sorted insertion into the row's list (16 lanes
+//     hold it; position = popcount of the comparison ballot; a DPP row shift makes room).  The loads of a slab's survivors are
+//     issued after its test and consumed one slab later: their latency overlaps a slab of streaming.
+// The lists therefore hold EXACT float32 distances at all times: no margin entries, no re-ranking epilogue, no guard -- whatever
+// the conditioning of the data, the selection is the reference's.  Ill-conditioned data (|x|^2 >> d^2) only lets more columns
+// through stage 1: slower, not wrong.
+// Warm start: the first tiles of a row tile -- every column passes until the lists are full and tight -- are k_st_knnbf's
+// (knnbf.hip: approximate values straight from the MFMAs, batched merges): the launcher runs it with a budget of STH_WARM
+// tiles, this kernel starts from its lists (exact after its epilogue), marks the tiles it evaluated as done and goes on in the
+// same ranking order with what is left of the budget.
+// Stream mechanics: 64-column slabs of hi halves (16 KB) by LDS-DMA into a ring of three slots; one workgroup barrier per slab.
+// After a slab's stream a wave waits for everything it has outstanding -- its pieces of the NEXT slab and the survivor loads, both
+// a whole slab old --, evaluates those survivors, and only then requests its pieces of the slab after the next and the new
+// survivors' rows: nothing younger than what a wait is for is ever in flight (see vm_wait_all).
+#include "streamed.h"
+
+#define STH_THREADS 256
+#define ST_BF_MARGIN_H 2   // (the warm-up kernel's list margin: its shapes are this kernel's)
+#define STH_COLS 64        // columns per slab
+#define STH_Q 8            // exact evaluations in flight per wave (deferred by one slab)
+#define STH_QCAP 64        // survivors a stream can queue (one lane of two registers each); more: the slab is rebuilt from the accumulators
+#define STH_BETA 1.0254e-3f   // 1.05 x 2^-10
+#define STH_SLACK 0.125f      // absolute slack of the test in scaled units (subnormal fp16 halves: <= 2^-25 per coordinate)
+
+typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
+
+// ST_PROFILE builds: per-wave cycle sums by segment (a.prof[0..7], printed by knn_tile_phase):
+//   0 slab barrier   1 stream (operand reads, MFMAs, tests, queueing)   2 wait for the outstanding loads   3 exact evaluations + insertions
+//   4 requests (next slab's pieces, survivors' rows)   5 tile choice + publication   6 many survivors: evaluated at once, waited for
+//   7 selection rounds, the rest
+#ifdef ST_PROFILE
+__device__ __forceinline__ long long sth_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return (long long)t;
+}
+#define PH(i) { const long long pf_n = sth_now(); pf[i] += pf_n - pf_t; pf_t = pf_n; }
+#elif defined(STH_MARK)
+#define PH(i) asm volatile("; STHMARK " #i ::: "memory");
+#else
+#define PH(i)
+#endif
+
+template <int KS> struct KnnSharedH {
+    float ring[3 * STH_COLS * 64];   // FIRST (LDS-DMA destinations below 64 KB): three slots of 64 columns x 128 fp16.  Between runs: the
+                                     // selection's sort buffers and histogram
+    float norms[3 * STH_COLS];       // the columns' squared norms (scaled, centred), one LDS-DMA request per slab
+    float list_d[ST_T][KS + 1];      // exact d^2 (original units), ascending by (d^2, column)
+    int32_t list_c[ST_T][KS + 1];
+    float thr[ST_T];                 // the row's K-th exact d^2 (-1: padding row, never a candidate)
+    float hb[ST_T];                  // ((1 - beta) |x_row|^2 - thr scale^2) / 2 - slack: the row side of the stage-1 test
+    float rrow[ST_T];                // |scale (x_row - c)|^2
+    float loI[64], hiI[64], midI[64];
+    float run_vb[ST_KEEP];
+    int32_t run_j[ST_KEEP];
+    uint32_t run_ev[ST_KEEP / 32];
+    float wave_thr[2][4];
+    int wave_ins[2][4];
+    int nsurv, sel_bin;
+    uint32_t sel_before;
+    int red[4];
+};
+struct SelBufH {   // candidate tiles of a selection round (aliases the ring, idle between runs)
+    float surv_lb[ST_SURV];
+    float surv_vb[ST_SURV];
+    int32_t surv_j[ST_SURV];
+};
+
+template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_st_knnh(KnnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemh[];
+    using Sh = KnnSharedH<KS>;
+    using SelBuf = SelBufH;
+    Sh &sh = *reinterpret_cast<Sh *>(smemh);
+    constexpr int DIM = 128, G = DIM / 16, NI = 4, OPS = NI + 1;
+    static_assert(sizeof(sh.ring) + sizeof(sh.norms) <= 65536, "LDS-DMA destinations must stay below 64 KB");
+    static_assert(sizeof(SelBuf) == 12288 && sizeof(sh.ring) >= 12288 + 16384, "selection buffers + histogram alias the ring");
+    static_assert(KS == 16, "a row's list lives in one 16-lane DPP row");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rg = wave;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smemh;
+    int bt;
+    {   // XCD-banded row-tile assignment (block b runs on XCD b % 8): neighbours in the k-d order share an L2
+        const int nb_ = gridDim.x, q = nb_ >> 3, r = nb_ & 7, x = blockIdx.x & 7, y = blockIdx.x >> 3;
+        bt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int I = a.tile_begin + bt;
+    const int64_t grow0 = (int64_t)I * ST_T;
+    const int K = a.K;
+    const int col = lane & 31, half = lane >> 5;
+    const int rowbase = rg * 32;
+    const int rowq = rowbase + 4 * half;   // C layout: row = rowq + (r & 3) + 8 (r >> 2), column = lane & 31
+    // ---- row operand: lane holds row (lane & 31), dimensions 16 g + 8 half .. + 7 of k-step g, fp16 hi halves of the centred, scaled values
+    f16x8h ah[G];
+    const float scale = a.cvec[DIM];
+    const float sc2 = scale * scale;
+    float rr_c;
+    {
+        const float *xr = a.Rs + (size_t)(grow0 + rowbase + col) * DIM + 8 * half;
+        const float *cv = a.cvec + 8 * half;
+        float acc2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4 t0 = *reinterpret_cast<const float4 *>(xr + 16 * g), t1 = *reinterpret_cast<const float4 *>(xr + 16 * g + 4);
+            const float4 c0 = *reinterpret_cast<const float4 *>(cv + 16 * g), c1 = *reinterpret_cast<const float4 *>(cv + 16 * g + 4);
+            const float xu[8] = {t0.x - c0.x, t0.y - c0.y, t0.z - c0.z, t0.w - c0.w, t1.x - c1.x, t1.y - c1.y, t1.z - c1.z, t1.w - c1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = xu[j] * scale;
+                ah[g][j] = (_Float16)x;
+                acc2 += x * x;
+            }
+        }
+        rr_c = acc2 + __shfl_xor(acc2, 32);
+    }
+    auto hb_of = [&](float thr_orig, float rr_s) -> float {
+        return thr_orig < 0.f ? INFINITY : (thr_orig < INFINITY ? 0.5f * ((1.f - STH_BETA) * rr_s - thr_orig * sc2) - STH_SLACK : -INFINITY);
+    };
+    if (threadIdx.x < ST_T) {
+        // the lists as the warm-up left them (k_st_knnbf's epilogue: exact d^2, original units)
+        const int row = threadIdx.x;
+        const bool real = a.rr[grow0 + row] < INFINITY;
+        float last = INFINITY;
+        for (int q = 0; q < KS; ++q) {
+            const bool have = q < K;
+            const float d = have ? a.out_d2[((size_t)bt * ST_T + row) * K + q] : INFINITY;
+            sh.list_d[row][q] = d;
+            sh.list_c[row][q] = have ? a.out_col[((size_t)bt * ST_T + row) * K + q] : 0x7fffffff;
+            if (have) last = d;
+        }
+        sh.thr[row] = real ? last : -1.f;
+    }
+    if (lane < 32) sh.rrow[rowbase + lane] = a.rr[grow0 + rowbase + lane] < INFINITY ? rr_c : INFINITY;
+    if ((int)threadIdx.x < a.na) {
+        sh.loI[threadIdx.x] = a.rlo[(size_t)threadIdx.x * a.nt_r + I];
+        sh.hiI[threadIdx.x] = a.rhi[(size_t)threadIdx.x * a.nt_r + I];
+        sh.midI[threadIdx.x] = a.rmid[(size_t)threadIdx.x * a.nt_r + I];
+    }
+    if (threadIdx.x < 8) sh.wave_ins[threadIdx.x >> 2][threadIdx.x & 3] = 0;
+    if (threadIdx.x == 0) sh.nsurv = 0;
+    if (threadIdx.x < 4) sh.red[threadIdx.x] = 0;
+    // ---- the column tiles the warm-up evaluated: never candidates again (their rank key becomes +inf), counted against the budget
+    float *skey = a.scr_key + (size_t)bt * a.nt_all;
+    float *slb = a.scr_lb + (size_t)bt * a.nt_all;
+    uint32_t *ebits = a.eval_bits ? a.eval_bits + (size_t)bt * a.eval_words : nullptr;
+    __syncthreads();
+    {
+        int mine = 0;
+        if (ebits)
+            for (int w = threadIdx.x; w < a.eval_words; w += STH_THREADS) {
+                uint32_t bits = ebits[w];
+                mine += __popc(bits);
+                while (bits) {
+                    const int b = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    if (32 * w + b < a.nt_all) skey[32 * w + b] = INFINITY;
+                }
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+        if (lane == 0) sh.red[wave] = mine;
+    }
+    if (threadIdx.x < ST_T) sh.hb[threadIdx.x] = hb_of(sh.thr[threadIdx.x], sh.rrow[threadIdx.x]);
+    __syncthreads();
+    int processed = sh.red[0] + sh.red[1] + sh.red[2] + sh.red[3];   // column tiles evaluated so far (uniform), warm-up included
+    const int processed0 = processed;
+    {   // the thresholds the first choice of a tile reads
+        float t = lane < 32 ? sh.thr[rowbase + lane] : -1.f;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) t = fmaxf(t, __shfl_xor(t, off));
+        if (lane == 0) sh.wave_thr[0][rg] = t;
+    }
+#ifdef ST_PROFILE
+    long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long pf_t = sth_now();
+#endif
+    int ins = 0;         // list insertions counted by lane 0
+    int tdone = 0;       // column tiles completed and published by this kernel (uniform); tile n publishes into slot (n + 1) & 1
+    int win_start = processed, win_ins = 0;
+    bool dried = false;
+    __syncthreads();
+
+    // ---------------------------------------------------------------- requests
+    uint32_t loff[NI];   // piece i of this wave: 64 units of 16 bytes, unit U = (rg NI + i) 64 + lane = (column U / 16, unit U % 16)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int u = (rg * NI + i) * 64 + lane;
+        const int c = u >> 4, x = u & 15;
+        loff[i] = (uint32_t)(c * (DIM * 4) + ((x ^ (c & 15)) << 4));   // (the hi half of column c starts its 512-byte row of the split copy)
+    }
+    const char *xb = reinterpret_cast<const char *>(a.Xb);
+    const uint32_t norm_addr = lds0 + (uint32_t)((const unsigned char *)&sh.norms[0] - smemh);
+    auto scalar_ptr = [](const void *ptr) -> const char * {
+        const uint64_t v = (uint64_t)(uintptr_t)ptr;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<const char *>((uintptr_t)(((uint64_t)hi << 32) | lo));
+    };
+    int seq = 0;   // sequence number of the slab being streamed (uniform, monotonic over the kernel): ring slot seq % 3
+    auto issue = [&](int Jv, int slab, int sq) __attribute__((always_inline)) {
+        const int J = __builtin_amdgcn_readfirstlane(Jv);
+        const int slot = __builtin_amdgcn_readfirstlane(sq % 3);
+        const char *src = scalar_ptr(xb + ((size_t)J * ST_T + slab * STH_COLS) * (DIM * 4));
+        const uint32_t dst = lds0 + (uint32_t)(slot * (STH_COLS * 256) + rg * NI * 1024);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(loff[0]), "v"(loff[1]), "v"(loff[2]), "v"(loff[3]), "s"(src), "s"(dst) : "memory", "scc");
+        const char *nsrc = scalar_ptr(a.rsb + (size_t)J * ST_T + slab * STH_COLS);
+        const uint32_t noff = (uint32_t)(lane * 4);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(noff), "s"(nsrc), "s"(norm_addr + (uint32_t)(slot * (STH_COLS * 4))) : "memory");
+    };
+
+    // ---------------------------------------------------------------- stage 2: exact evaluation + insertion
+    float2 xr[STH_Q], yr[STH_Q];   // the rows / columns of the evaluations in flight: dimensions 2 lane, 2 lane + 1
+#pragma unroll
+    for (int k = 0; k < STH_Q; ++k) { xr[k] = float2{0.f, 0.f}; yr[k] = float2{0.f, 0.f}; }
+    int qpk = 0;                   // the stream's queue: lane n = survivor n of the slab under test, row in the tile | column in the slab << 8
+    int nq = 0;                    // (uniform)
+    int fpk = 0, fbase = 0, nfl = 0;   // the evaluations in flight (their slab's first global column)
+    bool hq_stale = true;
+    float hqr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hqr[r] = 0.f;
+    const int e16 = lane & 15;
+    // loads of survivors b .. b + n - 1 of the queue (QR, QC) into slots 0 .. n - 1
+    auto issue_slots = [&](int b, int n, int QP, int QB) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < STH_Q; ++k)
+            if (k < n) {   // (uniform)
+                const int pk = __builtin_amdgcn_readlane(QP, b + k);
+                const int row = pk & 0xff, cc = QB + (pk >> 8);
+                xr[k] = *reinterpret_cast<const float2 *>(a.Rs + (size_t)(grow0 + row) * DIM + 2 * lane);
+                yr[k] = *reinterpret_cast<const float2 *>(a.Xs + (size_t)cc * DIM + 2 * lane);
+            }
+    };
+    // slots 0 .. n - 1 (survivors b .. of the queue): exact d^2, sorted insertion
+    auto consume_slots = [&](int b, int n, int QP, int QB) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < STH_Q; ++k)
+            if (k < n) {   // (uniform)
+                const float d0 = xr[k].x - yr[k].x, d1 = xr[k].y - yr[k].y;
+                float t = d0 * d0 + d1 * d1;
+                // wave sum by DPP: xor 1, xor 2 inside the quads, mirrors inside 8 and 16 lanes, then the rows' sums down the rows
+                // (tried: the sums of four slots at a time, straight-line, so that the dependent steps of one fill the others' gaps --
+                // slower: a slab has ~4 survivors and the slots beyond them were computed for nothing)
+                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, false));
+                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xf, 0xf, false));
+                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x141, 0xf, 0xf, false));
+                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x140, 0xf, 0xf, false));
+                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x142, 0xa, 0xf, false));
+                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x143, 0xc, 0xf, false));
+                const float d2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
+                const int pk = __builtin_amdgcn_readlane(QP, b + k);
+                const int row = pk & 0xff;
+                const int32_t cc = QB + (pk >> 8);
+                const float ld = e16 < K ? sh.list_d[row][e16] : INFINITY;
+                const int32_t lc = e16 < K ? sh.list_c[row][e16] : 0x7fffffff;
+                const bool before = e16 < K && (ld < d2 || (ld == d2 && lc < cc));
+                const int pos = __popcll(__ballot(before) & 0xffffull);
+                if (pos < K) {   // (uniform)
+                    const float pd = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ld), 0x111, 0xf, 0xf, false));   // row_shr:1
+                    const int32_t pc = __builtin_amdgcn_update_dpp(0, lc, 0x111, 0xf, 0xf, false);
+                    const float nd = e16 > pos ? pd : (e16 == pos ? d2 : ld);
+                    const int32_t nc = e16 > pos ? pc : (e16 == pos ? cc : lc);
+                    if (lane < 16 && e16 >= pos && e16 < K) { sh.list_d[row][e16] = nd; sh.list_c[row][e16] = nc; }
+                    if (lane == K - 1) { sh.thr[row] = nd; sh.hb[row] = hb_of(nd, sh.rrow[row]); }
+                    ins += lane == 0 ? 1 : 0;
+                    hq_stale = true;
+                }
+            }
+    };
+    // Every vector-memory wait of the kernel is "all of them", as the BUILTIN: the compiler's own wait bookkeeping sees it (it does
+    // not see the LDS-DMA requests, inline asm; a wait it does not know of leaves the survivors' loads "pending" in its books and it
+    // then waits for EVERYTHING -- the requests just made included -- before it reuses a register).  So nothing younger than what is
+    // waited for may be outstanding at a wait: the requests of a slab are made AFTER the wait of the slab before.
+    auto vm_wait_all = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_waitcnt(0x0F70); };   // vmcnt(0), expcnt / lgkmcnt untouched
+    // everything in the queue QP[0 .. n), now: batches of STH_Q, each waited for
+    auto drain_sync = [&](int n, int QP, int QB) __attribute__((always_inline)) {
+        for (int b = 0; b < n; b += STH_Q) {
+            const int m = min(STH_Q, n - b);
+            issue_slots(b, m, QP, QB);
+            vm_wait_all();
+            consume_slots(b, m, QP, QB);
+        }
+    };
+    // a survivor mask of the slab under test (lanes = columns of group g2, both half-waves' rows r) into the queue
+    int pc0 = 0;   // first global column of the slab under test (uniform)
+    auto push = [&](unsigned long long m, int g2, int r) __attribute__((always_inline)) {
+        while (m) {   // (uniform)
+            const int l = (int)__builtin_ctzll(m);
+            m &= m - 1;
+            const int row = rowbase + 4 * (l >> 5) + (r & 3) + 8 * (r >> 2);
+            const int cl = 32 * g2 + (l & 31);
+            if (!a.query && (int64_t)pc0 + cl == grow0 + row) continue;   // a point is not its own neighbour
+            qpk = lane == nq ? (row | (cl << 8)) : qpk;   // (v_writelane cannot take value and lane from two scalar registers)
+            ++nq;
+        }
+    };
+
+    // ---------------------------------------------------------------- stage 1: one slab
+    // 16 MFMAs of this wave's 32 rows against the 64 columns in ring slot `slot` into (c0, c1); the test of the slab before
+    // (accumulators p0, p1, first column pc0) in their shadow: two rows' masks per MFMA, a mask that is not empty is queued
+    auto stream = [&](int slot, f32x16 &c0, f32x16 &c1, const f32x16 &p0, const f32x16 &p1, bool pend) __attribute__((always_inline)) {
+        const float rj0 = sh.norms[slot * STH_COLS + col], rj1 = sh.norms[slot * STH_COLS + 32 + col];
+        if (hq_stale) {   // (uniform) the thresholds of the lane's 16 rows: read again after an insertion of this wave
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 h4 = *reinterpret_cast<const float4 *>(&sh.hb[rowq + 8 * q]);
+                hqr[4 * q] = h4.x; hqr[4 * q + 1] = h4.y; hqr[4 * q + 2] = h4.z; hqr[4 * q + 3] = h4.w;
+            }
+            hq_stale = false;
+        }
+        const float4 *base0 = reinterpret_cast<const float4 *>(&sh.ring[slot * (STH_COLS * 64)]) + col * 16;
+        const float4 *base1 = base0 + 32 * 16;
+        const int gsw = half ^ (col & 15);
+        float4 b0[G], b1[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) b0[g] = base0[(2 * g) ^ gsw];
+#pragma unroll
+        for (int g = 0; g < G; ++g) b1[g] = base1[(2 * g) ^ gsw];
+        const float n0 = -0.5f * (1.f - STH_BETA) * rj0, n1 = -0.5f * (1.f - STH_BETA) * rj1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c0[r] = n0; c1[r] = n1; }
+        // (a branch on a vector compare's mask waits out the vector pipe and holds the next MFMA back: ~30 cycles each, 32 of them
+        // doubled the stream.  Four rows' masks are taken together -- four compares back to back, ONE branch on their OR; the rare
+        // group with a survivor then looks at its four masks, which sit in scalar registers by then)
+#pragma unroll
+        for (int m = 0; m < 2 * G; m += 2) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int mm = m + h2;
+                if (mm < G) c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mm], __builtin_bit_cast(f16x8h, b0[mm]), c0, 0, 0, 0);
+                else c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mm - G], __builtin_bit_cast(f16x8h, b1[mm - G]), c1, 0, 0, 0);
+            }
+            if (pend) {   // (uniform)
+                unsigned long long mk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ti = 2 * m + u, g2 = ti >> 4, r = ti & 15;
+                    mk[u] = __ballot((g2 ? p1[r] : p0[r]) > hqr[r]);
+                }
+                if (mk[0] | mk[1] | mk[2] | mk[3]) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ti = 2 * m + u, g2 = ti >> 4, r = ti & 15;
+                        if (mk[u]) push(mk[u], g2, r);
+                    }
+                }
+            }
+            if (m < G) asm volatile("" : "+v"(c0));
+            else asm volatile("" : "+v"(c1));
+        }
+    };
+    // after a slab's stream: the survivor loads of one slab ago (and this wave's pieces of the next slab) have landed; evaluate
+    // them; then the survivors the stream has just queued: few -> their loads now, their evaluation after the next slab;
+    // many -> all of them now; more than the queue holds -> the slab is gone through again from the accumulators
+    auto post = [&](int dJ, int dslab, const f32x16 &p0, const f32x16 &p1, bool pend) __attribute__((always_inline)) {
+        PH(1)
+        vm_wait_all();   // this wave's pieces of slab seq + 1 (requested a slab ago) and the survivors' rows (likewise)
+        PH(2)
+        consume_slots(0, nfl, fpk, fbase);
+        nfl = 0;
+        PH(3)
+        if (dJ >= 0) issue(dJ, dslab, seq + 2);   // (its slot held slab seq - 1: every wave has passed this slab's barrier)
+        if (!pend) { nq = 0; return; }
+        if (nq > STH_QCAP) {
+            // (the first tiles after a cold start, ill-conditioned data) per-lane row masks from the accumulators, queue by queue
+            nq = 0;
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                uint32_t lp = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lp |= ((g2 ? p1[r] : p0[r]) > hqr[r] ? 1u : 0u) << r;
+                unsigned long long lanes = __ballot(lp != 0);
+                while (lanes) {   // (uniform)
+                    const int l = (int)__builtin_ctzll(lanes);
+                    lanes &= lanes - 1;
+                    uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)lp, l);
+                    while (pl) {
+                        const int r = __builtin_ctz(pl);
+                        pl &= pl - 1;
+                        const int row = rowbase + 4 * (l >> 5) + (r & 3) + 8 * (r >> 2);
+                        const int cl = 32 * g2 + (l & 31);
+                        if (!a.query && (int64_t)pc0 + cl == grow0 + row) continue;
+                        qpk = lane == nq ? (row | (cl << 8)) : qpk;
+                        if (++nq == STH_QCAP) { drain_sync(nq, qpk, pc0); nq = 0; }
+                    }
+                }
+            }
+            drain_sync(nq, qpk, pc0);
+            PH(6)
+        } else if (nq > STH_Q) {
+            PH(4)
+            drain_sync(nq, qpk, pc0);
+            PH(6)
+        } else if (nq > 0) {
+            issue_slots(0, nq, qpk, pc0);
+            fpk = qpk; fbase = pc0; nfl = nq;
+        }
+        nq = 0;
+        PH(4)
+    };
+    // the wave's insertion count and its rows' worst K-th distance, at the end of a tile
+    // (`ins` is counted by lane 0 alone; the maximum by DPP steps and two v_readlane -- a __shfl_xor is an LDS round trip, eleven of
+    // them in a chain were 15 % of the kernel)
+    auto publish = [&]() __attribute__((always_inline)) {
+        float t = lane < 32 ? sh.thr[rowbase + lane] : -1.f;
+        t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, false)));
+        t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x4E, 0xf, 0xf, false)));
+        t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x141, 0xf, 0xf, false)));
+        t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x140, 0xf, 0xf, false)));
+        const float tm = fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 0)),
+                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 16)));
+        if (lane == 0) { sh.wave_ins[(tdone + 1) & 1][wave] = ins; sh.wave_thr[(tdone + 1) & 1][rg] = tm; }
+    };
+    auto thrmax_now = [&]() {
+        const float *w = sh.wave_thr[tdone & 1];
+        return fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
+    };
+    auto slab_barrier = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    f32x16 a0, a1, b0a, b1a;   // the two 32-column groups of the even / odd slab of a tile
+    // One run of the stream over a list of tiles in rank order: entry q is (tile jl(q), valid bound vb(q)); entries whose bound has
+    // fallen behind the thresholds are skipped.  Uniform: every wave takes the same path.
+    auto run = [&](int ns, auto jl, auto vb) __attribute__((always_inline)) {
+        int q = 0;
+        if (threadIdx.x == 0)
+            for (int t = 0; t < ST_KEEP / 32; ++t) sh.run_ev[t] = 0;
+        // (entry q of the list is read when entry q - 1 is taken: the choice of a tile then waits for the thresholds alone, not for
+        // a chain of LDS round trips)
+        int cj = ns > 0 ? jl(0) : 0;
+        float cvb = ns > 0 ? vb(0) : 0.f;
+        auto next_tile = [&](int in_stream) -> int {
+            if (a.early_window > 0 && !dried) {
+                const int done = processed - in_stream;
+                if (done - win_start >= a.early_window) {
+                    int cur = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) cur += sh.wave_ins[tdone & 1][w];
+                    if (cur - win_ins < a.early_tau) dried = true;
+                    else { win_start = done; win_ins = cur; }
+                }
+            }
+            if (dried) return -1;
+            const float tm = thrmax_now();
+            while (q < ns && processed < a.max_tiles) {
+                const int J = cj;
+                const float lb = cvb;
+                ++q;
+                if (q < ns) { cj = jl(q); cvb = vb(q); }
+                if (lb * lb < tm) {
+                    ++processed;
+                    if (ebits && threadIdx.x == 0) sh.run_ev[(q - 1) >> 5] |= 1u << ((q - 1) & 31);   // (flushed at the end of the run)
+                    return __builtin_amdgcn_readfirstlane(J);
+                }
+            }
+            return -1;
+        };
+        PH(7)
+        int J = next_tile(0);
+        if (J < 0) return;
+        // fill: both slabs of the first tile (the ring is idle: a workgroup barrier precedes every run)
+        issue(J, 0, seq);
+        issue(J, 1, seq + 1);
+        vm_wait_all();
+        bool pend = false;
+        nq = 0; nfl = 0;
+        for (;;) {
+            // ---- slab 0: the tile after J is chosen (thresholds / insertion counts as published at the end of the tile before J)
+            // and its first slab requested
+            PH(5)
+            slab_barrier();
+            PH(0)
+            const int Jn = next_tile(1);
+            PH(5)
+            stream(seq % 3, a0, a1, b0a, b1a, pend);
+            post(Jn, 0, b0a, b1a, pend);
+            pend = true; pc0 = J * ST_T;
+            ++seq;
+            // ---- slab 1
+            slab_barrier();
+            PH(0)
+            stream(seq % 3, b0a, b1a, a0, a1, true);
+            post(Jn, 1, a0, a1, true);
+            pc0 = J * ST_T + STH_COLS;
+            ++seq;
+            publish();
+            ++tdone;
+            if (Jn < 0) break;
+            J = Jn;
+        }
+        // ---- tail: the evaluations in flight, then the last slab's test without a stream to hide it in
+        vm_wait_all();
+        consume_slots(0, nfl, fpk, fbase);
+        nfl = 0;
+        nq = STH_QCAP + 1;   // (the slab is gone through from its accumulators)
+        if (hq_stale) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 h4 = *reinterpret_cast<const float4 *>(&sh.hb[rowq + 8 * q4]);
+                hqr[4 * q4] = h4.x; hqr[4 * q4 + 1] = h4.y; hqr[4 * q4 + 2] = h4.z; hqr[4 * q4 + 3] = h4.w;
+            }
+            hq_stale = false;
+        }
+        post(-1, 0, b0a, b1a, true);
+        publish();
+        ++tdone;
+        __syncthreads();
+        if (ebits)
+            for (int t = threadIdx.x; t < ns; t += STH_THREADS)
+                if ((sh.run_ev[t >> 5] >> (t & 31)) & 1u) {
+                    const int Jt = jl(t);
+                    atomicOr(&ebits[Jt >> 5], 1u << (Jt & 31));
+                }
+    };
+
+    // ---- the remaining column tiles, exactly as k_st_knnbf ranks and selects them (knnbf.hip; the same code): rounds of {3-level
+    // radix selection of the next ST_KEEP tiles in (key, tile) order, collect, sort, stream}.  (The scratch rows were filled by
+    // k_st_rank_pairs -- the launcher insists --; the in-kernel ranking below is kept for the same reason it is there.)
+    if (!a.pre_ranked)   // (k_st_rank_pairs has filled the scratch rows: streamed.hip)
+    for (int J = threadIdx.x; J < a.nt_all; J += STH_THREADS) {
+        float lb = 0.f, lbc = 0.f;
+        for (int an = 0; an < a.na; ++an) {
+            const float lj = a.lo[(size_t)an * a.nt_all + J], hj = a.hi[(size_t)an * a.nt_all + J];
+            const float gap = fmaxf(sh.loI[an] - hj, lj - sh.hiI[an]);
+            // slack for the float32 rounding of D (bounds must stay valid lower bounds)
+            lb = fmaxf(lb, gap - 4e-6f * (fabsf(hj) + fabsf(sh.hiI[an])));
+            const float dm = a.mid[(size_t)an * a.nt_all + J] - sh.midI[an];
+            lbc += dm * dm;   // rank key: squared L2 distance between the tiles' mean anchor vectors
+        }
+        skey[J] = ((J == I && !a.query) || !(lbc < INFINITY)) ? INFINITY : lbc;   // +inf: never a candidate
+        slb[J] = lb;
+    }
+    __syncthreads();   // block-scope visibility of the scratch row (same CU)
+    uint32_t *hist = reinterpret_cast<uint32_t *>(&sh.ring[12288 / 4]);   // 4096 bins, behind the sort buffers in the idle ring
+    SelBuf &sb = *reinterpret_cast<SelBuf *>(&sh.ring[0]);           // the ring is idle between runs too
+    uint32_t done_bits = 0;   // (done_bits, done_j): key bits / index of the last tile already considered
+    int done_j = -1;
+    // SHORT LIST (round 5).  A selection round sweeps the scratch row four times (three histogram levels + the collection): at
+    // 62 500 column tiles that is 2 MB per round and row tile, a fifth of the kernel's wave cycles once the ranking had left it.
+    // Instead: ONE histogram sweep of the key's top 12 bits finds the key bound below which ~4 ST_KEEP eligible tiles lie, ONE
+    // more sweep copies those (key, bound, tile) to a short list, and the rounds select from the list -- the same tiles in the
+    // same order: every eligible tile below the key bound is in the list, and the list is rebuilt behind the cursor when a round
+    // finds fewer than ST_KEEP eligible tiles in it while tiles beyond its bound remain.
+    uint32_t *clk = a.scr_cl ? a.scr_cl + (size_t)bt * 3 * ST_CL_CAP : nullptr;   // [3][ST_CL_CAP]: key bits, bound bits, tile
+    int cl_n = 0;                               // (uniform)
+    bool cl_valid = false, cl_complete = false;
+    // entries (key bits, valid bound, tile) of the short list or of the whole scratch row, thread-strided
+    auto sweep = [&](bool from_list, auto f) {
+        if (from_list) {
+            for (int q = threadIdx.x; q < cl_n; q += STH_THREADS) f(clk[q], __uint_as_float(clk[ST_CL_CAP + q]), (int)clk[2 * ST_CL_CAP + q]);
+        } else {
+            for (int J = threadIdx.x; J < a.nt_all; J += STH_THREADS) f(__float_as_uint(skey[J]), slb[J], J);
+        }
+    };
+    // first bin whose cumulative count reaches `want` among nbins bins of `hist`: thread t owns bins [per t, per (t+1)); the
+    // bin in sh.sel_bin (-1: the total stays below `want`), the count before it in sh.sel_before
+    auto find_bin = [&](int nbins, uint32_t want) {
+        const int per = nbins >= STH_THREADS ? nbins / STH_THREADS : 1;
+        const bool owner = (int)threadIdx.x * per < nbins;
+        uint32_t mine = 0;
+        if (owner)
+            for (int q = 0; q < per; ++q) mine += hist[threadIdx.x * per + q];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        uint32_t *wtot = reinterpret_cast<uint32_t *>(&sb.surv_lb[0]);   // 4 wave totals (surv_lb is idle here)
+        if (threadIdx.x == 0) sh.sel_bin = -1;
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+        for (int w2 = 0; w2 < wave; ++w2) before += wtot[w2];
+        if (owner && before < want && before + mine >= want) {
+            uint32_t ac = before;
+            int q = threadIdx.x * per;
+            for (;; ++q) { if (ac + hist[q] >= want) break; ac += hist[q]; }
+            sh.sel_bin = q;
+            sh.sel_before = ac;
+        }
+        __syncthreads();
+    };
+    for (;;) {
+        const float thrmax = thrmax_now();
+        uint32_t prefix = 0;
+        uint32_t want = ST_KEEP;
+        bool all = false, use_list = false;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (clk && !cl_valid) {
+                // ---- (re)build the short list behind the cursor
+                for (int q = threadIdx.x; q < 4096; q += STH_THREADS) hist[q] = 0;
+                __syncthreads();
+                sweep(false, [&](uint32_t kb, float lb, int J) {
+                    const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
+                    if (kb < 0x7f800000u && after_done && lb * lb < thrmax) atomicAdd(&hist[kb >> 20], 1u);
+                });
+                __syncthreads();
+                find_bin(4096, ST_CL_TARGET);
+                const int bb = sh.sel_bin;
+                cl_complete = bb < 0;                                  // fewer than the target in all: the list holds every eligible tile
+                const uint32_t through = cl_complete ? 0u : sh.sel_before + hist[bb];
+                __syncthreads();
+                if (cl_complete || through <= ST_CL_CAP) {   // (else: a bin of equal leading key bits larger than the list -- the row is swept this round)
+                    const uint32_t bound_bits = cl_complete ? 0x7f800000u : (uint32_t)(bb + 1) << 20;
+                    if (threadIdx.x == 0) sh.nsurv = 0;
+                    __syncthreads();
+                    sweep(false, [&](uint32_t kb, float lb, int J) {
+                        const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
+                        if (kb < bound_bits && after_done && lb * lb < thrmax) {
+                            const int slot = atomicAdd(&sh.nsurv, 1);
+                            if (slot < ST_CL_CAP) { clk[slot] = kb; clk[ST_CL_CAP + slot] = __float_as_uint(lb); clk[2 * ST_CL_CAP + slot] = (uint32_t)J; }
+                        }
+                    });
+                    __syncthreads();
+                    cl_n = min(sh.nsurv, ST_CL_CAP);
+                    cl_valid = true;
+                    __syncthreads();
+                }
+            }
+            use_list = clk && cl_valid;
+            prefix = 0; want = ST_KEEP; all = false;
+            for (int level = 0; level < 3 && !all; ++level) {
+                const int shift = level == 0 ? 20 : level == 1 ? 8 : 0;
+                const int nbins = level == 2 ? 256 : 4096;
+                const uint32_t pmask = level == 0 ? 0u : level == 1 ? 0xfff00000u : 0xffffff00u;
+                for (int q = threadIdx.x; q < nbins; q += STH_THREADS) hist[q] = 0;
+                __syncthreads();
+                sweep(use_list, [&](uint32_t kb, float lb, int J) {
+                    const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
+                    if (kb < 0x7f800000u && after_done && lb * lb < thrmax && (kb & pmask) == prefix)
+                        atomicAdd(&hist[(kb >> shift) & (nbins - 1)], 1u);
+                });
+                __syncthreads();
+                find_bin(nbins, want);
+                if (sh.sel_bin < 0) all = true;
+                else { prefix |= (uint32_t)sh.sel_bin << shift; want -= sh.sel_before; }
+                __syncthreads();
+            }
+            if (!use_list || !all || cl_complete) break;
+            cl_valid = false;   // fewer than ST_KEEP eligible tiles left in the list, and tiles beyond its bound remain: rebuild, select again
+        }
+        const uint32_t cut_bits = all ? 0x7f7fffffu : prefix;   // take keys <= cut (ties resolved by the sort below)
+        if (threadIdx.x == 0) sh.nsurv = 0;
+        __syncthreads();
+        sweep(use_list, [&](uint32_t kb, float lb, int J) {
+            const bool after_done = kb > done_bits || (kb == done_bits && J > done_j);
+            if (kb < 0x7f800000u && after_done && lb * lb < thrmax && kb <= cut_bits) {
+                const int slot = atomicAdd(&sh.nsurv, 1);
+                if (slot < ST_SURV) { sb.surv_lb[slot] = __uint_as_float(kb); sb.surv_vb[slot] = lb; sb.surv_j[slot] = J; }
+            }
+        });
+        __syncthreads();
+        int ns = min(sh.nsurv, ST_SURV);
+        if (ns == 0) break;
+        {   // sort by (rank key, J): bitonic over ST_SURV slots
+            for (int q = threadIdx.x; q < ST_SURV; q += STH_THREADS)
+                if (q >= ns) { sb.surv_lb[q] = INFINITY; sb.surv_j[q] = 0x7fffffff; }
+            __syncthreads();
+            for (int k2 = 2; k2 <= ST_SURV; k2 <<= 1)
+                for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                    for (int q = threadIdx.x; q < ST_SURV; q += STH_THREADS) {
+                        const int p2 = q ^ j2;
+                        if (p2 > q) {
+                            const bool up = (q & k2) == 0;
+                            const float lq = sb.surv_lb[q], lp = sb.surv_lb[p2];
+                            const int jq = sb.surv_j[q], jp = sb.surv_j[p2];
+                            const bool gt = lq > lp || (lq == lp && jq > jp);
+                            if (gt == up) {
+                                sb.surv_lb[q] = lp; sb.surv_lb[p2] = lq; sb.surv_j[q] = jp; sb.surv_j[p2] = jq;
+                                const float t = sb.surv_vb[q]; sb.surv_vb[q] = sb.surv_vb[p2]; sb.surv_vb[p2] = t;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+        }
+        const bool more = !all;          // the selection was cut at ST_KEEP: later tiles remain
+        if (ns > ST_KEEP && more) ns = ST_KEEP;
+        const uint32_t round_last_bits = __float_as_uint(sb.surv_lb[ns - 1]);
+        const int round_last_j = sb.surv_j[ns - 1];
+        // the round's tiles leave the ring before the stream takes it back
+        for (int q = threadIdx.x; q < ns; q += STH_THREADS) { sh.run_j[q] = sb.surv_j[q]; sh.run_vb[q] = sb.surv_vb[q]; }
+        __syncthreads();   // the histogram and the sort buffers (both in the ring) are idle again: the stream may run
+        run(ns, [&](int q) { return sh.run_j[q]; }, [&](int q) { return sh.run_vb[q]; });
+        done_bits = round_last_bits;
+        done_j = round_last_j;
+        __syncthreads();
+        if (dried) break;
+        if (processed >= a.max_tiles) break;
+        if (!more) break;   // the selection saw every eligible tile
+    }
+    __syncthreads();
+    // ---- the lists ARE the result: exact float32 d^2 (original units), ascending by (d^2, column)
+    for (int q = threadIdx.x; q < ST_T * K; q += STH_THREADS) {
+        const int row = q / K, e = q - row * K;
+        const float d2 = sh.list_d[row][e];
+        a.out_d2[((size_t)bt * ST_T + row) * K + e] = d2;
+        a.out_col[((size_t)bt * ST_T + row) * K + e] = d2 < INFINITY ? sh.list_c[row][e] : 0x7fffffff;
+    }
+    if (threadIdx.x == 0) atomicAdd(a.evals, (unsigned long long)(processed - processed0));
+#ifdef ST_PROFILE
+    PH(7)
+    if (lane == 0 && a.prof)
+        for (int i = 0; i < 8; ++i) atomicAdd(a.prof + i, (unsigned long long)pf[i]);
+#endif
+}
+
+// The tile phase through the two-stage kernel when the shape fits it: graph builds (not queries) at padded dimension 128 with at most
+// 14 neighbours kept per row, the split copy present; *handled = false sends the caller to k_st_knnbf alone.  Two launches:
+// k_st_knnbf (through `warm`) with a budget of STH_WARM + 1 tiles per row tile and the evaluated tiles recorded, then k_st_knnh.
+#define STH_WARM 32
+// (the tile phase records the evaluated tiles for every build this returns true for, joins or not: the same kernels -- the same
+// float32 sums -- whichever entry point the build came through)
+bool ann_stream_knnh_fits(const KnnArgs &a, int dim_padded)
+{
+    static const char *kern = getenv("ANNCHOR_ST_KERNEL");   // default: this kernel; "bf4" / "bf3" / "4wave" / "bk" select the others for A/B runs
+    if (kern && strcmp(kern, "h")) return false;
+    return dim_padded == 128 && a.K + ST_BF_MARGIN_H <= 16 && a.Xb && a.rsb && a.cvec && !a.query;
+}
+int ann_stream_launch_knnh(annchor_ctx *c, const KnnArgs &a0, int dim_padded, bool *handled, int (*warm)(annchor_ctx *, const KnnArgs &, int, bool *, bool))
+{
+    *handled = false;
+    if (!ann_stream_knnh_fits(a0, dim_padded) || !a0.eval_bits || !a0.pre_ranked || a0.eval_halves != 1) return ANNCHOR_OK;
+    static const int warm_tiles = getenv("ANNCHOR_STH_WARM") ? std::max(0, atoi(getenv("ANNCHOR_STH_WARM"))) : STH_WARM;   // (A/B runs)
+    KnnArgs w = a0;
+    w.max_tiles = std::min(a0.max_tiles, warm_tiles + 1);
+    bool ok = false;
+    ANN_TRY(warm(c, w, dim_padded, &ok, false));
+    if (!ok) return ANNCHOR_OK;
+    *handled = true;
+    if (a0.max_tiles <= warm_tiles + 1) return ANNCHOR_OK;   // the warm-up was the whole budget
+    const size_t lds = sizeof(KnnSharedH<16>);
+    ANN_REQUIRE(c, lds <= 80 * 1024, ANNCHOR_ELIMIT, "streamed k-NN (two-stage form) needs %zu B of LDS", lds);
+    ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knnh<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_st_knnh<16><<<a0.tile_count, STH_THREADS, lds, c->stream>>>(a0);
+    ANN_CHECK_HIP(c, hipGetLastError());
+    return ANNCHOR_OK;
+}

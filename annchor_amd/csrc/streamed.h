@@ -145,6 +145,11 @@ int ann_stream_launch_knnbf(annchor_ctx *c, const struct KnnArgs &a, int dim_pad
 // tools/experiments/knnbf2.hip (builds with -DST_PAIR_KERNEL only): the same tile phase with two adjacent row tiles per 8-wave
 // workgroup sharing one column stream (graph builds, padded dim <= 128, K + 2 <= 16); *handled = false otherwise
 int ann_stream_launch_knnbf2(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled);
+// knnh.hip: the two-stage tile kernel (fp16 hi-only products as a rigorous filter, float32 differences for what passes), warm-started by
+// `warm` (k_st_knnbf with a small budget); graph builds at padded dimension 128, <= 14 neighbours; *handled = false otherwise
+bool ann_stream_knnh_fits(const struct KnnArgs &a, int dim_padded);
+int ann_stream_launch_knnh(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled,
+                           int (*warm)(annchor_ctx *, const struct KnnArgs &, int, bool *, bool));
 // knnbk.hip: the k-blocked split-fp16 kernel for padded dim 256 .. 1024 (tile phase and join passes, graph builds and queries)
 int ann_stream_launch_knnbk(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled, bool join = false);
 int ann_stream_split_rows(annchor_ctx *c, StreamState *s);     // Xb from Xs (after the ordering)

@@ -1782,7 +1782,8 @@ static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool 
                 }
             }
 #endif
-            if (!(kern && !strcmp(kern, "bk") && dim_padded == 128)) ANN_TRY(ann_stream_launch_knnbf(c, a, dim_padded, &handled, join));
+            if (!join) ANN_TRY(ann_stream_launch_knnh(c, a, dim_padded, &handled, ann_stream_launch_knnbf));   // (two-stage form: knnh.hip)
+            if (!handled && !(kern && !strcmp(kern, "bk") && dim_padded == 128)) ANN_TRY(ann_stream_launch_knnbf(c, a, dim_padded, &handled, join));
             if (!handled) ANN_TRY(ann_stream_launch_knnbk(c, a, dim_padded, &handled, join));   // padded dim 256 .. 1024: k-blocked
             if (handled) {
                 if (!join && st) st->last_kernel = 1;
@@ -1915,7 +1916,7 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
     a.eval_bits = nullptr;
     a.eval_words = (a.nt_all + 31) / 32;
     a.eval_halves = (a.K > ST_KMAX_BIG) ? 2 : 1;   // (KnnHalf: two workgroups per row tile, a bitmap row each)
-    if (record_tiles) {
+    if (record_tiles || ann_stream_knnh_fits(a, dim_padded)) {   // (the two-stage kernel resumes from the warm-up's record)
         const size_t nb = sizeof(uint32_t) * (size_t)a.tile_count * a.eval_halves * a.eval_words;
         ANN_TRY(sreserve(c, s->eval_bits, nb));
         ANN_CHECK_HIP(c, hipMemsetAsync(s->eval_bits.p, 0, nb, c->stream));

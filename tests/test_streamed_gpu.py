@@ -924,7 +924,13 @@ def test_tiled_ranking_pass_equals_the_in_kernel_ranking(monkeypatch):
         b = StreamedAnnchor(X, n_anchors=24, n_neighbors=k, p_work=pw).fit()
         qb = b.query(X[:300] + 0.01, nn=5, p_work=0.3)
         assert a.tile_evals == b.tile_evals, (n, d)
-        assert np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0]) and np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1]), (n, d)
+        assert np.array_equal(a.neighbor_graph[0], b.neighbor_graph[0]), (n, d)
+        # (distances: bit for bit where the same kernels ran; at 128 dimensions the pre-ranked build continues in the two-stage kernel
+        # k_st_knnh, whose float32 sums (x - y)^2 are taken in a different order -- the same neighbours, the last bit of a distance)
+        if d == 128:
+            np.testing.assert_allclose(a.neighbor_graph[1], b.neighbor_graph[1], rtol=3e-7, atol=0)
+        else:
+            assert np.array_equal(a.neighbor_graph[1], b.neighbor_graph[1]), (n, d)
         assert np.array_equal(qa[0], qb[0]) and np.array_equal(qa[1], qb[1]), (n, d)
         a._engine.close(); b._engine.close()
 

@@ -16,8 +16,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].replace("void ", "").split("(")[0]
-        if not k.startswith("k_st_knnbf<128, 16, false"): continue
+        if not (k.startswith("k_st_knnbf<128, 16, false") or k.startswith("k_st_knnh")): continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
+        if "Start_Timestamp" in r: pass
 out = {k: {c: v / n[k][c] for c, v in d.items()} | {"launches": max(n[k].values())} for k, d in agg.items()}
 json.dump(out, open(sys.argv[1] + "/pmc.json", "w"), indent=1)
 SW = 4040934 * 16.0   # slab-waves per launch (approx.)
