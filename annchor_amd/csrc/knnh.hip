@@ -195,7 +195,7 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long pf_t = sth_now();
 #endif
-    int ins = 0;         // list insertions counted by lane 0
+    int ins = 0;         // list insertions, counted by the first lane of each 16-lane row
     int tdone = 0;       // column tiles completed and published by this kernel (uniform); tile n publishes into slot (n + 1) & 1
     int win_start = processed, win_ins = 0;
     bool dried = false;
@@ -235,9 +235,16 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     };
 
     // ---------------------------------------------------------------- stage 2: exact evaluation + insertion
-    float2 xr[STH_Q], yr[STH_Q];   // the rows / columns of the evaluations in flight: dimensions 2 lane, 2 lane + 1
+    // Survivors are evaluated FOUR at a time, one per 16-lane row of the wave: lane e of row g holds dimensions 8 e .. 8 e + 7 of
+    // survivor g's row and column (two 16-byte loads each: the 16 lanes read 512 contiguous bytes), the 16-lane sum is four DPP
+    // steps and leaves d^2 in every lane of the row, which also holds that survivor's list -- the insertion needs nothing from a
+    // scalar register.  (First form: one survivor per wave pass, 64 lanes x 2 dimensions, a six-step reduction, v_readlane, ~58
+    // vector instructions per survivor; the wave's vector instructions, not the matrix pipe, were what a slab cost.)  Two such
+    // batches are in flight (STH_Q = 8 survivors).
+    constexpr int NB = STH_Q / 4;
+    float4 xa[NB], xc[NB], ya[NB], yc[NB];
 #pragma unroll
-    for (int k = 0; k < STH_Q; ++k) { xr[k] = float2{0.f, 0.f}; yr[k] = float2{0.f, 0.f}; }
+    for (int b = 0; b < NB; ++b) { xa[b] = float4{0.f, 0.f, 0.f, 0.f}; xc[b] = xa[b]; ya[b] = xa[b]; yc[b] = xa[b]; }
     int qpk = 0;                   // the stream's queue: lane n = survivor n of the slab under test, row in the tile | column in the slab << 8
     int nq = 0;                    // (uniform)
     int fpk = 0, fbase = 0, nfl = 0;   // the evaluations in flight (their slab's first global column)
@@ -245,51 +252,77 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     float hqr[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) hqr[r] = 0.f;
-    const int e16 = lane & 15;
-    // loads of survivors b .. b + n - 1 of the queue (QR, QC) into slots 0 .. n - 1
+    const int e16 = lane & 15, g16 = lane >> 4;
+    // the lane's survivor of batch `bi` of the queue QP starting at entry b: (valid, row, column)
+    auto my_survivor = [&](int b, int n, int bi, int QP, int QB, int &row, int32_t &cc) -> bool {
+        const int idx = b + 4 * bi + g16;
+        const int pk = __builtin_amdgcn_ds_bpermute(idx << 2, QP);
+        const bool valid = 4 * bi + g16 < n;
+        row = valid ? (pk & 0xff) : 0;                 // (lanes without a survivor read row 0 / the slab's first column: valid memory, ignored)
+        cc = valid ? QB + (pk >> 8) : QB;
+        return valid;
+    };
+    // loads of survivors b .. b + n - 1 of the queue (QP: packed entries, QB: their slab's first column), n <= STH_Q
     auto issue_slots = [&](int b, int n, int QP, int QB) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < STH_Q; ++k)
-            if (k < n) {   // (uniform)
-                const int pk = __builtin_amdgcn_readlane(QP, b + k);
-                const int row = pk & 0xff, cc = QB + (pk >> 8);
-                xr[k] = *reinterpret_cast<const float2 *>(a.Rs + (size_t)(grow0 + row) * DIM + 2 * lane);
-                yr[k] = *reinterpret_cast<const float2 *>(a.Xs + (size_t)cc * DIM + 2 * lane);
+        for (int bi = 0; bi < NB; ++bi)
+            if (4 * bi < n) {   // (uniform)
+                int row; int32_t cc;
+                (void)my_survivor(b, n, bi, QP, QB, row, cc);
+                const float4 *px = reinterpret_cast<const float4 *>(a.Rs + (size_t)(grow0 + row) * DIM + 8 * e16);
+                const float4 *py = reinterpret_cast<const float4 *>(a.Xs + (size_t)cc * DIM + 8 * e16);
+                xa[bi] = px[0]; xc[bi] = px[1]; ya[bi] = py[0]; yc[bi] = py[1];
             }
     };
-    // slots 0 .. n - 1 (survivors b .. of the queue): exact d^2, sorted insertion
+    // one round of insertions: row `row`, exact d^2 `d2` (+inf: nothing), column cc -- per 16-lane row, all four rows at once
+    auto insert_round = [&](int row, float d2, int32_t cc) __attribute__((always_inline)) {
+        const float ld = e16 < K ? sh.list_d[row][e16] : INFINITY;
+        const int32_t lc = e16 < K ? sh.list_c[row][e16] : 0x7fffffff;
+        const bool before = e16 < K && (ld < d2 || (ld == d2 && lc < cc));
+        const unsigned long long mk = __ballot(before);
+        const int pos = __popc((uint32_t)(mk >> (lane & 48)) & 0xffffu);   // entries of the lane's own row that stay ahead
+        const bool ok = pos < K && d2 < INFINITY;
+        const float pd = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ld), 0x111, 0xf, 0xf, false));   // row_shr:1
+        const int32_t pc = __builtin_amdgcn_update_dpp(0, lc, 0x111, 0xf, 0xf, false);
+        const float nd = e16 > pos ? pd : (e16 == pos ? d2 : ld);
+        const int32_t nc = e16 > pos ? pc : (e16 == pos ? cc : lc);
+        if (ok && e16 >= pos && e16 < K) { sh.list_d[row][e16] = nd; sh.list_c[row][e16] = nc; }
+        if (ok && e16 == K - 1) { sh.thr[row] = nd; sh.hb[row] = hb_of(nd, sh.rrow[row]); }
+        ins += (ok && e16 == 0) ? 1 : 0;
+        if (__ballot(ok)) hq_stale = true;
+    };
+    // slots of n survivors (b .. of the queue): exact d^2, sorted insertion
     auto consume_slots = [&](int b, int n, int QP, int QB) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < STH_Q; ++k)
-            if (k < n) {   // (uniform)
-                const float d0 = xr[k].x - yr[k].x, d1 = xr[k].y - yr[k].y;
-                float t = d0 * d0 + d1 * d1;
-                // wave sum by DPP: xor 1, xor 2 inside the quads, mirrors inside 8 and 16 lanes, then the rows' sums down the rows
-                // (tried: the sums of four slots at a time, straight-line, so that the dependent steps of one fill the others' gaps --
-                // slower: a slab has ~4 survivors and the slots beyond them were computed for nothing)
+        for (int bi = 0; bi < NB; ++bi)
+            if (4 * bi < n) {   // (uniform)
+                int row; int32_t cc;
+                const bool valid = my_survivor(b, n, bi, QP, QB, row, cc);
+                float t;
+                {
+                    const float d0 = xa[bi].x - ya[bi].x, d1 = xa[bi].y - ya[bi].y, d2_ = xa[bi].z - ya[bi].z, d3 = xa[bi].w - ya[bi].w;
+                    const float d4 = xc[bi].x - yc[bi].x, d5 = xc[bi].y - yc[bi].y, d6 = xc[bi].z - yc[bi].z, d7 = xc[bi].w - yc[bi].w;
+                    t = ((d0 * d0 + d1 * d1) + (d2_ * d2_ + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
+                }
+                // 16-lane sum by DPP (xor 1, xor 2 inside the quads, mirrors inside 8 and 16 lanes): every lane of the row has it
                 t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, false));
                 t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xf, 0xf, false));
                 t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x141, 0xf, 0xf, false));
                 t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x140, 0xf, 0xf, false));
-                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x142, 0xa, 0xf, false));
-                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x143, 0xc, 0xf, false));
-                const float d2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
-                const int pk = __builtin_amdgcn_readlane(QP, b + k);
-                const int row = pk & 0xff;
-                const int32_t cc = QB + (pk >> 8);
-                const float ld = e16 < K ? sh.list_d[row][e16] : INFINITY;
-                const int32_t lc = e16 < K ? sh.list_c[row][e16] : 0x7fffffff;
-                const bool before = e16 < K && (ld < d2 || (ld == d2 && lc < cc));
-                const int pos = __popcll(__ballot(before) & 0xffffull);
-                if (pos < K) {   // (uniform)
-                    const float pd = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ld), 0x111, 0xf, 0xf, false));   // row_shr:1
-                    const int32_t pc = __builtin_amdgcn_update_dpp(0, lc, 0x111, 0xf, 0xf, false);
-                    const float nd = e16 > pos ? pd : (e16 == pos ? d2 : ld);
-                    const int32_t nc = e16 > pos ? pc : (e16 == pos ? cc : lc);
-                    if (lane < 16 && e16 >= pos && e16 < K) { sh.list_d[row][e16] = nd; sh.list_c[row][e16] = nc; }
-                    if (lane == K - 1) { sh.thr[row] = nd; sh.hb[row] = hb_of(nd, sh.rrow[row]); }
-                    ins += lane == 0 ? 1 : 0;
-                    hq_stale = true;
+                const float d2 = valid ? t : INFINITY;
+                // two survivors of a batch with the same row must not insert at once: each would shift a list it has not seen the
+                // other's entry in.  (Rare once the lists are warm.)  Then the four rows take turns.
+                const int r0 = __builtin_amdgcn_readlane(row, 0), r1 = __builtin_amdgcn_readlane(row, 16), r2 = __builtin_amdgcn_readlane(row, 32),
+                          r3 = __builtin_amdgcn_readlane(row, 48);
+                const int nb = min(4, n - 4 * bi);
+                const bool clash = (nb > 1 && r0 == r1) || (nb > 2 && (r0 == r2 || r1 == r2)) || (nb > 3 && (r0 == r3 || r1 == r3 || r2 == r3));
+                if (!clash) {   // (uniform)
+                    insert_round(row, d2, cc);
+                } else {
+                    for (int g = 0; g < nb; ++g) {
+                        insert_round(row, g16 == g ? d2 : INFINITY, cc);
+                        wave_fence_lds();
+                    }
                 }
             }
     };
@@ -425,7 +458,7 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         PH(4)
     };
     // the wave's insertion count and its rows' worst K-th distance, at the end of a tile
-    // (`ins` is counted by lane 0 alone; the maximum by DPP steps and two v_readlane -- a __shfl_xor is an LDS round trip, eleven of
+    // (`ins` is counted by the first lane of each 16-lane row; the maximum by DPP steps and two v_readlane -- a __shfl_xor is an LDS round trip, eleven of
     // them in a chain were 15 % of the kernel)
     auto publish = [&]() __attribute__((always_inline)) {
         float t = lane < 32 ? sh.thr[rowbase + lane] : -1.f;
@@ -435,7 +468,8 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x140, 0xf, 0xf, false)));
         const float tm = fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 0)),
                                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 16)));
-        if (lane == 0) { sh.wave_ins[(tdone + 1) & 1][wave] = ins; sh.wave_thr[(tdone + 1) & 1][rg] = tm; }
+        const int wins = __builtin_amdgcn_readlane(ins, 0) + __builtin_amdgcn_readlane(ins, 16) + __builtin_amdgcn_readlane(ins, 32) + __builtin_amdgcn_readlane(ins, 48);
+        if (lane == 0) { sh.wave_ins[(tdone + 1) & 1][wave] = wins; sh.wave_thr[(tdone + 1) & 1][rg] = tm; }
     };
     auto thrmax_now = [&]() {
         const float *w = sh.wave_thr[tdone & 1];
