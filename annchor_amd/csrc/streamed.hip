@@ -322,6 +322,45 @@ __global__ void k_st_level_keys(const float *__restrict__ D, const uint32_t *__r
     keys[p] = ((unsigned long long)sgm << 32) | (unsigned long long)__float_as_uint(v);
 }
 
+// A level of the k-d order whose segments are short (<= ST_SEG_LDS rows): one workgroup per segment sorts it in LDS by (distance to
+// the segment's split anchor, position) -- the position makes the bitonic network stable, so the order is the radix sort's, bit for
+// bit -- and writes it back in place.  One launch per level instead of 17-20 (key kernel + 5-6 radix passes of three kernels): the
+// deep levels of the order were launch-bound, 1.5 ms at N = 10^6 whatever the number of ranks.
+#define ST_SEG_LDS 4096
+__global__ __launch_bounds__(256) void k_st_level_sort_lds(const float *__restrict__ D, uint32_t *__restrict__ order, int64_t n, int level,
+                                                          const int32_t *__restrict__ coord, int seg_lo)
+{
+    __shared__ unsigned long long key[ST_SEG_LDS];
+    __shared__ uint32_t val[ST_SEG_LDS];
+    const int sgm = seg_lo + blockIdx.x;
+    const int64_t sb = ((int64_t)sgm * n + (1ll << level) - 1) >> level, se = ((int64_t)(sgm + 1) * n + (1ll << level) - 1) >> level;
+    const int len = (int)(se - sb);
+    int P = 2;
+    while (P < len) P <<= 1;
+    const float *Dc = D + (size_t)coord[sgm] * n;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        if (i < len) {
+            const uint32_t v = order[sb + i];
+            val[i] = v;
+            key[i] = ((unsigned long long)__float_as_uint(Dc[v]) << 32) | (unsigned long long)(uint32_t)i;
+        } else {
+            key[i] = ~0ull;
+        }
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (int t = threadIdx.x; t < P / 2; t += 256) {
+                const int q = 2 * t - (t & (j2 - 1)), p2 = q + j2;   // the t-th pair of the stage
+                const bool up = (q & k2) == 0;
+                const unsigned long long a = key[q], b = key[p2];
+                if ((a > b) == up) { key[q] = b; key[p2] = a; }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < len; i += 256) order[sb + i] = val[(uint32_t)key[i]];
+}
+
 __global__ void k_st_iota(uint32_t *v, int64_t n)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -584,6 +623,11 @@ extern "C" int annchor_stream_order_begin(annchor_ctx *c, int32_t min_tiles, int
         const int seg_lo = st_seg_of(pb, n, level), seg_hi = st_seg_of(pe - 1, n, level);
         const int64_t lb = ((int64_t)seg_lo * n + (1ll << level) - 1) >> level, le = ((int64_t)(seg_hi + 1) * n + (1ll << level) - 1) >> level;
         k_st_split_coord<<<seg_hi - seg_lo + 1, 1024, 0, c->stream>>>(s->Dt.as<float>(), nap, cur, n, s->na, level, seg_lo, s->red_idx.as<int32_t>());
+        static const bool lds_levels = !getenv("ANNCHOR_ST_ORDER_RADIX_ONLY");   // (the switch: every level by the radix sort, as before round 6)
+        if (lds_levels && ((n + (1ll << level) - 1) >> level) <= ST_SEG_LDS) {   // every segment of the level fits a workgroup's LDS
+            k_st_level_sort_lds<<<seg_hi - seg_lo + 1, 256, 0, c->stream>>>(s->D.as<float>(), cur, n, level, s->red_idx.as<int32_t>(), seg_lo);
+            continue;
+        }
         k_st_level_keys<<<ann_blocks(le - lb, 256), 256, 0, c->stream>>>(s->D.as<float>(), cur, n, level, s->red_idx.as<int32_t>(),
                                                                         s->keys.as<unsigned long long>(), lb, le);
         // (segment, distance to the split anchor): stable sort = every segment ordered along its coordinate.  The sort runs on

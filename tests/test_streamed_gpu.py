@@ -1010,3 +1010,37 @@ np.savez(sys.argv[1], **{"a%%d_%%d" %% (i, j): np.asarray(v) for i, o in enumera
         diff = ia != ib
         if diff.any():
             np.testing.assert_allclose(da[diff], db[diff], rtol=3e-7, atol=1e-7)
+
+
+def test_lds_level_sorts_equal_the_radix_sorts():
+    """The deep levels of the k-d order (segments of <= 4096 rows) are sorted by one workgroup per segment in LDS, keyed by
+    (distance to the split anchor, position): a stable order, i.e. the radix sort's -- the tile structure, hence the graph, is bit for
+    bit the one of ANNCHOR_ST_ORDER_RADIX_ONLY=1 (every level through the radix passes), also with many equal keys (lattice data)."""
+    import subprocess
+    import tempfile
+
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_streamed_gpu import latent
+from annchor_amd.streamed import StreamedAnnchor
+out = []
+rng = np.random.default_rng(3)
+for X, k, pw in ((latent(200000, 128), 15, 0.1), (latent(70001, 48), 10, 0.2), (rng.integers(0, 3, size=(50000, 20)).astype(np.float32), 8, 0.3)):
+    sa = StreamedAnnchor(X, n_anchors=16, n_neighbors=k, p_work=pw).fit()
+    out.append((sa.tile_evals, sa.neighbor_graph[0], sa.neighbor_graph[1]))
+np.savez(sys.argv[1], **{"a%%d_%%d" %% (i, j): np.asarray(v) for i, o in enumerate(out) for j, v in enumerate(o)})
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, env in (("lds", {}), ("radix", {"ANNCHOR_ST_ORDER_RADIX_ONLY": "1"})):
+            out = os.path.join(tmp, name + ".npz")
+            envd = dict(os.environ, **env)
+            if not env:
+                envd.pop("ANNCHOR_ST_ORDER_RADIX_ONLY", None)
+            r = subprocess.run([sys.executable, "-c", code, out], env=envd, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res.append(dict(np.load(out)))
+    assert res[0].keys() == res[1].keys()
+    for key in res[0]:
+        assert np.array_equal(res[0][key], res[1][key]), key
