@@ -475,6 +475,9 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         const float *w = sh.wave_thr[tdone & 1];
         return fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
     };
+    // (tried, twice -- here and in knnbf.hip's three-slot form: per-wave progress flags in LDS instead of the barrier, so that the waves
+    // need not meet after the part of a slab whose length differs between them, the survivors.  63.8 ms against 55.0: a polling wave
+    // keeps issuing -- LDS reads, compares, s_sleep -- on a SIMD whose other wave could use every slot, a wave at s_barrier does not.)
     auto slab_barrier = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
