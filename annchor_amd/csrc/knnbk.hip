@@ -679,6 +679,7 @@ template <int KMAX, bool JOIN = false> __global__ __launch_bounds__(STBK_THREADS
     // ---- exact re-ranking: the lists hold KL >= K columns chosen by the split-fp16 distance (error ~1e-5 relative on a
     // neighbour's d^2); their exact float32 distances sum (x - y)^2 decide which K are handed on, and in which order
     if (threadIdx.x == 0) sh.nsurv = 0;
+    if (threadIdx.x < 4) sh.wave_ins[0][threadIdx.x] = 0;   // (idle now: the guard's bitmask of flagged rows)
     {
         float *ex = KMAX <= ST_SLAB + 1 ? &sh.cand_d[0][0] : &sh.ring[0];   // [ST_T][KMAX] exact d^2 (cand_d / the ring are idle now)
         for (int q = threadIdx.x; q < ST_T * KL; q += STBK_THREADS) {
@@ -734,7 +735,10 @@ template <int KMAX, bool JOIN = false> __global__ __launch_bounds__(STBK_THREADS
             // guard, part 2: a column left outside the list has an approximate d^2 >= the list's last approximate entry; it can
             // only belong among the K nearest if its exact d^2 is below the K-th exact one, i.e. if the products were off by more
             // than the room between the two -- flagged when that room is within twice the measured error
-            if (!JOIN && nfin > K && ex[row * KMAX + K - 1] + 2.f * eps > sh.list_d[row][KL - 1] * inv_scale2) atomicAdd(&sh.nsurv, 1);   // (nsurv is idle here)
+            if (!JOIN && nfin > K && ex[row * KMAX + K - 1] + 2.f * eps > sh.list_d[row][KL - 1] * inv_scale2) {
+                atomicAdd(&sh.nsurv, 1);   // (nsurv is idle here)
+                atomicOr(reinterpret_cast<uint32_t *>(&sh.wave_ins[0][0]) + (row >> 5), 1u << (row & 31));   // (so are the waves' counters: the flagged rows)
+            }
         }
         __syncthreads();
         for (int q = threadIdx.x; q < ST_T * K; q += STBK_THREADS) {
@@ -755,7 +759,8 @@ template <int KMAX, bool JOIN = false> __global__ __launch_bounds__(STBK_THREADS
     } else if (threadIdx.x == 0) {
         atomicAdd(a.evals, (unsigned long long)processed);
         if (sh.nsurv) atomicAdd(a.evals + 3, (unsigned long long)sh.nsurv);   // slot 3: rows flagged by the guard
-        if (a.guard_tiles) a.guard_tiles[bt] = (uint32_t)sh.nsurv;                // ... and per row tile: those are done again exactly (repair.hip)
+        if (a.guard_tiles)                                                        // ... and which rows: those are done again exactly (repair.hip)
+            for (int w = 0; w < 4; ++w) a.guard_tiles[(size_t)bt * 4 + w] = (uint32_t)sh.wave_ins[0][w];
     }
 #ifdef ST_PROFILE
     P8(7)

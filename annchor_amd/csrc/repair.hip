@@ -1,140 +1,133 @@
-// repair.hip -- exact repair of the row tiles the split-fp16 tile kernels flag (k_st_repair).
+// repair.hip -- exact repair of the rows the split-fp16 tile kernels flag (k_st_repair).
 //
 // The split-fp16 kernels (knnbf.hip, knnbk.hip) SELECT by |x|^2 + |y|^2 - 2 x.y with products good to ~2^-22 |x||y| and re-rank
 // what they keep exactly; their guard flags a row when its K-th exact distance comes within the measured error of its list's last
 // approximate entry -- a neighbour may then have been left outside the list (tight clusters far from the centre: |x|^2 >> d^2).
 // No product form in float32 resolves such rows (the exact-f32 MFMA kernel evaluates the same expanded form), and beyond 256
 // dimensions there was no second kernel at all.  The reference computes np.linalg.norm(x - y) on the float32 rows
-// (annchor/distances.py:8-13): DIFFERENCES.  So the flagged row tiles are done again that way: one workgroup per flagged row tile,
-// over the column tiles that row tile evaluated (its bitmap row; without a recorded bitmap -- a full-budget build -- every column
-// tile whose interval bound stays below the row tile's worst exact K-th distance), sum (x - y)^2 in float32 on the vector ALUs,
-// sorted insertion per row by (d^2, column).  A slow path by construction (~20 us per tile pair at 300 dimensions, against 9 us
-// for the split kernel's 128): it runs for the flagged row tiles only, and well-conditioned data flags none (C3: 0 rows).
+// (annchor/distances.py:8-13): DIFFERENCES.  So the flagged ROWS are done again that way: one workgroup per row tile that holds
+// any (the kernels leave a 128-bit mask per row tile), row by row, over the column tiles that row tile evaluated (its bitmap row;
+// without a recorded bitmap -- a full-budget build -- every column tile whose interval bound stays below the row's K-th exact
+// distance so far): two threads per column sum (x - y)^2 in float32, the columns that beat the row's K-th entry are collected and
+// inserted in (d^2, column) order.  ~1 ms per flagged row at N = 10^6 (512 tiles of 128 columns x 128 dimensions); well-conditioned
+// data flags none (C3: 0 rows), N = 8 x 10^6 a handful.  (First form of the round: the whole row tile again, 128 rows against every
+// evaluated tile on one CU -- 50 ms for ONE flagged row tile at N = 8 x 10^6, whatever the number of ranks.)
 // Any padded dimension, any list length of the split kernels (K <= 62), graph builds and queries.
 #include "streamed.h"
 
 #define RP_THREADS 256
-#define RP_KC 32   // dimensions per staged chunk
-#define RP_CH 64   // columns per pass (half a column tile)
+#define RP_MAXDIM 1024
 
-__global__ __launch_bounds__(RP_THREADS) void k_st_repair(KnnArgs a, int dimp, const uint32_t *__restrict__ guard_tiles)
+// the flagged rows as a list: one thread per mask word, entries (row tile << 7 | row) appended in any order
+__global__ void k_st_repair_list(const uint32_t *__restrict__ guard_tiles, int64_t nwords, uint32_t *__restrict__ list, uint32_t *__restrict__ count,
+                                 uint32_t cap)
 {
-    const int bt = blockIdx.x;
-    if (!guard_tiles[bt]) return;   // (uniform)
-    extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
-    const int K = a.K;
-    float *ld = reinterpret_cast<float *>(rsm);                       // [ST_T][K] exact d^2, ascending by (d^2, column)
-    int32_t *lc = reinterpret_cast<int32_t *>(ld + ST_T * K);         // [ST_T][K]
-    float *d2m = reinterpret_cast<float *>(lc + ST_T * K);            // [ST_T][RP_CH + 1]
-    float *xs = d2m + ST_T * (RP_CH + 1);                             // [ST_T][RP_KC + 1]
-    float *ys = xs + ST_T * (RP_KC + 1);                              // [RP_CH][RP_KC + 1]
-    __shared__ float thr_w[RP_THREADS / 64];
-    const int I = a.tile_begin + bt;
-    const int64_t grow0 = (int64_t)I * ST_T;
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;        // thread (ty, tx): rows 8 ty .. + 7, columns 4 tx .. + 3 of a pass
-    for (int q = tid; q < ST_T * K; q += RP_THREADS) { ld[q] = INFINITY; lc[q] = 0x7fffffff; }
-    const uint32_t *eb = a.eval_bits ? a.eval_bits + (size_t)bt * a.eval_halves * a.eval_words : nullptr;
-    const float *slb = a.scr_lb + (size_t)bt * a.nt_all;             // valid interval bounds of (this row tile, every column tile)
-    float thrmax = INFINITY;   // (uniform) worst K-th exact d^2 over the tile's real rows
-    __syncthreads();
-    for (int J = 0; J < a.nt_all; ++J) {
-        if (eb) {
-            if (!((eb[J >> 5] >> (J & 31)) & 1u)) continue;            // the tile phase's own set of column tiles (its budget)
-        } else {
-            const float lb = slb[J];
-            if (!(lb * lb < thrmax) && !(J == I && !a.query)) continue;
-        }
-        for (int h = 0; h < ST_T / RP_CH; ++h) {
-            const int64_t c0 = (int64_t)J * ST_T + h * RP_CH;
-            float acc[8][4];
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-            for (int k0 = 0; k0 < dimp; k0 += RP_KC) {
-                __syncthreads();
-                for (int u = tid; u < ST_T * RP_KC / 4; u += RP_THREADS) {
-                    const int row = u / (RP_KC / 4), q4 = u % (RP_KC / 4);
-                    const float4 v = *reinterpret_cast<const float4 *>(a.Rs + (size_t)(grow0 + row) * dimp + k0 + 4 * q4);
-                    float *d = xs + row * (RP_KC + 1) + 4 * q4;
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-                }
-                for (int u = tid; u < RP_CH * RP_KC / 4; u += RP_THREADS) {
-                    const int cl = u / (RP_KC / 4), q4 = u % (RP_KC / 4);
-                    const float4 v = *reinterpret_cast<const float4 *>(a.Xs + (size_t)(c0 + cl) * dimp + k0 + 4 * q4);
-                    float *d = ys + cl * (RP_KC + 1) + 4 * q4;
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-                }
-                __syncthreads();
-#pragma unroll 4
-                for (int kk = 0; kk < RP_KC; ++kk) {
-                    float xv[8], yv[4];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) xv[i] = xs[(8 * ty + i) * (RP_KC + 1) + kk];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) yv[j] = ys[(4 * tx + j) * (RP_KC + 1) + kk];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float df = xv[i] - yv[j];
-                            acc[i][j] += df * df;
-                        }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t cc = c0 + 4 * tx + j;
-                const bool colreal = a.rs[cc] < INFINITY;   // (padding columns carry +inf)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int row = 8 * ty + i;
-                    const bool self = !a.query && cc == grow0 + row;   // a point is not its own neighbour
-                    d2m[row * (RP_CH + 1) + 4 * tx + j] = (colreal && !self) ? acc[i][j] : INFINITY;
-                }
-            }
-            __syncthreads();
-            if (tid < ST_T && a.rr[grow0 + tid] < INFINITY) {   // one thread per (real) row: sorted insertion of what beats the row's K-th entry
-                const int row = tid;
-                float *rd = ld + row * K;
-                int32_t *rc = lc + row * K;
-                for (int cix = 0; cix < RP_CH; ++cix) {
-                    const float d = d2m[row * (RP_CH + 1) + cix];
-                    const int32_t cc = (int32_t)(c0 + cix);
-                    if (!(d < rd[K - 1] || (d == rd[K - 1] && cc < rc[K - 1]))) continue;
-                    int p = K - 1;
-                    while (p > 0 && (d < rd[p - 1] || (d == rd[p - 1] && cc < rc[p - 1]))) { rd[p] = rd[p - 1]; rc[p] = rc[p - 1]; --p; }
-                    rd[p] = d; rc[p] = cc;
-                }
-            }
-            __syncthreads();
-        }
-        if (!eb) {   // the pruning threshold: the worst K-th exact d^2 of the tile's real rows
-            float t = (tid < ST_T && a.rr[grow0 + tid] < INFINITY) ? ld[tid * K + K - 1] : -1.f;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) t = fmaxf(t, __shfl_xor(t, off));
-            if ((tid & 63) == 0) thr_w[tid >> 6] = t;
-            __syncthreads();
-            thrmax = fmaxf(fmaxf(thr_w[0], thr_w[1]), fmaxf(thr_w[2], thr_w[3]));
-            __syncthreads();
-        }
-    }
-    __syncthreads();
-    for (int q = tid; q < ST_T * K; q += RP_THREADS) {
-        const int row = q / K;
-        if (!(a.rr[grow0 + row] < INFINITY)) continue;   // (padding rows keep what the tile kernel wrote)
-        a.out_d2[(size_t)bt * ST_T * K + q] = ld[q];
-        a.out_col[(size_t)bt * ST_T * K + q] = ld[q] < INFINITY ? lc[q] : 0x7fffffff;
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    uint32_t bits = guard_tiles[w];
+    while (bits) {
+        const int b = __builtin_ctz(bits);
+        bits &= bits - 1;
+        const uint32_t slot = atomicAdd(count, 1u);
+        if (slot < cap) list[slot] = (uint32_t)((w >> 2) << 7) | (uint32_t)(((w & 3) << 5) + b);
     }
 }
 
-// the flagged row tiles of the tile phase just run (guard_tiles[tile_count]: rows flagged per row tile), exactly
-int ann_stream_repair_flagged(annchor_ctx *c, const KnnArgs &a, int dim_padded, const uint32_t *guard_tiles)
+__global__ __launch_bounds__(RP_THREADS) void k_st_repair(KnnArgs a, int dimp, const uint32_t *__restrict__ list, const uint32_t *__restrict__ count)
 {
-    const size_t lds = sizeof(float) * ((size_t)2 * ST_T * a.K + (size_t)ST_T * (RP_CH + 1) + (size_t)ST_T * (RP_KC + 1) + (size_t)RP_CH * (RP_KC + 1));
-    ANN_REQUIRE(c, lds <= 150 * 1024, ANNCHOR_ELIMIT, "exact repair: %d-entry lists need %zu B of LDS", a.K, lds);
-    ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_repair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_st_repair<<<a.tile_count, RP_THREADS, lds, c->stream>>>(a, dim_padded, guard_tiles);
+    if (blockIdx.x >= *count) return;
+    const uint32_t ent = list[blockIdx.x];
+    const int bt = (int)(ent >> 7);
+    uint32_t gw[4] = {0, 0, 0, 0};
+    gw[(ent & 127) >> 5] = 1u << (ent & 31);   // (one row per workgroup: the rows of a tile run side by side)
+    __shared__ float xrow[RP_MAXDIM];
+    __shared__ float ld[ST_KMAX_BIG];        // the row's list: exact d^2 ascending by (d^2, column)
+    __shared__ int32_t lc[ST_KMAX_BIG];
+    __shared__ float cd[ST_T];               // candidates of one column tile: what beats the K-th entry
+    __shared__ int32_t cc_[ST_T];
+    __shared__ int ncand;
+    const int K = a.K;
+    const int I = a.tile_begin + bt;
+    const int64_t grow0 = (int64_t)I * ST_T;
+    const int tid = threadIdx.x, cl = tid >> 1, hf = tid & 1;   // two threads per column: halves of the dimensions
+    const uint32_t *eb = a.eval_bits ? a.eval_bits + (size_t)bt * a.eval_halves * a.eval_words : nullptr;
+    const float *slb = a.scr_lb + (size_t)bt * a.nt_all;      // valid interval bounds of (this row tile, every column tile)
+    const int hd = dimp >> 1;                                // (dimp is a multiple of 32)
+    for (int row = 0; row < ST_T; ++row) {
+        if (!((gw[row >> 5] >> (row & 31)) & 1u)) continue;   // (uniform)
+        __syncthreads();
+        for (int k = tid; k < dimp; k += RP_THREADS) xrow[k] = a.Rs[(size_t)(grow0 + row) * dimp + k];
+        if (tid < K) { ld[tid] = INFINITY; lc[tid] = 0x7fffffff; }
+        if (tid == 0) ncand = 0;
+        __syncthreads();
+        // (word by word: a bitmap read per column tile -- 62 500 of them at N = 8 x 10^6 for ~660 evaluated -- was the kernel's time)
+        for (int w = 0; w < (a.nt_all + 31) / 32; ++w) {
+        uint32_t wbits = eb ? eb[w] : 0xffffffffu;
+        while (wbits) {   // (uniform)
+            const int J = 32 * w + __builtin_ctz(wbits);
+            wbits &= wbits - 1;
+            if (J >= a.nt_all) break;
+            const float thr = ld[K - 1];
+            const int32_t thc = lc[K - 1];
+            if (!eb) {   // (with a bitmap: the tile phase's own set of column tiles, its budget)
+                const float lb = slb[J];
+                if (!(lb * lb < thr) && !(J == I && !a.query)) continue;
+            }
+            const int64_t col = (int64_t)J * ST_T + cl;
+            const float4 *y = reinterpret_cast<const float4 *>(a.Xs + (size_t)col * dimp + hf * hd);
+            const float4 *x = reinterpret_cast<const float4 *>(xrow + hf * hd);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8   // (eight loads in flight per thread: one at a time, a tile cost sixteen global round trips)
+            for (int t = 0; t < hd / 4; ++t) {
+                const float4 u = x[t], v = y[t];
+                const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z, dw = u.w - v.w;
+                s0 += dx * dx; s1 += dy * dy; s2 += dz * dz; s3 += dw * dw;
+            }
+            float d = (s0 + s1) + (s2 + s3);
+            d += __shfl_xor(d, 1);
+            const bool real = a.rs[col] < INFINITY && !(!a.query && col == grow0 + row);   // (padding columns carry +inf; a point is not its own neighbour)
+            if (hf == 0 && real && (d < thr || (d == thr && (int32_t)col < thc))) {
+                const int slot = atomicAdd(&ncand, 1);
+                cd[slot] = d; cc_[slot] = (int32_t)col;
+            }
+            __syncthreads();
+            if (ncand) {   // (uniform)
+                if (tid == 0) {
+                    for (int q = 0; q < ncand; ++q) {
+                        const float dq = cd[q];
+                        const int32_t cq = cc_[q];
+                        if (!(dq < ld[K - 1] || (dq == ld[K - 1] && cq < lc[K - 1]))) continue;
+                        int p = K - 1;
+                        while (p > 0 && (dq < ld[p - 1] || (dq == ld[p - 1] && cq < lc[p - 1]))) { ld[p] = ld[p - 1]; lc[p] = lc[p - 1]; --p; }
+                        ld[p] = dq; lc[p] = cq;
+                    }
+                    ncand = 0;
+                }
+                __syncthreads();
+            }
+        }
+        }
+        __syncthreads();
+        if (tid < K) {
+            a.out_d2[((size_t)bt * ST_T + row) * K + tid] = ld[tid];
+            a.out_col[((size_t)bt * ST_T + row) * K + tid] = ld[tid] < INFINITY ? lc[tid] : 0x7fffffff;
+        }
+    }
+}
+
+// the flagged rows of the tile phase just run (guard_tiles [tile_count][4]: a bitmask of flagged rows per row tile; `flagged`: how
+// many, as the host read it), exactly: a list of them, then one workgroup per row
+int ann_stream_repair_flagged(annchor_ctx *c, StreamState *s, const KnnArgs &a, int dim_padded, const uint32_t *guard_tiles, int64_t flagged)
+{
+    ANN_REQUIRE(c, dim_padded <= RP_MAXDIM && a.K <= ST_KMAX_BIG, ANNCHOR_ELIMIT, "exact repair: padded dim %d, %d-entry lists", dim_padded, a.K);
+    if (flagged <= 0) return ANNCHOR_OK;
+    const int64_t cap = std::min<int64_t>(flagged, (int64_t)a.tile_count * ST_T);
+    ANN_TRY(ann_stream_reserve(c, s->guard_list, sizeof(uint32_t) * (size_t)(cap + 1)));
+    uint32_t *cnt = s->guard_list.as<uint32_t>(), *list = cnt + 1;
+    ANN_CHECK_HIP(c, hipMemsetAsync(cnt, 0, sizeof(uint32_t), c->stream));
+    const int64_t nwords = (int64_t)a.tile_count * 4;
+    k_st_repair_list<<<ann_blocks(nwords, 256), 256, 0, c->stream>>>(guard_tiles, nwords, list, cnt, (uint32_t)cap);
+    k_st_repair<<<(unsigned)cap, RP_THREADS, 0, c->stream>>>(a, dim_padded, list, cnt);
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;
 }

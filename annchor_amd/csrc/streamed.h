@@ -62,7 +62,8 @@ struct StreamState {
     int last_kernel = 0;   // tile phase of the last build: 0 k_st_knn (exact f32), 1 k_st_knnbf (split fp16)
     int64_t last_guard_rows = 0;   // rows the split-fp16 kernel flagged (error band of the split products reaches the list boundary)
     bool last_repaired = false;    // the flagged rows' row tiles were done again exactly (repair.hip)
-    DevBuf guard_tiles;            // uint32 [tile_count]: flagged rows per row tile
+    DevBuf guard_tiles;            // uint32 [tile_count][4]: bitmask of the flagged rows of every row tile
+    DevBuf guard_list;             // uint32 [1 + flagged]: their number, then (row tile << 7 | row) of each (repair.hip)
     int dim = 0, dimp = 0, na = 0, nt = 0;
     struct KnnArgs *run = nullptr;   // arguments of the graph build in progress (begin / join / end)
     const void *run_perm = nullptr;
@@ -127,7 +128,7 @@ struct KnnArgs {
     int dimr;                    // knnbk.hip: the rows' padded dimension (a multiple of 128), set by its launcher
     uint32_t *scr_cl;            // [tile_count][3][ST_CL_CAP] per row tile: the selection rounds' short list (NULL: the rounds sweep the scratch rows)
     int pre_ranked;              // scr_key / scr_lb already hold every (row tile, column tile) pair's rank key and bound (k_st_rank_pairs)
-    uint32_t *guard_tiles;       // [tile_count] rows the split-fp16 kernels' guard flagged, per row tile (NULL: not recorded); repair.hip
+    uint32_t *guard_tiles;       // [tile_count][4] bitmask of the rows the split-fp16 kernels' guard flagged (NULL: not recorded); repair.hip
 };
 
 StreamState *ann_stream_state(annchor_ctx *c, bool create);
@@ -154,7 +155,7 @@ int ann_stream_launch_knnh(annchor_ctx *c, const struct KnnArgs &a, int dim_padd
 int ann_stream_launch_knnbk(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, bool *handled, bool join = false);
 int ann_stream_split_rows(annchor_ctx *c, StreamState *s);     // Xb from Xs (after the ordering)
 // repair.hip: the row tiles the split kernels' guard flagged, done again with float32 DIFFERENCES (exact; any dimension)
-int ann_stream_repair_flagged(annchor_ctx *c, const struct KnnArgs &a, int dim_padded, const uint32_t *guard_tiles);
+int ann_stream_repair_flagged(annchor_ctx *c, struct StreamState *s, const struct KnnArgs &a, int dim_padded, const uint32_t *guard_tiles, int64_t flagged);
 // the split copy (+ centred norms, centre) that belongs to an ordered float32 array; false: none
 bool ann_stream_split_of(const void *Xs, const uint16_t **Xb, const float **rsb, const float **cvec);
 int ann_stream_reserve(annchor_ctx *c, DevBuf &b, size_t bytes);   // individual allocation, grow-only, contents NOT kept

@@ -1967,8 +1967,8 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
         a.eval_bits = s->eval_bits.as<uint32_t>();
     }
     a.lists_all = nullptr; a.ucand = nullptr; a.ucount = nullptr; a.ucap = JN_CAP; a.out_d2_new = nullptr; a.out_col_new = nullptr;
-    ANN_TRY(sreserve(c, s->guard_tiles, sizeof(uint32_t) * (size_t)a.tile_count));
-    ANN_CHECK_HIP(c, hipMemsetAsync(s->guard_tiles.p, 0, sizeof(uint32_t) * (size_t)a.tile_count, c->stream));
+    ANN_TRY(sreserve(c, s->guard_tiles, sizeof(uint32_t) * 4 * (size_t)a.tile_count));
+    ANN_CHECK_HIP(c, hipMemsetAsync(s->guard_tiles.p, 0, sizeof(uint32_t) * 4 * (size_t)a.tile_count, c->stream));
     a.guard_tiles = s->guard_tiles.as<uint32_t>();
     a.updates = nullptr;
     {
@@ -2030,7 +2030,7 @@ static int knn_tile_phase(annchor_ctx *c, StreamState *s, KnnArgs &a, int dim_pa
                                 "resolve (|x|^2 >> d^2); their row tiles are evaluated again with float32 differences (exact, slower)\n",
                         flagged, (long long)rows);
             ProfScope ps(c, "stream_tile_exact_repair", 0.0);
-            ANN_TRY(ann_stream_repair_flagged(c, a, dim_padded, a.guard_tiles));
+            ANN_TRY(ann_stream_repair_flagged(c, s, a, dim_padded, a.guard_tiles, (int64_t)flagged));
             s->last_repaired = true;
         } else if ((int64_t)flagged > std::max<int64_t>(8, rows / 200) && !no_fallback && dim_padded > 256) {
             // (the exact-f32 tile kernel stops at padded dim 256: the caller sees the count through annchor_stream_last_kernel)
