@@ -111,6 +111,7 @@ _SIGNATURES = {
                                                                                        ctypes.POINTER(_i32)]),
     "annchor_stream_last_counts": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "annchor_stream_last_kernel": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_i64)]),
+    "annchor_stream_last_tile_kernels": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "annchor_stream_budget": (ctypes.c_int, [_i32, _dbl, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "annchor_stream_knn_end": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "annchor_stream_knn_run": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _i32, _i32,
@@ -993,6 +994,12 @@ class Engine:
         k, g = ctypes.c_int32(), _i64()
         self._chk(self.lib.annchor_stream_last_kernel(self.h, ctypes.byref(k), ctypes.byref(g)))
         return (int(k.value), int(g.value)) if with_guard else int(k.value)
+
+    def stream_last_tile_kernels(self):
+        """(two_stage, repaired) of the last build's tile phase: k_st_knnh ran behind the warm-up; flagged rows were repaired exactly."""
+        a, b = ctypes.c_int32(), ctypes.c_int32()
+        self._chk(self.lib.annchor_stream_last_tile_kernels(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return bool(a.value), bool(b.value)
 
     def stream_join_tables(self, gathered, world, n_anchors, n_tiles, joined):
         self._chk(self.lib.annchor_stream_join_tables(self.h, gathered, int(world), int(n_anchors), int(n_tiles), joined))

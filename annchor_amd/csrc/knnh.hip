@@ -799,6 +799,7 @@ int ann_stream_launch_knnh(annchor_ctx *c, const KnnArgs &a0, int dim_padded, bo
     const size_t lds = sizeof(KnnSharedH<16>);
     ANN_REQUIRE(c, lds <= 80 * 1024, ANNCHOR_ELIMIT, "streamed k-NN (two-stage form) needs %zu B of LDS", lds);
     ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knnh<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope ps(c, "stream_tile_two_stage_kernel", 0.0);   // (inside stream_tile_gemm_topk: k_st_knnh alone, without the warm-up)
     k_st_knnh<16><<<a0.tile_count, STH_THREADS, lds, c->stream>>>(a0);
     ANN_CHECK_HIP(c, hipGetLastError());
     return ANNCHOR_OK;

@@ -61,7 +61,8 @@ struct StreamState {
     int64_t last_tile_evals = 0, last_join_chunks = 0, last_fetched_tiles = 0;
     int last_kernel = 0;   // tile phase of the last build: 0 k_st_knn (exact f32), 1 k_st_knnbf (split fp16)
     int64_t last_guard_rows = 0;   // rows the split-fp16 kernel flagged (error band of the split products reaches the list boundary)
-    bool last_repaired = false;    // the flagged rows' row tiles were done again exactly (repair.hip)
+    bool last_repaired = false;    // the flagged rows were done again exactly (repair.hip)
+    bool last_two_stage = false;   // the tile phase ran k_st_knnh (knnh.hip) behind its warm-up
     DevBuf guard_tiles;            // uint32 [tile_count][4]: bitmask of the flagged rows of every row tile
     DevBuf guard_list;             // uint32 [1 + flagged]: their number, then (row tile << 7 | row) of each (repair.hip)
     int dim = 0, dimp = 0, na = 0, nt = 0;

@@ -1826,7 +1826,10 @@ static int launch_by_dim(annchor_ctx *c, const KnnArgs &a, int dim_padded, bool 
                 }
             }
 #endif
-            if (!join) ANN_TRY(ann_stream_launch_knnh(c, a, dim_padded, &handled, ann_stream_launch_knnbf));   // (two-stage form: knnh.hip)
+            if (!join) {   // (two-stage form: knnh.hip)
+                ANN_TRY(ann_stream_launch_knnh(c, a, dim_padded, &handled, ann_stream_launch_knnbf));
+                if (st) st->last_two_stage = handled;
+            }
             if (!handled && !(kern && !strcmp(kern, "bk") && dim_padded == 128)) ANN_TRY(ann_stream_launch_knnbf(c, a, dim_padded, &handled, join));
             if (!handled) ANN_TRY(ann_stream_launch_knnbk(c, a, dim_padded, &handled, join));   // padded dim 256 .. 1024: k-blocked
             if (handled) {
@@ -2207,6 +2210,18 @@ extern "C" int annchor_stream_last_kernel(annchor_ctx *c, int32_t *kind, int64_t
     ANN_REQUIRE(c, s != nullptr, ANNCHOR_ESTATE, "no streamed build on this context");
     *kind = s->last_kernel;
     *guard_rows = s->last_guard_rows;
+    return ANNCHOR_OK;
+}
+
+// *two_stage: the last tile phase ran the two-stage kernel k_st_knnh (fp16 hi-only filter + float32 differences) behind
+// k_st_knnbf's warm-up; *repaired: rows flagged by the split kernels' guard were evaluated again exactly (k_st_repair)
+extern "C" int annchor_stream_last_tile_kernels(annchor_ctx *c, int32_t *two_stage, int32_t *repaired)
+{
+    if (!c || !two_stage || !repaired) return ANNCHOR_EINVAL;
+    StreamState *s = state_of(c, false);
+    ANN_REQUIRE(c, s, ANNCHOR_ESTATE, "no streamed build on this context");
+    *two_stage = s->last_two_stage ? 1 : 0;
+    *repaired = s->last_repaired ? 1 : 0;
     return ANNCHOR_OK;
 }
 

@@ -354,6 +354,26 @@ def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, r
                                    "tile_pairs": int(tile_phase_evals),
                                    "note": "algorithmic flops = tile pairs of the tile phase (<= its budget x row tiles of rank 0) "
                                            "x 128 x 128 x 2 x d; peak = dense f32 MFMA"}
+            elif hasattr(last._engine, "stream_last_tile_kernels") and last._engine.stream_last_tile_kernels()[0] and "stream_tile_two_stage_kernel" in prof:
+                # the two-stage tile phase (csrc/knnh.hip): k_st_knnh behind k_st_knnbf's warm-up of 33 tiles per row tile.  The dominant
+                # kernel streams the fp16 hi halves of every evaluated column tile ONCE: 128 columns x 256 B + 128 norms = 33 280 B per tile
+                # pair -- its algorithmic bytes -- and 8 MFMAs per 32 x 32 x 128 block (one product per pair of hi halves)
+                tk = prof["stream_tile_two_stage_kernel"]
+                t_h = tk["ms"] / max(1, tk["launches"]) * 1e-3
+                warm_pairs = min(int(tile_phase_evals), int(last.n_tiles_total if world == 1 else -(-last.n_tiles_total // world)) * 33)
+                pairs_h = max(0, int(tile_phase_evals) - warm_pairs)
+                bytes_h = pairs_h * 33280.0
+                out["roofline"] = {"kernel": "stream_tile_gemm_topk / k_st_knnh (two-stage: fp16 hi-only MFMA filter with a rigorous bound + exact float32 differences for the survivors)",
+                                   "bound": "hbm", "achieved": bytes_h / t_h / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_h / t_h / 1e9 / HBM_PEAK_GBS,
+                                   "traffic": pmc_traffic("k_st_knnh", largest=True), "tile_pairs": pairs_h, "kernel_ms": round(t_h * 1e3, 3),
+                                   "warm_up": {"kernel": "k_st_knnbf<128, 16> with a budget of 33 tiles per row tile", "tile_pairs_at_most": warm_pairs,
+                                               "ms": round((gemm_s - t_h) * 1e3, 3), "traffic": pmc_traffic("k_st_knnbf<128, 16, false", largest=True)},
+                                   "mfma_view": {"bound": "mfma", "achieved": pairs_h * 128.0 * 128.0 * 2.0 * 128.0 / t_h / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                 "frac": pairs_h * 128.0 * 128.0 * 2.0 * 128.0 / t_h / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                                                 "note": "issued = algorithmic here: one fp16 MFMA product per coordinate pair (the split-fp16 kernel issued three)"},
+                                   "note": "algorithmic bytes = tile pairs of k_st_knnh x 33 280 B (the hi halves of 128 columns + their norms, fetched once each); the "
+                                           "kernel is bound by what its waves ISSUE (a SIMD issues for one of its two waves at a time: 256 matrix-pipe cycles + ~110 vector "
+                                           "and ~70 scalar instructions per 32 columns and wave, DESIGN.md section 7), on neither roof; traffic = the PMC passes' bytes per launch"}
             else:
                 name = "k_st_knnbf"
                 out["roofline"] = {"kernel": "stream_tile_gemm_topk (%s: split-fp16 tile GEMMs, 3 x v_mfma_f32_32x32x16_f16 per 16 dimensions)" % name,
@@ -452,7 +472,8 @@ def cpu_baseline(X, cfg):
     ora = O.OracleAnnchor(len(X), P.pairs, **cfg).fit()
     dt = time.perf_counter() - t
     return dict(value=1.0 / dt, unit="graphs/s", fit_time_s=dt, cores=int(getattr(P, "threads", os.cpu_count())),
-                kind="port", sample="1 full fit() of the same workload (metric in C/OpenMP, pipeline in NumPy)",
+                kind="port", port_of="the oracle: NumPy pipeline + C/OpenMP metric (a NumPy-pipeline port, not a C++ restatement of the pipeline)",
+                sample="1 full fit() of the same workload (metric in C/OpenMP, pipeline in NumPy)",
                 evals=int(ora.evals))
 
 

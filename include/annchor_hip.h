@@ -414,6 +414,13 @@ int annchor_stream_last_counts(annchor_ctx *ctx, int64_t *tile_phase_evals, int6
  * reported neighbour distances are exact float32 in every case (the metric of the reference on float32 rows:
  * distances.py:8-13). */
 int annchor_stream_last_kernel(annchor_ctx *ctx, int32_t *kind, int64_t *guard_rows);
+/* Round 6.  *two_stage = 1: the tile phase of the last build ran k_st_knnh (csrc/knnh.hip) behind a short k_st_knnbf warm-up -- fp16
+ * hi-only products with a rigorous error bound decide which columns MAY enter a row's list, float32 differences of the original rows
+ * (the reference's arithmetic, distances.py:8-13) decide which do: graph builds at padded dimension 128, <= 14 neighbours kept.
+ * *repaired = 1: rows flagged by the split kernels' guard (see above) were evaluated again with float32 differences over the column
+ * tiles their row tile evaluated (csrc/repair.hip: any dimension) -- this replaces both the 1-in-200 allowance and the repetition on
+ * the exact-f32 kernel (ANNCHOR_ST_FALLBACK=rerun keeps those). */
+int annchor_stream_last_tile_kernels(annchor_ctx *ctx, int32_t *two_stage, int32_t *repaired);
 /* Queries against a fitted data set in the streamed form (Annchor.query, annchor.py:643-683 ->
  * query_functions.py:183-212, for data sets beyond the pair-list form).  The context holds
  * the QUERY rows: bound with annchor_stream_bind (global_base 0), given the data set's anchor
