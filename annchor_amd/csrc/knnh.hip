@@ -34,7 +34,10 @@
 #define STH_THREADS 256
 #define ST_BF_MARGIN_H 2   // (the warm-up kernel's list margin: its shapes are this kernel's)
 #define STH_COLS 64        // columns per slab
-#define STH_Q 8            // exact evaluations in flight per wave (deferred by one slab)
+#ifndef STH_Q
+#define STH_Q 4            // exact evaluations in flight per wave (deferred by one slab): one batch.  (8: 52.6 ms against 51.4 at C3 --
+                           // sixteen more registers and twice the code for a second batch that is rarely full; 12 spills: 87 ms)
+#endif
 #define STH_QCAP 64        // survivors a stream can queue (one lane of two registers each); more: the slab is rebuilt from the accumulators
 #define STH_BETA 1.0254e-3f   // 1.05 x 2^-10
 #define STH_SLACK 0.125f      // absolute slack of the test in scaled units (subnormal fp16 halves: <= 2^-25 per coordinate)
@@ -239,8 +242,8 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     // survivor g's row and column (two 16-byte loads each: the 16 lanes read 512 contiguous bytes), the 16-lane sum is four DPP
     // steps and leaves d^2 in every lane of the row, which also holds that survivor's list -- the insertion needs nothing from a
     // scalar register.  (First form: one survivor per wave pass, 64 lanes x 2 dimensions, a six-step reduction, v_readlane, ~58
-    // vector instructions per survivor; the wave's vector instructions, not the matrix pipe, were what a slab cost.)  Two such
-    // batches are in flight (STH_Q = 8 survivors).
+    // vector instructions per survivor; the wave's vector instructions, not the matrix pipe, were what a slab cost.)  STH_Q / 4
+    // such batches are in flight.
     constexpr int NB = STH_Q / 4;
     float4 xa[NB], xc[NB], ya[NB], yc[NB];
 #pragma unroll
@@ -377,7 +380,7 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         for (int g = 0; g < G; ++g) b1[g] = base1[(2 * g) ^ gsw];
         const float n0 = -0.5f * (1.f - STH_BETA) * rj0, n1 = -0.5f * (1.f - STH_BETA) * rj1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { c0[r] = n0; c1[r] = n1; }
+        for (int r = 0; r < 16; ++r) c0[r] = n0;
         // (a branch on a vector compare's mask waits out the vector pipe and holds the next MFMA back: ~30 cycles each, 32 of them
         // doubled the stream.  Four rows' masks are taken together -- four compares back to back, ONE branch on their OR; the rare
         // group with a survivor then looks at its four masks, which sit in scalar registers by then)
@@ -388,6 +391,10 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
                 const int mm = m + h2;
                 if (mm < G) c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mm], __builtin_bit_cast(f16x8h, b0[mm]), c0, 0, 0, 0);
                 else c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mm - G], __builtin_bit_cast(f16x8h, b1[mm - G]), c1, 0, 0, 0);
+                if (mm == 0) {   // the second group's accumulators start in the first MFMAs' shadow
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c1[r] = n1;
+                }
             }
             if (pend) {   // (uniform)
                 unsigned long long mk[4];
