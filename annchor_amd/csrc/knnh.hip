@@ -269,7 +269,7 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     auto issue_slots = [&](int b, int n, int QP, int QB) __attribute__((always_inline)) {
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi)
-            if (4 * bi < n) {   // (uniform)
+            if (__builtin_expect(4 * bi < n, 0)) {   // (uniform)
                 int row; int32_t cc;
                 (void)my_survivor(b, n, bi, QP, QB, row, cc);
                 const float4 *px = reinterpret_cast<const float4 *>(a.Rs + (size_t)(grow0 + row) * DIM + 8 * e16);
@@ -298,7 +298,7 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     auto consume_slots = [&](int b, int n, int QP, int QB) __attribute__((always_inline)) {
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi)
-            if (4 * bi < n) {   // (uniform)
+            if (__builtin_expect(4 * bi < n, 0)) {   // (uniform)
                 int row; int32_t cc;
                 const bool valid = my_survivor(b, n, bi, QP, QB, row, cc);
                 float t;
@@ -319,7 +319,7 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
                           r3 = __builtin_amdgcn_readlane(row, 48);
                 const int nb = min(4, n - 4 * bi);
                 const bool clash = (nb > 1 && r0 == r1) || (nb > 2 && (r0 == r2 || r1 == r2)) || (nb > 3 && (r0 == r3 || r1 == r3 || r2 == r3));
-                if (!clash) {   // (uniform)
+                if (__builtin_expect(!clash, 1)) {   // (uniform)
                     insert_round(row, d2, cc);
                 } else {
                     for (int g = 0; g < nb; ++g) {
@@ -362,7 +362,7 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     // (accumulators p0, p1, first column pc0) in their shadow: two rows' masks per MFMA, a mask that is not empty is queued
     auto stream = [&](int slot, f32x16 &c0, f32x16 &c1, const f32x16 &p0, const f32x16 &p1, bool pend) __attribute__((always_inline)) {
         const float rj0 = sh.norms[slot * STH_COLS + col], rj1 = sh.norms[slot * STH_COLS + 32 + col];
-        if (hq_stale) {   // (uniform) the thresholds of the lane's 16 rows: read again after an insertion of this wave
+        if (__builtin_expect(hq_stale, 0)) {   // (uniform) the thresholds of the lane's 16 rows: read again after an insertion of this wave
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 h4 = *reinterpret_cast<const float4 *>(&sh.hb[rowq + 8 * q]);
@@ -403,7 +403,10 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
                     const int ti = 2 * m + u, g2 = ti >> 4, r = ti & 15;
                     mk[u] = __ballot((g2 ? p1[r] : p0[r]) > hqr[r]);
                 }
-                if (mk[0] | mk[1] | mk[2] | mk[3]) {
+                // (86 % of the slabs have no survivor at all once the lists are warm -- 0.43 per wave and slab at C3 --: everything
+                // behind these branches is cold code, and is told so: the kernel is larger than the instruction cache two CUs
+                // share, what the hot loop does not run must not sit between what it does)
+                if (__builtin_expect((mk[0] | mk[1] | mk[2] | mk[3]) != 0, 0)) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int ti = 2 * m + u, g2 = ti >> 4, r = ti & 15;
@@ -427,7 +430,7 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         PH(3)
         if (dJ >= 0) issue(dJ, dslab, seq + 2);   // (its slot held slab seq - 1: every wave has passed this slab's barrier)
         if (!pend) { nq = 0; return; }
-        if (nq > STH_QCAP) {
+        if (__builtin_expect(nq > STH_QCAP, 0)) {
             // (the first tiles after a cold start, ill-conditioned data) per-lane row masks from the accumulators, queue by queue
             nq = 0;
 #pragma unroll
@@ -453,11 +456,11 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
             }
             drain_sync(nq, qpk, pc0);
             PH(6)
-        } else if (nq > STH_Q) {
+        } else if (__builtin_expect(nq > STH_Q, 0)) {
             PH(4)
             drain_sync(nq, qpk, pc0);
             PH(6)
-        } else if (nq > 0) {
+        } else if (__builtin_expect(nq > 0, 0)) {
             issue_slots(0, nq, qpk, pc0);
             fpk = qpk; fbase = pc0; nfl = nq;
         }
@@ -505,7 +508,7 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         auto next_tile = [&](int in_stream) -> int {
             if (a.early_window > 0 && !dried) {
                 const int done = processed - in_stream;
-                if (done - win_start >= a.early_window) {
+                if (__builtin_expect(done - win_start >= a.early_window, 0)) {
                     int cur = 0;
 #pragma unroll
                     for (int w = 0; w < 4; ++w) cur += sh.wave_ins[tdone & 1][w];
