@@ -983,8 +983,10 @@ def main():
             "value": res["graphs_per_s"], "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["fit_time_s"] * 1e3, "fit_time_s": res["fit_time_s"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 rows; tile selection on fp16 hi + lo split operands with f32 accumulation (v_mfma_f32_32x32x16_f16: products to 2^-22 |x||y|, the accuracy of the f32 MFMA stream), the kept "
-                     "columns re-ranked by exact f32 distances; reported distances exact f32, widened to f64",
+            "dtype": "f32 rows; tile phase in two stages: fp16 hi-half products with f32 accumulation (v_mfma_f32_32x32x16_f16) and a proven error bound "
+                     "decide which columns MAY enter a row's list, exact f32 sums of (x - y)^2 decide which do (the first 32 tiles per row tile and the "
+                     "join passes: split fp16 hi + lo products to 2^-22 |x||y|, kept columns re-ranked by the same exact f32 sums); reported distances "
+                     "exact f32, widened to f64",
             "data": "synthetic (SURVEY.md 8d recipe: 8-d latent manifold in 128-d, float32), generated per shard",
             "config": {"workload": res["workload"] + ("" if world == 1 and args.workload == "euclid" else
                                                       " -- NOT the --gpus 1 default workload (configs[1] strings, which does not shard): the "

@@ -25,6 +25,16 @@ timeout 600 python tools/serial_ranks.py --n 1000000 --worlds 1,2,4,8 --out $O/s
 timeout 900 python tools/serial_ranks.py --n 8000000 --worlds 1,2,4,8 --out $O/serial_ranks_c5.json > $O/serial_ranks_c5.log 2>&1
 python tools/scaling_model.py $O/serial_ranks_c3.json > $O/scaling_model_c3.json; python tools/scaling_model.py $O/serial_ranks_c5.json > $O/scaling_model_c5.json
 python tools/scaling_model.py $O/serial_ranks_c5.json --md > $O/scaling_model_c5.md; python tools/scaling_model.py $O/serial_ranks_c3.json --md > $O/scaling_model_c3.md
+# round 6: instruction counts per wave and 32-column slab of the tile kernels (two-stage default, round 5's for comparison)
+( bash tools/r6_pmc.sh refresh/pmc_tile_h h; bash tools/r6_pmc.sh refresh/pmc_tile_bf4 bf4 ) > $O/pmc_tile.log 2>&1
+python - "$O" <<'PY'
+import json, sys, os
+o = sys.argv[1]; out = {}
+for k in ("h", "bf4"):
+    p = os.path.join(o, "pmc_tile_" + k, "pmc.json")
+    if os.path.exists(p): out["ANNCHOR_ST_KERNEL=" + k] = json.load(open(p))
+json.dump(out, open(os.path.join(o, "pmc_tile_kernels.json"), "w"), indent=1)
+PY
 # rows of more than 128 dimensions (k-blocked kernel)
 for d in 256 768; do timeout 300 python tools/dim_probe.py 1000000 $d 2>/dev/null | tail -1 > $O/dim_probe_$d.json; done
 find $O -name "*kernel_stats.csv" | head; find $O -name "*counter_collection.csv" -size +30M -delete
