@@ -67,7 +67,6 @@ __device__ __forceinline__ long long sth_now()
 template <int KS> struct KnnSharedH {
     float ring[3 * STH_COLS * 64];   // FIRST (LDS-DMA destinations below 64 KB): three slots of 64 columns x 128 fp16.  Between runs: the
                                      // selection's sort buffers and histogram
-    float norms[3 * STH_COLS];       // the columns' squared norms (scaled, centred), one LDS-DMA request per slab
     float list_d[ST_T][KS + 1];      // exact d^2 (original units), ascending by (d^2, column)
     int32_t list_c[ST_T][KS + 1];
     float thr[ST_T];                 // the row's K-th exact d^2 (-1: padding row, never a candidate)
@@ -96,7 +95,7 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     using SelBuf = SelBufH;
     Sh &sh = *reinterpret_cast<Sh *>(smemh);
     constexpr int DIM = 128, G = DIM / 16, NI = 4, OPS = NI + 1;
-    static_assert(sizeof(sh.ring) + sizeof(sh.norms) <= 65536, "LDS-DMA destinations must stay below 64 KB");
+    static_assert(sizeof(sh.ring) <= 65536, "LDS-DMA destinations must stay below 64 KB");
     static_assert(sizeof(SelBuf) == 12288 && sizeof(sh.ring) >= 12288 + 16384, "selection buffers + histogram alias the ring");
     static_assert(KS == 16, "a row's list lives in one 16-lane DPP row");
     const int lane = threadIdx.x & 63;
@@ -138,7 +137,9 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         rr_c = acc2 + __shfl_xor(acc2, 32);
     }
     auto hb_of = [&](float thr_orig, float rr_s) -> float {
-        return thr_orig < 0.f ? INFINITY : (thr_orig < INFINITY ? 0.5f * ((1.f - STH_BETA) * rr_s - thr_orig * sc2) - STH_SLACK : -INFINITY);
+        // (a row whose list is not full yet takes everything: -3e38, not -inf -- the accumulators start from column term - row term, and
+        // a padding column's term is -inf)
+        return thr_orig < 0.f ? INFINITY : (thr_orig < INFINITY ? 0.5f * ((1.f - STH_BETA) * rr_s - thr_orig * sc2) - STH_SLACK : -3.0e38f);
     };
     if (threadIdx.x < ST_T) {
         // the lists as the warm-up left them (k_st_knnbf's epilogue: exact d^2, original units)
@@ -210,31 +211,39 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     for (int i = 0; i < NI; ++i) {
         const int u = (rg * NI + i) * 64 + lane;
         const int c = u >> 4, x = u & 15;
-        loff[i] = (uint32_t)(c * (DIM * 4) + ((x ^ (c & 15)) << 4));   // (the hi half of column c starts its 512-byte row of the split copy)
+        // (the hi half of column c starts its 512-byte row of the split copy; piece i is requested with the instruction offset 1024 i,
+        // which moves its LDS destination AND its source: taken off here -- c >= 4 i, so the difference stays >= 0)
+        loff[i] = (uint32_t)(c * (DIM * 4) + ((x ^ (c & 15)) << 4)) - 1024u * i;
     }
+    const uint32_t coloff = (uint32_t)col * 4;   // (the norms' loads: an offset register nothing ever overwrites, see issue)
     const char *xb = reinterpret_cast<const char *>(a.Xb);
-    const uint32_t norm_addr = lds0 + (uint32_t)((const unsigned char *)&sh.norms[0] - smemh);
     auto scalar_ptr = [](const void *ptr) -> const char * {
         const uint64_t v = (uint64_t)(uintptr_t)ptr;
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
         return reinterpret_cast<const char *>((uintptr_t)(((uint64_t)hi << 32) | lo));
     };
-    int seq = 0;   // sequence number of the slab being streamed (uniform, monotonic over the kernel): ring slot seq % 3
-    auto issue = [&](int Jv, int slab, int sq) __attribute__((always_inline)) {
+    int slot_cur = 0;   // ring slot of the slab being streamed (uniform): 0, 1, 2, 0 ..; the slab after the next goes to the slot before it
+    // the columns' squared norms (scaled, centred) come as plain loads with the slab's requests: (nl0, nl1) the newest request's,
+    // (nn0, nn1) the next slab's, moved there after the wait that covers them (lane: columns col and 32 + col)
+    float nn0 = 0.f, nn1 = 0.f, nl0 = 0.f, nl1 = 0.f;
+    auto issue = [&](int Jv, int slab, int slotv, float &d0, float &d1) __attribute__((always_inline)) {
         const int J = __builtin_amdgcn_readfirstlane(Jv);
-        const int slot = __builtin_amdgcn_readfirstlane(sq % 3);
+        const int slot = __builtin_amdgcn_readfirstlane(slotv);
         const char *src = scalar_ptr(xb + ((size_t)J * ST_T + slab * STH_COLS) * (DIM * 4));
         const uint32_t dst = lds0 + (uint32_t)(slot * (STH_COLS * 256) + rg * NI * 1024);
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(loff[0]), "v"(loff[1]), "v"(loff[2]), "v"(loff[3]), "s"(src), "s"(dst) : "memory", "scc");
+        // What a wave does AFTER these requests must not depend on the memory pipeline having taken them: a profile of the first form
+        // showed ~900 cycles per slab between the last request and the barrier -- m0 rewritten between the four LDS-DMA instructions
+        // and restored after them (each write waits until the instruction before it has been dispatched), and the two norm loads'
+        // address registers, temporaries the next vector instructions overwrote (a write-after-read wait on a load still queued
+        // behind the four DMA instructions).  Now: the norm loads first, from a scalar base + the lane's constant offset register;
+        // m0 written ONCE (nothing else in the kernel uses it: not restored), the four destinations by the instruction offset.
         const char *nsrc = scalar_ptr(a.rsb + (size_t)J * ST_T + slab * STH_COLS);
-        const uint32_t noff = (uint32_t)(lane * 4);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(noff), "s"(nsrc), "s"(norm_addr + (uint32_t)(slot * (STH_COLS * 4))) : "memory");
+        asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:128" : "=&v"(d0), "=&v"(d1) : "v"(coloff), "s"(nsrc) : "memory");
+        asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %4\n\t"
+                     "global_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %2, %4 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %3, %4 offset:3072"
+                     : : "v"(loff[0]), "v"(loff[1]), "v"(loff[2]), "v"(loff[3]), "s"(src), "s"(dst) : "memory");   // (m0: no other user in this kernel -- checked in the ISA)
     };
 
     // ---------------------------------------------------------------- stage 2: exact evaluation + insertion
@@ -358,10 +367,11 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     };
 
     // ---------------------------------------------------------------- stage 1: one slab
-    // 16 MFMAs of this wave's 32 rows against the 64 columns in ring slot `slot` into (c0, c1); the test of the slab before
-    // (accumulators p0, p1, first column pc0) in their shadow: two rows' masks per MFMA, a mask that is not empty is queued
+    // 16 MFMAs of this wave's 32 rows against the 64 columns in ring slot `slot` into (c0, c1), which start from (column term - row
+    // term); the test of the slab before (accumulators p0, p1, first column pc0) in their shadow: the running maximum of each
+    // lane's 32 accumulators (v_max3), one compare against zero at the end; the survivors of a slab that has any are queued
     auto stream = [&](int slot, f32x16 &c0, f32x16 &c1, const f32x16 &p0, const f32x16 &p1, bool pend) __attribute__((always_inline)) {
-        const float rj0 = sh.norms[slot * STH_COLS + col], rj1 = sh.norms[slot * STH_COLS + 32 + col];
+        const float rj0 = nn0, rj1 = nn1;
         if (__builtin_expect(hq_stale, 0)) {   // (uniform) the thresholds of the lane's 16 rows: read again after an insertion of this wave
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -379,11 +389,9 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
 #pragma unroll
         for (int g = 0; g < G; ++g) b1[g] = base1[(2 * g) ^ gsw];
         const float n0 = -0.5f * (1.f - STH_BETA) * rj0, n1 = -0.5f * (1.f - STH_BETA) * rj1;
+        float mx0 = 0.f, mx1 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) c0[r] = n0;
-        // (a branch on a vector compare's mask waits out the vector pipe and holds the next MFMA back: ~30 cycles each, 32 of them
-        // doubled the stream.  Four rows' masks are taken together -- four compares back to back, ONE branch on their OR; the rare
-        // group with a survivor then looks at its four masks, which sit in scalar registers by then)
+        for (int r = 0; r < 16; ++r) c0[r] = n0 - hqr[r];   // column term - row term: the test of this slab is "any accumulator > 0"
 #pragma unroll
         for (int m = 0; m < 2 * G; m += 2) {
 #pragma unroll
@@ -393,29 +401,29 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
                 else c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mm - G], __builtin_bit_cast(f16x8h, b1[mm - G]), c1, 0, 0, 0);
                 if (mm == 0) {   // the second group's accumulators start in the first MFMAs' shadow
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) c1[r] = n1;
+                    for (int r = 0; r < 16; ++r) c1[r] = n1 - hqr[r];
                 }
             }
-            if (pend) {   // (uniform)
-                unsigned long long mk[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ti = 2 * m + u, g2 = ti >> 4, r = ti & 15;
-                    mk[u] = __ballot((g2 ? p1[r] : p0[r]) > hqr[r]);
-                }
-                // (86 % of the slabs have no survivor at all once the lists are warm -- 0.43 per wave and slab at C3 --: everything
-                // behind these branches is cold code, and is told so: the kernel is larger than the instruction cache two CUs
-                // share, what the hot loop does not run must not sit between what it does)
-                if (__builtin_expect((mk[0] | mk[1] | mk[2] | mk[3]) != 0, 0)) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int ti = 2 * m + u, g2 = ti >> 4, r = ti & 15;
-                        if (mk[u]) push(mk[u], g2, r);
-                    }
-                }
+            {   // two steps of each group's running maximum behind this pair of MFMAs (a run's first slab: zeros)
+                const int k = m >> 1;   // 0 .. 7
+                if (k == 0) { mx0 = __builtin_fmaxf(__builtin_fmaxf(p0[0], p0[1]), p0[2]); mx1 = __builtin_fmaxf(__builtin_fmaxf(p1[0], p1[1]), p1[2]); }
+                else if (k < 7) { mx0 = __builtin_fmaxf(__builtin_fmaxf(mx0, p0[2 * k + 1]), p0[2 * k + 2]); mx1 = __builtin_fmaxf(__builtin_fmaxf(mx1, p1[2 * k + 1]), p1[2 * k + 2]); }
+                else mx0 = __builtin_fmaxf(__builtin_fmaxf(mx0, p0[15]), __builtin_fmaxf(mx1, p1[15]));
             }
             if (m < G) asm volatile("" : "+v"(c0));
             else asm volatile("" : "+v"(c1));
+        }
+        // (86 % of the slabs have no survivor at all once the lists are warm -- 0.43 per wave and slab at C3 --: ONE compare and one
+        // branch per slab; the rows' masks are taken behind it.  First form: a v_cmp per row into a scalar pair, four masks ORed per
+        // branch -- 32 compares, 24 s_or, 8 branches per slab, and the masks kept alive for the cold blocks spilled scalar registers
+        // into vector lanes in the hot loop.)
+        if (pend && __builtin_expect(__ballot(mx0 > 0.f) != 0, 0)) {
+#pragma unroll
+            for (int ti = 0; ti < 32; ++ti) {
+                const int g2 = ti >> 4, r = ti & 15;
+                const unsigned long long mk = __ballot((g2 ? p1[r] : p0[r]) > 0.f);
+                if (mk) push(mk, g2, r);
+            }
         }
     };
     // after a slab's stream: the survivor loads of one slab ago (and this wave's pieces of the next slab) have landed; evaluate
@@ -423,12 +431,13 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     // many -> all of them now; more than the queue holds -> the slab is gone through again from the accumulators
     auto post = [&](int dJ, int dslab, const f32x16 &p0, const f32x16 &p1, bool pend) __attribute__((always_inline)) {
         PH(1)
-        vm_wait_all();   // this wave's pieces of slab seq + 1 (requested a slab ago) and the survivors' rows (likewise)
+        vm_wait_all();   // this wave's pieces of the next slab (requested a slab ago), its norms and the survivors' rows (likewise)
         PH(2)
         consume_slots(0, nfl, fpk, fbase);
         nfl = 0;
         PH(3)
-        if (dJ >= 0) issue(dJ, dslab, seq + 2);   // (its slot held slab seq - 1: every wave has passed this slab's barrier)
+        nn0 = nl0; nn1 = nl1;   // (landed: the next slab's norms)
+        if (dJ >= 0) issue(dJ, dslab, slot_cur == 0 ? 2 : slot_cur - 1, nl0, nl1);   // (that slot held the slab before this one: every wave has passed this slab's barrier)
         if (!pend) { nq = 0; return; }
         if (__builtin_expect(nq > STH_QCAP, 0)) {
             // (the first tiles after a cold start, ill-conditioned data) per-lane row masks from the accumulators, queue by queue
@@ -437,7 +446,7 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
             for (int g2 = 0; g2 < 2; ++g2) {
                 uint32_t lp = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) lp |= ((g2 ? p1[r] : p0[r]) > hqr[r] ? 1u : 0u) << r;
+                for (int r = 0; r < 16; ++r) lp |= ((g2 ? p1[r] : p0[r]) > 0.f ? 1u : 0u) << r;
                 unsigned long long lanes = __ballot(lp != 0);
                 while (lanes) {   // (uniform)
                     const int l = (int)__builtin_ctzll(lanes);
@@ -522,10 +531,13 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
                 const int J = cj;
                 const float lb = cvb;
                 ++q;
-                if (q < ns) { cj = jl(q); cvb = vb(q); }
+                {   // (read whether or not there is a next entry: a conditional read is waited for where it is made)
+                    const int qn = min(q, ns - 1);
+                    cj = jl(qn); cvb = vb(qn);
+                }
                 if (lb * lb < tm) {
                     ++processed;
-                    if (ebits && threadIdx.x == 0) sh.run_ev[(q - 1) >> 5] |= 1u << ((q - 1) & 31);   // (flushed at the end of the run)
+                    if (ebits && threadIdx.x == 0) atomicOr(&sh.run_ev[(q - 1) >> 5], 1u << ((q - 1) & 31));   // (flushed at the end of the run; no value comes back: nothing to wait for)
                     return __builtin_amdgcn_readfirstlane(J);
                 }
             }
@@ -535,30 +547,35 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         int J = next_tile(0);
         if (J < 0) return;
         // fill: both slabs of the first tile (the ring is idle: a workgroup barrier precedes every run)
-        issue(J, 0, seq);
-        issue(J, 1, seq + 1);
+        issue(J, 0, slot_cur, nn0, nn1);
+        issue(J, 1, slot_cur == 2 ? 0 : slot_cur + 1, nl0, nl1);
         vm_wait_all();
         bool pend = false;
         nq = 0; nfl = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { b0a[r] = 0.f; b1a[r] = 0.f; }   // (the first slab's "slab before": nothing passes)
         for (;;) {
             // ---- slab 0: the tile after J is chosen (thresholds / insertion counts as published at the end of the tile before J)
             // and its first slab requested
             PH(5)
             slab_barrier();
             PH(0)
+            // (the choice of the next tile: after the stream -- its LDS round trips then find the LDS quiet -- not in front of it;
+            // tried between the stream's operand reads and its MFMAs: 49.0 ms against 47.8)
+            stream(slot_cur, a0, a1, b0a, b1a, pend);
+            PH(1)
             const int Jn = next_tile(1);
             PH(5)
-            stream(seq % 3, a0, a1, b0a, b1a, pend);
             post(Jn, 0, b0a, b1a, pend);
             pend = true; pc0 = J * ST_T;
-            ++seq;
+            slot_cur = slot_cur == 2 ? 0 : slot_cur + 1;
             // ---- slab 1
             slab_barrier();
             PH(0)
-            stream(seq % 3, b0a, b1a, a0, a1, true);
+            stream(slot_cur, b0a, b1a, a0, a1, true);
             post(Jn, 1, a0, a1, true);
             pc0 = J * ST_T + STH_COLS;
-            ++seq;
+            slot_cur = slot_cur == 2 ? 0 : slot_cur + 1;
             publish();
             ++tdone;
             if (Jn < 0) break;
@@ -569,14 +586,6 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         consume_slots(0, nfl, fpk, fbase);
         nfl = 0;
         nq = STH_QCAP + 1;   // (the slab is gone through from its accumulators)
-        if (hq_stale) {
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const float4 h4 = *reinterpret_cast<const float4 *>(&sh.hb[rowq + 8 * q4]);
-                hqr[4 * q4] = h4.x; hqr[4 * q4 + 1] = h4.y; hqr[4 * q4 + 2] = h4.z; hqr[4 * q4 + 3] = h4.w;
-            }
-            hq_stale = false;
-        }
         post(-1, 0, b0a, b1a, true);
         publish();
         ++tdone;
@@ -806,8 +815,9 @@ int ann_stream_launch_knnh(annchor_ctx *c, const KnnArgs &a0, int dim_padded, bo
     if (!ok) return ANNCHOR_OK;
     *handled = true;
     if (a0.max_tiles <= warm_tiles + 1) return ANNCHOR_OK;   // the warm-up was the whole budget
-    const size_t lds = sizeof(KnnSharedH<16>);
-    ANN_REQUIRE(c, lds <= 80 * 1024, ANNCHOR_ELIMIT, "streamed k-NN (two-stage form) needs %zu B of LDS", lds);
+    static const size_t lds_pad = getenv("ANNCHOR_STH_LDS_PAD") ? (size_t)atoi(getenv("ANNCHOR_STH_LDS_PAD")) : 0;   // (experiments: > 80 KB in all = one workgroup per CU)
+    const size_t lds = sizeof(KnnSharedH<16>) + lds_pad;
+    ANN_REQUIRE(c, lds <= 160 * 1024, ANNCHOR_ELIMIT, "streamed k-NN (two-stage form) needs %zu B of LDS", lds);
     ANN_CHECK_HIP(c, hipFuncSetAttribute((const void *)k_st_knnh<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(c, "stream_tile_two_stage_kernel", 0.0);   // (inside stream_tile_gemm_topk: k_st_knnh alone, without the warm-up)
     k_st_knnh<16><<<a0.tile_count, STH_THREADS, lds, c->stream>>>(a0);
