@@ -43,6 +43,7 @@
 #define STH_SLACK 0.125f      // absolute slack of the test in scaled units (subnormal fp16 halves: <= 2^-25 per coordinate)
 
 typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
+typedef float f32x4h __attribute__((ext_vector_type(4)));
 
 // ST_PROFILE builds: per-wave cycle sums by segment (a.prof[0..7], printed by knn_tile_phase):
 //   0 slab barrier   1 stream (operand reads, MFMAs, tests, queueing)   2 wait for the outstanding loads   3 exact evaluations + insertions
@@ -222,6 +223,11 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
         return reinterpret_cast<const char *>((uintptr_t)(((uint64_t)hi << 32) | lo));
     };
+    auto scalar_ptrf = [](const float *ptr) -> const float * {
+        const uint64_t v = (uint64_t)(uintptr_t)ptr;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<const float *>((uintptr_t)(((uint64_t)hi << 32) | lo));
+    };
     int slot_cur = 0;   // ring slot of the slab being streamed (uniform): 0, 1, 2, 0 ..; the slab after the next goes to the slot before it
     // the columns' squared norms (scaled, centred) come as plain loads with the slab's requests: (nl0, nl1) the newest request's,
     // (nn0, nn1) the next slab's, moved there after the wait that covers them (lane: columns col and 32 + col)
@@ -254,9 +260,9 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     // vector instructions per survivor; the wave's vector instructions, not the matrix pipe, were what a slab cost.)  STH_Q / 4
     // such batches are in flight.
     constexpr int NB = STH_Q / 4;
-    float4 xa[NB], xc[NB], ya[NB], yc[NB];
+    f32x4h xa[NB], xc[NB], ya[NB], yc[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) { xa[b] = float4{0.f, 0.f, 0.f, 0.f}; xc[b] = xa[b]; ya[b] = xa[b]; yc[b] = xa[b]; }
+    for (int b = 0; b < NB; ++b) { xa[b] = f32x4h{0.f, 0.f, 0.f, 0.f}; xc[b] = xa[b]; ya[b] = xa[b]; yc[b] = xa[b]; }
     int qpk = 0;                   // the stream's queue: lane n = survivor n of the slab under test, row in the tile | column in the slab << 8
     int nq = 0;                    // (uniform)
     int fpk = 0, fbase = 0, nfl = 0;   // the evaluations in flight (their slab's first global column)
@@ -275,16 +281,31 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         return valid;
     };
     // loads of survivors b .. b + n - 1 of the queue (QP: packed entries, QB: their slab's first column), n <= STH_Q
+    // These loads are executed whether or not there is a survivor, as BUFFER loads: a lane without one asks for an offset beyond
+    // its descriptor's range and gets zeros without a memory access.  As plain loads behind `if (n > 0)` they made the compiler
+    // copy the four registers where the branches meet and put `s_waitcnt vmcnt(0)` in front of the copies -- on EVERY path, right
+    // behind the slab's LDS-DMA requests: each wave waited out the memory latency of the slab it had just requested, every slab
+    // (the profile's "requests" segment: ~900 of a slab's ~4700 ticks, and the waves it kept from the barrier).  No branch around a
+    // load, no meeting point: the compiler waits for them where they are read, after vm_wait_all.
+    // (rows: the row tile's 64 KB of a.Rs; columns: the survivors' slab, 64 columns of a.Xs from QB on)
+    const __amdgpu_buffer_rsrc_t srd_rows = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(scalar_ptrf(a.Rs + (size_t)grow0 * DIM)), 0, ST_T * DIM * 4, 0x00020000);
     auto issue_slots = [&](int b, int n, int QP, int QB) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t srd_cols = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(scalar_ptrf(a.Xs + (size_t)__builtin_amdgcn_readfirstlane(QB) * DIM)), 0, STH_COLS * DIM * 4, 0x00020000);
 #pragma unroll
-        for (int bi = 0; bi < NB; ++bi)
+        for (int bi = 0; bi < NB; ++bi) {
+            uint32_t vx = 0xFFFFFF00u, vy = 0xFFFFFF00u;   // (out of range: zeros, no access)
             if (__builtin_expect(4 * bi < n, 0)) {   // (uniform)
-                int row; int32_t cc;
-                (void)my_survivor(b, n, bi, QP, QB, row, cc);
-                const float4 *px = reinterpret_cast<const float4 *>(a.Rs + (size_t)(grow0 + row) * DIM + 8 * e16);
-                const float4 *py = reinterpret_cast<const float4 *>(a.Xs + (size_t)cc * DIM + 8 * e16);
-                xa[bi] = px[0]; xc[bi] = px[1]; ya[bi] = py[0]; yc[bi] = py[1];
+                const int idx = b + 4 * bi + g16;
+                const int pk = __builtin_amdgcn_ds_bpermute(idx << 2, QP);
+                const bool valid = 4 * bi + g16 < n;
+                vx = valid ? (uint32_t)((pk & 0xff) * (DIM * 4) + 32 * e16) : vx;
+                vy = valid ? (uint32_t)((pk >> 8) * (DIM * 4) + 32 * e16) : vy;
             }
+            xa[bi] = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(srd_rows, vx, 0, 0));
+            xc[bi] = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(srd_rows, vx + 16, 0, 0));
+            ya[bi] = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(srd_cols, vy, 0, 0));
+            yc[bi] = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(srd_cols, vy + 16, 0, 0));
+        }
     };
     // one round of insertions: row `row`, exact d^2 `d2` (+inf: nothing), column cc -- per 16-lane row, all four rows at once
     auto insert_round = [&](int row, float d2, int32_t cc) __attribute__((always_inline)) {
@@ -438,7 +459,8 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         PH(3)
         nn0 = nl0; nn1 = nl1;   // (landed: the next slab's norms)
         if (dJ >= 0) issue(dJ, dslab, slot_cur == 0 ? 2 : slot_cur - 1, nl0, nl1);   // (that slot held the slab before this one: every wave has passed this slab's barrier)
-        if (!pend) { nq = 0; return; }
+        if (!pend) nq = 0;   // (a run's first slab: nothing was under test)
+        int n_async = 0;     // survivors whose rows are requested now and evaluated after the next slab
         if (__builtin_expect(nq > STH_QCAP, 0)) {
             // (the first tiles after a cold start, ill-conditioned data) per-lane row masks from the accumulators, queue by queue
             nq = 0;
@@ -469,10 +491,12 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
             PH(4)
             drain_sync(nq, qpk, pc0);
             PH(6)
-        } else if (__builtin_expect(nq > 0, 0)) {
-            issue_slots(0, nq, qpk, pc0);
-            fpk = qpk; fbase = pc0; nfl = nq;
+        } else {
+            n_async = nq;
         }
+        // (ONE place, behind the branches: the four registers are defined here on every path -- nothing to merge, nothing to copy)
+        issue_slots(0, n_async, qpk, pc0);
+        fpk = qpk; fbase = pc0; nfl = n_async;
         nq = 0;
         PH(4)
     };
