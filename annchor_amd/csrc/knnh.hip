@@ -200,7 +200,7 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long pf_t = sth_now();
 #endif
-    int ins = 0;         // list insertions, counted by the first lane of each 16-lane row
+    int ins = 0;         // list insertions of this wave (uniform)
     int tdone = 0;       // column tiles completed and published by this kernel (uniform); tile n publishes into slot (n + 1) & 1
     int win_start = processed, win_ins = 0;
     bool dried = false;
@@ -267,6 +267,8 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     int nq = 0;                    // (uniform)
     int fpk = 0, fbase = 0, nfl = 0;   // the evaluations in flight (their slab's first global column)
     bool hq_stale = true;
+    bool tm_stale = true;   // (uniform) an insertion since the wave's worst K-th distance was last taken
+    float wave_tm = 0.f;    // (uniform) that distance
     float hqr[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) hqr[r] = 0.f;
@@ -321,8 +323,11 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         const int32_t nc = e16 > pos ? pc : (e16 == pos ? cc : lc);
         if (ok && e16 >= pos && e16 < K) { sh.list_d[row][e16] = nd; sh.list_c[row][e16] = nc; }
         if (ok && e16 == K - 1) { sh.thr[row] = nd; sh.hb[row] = hb_of(nd, sh.rrow[row]); }
-        ins += (ok && e16 == 0) ? 1 : 0;
-        if (__ballot(ok)) hq_stale = true;
+        {   // (uniform: the wave's insertion count and "its rows' thresholds have changed" -- nothing to gather at the end of a tile)
+            const unsigned long long okm = __ballot(ok && e16 == 0);
+            ins += __popcll(okm);
+            if (okm) { hq_stale = true; tm_stale = true; }
+        }
     };
     // slots of n survivors (b .. of the queue): exact d^2, sorted insertion
     auto consume_slots = [&](int b, int n, int QP, int QB) __attribute__((always_inline)) {
@@ -500,19 +505,21 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         nq = 0;
         PH(4)
     };
-    // the wave's insertion count and its rows' worst K-th distance, at the end of a tile
-    // (`ins` is counted by the first lane of each 16-lane row; the maximum by DPP steps and two v_readlane -- a __shfl_xor is an LDS round trip, eleven of
-    // them in a chain were 15 % of the kernel)
+    // the wave's insertion count and its rows' worst K-th distance, at the end of a tile: both uniform, the distance taken again only
+    // after an insertion (one tile in five once the lists are warm).  (First form: every tile an LDS read of the 32 thresholds, eight DPP
+    // steps, six v_readlane -- with next_tile's own round trips a fifth of a slab's time.)
     auto publish = [&]() __attribute__((always_inline)) {
-        float t = lane < 32 ? sh.thr[rowbase + lane] : -1.f;
-        t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, false)));
-        t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x4E, 0xf, 0xf, false)));
-        t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x141, 0xf, 0xf, false)));
-        t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x140, 0xf, 0xf, false)));
-        const float tm = fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 0)),
-                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 16)));
-        const int wins = __builtin_amdgcn_readlane(ins, 0) + __builtin_amdgcn_readlane(ins, 16) + __builtin_amdgcn_readlane(ins, 32) + __builtin_amdgcn_readlane(ins, 48);
-        if (lane == 0) { sh.wave_ins[(tdone + 1) & 1][wave] = wins; sh.wave_thr[(tdone + 1) & 1][rg] = tm; }
+        if (__builtin_expect(tm_stale, 0)) {   // (uniform)
+            float t = lane < 32 ? sh.thr[rowbase + lane] : -1.f;
+            t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, false)));
+            t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x4E, 0xf, 0xf, false)));
+            t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x141, 0xf, 0xf, false)));
+            t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x140, 0xf, 0xf, false)));
+            wave_tm = fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 0)),
+                            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 16)));
+            tm_stale = false;
+        }
+        if (lane == 0) { sh.wave_ins[(tdone + 1) & 1][wave] = ins; sh.wave_thr[(tdone + 1) & 1][rg] = wave_tm; }
     };
     auto thrmax_now = [&]() {
         const float *w = sh.wave_thr[tdone & 1];
