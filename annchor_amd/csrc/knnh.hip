@@ -662,10 +662,30 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     bool cl_valid = false, cl_complete = false;
     // entries (key bits, valid bound, tile) of the short list or of the whole scratch row, thread-strided
     auto sweep = [&](bool from_list, auto f) {
+        // (eight entries' loads in flight per thread: one entry at a time, a sweep of the 62 500 tiles of N = 8 x 10^6 was 244 dependent
+        // global round trips per thread -- the selection rounds were 15 % of the two-stage kernel there, 7 % at N = 10^6)
+        constexpr int SW = 8;
         if (from_list) {
-            for (int q = threadIdx.x; q < cl_n; q += STH_THREADS) f(clk[q], __uint_as_float(clk[ST_CL_CAP + q]), (int)clk[2 * ST_CL_CAP + q]);
+            int q = threadIdx.x;
+            for (; q + (SW - 1) * STH_THREADS < cl_n; q += SW * STH_THREADS) {
+                uint32_t kb[SW], lbb[SW], jj[SW];
+#pragma unroll
+                for (int u = 0; u < SW; ++u) { kb[u] = clk[q + u * STH_THREADS]; lbb[u] = clk[ST_CL_CAP + q + u * STH_THREADS]; jj[u] = clk[2 * ST_CL_CAP + q + u * STH_THREADS]; }
+#pragma unroll
+                for (int u = 0; u < SW; ++u) f(kb[u], __uint_as_float(lbb[u]), (int)jj[u]);
+            }
+            for (; q < cl_n; q += STH_THREADS) f(clk[q], __uint_as_float(clk[ST_CL_CAP + q]), (int)clk[2 * ST_CL_CAP + q]);
         } else {
-            for (int J = threadIdx.x; J < a.nt_all; J += STH_THREADS) f(__float_as_uint(skey[J]), slb[J], J);
+            int J = threadIdx.x;
+            for (; J + (SW - 1) * STH_THREADS < a.nt_all; J += SW * STH_THREADS) {
+                uint32_t kb[SW];
+                float lbv[SW];
+#pragma unroll
+                for (int u = 0; u < SW; ++u) { kb[u] = __float_as_uint(skey[J + u * STH_THREADS]); lbv[u] = slb[J + u * STH_THREADS]; }
+#pragma unroll
+                for (int u = 0; u < SW; ++u) f(kb[u], lbv[u], J + u * STH_THREADS);
+            }
+            for (; J < a.nt_all; J += STH_THREADS) f(__float_as_uint(skey[J]), slb[J], J);
         }
     };
     // first bin whose cumulative count reaches `want` among nbins bins of `hist`: thread t owns bins [per t, per (t+1)); the
