@@ -194,12 +194,21 @@ template <int DIM, int KMAX, bool JOIN = false, bool R3 = false> __global__ __la
         if constexpr (JOIN) {
             // the lists as the previous phase left them (exact d^2, original units -> scaled); the KL - K spare entries start
             // as copies of the K-th value without a column, so that the row's threshold is its current K-th distance
+            // (all of a row's entries requested before the first is looked at: one at a time, 2 x K dependent global round trips opened
+            // every workgroup of a pass)
+            float dv[KMAX];
+            int32_t cv[KMAX];
+            const float *pd = a.out_d2 + ((size_t)bt * ST_T + row) * K;
+            const int32_t *pc = a.lists_all + ((size_t)grow0 + row) * K;
+#pragma unroll
+            for (int q = 0; q < KMAX; ++q) { dv[q] = pd[min(q, K - 1)]; cv[q] = pc[min(q, K - 1)]; }
             float last = INFINITY;
+#pragma unroll
             for (int q = 0; q < KMAX; ++q) {
                 const bool have = q < K;
-                const float d = have ? a.out_d2[((size_t)bt * ST_T + row) * K + q] * (scale * scale) : last;
+                const float d = have ? dv[q] * (scale * scale) : last;
                 sh.list_d[row][q] = q < KL ? d : INFINITY;
-                sh.list_c[row][q] = have ? a.lists_all[((size_t)grow0 + row) * K + q] : 0x7fffffff;
+                sh.list_c[row][q] = have ? cv[q] : 0x7fffffff;
                 if (have) last = d;
             }
             sh.thr[row] = real ? last : -1.f;

@@ -146,13 +146,21 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         // the lists as the warm-up left them (k_st_knnbf's epilogue: exact d^2, original units)
         const int row = threadIdx.x;
         const bool real = a.rr[grow0 + row] < INFINITY;
+        // (all of a row's entries requested before the first is looked at: one entry at a time, 2 x 16 dependent global round trips
+        // opened every workgroup)
+        float dv[KS];
+        int32_t cv[KS];
+        const float *pd = a.out_d2 + ((size_t)bt * ST_T + row) * K;
+        const int32_t *pc = a.out_col + ((size_t)bt * ST_T + row) * K;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) { dv[q] = pd[min(q, K - 1)]; cv[q] = pc[min(q, K - 1)]; }
         float last = INFINITY;
+#pragma unroll
         for (int q = 0; q < KS; ++q) {
             const bool have = q < K;
-            const float d = have ? a.out_d2[((size_t)bt * ST_T + row) * K + q] : INFINITY;
-            sh.list_d[row][q] = d;
-            sh.list_c[row][q] = have ? a.out_col[((size_t)bt * ST_T + row) * K + q] : 0x7fffffff;
-            if (have) last = d;
+            sh.list_d[row][q] = have ? dv[q] : INFINITY;
+            sh.list_c[row][q] = have ? cv[q] : 0x7fffffff;
+            if (have) last = dv[q];
         }
         sh.thr[row] = real ? last : -1.f;
     }
