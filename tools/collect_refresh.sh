@@ -11,6 +11,6 @@ done
 cp $O/pmc_traffic_scale.json $D/${P}_scale_pmc_traffic.json
 cp $O/scaling_model_c3.md $D/${P}_scaling_model_c3.md; cp $O/scaling_model_c5.md $D/${P}_scaling_model_c5.md
 cp $O/pairlist_scale.log $D/${P}_pairlist_scale.log
-tail -3 $O/pytest_gpu.log | head -1 > $D/${P}_pytest_gpu.txt
+grep -E "passed|failed" $O/pytest_gpu.log > $D/${P}_pytest_gpu.txt
 git rev-parse HEAD >> $D/${P}_pytest_gpu.txt
 ls -la $D/${P}_*
