@@ -1899,26 +1899,39 @@ void ann_stream_free_run(StreamState *s)
 // (the keys and bounds, hence the selection rounds and the graph, are bit for bit what the in-kernel ranking produced).
 #define RK_I 32
 #define RK_J 256
+// (round 6) Branch-free and two anchors per instruction: anchors beyond a.na are zeros on both sides (a zero interval against a zero
+// interval: gap 0, slack 0, difference of the means 0 -- lb = max(lb, 0) and lbc + 0 change nothing), so the anchor loop has no
+// `an < na` test (it was a scalar compare + branch per anchor and pair); the subtractions, the slack and the squares are packed
+// float32 operations (v_pk_add_f32 / v_pk_mul_f32: the same IEEE results lane by lane), the running maximum and the running sum
+// stay scalar in the original order -- keys and bounds bit for bit as before.  N = 8 x 10^6 (3.9 x 10^9 pairs x 32 anchors): see
+// NOTEBOOK.md, round 6.
+typedef float rk_f2 __attribute__((ext_vector_type(2)));
 template <int NA> __global__ __launch_bounds__(RK_J) void k_st_rank_pairs(KnnArgs a)
 {
-    __shared__ float rowt[RK_I][NA][3];   // [row tile][anchor]{lo, hi, mid} of the block's row tiles
+    static_assert(NA % 2 == 0, "anchors in pairs");
+    __shared__ __attribute__((aligned(8))) float rowt[RK_I][4][NA];   // [row tile]{lo, hi, mid, |hi|}[anchor] of the block's row tiles
     const int J = blockIdx.x * RK_J + threadIdx.x;
     const int i0 = blockIdx.y * RK_I, ni = min(RK_I, a.tile_count - i0);
-    for (int t = threadIdx.x; t < ni * a.na; t += RK_J) {
-        const int i = t / a.na, an = t - i * a.na;
+    for (int t = threadIdx.x; t < ni * NA; t += RK_J) {
+        const int i = t / NA, an = t - i * NA;
         const int I = a.tile_begin + i0 + i;
-        rowt[i][an][0] = a.rlo[(size_t)an * a.nt_r + I];
-        rowt[i][an][1] = a.rhi[(size_t)an * a.nt_r + I];
-        rowt[i][an][2] = a.rmid[(size_t)an * a.nt_r + I];
+        const bool ok = an < a.na;
+        const float h = ok ? a.rhi[(size_t)an * a.nt_r + I] : 0.f;
+        rowt[i][0][an] = ok ? a.rlo[(size_t)an * a.nt_r + I] : 0.f;
+        rowt[i][1][an] = h;
+        rowt[i][2][an] = ok ? a.rmid[(size_t)an * a.nt_r + I] : 0.f;
+        rowt[i][3][an] = fabsf(h);
     }
-    float lj[NA], hj[NA], mj[NA];
+    rk_f2 lj[NA / 2], hj[NA / 2], mj[NA / 2], ahj[NA / 2];
     const bool have = J < a.nt_all;
 #pragma unroll
     for (int an = 0; an < NA; ++an) {
         const bool ok = have && an < a.na;
-        lj[an] = ok ? a.lo[(size_t)an * a.nt_all + J] : 0.f;
-        hj[an] = ok ? a.hi[(size_t)an * a.nt_all + J] : 0.f;
-        mj[an] = ok ? a.mid[(size_t)an * a.nt_all + J] : 0.f;
+        const float l = ok ? a.lo[(size_t)an * a.nt_all + J] : 0.f, h = ok ? a.hi[(size_t)an * a.nt_all + J] : 0.f;
+        lj[an >> 1][an & 1] = l;
+        hj[an >> 1][an & 1] = h;
+        mj[an >> 1][an & 1] = ok ? a.mid[(size_t)an * a.nt_all + J] : 0.f;
+        ahj[an >> 1][an & 1] = fabsf(h);
     }
     __syncthreads();
     if (!have) return;
@@ -1926,15 +1939,19 @@ template <int NA> __global__ __launch_bounds__(RK_J) void k_st_rank_pairs(KnnArg
         const int I = a.tile_begin + i0 + i;
         float lb = 0.f, lbc = 0.f;
 #pragma unroll
-        for (int an = 0; an < NA; ++an)
-            if (an < a.na) {
-                const float loI = rowt[i][an][0], hiI = rowt[i][an][1], midI = rowt[i][an][2];
-                const float gap = fmaxf(loI - hj[an], lj[an] - hiI);
-                // slack for the float32 rounding of D (bounds must stay valid lower bounds)
-                lb = fmaxf(lb, gap - 4e-6f * (fabsf(hj[an]) + fabsf(hiI)));
-                const float dm = mj[an] - midI;
-                lbc += dm * dm;   // rank key: squared L2 distance between the tiles' mean anchor vectors
-            }
+        for (int q = 0; q < NA / 2; ++q) {
+            const rk_f2 loI = *reinterpret_cast<const rk_f2 *>(&rowt[i][0][2 * q]), hiI = *reinterpret_cast<const rk_f2 *>(&rowt[i][1][2 * q]);
+            const rk_f2 midI = *reinterpret_cast<const rk_f2 *>(&rowt[i][2][2 * q]), ahiI = *reinterpret_cast<const rk_f2 *>(&rowt[i][3][2 * q]);
+            const rk_f2 g1 = loI - hj[q], g2 = lj[q] - hiI;
+            // slack for the float32 rounding of D (bounds must stay valid lower bounds)
+            const rk_f2 u = 4e-6f * (ahj[q] + ahiI);
+            const rk_f2 v = rk_f2{fmaxf(g1.x, g2.x), fmaxf(g1.y, g2.y)} - u;
+            lb = fmaxf(fmaxf(lb, v.x), v.y);
+            const rk_f2 dm = mj[q] - midI;
+            const rk_f2 d2 = dm * dm;
+            lbc += d2.x;   // rank key: squared L2 distance between the tiles' mean anchor vectors (summed in anchor order)
+            lbc += d2.y;
+        }
         a.scr_key[(size_t)(i0 + i) * a.nt_all + J] = ((J == I && !a.query) || !(lbc < INFINITY)) ? INFINITY : lbc;   // +inf: never a candidate
         a.scr_lb[(size_t)(i0 + i) * a.nt_all + J] = lb;
     }
