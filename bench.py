@@ -372,8 +372,9 @@ def euclid_run(world, rank, local, dist_mod, n_per_rank, steps, warmup, torch, r
                                                  "frac": pairs_h * 128.0 * 128.0 * 2.0 * 128.0 / t_h / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                                                  "note": "issued = algorithmic here: one fp16 MFMA product per coordinate pair (the split-fp16 kernel issued three)"},
                                    "note": "algorithmic bytes = tile pairs of k_st_knnh x 33 280 B (the hi halves of 128 columns + their norms, fetched once each); the "
-                                           "kernel is bound by what its waves ISSUE (a SIMD issues for one of its two waves at a time: 256 matrix-pipe cycles + ~110 vector "
-                                           "and ~70 scalar instructions per 32 columns and wave, DESIGN.md section 7), on neither roof; traffic = the PMC passes' bytes per launch"}
+                                           "kernel is a per-workgroup latency chain (barrier -> 16 MFMAs on 16 LDS operand reads -> choice of the next tile -> requests, per 64 "
+                                           "columns: ~4200 ticks where the matrix pipe needs 830 and HBM 2220 -- tools/microbench/stream_seq.hip, DESIGN.md section 7), on "
+                                           "neither roof; traffic = the PMC passes' bytes per launch"}
             else:
                 name = "k_st_knnbf"
                 out["roofline"] = {"kernel": "stream_tile_gemm_topk (%s: split-fp16 tile GEMMs, 3 x v_mfma_f32_32x32x16_f16 per 16 dimensions)" % name,
