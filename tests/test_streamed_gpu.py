@@ -839,6 +839,45 @@ def test_split_fp16_guard_repairs_flagged_rows_exactly(monkeypatch):
     assert kind == 1 and flagged <= n // 1000, (kind, flagged)
 
 
+@pytest.mark.parametrize("seed", [11, 77])
+def test_two_stage_kernel_random_shapes_are_exact_at_full_budget(monkeypatch, seed):
+    """k_st_knnh's shapes (padded dimension 128, <= 14 neighbours kept) over random N / dimension / k / anchor counts, duplicated rows,
+    data far from the origin, a tight cluster beside a wide cloud, through the one-call entry point and the sharded one: with the full
+    budget (and the sharded path's early stop switched off) the graph is the exact k-NN graph -- float64 brute force on 300 rows, the
+    reference's definition (annchor/distances.py:8-13 on every pair) --, and two builds at a small budget agree bit for bit
+    (tools/stress_knnh.py is the long form: 60 cases)."""
+    from annchor_amd.streamed import StreamedAnnchor
+
+    monkeypatch.setenv("ANNCHOR_ST_EARLY_WINDOW", "0")
+    rng = np.random.default_rng(seed)
+    for case in range(5):
+        n = int(rng.integers(1500, 40000)); dim = int(rng.choice([65, 100, 127, 128])); k = int(rng.integers(2, 16))
+        na = int(rng.integers(2, 40)); lat = int(rng.integers(2, 10))
+        X = (rng.standard_normal((n, lat)) @ rng.standard_normal((lat, dim)) + 0.05 * rng.standard_normal((n, dim))).astype(np.float32)
+        if case % 3 == 0:
+            X[rng.integers(0, n, n // 10)] = X[rng.integers(0, n, n // 10)]
+        if case % 4 == 1:
+            X += (30.0 * rng.standard_normal((1, dim))).astype(np.float32)
+        if case % 5 == 2:
+            X[: n // 2] = (X[: n // 2] * 1e-2 + X[0]).astype(np.float32)
+        sa = StreamedAnnchor(X, n_anchors=na, n_neighbors=k, p_work=1.0, force_exchange=bool(case % 2)).fit()
+        assert sa._engine.stream_last_tile_kernels()[0], "the two-stage kernel did not run"
+        idx, dist = sa.neighbor_graph
+        Xd = X.astype(np.float64)
+        rows = rng.choice(n, 300, replace=False)
+        d2 = np.maximum((Xd[rows] ** 2).sum(1)[:, None] + (Xd ** 2).sum(1)[None, :] - 2.0 * Xd[rows] @ Xd.T, 0)
+        d2[np.arange(len(rows)), rows] = -1
+        truth = np.sqrt(np.maximum(np.sort(d2, axis=1)[:, :k], 0))
+        scale = max(1.0, float(np.abs(Xd).max()))
+        np.testing.assert_allclose(dist[rows], truth, rtol=3e-4, atol=3e-4 * scale, err_msg="case %d" % case)
+        assert np.array_equal(idx[rows, 0], rows)
+        rep = np.sqrt(((Xd[idx[rows]] - Xd[rows][:, None, :]) ** 2).sum(-1))
+        np.testing.assert_allclose(rep, dist[rows], rtol=1e-4, atol=1e-4 * scale)
+        a_ = StreamedAnnchor(X, n_anchors=na, n_neighbors=k, p_work=0.1).fit().neighbor_graph
+        b_ = StreamedAnnchor(X, n_anchors=na, n_neighbors=k, p_work=0.1).fit().neighbor_graph
+        assert np.array_equal(a_[0], b_[0]) and np.array_equal(a_[1], b_[1])
+
+
 def test_guard_beyond_256_dimensions_repairs_exactly():
     """Beyond 256 dimensions there is no exact-f32 tile kernel: ill-conditioned data (tight clusters far from the centre) used to be
     reported and returned from the split selection.  Now the flagged rows' row tiles are evaluated again with float32 differences
