@@ -240,7 +240,16 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
     // the columns' squared norms (scaled, centred) come as plain loads with the slab's requests: (nl0, nl1) the newest request's,
     // (nn0, nn1) the next slab's, moved there after the wait that covers them (lane: columns col and 32 + col)
     float nn0 = 0.f, nn1 = 0.f, nl0 = 0.f, nl1 = 0.f;
-    auto issue = [&](int Jv, int slab, int slotv, float &d0, float &d1) __attribute__((always_inline)) {
+    // (buffer loads, executed on every path -- beyond the last tile the offset is out of range: zeros, no access --: a load the compiler
+    // sees must not sit inside a branch, see issue_slots; an inline-asm load's destination would be the compiler's to copy before the
+    // data has landed)
+    const __amdgpu_buffer_rsrc_t srd_rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(scalar_ptrf(a.rsb)), 0, a.nt_all * ST_T * 4, 0x00020000);
+    auto norms_of = [&](int Jv, int slab, float &d0, float &d1) __attribute__((always_inline)) {
+        const uint32_t off = Jv >= 0 ? (uint32_t)((Jv * ST_T + slab * STH_COLS) * 4) + coloff : 0xFFFFFF00u;
+        d0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_rsb, off, 0, 0));
+        d1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_rsb, off + 128, 0, 0));
+    };
+    auto issue = [&](int Jv, int slab, int slotv) __attribute__((always_inline)) {
         const int J = __builtin_amdgcn_readfirstlane(Jv);
         const int slot = __builtin_amdgcn_readfirstlane(slotv);
         const char *src = scalar_ptr(xb + ((size_t)J * ST_T + slab * STH_COLS) * (DIM * 4));
@@ -249,10 +258,8 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         // showed ~900 cycles per slab between the last request and the barrier -- m0 rewritten between the four LDS-DMA instructions
         // and restored after them (each write waits until the instruction before it has been dispatched), and the two norm loads'
         // address registers, temporaries the next vector instructions overwrote (a write-after-read wait on a load still queued
-        // behind the four DMA instructions).  Now: the norm loads first, from a scalar base + the lane's constant offset register;
+        // behind the four DMA instructions).  Now: the norm loads apart (norms_of below: buffer loads on every path);
         // m0 written ONCE (nothing else in the kernel uses it: not restored), the four destinations by the instruction offset.
-        const char *nsrc = scalar_ptr(a.rsb + (size_t)J * ST_T + slab * STH_COLS);
-        asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:128" : "=&v"(d0), "=&v"(d1) : "v"(coloff), "s"(nsrc) : "memory");
         asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %4\n\t"
                      "global_load_lds_dwordx4 %1, %4 offset:1024\n\t"
                      "global_load_lds_dwordx4 %2, %4 offset:2048\n\t"
@@ -471,7 +478,8 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         nfl = 0;
         PH(3)
         nn0 = nl0; nn1 = nl1;   // (landed: the next slab's norms)
-        if (dJ >= 0) issue(dJ, dslab, slot_cur == 0 ? 2 : slot_cur - 1, nl0, nl1);   // (that slot held the slab before this one: every wave has passed this slab's barrier)
+        norms_of(dJ, dslab, nl0, nl1);
+        if (dJ >= 0) issue(dJ, dslab, slot_cur == 0 ? 2 : slot_cur - 1);   // (that slot held the slab before this one: every wave has passed this slab's barrier)
         if (!pend) nq = 0;   // (a run's first slab: nothing was under test)
         int n_async = 0;     // survivors whose rows are requested now and evaluated after the next slab
         if (__builtin_expect(nq > STH_QCAP, 0)) {
@@ -586,8 +594,10 @@ template <int KS> __global__ __launch_bounds__(STH_THREADS, 2) __attribute__((am
         int J = next_tile(0);
         if (J < 0) return;
         // fill: both slabs of the first tile (the ring is idle: a workgroup barrier precedes every run)
-        issue(J, 0, slot_cur, nn0, nn1);
-        issue(J, 1, slot_cur == 2 ? 0 : slot_cur + 1, nl0, nl1);
+        norms_of(J, 0, nn0, nn1);
+        norms_of(J, 1, nl0, nl1);
+        issue(J, 0, slot_cur);
+        issue(J, 1, slot_cur == 2 ? 0 : slot_cur + 1);
         vm_wait_all();
         bool pend = false;
         nq = 0; nfl = 0;
