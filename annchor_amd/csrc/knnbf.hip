@@ -986,8 +986,11 @@ template <int DIM, int KMAX, bool JOIN = false, bool R3 = false> __global__ __la
     };
     for (;;) {
         const float thrmax = thrmax_now();
+        // (a round selects what the budget can still use, twice over for the entries the bounds will drop: the warm-up of the two-stage
+        // kernel -- 33 tiles -- selected, collected and sorted 512 like everyone else; the tiles and their order are the same)
+        const uint32_t keep = (uint32_t)min(ST_KEEP, max(64, 2 * (a.max_tiles - processed)));
         uint32_t prefix = 0;
-        uint32_t want = ST_KEEP;
+        uint32_t want = keep;
         bool all = false, use_list = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
             if (clk && !cl_valid) {
@@ -1022,7 +1025,7 @@ template <int DIM, int KMAX, bool JOIN = false, bool R3 = false> __global__ __la
                 }
             }
             use_list = clk && cl_valid;
-            prefix = 0; want = ST_KEEP; all = false;
+            prefix = 0; want = keep; all = false;
             for (int level = 0; level < 3 && !all; ++level) {
                 const int shift = level == 0 ? 20 : level == 1 ? 8 : 0;
                 const int nbins = level == 2 ? 256 : 4096;
@@ -1056,13 +1059,15 @@ template <int DIM, int KMAX, bool JOIN = false, bool R3 = false> __global__ __la
         __syncthreads();
         int ns = min(sh.nsurv, ST_SURV);
         if (ns == 0) break;
-        {   // sort by (rank key, J): bitonic over ST_SURV slots
-            for (int q = threadIdx.x; q < ST_SURV; q += STB_THREADS)
+        {   // sort by (rank key, J): bitonic over the next power of two >= ns slots
+            int sortn = 2;
+            while (sortn < ns) sortn <<= 1;
+            for (int q = threadIdx.x; q < sortn; q += STB_THREADS)
                 if (q >= ns) { sb.surv_lb[q] = INFINITY; sb.surv_j[q] = 0x7fffffff; }
             __syncthreads();
-            for (int k2 = 2; k2 <= ST_SURV; k2 <<= 1)
+            for (int k2 = 2; k2 <= sortn; k2 <<= 1)
                 for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-                    for (int q = threadIdx.x; q < ST_SURV; q += STB_THREADS) {
+                    for (int q = threadIdx.x; q < sortn; q += STB_THREADS) {
                         const int p2 = q ^ j2;
                         if (p2 > q) {
                             const bool up = (q & k2) == 0;
@@ -1079,7 +1084,7 @@ template <int DIM, int KMAX, bool JOIN = false, bool R3 = false> __global__ __la
                 }
         }
         const bool more = !all;          // the selection was cut at ST_KEEP: later tiles remain
-        if (ns > ST_KEEP && more) ns = ST_KEEP;
+        if (ns > (int)keep && more) ns = (int)keep;
         const uint32_t round_last_bits = __float_as_uint(sb.surv_lb[ns - 1]);
         const int round_last_j = sb.surv_j[ns - 1];
         // the round's tiles leave the ring before the stream takes it back
